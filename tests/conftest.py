@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "differentiable-wdfs_amd", "lib")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (oracle/liboracle.so), built on demand.  Checker only."""
+    import oracle as O
+    O.build(ref=os.path.isdir("/root/reference"))
+    return O
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return load
