@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- the BASELINE.json metric on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch: diode-clipper forward over
+B x T samples, MSE against synthetic targets, reverse sweep to dL/d{Is, nVt, R, C}, and (N > 1)
+one RCCL all-reduce of the fused [loss, grads] buffer.  Workload = BASELINE.json configs[2]:
+1N4148 diode clipper fwd+bwd, batch 8192 sequences x 4096 samples @ 48 kHz per GPU
+("scaling": "weak": every rank holds its own 8192-sequence shard of the global batch).
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "differentiable-wdfs_amd", "lib"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from wdf_hip import binding, dist as wdist, workload  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_FWD = 12                 # x 4 + y 4 + z-stash 4   (fwd 8 B + 4 B stash)
+BYTES_BWD = 12                 # x 4 + z 4 + dL/dy 4
+
+
+def cpu_baseline(T, fs, budget_s=12.0):
+    """The oracle's fused fwd + MSE + bwd step ("port": C restatement of the reference
+    algorithm, OpenMP over sequences) timed on the host cores on a bounded sample of the
+    same workload.  Checker code used as a reported baseline only."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    Bs = max(64, 8 * cores)
+    x = workload.sweep_batch(8192, T, b0=0, b1=Bs)
+    th = workload.clipper_theta()
+    tgt = O.clipper_fwd(workload.target_theta(), fs, x, dtype=np.float32, n_threads=cores)
+    O.clipper_mse_step(th, fs, x, tgt, n_threads=cores)          # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        O.clipper_mse_step(th, fs, x, tgt, n_threads=cores)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 200:
+            break
+    return {"value": Bs * T * n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fused fwd+MSE+bwd steps of oracle_clipper_mse_step_f32 on {Bs} sequences x {T} "
+                      f"samples of the same sweep workload ({dt:.1f} s, OpenMP {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8192, help="sequences per GPU")
+    ap.add_argument("--seq-len", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world, rank, local = wdist.init()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    binding.require_gpu()
+    dev = torch.device("cuda", local)
+    fs, B, T = workload.FS, args.batch, args.seq_len
+    Bg = B * world
+    b0, b1 = wdist.shard_range(Bg, rank, world)
+
+    # ---- resident inputs ---------------------------------------------------------------
+    x = torch.as_tensor(workload.sweep_batch(Bg, T, b0=b0, b1=b1), device=dev)
+    theta = torch.tensor(workload.clipper_theta(), dtype=torch.float32, device=dev)
+    theta_star = torch.tensor(workload.target_theta(), dtype=torch.float32, device=dev)
+    target, _, _ = binding.clipper_fwd(x, theta_star, fs, want_stash=False)
+    ws = torch.empty((binding.lib().wdf_clipper_bwd_ws_bytes(B),), dtype=torch.uint8, device=dev)
+    gtheta = torch.zeros(4, dtype=torch.float32, device=dev)
+    n_global = float(Bg * T)
+
+    ev = [binding.Event() for _ in range(4)]
+    t_fwd, t_bwd = [], []
+
+    def step(timed):
+        if timed:
+            ev[0].record()
+        y, zs, _ = binding.clipper_fwd(x, theta, fs, want_stash=True)
+        if timed:
+            ev[1].record()
+        d = y - target
+        sse = torch.sum(d * d)
+        gy = d * 2.0                                   # d SSE / dy ; normalised after the all-reduce
+        if timed:
+            ev[2].record()
+        binding.clipper_bwd(x, theta, fs, zs, gy, gtheta=gtheta, ws=ws)
+        if timed:
+            ev[3].record()
+        loss, grad = wdist.mse_step_allreduce(sse, gtheta, n_global)
+        if timed:
+            t_fwd.append(ev[0].elapsed_ms(ev[1]))
+            t_bwd.append(ev[2].elapsed_ms(ev[3]))
+        return loss, grad
+
+    for _ in range(args.warmup):
+        step(False)
+    wdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, grad = step(False)
+    torch.cuda.synchronize()
+    wdist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax)
+
+    # per-kernel durations (HIP events on the launch stream), outside the timed region so the
+    # event synchronisation does not perturb the whole-job number
+    for _ in range(min(args.steps, 10)):
+        step(True)
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = Bg * T / (dt / args.steps)
+        f_ms, b_ms = float(np.mean(t_fwd)), float(np.mean(t_bwd))
+        dom, dom_ms, dom_bytes = ("clipper_fwd_kernel", f_ms, BYTES_FWD) if f_ms >= b_ms else \
+                                 ("clipper_bwd_kernel", b_ms, BYTES_BWD)
+        achieved = dom_bytes * B * T / (dom_ms * 1e-3) / 1e9
+        out = {
+            "metric": "samples/sec fwd+bwd, 1N4148 diode clipper @48kHz batch=8192; 1->8 GPU scaling",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"1N4148 diode clipper fwd+bwd (grads wrt Is,nVt,R,C), MSE loss, "
+                                   f"{B} sequences x {T} samples @ {int(fs)} Hz per GPU (BASELINE configs[2])",
+                       "global_batch": Bg, "seq_len": T, "parallelism": f"dp{world}",
+                       "loss": float(loss), "grad": [float(g) for g in grad]},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_sample": dom_bytes,
+                         "fwd_kernel_ms": f_ms, "bwd_kernel_ms": b_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T, fs)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

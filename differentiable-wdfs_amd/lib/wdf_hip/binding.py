@@ -1,0 +1,193 @@
+"""ctypes binding of libwdf_hip.so (C ABI: include/wdf_hip.h).
+
+PyTorch is used here only as plumbing: it owns device memory (tensor.data_ptr()) and the
+HIP stream the kernels are enqueued on.  There is NO fallback: if the HIP library is
+missing or a call fails, this raises -- the product never computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwdf_hip.so")
+
+WDF_X_TIME_MAJOR = 1 << 0
+WDF_PREC_F64 = 1 << 1
+
+
+class WdfHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libwdf_hip.so (once).  Raises WdfHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WdfHipError(
+            f"{LIB_PATH} not found: build it with `make -C differentiable-wdfs_amd/csrc` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, fp, i64, ci, cf = C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float
+    L.wdf_abi_version.restype = ci
+    L.wdf_last_error.restype = C.c_char_p
+    L.wdf_device_info.restype = ci
+    L.wdf_device_info.argtypes = [ci, C.c_char_p, ci]
+    L.wdf_clipper_fwd.restype = ci
+    L.wdf_clipper_fwd.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, fp, i64, i64, ci, vp]
+    L.wdf_clipper_bwd.restype = ci
+    L.wdf_clipper_bwd.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, vp, fp, fp, ci, i64, i64, ci, vp]
+    L.wdf_clipper_bwd_ws_bytes.restype = C.c_size_t
+    L.wdf_clipper_bwd_ws_bytes.argtypes = [i64]
+    L.wdf_omega_f32.restype = ci
+    L.wdf_omega_f32.argtypes = [fp, fp, vp, i64, vp]
+    L.wdf_diode_pair_f32.restype = ci
+    L.wdf_diode_pair_f32.argtypes = [fp, fp, cf, cf, ci, ci, fp, i64, vp]
+    L.wdf_event_create.restype = vp
+    L.wdf_event_record.restype = ci
+    L.wdf_event_record.argtypes = [vp, vp]
+    L.wdf_event_elapsed_ms.restype = ci
+    L.wdf_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.wdf_event_destroy.restype = None
+    L.wdf_event_destroy.argtypes = [vp]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "wdf_abi_version", "wdf_last_error", "wdf_device_info",
+    "wdf_clipper_fwd", "wdf_clipper_bwd", "wdf_clipper_bwd_ws_bytes",
+    "wdf_omega_f32", "wdf_diode_pair_f32",
+    "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy",
+)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise WdfHipError(f"{what} failed (rc={rc}): {lib().wdf_last_error().decode()}")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32_dev(t, name):
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise WdfHipError(f"{name}: expected a contiguous float32 tensor on the GPU, got "
+                          f"{type(t).__name__} {getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
+    return t
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise WdfHipError("no HIP device visible: the WDF engine runs on MI355X only (no CPU fallback)")
+
+
+def clipper_fwd(x, theta, fs, r=None, n_up=1, n_down=1, want_stash=True, z0=None, want_zT=False,
+                time_major=False):
+    """x [B,T] (or [T,B] if time_major) -> y [T,B], zstash [T,B] | None, zT [B] | None."""
+    require_gpu()
+    x = _f32_dev(x, "x")
+    r = _f32_dev(r, "r")
+    theta = _f32_dev(theta, "theta")
+    z0 = _f32_dev(z0, "z0")
+    if theta.numel() != 4:
+        raise WdfHipError("theta must hold {Is, nVt, R, C}")
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+    if r is not None and r.shape != x.shape:
+        raise WdfHipError("r must have the shape of x")
+    y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zs = torch.empty((T, B), dtype=torch.float32, device=x.device) if want_stash else None
+    zT = torch.empty((B,), dtype=torch.float32, device=x.device) if want_zT else None
+    flags = WDF_X_TIME_MAJOR if time_major else 0
+    rc = lib().wdf_clipper_fwd(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
+                               _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, flags, _stream())
+    _check(rc, "wdf_clipper_fwd")
+    return y, zs, zT
+
+
+def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=False, time_major=False,
+                gtheta=None, accumulate=False, ws=None):
+    """dL/d{Is, nVt, R, C} as a float32[4] device tensor (and dL/dz0 [B] if requested)."""
+    require_gpu()
+    x = _f32_dev(x, "x")
+    r = _f32_dev(r, "r")
+    theta = _f32_dev(theta, "theta")
+    zstash = _f32_dev(zstash, "zstash")
+    gy = _f32_dev(gy, "gy")
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+    if tuple(gy.shape) != (T, B) or tuple(zstash.shape) != (T, B):
+        raise WdfHipError(f"gy / zstash must be [T,B] = [{T},{B}]")
+    if ws is None:
+        ws = torch.empty((lib().wdf_clipper_bwd_ws_bytes(B),), dtype=torch.uint8, device=x.device)
+    if gtheta is None:
+        gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
+        accumulate = False
+    gz0 = torch.empty((B,), dtype=torch.float32, device=x.device) if want_gz0 else None
+    flags = WDF_X_TIME_MAJOR if time_major else 0
+    rc = lib().wdf_clipper_bwd(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
+                               _ptr(zstash), _ptr(gy), _ptr(ws), _ptr(gtheta), _ptr(gz0),
+                               1 if accumulate else 0, B, T, flags, _stream())
+    _check(rc, "wdf_clipper_bwd")
+    return gtheta, gz0
+
+
+def omega(x, want_iters=False):
+    require_gpu()
+    x = _f32_dev(x, "x")
+    w = torch.empty_like(x)
+    it = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_iters else None
+    _check(lib().wdf_omega_f32(_ptr(x), _ptr(w), _ptr(it), x.numel(), _stream()), "wdf_omega_f32")
+    return (w, it) if want_iters else w
+
+
+def diode_pair(a, R_port, Is, nVt, n_up=1, n_down=1):
+    require_gpu()
+    a = _f32_dev(a, "a")
+    R_port = _f32_dev(R_port, "R_port")
+    b = torch.empty_like(a)
+    _check(lib().wdf_diode_pair_f32(_ptr(a), _ptr(R_port), float(Is), float(nVt), int(n_up), int(n_down),
+                                    _ptr(b), a.numel(), _stream()), "wdf_diode_pair_f32")
+    return b
+
+
+def device_info(device=0):
+    buf = C.create_string_buffer(64)
+    cus = lib().wdf_device_info(int(device), buf, 64)
+    if cus < 0:
+        raise WdfHipError(lib().wdf_last_error().decode())
+    return buf.value.decode(), cus
+
+
+class Event:
+    """HIP event on the stream the kernels run on (bench.py roofline timing)."""
+
+    def __init__(self):
+        self.h = lib().wdf_event_create()
+        if not self.h:
+            raise WdfHipError("hipEventCreate failed")
+
+    def record(self):
+        _check(lib().wdf_event_record(self.h, _stream()), "wdf_event_record")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float(0.0)
+        _check(lib().wdf_event_elapsed_ms(self.h, stop.h, C.byref(ms)), "wdf_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().wdf_event_destroy(self.h)
+        except Exception:
+            pass

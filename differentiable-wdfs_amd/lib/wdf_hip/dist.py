@@ -1,0 +1,65 @@
+"""Data-parallel sharding of the sequence batch.
+
+Sequences are independent (zero initial state per sequence, clipper_pot.py:110-111) and the
+parameters are a handful of replicated scalars, so the batch dimension shards contiguously
+across ranks with NO data-path collective.  The only exchange is one all-reduce (RCCL over
+xGMI via torch.distributed backend "nccl"; gloo in the CPU tests) of a single fused fp32
+buffer per step: [loss partial sums..., parameter-gradient vector].  The buffer is 5 floats
+for the diode clipper (609+ for an MLP root): latency-bound, so exactly one collective per
+step, issued on the compute stream right behind the reduce kernel.
+The reference has no distributed path at all; this is new.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1).
+    Returns (world, rank, local_rank)."""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return world, rank, local
+
+
+def shard_range(n_global, rank, world):
+    """Contiguous [b0, b1) of rank's shard; remainders go to the lowest ranks."""
+    q, r = divmod(n_global, world)
+    b0 = rank * q + min(rank, r)
+    return b0, b0 + q + (1 if rank < r else 0)
+
+
+def allreduce_sum_(buf):
+    """In-place SUM all-reduce of one fused buffer (no-op for world size 1)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf
+
+
+def mse_step_allreduce(sse_local, gtheta_local_unnormalised, n_global):
+    """Combine per-rank results of an MSE step.
+    sse_local: sum of squared errors over the local shard (0-dim tensor);
+    gtheta_local_unnormalised: dSSE_local/dtheta.  Returns (loss, grad) of the GLOBAL mean."""
+    buf = torch.cat([sse_local.reshape(1), gtheta_local_unnormalised.reshape(-1)])
+    allreduce_sum_(buf)
+    return buf[0] / n_global, buf[1:] / n_global
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()

@@ -1,0 +1,51 @@
+"""Synthetic workloads of BASELINE.json / SURVEY.md section 8(d) (all seeds fixed).
+
+The measured dataset of the reference is absent (.MISSING_LARGE_BLOBS), so inputs are
+per-sequence exponential sine sweeps 100 Hz -> 10 kHz at 48 kHz (the family lpf.py:58 uses)
+with amplitude A_b ~ U(0.1, 5) V and start phase phi_b ~ U(0, 2 pi),
+numpy.random.default_rng(1234); zero initial state (clipper_pot.py:110-111).
+"""
+import numpy as np
+
+FS = 48000.0
+# 1N4148 (diode_config.py:14-16), Vs resistance (clipper_pot.py:97), C (clipper_pot.py:50)
+IS_1N4148 = 4.352e-9
+VT = 25.85e-3
+NABLA_1N4148 = 1.906
+R_CLIPPER = 45.0e3
+C_CLIPPER = 4.7e-9
+
+
+def clipper_theta():
+    """{Is, nVt, R, C} of the 1N4148 diode clipper."""
+    return np.array([IS_1N4148, VT * NABLA_1N4148, R_CLIPPER, C_CLIPPER], dtype=np.float64)
+
+
+def target_theta():
+    """theta* the synthetic targets are generated at: (1.2 Is, 0.95 nVt, 0.9 R, 1.1 C)."""
+    return clipper_theta() * np.array([1.2, 0.95, 0.9, 1.1])
+
+
+def sweep_batch(B_global, T, fs=FS, seed=1234, b0=0, b1=None, f0=100.0, f1=10000.0, dtype=np.float32):
+    """Rows b0:b1 of the global [B_global, T] input batch (so N ranks can each build their
+    shard of the SAME global batch without materialising the rest)."""
+    b1 = B_global if b1 is None else b1
+    rng = np.random.default_rng(seed)
+    amp = rng.uniform(0.1, 5.0, B_global)[b0:b1]
+    phase = rng.uniform(0.0, 2.0 * np.pi, B_global)[b0:b1]
+    t = np.arange(T, dtype=np.float64) / fs
+    dur = T / fs
+    k = np.log(f1 / f0)
+    inst = 2.0 * np.pi * f0 * dur / k * (np.exp(t / dur * k) - 1.0)
+    x = amp[:, None] * np.sin(inst[None, :] + phase[:, None])
+    return np.ascontiguousarray(x, dtype=dtype)
+
+
+def pot_resistance_batch(B_global, T, b0=0, b1=None, dtype=np.float32):
+    """Per-sequence constant pot values on the reference's file-name grid
+    (.MISSING_LARGE_BLOBS:1-5: 10.0k, 25.2k, 45.2k, 75.0k, 99.1k), as clipper_pot.py feeds them
+    through input channel 1 (dataimport.py:96)."""
+    b1 = B_global if b1 is None else b1
+    grid = np.array([10.0e3, 25.2e3, 45.2e3, 75.0e3, 99.1e3])
+    r = grid[np.arange(b0, b1) % len(grid)]
+    return np.ascontiguousarray(np.repeat(r[:, None], T, axis=1), dtype=dtype)

@@ -1,0 +1,115 @@
+/*
+ * wdf_hip.h -- C ABI of libwdf_hip.so: the MI355X (gfx950) engine for the wdf_py hot path.
+ *
+ * The reference has no FFI for this path: its boundary is the Python module surface of
+ * wdf_py/lib (tf_wdf.py, layers.py) plus the per-sample loops the scripts own
+ * (lpf.py:30-49, clipper_pot.py:103-127).  The drop-in keeps that Python surface
+ * (differentiable-wdfs_amd/lib/tf_wdf.py, layers.py) and lowers ONE WHOLE SEQUENCE LOOP
+ * per call to the entry points below.  Each entry point cites the reference code it
+ * replaces.  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (torch allocates it in the Python host layer); the library allocates nothing
+ *     persistent and keeps no state besides the per-thread error string;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream), so the caller's stream / RCCL ordering applies unchanged;
+ *   - return 0 on success, a negative WDF_E* code on error (never throws, never exits);
+ *     wdf_last_error() describes the last failure on the calling thread;
+ *   - sequences are independent: lane b of the grid owns sequence b.  Inputs are batch-major
+ *     [B][T] as the reference scripts index them (input[:, i]) -- or time-major [T][B] with
+ *     WDF_X_TIME_MAJOR -- outputs are time-major [T][B] as TensorArray.stack() returns them
+ *     (lpf.py:48, clipper_pot.py:126).
+ */
+#ifndef WDF_HIP_H
+#define WDF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WDF_HIP_ABI_VERSION 1
+
+enum {
+    WDF_OK = 0,
+    WDF_EINVAL = -1,   /* bad argument (null pointer, size <= 0, unknown enum)          */
+    WDF_ELAUNCH = -2,  /* HIP launch / runtime error (message has hipGetErrorString)     */
+    WDF_EUNSUPPORTED = -3
+};
+
+/* flags */
+enum {
+    WDF_X_TIME_MAJOR = 1 << 0, /* x (and r) are [T][B] instead of [B][T]                 */
+    WDF_PREC_F64     = 1 << 1  /* evaluate the root solve in fp64 (config C5); I/O stays f32 */
+};
+
+/* ------------------------------------------------------------------------------------
+ * Diode clipper:  P1 = Parallel(ResistiveVoltageSource(R), Capacitor(C, fs)), root =
+ * diode pair  b = a - 2 nVt lam (mu0 w(log(Rp Is/(mu0 nVt)) + lam a/(mu0 nVt))
+ *                               - mu1 w(log(Rp Is/(mu1 nVt)) - lam a/(mu1 nVt)))
+ *
+ * Replaces, per call, the whole loop  clipper_pot.py:103-127  run with the analytic root
+ * (DiodeClipperWDF.cpp:24-28 order: dp.incident(P1.reflected()); P1.incident(dp.reflected())):
+ *     Capacitor.calc_impedance  tf_wdf.py:114-115     Parallel.calc_impedance  tf_wdf.py:168-177
+ *     Parallel.reflected        tf_wdf.py:185-192     Parallel.incident        tf_wdf.py:179-183
+ *     ResistiveVoltageSource.*  tf_wdf.py:31-59       Capacitor.incident/reflected :120-126
+ *     voltage(C)                tf_wdf.py:8-10        diode pair  diode_pretraining.py:39-60,
+ *     Wright omega              toms917.cpp:134-375   Toms917DiodePair.h:28-59
+ *
+ * theta   device float[4] = {Is, nVt, R, C}  (read on the device: no host sync, so an
+ *         optimizer can update it in place between calls)
+ * x       [B][T] input voltage (clipper_pot.py:114); r: optional [B][T] per-sample source
+ *         resistance (clipper_pot.py:116, overrides theta[2]); NULL = scalar R
+ * y       [T][B] capacitor voltage (clipper_pot.py:123-124)
+ * zstash  optional [T][B]: capacitor state BEFORE each step, kept for wdf_clipper_bwd
+ * z0      optional [B] initial capacitor state (NULL = reset(), clipper_pot.py:110-111)
+ * zT      optional [B] final capacitor state
+ * ---------------------------------------------------------------------------------- */
+int wdf_clipper_fwd(const float* x, const float* r, const float* theta,
+                    float fs, int n_up, int n_down,
+                    float* y, float* zstash, const float* z0, float* zT,
+                    int64_t B, int64_t T, int flags, void* stream);
+
+/* Reverse sweep of the same loop: what tape.gradient(loss, [Is, nVt, R, C]) computes in the
+ * reference's execution model (clipper_pot.py:246-268), for a given dL/dy.
+ * gy      [T][B] = dL/dy
+ * ws      workspace of wdf_clipper_bwd_ws_bytes(B) bytes
+ * gtheta  device float[4] = dL/d{Is, nVt, R, C}; entry 2 is 0 when r != NULL.
+ *         Overwritten (not accumulated) unless accumulate != 0.
+ * gz0     optional [B]: dL/d z0 (adjoint of the initial state)                          */
+int wdf_clipper_bwd(const float* x, const float* r, const float* theta,
+                    float fs, int n_up, int n_down,
+                    const float* zstash, const float* gy,
+                    void* ws, float* gtheta, float* gz0, int accumulate,
+                    int64_t B, int64_t T, int flags, void* stream);
+
+size_t wdf_clipper_bwd_ws_bytes(int64_t B);
+
+/* Element-wise diode-pair root and Wright omega on device arrays (n elements): the
+ * building blocks above, exposed for parity tests against diode_pretraining.py:39-60 /
+ * toms917.cpp.  R_port is the port resistance seen by the root (P1.R).
+ * iters (optional int32[n]) receives the number of FSC iterations taken per element.     */
+int wdf_omega_f32(const float* x, float* w, int32_t* iters, int64_t n, void* stream);
+int wdf_diode_pair_f32(const float* a, const float* R_port, float Is, float nVt,
+                       int n_up, int n_down, float* b, int64_t n, void* stream);
+
+/* library / device info */
+int wdf_abi_version(void);
+const char* wdf_last_error(void);
+/* fills name (<= cap bytes) with the gcnArchName of `device`, returns the CU count or <0 */
+int wdf_device_info(int device, char* name, int cap);
+
+/* Timing helper for bench.py: HIP events on the stream the kernels run on.
+ * wdf_timer_* wrap hipEventCreate/Record/ElapsedTime so Python needs no HIP binding.     */
+void* wdf_event_create(void);
+int wdf_event_record(void* ev, void* stream);
+int wdf_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+void wdf_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WDF_HIP_H */
