@@ -37,8 +37,12 @@ void launch_fwd(const float* x, const float* r, const float* theta, float fs, in
                 float* zstash, const float* z0, float* zT, int64_t B, int64_t T, hipStream_t s)
 {
     const unsigned grid = (unsigned)((B + 63) / 64);
-    hipLaunchKernelGGL((wdf::clipper_fwd_kernel<DYN_R, SYM, TM, V4>), dim3(grid), dim3(64), 0, s, x, r, theta, fs,
-                       n_up, n_down, y, zstash, z0, zT, B, T);
+    if (zstash)
+        hipLaunchKernelGGL((wdf::clipper_fwd_kernel<DYN_R, SYM, TM, V4, true>), dim3(grid), dim3(64), 0, s, x, r, theta,
+                           fs, n_up, n_down, y, zstash, z0, zT, B, T);
+    else
+        hipLaunchKernelGGL((wdf::clipper_fwd_kernel<DYN_R, SYM, TM, V4, false>), dim3(grid), dim3(64), 0, s, x, r,
+                           theta, fs, n_up, n_down, y, zstash, z0, zT, B, T);
 }
 
 template <bool DYN_R, bool SYM, bool TM, bool V4>

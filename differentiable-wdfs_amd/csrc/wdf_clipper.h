@@ -115,17 +115,20 @@ __device__ __forceinline__ float fwd_step(const ClipConsts& c, float xin, float 
     return y;
 }
 
-template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4>
+template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH>
 __global__ __launch_bounds__(64) void clipper_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T)
 {
+    // Lanes past the end of the batch shadow the last sequence: they compute and store the
+    // same values to the same addresses as its owner, so no store needs an exec-mask branch.
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool live = b_raw < B;
-    const int64_t b = live ? b_raw : B - 1;     // dead lanes shadow the last sequence, stores masked
+    const int64_t b = b_raw < B ? b_raw : B - 1;
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     float z = z0 ? z0[b] : 0.0f;                // reset(): clipper_pot.py:110-111
+    float* __restrict__ yp = y + b;             // walks down column b of the [T][B] outputs
+    float* __restrict__ zp = STASH ? zstash + b : nullptr;
 
     const int64_t nfull = T / kBlk;
     float xc[kBlk], xn[kBlk], rc[kBlk], rn[kBlk];
@@ -145,25 +148,19 @@ __global__ __launch_bounds__(64) void clipper_fwd_kernel(
         }
 #pragma unroll
         for (int k = 0; k < kBlk; ++k) {
-            const float z_old = z;
-            const float yv = fwd_step<DYN_R, SYM>(c, xc[k], rc[k], z);
-            if (live) {
-                y[(t0 + k) * B + b] = yv;
-                if (zstash) zstash[(t0 + k) * B + b] = z_old;
-            }
+            if constexpr (STASH) { *zp = z; zp += B; }
+            *yp = fwd_step<DYN_R, SYM>(c, xc[k], rc[k], z);
+            yp += B;
         }
     }
     for (int64_t t = nfull * kBlk; t < T; ++t) {   // tail (T % 8 steps)
         const float xin = load_one<TIME_MAJOR>(x, b, B, T, t);
         const float rin = DYN_R ? load_one<TIME_MAJOR>(r, b, B, T, t) : 1.0f;
-        const float z_old = z;
-        const float yv = fwd_step<DYN_R, SYM>(c, xin, rin, z);
-        if (live) {
-            y[t * B + b] = yv;
-            if (zstash) zstash[t * B + b] = z_old;
-        }
+        if constexpr (STASH) { *zp = z; zp += B; }
+        *yp = fwd_step<DYN_R, SYM>(c, xin, rin, z);
+        yp += B;
     }
-    if (live && zT) zT[b] = z;
+    if (zT) zT[b] = z;
 }
 
 // =========================================================================================

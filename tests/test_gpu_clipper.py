@@ -38,16 +38,25 @@ def inputs(B, T, seed=0, amp_hi=5.0):
 
 
 # ------------------------------------------------------------------------------- omega
+def assert_omega_close(w, ref, x):
+    """x > -20: relative 1.5e-6.  x <= -20 (omega < 2e-9, i.e. < 2e-10 V in the diode pair):
+    relative 1e-5 -- exp is evaluated as v_exp_f32(x * log2 e) and the fp32 product carries
+    |x| 2^-24 -- plus an absolute floor of 1.2e-38, below which v_exp_f32 flushes to zero."""
+    err = np.abs(w - ref)
+    near = x > -20
+    assert np.max(err[near] / np.abs(ref[near])) < 1.5e-6
+    assert np.all(err[~near] <= 1e-5 * np.abs(ref[~near]) + 1.2e-38)
+
+
 def test_omega_vs_golden_and_oracle(wb, oracle, golden):
     g = golden("g5_omega.npz")
     x32 = g["x"].astype(np.float32)
     w, it = wb.omega(dev(x32), want_iters=True)
     w = w.cpu().numpy().astype(np.float64)
     ref = oracle.wright_omega(x32.astype(np.float64))      # exact omega at the fp32 argument
-    err = np.abs(w - ref) / np.maximum(np.abs(ref), 1e-37)
-    assert np.max(err) < 1.5e-6
+    assert_omega_close(w, ref, x32)
     # against the golden (reference toms917 build) the fp32 rounding of x itself adds |dx| w/(1+w)
-    err_g = np.abs(w - g["w_toms917"]) / np.maximum(np.abs(g["w_toms917"]), 1e-37)
+    err_g = np.abs(w - g["w_toms917"]) / np.maximum(np.abs(g["w_toms917"]), 1e-35)
     assert np.max(err_g[np.abs(g["x"]) < 100]) < 1e-5
     it = it.cpu().numpy()
     assert set(np.unique(it)) <= {0, 1, 2}
@@ -59,8 +68,7 @@ def test_omega_dense_random(wb, oracle):
                           np.array([-2.0, -4.0, 4.1415925, 4.141593, 0.0, 1.0])]).astype(np.float32)
     w = wb.omega(dev(x32)).cpu().numpy().astype(np.float64)
     ref = oracle.wright_omega(x32.astype(np.float64))
-    err = np.abs(w - ref) / np.maximum(np.abs(ref), 1e-37)
-    assert np.max(err) < 1.5e-6
+    assert_omega_close(w, ref, x32)
     assert np.all(np.isfinite(w))
 
 
