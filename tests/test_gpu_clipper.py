@@ -56,8 +56,8 @@ def test_omega_vs_golden_and_oracle(wb, oracle, golden):
     ref = oracle.wright_omega(x32.astype(np.float64))      # exact omega at the fp32 argument
     assert_omega_close(w, ref, x32)
     # against the golden (reference toms917 build) the fp32 rounding of x itself adds |dx| w/(1+w)
-    err_g = np.abs(w - g["w_toms917"]) / np.maximum(np.abs(g["w_toms917"]), 1e-35)
-    assert np.max(err_g[np.abs(g["x"]) < 100]) < 1e-5
+    sel = (g["x"] > -20) & (g["x"] < 100)
+    assert np.max(np.abs(w - g["w_toms917"])[sel] / g["w_toms917"][sel]) < 1e-5
     it = it.cpu().numpy()
     assert set(np.unique(it)) <= {0, 1, 2}
 
