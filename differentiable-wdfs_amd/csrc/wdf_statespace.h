@@ -1,0 +1,341 @@
+// wdf_statespace.h -- generic WDF tree + one root, lowered to a state-space recursion.
+//
+// Every adaptor / one-port of wdf_py/lib/tf_wdf.py (Series :129-155, Parallel :158-192,
+// Inverter :195-214, Resistor :62-88, Capacitor :91-126, ResistiveVoltageSource :31-59) is
+// LINEAR in the waves; the only nonlinearity sits at the root.  So one time step of any tree
+// (lpf.py:39-46, voltage_divider.py:35-42, clipper_pot.py:113-124) is exactly
+//
+//     a  = ca . z + da . x                  wave sent up into the root   (reflected() sweep)
+//     b  = root(a)                          IdealVoltageSource :23-28 / diode pair / MLP
+//     z' = A z + Bx x + E b                 new capacitor states         (incident() sweep)
+//     y  = cy . z + dy . x + fy b           voltage() of the probed element :8-10
+//
+// with z the capacitor states (Capacitor.z), x the source voltages of this sample, and the
+// small matrices functions of the component values only.  The Python host derives them by
+// running its tf_wdf-compatible elements once on unit vectors (differentiably, so dL/dR and
+// dL/dC chain through them); this kernel runs the recursion for B sequences x T samples with
+// one lane per sequence, the matrices in SGPRs and the states in VGPRs.  An ideal-source
+// root (b = -a + 2 Vs) is folded into the matrices by the host: root kind NONE.
+//
+// Layouts: x [B][T][NI] (the reference's input[:, i, c]), y [T][B], state stash [T][NS][B],
+// z0 / zT [NS][B].  coef (device, fp32):
+//     A[NS][NS] | Bx[NS][NI] | E[NS] | ca[NS] | da[NI] | cy[NS] | dy[NI] | fy
+// rootp (device, fp32) for the diode pair: {Is, nVt, R_port}.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wdf_omega.h"
+
+namespace wdf {
+
+enum { kRootNone = 0, kRootDiode = 2 };
+
+template <int NS, int NI>
+struct SSCoef {
+    static constexpr int kN = NS * NS + NS * NI + NS + NS + NI + NS + NI + 1;
+    static constexpr int oA = 0, oB = oA + NS * NS, oE = oB + NS * NI, oCa = oE + NS, oDa = oCa + NS,
+                         oCy = oDa + NI, oDy = oCy + NS, oFy = oDy + NI;
+    float v[kN];
+    __device__ __forceinline__ void load(const float* __restrict__ p)
+    {
+#pragma unroll
+        for (int i = 0; i < kN; ++i) v[i] = p[i];
+    }
+};
+
+struct SSDiode {
+    float L, V, Is, Rport;
+    DiodeStatic d;
+    __device__ __forceinline__ void load(const float* __restrict__ rp, int n_up, int n_down)
+    {
+        Is = rp[0]; V = rp[1]; Rport = rp[2];
+        L = logf(Rport * Is / V);
+        d = make_diode_static(V, n_up, n_down);
+    }
+};
+
+// loads kBlkSS steps x NI channels of lane b's row into v[step][chan]
+constexpr int kBlkSS = 8;
+
+template <int NI, bool VEC4>
+__device__ __forceinline__ void ss_load_block(const float* __restrict__ x, int64_t b, int64_t T, int64_t t0,
+                                              float (&v)[kBlkSS][NI])
+{
+    const float* p = x + (b * T + t0) * NI;
+    if constexpr (VEC4) {
+        const float4* q = reinterpret_cast<const float4*>(p);
+        float tmp[kBlkSS * NI];
+#pragma unroll
+        for (int i = 0; i < kBlkSS * NI / 4; ++i) {
+            const float4 f = q[i];
+            tmp[4 * i] = f.x; tmp[4 * i + 1] = f.y; tmp[4 * i + 2] = f.z; tmp[4 * i + 3] = f.w;
+        }
+#pragma unroll
+        for (int k = 0; k < kBlkSS; ++k)
+#pragma unroll
+            for (int c = 0; c < NI; ++c) v[k][c] = tmp[k * NI + c];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kBlkSS; ++k)
+#pragma unroll
+            for (int c = 0; c < NI; ++c) v[k][c] = p[k * NI + c];
+    }
+}
+
+template <int NS, int NI, int ROOT, bool SYM>
+__device__ __forceinline__ float ss_fwd_step(const SSCoef<NS, NI>& c, const SSDiode& dp, const float (&x)[NI],
+                                             float (&z)[NS > 0 ? NS : 1])
+{
+    using C = SSCoef<NS, NI>;
+    float b = 0.0f;
+    if constexpr (ROOT == kRootDiode) {
+        float a = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a = fmaf(c.v[C::oCa + s], z[s], a);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a = fmaf(c.v[C::oDa + i], x[i], a);
+        b = diode_pair<SYM>(a, dp.L, dp.d).b;
+    }
+    float y = c.v[C::oFy] * b;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) y = fmaf(c.v[C::oCy + s], z[s], y);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) y = fmaf(c.v[C::oDy + i], x[i], y);
+    float zn[NS > 0 ? NS : 1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float acc = c.v[C::oE + s] * b;
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) acc = fmaf(c.v[C::oA + s * NS + s2], z[s2], acc);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc = fmaf(c.v[C::oB + s * NI + i], x[i], acc);
+        zn[s] = acc;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) z[s] = zn[s];
+    return y;
+}
+
+template <int NS, int NI, int ROOT, bool SYM, bool VEC4>
+__global__ __launch_bounds__(64) void ss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                    const float* __restrict__ rootp, int n_up, int n_down,
+                                                    float* __restrict__ y, float* __restrict__ zstash,
+                                                    const float* __restrict__ z0, float* __restrict__ zT,
+                                                    int64_t B, int64_t T)
+{
+    constexpr int NSa = NS > 0 ? NS : 1;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;     // dead lanes shadow the last sequence
+    SSCoef<NS, NI> c;
+    c.load(coef);
+    SSDiode dp = {};
+    if constexpr (ROOT == kRootDiode) dp.load(rootp, n_up, n_down);
+    float z[NSa];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) z[s] = z0 ? z0[s * B + b] : 0.0f;
+    float* __restrict__ yp = y + b;
+    float* __restrict__ zp = zstash + b;
+    const bool STASH = (zstash != nullptr) && NS > 0;       // wave-uniform
+
+    const int64_t nfull = T / kBlkSS;
+    float xc[kBlkSS][NI], xn[kBlkSS][NI];
+    if (nfull > 0) ss_load_block<NI, VEC4>(x, b, T, 0, xn);
+    for (int64_t blk = 0; blk < nfull; ++blk) {
+#pragma unroll
+        for (int k = 0; k < kBlkSS; ++k)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) xc[k][i] = xn[k][i];
+        if (blk + 1 < nfull) ss_load_block<NI, VEC4>(x, b, T, (blk + 1) * kBlkSS, xn);
+#pragma unroll
+        for (int k = 0; k < kBlkSS; ++k) {
+            if (STASH) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) zp[s * B] = z[s];
+                zp += (int64_t)NS * B;
+            }
+            *yp = ss_fwd_step<NS, NI, ROOT, SYM>(c, dp, xc[k], z);
+            yp += B;
+        }
+    }
+    for (int64_t t = nfull * kBlkSS; t < T; ++t) {
+        float xt[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xt[i] = x[(b * T + t) * NI + i];
+        if (STASH) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zp[s * B] = z[s];
+            zp += (int64_t)NS * B;
+        }
+        *yp = ss_fwd_step<NS, NI, ROOT, SYM>(c, dp, xt, z);
+        yp += B;
+    }
+    if (zT) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) zT[s * B + b] = z[s];
+    }
+}
+
+// ---- reverse sweep -----------------------------------------------------------------------
+// With g = dL/dy[n] and lam[s] = dL/dz'[s] (state after step n):
+//   gb = fy g + E . lam ;  ga = gb D_a(a)
+//   lam'[s'] = cy[s'] g + sum_s A[s][s'] lam[s] + ca[s'] ga
+//   dA[s][s'] += lam[s] z[s'] ; dBx[s][i] += lam[s] x[i] ; dE[s] += lam[s] b
+//   dca[s] += ga z[s] ; dda[i] += ga x[i] ; dcy[s] += g z[s] ; ddy[i] += g x[i] ; dfy += g b
+//   diode: dL += gb D_L ; dV += gb D_V   (D's partials as in wdf_clipper.h)
+// Accumulators per lane: SSCoef::kN coefficient gradients + 2 root sums, fp32 inside a
+// block of 8 steps, fp64 across blocks.
+template <int NS, int NI, int ROOT, bool SYM>
+__device__ __forceinline__ void ss_bwd_step(const SSCoef<NS, NI>& c, const SSDiode& dp, const float (&x)[NI],
+                                            const float (&z)[NS > 0 ? NS : 1], float g,
+                                            float (&lam)[NS > 0 ? NS : 1], float (&acc)[SSCoef<NS, NI>::kN + 2])
+{
+    using C = SSCoef<NS, NI>;
+    float b = 0.0f, Da = 0.0f, DL = 0.0f, DV = 0.0f;
+    if constexpr (ROOT == kRootDiode) {
+        float a = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a = fmaf(c.v[C::oCa + s], z[s], a);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a = fmaf(c.v[C::oDa + i], x[i], a);
+        const DiodeOut o = diode_pair<SYM>(a, dp.L, dp.d);
+        b = o.b;
+        const float w0p = o.w0 * fast_rcp(1.0f + o.w0);
+        const float w1p = o.w1 * fast_rcp(1.0f + o.w1);
+        const float l2 = o.lam * o.lam;
+        const float sp = w0p + w1p;
+        Da = fmaf(-2.0f * l2, sp, 1.0f);
+        DL = -dp.d.two_v * o.lam * (o.m0 * w0p - o.m1 * w1p);
+        DV = fmaf(2.0f * l2 * a, sp * fast_rcp(dp.V), -2.0f * o.lam * (o.m0 * o.w0 - o.m1 * o.w1));
+    }
+    float gb = c.v[C::oFy] * g;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) gb = fmaf(c.v[C::oE + s], lam[s], gb);
+    const float ga = gb * Da;
+    // coefficient gradients
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) acc[C::oA + s * NS + s2] = fmaf(lam[s], z[s2], acc[C::oA + s * NS + s2]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[C::oB + s * NI + i] = fmaf(lam[s], x[i], acc[C::oB + s * NI + i]);
+        acc[C::oE + s] = fmaf(lam[s], b, acc[C::oE + s]);
+        acc[C::oCa + s] = fmaf(ga, z[s], acc[C::oCa + s]);
+        acc[C::oCy + s] = fmaf(g, z[s], acc[C::oCy + s]);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        acc[C::oDa + i] = fmaf(ga, x[i], acc[C::oDa + i]);
+        acc[C::oDy + i] = fmaf(g, x[i], acc[C::oDy + i]);
+    }
+    acc[C::oFy] = fmaf(g, b, acc[C::oFy]);
+    acc[C::kN + 0] = fmaf(gb, DL, acc[C::kN + 0]);
+    acc[C::kN + 1] = fmaf(gb, DV, acc[C::kN + 1]);
+    // adjoint of the state
+    float ln[NS > 0 ? NS : 1];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+        float v = fmaf(c.v[C::oCa + s2], ga, c.v[C::oCy + s2] * g);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v = fmaf(c.v[C::oA + s * NS + s2], lam[s], v);
+        ln[s2] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) lam[s] = ln[s];
+}
+
+// ws: double[gridDim.x][kN + 2] per-wave partial sums
+template <int NS, int NI, int ROOT, bool SYM, bool VEC4>
+__global__ __launch_bounds__(64) void ss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                    const float* __restrict__ rootp, int n_up, int n_down,
+                                                    const float* __restrict__ zstash, const float* __restrict__ gy,
+                                                    double* __restrict__ ws, float* __restrict__ gz0, int64_t B,
+                                                    int64_t T)
+{
+    using C = SSCoef<NS, NI>;
+    constexpr int NSa = NS > 0 ? NS : 1;
+    constexpr int NACC = C::kN + 2;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    C c;
+    c.load(coef);
+    SSDiode dp = {};
+    if constexpr (ROOT == kRootDiode) dp.load(rootp, n_up, n_down);
+
+    double tot[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) tot[i] = 0.0;
+    float lam[NSa];
+#pragma unroll
+    for (int s = 0; s < NSa; ++s) lam[s] = 0.0f;
+
+    const int64_t nfull = T / kBlkSS;
+    for (int64_t t = T - 1; t >= nfull * kBlkSS; --t) {      // tail first (highest t)
+        float acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+        float xt[NI], zt[NSa];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xt[i] = x[(b * T + t) * NI + i];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) zt[s] = zstash[(t * NS + s) * B + b];
+        ss_bwd_step<NS, NI, ROOT, SYM>(c, dp, xt, zt, gy[t * B + b], lam, acc);
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) tot[i] += acc[i];
+    }
+    float xc[kBlkSS][NI];
+    for (int64_t blk = nfull - 1; blk >= 0; --blk) {
+        const int64_t t0 = blk * kBlkSS;
+        ss_load_block<NI, VEC4>(x, b, T, t0, xc);
+        float zc[kBlkSS][NSa], gc[kBlkSS];
+#pragma unroll
+        for (int k = 0; k < kBlkSS; ++k) {
+            gc[k] = gy[(t0 + k) * B + b];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zc[k][s] = zstash[((t0 + k) * NS + s) * B + b];
+        }
+        float acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int k = kBlkSS - 1; k >= 0; --k) ss_bwd_step<NS, NI, ROOT, SYM>(c, dp, xc[k], zc[k], gc[k], lam, acc);
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) tot[i] += acc[i];
+    }
+    if (live && gz0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) gz0[s * B + b] = lam[s];
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        double v = live ? tot[i] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0) ws[(int64_t)blockIdx.x * NACC + i] = v;
+    }
+}
+
+// Fixed-order sum of the per-wave partials; writes gcoef[kN] and, for the diode root,
+// groot[3] = dL/d{Is, nVt, R_port}  (L = log(R_port Is / nVt)).
+__global__ __launch_bounds__(64) void ss_grad_reduce_kernel(const double* __restrict__ ws, int nparts, int nacc,
+                                                            int ncoef, const float* __restrict__ rootp,
+                                                            float* __restrict__ gcoef, float* __restrict__ groot)
+{
+    // one lane per accumulator column (nacc <= 64)
+    const int i = threadIdx.x;
+    double s = 0.0;
+    if (i < nacc)
+        for (int p = 0; p < nparts; ++p) s += ws[(int64_t)p * nacc + i];
+    if (i < ncoef) gcoef[i] = (float)s;
+    const double sL = __shfl(s, ncoef, 64), sV = __shfl(s, ncoef + 1, 64);
+    if (i == 0 && groot && rootp) {
+        const double Is = rootp[0], V = rootp[1], Rp = rootp[2];
+        groot[0] = (float)(sL / Is);
+        groot[1] = (float)(sV - sL / V);
+        groot[2] = (float)(sL / Rp);
+    }
+}
+
+}  // namespace wdf

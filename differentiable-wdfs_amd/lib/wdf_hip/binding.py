@@ -44,6 +44,14 @@ def lib():
     L.wdf_clipper_bwd.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, vp, fp, fp, ci, i64, i64, ci, vp]
     L.wdf_clipper_bwd_ws_bytes.restype = C.c_size_t
     L.wdf_clipper_bwd_ws_bytes.argtypes = [i64]
+    L.wdf_ss_ncoef.restype = ci
+    L.wdf_ss_ncoef.argtypes = [ci, ci]
+    L.wdf_ss_fwd.restype = ci
+    L.wdf_ss_fwd.argtypes = [fp, fp, fp, ci, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, ci, vp]
+    L.wdf_ss_bwd.restype = ci
+    L.wdf_ss_bwd.argtypes = [fp, fp, fp, ci, ci, ci, ci, ci, fp, fp, vp, fp, fp, fp, i64, i64, ci, vp]
+    L.wdf_ss_bwd_ws_bytes.restype = C.c_size_t
+    L.wdf_ss_bwd_ws_bytes.argtypes = [ci, ci, i64]
     L.wdf_omega_f32.restype = ci
     L.wdf_omega_f32.argtypes = [fp, fp, vp, i64, vp]
     L.wdf_diode_pair_f32.restype = ci
@@ -62,6 +70,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "wdf_abi_version", "wdf_last_error", "wdf_device_info",
     "wdf_clipper_fwd", "wdf_clipper_bwd", "wdf_clipper_bwd_ws_bytes",
+    "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
     "wdf_omega_f32", "wdf_diode_pair_f32",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy",
 )
@@ -141,6 +150,54 @@ def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=Fal
                                1 if accumulate else 0, B, T, flags, _stream())
     _check(rc, "wdf_clipper_bwd")
     return gtheta, gz0
+
+
+ROOT_NONE, ROOT_DIODE_PAIR = 0, 2
+
+
+def ss_fwd(x, coef, ns, ni, root_kind=ROOT_NONE, rootp=None, n_up=1, n_down=1, want_stash=True, z0=None,
+           want_zT=False):
+    """State-space recursion.  x [B,T,ni] (or [B,T] when ni == 1) -> y [T,B], zstash [T,ns,B] | None,
+    zT [ns,B] | None."""
+    require_gpu()
+    x = _f32_dev(x, "x")
+    coef = _f32_dev(coef, "coef")
+    rootp = _f32_dev(rootp, "rootp")
+    z0 = _f32_dev(z0, "z0")
+    B, T = x.shape[0], x.shape[1]
+    if x.numel() != B * T * ni:
+        raise WdfHipError(f"x has {x.numel()} elements, expected B*T*ni = {B * T * ni}")
+    if coef.numel() != lib().wdf_ss_ncoef(ns, ni):
+        raise WdfHipError(f"coef must hold {lib().wdf_ss_ncoef(ns, ni)} values for ns={ns}, ni={ni}")
+    y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zs = torch.empty((T, ns, B), dtype=torch.float32, device=x.device) if (want_stash and ns > 0) else None
+    zT = torch.empty((ns, B), dtype=torch.float32, device=x.device) if want_zT else None
+    rc = lib().wdf_ss_fwd(_ptr(x), _ptr(coef), _ptr(rootp), ns, ni, root_kind, int(n_up), int(n_down),
+                          _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, 0, _stream())
+    _check(rc, "wdf_ss_fwd")
+    return y, zs, zT
+
+
+def ss_bwd(x, coef, ns, ni, zstash, gy, root_kind=ROOT_NONE, rootp=None, n_up=1, n_down=1, want_gz0=False):
+    """Returns (gcoef [ncoef], groot [3] | None, gz0 [ns,B] | None)."""
+    require_gpu()
+    x = _f32_dev(x, "x")
+    coef = _f32_dev(coef, "coef")
+    rootp = _f32_dev(rootp, "rootp")
+    zstash = _f32_dev(zstash, "zstash")
+    gy = _f32_dev(gy, "gy")
+    B, T = x.shape[0], x.shape[1]
+    if tuple(gy.shape) != (T, B):
+        raise WdfHipError(f"gy must be [T,B] = [{T},{B}]")
+    ncoef = lib().wdf_ss_ncoef(ns, ni)
+    ws = torch.empty((lib().wdf_ss_bwd_ws_bytes(ns, ni, B),), dtype=torch.uint8, device=x.device)
+    gcoef = torch.empty((ncoef,), dtype=torch.float32, device=x.device)
+    groot = torch.empty((3,), dtype=torch.float32, device=x.device) if root_kind == ROOT_DIODE_PAIR else None
+    gz0 = torch.empty((ns, B), dtype=torch.float32, device=x.device) if (want_gz0 and ns > 0) else None
+    rc = lib().wdf_ss_bwd(_ptr(x), _ptr(coef), _ptr(rootp), ns, ni, root_kind, int(n_up), int(n_down),
+                          _ptr(zstash), _ptr(gy), _ptr(ws), _ptr(gcoef), _ptr(groot), _ptr(gz0), B, T, 0, _stream())
+    _check(rc, "wdf_ss_bwd")
+    return gcoef, groot, gz0
 
 
 def omega(x, want_iters=False):

@@ -1,0 +1,463 @@
+"""The `tf` namespace the drop-in tf_wdf module exports (`from tf_wdf import tf`).
+
+The reference scripts take TensorFlow itself from the library module (lpf.py:8-9,
+voltage_divider.py:8-9, clipper_pot.py:11-12), so whoever provides `tf_wdf` provides `tf`.
+This is the subset of the TF 2.5 eager API those scripts and wdf_py/lib touch (SURVEY 8b:
+39 names), mapped onto torch: torch is the plumbing that owns parameters, the loss and the
+optimizer; the per-sample WDF recursion itself never runs here -- it is lowered to the HIP
+kernels (tf_wdf.Circuit / the loop recorder in wdf_hip.trace).
+
+Semantics kept from TF because the scripts depend on them:
+  * tf.Module.trainable_variables: depth-first over attributes sorted by name
+    (lpf.py:98-99 relies on [C1.C, R1.R]);
+  * tf.Variable(constraint=...) is applied by the optimizer after each update
+    (tf_wdf.py:69-75, :99-105 clip R and C);
+  * tf.GradientTape().gradient(loss, variables) -> list aligned with `variables`;
+  * keras Adam: m/v moments with epsilon OUTSIDE the sqrt bias correction, lr_t = lr *
+    sqrt(1-b2^t)/(1-b1^t), epsilon = 1e-7.
+"""
+import numpy as np
+import torch
+
+float32 = torch.float32
+float64 = torch.float64
+int32 = torch.int32
+
+_DEFAULT = torch.float32
+
+
+def _dtype(d):
+    return _DEFAULT if d is None else d
+
+
+class Tensor(torch.Tensor):
+    """torch.Tensor with the two TF-isms the scripts use on results: .numpy() on tensors that
+    require grad, and .assign() on variables."""
+
+    def numpy(self):
+        return torch.Tensor.numpy(self.detach().cpu().as_subclass(torch.Tensor))
+
+    def assign(self, value):
+        with torch.no_grad():
+            self.copy_(convert(value, dtype=self.dtype, device=self.device).reshape(self.shape))
+        return self
+
+    def __float__(self):
+        return float(self.detach().as_subclass(torch.Tensor))
+
+    def __format__(self, spec):
+        if self.numel() == 1:
+            return format(float(self.detach()), spec)
+        return str(self)
+
+
+def _wrap(t):
+    return t.as_subclass(Tensor) if isinstance(t, torch.Tensor) and not isinstance(t, Tensor) else t
+
+
+def convert(x, dtype=None, device=None):
+    """tf.convert_to_tensor: numpy / python numbers / nested lists of tensors -> Tensor."""
+    if isinstance(x, torch.Tensor):
+        t = x
+        if dtype is not None and t.dtype != dtype and t.is_floating_point():
+            t = t.to(dtype)
+        if device is not None and t.device != torch.device(device):
+            t = t.to(device)
+        return _wrap(t)
+    if isinstance(x, (list, tuple)) and len(x) and isinstance(x[0], torch.Tensor):
+        return _wrap(torch.stack([convert(v, dtype, device) for v in x]))
+    arr = np.asarray(x)
+    if arr.dtype.kind == "f" or dtype is not None:
+        t = torch.as_tensor(arr, dtype=dtype if dtype is not None else _DEFAULT)
+    else:
+        t = torch.as_tensor(arr)
+    if device is not None:
+        t = t.to(device)
+    return _wrap(t)
+
+
+# ------------------------------------------------------------------------------ variables
+class _VariableMeta(type(torch.Tensor)):
+    def __instancecheck__(cls, obj):
+        return isinstance(obj, torch.Tensor) and getattr(obj, "_is_tf_variable", False)
+
+
+class Variable(Tensor, metaclass=_VariableMeta):
+    """tf.Variable(initial_value, name=, trainable=, dtype=, constraint=)."""
+
+    def __new__(cls, initial_value=None, name=None, trainable=True, dtype=None, constraint=None, **_):
+        t = convert(initial_value, dtype=_dtype(dtype)).detach().clone().as_subclass(Tensor)
+        t.requires_grad_(bool(trainable))
+        t._is_tf_variable = True
+        t.trainable = bool(trainable)
+        t.constraint = constraint
+        t.var_name = name
+        return t
+
+
+class Module:
+    """tf.Module: attribute container with TF's variable traversal order."""
+
+    def __init__(self, name=None):
+        self._tf_name = name
+
+    def _walk_variables(self):
+        out, seen = [], set()
+
+        def visit(obj):
+            if id(obj) in seen:
+                return
+            seen.add(id(obj))
+            if isinstance(obj, torch.Tensor):
+                if getattr(obj, "_is_tf_variable", False):
+                    out.append(obj)
+                return
+            if isinstance(obj, Module):
+                for k in sorted(vars(obj)):
+                    visit(vars(obj)[k])
+            elif isinstance(obj, (list, tuple)):
+                for v in obj:
+                    visit(v)
+            elif isinstance(obj, dict):
+                for k in sorted(obj):
+                    visit(obj[k])
+
+        visit(self)
+        return out
+
+    @property
+    def variables(self):
+        return tuple(self._walk_variables())
+
+    @property
+    def trainable_variables(self):
+        return tuple(v for v in self._walk_variables() if v.trainable)
+
+    @property
+    def submodules(self):
+        out, seen = [], set()
+
+        def visit(obj):
+            if id(obj) in seen:
+                return
+            seen.add(id(obj))
+            if isinstance(obj, Module):
+                if obj is not self:
+                    out.append(obj)
+                for k in sorted(vars(obj)):
+                    visit(vars(obj)[k])
+            elif isinstance(obj, (list, tuple)):
+                for v in obj:
+                    visit(v)
+
+        visit(self)
+        return tuple(out)
+
+
+# ------------------------------------------------------------------------------ creation ops
+def constant(value, dtype=None, shape=None):
+    t = convert(value, dtype=_dtype(dtype) if not isinstance(value, torch.Tensor) else dtype)
+    return t if shape is None else _wrap(t.reshape(shape))
+
+
+def convert_to_tensor(value, dtype=None):
+    return convert(value, dtype=dtype)
+
+
+def zeros(shape, dtype=None):
+    return _wrap(torch.zeros(shape, dtype=_dtype(dtype)))
+
+
+def ones(shape, dtype=None):
+    return _wrap(torch.ones(shape, dtype=_dtype(dtype)))
+
+
+def _like(x, fn):
+    if hasattr(x, "__wdf_like__"):
+        return x.__wdf_like__(fn.__name__)
+    return _wrap(fn(convert(x)))
+
+
+def zeros_like(x, dtype=None):
+    return _like(x, torch.zeros_like)
+
+
+def ones_like(x, dtype=None):
+    return _like(x, torch.ones_like)
+
+
+def cast(x, dtype=None):
+    if hasattr(x, "__wdf_cast__"):
+        return x.__wdf_cast__(dtype)
+    t = convert(x)
+    return _wrap(t.to(_dtype(dtype)))
+
+
+def shape(x):
+    return _wrap(torch.tensor(list(x.shape), dtype=torch.int32))
+
+
+def expand_dims(x, axis):
+    if hasattr(x, "__wdf_expand_dims__"):
+        return x.__wdf_expand_dims__(axis)
+    return _wrap(convert(x).unsqueeze(axis))
+
+
+def squeeze(x, axis=None):
+    t = convert(x)
+    return _wrap(t.squeeze() if axis is None else t.squeeze(axis))
+
+
+def reshape(x, shape):
+    return _wrap(convert(x).reshape(tuple(shape)))
+
+
+def concat(values, axis):
+    if any(hasattr(v, "__wdf_concat__") for v in values):
+        first = next(v for v in values if hasattr(v, "__wdf_concat__"))
+        return first.__wdf_concat__(values, axis)
+    vs = [convert(v) for v in values]
+    dev = next((v.device for v in vs if v.is_cuda), vs[0].device)
+    return _wrap(torch.cat([v.to(dev) for v in vs], dim=axis))
+
+
+def stack(values, axis=0):
+    vs = [convert(v) for v in values]
+    return _wrap(torch.stack(vs, dim=axis))
+
+
+def transpose(x, perm=None):
+    if hasattr(x, "__wdf_transpose__"):
+        return x.__wdf_transpose__(perm)
+    t = convert(x)
+    return _wrap(t.permute(*perm) if perm is not None else t.permute(*reversed(range(t.dim()))))
+
+
+def matmul(a, b):
+    return _wrap(torch.matmul(convert(a), convert(b)))
+
+
+def clip_by_value(x, lo, hi):
+    return _wrap(torch.clamp(convert(x), lo, hi))
+
+
+def sqrt(x):
+    return _wrap(torch.sqrt(convert(x)))
+
+
+def square(x):
+    return _wrap(torch.square(convert(x)))
+
+
+def abs(x):  # noqa: A001
+    return _wrap(torch.abs(convert(x)))
+
+
+def exp(x):
+    return _wrap(torch.exp(convert(x)))
+
+
+def tanh(x):
+    return _wrap(torch.tanh(convert(x)))
+
+
+def reduce_sum(x, axis=None):
+    t = convert(x)
+    return _wrap(t.sum() if axis is None else t.sum(dim=axis))
+
+
+def reduce_mean(x, axis=None):
+    t = convert(x)
+    return _wrap(t.mean() if axis is None else t.mean(dim=axis))
+
+
+def reduce_min(x, axis=None):
+    t = convert(x)
+    return _wrap(t.min() if axis is None else t.amin(dim=axis))
+
+
+def reduce_max(x, axis=None):
+    t = convert(x)
+    return _wrap(t.max() if axis is None else t.amax(dim=axis))
+
+
+def _reciprocal(x):
+    if hasattr(x, "__wdf_reciprocal__"):
+        return x.__wdf_reciprocal__()
+    return _wrap(torch.reciprocal(convert(x)))
+
+
+def _log(x):
+    if hasattr(x, "__wdf_log__"):
+        return x.__wdf_log__()
+    return _wrap(torch.log(convert(x)))
+
+
+class math:  # noqa: N801  (tf.math)
+    reciprocal = staticmethod(_reciprocal)
+    log = staticmethod(_log)
+    exp = staticmethod(exp)
+    square = staticmethod(square)
+    sqrt = staticmethod(sqrt)
+    abs = staticmethod(abs)
+    tanh = staticmethod(tanh)
+    reduce_sum = staticmethod(reduce_sum)
+    reduce_mean = staticmethod(reduce_mean)
+    reduce_min = staticmethod(reduce_min)
+    reduce_max = staticmethod(reduce_max)
+
+
+def _relu(x):
+    return _wrap(torch.relu(convert(x)))
+
+
+class nn:  # noqa: N801  (tf.nn) -- identity matters: clipper_pot.py:307 tests `layer == tf.nn.tanh`
+    tanh = staticmethod(tanh)
+    relu = staticmethod(_relu)
+
+
+class _Logger:
+    def setLevel(self, *_):  # noqa: N802
+        pass
+
+
+def get_logger():
+    return _Logger()
+
+
+# ------------------------------------------------------------------------------ TensorArray
+class TensorArray:
+    """tf.TensorArray(dtype, size, clear_after_read): write(i, v) returns the array,
+    stack() -> [size, ...].  If the written values are recorded WDF outputs (wdf_hip.trace),
+    stack() is where the whole loop is lowered to the HIP kernel."""
+
+    def __init__(self, dtype=None, size=0, dynamic_size=False, clear_after_read=True, **_):
+        self._items = [None] * int(size)
+        self._dtype = dtype
+
+    def write(self, index, value):
+        if index >= len(self._items):
+            self._items.extend([None] * (index + 1 - len(self._items)))
+        self._items[index] = value
+        return self
+
+    def read(self, index):
+        return self._items[index]
+
+    def size(self):
+        return len(self._items)
+
+    def stack(self):
+        first = next((v for v in self._items if v is not None), None)
+        if first is not None and hasattr(first, "__wdf_stack__"):
+            return first.__wdf_stack__(self._items)
+        return _wrap(torch.stack([convert(v) for v in self._items]))
+
+
+# ------------------------------------------------------------------------------ autodiff
+class GradientTape:
+    """with tf.GradientTape() as tape: ...; tape.gradient(loss, variables).
+    torch records the graph eagerly, so the tape only has to run autograd.grad."""
+
+    def __init__(self, persistent=False, watch_accessed_variables=True):
+        self._persistent = persistent
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def watch(self, t):
+        if isinstance(t, torch.Tensor) and not t.requires_grad:
+            t.requires_grad_(True)
+
+    def gradient(self, target, sources):
+        single = isinstance(sources, torch.Tensor)
+        srcs = [sources] if single else list(sources)
+        grads = torch.autograd.grad(target, srcs, allow_unused=True, retain_graph=self._persistent)
+        grads = [None if g is None else _wrap(g) for g in grads]
+        return grads[0] if single else grads
+
+
+# ------------------------------------------------------------------------------ keras
+class _MeanSquaredError:
+    def __call__(self, y_true, y_pred):
+        a, b = convert(y_true), convert(y_pred)
+        dev = a.device if a.is_cuda else b.device
+        return _wrap(torch.mean(torch.square(a.to(dev) - b.to(dev, a.dtype))))
+
+
+class _Adam:
+    """tf.keras.optimizers.Adam (TF 2.5 defaults: beta_1 0.9, beta_2 0.999, epsilon 1e-7);
+    honours Variable.constraint after the update like Keras does."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, **_):
+        self.lr, self.b1, self.b2, self.eps = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
+        self.iterations = 0
+        self._slots = {}
+
+    def apply_gradients(self, grads_and_vars):
+        self.iterations += 1
+        t = self.iterations
+        lr_t = self.lr * np.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        with torch.no_grad():
+            for g, v in grads_and_vars:
+                if g is None:
+                    continue
+                g = convert(g).to(v.device, v.dtype).reshape(v.shape).as_subclass(torch.Tensor)
+                key = id(v)
+                if key not in self._slots:
+                    self._slots[key] = (torch.zeros_like(g), torch.zeros_like(g))
+                m, s = self._slots[key]
+                m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+                s.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+                vt = v.as_subclass(torch.Tensor)
+                vt.sub_(lr_t * m / (torch.sqrt(s) + self.eps))
+                c = getattr(v, "constraint", None)
+                if c is not None:
+                    vt.copy_(convert(c(v)).as_subclass(torch.Tensor))
+
+
+class _SGD:
+    def __init__(self, learning_rate=0.01, **_):
+        self.lr = float(learning_rate)
+
+    def apply_gradients(self, grads_and_vars):
+        with torch.no_grad():
+            for g, v in grads_and_vars:
+                if g is None:
+                    continue
+                vt = v.as_subclass(torch.Tensor)
+                vt.sub_(self.lr * convert(g).to(v.device, v.dtype).reshape(v.shape).as_subclass(torch.Tensor))
+                c = getattr(v, "constraint", None)
+                if c is not None:
+                    vt.copy_(convert(c(v)).as_subclass(torch.Tensor))
+
+
+class _Orthogonal:
+    def __init__(self, gain=1.0, seed=None):
+        self.gain = gain
+
+    def __call__(self, shape, dtype=None):
+        w = torch.empty(*shape, dtype=_dtype(dtype))
+        torch.nn.init.orthogonal_(w, gain=self.gain)
+        return _wrap(w)
+
+
+class _Zeros:
+    def __call__(self, shape, dtype=None):
+        return zeros(shape, dtype)
+
+
+class keras:  # noqa: N801
+    class losses:  # noqa: N801
+        MeanSquaredError = _MeanSquaredError
+
+    class optimizers:  # noqa: N801
+        Adam = _Adam
+        SGD = _SGD
+
+    class initializers:  # noqa: N801
+        Orthogonal = _Orthogonal
+        Zeros = _Zeros

@@ -1,0 +1,232 @@
+"""Lowering of a tf_wdf element tree + root to the HIP kernels (the fast tier).
+
+Circuit(top, root, probe) walks the tree the user built from tf_wdf elements, probes ONE
+time step of it with unit vectors -- every adaptor / one-port is linear in the waves
+(tf_wdf.py:31-214), so that step is a = ca.z + da.x ; b = root(a) ; z' = A z + Bx x + E b ;
+y = cy.z + dy.x + fy b -- and runs the T-step recursion for the whole batch in one launch of
+csrc/wdf_statespace.h (or csrc/wdf_clipper.h for the diode-clipper topology, which also
+takes the per-sample resistance channel of clipper_pot.py:116-117).  The probe runs the
+elements' own calc_impedance / reflected / incident code on tiny float64 torch vectors, so
+the matrices carry the autograd graph back to R and C: the reverse-sweep kernel returns
+dL/d(matrices) and torch chains it to the component values -- which is what
+tape.gradient(loss, model.trainable_variables) is in the reference (lpf.py:87-90).
+"""
+import torch
+
+from . import binding
+from . import compat_tf as tf
+
+
+# ------------------------------------------------------------------------------ autograd glue
+class _StateSpaceFn(torch.autograd.Function):
+    """y [T,B] = statespace(coef, rootp, x [B,T,ni], z0)."""
+
+    @staticmethod
+    def forward(ctx, coef, rootp, x, z0, ns, ni, root_kind, n_up, n_down, want_zT):
+        need = coef.requires_grad or (rootp is not None and rootp.requires_grad) or (z0 is not None and z0.requires_grad)
+        c = coef.detach().contiguous()
+        rp = None if rootp is None else rootp.detach().contiguous()
+        y, zs, zT = binding.ss_fwd(x, c, ns, ni, root_kind, rp, n_up, n_down, want_stash=need,
+                                   z0=None if z0 is None else z0.detach().contiguous(), want_zT=want_zT)
+        ctx.cfg = (ns, ni, root_kind, n_up, n_down, z0 is not None)
+        ctx.save_for_backward(c, rp, x, zs)
+        if want_zT:
+            ctx.mark_non_differentiable(zT)
+            return y, zT
+        return y, None
+
+    @staticmethod
+    def backward(ctx, gy, _gzT):
+        ns, ni, root_kind, n_up, n_down, has_z0 = ctx.cfg
+        c, rp, x, zs = ctx.saved_tensors
+        gcoef, groot, gz0 = binding.ss_bwd(x, c, ns, ni, zs, gy.contiguous(), root_kind, rp, n_up, n_down,
+                                           want_gz0=has_z0)
+        return gcoef, groot, None, gz0, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------ tree walking
+def _kind(e):
+    return type(e).__name__
+
+
+def _walk(top):
+    """Post-order list of the elements under `top` (P1 before P2, children before parents)."""
+    order, seen = [], set()
+
+    def visit(e):
+        if id(e) in seen:
+            raise ValueError("a WDF element appears twice in the tree")
+        seen.add(id(e))
+        for child in (getattr(e, "P1", None), getattr(e, "P2", None)):
+            if child is not None:
+                visit(child)
+        order.append(e)
+
+    visit(top)
+    return order
+
+
+_STATE_ATTRS = ("a", "b", "z", "Vs", "R", "p1R", "p2R", "b_diff", "b_temp")
+
+
+class _Saved:
+    """Saves / restores the wave attributes the probe overwrites."""
+
+    def __init__(self, elements):
+        self.snap = [(e, {k: e.__dict__[k] for k in _STATE_ATTRS if k in e.__dict__}) for e in elements]
+
+    def restore(self):
+        for e, d in self.snap:
+            for k in _STATE_ATTRS:
+                if k in d:
+                    e.__dict__[k] = d[k]
+                elif k in e.__dict__ and k not in ("R",):
+                    del e.__dict__[k]
+
+
+def diode_pair_reflected(dp):
+    """DiodePair.reflected(): recorded by the loop recorder, or -- on concrete GPU tensors --
+    evaluated element-wise by the HIP kernel (no autograd; the differentiable path is Circuit)."""
+    a = dp.a
+    if hasattr(a, "__wdf_root__"):
+        return a.__wdf_root__(dp)
+    if isinstance(a, torch.Tensor) and a.is_cuda:
+        R = tf.convert(dp.R, dtype=torch.float32, device=a.device).expand_as(a).contiguous()
+        return binding.diode_pair(a.contiguous().float(), R, float(dp.Is), float(dp.nVt), dp.N_up, dp.N_down)
+    raise binding.WdfHipError(
+        "DiodePair.reflected() needs the GPU: pass CUDA tensors, or run the loop through "
+        "tf_wdf.Circuit / a recorded TensorArray loop (there is no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------ Circuit
+class Circuit:
+    """The fast tier.  top: element connected to the root (e.g. the Inverter of lpf.py:28 or
+    P1 of clipper_pot.py:99); root: IdealVoltageSource, DiodePair or layers.DenseRootModel;
+    probe: element whose voltage() is the output (C1 in lpf.py:44, C in clipper_pot.py:123).
+
+    Input channels: channel k of x feeds the k-th voltage source found walking the tree in
+    post-order (ResistiveVoltageSource leaves), then the ideal-source root if there is one.
+    per_sample_R: a ResistiveVoltageSource whose resistance is streamed from the NEXT input
+    channel (clipper_pot.py:114-116: channel 0 = Vin, channel 1 = R); diode-clipper
+    topology only.
+    """
+
+    def __init__(self, top, root, probe, per_sample_R=None, force_generic=False):
+        self.top, self.root, self.probe = top, root, probe
+        self.force_generic = bool(force_generic)    # tests: run the clipper tree through the generic kernel
+        self.elements = _walk(top)
+        if probe not in self.elements:
+            raise ValueError("probe must be an element of the tree under `top`")
+        self.caps = [e for e in self.elements if _kind(e) == "Capacitor"]
+        self.sources = [e for e in self.elements if _kind(e) == "ResistiveVoltageSource"]
+        self.root_kind = _kind(root)
+        if self.root_kind not in ("IdealVoltageSource", "DiodePair", "DenseRootModel"):
+            raise ValueError(f"unsupported root {self.root_kind}")
+        self.ns = len(self.caps)
+        self.ni = len(self.sources) + (1 if self.root_kind == "IdealVoltageSource" else 0)
+        self.per_sample_R = per_sample_R
+        if per_sample_R is not None and not self._is_clipper():
+            raise binding.WdfHipError("a per-sample resistance channel is supported on the diode-clipper topology "
+                                      "Parallel(ResistiveVoltageSource, Capacitor) only (clipper_pot.py:94-101)")
+        if self.ni < 1:
+            raise ValueError("the circuit has no voltage source")
+
+    # -- topology tests
+    def _is_clipper(self):
+        t = self.top
+        return (_kind(t) == "Parallel" and _kind(t.P1) == "ResistiveVoltageSource" and _kind(t.P2) == "Capacitor"
+                and self.probe is t.P2)
+
+    # -- one probed step -> state-space matrices (float64 CPU tensors with autograd graph)
+    def matrices(self):
+        ns, ni = self.ns, self.ni
+        K = ns + ni + 1
+        eye = torch.eye(K, dtype=torch.float64)
+        saved = _Saved(self.elements + [self.root])
+        try:
+            for s, cap in enumerate(self.caps):
+                cap.z = eye[s]
+            for i, src in enumerate(self.sources):
+                src.Vs = eye[ns + i]
+            self.top.calc_impedance()
+            up = self.top.reflected() + torch.zeros(K, dtype=torch.float64)        # broadcast scalars
+            self.top.incident(eye[K - 1])
+            znew = [cap.z + torch.zeros(K, dtype=torch.float64) for cap in self.caps]
+            yv = (self.probe.a + self.probe.b) * 0.5 + torch.zeros(K, dtype=torch.float64)
+            r_port = self.top.R
+        finally:
+            saved.restore()
+        up, yv = up.as_subclass(torch.Tensor), yv.as_subclass(torch.Tensor)
+        Z = torch.stack([z.as_subclass(torch.Tensor) for z in znew]) if ns else torch.zeros(0, K, dtype=torch.float64)
+        A, Bx, E = Z[:, :ns], Z[:, ns:ns + ni], Z[:, K - 1]
+        ca, da = up[:ns], up[ns:ns + ni]
+        cy, dy, fy = yv[:ns], yv[ns:ns + ni], yv[K - 1]
+        if self.root_kind == "IdealVoltageSource":
+            # b = -a + 2 Vs (tf_wdf.py:26-28) is linear: fold it in.  Vs is the LAST channel.
+            er = torch.zeros(ni, dtype=torch.float64)
+            er[ni - 1] = 1.0
+            A = A - torch.outer(E, ca)
+            Bx = Bx - torch.outer(E, da) + 2.0 * torch.outer(E, er)
+            cy = cy - fy * ca
+            dy = dy - fy * da + 2.0 * fy * er
+            E, ca, da, fy = torch.zeros_like(E), torch.zeros_like(ca), torch.zeros_like(da), torch.zeros_like(fy)
+        coef = torch.cat([A.reshape(-1), Bx.reshape(-1), E, ca, da, cy, dy, fy.reshape(1)])
+        return coef, r_port.as_subclass(torch.Tensor) if isinstance(r_port, torch.Tensor) else torch.tensor(float(r_port))
+
+    # -- run
+    def __call__(self, x, z0=None, return_state=False):
+        """x: [B,T] or [B,T,n_in] float32 CUDA tensor (batch-major, the reference's
+        input[:, i, c] layout).  Returns y [T,B] (and the final capacitor states [ns,B])."""
+        binding.require_gpu()
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(x)
+        x = x.as_subclass(torch.Tensor)
+        if not x.is_cuda:
+            x = x.cuda()
+        x = x.float()
+        if x.dim() == 2:
+            x = x.unsqueeze(-1)
+        nchan = self.ni + (1 if self.per_sample_R is not None else 0)
+        if x.dim() != 3 or x.shape[2] != nchan:
+            raise binding.WdfHipError(f"x must be [B,T,{nchan}] (or [B,T] for one channel), got {tuple(x.shape)}")
+        dev = x.device
+
+        if self._is_clipper() and self.root_kind == "DiodePair" and not self.force_generic:
+            return self._run_clipper(x, z0, return_state)
+        if self.root_kind == "DenseRootModel":
+            from . import mlp_root
+            return mlp_root.run_clipper_mlp(self, x, z0, return_state)
+
+        coef64, r_port = self.matrices()
+        coef = coef64.to(device=dev, dtype=torch.float32)
+        if self.root_kind == "DiodePair":
+            dp = self.root
+            rootp = torch.stack([dp.Is.as_subclass(torch.Tensor).double().reshape(()),
+                                 dp.nVt.as_subclass(torch.Tensor).double().reshape(()),
+                                 r_port.double().reshape(())]).to(device=dev, dtype=torch.float32)
+            kind, n_up, n_down = binding.ROOT_DIODE_PAIR, dp.N_up, dp.N_down
+        else:
+            rootp, kind, n_up, n_down = None, binding.ROOT_NONE, 1, 1
+        z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(self.ns, -1).contiguous()
+        y, zT = _StateSpaceFn.apply(coef, rootp, x.contiguous(), z0t, self.ns, self.ni, kind, n_up, n_down,
+                                    bool(return_state))
+        y = y.as_subclass(tf.Tensor)
+        return (y, zT) if return_state else y
+
+    def _run_clipper(self, x, z0, return_state):
+        from . import engine
+        dp, vs, cap = self.root, self.top.P1, self.top.P2
+        dev = x.device
+        parts = [dp.Is, dp.nVt, vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)), cap.C]
+        theta = torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(dev)
+        r = None
+        if self.per_sample_R is not None:
+            r = x[:, :, 1].contiguous()
+        xv = x[:, :, 0].contiguous()
+        if z0 is not None or return_state:
+            z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(-1).contiguous()
+            y, zT = engine.clipper_stateful(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, z0=z0t)
+            y = y.as_subclass(tf.Tensor)
+            return (y, zT.reshape(1, -1)) if return_state else y
+        y = engine.clipper(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down)
+        return y.as_subclass(tf.Tensor)

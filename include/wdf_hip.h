@@ -88,6 +88,37 @@ int wdf_clipper_bwd(const float* x, const float* r, const float* theta,
 
 size_t wdf_clipper_bwd_ws_bytes(int64_t B);
 
+/* ------------------------------------------------------------------------------------
+ * Generic tree + one root, as a state-space recursion (csrc/wdf_statespace.h):
+ *     a = ca.z + da.x ;  b = root(a) ;  z' = A z + Bx x + E b ;  y = cy.z + dy.x + fy b
+ * Replaces, per call, the whole per-sample loop of lpf.py:39-46 / voltage_divider.py:35-42 /
+ * clipper_pot.py:113-124 for ANY tree built from tf_wdf.py's Resistor, Capacitor,
+ * ResistiveVoltageSource, Series, Parallel, Inverter (:31-214) with static impedances
+ * (calc_impedance once per forward, lpf.py:38).  The host derives the matrices from the
+ * component values by running its tf_wdf-compatible elements on unit vectors.
+ *
+ * ns (0..3) capacitor states, ni (1..2) input channels.
+ * coef    device float[wdf_ss_ncoef(ns, ni)]:
+ *         A[ns][ns] | Bx[ns][ni] | E[ns] | ca[ns] | da[ni] | cy[ns] | dy[ni] | fy
+ * root_kind  WDF_ROOT_NONE (ideal source folded into the matrices; IdealVoltageSource
+ *         tf_wdf.py:13-28) or WDF_ROOT_DIODE_PAIR with rootp = device float[3] {Is, nVt, R_port}
+ * x       [B][T][ni] ; y [T][B] ; zstash [T][ns][B] ; z0, zT, gz0 [ns][B]
+ * bwd:    gcoef[ncoef] = dL/dcoef, groot[3] = dL/d{Is, nVt, R_port}; ws of wdf_ss_bwd_ws_bytes.
+ * ---------------------------------------------------------------------------------- */
+enum { WDF_ROOT_NONE = 0, WDF_ROOT_DIODE_PAIR = 2 };
+
+int wdf_ss_ncoef(int ns, int ni);
+int wdf_ss_fwd(const float* x, const float* coef, const float* rootp,
+               int ns, int ni, int root_kind, int n_up, int n_down,
+               float* y, float* zstash, const float* z0, float* zT,
+               int64_t B, int64_t T, int flags, void* stream);
+int wdf_ss_bwd(const float* x, const float* coef, const float* rootp,
+               int ns, int ni, int root_kind, int n_up, int n_down,
+               const float* zstash, const float* gy,
+               void* ws, float* gcoef, float* groot, float* gz0,
+               int64_t B, int64_t T, int flags, void* stream);
+size_t wdf_ss_bwd_ws_bytes(int ns, int ni, int64_t B);
+
 /* Element-wise diode-pair root and Wright omega on device arrays (n elements): the
  * building blocks above, exposed for parity tests against diode_pretraining.py:39-60 /
  * toms917.cpp.  R_port is the port resistance seen by the root (P1.R).

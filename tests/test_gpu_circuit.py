@@ -1,0 +1,243 @@
+"""GPU: the tf_wdf drop-in API (elements + Circuit fast tier) against the reference-derived
+goldens and the oracle's generic tree interpreter.  These read like the reference scripts:
+the circuits are built exactly as lpf.py:20-28, voltage_divider.py:17-25 and
+clipper_pot.py:94-101 build them.
+
+Tolerances: y absolute 3e-5 (2e-6 for the linear trees); gradients relative 2e-3.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+FS = 48000
+
+
+@pytest.fixture(scope="module")
+def wdf():
+    import tf_wdf
+    from wdf_hip import binding
+    binding.require_gpu()
+    return tf_wdf
+
+
+def cuda(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b) / np.abs(b)))
+
+
+# ---- lpf.py ----------------------------------------------------------------------------
+def build_lpf(wdf):
+    Vs = wdf.IdealVoltageSource()
+    R1 = wdf.Resistor(1000, True)
+    C1 = wdf.Capacitor(1.0e-6, FS, True)
+    S1 = wdf.Series(R1, C1)
+    I1 = wdf.Inverter(S1)
+    return Vs, R1, C1, I1
+
+
+def test_rc_lowpass_forward_and_grads(wdf, golden):
+    tf = wdf.tf
+    g = golden("g1_rc_lowpass.npz")
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    circ = wdf.Circuit(I1, Vs, C1)
+    with tf.GradientTape() as tape:
+        outs = circ(cuda(g["x"][None, :]))                       # [T,1]
+        loss = tf.keras.losses.MeanSquaredError()(outs, cuda(g["target"][:, None]))
+    grads = tape.gradient(loss, [C1.C, R1.R])                    # lpf.py:90,98-99 order
+    assert np.max(np.abs(outs.numpy()[:, 0] - g["y_f64"])) < 2e-6
+    assert abs(float(loss) - float(g["loss_f64"])) < 1e-6
+    assert rel(grads[0].numpy(), g["dC_f64"]) < 2e-3
+    assert rel(grads[1].numpy(), g["dR_f64"]) < 2e-3
+
+
+def test_rc_lowpass_trainable_variables_order(wdf):
+    tf = wdf.tf
+
+    class Model(tf.Module):
+        def __init__(self):
+            super().__init__()
+            self.Vs, self.R1, self.C1, self.I1 = build_lpf(wdf)
+
+    m = Model()
+    tv = m.trainable_variables
+    assert len(tv) == 2 and tv[0] is m.C1.C and tv[1] is m.R1.R     # lpf.py:98-99 relies on it
+
+
+def test_rc_lowpass_state_carry(wdf, golden):
+    """lpf.py never resets C1: the second forward starts from the first one's final state."""
+    g = golden("g1_rc_lowpass.npz")
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    circ = wdf.Circuit(I1, Vs, C1)
+    x = cuda(g["x"][None, :])
+    y1, zT = circ(x, return_state=True)
+    assert abs(float(zT[0, 0]) - float(g["z_after_f64"][0])) < 2e-6
+    y2 = circ(x, z0=zT)
+    assert np.max(np.abs(y2.numpy()[:, 0] - g["y_second_call_f64"])) < 2e-6
+
+
+# ---- voltage_divider.py ------------------------------------------------------------------
+def test_voltage_divider(wdf, golden):
+    tf = wdf.tf
+    g = golden("g2_voltage_divider.npz")
+    Vs = wdf.IdealVoltageSource()
+    R1 = wdf.Resistor(2.0e3, True)
+    R2 = wdf.Resistor(100.0, True)
+    I1 = wdf.Inverter(wdf.Series(R1, R2))
+    circ = wdf.Circuit(I1, Vs, R1)
+    assert circ.ns == 0 and circ.ni == 1
+    with tf.GradientTape() as tape:
+        outs = circ(cuda(g["x"][None, :]))
+        loss = tf.keras.losses.MeanSquaredError()(outs, cuda(g["target"][:, None]))
+    grads = tape.gradient(loss, [R1.R, R2.R])
+    assert np.max(np.abs(outs.numpy()[:, 0] - g["x"] * 2000.0 / 2100.0)) < 1e-6      # analytic
+    assert rel(grads[0].numpy(), g["dR1_f64"]) < 2e-3
+    assert rel(grads[1].numpy(), g["dR2_f64"]) < 2e-3
+
+
+# ---- diode clipper through the element API -----------------------------------------------
+def build_clipper(wdf, theta, n_up=1, n_down=1):
+    Is, nVt, R, C = [float(t) for t in theta]
+    Vs = wdf.ResistiveVoltageSource(R, trainable=True)
+    Cap = wdf.Capacitor(C, FS, trainable=True)
+    P1 = wdf.Parallel(Vs, Cap)
+    dp = wdf.DiodePair(P1, Is, Vt=nVt, nDiodes=1.0, N_up=n_up, N_down=n_down, trainable=True)
+    return Vs, Cap, P1, dp
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("cfg,n_up,n_down", [("1u1d", 1, 1), ("2u3d", 2, 3)])
+def test_diode_clipper_api(wdf, golden, cfg, n_up, n_down, generic):
+    tf = wdf.tf
+    g = golden("g6_diode_clipper.npz")
+    Vs, Cap, P1, dp = build_clipper(wdf, g["theta"], n_up, n_down)
+    circ = wdf.Circuit(P1, dp, Cap, force_generic=generic)
+    with tf.GradientTape() as tape:
+        y = circ(cuda(g["x"]))
+        loss = tf.reduce_mean(tf.square(y - cuda(g["target"])))
+    grads = tape.gradient(loss, [dp.Is, dp.nVt, Vs.R, Cap.C])
+    assert np.max(np.abs(y.numpy() - g[f"y_{cfg}_f64"])) < 3e-5
+    got = np.array([float(x) for x in grads])
+    assert rel(got, g[f"grad_{cfg}_f64"]) < 2e-3, (got, g[f"grad_{cfg}_f64"])
+
+
+def test_diode_clipper_pot_channel(wdf, golden):
+    tf = wdf.tf
+    g = golden("g6_diode_clipper.npz")
+    Vs, Cap, P1, dp = build_clipper(wdf, g["theta"])
+    circ = wdf.Circuit(P1, dp, Cap, per_sample_R=Vs)
+    xin = np.stack([g["x"], g["r"]], axis=-1)                     # clipper_pot.py:68-70 layout
+    with tf.GradientTape() as tape:
+        y = circ(cuda(xin))
+        loss = tf.reduce_mean(tf.square(y - cuda(g["target"])))
+    grads = tape.gradient(loss, [dp.Is, dp.nVt, Cap.C])
+    assert np.max(np.abs(y.numpy() - g["y_1u1d_rpot_f64"])) < 3e-5
+    assert rel(np.array([float(x) for x in grads]), g["grad_1u1d_rpot_f64"]) < 2e-3
+
+
+# ---- trees beyond the two scripts, against the oracle's interpreter ------------------------
+def test_two_capacitor_two_source_tree_vs_oracle(wdf, oracle):
+    """Series(Parallel(Vs1, C1), Parallel(Series(R1, Vs2), C2)) + diode pair: ns = 2, ni = 2."""
+    tf = wdf.tf
+    O = oracle
+    rng = np.random.default_rng(4)
+    B, T = 70, 515
+    x = (rng.standard_normal((B, T, 2)) * np.array([1.5, 0.7])).astype(np.float32)
+    vals = dict(Rs1=22.0e3, C1=4.7e-9, R1=3.3e3, Rs2=10.0e3, C2=10.0e-9, Is=4.352e-9, nVt=0.0493)
+    Vs1 = wdf.ResistiveVoltageSource(vals["Rs1"], trainable=True)
+    C1 = wdf.Capacitor(vals["C1"], FS, trainable=True)
+    R1 = wdf.Resistor(vals["R1"], True)
+    Vs2 = wdf.ResistiveVoltageSource(vals["Rs2"], trainable=True)
+    C2 = wdf.Capacitor(vals["C2"], FS, trainable=True)
+    top = wdf.Series(wdf.Parallel(Vs1, C1), wdf.Parallel(wdf.Series(R1, Vs2), C2))
+    dp = wdf.DiodePair(top, vals["Is"], Vt=vals["nVt"], trainable=True)
+    circ = wdf.Circuit(top, dp, C2)
+    assert (circ.ns, circ.ni) == (2, 2)
+    # same program for the oracle: theta = [Rs1, C1, R1, Rs2, C2, Is, nVt]
+    nodes = [(O.NODE_RES_VSOURCE, -1, -1, 0, 0, -1), (O.NODE_CAPACITOR, -1, -1, 1, -1, -1),
+             (O.NODE_PARALLEL, 0, 1, -1, -1, -1),
+             (O.NODE_RESISTOR, -1, -1, 2, -1, -1), (O.NODE_RES_VSOURCE, -1, -1, 3, 1, -1),
+             (O.NODE_SERIES, 3, 4, -1, -1, -1), (O.NODE_CAPACITOR, -1, -1, 4, -1, -1),
+             (O.NODE_PARALLEL, 5, 6, -1, -1, -1), (O.NODE_SERIES, 2, 7, -1, -1, -1)]
+    oc = O.Circuit(nodes, top=8, probe=6, n_in=2, root_kind=O.ROOT_DIODE_PAIR, fs=FS, p_is=5, p_nvt=6)
+    th32 = np.array([vals[k] for k in ("Rs1", "C1", "R1", "Rs2", "C2", "Is", "nVt")], dtype=np.float32)
+    theta = th32.astype(np.float64)
+    yref = O.tree_fwd(oc, theta, x.astype(np.float64))
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    y = circ(cuda(x))
+    assert np.max(np.abs(y.numpy() - yref)) < 3e-5
+    loss = tf.reduce_sum(y * cuda(gy))
+    params = [Vs1.R, C1.C, R1.R, Vs2.R, C2.C, dp.Is, dp.nVt]
+    grads = tf.GradientTape().gradient(loss, params)
+    gref = O.tree_grad(oc, theta, x.astype(np.float64), gy.astype(np.float64))
+    got = np.array([float(v) for v in grads])
+    assert rel(got, gref) < 3e-3, (got, gref)
+
+
+def test_three_state_linear_ladder_vs_oracle(wdf, oracle):
+    """RC ladder with an ideal source root: ns = 3, ni = 1, root folded into the matrices."""
+    tf = wdf.tf
+    O = oracle
+    rng = np.random.default_rng(9)
+    B, T = 5, 300
+    x = rng.standard_normal((B, T)).astype(np.float32)
+    Ra, Rb, Rc = wdf.Resistor(1.0e3, True), wdf.Resistor(2.2e3, True), wdf.Resistor(4.7e3, True)
+    Ca, Cb, Cc = wdf.Capacitor(1.0e-7, FS, True), wdf.Capacitor(2.2e-7, FS, True), wdf.Capacitor(4.7e-8, FS, True)
+    st3 = wdf.Series(Rc, Cc)
+    st2 = wdf.Series(Rb, wdf.Parallel(Cb, st3))
+    top = wdf.Inverter(wdf.Series(Ra, wdf.Parallel(Ca, st2)))
+    Vs = wdf.IdealVoltageSource()
+    circ = wdf.Circuit(top, Vs, Cc)
+    assert (circ.ns, circ.ni) == (3, 1)
+    # post-order for the oracle: Ra, Ca, Rb, Cb, Rc, Cc, st3, P(Cb,st3), st2, P(Ca,st2), S(Ra,.), Inv
+    nodes = [(O.NODE_RESISTOR, -1, -1, 0, -1, -1), (O.NODE_CAPACITOR, -1, -1, 1, -1, -1),
+             (O.NODE_RESISTOR, -1, -1, 2, -1, -1), (O.NODE_CAPACITOR, -1, -1, 3, -1, -1),
+             (O.NODE_RESISTOR, -1, -1, 4, -1, -1), (O.NODE_CAPACITOR, -1, -1, 5, -1, -1),
+             (O.NODE_SERIES, 4, 5, -1, -1, -1), (O.NODE_PARALLEL, 3, 6, -1, -1, -1),
+             (O.NODE_SERIES, 2, 7, -1, -1, -1), (O.NODE_PARALLEL, 1, 8, -1, -1, -1),
+             (O.NODE_SERIES, 0, 9, -1, -1, -1), (O.NODE_INVERTER, 10, -1, -1, -1, -1)]
+    oc = O.Circuit(nodes, top=11, probe=5, n_in=1, root_kind=O.ROOT_IDEAL_VSOURCE, fs=FS, root_vin=0)
+    theta = np.array([1.0e3, 1.0e-7, 2.2e3, 2.2e-7, 4.7e3, 4.7e-8], dtype=np.float32).astype(np.float64)
+    yref = O.tree_fwd(oc, theta, x.astype(np.float64))
+    y = circ(cuda(x))
+    assert np.max(np.abs(y.numpy() - yref)) < 5e-6
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    grads = tf.GradientTape().gradient(tf.reduce_sum(y * cuda(gy)), [Ra.R, Ca.C, Rb.R, Cb.C, Rc.R, Cc.C])
+    gref = O.tree_grad(oc, theta, x.astype(np.float64), gy.astype(np.float64))
+    assert rel(np.array([float(v) for v in grads]), gref) < 3e-3
+
+
+def test_training_loop_rc_lowpass_converges(wdf, golden):
+    """lpf.py:77-113 with the fast tier: R -> ~315 ohm, C -> ~0.69 uF (RC_lpf.png), i.e.
+    fc = 1/(2 pi R C) ~ 720-730 Hz, loss -> ~0."""
+    tf = wdf.tf
+    g = golden("g1_rc_lowpass.npz")
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    circ = wdf.Circuit(I1, Vs, C1)
+    x, tgt = cuda(g["x"][None, :]), cuda(g["target"][:, None])
+    loss_func = tf.keras.losses.MeanSquaredError()
+    R_opt = tf.keras.optimizers.Adam(learning_rate=25.0)
+    C_opt = tf.keras.optimizers.Adam(learning_rate=10.0e-9)
+    zT = None
+    for epoch in range(100):
+        with tf.GradientTape() as tape:
+            outs, zT = circ(x, z0=zT, return_state=True)           # state carries like lpf.py
+            loss = loss_func(outs, tgt)
+        grads = tape.gradient(loss, [C1.C, R1.R])
+        R_opt.apply_gradients([(grads[1], R1.R)])
+        C_opt.apply_gradients([(grads[0], C1.C)])
+    fc = 1.0 / (2 * np.pi * float(R1.R) * float(C1.C))
+    assert float(loss) < 2e-4
+    assert 650.0 < fc < 800.0, (float(R1.R), float(C1.C), fc)
+
+
+def test_clip_constraint_applied_by_optimizer(wdf):
+    tf = wdf.tf
+    R2 = wdf.Resistor(100.0, True)
+    opt = tf.keras.optimizers.Adam(learning_rate=25.0)
+    opt.apply_gradients([(tf.constant(1.0), R2.R)])
+    assert float(R2.R) == 180.0                                  # tf_wdf.py:74 clip, voltage_divider.png
