@@ -1,0 +1,79 @@
+"""CPU, world_size 2, gloo: the data-parallel sharding + single fused all-reduce of
+wdf_hip.dist gives the same loss / gradient as the unsharded batch.  The local compute in
+this test is the CPU oracle (allowed in tests); on the GPU box bench.py plugs the HIP kernels
+into the same helper with the nccl (= RCCL) backend."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.multiprocessing as mp  # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, T, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    for p in (os.path.join(REPO, "oracle"), os.path.join(REPO, "differentiable-wdfs_amd", "lib")):
+        sys.path.insert(0, p)
+    import oracle as O
+    from wdf_hip import dist as wdist, workload
+    w, r, _ = wdist.init(backend="gloo")
+    assert (w, r) == (world, rank)
+    b0, b1 = wdist.shard_range(B, rank, world)
+    x = workload.sweep_batch(B, T, b0=b0, b1=b1, dtype=np.float64)       # this rank's rows of the global batch
+    theta, fs = workload.clipper_theta(), workload.FS
+    tgt = O.clipper_fwd(workload.target_theta(), fs, x)
+    y = O.clipper_fwd(theta, fs, x)
+    d = y - tgt
+    _, g = O.clipper_fwd_bwd(theta, fs, x, 2.0 * d)                       # dSSE_local/dtheta
+    loss, grad = wdist.mse_step_allreduce(torch.tensor(float(np.sum(d * d)), dtype=torch.float64),
+                                          torch.tensor(g, dtype=torch.float64), float(B * T))
+    if rank == 0:
+        out.put((float(loss), grad.numpy().copy()))
+    wdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_range_covers_batch():
+    sys.path.insert(0, os.path.join(REPO, "differentiable-wdfs_amd", "lib"))
+    from wdf_hip import dist as wdist
+    for n, w in [(8192, 8), (10, 3), (7, 8), (1340, 8)]:
+        spans = [wdist.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_rank(oracle):
+    from wdf_hip import workload
+    B, T, world = 10, 300, 2                                              # ragged split 5 + 5; also 3 ranks below
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    loss, grad = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x = workload.sweep_batch(B, T, dtype=np.float64)
+    theta, fs = workload.clipper_theta(), workload.FS
+    tgt = oracle.clipper_fwd(workload.target_theta(), fs, x)
+    l1, g1, _ = oracle.clipper_mse_step(theta, fs, x, tgt, dtype=np.float64)
+    assert abs(loss - l1) < 1e-12 * max(1.0, abs(l1))
+    assert np.max(np.abs(grad - g1) / np.abs(g1)) < 1e-9
