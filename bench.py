@@ -23,11 +23,12 @@ sys.path.insert(0, os.path.join(REPO, "differentiable-wdfs_amd", "lib"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from wdf_hip import binding, dist as wdist, workload  # noqa: E402
+from wdf_hip import binding, dist as wdist, engine, workload  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_FWD = 12                 # x 4 + y 4 + z-stash 4   (fwd 8 B + 4 B stash)
-BYTES_BWD = 12                 # x 4 + z 4 + dL/dy 4
+BYTES_BWD = 12                 # x 4 + z 4 + dL/dy 4     (the fused-MSE sweep reads y and target instead of
+                               # dL/dy, 16 B; the algorithmic figure stays SURVEY's 12)
 
 
 def cpu_baseline(T, fs, budget_s=12.0):
@@ -73,6 +74,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="sequences per GPU")
     ap.add_argument("--seq-len", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sequential", action="store_true", help="one lane per sequence, no time-parallel chunks")
     args = ap.parse_args()
 
     world, rank, local = wdist.init()
@@ -87,35 +89,35 @@ def main():
 
     # ---- resident inputs ---------------------------------------------------------------
     x = torch.as_tensor(workload.sweep_batch(Bg, T, b0=b0, b1=b1), device=dev)
-    theta = torch.tensor(workload.clipper_theta(), dtype=torch.float32, device=dev)
+    th_host = workload.clipper_theta()
+    theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
     theta_star = torch.tensor(workload.target_theta(), dtype=torch.float32, device=dev)
     target, _, _ = binding.clipper_fwd(x, theta_star, fs, want_stash=False)
-    ws = torch.empty((binding.lib().wdf_clipper_bwd_ws_bytes(B),), dtype=torch.uint8, device=dev)
-    gtheta = torch.zeros(4, dtype=torch.float32, device=dev)
     n_global = float(Bg * T)
+    tp = None if args.sequential else engine.plan_time_parallel(B, T, th_host[2], th_host[3], fs)
+    stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global)
 
     ev = [binding.Event() for _ in range(4)]
     t_fwd, t_bwd = [], []
 
     def step(timed):
+        # forward (x -> y, state stash), then the MSE-fused reverse sweep (-> SSE, dSSE-mean/dtheta),
+        # then ONE fused all-reduce of [SSE, grads] (no-op on 1 GPU)
         if timed:
             ev[0].record()
-        y, zs, _ = binding.clipper_fwd(x, theta, fs, want_stash=True)
+        stepper.forward(theta, x)
         if timed:
             ev[1].record()
-        d = y - target
-        sse = torch.sum(d * d)
-        gy = d * 2.0                                   # d SSE / dy ; normalised after the all-reduce
-        if timed:
             ev[2].record()
-        binding.clipper_bwd(x, theta, fs, zs, gy, gtheta=gtheta, ws=ws)
+        sse, gtheta = stepper.backward(theta, x, target)
         if timed:
             ev[3].record()
-        loss, grad = wdist.mse_step_allreduce(sse, gtheta, n_global)
+        buf = torch.cat([sse / n_global, gtheta])
+        wdist.allreduce_sum_(buf)
         if timed:
             t_fwd.append(ev[0].elapsed_ms(ev[1]))
             t_bwd.append(ev[2].elapsed_ms(ev[3]))
-        return loss, grad
+        return buf[0], buf[1:]
 
     for _ in range(args.warmup):
         step(False)
@@ -132,18 +134,19 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
 
-    # per-kernel durations (HIP events on the launch stream), outside the timed region so the
+    # per-launch durations (HIP events on the launch stream), outside the timed region so the
     # event synchronisation does not perturb the whole-job number
     for _ in range(min(args.steps, 10)):
         step(True)
     torch.cuda.synchronize()
+    tp_stat = binding.tp_status(stepper.status) if tp is not None and tp.k_fwd > 1 else None
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = Bg * T / (dt / args.steps)
         f_ms, b_ms = float(np.mean(t_fwd)), float(np.mean(t_bwd))
-        dom, dom_ms, dom_bytes = ("clipper_fwd_kernel", f_ms, BYTES_FWD) if f_ms >= b_ms else \
-                                 ("clipper_bwd_kernel", b_ms, BYTES_BWD)
+        fname = "clipper_fwd_tp_kernel" if (tp is not None and tp.k_fwd > 1) else "clipper_fwd_kernel"
+        dom, dom_ms, dom_bytes = (fname, f_ms, BYTES_FWD) if f_ms >= b_ms else ("clipper_bwd_tp_kernel", b_ms, BYTES_BWD)
         achieved = dom_bytes * B * T / (dom_ms * 1e-3) / 1e9
         out = {
             "metric": "samples/sec fwd+bwd, 1N4148 diode clipper @48kHz batch=8192; 1->8 GPU scaling",
@@ -153,7 +156,10 @@ def main():
             "config": {"workload": f"1N4148 diode clipper fwd+bwd (grads wrt Is,nVt,R,C), MSE loss, "
                                    f"{B} sequences x {T} samples @ {int(fs)} Hz per GPU (BASELINE configs[2])",
                        "global_batch": Bg, "seq_len": T, "parallelism": f"dp{world}",
-                       "loss": float(loss), "grad": [float(g) for g in grad]},
+                       "loss": float(loss), "grad": [float(g) for g in grad],
+                       "time_parallel": None if tp is None else
+                       {"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup, "verify_tol": tp.tol,
+                        "bwd_chunks": tp.k_bwd, "verify_status": tp_stat}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_sample": dom_bytes,

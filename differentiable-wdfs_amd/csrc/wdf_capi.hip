@@ -87,6 +87,74 @@ int check_common(const float* x, const float* theta, int n_up, int n_down, int64
     return WDF_OK;
 }
 
+// ---- time-parallel clipper dispatch -----------------------------------------------------------
+#define WDF_DISPATCH3(FN, dyn, sym, v4, ...)                                                     \
+    do {                                                                                         \
+        const int key3 = ((dyn) ? 4 : 0) | ((sym) ? 2 : 0) | ((v4) ? 1 : 0);                     \
+        switch (key3) {                                                                          \
+        case 0: FN<false, false, false>(__VA_ARGS__); break;                                     \
+        case 1: FN<false, false, true>(__VA_ARGS__); break;                                      \
+        case 2: FN<false, true, false>(__VA_ARGS__); break;                                      \
+        case 3: FN<false, true, true>(__VA_ARGS__); break;                                       \
+        case 4: FN<true, false, false>(__VA_ARGS__); break;                                      \
+        case 5: FN<true, false, true>(__VA_ARGS__); break;                                       \
+        case 6: FN<true, true, false>(__VA_ARGS__); break;                                       \
+        default: FN<true, true, true>(__VA_ARGS__); break;                                       \
+        }                                                                                        \
+    } while (0)
+
+struct TpGeom { int64_t L; int K; };
+
+TpGeom tp_geom(int64_t T, int n_chunks)
+{
+    if (n_chunks < 1) n_chunks = 1;
+    int64_t L = (T + n_chunks - 1) / n_chunks;
+    L = (L + wdf::kBlk - 1) / wdf::kBlk * wdf::kBlk;
+    return {L, (int)((T + L - 1) / L)};
+}
+
+template <bool DYN_R, bool SYM, bool V4>
+void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
+                   float* zstash, const float* z0, float* zT, float* zwarm, float* zend, wdf::TpStatus* status,
+                   float tol, int64_t B, int64_t T, TpGeom g, int64_t W, hipStream_t s)
+{
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)g.K);
+    const unsigned gseq = (unsigned)((B + 63) / 64);
+    if (zstash) {
+        hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, V4, true>), grid, dim3(64), 0, s, x, r, theta, fs,
+                           n_up, n_down, y, zstash, z0, zT, zwarm, zend, B, T, g.L, W);
+    } else {
+        hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, V4, false>), grid, dim3(64), 0, s, x, r, theta, fs,
+                           n_up, n_down, y, zstash, z0, zT, zwarm, zend, B, T, g.L, W);
+    }
+    if (g.K > 1) {
+        if (zstash)
+            hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, V4, true>), dim3(gseq), dim3(64), 0, s,
+                               x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, B, T, (int64_t)g.K, tol,
+                               status);
+        else
+            hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, V4, false>), dim3(gseq), dim3(64), 0, s,
+                               x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, B, T, (int64_t)g.K, tol,
+                               status);
+    }
+}
+
+template <bool DYN_R, bool SYM, bool V4>
+void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                   const float* zstash, const float* gy, const float* target, float gscale, float* part, double* ws,
+                   float* gz0, int64_t B, int64_t T, TpGeom g, hipStream_t s)
+{
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)g.K);
+    if (target)
+        hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, V4, true>), grid, dim3(64), 0, s, x, r, theta, fs,
+                           n_up, n_down, zstash, gy, target, gscale, part, B, T, g.L);
+    else
+        hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, V4, false>), grid, dim3(64), 0, s, x, r, theta, fs,
+                           n_up, n_down, zstash, gy, target, gscale, part, B, T, g.L);
+    hipLaunchKernelGGL(wdf::clipper_bwd_tp_combine_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, part, B,
+                       (int64_t)g.K, ws, gz0);
+}
+
 // ---- state-space dispatch ------------------------------------------------------------------
 template <int NS, int NI, int ROOT, bool V4>
 void ss_launch_fwd(const float* x, const float* coef, const float* rootp, int n_up, int n_down, float* y,
@@ -228,7 +296,76 @@ int wdf_clipper_bwd(const float* x, const float* r, const float* theta, float fs
     if (rc) return rc;
     const int nparts = (int)((B + 63) / 64);
     hipLaunchKernelGGL(wdf::clipper_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
-                       (const double*)ws, nparts, theta, fs, r != nullptr ? 1 : 0, gtheta, accumulate);
+                       (const double*)ws, nparts, theta, fs, r != nullptr ? 1 : 0, gtheta, accumulate,
+                       (float*)nullptr);
+    return check_launch("wdf_clipper_grad_reduce");
+}
+
+int wdf_clipper_tp_chunks(int64_t T, int n_chunks) { return T > 0 ? tp_geom(T, n_chunks).K : 0; }
+
+size_t wdf_clipper_fwd_tp_ws_bytes(int64_t B, int n_chunks)
+{
+    return (B > 0 && n_chunks > 0) ? (size_t)2 * (size_t)n_chunks * (size_t)B * sizeof(float) : 0;
+}
+
+int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
+                       float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup,
+                       float tol, void* ws, void* status, int flags, void* stream)
+{
+    int rc = check_common(x, theta, n_up, n_down, B, T, flags);
+    if (rc) return rc;
+    if (flags & WDF_X_TIME_MAJOR) return fail(WDF_EUNSUPPORTED, "time-parallel kernels take batch-major x");
+    if (!y || !ws || !status) return fail(WDF_EINVAL, "null y/ws/status");
+    if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
+    if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
+    const TpGeom g = tp_geom(T, n_chunks);
+    const int64_t W = ((int64_t)warmup + wdf::kBlk - 1) / wdf::kBlk * wdf::kBlk;
+    const hipError_t e = hipMemsetAsync(status, 0, sizeof(wdf::TpStatus), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(WDF_ELAUNCH, "hipMemsetAsync(status): %s", hipGetErrorString(e));
+    float* zwarm = (float*)ws;
+    float* zend = zwarm + (size_t)g.K * (size_t)B;
+    const bool v4 = (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    WDF_DISPATCH3(launch_fwd_tp, r != nullptr, n_up == n_down, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
+                  zwarm, zend, (wdf::TpStatus*)status, tol, B, T, g, W, (hipStream_t)stream);
+    return check_launch("wdf_clipper_fwd_tp");
+}
+
+size_t wdf_clipper_bwd_tp_ws_bytes(int64_t B, int n_chunks)
+{
+    if (B <= 0 || n_chunks <= 0) return 0;
+    return (size_t)n_chunks * wdf::kTpOut * (size_t)B * sizeof(float) + wdf_clipper_bwd_ws_bytes(B);
+}
+
+int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                       const float* zstash, const float* gy, void* ws, float* gtheta, float* gz0, int accumulate,
+                       int64_t B, int64_t T, int n_chunks, int flags, void* stream)
+{
+    return wdf_clipper_bwd_mse_tp(x, r, theta, fs, n_up, n_down, zstash, gy, nullptr, 0.0f, ws, gtheta, nullptr, gz0,
+                                  accumulate, B, T, n_chunks, flags, stream);
+}
+
+int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                           const float* zstash, const float* gy, const float* target, float gscale, void* ws,
+                           float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T, int n_chunks,
+                           int flags, void* stream)
+{
+    int rc = check_common(x, theta, n_up, n_down, B, T, flags);
+    if (rc) return rc;
+    if (flags & WDF_X_TIME_MAJOR) return fail(WDF_EUNSUPPORTED, "time-parallel kernels take batch-major x");
+    if (!zstash || !gy || !ws || !gtheta) return fail(WDF_EINVAL, "null zstash/gy/ws/gtheta");
+    if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
+    if (n_chunks < 1) return fail(WDF_EINVAL, "n_chunks >= 1");
+    const TpGeom g = tp_geom(T, n_chunks);
+    double* wsd = (double*)ws;                                       // [nparts][4] doubles first (8-byte aligned)
+    float* part = (float*)((char*)ws + wdf_clipper_bwd_ws_bytes(B)); // then [K][8][B] floats
+    const bool v4 = (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    WDF_DISPATCH3(launch_bwd_tp, r != nullptr, n_up == n_down, v4, x, r, theta, fs, n_up, n_down, zstash, gy, target,
+                  gscale, part, wsd, gz0, B, T, g, (hipStream_t)stream);
+    rc = check_launch("wdf_clipper_bwd_tp");
+    if (rc) return rc;
+    const int nparts = (int)((B + 63) / 64);
+    hipLaunchKernelGGL(wdf::clipper_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)wsd,
+                       nparts, theta, fs, r != nullptr ? 1 : 0, gtheta, accumulate, target ? sse : nullptr);
     return check_launch("wdf_clipper_grad_reduce");
 }
 

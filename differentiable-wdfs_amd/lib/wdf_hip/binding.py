@@ -44,6 +44,19 @@ def lib():
     L.wdf_clipper_bwd.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, vp, fp, fp, ci, i64, i64, ci, vp]
     L.wdf_clipper_bwd_ws_bytes.restype = C.c_size_t
     L.wdf_clipper_bwd_ws_bytes.argtypes = [i64]
+    L.wdf_clipper_tp_chunks.restype = ci
+    L.wdf_clipper_tp_chunks.argtypes = [i64, ci]
+    L.wdf_clipper_fwd_tp_ws_bytes.restype = C.c_size_t
+    L.wdf_clipper_fwd_tp_ws_bytes.argtypes = [i64, ci]
+    L.wdf_clipper_fwd_tp.restype = ci
+    L.wdf_clipper_fwd_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, ci, vp]
+    L.wdf_clipper_bwd_tp_ws_bytes.restype = C.c_size_t
+    L.wdf_clipper_bwd_tp_ws_bytes.argtypes = [i64, ci]
+    L.wdf_clipper_bwd_tp.restype = ci
+    L.wdf_clipper_bwd_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, vp, fp, fp, ci, i64, i64, ci, ci, vp]
+    L.wdf_clipper_bwd_mse_tp.restype = ci
+    L.wdf_clipper_bwd_mse_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, cf, vp, fp, fp, fp, ci, i64, i64, ci,
+                                         ci, vp]
     L.wdf_ss_ncoef.restype = ci
     L.wdf_ss_ncoef.argtypes = [ci, ci]
     L.wdf_ss_fwd.restype = ci
@@ -70,6 +83,8 @@ def lib():
 EXPORTED_SYMBOLS = (
     "wdf_abi_version", "wdf_last_error", "wdf_device_info",
     "wdf_clipper_fwd", "wdf_clipper_bwd", "wdf_clipper_bwd_ws_bytes",
+    "wdf_clipper_tp_chunks", "wdf_clipper_fwd_tp_ws_bytes", "wdf_clipper_fwd_tp",
+    "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
     "wdf_omega_f32", "wdf_diode_pair_f32",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy",
@@ -150,6 +165,92 @@ def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=Fal
                                1 if accumulate else 0, B, T, flags, _stream())
     _check(rc, "wdf_clipper_bwd")
     return gtheta, gz0
+
+
+def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_down=1, want_stash=True, z0=None,
+                   want_zT=False, ws=None, status=None):
+    """Time-parallel forward.  Returns y [T,B], zstash | None, zT | None, status (device int32[4]:
+    n_bad, max-miss float bits, fallback_ran, 0 -- read it with tp_status())."""
+    require_gpu()
+    x = _f32_dev(x, "x")
+    r = _f32_dev(r, "r")
+    theta = _f32_dev(theta, "theta")
+    z0 = _f32_dev(z0, "z0")
+    B, T = x.shape
+    if r is not None and r.shape != x.shape:
+        raise WdfHipError("r must have the shape of x")
+    y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zs = torch.empty((T, B), dtype=torch.float32, device=x.device) if want_stash else None
+    zT = torch.empty((B,), dtype=torch.float32, device=x.device) if want_zT else None
+    if ws is None:
+        ws = torch.empty((lib().wdf_clipper_fwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
+    if status is None:
+        status = torch.empty((4,), dtype=torch.int32, device=x.device)
+    rc = lib().wdf_clipper_fwd_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(y),
+                                  _ptr(zs), _ptr(z0), _ptr(zT), B, T, int(n_chunks), int(warmup), float(tol),
+                                  _ptr(ws), _ptr(status), 0, _stream())
+    _check(rc, "wdf_clipper_fwd_tp")
+    return y, zs, zT, status
+
+
+def tp_status(status):
+    """Host view of a time-parallel status word (synchronises)."""
+    s = status.cpu()
+    return {"n_bad": int(s[0]), "max_miss": float(s[1:2].view(torch.float32)[0]), "fallback_ran": bool(int(s[2])),
+            "repaired_tiles": int(s[2])}
+
+
+def clipper_bwd_tp(x, theta, fs, zstash, gy, n_chunks, r=None, n_up=1, n_down=1, want_gz0=False, gtheta=None,
+                   accumulate=False, ws=None):
+    require_gpu()
+    x = _f32_dev(x, "x")
+    r = _f32_dev(r, "r")
+    theta = _f32_dev(theta, "theta")
+    zstash = _f32_dev(zstash, "zstash")
+    gy = _f32_dev(gy, "gy")
+    B, T = x.shape
+    if tuple(gy.shape) != (T, B) or tuple(zstash.shape) != (T, B):
+        raise WdfHipError(f"gy / zstash must be [T,B] = [{T},{B}]")
+    if ws is None:
+        ws = torch.empty((lib().wdf_clipper_bwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
+    if gtheta is None:
+        gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
+        accumulate = False
+    gz0 = torch.empty((B,), dtype=torch.float32, device=x.device) if want_gz0 else None
+    rc = lib().wdf_clipper_bwd_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(zstash),
+                                  _ptr(gy), _ptr(ws), _ptr(gtheta), _ptr(gz0), 1 if accumulate else 0, B, T,
+                                  int(n_chunks), 0, _stream())
+    _check(rc, "wdf_clipper_bwd_tp")
+    return gtheta, gz0
+
+
+def clipper_bwd_mse_tp(x, theta, fs, zstash, y, target, gscale, n_chunks, r=None, n_up=1, n_down=1, gtheta=None,
+                       sse=None, accumulate=False, ws=None):
+    """MSE-fused reverse sweep: dL/dy = gscale (y - target) formed in the kernel.
+    Returns (gtheta float32[4], sse float32[1] = sum (y - target)^2 over this batch)."""
+    require_gpu()
+    x = _f32_dev(x, "x")
+    r = _f32_dev(r, "r")
+    theta = _f32_dev(theta, "theta")
+    zstash = _f32_dev(zstash, "zstash")
+    y = _f32_dev(y, "y")
+    target = _f32_dev(target, "target")
+    B, T = x.shape
+    for name, t in (("y", y), ("target", target), ("zstash", zstash)):
+        if tuple(t.shape) != (T, B):
+            raise WdfHipError(f"{name} must be [T,B] = [{T},{B}]")
+    if ws is None:
+        ws = torch.empty((lib().wdf_clipper_bwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
+    if gtheta is None:
+        gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
+        accumulate = False
+    if sse is None:
+        sse = torch.empty((1,), dtype=torch.float32, device=x.device)
+    rc = lib().wdf_clipper_bwd_mse_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
+                                      _ptr(zstash), _ptr(y), _ptr(target), float(gscale), _ptr(ws), _ptr(gtheta),
+                                      _ptr(sse), None, 1 if accumulate else 0, B, T, int(n_chunks), 0, _stream())
+    _check(rc, "wdf_clipper_bwd_mse_tp")
+    return gtheta, sse
 
 
 ROOT_NONE, ROOT_DIODE_PAIR = 0, 2

@@ -5,20 +5,69 @@ The forward call replaces the reference's whole per-sample Python loop
 (clipper_pot.py:246-268) by one reverse-sweep launch.  torch only carries tensors between
 the two and into the loss / optimizer.
 """
+import math
+from collections import namedtuple
+
 import torch
 
 from . import binding
+
+# ---- time-parallel plan -------------------------------------------------------------------
+# k_fwd / warmup / tol: chunks, warm-up steps and verified tolerance of the speculative forward
+# (csrc/wdf_clipper.h "Time-parallel variants"); k_bwd: chunks of the exact reverse sweep.
+TpPlan = namedtuple("TpPlan", ["k_fwd", "warmup", "tol", "k_bwd"])
+
+N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
+
+
+def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, r_min=None):
+    """Choose chunk counts from the batch shape and the circuit's memory.
+
+    Sequential mode gives ceil(B/64) waves for 1024 SIMDs; the plan aims at ~2 waves per SIMD
+    for the forward and ~4 for the reverse sweep.  The forward's warm-up must outlast the
+    circuit's memory: with the diode off the state contracts by (1 - 2p) per sample
+    (p = Rc/(R+Rc), Rc = 1/(2 C fs)); W is the number of steps that shrinks an O(10 V) error
+    below 1e-9.  If W would make chunks more than 2x redundant, fewer chunks are used; if
+    even 2 chunks do not pay, the forward stays sequential (k_fwd = 1).  The verify kernel
+    still guards every run, so a bad estimate costs time, never correctness.
+    """
+    waves = max(1, -(-B // 64))
+    Rc = 1.0 / (2.0 * float(C) * float(fs))
+    Rv = float(R if r_min is None else r_min)
+    p = Rc / (Rv + Rc)
+    rho = abs(1.0 - 2.0 * p)
+    if rho <= 0.0:
+        W = 8
+    elif rho >= 1.0 - 1e-9:
+        W = T
+    else:
+        W = int(math.ceil(math.log(1.0e-10) / math.log(rho)))
+    W = max(8, -(-W // 8) * 8)
+    k_fwd = max(1, min((2 * N_SIMD) // waves, T // max(W, 64)))
+    if k_fwd < 2:
+        k_fwd = 1
+    k_bwd = max(1, min((4 * N_SIMD) // waves, T // 64))
+    return TpPlan(k_fwd, W, float(tol), k_bwd)
+
+
+LAST_TP_STATUS = {"status": None}     # device status word of the most recent time-parallel forward
 
 
 class _ClipperFn(torch.autograd.Function):
     """y[T,B] = clipper(theta = {Is, nVt, R, C}, x[B,T] (, r[B,T]))."""
 
     @staticmethod
-    def forward(ctx, theta, x, r, fs, n_up, n_down, time_major):
+    def forward(ctx, theta, x, r, fs, n_up, n_down, time_major, tp):
         need_grad = theta.requires_grad
         th = theta.detach().contiguous()
-        y, zs, _ = binding.clipper_fwd(x, th, fs, r=r, n_up=n_up, n_down=n_down, want_stash=need_grad,
-                                       time_major=time_major)
+        if tp is not None and not time_major and tp.k_fwd > 1:
+            y, zs, _, st = binding.clipper_fwd_tp(x, th, fs, tp.k_fwd, tp.warmup, tp.tol, r=r, n_up=n_up,
+                                                  n_down=n_down, want_stash=need_grad)
+            LAST_TP_STATUS["status"] = st
+        else:
+            y, zs, _ = binding.clipper_fwd(x, th, fs, r=r, n_up=n_up, n_down=n_down, want_stash=need_grad,
+                                           time_major=time_major)
+        ctx.tp = tp if (tp is not None and not time_major) else None
         ctx.cfg = (fs, n_up, n_down, time_major)
         ctx.has_r = r is not None
         if need_grad:
@@ -31,15 +80,60 @@ class _ClipperFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         th, x, zs = saved[0], saved[1], saved[2]
         r = saved[3] if ctx.has_r else None
-        gtheta, _ = binding.clipper_bwd(x, th, fs, zs, gy.contiguous(), r=r, n_up=n_up, n_down=n_down,
-                                        time_major=time_major)
-        return gtheta, None, None, None, None, None, None
+        if ctx.tp is not None and ctx.tp.k_bwd > 1:
+            gtheta, _ = binding.clipper_bwd_tp(x, th, fs, zs, gy.contiguous(), ctx.tp.k_bwd, r=r, n_up=n_up,
+                                               n_down=n_down)
+        else:
+            gtheta, _ = binding.clipper_bwd(x, th, fs, zs, gy.contiguous(), r=r, n_up=n_up, n_down=n_down,
+                                            time_major=time_major)
+        return gtheta, None, None, None, None, None, None, None
 
 
-def clipper(theta, x, fs, r=None, n_up=1, n_down=1, time_major=False):
+def clipper(theta, x, fs, r=None, n_up=1, n_down=1, time_major=False, tp=None):
     """Diode-clipper sequence loop on the GPU.  theta: float32[4] = {Is, nVt, R, C} on the
-    device (may require grad); x, r: [B,T] (or [T,B] when time_major).  Returns y [T,B]."""
-    return _ClipperFn.apply(theta, x, r, float(fs), int(n_up), int(n_down), bool(time_major))
+    device (may require grad); x, r: [B,T] (or [T,B] when time_major).  Returns y [T,B].
+    tp: a TpPlan (plan_time_parallel) to run the time-parallel kernels, None = sequential."""
+    return _ClipperFn.apply(theta, x, r, float(fs), int(n_up), int(n_down), bool(time_major), tp)
+
+
+class MseStep:
+    """Fused training step for the mean-squared-error loss (lpf.py:78, clipper_pot.py:176):
+    forward, loss and reverse sweep in two kernel launches + two tiny ones, all buffers
+    preallocated.  step() returns device tensors (sse[1], gtheta[4]): the sum of squared errors
+    over THIS batch and d(mean over n_global)/d{Is, nVt, R, C}; nothing synchronises."""
+
+    def __init__(self, B, T, fs, tp, device, n_up=1, n_down=1, n_global=None, with_r=False):
+        self.B, self.T, self.fs, self.tp = B, T, float(fs), tp
+        self.n_up, self.n_down = n_up, n_down
+        self.gscale = 2.0 / float(n_global if n_global is not None else B * T)
+        L = binding.lib()
+        kf, kb = (tp.k_fwd, tp.k_bwd) if tp is not None else (1, 1)
+        self.ws_f = torch.empty((max(16, L.wdf_clipper_fwd_tp_ws_bytes(B, kf)),), dtype=torch.uint8, device=device)
+        self.ws_b = torch.empty((L.wdf_clipper_bwd_tp_ws_bytes(B, kb),), dtype=torch.uint8, device=device)
+        self.status = torch.zeros((4,), dtype=torch.int32, device=device)
+        self.gtheta = torch.zeros((4,), dtype=torch.float32, device=device)
+        self.sse = torch.zeros((1,), dtype=torch.float32, device=device)
+        self.y = self.zs = None
+
+    def forward(self, theta, x, r=None):
+        tp = self.tp
+        if tp is not None and tp.k_fwd > 1:
+            self.y, self.zs, _, _ = binding.clipper_fwd_tp(x, theta, self.fs, tp.k_fwd, tp.warmup, tp.tol, r=r,
+                                                            n_up=self.n_up, n_down=self.n_down, ws=self.ws_f,
+                                                            status=self.status)
+        else:
+            self.y, self.zs, _ = binding.clipper_fwd(x, theta, self.fs, r=r, n_up=self.n_up, n_down=self.n_down)
+        return self.y
+
+    def backward(self, theta, x, target, r=None):
+        kb = self.tp.k_bwd if self.tp is not None else 1
+        binding.clipper_bwd_mse_tp(x, theta, self.fs, self.zs, self.y, target, self.gscale, kb, r=r, n_up=self.n_up,
+                                   n_down=self.n_down, gtheta=self.gtheta, sse=self.sse, ws=self.ws_b)
+        return self.sse, self.gtheta
+
+    def step(self, theta, x, target, r=None):
+        self.forward(theta, x, r)
+        return self.backward(theta, x, target, r)
 
 
 class _ClipperStatefulFn(torch.autograd.Function):

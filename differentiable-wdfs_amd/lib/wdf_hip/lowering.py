@@ -111,8 +111,9 @@ class Circuit:
     topology only.
     """
 
-    def __init__(self, top, root, probe, per_sample_R=None, force_generic=False):
+    def __init__(self, top, root, probe, per_sample_R=None, force_generic=False, time_parallel="auto"):
         self.top, self.root, self.probe = top, root, probe
+        self.time_parallel = time_parallel          # "auto" | None | engine.TpPlan
         self.force_generic = bool(force_generic)    # tests: run the clipper tree through the generic kernel
         self.elements = _walk(top)
         if probe not in self.elements:
@@ -228,5 +229,13 @@ class Circuit:
             y, zT = engine.clipper_stateful(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, z0=z0t)
             y = y.as_subclass(tf.Tensor)
             return (y, zT.reshape(1, -1)) if return_state else y
-        y = engine.clipper(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down)
+        tp = self.time_parallel
+        if tp == "auto":
+            # component values live on the host (tiny CPU variables): planning costs no sync
+            r_min = None if r is None else 1.0e3
+            tp = engine.plan_time_parallel(xv.shape[0], xv.shape[1], float(parts[2]), float(cap.C), float(cap.FS),
+                                           r_min=r_min)
+            if r is not None:
+                tp = tp._replace(k_fwd=1)       # per-sample R: memory depends on the data, stay sequential
+        y = engine.clipper(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp)
         return y.as_subclass(tf.Tensor)

@@ -89,6 +89,46 @@ int wdf_clipper_bwd(const float* x, const float* r, const float* theta,
 size_t wdf_clipper_bwd_ws_bytes(int64_t B);
 
 /* ------------------------------------------------------------------------------------
+ * Time-parallel variants of the two calls above (same results, more waves in flight; see
+ * csrc/wdf_clipper.h "Time-parallel variants").  The time axis is cut into n_chunks chunks
+ * (chunk length rounded up to a multiple of 8; wdf_clipper_tp_chunks() returns the number
+ * actually used).  Batch-major x only.
+ *
+ * wdf_clipper_bwd_tp: EXACT -- the adjoint recurrence is linear, chunk results are combined
+ *   by a second tiny kernel; only the (fixed) summation order differs from wdf_clipper_bwd.
+ * wdf_clipper_fwd_tp: every chunk starts `warmup` steps early from z = 0; the state it
+ *   arrives with is checked on the device against the previous chunk's final state
+ *   (|diff| <= tol for every sequence and chunk) by a verify kernel that, where a check
+ *   fails, recomputes that wave's 64 sequences sequentially (exact) on the spot.
+ *   Either way the outputs are within tol of wdf_clipper_fwd's, with no host round trip.
+ *   status: device int32[4] = {n_bad pairs, max |miss| (float bits), repaired tiles, 0},
+ *   written by the call (zeroed first); the caller may read it later to report / adapt
+ *   `warmup`.
+ * ---------------------------------------------------------------------------------- */
+int wdf_clipper_tp_chunks(int64_t T, int n_chunks);
+size_t wdf_clipper_fwd_tp_ws_bytes(int64_t B, int n_chunks);
+int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta,
+                       float fs, int n_up, int n_down,
+                       float* y, float* zstash, const float* z0, float* zT,
+                       int64_t B, int64_t T, int n_chunks, int warmup, float tol,
+                       void* ws, void* status, int flags, void* stream);
+size_t wdf_clipper_bwd_tp_ws_bytes(int64_t B, int n_chunks);
+/* MSE-fused reverse sweep (lpf.py:78 / clipper_pot.py:176 loss): `y` is the forward output,
+ * `target` [T][B] the training target; dL/dy = gscale (y - target) is formed in the kernel
+ * (gscale = 2/N for a mean over N samples, N the GLOBAL sample count under data
+ * parallelism) and *sse (device float) receives sum (y - target)^2 over this call's batch. */
+int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta,
+                           float fs, int n_up, int n_down,
+                           const float* zstash, const float* y, const float* target, float gscale,
+                           void* ws, float* gtheta, float* sse, float* gz0, int accumulate,
+                           int64_t B, int64_t T, int n_chunks, int flags, void* stream);
+int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta,
+                       float fs, int n_up, int n_down,
+                       const float* zstash, const float* gy,
+                       void* ws, float* gtheta, float* gz0, int accumulate,
+                       int64_t B, int64_t T, int n_chunks, int flags, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Generic tree + one root, as a state-space recursion (csrc/wdf_statespace.h):
  *     a = ca.z + da.x ;  b = root(a) ;  z' = A z + Bx x + E b ;  y = cy.z + dy.x + fy b
  * Replaces, per call, the whole per-sample loop of lpf.py:39-46 / voltage_divider.py:35-42 /

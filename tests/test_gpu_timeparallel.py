@@ -1,0 +1,158 @@
+"""GPU: the time-parallel kernels give the sequential kernels' results.
+
+* reverse sweep: exact up to summation order -> gradients agree to 2e-5 relative;
+* forward: outputs within the verified tolerance of the sequential kernel, status clean; and
+  when the warm-up is deliberately too short for the circuit's memory, the on-device
+  verification notices and the gated sequential kernel makes the result exact anyway.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+FS = 48000.0
+
+
+@pytest.fixture(scope="module")
+def wb():
+    from wdf_hip import binding
+    binding.require_gpu()
+    return binding
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
+
+
+def setup(B, T, seed=0):
+    from wdf_hip import workload
+    x = workload.sweep_batch(B, T, seed=seed)
+    return dev(x), dev(workload.clipper_theta())
+
+
+@pytest.mark.parametrize("B,T,K", [(64, 512, 4), (70, 1001, 7), (130, 2048, 16), (5, 96, 12), (3, 8, 4)])
+@pytest.mark.parametrize("n_up,n_down", [(1, 1), (2, 3)])
+def test_bwd_tp_matches_sequential(wb, B, T, K, n_up, n_down):
+    x, th = setup(B, T, seed=B + T)
+    y, zs, _ = wb.clipper_fwd(x, th, FS, n_up=n_up, n_down=n_down)
+    gy = dev(np.random.default_rng(B).standard_normal((T, B)) / (B * T))
+    g_seq, gz_seq = wb.clipper_bwd(x, th, FS, zs, gy, n_up=n_up, n_down=n_down, want_gz0=True)
+    g_tp, gz_tp = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, n_up=n_up, n_down=n_down, want_gz0=True)
+    assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0), (g_tp, g_seq)
+    assert torch.allclose(gz_tp, gz_seq, rtol=1e-4, atol=1e-12)
+    g_tp2, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, n_up=n_up, n_down=n_down)
+    assert torch.equal(g_tp, g_tp2)                                  # deterministic
+
+
+def test_bwd_tp_per_sample_r(wb):
+    B, T, K = 70, 520, 5
+    x, th = setup(B, T, seed=3)
+    r = dev(45.0e3 * np.exp(0.8 * np.sin(np.arange(T)[None, :] * 0.01 * (1 + np.arange(B)[:, None] % 5))))
+    y, zs, _ = wb.clipper_fwd(x, th, FS, r=r)
+    gy = dev(np.random.default_rng(1).standard_normal((T, B)) / (B * T))
+    g_seq, _ = wb.clipper_bwd(x, th, FS, zs, gy, r=r)
+    g_tp, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, r=r)
+    assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("B,T,K,W", [(64, 2048, 4, 256), (70, 4096, 16, 256), (130, 1001, 3, 248), (5, 4096, 8, 512)])
+def test_fwd_tp_matches_sequential(wb, B, T, K, W):
+    x, th = setup(B, T, seed=B + T)
+    y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
+    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, K, W, tol=1e-6, want_zT=True)
+    s = wb.tp_status(st)
+    assert s["n_bad"] == 0 and not s["fallback_ran"], s
+    assert s["max_miss"] <= 1e-6
+    assert float((y2 - y).abs().max()) <= 1e-6
+    assert float((zs2 - zs).abs().max()) <= 2e-6
+    assert float((zT2 - zT).abs().max()) <= 2e-6
+    # chunk 0 is the sequential computation itself
+    L = -(-T // K)
+    L = -(-L // 8) * 8
+    assert torch.equal(y2[:L], y[:L])
+
+
+def test_fwd_tp_falls_back_when_warmup_is_too_short(wb):
+    """C = 1 uF: the circuit remembers ~4000 samples, a 64-step warm-up cannot work.  The
+    verification must catch it and the gated kernel must restore the exact result."""
+    from wdf_hip import workload
+    B, T = 70, 2048
+    x = dev(workload.sweep_batch(B, T, seed=11))
+    theta = workload.clipper_theta()
+    theta[3] = 1.0e-6
+    th = dev(theta)
+    y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
+    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, 8, 64, tol=1e-6, want_zT=True)
+    s = wb.tp_status(st)
+    assert s["n_bad"] > 0 and s["fallback_ran"], s
+    assert torch.equal(y2, y) and torch.equal(zs2, zs) and torch.equal(zT2, zT)
+
+
+def test_fwd_tp_initial_state_and_no_stash(wb):
+    B, T = 64, 1024
+    x, th = setup(B, T, seed=2)
+    z0 = dev(np.random.default_rng(0).uniform(-0.3, 0.3, B))
+    y, _, _ = wb.clipper_fwd(x, th, FS, z0=z0, want_stash=False)
+    y2, zs2, _, st = wb.clipper_fwd_tp(x, th, FS, 4, 256, z0=z0, want_stash=False)
+    assert zs2 is None and wb.tp_status(st)["n_bad"] == 0
+    assert float((y2 - y).abs().max()) <= 1e-6
+
+
+def test_tp_full_size_against_oracle(wb, oracle):
+    from wdf_hip import workload
+    B, T, K, W = 8192, 4096, 16, 256
+    theta = workload.clipper_theta()
+    x = workload.sweep_batch(B, T)
+    xd, th = dev(x), dev(theta)
+    y, zs, _, st = wb.clipper_fwd_tp(xd, th, FS, K, W)
+    s = wb.tp_status(st)
+    assert s["n_bad"] == 0, s
+    pick = np.random.default_rng(5).choice(B, 16, replace=False)
+    ref = oracle.clipper_fwd(theta.astype(np.float32).astype(np.float64), FS, x[pick].astype(np.float64))
+    assert np.max(np.abs(y[:, torch.as_tensor(pick, device="cuda")].cpu().numpy() - ref)) < 3e-5
+    tgt, _, _ = wb.clipper_fwd(xd, dev(workload.target_theta()), FS, want_stash=False)
+    gy = (2.0 * (y - tgt) / y.numel()).contiguous()
+    g_tp, _ = wb.clipper_bwd_tp(xd, th, FS, zs, gy, 64)
+    g_seq, _ = wb.clipper_bwd(xd, th, FS, zs, gy)
+    assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0), (g_tp, g_seq)
+
+
+def test_fused_mse_step_matches_autograd_path(wb):
+    """engine.MseStep (time-parallel forward + MSE-fused reverse sweep) == the plain path:
+    sequential forward, torch MSE, sequential reverse sweep."""
+    from wdf_hip import engine, workload
+    B, T = 200, 2048
+    x, th = setup(B, T, seed=21)
+    tgt, _, _ = wb.clipper_fwd(x, dev(workload.target_theta()), FS, want_stash=False)
+    theta = workload.clipper_theta()
+    tp = engine.plan_time_parallel(B, T, theta[2], theta[3], FS)
+    assert tp.k_fwd > 1 and tp.k_bwd > 1 and tp.warmup % 8 == 0
+    stepper = engine.MseStep(B, T, FS, tp, x.device)
+    sse, g = stepper.step(th, x, tgt)
+    assert wb.tp_status(stepper.status)["n_bad"] == 0
+    thr = th.clone().requires_grad_(True)
+    y = engine.clipper(thr, x, FS)
+    loss = torch.mean((y - tgt) ** 2)
+    loss.backward()
+    assert abs(float(sse) / (B * T) - float(loss)) < 1e-6 * float(loss) + 1e-12
+    assert torch.allclose(g, thr.grad, rtol=5e-5, atol=0), (g, thr.grad)
+    # and through the element API with the automatic plan
+    import tf_wdf as wdf
+    Vs = wdf.ResistiveVoltageSource(float(theta[2]), trainable=True)
+    Cap = wdf.Capacitor(float(theta[3]), FS, trainable=True)
+    P1 = wdf.Parallel(Vs, Cap)
+    dp = wdf.DiodePair(P1, float(theta[0]), Vt=float(theta[1]), trainable=True)
+    ya = wdf.Circuit(P1, dp, Cap)(x)                                   # time_parallel="auto"
+    ys = wdf.Circuit(P1, dp, Cap, time_parallel=None)(x)
+    assert float((ya - ys).abs().max()) <= 1e-6
+
+
+def test_plan_time_parallel_degrades_gracefully():
+    from wdf_hip import engine
+    p = engine.plan_time_parallel(8192, 4096, 45.0e3, 4.7e-9, 48000.0)
+    assert p.k_fwd == 16 and p.k_bwd == 32 and 192 <= p.warmup <= 256
+    slow = engine.plan_time_parallel(8192, 4096, 45.0e3, 1.0e-6, 48000.0)   # memory >> T/2: no forward chunks
+    assert slow.k_fwd == 1 and slow.k_bwd == 32
+    big = engine.plan_time_parallel(1 << 20, 4096, 45.0e3, 4.7e-9, 48000.0)  # plenty of waves already
+    assert big.k_fwd == 1 and big.k_bwd == 1
