@@ -112,7 +112,7 @@ def main():
         sse, gtheta = stepper.backward(theta, x, target)
         if timed:
             ev[3].record()
-        buf = torch.cat([sse / n_global, gtheta])
+        buf = stepper.out                              # [SSE, grads]: the kernels wrote it in place
         wdist.allreduce_sum_(buf)
         if timed:
             t_fwd.append(ev[0].elapsed_ms(ev[1]))
@@ -156,7 +156,7 @@ def main():
             "config": {"workload": f"1N4148 diode clipper fwd+bwd (grads wrt Is,nVt,R,C), MSE loss, "
                                    f"{B} sequences x {T} samples @ {int(fs)} Hz per GPU (BASELINE configs[2])",
                        "global_batch": Bg, "seq_len": T, "parallelism": f"dp{world}",
-                       "loss": float(loss), "grad": [float(g) for g in grad],
+                       "loss": float(loss) / n_global, "grad": [float(g) for g in grad],
                        "time_parallel": None if tp is None else
                        {"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup, "verify_tol": tp.tol,
                         "bwd_chunks": tp.k_bwd, "verify_status": tp_stat}},

@@ -82,7 +82,7 @@ int check_common(const float* x, const float* theta, int n_up, int n_down, int64
     if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "B and T must be positive (got B=%lld T=%lld)", (long long)B, (long long)T);
     if (B > (int64_t)64 * 0x7fffffff) return fail(WDF_EINVAL, "B too large");
     if (n_up < 1 || n_down < 1 || n_up > 16 || n_down > 16) return fail(WDF_EINVAL, "n_up/n_down must be in [1,16]");
-    if (flags & ~(WDF_X_TIME_MAJOR | WDF_PREC_F64)) return fail(WDF_EINVAL, "unknown flag bits 0x%x", flags);
+    if (flags & ~(WDF_X_TIME_MAJOR | WDF_PREC_F64 | WDF_TP_PACK2)) return fail(WDF_EINVAL, "unknown flag bits 0x%x", flags);
     if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 is not available for the Wright-omega clipper");
     return WDF_OK;
 }
@@ -116,17 +116,20 @@ TpGeom tp_geom(int64_t T, int n_chunks)
 template <bool DYN_R, bool SYM, bool V4>
 void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
                    float* zstash, const float* z0, float* zT, float* zwarm, float* zend, wdf::TpStatus* status,
-                   float tol, int64_t B, int64_t T, TpGeom g, int64_t W, hipStream_t s)
+                   float tol, int64_t B, int64_t T, TpGeom g, int64_t W, bool pack, hipStream_t s)
 {
-    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)g.K);
     const unsigned gseq = (unsigned)((B + 63) / 64);
-    if (zstash) {
-        hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, V4, true>), grid, dim3(64), 0, s, x, r, theta, fs,
-                           n_up, n_down, y, zstash, z0, zT, zwarm, zend, B, T, g.L, W);
+    const int64_t Bh = pack ? (B + 1) / 2 : B;
+    const dim3 grid((unsigned)((Bh + 63) / 64), (unsigned)g.K);
+#define WDF_FWD_TP(STASH_, V_)                                                                             \
+    hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, V4, STASH_, V_>), grid, dim3(64), 0, s, x, r, theta, \
+                       fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, status, B, Bh, T, g.L, W)
+    if (pack) {
+        if (zstash) WDF_FWD_TP(true, wdf::v2f); else WDF_FWD_TP(false, wdf::v2f);
     } else {
-        hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, V4, false>), grid, dim3(64), 0, s, x, r, theta, fs,
-                           n_up, n_down, y, zstash, z0, zT, zwarm, zend, B, T, g.L, W);
+        if (zstash) WDF_FWD_TP(true, float); else WDF_FWD_TP(false, float);
     }
+#undef WDF_FWD_TP
     if (g.K > 1) {
         if (zstash)
             hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, V4, true>), dim3(gseq), dim3(64), 0, s,
@@ -142,15 +145,19 @@ void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs,
 template <bool DYN_R, bool SYM, bool V4>
 void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
                    const float* zstash, const float* gy, const float* target, float gscale, float* part, double* ws,
-                   float* gz0, int64_t B, int64_t T, TpGeom g, hipStream_t s)
+                   float* gz0, int64_t B, int64_t T, TpGeom g, bool pack, hipStream_t s)
 {
-    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)g.K);
-    if (target)
-        hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, V4, true>), grid, dim3(64), 0, s, x, r, theta, fs,
-                           n_up, n_down, zstash, gy, target, gscale, part, B, T, g.L);
-    else
-        hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, V4, false>), grid, dim3(64), 0, s, x, r, theta, fs,
-                           n_up, n_down, zstash, gy, target, gscale, part, B, T, g.L);
+    const int64_t Bh = pack ? (B + 1) / 2 : B;
+    const dim3 grid((unsigned)((Bh + 63) / 64), (unsigned)g.K);
+#define WDF_BWD_TP(MSE_, V_)                                                                               \
+    hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, V4, MSE_, V_>), grid, dim3(64), 0, s, x, r, theta, fs, \
+                       n_up, n_down, zstash, gy, target, gscale, part, B, Bh, T, g.L)
+    if (pack) {
+        if (target) WDF_BWD_TP(true, wdf::v2f); else WDF_BWD_TP(false, wdf::v2f);
+    } else {
+        if (target) WDF_BWD_TP(true, float); else WDF_BWD_TP(false, float);
+    }
+#undef WDF_BWD_TP
     hipLaunchKernelGGL(wdf::clipper_bwd_tp_combine_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, part, B,
                        (int64_t)g.K, ws, gz0);
 }
@@ -320,13 +327,12 @@ int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta, float
     if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
     const TpGeom g = tp_geom(T, n_chunks);
     const int64_t W = ((int64_t)warmup + wdf::kBlk - 1) / wdf::kBlk * wdf::kBlk;
-    const hipError_t e = hipMemsetAsync(status, 0, sizeof(wdf::TpStatus), (hipStream_t)stream);
-    if (e != hipSuccess) return fail(WDF_ELAUNCH, "hipMemsetAsync(status): %s", hipGetErrorString(e));
     float* zwarm = (float*)ws;
     float* zend = zwarm + (size_t)g.K * (size_t)B;
     const bool v4 = (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH3(launch_fwd_tp, r != nullptr, n_up == n_down, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
-                  zwarm, zend, (wdf::TpStatus*)status, tol, B, T, g, W, (hipStream_t)stream);
+                  zwarm, zend, (wdf::TpStatus*)status, tol, B, T, g, W, (flags & WDF_TP_PACK2) != 0 && B >= 2,
+                  (hipStream_t)stream);
     return check_launch("wdf_clipper_fwd_tp");
 }
 
@@ -360,7 +366,7 @@ int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta, f
     float* part = (float*)((char*)ws + wdf_clipper_bwd_ws_bytes(B)); // then [K][8][B] floats
     const bool v4 = (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH3(launch_bwd_tp, r != nullptr, n_up == n_down, v4, x, r, theta, fs, n_up, n_down, zstash, gy, target,
-                  gscale, part, wsd, gz0, B, T, g, (hipStream_t)stream);
+                  gscale, part, wsd, gz0, B, T, g, (flags & WDF_TP_PACK2) != 0 && B >= 2, (hipStream_t)stream);
     rc = check_launch("wdf_clipper_bwd_tp");
     if (rc) return rc;
     const int nparts = (int)((B + 63) / 64);

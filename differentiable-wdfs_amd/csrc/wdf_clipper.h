@@ -56,18 +56,18 @@ __device__ __forceinline__ ClipConsts load_consts(const float* __restrict__ thet
 }
 
 // adaptor coefficients for this step
-template <bool DYN_R>
-__device__ __forceinline__ void step_coeffs(const ClipConsts& c, float rin, float& p, float& Rp, float& L)
+template <bool DYN_R, typename V>
+__device__ __forceinline__ void step_coeffs(const ClipConsts& c, V rin, V& p, V& Rp, V& L)
 {
     if constexpr (DYN_R) {                       // set_resistance + calc_impedance every step
-        const float G1 = fast_rcp(rin);
-        Rp = fast_rcp(G1 + c.G2);
+        const V G1 = vrcp(rin);
+        Rp = vrcp(G1 + c.G2);
         p = G1 * Rp;
-        L = fast_log(Rp) + c.lIV;
+        L = vfma(vlog2(Rp), kLn2, vsplat<V>(c.lIV));
     } else {
-        p = c.p;
-        Rp = c.Rp;
-        L = c.L;
+        p = vsplat<V>(c.p);
+        Rp = vsplat<V>(c.Rp);
+        L = vsplat<V>(c.L);
     }
 }
 
@@ -100,17 +100,17 @@ __device__ __forceinline__ float load_one(const float* __restrict__ x, int64_t b
 // =========================================================================================
 // forward
 // =========================================================================================
-template <bool DYN_R, bool SYM>
-__device__ __forceinline__ float fwd_step(const ClipConsts& c, float xin, float rin, float& z)
+template <bool DYN_R, bool SYM, typename V>
+__device__ __forceinline__ V fwd_step(const ClipConsts& c, V xin, V rin, V& z)
 {
-    float p, Rp, L;
-    step_coeffs<DYN_R>(c, rin, p, Rp, L);
-    const float b_diff = z - xin;
-    const float b_temp = -p * b_diff;
-    const float a = z + b_temp;
-    const DiodeOut o = diode_pair<SYM>(a, L, c.d);
-    const float zn = o.b + b_temp;
-    const float y = 0.5f * (zn + z);
+    V p, Rp, L;
+    step_coeffs<DYN_R, V>(c, rin, p, Rp, L);
+    const V b_diff = z - xin;
+    const V b_temp = -p * b_diff;
+    const V a = z + b_temp;
+    const DiodeOutT<V> o = diode_pair<SYM, V>(a, L, c.d);
+    const V zn = o.b + b_temp;
+    const V y = 0.5f * (zn + z);
     z = zn;
     return y;
 }
@@ -185,10 +185,10 @@ __device__ __forceinline__ void bwd_step(const ClipConsts& c, float xin, float r
                                          float& gz, StepGrads& acc)
 {
     float p, Rp, L;
-    step_coeffs<DYN_R>(c, rin, p, Rp, L);
+    step_coeffs<DYN_R, float>(c, rin, p, Rp, L);
     const float b_diff = z - xin;
     const float a = fmaf(-p, b_diff, z);
-    const DiodeOut o = diode_pair<SYM>(a, L, c.d);
+    const DiodeOut o = diode_pair<SYM, float>(a, L, c.d);
     const float w0p = o.w0 * fast_rcp(1.0f + o.w0);
     const float w1p = o.w1 * fast_rcp(1.0f + o.w1);
     const float l2 = o.lam * o.lam;
@@ -337,7 +337,7 @@ __global__ void diode_pair_kernel(const float* __restrict__ a, const float* __re
     const int64_t j = i < n ? i : n - 1;
     const DiodeStatic d = make_diode_static(nVt, n_up, n_down);
     const float L = logf(Rp[j] * Is / nVt);
-    const DiodeOut o = (n_up == n_down) ? diode_pair<false>(a[j], L, d) : diode_pair<false>(a[j], L, d);
+    const DiodeOut o = diode_pair<false, float>(a[j], L, d);
     if (i < n) b[i] = o.b;
 }
 
@@ -374,75 +374,133 @@ struct TpStatus {
     int pad;
 };
 
-template <bool DYN_R, bool SYM, bool VEC4, bool STASH>
+// Lanes of the time-parallel kernels run VT<V>::N sequences each (wdf_vec.h): lane l of tile
+// blockIdx.x owns sequences  b_j = 64 blockIdx.x + l + j Bh,  Bh = ceil(B / N) (host passes it).
+// Indices past the end shadow the last sequence (same values to the same addresses).
+template <typename V>
+struct LaneSeqs {
+    int64_t b[VT<V>::N];
+    __device__ __forceinline__ LaneSeqs(int64_t B, int64_t Bh)
+    {
+        const int64_t b0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < VT<V>::N; ++j) {
+            const int64_t bj = (b0 < Bh ? b0 : Bh - 1) + j * Bh;
+            b[j] = bj < B ? bj : B - 1;
+        }
+    }
+};
+
+template <typename V, bool TIME_MAJOR, bool VEC4>
+__device__ __forceinline__ void load_block_v(const float* __restrict__ x, const LaneSeqs<V>& q, int64_t B, int64_t T,
+                                             int64_t t0, float (&v)[VT<V>::N][kBlk])
+{
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) load_block<TIME_MAJOR, VEC4>(x, q.b[j], B, T, t0, v[j]);
+}
+
+template <typename V>
+__device__ __forceinline__ V gather(const float (&v)[VT<V>::N][kBlk], int i)
+{
+    V r = vsplat<V>(0.0f);
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) vset(r, j, v[j][i]);
+    return r;
+}
+
+template <typename V>
+__device__ __forceinline__ V load_one_v(const float* __restrict__ x, const LaneSeqs<V>& q, int64_t stride_b,
+                                        int64_t stride_t, int64_t t)
+{
+    V r = vsplat<V>(0.0f);
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) vset(r, j, x[q.b[j] * stride_b + t * stride_t]);
+    return r;
+}
+
+template <typename V>
+__device__ __forceinline__ void store_v(float* __restrict__ p, const LaneSeqs<V>& q, int64_t off, V v)
+{
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) p[off + q.b[j]] = vget(v, j);
+}
+
+template <bool DYN_R, bool SYM, bool VEC4, bool STASH, typename V>
 __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
-    int64_t B, int64_t T, int64_t L, int64_t W)
+    TpStatus* __restrict__ status, int64_t B, int64_t Bh, int64_t T, int64_t L, int64_t W)
 {
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int64_t b = b_raw < B ? b_raw : B - 1;
+    constexpr int N = VT<V>::N;
+    // the verify kernel (next launch on the stream) accumulates into the status word: clear it here
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = TpStatus{0, 0.0f, 0, 0};
+    const LaneSeqs<V> q(B, Bh);
     const int64_t k = blockIdx.y;
     const int64_t t0 = k * L;                               // first owned step (multiple of kBlk)
     const int64_t t1 = (t0 + L < T) ? t0 + L : T;           // one past the last owned step
     const int64_t tw = (t0 > W) ? t0 - W : 0;               // warm-up start (multiple of kBlk)
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    float z = (tw == 0 && z0) ? z0[b] : 0.0f;
+    V z = vsplat<V>(0.0f);
+    if (tw == 0 && z0) z = load_one_v<V>(z0, q, 1, 0, 0);
 
-    float xc[kBlk], xn[kBlk], rc[kBlk], rn[kBlk];
+    float xc[N][kBlk], xn[N][kBlk], rc[N][kBlk], rn[N][kBlk];
 #pragma unroll
-    for (int i = 0; i < kBlk; ++i) { xc[i] = xn[i] = 0.0f; rc[i] = rn[i] = 1.0f; }
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < kBlk; ++i) { xc[j][i] = xn[j][i] = 0.0f; rc[j][i] = rn[j][i] = 1.0f; }
     const int64_t nfull_end = t1 - (t1 - tw) % kBlk;        // full blocks cover [tw, nfull_end)
     if (tw < nfull_end) {
-        load_block<false, VEC4>(x, b, B, T, tw, xn);
-        if constexpr (DYN_R) load_block<false, VEC4>(r, b, B, T, tw, rn);
+        load_block_v<V, false, VEC4>(x, q, B, T, tw, xn);
+        if constexpr (DYN_R) load_block_v<V, false, VEC4>(r, q, B, T, tw, rn);
     }
     // ---- warm-up: [tw, t0), nothing stored -------------------------------------------------
     for (int64_t t = tw; t < t0; t += kBlk) {
 #pragma unroll
-        for (int i = 0; i < kBlk; ++i) { xc[i] = xn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int i = 0; i < kBlk; ++i) { xc[j][i] = xn[j][i]; if constexpr (DYN_R) rc[j][i] = rn[j][i]; }
         if (t + kBlk < nfull_end) {
-            load_block<false, VEC4>(x, b, B, T, t + kBlk, xn);
-            if constexpr (DYN_R) load_block<false, VEC4>(r, b, B, T, t + kBlk, rn);
+            load_block_v<V, false, VEC4>(x, q, B, T, t + kBlk, xn);
+            if constexpr (DYN_R) load_block_v<V, false, VEC4>(r, q, B, T, t + kBlk, rn);
         }
 #pragma unroll
-        for (int i = 0; i < kBlk; ++i) (void)fwd_step<DYN_R, SYM>(c, xc[i], rc[i], z);
+        for (int i = 0; i < kBlk; ++i) (void)fwd_step<DYN_R, SYM, V>(c, gather<V>(xc, i), gather<V>(rc, i), z);
     }
-    zwarm[k * B + b] = z;
+    store_v<V>(zwarm, q, k * B, z);
     // ---- owned steps: [t0, t1) ---------------------------------------------------------------
-    float* __restrict__ yp = y + t0 * B + b;
-    float* __restrict__ zp = STASH ? zstash + t0 * B + b : nullptr;
+    int64_t off = t0 * B;
     for (int64_t t = t0; t < nfull_end; t += kBlk) {
 #pragma unroll
-        for (int i = 0; i < kBlk; ++i) { xc[i] = xn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int i = 0; i < kBlk; ++i) { xc[j][i] = xn[j][i]; if constexpr (DYN_R) rc[j][i] = rn[j][i]; }
         if (t + kBlk < nfull_end) {
-            load_block<false, VEC4>(x, b, B, T, t + kBlk, xn);
-            if constexpr (DYN_R) load_block<false, VEC4>(r, b, B, T, t + kBlk, rn);
+            load_block_v<V, false, VEC4>(x, q, B, T, t + kBlk, xn);
+            if constexpr (DYN_R) load_block_v<V, false, VEC4>(r, q, B, T, t + kBlk, rn);
         }
 #pragma unroll
         for (int i = 0; i < kBlk; ++i) {
-            if constexpr (STASH) { *zp = z; zp += B; }
-            *yp = fwd_step<DYN_R, SYM>(c, xc[i], rc[i], z);
-            yp += B;
+            if constexpr (STASH) store_v<V>(zstash, q, off, z);
+            store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V>(c, gather<V>(xc, i), gather<V>(rc, i), z));
+            off += B;
         }
     }
     for (int64_t t = nfull_end; t < t1; ++t) {              // tail of the last chunk (T % 8)
-        const float xin = load_one<false>(x, b, B, T, t);
-        const float rin = DYN_R ? load_one<false>(r, b, B, T, t) : 1.0f;
-        if constexpr (STASH) { *zp = z; zp += B; }
-        *yp = fwd_step<DYN_R, SYM>(c, xin, rin, z);
-        yp += B;
+        const V xin = load_one_v<V>(x, q, T, 1, t);
+        const V rin = DYN_R ? load_one_v<V>(r, q, T, 1, t) : vsplat<V>(1.0f);
+        if constexpr (STASH) store_v<V>(zstash, q, off, z);
+        store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V>(c, xin, rin, z));
+        off += B;
     }
-    zend[k * B + b] = z;
-    if (zT && t1 == T) zT[b] = z;
+    store_v<V>(zend, q, k * B, z);
+    if (zT && t1 == T) store_v<V>(zT, q, 0, z);
 }
 
-// Verification + tile-local repair in one launch (status must be zeroed before).  Wave w owns
-// sequences [64 w, 64 w + 64): it compares zwarm[k] with zend[k-1] for its own sequences and
-// every chunk; if any of them misses by more than tol, this wave alone re-runs ITS 64
-// sequences sequentially (exact) over the whole time axis.  The common case is K-1 coalesced
-// loads and an early exit.
+// Verification + tile-local repair in one launch.  Wave w owns sequences [64 w, 64 w + 64): it
+// compares zwarm[k] with zend[k-1] for its own sequences and every chunk; if any of them misses
+// by more than tol, this wave alone re-runs ITS 64 sequences sequentially (exact) over the
+// whole time axis.  The common case is K-1 coalesced loads and an early exit.
 template <bool DYN_R, bool SYM, bool VEC4, bool STASH>
 __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
@@ -491,38 +549,47 @@ __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
 //   S_L += g_b2n DL ; S_V += g_b2n DV ; S_P += g_b2n cP,  cP = -(1+Da) b_diff   (static R)
 //                                                         cP = Rp (-(1+Da) b_diff p + DL) (per-sample R)
 // and gz = alpha G + beta.
-struct TpAcc {
-    float aL, aV, aP;   // coefficients of G
-    float bL, bV, bP;   // constant parts
+template <typename V>
+struct TpAccT {
+    V aL, aV, aP;   // coefficients of G
+    V bL, bV, bP;   // constant parts
 };
 
-template <bool DYN_R, bool SYM>
-__device__ __forceinline__ void bwd_tp_step(const ClipConsts& c, float xin, float rin, float z, float g,
-                                            float& alpha, float& beta, TpAcc& acc)
+template <bool DYN_R, bool SYM, typename V>
+__device__ __forceinline__ void bwd_tp_step(const ClipConsts& c, V xin, V rin, V z, V g, V& alpha, V& beta,
+                                            TpAccT<V>& acc)
 {
-    float p, Rp, L;
-    step_coeffs<DYN_R>(c, rin, p, Rp, L);
-    const float b_diff = z - xin;
-    const float a = fmaf(-p, b_diff, z);
-    const DiodeOut o = diode_pair<SYM>(a, L, c.d);
-    const float w0p = o.w0 * fast_rcp(1.0f + o.w0);
-    const float w1p = o.w1 * fast_rcp(1.0f + o.w1);
-    const float l2 = o.lam * o.lam;
-    const float sp = w0p + w1p;
-    const float Da = fmaf(-2.0f * l2, sp, 1.0f);
-    const float DL = -c.d.two_v * o.lam * (o.m0 * w0p - o.m1 * w1p);
-    const float DV = fmaf(2.0f * l2 * a, sp * fast_rcp(c.V), -2.0f * o.lam * (o.m0 * o.w0 - o.m1 * o.w1));
-    const float opd = 1.0f + Da;
-    float cP = -opd * b_diff;
-    if constexpr (DYN_R) cP = Rp * fmaf(cP, p, DL);
-    const float kappa = fmaf(-p, opd, Da);
-    const float hg = 0.5f * g;
-    const float bb = beta + hg;                      // constant part of g_b2n
-    acc.aL = fmaf(alpha, DL, acc.aL); acc.bL = fmaf(bb, DL, acc.bL);
-    acc.aV = fmaf(alpha, DV, acc.aV); acc.bV = fmaf(bb, DV, acc.bV);
-    acc.aP = fmaf(alpha, cP, acc.aP); acc.bP = fmaf(bb, cP, acc.bP);
-    alpha *= kappa;
-    beta = fmaf(kappa, bb, hg);
+    V p, Rp, L;
+    step_coeffs<DYN_R, V>(c, rin, p, Rp, L);
+    const V b_diff = z - xin;
+    const V a = z - p * b_diff;
+    const DiodeOutT<V> o = diode_pair<SYM, V>(a, L, c.d);
+    const V w0p = o.w0 * vrcp(o.w0 + 1.0f);
+    const V w1p = o.w1 * vrcp(o.w1 + 1.0f);
+    const V l2 = o.lam * o.lam;
+    const V sp = w0p + w1p;
+    const V tl = -2.0f * l2;
+    const V Da = vfma(tl, sp, 1.0f);
+    V DL, DV;
+    if constexpr (SYM) {
+        const float tvm = c.d.two_v * c.d.m_dn;
+        DL = (-tvm) * (o.lam * (w0p - w1p));
+        DV = vfma(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * (o.lam * (o.w0 - o.w1)));
+    } else {
+        DL = (-c.d.two_v) * (o.lam * (o.m0 * w0p - o.m1 * w1p));
+        DV = vfma(tl * a, sp * (-1.0f / c.V), -2.0f * (o.lam * (o.m0 * o.w0 - o.m1 * o.w1)));
+    }
+    const V opd = Da + 1.0f;
+    V cP = -opd * b_diff;
+    if constexpr (DYN_R) cP = Rp * vfma(cP, p, DL);
+    const V kappa = Da - p * opd;
+    const V hg = 0.5f * g;
+    const V bb = beta + hg;                          // constant part of g_b2n
+    acc.aL = vfma(alpha, DL, acc.aL); acc.bL = vfma(bb, DL, acc.bL);
+    acc.aV = vfma(alpha, DV, acc.aV); acc.bV = vfma(bb, DV, acc.bV);
+    acc.aP = vfma(alpha, cP, acc.aP); acc.bP = vfma(bb, cP, acc.bP);
+    alpha = alpha * kappa;
+    beta = vfma(kappa, bb, hg);
 }
 
 // out: float [K][9][B] = {aL, aV, aP, bL, bV, bP, alpha_end, beta_end, sse}
@@ -531,87 +598,110 @@ __device__ __forceinline__ void bwd_tp_step(const ClipConsts& c, float xin, floa
 // sum (y - target)^2, so a training step needs no separate loss pass over y.
 constexpr int kTpOut = 9;
 
-template <bool MSE>
-__device__ __forceinline__ float tp_grad_in(float gy_or_y, float tgt, float gscale, float& sse)
+template <bool MSE, typename V>
+__device__ __forceinline__ V tp_grad_in(V gy_or_y, V tgt, float gscale, V& sse)
 {
     if constexpr (MSE) {
-        const float d = gy_or_y - tgt;
-        sse = fmaf(d, d, sse);
+        const V d = gy_or_y - tgt;
+        sse = vfma(d, d, sse);
         return gscale * d;
     } else {
         return gy_or_y;
     }
 }
 
-template <bool DYN_R, bool SYM, bool VEC4, bool MSE>
+template <bool DYN_R, bool SYM, bool VEC4, bool MSE, typename V>
 __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, const float* __restrict__ zstash, const float* __restrict__ gy,
-    const float* __restrict__ target, float gscale, float* __restrict__ out, int64_t B, int64_t T, int64_t L)
+    const float* __restrict__ target, float gscale, float* __restrict__ out, int64_t B, int64_t Bh, int64_t T,
+    int64_t L)
 {
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int64_t b = b_raw < B ? b_raw : B - 1;
+    constexpr int N = VT<V>::N;
+    const LaneSeqs<V> q(B, Bh);
     const int64_t k = blockIdx.y;
     const int64_t t0 = k * L;
     const int64_t t1 = (t0 + L < T) ? t0 + L : T;
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    float alpha = 1.0f, beta = 0.0f;
-    double dbL = 0.0, dbV = 0.0, dbP = 0.0, dsse = 0.0;   // constant parts: fp64 across 8-step blocks
-    float saL = 0.0f, saV = 0.0f, saP = 0.0f;         // G-coefficients decay geometrically: fp32 is enough
+    V alpha = vsplat<V>(1.0f), beta = vsplat<V>(0.0f);
+    // constant parts: fp64 across 8-step blocks; G-coefficients decay geometrically: fp32 is enough
+    double dbL[N], dbV[N], dbP[N], dsse[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) dbL[j] = dbV[j] = dbP[j] = dsse[j] = 0.0;
+    V saL = vsplat<V>(0.0f), saV = vsplat<V>(0.0f), saP = vsplat<V>(0.0f);
 
     const int64_t nfull_end = t1 - (t1 - t0) % kBlk;
     for (int64_t t = t1 - 1; t >= nfull_end; --t) {   // tail of the last chunk first (highest t)
-        TpAcc acc = {0, 0, 0, 0, 0, 0};
-        const float xin = load_one<false>(x, b, B, T, t);
-        const float rin = DYN_R ? load_one<false>(r, b, B, T, t) : 1.0f;
-        float sse1 = 0.0f;
-        const float g = tp_grad_in<MSE>(gy[t * B + b], MSE ? target[t * B + b] : 0.0f, gscale, sse1);
-        bwd_tp_step<DYN_R, SYM>(c, xin, rin, zstash[t * B + b], g, alpha, beta, acc);
-        saL += acc.aL; saV += acc.aV; saP += acc.aP; dbL += acc.bL; dbV += acc.bV; dbP += acc.bP;
-        dsse += sse1;
-    }
-    float xc[kBlk], xn[kBlk], rc[kBlk], rn[kBlk], zc[kBlk], zn[kBlk], gc[kBlk], gn[kBlk], tc[kBlk], tn[kBlk];
+        TpAccT<V> acc = {vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f),
+                         vsplat<V>(0.0f)};
+        const V xin = load_one_v<V>(x, q, T, 1, t);
+        const V rin = DYN_R ? load_one_v<V>(r, q, T, 1, t) : vsplat<V>(1.0f);
+        V sse1 = vsplat<V>(0.0f);
+        const V tg = MSE ? load_one_v<V>(target, q, 1, B, t) : vsplat<V>(0.0f);
+        const V g = tp_grad_in<MSE, V>(load_one_v<V>(gy, q, 1, B, t), tg, gscale, sse1);
+        bwd_tp_step<DYN_R, SYM, V>(c, xin, rin, load_one_v<V>(zstash, q, 1, B, t), g, alpha, beta, acc);
+        saL += acc.aL; saV += acc.aV; saP += acc.aP;
 #pragma unroll
-    for (int i = 0; i < kBlk; ++i) {
-        xc[i] = xn[i] = zc[i] = zn[i] = gc[i] = gn[i] = tc[i] = tn[i] = 0.0f;
-        rc[i] = rn[i] = 1.0f;
+        for (int j = 0; j < N; ++j) {
+            dbL[j] += vget(acc.bL, j); dbV[j] += vget(acc.bV, j); dbP[j] += vget(acc.bP, j);
+            dsse[j] += vget(sse1, j);
+        }
     }
+    float xc[N][kBlk], xn[N][kBlk], rc[N][kBlk], rn[N][kBlk], zc[N][kBlk], zn[N][kBlk], gc[N][kBlk], gn[N][kBlk],
+        tc[N][kBlk], tn[N][kBlk];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < kBlk; ++i) {
+            xc[j][i] = xn[j][i] = zc[j][i] = zn[j][i] = gc[j][i] = gn[j][i] = tc[j][i] = tn[j][i] = 0.0f;
+            rc[j][i] = rn[j][i] = 1.0f;
+        }
     if (nfull_end > t0) {
         const int64_t tb = nfull_end - kBlk;
-        load_block<false, VEC4>(x, b, B, T, tb, xn);
-        if constexpr (DYN_R) load_block<false, VEC4>(r, b, B, T, tb, rn);
-        load_block<true, false>(zstash, b, B, T, tb, zn);
-        load_block<true, false>(gy, b, B, T, tb, gn);
-        if constexpr (MSE) load_block<true, false>(target, b, B, T, tb, tn);
+        load_block_v<V, false, VEC4>(x, q, B, T, tb, xn);
+        if constexpr (DYN_R) load_block_v<V, false, VEC4>(r, q, B, T, tb, rn);
+        load_block_v<V, true, false>(zstash, q, B, T, tb, zn);
+        load_block_v<V, true, false>(gy, q, B, T, tb, gn);
+        if constexpr (MSE) load_block_v<V, true, false>(target, q, B, T, tb, tn);
     }
     for (int64_t tb = nfull_end - kBlk; tb >= t0; tb -= kBlk) {
 #pragma unroll
-        for (int i = 0; i < kBlk; ++i) {
-            xc[i] = xn[i]; zc[i] = zn[i]; gc[i] = gn[i];
-            if constexpr (DYN_R) rc[i] = rn[i];
-            if constexpr (MSE) tc[i] = tn[i];
-        }
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int i = 0; i < kBlk; ++i) {
+                xc[j][i] = xn[j][i]; zc[j][i] = zn[j][i]; gc[j][i] = gn[j][i];
+                if constexpr (DYN_R) rc[j][i] = rn[j][i];
+                if constexpr (MSE) tc[j][i] = tn[j][i];
+            }
         if (tb - kBlk >= t0) {
-            load_block<false, VEC4>(x, b, B, T, tb - kBlk, xn);
-            if constexpr (DYN_R) load_block<false, VEC4>(r, b, B, T, tb - kBlk, rn);
-            load_block<true, false>(zstash, b, B, T, tb - kBlk, zn);
-            load_block<true, false>(gy, b, B, T, tb - kBlk, gn);
-            if constexpr (MSE) load_block<true, false>(target, b, B, T, tb - kBlk, tn);
+            load_block_v<V, false, VEC4>(x, q, B, T, tb - kBlk, xn);
+            if constexpr (DYN_R) load_block_v<V, false, VEC4>(r, q, B, T, tb - kBlk, rn);
+            load_block_v<V, true, false>(zstash, q, B, T, tb - kBlk, zn);
+            load_block_v<V, true, false>(gy, q, B, T, tb - kBlk, gn);
+            if constexpr (MSE) load_block_v<V, true, false>(target, q, B, T, tb - kBlk, tn);
         }
-        TpAcc acc = {0, 0, 0, 0, 0, 0};
-        float sse8 = 0.0f;
+        TpAccT<V> acc = {vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f),
+                         vsplat<V>(0.0f)};
+        V sse8 = vsplat<V>(0.0f);
 #pragma unroll
         for (int i = kBlk - 1; i >= 0; --i) {
-            const float g = tp_grad_in<MSE>(gc[i], tc[i], gscale, sse8);
-            bwd_tp_step<DYN_R, SYM>(c, xc[i], rc[i], zc[i], g, alpha, beta, acc);
+            const V g = tp_grad_in<MSE, V>(gather<V>(gc, i), gather<V>(tc, i), gscale, sse8);
+            bwd_tp_step<DYN_R, SYM, V>(c, gather<V>(xc, i), gather<V>(rc, i), gather<V>(zc, i), g, alpha, beta, acc);
         }
-        saL += acc.aL; saV += acc.aV; saP += acc.aP; dbL += acc.bL; dbV += acc.bV; dbP += acc.bP;
-        dsse += sse8;
+        saL += acc.aL; saV += acc.aV; saP += acc.aP;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            dbL[j] += vget(acc.bL, j); dbV[j] += vget(acc.bV, j); dbP[j] += vget(acc.bP, j);
+            dsse[j] += vget(sse8, j);
+        }
     }
-    float* __restrict__ o = out + (k * kTpOut) * B + b;
-    o[0 * B] = saL; o[1 * B] = saV; o[2 * B] = saP;
-    o[3 * B] = (float)dbL; o[4 * B] = (float)dbV; o[5 * B] = (float)dbP;
-    o[6 * B] = alpha; o[7 * B] = beta; o[8 * B] = (float)dsse;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        float* __restrict__ o = out + (k * kTpOut) * B + q.b[j];
+        o[0 * B] = vget(saL, j); o[1 * B] = vget(saV, j); o[2 * B] = vget(saP, j);
+        o[3 * B] = (float)dbL[j]; o[4 * B] = (float)dbV[j]; o[5 * B] = (float)dbP[j];
+        o[6 * B] = vget(alpha, j); o[7 * B] = vget(beta, j); o[8 * B] = (float)dsse[j];
+    }
 }
 
 // Walks the K chunks of each sequence from last to first; ws: double[gridDim.x][4] like
@@ -624,7 +714,23 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_combine_kernel(const float*
     const bool live = b_raw < B;
     const int64_t b = live ? b_raw : B - 1;
     double G = 0.0, dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0;
-    for (int64_t k = K - 1; k >= 0; --k) {
+    int64_t k = K - 1;
+    for (; k >= 3; k -= 4) {                          // 4 chunks' 36 loads in flight together
+        float v[4][kTpOut];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < kTpOut; ++i) v[j][i] = part[((k - j) * kTpOut + i) * B + b];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dL += (double)v[j][0] * G + (double)v[j][3];
+            dV += (double)v[j][1] * G + (double)v[j][4];
+            dP += (double)v[j][2] * G + (double)v[j][5];
+            dS += (double)v[j][8];
+            G = (double)v[j][6] * G + (double)v[j][7];
+        }
+    }
+    for (; k >= 0; --k) {
         const float* __restrict__ o = part + (k * kTpOut) * B + b;
         dL += (double)o[0 * B] * G + (double)o[3 * B];
         dV += (double)o[1 * B] * G + (double)o[4 * B];

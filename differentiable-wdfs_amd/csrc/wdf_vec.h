@@ -1,0 +1,90 @@
+// wdf_vec.h -- one-or-two-wide fp32 value types for the WDF kernels.
+//
+// The recursion is VALU-issue bound on MI355X (rocprof: ~85 % VALU busy at 2 waves/SIMD), and
+// a CDNA4 SIMD retires a packed v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two fp32 lanes-ops
+// per lane) at the cost of one plain VALU op.  So the kernels are written once over a value
+// type V: V = float runs one sequence per lane; V = v2f runs TWO independent sequences per lane
+// and lets the compiler pack every add / mul / fma of the step.  Transcendentals, compares
+// and selects stay per component.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace wdf {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+template <typename V> struct VT;
+template <> struct VT<float> {
+    using mask = bool;
+    static constexpr int N = 1;
+};
+template <> struct VT<v2f> {
+    using mask = v2i;
+    static constexpr int N = 2;
+};
+
+template <typename V> __device__ __forceinline__ V vsplat(float x);
+template <> __device__ __forceinline__ float vsplat<float>(float x) { return x; }
+template <> __device__ __forceinline__ v2f vsplat<v2f>(float x) { return v2f{x, x}; }
+
+__device__ __forceinline__ float vget(float v, int) { return v; }
+__device__ __forceinline__ float vget(v2f v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ void vset(float& v, int, float x) { v = x; }
+__device__ __forceinline__ void vset(v2f& v, int i, float x) { if (i == 0) v.x = x; else v.y = x; }
+
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f vfma(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, v2f{b, b}, c); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, float c) { return __builtin_elementwise_fma(a, b, v2f{c, c}); }
+__device__ __forceinline__ v2f vfma(v2f a, float b, float c) { return __builtin_elementwise_fma(a, v2f{b, b}, v2f{c, c}); }
+__device__ __forceinline__ v2f vfma(float a, v2f b, v2f c) { return __builtin_elementwise_fma(v2f{a, a}, b, c); }
+__device__ __forceinline__ v2f vfma(float a, v2f b, float c) { return __builtin_elementwise_fma(v2f{a, a}, b, v2f{c, c}); }
+
+__device__ __forceinline__ float vabs(float a) { return fabsf(a); }
+__device__ __forceinline__ v2f vabs(v2f a) { return v2f{fabsf(a.x), fabsf(a.y)}; }
+// min / max against a constant, written as compare+select (no NaN canonicalisation ops)
+__device__ __forceinline__ float vmin_c(float a, float c) { return a < c ? a : c; }
+__device__ __forceinline__ v2f vmin_c(v2f a, float c) { return v2f{a.x < c ? a.x : c, a.y < c ? a.y : c}; }
+__device__ __forceinline__ float vmax_c(float a, float c) { return a > c ? a : c; }
+__device__ __forceinline__ v2f vmax_c(v2f a, float c) { return v2f{a.x > c ? a.x : c, a.y > c ? a.y : c}; }
+
+__device__ __forceinline__ float vexp2(float a) { return __builtin_amdgcn_exp2f(a); }
+__device__ __forceinline__ v2f vexp2(v2f a) { return v2f{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
+__device__ __forceinline__ float vlog2(float a) { return __builtin_amdgcn_logf(a); }
+__device__ __forceinline__ v2f vlog2(v2f a) { return v2f{__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)}; }
+__device__ __forceinline__ float vrcp(float a) { return __builtin_amdgcn_rcpf(a); }
+__device__ __forceinline__ v2f vrcp(v2f a) { return v2f{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+
+// compares against a constant -> mask
+__device__ __forceinline__ bool vle_c(float a, float c) { return a <= c; }
+__device__ __forceinline__ v2i vle_c(v2f a, float c) { return a <= v2f{c, c}; }
+__device__ __forceinline__ bool vgt_c(float a, float c) { return a > c; }
+__device__ __forceinline__ v2i vgt_c(v2f a, float c) { return a > v2f{c, c}; }
+__device__ __forceinline__ bool vge_c(float a, float c) { return a >= c; }
+__device__ __forceinline__ v2i vge_c(v2f a, float c) { return a >= v2f{c, c}; }
+__device__ __forceinline__ bool vlt_c(float a, float c) { return a < c; }
+__device__ __forceinline__ v2i vlt_c(v2f a, float c) { return a < v2f{c, c}; }
+
+__device__ __forceinline__ bool mand(bool a, bool b) { return a && b; }
+__device__ __forceinline__ v2i mand(v2i a, v2i b) { return a & b; }
+__device__ __forceinline__ bool mor(bool a, bool b) { return a || b; }
+__device__ __forceinline__ v2i mor(v2i a, v2i b) { return a | b; }
+__device__ __forceinline__ bool many(bool a) { return a; }
+__device__ __forceinline__ bool many(v2i a) { return (a.x | a.y) != 0; }
+
+__device__ __forceinline__ float vsel(bool m, float a, float b) { return m ? a : b; }
+__device__ __forceinline__ v2f vsel(v2i m, v2f a, v2f b) { return v2f{m.x ? a.x : b.x, m.y ? a.y : b.y}; }
+__device__ __forceinline__ v2f vsel(v2i m, v2f a, float b) { return v2f{m.x ? a.x : b, m.y ? a.y : b}; }
+__device__ __forceinline__ v2f vsel(v2i m, float a, float b) { return v2f{m.x ? a : b, m.y ? a : b}; }
+
+// sign(a) in {-1, 0, +1}  (np.sign)
+__device__ __forceinline__ float vsign(float a) { return (a > 0.0f) ? 1.0f : ((a < 0.0f) ? -1.0f : 0.0f); }
+__device__ __forceinline__ v2f vsign(v2f a) { return v2f{vsign(a.x), vsign(a.y)}; }
+
+// keep a value as computed (opaque to the optimiser at this point)
+__device__ __forceinline__ void vpin(float& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void vpin(v2f& a) { asm volatile("" : "+v"(a)); }
+
+}  // namespace wdf

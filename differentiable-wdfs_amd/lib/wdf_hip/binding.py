@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libwdf_hip.so")
 
 WDF_X_TIME_MAJOR = 1 << 0
 WDF_PREC_F64 = 1 << 1
+WDF_TP_PACK2 = 1 << 2
 
 
 class WdfHipError(RuntimeError):
@@ -168,7 +169,7 @@ def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=Fal
 
 
 def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_down=1, want_stash=True, z0=None,
-                   want_zT=False, ws=None, status=None):
+                   want_zT=False, ws=None, status=None, pack=False):
     """Time-parallel forward.  Returns y [T,B], zstash | None, zT | None, status (device int32[4]:
     n_bad, max-miss float bits, fallback_ran, 0 -- read it with tp_status())."""
     require_gpu()
@@ -188,7 +189,7 @@ def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_d
         status = torch.empty((4,), dtype=torch.int32, device=x.device)
     rc = lib().wdf_clipper_fwd_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(y),
                                   _ptr(zs), _ptr(z0), _ptr(zT), B, T, int(n_chunks), int(warmup), float(tol),
-                                  _ptr(ws), _ptr(status), 0, _stream())
+                                  _ptr(ws), _ptr(status), WDF_TP_PACK2 if pack else 0, _stream())
     _check(rc, "wdf_clipper_fwd_tp")
     return y, zs, zT, status
 
@@ -201,7 +202,7 @@ def tp_status(status):
 
 
 def clipper_bwd_tp(x, theta, fs, zstash, gy, n_chunks, r=None, n_up=1, n_down=1, want_gz0=False, gtheta=None,
-                   accumulate=False, ws=None):
+                   accumulate=False, ws=None, pack=False):
     require_gpu()
     x = _f32_dev(x, "x")
     r = _f32_dev(r, "r")
@@ -219,13 +220,13 @@ def clipper_bwd_tp(x, theta, fs, zstash, gy, n_chunks, r=None, n_up=1, n_down=1,
     gz0 = torch.empty((B,), dtype=torch.float32, device=x.device) if want_gz0 else None
     rc = lib().wdf_clipper_bwd_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(zstash),
                                   _ptr(gy), _ptr(ws), _ptr(gtheta), _ptr(gz0), 1 if accumulate else 0, B, T,
-                                  int(n_chunks), 0, _stream())
+                                  int(n_chunks), WDF_TP_PACK2 if pack else 0, _stream())
     _check(rc, "wdf_clipper_bwd_tp")
     return gtheta, gz0
 
 
 def clipper_bwd_mse_tp(x, theta, fs, zstash, y, target, gscale, n_chunks, r=None, n_up=1, n_down=1, gtheta=None,
-                       sse=None, accumulate=False, ws=None):
+                       sse=None, accumulate=False, ws=None, pack=False):
     """MSE-fused reverse sweep: dL/dy = gscale (y - target) formed in the kernel.
     Returns (gtheta float32[4], sse float32[1] = sum (y - target)^2 over this batch)."""
     require_gpu()
@@ -248,7 +249,8 @@ def clipper_bwd_mse_tp(x, theta, fs, zstash, y, target, gscale, n_chunks, r=None
         sse = torch.empty((1,), dtype=torch.float32, device=x.device)
     rc = lib().wdf_clipper_bwd_mse_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
                                       _ptr(zstash), _ptr(y), _ptr(target), float(gscale), _ptr(ws), _ptr(gtheta),
-                                      _ptr(sse), None, 1 if accumulate else 0, B, T, int(n_chunks), 0, _stream())
+                                      _ptr(sse), None, 1 if accumulate else 0, B, T, int(n_chunks),
+                                      WDF_TP_PACK2 if pack else 0, _stream())
     _check(rc, "wdf_clipper_bwd_mse_tp")
     return gtheta, sse
 

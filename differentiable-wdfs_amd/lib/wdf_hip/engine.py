@@ -23,11 +23,12 @@ N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
 def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, r_min=None):
     """Choose chunk counts from the batch shape and the circuit's memory.
 
-    Sequential mode gives ceil(B/64) waves for 1024 SIMDs; the plan aims at ~2 waves per SIMD
-    for the forward and ~4 for the reverse sweep.  The forward's warm-up must outlast the
-    circuit's memory: with the diode off the state contracts by (1 - 2p) per sample
-    (p = Rc/(R+Rc), Rc = 1/(2 C fs)); W is the number of steps that shrinks an O(10 V) error
-    below 1e-9.  If W would make chunks more than 2x redundant, fewer chunks are used; if
+    Sequential mode gives ceil(B/64) waves for 1024 SIMDs; the plan aims at ~1 wave per SIMD
+    for the forward (every extra chunk costs a warm-up; measured optimum on MI355X) and ~4 for
+    the reverse sweep (no redundancy there).  The forward's warm-up must outlast the circuit's
+    memory: with the diode off the state contracts by (1 - 2p) per sample (p = Rc/(R+Rc),
+    Rc = 1/(2 C fs)); W is the number of steps that shrinks an O(10 V) error below 1e-7
+    (measured miss at the headline circuit: 3e-8 against a verified tolerance of 1e-6).  If W would make chunks more than 2x redundant, fewer chunks are used; if
     even 2 chunks do not pay, the forward stays sequential (k_fwd = 1).  The verify kernel
     still guards every run, so a bad estimate costs time, never correctness.
     """
@@ -41,9 +42,9 @@ def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, r_min=None):
     elif rho >= 1.0 - 1e-9:
         W = T
     else:
-        W = int(math.ceil(math.log(1.0e-10) / math.log(rho)))
+        W = int(math.ceil(math.log(1.0e-8) / math.log(rho)))
     W = max(8, -(-W // 8) * 8)
-    k_fwd = max(1, min((2 * N_SIMD) // waves, T // max(W, 64)))
+    k_fwd = max(1, min(N_SIMD // waves, T // max(W, 64)))
     if k_fwd < 2:
         k_fwd = 1
     k_bwd = max(1, min((4 * N_SIMD) // waves, T // 64))
@@ -111,8 +112,9 @@ class MseStep:
         self.ws_f = torch.empty((max(16, L.wdf_clipper_fwd_tp_ws_bytes(B, kf)),), dtype=torch.uint8, device=device)
         self.ws_b = torch.empty((L.wdf_clipper_bwd_tp_ws_bytes(B, kb),), dtype=torch.uint8, device=device)
         self.status = torch.zeros((4,), dtype=torch.int32, device=device)
-        self.gtheta = torch.zeros((4,), dtype=torch.float32, device=device)
-        self.sse = torch.zeros((1,), dtype=torch.float32, device=device)
+        # one fused buffer [sse, dIs, dnVt, dR, dC]: it is also the all-reduce payload
+        self.out = torch.zeros((5,), dtype=torch.float32, device=device)
+        self.sse, self.gtheta = self.out[0:1], self.out[1:5]
         self.y = self.zs = None
 
     def forward(self, theta, x, r=None):

@@ -43,7 +43,8 @@ enum {
 /* flags */
 enum {
     WDF_X_TIME_MAJOR = 1 << 0, /* x (and r) are [T][B] instead of [B][T]                 */
-    WDF_PREC_F64     = 1 << 1  /* evaluate the root solve in fp64 (config C5); I/O stays f32 */
+    WDF_PREC_F64     = 1 << 1, /* evaluate the root solve in fp64 (config C5); I/O stays f32 */
+    WDF_TP_PACK2     = 1 << 2  /* time-parallel kernels: two sequences per lane, packed v_pk_* math */
 };
 
 /* ------------------------------------------------------------------------------------

@@ -31,46 +31,55 @@ def setup(B, T, seed=0):
     return dev(x), dev(workload.clipper_theta())
 
 
-@pytest.mark.parametrize("B,T,K", [(64, 512, 4), (70, 1001, 7), (130, 2048, 16), (5, 96, 12), (3, 8, 4)])
+@pytest.mark.parametrize("pack", [False, True])
+@pytest.mark.parametrize("B,T,K", [(64, 512, 4), (70, 1001, 7), (130, 2048, 16), (5, 96, 12), (3, 8, 4), (1, 64, 2)])
 @pytest.mark.parametrize("n_up,n_down", [(1, 1), (2, 3)])
-def test_bwd_tp_matches_sequential(wb, B, T, K, n_up, n_down):
+def test_bwd_tp_matches_sequential(wb, B, T, K, n_up, n_down, pack):
     x, th = setup(B, T, seed=B + T)
     y, zs, _ = wb.clipper_fwd(x, th, FS, n_up=n_up, n_down=n_down)
     gy = dev(np.random.default_rng(B).standard_normal((T, B)) / (B * T))
     g_seq, gz_seq = wb.clipper_bwd(x, th, FS, zs, gy, n_up=n_up, n_down=n_down, want_gz0=True)
-    g_tp, gz_tp = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, n_up=n_up, n_down=n_down, want_gz0=True)
+    g_tp, gz_tp = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, n_up=n_up, n_down=n_down, want_gz0=True, pack=pack)
     assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0), (g_tp, g_seq)
     assert torch.allclose(gz_tp, gz_seq, rtol=1e-4, atol=1e-12)
-    g_tp2, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, n_up=n_up, n_down=n_down)
+    g_tp2, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, n_up=n_up, n_down=n_down, pack=pack)
     assert torch.equal(g_tp, g_tp2)                                  # deterministic
 
 
-def test_bwd_tp_per_sample_r(wb):
-    B, T, K = 70, 520, 5
+@pytest.mark.parametrize("pack", [False, True])
+def test_bwd_tp_per_sample_r(wb, pack):
+    B, T, K = 71, 520, 5
     x, th = setup(B, T, seed=3)
     r = dev(45.0e3 * np.exp(0.8 * np.sin(np.arange(T)[None, :] * 0.01 * (1 + np.arange(B)[:, None] % 5))))
     y, zs, _ = wb.clipper_fwd(x, th, FS, r=r)
     gy = dev(np.random.default_rng(1).standard_normal((T, B)) / (B * T))
     g_seq, _ = wb.clipper_bwd(x, th, FS, zs, gy, r=r)
-    g_tp, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, r=r)
+    g_tp, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, r=r, pack=pack)
     assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0)
+    # forward with the per-sample resistance channel, time-parallel (r >= 16 kOhm: W = 256 is plenty)
+    y2, _, _, st = wb.clipper_fwd_tp(x, th, FS, 2, 256, r=r, pack=pack)
+    assert wb.tp_status(st)["n_bad"] == 0
+    assert float((y2 - y).abs().max()) <= 1e-6
 
 
-@pytest.mark.parametrize("B,T,K,W", [(64, 2048, 4, 256), (70, 4096, 16, 256), (130, 1001, 3, 248), (5, 4096, 8, 512)])
-def test_fwd_tp_matches_sequential(wb, B, T, K, W):
+@pytest.mark.parametrize("pack", [False, True])
+@pytest.mark.parametrize("B,T,K,W", [(64, 2048, 4, 256), (70, 4096, 16, 256), (131, 1001, 3, 248), (5, 4096, 8, 512),
+                                     (1, 2048, 4, 256)])
+def test_fwd_tp_matches_sequential(wb, B, T, K, W, pack):
     x, th = setup(B, T, seed=B + T)
     y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
-    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, K, W, tol=1e-6, want_zT=True)
+    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, K, W, tol=1e-6, want_zT=True, pack=pack)
     s = wb.tp_status(st)
     assert s["n_bad"] == 0 and not s["fallback_ran"], s
     assert s["max_miss"] <= 1e-6
     assert float((y2 - y).abs().max()) <= 1e-6
     assert float((zs2 - zs).abs().max()) <= 2e-6
     assert float((zT2 - zT).abs().max()) <= 2e-6
-    # chunk 0 is the sequential computation itself
+    # chunk 0 is the sequential computation itself (same arithmetic when not packed)
     L = -(-T // K)
     L = -(-L // 8) * 8
-    assert torch.equal(y2[:L], y[:L])
+    if not pack:
+        assert torch.equal(y2[:L], y[:L])
 
 
 def test_fwd_tp_falls_back_when_warmup_is_too_short(wb):
@@ -83,9 +92,9 @@ def test_fwd_tp_falls_back_when_warmup_is_too_short(wb):
     theta[3] = 1.0e-6
     th = dev(theta)
     y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
-    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, 8, 64, tol=1e-6, want_zT=True)
+    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, 8, 64, tol=1e-6, want_zT=True, pack=True)
     s = wb.tp_status(st)
-    assert s["n_bad"] > 0 and s["fallback_ran"], s
+    assert s["n_bad"] > 0 and s["fallback_ran"] and s["repaired_tiles"] == 2, s
     assert torch.equal(y2, y) and torch.equal(zs2, zs) and torch.equal(zT2, zT)
 
 
@@ -105,7 +114,7 @@ def test_tp_full_size_against_oracle(wb, oracle):
     theta = workload.clipper_theta()
     x = workload.sweep_batch(B, T)
     xd, th = dev(x), dev(theta)
-    y, zs, _, st = wb.clipper_fwd_tp(xd, th, FS, K, W)
+    y, zs, _, st = wb.clipper_fwd_tp(xd, th, FS, 2 * K, W, pack=True)
     s = wb.tp_status(st)
     assert s["n_bad"] == 0, s
     pick = np.random.default_rng(5).choice(B, 16, replace=False)
@@ -113,9 +122,10 @@ def test_tp_full_size_against_oracle(wb, oracle):
     assert np.max(np.abs(y[:, torch.as_tensor(pick, device="cuda")].cpu().numpy() - ref)) < 3e-5
     tgt, _, _ = wb.clipper_fwd(xd, dev(workload.target_theta()), FS, want_stash=False)
     gy = (2.0 * (y - tgt) / y.numel()).contiguous()
-    g_tp, _ = wb.clipper_bwd_tp(xd, th, FS, zs, gy, 64)
     g_seq, _ = wb.clipper_bwd(xd, th, FS, zs, gy)
-    assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0), (g_tp, g_seq)
+    for pack in (False, True):
+        g_tp, _ = wb.clipper_bwd_tp(xd, th, FS, zs, gy, 64, pack=pack)
+        assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0), (pack, g_tp, g_seq)
 
 
 def test_fused_mse_step_matches_autograd_path(wb):
@@ -151,7 +161,7 @@ def test_fused_mse_step_matches_autograd_path(wb):
 def test_plan_time_parallel_degrades_gracefully():
     from wdf_hip import engine
     p = engine.plan_time_parallel(8192, 4096, 45.0e3, 4.7e-9, 48000.0)
-    assert p.k_fwd == 16 and p.k_bwd == 32 and 192 <= p.warmup <= 256
+    assert p.k_fwd == 8 and p.k_bwd == 32 and 184 <= p.warmup <= 256
     slow = engine.plan_time_parallel(8192, 4096, 45.0e3, 1.0e-6, 48000.0)   # memory >> T/2: no forward chunks
     assert slow.k_fwd == 1 and slow.k_bwd == 32
     big = engine.plan_time_parallel(1 << 20, 4096, 45.0e3, 4.7e-9, 48000.0)  # plenty of waves already

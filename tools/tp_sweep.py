@@ -23,12 +23,15 @@ def timeit(fn, n=10):
 y, zs, _ = wb.clipper_fwd(x, th, fs)
 gy = (2.0 * (y - tgt) / y.numel()).contiguous()
 print("seq fwd ms", timeit(lambda: wb.clipper_fwd(x, th, fs)), " seq bwd ms", timeit(lambda: wb.clipper_bwd(x, th, fs, zs, gy)))
-for K in (4, 8, 16, 32, 64):
-    ws = torch.empty((wb.lib().wdf_clipper_bwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda")
-    g = torch.empty(4, device="cuda")
-    print(f"bwd_tp K={K}: {timeit(lambda: wb.clipper_bwd_tp(x, th, fs, zs, gy, K, ws=ws, gtheta=g)):.3f} ms")
-for K, W in ((4, 256), (8, 256), (16, 256), (16, 192), (32, 256), (32, 192), (64, 192), (64, 256), (32, 128)):
-    ws = torch.empty((wb.lib().wdf_clipper_fwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda")
-    st = torch.empty(4, dtype=torch.int32, device="cuda")
-    ms = timeit(lambda: wb.clipper_fwd_tp(x, th, fs, K, W, ws=ws, status=st))
-    print(f"fwd_tp K={K} W={W}: {ms:.3f} ms  status {wb.tp_status(st)}")
+for pack in (False, True):
+    for K in (8, 16, 32, 64, 128):
+        ws = torch.empty((wb.lib().wdf_clipper_bwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda")
+        g = torch.empty(4, device="cuda")
+        ms = timeit(lambda: wb.clipper_bwd_tp(x, th, fs, zs, gy, K, ws=ws, gtheta=g, pack=pack))
+        print(f"bwd_tp pack={pack} K={K}: {ms:.3f} ms")
+for pack in (False, True):
+    for K, W in ((8, 192), (16, 192), (16, 64), (32, 192), (32, 64), (64, 192), (64, 64), (128, 64)):
+        ws = torch.empty((wb.lib().wdf_clipper_fwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda")
+        st = torch.empty(4, dtype=torch.int32, device="cuda")
+        ms = timeit(lambda: wb.clipper_fwd_tp(x, th, fs, K, W, ws=ws, status=st, pack=pack))
+        print(f"fwd_tp pack={pack} K={K} W={W}: {ms:.3f} ms  n_bad {wb.tp_status(st)['n_bad']} miss {wb.tp_status(st)['max_miss']:.1e}")
