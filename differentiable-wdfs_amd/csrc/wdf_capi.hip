@@ -9,6 +9,7 @@
 
 #include "../../include/wdf_hip.h"
 #include "wdf_clipper.h"
+#include "wdf_mlp.h"
 #include "wdf_statespace.h"
 
 namespace {
@@ -373,6 +374,68 @@ int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta, f
     hipLaunchKernelGGL(wdf::clipper_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)wsd,
                        nparts, theta, fs, r != nullptr ? 1 : 0, gtheta, accumulate, target ? sse : nullptr);
     return check_launch("wdf_clipper_grad_reduce");
+}
+
+int wdf_mlp_weight_count(int hidden, int n_tanh_layers)
+{
+    if (hidden < 1 || n_tanh_layers < 1) return 0;
+    return 2 * hidden + hidden + (n_tanh_layers - 1) * (hidden * hidden + hidden) + hidden + 1;
+}
+
+#define WDF_MLP_CASE(H_, NL_, DYN_, KERNEL, ...)                                                              \
+    if (hidden == H_ && n_tanh_layers == NL_ && dyn == DYN_)                                                  \
+        hipLaunchKernelGGL((wdf::KERNEL<H_, NL_, DYN_>), dim3(grid), dim3(64), 0, (hipStream_t)stream, __VA_ARGS__);
+#define WDF_MLP_DISPATCH(KERNEL, ...)                                                                         \
+    WDF_MLP_CASE(4, 3, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(4, 3, true, KERNEL, __VA_ARGS__)              \
+    WDF_MLP_CASE(8, 3, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(8, 3, true, KERNEL, __VA_ARGS__)              \
+    WDF_MLP_CASE(16, 3, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(16, 3, true, KERNEL, __VA_ARGS__)            \
+    WDF_MLP_CASE(4, 5, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(4, 5, true, KERNEL, __VA_ARGS__)              \
+    WDF_MLP_CASE(8, 5, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(8, 5, true, KERNEL, __VA_ARGS__)
+
+static int mlp_check(const float* x, const float* theta2, const float* w, int hidden, int n_tanh_layers, float fs,
+                     int64_t B, int64_t T, int flags)
+{
+    if (!x || !theta2 || !w) return fail(WDF_EINVAL, "null x/theta2/w");
+    if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "B and T must be positive");
+    if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
+    if (flags != 0) return fail(WDF_EINVAL, "MLP-root kernels take flags = 0");
+    const bool ok = ((hidden == 4 || hidden == 8 || hidden == 16) && n_tanh_layers == 3) ||
+                    ((hidden == 4 || hidden == 8) && n_tanh_layers == 5);
+    if (!ok)
+        return fail(WDF_EUNSUPPORTED, "MLP root: hidden in {4,8,16} with 3 tanh layers or {4,8} with 5 (got %dx%d)",
+                    hidden, n_tanh_layers);
+    return WDF_OK;
+}
+
+int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                        int n_tanh_layers, float fs, float* y, float* zstash, const float* z0, float* zT, int64_t B,
+                        int64_t T, int flags, void* stream)
+{
+    int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, flags);
+    if (rc) return rc;
+    if (!y) return fail(WDF_EINVAL, "null y");
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    const bool dyn = r != nullptr;
+    WDF_MLP_DISPATCH(clipper_mlp_fwd_kernel, x, r, theta2, w, fs, y, zstash, z0, zT, B, T)
+    return check_launch("wdf_clipper_mlp_fwd");
+}
+
+int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                        int n_tanh_layers, float fs, const float* zstash, const float* gy, float* gb, float* ain,
+                        float* lrin, void* ws, float* gtheta2, int64_t B, int64_t T, int flags, void* stream)
+{
+    int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, flags);
+    if (rc) return rc;
+    if (!zstash || !gy || !gb || !ain || !ws || !gtheta2) return fail(WDF_EINVAL, "null zstash/gy/gb/ain/ws/gtheta2");
+    if (r && !lrin) return fail(WDF_EINVAL, "per-sample resistance needs lrin");
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    const bool dyn = r != nullptr;
+    WDF_MLP_DISPATCH(clipper_mlp_bwd_kernel, x, r, theta2, w, fs, zstash, gy, gb, ain, lrin, (double*)ws, B, T)
+    rc = check_launch("wdf_clipper_mlp_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wdf::clipper_mlp_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)ws, (int)grid, theta2, fs, dyn ? 1 : 0, gtheta2);
+    return check_launch("wdf_clipper_mlp_grad_reduce");
 }
 
 int wdf_omega_f32(const float* x, float* w, int32_t* iters, int64_t n, void* stream)

@@ -1,0 +1,251 @@
+// wdf_mlp.h -- diode clipper with the tanh-MLP root of clipper_pot.py, gfx950.
+//
+// Circuit (clipper_pot.py:94-127):  P1 = Parallel(ResistiveVoltageSource(R or per-sample r),
+// Capacitor(C, fs)); the root is DenseRootModel (layers.py:42-82) fed (a, log P1.R), and the
+// wave sent back down is -MLP(a, log R) (clipper_pot.py:119-121).  Per step:
+//     b_diff = z - x ; b_temp = -p b_diff ; a = z + b_temp          Parallel.reflected  tf_wdf.py:185-192
+//     b = -MLP(a, log Rp)                                           layers.py:76-82, DenseLayer :38-39
+//     z' = b + b_temp ; y = (z' + z)/2                              tf_wdf.py:179-183, :8-10
+// One lane per sequence; the network is evaluated per lane in VGPRs with the weights read
+// through the scalar cache (wave-uniform addresses -> s_load + SGPR operands), so the 609
+// weights of a 2x16 net cost no VGPRs and no LDS.  Networks: 2 -> H -> ... -> H -> 1 with NL
+// tanh layers, H in {4, 8, 16}, NL in {3, 5}: the "2xH" and "4xH" families of
+// wdf_py/diode_clipper/models (n_layers + 1 hidden layers, diode_pretraining.py:113-126).
+// Weight layout (the JSON order, layers.py:31-36): per layer kernel[in][out] row-major, then
+// bias[out].
+//
+// Reverse sweep: the per-lane kernel does the scalar adjoint recurrence and the input-
+// Jacobian of the network (d out / d a, d out / d log R); it writes g_b[n] = dL/d b[n] and the
+// network inputs (a[n], log R[n]).  The weight gradient is then an ordinary dense problem,
+// dL/dW = -sum_n g_b[n] d MLP(a[n], lr[n]) / dW over B*T independent samples, which the host
+// runs as plain GEMMs (torch -> hipBLASLt); doing it per lane would need 609 accumulators
+// per lane.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wdf_clipper.h"
+
+namespace wdf {
+
+__device__ __forceinline__ float tanh_fast(float x)
+{
+    const float t = __builtin_amdgcn_exp2f(-2.0f * kLog2e * fabsf(x));     // exp(-2|x|) in (0, 1]
+    const float r = (1.0f - t) * fast_rcp(1.0f + t);
+    return copysignf(r, x);
+}
+
+template <int H, int NL>
+struct Mlp {
+    static constexpr int kW0 = 0;                       // kernel0 [2][H]
+    static constexpr int kB0 = 2 * H;                   // bias0 [H]
+    static constexpr int kMid = 3 * H;                  // then (NL-1) x { kernel [H][H], bias [H] }
+    static constexpr int kMidStride = H * H + H;
+    static constexpr int kWo = kMid + (NL - 1) * kMidStride;   // kernel_out [H][1]
+    static constexpr int kBo = kWo + H;                 // bias_out [1]
+    static constexpr int kCount = kBo + 1;
+
+    // out = MLP(a, lr); act[l][i] keeps the tanh outputs of layer l
+    static __device__ __forceinline__ float fwd(const float* __restrict__ w, float a, float lr, float (&act)[NL][H])
+    {
+#pragma unroll
+        for (int o = 0; o < H; ++o)
+            act[0][o] = tanh_fast(fmaf(lr, w[kW0 + H + o], fmaf(a, w[kW0 + o], w[kB0 + o])));
+#pragma unroll
+        for (int l = 1; l < NL; ++l) {
+            const float* __restrict__ k = w + kMid + (l - 1) * kMidStride;
+#pragma unroll
+            for (int o = 0; o < H; ++o) {
+                float acc = k[H * H + o];
+#pragma unroll
+                for (int i = 0; i < H; ++i) acc = fmaf(act[l - 1][i], k[i * H + o], acc);
+                act[l][o] = tanh_fast(acc);
+            }
+        }
+        float out = w[kBo];
+#pragma unroll
+        for (int i = 0; i < H; ++i) out = fmaf(act[NL - 1][i], w[kWo + i], out);
+        return out;
+    }
+
+    // d out / d a and d out / d lr from the kept activations
+    static __device__ __forceinline__ void grad_in(const float* __restrict__ w, const float (&act)[NL][H], float& da,
+                                                   float& dlr)
+    {
+        float d[H], dn[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) d[i] = w[kWo + i] * fmaf(-act[NL - 1][i], act[NL - 1][i], 1.0f);
+#pragma unroll
+        for (int l = NL - 1; l >= 1; --l) {
+            const float* __restrict__ k = w + kMid + (l - 1) * kMidStride;
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < H; ++i) acc = fmaf(k[j * H + i], d[i], acc);
+                dn[j] = acc * fmaf(-act[l - 1][j], act[l - 1][j], 1.0f);
+            }
+#pragma unroll
+            for (int j = 0; j < H; ++j) d[j] = dn[j];
+        }
+        da = 0.0f;
+        dlr = 0.0f;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            da = fmaf(w[kW0 + i], d[i], da);
+            dlr = fmaf(w[kW0 + H + i], d[i], dlr);
+        }
+    }
+};
+
+struct MlpClipConsts {
+    float G2;         // 2 C fs
+    float p, Rp, lr;  // static R: G1/(G1+G2), 1/(G1+G2), log Rp
+};
+
+__device__ __forceinline__ MlpClipConsts mlp_load_consts(const float* __restrict__ theta2, float fs)
+{
+    MlpClipConsts c;
+    const float R = theta2[0], C = theta2[1];
+    c.G2 = C * (2.0f * fs);
+    const float G1 = 1.0f / R, G = G1 + c.G2;
+    c.Rp = 1.0f / G;
+    c.p = G1 / G;
+    c.lr = logf(c.Rp);
+    return c;
+}
+
+template <bool DYN_R>
+__device__ __forceinline__ void mlp_step_coeffs(const MlpClipConsts& c, float rin, float& p, float& Rp, float& lr)
+{
+    if constexpr (DYN_R) {                    // set_resistance + calc_impedance every step (clipper_pot.py:116-117)
+        const float G1 = fast_rcp(rin);
+        Rp = fast_rcp(G1 + c.G2);
+        p = G1 * Rp;
+        lr = fast_log(Rp);                    // tf.math.log(P1.R), clipper_pot.py:119
+    } else {
+        p = c.p; Rp = c.Rp; lr = c.lr;
+    }
+}
+
+// x, r: [B][T]; y, zstash: [T][B]; theta2 = {R, C}; w: flat weights (Mlp<H,NL>::kCount floats)
+template <int H, int NL, bool DYN_R>
+__global__ __launch_bounds__(64) void clipper_mlp_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
+    const float* __restrict__ w, float fs, float* __restrict__ y, float* __restrict__ zstash,
+    const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const MlpClipConsts c = mlp_load_consts(theta2, fs);
+    float z = z0 ? z0[b] : 0.0f;                           // reset(): clipper_pot.py:110-111
+    float* __restrict__ yp = y + b;
+    float* __restrict__ zp = zstash ? zstash + b : nullptr;
+    const float* __restrict__ xp = x + b * T;
+    const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
+    float act[NL][H];
+    for (int64_t t = 0; t < T; ++t) {
+        float p, Rp, lr;
+        mlp_step_coeffs<DYN_R>(c, DYN_R ? rp[t] : 1.0f, p, Rp, lr);
+        const float b_diff = z - xp[t];
+        const float b_temp = -p * b_diff;
+        const float a = z + b_temp;
+        const float broot = -Mlp<H, NL>::fwd(w, a, lr, act);
+        const float zn = broot + b_temp;
+        if (zp) { *zp = z; zp += B; }
+        *yp = 0.5f * (zn + z);
+        yp += B;
+        z = zn;
+    }
+    if (zT) zT[b] = z;
+}
+
+// Reverse sweep.  Outputs: gb [T][B] = dL/d b_root, ain [T][B] = a, lrin [T][B] = log Rp (only
+// when DYN_R), and per-wave partials ws: double[gridDim.x][4] = {S_lr, 0, S_P, 0} in the
+// clipper convention (static R: S_P = sum g_p, S_lr = sum g_lr; per-sample R:
+// S_P = sum Rp (g_p p + g_lr)).
+template <int H, int NL, bool DYN_R>
+__global__ __launch_bounds__(64) void clipper_mlp_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
+    const float* __restrict__ w, float fs, const float* __restrict__ zstash, const float* __restrict__ gy,
+    float* __restrict__ gb, float* __restrict__ ain, float* __restrict__ lrin, double* __restrict__ ws,
+    int64_t B, int64_t T)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    const MlpClipConsts c = mlp_load_consts(theta2, fs);
+    const float* __restrict__ xp = x + b * T;
+    const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
+    double dLr = 0.0, dP = 0.0;
+    float gz = 0.0f;
+    float act[NL][H];
+    for (int64_t t = T - 1; t >= 0; --t) {
+        float p, Rp, lr;
+        mlp_step_coeffs<DYN_R>(c, DYN_R ? rp[t] : 1.0f, p, Rp, lr);
+        const float z = zstash[t * B + b];
+        const float b_diff = z - xp[t];
+        const float a = fmaf(-p, b_diff, z);
+        (void)Mlp<H, NL>::fwd(w, a, lr, act);
+        float da, dlr;
+        Mlp<H, NL>::grad_in(w, act, da, dlr);
+        const float Da = -da, Dlr = -dlr;                    // b_root = -MLP
+        const float g = gy[t * B + b];
+        const float g_b2n = fmaf(0.5f, g, gz);
+        const float g_a = g_b2n * Da;
+        const float g_lr = g_b2n * Dlr;
+        const float g_bt = g_b2n + g_a;
+        const float g_p = -g_bt * b_diff;
+        gb[t * B + b] = g_b2n;
+        ain[t * B + b] = a;
+        if constexpr (DYN_R) {
+            lrin[t * B + b] = lr;
+            dP += (double)(Rp * fmaf(g_p, p, g_lr));
+        } else {
+            dP += (double)g_p;
+            dLr += (double)g_lr;
+        }
+        gz = fmaf(-p, g_bt, fmaf(0.5f, g, g_a));
+    }
+    if (!live) { dLr = dP = 0.0; }
+    dLr = wave_sum(dLr); dP = wave_sum(dP);
+    if (threadIdx.x == 0) {
+        double* o = ws + (int64_t)blockIdx.x * 4;
+        o[0] = dLr; o[1] = 0.0; o[2] = dP; o[3] = 0.0;
+    }
+}
+
+// gtheta2 = dL/d{R, C}:  static R: lr = log Rp, so with S_L := S_lr the clipper formulas apply
+//   dR = Rp G1^2 (S_lr - S_P (1-p)) ; dC = -2 fs Rp (S_P p + S_lr);  per-sample R: dR = 0, dC = -2 fs S_P
+__global__ __launch_bounds__(256) void clipper_mlp_grad_reduce_kernel(const double* __restrict__ ws, int nparts,
+                                                                      const float* __restrict__ theta2, float fs,
+                                                                      int dyn_r, float* __restrict__ gtheta2)
+{
+    __shared__ double sh[256][2];
+    double s0 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) { s0 += ws[(int64_t)i * 4 + 0]; s2 += ws[(int64_t)i * 4 + 2]; }
+    sh[threadIdx.x][0] = s0; sh[threadIdx.x][1] = s2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sh[threadIdx.x][0] += sh[threadIdx.x + off][0];
+            sh[threadIdx.x][1] += sh[threadIdx.x + off][1];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double SL = sh[0][0], SP = sh[0][1];
+        const double R = theta2[0], C = theta2[1];
+        const double G1 = 1.0 / R, G2 = C * (2.0 * (double)fs), Rp = 1.0 / (G1 + G2), p = G1 * Rp;
+        if (dyn_r) {
+            gtheta2[0] = 0.0f;
+            gtheta2[1] = (float)(-2.0 * (double)fs * SP);
+        } else {
+            gtheta2[0] = (float)(Rp * G1 * G1 * (SL - SP * (1.0 - p)));
+            gtheta2[1] = (float)(-2.0 * (double)fs * Rp * (SP * p + SL));
+        }
+    }
+}
+
+}  // namespace wdf

@@ -58,6 +58,12 @@ def lib():
     L.wdf_clipper_bwd_mse_tp.restype = ci
     L.wdf_clipper_bwd_mse_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, cf, vp, fp, fp, fp, ci, i64, i64, ci,
                                          ci, vp]
+    L.wdf_mlp_weight_count.restype = ci
+    L.wdf_mlp_weight_count.argtypes = [ci, ci]
+    L.wdf_clipper_mlp_fwd.restype = ci
+    L.wdf_clipper_mlp_fwd.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, i64, i64, ci, vp]
+    L.wdf_clipper_mlp_bwd.restype = ci
+    L.wdf_clipper_mlp_bwd.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, fp, vp, fp, i64, i64, ci, vp]
     L.wdf_ss_ncoef.restype = ci
     L.wdf_ss_ncoef.argtypes = [ci, ci]
     L.wdf_ss_fwd.restype = ci
@@ -86,6 +92,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_fwd", "wdf_clipper_bwd", "wdf_clipper_bwd_ws_bytes",
     "wdf_clipper_tp_chunks", "wdf_clipper_fwd_tp_ws_bytes", "wdf_clipper_fwd_tp",
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
+    "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
     "wdf_omega_f32", "wdf_diode_pair_f32",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy",
@@ -253,6 +260,49 @@ def clipper_bwd_mse_tp(x, theta, fs, zstash, y, target, gscale, n_chunks, r=None
                                       WDF_TP_PACK2 if pack else 0, _stream())
     _check(rc, "wdf_clipper_bwd_mse_tp")
     return gtheta, sse
+
+
+def clipper_mlp_fwd(x, theta2, w, hidden, n_tanh, fs, r=None, want_stash=True, z0=None, want_zT=False):
+    """MLP-root clipper forward.  x [B,T], theta2 = {R, C}, w flat weights.  -> y [T,B], zstash, zT."""
+    require_gpu()
+    x = _f32_dev(x, "x")
+    r = _f32_dev(r, "r")
+    theta2 = _f32_dev(theta2, "theta2")
+    w = _f32_dev(w, "w")
+    z0 = _f32_dev(z0, "z0")
+    n = lib().wdf_mlp_weight_count(int(hidden), int(n_tanh))
+    if w.numel() != n:
+        raise WdfHipError(f"a {n_tanh - 1}x{hidden} network has {n} weights, got {w.numel()}")
+    B, T = x.shape
+    y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zs = torch.empty((T, B), dtype=torch.float32, device=x.device) if want_stash else None
+    zT = torch.empty((B,), dtype=torch.float32, device=x.device) if want_zT else None
+    rc = lib().wdf_clipper_mlp_fwd(_ptr(x), _ptr(r), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh), float(fs),
+                                   _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, 0, _stream())
+    _check(rc, "wdf_clipper_mlp_fwd")
+    return y, zs, zT
+
+
+def clipper_mlp_bwd(x, theta2, w, hidden, n_tanh, fs, zstash, gy, r=None):
+    """-> gtheta2 [2], gb [T,B], ain [T,B], lrin [T,B] | None (see include/wdf_hip.h)."""
+    require_gpu()
+    x = _f32_dev(x, "x")
+    r = _f32_dev(r, "r")
+    theta2 = _f32_dev(theta2, "theta2")
+    w = _f32_dev(w, "w")
+    zstash = _f32_dev(zstash, "zstash")
+    gy = _f32_dev(gy, "gy")
+    B, T = x.shape
+    gb = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    ain = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    lrin = torch.empty((T, B), dtype=torch.float32, device=x.device) if r is not None else None
+    ws = torch.empty((lib().wdf_clipper_bwd_ws_bytes(B),), dtype=torch.uint8, device=x.device)
+    gth = torch.empty((2,), dtype=torch.float32, device=x.device)
+    rc = lib().wdf_clipper_mlp_bwd(_ptr(x), _ptr(r), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh), float(fs),
+                                   _ptr(zstash), _ptr(gy), _ptr(gb), _ptr(ain), _ptr(lrin), _ptr(ws), _ptr(gth),
+                                   B, T, 0, _stream())
+    _check(rc, "wdf_clipper_mlp_bwd")
+    return gth, gb, ain, lrin
 
 
 ROOT_NONE, ROOT_DIODE_PAIR = 0, 2

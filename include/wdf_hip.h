@@ -130,6 +130,33 @@ int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta,
                        int64_t B, int64_t T, int n_chunks, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Diode clipper with the tanh-MLP root of clipper_pot.py (csrc/wdf_mlp.h).  Replaces, per call,
+ * ClipperModel.forward's loop (clipper_pot.py:103-127): P1 = Parallel(Vs, C), model_in =
+ * (P1.reflected(), log P1.R) (:119), P1.incident(-model.reflected()) (:121) with
+ * DenseRootModel / DenseLayer (layers.py:38-39,72-82).
+ *
+ * Network 2 -> hidden -> ... -> hidden -> 1 with n_tanh_layers tanh layers and a linear output;
+ * hidden in {4, 8, 16}, n_tanh_layers in {3, 5} (the 2xH / 4xH model families).
+ * w       device float[wdf_mlp_weight_count()]: per layer kernel[in][out] then bias[out]
+ *         (the JSON "weights" order, layers.py:31-36)
+ * theta2  device float[2] = {R, C}; r: optional [B][T] per-sample resistance (clipper_pot.py:116)
+ * bwd:    gy [T][B] -> gtheta2[2] = dL/d{R, C} (R entry 0 when r != NULL), and for the dense
+ *         weight-gradient pass on the host side: gb [T][B] = dL/d(root output b = -MLP),
+ *         ain [T][B] = a, lrin [T][B] = log P1.R (written only when r != NULL).
+ *         dL/dw = -sum_n gb[n] dMLP(ain[n], lrin[n])/dw  is a plain batched-MLP backward.
+ * ---------------------------------------------------------------------------------- */
+int wdf_mlp_weight_count(int hidden, int n_tanh_layers);
+int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, const float* w,
+                        int hidden, int n_tanh_layers, float fs,
+                        float* y, float* zstash, const float* z0, float* zT,
+                        int64_t B, int64_t T, int flags, void* stream);
+int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, const float* w,
+                        int hidden, int n_tanh_layers, float fs,
+                        const float* zstash, const float* gy,
+                        float* gb, float* ain, float* lrin, void* ws, float* gtheta2,
+                        int64_t B, int64_t T, int flags, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Generic tree + one root, as a state-space recursion (csrc/wdf_statespace.h):
  *     a = ca.z + da.x ;  b = root(a) ;  z' = A z + Bx x + E b ;  y = cy.z + dy.x + fy b
  * Replaces, per call, the whole per-sample loop of lpf.py:39-46 / voltage_divider.py:35-42 /
