@@ -30,6 +30,7 @@ import torch
 
 from wdf_hip import compat_tf as tf
 from wdf_hip import lowering as _lowering
+from wdf_hip import trace as _trace
 
 tf.get_logger().setLevel("WARN")
 
@@ -51,7 +52,7 @@ class IdealVoltageSource(_Element):
     '''Ideal voltage source ROOT: b = -a + 2 Vs  (tf_wdf.py:13-28).'''
 
     def set_voltage(self, voltage):
-        self.Vs = voltage
+        self.Vs = _trace.bind_voltage(voltage)       # a sample of a sequence tensor starts/continues a recorded loop
 
     def incident(self, x):
         self.a = x
@@ -76,10 +77,10 @@ class ResistiveVoltageSource(_Element):
         self.a = tf.zeros(1)
 
     def set_voltage(self, voltage):
-        self.Vs = voltage
+        self.Vs = _trace.bind_voltage(voltage)
 
     def set_resistance(self, resistance):
-        self.R = resistance
+        self.R = _trace.bind_resistance(self, resistance)
 
     def incident(self, x):
         self.a = x
@@ -138,7 +139,7 @@ class Capacitor(_Element):
         self.z = self.a
 
     def reflected(self):
-        self.b = self.z
+        self.b = _trace.state(self)      # = self.z (as the step's state symbol while a loop is recorded)
         return self.b
 
 

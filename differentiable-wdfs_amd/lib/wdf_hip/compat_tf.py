@@ -45,6 +45,16 @@ class Tensor(torch.Tensor):
     def __float__(self):
         return float(self.detach().as_subclass(torch.Tensor))
 
+    def __getitem__(self, idx):
+        out = super().__getitem__(idx)
+        # `input[:, i]` / `input[:, i, 0:1]` (lpf.py:40, clipper_pot.py:114-116): remember which
+        # sample of which sequence tensor this is, so the loop recorder (wdf_hip.trace) can
+        # recognise the script's time loop.  The result is still the real slice.
+        if (isinstance(idx, tuple) and len(idx) >= 2 and isinstance(idx[0], slice) and idx[0] == slice(None)
+                and isinstance(idx[1], int) and isinstance(out, torch.Tensor)):
+            out._wdf_src = (self, idx[1], tuple(idx[2:]))
+        return out
+
     def __format__(self, spec):
         if self.numel() == 1:
             return format(float(self.detach()), spec)
@@ -339,6 +349,8 @@ class TensorArray:
         if index >= len(self._items):
             self._items.extend([None] * (index + 1 - len(self._items)))
         self._items[index] = value
+        if hasattr(value, "__wdf_stack__"):          # a recorded wave: this step's output
+            value.rec.note_output(value)
         return self
 
     def read(self, index):

@@ -143,7 +143,9 @@ class Circuit:
         ns, ni = self.ns, self.ni
         K = ns + ni + 1
         eye = torch.eye(K, dtype=torch.float64)
+        from . import trace
         saved = _Saved(self.elements + [self.root])
+        rec, trace._current = trace._current, None      # probing is never part of a recorded loop
         try:
             for s, cap in enumerate(self.caps):
                 cap.z = eye[s]
@@ -157,6 +159,7 @@ class Circuit:
             r_port = self.top.R
         finally:
             saved.restore()
+            trace._current = rec
         up, yv = up.as_subclass(torch.Tensor), yv.as_subclass(torch.Tensor)
         Z = torch.stack([z.as_subclass(torch.Tensor) for z in znew]) if ns else torch.zeros(0, K, dtype=torch.float64)
         A, Bx, E = Z[:, :ns], Z[:, ns:ns + ni], Z[:, K - 1]
