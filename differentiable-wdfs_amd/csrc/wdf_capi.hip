@@ -390,7 +390,9 @@ int wdf_mlp_weight_count(int hidden, int n_tanh_layers)
     WDF_MLP_CASE(8, 3, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(8, 3, true, KERNEL, __VA_ARGS__)              \
     WDF_MLP_CASE(16, 3, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(16, 3, true, KERNEL, __VA_ARGS__)            \
     WDF_MLP_CASE(4, 5, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(4, 5, true, KERNEL, __VA_ARGS__)              \
-    WDF_MLP_CASE(8, 5, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(8, 5, true, KERNEL, __VA_ARGS__)
+    WDF_MLP_CASE(8, 5, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(8, 5, true, KERNEL, __VA_ARGS__)              \
+    WDF_MLP_CASE(4, 4, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(4, 4, true, KERNEL, __VA_ARGS__)              \
+    WDF_MLP_CASE(8, 4, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(8, 4, true, KERNEL, __VA_ARGS__)
 
 static int mlp_check(const float* x, const float* theta2, const float* w, int hidden, int n_tanh_layers, float fs,
                      int64_t B, int64_t T, int flags)
@@ -400,9 +402,10 @@ static int mlp_check(const float* x, const float* theta2, const float* w, int hi
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
     if (flags != 0) return fail(WDF_EINVAL, "MLP-root kernels take flags = 0");
     const bool ok = ((hidden == 4 || hidden == 8 || hidden == 16) && n_tanh_layers == 3) ||
-                    ((hidden == 4 || hidden == 8) && n_tanh_layers == 5);
+                    ((hidden == 4 || hidden == 8) && (n_tanh_layers == 4 || n_tanh_layers == 5));
     if (!ok)
-        return fail(WDF_EUNSUPPORTED, "MLP root: hidden in {4,8,16} with 3 tanh layers or {4,8} with 5 (got %dx%d)",
+        return fail(WDF_EUNSUPPORTED,
+                    "MLP root: hidden in {4,8,16} with 3 tanh layers or {4,8} with 4 or 5 (got width %d, %d tanh layers)",
                     hidden, n_tanh_layers);
     return WDF_OK;
 }

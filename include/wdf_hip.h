@@ -136,7 +136,8 @@ int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta,
  * DenseRootModel / DenseLayer (layers.py:38-39,72-82).
  *
  * Network 2 -> hidden -> ... -> hidden -> 1 with n_tanh_layers tanh layers and a linear output;
- * hidden in {4, 8, 16}, n_tanh_layers in {3, 5} (the 2xH / 4xH model families).
+ * hidden in {4, 8, 16} with n_tanh_layers = 3, or hidden in {4, 8} with 4 or 5 (every
+ * architecture among the reference's committed model files).
  * w       device float[wdf_mlp_weight_count()]: per layer kernel[in][out] then bias[out]
  *         (the JSON "weights" order, layers.py:31-36)
  * theta2  device float[2] = {R, C}; r: optional [B][T] per-sample resistance (clipper_pot.py:116)
