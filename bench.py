@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sequential", action="store_true", help="one lane per sequence, no time-parallel chunks")
+    ap.add_argument("--x-batch-major", action="store_true",
+                    help="hand the kernels x as [B,T] (the reference scripts' layout) instead of the engine's "
+                         "resident time-major copy")
     args = ap.parse_args()
 
     world, rank, local = wdist.init()
@@ -88,14 +91,18 @@ def main():
     b0, b1 = wdist.shard_range(Bg, rank, world)
 
     # ---- resident inputs ---------------------------------------------------------------
-    x = torch.as_tensor(workload.sweep_batch(Bg, T, b0=b0, b1=b1), device=dev)
+    x = torch.as_tensor(workload.sweep_batch(Bg, T, b0=b0, b1=b1), device=dev)        # [B,T] as the scripts hold it
+    tm = not args.x_batch_major
+    xk = x.t().contiguous() if tm else x          # one-off: the engine keeps its training inputs resident time-major
     th_host = workload.clipper_theta()
     theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
     theta_star = torch.tensor(workload.target_theta(), dtype=torch.float32, device=dev)
     target, _, _ = binding.clipper_fwd(x, theta_star, fs, want_stash=False)
     n_global = float(Bg * T)
-    tp = None if args.sequential else engine.plan_time_parallel(B, T, th_host[2], th_host[3], fs)
-    stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global)
+    tp = None if args.sequential else engine.plan_time_parallel(B, T, th_host[2], th_host[3], fs, time_major=tm)
+    if tp is not None:                      # part of the untimed set-up: pick chunk counts on this box
+        tp = engine.autotune_time_parallel(theta, xk, target, fs, tp, time_major=tm)
+    stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global, time_major=tm)
 
     ev = [binding.Event() for _ in range(4)]
     t_fwd, t_bwd = [], []
@@ -105,11 +112,11 @@ def main():
         # then ONE fused all-reduce of [SSE, grads] (no-op on 1 GPU)
         if timed:
             ev[0].record()
-        stepper.forward(theta, x)
+        stepper.forward(theta, xk)
         if timed:
             ev[1].record()
             ev[2].record()
-        sse, gtheta = stepper.backward(theta, x, target)
+        sse, gtheta = stepper.backward(theta, xk, target)
         if timed:
             ev[3].record()
         buf = stepper.out                              # [SSE, grads]: the kernels wrote it in place
@@ -157,6 +164,8 @@ def main():
                                    f"{B} sequences x {T} samples @ {int(fs)} Hz per GPU (BASELINE configs[2])",
                        "global_batch": Bg, "seq_len": T, "parallelism": f"dp{world}",
                        "loss": float(loss) / n_global, "grad": [float(g) for g in grad],
+                       "x_layout": "time-major [T,B] resident copy (one-off transpose at data load, outside the timed "
+                                   "region)" if tm else "batch-major [B,T] as the reference scripts hold it",
                        "time_parallel": None if tp is None else
                        {"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup, "verify_tol": tp.tol,
                         "bwd_chunks": tp.k_bwd, "verify_status": tp_stat}},

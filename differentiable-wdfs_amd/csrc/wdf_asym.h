@@ -1,0 +1,187 @@
+// wdf_asym.h -- diode clipper with two DIFFERENT antiparallel diodes (BASELINE config 5):
+// fp64 Newton on the exact Shockley pair versus the fp32 Wright-omega closed form.
+//
+// Tree as in wdf_clipper.h (P1 = Parallel(ResistiveVoltageSource(R), Capacitor(C, fs))).
+// Root: up-diode (Is1, V1 = n1 Vt) conducts for v > 0, down-diode (Is2, V2) for v < 0:
+//     i(v) = Is1 (exp(v/V1) - 1) - Is2 (exp(-v/V2) - 1),   a = v + Rp i,  b = v - Rp i.
+// The reference has no such element (its pairs are N_up/N_down copies of ONE diode,
+// diode_pretraining.py:46-47; chowdsp's DiodeT/DiodePairT are absent), so there is nothing
+// to pin parity against: the oracle is an fp64 safeguarded Newton (oracle/wdf_oracle.c) and
+// mpmath in the tests.
+//
+//  NEWTON (fp64): solve v + Rp i(v) - a = 0 per lane, started from the omega closed form,
+//      iterated until EVERY lane of the wave meets |dv| <= tol (|v| + V) -- the wavefront
+//      ballot is the loop condition, so a wave stops as soon as its slowest sequence has
+//      converged -- or max_iter is reached.
+//  OMEGA (fp32): the two-diode generalisation of Werner eqn 39 (Toms917DiodePair.h:51-59):
+//      b = a - 2 lam (Vf w(log(Rp Isf/Vf) + lam a/Vf) - Vr w(log(Rp Isr/Vr) - lam a/Vr)),
+//      f = the diode that conducts for this sign of a, r = the other.  Like eqn 39 it neglects
+//      the reverse diode's saturation current in the forward branch (error ~ Rp Is_r).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wdf_omega.h"
+
+namespace wdf {
+
+struct AsymConsts {
+    float p, Rp;
+    float Is1, V1, Is2, V2;
+    float l1, l2;          // log(Rp Is1 / V1), log(Rp Is2 / V2)
+};
+
+__device__ __forceinline__ AsymConsts asym_load(const float* __restrict__ th, float fs)
+{
+    AsymConsts c;
+    c.Is1 = th[0]; c.V1 = th[1]; c.Is2 = th[2]; c.V2 = th[3];
+    const float R = th[4], C = th[5];
+    const float G1 = 1.0f / R, G2 = C * (2.0f * fs), G = G1 + G2;
+    c.Rp = 1.0f / G;
+    c.p = G1 / G;
+    c.l1 = logf(c.Rp * c.Is1 / c.V1);
+    c.l2 = logf(c.Rp * c.Is2 / c.V2);
+    return c;
+}
+
+__device__ __forceinline__ float asym_omega_root(const AsymConsts& c, float a)
+{
+    const float lam = vsign(a);
+    const float aa = fabsf(a);
+    const bool pos = a >= 0.0f;
+    const float Vf = pos ? c.V1 : c.V2, Vr = pos ? c.V2 : c.V1;
+    const float lf = pos ? c.l1 : c.l2, lr = pos ? c.l2 : c.l1;
+    const float wf = wright_omega(fmaf(aa, fast_rcp(Vf), lf));
+    const float wr = wright_omega(fmaf(-aa, fast_rcp(Vr), lr));
+    return a - 2.0f * lam * (Vf * wf - Vr * wr);
+}
+
+// returns b; *iters += Newton iterations this wave ran
+__device__ __forceinline__ double asym_newton_root(const AsymConsts& c, double a, double v0, double tol, int max_iter,
+                                                   int& iters)
+{
+    const double Rp = c.Rp, Is1 = c.Is1, Is2 = c.Is2, iV1 = 1.0 / (double)c.V1, iV2 = 1.0 / (double)c.V2;
+    const double vscale = fmin((double)c.V1, (double)c.V2);
+    double v = v0;
+    for (int it = 0; it < max_iter; ++it) {
+        const double e1 = exp(v * iV1), e2 = exp(-v * iV2);
+        const double f = v + Rp * (Is1 * (e1 - 1.0) - Is2 * (e2 - 1.0)) - a;
+        const double fp = 1.0 + Rp * (Is1 * iV1 * e1 + Is2 * iV2 * e2);
+        double dv = f / fp;
+        // damping: never move more than a few thermal voltages (exp overshoot guard)
+        const double lim = 4.0 * vscale;
+        dv = fmin(fmax(dv, -lim), lim);
+        v -= dv;
+        ++iters;
+        const bool active = fabs(dv) > tol * (fabs(v) + vscale);
+        if (__builtin_amdgcn_ballot_w64(active) == 0) break;     // the whole wave has converged
+    }
+    const double i = Is1 * (exp(v * iV1) - 1.0) - Is2 * (exp(-v * iV2) - 1.0);
+    return v - Rp * i;
+}
+
+// One step of the tree around the root; S is the state type (double for NEWTON, float otherwise).
+template <bool NEWTON>
+struct AsymStep;
+template <>
+struct AsymStep<true> {
+    using S = double;
+    static __device__ __forceinline__ float run(const AsymConsts& c, float xin, double& z, double tol, int max_iter,
+                                                int& iters)
+    {
+        const double b_diff = z - (double)xin;
+        const double b_temp = -(double)c.p * b_diff;
+        const double a = z + b_temp;
+        const float bw = asym_omega_root(c, (float)a);                   // start value: v0 = (a + b)/2
+        const double br = asym_newton_root(c, a, 0.5 * (a + (double)bw), tol, max_iter, iters);
+        const double zn = br + b_temp;
+        const float y = (float)(0.5 * (zn + z));
+        z = zn;
+        return y;
+    }
+};
+template <>
+struct AsymStep<false> {
+    using S = float;
+    static __device__ __forceinline__ float run(const AsymConsts& c, float xin, float& z, double, int, int&)
+    {
+        const float b_diff = z - xin;
+        const float b_temp = -c.p * b_diff;
+        const float a = z + b_temp;
+        const float zn = asym_omega_root(c, a) + b_temp;
+        const float y = 0.5f * (zn + z);
+        z = zn;
+        return y;
+    }
+};
+
+// x [B][T] -> y [T][B]; theta6 = {Is1, V1, Is2, V2, R, C}; iters_out: optional int64[gridDim.x]
+template <bool NEWTON, bool VEC4>
+__global__ __launch_bounds__(64) void clipper_asym_fwd_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ theta6, float fs,
+                                                              float* __restrict__ y, const float* __restrict__ z0,
+                                                              float* __restrict__ zT, double tol, int max_iter,
+                                                              long long* __restrict__ iters_out, int64_t B, int64_t T)
+{
+    using S = typename AsymStep<NEWTON>::S;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const AsymConsts c = asym_load(theta6, fs);
+    float* __restrict__ yp = y + b;
+    int iters = 0;
+    S z = z0 ? (S)z0[b] : (S)0;
+    constexpr int kB = 8;
+    const int64_t nfull = T / kB;
+    float xc[kB], xn[kB];
+#pragma unroll
+    for (int k = 0; k < kB; ++k) xc[k] = xn[k] = 0.0f;
+    auto load8 = [&](int64_t t0, float(&v)[kB]) {
+        if constexpr (VEC4) {
+            const float4* p = reinterpret_cast<const float4*>(x + b * T + t0);
+            const float4 a = p[0], d = p[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kB; ++k) v[k] = x[b * T + t0 + k];
+        }
+    };
+    if (nfull > 0) load8(0, xn);
+    for (int64_t blk = 0; blk < nfull; ++blk) {
+#pragma unroll
+        for (int k = 0; k < kB; ++k) xc[k] = xn[k];
+        if (blk + 1 < nfull) load8((blk + 1) * kB, xn);       // one block ahead of the recursion
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+            *yp = AsymStep<NEWTON>::run(c, xc[k], z, tol, max_iter, iters);
+            yp += B;
+        }
+    }
+    for (int64_t t = nfull * kB; t < T; ++t) {
+        *yp = AsymStep<NEWTON>::run(c, x[b * T + t], z, tol, max_iter, iters);
+        yp += B;
+    }
+    if (zT) zT[b] = (float)z;
+    if (iters_out && threadIdx.x == 0) iters_out[blockIdx.x] = iters;   // wave-uniform count
+}
+
+// element-wise root, for accuracy sweeps: b[i] = root(a[i])
+template <bool NEWTON>
+__global__ void asym_root_kernel(const float* __restrict__ a, const float* __restrict__ theta6, float fs,
+                                 double* __restrict__ b, double tol, int max_iter, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = i < n ? i : n - 1;
+    const AsymConsts c = asym_load(theta6, fs);
+    double r;
+    if constexpr (NEWTON) {
+        int it = 0;
+        const float bw = asym_omega_root(c, a[j]);
+        r = asym_newton_root(c, (double)a[j], 0.5 * ((double)a[j] + (double)bw), tol, max_iter, it);
+    } else {
+        r = (double)asym_omega_root(c, a[j]);
+    }
+    if (i < n) b[i] = r;
+}
+
+}  // namespace wdf

@@ -9,6 +9,7 @@
 
 #include "../../include/wdf_hip.h"
 #include "wdf_clipper.h"
+#include "wdf_asym.h"
 #include "wdf_mlp.h"
 #include "wdf_statespace.h"
 
@@ -110,11 +111,11 @@ TpGeom tp_geom(int64_t T, int n_chunks)
 {
     if (n_chunks < 1) n_chunks = 1;
     int64_t L = (T + n_chunks - 1) / n_chunks;
-    L = (L + wdf::kBlk - 1) / wdf::kBlk * wdf::kBlk;
+    L = (L + wdf::kTile - 1) / wdf::kTile * wdf::kTile;
     return {L, (int)((T + L - 1) / L)};
 }
 
-template <bool DYN_R, bool SYM, bool V4>
+template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
                    float* zstash, const float* z0, float* zT, float* zwarm, float* zend, wdf::TpStatus* status,
                    float tol, int64_t B, int64_t T, TpGeom g, int64_t W, bool pack, hipStream_t s)
@@ -123,7 +124,7 @@ void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs,
     const int64_t Bh = pack ? (B + 1) / 2 : B;
     const dim3 grid((unsigned)((Bh + 63) / 64), (unsigned)g.K);
 #define WDF_FWD_TP(STASH_, V_)                                                                             \
-    hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, V4, STASH_, V_>), grid, dim3(64), 0, s, x, r, theta, \
+    hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, TM, V4, STASH_, V_>), grid, dim3(64), 0, s, x, r, theta, \
                        fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, status, B, Bh, T, g.L, W)
     if (pack) {
         if (zstash) WDF_FWD_TP(true, wdf::v2f); else WDF_FWD_TP(false, wdf::v2f);
@@ -132,27 +133,28 @@ void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs,
     }
 #undef WDF_FWD_TP
     if (g.K > 1) {
+        // the repair path reads x row-wise; give it a batch-major view only if x is batch-major
         if (zstash)
-            hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, V4, true>), dim3(gseq), dim3(64), 0, s,
+            hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, TM, true>), dim3(gseq), dim3(64), 0, s,
                                x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, B, T, (int64_t)g.K, tol,
                                status);
         else
-            hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, V4, false>), dim3(gseq), dim3(64), 0, s,
+            hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, TM, false>), dim3(gseq), dim3(64), 0, s,
                                x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, B, T, (int64_t)g.K, tol,
                                status);
     }
 }
 
-template <bool DYN_R, bool SYM, bool V4>
+template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
-                   const float* zstash, const float* gy, const float* target, float gscale, float* part, double* ws,
-                   float* gz0, int64_t B, int64_t T, TpGeom g, bool pack, hipStream_t s)
+                   const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
+                   float* part, double* ws, float* gz0, int64_t B, int64_t T, TpGeom g, bool pack, hipStream_t s)
 {
     const int64_t Bh = pack ? (B + 1) / 2 : B;
     const dim3 grid((unsigned)((Bh + 63) / 64), (unsigned)g.K);
 #define WDF_BWD_TP(MSE_, V_)                                                                               \
-    hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, V4, MSE_, V_>), grid, dim3(64), 0, s, x, r, theta, fs, \
-                       n_up, n_down, zstash, gy, target, gscale, part, B, Bh, T, g.L)
+    hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, TM, V4, MSE_, V_>), grid, dim3(64), 0, s, x, r, theta, \
+                       fs, n_up, n_down, zstash, gy, target, zT, gscale, part, B, Bh, T, g.L)
     if (pack) {
         if (target) WDF_BWD_TP(true, wdf::v2f); else WDF_BWD_TP(false, wdf::v2f);
     } else {
@@ -322,20 +324,25 @@ int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta, float
 {
     int rc = check_common(x, theta, n_up, n_down, B, T, flags);
     if (rc) return rc;
-    if (flags & WDF_X_TIME_MAJOR) return fail(WDF_EUNSUPPORTED, "time-parallel kernels take batch-major x");
     if (!y || !ws || !status) return fail(WDF_EINVAL, "null y/ws/status");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
     if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
     const TpGeom g = tp_geom(T, n_chunks);
-    const int64_t W = ((int64_t)warmup + wdf::kBlk - 1) / wdf::kBlk * wdf::kBlk;
+    const int64_t W = ((int64_t)warmup + wdf::kTile - 1) / wdf::kTile * wdf::kTile;
     float* zwarm = (float*)ws;
     float* zend = zwarm + (size_t)g.K * (size_t)B;
-    const bool v4 = (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
-    WDF_DISPATCH3(launch_fwd_tp, r != nullptr, n_up == n_down, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
+    const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
+    const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    WDF_DISPATCH4(launch_fwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
                   zwarm, zend, (wdf::TpStatus*)status, tol, B, T, g, W, (flags & WDF_TP_PACK2) != 0 && B >= 2,
                   (hipStream_t)stream);
     return check_launch("wdf_clipper_fwd_tp");
 }
+
+static int bwd_tp_common(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                         const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
+                         void* ws, float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T,
+                         int n_chunks, int flags, void* stream);
 
 size_t wdf_clipper_bwd_tp_ws_bytes(int64_t B, int n_chunks)
 {
@@ -347,33 +354,77 @@ int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta, float
                        const float* zstash, const float* gy, void* ws, float* gtheta, float* gz0, int accumulate,
                        int64_t B, int64_t T, int n_chunks, int flags, void* stream)
 {
-    return wdf_clipper_bwd_mse_tp(x, r, theta, fs, n_up, n_down, zstash, gy, nullptr, 0.0f, ws, gtheta, nullptr, gz0,
-                                  accumulate, B, T, n_chunks, flags, stream);
+    if (!gy) return fail(WDF_EINVAL, "null gy");
+    return bwd_tp_common(x, r, theta, fs, n_up, n_down, zstash, gy, nullptr, nullptr, 0.0f, ws, gtheta, nullptr, gz0,
+                         accumulate, B, T, n_chunks, flags, stream);
 }
 
 int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
-                           const float* zstash, const float* gy, const float* target, float gscale, void* ws,
+                           const float* zstash, const float* zT, const float* target, float gscale, void* ws,
                            float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T, int n_chunks,
                            int flags, void* stream)
 {
+    if (!zT || !target) return fail(WDF_EINVAL, "null zT/target");
+    return bwd_tp_common(x, r, theta, fs, n_up, n_down, zstash, nullptr, target, zT, gscale, ws, gtheta, sse, gz0,
+                         accumulate, B, T, n_chunks, flags, stream);
+}
+
+static int bwd_tp_common(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                         const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
+                         void* ws, float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T,
+                         int n_chunks, int flags, void* stream)
+{
     int rc = check_common(x, theta, n_up, n_down, B, T, flags);
     if (rc) return rc;
-    if (flags & WDF_X_TIME_MAJOR) return fail(WDF_EUNSUPPORTED, "time-parallel kernels take batch-major x");
-    if (!zstash || !gy || !ws || !gtheta) return fail(WDF_EINVAL, "null zstash/gy/ws/gtheta");
+    if (!zstash || !ws || !gtheta) return fail(WDF_EINVAL, "null zstash/ws/gtheta");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
     if (n_chunks < 1) return fail(WDF_EINVAL, "n_chunks >= 1");
     const TpGeom g = tp_geom(T, n_chunks);
     double* wsd = (double*)ws;                                       // [nparts][4] doubles first (8-byte aligned)
     float* part = (float*)((char*)ws + wdf_clipper_bwd_ws_bytes(B)); // then [K][8][B] floats
-    const bool v4 = (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
-    WDF_DISPATCH3(launch_bwd_tp, r != nullptr, n_up == n_down, v4, x, r, theta, fs, n_up, n_down, zstash, gy, target,
-                  gscale, part, wsd, gz0, B, T, g, (flags & WDF_TP_PACK2) != 0 && B >= 2, (hipStream_t)stream);
+    const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
+    const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    WDF_DISPATCH4(launch_bwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy, target,
+                  zT, gscale, part, wsd, gz0, B, T, g, (flags & WDF_TP_PACK2) != 0 && B >= 2, (hipStream_t)stream);
     rc = check_launch("wdf_clipper_bwd_tp");
     if (rc) return rc;
     const int nparts = (int)((B + 63) / 64);
     hipLaunchKernelGGL(wdf::clipper_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)wsd,
                        nparts, theta, fs, r != nullptr ? 1 : 0, gtheta, accumulate, target ? sse : nullptr);
     return check_launch("wdf_clipper_grad_reduce");
+}
+
+int wdf_clipper_asym_fwd(const float* x, const float* theta6, float fs, int mode, double tol, int max_iter, float* y,
+                         const float* z0, float* zT, long long* iters, int64_t B, int64_t T, void* stream)
+{
+    if (!x || !theta6 || !y) return fail(WDF_EINVAL, "null x/theta6/y");
+    if (B <= 0 || T <= 0 || !(fs > 0.0f)) return fail(WDF_EINVAL, "B, T, fs must be positive");
+    if (mode != WDF_ASYM_OMEGA_F32 && mode != WDF_ASYM_NEWTON_F64) return fail(WDF_EINVAL, "unknown mode %d", mode);
+    if (mode == WDF_ASYM_NEWTON_F64 && (!(tol > 0.0) || max_iter < 1)) return fail(WDF_EINVAL, "tol > 0, max_iter >= 1");
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    const bool v4 = (T % 4 == 0) && aligned16(x);
+#define WDF_ASYM(NEWTON_, V4_)                                                                                \
+    hipLaunchKernelGGL((wdf::clipper_asym_fwd_kernel<NEWTON_, V4_>), dim3(grid), dim3(64), 0, (hipStream_t)stream, x, \
+                       theta6, fs, y, z0, zT, tol, max_iter, iters, B, T)
+    if (mode == WDF_ASYM_NEWTON_F64) { if (v4) WDF_ASYM(true, true); else WDF_ASYM(true, false); }
+    else { if (v4) WDF_ASYM(false, true); else WDF_ASYM(false, false); }
+#undef WDF_ASYM
+    return check_launch("wdf_clipper_asym_fwd");
+}
+
+int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, double tol, int max_iter, double* b, int64_t n,
+                  void* stream)
+{
+    if (!a || !theta6 || !b || n <= 0) return fail(WDF_EINVAL, "wdf_asym_root: bad arguments");
+    if (mode != WDF_ASYM_OMEGA_F32 && mode != WDF_ASYM_NEWTON_F64) return fail(WDF_EINVAL, "unknown mode %d", mode);
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (mode == WDF_ASYM_NEWTON_F64)
+        hipLaunchKernelGGL((wdf::asym_root_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, theta6, fs, b,
+                           tol, max_iter, n);
+    else
+        hipLaunchKernelGGL((wdf::asym_root_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, theta6, fs, b,
+                           tol, max_iter, n);
+    return check_launch("wdf_asym_root");
 }
 
 int wdf_mlp_weight_count(int hidden, int n_tanh_layers)

@@ -91,6 +91,28 @@ __device__ __forceinline__ void load_block(const float* __restrict__ x, int64_t 
     }
 }
 
+// n-step variant for the time-parallel kernels: with NSTEP = 32 a lane consumes one whole 128-byte
+// line of its row per burst of 8 back-to-back 16-byte loads, so the line is fetched from HBM
+// once (measured: with 8-step blocks and thousands of waves in flight the 4 visits to a line
+// were far enough apart for it to be evicted in between -- FETCH_SIZE 3.9x the algorithmic
+// bytes; see profiles/ r01 PMC notes).
+template <int NSTEP, bool VEC4>
+__device__ __forceinline__ void load_row(const float* __restrict__ x, int64_t b, int64_t T, int64_t t0,
+                                         float (&v)[NSTEP])
+{
+    if constexpr (VEC4) {
+        const float4* p = reinterpret_cast<const float4*>(x + b * T + t0);
+#pragma unroll
+        for (int i = 0; i < NSTEP / 4; ++i) {
+            const float4 f = p[i];
+            v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) v[k] = x[b * T + t0 + k];
+    }
+}
+
 template <bool TIME_MAJOR>
 __device__ __forceinline__ float load_one(const float* __restrict__ x, int64_t b, int64_t B, int64_t T, int64_t t)
 {
@@ -425,7 +447,34 @@ __device__ __forceinline__ void store_v(float* __restrict__ p, const LaneSeqs<V>
     for (int j = 0; j < VT<V>::N; ++j) p[off + q.b[j]] = vget(v, j);
 }
 
-template <bool DYN_R, bool SYM, bool VEC4, bool STASH, typename V>
+constexpr int kTile = 32;      // x / r steps per lane per load burst = one 128-byte line of the row
+
+template <typename V, bool TM, bool VEC4>
+__device__ __forceinline__ void load_tile_v(const float* __restrict__ x, const LaneSeqs<V>& q, int64_t B, int64_t T,
+                                            int64_t t0, float (&v)[VT<V>::N][kTile])
+{
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) {
+        if constexpr (TM) {
+#pragma unroll
+            for (int i = 0; i < kTile; ++i) v[j][i] = x[(t0 + i) * B + q.b[j]];     // coalesced across lanes
+        } else {
+            load_row<kTile, VEC4>(x, q.b[j], T, t0, v[j]);
+        }
+    }
+}
+
+template <typename V>
+__device__ __forceinline__ V gather_t(const float (&v)[VT<V>::N][kTile], int i)
+{
+    V r = vsplat<V>(0.0f);
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) vset(r, j, v[j][i]);
+    return r;
+}
+
+// Chunk geometry: L and W are multiples of kTile (host guarantees it).  TM: x and r are [T][B].
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V>
 __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
@@ -437,58 +486,50 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = TpStatus{0, 0.0f, 0, 0};
     const LaneSeqs<V> q(B, Bh);
     const int64_t k = blockIdx.y;
-    const int64_t t0 = k * L;                               // first owned step (multiple of kBlk)
+    const int64_t t0 = k * L;                               // first owned step (multiple of kTile)
     const int64_t t1 = (t0 + L < T) ? t0 + L : T;           // one past the last owned step
-    const int64_t tw = (t0 > W) ? t0 - W : 0;               // warm-up start (multiple of kBlk)
+    const int64_t tw = (t0 > W) ? t0 - W : 0;               // warm-up start (multiple of kTile)
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     V z = vsplat<V>(0.0f);
     if (tw == 0 && z0) z = load_one_v<V>(z0, q, 1, 0, 0);
 
-    float xc[N][kBlk], xn[N][kBlk], rc[N][kBlk], rn[N][kBlk];
+    float xc[N][kTile], xn[N][kTile], rc[N][kTile], rn[N][kTile];
 #pragma unroll
     for (int j = 0; j < N; ++j)
 #pragma unroll
-        for (int i = 0; i < kBlk; ++i) { xc[j][i] = xn[j][i] = 0.0f; rc[j][i] = rn[j][i] = 1.0f; }
-    const int64_t nfull_end = t1 - (t1 - tw) % kBlk;        // full blocks cover [tw, nfull_end)
+        for (int i = 0; i < kTile; ++i) { xc[j][i] = xn[j][i] = 0.0f; rc[j][i] = rn[j][i] = 1.0f; }
+    const int64_t nfull_end = t1 - (t1 - tw) % kTile;       // full tiles cover [tw, nfull_end)
     if (tw < nfull_end) {
-        load_block_v<V, false, VEC4>(x, q, B, T, tw, xn);
-        if constexpr (DYN_R) load_block_v<V, false, VEC4>(r, q, B, T, tw, rn);
+        load_tile_v<V, TM, VEC4>(x, q, B, T, tw, xn);
+        if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, tw, rn);
     }
-    // ---- warm-up: [tw, t0), nothing stored -------------------------------------------------
-    for (int64_t t = tw; t < t0; t += kBlk) {
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-#pragma unroll
-            for (int i = 0; i < kBlk; ++i) { xc[j][i] = xn[j][i]; if constexpr (DYN_R) rc[j][i] = rn[j][i]; }
-        if (t + kBlk < nfull_end) {
-            load_block_v<V, false, VEC4>(x, q, B, T, t + kBlk, xn);
-            if constexpr (DYN_R) load_block_v<V, false, VEC4>(r, q, B, T, t + kBlk, rn);
-        }
-#pragma unroll
-        for (int i = 0; i < kBlk; ++i) (void)fwd_step<DYN_R, SYM, V>(c, gather<V>(xc, i), gather<V>(rc, i), z);
-    }
-    store_v<V>(zwarm, q, k * B, z);
-    // ---- owned steps: [t0, t1) ---------------------------------------------------------------
     int64_t off = t0 * B;
-    for (int64_t t = t0; t < nfull_end; t += kBlk) {
+    for (int64_t t = tw; t < nfull_end; t += kTile) {
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-            for (int i = 0; i < kBlk; ++i) { xc[j][i] = xn[j][i]; if constexpr (DYN_R) rc[j][i] = rn[j][i]; }
-        if (t + kBlk < nfull_end) {
-            load_block_v<V, false, VEC4>(x, q, B, T, t + kBlk, xn);
-            if constexpr (DYN_R) load_block_v<V, false, VEC4>(r, q, B, T, t + kBlk, rn);
+            for (int i = 0; i < kTile; ++i) { xc[j][i] = xn[j][i]; if constexpr (DYN_R) rc[j][i] = rn[j][i]; }
+        if (t + kTile < nfull_end) {                        // next tile: one whole line per lane, a tile ahead
+            load_tile_v<V, TM, VEC4>(x, q, B, T, t + kTile, xn);
+            if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, t + kTile, rn);
         }
+        if (t < t0) {                                       // ---- warm-up tile: nothing stored
 #pragma unroll
-        for (int i = 0; i < kBlk; ++i) {
-            if constexpr (STASH) store_v<V>(zstash, q, off, z);
-            store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V>(c, gather<V>(xc, i), gather<V>(rc, i), z));
-            off += B;
+            for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z);
+            if (t + kTile == t0) store_v<V>(zwarm, q, k * B, z);
+        } else {                                            // ---- owned tile
+#pragma unroll
+            for (int i = 0; i < kTile; ++i) {
+                if constexpr (STASH) store_v<V>(zstash, q, off, z);
+                store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z));
+                off += B;
+            }
         }
     }
-    for (int64_t t = nfull_end; t < t1; ++t) {              // tail of the last chunk (T % 8)
-        const V xin = load_one_v<V>(x, q, T, 1, t);
-        const V rin = DYN_R ? load_one_v<V>(r, q, T, 1, t) : vsplat<V>(1.0f);
+    if (tw == t0) store_v<V>(zwarm, q, k * B, z);           // chunk 0 (or W = 0): no warm-up ran
+    for (int64_t t = nfull_end; t < t1; ++t) {              // tail of the last chunk (T % 32)
+        const V xin = load_one_v<V>(x, q, TM ? 1 : T, TM ? B : 1, t);
+        const V rin = DYN_R ? load_one_v<V>(r, q, TM ? 1 : T, TM ? B : 1, t) : vsplat<V>(1.0f);
         if constexpr (STASH) store_v<V>(zstash, q, off, z);
         store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V>(c, xin, rin, z));
         off += B;
@@ -501,7 +542,7 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
 // compares zwarm[k] with zend[k-1] for its own sequences and every chunk; if any of them misses
 // by more than tol, this wave alone re-runs ITS 64 sequences sequentially (exact) over the
 // whole time axis.  The common case is K-1 coalesced loads and an early exit.
-template <bool DYN_R, bool SYM, bool VEC4, bool STASH>
+template <bool DYN_R, bool SYM, bool TM, bool STASH>
 __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
@@ -534,8 +575,8 @@ __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
     float* __restrict__ yp = y + b;
     float* __restrict__ zp = STASH ? zstash + b : nullptr;
     for (int64_t t = 0; t < T; ++t) {                           // cold path: plain loop
-        const float xin = load_one<false>(x, b, B, T, t);
-        const float rin = DYN_R ? load_one<false>(r, b, B, T, t) : 1.0f;
+        const float xin = load_one<TM>(x, b, B, T, t);
+        const float rin = DYN_R ? load_one<TM>(r, b, B, T, t) : 1.0f;
         if constexpr (STASH) { *zp = z; zp += B; }
         *yp = fwd_step<DYN_R, SYM>(c, xin, rin, z);
         yp += B;
@@ -598,24 +639,30 @@ __device__ __forceinline__ void bwd_tp_step(const ClipConsts& c, V xin, V rin, V
 // sum (y - target)^2, so a training step needs no separate loss pass over y.
 constexpr int kTpOut = 9;
 
+// dL/dy for this step.  MSE: y[n] = (z[n+1] + z[n])/2 is rebuilt from the state stash (z_next is
+// the state after the step = the stash entry of the following step), so the sweep reads neither
+// y nor a dL/dy array: x, stash and target are its 12 B/sample.
 template <bool MSE, typename V>
-__device__ __forceinline__ V tp_grad_in(V gy_or_y, V tgt, float gscale, V& sse)
+__device__ __forceinline__ V tp_grad_in(V gy, V z, V z_next, V tgt, float gscale, V& sse)
 {
     if constexpr (MSE) {
-        const V d = gy_or_y - tgt;
+        const V d = 0.5f * (z_next + z) - tgt;
         sse = vfma(d, d, sse);
         return gscale * d;
     } else {
-        return gy_or_y;
+        return gy;
     }
 }
 
-template <bool DYN_R, bool SYM, bool VEC4, bool MSE, typename V>
+// MSE: `gy` is unused, `target` [T][B] the training target, zT [B] the final state of the forward
+// (needed for y[T-1]); dL/dy = gscale (y - target), gscale = 2/N for a mean over N samples; the
+// kernel also returns sum (y - target)^2.
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool MSE, typename V>
 __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, const float* __restrict__ zstash, const float* __restrict__ gy,
-    const float* __restrict__ target, float gscale, float* __restrict__ out, int64_t B, int64_t Bh, int64_t T,
-    int64_t L)
+    const float* __restrict__ target, const float* __restrict__ zT, float gscale, float* __restrict__ out,
+    int64_t B, int64_t Bh, int64_t T, int64_t L)
 {
     constexpr int N = VT<V>::N;
     const LaneSeqs<V> q(B, Bh);
@@ -629,17 +676,22 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
 #pragma unroll
     for (int j = 0; j < N; ++j) dbL[j] = dbV[j] = dbP[j] = dsse[j] = 0.0;
     V saL = vsplat<V>(0.0f), saV = vsplat<V>(0.0f), saP = vsplat<V>(0.0f);
+    const V zero = vsplat<V>(0.0f);
+    V z_next = zero;                                          // state after the step being processed
+    if constexpr (MSE) z_next = (t1 < T) ? load_one_v<V>(zstash, q, 1, B, t1) : load_one_v<V>(zT, q, 1, 0, 0);
 
     const int64_t nfull_end = t1 - (t1 - t0) % kBlk;
-    for (int64_t t = t1 - 1; t >= nfull_end; --t) {   // tail of the last chunk first (highest t)
-        TpAccT<V> acc = {vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f),
-                         vsplat<V>(0.0f)};
-        const V xin = load_one_v<V>(x, q, T, 1, t);
-        const V rin = DYN_R ? load_one_v<V>(r, q, T, 1, t) : vsplat<V>(1.0f);
-        V sse1 = vsplat<V>(0.0f);
-        const V tg = MSE ? load_one_v<V>(target, q, 1, B, t) : vsplat<V>(0.0f);
-        const V g = tp_grad_in<MSE, V>(load_one_v<V>(gy, q, 1, B, t), tg, gscale, sse1);
-        bwd_tp_step<DYN_R, SYM, V>(c, xin, rin, load_one_v<V>(zstash, q, 1, B, t), g, alpha, beta, acc);
+    for (int64_t t = t1 - 1; t >= nfull_end; --t) {          // tail of the last chunk first (highest t)
+        TpAccT<V> acc = {zero, zero, zero, zero, zero, zero};
+        const V xin = load_one_v<V>(x, q, TM ? 1 : T, TM ? B : 1, t);
+        const V rin = DYN_R ? load_one_v<V>(r, q, TM ? 1 : T, TM ? B : 1, t) : vsplat<V>(1.0f);
+        const V zv = load_one_v<V>(zstash, q, 1, B, t);
+        V sse1 = zero;
+        const V tg = MSE ? load_one_v<V>(target, q, 1, B, t) : zero;
+        const V gin = MSE ? zero : load_one_v<V>(gy, q, 1, B, t);
+        const V g = tp_grad_in<MSE, V>(gin, zv, z_next, tg, gscale, sse1);
+        bwd_tp_step<DYN_R, SYM, V>(c, xin, rin, zv, g, alpha, beta, acc);
+        z_next = zv;
         saL += acc.aL; saV += acc.aV; saP += acc.aP;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -647,22 +699,21 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
             dsse[j] += vget(sse1, j);
         }
     }
-    float xc[N][kBlk], xn[N][kBlk], rc[N][kBlk], rn[N][kBlk], zc[N][kBlk], zn[N][kBlk], gc[N][kBlk], gn[N][kBlk],
-        tc[N][kBlk], tn[N][kBlk];
+    float xc[N][kBlk], xn[N][kBlk], rc[N][kBlk], rn[N][kBlk], zc[N][kBlk], zn[N][kBlk], gc[N][kBlk], gn[N][kBlk];
 #pragma unroll
     for (int j = 0; j < N; ++j)
 #pragma unroll
         for (int i = 0; i < kBlk; ++i) {
-            xc[j][i] = xn[j][i] = zc[j][i] = zn[j][i] = gc[j][i] = gn[j][i] = tc[j][i] = tn[j][i] = 0.0f;
+            xc[j][i] = xn[j][i] = zc[j][i] = zn[j][i] = gc[j][i] = gn[j][i] = 0.0f;
             rc[j][i] = rn[j][i] = 1.0f;
         }
+    const float* __restrict__ gsrc = MSE ? target : gy;       // the third stream: target (MSE) or dL/dy
     if (nfull_end > t0) {
         const int64_t tb = nfull_end - kBlk;
-        load_block_v<V, false, VEC4>(x, q, B, T, tb, xn);
-        if constexpr (DYN_R) load_block_v<V, false, VEC4>(r, q, B, T, tb, rn);
+        load_block_v<V, TM, VEC4>(x, q, B, T, tb, xn);
+        if constexpr (DYN_R) load_block_v<V, TM, VEC4>(r, q, B, T, tb, rn);
         load_block_v<V, true, false>(zstash, q, B, T, tb, zn);
-        load_block_v<V, true, false>(gy, q, B, T, tb, gn);
-        if constexpr (MSE) load_block_v<V, true, false>(target, q, B, T, tb, tn);
+        load_block_v<V, true, false>(gsrc, q, B, T, tb, gn);
     }
     for (int64_t tb = nfull_end - kBlk; tb >= t0; tb -= kBlk) {
 #pragma unroll
@@ -671,22 +722,21 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
             for (int i = 0; i < kBlk; ++i) {
                 xc[j][i] = xn[j][i]; zc[j][i] = zn[j][i]; gc[j][i] = gn[j][i];
                 if constexpr (DYN_R) rc[j][i] = rn[j][i];
-                if constexpr (MSE) tc[j][i] = tn[j][i];
             }
         if (tb - kBlk >= t0) {
-            load_block_v<V, false, VEC4>(x, q, B, T, tb - kBlk, xn);
-            if constexpr (DYN_R) load_block_v<V, false, VEC4>(r, q, B, T, tb - kBlk, rn);
+            load_block_v<V, TM, VEC4>(x, q, B, T, tb - kBlk, xn);
+            if constexpr (DYN_R) load_block_v<V, TM, VEC4>(r, q, B, T, tb - kBlk, rn);
             load_block_v<V, true, false>(zstash, q, B, T, tb - kBlk, zn);
-            load_block_v<V, true, false>(gy, q, B, T, tb - kBlk, gn);
-            if constexpr (MSE) load_block_v<V, true, false>(target, q, B, T, tb - kBlk, tn);
+            load_block_v<V, true, false>(gsrc, q, B, T, tb - kBlk, gn);
         }
-        TpAccT<V> acc = {vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f), vsplat<V>(0.0f),
-                         vsplat<V>(0.0f)};
-        V sse8 = vsplat<V>(0.0f);
+        TpAccT<V> acc = {zero, zero, zero, zero, zero, zero};
+        V sse8 = zero;
 #pragma unroll
         for (int i = kBlk - 1; i >= 0; --i) {
-            const V g = tp_grad_in<MSE, V>(gather<V>(gc, i), gather<V>(tc, i), gscale, sse8);
-            bwd_tp_step<DYN_R, SYM, V>(c, gather<V>(xc, i), gather<V>(rc, i), gather<V>(zc, i), g, alpha, beta, acc);
+            const V zv = gather<V>(zc, i);
+            const V g = tp_grad_in<MSE, V>(gather<V>(gc, i), zv, z_next, gather<V>(gc, i), gscale, sse8);
+            bwd_tp_step<DYN_R, SYM, V>(c, gather<V>(xc, i), gather<V>(rc, i), zv, g, alpha, beta, acc);
+            z_next = zv;
         }
         saL += acc.aL; saV += acc.aV; saP += acc.aP;
 #pragma unroll

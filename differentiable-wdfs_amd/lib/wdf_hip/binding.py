@@ -58,6 +58,10 @@ def lib():
     L.wdf_clipper_bwd_mse_tp.restype = ci
     L.wdf_clipper_bwd_mse_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, cf, vp, fp, fp, fp, ci, i64, i64, ci,
                                          ci, vp]
+    L.wdf_clipper_asym_fwd.restype = ci
+    L.wdf_clipper_asym_fwd.argtypes = [fp, fp, cf, ci, C.c_double, ci, fp, fp, fp, vp, i64, i64, vp]
+    L.wdf_asym_root.restype = ci
+    L.wdf_asym_root.argtypes = [fp, fp, cf, ci, C.c_double, ci, vp, i64, vp]
     L.wdf_mlp_weight_count.restype = ci
     L.wdf_mlp_weight_count.argtypes = [ci, ci]
     L.wdf_clipper_mlp_fwd.restype = ci
@@ -92,6 +96,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_fwd", "wdf_clipper_bwd", "wdf_clipper_bwd_ws_bytes",
     "wdf_clipper_tp_chunks", "wdf_clipper_fwd_tp_ws_bytes", "wdf_clipper_fwd_tp",
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
+    "wdf_clipper_asym_fwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
     "wdf_omega_f32", "wdf_diode_pair_f32",
@@ -176,7 +181,7 @@ def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=Fal
 
 
 def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_down=1, want_stash=True, z0=None,
-                   want_zT=False, ws=None, status=None, pack=False):
+                   want_zT=False, ws=None, status=None, pack=False, time_major=False):
     """Time-parallel forward.  Returns y [T,B], zstash | None, zT | None, status (device int32[4]:
     n_bad, max-miss float bits, fallback_ran, 0 -- read it with tp_status())."""
     require_gpu()
@@ -184,7 +189,7 @@ def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_d
     r = _f32_dev(r, "r")
     theta = _f32_dev(theta, "theta")
     z0 = _f32_dev(z0, "z0")
-    B, T = x.shape
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
     if r is not None and r.shape != x.shape:
         raise WdfHipError("r must have the shape of x")
     y = torch.empty((T, B), dtype=torch.float32, device=x.device)
@@ -196,7 +201,8 @@ def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_d
         status = torch.empty((4,), dtype=torch.int32, device=x.device)
     rc = lib().wdf_clipper_fwd_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(y),
                                   _ptr(zs), _ptr(z0), _ptr(zT), B, T, int(n_chunks), int(warmup), float(tol),
-                                  _ptr(ws), _ptr(status), WDF_TP_PACK2 if pack else 0, _stream())
+                                  _ptr(ws), _ptr(status),
+                                  (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0), _stream())
     _check(rc, "wdf_clipper_fwd_tp")
     return y, zs, zT, status
 
@@ -209,14 +215,14 @@ def tp_status(status):
 
 
 def clipper_bwd_tp(x, theta, fs, zstash, gy, n_chunks, r=None, n_up=1, n_down=1, want_gz0=False, gtheta=None,
-                   accumulate=False, ws=None, pack=False):
+                   accumulate=False, ws=None, pack=False, time_major=False):
     require_gpu()
     x = _f32_dev(x, "x")
     r = _f32_dev(r, "r")
     theta = _f32_dev(theta, "theta")
     zstash = _f32_dev(zstash, "zstash")
     gy = _f32_dev(gy, "gy")
-    B, T = x.shape
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
     if tuple(gy.shape) != (T, B) or tuple(zstash.shape) != (T, B):
         raise WdfHipError(f"gy / zstash must be [T,B] = [{T},{B}]")
     if ws is None:
@@ -227,26 +233,30 @@ def clipper_bwd_tp(x, theta, fs, zstash, gy, n_chunks, r=None, n_up=1, n_down=1,
     gz0 = torch.empty((B,), dtype=torch.float32, device=x.device) if want_gz0 else None
     rc = lib().wdf_clipper_bwd_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(zstash),
                                   _ptr(gy), _ptr(ws), _ptr(gtheta), _ptr(gz0), 1 if accumulate else 0, B, T,
-                                  int(n_chunks), WDF_TP_PACK2 if pack else 0, _stream())
+                                  int(n_chunks),
+                                  (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0), _stream())
     _check(rc, "wdf_clipper_bwd_tp")
     return gtheta, gz0
 
 
-def clipper_bwd_mse_tp(x, theta, fs, zstash, y, target, gscale, n_chunks, r=None, n_up=1, n_down=1, gtheta=None,
-                       sse=None, accumulate=False, ws=None, pack=False):
-    """MSE-fused reverse sweep: dL/dy = gscale (y - target) formed in the kernel.
+def clipper_bwd_mse_tp(x, theta, fs, zstash, zT, target, gscale, n_chunks, r=None, n_up=1, n_down=1, gtheta=None,
+                       sse=None, accumulate=False, ws=None, pack=False, time_major=False):
+    """MSE-fused reverse sweep: y is rebuilt from the state stash (zstash [T,B], zT [B]) and
+    dL/dy = gscale (y - target) is formed in the kernel.
     Returns (gtheta float32[4], sse float32[1] = sum (y - target)^2 over this batch)."""
     require_gpu()
     x = _f32_dev(x, "x")
     r = _f32_dev(r, "r")
     theta = _f32_dev(theta, "theta")
     zstash = _f32_dev(zstash, "zstash")
-    y = _f32_dev(y, "y")
+    zT = _f32_dev(zT, "zT")
     target = _f32_dev(target, "target")
-    B, T = x.shape
-    for name, t in (("y", y), ("target", target), ("zstash", zstash)):
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+    for name, t in (("target", target), ("zstash", zstash)):
         if tuple(t.shape) != (T, B):
             raise WdfHipError(f"{name} must be [T,B] = [{T},{B}]")
+    if zT.numel() != B:
+        raise WdfHipError("zT must hold the B final states of the forward")
     if ws is None:
         ws = torch.empty((lib().wdf_clipper_bwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
     if gtheta is None:
@@ -255,9 +265,10 @@ def clipper_bwd_mse_tp(x, theta, fs, zstash, y, target, gscale, n_chunks, r=None
     if sse is None:
         sse = torch.empty((1,), dtype=torch.float32, device=x.device)
     rc = lib().wdf_clipper_bwd_mse_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
-                                      _ptr(zstash), _ptr(y), _ptr(target), float(gscale), _ptr(ws), _ptr(gtheta),
+                                      _ptr(zstash), _ptr(zT), _ptr(target), float(gscale), _ptr(ws), _ptr(gtheta),
                                       _ptr(sse), None, 1 if accumulate else 0, B, T, int(n_chunks),
-                                      WDF_TP_PACK2 if pack else 0, _stream())
+                                      (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0),
+                                      _stream())
     _check(rc, "wdf_clipper_bwd_mse_tp")
     return gtheta, sse
 
@@ -303,6 +314,37 @@ def clipper_mlp_bwd(x, theta2, w, hidden, n_tanh, fs, zstash, gy, r=None):
                                    B, T, 0, _stream())
     _check(rc, "wdf_clipper_mlp_bwd")
     return gth, gb, ain, lrin
+
+
+ASYM_OMEGA_F32, ASYM_NEWTON_F64 = 0, 1
+
+
+def clipper_asym_fwd(x, theta6, fs, mode, tol=1e-12, max_iter=50, z0=None, want_zT=False, want_iters=False):
+    """Two-different-diode clipper forward.  Returns y [T,B], zT | None, iters (int64 per wave) | None."""
+    require_gpu()
+    x = _f32_dev(x, "x")
+    theta6 = _f32_dev(theta6, "theta6")
+    z0 = _f32_dev(z0, "z0")
+    if theta6.numel() != 6:
+        raise WdfHipError("theta6 must hold {Is_up, nVt_up, Is_down, nVt_down, R, C}")
+    B, T = x.shape
+    y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zT = torch.empty((B,), dtype=torch.float32, device=x.device) if want_zT else None
+    it = torch.zeros(((B + 63) // 64,), dtype=torch.int64, device=x.device) if want_iters else None
+    rc = lib().wdf_clipper_asym_fwd(_ptr(x), _ptr(theta6), float(fs), int(mode), float(tol), int(max_iter), _ptr(y),
+                                    _ptr(z0), _ptr(zT), _ptr(it), B, T, _stream())
+    _check(rc, "wdf_clipper_asym_fwd")
+    return y, zT, it
+
+
+def asym_root(a, theta6, fs, mode, tol=1e-12, max_iter=50):
+    require_gpu()
+    a = _f32_dev(a, "a")
+    theta6 = _f32_dev(theta6, "theta6")
+    b = torch.empty(a.shape, dtype=torch.float64, device=a.device)
+    _check(lib().wdf_asym_root(_ptr(a), _ptr(theta6), float(fs), int(mode), float(tol), int(max_iter), _ptr(b),
+                               a.numel(), _stream()), "wdf_asym_root")
+    return b
 
 
 ROOT_NONE, ROOT_DIODE_PAIR = 0, 2

@@ -20,12 +20,13 @@ TpPlan = namedtuple("TpPlan", ["k_fwd", "warmup", "tol", "k_bwd"])
 N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
 
 
-def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, r_min=None):
+def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, r_min=None, time_major=False):
     """Choose chunk counts from the batch shape and the circuit's memory.
 
-    Sequential mode gives ceil(B/64) waves for 1024 SIMDs; the plan aims at ~1 wave per SIMD
-    for the forward (every extra chunk costs a warm-up; measured optimum on MI355X) and ~4 for
-    the reverse sweep (no redundancy there).  The forward's warm-up must outlast the circuit's
+    Sequential mode gives ceil(B/64) waves for 1024 SIMDs, each a dependent chain (a dependent
+    VALU op issues every ~7 cycles on gfx950, an independent one every ~2.3: tools/ubench).  The
+    plan aims at ~2 waves per SIMD for the forward (every extra chunk costs a warm-up) and 4-8
+    for the reverse sweep (no redundancy there; 8 when x is time-major, i.e. all loads coalesced).  The forward's warm-up must outlast the circuit's
     memory: with the diode off the state contracts by (1 - 2p) per sample (p = Rc/(R+Rc),
     Rc = 1/(2 C fs)); W is the number of steps that shrinks an O(10 V) error below 1e-7
     (measured miss at the headline circuit: 3e-8 against a verified tolerance of 1e-6).  If W would make chunks more than 2x redundant, fewer chunks are used; if
@@ -43,11 +44,11 @@ def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, r_min=None):
         W = T
     else:
         W = int(math.ceil(math.log(1.0e-8) / math.log(rho)))
-    W = max(8, -(-W // 8) * 8)
-    k_fwd = max(1, min(N_SIMD // waves, T // max(W, 64)))
+    W = max(32, -(-W // 32) * 32)
+    k_fwd = max(1, min((2 * N_SIMD) // waves, T // max(W, 64)))
     if k_fwd < 2:
         k_fwd = 1
-    k_bwd = max(1, min((4 * N_SIMD) // waves, T // 64))
+    k_bwd = max(1, min(((8 if time_major else 4) * N_SIMD) // waves, T // 64))
     return TpPlan(k_fwd, W, float(tol), k_bwd)
 
 
@@ -99,13 +100,17 @@ def clipper(theta, x, fs, r=None, n_up=1, n_down=1, time_major=False, tp=None):
 
 class MseStep:
     """Fused training step for the mean-squared-error loss (lpf.py:78, clipper_pot.py:176):
-    forward, loss and reverse sweep in two kernel launches + two tiny ones, all buffers
+    forward, loss and reverse sweep in two kernel launches + three tiny ones, all buffers
     preallocated.  step() returns device tensors (sse[1], gtheta[4]): the sum of squared errors
-    over THIS batch and d(mean over n_global)/d{Is, nVt, R, C}; nothing synchronises."""
+    over THIS batch and d(mean over n_global)/d{Is, nVt, R, C}; nothing synchronises.
 
-    def __init__(self, B, T, fs, tp, device, n_up=1, n_down=1, n_global=None, with_r=False):
+    time_major: x (and r) are [T,B] -- the layout an engine keeps its training inputs resident
+    in (one transpose when the dataset is loaded; the reference trains on the same train_X
+    for all 501 epochs, clipper_pot.py:245-248), giving fully coalesced loads."""
+
+    def __init__(self, B, T, fs, tp, device, n_up=1, n_down=1, n_global=None, time_major=False):
         self.B, self.T, self.fs, self.tp = B, T, float(fs), tp
-        self.n_up, self.n_down = n_up, n_down
+        self.n_up, self.n_down, self.time_major = n_up, n_down, bool(time_major)
         self.gscale = 2.0 / float(n_global if n_global is not None else B * T)
         L = binding.lib()
         kf, kb = (tp.k_fwd, tp.k_bwd) if tp is not None else (1, 1)
@@ -115,22 +120,25 @@ class MseStep:
         # one fused buffer [sse, dIs, dnVt, dR, dC]: it is also the all-reduce payload
         self.out = torch.zeros((5,), dtype=torch.float32, device=device)
         self.sse, self.gtheta = self.out[0:1], self.out[1:5]
-        self.y = self.zs = None
+        self.y = self.zs = self.zT = None
 
     def forward(self, theta, x, r=None):
         tp = self.tp
         if tp is not None and tp.k_fwd > 1:
-            self.y, self.zs, _, _ = binding.clipper_fwd_tp(x, theta, self.fs, tp.k_fwd, tp.warmup, tp.tol, r=r,
-                                                            n_up=self.n_up, n_down=self.n_down, ws=self.ws_f,
-                                                            status=self.status)
+            self.y, self.zs, self.zT, _ = binding.clipper_fwd_tp(
+                x, theta, self.fs, tp.k_fwd, tp.warmup, tp.tol, r=r, n_up=self.n_up, n_down=self.n_down,
+                want_zT=True, ws=self.ws_f, status=self.status, time_major=self.time_major)
         else:
-            self.y, self.zs, _ = binding.clipper_fwd(x, theta, self.fs, r=r, n_up=self.n_up, n_down=self.n_down)
+            self.y, self.zs, self.zT = binding.clipper_fwd(x, theta, self.fs, r=r, n_up=self.n_up,
+                                                           n_down=self.n_down, want_zT=True,
+                                                           time_major=self.time_major)
         return self.y
 
     def backward(self, theta, x, target, r=None):
         kb = self.tp.k_bwd if self.tp is not None else 1
-        binding.clipper_bwd_mse_tp(x, theta, self.fs, self.zs, self.y, target, self.gscale, kb, r=r, n_up=self.n_up,
-                                   n_down=self.n_down, gtheta=self.gtheta, sse=self.sse, ws=self.ws_b)
+        binding.clipper_bwd_mse_tp(x, theta, self.fs, self.zs, self.zT, target, self.gscale, kb, r=r,
+                                   n_up=self.n_up, n_down=self.n_down, gtheta=self.gtheta, sse=self.sse,
+                                   ws=self.ws_b, time_major=self.time_major)
         return self.sse, self.gtheta
 
     def step(self, theta, x, target, r=None):
@@ -138,34 +146,37 @@ class MseStep:
         return self.backward(theta, x, target, r)
 
 
-class _ClipperStatefulFn(torch.autograd.Function):
-    """Same loop with an explicit initial capacitor state z0 [B] and the final state returned
-    (the reference carries Capacitor.z across forward() calls when a script never calls
-    reset(), lpf.py:30-49)."""
+def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=1, reps=3):
+    """Refine a TpPlan's chunk counts by timing a few candidates on the actual batch (HIP events
+    on the launch stream, a handful of launches each).  Only the chunk counts change -- warm-up
+    and tolerance stay as planned, and every candidate is still verified on the device."""
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+    if plan is None:
+        return plan
 
-    @staticmethod
-    def forward(ctx, theta, x, r, z0, fs, n_up, n_down):
-        need_grad = theta.requires_grad
-        th = theta.detach().contiguous()
-        y, zs, zT = binding.clipper_fwd(x, th, fs, r=r, n_up=n_up, n_down=n_down, want_stash=need_grad,
-                                        z0=z0, want_zT=True)
-        ctx.cfg = (fs, n_up, n_down)
-        ctx.has_r = r is not None
-        if need_grad:
-            ctx.save_for_backward(th, x, zs, *([r] if r is not None else []))
-        ctx.mark_non_differentiable(zT)
-        return y, zT
+    def timed(fn):
+        fn()
+        e0, e1 = binding.Event(), binding.Event()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        return e0.elapsed_ms(e1) / reps
 
-    @staticmethod
-    def backward(ctx, gy, _gzT):
-        fs, n_up, n_down = ctx.cfg
-        saved = ctx.saved_tensors
-        th, x, zs = saved[0], saved[1], saved[2]
-        r = saved[3] if ctx.has_r else None
-        gtheta, _ = binding.clipper_bwd(x, th, fs, zs, gy.contiguous(), r=r, n_up=n_up, n_down=n_down)
-        return gtheta, None, None, None, None, None, None
-
-
-def clipper_stateful(theta, x, fs, r=None, n_up=1, n_down=1, z0=None):
-    """Returns (y [T,B], zT [B])."""
-    return _ClipperStatefulFn.apply(theta, x, r, z0, float(fs), int(n_up), int(n_down))
+    best_f, best_b = plan.k_fwd, plan.k_bwd
+    if plan.k_fwd > 1:
+        cands = sorted({k for k in (plan.k_fwd // 2, plan.k_fwd, plan.k_fwd * 2) if 2 <= k <= T // max(plan.warmup, 64)})
+        times = {}
+        for k in cands:
+            st = MseStep(B, T, fs, plan._replace(k_fwd=k), x.device, n_up=n_up, n_down=n_down, time_major=time_major)
+            times[k] = timed(lambda: st.forward(theta, x))
+        best_f = min(times, key=times.get)
+    st = MseStep(B, T, fs, plan._replace(k_fwd=best_f), x.device, n_up=n_up, n_down=n_down, time_major=time_major)
+    st.forward(theta, x)
+    times = {}
+    for k in sorted({k for k in (plan.k_bwd // 2, plan.k_bwd, plan.k_bwd * 2) if 1 <= k <= max(1, T // 32)}):
+        st.tp = plan._replace(k_fwd=best_f, k_bwd=k)
+        st.ws_b = torch.empty((binding.lib().wdf_clipper_bwd_tp_ws_bytes(B, k),), dtype=torch.uint8, device=x.device)
+        times[k] = timed(lambda: st.backward(theta, x, target))
+    best_b = min(times, key=times.get)
+    return plan._replace(k_fwd=best_f, k_bwd=best_b)

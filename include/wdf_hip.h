@@ -92,8 +92,9 @@ size_t wdf_clipper_bwd_ws_bytes(int64_t B);
 /* ------------------------------------------------------------------------------------
  * Time-parallel variants of the two calls above (same results, more waves in flight; see
  * csrc/wdf_clipper.h "Time-parallel variants").  The time axis is cut into n_chunks chunks
- * (chunk length rounded up to a multiple of 8; wdf_clipper_tp_chunks() returns the number
- * actually used).  Batch-major x only.
+ * (chunk length and warm-up rounded up to multiples of 32; wdf_clipper_tp_chunks() returns the number
+ * actually used).  x may be batch-major [B][T] or, with WDF_X_TIME_MAJOR, [T][B] (an engine
+ * that keeps its training inputs resident in that layout gets fully coalesced loads).
  *
  * wdf_clipper_bwd_tp: EXACT -- the adjoint recurrence is linear, chunk results are combined
  *   by a second tiny kernel; only the (fixed) summation order differs from wdf_clipper_bwd.
@@ -114,13 +115,15 @@ int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta,
                        int64_t B, int64_t T, int n_chunks, int warmup, float tol,
                        void* ws, void* status, int flags, void* stream);
 size_t wdf_clipper_bwd_tp_ws_bytes(int64_t B, int n_chunks);
-/* MSE-fused reverse sweep (lpf.py:78 / clipper_pot.py:176 loss): `y` is the forward output,
- * `target` [T][B] the training target; dL/dy = gscale (y - target) is formed in the kernel
+/* MSE-fused reverse sweep (lpf.py:78 / clipper_pot.py:176 loss): `target` [T][B] is the
+ * training target and zT [B] the forward's final state; the kernel rebuilds y[n] =
+ * (z[n+1] + z[n])/2 from the state stash, forms dL/dy = gscale (y - target) itself
  * (gscale = 2/N for a mean over N samples, N the GLOBAL sample count under data
- * parallelism) and *sse (device float) receives sum (y - target)^2 over this call's batch. */
+ * parallelism) and *sse (device float) receives sum (y - target)^2 over this call's batch.
+ * It reads exactly x, the stash and the target: 12 B/sample. */
 int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta,
                            float fs, int n_up, int n_down,
-                           const float* zstash, const float* y, const float* target, float gscale,
+                           const float* zstash, const float* zT, const float* target, float gscale,
                            void* ws, float* gtheta, float* sse, float* gz0, int accumulate,
                            int64_t B, int64_t T, int n_chunks, int flags, void* stream);
 int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta,
@@ -187,6 +190,24 @@ int wdf_ss_bwd(const float* x, const float* coef, const float* rootp,
                void* ws, float* gcoef, float* groot, float* gz0,
                int64_t B, int64_t T, int flags, void* stream);
 size_t wdf_ss_bwd_ws_bytes(int ns, int ni, int64_t B);
+
+/* ------------------------------------------------------------------------------------
+ * Clipper with two DIFFERENT antiparallel diodes (BASELINE config 5; csrc/wdf_asym.h).  New
+ * API, no reference counterpart (its pairs are copies of one diode, diode_pretraining.py:46-47).
+ * theta6  device float[6] = {Is_up, nVt_up, Is_down, nVt_down, R, C}
+ * mode    WDF_ASYM_OMEGA_F32: fp32 Wright-omega closed form (two-diode form of eqn 39);
+ *         WDF_ASYM_NEWTON_F64: fp64 Newton on the exact Shockley pair, iterated per wave until
+ *         every lane meets |dv| <= tol (|v| + nVt) (wavefront ballot) or max_iter.
+ * iters   optional device int64[(B+63)/64]: Newton iterations each wave ran (sum / (B T / 64
+ *         * ...) gives the mean per sample).  Forward only.
+ * wdf_asym_root: b[i] = root(a[i]) (double out) for accuracy sweeps.
+ * ---------------------------------------------------------------------------------- */
+enum { WDF_ASYM_OMEGA_F32 = 0, WDF_ASYM_NEWTON_F64 = 1 };
+int wdf_clipper_asym_fwd(const float* x, const float* theta6, float fs, int mode, double tol, int max_iter,
+                         float* y, const float* z0, float* zT, long long* iters,
+                         int64_t B, int64_t T, void* stream);
+int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, double tol, int max_iter,
+                  double* b, int64_t n, void* stream);
 
 /* Element-wise diode-pair root and Wright omega on device arrays (n elements): the
  * building blocks above, exposed for parity tests against diode_pretraining.py:39-60 /

@@ -67,6 +67,8 @@ def lib():
         L.oracle_diode_pair_f32.restype = C.c_float
         L.oracle_diode_pair_f32.argtypes = [C.c_float] * 5 + [C.c_int] * 2
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_asym_root_f64.restype = C.c_double
+        L.oracle_asym_root_f64.argtypes = [C.c_double] * 6
         _lib = L
     return _lib
 
@@ -287,6 +289,21 @@ def clipper_mse_step(theta4, fs, x, target, n_up=1, n_down=1, dtype=np.float32, 
     f(_p(th, ct), C.c_double(fs), n_up, n_down, _p(x, ct), _p(tg, ct), _p(y, ct), _p(g, C.c_double),
       C.byref(loss), C.c_int64(B), C.c_int64(T), n_threads)
     return loss.value, g, y
+
+
+def asym_root(a, Rp, Is1, V1, Is2, V2):
+    a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+    return np.array([lib().oracle_asym_root_f64(ai, Rp, Is1, V1, Is2, V2) for ai in a])
+
+
+def clipper_asym_fwd(theta6, fs, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    B, T = x.shape
+    th = np.ascontiguousarray(theta6, dtype=np.float64)
+    y = np.empty((T, B))
+    lib().oracle_clipper_asym_fwd_f64(_p(th, C.c_double), C.c_double(fs), _p(x, C.c_double), _p(y, C.c_double),
+                                      C.c_int64(B), C.c_int64(T))
+    return y
 
 
 def max_threads():

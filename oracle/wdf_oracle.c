@@ -224,4 +224,49 @@ int oracle_clipper_mse_step_f64(const double* th, double fs, int n_up, int n_dow
                                 int64_t B, int64_t T, int n_threads)
 { return clipper_run_f64(th, fs, n_up, n_down, x, NULL, NULL, target, y, g4, loss, 1, B, T, n_threads); }
 
+static double asym_resid(double v, double a, double Rp, double Is1, double V1, double Is2, double V2)
+{
+    return v + Rp * (Is1 * expm1(v / V1) - Is2 * expm1(-v / V2)) - a;
+}
+
+double oracle_asym_root_f64(double a, double Rp, double Is1, double V1, double Is2, double V2)
+{
+    /* the residual is strictly increasing in v and the solution lies between 0 and a */
+    double lo = a < 0.0 ? a : 0.0, hi = a < 0.0 ? 0.0 : a, v = 0.5 * (lo + hi);
+    int it;
+    for (it = 0; it < 200; ++it) {
+        const double f = asym_resid(v, a, Rp, Is1, V1, Is2, V2);
+        const double fp = 1.0 + Rp * (Is1 / V1 * exp(v / V1) + Is2 / V2 * exp(-v / V2));
+        double vn;
+        if (f > 0.0) hi = v; else lo = v;
+        vn = v - f / fp;
+        if (!(vn > lo && vn < hi)) vn = 0.5 * (lo + hi);        /* Newton left the bracket: bisect */
+        if (fabs(vn - v) <= 1e-16 * (fabs(vn) + 1e-300) || hi - lo <= 0.0) { v = vn; break; }
+        v = vn;
+    }
+    return v - Rp * (Is1 * expm1(v / V1) - Is2 * expm1(-v / V2));
+}
+
+int oracle_clipper_asym_fwd_f64(const double* th, double fs, const double* x, double* y, int64_t B, int64_t T)
+{
+    const double Is1 = th[0], V1 = th[1], Is2 = th[2], V2 = th[3], R = th[4], C = th[5];
+    const double G1 = 1.0 / R, G2 = C * (2.0 * fs), G = G1 + G2, Rp = 1.0 / G, p = G1 / G;
+    int64_t b;
+#pragma omp parallel for schedule(static)
+    for (b = 0; b < B; ++b) {
+        double z = 0.0;
+        int64_t t;
+        for (t = 0; t < T; ++t) {
+            const double b_diff = z - x[b * T + t];             /* tf_wdf.py:185-192 */
+            const double b_temp = -p * b_diff;
+            const double a = z + b_temp;
+            const double br = oracle_asym_root_f64(a, Rp, Is1, V1, Is2, V2);
+            const double zn = br + b_temp;                      /* tf_wdf.py:179-183 */
+            y[t * B + b] = 0.5 * (zn + z);                      /* tf_wdf.py:8-10 */
+            z = zn;
+        }
+    }
+    return 0;
+}
+
 int oracle_max_threads(void) { return omp_get_max_threads(); }

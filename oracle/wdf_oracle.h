@@ -157,6 +157,15 @@ int oracle_clipper_mse_step_f64(const double* theta4, double fs, int n_up, int n
                                 double* gtheta4, double* loss,
                                 int64_t B, int64_t T, int n_threads);
 
+/* ---- two DIFFERENT antiparallel diodes (BASELINE config 5; no reference counterpart) ------
+ * i(v) = Is1 (exp(v/V1) - 1) - Is2 (exp(-v/V2) - 1);  root: a = v + Rp i, b = v - Rp i.
+ * Solved by Newton with a bisection safeguard on the monotone residual to 1e-15 relative.
+ * Parity unpinned by the reference; pinned against mpmath in tests/test_oracle_golden.py. */
+double oracle_asym_root_f64(double a, double Rp, double Is1, double V1, double Is2, double V2);
+/* theta6 = {Is1, V1, Is2, V2, R, C}; x [B][T] -> y [T][B] */
+int oracle_clipper_asym_fwd_f64(const double* theta6, double fs, const double* x, double* y,
+                                int64_t B, int64_t T);
+
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

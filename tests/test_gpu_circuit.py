@@ -241,3 +241,66 @@ def test_clip_constraint_applied_by_optimizer(wdf):
     opt = tf.keras.optimizers.Adam(learning_rate=25.0)
     opt.apply_gradients([(tf.constant(1.0), R2.R)])
     assert float(R2.R) == 180.0                                  # tf_wdf.py:74 clip, voltage_divider.png
+
+
+def test_hpf_clipper_topology_vs_oracle(wdf, oracle):
+    """HPFDiodeClipper.h:28-32 topology: Parallel(R, Series(Vs, C)) with a 2U-3D diode-pair root --
+    a tree the two Python scripts do not use (SURVEY 8f #4), through the generic kernel."""
+    tf = wdf.tf
+    O = oracle
+    rng = np.random.default_rng(12)
+    B, T = 40, 700
+    x = (rng.standard_normal((B, T)) * 1.2).astype(np.float32)
+    R = wdf.Resistor(33.0e3, True)
+    Vs = wdf.ResistiveVoltageSource(1.0e3, trainable=True)
+    C = wdf.Capacitor(22.0e-9, FS, True)
+    top = wdf.Parallel(R, wdf.Series(Vs, C))
+    dp = wdf.DiodePair(top, 4.352e-9, Vt=25.85e-3, nDiodes=1.906, N_up=2, N_down=3, trainable=True)
+    circ = wdf.Circuit(top, dp, R)
+    assert (circ.ns, circ.ni) == (1, 1)
+    nodes = [(O.NODE_RESISTOR, -1, -1, 0, -1, -1), (O.NODE_RES_VSOURCE, -1, -1, 1, 0, -1),
+             (O.NODE_CAPACITOR, -1, -1, 2, -1, -1), (O.NODE_SERIES, 1, 2, -1, -1, -1), (O.NODE_PARALLEL, 0, 3, -1, -1, -1)]
+    oc = O.Circuit(nodes, top=4, probe=0, n_in=1, root_kind=O.ROOT_DIODE_PAIR, fs=FS, p_is=3, p_nvt=4, n_up=2, n_down=3)
+    theta = np.array([33.0e3, 1.0e3, 22.0e-9, 4.352e-9, 25.85e-3 * 1.906], dtype=np.float32).astype(np.float64)
+    yref = O.tree_fwd(oc, theta, x.astype(np.float64))
+    y = circ(cuda(x))
+    assert np.max(np.abs(y.numpy() - yref)) < 3e-5
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    grads = tf.GradientTape().gradient(tf.reduce_sum(y * cuda(gy)), [R.R, Vs.R, C.C, dp.Is, dp.nVt])
+    gref = O.tree_grad(oc, theta, x.astype(np.float64), gy.astype(np.float64))
+    assert rel(np.array([float(v) for v in grads]), gref) < 3e-3
+
+
+def test_dataset_shaped_batch_config_c4(wdf, oracle):
+    """BASELINE configs[3] shape: sequences of 2048 samples cut from per-R recordings (clipper_pot.py:58),
+    pot resistance per sequence on the reference's file-name grid, streamed through input channel 1."""
+    from wdf_hip import workload
+    tf = wdf.tf
+    B, T = 1340, 2048                                           # SURVEY 8d: 1340 training sequences of 2048
+    x = workload.sweep_batch(B, T, seed=4)
+    r = workload.pot_resistance_batch(B, T)
+    theta = workload.clipper_theta()
+    Vs = wdf.ResistiveVoltageSource(float(theta[2]))
+    Cap = wdf.Capacitor(float(theta[3]), FS, trainable=True)
+    P1 = wdf.Parallel(Vs, Cap)
+    dp = wdf.DiodePair(P1, float(theta[0]), Vt=float(theta[1]), trainable=True)
+    circ = wdf.Circuit(P1, dp, Cap, per_sample_R=Vs)
+    xin = cuda(np.stack([x, r], axis=-1))
+    with tf.GradientTape() as tape:
+        y = circ(xin)
+        loss = tf.reduce_mean(tf.square(y[50:]))                 # skip_samples = 50 (clipper_pot.py:232)
+    g = tape.gradient(loss, [dp.Is, dp.nVt, Cap.C])
+    pick = np.random.default_rng(0).choice(B, 12, replace=False)
+    th64 = theta.astype(np.float32).astype(np.float64)
+    ref = oracle.clipper_fwd(th64, FS, x[pick].astype(np.float64), r=r[pick].astype(np.float64))
+    assert np.max(np.abs(y.numpy()[:, pick] - ref)) < 3e-5
+    gy = np.zeros((T, B))
+    gy[50:] = 2.0 * y.numpy()[50:] / ((T - 50) * B)
+    _, gref = oracle.clipper_fwd_bwd(th64, FS, x[pick].astype(np.float64), gy[:, pick], r=r[pick].astype(np.float64))
+    # gradient of the picked sequences only: rerun the kernel on that sub-batch
+    circ2 = wdf.Circuit(P1, dp, Cap, per_sample_R=Vs)
+    y2 = circ2(cuda(np.stack([x[pick], r[pick]], axis=-1)))
+    g2 = tf.GradientTape().gradient(tf.reduce_sum(y2 * cuda(gy[:, pick])), [dp.Is, dp.nVt, Cap.C])
+    got = np.array([float(v) for v in g2])
+    assert rel(got, gref[[0, 1, 3]]) < 3e-3
+    assert all(np.isfinite(float(v)) for v in g)

@@ -239,3 +239,23 @@ def test_diode_clipper_f32_twin_and_fd(oracle, golden):
     loss, g4, _ = oracle.clipper_mse_step(theta, 48000.0, x, g["target"], dtype=np.float64)
     assert abs(loss - float(g["loss_1u1d_f64"])) < 1e-14
     assert np.max(np.abs(g4 - adj) / np.abs(adj)) < 1e-12
+
+
+# ---- two different diodes (config C5): the oracle's own root, against mpmath -------------------
+def test_asym_root_vs_mpmath(oracle):
+    import mpmath as mp
+    mp.mp.dps = 40
+    Rp, Is1, V1, Is2, V2 = 2112.0, 4.352e-9, 0.0492701, 2.0e-6, 0.03619
+    for a in (-5.0, -1.2, -0.3, -1e-3, 0.0, 1e-4, 0.25, 0.9, 4.0):
+        f = lambda v: v + Rp * (Is1 * (mp.e ** (v / V1) - 1) - Is2 * (mp.e ** (-v / V2) - 1)) - a   # noqa: E731
+        lo, hi = (mp.mpf(a), mp.mpf(0)) if a < 0 else (mp.mpf(0), mp.mpf(a))
+        v = mp.findroot(f, (lo, hi), solver="illinois", tol=1e-60, maxsteps=400) if a != 0.0 else mp.mpf(0)
+        b_ref = float(2 * v - a)
+        b = oracle.asym_root(a, Rp, Is1, V1, Is2, V2)[0]
+        assert abs(b - b_ref) < 1e-12 * max(1.0, abs(b_ref)), (a, b, b_ref)
+    # equal diodes: the exact pair vs the reference's Wright-omega closed form (eqn 39/45),
+    # which neglects the reverse diode's saturation current: ~2 Rp Is of difference
+    a = np.linspace(-5, 5, 41)
+    exact = oracle.asym_root(a, Rp, Is1, V1, Is1, V1)
+    closed = oracle.diode_pair(a, Rp, Is1, V1, 1.0)
+    assert np.max(np.abs(exact - closed)) < 4 * Rp * Is1

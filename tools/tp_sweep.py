@@ -1,7 +1,9 @@
 """GPU: sweep chunk count / warm-up of the time-parallel kernels at the headline size."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, "differentiable-wdfs_amd/lib")
+import os
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "differentiable-wdfs_amd", "lib"))
 from wdf_hip import binding as wb, workload
 
 B, T, fs = 8192, 4096, workload.FS
@@ -23,15 +25,18 @@ def timeit(fn, n=10):
 y, zs, _ = wb.clipper_fwd(x, th, fs)
 gy = (2.0 * (y - tgt) / y.numel()).contiguous()
 print("seq fwd ms", timeit(lambda: wb.clipper_fwd(x, th, fs)), " seq bwd ms", timeit(lambda: wb.clipper_bwd(x, th, fs, zs, gy)))
-for pack in (False, True):
-    for K in (8, 16, 32, 64, 128):
+zT = wb.clipper_fwd(x, th, fs, want_zT=True)[2]
+xt = x.t().contiguous()
+gscale = 2.0 / y.numel()
+for tm, xin in ((False, x), (True, xt)):
+    for K in (8, 16, 32, 64):
         ws = torch.empty((wb.lib().wdf_clipper_bwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda")
-        g = torch.empty(4, device="cuda")
-        ms = timeit(lambda: wb.clipper_bwd_tp(x, th, fs, zs, gy, K, ws=ws, gtheta=g, pack=pack))
-        print(f"bwd_tp pack={pack} K={K}: {ms:.3f} ms")
-for pack in (False, True):
-    for K, W in ((8, 192), (16, 192), (16, 64), (32, 192), (32, 64), (64, 192), (64, 64), (128, 64)):
+        g = torch.empty(4, device="cuda"); sse = torch.empty(1, device="cuda")
+        ms = timeit(lambda: wb.clipper_bwd_mse_tp(xin, th, fs, zs, zT, tgt, gscale, K, ws=ws, gtheta=g, sse=sse, time_major=tm))
+        print(f"bwd_mse_tp time_major={tm} K={K}: {ms:.3f} ms")
+for tm, xin in ((False, x), (True, xt)):
+    for K, W in ((8, 192), (16, 192), (32, 192)):
         ws = torch.empty((wb.lib().wdf_clipper_fwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda")
         st = torch.empty(4, dtype=torch.int32, device="cuda")
-        ms = timeit(lambda: wb.clipper_fwd_tp(x, th, fs, K, W, ws=ws, status=st, pack=pack))
-        print(f"fwd_tp pack={pack} K={K} W={W}: {ms:.3f} ms  n_bad {wb.tp_status(st)['n_bad']} miss {wb.tp_status(st)['max_miss']:.1e}")
+        ms = timeit(lambda: wb.clipper_fwd_tp(xin, th, fs, K, W, ws=ws, status=st, time_major=tm))
+        print(f"fwd_tp time_major={tm} K={K} W={W}: {ms:.3f} ms  n_bad {wb.tp_status(st)['n_bad']} miss {wb.tp_status(st)['max_miss']:.1e}")
