@@ -26,6 +26,20 @@ import torch  # noqa: E402
 from wdf_hip import binding, dist as wdist, engine, workload  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_c_pmc_traffic.json")
+
+
+def measured_traffic(kernel, cfg):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (profiles/r01_c_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, see its _doc) -- only
+    if they were taken on the configuration being run; otherwise None."""
+    try:
+        d = json.load(open(PMC_TRAFFIC))
+        if all(d["config"].get(k) == v for k, v in cfg.items()) and kernel in d["kernels"]:
+            return d["kernels"][kernel]["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 BYTES_FWD = 12                 # x 4 + y 4 + z-stash 4   (SURVEY 8d: fwd 8 B + 4 B stash)
 BYTES_BWD = 12                 # x 4 + z 4 + dL/dy 4     (the fused-MSE sweep reads y and target instead of
                                # dL/dy, 16 B; the algorithmic figure stays SURVEY's 12)
@@ -155,6 +169,9 @@ def main():
         fname = "clipper_fwd_tp_kernel" if (tp is not None and tp.k_fwd > 1) else "clipper_fwd_kernel"
         dom, dom_ms, dom_bytes = (fname, f_ms, BYTES_FWD) if f_ms >= b_ms else ("clipper_bwd_tp_kernel", b_ms, BYTES_BWD)
         achieved = dom_bytes * B * T / (dom_ms * 1e-3) / 1e9
+        traffic = None if tp is None else measured_traffic(dom, {
+            "B": B, "T": T, "x_layout": "time-major" if tm else "batch-major", "fwd_chunks": tp.k_fwd,
+            "fwd_warmup_steps": tp.warmup, "bwd_chunks": tp.k_bwd})
         out = {
             "metric": "samples/sec fwd+bwd, 1N4148 diode clipper @48kHz batch=8192; 1->8 GPU scaling",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -170,7 +187,8 @@ def main():
                        {"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup, "verify_tol": tp.tol,
                         "bwd_chunks": tp.k_bwd, "verify_status": tp_stat}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": None if traffic is None else "profiles/r01_c_pmc_traffic.json",
                          "algorithmic_bytes_per_sample": dom_bytes,
                          "fwd_kernel_ms": f_ms, "bwd_kernel_ms": b_ms},
         }
