@@ -1,0 +1,114 @@
+"""GPU: the clipper_pot.py workflow end to end on synthetic stand-ins for the missing dataset:
+CSV files in the reference's format and names -> load_diode_data -> batch_data -> ClipperModel
+(the script's own loop, recorded) -> MSE+ESR loss with the script's argument order -> Adam ->
+save the weights as JSON in the plugin's schema.  The "measurement" is the GPU diode-pair
+clipper (north-star root); the model being trained is the reference's tanh-MLP root."""
+import json
+from collections import namedtuple
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+DiodeConfig = namedtuple("DiodeConfig", ["name", "Is", "nabla", "Vt", "N_up", "N_down"])
+D1 = DiodeConfig("1N4148 (1U-1D)", 4.352e-9, 1.906, 25.85e-3, 1, 1)
+
+
+def test_clipper_pot_workflow(tmp_path, golden):
+    import dataimport as di
+    import model_utils as mu
+    import tf_wdf as wdf
+    from tf_wdf import tf
+    from layers import DenseRootModel
+    from wdf_hip import binding as wb
+    from test_gpu_mlp_root import model_json
+
+    FS_DATA = 48000.0
+    C_val = 4.7e-9
+
+    # ---- "measure" the circuit: diode-pair clipper on the GPU, written as the 5 CSVs of 1up1down
+    def simulate(x, R):
+        th = torch.tensor([D1.Is, D1.Vt * D1.nabla, R, C_val], dtype=torch.float32, device="cuda")
+        xd = torch.as_tensor(x[None, :], dtype=torch.float32, device="cuda").contiguous()
+        y, _, _ = wb.clipper_fwd(xd, th, FS_DATA, want_stash=False)
+        return y[:, 0].cpu().numpy()
+
+    secs = di.TIME_REMOVE_PRE + 0.45                          # short recordings keep the test fast
+    files = di.write_synthetic_dataset(tmp_path, simulate, fs=FS_DATA, seconds=secs)
+    assert len(files) == 5
+
+    # ---- clipper_pot.py:48-85
+    train_data, train_N, val_data, val_N, FS = di.load_diode_data(D1, tmp_path)
+    assert FS == FS_DATA and train_N == 4 * val_N
+    batch_size = 2048
+    train_X, train_Y = di.batch_data(train_data, train_N, batch_size)
+    val_X, val_Y = di.batch_data(val_data, val_N, batch_size)
+    assert train_X.shape[1:] == (2048, 2) and val_X.shape[0] >= 1
+
+    # ---- clipper_pot.py:94-127 (the script's ClipperModel, verbatim shape)
+    class ClipperModel(tf.Module):
+        def __init__(self, json):  # noqa: A002
+            super(ClipperModel, self).__init__()
+            self.Vs = wdf.ResistiveVoltageSource(45.0e3)
+            self.C = wdf.Capacitor(C_val, FS)
+            self.P1 = wdf.Parallel(self.Vs, self.C)
+            self.model = DenseRootModel(json)
+
+        def forward(self, input):  # noqa: A002
+            sequence_length = input.shape[1]
+            input = tf.cast(tf.expand_dims(input, axis=-1), dtype=tf.float32)  # noqa: A001
+            output_sequence = tf.TensorArray(dtype=tf.float32, size=sequence_length, clear_after_read=False)
+            self.Vs.reset()
+            self.C.reset()
+            for i in range(sequence_length):
+                self.Vs.set_voltage(input[:, i, 0:1])
+                self.Vs.set_resistance(input[:, i, 1:2])
+                self.P1.calc_impedance()
+                model_in = tf.concat((self.P1.reflected(), tf.math.log(self.P1.R)), axis=1)
+                self.model.incident(tf.transpose(model_in, perm=[0, 2, 1]))
+                self.P1.incident(-1 * self.model.reflected())
+                output = wdf.voltage(self.C)
+                output_sequence = output_sequence.write(i, output)
+            output_sequence = output_sequence.stack()
+            return output_sequence
+
+    eps = np.finfo(float).eps
+
+    def esr_loss(target_y, predicted_y):
+        mse = tf.math.reduce_sum(tf.math.square(target_y - predicted_y))
+        energy = tf.math.reduce_sum(tf.math.square(target_y))
+        loss_unnorm = mse / tf.cast(energy + eps, tf.float32)
+        N = tf.cast((tf.shape(target_y)[0] * tf.shape(target_y)[1]), tf.float32)
+        return tf.sqrt(loss_unnorm / N)
+
+    mse_loss = tf.keras.losses.MeanSquaredError()
+    loss_func = lambda target, pred: mse_loss(target, pred) + esr_loss(target, pred)  # noqa: E731
+    optimizer = tf.keras.optimizers.Adam(learning_rate=0.0001, beta_1=0.5, beta_2=0.999)   # clipper_pot.py:180
+
+    g = golden("g3_mlp_clipper.npz")
+    model = ClipperModel(model_json(g, "2x16_pre"))            # warm start from the PRE-trained weights (clipper_pot.py:132-137)
+    skip_samples = 50
+    tY, vY = tf.constant(train_Y).cuda(), tf.constant(val_Y).cuda()
+    losses = []
+    for epoch in range(8):                                     # clipper_pot.py:245-269
+        with tf.GradientTape() as tape:
+            outs = tf.transpose(model.forward(train_X)[..., 0], perm=[1, 0, 2])
+            loss = loss_func(outs[:, skip_samples:, :], tY[:, skip_samples:, :])
+        val_outs = tf.transpose(model.forward(val_X)[..., 0], perm=[1, 0, 2])
+        val_loss = loss_func(val_outs[:, skip_samples:, :], vY[:, skip_samples:, :])
+        grads = tape.gradient(loss, model.trainable_variables)
+        optimizer.apply_gradients(zip(grads, model.trainable_variables))
+        losses.append((float(loss), float(val_loss)))
+    assert all(np.isfinite(l) and np.isfinite(v) for l, v in losses)
+    # The warm start already fits to 2e-4; Adam's first normalised step (lr per weight on all 609
+    # weights, beta_1 = 0.5) kicks the loss up, after which it must come back down.
+    assert losses[-1][0] < 0.1 * losses[1][0] and losses[-1][1] < 0.1 * losses[1][1], losses
+    # ---- clipper_pot.py:298-331: write the trained root as JSON, reload it
+    out = tmp_path / "model.json"
+    mu.save_model(model.model, out)
+    js = json.load(open(out))
+    assert [l["activation"] for l in js["layers"]] == ["tanh", "tanh", "tanh", ""] and js["in_shape"] == [None, 2]
+    m2 = DenseRootModel(js)
+    assert np.array_equal(m2.layers[0].kernel.numpy(), model.model.layers[0].kernel.numpy())
