@@ -6,9 +6,11 @@
 //     b_diff = z - x ; b_temp = -p b_diff ; a = z + b_temp          Parallel.reflected  tf_wdf.py:185-192
 //     b = -MLP(a, log Rp)                                           layers.py:76-82, DenseLayer :38-39
 //     z' = b + b_temp ; y = (z' + z)/2                              tf_wdf.py:179-183, :8-10
-// One lane per sequence; the network is evaluated per lane in VGPRs with the weights read
-// through the scalar cache (wave-uniform addresses -> s_load + SGPR operands), so the 609
-// weights of a 2x16 net cost no VGPRs and no LDS.  Networks: 2 -> H -> ... -> H -> 1 with NL
+// One lane per sequence; the network is evaluated per lane in VGPRs.  The weights (609 floats
+// for a 2x16 net) are staged once per wave into LDS and read from there with wave-uniform
+// addresses (broadcast ds_read, immediate offsets): left in global memory, LLVM hoists all
+// of them out of the time loop into SGPRs and spills them to VGPR lanes (measured 6300
+// v_readlane per step, 12x slower than the FLOPs warrant).  Networks: 2 -> H -> ... -> H -> 1 with NL
 // tanh layers, H in {4, 8, 16}, NL in {3, 5}: the "2xH" and "4xH" families of
 // wdf_py/diode_clipper/models (n_layers + 1 hidden layers, diode_pretraining.py:113-126).
 // Weight layout (the JSON order, layers.py:31-36): per layer kernel[in][out] row-major, then
@@ -46,55 +48,101 @@ struct Mlp {
     static constexpr int kBo = kWo + H;                 // bias_out [1]
     static constexpr int kCount = kBo + 1;
 
+    // Weights live in LDS (staged once per wave) and are consumed ROW-wise: row i of a layer's
+    // kernel[in][out] is H contiguous floats, fetched with H/4 ds_read_b128 (wave-uniform address:
+    // broadcast) one row ahead of the H FMAs that use it.  A scheduling fence per row keeps the
+    // scheduler from lifting every weight read of the unrolled network to the top of the step
+    // (which needs 600 VGPRs) and keeps the next row's reads in flight under this row's FMAs.
+    static __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&r)[H])
+    {
+#pragma unroll
+        for (int q = 0; q < H / 4; ++q) {
+            const float4 v = reinterpret_cast<const float4*>(p)[q];
+            r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+        }
+    }
+
     // out = MLP(a, lr); act[l][i] keeps the tanh outputs of layer l
     static __device__ __forceinline__ float fwd(const float* __restrict__ w, float a, float lr, float (&act)[NL][H])
     {
+        float acc[H], kr[H], kn[H];
+        // layer 0: acc = bias0 + a k0[0][:] + lr k0[1][:]
+        load_row(w + kB0, acc);
+        load_row(w + kW0, kr);
+        load_row(w + kW0 + H, kn);
 #pragma unroll
-        for (int o = 0; o < H; ++o)
-            act[0][o] = tanh_fast(fmaf(lr, w[kW0 + H + o], fmaf(a, w[kW0 + o], w[kB0 + o])));
+        for (int o = 0; o < H; ++o) acc[o] = fmaf(lr, kn[o], fmaf(a, kr[o], acc[o]));
+        load_row(w + kMid, kr);                               // first row of the next layer (or of the output layer)
+#pragma unroll
+        for (int o = 0; o < H; ++o) act[0][o] = tanh_fast(acc[o]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int l = 1; l < NL; ++l) {
             const float* __restrict__ k = w + kMid + (l - 1) * kMidStride;
+            load_row(k + H * H, acc);                         // bias
 #pragma unroll
-            for (int o = 0; o < H; ++o) {
-                float acc = k[H * H + o];
+            for (int i = 0; i < H; ++i) {
+                if (i + 1 < H) load_row(k + (i + 1) * H, kn);
+                else load_row(k + kMidStride, kn);            // next layer's first row / the output kernel
 #pragma unroll
-                for (int i = 0; i < H; ++i) acc = fmaf(act[l - 1][i], k[i * H + o], acc);
-                act[l][o] = tanh_fast(acc);
+                for (int o = 0; o < H; ++o) acc[o] = fmaf(act[l - 1][i], kr[o], acc[o]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int o = 0; o < H; ++o) kr[o] = kn[o];
             }
+#pragma unroll
+            for (int o = 0; o < H; ++o) act[l][o] = tanh_fast(acc[o]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // kr now holds the output kernel [H][1] (contiguous right after the last hidden layer)
         float out = w[kBo];
 #pragma unroll
-        for (int i = 0; i < H; ++i) out = fmaf(act[NL - 1][i], w[kWo + i], out);
+        for (int i = 0; i < H; ++i) out = fmaf(act[NL - 1][i], kr[i], out);
         return out;
     }
 
-    // d out / d a and d out / d lr from the kept activations
+    // d out / d a and d out / d lr from the kept activations:
+    //   d_L = Wo (.) (1 - h_L^2) ;  d_{l-1}[j] = (sum_i W_l[j][i] d_l[i]) (1 - h_{l-1}[j]^2) ;  row j of W_l is contiguous
     static __device__ __forceinline__ void grad_in(const float* __restrict__ w, const float (&act)[NL][H], float& da,
                                                    float& dlr)
     {
-        float d[H], dn[H];
+        float d[H], dn[H], kr[H], kn[H];
+        load_row(w + kWo, kr);
 #pragma unroll
-        for (int i = 0; i < H; ++i) d[i] = w[kWo + i] * fmaf(-act[NL - 1][i], act[NL - 1][i], 1.0f);
+        for (int i = 0; i < H; ++i) d[i] = kr[i] * fmaf(-act[NL - 1][i], act[NL - 1][i], 1.0f);
 #pragma unroll
         for (int l = NL - 1; l >= 1; --l) {
             const float* __restrict__ k = w + kMid + (l - 1) * kMidStride;
+            load_row(k, kr);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < H; ++j) {
-                float acc = 0.0f;
+                if (j + 1 < H) load_row(k + (j + 1) * H, kn);
+                // four partial sums: a 16-long dependent FMA chain would cost 16 x 7 cycles
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
-                for (int i = 0; i < H; ++i) acc = fmaf(k[j * H + i], d[i], acc);
-                dn[j] = acc * fmaf(-act[l - 1][j], act[l - 1][j], 1.0f);
+                for (int i = 0; i < H; i += 4) {
+                    s0 = fmaf(kr[i], d[i], s0); s1 = fmaf(kr[i + 1], d[i + 1], s1);
+                    s2 = fmaf(kr[i + 2], d[i + 2], s2); s3 = fmaf(kr[i + 3], d[i + 3], s3);
+                }
+                dn[j] = ((s0 + s1) + (s2 + s3)) * fmaf(-act[l - 1][j], act[l - 1][j], 1.0f);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < H) {
+#pragma unroll
+                    for (int i = 0; i < H; ++i) kr[i] = kn[i];
+                }
             }
 #pragma unroll
             for (int j = 0; j < H; ++j) d[j] = dn[j];
         }
+        load_row(w + kW0, kr);
+        load_row(w + kW0 + H, kn);
         da = 0.0f;
         dlr = 0.0f;
 #pragma unroll
         for (int i = 0; i < H; ++i) {
-            da = fmaf(w[kW0 + i], d[i], da);
-            dlr = fmaf(w[kW0 + H + i], d[i], dlr);
+            da = fmaf(kr[i], d[i], da);
+            dlr = fmaf(kn[i], d[i], dlr);
         }
     }
 };
@@ -133,12 +181,15 @@ __device__ __forceinline__ void mlp_step_coeffs(const MlpClipConsts& c, float ri
 template <int H, int NL, bool DYN_R>
 __global__ __launch_bounds__(64) void clipper_mlp_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
-    const float* __restrict__ w, float fs, float* __restrict__ y, float* __restrict__ zstash,
+    const float* __restrict__ w_in, float fs, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T)
 {
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;
     const MlpClipConsts c = mlp_load_consts(theta2, fs);
+    __shared__ __attribute__((aligned(16))) float w[Mlp<H, NL>::kCount + 4];
+    for (int i = threadIdx.x; i < Mlp<H, NL>::kCount; i += 64) w[i] = w_in[i];
+    __syncthreads();
     float z = z0 ? z0[b] : 0.0f;                           // reset(): clipper_pot.py:110-111
     float* __restrict__ yp = y + b;
     float* __restrict__ zp = zstash ? zstash + b : nullptr;
@@ -146,6 +197,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_fwd_kernel(
     const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
     float act[NL][H];
     for (int64_t t = 0; t < T; ++t) {
+        asm volatile("" ::: "memory");      // re-read the weights from LDS every step (see the header comment)
         float p, Rp, lr;
         mlp_step_coeffs<DYN_R>(c, DYN_R ? rp[t] : 1.0f, p, Rp, lr);
         const float b_diff = z - xp[t];
@@ -168,7 +220,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_fwd_kernel(
 template <int H, int NL, bool DYN_R>
 __global__ __launch_bounds__(64) void clipper_mlp_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
-    const float* __restrict__ w, float fs, const float* __restrict__ zstash, const float* __restrict__ gy,
+    const float* __restrict__ w_in, float fs, const float* __restrict__ zstash, const float* __restrict__ gy,
     float* __restrict__ gb, float* __restrict__ ain, float* __restrict__ lrin, double* __restrict__ ws,
     int64_t B, int64_t T)
 {
@@ -176,12 +228,16 @@ __global__ __launch_bounds__(64) void clipper_mlp_bwd_kernel(
     const bool live = b_raw < B;
     const int64_t b = live ? b_raw : B - 1;
     const MlpClipConsts c = mlp_load_consts(theta2, fs);
+    __shared__ __attribute__((aligned(16))) float w[Mlp<H, NL>::kCount + 4];
+    for (int i = threadIdx.x; i < Mlp<H, NL>::kCount; i += 64) w[i] = w_in[i];
+    __syncthreads();
     const float* __restrict__ xp = x + b * T;
     const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
     double dLr = 0.0, dP = 0.0;
     float gz = 0.0f;
     float act[NL][H];
     for (int64_t t = T - 1; t >= 0; --t) {
+        asm volatile("" ::: "memory");      // re-read the weights from LDS every step
         float p, Rp, lr;
         mlp_step_coeffs<DYN_R>(c, DYN_R ? rp[t] : 1.0f, p, Rp, lr);
         const float z = zstash[t * B + b];

@@ -1,0 +1,32 @@
+"""GPU: timing of the MLP-root clipper kernels at the reference's training-set shape
+(1340 sequences x 2048 samples, clipper_pot.py:58 / SURVEY 8d C4)."""
+import os, sys
+import numpy as np, torch
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "differentiable-wdfs_amd", "lib"))
+from wdf_hip import binding as wb, workload
+
+B, T, fs = 1340, 2048, workload.FS
+x = torch.as_tensor(workload.sweep_batch(B, T, seed=4), device="cuda")
+r = torch.as_tensor(workload.pot_resistance_batch(B, T), device="cuda")
+th2 = torch.tensor([45.0e3, 4.7e-9], dtype=torch.float32, device="cuda")
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = wb.Event(), wb.Event()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    return e0.elapsed_ms(e1) / n
+
+
+for hidden, n_tanh in ((4, 3), (8, 3), (16, 3), (8, 5)):
+    nw = wb.lib().wdf_mlp_weight_count(hidden, n_tanh)
+    w = (torch.randn(nw, device="cuda") * 0.3).contiguous()
+    y, zs, _ = wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, fs, r=r)
+    gy = torch.randn_like(y) / y.numel()
+    tf_ = timeit(lambda: wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, fs, r=r))
+    tb_ = timeit(lambda: wb.clipper_mlp_bwd(x, th2, w, hidden, n_tanh, fs, zs, gy, r=r))
+    print(f"{n_tanh - 1}x{hidden}: fwd {tf_:.3f} ms  bwd(kernel) {tb_:.3f} ms   -> {B * T / (tf_ + tb_) / 1e3:.1f} M samples/s (kernels only)")
