@@ -6,7 +6,7 @@
 //     i(v) = Is1 (exp(v/V1) - 1) - Is2 (exp(-v/V2) - 1),   a = v + Rp i,  b = v - Rp i.
 // The reference has no such element (its pairs are N_up/N_down copies of ONE diode,
 // diode_pretraining.py:46-47; chowdsp's DiodeT/DiodePairT are absent), so there is nothing
-// to pin parity against: the oracle is an fp64 safeguarded Newton (oracle/wdf_oracle.c) and
+// to pin parity against: the oracle is an fp64 safeguarded Newton and
 // mpmath in the tests.
 //
 //  NEWTON (fp64): solve v + Rp i(v) - a = 0 per lane, started from the omega closed form,

@@ -492,6 +492,42 @@ int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, con
     return check_launch("wdf_clipper_mlp_grad_reduce");
 }
 
+static unsigned mlp_wgrad_blocks(int64_t S)
+{
+    const int64_t want = (S + 63) / 64;
+    return (unsigned)(want < 2048 ? want : 2048);
+}
+
+int64_t wdf_clipper_mlp_wgrad_ws_bytes(int hidden, int n_tanh_layers, int64_t S)
+{
+    const int64_t count = wdf_mlp_weight_count(hidden, n_tanh_layers);
+    if (count <= 0 || S <= 0) return 0;
+    return (int64_t)mlp_wgrad_blocks(S) * count * (int64_t)sizeof(float);
+}
+
+#define WDF_WGRAD_CASE(H_, NL_)                                                                               \
+    if (hidden == H_ && n_tanh_layers == NL_)                                                                 \
+        hipLaunchKernelGGL((wdf::mlp_wgrad_kernel<H_, NL_>), dim3(nblk, wdf::Mlp<H_, NL_>::kParts), dim3(64), 0, (hipStream_t)stream, ain,  \
+                           lrin, gb, theta2, w, fs, (float*)ws, S);
+
+int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb, const float* theta2, const float* w,
+                          int hidden, int n_tanh_layers, float fs, void* ws, float* gw, int64_t S, void* stream)
+{
+    if (!ain || !gb || !theta2 || !w || !ws || !gw) return fail(WDF_EINVAL, "null ain/gb/theta2/w/ws/gw");
+    if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
+    const int count = wdf_mlp_weight_count(hidden, n_tanh_layers);
+    if (count <= 0)
+        return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
+    const unsigned nblk = mlp_wgrad_blocks(S);
+    WDF_WGRAD_CASE(4, 3) WDF_WGRAD_CASE(8, 3) WDF_WGRAD_CASE(16, 3) WDF_WGRAD_CASE(4, 4) WDF_WGRAD_CASE(8, 4)
+    WDF_WGRAD_CASE(4, 5) WDF_WGRAD_CASE(8, 5)
+    int rc = check_launch("wdf_clipper_mlp_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)ws, (int)nblk, count, gw);
+    return check_launch("wdf_clipper_mlp_wgrad_reduce");
+}
+
 int wdf_omega_f32(const float* x, float* w, int32_t* iters, int64_t n, void* stream)
 {
     if (!x || !w || n <= 0) return fail(WDF_EINVAL, "wdf_omega_f32: bad arguments");

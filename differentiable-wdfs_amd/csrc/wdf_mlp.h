@@ -61,6 +61,30 @@ struct Mlp {
             r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
         }
     }
+    // The same read, but not before `dep` has been computed: the offset goes through an empty asm
+    // that also names dep, so the LDS reads of row i+1 cannot be lifted above the FMAs of row i-1.
+    // (sched_barrier alone does not hold them: instruction selection is free to place loads with
+    // constant addresses at the top of the block, and a 2x16 step then spills 120 VGPRs.)
+    // Measured (1340 x 2048, per-sample R): 2x16 forward 12.0 -> 5.4 ms with the fence; the H <= 8
+    // nets have registers to spare and lose 20% of their prefetch distance to it, so they go without.
+    static constexpr bool kFence = H > 8;
+    static __device__ __forceinline__ void load_row_after(const float* __restrict__ w, int off, float dep, float (&r)[H])
+    {
+        if constexpr (kFence) asm volatile("" : "+v"(off) : "v"(dep));
+        load_row(w + off, r);
+    }
+    // ... not before ALL of dep[0..H) (one dependence would let the other H-1 FMAs of the row be
+    // deferred behind every later load)
+    static __device__ __forceinline__ void load_row_after(const float* __restrict__ w, int off, const float (&dep)[H],
+                                                          float (&r)[H])
+    {
+        static_assert(!kFence || H == 16, "write the operand list for this width");
+        if constexpr (kFence)
+            asm volatile("" : "+v"(off) : "v"(dep[0]), "v"(dep[1]), "v"(dep[2]), "v"(dep[3]), "v"(dep[4]), "v"(dep[5]),
+                         "v"(dep[6]), "v"(dep[7]), "v"(dep[8]), "v"(dep[9]), "v"(dep[10]), "v"(dep[11]), "v"(dep[12]),
+                         "v"(dep[13]), "v"(dep[14]), "v"(dep[15]));
+        load_row(w + off, r);
+    }
 
     // out = MLP(a, lr); act[l][i] keeps the tanh outputs of layer l
     static __device__ __forceinline__ float fwd(const float* __restrict__ w, float a, float lr, float (&act)[NL][H])
@@ -72,18 +96,18 @@ struct Mlp {
         load_row(w + kW0 + H, kn);
 #pragma unroll
         for (int o = 0; o < H; ++o) acc[o] = fmaf(lr, kn[o], fmaf(a, kr[o], acc[o]));
-        load_row(w + kMid, kr);                               // first row of the next layer (or of the output layer)
+        load_row_after(w, kMid, acc, kr);                     // first row of the next layer (or of the output layer)
 #pragma unroll
         for (int o = 0; o < H; ++o) act[0][o] = tanh_fast(acc[o]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int l = 1; l < NL; ++l) {
-            const float* __restrict__ k = w + kMid + (l - 1) * kMidStride;
-            load_row(k + H * H, acc);                         // bias
+            load_row_after(w, kMid + (l - 1) * kMidStride + H * H, act[l - 1], acc);   // bias
 #pragma unroll
             for (int i = 0; i < H; ++i) {
-                if (i + 1 < H) load_row(k + (i + 1) * H, kn);
-                else load_row(k + kMidStride, kn);            // next layer's first row / the output kernel
+                const int koff = kMid + (l - 1) * kMidStride;
+                if (i + 1 < H) load_row_after(w, koff + (i + 1) * H, acc, kn);
+                else load_row_after(w, koff + kMidStride, acc, kn);   // next layer's first row / the output kernel
 #pragma unroll
                 for (int o = 0; o < H; ++o) acc[o] = fmaf(act[l - 1][i], kr[o], acc[o]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -112,12 +136,12 @@ struct Mlp {
         for (int i = 0; i < H; ++i) d[i] = kr[i] * fmaf(-act[NL - 1][i], act[NL - 1][i], 1.0f);
 #pragma unroll
         for (int l = NL - 1; l >= 1; --l) {
-            const float* __restrict__ k = w + kMid + (l - 1) * kMidStride;
-            load_row(k, kr);
+            const int koff = kMid + (l - 1) * kMidStride;
+            load_row_after(w, koff, d[0], kr);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < H; ++j) {
-                if (j + 1 < H) load_row(k + (j + 1) * H, kn);
+                if (j + 1 < H) load_row_after(w, koff + (j + 1) * H, j == 0 ? d[0] : dn[j - 1], kn);
                 // four partial sums: a 16-long dependent FMA chain would cost 16 x 7 cycles
                 float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
@@ -143,6 +167,79 @@ struct Mlp {
         for (int i = 0; i < H; ++i) {
             da = fmaf(kr[i], d[i], da);
             dlr = fmaf(kn[i], d[i], dlr);
+        }
+    }
+
+    // Weight-gradient accumulation for ONE sample: acc += dout * d MLP / d W restricted to `part`
+    // (wave-uniform).  part 0: acc[0..3H) = kernel0 rows (a, lr) + bias0, acc[3H..4H] = output
+    // kernel + output bias.  Mid layer l in 1..NL-1 is split into kSplit row groups (H = 16: two
+    // halves, so that the accumulators fit in 256 VGPRs): part = 1 + (l-1) kSplit + g holds rows
+    // [g kRows, (g+1) kRows) of the kernel [in][out] in acc[0..kRows*H) and, for g = 0, the bias
+    // in acc[kRows*H .. kRows*H + H).
+    static constexpr int kSplit = H > 8 ? 2 : 1;
+    static constexpr int kRows = H / kSplit;
+    static constexpr int kAcc = kRows * H + H;
+    static constexpr int kParts = 1 + (NL - 1) * kSplit;
+    static_assert(kAcc >= 4 * H + 1, "part 0 must fit");
+
+    template <int G>
+    static __device__ __forceinline__ void wgrad_rows(const float (&h)[H], const float (&d)[H], float (&acc)[kAcc])
+    {
+#pragma unroll
+        for (int jj = 0; jj < kRows; ++jj)
+#pragma unroll
+            for (int i = 0; i < H; ++i) acc[jj * H + i] = fmaf(h[G * kRows + jj], d[i], acc[jj * H + i]);
+        if constexpr (G == 0) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) acc[kRows * H + i] += d[i];
+        }
+    }
+
+    static __device__ __forceinline__ void wgrad(const float* __restrict__ w, const float (&act)[NL][H], float a, float lr,
+                                                 float dout, int part, float (&acc)[kAcc])
+    {
+        float d[H], dn[H], kr[H], kn[H];
+        load_row(w + kWo, kr);
+#pragma unroll
+        for (int i = 0; i < H; ++i) d[i] = dout * kr[i] * fmaf(-act[NL - 1][i], act[NL - 1][i], 1.0f);
+        if (part == 0) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) acc[3 * H + i] = fmaf(dout, act[NL - 1][i], acc[3 * H + i]);
+            acc[4 * H] += dout;
+        }
+#pragma unroll
+        for (int l = NL - 1; l >= 1; --l) {
+            if (part == 1 + (l - 1) * kSplit) wgrad_rows<0>(act[l - 1], d, acc);
+            if constexpr (kSplit == 2) {
+                if (part == 2 + (l - 1) * kSplit) wgrad_rows<1>(act[l - 1], d, acc);
+            }
+            const float* __restrict__ k = w + kMid + (l - 1) * kMidStride;
+            load_row(k, kr);
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                if (j + 1 < H) load_row(k + (j + 1) * H, kn);
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < H; i += 4) {
+                    s0 = fmaf(kr[i], d[i], s0); s1 = fmaf(kr[i + 1], d[i + 1], s1);
+                    s2 = fmaf(kr[i + 2], d[i + 2], s2); s3 = fmaf(kr[i + 3], d[i + 3], s3);
+                }
+                dn[j] = ((s0 + s1) + (s2 + s3)) * fmaf(-act[l - 1][j], act[l - 1][j], 1.0f);
+                if (j + 1 < H) {
+#pragma unroll
+                    for (int i = 0; i < H; ++i) kr[i] = kn[i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < H; ++j) d[j] = dn[j];
+        }
+        if (part == 0) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                acc[i] = fmaf(a, d[i], acc[i]);
+                acc[H + i] = fmaf(lr, d[i], acc[H + i]);
+                acc[2 * H + i] += d[i];
+            }
         }
     }
 };
@@ -302,6 +399,61 @@ __global__ __launch_bounds__(256) void clipper_mlp_grad_reduce_kernel(const doub
             gtheta2[1] = (float)(-2.0 * (double)fs * Rp * (SP * p + SL));
         }
     }
+}
+
+// Weight gradient of the MLP root: gw = -sum_n gb[n] dMLP(ain[n], lr[n])/dW over S = B*T
+// samples (lrin == nullptr: lr = log Rp from theta2).  grid = (nblk, Mlp::kParts): blockIdx.y is the
+// layer part (Mlp::wgrad); each wave writes its slice of ws [nblk][kCount].
+template <int H, int NL>
+__global__ __launch_bounds__(64) void mlp_wgrad_kernel(
+    const float* __restrict__ ain, const float* __restrict__ lrin, const float* __restrict__ gb,
+    const float* __restrict__ theta2, const float* __restrict__ w_in, float fs, float* __restrict__ ws, int64_t S)
+{
+    using M = Mlp<H, NL>;
+    __shared__ __attribute__((aligned(16))) float w[M::kCount + 4];
+    for (int i = threadIdx.x; i < M::kCount; i += 64) w[i] = w_in[i];
+    __syncthreads();
+    const int part = blockIdx.y;
+    const float lr_static = mlp_load_consts(theta2, fs).lr;
+    float acc[M::kAcc];
+#pragma unroll
+    for (int i = 0; i < M::kAcc; ++i) acc[i] = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 64;
+    float act[NL][H];
+    for (int64_t n0 = (int64_t)blockIdx.x * 64; n0 < S; n0 += stride) {
+        const int64_t n_raw = n0 + threadIdx.x;
+        const int64_t n = n_raw < S ? n_raw : S - 1;
+        const float a = ain[n];
+        const float lr = lrin ? lrin[n] : lr_static;
+        const float dout = n_raw < S ? -gb[n] : 0.0f;          // L depends on b_root = -MLP
+        (void)M::fwd(w, a, lr, act);
+        M::wgrad(w, act, a, lr, dout, part, acc);
+    }
+    // where acc[i] goes in the flat weight vector (-1: unused slot)
+    const int l = part == 0 ? 0 : 1 + (part - 1) / M::kSplit, g = part == 0 ? 0 : (part - 1) % M::kSplit;
+    const int layer = M::kMid + (l - 1) * M::kMidStride;
+    float* __restrict__ o = ws + (int64_t)blockIdx.x * M::kCount;
+#pragma unroll
+    for (int i = 0; i < M::kAcc; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        int dst;
+        if (part == 0) dst = i < 3 * H ? i : (i <= 4 * H ? M::kWo + (i - 3 * H) : -1);
+        else if (i < M::kRows * H) dst = layer + g * M::kRows * H + i;
+        else dst = g == 0 ? layer + H * H + (i - M::kRows * H) : -1;
+        if (threadIdx.x == 0 && dst >= 0) o[dst] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(const float* __restrict__ ws, int nblk, int count,
+                                                               float* __restrict__ gw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)ws[(int64_t)b * count + i];
+    gw[i] = (float)s;
 }
 
 }  // namespace wdf

@@ -68,6 +68,10 @@ def lib():
     L.wdf_clipper_mlp_fwd.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, i64, i64, ci, vp]
     L.wdf_clipper_mlp_bwd.restype = ci
     L.wdf_clipper_mlp_bwd.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, fp, vp, fp, i64, i64, ci, vp]
+    L.wdf_clipper_mlp_wgrad_ws_bytes.restype = i64
+    L.wdf_clipper_mlp_wgrad_ws_bytes.argtypes = [ci, ci, i64]
+    L.wdf_clipper_mlp_wgrad.restype = ci
+    L.wdf_clipper_mlp_wgrad.argtypes = [fp, fp, fp, fp, fp, ci, ci, cf, vp, fp, i64, vp]
     L.wdf_ss_ncoef.restype = ci
     L.wdf_ss_ncoef.argtypes = [ci, ci]
     L.wdf_ss_fwd.restype = ci
@@ -98,6 +102,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_asym_fwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd",
+    "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
     "wdf_omega_f32", "wdf_diode_pair_f32",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy",
@@ -314,6 +319,28 @@ def clipper_mlp_bwd(x, theta2, w, hidden, n_tanh, fs, zstash, gy, r=None):
                                    B, T, 0, _stream())
     _check(rc, "wdf_clipper_mlp_bwd")
     return gth, gb, ain, lrin
+
+
+def clipper_mlp_wgrad(ain, lrin, gb, theta2, w, hidden, n_tanh, fs):
+    """-> gw [wdf_mlp_weight_count]: dL/dw from what clipper_mlp_bwd wrote (see include/wdf_hip.h)."""
+    require_gpu()
+    ain = _f32_dev(ain, "ain")
+    lrin = _f32_dev(lrin, "lrin")
+    gb = _f32_dev(gb, "gb")
+    theta2 = _f32_dev(theta2, "theta2")
+    w = _f32_dev(w, "w")
+    S = ain.numel()
+    if gb.numel() != S or (lrin is not None and lrin.numel() != S):
+        raise WdfHipError("clipper_mlp_wgrad: ain, lrin and gb must have the same number of samples")
+    nbytes = lib().wdf_clipper_mlp_wgrad_ws_bytes(int(hidden), int(n_tanh), S)
+    if nbytes <= 0:
+        raise WdfHipError(f"unsupported MLP root: width {hidden}, {n_tanh} tanh layers")
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=ain.device)
+    gw = torch.empty((w.numel(),), dtype=torch.float32, device=ain.device)
+    rc = lib().wdf_clipper_mlp_wgrad(_ptr(ain), _ptr(lrin), _ptr(gb), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh),
+                                     float(fs), _ptr(ws), _ptr(gw), S, _stream())
+    _check(rc, "wdf_clipper_mlp_wgrad")
+    return gw
 
 
 ASYM_OMEGA_F32, ASYM_NEWTON_F64 = 0, 1

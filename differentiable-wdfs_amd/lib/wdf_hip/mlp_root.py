@@ -1,16 +1,13 @@
 """Host side of the MLP-root diode clipper (csrc/wdf_mlp.h): weight flattening, the autograd
-Function, and the dense weight-gradient pass.
+Function and the data-level time-parallel segmentation.
 
 The per-lane reverse-sweep kernel returns g_b[n] = dL/d b[n] and the network inputs
-(a[n], log R[n]); the weight gradient  dL/dW = -sum_n g_b[n] dMLP(a[n], lr[n])/dW  is then a
-batched-MLP backward over B*T independent samples: plain GEMMs, run through torch
-(hipBLASLt) in chunks.  That is the one place this package uses library GEMMs."""
+(a[n], log R[n]); the weight gradient  dL/dW = -sum_n g_b[n] dMLP(a[n], lr[n])/dW  is a sum
+over B*T independent samples, done by wdf_clipper_mlp_wgrad (fully parallel HIP kernel)."""
 import torch
 
 from . import binding
 from . import compat_tf as tf
-
-_DENSE_CHUNK = 1 << 22        # samples per chunk of the dense pass (activations: chunk x 16 x 4 B x layers)
 
 
 def describe(model):
@@ -39,65 +36,126 @@ def flat_weights(dense):
     return torch.cat(parts)
 
 
-def _dense_forward(w, hidden, n_tanh, inp):
-    """MLP(inp [N,2]) -> [N] with the flat weight vector w (same layout as the kernel)."""
-    o = 0
-    h = inp
-    n_in = 2
-    for _ in range(n_tanh):
-        k = w[o:o + n_in * hidden].reshape(n_in, hidden)
-        o += n_in * hidden
-        b = w[o:o + hidden]
-        o += hidden
-        h = torch.tanh(h @ k + b)
-        n_in = hidden
-    k = w[o:o + hidden].reshape(hidden, 1)
-    o += hidden
-    return (h @ k)[:, 0] + w[o]
-
-
 class _ClipperMlpFn(torch.autograd.Function):
     """y [T,B] = clipper_mlp(theta2 = {R, C}, w, x [B,T] (, r [B,T]))."""
 
     @staticmethod
-    def forward(ctx, theta2, w, x, r, z0, fs, hidden, n_tanh, want_zT):
+    def forward(ctx, theta2, w, x, r, z0, fs, hidden, n_tanh, want_zT, want_stash=False):
         need = theta2.requires_grad or w.requires_grad
         th, wd = theta2.detach().contiguous(), w.detach().contiguous()
-        y, zs, zT = binding.clipper_mlp_fwd(x, th, wd, hidden, n_tanh, fs, r=r, want_stash=need, z0=z0,
-                                            want_zT=want_zT)
+        y, zs, zT = binding.clipper_mlp_fwd(x, th, wd, hidden, n_tanh, fs, r=r, want_stash=need or want_stash,
+                                            z0=z0, want_zT=want_zT)
         ctx.cfg = (fs, hidden, n_tanh, r is not None)
         if need:
             ctx.save_for_backward(th, wd, x, zs, *([r] if r is not None else []))
         if want_zT:
             ctx.mark_non_differentiable(zT)
+        if want_stash:
+            zs_out = zs.detach()
+            ctx.mark_non_differentiable(zs_out)
+            return y, zT, zs_out
         return y, zT
 
     @staticmethod
-    def backward(ctx, gy, _gzT):
+    def backward(ctx, gy, *_unused):
         fs, hidden, n_tanh, has_r = ctx.cfg
         saved = ctx.saved_tensors
         th, wd, x, zs = saved[:4]
         r = saved[4] if has_r else None
         gth, gb, ain, lrin = binding.clipper_mlp_bwd(x, th, wd, hidden, n_tanh, fs, zs, gy.contiguous(), r=r)
-        # dense weight-gradient pass: dL/dw = -sum_n gb[n] dMLP(a[n], lr[n])/dw
-        a_flat, g_flat = ain.reshape(-1), gb.reshape(-1)
-        if lrin is not None:
-            lr_flat = lrin.reshape(-1)
-        else:
-            R, C = th[0].double(), th[1].double()
-            lr_const = torch.log(1.0 / (1.0 / R + 2.0 * C * fs)).float()
-            lr_flat = None
-        gw = torch.zeros_like(wd)
-        n = a_flat.numel()
-        with torch.enable_grad():
-            for s in range(0, n, _DENSE_CHUNK):
-                e = min(n, s + _DENSE_CHUNK)
-                wv = wd.detach().requires_grad_(True)
-                lr_c = lr_flat[s:e] if lr_flat is not None else lr_const.expand(e - s)
-                out = _dense_forward(wv, hidden, n_tanh, torch.stack([a_flat[s:e], lr_c], dim=1))
-                proxy = -(g_flat[s:e] * out).sum()
-                gw += torch.autograd.grad(proxy, wv)[0]
-        return gth, gw, None, None, None, None, None, None, None
+        # weight gradient: dL/dw = -sum_n gb[n] dMLP(a[n], lr[n])/dw, all B*T samples in parallel
+        gw = binding.clipper_mlp_wgrad(ain, lrin, gb, th, wd, hidden, n_tanh, fs)
+        return gth, gw, None, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------ time-parallel segments
+# The MLP kernels are sequential in time; with the reference's training set (1340 sequences,
+# clipper_pot.py:58) that is 21 waves on a 1024-SIMD chip.  More parallelism is obtained at the
+# DATA level, with no extra device code: the time axis is cut into K chunks and every chunk but
+# the first becomes its own "sequence" that starts W steps early from z = 0 (the circuit forgets
+# its state: |dz'/dz| < 1; the reference itself discards the first 50 outputs, clipper_pot.py:232).
+# The outputs of the W warm-up steps are dropped, so autograd sends no gradient there, and the
+# adjoint that would cross a chunk boundary flows through the next chunk's warm-up copy of the
+# same samples instead (overlapped truncated BPTT; the truncation error decays like the
+# forward's).  The state each chunk arrives with is compared with the state the previous chunk
+# ended in; if any differ by more than tol the call is redone sequentially.
+_R_MAX_CACHE = {}
+
+
+def _r_max(r):
+    key = (r.data_ptr(), tuple(r.shape), r._version)
+    if key not in _R_MAX_CACHE:
+        if len(_R_MAX_CACHE) > 64:
+            _R_MAX_CACHE.clear()
+        _R_MAX_CACHE[key] = float(r.max())
+    return _R_MAX_CACHE[key]
+
+
+def segment_plan(B, T, R_slowest, C, fs, tol=1.0e-6):
+    """(K, L, W) or None.  W outlasts the slowest (largest-R) sequence's memory; chunks are at
+    least W long (<= 2x redundant work); no more chunks than it takes to fill the chip."""
+    import math
+    Rc = 1.0 / (2.0 * float(C) * float(fs))
+    rho = abs(1.0 - 2.0 * Rc / (float(R_slowest) + Rc))
+    if rho >= 1.0 - 1e-9:
+        return None
+    W = 8 if rho <= 0.0 else int(math.ceil(math.log(0.01 * tol) / math.log(rho)))
+    W = max(8, -(-W // 8) * 8)
+    waves = max(1, -(-B // 64))
+    K = min(T // max(W, 64), max(1, 2048 // waves))
+    if K < 2:
+        return None
+    L = -(-(-(-T // K)) // 8) * 8
+    K = -(-T // L)
+    return (K, L, W) if K >= 2 and L >= W else None
+
+
+def clipper_mlp_segmented(theta2, w, x, r, fs, hidden, n_tanh, plan, tol=1.0e-6, z0=None):
+    """y [T,B] and the final state [B] through K overlapping segments; redone sequentially if the
+    verification fails.  Returns (y, zT, max_miss)."""
+    K, L, W = plan
+    B, T = x.shape
+    Tp = K * L
+    xp, rp = x, r
+    if Tp > T:                                               # pad the tail (outputs dropped below)
+        xp = torch.nn.functional.pad(x, (0, Tp - T))
+        if r is not None:
+            rp = torch.cat([r, r[:, -1:].expand(B, Tp - T)], dim=1)
+    y0, zT0, _ = _ClipperMlpFn.apply(theta2, w, xp[:, :L].contiguous(), None if r is None else rp[:, :L].contiguous(),
+                                     z0, fs, hidden, n_tanh, True, True)
+
+    def segments(v):
+        return torch.stack([v[:, k * L - W:(k + 1) * L] for k in range(1, K)], dim=0).reshape((K - 1) * B, W + L)
+
+    ys, zTs, zss = _ClipperMlpFn.apply(theta2, w, segments(xp).contiguous(), None if r is None else segments(rp).contiguous(),
+                                       None, fs, hidden, n_tanh, True, True)
+    # verification: the state each segment has after its warm-up vs the state its predecessor ended in
+    arrive = zss[W].reshape(K - 1, B)
+    ended = torch.cat([zT0.reshape(1, B), zTs.reshape(K - 1, B)[:-1]], dim=0)
+    miss = float((arrive.detach() - ended.detach()).abs().max())
+    if not miss <= tol:
+        y, zT = _ClipperMlpFn.apply(theta2, w, x.contiguous(), None if r is None else r.contiguous(),
+                                    z0, fs, hidden, n_tanh, True, False)
+        return y, zT, miss
+    y = torch.cat([y0, ys[W:].reshape(L, K - 1, B).permute(1, 0, 2).reshape((K - 1) * L, B)], dim=0)[:T]
+    last = T - (K - 1) * L                                   # true steps in the last segment
+    zT = zTs.reshape(K - 1, B)[-1] if last == L else zss[W + last].reshape(K - 1, B)[-1]
+    return y, zT, miss
+
+
+def clipper_mlp(theta2, w, x, r, z0, fs, hidden, n_tanh, C, R_static=None, time_parallel="auto"):
+    """The MLP-root clipper over a batch: segmented when the plan allows, else the sequential
+    kernels.  Returns (y [T,B], zT [B])."""
+    if time_parallel == "auto":
+        plan = segment_plan(x.shape[0], x.shape[1], _r_max(r) if r is not None else float(R_static), float(C), fs)
+        if plan is not None:
+            y, zT, miss = clipper_mlp_segmented(theta2, w, x, r, fs, hidden, n_tanh, plan, z0=z0)
+            LAST_SEGMENT_MISS["miss"] = miss
+            return y, zT
+    return _ClipperMlpFn.apply(theta2, w, x, r, z0, fs, hidden, n_tanh, True)
+
+
+LAST_SEGMENT_MISS = {"miss": None}
 
 
 def run_clipper_mlp(circ, x, z0, return_state):
@@ -115,6 +173,7 @@ def run_clipper_mlp(circ, x, z0, return_state):
     r = x[:, :, 1].contiguous() if circ.per_sample_R is not None else None
     xv = x[:, :, 0].contiguous()
     z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(-1).contiguous()
-    y, zT = _ClipperMlpFn.apply(theta2, w, xv, r, z0t, float(cap.FS), hidden, n_tanh, bool(return_state))
+    y, zT = clipper_mlp(theta2, w, xv, r, z0t, float(cap.FS), hidden, n_tanh, float(cap.C), R_static=Rv,
+                        time_parallel=getattr(circ, "time_parallel", None))
     y = y.as_subclass(tf.Tensor)
     return (y, zT.reshape(1, -1)) if return_state else y

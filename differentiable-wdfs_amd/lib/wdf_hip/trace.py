@@ -504,7 +504,7 @@ class Recorder:
             dense, hidden, n_tanh = mlp_root.describe(self.root)
             theta2 = torch.stack([torch.tensor(1.0), cap.C.as_subclass(torch.Tensor).float().reshape(())]).to(dev)
             w = mlp_root.flat_weights(dense).float().to(dev)
-            y_tb, zT = mlp_root._ClipperMlpFn.apply(theta2, w, x, r, z0v, float(cap.FS), hidden, n_tanh, True)
+            y_tb, zT = mlp_root.clipper_mlp(theta2, w, x, r, z0v, float(cap.FS), hidden, n_tanh, float(cap.C))
         else:
             raise WdfTraceError(f"unsupported root {root_kind} with a per-sample resistance")
         return y_tb, zT.reshape(1, -1)
@@ -529,7 +529,7 @@ class Recorder:
         w = mlp_root.flat_weights(dense).float().to(dev)
         x = self._gather_inputs([self.inputs[0][0]], dev)[:, :, 0].contiguous()
         z0v = None if z0 is None else z0[0].contiguous()
-        y_tb, zT = mlp_root._ClipperMlpFn.apply(theta2, w, x, None, z0v, float(cap.FS), hidden, n_tanh, True)
+        y_tb, zT = mlp_root.clipper_mlp(theta2, w, x, None, z0v, float(cap.FS), hidden, n_tanh, float(C), R_static=float(R))
         return y_tb, zT.reshape(1, -1)
 
 

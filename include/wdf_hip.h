@@ -144,10 +144,13 @@ int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta,
  * w       device float[wdf_mlp_weight_count()]: per layer kernel[in][out] then bias[out]
  *         (the JSON "weights" order, layers.py:31-36)
  * theta2  device float[2] = {R, C}; r: optional [B][T] per-sample resistance (clipper_pot.py:116)
- * bwd:    gy [T][B] -> gtheta2[2] = dL/d{R, C} (R entry 0 when r != NULL), and for the dense
- *         weight-gradient pass on the host side: gb [T][B] = dL/d(root output b = -MLP),
- *         ain [T][B] = a, lrin [T][B] = log P1.R (written only when r != NULL).
- *         dL/dw = -sum_n gb[n] dMLP(ain[n], lrin[n])/dw  is a plain batched-MLP backward.
+ * bwd:    gy [T][B] -> gtheta2[2] = dL/d{R, C} (R entry 0 when r != NULL), and for the
+ *         weight-gradient pass: gb [T][B] = dL/d(root output b = -MLP), ain [T][B] = a,
+ *         lrin [T][B] = log P1.R (written only when r != NULL).
+ * wgrad:  gw[wdf_mlp_weight_count()] = dL/dw = -sum_n gb[n] dMLP(ain[n], lrin[n])/dw over the
+ *         S = B*T samples bwd wrote (lrin NULL: log P1.R from theta2); what tape.gradient
+ *         returns for model.trainable_variables (clipper_pot.py:181-184).  ws: scratch of
+ *         wdf_clipper_mlp_wgrad_ws_bytes() bytes.  Deterministic (fixed-order reduction).
  * ---------------------------------------------------------------------------------- */
 int wdf_mlp_weight_count(int hidden, int n_tanh_layers);
 int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, const float* w,
@@ -159,6 +162,10 @@ int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, con
                         const float* zstash, const float* gy,
                         float* gb, float* ain, float* lrin, void* ws, float* gtheta2,
                         int64_t B, int64_t T, int flags, void* stream);
+int64_t wdf_clipper_mlp_wgrad_ws_bytes(int hidden, int n_tanh_layers, int64_t S);
+int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb,
+                          const float* theta2, const float* w, int hidden, int n_tanh_layers,
+                          float fs, void* ws, float* gw, int64_t S, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Generic tree + one root, as a state-space recursion (csrc/wdf_statespace.h):

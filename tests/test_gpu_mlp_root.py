@@ -112,3 +112,74 @@ def test_unsupported_network_is_an_error(golden):
     circ = wdf.Circuit(P1, DenseRootModel(js), C)
     with pytest.raises(binding.WdfHipError):
         circ(cuda(np.zeros((2, 16))))
+
+
+def test_segmented_time_parallel_matches_sequential(golden):
+    """Data-level time parallelism of the MLP path: K overlapping segments == the sequential run
+    (outputs within the verified 1e-6, gradients within 1e-4 relative), and a circuit whose
+    memory outlasts the segments falls back to the sequential call."""
+    import tf_wdf as wdf
+    from tf_wdf import tf
+    from layers import DenseRootModel, DenseLayer
+    from wdf_hip import mlp_root, workload
+    g = golden("g3_mlp_clipper.npz")
+    B, T = 96, 2048
+    x = workload.sweep_batch(B, T, seed=9) * 0.6
+    r = workload.pot_resistance_batch(B, T)
+    xin = cuda(np.stack([x, r], axis=-1))
+    gy = cuda(np.random.default_rng(1).standard_normal((T, B)) / (B * T))
+
+    def run(tp):
+        Vs = wdf.ResistiveVoltageSource(45.0e3)
+        C = wdf.Capacitor(float(g["C"]), FS, trainable=True)
+        P1 = wdf.Parallel(Vs, C)
+        model = DenseRootModel(model_json(g, "2x8"))
+        circ = wdf.Circuit(P1, model, C, per_sample_R=Vs, time_parallel=tp)
+        y = circ(xin)
+        dense = [l for l in model.layers if isinstance(l, DenseLayer)]
+        grads = tf.GradientTape().gradient(tf.reduce_sum(y * gy), [C.C, dense[0].kernel, dense[2].kernel, dense[3].bias])
+        return y, [gr.numpy().ravel() for gr in grads]
+
+    assert mlp_root.segment_plan(B, T, 99.1e3, float(g["C"]), FS) is not None
+    mlp_root.LAST_SEGMENT_MISS["miss"] = None
+    y_seq, g_seq = run(None)
+    y_tp, g_tp = run("auto")
+    assert mlp_root.LAST_SEGMENT_MISS["miss"] is not None and mlp_root.LAST_SEGMENT_MISS["miss"] <= 1e-6
+    assert float((y_tp - y_seq).abs().max()) <= 2e-6
+    for a, b in zip(g_tp, g_seq):
+        assert np.max(np.abs(a - b)) <= 1e-4 * np.max(np.abs(b)) + 1e-12
+    # too-short segments are caught by the verification and the result is still the sequential one
+    y_bad, _, miss = mlp_root.clipper_mlp_segmented(
+        cuda([45.0e3, float(g["C"])]), mlp_root.flat_weights([l for l in DenseRootModel(model_json(g, "2x8")).layers
+                                                             if isinstance(l, DenseLayer)]).float().cuda(),
+        cuda(x), cuda(r), float(FS), 8, 3, (8, 256, 16))
+    assert miss > 1e-6 and float((y_bad - y_seq).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("hidden,n_tanh", [(4, 3), (8, 3), (16, 3), (8, 4), (4, 5), (8, 5)])
+@pytest.mark.parametrize("dyn", [False, True])
+def test_wgrad_kernel_matches_dense_autograd(hidden, n_tanh, dyn):
+    """wdf_clipper_mlp_wgrad == -sum_n gb[n] dMLP(a[n], lr[n])/dw by float64 torch autograd of the
+    same network (tolerance 2e-5 of the largest entry: fp32 per-lane accumulation, double reduction)."""
+    import torch
+    from wdf_hip import binding as wb
+    rng = np.random.default_rng(hidden * 10 + n_tanh)
+    S = 64 * 700 + 37                                  # ragged: the tail lanes must contribute nothing
+    nw = wb.lib().wdf_mlp_weight_count(hidden, n_tanh)
+    w = cuda(rng.standard_normal(nw) * 0.4)
+    a = cuda(rng.standard_normal(S) * 2.0)
+    gb = cuda(rng.standard_normal(S) / S)
+    th2 = cuda([45.0e3, 4.7e-9])
+    lr = cuda(np.log(rng.uniform(100.0, 2.0e3, S))) if dyn else None
+    gw = wb.clipper_mlp_wgrad(a, lr, gb, th2, w, hidden, n_tanh, FS)
+    wd = w.double().requires_grad_(True)
+    lr_d = lr.double() if dyn else torch.log(1.0 / (1.0 / th2[0].double() + 2.0 * th2[1].double() * FS)).expand(S)
+    h, o, n_in = torch.stack([a.double(), lr_d], dim=1), 0, 2
+    for _ in range(n_tanh):
+        k = wd[o:o + n_in * hidden].reshape(n_in, hidden); o += n_in * hidden
+        h = torch.tanh(h @ k + wd[o:o + hidden]); o += hidden
+        n_in = hidden
+    out = (h @ wd[o:o + hidden].reshape(hidden, 1))[:, 0] + wd[o + hidden]
+    want = torch.autograd.grad(-(gb.double() * out).sum(), wd)[0]
+    err = float((gw.double() - want).abs().max())
+    assert err <= 2e-5 * float(want.abs().max()), (err, float(want.abs().max()))

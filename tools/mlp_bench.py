@@ -30,3 +30,23 @@ for hidden, n_tanh in ((4, 3), (8, 3), (16, 3), (8, 5)):
     tf_ = timeit(lambda: wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, fs, r=r))
     tb_ = timeit(lambda: wb.clipper_mlp_bwd(x, th2, w, hidden, n_tanh, fs, zs, gy, r=r))
     print(f"{n_tanh - 1}x{hidden}: fwd {tf_:.3f} ms  bwd(kernel) {tb_:.3f} ms   -> {B * T / (tf_ + tb_) / 1e3:.1f} M samples/s (kernels only)")
+
+# whole training step (forward + autograd backward incl. the dense weight-gradient pass):
+# sequential kernels vs the data-level segmented time-parallel path, static R and per-sample R
+from wdf_hip import mlp_root
+for R_kind in ("static 45k", "per-sample pot"):
+    rr = r if R_kind != "static 45k" else None
+    for hidden, n_tanh in ((8, 3), (16, 3)):
+        nw = wb.lib().wdf_mlp_weight_count(hidden, n_tanh)
+        w = (torch.randn(nw, device="cuda") * 0.3).requires_grad_(True)
+        th = th2.clone().requires_grad_(True)
+        gy = torch.randn(T, B, device="cuda") / (T * B)
+
+        def step(tp):
+            y, _ = mlp_root.clipper_mlp(th, w, x, rr, None, fs, hidden, n_tanh, 4.7e-9, R_static=45.0e3, time_parallel=tp)
+            torch.autograd.grad((y * gy).sum(), [th, w])
+
+        t_seq, t_tp = timeit(lambda: step(None), 3), timeit(lambda: step("auto"), 3)
+        plan = mlp_root.segment_plan(B, T, mlp_root._r_max(rr) if rr is not None else 45.0e3, 4.7e-9, fs)
+        print(f"step {n_tanh - 1}x{hidden} R {R_kind}: sequential {t_seq:.2f} ms, segmented {t_tp:.2f} ms "
+              f"(plan K,L,W={plan}, miss={mlp_root.LAST_SEGMENT_MISS['miss']})")
