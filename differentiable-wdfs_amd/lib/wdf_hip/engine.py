@@ -20,8 +20,9 @@ TpPlan = namedtuple("TpPlan", ["k_fwd", "warmup", "tol", "k_bwd"])
 N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
 
 
-def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, r_min=None, time_major=False):
-    """Choose chunk counts from the batch shape and the circuit's memory.
+def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, time_major=False):
+    """Choose chunk counts from the batch shape and the circuit's memory.  R: the source
+    resistance; with a per-sample resistance pass the LARGEST value present (slowest memory).
 
     Sequential mode gives ceil(B/64) waves for 1024 SIMDs, each a dependent chain (a dependent
     VALU op issues every ~7 cycles on gfx950, an independent one every ~2.3: tools/ubench).  The
@@ -35,7 +36,7 @@ def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, r_min=None, time_major=False)
     """
     waves = max(1, -(-B // 64))
     Rc = 1.0 / (2.0 * float(C) * float(fs))
-    Rv = float(R if r_min is None else r_min)
+    Rv = float(R)
     p = Rc / (Rv + Rc)
     rho = abs(1.0 - 2.0 * p)
     if rho <= 0.0:
@@ -50,6 +51,20 @@ def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, r_min=None, time_major=False)
         k_fwd = 1
     k_bwd = max(1, min(((8 if time_major else 4) * N_SIMD) // waves, T // 64))
     return TpPlan(k_fwd, W, float(tol), k_bwd)
+
+
+_R_MAX_CACHE = {}
+
+
+def resistance_max(r):
+    """max of a per-sample resistance tensor (one device sync, cached per tensor version): the
+    planner needs the slowest sequence's memory."""
+    key = (r.data_ptr(), tuple(r.shape), r._version)
+    if key not in _R_MAX_CACHE:
+        if len(_R_MAX_CACHE) > 64:
+            _R_MAX_CACHE.clear()
+        _R_MAX_CACHE[key] = float(r.max())
+    return _R_MAX_CACHE[key]
 
 
 LAST_TP_STATUS = {"status": None}     # device status word of the most recent time-parallel forward

@@ -235,10 +235,8 @@ class Circuit:
         tp = self.time_parallel
         if tp == "auto":
             # component values live on the host (tiny CPU variables): planning costs no sync
-            r_min = None if r is None else 1.0e3
-            tp = engine.plan_time_parallel(xv.shape[0], xv.shape[1], float(parts[2]), float(cap.C), float(cap.FS),
-                                           r_min=r_min)
-            if r is not None:
-                tp = tp._replace(k_fwd=1)       # per-sample R: memory depends on the data, stay sequential
+            # per-sample R: the warm-up must outlast the slowest (largest-R) sequence in the batch
+            R_plan = float(parts[2]) if r is None else engine.resistance_max(r)
+            tp = engine.plan_time_parallel(xv.shape[0], xv.shape[1], R_plan, float(cap.C), float(cap.FS))
         y = engine.clipper(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp)
         return y.as_subclass(tf.Tensor)

@@ -7,6 +7,7 @@ over B*T independent samples, done by wdf_clipper_mlp_wgrad (fully parallel HIP 
 import torch
 
 from . import binding
+from . import engine
 from . import compat_tf as tf
 
 
@@ -79,18 +80,6 @@ class _ClipperMlpFn(torch.autograd.Function):
 # same samples instead (overlapped truncated BPTT; the truncation error decays like the
 # forward's).  The state each chunk arrives with is compared with the state the previous chunk
 # ended in; if any differ by more than tol the call is redone sequentially.
-_R_MAX_CACHE = {}
-
-
-def _r_max(r):
-    key = (r.data_ptr(), tuple(r.shape), r._version)
-    if key not in _R_MAX_CACHE:
-        if len(_R_MAX_CACHE) > 64:
-            _R_MAX_CACHE.clear()
-        _R_MAX_CACHE[key] = float(r.max())
-    return _R_MAX_CACHE[key]
-
-
 def segment_plan(B, T, R_slowest, C, fs, tol=1.0e-6):
     """(K, L, W) or None.  W outlasts the slowest (largest-R) sequence's memory; chunks are at
     least W long (<= 2x redundant work); no more chunks than it takes to fill the chip."""
@@ -147,7 +136,7 @@ def clipper_mlp(theta2, w, x, r, z0, fs, hidden, n_tanh, C, R_static=None, time_
     """The MLP-root clipper over a batch: segmented when the plan allows, else the sequential
     kernels.  Returns (y [T,B], zT [B])."""
     if time_parallel == "auto":
-        plan = segment_plan(x.shape[0], x.shape[1], _r_max(r) if r is not None else float(R_static), float(C), fs)
+        plan = segment_plan(x.shape[0], x.shape[1], engine.resistance_max(r) if r is not None else float(R_static), float(C), fs)
         if plan is not None:
             y, zT, miss = clipper_mlp_segmented(theta2, w, x, r, fs, hidden, n_tanh, plan, z0=z0)
             LAST_SEGMENT_MISS["miss"] = miss

@@ -286,9 +286,16 @@ def test_dataset_shaped_batch_config_c4(wdf, oracle):
     dp = wdf.DiodePair(P1, float(theta[0]), Vt=float(theta[1]), trainable=True)
     circ = wdf.Circuit(P1, dp, Cap, per_sample_R=Vs)
     xin = cuda(np.stack([x, r], axis=-1))
+    from wdf_hip import engine, binding as wb
+    engine.LAST_TP_STATUS["status"] = None
     with tf.GradientTape() as tape:
         y = circ(xin)
         loss = tf.reduce_mean(tf.square(y[50:]))                 # skip_samples = 50 (clipper_pot.py:232)
+    # per-sample R runs time-parallel too: the warm-up is planned from the largest R in the batch
+    plan = engine.plan_time_parallel(B, T, float(r.max()), float(theta[3]), FS)
+    assert plan.k_fwd > 1 and plan.warmup >= 384
+    st = wb.tp_status(engine.LAST_TP_STATUS["status"])
+    assert st["n_bad"] == 0 and st["max_miss"] <= 1e-6, st
     g = tape.gradient(loss, [dp.Is, dp.nVt, Cap.C])
     pick = np.random.default_rng(0).choice(B, 12, replace=False)
     th64 = theta.astype(np.float32).astype(np.float64)

@@ -47,6 +47,6 @@ for R_kind in ("static 45k", "per-sample pot"):
             torch.autograd.grad((y * gy).sum(), [th, w])
 
         t_seq, t_tp = timeit(lambda: step(None), 3), timeit(lambda: step("auto"), 3)
-        plan = mlp_root.segment_plan(B, T, mlp_root._r_max(rr) if rr is not None else 45.0e3, 4.7e-9, fs)
+        plan = mlp_root.segment_plan(B, T, mlp_root.engine.resistance_max(rr) if rr is not None else 45.0e3, 4.7e-9, fs)
         print(f"step {n_tanh - 1}x{hidden} R {R_kind}: sequential {t_seq:.2f} ms, segmented {t_tp:.2f} ms "
               f"(plan K,L,W={plan}, miss={mlp_root.LAST_SEGMENT_MISS['miss']})")
