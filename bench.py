@@ -74,10 +74,32 @@ def cpu_baseline(T, fs, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 400:
             break
+    t1 = time.perf_counter()                            # and the same step on ONE core
+    n1 = 0
+    x1, tgt1 = x[:32], tgt[:, :32].copy()
+    while time.perf_counter() - t1 < 2.0:
+        O.clipper_mse_step(th, fs, x1, tgt1, n_threads=1)
+        n1 += 1
+    one_core = 32 * T * n1 / (time.perf_counter() - t1)
     return {"value": Bs * T * n / dt, "unit": "samples/s", "cores": best, "kind": "port",
-            "logical_cpus": avail,
+            "logical_cpus": avail, "value_one_core": one_core,
             "sample": f"{n} fused fwd+MSE+bwd steps of oracle_clipper_mse_step_f32 on {Bs} sequences x {T} "
                       f"samples of the same sweep workload ({dt:.1f} s, OpenMP {best} threads, best of {cands})"}
+
+
+def copy_bandwidth_gbs(dev, nbytes=1 << 29, reps=10):
+    """Achievable HBM bandwidth on this box: a device-to-device copy of `nbytes` (read + write
+    counted), HIP events on the launch stream.  SURVEY 8d's second roofline denominator."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = binding.Event(), binding.Event()
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    ms = e0.elapsed_ms(e1) / reps
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
 def main():
@@ -124,15 +146,14 @@ def main():
     def step(timed):
         # forward (x -> y, state stash), then the MSE-fused reverse sweep (-> SSE, dSSE-mean/dtheta),
         # then ONE fused all-reduce of [SSE, grads] (no-op on 1 GPU)
+        # timed: events bracket exactly the forward / reverse recurrence kernel (what rocprofv3
+        # lists under that name), not the verify / combine / reduce helpers of the same call
         if timed:
-            ev[0].record()
+            binding.Event.bracket_next(ev[0], ev[1])
         stepper.forward(theta, xk)
         if timed:
-            ev[1].record()
-            ev[2].record()
+            binding.Event.bracket_next(ev[2], ev[3])
         sse, gtheta = stepper.backward(theta, xk, target)
-        if timed:
-            ev[3].record()
         buf = stepper.out                              # [SSE, grads]: the kernels wrote it in place
         wdist.allreduce_sum_(buf)
         if timed:
@@ -163,6 +184,7 @@ def main():
     tp_stat = binding.tp_status(stepper.status) if tp is not None and tp.k_fwd > 1 else None
 
     if rank == 0:
+        copy_gbs = copy_bandwidth_gbs(dev)
         ms_step = dt / args.steps * 1e3
         value = Bg * T / (dt / args.steps)
         f_ms, b_ms = float(np.mean(t_fwd)), float(np.mean(t_bwd))
@@ -190,7 +212,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": None if traffic is None else "profiles/r01_c_pmc_traffic.json",
                          "algorithmic_bytes_per_sample": dom_bytes,
-                         "fwd_kernel_ms": f_ms, "bwd_kernel_ms": b_ms},
+                         "fwd_kernel_ms": f_ms, "bwd_kernel_ms": b_ms,
+                         "copy_bandwidth": copy_gbs, "frac_of_copy_bandwidth": achieved / copy_gbs},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, fs)

@@ -33,6 +33,26 @@ int check_launch(const char* what)
     return WDF_OK;
 }
 
+// wdf_event_bracket_next(): events to record immediately before / after the next RECURRENCE
+// kernel launched from this thread (the forward or reverse sweep itself, not the verify /
+// combine / reduce helpers that share its C call), so a harness can time exactly the kernel
+// rocprofv3 reports.  One-shot.
+thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+
+struct EventBracket {
+    hipStream_t s;
+    hipEvent_t e1;
+    explicit EventBracket(hipStream_t stream) : s(stream), e1(g_ev1)
+    {
+        if (g_ev0) (void)hipEventRecord(g_ev0, s);
+        g_ev0 = g_ev1 = nullptr;
+    }
+    ~EventBracket()
+    {
+        if (e1) (void)hipEventRecord(e1, s);
+    }
+};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <bool DYN_R, bool SYM, bool TM, bool V4>
@@ -40,6 +60,7 @@ void launch_fwd(const float* x, const float* r, const float* theta, float fs, in
                 float* zstash, const float* z0, float* zT, int64_t B, int64_t T, hipStream_t s)
 {
     const unsigned grid = (unsigned)((B + 63) / 64);
+    EventBracket bracket(s);
     if (zstash)
         hipLaunchKernelGGL((wdf::clipper_fwd_kernel<DYN_R, SYM, TM, V4, true>), dim3(grid), dim3(64), 0, s, x, r, theta,
                            fs, n_up, n_down, y, zstash, z0, zT, B, T);
@@ -53,6 +74,7 @@ void launch_bwd(const float* x, const float* r, const float* theta, float fs, in
                 const float* zstash, const float* gy, double* ws, float* gz0, int64_t B, int64_t T, hipStream_t s)
 {
     const unsigned grid = (unsigned)((B + 63) / 64);
+    EventBracket bracket(s);
     hipLaunchKernelGGL((wdf::clipper_bwd_kernel<DYN_R, SYM, TM, V4>), dim3(grid), dim3(64), 0, s, x, r, theta, fs,
                        n_up, n_down, zstash, gy, ws, gz0, B, T);
 }
@@ -126,10 +148,13 @@ void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs,
 #define WDF_FWD_TP(STASH_, V_)                                                                             \
     hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, TM, V4, STASH_, V_>), grid, dim3(64), 0, s, x, r, theta, \
                        fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, status, B, Bh, T, g.L, W)
-    if (pack) {
-        if (zstash) WDF_FWD_TP(true, wdf::v2f); else WDF_FWD_TP(false, wdf::v2f);
-    } else {
-        if (zstash) WDF_FWD_TP(true, float); else WDF_FWD_TP(false, float);
+    {
+        EventBracket bracket(s);
+        if (pack) {
+            if (zstash) WDF_FWD_TP(true, wdf::v2f); else WDF_FWD_TP(false, wdf::v2f);
+        } else {
+            if (zstash) WDF_FWD_TP(true, float); else WDF_FWD_TP(false, float);
+        }
     }
 #undef WDF_FWD_TP
     if (g.K > 1) {
@@ -155,10 +180,13 @@ void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs,
 #define WDF_BWD_TP(MSE_, V_)                                                                               \
     hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, TM, V4, MSE_, V_>), grid, dim3(64), 0, s, x, r, theta, \
                        fs, n_up, n_down, zstash, gy, target, zT, gscale, part, B, Bh, T, g.L)
-    if (pack) {
-        if (target) WDF_BWD_TP(true, wdf::v2f); else WDF_BWD_TP(false, wdf::v2f);
-    } else {
-        if (target) WDF_BWD_TP(true, float); else WDF_BWD_TP(false, float);
+    {
+        EventBracket bracket(s);
+        if (pack) {
+            if (target) WDF_BWD_TP(true, wdf::v2f); else WDF_BWD_TP(false, wdf::v2f);
+        } else {
+            if (target) WDF_BWD_TP(true, float); else WDF_BWD_TP(false, float);
+        }
     }
 #undef WDF_BWD_TP
     hipLaunchKernelGGL(wdf::clipper_bwd_tp_combine_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, part, B,
@@ -564,6 +592,12 @@ int wdf_event_elapsed_ms(void* start, void* stop, float* ms)
     hipError_t e = hipEventSynchronize((hipEvent_t)stop);
     if (e == hipSuccess) e = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
     return e == hipSuccess ? WDF_OK : fail(WDF_ELAUNCH, "hipEventElapsedTime: %s", hipGetErrorString(e));
+}
+
+void wdf_event_bracket_next(void* start, void* stop)
+{
+    g_ev0 = (hipEvent_t)start;
+    g_ev1 = (hipEvent_t)stop;
 }
 
 void wdf_event_destroy(void* ev)

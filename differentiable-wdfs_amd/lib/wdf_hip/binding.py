@@ -91,6 +91,8 @@ def lib():
     L.wdf_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.wdf_event_destroy.restype = None
     L.wdf_event_destroy.argtypes = [vp]
+    L.wdf_event_bracket_next.restype = None
+    L.wdf_event_bracket_next.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -105,7 +107,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
     "wdf_omega_f32", "wdf_diode_pair_f32",
-    "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy",
+    "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy", "wdf_event_bracket_next",
 )
 
 
@@ -464,6 +466,12 @@ class Event:
         ms = C.c_float(0.0)
         _check(lib().wdf_event_elapsed_ms(self.h, stop.h, C.byref(ms)), "wdf_event_elapsed_ms")
         return ms.value
+
+    @staticmethod
+    def bracket_next(start, stop):
+        """Record start/stop right around the next recurrence kernel launched from this thread
+        (excluding the verify / combine / reduce helpers of the same C call)."""
+        lib().wdf_event_bracket_next(start.h, stop.h)
 
     def __del__(self):
         try:
