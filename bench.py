@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="sequences per GPU")
     ap.add_argument("--seq-len", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true",
+                    help="skip the on-device Adam update of {Is, nVt, R, C} that closes every step")
     ap.add_argument("--sequential", action="store_true", help="one lane per sequence, no time-parallel chunks")
     ap.add_argument("--x-batch-major", action="store_true",
                     help="hand the kernels x as [B,T] (the reference scripts' layout) instead of the engine's "
@@ -140,6 +142,12 @@ def main():
         tp = engine.autotune_time_parallel(theta, xk, target, fs, tp, time_major=tm)
     stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global, time_major=tm)
 
+    # the update that closes a training step (lpf.py:93-94: one Adam per component, its learning
+    # rate scaled to the component; tf_wdf.py:74,104 clip constraints), on the device
+    adam = None if args.no_optimizer else binding.Adam(
+        4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
+    loss_trace = []
+
     ev = [binding.Event() for _ in range(4)]
     t_fwd, t_bwd = [], []
 
@@ -156,6 +164,12 @@ def main():
         sse, gtheta = stepper.backward(theta, xk, target)
         buf = stepper.out                              # [SSE, grads]: the kernels wrote it in place
         wdist.allreduce_sum_(buf)
+        if adam is not None:
+            if len(loss_trace) < 2:
+                loss_trace.append(buf[0:1].clone())
+            else:
+                loss_trace[1] = buf[0:1].clone()
+            adam.apply(theta, buf[1:])
         if timed:
             t_fwd.append(ev[0].elapsed_ms(ev[1]))
             t_bwd.append(ev[2].elapsed_ms(ev[3]))
@@ -203,6 +217,11 @@ def main():
                                    f"{B} sequences x {T} samples @ {int(fs)} Hz per GPU (BASELINE configs[2])",
                        "global_batch": Bg, "seq_len": T, "parallelism": f"dp{world}",
                        "loss": float(loss) / n_global, "grad": [float(g) for g in grad],
+                       "optimizer": None if adam is None else
+                       {"kind": "Adam on device (wdf_adam_step), lr = 1e-3 x component value, clip constraints",
+                        "loss_first_step": float(loss_trace[0]) / n_global,
+                        "loss_last_step": float(loss_trace[1]) / n_global,
+                        "theta_final": [float(v) for v in theta]},
                        "x_layout": "time-major [T,B] resident copy (one-off transpose at data load, outside the timed "
                                    "region)" if tm else "batch-major [B,T] as the reference scripts hold it",
                        "time_parallel": None if tp is None else

@@ -12,6 +12,7 @@
 #include "wdf_asym.h"
 #include "wdf_mlp.h"
 #include "wdf_statespace.h"
+#include "wdf_optim.h"
 
 namespace {
 
@@ -541,7 +542,8 @@ int64_t wdf_clipper_mlp_wgrad_ws_bytes(int hidden, int n_tanh_layers, int64_t S)
 int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb, const float* theta2, const float* w,
                           int hidden, int n_tanh_layers, float fs, void* ws, float* gw, int64_t S, void* stream)
 {
-    if (!ain || !gb || !theta2 || !w || !ws || !gw) return fail(WDF_EINVAL, "null ain/gb/theta2/w/ws/gw");
+    if (!ain || !gb || !w || !ws || !gw) return fail(WDF_EINVAL, "null ain/gb/w/ws/gw");
+    if (!lrin && !theta2) return fail(WDF_EINVAL, "theta2 is needed when lrin is NULL");
     if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
     const int count = wdf_mlp_weight_count(hidden, n_tanh_layers);
     if (count <= 0)
@@ -554,6 +556,24 @@ int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb, 
     hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float*)ws, (int)nblk, count, gw);
     return check_launch("wdf_clipper_mlp_wgrad_reduce");
+}
+
+#define WDF_EVAL_CASE(H_, NL_)                                                                                \
+    if (hidden == H_ && n_tanh_layers == NL_)                                                                 \
+        hipLaunchKernelGGL((wdf::mlp_eval_kernel<H_, NL_>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, ain, lrin, w, \
+                           out, S);
+
+int wdf_mlp_eval(const float* ain, const float* lrin, const float* w, int hidden, int n_tanh_layers, float* out,
+                 int64_t S, void* stream)
+{
+    if (!ain || !lrin || !w || !out) return fail(WDF_EINVAL, "null ain/lrin/w/out");
+    if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
+    if (wdf_mlp_weight_count(hidden, n_tanh_layers) <= 0)
+        return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
+    const unsigned nblk = mlp_wgrad_blocks(S);
+    WDF_EVAL_CASE(4, 3) WDF_EVAL_CASE(8, 3) WDF_EVAL_CASE(16, 3) WDF_EVAL_CASE(4, 4) WDF_EVAL_CASE(8, 4)
+    WDF_EVAL_CASE(4, 5) WDF_EVAL_CASE(8, 5)
+    return check_launch("wdf_mlp_eval");
 }
 
 int wdf_omega_f32(const float* x, float* w, int32_t* iters, int64_t n, void* stream)
@@ -572,6 +592,16 @@ int wdf_diode_pair_f32(const float* a, const float* R_port, float Is, float nVt,
     hipLaunchKernelGGL(wdf::diode_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
                        R_port, Is, nVt, n_up, n_down, b, n);
     return check_launch("wdf_diode_pair_f32");
+}
+
+int wdf_adam_step(float* theta, const float* grad, float* m, float* v, int32_t* step, const float* lr, float beta1,
+                  float beta2, float eps, const float* lo, const float* hi, int n, void* stream)
+{
+    if (!theta || !grad || !m || !v || !step || !lr) return fail(WDF_EINVAL, "null theta/grad/m/v/step/lr");
+    if (n <= 0 || n > 1024) return fail(WDF_EINVAL, "wdf_adam_step: n must be in 1..1024 (got %d)", n);
+    hipLaunchKernelGGL(wdf::adam_clip_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, theta, grad, m, v, step, lr,
+                       beta1, beta2, eps, lo, hi, n);
+    return check_launch("wdf_adam_step");
 }
 
 void* wdf_event_create(void)

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64) void mlp_wgrad_kernel(
     for (int i = threadIdx.x; i < M::kCount; i += 64) w[i] = w_in[i];
     __syncthreads();
     const int part = blockIdx.y;
-    const float lr_static = mlp_load_consts(theta2, fs).lr;
+    const float lr_static = lrin ? 0.0f : mlp_load_consts(theta2, fs).lr;
     float acc[M::kAcc];
 #pragma unroll
     for (int i = 0; i < M::kAcc; ++i) acc[i] = 0.0f;
@@ -443,6 +443,26 @@ __global__ __launch_bounds__(64) void mlp_wgrad_kernel(
         else if (i < M::kRows * H) dst = layer + g * M::kRows * H + i;
         else dst = g == 0 ? layer + H * H + (i - M::kRows * H) : -1;
         if (threadIdx.x == 0 && dst >= 0) o[dst] = v;
+    }
+}
+
+// out[n] = MLP(a[n], lr[n]) over S independent samples: DenseRootModel.incident/reflected on a
+// table (layers.py:76-82), the forward of diode_pretraining.py's fit (:113-126, :159-160).
+template <int H, int NL>
+__global__ __launch_bounds__(64) void mlp_eval_kernel(const float* __restrict__ ain, const float* __restrict__ lrin,
+                                                      const float* __restrict__ w_in, float* __restrict__ out, int64_t S)
+{
+    using M = Mlp<H, NL>;
+    __shared__ __attribute__((aligned(16))) float w[M::kCount + 4];
+    for (int i = threadIdx.x; i < M::kCount; i += 64) w[i] = w_in[i];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 64;
+    float act[NL][H];
+    for (int64_t n0 = (int64_t)blockIdx.x * 64; n0 < S; n0 += stride) {
+        const int64_t n_raw = n0 + threadIdx.x;
+        const int64_t n = n_raw < S ? n_raw : S - 1;
+        const float v = M::fwd(w, ain[n], lrin[n], act);
+        if (n_raw < S) out[n] = v;
     }
 }
 

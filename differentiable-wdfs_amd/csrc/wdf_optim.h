@@ -1,0 +1,44 @@
+// wdf_optim.h -- the optimizer step of the training loops, on the device.
+//
+// tf.keras.optimizers.Adam.apply_gradients as the reference scripts use it (lpf.py:79-80,93-94:
+// one optimizer per component with its own learning rate; clipper_pot.py:179,183-184), followed
+// by the Variable's constraint (tf_wdf.py:74 R in [180, 1e6], :104 C in [1e-13, 1]), which Keras
+// applies after every update.  Update rule (TF 2.5 Adam, non-amsgrad):
+//     t += 1 ; lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)
+//     m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; theta -= lr_t m / (sqrt(v) + eps)
+// The component values live on the device (the kernels read them there), so the whole training
+// step -- forward, reverse sweep, all-reduce, update -- runs without a host round trip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wdf {
+
+// One thread per parameter; `step` is the shared iteration counter (read by all, bumped by thread 0
+// after a barrier -- n <= 1024, one block).
+__global__ __launch_bounds__(1024) void adam_clip_kernel(float* __restrict__ theta, const float* __restrict__ grad,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         int32_t* __restrict__ step, const float* __restrict__ lr,
+                                                         float b1, float b2, float eps, const float* __restrict__ lo,
+                                                         const float* __restrict__ hi, int n)
+{
+    const int i = threadIdx.x;
+    const int t = *step + 1;
+    __syncthreads();
+    if (i == 0) *step = t;
+    if (i >= n) return;
+    const double c1 = 1.0 - pow((double)b1, (double)t), c2 = 1.0 - pow((double)b2, (double)t);
+    const float g = grad[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * g;
+    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float lr_t = (float)((double)lr[i] * sqrt(c2) / c1);
+    float th = theta[i] - lr_t * mi / (sqrtf(vi) + eps);
+    if (lo) th = fmaxf(th, lo[i]);
+    if (hi) th = fminf(th, hi[i]);
+    theta[i] = th;
+}
+
+}  // namespace wdf

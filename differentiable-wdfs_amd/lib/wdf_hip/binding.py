@@ -68,6 +68,8 @@ def lib():
     L.wdf_clipper_mlp_fwd.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, i64, i64, ci, vp]
     L.wdf_clipper_mlp_bwd.restype = ci
     L.wdf_clipper_mlp_bwd.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, fp, vp, fp, i64, i64, ci, vp]
+    L.wdf_mlp_eval.restype = ci
+    L.wdf_mlp_eval.argtypes = [fp, fp, fp, ci, ci, fp, i64, vp]
     L.wdf_clipper_mlp_wgrad_ws_bytes.restype = i64
     L.wdf_clipper_mlp_wgrad_ws_bytes.argtypes = [ci, ci, i64]
     L.wdf_clipper_mlp_wgrad.restype = ci
@@ -84,6 +86,8 @@ def lib():
     L.wdf_omega_f32.argtypes = [fp, fp, vp, i64, vp]
     L.wdf_diode_pair_f32.restype = ci
     L.wdf_diode_pair_f32.argtypes = [fp, fp, cf, cf, ci, ci, fp, i64, vp]
+    L.wdf_adam_step.restype = ci
+    L.wdf_adam_step.argtypes = [fp, fp, fp, fp, vp, fp, cf, cf, cf, fp, fp, ci, vp]
     L.wdf_event_create.restype = vp
     L.wdf_event_record.restype = ci
     L.wdf_event_record.argtypes = [vp, vp]
@@ -104,9 +108,9 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_asym_fwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd",
-    "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad",
+    "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
-    "wdf_omega_f32", "wdf_diode_pair_f32",
+    "wdf_omega_f32", "wdf_diode_pair_f32", "wdf_adam_step",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy", "wdf_event_bracket_next",
 )
 
@@ -323,6 +327,20 @@ def clipper_mlp_bwd(x, theta2, w, hidden, n_tanh, fs, zstash, gy, r=None):
     return gth, gb, ain, lrin
 
 
+def mlp_eval(ain, lrin, w, hidden, n_tanh):
+    """out[n] = MLP(ain[n], lrin[n]) (flat float32 device tensors)."""
+    require_gpu()
+    ain = _f32_dev(ain, "ain")
+    lrin = _f32_dev(lrin, "lrin")
+    w = _f32_dev(w, "w")
+    if lrin.numel() != ain.numel():
+        raise WdfHipError("mlp_eval: ain and lrin must have the same number of samples")
+    out = torch.empty((ain.numel(),), dtype=torch.float32, device=ain.device)
+    rc = lib().wdf_mlp_eval(_ptr(ain), _ptr(lrin), _ptr(w), int(hidden), int(n_tanh), _ptr(out), ain.numel(), _stream())
+    _check(rc, "wdf_mlp_eval")
+    return out
+
+
 def clipper_mlp_wgrad(ain, lrin, gb, theta2, w, hidden, n_tanh, fs):
     """-> gw [wdf_mlp_weight_count]: dL/dw from what clipper_mlp_bwd wrote (see include/wdf_hip.h)."""
     require_gpu()
@@ -441,6 +459,34 @@ def diode_pair(a, R_port, Is, nVt, n_up=1, n_down=1):
     _check(lib().wdf_diode_pair_f32(_ptr(a), _ptr(R_port), float(Is), float(nVt), int(n_up), int(n_down),
                                     _ptr(b), a.numel(), _stream()), "wdf_diode_pair_f32")
     return b
+
+
+class Adam:
+    """Device-resident tf.keras.optimizers.Adam for a small float32 parameter vector (component
+    values, flat MLP weights <= 1024): per-parameter learning rates and clip constraints
+    (tf_wdf.py:74,104); one kernel launch per step, no host round trip."""
+
+    def __init__(self, n, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7, lo=None, hi=None, device="cuda"):
+        require_gpu()
+        self.n = int(n)
+        self.b1, self.b2, self.eps = float(beta_1), float(beta_2), float(epsilon)
+        f = lambda a: torch.as_tensor(a, dtype=torch.float32).expand(self.n).contiguous().to(device)  # noqa: E731
+        self.lr = f(lr)
+        self.lo = None if lo is None else f(lo)
+        self.hi = None if hi is None else f(hi)
+        self.m = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.step = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def apply(self, theta, grad):
+        """theta (in place) <- Adam update with grad, then the clip constraint."""
+        theta = _f32_dev(theta, "theta")
+        grad = _f32_dev(grad, "grad")
+        if theta.numel() != self.n or grad.numel() != self.n:
+            raise WdfHipError(f"Adam: expected {self.n} parameters")
+        rc = lib().wdf_adam_step(_ptr(theta), _ptr(grad), _ptr(self.m), _ptr(self.v), _ptr(self.step), _ptr(self.lr),
+                                 self.b1, self.b2, self.eps, _ptr(self.lo), _ptr(self.hi), self.n, _stream())
+        _check(rc, "wdf_adam_step")
 
 
 def device_info(device=0):

@@ -162,6 +162,12 @@ int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, con
                         const float* zstash, const float* gy,
                         float* gb, float* ain, float* lrin, void* ws, float* gtheta2,
                         int64_t B, int64_t T, int flags, void* stream);
+/* out[n] = MLP(ain[n], lrin[n]), n < S: DenseRootModel on a table of (a, log R) points
+ * (layers.py:76-82), the forward of the pre-training fit (diode_pretraining.py:113-126,159-160);
+ * its weight gradient is wdf_clipper_mlp_wgrad with gb = -dL/dout (theta2 may be NULL there
+ * when lrin is given).                                                                    */
+int wdf_mlp_eval(const float* ain, const float* lrin, const float* w, int hidden, int n_tanh_layers,
+                 float* out, int64_t S, void* stream);
 int64_t wdf_clipper_mlp_wgrad_ws_bytes(int hidden, int n_tanh_layers, int64_t S);
 int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb,
                           const float* theta2, const float* w, int hidden, int n_tanh_layers,
@@ -223,6 +229,17 @@ int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, doubl
 int wdf_omega_f32(const float* x, float* w, int32_t* iters, int64_t n, void* stream);
 int wdf_diode_pair_f32(const float* a, const float* R_port, float Is, float nVt,
                        int n_up, int n_down, float* b, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimizer step on the device (csrc/wdf_optim.h): tf.keras.optimizers.Adam.apply_gradients
+ * as the scripts call it (lpf.py:79-80,93-94; clipper_pot.py:179,183-184) followed by the
+ * Variable constraint clip (tf_wdf.py:74,104), for n <= 1024 parameters (component values or a
+ * flat MLP weight vector).  lr: per-parameter learning rates (the reference keeps one optimizer
+ * per component); lo / hi: optional clip bounds; step: device iteration counter, incremented.
+ * ---------------------------------------------------------------------------------- */
+int wdf_adam_step(float* theta, const float* grad, float* m, float* v, int32_t* step,
+                  const float* lr, float beta1, float beta2, float eps,
+                  const float* lo, const float* hi, int n, void* stream);
 
 /* library / device info */
 int wdf_abi_version(void);

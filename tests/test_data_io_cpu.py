@@ -103,3 +103,21 @@ def test_audio_dspy_helpers():
     w = 2 * np.pi * 720 / 48000
     H = (b[0] + b[1] * np.exp(-1j * w)) / (a[0] + a[1] * np.exp(-1j * w))
     assert abs(abs(H) - 1 / np.sqrt(2)) < 1e-9 and abs(sum(b) / sum(a) - 1.0) < 1e-12
+
+
+def test_pretraining_module_has_no_cpu_path():
+    """diode_config mirrors the reference's named configurations; diode_pretraining imports on a
+    CPU-only box but every computing entry point raises (no fallback)."""
+    import torch
+    import diode_config as dc
+    import diode_pretraining as dp
+    from wdf_hip.binding import WdfHipError
+    d = dc.diode_1n4148_2u3d
+    assert (d.name, d.Is, d.nabla, d.Vt, d.N_up, d.N_down) == ("1N4148 (2U-3D)", 4.352e-9, 1.906, 25.85e-3, 2, 3)
+    assert dc.default_diode == dc.DiodeConfig("DefaultDiode", 1.0e-9, 1.0, 25.85e-3, 1, 1)
+    m = dp.build_model(2, 4, seed=0)                        # host-side construction works anywhere
+    assert [tuple(v.shape) for v in m.trainable_variables][:2] in ([(1, 2, 4), (1, 4)], [(1, 4), (1, 2, 4)])
+    if not torch.cuda.is_available():
+        import pytest
+        with pytest.raises(WdfHipError):
+            dp.synthetic_table(d)
