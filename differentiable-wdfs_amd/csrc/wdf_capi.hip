@@ -576,6 +576,27 @@ int wdf_mlp_eval(const float* ain, const float* lrin, const float* w, int hidden
     return check_launch("wdf_mlp_eval");
 }
 
+#define WDF_FIT_CASE(H_, NL_)                                                                                 \
+    if (hidden == H_ && n_tanh_layers == NL_)                                                                 \
+        hipLaunchKernelGGL((wdf::mlp_fit_epoch_kernel<H_, NL_>), dim3(1), dim3(64 * wdf::Mlp<H_, NL_>::kParts), 0,   \
+                           (hipStream_t)stream, xa, xl, ys, S, batch, w, m, v, step, lr, beta1, beta2, eps, esr_n,   \
+                           eps_energy, loss_sum);
+
+int wdf_mlp_fit_epoch(const float* xa, const float* xl, const float* ys, int64_t S, int batch, float* w, float* m,
+                      float* v, int32_t* step, float lr, float beta1, float beta2, float eps, float esr_n,
+                      float eps_energy, double* loss_sum, int hidden, int n_tanh_layers, void* stream)
+{
+    if (!xa || !xl || !ys || !w || !m || !v || !step || !loss_sum) return fail(WDF_EINVAL, "null argument");
+    if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
+    if (batch < 1 || batch > 64) return fail(WDF_EUNSUPPORTED, "wdf_mlp_fit_epoch: batch must be in 1..64 (got %d)", batch);
+    if (!(esr_n > 0.0f)) return fail(WDF_EINVAL, "esr_n must be positive");
+    if (wdf_mlp_weight_count(hidden, n_tanh_layers) <= 0)
+        return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
+    WDF_FIT_CASE(4, 3) WDF_FIT_CASE(8, 3) WDF_FIT_CASE(16, 3) WDF_FIT_CASE(4, 4) WDF_FIT_CASE(8, 4)
+    WDF_FIT_CASE(4, 5) WDF_FIT_CASE(8, 5)
+    return check_launch("wdf_mlp_fit_epoch");
+}
+
 int wdf_omega_f32(const float* x, float* w, int32_t* iters, int64_t n, void* stream)
 {
     if (!x || !w || n <= 0) return fail(WDF_EINVAL, "wdf_omega_f32: bad arguments");

@@ -466,6 +466,85 @@ __global__ __launch_bounds__(64) void mlp_eval_kernel(const float* __restrict__ 
     }
 }
 
+// One EPOCH of the pre-training fit in one launch (diode_pretraining.py:159-160: Keras fit with
+// Adam, mini-batches of <= 64 table points, loss = MSE + ESR of :136-155): the mini-batch loop is
+// launch-bound when driven from the host (25 launches of ~1 us of work each per step), so the
+// whole sequential loop runs inside one workgroup.  Weights, Adam moments and the gradient live in
+// LDS; wave p of the block owns layer part p (Mlp::wgrad), every wave evaluates the same batch
+// (one table point per lane), reduces its part's gradient across lanes, and after a barrier all
+// threads apply the Adam update.  xa / xl / ys are the table in the order to visit (the host
+// reshuffles per epoch).  esr_n: the ESR normaliser N (:145, the script's global N = 1000).
+template <int H, int NL>
+__global__ __launch_bounds__((64 * Mlp<H, NL>::kParts)) void mlp_fit_epoch_kernel(
+    const float* __restrict__ xa, const float* __restrict__ xl, const float* __restrict__ ys, int64_t S, int batch,
+    float* __restrict__ w_io, float* __restrict__ m_io, float* __restrict__ v_io, int32_t* __restrict__ step, float lr,
+    float b1, float b2, float eps_adam, float esr_n, float eps_energy, double* __restrict__ loss_sum)
+{
+    using M = Mlp<H, NL>;
+    constexpr int kThreads = 64 * M::kParts;
+    __shared__ __attribute__((aligned(16))) float w[M::kCount + 4];
+    __shared__ float mo[M::kCount], vo[M::kCount], g[M::kCount];
+    for (int i = threadIdx.x; i < M::kCount; i += kThreads) { w[i] = w_io[i]; mo[i] = m_io[i]; vo[i] = v_io[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int part = threadIdx.x >> 6;
+    const int l = part == 0 ? 0 : 1 + (part - 1) / M::kSplit, grp = part == 0 ? 0 : (part - 1) % M::kSplit;
+    const int layer = M::kMid + (l - 1) * M::kMidStride;
+    const int t_start = *step;
+    double pb1 = pow((double)b1, (double)t_start), pb2 = pow((double)b2, (double)t_start), loss_acc = 0.0;
+    int t = t_start;
+    float act[NL][H];
+    for (int64_t b0 = 0; b0 < S; b0 += batch) {
+        asm volatile("" ::: "memory");                          // the weights in LDS changed
+        const int nb = (int)((S - b0 < batch) ? S - b0 : batch);
+        const bool live = lane < nb;
+        const int64_t n = b0 + (live ? lane : 0);
+        const float a = xa[n], lrin = xl[n], y = live ? ys[n] : 0.0f;
+        const float out = M::fwd(w, a, lrin, act);
+        const float d = live ? out - y : 0.0f;
+        float sse = d * d, energy = y * y;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sse += __shfl_xor(sse, off, 64); energy += __shfl_xor(energy, off, 64); }
+        energy += eps_energy;
+        const float inv_nb = 1.0f / (float)nb;
+        const float esr = sqrtf(sse / energy / esr_n);
+        // d loss / d out = 2 d / nb + d / (esr energy N)
+        const float gout = d * (2.0f * inv_nb + (esr > 0.0f ? 1.0f / (esr * energy * esr_n) : 0.0f));
+        float acc[M::kAcc];
+#pragma unroll
+        for (int i = 0; i < M::kAcc; ++i) acc[i] = 0.0f;
+        M::wgrad(w, act, a, lrin, gout, part, acc);
+#pragma unroll
+        for (int i = 0; i < M::kAcc; ++i) {
+            float s = acc[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            int dst;
+            if (part == 0) dst = i < 3 * H ? i : (i <= 4 * H ? M::kWo + (i - 3 * H) : -1);
+            else if (i < M::kRows * H) dst = layer + grp * M::kRows * H + i;
+            else dst = grp == 0 ? layer + H * H + (i - M::kRows * H) : -1;
+            if (lane == 0 && dst >= 0) g[dst] = s;
+        }
+        __syncthreads();
+        t += 1;
+        pb1 *= (double)b1;
+        pb2 *= (double)b2;
+        const float lr_t = (float)((double)lr * sqrt(1.0 - pb2) / (1.0 - pb1));
+        for (int i = threadIdx.x; i < M::kCount; i += kThreads) {
+            const float gi = g[i];
+            const float mi = b1 * mo[i] + (1.0f - b1) * gi;
+            const float vi = b2 * vo[i] + (1.0f - b2) * gi * gi;
+            mo[i] = mi;
+            vo[i] = vi;
+            w[i] -= lr_t * mi / (sqrtf(vi) + eps_adam);
+        }
+        loss_acc += (double)(sse * inv_nb + esr);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < M::kCount; i += kThreads) { w_io[i] = w[i]; m_io[i] = mo[i]; v_io[i] = vo[i]; }
+    if (threadIdx.x == 0) { *step = t; *loss_sum = loss_acc; }
+}
+
 __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(const float* __restrict__ ws, int nblk, int count,
                                                                float* __restrict__ gw)
 {

@@ -122,9 +122,14 @@ def _write_back(model, w):
         o += n_out
 
 
-def fit(model, x, y, epochs, learning_rate=2e-5, batch_size=32, shuffle=True, seed=0, loss=my_loss, log=None):
+def fit(model, x, y, epochs, learning_rate=2e-5, batch_size=32, shuffle=True, seed=0, loss=my_loss, log=None,
+        fused=True):
     """Adam on mini-batches (Keras fit semantics: reshuffle every epoch, last batch may be short).
-    Returns the per-epoch mean batch loss.  The model's Variables are updated at the end."""
+    Returns the per-epoch mean batch loss.  The model's Variables are updated at the end.
+
+    fused (and loss is my_loss, batch_size <= 64): each epoch is ONE launch of
+    wdf_mlp_fit_epoch, the whole mini-batch loop inside a workgroup.  Otherwise one
+    eval / weight-gradient / Adam launch sequence per mini-batch with any torch loss."""
     dense, hidden, n_tanh = mlp_root.describe(model)
     dev = _dev()
     xt = torch.as_tensor(np.asarray(x, dtype=np.float32), device=dev)
@@ -135,6 +140,19 @@ def fit(model, x, y, epochs, learning_rate=2e-5, batch_size=32, shuffle=True, se
     gen = torch.Generator(device=dev)
     gen.manual_seed(int(seed))
     history = []
+    if fused and loss is my_loss and batch_size <= 64:
+        w = w.detach()
+        nb = -(-S // batch_size)
+        sums = torch.zeros(int(epochs), dtype=torch.float64, device=dev)
+        for epoch in range(int(epochs)):
+            perm = torch.randperm(S, device=dev, generator=gen) if shuffle else torch.arange(S, device=dev)
+            xa, xl, ys = xt[perm, 0].contiguous(), xt[perm, 1].contiguous(), yt[perm].contiguous()
+            binding.mlp_fit_epoch(xa, xl, ys, batch_size, w, adam, hidden, n_tanh, N, eps, sums[epoch:epoch + 1])
+            if log is not None:
+                log(epoch, float(sums[epoch]) / nb)
+        history = [float(v) / nb for v in sums.cpu()]
+        _write_back(model, w)
+        return history
     for epoch in range(int(epochs)):
         perm = torch.randperm(S, device=dev, generator=gen) if shuffle else torch.arange(S, device=dev)
         xa, xl, ys = xt[perm, 0].contiguous(), xt[perm, 1].contiguous(), yt[perm].contiguous()
@@ -156,14 +174,15 @@ def fit(model, x, y, epochs, learning_rate=2e-5, batch_size=32, shuffle=True, se
     return history
 
 
-def pretrain(diode, n_layers=2, layer_size=16, epochs=2000, learning_rate=2e-5, batch_size=32, seed=0, log=None):
+def pretrain(diode, n_layers=2, layer_size=16, epochs=2000, learning_rate=2e-5, batch_size=32, seed=0, log=None,
+             fused=True):
     """The reference script end to end: table, model, fit; returns (model, stats)."""
     test_x, ideal_y = synthetic_table(diode)
     model = build_model(n_layers, layer_size, seed=seed)
     dev = _dev()
     yt = torch.as_tensor(ideal_y, device=dev)
     before = (float(mse_loss(yt, model_apply(model, test_x))), float(esr_loss(yt, model_apply(model, test_x))))
-    hist = fit(model, test_x, ideal_y, epochs, learning_rate, batch_size, seed=seed, log=log)
+    hist = fit(model, test_x, ideal_y, epochs, learning_rate, batch_size, seed=seed, log=log, fused=fused)
     after = (float(mse_loss(yt, model_apply(model, test_x))), float(esr_loss(yt, model_apply(model, test_x))))
     return model, {"name": f"{diode.name}_{n_layers}x{layer_size}_pretrained", "before": before, "after": after,
                    "history": hist}

@@ -7,6 +7,8 @@ missing or a call fails, this raises -- the product never computes on the CPU.
 import ctypes as C
 import os
 
+import numpy as np
+
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -70,6 +72,8 @@ def lib():
     L.wdf_clipper_mlp_bwd.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, fp, vp, fp, i64, i64, ci, vp]
     L.wdf_mlp_eval.restype = ci
     L.wdf_mlp_eval.argtypes = [fp, fp, fp, ci, ci, fp, i64, vp]
+    L.wdf_mlp_fit_epoch.restype = ci
+    L.wdf_mlp_fit_epoch.argtypes = [fp, fp, fp, i64, ci, fp, fp, fp, vp, cf, cf, cf, cf, cf, cf, vp, ci, ci, vp]
     L.wdf_clipper_mlp_wgrad_ws_bytes.restype = i64
     L.wdf_clipper_mlp_wgrad_ws_bytes.argtypes = [ci, ci, i64]
     L.wdf_clipper_mlp_wgrad.restype = ci
@@ -108,7 +112,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_asym_fwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd",
-    "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval",
+    "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
     "wdf_omega_f32", "wdf_diode_pair_f32", "wdf_adam_step",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy", "wdf_event_bracket_next",
@@ -341,6 +345,22 @@ def mlp_eval(ain, lrin, w, hidden, n_tanh):
     return out
 
 
+def mlp_fit_epoch(xa, xl, ys, batch, w, opt, hidden, n_tanh, esr_n, eps_energy, loss_sum):
+    """One epoch of mini-batch Adam on the table (xa, xl, ys) in the given order; w and the Adam
+    state `opt` (binding.Adam with a scalar learning rate) are updated in place; loss_sum: device
+    float64[1] receiving the sum of batch losses."""
+    require_gpu()
+    xa, xl, ys, w = _f32_dev(xa, "xa"), _f32_dev(xl, "xl"), _f32_dev(ys, "ys"), _f32_dev(w, "w")
+    if not (xa.numel() == xl.numel() == ys.numel()):
+        raise WdfHipError("mlp_fit_epoch: xa, xl, ys must have the same length")
+    if loss_sum.dtype != torch.float64 or not loss_sum.is_cuda:
+        raise WdfHipError("loss_sum must be a float64 device tensor")
+    rc = lib().wdf_mlp_fit_epoch(_ptr(xa), _ptr(xl), _ptr(ys), xa.numel(), int(batch), _ptr(w), _ptr(opt.m), _ptr(opt.v),
+                                 _ptr(opt.step), float(opt.lr_scalar), opt.b1, opt.b2, opt.eps, float(esr_n),
+                                 float(eps_energy), _ptr(loss_sum), int(hidden), int(n_tanh), _stream())
+    _check(rc, "wdf_mlp_fit_epoch")
+
+
 def clipper_mlp_wgrad(ain, lrin, gb, theta2, w, hidden, n_tanh, fs):
     """-> gw [wdf_mlp_weight_count]: dL/dw from what clipper_mlp_bwd wrote (see include/wdf_hip.h)."""
     require_gpu()
@@ -472,6 +492,7 @@ class Adam:
         self.b1, self.b2, self.eps = float(beta_1), float(beta_2), float(epsilon)
         f = lambda a: torch.as_tensor(a, dtype=torch.float32).expand(self.n).contiguous().to(device)  # noqa: E731
         self.lr = f(lr)
+        self.lr_scalar = float(lr) if np.ndim(lr) == 0 else None
         self.lo = None if lo is None else f(lo)
         self.hi = None if hi is None else f(hi)
         self.m = torch.zeros(self.n, dtype=torch.float32, device=device)

@@ -168,6 +168,15 @@ int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, con
  * when lrin is given).                                                                    */
 int wdf_mlp_eval(const float* ain, const float* lrin, const float* w, int hidden, int n_tanh_layers,
                  float* out, int64_t S, void* stream);
+/* One epoch of the pre-training fit in ONE launch (diode_pretraining.py:159-160: Keras fit =
+ * Adam over shuffled mini-batches; loss = MSE + ESR, :136-155 with its N = esr_n): visits the S
+ * table points (xa = a, xl = log R, ys = target) in the order given, `batch` (<= 64) at a time,
+ * updating w and the Adam moments m, v and the iteration counter `step` in place; *loss_sum
+ * receives the sum of the batch losses.  The host reshuffles between epochs.                  */
+int wdf_mlp_fit_epoch(const float* xa, const float* xl, const float* ys, int64_t S, int batch,
+                      float* w, float* m, float* v, int32_t* step, float lr, float beta1,
+                      float beta2, float eps, float esr_n, float eps_energy, double* loss_sum,
+                      int hidden, int n_tanh_layers, void* stream);
 int64_t wdf_clipper_mlp_wgrad_ws_bytes(int hidden, int n_tanh_layers, int64_t S);
 int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb,
                           const float* theta2, const float* w, int hidden, int n_tanh_layers,

@@ -48,7 +48,7 @@ def test_pretrained_2x16_reproduces_documented_losses(golden):
     assert abs(esr - 9.49e-5) < 0.02e-5, esr             #                            "ESR = 9.49e-5"
 
 
-@pytest.mark.parametrize("n_layers,size", [(2, 8), (4, 4)])
+@pytest.mark.parametrize("n_layers,size", [(2, 8), (4, 4), (2, 16), (3, 8)])
 def test_fit_follows_float64_adam(n_layers, size):
     """fit() (HIP eval + HIP weight gradient + Adam on the device) against the same loop in
     float64 torch autograd, unshuffled so both see the same batches: after 40 steps the weights
@@ -65,8 +65,12 @@ def test_fit_follows_float64_adam(n_layers, size):
     assert (hidden, n_tanh) == (size, n_layers + 1)
     w0 = mlp_root.flat_weights(dense).detach().double()
     lr, bs, epochs = 1e-3, 32, 1
-    hist = dp.fit(model, x, y, epochs, learning_rate=lr, batch_size=bs, shuffle=False)
+    hist = dp.fit(model, x, y, epochs, learning_rate=lr, batch_size=bs, shuffle=False, fused=False)
     w_hip = mlp_root.flat_weights(mlp_root.describe(model)[0]).detach().double()
+    # the one-launch-per-epoch kernel (wdf_mlp_fit_epoch) walks the same batches
+    model_f = dp.build_model(n_layers, size, seed=3)
+    hist_f = dp.fit(model_f, x, y, epochs, learning_rate=lr, batch_size=bs, shuffle=False, fused=True)
+    w_fused = mlp_root.flat_weights(mlp_root.describe(model_f)[0]).detach().double()
 
     w = w0.clone().requires_grad_(True)
     m, v = torch.zeros_like(w), torch.zeros_like(w)
@@ -90,8 +94,18 @@ def test_fit_follows_float64_adam(n_layers, size):
             w.sub_(lr_t * m / (torch.sqrt(v) + 1e-7))
         losses.append(float(loss))
     assert it == 40
+    # a short last batch (Keras keeps it): 1280 points in batches of 48 -> 26 full + one of 32
+    m_a, m_b = dp.build_model(n_layers, size, seed=4), dp.build_model(n_layers, size, seed=4)
+    h_a = dp.fit(m_a, x, y, 2, learning_rate=lr, batch_size=48, shuffle=True, seed=7, fused=False)
+    h_b = dp.fit(m_b, x, y, 2, learning_rate=lr, batch_size=48, shuffle=True, seed=7, fused=True)
+    wa = mlp_root.flat_weights(mlp_root.describe(m_a)[0]).detach()
+    wb_ = mlp_root.flat_weights(mlp_root.describe(m_b)[0]).detach()
+    assert float((wa - wb_).abs().max()) <= 5e-4 * float(wa.abs().max())
+    assert np.allclose(h_a, h_b, rtol=2e-4)
     assert float((w_hip - w.detach()).abs().max()) <= 2e-4 * float(w.detach().abs().max())
     assert abs(hist[0] - np.mean(losses)) <= 1e-4 * np.mean(losses)
+    assert float((w_fused - w.detach()).abs().max()) <= 2e-4 * float(w.detach().abs().max())
+    assert abs(hist_f[0] - np.mean(losses)) <= 1e-4 * np.mean(losses)
     assert np.mean(losses[-8:]) < np.mean(losses[:8])
 
 
