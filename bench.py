@@ -165,10 +165,8 @@ def main():
         buf = stepper.out                              # [SSE, grads]: the kernels wrote it in place
         wdist.allreduce_sum_(buf)
         if adam is not None:
-            if len(loss_trace) < 2:
-                loss_trace.append(buf[0:1].clone())
-            else:
-                loss_trace[1] = buf[0:1].clone()
+            if not loss_trace:
+                loss_trace.append(buf[0:1].clone())        # SSE of the very first step, for the report
             adam.apply(theta, buf[1:])
         if timed:
             t_fwd.append(ev[0].elapsed_ms(ev[1]))
@@ -196,6 +194,7 @@ def main():
         step(True)
     torch.cuda.synchronize()
     tp_stat = binding.tp_status(stepper.status) if tp is not None and tp.k_fwd > 1 else None
+    buf_last = stepper.out.clone()
 
     if rank == 0:
         copy_gbs = copy_bandwidth_gbs(dev)
@@ -220,7 +219,7 @@ def main():
                        "optimizer": None if adam is None else
                        {"kind": "Adam on device (wdf_adam_step), lr = 1e-3 x component value, clip constraints",
                         "loss_first_step": float(loss_trace[0]) / n_global,
-                        "loss_last_step": float(loss_trace[1]) / n_global,
+                        "loss_last_step": float(buf_last[0]) / n_global,
                         "theta_final": [float(v) for v in theta]},
                        "x_layout": "time-major [T,B] resident copy (one-off transpose at data load, outside the timed "
                                    "region)" if tm else "batch-major [B,T] as the reference scripts hold it",
