@@ -26,20 +26,23 @@ import torch  # noqa: E402
 from wdf_hip import binding, dist as wdist, engine, workload  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_c_pmc_traffic.json")
+PMC_TRAFFIC_GLOB = os.path.join(REPO, "profiles", "*_pmc_traffic.json")
 
 
 def measured_traffic(kernel, cfg):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01_c_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, see its _doc) -- only
-    if they were taken on the configuration being run; otherwise None."""
-    try:
-        d = json.load(open(PMC_TRAFFIC))
-        if all(d["config"].get(k) == v for k, v in cfg.items()) and kernel in d["kernels"]:
-            return d["kernels"][kernel]["traffic_bytes"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    """(HBM bytes per launch of `kernel`, source file) from the committed rocprofv3 PMC passes of
+    this same command (profiles/*_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, see their _doc,
+    collected by tools/pmc_traffic.sh) -- only from a file taken on the configuration being run;
+    otherwise (None, None)."""
+    import glob
+    for path in sorted(glob.glob(PMC_TRAFFIC_GLOB), reverse=True):
+        try:
+            d = json.load(open(path))
+            if all(d["config"].get(k) == v for k, v in cfg.items()) and kernel in d["kernels"]:
+                return d["kernels"][kernel]["traffic_bytes"], os.path.relpath(path, REPO)
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
+    return None, None
 BYTES_FWD = 12                 # x 4 + y 4 + z-stash 4   (SURVEY 8d: fwd 8 B + 4 B stash)
 BYTES_BWD = 12                 # x 4 + z 4 + dL/dy 4     (the fused-MSE sweep reads y and target instead of
                                # dL/dy, 16 B; the algorithmic figure stays SURVEY's 12)
@@ -112,6 +115,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="skip the on-device Adam update of {Is, nVt, R, C} that closes every step")
+    ap.add_argument("--plan", default=None, metavar="KF,W,KB",
+                    help="pin the time-parallel plan (forward chunks, warm-up steps, reverse chunks) instead of "
+                         "autotuning it; used to profile one configuration across several rocprofv3 passes")
     ap.add_argument("--sequential", action="store_true", help="one lane per sequence, no time-parallel chunks")
     ap.add_argument("--x-batch-major", action="store_true",
                     help="hand the kernels x as [B,T] (the reference scripts' layout) instead of the engine's "
@@ -138,7 +144,10 @@ def main():
     target, _, _ = binding.clipper_fwd(x, theta_star, fs, want_stash=False)
     n_global = float(Bg * T)
     tp = None if args.sequential else engine.plan_time_parallel(B, T, th_host[2], th_host[3], fs, time_major=tm)
-    if tp is not None:                      # part of the untimed set-up: pick chunk counts on this box
+    if tp is not None and args.plan:
+        kf, w, kb = (int(v) for v in args.plan.split(","))
+        tp = tp._replace(k_fwd=kf, warmup=w, k_bwd=kb)
+    elif tp is not None:                    # part of the untimed set-up: pick chunk counts on this box
         tp = engine.autotune_time_parallel(theta, xk, target, fs, tp, time_major=tm)
     stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global, time_major=tm)
 
@@ -204,9 +213,12 @@ def main():
         fname = "clipper_fwd_tp_kernel" if (tp is not None and tp.k_fwd > 1) else "clipper_fwd_kernel"
         dom, dom_ms, dom_bytes = (fname, f_ms, BYTES_FWD) if f_ms >= b_ms else ("clipper_bwd_tp_kernel", b_ms, BYTES_BWD)
         achieved = dom_bytes * B * T / (dom_ms * 1e-3) / 1e9
-        traffic = None if tp is None else measured_traffic(dom, {
-            "B": B, "T": T, "x_layout": "time-major" if tm else "batch-major", "fwd_chunks": tp.k_fwd,
-            "fwd_warmup_steps": tp.warmup, "bwd_chunks": tp.k_bwd})
+        # a kernel's traffic depends on the batch, the layout and its OWN chunking only
+        key = {"B": B, "T": T, "x_layout": "time-major" if tm else "batch-major"}
+        if tp is not None:
+            key.update({"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup} if dom.startswith("clipper_fwd")
+                       else {"bwd_chunks": tp.k_bwd})
+        traffic, traffic_src = (None, None) if tp is None else measured_traffic(dom, key)
         out = {
             "metric": "samples/sec fwd+bwd, 1N4148 diode clipper @48kHz batch=8192; 1->8 GPU scaling",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -228,7 +240,7 @@ def main():
                         "bwd_chunks": tp.k_bwd, "verify_status": tp_stat}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": None if traffic is None else "profiles/r01_c_pmc_traffic.json",
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_sample": dom_bytes,
                          "fwd_kernel_ms": f_ms, "bwd_kernel_ms": b_ms,
                          "copy_bandwidth": copy_gbs, "frac_of_copy_bandwidth": achieved / copy_gbs},

@@ -35,7 +35,7 @@ for tm, xin in ((False, x), (True, xt)):
         ms = timeit(lambda: wb.clipper_bwd_mse_tp(xin, th, fs, zs, zT, tgt, gscale, K, ws=ws, gtheta=g, sse=sse, time_major=tm))
         print(f"bwd_mse_tp time_major={tm} K={K}: {ms:.3f} ms")
 for tm, xin in ((False, x), (True, xt)):
-    for K, W in ((8, 192), (16, 192), (32, 192)):
+    for K, W in ((8, 192), (16, 192), (16, 160), (16, 128), (24, 192), (32, 192), (32, 160), (32, 128), (64, 192)):
         ws = torch.empty((wb.lib().wdf_clipper_fwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda")
         st = torch.empty(4, dtype=torch.int32, device="cuda")
         ms = timeit(lambda: wb.clipper_fwd_tp(xin, th, fs, K, W, ws=ws, status=st, time_major=tm))
