@@ -553,10 +553,20 @@ __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
     const int64_t b = b_raw < B ? b_raw : B - 1;
     float miss = 0.0f;
     bool bad = false;
-    for (int64_t k = 1; k < K; ++k) {
-        const float m = fabsf(zwarm[k * B + b] - zend[(k - 1) * B + b]);
-        bad = bad || !(m <= tol);                               // NaN counts as bad
-        miss = fmaxf(miss, m);
+    // 8 boundaries' 16 loads in flight together: one at a time this loop is K dependent HBM
+    // round trips (measured 8.7 us for K = 16, more than the rest of the kernel's launch)
+    for (int64_t k0 = 1; k0 < K; k0 += 8) {
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t k = (k0 + j < K) ? k0 + j : K - 1;   // clamped: re-checks the last boundary
+            m[j] = fabsf(zwarm[k * B + b] - zend[(k - 1) * B + b]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bad = bad || !(m[j] <= tol);                        // NaN counts as bad
+            miss = fmaxf(miss, m[j]);
+        }
     }
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(bad);
     float wmax = miss;
@@ -765,14 +775,14 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_combine_kernel(const float*
     const int64_t b = live ? b_raw : B - 1;
     double G = 0.0, dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0;
     int64_t k = K - 1;
-    for (; k >= 3; k -= 4) {                          // 4 chunks' 36 loads in flight together
-        float v[4][kTpOut];
+    for (; k >= 7; k -= 8) {                          // 8 chunks' 72 loads in flight together
+        float v[8][kTpOut];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int i = 0; i < kTpOut; ++i) v[j][i] = part[((k - j) * kTpOut + i) * B + b];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
             dL += (double)v[j][0] * G + (double)v[j][3];
             dV += (double)v[j][1] * G + (double)v[j][4];
             dP += (double)v[j][2] * G + (double)v[j][5];
