@@ -122,32 +122,38 @@ __device__ __forceinline__ float load_one(const float* __restrict__ x, int64_t b
 // =========================================================================================
 // forward
 // =========================================================================================
-template <bool DYN_R, bool SYM, typename V>
+// FAST: see diode_pair; only with a static port resistance.
+__device__ __forceinline__ bool series_only_omega1(const ClipConsts& c)
+{
+    return c.L - fminf(c.d.l_up, c.d.l_dn) <= kSeriesOnlyBelow;
+}
+
+template <bool DYN_R, bool SYM, typename V, bool FAST = false>
 __device__ __forceinline__ V fwd_step(const ClipConsts& c, V xin, V rin, V& z)
 {
+    static_assert(!(FAST && DYN_R), "FAST needs a wave-uniform L");
     V p, Rp, L;
     step_coeffs<DYN_R, V>(c, rin, p, Rp, L);
     const V b_diff = z - xin;
     const V b_temp = -p * b_diff;
     const V a = z + b_temp;
-    const DiodeOutT<V> o = diode_pair<SYM, V>(a, L, c.d);
+    const DiodeOutT<V> o = diode_pair<SYM, V, FAST>(a, L, c.d);
     const V zn = o.b + b_temp;
     const V y = 0.5f * (zn + z);
     z = zn;
     return y;
 }
 
-template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH>
-__global__ __launch_bounds__(64) void clipper_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
-    float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
-    const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T)
+template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH, bool FAST>
+__device__ __forceinline__ void clipper_fwd_body(const ClipConsts& c, const float* __restrict__ x,
+                                                 const float* __restrict__ r, float* __restrict__ y,
+                                                 float* __restrict__ zstash, const float* __restrict__ z0,
+                                                 float* __restrict__ zT, int64_t B, int64_t T)
 {
     // Lanes past the end of the batch shadow the last sequence: they compute and store the
     // same values to the same addresses as its owner, so no store needs an exec-mask branch.
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;
-    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     float z = z0 ? z0[b] : 0.0f;                // reset(): clipper_pot.py:110-111
     float* __restrict__ yp = y + b;             // walks down column b of the [T][B] outputs
     float* __restrict__ zp = STASH ? zstash + b : nullptr;
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(64) void clipper_fwd_kernel(
 #pragma unroll
         for (int k = 0; k < kBlk; ++k) {
             if constexpr (STASH) { *zp = z; zp += B; }
-            *yp = fwd_step<DYN_R, SYM>(c, xc[k], rc[k], z);
+            *yp = fwd_step<DYN_R, SYM, float, FAST>(c, xc[k], rc[k], z);
             yp += B;
         }
     }
@@ -179,10 +185,29 @@ __global__ __launch_bounds__(64) void clipper_fwd_kernel(
         const float xin = load_one<TIME_MAJOR>(x, b, B, T, t);
         const float rin = DYN_R ? load_one<TIME_MAJOR>(r, b, B, T, t) : 1.0f;
         if constexpr (STASH) { *zp = z; zp += B; }
-        *yp = fwd_step<DYN_R, SYM>(c, xin, rin, z);
+        *yp = fwd_step<DYN_R, SYM, float, FAST>(c, xin, rin, z);
         yp += B;
     }
     if (zT) zT[b] = z;
+}
+
+// The same FAST / general choice as the time-parallel forward (one wave-uniform test per kernel),
+// so both kernels run the same arithmetic on the same data: chunk 0 of the time-parallel forward
+// is bit-identical to this kernel, and a repaired tile is bit-identical to an unrepaired run.
+template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH>
+__global__ __launch_bounds__(64) void clipper_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
+    float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
+    const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T)
+{
+    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+    if constexpr (!DYN_R) {
+        if (series_only_omega1(c)) {
+            clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, true>(c, x, r, y, zstash, z0, zT, B, T);
+            return;
+        }
+    }
+    clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, false>(c, x, r, y, zstash, z0, zT, B, T);
 }
 
 // =========================================================================================
@@ -474,22 +499,18 @@ __device__ __forceinline__ V gather_t(const float (&v)[VT<V>::N][kTile], int i)
 }
 
 // Chunk geometry: L and W are multiples of kTile (host guarantees it).  TM: x and r are [T][B].
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V>
-__global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
-    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
-    float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
-    const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
-    TpStatus* __restrict__ status, int64_t B, int64_t Bh, int64_t T, int64_t L, int64_t W)
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V, bool FAST>
+__device__ __forceinline__ void clipper_fwd_tp_body(
+    const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r, float* __restrict__ y,
+    float* __restrict__ zstash, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
+    float* __restrict__ zend, int64_t B, int64_t Bh, int64_t T, int64_t L, int64_t W)
 {
     constexpr int N = VT<V>::N;
-    // the verify kernel (next launch on the stream) accumulates into the status word: clear it here
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = TpStatus{0, 0.0f, 0, 0};
     const LaneSeqs<V> q(B, Bh);
     const int64_t k = blockIdx.y;
     const int64_t t0 = k * L;                               // first owned step (multiple of kTile)
     const int64_t t1 = (t0 + L < T) ? t0 + L : T;           // one past the last owned step
     const int64_t tw = (t0 > W) ? t0 - W : 0;               // warm-up start (multiple of kTile)
-    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     V z = vsplat<V>(0.0f);
     if (tw == 0 && z0) z = load_one_v<V>(z0, q, 1, 0, 0);
 
@@ -515,13 +536,13 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
         }
         if (t < t0) {                                       // ---- warm-up tile: nothing stored
 #pragma unroll
-            for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z);
+            for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z);
             if (t + kTile == t0) store_v<V>(zwarm, q, k * B, z);
         } else {                                            // ---- owned tile
 #pragma unroll
             for (int i = 0; i < kTile; ++i) {
                 if constexpr (STASH) store_v<V>(zstash, q, off, z);
-                store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z));
+                store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V, FAST>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z));
                 off += B;
             }
         }
@@ -531,11 +552,31 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
         const V xin = load_one_v<V>(x, q, TM ? 1 : T, TM ? B : 1, t);
         const V rin = DYN_R ? load_one_v<V>(r, q, TM ? 1 : T, TM ? B : 1, t) : vsplat<V>(1.0f);
         if constexpr (STASH) store_v<V>(zstash, q, off, z);
-        store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V>(c, xin, rin, z));
+        store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V, FAST>(c, xin, rin, z));
         off += B;
     }
     store_v<V>(zend, q, k * B, z);
     if (zT && t1 == T) store_v<V>(zT, q, 0, z);
+}
+
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V>
+__global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
+    float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
+    const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
+    TpStatus* __restrict__ status, int64_t B, int64_t Bh, int64_t T, int64_t L, int64_t W)
+{
+    // the verify kernel (next launch on the stream) accumulates into the status word: clear it here
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = TpStatus{0, 0.0f, 0, 0};
+    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+    if constexpr (!DYN_R) {
+        if (series_only_omega1(c)) {                        // wave-uniform: every practical diode
+            clipper_fwd_tp_body<DYN_R, SYM, TM, VEC4, STASH, V, true>(c, x, r, y, zstash, z0, zT, zwarm, zend, B, Bh, T,
+                                                                      L, W);
+            return;
+        }
+    }
+    clipper_fwd_tp_body<DYN_R, SYM, TM, VEC4, STASH, V, false>(c, x, r, y, zstash, z0, zT, zwarm, zend, B, Bh, T, L, W);
 }
 
 // Verification + tile-local repair in one launch.  Wave w owns sequences [64 w, 64 w + 64): it
@@ -580,18 +621,16 @@ __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
         }
     }
     if (mask == 0) return;                                      // wave-uniform: the common case
+    // cold path: this wave re-runs its 64 sequences with the sequential kernel's own body (same
+    // source, same FAST / general choice => the same arithmetic as an unrepaired sequential run)
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    float z = z0 ? z0[b] : 0.0f;
-    float* __restrict__ yp = y + b;
-    float* __restrict__ zp = STASH ? zstash + b : nullptr;
-    for (int64_t t = 0; t < T; ++t) {                           // cold path: plain loop
-        const float xin = load_one<TM>(x, b, B, T, t);
-        const float rin = DYN_R ? load_one<TM>(r, b, B, T, t) : 1.0f;
-        if constexpr (STASH) { *zp = z; zp += B; }
-        *yp = fwd_step<DYN_R, SYM>(c, xin, rin, z);
-        yp += B;
+    if constexpr (!DYN_R) {
+        if (series_only_omega1(c)) {
+            clipper_fwd_body<DYN_R, SYM, TM, false, STASH, true>(c, x, r, y, zstash, z0, zT, B, T);
+            return;
+        }
     }
-    if (zT) zT[b] = z;
+    clipper_fwd_body<DYN_R, SYM, TM, false, STASH, false>(c, x, r, y, zstash, z0, zT, B, T);
 }
 
 // ---- exact time-parallel reverse sweep ----------------------------------------------------------

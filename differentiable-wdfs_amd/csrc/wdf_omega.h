@@ -155,7 +155,14 @@ using DiodeOut = DiodeOutT<float>;
 // Reflected wave of the diode pair (diode_pretraining.py:46-59).  L = log(Rp Is / nVt) (a V:
 // it varies per lane when a per-sample resistance is streamed).
 // SYM: N_up == N_down (mu0 = mu1, no per-sign select).
-template <bool SYM, typename V>
+// FAST: the caller has checked, once per kernel, that L - min(log N_up, log N_down) <=
+// kSeriesOnlyBelow (static port resistance: a wave-uniform fact), i.e. that omega_1's argument
+// can never leave the series-only region; the per-step wavefront ballot and its bookkeeping go
+// (the second-iteration request it also guards is provably never raised in fp32, see
+// kSecondIterResidual).  With SYM, lam (w0 - w1) becomes copysign(w0 - w1, a): w0 >= w1 since
+// omega is increasing, and at a = 0 both are the same series of the same argument, so the
+// difference is exactly 0 as lam = sign(0) = 0 requires.
+template <bool SYM, typename V, bool FAST = false>
 __device__ __forceinline__ DiodeOutT<V> diode_pair(V a, V L, const DiodeStatic& c)
 {
     DiodeOutT<V> o;
@@ -186,15 +193,18 @@ __device__ __forceinline__ DiodeOutT<V> diode_pair(V a, V L, const DiodeStatic& 
     typename VT<V>::mask again0;
     o.w0 = omega_one_step<V>(u0, again0);
     o.w1 = omega_series<V>(u1);
-    const auto general1 = vgt_c(u1, kSeriesOnlyBelow);
-    if (__builtin_amdgcn_ballot_w64(many(mor(again0, general1)))) {
-        o.w0 = omega_second_step<V>(u0, o.w0, again0);
-        typename VT<V>::mask again1;
-        V w1g = omega_one_step<V>(u1, again1);
-        w1g = omega_second_step<V>(u1, w1g, again1);
-        o.w1 = vsel(general1, w1g, o.w1);
+    if constexpr (!FAST) {
+        const auto general1 = vgt_c(u1, kSeriesOnlyBelow);
+        if (__builtin_amdgcn_ballot_w64(many(mor(again0, general1)))) {
+            o.w0 = omega_second_step<V>(u0, o.w0, again0);
+            typename VT<V>::mask again1;
+            V w1g = omega_one_step<V>(u1, again1);
+            w1g = omega_second_step<V>(u1, w1g, again1);
+            o.w1 = vsel(general1, w1g, o.w1);
+        }
     }
-    if constexpr (SYM) o.b = a - (c.two_v * c.m_dn) * (o.lam * (o.w0 - o.w1));        // (:56-59)
+    if constexpr (SYM && FAST) o.b = a - (c.two_v * c.m_dn) * vcopysign(o.w0 - o.w1, a);
+    else if constexpr (SYM) o.b = a - (c.two_v * c.m_dn) * (o.lam * (o.w0 - o.w1));   // (:56-59)
     else o.b = a - c.two_v * (o.lam * (o.m0 * o.w0 - o.m1 * o.w1));
     return o;
 }

@@ -82,6 +82,9 @@ __device__ __forceinline__ v2f vsel(v2i m, float a, float b) { return v2f{m.x ? 
 // sign(a) in {-1, 0, +1}  (np.sign)
 __device__ __forceinline__ float vsign(float a) { return (a > 0.0f) ? 1.0f : ((a < 0.0f) ? -1.0f : 0.0f); }
 __device__ __forceinline__ v2f vsign(v2f a) { return v2f{vsign(a.x), vsign(a.y)}; }
+// |m| with the sign of s: one v_bfi_b32
+__device__ __forceinline__ float vcopysign(float m, float s) { return __builtin_copysignf(m, s); }
+__device__ __forceinline__ v2f vcopysign(v2f m, v2f s) { return v2f{__builtin_copysignf(m.x, s.x), __builtin_copysignf(m.y, s.y)}; }
 
 // keep a value as computed (opaque to the optimiser at this point)
 __device__ __forceinline__ void vpin(float& a) { asm volatile("" : "+v"(a)); }
