@@ -16,13 +16,16 @@ import numpy as np
 from wdf_hip import compat_tf as tf
 
 
+_ACTIVATIONS = {"tanh": tf.nn.tanh, "relu": tf.nn.relu}      # JSON "activation" -> entry appended to .layers
+
+
 class DenseLayer(tf.Module):
-    """Dense layer without weights sharing (layers.py:7-39)."""
+    """Dense layer without weights sharing (layers.py:7-39): kernel [1, in, out], bias [1, out]."""
 
     def __init__(self, in_size, out_size, kernel_init=None, bias_init=None):
         super().__init__()
-        kernel_init = tf.keras.initializers.Orthogonal() if kernel_init is None else kernel_init
-        bias_init = tf.keras.initializers.Zeros() if bias_init is None else bias_init
+        kernel_init = kernel_init or tf.keras.initializers.Orthogonal()
+        bias_init = bias_init or tf.keras.initializers.Zeros()
         self.kernel = tf.Variable(self.init_weights(in_size, out_size, kernel_init), dtype=tf.float32)
         self.bias = tf.Variable(self.init_bias(out_size, bias_init), dtype=tf.float32)
 
@@ -33,8 +36,9 @@ class DenseLayer(tf.Module):
         return [initializer(shape=(size,) if np.isscalar(size) else size)]
 
     def set_weights(self, json_weights):
-        self.kernel.assign(np.array([json_weights[0]]))
-        self.bias.assign(np.array([json_weights[1]]))
+        kernel, bias = json_weights[0], json_weights[1]
+        self.kernel.assign(np.array([kernel]))
+        self.bias.assign(np.array([bias]))
 
     def __call__(self, input):  # noqa: A002
         return tf.matmul(input, self.kernel) + self.bias
@@ -47,21 +51,20 @@ class DenseRootModel(tf.Module):
         super().__init__()
         self.a = tf.Variable(initial_value=tf.zeros(1), name="incident_wave", trainable=False)
         self.b = tf.Variable(initial_value=tf.zeros(1), name="reflected_wave", trainable=False)
-        in_size = json["in_shape"][-1]
         self.layers = []
-        prev_size = in_size
-        for l in json["layers"]:
-            if l["type"] == "dense":
-                next_size = l["shape"][-1]
-                if verbose:
-                    print(f"Adding Dense layer with size [{prev_size}, {next_size}]")
-                self.layers.append(DenseLayer(prev_size, next_size))
-                self.layers[-1].set_weights(l["weights"])
-                prev_size = next_size
-                if l["activation"] == "relu":
-                    self.layers.append(tf.nn.relu)
-                elif l["activation"] == "tanh":
-                    self.layers.append(tf.nn.tanh)
+        width = json["in_shape"][-1]
+        for entry in json["layers"]:
+            if entry["type"] != "dense":                     # e.g. the Keras InputLayer written as "unknown"
+                continue
+            out_width = entry["shape"][-1]
+            if verbose:
+                print(f"Adding Dense layer with size [{width}, {out_width}]")
+            dense = DenseLayer(width, out_width)
+            dense.set_weights(entry["weights"])
+            self.layers.append(dense)
+            if entry["activation"] in _ACTIVATIONS:
+                self.layers.append(_ACTIVATIONS[entry["activation"]])
+            width = out_width
 
     def incident(self, x):
         self.a = x[:, :, 0]
@@ -72,7 +75,7 @@ class DenseRootModel(tf.Module):
         if hasattr(x, "__wdf_root__"):
             self.b = x.__wdf_root__(self)        # recorded loop: becomes the kernel's root
             return self.b
-        for l in self.layers:
-            x = l(x)
+        for layer in self.layers:
+            x = layer(x)
         self.b = x
         return self.b

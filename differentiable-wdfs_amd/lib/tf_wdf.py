@@ -41,28 +41,43 @@ def voltage(wdf):
 
 
 class _Element(tf.Module):
+    """What every one-port / adaptor shares (tf_wdf.py:16-17 and the like): zero-initialised
+    incident and reflected waves, `incident` storing the wave, a no-op `calc_impedance`."""
+
     def __init__(self):
         super().__init__()
-        # tf_wdf.py:16-17 etc.: every element starts with zero incident / reflected waves
         self.a = tf.Variable(initial_value=tf.zeros(1), name="incident_wave", trainable=False)
         self.b = tf.Variable(initial_value=tf.zeros(1), name="reflected_wave", trainable=False)
 
-
-class IdealVoltageSource(_Element):
-    '''Ideal voltage source ROOT: b = -a + 2 Vs  (tf_wdf.py:13-28).'''
-
-    def set_voltage(self, voltage):
-        self.Vs = _trace.bind_voltage(voltage)       # a sample of a sequence tensor starts/continues a recorded loop
+    def calc_impedance(self):
+        pass
 
     def incident(self, x):
         self.a = x
 
+    def _emit(self, wave):
+        self.b = wave
+        return wave
+
+
+class _Source:
+    def set_voltage(self, voltage):
+        # a sample of a sequence tensor starts / continues a recorded loop (wdf_hip.trace)
+        self.Vs = _trace.bind_voltage(voltage)
+
+
+def _clipped(lo, hi):
+    return lambda z: tf.clip_by_value(z, lo, hi)
+
+
+class IdealVoltageSource(_Source, _Element):
+    '''Ideal voltage source ROOT: b = -a + 2 Vs  (tf_wdf.py:13-28).'''
+
     def reflected(self):
-        self.b = -self.a + tf.constant(2.0) * self.Vs
-        return self.b
+        return self._emit(-self.a + tf.constant(2.0) * self.Vs)
 
 
-class ResistiveVoltageSource(_Element):
+class ResistiveVoltageSource(_Source, _Element):
     '''Resistive voltage source leaf: b = Vs  (tf_wdf.py:31-59).  R defaults to 1e-9, may be
     trainable, has no constraint; set_resistance REPLACES R by a tensor (:51-52).'''
 
@@ -70,24 +85,14 @@ class ResistiveVoltageSource(_Element):
         super().__init__()
         self.R = tf.Variable(initial_value=initial_R, name="resistance", trainable=trainable)
 
-    def calc_impedance(self):
-        pass
-
     def reset(self):
         self.a = tf.zeros(1)
-
-    def set_voltage(self, voltage):
-        self.Vs = _trace.bind_voltage(voltage)
 
     def set_resistance(self, resistance):
         self.R = _trace.bind_resistance(self, resistance)
 
-    def incident(self, x):
-        self.a = x
-
     def reflected(self):
-        self.b = self.Vs * tf.ones_like(self.a)
-        return self.b
+        return self._emit(self.Vs * tf.ones_like(self.a))
 
 
 class Resistor(_Element):
@@ -95,23 +100,14 @@ class Resistor(_Element):
 
     def __init__(self, initial_R, trainable=False):
         super().__init__()
-        self.R = tf.Variable(
-            initial_value=initial_R, name="resistance", dtype=tf.float32, trainable=trainable,
-            constraint=lambda z: tf.clip_by_value(z, 180.0, 1.0e6),
-        )
-
-    def calc_impedance(self):
-        pass
+        self.R = tf.Variable(initial_value=initial_R, name="resistance", dtype=tf.float32, trainable=trainable,
+                             constraint=_clipped(180.0, 1.0e6))
 
     def set_resistance(self, resistance):
         self.R = resistance
 
-    def incident(self, x):
-        self.a = x
-
     def reflected(self):
-        self.b = tf.zeros_like(self.a)
-        return self.b
+        return self._emit(tf.zeros_like(self.a))
 
 
 class Capacitor(_Element):
@@ -121,10 +117,8 @@ class Capacitor(_Element):
     def __init__(self, initial_C, FS, trainable=False):
         super().__init__()
         self.FS = FS
-        self.C = tf.Variable(
-            initial_value=initial_C, name="capacitance", dtype=tf.float32, trainable=trainable,
-            constraint=lambda z: tf.clip_by_value(z, 0.1e-12, 1.0),
-        )
+        self.C = tf.Variable(initial_value=initial_C, name="capacitance", dtype=tf.float32, trainable=trainable,
+                             constraint=_clipped(0.1e-12, 1.0))
         self.R = tf.Variable(initial_value=1.0 / (2.0 * initial_C * FS), name="impedance", trainable=False)
         self.z = tf.Variable(initial_value=0.0, name="state", trainable=False)
 
@@ -135,83 +129,80 @@ class Capacitor(_Element):
         self.z = tf.zeros(1)
 
     def incident(self, x):
-        self.a = x
-        self.z = self.a
+        self.a = self.z = x
 
     def reflected(self):
-        self.b = _trace.state(self)      # = self.z (as the step's state symbol while a loop is recorded)
-        return self.b
+        return self._emit(_trace.state(self))    # = self.z (the step's state symbol while a loop is recorded)
 
 
-class Series(_Element):
+class _Adaptor(_Element):
+    def __init__(self, *ports):
+        super().__init__()
+        for i, port in enumerate(ports, start=1):
+            setattr(self, f"P{i}", port)
+        self._n_ports = len(ports)
+
+    def _children_impedance(self):
+        for i in range(1, self._n_ports + 1):
+            getattr(self, f"P{i}").calc_impedance()
+
+
+class Series(_Adaptor):
     '''3-port series adaptor, port 3 reflection-free (tf_wdf.py:129-155).'''
 
     def __init__(self, P1, P2):
-        super().__init__()
-        self.P1 = P1
-        self.P2 = P2
+        super().__init__(P1, P2)
 
     def calc_impedance(self):
-        self.P1.calc_impedance()
-        self.P2.calc_impedance()
+        self._children_impedance()
         self.R = self.P1.R + self.P2.R
-        self.p1R = self.P1.R / self.R
-        self.p2R = self.P2.R / self.R
+        self.p1R, self.p2R = self.P1.R / self.R, self.P2.R / self.R
 
     def incident(self, x):
-        # reads the children's waves stored by the last reflected() (:148)
-        b1 = self.P1.b - self.p1R * (x + self.P1.b + self.P2.b)
-        self.P1.incident(b1)
-        self.P2.incident(-(x + b1))
+        # uses the children's waves stored by the last reflected() (:148)
+        down1 = self.P1.b - self.p1R * (x + self.P1.b + self.P2.b)
+        self.P1.incident(down1)
+        self.P2.incident(-(x + down1))
         self.a = x
 
     def reflected(self):
-        self.b = -(self.P1.reflected() + self.P2.reflected())
-        return self.b
+        return self._emit(-(self.P1.reflected() + self.P2.reflected()))
 
 
-class Parallel(_Element):
+class Parallel(_Adaptor):
     '''3-port parallel adaptor (tf_wdf.py:158-192); b_diff / b_temp carry from reflected()
     to incident().'''
 
     def __init__(self, P1, P2):
-        super().__init__()
-        self.P1 = P1
-        self.P2 = P2
+        super().__init__(P1, P2)
 
     def calc_impedance(self):
-        self.P1.calc_impedance()
-        self.P2.calc_impedance()
-        G1 = 1.0 / self.P1.R
-        G2 = 1.0 / self.P2.R
-        G = G1 + G2
-        self.R = 1.0 / G
-        self.p1R = G1 / G
+        self._children_impedance()
+        G1, G2 = 1.0 / self.P1.R, 1.0 / self.P2.R
+        self.R = 1.0 / (G1 + G2)
+        self.p1R = G1 / (G1 + G2)
 
     def incident(self, x):
-        b2 = x + self.b_temp
-        self.P1.incident(self.b_diff + b2)
-        self.P2.incident(b2)
+        down2 = x + self.b_temp
+        self.P1.incident(self.b_diff + down2)
+        self.P2.incident(down2)
         self.a = x
 
     def reflected(self):
-        b1 = self.P1.reflected()
-        b2 = self.P2.reflected()
-        self.b_diff = b2 - b1
+        up1, up2 = self.P1.reflected(), self.P2.reflected()
+        self.b_diff = up2 - up1
         self.b_temp = -self.p1R * self.b_diff
-        self.b = b2 + self.b_temp
-        return self.b
+        return self._emit(up2 + self.b_temp)
 
 
-class Inverter(_Element):
+class Inverter(_Adaptor):
     '''2-port polarity inverter (tf_wdf.py:195-214).'''
 
     def __init__(self, P1):
-        super().__init__()
-        self.P1 = P1
+        super().__init__(P1)
 
     def calc_impedance(self):
-        self.P1.calc_impedance()
+        self._children_impedance()
         self.R = self.P1.R
 
     def incident(self, x):
@@ -219,8 +210,7 @@ class Inverter(_Element):
         self.a = x
 
     def reflected(self):
-        self.b = -self.P1.reflected()
-        return self.b
+        return self._emit(-self.P1.reflected())
 
 
 class DiodePair(_Element):
@@ -243,21 +233,17 @@ class DiodePair(_Element):
         self.next = next
         self.N_up, self.N_down = int(N_up), int(N_down)
         self.Is = tf.Variable(initial_value=Is, name="saturation_current", dtype=tf.float32, trainable=trainable,
-                              constraint=lambda z: tf.clip_by_value(z, 1.0e-15, 1.0e-3))
+                              constraint=_clipped(1.0e-15, 1.0e-3))
         self.nVt = tf.Variable(initial_value=float(nDiodes) * float(Vt), name="n_thermal_voltage",
                                dtype=tf.float32, trainable=trainable,
-                               constraint=lambda z: tf.clip_by_value(z, 1.0e-3, 1.0))
+                               constraint=_clipped(1.0e-3, 1.0))
 
     def calc_impedance(self):
         # Toms917DiodePair.h:37-42: the root's constants follow the tree's port resistance
         self.R = self.next.R
 
-    def incident(self, x):
-        self.a = x
-
     def reflected(self):
-        self.b = _lowering.diode_pair_reflected(self)
-        return self.b
+        return self._emit(_lowering.diode_pair_reflected(self))
 
 
 # ---- fast tier ------------------------------------------------------------------------------
