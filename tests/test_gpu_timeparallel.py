@@ -193,3 +193,38 @@ def test_plan_time_parallel_degrades_gracefully():
     assert slow.k_fwd == 1 and slow.k_bwd == 32
     big = engine.plan_time_parallel(1 << 20, 4096, 45.0e3, 4.7e-9, 48000.0)  # plenty of waves already
     assert big.k_fwd == 1 and big.k_bwd == 1
+
+
+def test_indexing_beyond_2_31_elements(wb):
+    """Maximum-size edge: B*T = 2.29e9 elements per array (> 2^31, 9.2 GB each).  Picked sequences
+    -- first, last, and ones whose offsets b*T straddle 2^31 and 2^32 bytes -- must equal the same
+    sequences run alone, forward (sequential and time-parallel) and reverse sweep."""
+    B, T = 32768, 70000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * (1 << 30):
+        pytest.skip("needs 60 GB of free HBM")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    x = torch.empty((B, T), dtype=torch.float32, device="cuda").normal_(0.0, 1.2, generator=gen)
+    from wdf_hip import workload
+    th = dev(workload.clipper_theta())
+    pick = [0, 1, 7669, 7670, 15339, 15340, 30678, 30679, B - 2, B - 1]     # 2^29/T, 2^30/T, 2^31/T element offsets
+    xs = x[pick].contiguous()
+    y_ref, zs_ref, _ = wb.clipper_fwd(xs, th, FS)
+    y, zs, _ = wb.clipper_fwd(x, th, FS)
+    assert torch.equal(y[:, pick], y_ref) and torch.equal(zs[:, pick], zs_ref)
+    del y
+    y2, zs2, _, st = wb.clipper_fwd_tp(x, th, FS, 16, 192)
+    assert wb.tp_status(st)["n_bad"] == 0
+    assert float((y2[:, pick] - y_ref).abs().max()) <= 1e-6
+    del zs2
+    # reverse sweep: a gradient that is non-zero only on the picked sequences must equal theirs alone
+    gy = y2
+    gy.zero_()
+    g_small = torch.randn(T, len(pick), device="cuda", generator=gen) / T
+    gy[:, pick] = g_small
+    g_ref, _ = wb.clipper_bwd(xs, th, FS, zs_ref, g_small.contiguous())
+    g_seq, _ = wb.clipper_bwd(x, th, FS, zs, gy)
+    g_tp, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, 32)
+    for g in (g_seq, g_tp):
+        assert float(((g - g_ref).abs() / g_ref.abs()).max()) <= 2e-5, (g, g_ref)
