@@ -427,6 +427,7 @@ struct TpStatus {
 template <typename V>
 struct LaneSeqs {
     int64_t b[VT<V>::N];
+    uint32_t boff[VT<V>::N];       // b * 4: byte offset of the lane's sequence inside a [B] row (B < 2^30)
     __device__ __forceinline__ LaneSeqs(int64_t B, int64_t Bh)
     {
         const int64_t b0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -434,16 +435,32 @@ struct LaneSeqs {
         for (int j = 0; j < VT<V>::N; ++j) {
             const int64_t bj = (b0 < Bh ? b0 : Bh - 1) + j * Bh;
             b[j] = bj < B ? bj : B - 1;
+            boff[j] = (uint32_t)b[j] * 4u;
         }
     }
 };
+
+// One element of a wave-uniform [B] row at the lane's 32-bit byte offset: selects
+// `global_load_dword v, voff, s[row]` (see store_row_v).
+__device__ __forceinline__ float load_row_elem(const float* __restrict__ row, uint32_t boff)
+{
+    asm("" : "+v"(boff));
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + boff);
+}
 
 template <typename V, bool TIME_MAJOR, bool VEC4>
 __device__ __forceinline__ void load_block_v(const float* __restrict__ x, const LaneSeqs<V>& q, int64_t B, int64_t T,
                                              int64_t t0, float (&v)[VT<V>::N][kBlk])
 {
 #pragma unroll
-    for (int j = 0; j < VT<V>::N; ++j) load_block<TIME_MAJOR, VEC4>(x, q.b[j], B, T, t0, v[j]);
+    for (int j = 0; j < VT<V>::N; ++j) {
+        if constexpr (TIME_MAJOR) {
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k) v[j][k] = load_row_elem(x + (t0 + k) * B, q.boff[j]);
+        } else {
+            load_block<TIME_MAJOR, VEC4>(x, q.b[j], B, T, t0, v[j]);
+        }
+    }
 }
 
 template <typename V>
@@ -472,6 +489,23 @@ __device__ __forceinline__ void store_v(float* __restrict__ p, const LaneSeqs<V>
     for (int j = 0; j < VT<V>::N; ++j) p[off + q.b[j]] = vget(v, j);
 }
 
+// Row store: `row` is a wave-uniform pointer to a [B] row of a time-major array, the lane adds its
+// 32-bit byte offset.  Written this way the store is `global_store_dword voff, vdata, s[row]`: the
+// row pointer advances on the scalar unit and the step spends no VALU instruction on addresses
+// (with per-lane 64-bit pointers every store costs a v_lshl_add_u64).
+template <typename V>
+__device__ __forceinline__ void store_row_v(float* __restrict__ row, const LaneSeqs<V>& q, V v)
+{
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) {
+        // the empty asm keeps the 32 -> 64-bit extension of the offset in this basic block, where
+        // instruction selection can see it and pick the SGPR-base addressing mode
+        uint32_t o = q.boff[j];
+        asm("" : "+v"(o));
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(row) + o) = vget(v, j);
+    }
+}
+
 constexpr int kTile = 32;      // x / r steps per lane per load burst = one 128-byte line of the row
 
 template <typename V, bool TM, bool VEC4>
@@ -482,7 +516,7 @@ __device__ __forceinline__ void load_tile_v(const float* __restrict__ x, const L
     for (int j = 0; j < VT<V>::N; ++j) {
         if constexpr (TM) {
 #pragma unroll
-            for (int i = 0; i < kTile; ++i) v[j][i] = x[(t0 + i) * B + q.b[j]];     // coalesced across lanes
+            for (int i = 0; i < kTile; ++i) v[j][i] = load_row_elem(x + (t0 + i) * B, q.boff[j]);   // coalesced across lanes
         } else {
             load_row<kTile, VEC4>(x, q.b[j], T, t0, v[j]);
         }
@@ -524,8 +558,13 @@ __device__ __forceinline__ void clipper_fwd_tp_body(
         load_tile_v<V, TM, VEC4>(x, q, B, T, tw, xn);
         if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, tw, rn);
     }
-    int64_t off = t0 * B;
-    for (int64_t t = tw; t < nfull_end; t += kTile) {
+    float* __restrict__ yrow = y + t0 * B;                   // wave-uniform row pointers
+    float* __restrict__ zrow = STASH ? zstash + t0 * B : nullptr;
+    // Two loops, not one loop with a branch: the s_waitcnt the compiler places before the tile
+    // copy has to hold for every path into it, and behind the store-free warm-up path only
+    // vmcnt(0) does -- which, on the owned path, would drain all of a tile's stores.
+    int64_t t = tw;
+    for (; t < t0 && t < nfull_end; t += kTile) {           // ---- warm-up tiles: nothing stored
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
@@ -534,26 +573,43 @@ __device__ __forceinline__ void clipper_fwd_tp_body(
             load_tile_v<V, TM, VEC4>(x, q, B, T, t + kTile, xn);
             if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, t + kTile, rn);
         }
-        if (t < t0) {                                       // ---- warm-up tile: nothing stored
 #pragma unroll
-            for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z);
-            if (t + kTile == t0) store_v<V>(zwarm, q, k * B, z);
-        } else {                                            // ---- owned tile
+        for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z);
+    }
+    if (tw < t0) store_v<V>(zwarm, q, k * B, z);            // the state this chunk arrives with
+    for (; t < nfull_end; t += kTile) {                     // ---- owned tiles
 #pragma unroll
-            for (int i = 0; i < kTile; ++i) {
-                if constexpr (STASH) store_v<V>(zstash, q, off, z);
-                store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V, FAST>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z));
-                off += B;
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int i = 0; i < kTile; ++i) { xc[j][i] = xn[j][i]; if constexpr (DYN_R) rc[j][i] = rn[j][i]; }
+        const bool more = t + kTile < nfull_end;
+        // The prefetch goes in the MIDDLE of the tile: vmcnt counts loads and stores in one queue
+        // (6 bits), so with the loads issued first the 64 stores of a tile behind them cannot be
+        // expressed and the latch waits for vmcnt(0), draining every store once per tile
+        // (measured: 16 % of the kernel).  Issued after half the steps, only 32 stores are younger
+        // than the loads and the latch waits for the loads alone.
+#pragma unroll
+        for (int i = 0; i < kTile; ++i) {
+            if (i == kTile / 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    load_tile_v<V, TM, VEC4>(x, q, B, T, t + kTile, xn);
+                    if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, t + kTile, rn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (STASH) { store_row_v<V>(zrow, q, z); zrow += B; }
+            store_row_v<V>(yrow, q, fwd_step<DYN_R, SYM, V, FAST>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z));
+            yrow += B;
         }
     }
     if (tw == t0) store_v<V>(zwarm, q, k * B, z);           // chunk 0 (or W = 0): no warm-up ran
     for (int64_t t = nfull_end; t < t1; ++t) {              // tail of the last chunk (T % 32)
         const V xin = load_one_v<V>(x, q, TM ? 1 : T, TM ? B : 1, t);
         const V rin = DYN_R ? load_one_v<V>(r, q, TM ? 1 : T, TM ? B : 1, t) : vsplat<V>(1.0f);
-        if constexpr (STASH) store_v<V>(zstash, q, off, z);
-        store_v<V>(y, q, off, fwd_step<DYN_R, SYM, V, FAST>(c, xin, rin, z));
-        off += B;
+        if constexpr (STASH) { store_row_v<V>(zrow, q, z); zrow += B; }
+        store_row_v<V>(yrow, q, fwd_step<DYN_R, SYM, V, FAST>(c, xin, rin, z));
+        yrow += B;
     }
     store_v<V>(zend, q, k * B, z);
     if (zT && t1 == T) store_v<V>(zT, q, 0, z);

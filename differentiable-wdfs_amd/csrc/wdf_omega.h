@@ -32,8 +32,8 @@ __device__ __forceinline__ V fsc_step(V x, V w, V& r)
 {
     r = vfma(vlog2(w), -kLn2, x - w);                          // x - w - log(w)
     const V wp1 = w + 1.0f;
-    const V t = (wp1 + wp1) * vfma(r, 2.0f / 3.0f, wp1);       // 2 wp1 (wp1 + 2/3 r)
-    const V e = (r * (t - r)) * vrcp(wp1 * vfma(r, -2.0f, t));
+    const V tmr = vfma(wp1 + wp1, vfma(r, 2.0f / 3.0f, wp1), -r);   // t - r,  t = 2 wp1 (wp1 + 2/3 r)
+    const V e = (r * tmr) * vrcp(wp1 * (tmr - r));             // r (t - r) / (wp1 (t - 2r))
     return vfma(w, e, w);
 }
 
@@ -53,10 +53,15 @@ constexpr float kSecondIterResidual = 0.05f;
 
 // The region-3 series: p (1 - p + 3/2 p^2 - 8/3 p^3 + 125/24 p^4), p = exp(x)  (:240-248)
 template <typename V>
+__device__ __forceinline__ V omega_series_of_exp(V p)
+{
+    return p * vfma(p, vfma(p, vfma(p, vfma(p, 125.0f / 24.0f, -8.0f / 3.0f), 1.5f), -1.0f), 1.0f);
+}
+
+template <typename V>
 __device__ __forceinline__ V omega_series(V x)
 {
-    const V p = vexp2(vmin_c(x, -2.0f) * kLog2e);              // clamp: never overflows
-    return p * vfma(p, vfma(p, vfma(p, vfma(p, 125.0f / 24.0f, -8.0f / 3.0f), 1.5f), -1.0f), 1.0f);
+    return omega_series_of_exp(vexp2(vmin_c(x, -2.0f) * kLog2e));   // clamp: never overflows
 }
 
 // Start value, branch-free: all three regional series are evaluated (their arguments clamped
@@ -71,14 +76,16 @@ __device__ __forceinline__ V omega_start(V x)
     const V q = x - 1.0f;
     const V sB = vfma(q, vfma(q, vfma(q, 13.0f / 61440.0f, -1.0f / 3072.0f), -1.0f / 192.0f), 1.0f / 16.0f);
     V wB = vfma(sB, q * q, vfma(x, 0.5f, 0.5f));
-    // region 7 (x > 1+pi): series about +infinity                     (toms917.cpp:290-296)
-    //   ((1 + (-3/2 + l/3) l) l + ((-1 + l/2) l + (l + (x - l) x) x) x) / x^3, Horner in 1/x
+    // region 7 (x > 1+pi): the leading terms of the series about +infinity, x - l + l/x, l = log x.
+    // toms917.cpp:290-296 carries two more orders (l (l/2 - 1)/x^2 + l (l^2/3 - 3l/2 + 1)/x^3); they
+    // are at most 0.033 in absolute value (at x = 1+pi, where omega = 2.96), i.e. a start value
+    // within 1.1e-2 relative, and the FSC step that always follows is fourth order: what is left
+    // is below 2e-8 relative, under fp32 rounding -- while the two orders cost 7 of the step's 68
+    // VALU instructions.  |r| stays below kSecondIterResidual (0.044 at the boundary).
     const V xc = vmax_c(x, kRegion4Hi);
-    const V l = vlog2(xc) * kLn2;
-    const V ix = vrcp(xc);
-    const V c3 = l * vfma(l, vfma(l, 1.0f / 3.0f, -1.5f), 1.0f);
-    const V c2 = l * vfma(l, 0.5f, -1.0f);
-    V wC = (xc - l) + ix * vfma(ix, vfma(ix, c3, c2), l);
+    const V lg = vlog2(xc);
+    const V l = lg * kLn2;
+    V wC = vfma(l, vrcp(xc), vfma(lg, -kLn2, xc));
     // Pin the three values as computed: without this LLVM turns the selects back into
     // exec-masked branches around the transcendentals, which serialises the two omega
     // evaluations of a step and costs more in exec-mask bookkeeping than it saves.
@@ -168,12 +175,13 @@ __device__ __forceinline__ DiodeOutT<V> diode_pair(V a, V L, const DiodeStatic& 
     DiodeOutT<V> o;
     o.lam = vsign(a);                                          // np.sign (:52)
     const V aa = vabs(a);                                      // lam * a
-    V u0, u1;
+    V u0, u1, e1 = vsplat<V>(0.0f);
     if constexpr (SYM) {
         o.m0 = o.m1 = vsplat<V>(c.m_dn);
         const V l0 = L - c.l_dn;
         u0 = vfma(aa, c.i_dn, l0);                             // (:57)
         u1 = vfma(aa, -c.i_dn, l0);                            // (:58)
+        e1 = vfma(aa, -c.i_dn * kLog2e, l0 * kLog2e);          // u1 log2(e), FAST only
     } else {
         const auto pos = vge_c(a, 0.0f);                       // mu0 = N_down if a >= 0 (:46-47)
         o.m0 = vsel(pos, c.m_dn, c.m_up);
@@ -192,7 +200,15 @@ __device__ __forceinline__ DiodeOutT<V> diode_pair(V a, V L, const DiodeStatic& 
     // one of its sequences needs it.
     typename VT<V>::mask again0;
     o.w0 = omega_one_step<V>(u0, again0);
-    o.w1 = omega_series<V>(u1);
+    if constexpr (FAST && SYM) {
+        // u1 <= kSeriesOnlyBelow on every lane: the same series as omega_series, with log2(e) folded
+        // into the argument's FMA and without the overflow clamp.  At a = 0 the exponent is
+        // l0 * log2(e), the very product omega_series(u0 = l0) forms, so w1 == w0 bit for bit there
+        // (needed for lam = 0, see above).
+        o.w1 = omega_series_of_exp<V>(vexp2(e1));
+    } else {
+        o.w1 = omega_series<V>(u1);
+    }
     if constexpr (!FAST) {
         const auto general1 = vgt_c(u1, kSeriesOnlyBelow);
         if (__builtin_amdgcn_ballot_w64(many(mor(again0, general1)))) {
