@@ -58,16 +58,16 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_fwd(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
-                float* zstash, const float* z0, float* zT, int64_t B, int64_t T, hipStream_t s)
+                float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int general, hipStream_t s)
 {
     const unsigned grid = (unsigned)((B + 63) / 64);
     EventBracket bracket(s);
     if (zstash)
         hipLaunchKernelGGL((wdf::clipper_fwd_kernel<DYN_R, SYM, TM, V4, true>), dim3(grid), dim3(64), 0, s, x, r, theta,
-                           fs, n_up, n_down, y, zstash, z0, zT, B, T);
+                           fs, n_up, n_down, y, zstash, z0, zT, B, T, general);
     else
         hipLaunchKernelGGL((wdf::clipper_fwd_kernel<DYN_R, SYM, TM, V4, false>), dim3(grid), dim3(64), 0, s, x, r,
-                           theta, fs, n_up, n_down, y, zstash, z0, zT, B, T);
+                           theta, fs, n_up, n_down, y, zstash, z0, zT, B, T, general);
 }
 
 template <bool DYN_R, bool SYM, bool TM, bool V4>
@@ -107,7 +107,7 @@ int check_common(const float* x, const float* theta, int n_up, int n_down, int64
     if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "B and T must be positive (got B=%lld T=%lld)", (long long)B, (long long)T);
     if (B > (int64_t)64 * 0x7fffffff) return fail(WDF_EINVAL, "B too large");
     if (n_up < 1 || n_down < 1 || n_up > 16 || n_down > 16) return fail(WDF_EINVAL, "n_up/n_down must be in [1,16]");
-    if (flags & ~(WDF_X_TIME_MAJOR | WDF_PREC_F64 | WDF_TP_PACK2)) return fail(WDF_EINVAL, "unknown flag bits 0x%x", flags);
+    if (flags & ~(WDF_X_TIME_MAJOR | WDF_PREC_F64 | WDF_TP_PACK2 | WDF_GENERAL_ROOT)) return fail(WDF_EINVAL, "unknown flag bits 0x%x", flags);
     if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 is not available for the Wright-omega clipper");
     return WDF_OK;
 }
@@ -141,14 +141,14 @@ TpGeom tp_geom(int64_t T, int n_chunks)
 template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
                    float* zstash, const float* z0, float* zT, float* zwarm, float* zend, wdf::TpStatus* status,
-                   float tol, int64_t B, int64_t T, TpGeom g, int64_t W, bool pack, hipStream_t s)
+                   float tol, int64_t B, int64_t T, TpGeom g, int64_t W, bool pack, int general, hipStream_t s)
 {
     const unsigned gseq = (unsigned)((B + 63) / 64);
     const int64_t Bh = pack ? (B + 1) / 2 : B;
     const dim3 grid((unsigned)((Bh + 63) / 64), (unsigned)g.K);
 #define WDF_FWD_TP(STASH_, V_)                                                                             \
     hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, TM, V4, STASH_, V_>), grid, dim3(64), 0, s, x, r, theta, \
-                       fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, status, B, Bh, T, g.L, W)
+                       fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, status, B, Bh, T, g.L, W, general)
     {
         EventBracket bracket(s);
         if (pack) {
@@ -163,11 +163,11 @@ void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs,
         if (zstash)
             hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, TM, true>), dim3(gseq), dim3(64), 0, s,
                                x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, B, T, (int64_t)g.K, tol,
-                               status);
+                               status, general);
         else
             hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, TM, false>), dim3(gseq), dim3(64), 0, s,
                                x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, B, T, (int64_t)g.K, tol,
-                               status);
+                               status, general);
     }
 }
 
@@ -313,7 +313,7 @@ int wdf_clipper_fwd(const float* x, const float* r, const float* theta, float fs
     const bool tm = flags & WDF_X_TIME_MAJOR;
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH4(launch_fwd, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
-                  B, T, (hipStream_t)stream);
+                  B, T, (flags & WDF_GENERAL_ROOT) ? 1 : 0, (hipStream_t)stream);
     return check_launch("wdf_clipper_fwd");
 }
 
@@ -364,6 +364,7 @@ int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta, float
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH4(launch_fwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
                   zwarm, zend, (wdf::TpStatus*)status, tol, B, T, g, W, (flags & WDF_TP_PACK2) != 0 && B >= 2,
+                  (flags & WDF_GENERAL_ROOT) ? 1 : 0,
                   (hipStream_t)stream);
     return check_launch("wdf_clipper_fwd_tp");
 }

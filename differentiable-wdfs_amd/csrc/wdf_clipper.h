@@ -198,11 +198,11 @@ template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH>
 __global__ __launch_bounds__(64) void clipper_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
-    const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T)
+    const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T, int general)
 {
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     if constexpr (!DYN_R) {
-        if (series_only_omega1(c)) {
+        if (!general && series_only_omega1(c)) {
             clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, true>(c, x, r, y, zstash, z0, zT, B, T);
             return;
         }
@@ -620,13 +620,13 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
-    TpStatus* __restrict__ status, int64_t B, int64_t Bh, int64_t T, int64_t L, int64_t W)
+    TpStatus* __restrict__ status, int64_t B, int64_t Bh, int64_t T, int64_t L, int64_t W, int general)
 {
     // the verify kernel (next launch on the stream) accumulates into the status word: clear it here
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = TpStatus{0, 0.0f, 0, 0};
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     if constexpr (!DYN_R) {
-        if (series_only_omega1(c)) {                        // wave-uniform: every practical diode
+        if (!general && series_only_omega1(c)) {                        // wave-uniform: every practical diode
             clipper_fwd_tp_body<DYN_R, SYM, TM, VEC4, STASH, V, true>(c, x, r, y, zstash, z0, zT, zwarm, zend, B, Bh, T,
                                                                       L, W);
             return;
@@ -644,7 +644,8 @@ __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, const float* __restrict__ zwarm,
-    const float* __restrict__ zend, int64_t B, int64_t T, int64_t K, float tol, TpStatus* __restrict__ status)
+    const float* __restrict__ zend, int64_t B, int64_t T, int64_t K, float tol, TpStatus* __restrict__ status,
+    int general)
 {
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
     // source, same FAST / general choice => the same arithmetic as an unrepaired sequential run)
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     if constexpr (!DYN_R) {
-        if (series_only_omega1(c)) {
+        if (!general && series_only_omega1(c)) {
             clipper_fwd_body<DYN_R, SYM, TM, false, STASH, true>(c, x, r, y, zstash, z0, zT, B, T);
             return;
         }
@@ -701,6 +702,9 @@ struct TpAccT {
     V bL, bV, bP;   // constant parts
 };
 
+// (The forward's FAST variant was tried here too: 10 % fewer VALU instructions, no change in run
+// time -- the sweep is not bound by instruction issue, see DESIGN.md -- so the reverse sweep keeps
+// the one general step.)
 template <bool DYN_R, bool SYM, typename V>
 __device__ __forceinline__ void bwd_tp_step(const ClipConsts& c, V xin, V rin, V z, V g, V& alpha, V& beta,
                                             TpAccT<V>& acc)
@@ -770,11 +774,11 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     int64_t B, int64_t Bh, int64_t T, int64_t L)
 {
     constexpr int N = VT<V>::N;
+    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     const LaneSeqs<V> q(B, Bh);
     const int64_t k = blockIdx.y;
     const int64_t t0 = k * L;
     const int64_t t1 = (t0 + L < T) ? t0 + L : T;
-    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     V alpha = vsplat<V>(1.0f), beta = vsplat<V>(0.0f);
     // constant parts: fp64 across 8-step blocks; G-coefficients decay geometrically: fp32 is enough
     double dbL[N], dbV[N], dbP[N], dsse[N];

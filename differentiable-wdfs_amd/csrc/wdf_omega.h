@@ -206,6 +206,7 @@ __device__ __forceinline__ DiodeOutT<V> diode_pair(V a, V L, const DiodeStatic& 
         // l0 * log2(e), the very product omega_series(u0 = l0) forms, so w1 == w0 bit for bit there
         // (needed for lam = 0, see above).
         o.w1 = omega_series_of_exp<V>(vexp2(e1));
+        vpin(o.w1);      // as a rounded value: contracted into w0 - w1 as an FMA it would not cancel at a = 0
     } else {
         o.w1 = omega_series<V>(u1);
     }

@@ -17,6 +17,15 @@ LIB_PATH = os.path.join(_HERE, "libwdf_hip.so")
 WDF_X_TIME_MAJOR = 1 << 0
 WDF_PREC_F64 = 1 << 1
 WDF_TP_PACK2 = 1 << 2
+WDF_GENERAL_ROOT = 1 << 3
+
+# Set True to make every clipper call take the general per-step root evaluation (WDF_GENERAL_ROOT):
+# parity tests compare it with the default path, tools time one against the other on the same box.
+GENERAL_ROOT = False
+
+
+def _root_flag():
+    return WDF_GENERAL_ROOT if GENERAL_ROOT else 0
 
 
 class WdfHipError(RuntimeError):
@@ -162,7 +171,7 @@ def clipper_fwd(x, theta, fs, r=None, n_up=1, n_down=1, want_stash=True, z0=None
     y = torch.empty((T, B), dtype=torch.float32, device=x.device)
     zs = torch.empty((T, B), dtype=torch.float32, device=x.device) if want_stash else None
     zT = torch.empty((B,), dtype=torch.float32, device=x.device) if want_zT else None
-    flags = WDF_X_TIME_MAJOR if time_major else 0
+    flags = (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag()
     rc = lib().wdf_clipper_fwd(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
                                _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, flags, _stream())
     _check(rc, "wdf_clipper_fwd")
@@ -187,7 +196,7 @@ def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=Fal
         gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
         accumulate = False
     gz0 = torch.empty((B,), dtype=torch.float32, device=x.device) if want_gz0 else None
-    flags = WDF_X_TIME_MAJOR if time_major else 0
+    flags = (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag()
     rc = lib().wdf_clipper_bwd(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
                                _ptr(zstash), _ptr(gy), _ptr(ws), _ptr(gtheta), _ptr(gz0),
                                1 if accumulate else 0, B, T, flags, _stream())
@@ -217,7 +226,7 @@ def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_d
     rc = lib().wdf_clipper_fwd_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(y),
                                   _ptr(zs), _ptr(z0), _ptr(zT), B, T, int(n_chunks), int(warmup), float(tol),
                                   _ptr(ws), _ptr(status),
-                                  (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0), _stream())
+                                  (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(), _stream())
     _check(rc, "wdf_clipper_fwd_tp")
     return y, zs, zT, status
 
@@ -249,7 +258,7 @@ def clipper_bwd_tp(x, theta, fs, zstash, gy, n_chunks, r=None, n_up=1, n_down=1,
     rc = lib().wdf_clipper_bwd_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(zstash),
                                   _ptr(gy), _ptr(ws), _ptr(gtheta), _ptr(gz0), 1 if accumulate else 0, B, T,
                                   int(n_chunks),
-                                  (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0), _stream())
+                                  (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(), _stream())
     _check(rc, "wdf_clipper_bwd_tp")
     return gtheta, gz0
 
@@ -282,7 +291,7 @@ def clipper_bwd_mse_tp(x, theta, fs, zstash, zT, target, gscale, n_chunks, r=Non
     rc = lib().wdf_clipper_bwd_mse_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
                                       _ptr(zstash), _ptr(zT), _ptr(target), float(gscale), _ptr(ws), _ptr(gtheta),
                                       _ptr(sse), None, 1 if accumulate else 0, B, T, int(n_chunks),
-                                      (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0),
+                                      (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(),
                                       _stream())
     _check(rc, "wdf_clipper_bwd_mse_tp")
     return gtheta, sse

