@@ -1,6 +1,10 @@
 // VALU issue-rate microbenchmark for gfx950: cycles per wave64 instruction for plain fp32 FMA,
 // packed fp32 FMA and transcendentals, at 1/2/4 waves per SIMD, dependent vs independent chains.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rate.hip -o gpurun_out/valu_rate
+// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rate.hip -o /tmp/valu_rate
+// NOTE on reading the "fma ILP=4" rows: LLVM's SLP vectoriser turns the four independent scalar
+// FMAs into v_pk_fma_f32 pairs (32 v_pk_fma per 64 source FMAs), so "ns per inst" there is per
+// SOURCE operation; one issued VALU instruction (plain or packed) costs ~2 ns per SIMD on these
+// boxes, a dependent one ~3.3 ns, a transcendental ~3.4 ns.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float v2f __attribute__((ext_vector_type(2)));
