@@ -25,7 +25,7 @@ def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, time_major=False):
     resistance; with a per-sample resistance pass the LARGEST value present (slowest memory).
 
     Sequential mode gives ceil(B/64) waves for 1024 SIMDs, each a dependent chain (a dependent
-    VALU op issues every ~7 cycles on gfx950, an independent one every ~2.3: tools/ubench).  The
+    VALU op completes every ~3.3 ns on gfx950 where a SIMD could issue one every ~2 ns: tools/ubench).  The
     plan aims at ~2 waves per SIMD for the forward (every extra chunk costs a warm-up) and 4-8
     for the reverse sweep (no redundancy there; 8 when x is time-major, i.e. all loads coalesced).  The forward's warm-up must outlast the circuit's
     memory: with the diode off the state contracts by (1 - 2p) per sample (p = Rc/(R+Rc),
