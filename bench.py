@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="skip the on-device Adam update of {Is, nVt, R, C} that closes every step")
+    ap.add_argument("--loss", default="mse", choices=["mse", "mse+esr"],
+                    help="mse: the metric's loss (default). mse+esr: clipper_pot.py's training loss past 50 samples, "
+                         "fused the same way (one extra streaming pass for the two loss sums)")
     ap.add_argument("--plan", default=None, metavar="KF,W,KB",
                     help="pin the time-parallel plan (forward chunks, warm-up steps, reverse chunks) instead of "
                          "autotuning it; used to profile one configuration across several rocprofv3 passes")
@@ -142,14 +145,16 @@ def main():
     theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
     theta_star = torch.tensor(workload.target_theta(), dtype=torch.float32, device=dev)
     target, _, _ = binding.clipper_fwd(x, theta_star, fs, want_stash=False)
-    n_global = float(Bg * T)
+    skip = 50 if args.loss == "mse+esr" else 0               # skip_samples, clipper_pot.py:232
+    n_global = float(Bg * (T - skip))
     tp = None if args.sequential else engine.plan_time_parallel(B, T, th_host[2], th_host[3], fs, time_major=tm)
     if tp is not None and args.plan:
         kf, w, kb = (int(v) for v in args.plan.split(","))
         tp = tp._replace(k_fwd=kf, warmup=w, k_bwd=kb)
     elif tp is not None:                    # part of the untimed set-up: pick chunk counts on this box
         tp = engine.autotune_time_parallel(theta, xk, target, fs, tp, time_major=tm)
-    stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global, time_major=tm)
+    stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global, time_major=tm, loss=args.loss, skip=skip,
+                             sums_allreduce=wdist.allreduce_sum_ if world > 1 else None)
 
     # the update that closes a training step (lpf.py:93-94: one Adam per component, its learning
     # rate scaled to the component; tf_wdf.py:74,104 clip constraints), on the device
@@ -224,7 +229,7 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"1N4148 diode clipper fwd+bwd (grads wrt Is,nVt,R,C), MSE loss, "
+            "config": {"workload": f"1N4148 diode clipper fwd+bwd (grads wrt Is,nVt,R,C), {args.loss.upper()} loss, "
                                    f"{B} sequences x {T} samples @ {int(fs)} Hz per GPU (BASELINE configs[2])",
                        "global_batch": Bg, "seq_len": T, "parallelism": f"dp{world}",
                        "loss": float(loss) / n_global, "grad": [float(g) for g in grad],

@@ -174,19 +174,22 @@ void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs,
 template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
                    const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
-                   float* part, double* ws, float* gz0, int64_t B, int64_t T, TpGeom g, bool pack, hipStream_t s)
+                   float* part, double* ws, float* gz0, int64_t B, int64_t T, TpGeom g, bool pack, const float* gcoef,
+                   int64_t skip, hipStream_t s)
 {
     const int64_t Bh = pack ? (B + 1) / 2 : B;
     const dim3 grid((unsigned)((Bh + 63) / 64), (unsigned)g.K);
 #define WDF_BWD_TP(MSE_, V_)                                                                               \
     hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, TM, V4, MSE_, V_>), grid, dim3(64), 0, s, x, r, theta, \
-                       fs, n_up, n_down, zstash, gy, target, zT, gscale, part, B, Bh, T, g.L)
+                       fs, n_up, n_down, zstash, gy, target, zT, gscale, part, B, Bh, T, g.L, gcoef, skip)
     {
         EventBracket bracket(s);
-        if (pack) {
-            if (target) WDF_BWD_TP(true, wdf::v2f); else WDF_BWD_TP(false, wdf::v2f);
+        if (gcoef) {
+            WDF_BWD_TP(2, float);                            // MSE + ESR (one sequence per lane only)
+        } else if (pack) {
+            if (target) WDF_BWD_TP(1, wdf::v2f); else WDF_BWD_TP(0, wdf::v2f);
         } else {
-            if (target) WDF_BWD_TP(true, float); else WDF_BWD_TP(false, float);
+            if (target) WDF_BWD_TP(1, float); else WDF_BWD_TP(0, float);
         }
     }
 #undef WDF_BWD_TP
@@ -372,7 +375,7 @@ int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta, float
 static int bwd_tp_common(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
                          const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
                          void* ws, float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T,
-                         int n_chunks, int flags, void* stream);
+                         int n_chunks, int flags, void* stream, const float* gcoef = nullptr, int64_t skip = 0);
 
 size_t wdf_clipper_bwd_tp_ws_bytes(int64_t B, int n_chunks)
 {
@@ -402,7 +405,7 @@ int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta, f
 static int bwd_tp_common(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
                          const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
                          void* ws, float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T,
-                         int n_chunks, int flags, void* stream)
+                         int n_chunks, int flags, void* stream, const float* gcoef, int64_t skip)
 {
     int rc = check_common(x, theta, n_up, n_down, B, T, flags);
     if (rc) return rc;
@@ -415,13 +418,54 @@ static int bwd_tp_common(const float* x, const float* r, const float* theta, flo
     const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH4(launch_bwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy, target,
-                  zT, gscale, part, wsd, gz0, B, T, g, (flags & WDF_TP_PACK2) != 0 && B >= 2, (hipStream_t)stream);
+                  zT, gscale, part, wsd, gz0, B, T, g, (flags & WDF_TP_PACK2) != 0 && B >= 2 && !gcoef, gcoef, skip,
+                  (hipStream_t)stream);
     rc = check_launch("wdf_clipper_bwd_tp");
     if (rc) return rc;
     const int nparts = (int)((B + 63) / 64);
     hipLaunchKernelGGL(wdf::clipper_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)wsd,
                        nparts, theta, fs, r != nullptr ? 1 : 0, gtheta, accumulate, target ? sse : nullptr);
     return check_launch("wdf_clipper_grad_reduce");
+}
+
+int wdf_clipper_bwd_esr_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                           const float* zstash, const float* zT, const float* target, const float* gcoef, int64_t skip,
+                           void* ws, float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T,
+                           int n_chunks, int flags, void* stream)
+{
+    if (!zT || !target || !gcoef) return fail(WDF_EINVAL, "null zT/target/gcoef");
+    if (skip < 0 || skip > T) return fail(WDF_EINVAL, "skip must be in 0..T");
+    return bwd_tp_common(x, r, theta, fs, n_up, n_down, zstash, nullptr, target, zT, 0.0f, ws, gtheta, sse, gz0,
+                         accumulate, B, T, n_chunks, flags, stream, gcoef, skip);
+}
+
+static unsigned loss_blocks(int64_t n)
+{
+    const int64_t want = (n + 256 * 8 - 1) / (256 * 8);
+    return (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+}
+
+int64_t wdf_loss_sums_ws_bytes(void) { return 2048 * 2 * (int64_t)sizeof(double); }
+
+int wdf_loss_sums(const float* y, const float* target, int64_t B, int64_t T, int64_t skip, void* ws, double* sums,
+                  void* stream)
+{
+    if (!y || !target || !ws || !sums) return fail(WDF_EINVAL, "null y/target/ws/sums");
+    if (B <= 0 || T <= 0 || skip < 0 || skip >= T) return fail(WDF_EINVAL, "need B, T > 0 and 0 <= skip < T");
+    const int64_t n0 = skip * B, n1 = T * B;
+    const unsigned nblk = loss_blocks(n1 - n0);
+    hipLaunchKernelGGL(wdf::loss_sums_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, target, n0, n1, (double*)ws);
+    hipLaunchKernelGGL(wdf::loss_sums_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
+                       (int)nblk, sums);
+    return check_launch("wdf_loss_sums");
+}
+
+int wdf_esr_coef(const double* sums, double n, double eps, float* gcoef, float* loss, void* stream)
+{
+    if (!sums || !gcoef || !loss) return fail(WDF_EINVAL, "null sums/gcoef/loss");
+    if (!(n > 0.0)) return fail(WDF_EINVAL, "n must be positive");
+    hipLaunchKernelGGL(wdf::esr_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums, n, eps, gcoef, loss);
+    return check_launch("wdf_esr_coef");
 }
 
 int wdf_clipper_asym_fwd(const float* x, const float* theta6, float fs, int mode, double tol, int max_iter, float* y,

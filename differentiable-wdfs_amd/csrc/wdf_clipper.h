@@ -367,6 +367,56 @@ __global__ __launch_bounds__(256) void clipper_grad_reduce_kernel(
     }
 }
 
+// ---- MSE + ESR loss (clipper_pot.py:146-156,177) ---------------------------------------------
+// Sums over the samples past skip_samples of one rank's [T][B] arrays: S = sum (y - t)^2 and
+// E = sum y^2 (the script passes (outs, target) as (target_y, predicted_y), :248, so the energy is
+// the model output's).  Grid-stride, per-block partials in double, fixed-order finish.
+__global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict__ y, const float* __restrict__ target,
+                                                        int64_t n0, int64_t n1, double* __restrict__ part)
+{
+    __shared__ double sh[256][2];
+    double s = 0.0, e = 0.0;
+    for (int64_t i = n0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n1; i += (int64_t)gridDim.x * 256) {
+        const float yv = y[i], d = yv - target[i];
+        s += (double)(d * d);
+        e += (double)(yv * yv);
+    }
+    sh[threadIdx.x][0] = s; sh[threadIdx.x][1] = e;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { sh[threadIdx.x][0] += sh[threadIdx.x + off][0]; sh[threadIdx.x][1] += sh[threadIdx.x + off][1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0][0]; part[2 * blockIdx.x + 1] = sh[0][1]; }
+}
+
+__global__ __launch_bounds__(256) void loss_sums_finish_kernel(const double* __restrict__ part, int nblk,
+                                                               double* __restrict__ sums)
+{
+    __shared__ double sh[256][2];
+    double s = 0.0, e = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) { s += part[2 * i]; e += part[2 * i + 1]; }
+    sh[threadIdx.x][0] = s; sh[threadIdx.x][1] = e;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { sh[threadIdx.x][0] += sh[threadIdx.x + off][0]; sh[threadIdx.x][1] += sh[threadIdx.x + off][1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sums[0] = sh[0][0]; sums[1] = sh[0][1]; }
+}
+
+// From the (global) sums: loss = S/n + sqrt(S / (E + eps) / n) and its derivative w.r.t. y,
+//   dL/dy_i = ga (y_i - t_i) + gb y_i ,  ga = 2/n + 1/(esr (E+eps) n) ,  gb = -esr / (E+eps).
+__global__ void esr_coef_kernel(const double* __restrict__ sums, double n, double eps, float* __restrict__ gcoef,
+                                float* __restrict__ loss)
+{
+    const double S = sums[0], E = sums[1] + eps;
+    const double mse = S / n, esr = sqrt(S / E / n);
+    gcoef[0] = (float)(2.0 / n + (esr > 0.0 ? 1.0 / (esr * E * n) : 0.0));
+    gcoef[1] = (float)(-esr / E);
+    loss[0] = (float)mse; loss[1] = (float)esr; loss[2] = (float)(mse + esr);
+}
+
 // ---- element-wise building blocks (parity tests) ----------------------------------------
 __global__ void omega_kernel(const float* __restrict__ x, float* __restrict__ w, int32_t* __restrict__ iters, int64_t n)
 {
@@ -751,13 +801,21 @@ constexpr int kTpOut = 9;
 // dL/dy for this step.  MSE: y[n] = (z[n+1] + z[n])/2 is rebuilt from the state stash (z_next is
 // the state after the step = the stash entry of the following step), so the sweep reads neither
 // y nor a dL/dy array: x, stash and target are its 12 B/sample.
-template <bool MSE, typename V>
-__device__ __forceinline__ V tp_grad_in(V gy, V z, V z_next, V tgt, float gscale, V& sse)
+// MSE = 2 (MSE + ESR, clipper_pot.py:146-156,177, with the script's argument order: the energy is
+// that of the model output): dL/dy = ga (y - target) + gb y on the samples past skip_samples
+// (:232,248), ga / gb from esr_coef_kernel; `live` is the wave-uniform 0/1 mask of this step.
+template <int MSE, typename V>
+__device__ __forceinline__ V tp_grad_in(V gy, V z, V z_next, V tgt, float gscale, float gb, float live, V& sse)
 {
-    if constexpr (MSE) {
+    if constexpr (MSE == 1) {
         const V d = 0.5f * (z_next + z) - tgt;
         sse = vfma(d, d, sse);
         return gscale * d;
+    } else if constexpr (MSE == 2) {
+        const V y = live * (0.5f * (z_next + z));
+        const V d = y - live * tgt;
+        sse = vfma(d, d, sse);
+        return vfma(d, vsplat<V>(gscale), gb * y);
     } else {
         return gy;
     }
@@ -766,15 +824,17 @@ __device__ __forceinline__ V tp_grad_in(V gy, V z, V z_next, V tgt, float gscale
 // MSE: `gy` is unused, `target` [T][B] the training target, zT [B] the final state of the forward
 // (needed for y[T-1]); dL/dy = gscale (y - target), gscale = 2/N for a mean over N samples; the
 // kernel also returns sum (y - target)^2.
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool MSE, typename V>
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, int MSE, typename V>
 __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, const float* __restrict__ zstash, const float* __restrict__ gy,
     const float* __restrict__ target, const float* __restrict__ zT, float gscale, float* __restrict__ out,
-    int64_t B, int64_t Bh, int64_t T, int64_t L)
+    int64_t B, int64_t Bh, int64_t T, int64_t L, const float* __restrict__ gcoef, int64_t skip)
 {
     constexpr int N = VT<V>::N;
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+    float gb = 0.0f;
+    if constexpr (MSE == 2) { gscale = gcoef[0]; gb = gcoef[1]; }
     const LaneSeqs<V> q(B, Bh);
     const int64_t k = blockIdx.y;
     const int64_t t0 = k * L;
@@ -798,7 +858,7 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
         V sse1 = zero;
         const V tg = MSE ? load_one_v<V>(target, q, 1, B, t) : zero;
         const V gin = MSE ? zero : load_one_v<V>(gy, q, 1, B, t);
-        const V g = tp_grad_in<MSE, V>(gin, zv, z_next, tg, gscale, sse1);
+        const V g = tp_grad_in<MSE, V>(gin, zv, z_next, tg, gscale, gb, t >= skip ? 1.0f : 0.0f, sse1);
         bwd_tp_step<DYN_R, SYM, V>(c, xin, rin, zv, g, alpha, beta, acc);
         z_next = zv;
         saL += acc.aL; saV += acc.aV; saP += acc.aP;
@@ -843,7 +903,8 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
 #pragma unroll
         for (int i = kBlk - 1; i >= 0; --i) {
             const V zv = gather<V>(zc, i);
-            const V g = tp_grad_in<MSE, V>(gather<V>(gc, i), zv, z_next, gather<V>(gc, i), gscale, sse8);
+            const V g = tp_grad_in<MSE, V>(gather<V>(gc, i), zv, z_next, gather<V>(gc, i), gscale, gb,
+                                          tb + i >= skip ? 1.0f : 0.0f, sse8);
             bwd_tp_step<DYN_R, SYM, V>(c, gather<V>(xc, i), gather<V>(rc, i), zv, g, alpha, beta, acc);
             z_next = zv;
         }

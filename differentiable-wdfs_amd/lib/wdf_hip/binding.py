@@ -69,6 +69,14 @@ def lib():
     L.wdf_clipper_bwd_mse_tp.restype = ci
     L.wdf_clipper_bwd_mse_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, cf, vp, fp, fp, fp, ci, i64, i64, ci,
                                          ci, vp]
+    L.wdf_loss_sums_ws_bytes.restype = i64
+    L.wdf_loss_sums.restype = ci
+    L.wdf_loss_sums.argtypes = [fp, fp, i64, i64, i64, vp, vp, vp]
+    L.wdf_esr_coef.restype = ci
+    L.wdf_esr_coef.argtypes = [vp, C.c_double, C.c_double, fp, fp, vp]
+    L.wdf_clipper_bwd_esr_tp.restype = ci
+    L.wdf_clipper_bwd_esr_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, fp, i64, vp, fp, fp, fp, ci, i64, i64, ci,
+                                         ci, vp]
     L.wdf_clipper_asym_fwd.restype = ci
     L.wdf_clipper_asym_fwd.argtypes = [fp, fp, cf, ci, C.c_double, ci, fp, fp, fp, vp, i64, i64, vp]
     L.wdf_asym_root.restype = ci
@@ -119,6 +127,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_fwd", "wdf_clipper_bwd", "wdf_clipper_bwd_ws_bytes",
     "wdf_clipper_tp_chunks", "wdf_clipper_fwd_tp_ws_bytes", "wdf_clipper_fwd_tp",
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
+    "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd",
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
@@ -229,6 +238,57 @@ def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_d
                                   (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(), _stream())
     _check(rc, "wdf_clipper_fwd_tp")
     return y, zs, zT, status
+
+
+def loss_sums(y, target, skip, sums=None, ws=None):
+    """S = sum (y - target)^2 and E = sum y^2 over rows skip.. of [T,B] arrays -> float64[2] on the device."""
+    require_gpu()
+    y, target = _f32_dev(y, "y"), _f32_dev(target, "target")
+    T, B = y.shape
+    if tuple(target.shape) != (T, B):
+        raise WdfHipError("target must have y's shape [T,B]")
+    if ws is None:
+        ws = torch.empty((lib().wdf_loss_sums_ws_bytes(),), dtype=torch.uint8, device=y.device)
+    if sums is None:
+        sums = torch.empty((2,), dtype=torch.float64, device=y.device)
+    _check(lib().wdf_loss_sums(_ptr(y), _ptr(target), B, T, int(skip), _ptr(ws), _ptr(sums), _stream()), "wdf_loss_sums")
+    return sums
+
+
+def esr_coef(sums, n, eps, gcoef=None, loss=None):
+    """(gcoef[2] = {ga, gb}, loss[3] = {mse, esr, mse + esr}) from the global sums; see include/wdf_hip.h."""
+    require_gpu()
+    if sums.dtype != torch.float64 or not sums.is_cuda or sums.numel() != 2:
+        raise WdfHipError("sums must be a float64[2] device tensor")
+    if gcoef is None:
+        gcoef = torch.empty((2,), dtype=torch.float32, device=sums.device)
+    if loss is None:
+        loss = torch.empty((3,), dtype=torch.float32, device=sums.device)
+    _check(lib().wdf_esr_coef(_ptr(sums), float(n), float(eps), _ptr(gcoef), _ptr(loss), _stream()), "wdf_esr_coef")
+    return gcoef, loss
+
+
+def clipper_bwd_esr_tp(x, theta, fs, zstash, zT, target, gcoef, skip, n_chunks, r=None, n_up=1, n_down=1, gtheta=None,
+                       sse=None, ws=None, time_major=False):
+    """Reverse sweep with dL/dy = ga (y - target) + gb y past `skip` (MSE + ESR); -> gtheta[4], sse[1]."""
+    require_gpu()
+    x, r, theta = _f32_dev(x, "x"), _f32_dev(r, "r"), _f32_dev(theta, "theta")
+    zstash, zT, target, gcoef = _f32_dev(zstash, "zstash"), _f32_dev(zT, "zT"), _f32_dev(target, "target"), _f32_dev(gcoef, "gcoef")
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+    if tuple(target.shape) != (T, B) or tuple(zstash.shape) != (T, B):
+        raise WdfHipError(f"target / zstash must be [T,B] = [{T},{B}]")
+    if ws is None:
+        ws = torch.empty((lib().wdf_clipper_bwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
+    if gtheta is None:
+        gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
+    if sse is None:
+        sse = torch.empty((1,), dtype=torch.float32, device=x.device)
+    rc = lib().wdf_clipper_bwd_esr_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(zstash),
+                                      _ptr(zT), _ptr(target), _ptr(gcoef), int(skip), _ptr(ws), _ptr(gtheta), _ptr(sse),
+                                      None, 0, B, T, int(n_chunks), (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(),
+                                      _stream())
+    _check(rc, "wdf_clipper_bwd_esr_tp")
+    return gtheta, sse
 
 
 def tp_status(status):

@@ -123,10 +123,26 @@ class MseStep:
     in (one transpose when the dataset is loaded; the reference trains on the same train_X
     for all 501 epochs, clipper_pot.py:245-248), giving fully coalesced loads."""
 
-    def __init__(self, B, T, fs, tp, device, n_up=1, n_down=1, n_global=None, time_major=False):
+    def __init__(self, B, T, fs, tp, device, n_up=1, n_down=1, n_global=None, time_major=False, loss="mse",
+                 skip=0, sums_allreduce=None):
+        """loss: "mse" (mean over n_global samples) or "mse+esr", the training loss of
+        clipper_pot.py:177 evaluated past `skip` samples (:232,248; n_global then counts the samples
+        past skip over all ranks).  sums_allreduce: in-place SUM all-reduce for the two float64 loss
+        sums when the batch is sharded (wdf_hip.dist.allreduce_sum_)."""
+        if loss not in ("mse", "mse+esr"):
+            raise binding.WdfHipError(f"unknown loss {loss!r}")
+        if loss == "mse" and skip:
+            raise binding.WdfHipError("skip is only meaningful with loss='mse+esr'")
         self.B, self.T, self.fs, self.tp = B, T, float(fs), tp
         self.n_up, self.n_down, self.time_major = n_up, n_down, bool(time_major)
-        self.gscale = 2.0 / float(n_global if n_global is not None else B * T)
+        self.loss_kind, self.skip, self.sums_allreduce = loss, int(skip), sums_allreduce
+        self.n_global = float(n_global if n_global is not None else B * (T - self.skip))
+        self.gscale = 2.0 / self.n_global
+        if loss == "mse+esr":
+            self.ws_l = torch.empty((binding.lib().wdf_loss_sums_ws_bytes(),), dtype=torch.uint8, device=device)
+            self.sums = torch.zeros((2,), dtype=torch.float64, device=device)
+            self.gcoef = torch.zeros((2,), dtype=torch.float32, device=device)
+            self.loss = torch.zeros((3,), dtype=torch.float32, device=device)      # mse, esr, mse + esr
         L = binding.lib()
         kf, kb = (tp.k_fwd, tp.k_bwd) if tp is not None else (1, 1)
         self.ws_f = torch.empty((max(16, L.wdf_clipper_fwd_tp_ws_bytes(B, kf)),), dtype=torch.uint8, device=device)
@@ -151,6 +167,17 @@ class MseStep:
 
     def backward(self, theta, x, target, r=None):
         kb = self.tp.k_bwd if self.tp is not None else 1
+        if self.loss_kind == "mse+esr":
+            # loss sums over this rank's y (one streaming pass), made global, then the two
+            # coefficients of dL/dy = ga (y - t) + gb y; the sweep itself is the MSE one
+            binding.loss_sums(self.y, target, self.skip, sums=self.sums, ws=self.ws_l)
+            if self.sums_allreduce is not None:
+                self.sums_allreduce(self.sums)
+            binding.esr_coef(self.sums, self.n_global, float(torch.finfo(torch.float64).eps), self.gcoef, self.loss)
+            binding.clipper_bwd_esr_tp(x, theta, self.fs, self.zs, self.zT, target, self.gcoef, self.skip, kb, r=r,
+                                       n_up=self.n_up, n_down=self.n_down, gtheta=self.gtheta, sse=self.sse,
+                                       ws=self.ws_b, time_major=self.time_major)
+            return self.sse, self.gtheta
         binding.clipper_bwd_mse_tp(x, theta, self.fs, self.zs, self.zT, target, self.gscale, kb, r=r,
                                    n_up=self.n_up, n_down=self.n_down, gtheta=self.gtheta, sse=self.sse,
                                    ws=self.ws_b, time_major=self.time_major)

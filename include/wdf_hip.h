@@ -130,6 +130,25 @@ int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta,
                            const float* zstash, const float* zT, const float* target, float gscale,
                            void* ws, float* gtheta, float* sse, float* gz0, int accumulate,
                            int64_t B, int64_t T, int n_chunks, int flags, void* stream);
+
+/* MSE + ESR, the training loss of clipper_pot.py (:146-156 esr_loss, :177 loss_func, :232,248
+ * evaluated past skip_samples with (outs, target) passed as (target_y, predicted_y), so the energy
+ * is the model output's):   loss = S/n + sqrt(S / (E + eps) / n),  S = sum (y-t)^2, E = sum y^2.
+ *   wdf_loss_sums   S and E over this rank's y, target [T][B] rows skip..T-1 -> sums[2] (device
+ *                   double; all-reduce them when the batch is sharded); ws: wdf_loss_sums_ws_bytes()
+ *   wdf_esr_coef    sums, n (global sample count), eps -> gcoef[2] = {ga, gb} with
+ *                   dL/dy = ga (y - t) + gb y, and loss[3] = {mse, esr, mse + esr}
+ *   wdf_clipper_bwd_esr_tp   the reverse sweep of wdf_clipper_bwd_mse_tp with that dL/dy (rows
+ *                   before `skip` contribute nothing); sse receives this rank's S.              */
+int64_t wdf_loss_sums_ws_bytes(void);
+int wdf_loss_sums(const float* y, const float* target, int64_t B, int64_t T, int64_t skip, void* ws,
+                  double* sums, void* stream);
+int wdf_esr_coef(const double* sums, double n, double eps, float* gcoef, float* loss, void* stream);
+int wdf_clipper_bwd_esr_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                           const float* zstash, const float* zT, const float* target,
+                           const float* gcoef, int64_t skip, void* ws, float* gtheta, float* sse,
+                           float* gz0, int accumulate, int64_t B, int64_t T, int n_chunks,
+                           int flags, void* stream);
 int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta,
                        float fs, int n_up, int n_down,
                        const float* zstash, const float* gy,

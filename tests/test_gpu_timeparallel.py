@@ -265,3 +265,47 @@ def test_fast_step_equals_general_root_path(wb):
         assert torch.equal(ya, yb)
     finally:
         wb.GENERAL_ROOT = False
+
+
+@pytest.mark.parametrize("time_major", [False, True])
+def test_fused_mse_esr_step_matches_autograd_and_oracle(wb, oracle, time_major):
+    """engine.MseStep(loss="mse+esr", skip=50): the training loss of clipper_pot.py:146-156,177,232,248
+    (energy of the model output, first 50 samples dropped) fused into the reverse sweep, against
+    (a) the same loss written with torch ops on the kernel's y and differentiated by autograd through
+    the plain reverse sweep (5e-5 relative), and (b) the fp64 oracle's adjoint fed the fp64 dL/dy of
+    that loss (2e-3 relative, the gradient tolerance of every fp32-vs-fp64 comparison here)."""
+    from wdf_hip import engine, workload
+    B, T, skip = 96, 2048, 50
+    x, th = setup(B, T, seed=31)
+    theta = workload.clipper_theta()
+    tgt, _, _ = wb.clipper_fwd(x, dev(workload.target_theta()), FS, want_stash=False)
+    tp = engine.plan_time_parallel(B, T, theta[2], theta[3], FS, time_major=time_major)
+    step = engine.MseStep(B, T, FS, tp, x.device, time_major=time_major, loss="mse+esr", skip=skip)
+    xin = x.t().contiguous() if time_major else x
+    sse, g = step.step(th, xin, tgt)
+    eps = float(np.finfo(float).eps)
+
+    def loss_fn(y, t, lib):
+        o, tt = y[skip:], t[skip:]
+        n = o.numel() if lib is torch else o.size
+        S = ((o - tt) ** 2).sum()
+        return S / n + lib.sqrt(S / ((o ** 2).sum() + eps) / n)
+
+    thr = th.clone().requires_grad_(True)
+    y = engine.clipper(thr, x, FS)
+    loss = loss_fn(y, tgt, torch)
+    loss.backward()
+    assert abs(float(step.loss[2]) - float(loss)) <= 2e-6 * float(loss)
+    assert abs(float(step.loss[0]) + float(step.loss[1]) - float(step.loss[2])) <= 1e-6 * float(loss)
+    assert torch.allclose(g, thr.grad, rtol=5e-5, atol=0), (g, thr.grad)
+    assert abs(float(sse) - float(((y[skip:] - tgt[skip:]) ** 2).sum())) <= 1e-4 * float(sse)
+    # fp64: oracle forward, dL/dy of the same loss by torch autograd in float64, oracle adjoint
+    th64 = theta.astype(np.float32).astype(np.float64)
+    x64 = x.cpu().numpy().astype(np.float64)
+    y64 = torch.tensor(oracle.clipper_fwd(th64, FS, x64), requires_grad=True)
+    l64 = loss_fn(y64, tgt.cpu().double(), torch)
+    (gy64,) = torch.autograd.grad(l64, [y64])
+    _, gref = oracle.clipper_fwd_bwd(th64, FS, x64, gy64.numpy())
+    got = g.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - gref) / np.abs(gref)) < 2e-3, (got, gref)
+    assert abs(float(step.loss[2]) - float(l64)) <= 1e-4 * float(l64)
