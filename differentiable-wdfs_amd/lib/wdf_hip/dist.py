@@ -63,3 +63,21 @@ def mse_step_allreduce(sse_local, gtheta_local_unnormalised, n_global):
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+def esr_coefficients(S, E, n, eps):
+    """Host mirror of esr_coef_kernel (csrc/wdf_clipper.h): from the GLOBAL sums S = sum (y-t)^2,
+    E = sum y^2 over n samples -> (ga, gb, mse, esr) with dL/dy = ga (y - t) + gb y for
+    L = S/n + sqrt(S / (E + eps) / n)   (clipper_pot.py:146-156,177)."""
+    E = E + eps
+    mse = S / n
+    esr = (S / E / n) ** 0.5
+    ga = 2.0 / n + (1.0 / (esr * E * n) if esr > 0.0 else 0.0)
+    return ga, -esr / E, mse, esr
+
+
+def esr_sums_allreduce(S_local, E_local):
+    """Stage 1 of a sharded MSE + ESR step: the two loss sums made global (one 16-byte all-reduce)."""
+    buf = torch.tensor([float(S_local), float(E_local)], dtype=torch.float64)
+    allreduce_sum_(buf)
+    return float(buf[0]), float(buf[1])

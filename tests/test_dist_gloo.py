@@ -47,6 +47,63 @@ def _worker(rank, world, port, B, T, out):
     torch.distributed.destroy_process_group()
 
 
+def _worker_esr(rank, world, port, B, T, skip, out):
+    """MSE + ESR (clipper_pot.py:177): two exchanges per step -- the loss sums after the forward,
+    the gradient after the reverse sweep."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    for p in (os.path.join(REPO, "oracle"), os.path.join(REPO, "differentiable-wdfs_amd", "lib")):
+        sys.path.insert(0, p)
+    import oracle as O
+    from wdf_hip import dist as wdist, workload
+    wdist.init(backend="gloo")
+    b0, b1 = wdist.shard_range(B, rank, world)
+    x = workload.sweep_batch(B, T, b0=b0, b1=b1, dtype=np.float64)
+    theta, fs = workload.clipper_theta(), workload.FS
+    tgt = O.clipper_fwd(workload.target_theta(), fs, x)
+    y = O.clipper_fwd(theta, fs, x)
+    S, E = wdist.esr_sums_allreduce(np.sum((y[skip:] - tgt[skip:]) ** 2), np.sum(y[skip:] ** 2))
+    ga, gb, mse, esr = wdist.esr_coefficients(S, E, float(B * (T - skip)), np.finfo(float).eps)
+    gy = ga * (y - tgt) + gb * y
+    gy[:skip] = 0.0
+    _, g = O.clipper_fwd_bwd(theta, fs, x, gy)
+    grad = wdist.allreduce_sum_(torch.tensor(g, dtype=torch.float64))
+    if rank == 0:
+        out.put((mse + esr, grad.numpy().copy()))
+    wdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_mse_esr_matches_single_rank(oracle):
+    """Sharded MSE + ESR == the unsharded loss and gradient (torch float64 autograd of the loss as the
+    script writes it, through the oracle's adjoint)."""
+    from wdf_hip import workload
+    B, T, skip, world = 9, 260, 50, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_esr, args=(r, world, port, B, T, skip, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    loss, grad = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x = workload.sweep_batch(B, T, dtype=np.float64)
+    theta, fs = workload.clipper_theta(), workload.FS
+    tgt = torch.tensor(oracle.clipper_fwd(workload.target_theta(), fs, x))
+    y = torch.tensor(oracle.clipper_fwd(theta, fs, x), requires_grad=True)
+    o, t = y[skip:], tgt[skip:]
+    n = o.numel()
+    S = ((o - t) ** 2).sum()
+    l1 = S / n + torch.sqrt(S / ((o ** 2).sum() + np.finfo(float).eps) / n)      # clipper_pot.py:146-156,177
+    (gy,) = torch.autograd.grad(l1, [y])
+    _, g1 = oracle.clipper_fwd_bwd(theta, fs, x, gy.numpy())
+    assert abs(loss - float(l1)) < 1e-12 * max(1.0, abs(float(l1)))
+    assert np.max(np.abs(grad - g1) / np.abs(g1)) < 1e-9
+
+
 def test_shard_range_covers_batch():
     sys.path.insert(0, os.path.join(REPO, "differentiable-wdfs_amd", "lib"))
     from wdf_hip import dist as wdist
