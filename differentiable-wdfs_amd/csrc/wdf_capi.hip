@@ -501,6 +501,13 @@ int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, doubl
     return check_launch("wdf_asym_root");
 }
 
+// the architectures the MLP kernels are instantiated for (every one among the reference's model files)
+static bool mlp_arch_ok(int hidden, int n_tanh_layers)
+{
+    return ((hidden == 4 || hidden == 8 || hidden == 16) && n_tanh_layers == 3) ||
+           ((hidden == 4 || hidden == 8) && (n_tanh_layers == 4 || n_tanh_layers == 5));
+}
+
 int wdf_mlp_weight_count(int hidden, int n_tanh_layers)
 {
     if (hidden < 1 || n_tanh_layers < 1) return 0;
@@ -526,9 +533,7 @@ static int mlp_check(const float* x, const float* theta2, const float* w, int hi
     if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "B and T must be positive");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
     if (flags != 0) return fail(WDF_EINVAL, "MLP-root kernels take flags = 0");
-    const bool ok = ((hidden == 4 || hidden == 8 || hidden == 16) && n_tanh_layers == 3) ||
-                    ((hidden == 4 || hidden == 8) && (n_tanh_layers == 4 || n_tanh_layers == 5));
-    if (!ok)
+    if (!mlp_arch_ok(hidden, n_tanh_layers))
         return fail(WDF_EUNSUPPORTED,
                     "MLP root: hidden in {4,8,16} with 3 tanh layers or {4,8} with 4 or 5 (got width %d, %d tanh layers)",
                     hidden, n_tanh_layers);
@@ -575,7 +580,7 @@ static unsigned mlp_wgrad_blocks(int64_t S)
 int64_t wdf_clipper_mlp_wgrad_ws_bytes(int hidden, int n_tanh_layers, int64_t S)
 {
     const int64_t count = wdf_mlp_weight_count(hidden, n_tanh_layers);
-    if (count <= 0 || S <= 0) return 0;
+    if (count <= 0 || S <= 0 || !mlp_arch_ok(hidden, n_tanh_layers)) return 0;
     return (int64_t)mlp_wgrad_blocks(S) * count * (int64_t)sizeof(float);
 }
 
@@ -591,7 +596,7 @@ int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb, 
     if (!lrin && !theta2) return fail(WDF_EINVAL, "theta2 is needed when lrin is NULL");
     if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
     const int count = wdf_mlp_weight_count(hidden, n_tanh_layers);
-    if (count <= 0)
+    if (!mlp_arch_ok(hidden, n_tanh_layers))
         return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
     const unsigned nblk = mlp_wgrad_blocks(S);
     WDF_WGRAD_CASE(4, 3) WDF_WGRAD_CASE(8, 3) WDF_WGRAD_CASE(16, 3) WDF_WGRAD_CASE(4, 4) WDF_WGRAD_CASE(8, 4)
@@ -613,7 +618,7 @@ int wdf_mlp_eval(const float* ain, const float* lrin, const float* w, int hidden
 {
     if (!ain || !lrin || !w || !out) return fail(WDF_EINVAL, "null ain/lrin/w/out");
     if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
-    if (wdf_mlp_weight_count(hidden, n_tanh_layers) <= 0)
+    if (!mlp_arch_ok(hidden, n_tanh_layers))
         return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
     const unsigned nblk = mlp_wgrad_blocks(S);
     WDF_EVAL_CASE(4, 3) WDF_EVAL_CASE(8, 3) WDF_EVAL_CASE(16, 3) WDF_EVAL_CASE(4, 4) WDF_EVAL_CASE(8, 4)
@@ -635,7 +640,7 @@ int wdf_mlp_fit_epoch(const float* xa, const float* xl, const float* ys, int64_t
     if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
     if (batch < 1 || batch > 64) return fail(WDF_EUNSUPPORTED, "wdf_mlp_fit_epoch: batch must be in 1..64 (got %d)", batch);
     if (!(esr_n > 0.0f)) return fail(WDF_EINVAL, "esr_n must be positive");
-    if (wdf_mlp_weight_count(hidden, n_tanh_layers) <= 0)
+    if (!mlp_arch_ok(hidden, n_tanh_layers))
         return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
     WDF_FIT_CASE(4, 3) WDF_FIT_CASE(8, 3) WDF_FIT_CASE(16, 3) WDF_FIT_CASE(4, 4) WDF_FIT_CASE(8, 4)
     WDF_FIT_CASE(4, 5) WDF_FIT_CASE(8, 5)

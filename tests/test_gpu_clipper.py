@@ -260,3 +260,34 @@ def test_error_behaviour(wb):
         wb.clipper_fwd(x, th, FS, n_up=0)                     # rc = WDF_EINVAL from the library
     with pytest.raises(wb.WdfHipError):
         wb.clipper_fwd(x, th, -1.0)
+
+
+def test_error_behaviour_of_the_training_entry_points(wb):
+    """Every entry point added around the training loops refuses what it cannot do with a WdfHipError
+    carrying the library's message (no silent fallback): unsupported networks, batches, sizes, flags."""
+    f = lambda *s: torch.zeros(*s, dtype=torch.float32, device="cuda")  # noqa: E731
+    with pytest.raises(wb.WdfHipError, match="unsupported"):
+        wb.clipper_mlp_wgrad(f(64), f(64), f(64), f(2) + 1, f(100), 12, 3, FS)           # width 12
+    with pytest.raises(wb.WdfHipError, match="unsupported"):
+        wb.mlp_eval(f(64), f(64), f(100), 16, 5)                                        # 4x16 has no kernel
+    opt = wb.Adam(105, 1e-3)
+    with pytest.raises(wb.WdfHipError, match="batch"):
+        wb.mlp_fit_epoch(f(200), f(200), f(200), 65, f(105), opt, 8, 3, 1000.0, 1e-7,
+                         torch.zeros(1, dtype=torch.float64, device="cuda"))
+    with pytest.raises(wb.WdfHipError, match="1..1024"):
+        wb.Adam(2000, 1e-3).apply(f(2000), f(2000))
+    with pytest.raises(wb.WdfHipError, match="parameters"):
+        opt.apply(f(4), f(4))
+    with pytest.raises(wb.WdfHipError, match="skip"):
+        wb.loss_sums(f(8, 4), f(8, 4), 8)
+    with pytest.raises(wb.WdfHipError, match="float64"):
+        wb.esr_coef(f(2), 10.0, 1e-16)
+    x = f(4, 64)
+    th = torch.as_tensor(np.array([4.352e-9, 0.0493, 45.0e3, 4.7e-9], dtype=np.float32), device="cuda")
+    y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
+    with pytest.raises(wb.WdfHipError, match="skip"):
+        wb.clipper_bwd_esr_tp(x, th, FS, zs, zT, y, f(2), 65, 2)
+    with pytest.raises(wb.WdfHipError, match="unknown flag"):
+        rc = wb.lib().wdf_clipper_fwd(x.data_ptr(), None, th.data_ptr(), FS, 1, 1, y.data_ptr(), None, None, None, 4, 64,
+                                      1 << 9, None)
+        wb._check(rc, "wdf_clipper_fwd")
