@@ -254,6 +254,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(T, fs)
         print(json.dumps(out), flush=True)
     if world > 1:
+        wdist.barrier()                      # rank 0 finishes its report before any communicator goes away
         torch.distributed.destroy_process_group()
 
 
