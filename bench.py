@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="skip the on-device Adam update of {Is, nVt, R, C} that closes every step")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="testing aid: run the multi-rank code path (sharding, all-reduce, max-over-ranks timing) with "
+                         "every rank on cuda:0 and the gloo backend, where only one GPU is available")
     ap.add_argument("--loss", default="mse", choices=["mse", "mse+esr"],
                     help="mse: the metric's loss (default). mse+esr: clipper_pot.py's training loss past 50 samples, "
                          "fused the same way (one extra streaming pass for the two loss sums)")
@@ -127,7 +130,11 @@ def main():
                          "resident time-major copy")
     args = ap.parse_args()
 
-    world, rank, local = wdist.init()
+    if args.rehearse_on_one_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+        world, rank, local = wdist.init(backend="gloo")
+    else:
+        world, rank, local = wdist.init()
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

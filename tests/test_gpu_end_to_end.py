@@ -112,3 +112,28 @@ def test_clipper_pot_workflow(tmp_path, golden):
     assert [l["activation"] for l in js["layers"]] == ["tanh", "tanh", "tanh", ""] and js["in_shape"] == [None, 2]
     m2 = DenseRootModel(js)
     assert np.array_equal(m2.layers[0].kernel.numpy(), model.model.layers[0].kernel.numpy())
+
+
+def test_bench_two_rank_path_rehearsal():
+    """bench.py's multi-rank path (batch shards per rank, the fused [SSE, grads] all-reduce, Adam on
+    every rank, max-over-ranks timing, one JSON line from rank 0) run as the driver launches it --
+    torch.distributed.run, 2 ranks -- but with both ranks on cuda:0 over gloo, since the test box has
+    one GPU.  Checks the contract fields and that both ranks really trained on a 2 x 8192 batch."""
+    import json, os, socket, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--batch", "1024", "--seq-len", "2048", "--rehearse-on-one-gpu"]
+    out = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2048 * 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and 0.0 < d["roofline"]["frac"] < 1.0
+    assert "cpu_baseline" not in d                           # rank 0 at N = 1 only
+    assert d["config"]["optimizer"]["loss_last_step"] < d["config"]["optimizer"]["loss_first_step"]
