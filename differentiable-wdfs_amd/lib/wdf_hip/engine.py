@@ -6,6 +6,7 @@ The forward call replaces the reference's whole per-sample Python loop
 the two and into the loss / optimizer.
 """
 import math
+import weakref
 from collections import namedtuple
 
 import torch
@@ -53,18 +54,40 @@ def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, time_major=False):
     return TpPlan(k_fwd, W, float(tol), k_bwd)
 
 
-_R_MAX_CACHE = {}
+_R_MAX_CACHE = {}      # id(tensor) -> (weakref to the tensor, version, max)
 
 
 def resistance_max(r):
-    """max of a per-sample resistance tensor (one device sync, cached per tensor version): the
-    planner needs the slowest sequence's memory."""
-    key = (r.data_ptr(), tuple(r.shape), r._version)
-    if key not in _R_MAX_CACHE:
-        if len(_R_MAX_CACHE) > 64:
-            _R_MAX_CACHE.clear()
-        _R_MAX_CACHE[key] = float(r.max())
-    return _R_MAX_CACHE[key]
+    """max of a per-sample resistance tensor: the planner needs the slowest sequence's memory.
+    One device sync, cached per tensor OBJECT and version (a training set is the same tensor every
+    epoch; a fresh tensor -- even one the allocator put at a recycled address -- is looked at again)."""
+    hit = _R_MAX_CACHE.get(id(r))
+    if hit is None or hit[0]() is not r or hit[1] != r._version:
+        if len(_R_MAX_CACHE) > 256:
+            for k in [k for k, v in _R_MAX_CACHE.items() if v[0]() is None]:
+                del _R_MAX_CACHE[k]
+        hit = (weakref.ref(r), r._version, float(r.max()))
+        _R_MAX_CACHE[id(r)] = hit
+    return hit[2]
+
+
+_SPLIT_CACHE = {}      # id(x) -> (weakref to x, version, xv, r)
+
+
+def split_channels(x, with_r):
+    """The kernels' contiguous views of a [B,T,2] script input (Vin, R: clipper_pot.py:68-70):
+    xv = x[..., 0] and r = x[..., 1].  Cached per input tensor object and version -- the reference
+    feeds the same train_X every epoch (clipper_pot.py:245-248), so the two de-interleaving copies
+    (and the planner's look at max R) happen once, not per forward."""
+    xt = x.as_subclass(torch.Tensor)
+    hit = _SPLIT_CACHE.get(id(x))
+    if hit is None or hit[0]() is not x or hit[1] != xt._version or (with_r and hit[3] is None):
+        if len(_SPLIT_CACHE) > 64:
+            for k in [k for k, v in _SPLIT_CACHE.items() if v[0]() is None]:
+                del _SPLIT_CACHE[k]
+        hit = (weakref.ref(x), xt._version, xt[:, :, 0].contiguous(), xt[:, :, 1].contiguous() if with_r else None)
+        _SPLIT_CACHE[id(x)] = hit
+    return hit[2], (hit[3] if with_r else None)
 
 
 LAST_TP_STATUS = {"status": None}     # device status word of the most recent time-parallel forward

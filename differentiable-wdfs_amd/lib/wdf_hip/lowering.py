@@ -223,10 +223,7 @@ class Circuit:
         dev = x.device
         parts = [dp.Is, dp.nVt, vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)), cap.C]
         theta = torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(dev)
-        r = None
-        if self.per_sample_R is not None:
-            r = x[:, :, 1].contiguous()
-        xv = x[:, :, 0].contiguous()
+        xv, r = engine.split_channels(x, self.per_sample_R is not None)
         if z0 is not None or return_state:
             z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(-1).contiguous()
             y, zT = engine.clipper_stateful(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, z0=z0t)

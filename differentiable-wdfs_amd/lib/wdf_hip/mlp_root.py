@@ -159,8 +159,7 @@ def run_clipper_mlp(circ, x, z0, return_state):
     theta2 = torch.stack([Rv.as_subclass(torch.Tensor).float().reshape(()),
                           cap.C.as_subclass(torch.Tensor).float().reshape(())]).to(dev)
     w = flat_weights(dense).float().to(dev)
-    r = x[:, :, 1].contiguous() if circ.per_sample_R is not None else None
-    xv = x[:, :, 0].contiguous()
+    xv, r = engine.split_channels(x, circ.per_sample_R is not None)
     z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(-1).contiguous()
     y, zT = clipper_mlp(theta2, w, xv, r, z0t, float(cap.FS), hidden, n_tanh, float(cap.C), R_static=Rv,
                         time_parallel=getattr(circ, "time_parallel", None))
