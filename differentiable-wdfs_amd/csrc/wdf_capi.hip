@@ -11,6 +11,7 @@
 #include "wdf_clipper.h"
 #include "wdf_asym.h"
 #include "wdf_mlp.h"
+#include "wdf_mlp_row.h"
 #include "wdf_statespace.h"
 #include "wdf_optim.h"
 
@@ -532,7 +533,7 @@ static int mlp_check(const float* x, const float* theta2, const float* w, int hi
     if (!x || !theta2 || !w) return fail(WDF_EINVAL, "null x/theta2/w");
     if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "B and T must be positive");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
-    if (flags != 0) return fail(WDF_EINVAL, "MLP-root kernels take flags = 0");
+    if (flags & ~WDF_MLP_LANE_PER_SEQUENCE) return fail(WDF_EINVAL, "MLP-root kernels take flags = 0 or WDF_MLP_LANE_PER_SEQUENCE");
     if (!mlp_arch_ok(hidden, n_tanh_layers))
         return fail(WDF_EUNSUPPORTED,
                     "MLP root: hidden in {4,8,16} with 3 tanh layers or {4,8} with 4 or 5 (got width %d, %d tanh layers)",
@@ -549,7 +550,20 @@ int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, con
     if (!y) return fail(WDF_EINVAL, "null y");
     const unsigned grid = (unsigned)((B + 63) / 64);
     const bool dyn = r != nullptr;
-    WDF_MLP_DISPATCH(clipper_mlp_fwd_kernel, x, r, theta2, w, fs, y, zstash, z0, zT, B, T)
+    if (flags & WDF_MLP_LANE_PER_SEQUENCE) {
+        WDF_MLP_DISPATCH(clipper_mlp_fwd_kernel, x, r, theta2, w, fs, y, zstash, z0, zT, B, T)
+    } else {                                      // one 16-lane row per sequence (wdf_mlp_row.h)
+        const unsigned grow = (unsigned)((B + 3) / 4);
+#define WDF_ROW_FWD(NL_)                                                                                       \
+    if (n_tanh_layers == NL_) {                                                                                \
+        if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, true>), dim3(grow), dim3(64), 0,        \
+                                    (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, B, T);   \
+        else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, false>), dim3(grow), dim3(64), 0,           \
+                                (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, B, T);       \
+    }
+        WDF_ROW_FWD(3) WDF_ROW_FWD(4) WDF_ROW_FWD(5)
+#undef WDF_ROW_FWD
+    }
     return check_launch("wdf_clipper_mlp_fwd");
 }
 

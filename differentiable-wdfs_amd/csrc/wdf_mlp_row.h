@@ -1,0 +1,157 @@
+// wdf_mlp_row.h -- the MLP-root clipper with one 16-lane DPP row per sequence, gfx950.
+//
+// wdf_mlp.h gives every sequence ONE lane, which evaluates the whole network serially: a 2x16 net
+// is ~600 dependent FMAs per time step, and the reference's 1340 training sequences
+// (clipper_pot.py:58) fill 21 waves of a 1024-SIMD chip.  Here a sequence owns a ROW of 16 lanes,
+// lane j = hidden neuron j (widths 4 and 8 are zero-padded to 16):
+//   * a hidden layer is 16 FMAs per lane, the activations of the previous layer arriving by DPP
+//     row rotation (v_mov_dpp row_ror:s, folded into the FMA where the compiler can) -- no LDS,
+//     no weight traffic: lane j keeps its 16 weights per layer, ordered by rotation, in VGPRs;
+//   * the output layer is one product per lane and a 4-step row reduction;
+//   * a wave carries 4 sequences, so the same batch is 16x more waves with a ~6x shorter
+//     dependent chain per step.
+// The clipper arithmetic (tf_wdf.py:179-192) is replicated in the 16 lanes of a row; lane 0 of
+// the row stores.  Same math as wdf_mlp.h up to summation order inside a layer.
+// Which lane a rotation reads from is not assumed: the lane index itself is sent through the
+// same DPP control, and the weights are gathered with the index that comes back.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wdf_mlp.h"
+
+namespace wdf {
+
+template <int S>
+__device__ __forceinline__ float row_rot(float v)
+{
+    if constexpr (S == 0) return v;
+    else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + S, 0xf, 0xf, false));
+}
+template <int S>
+__device__ __forceinline__ int row_rot_i(int v)
+{
+    if constexpr (S == 0) return v;
+    else return __builtin_amdgcn_update_dpp(0, v, 0x120 + S, 0xf, 0xf, false);
+}
+
+// sum over the 16 lanes of a row, result in every lane: rotations by 8, 4, 2, 1
+__device__ __forceinline__ float row_sum(float v)
+{
+    v += row_rot<8>(v);
+    v += row_rot<4>(v);
+    v += row_rot<2>(v);
+    v += row_rot<1>(v);
+    return v;
+}
+
+// The weights one lane (neuron j) holds.  mid[l][s] multiplies the activation that rotation s
+// delivers to this lane, i.e. W_l[src(s)][j] with src(s) = row_rot_i<s>(j).
+template <int NL>
+struct RowWeights {
+    float k0a, k0l, b0;            // layer 0: out_j = b0 + a k0a + lr k0l          (kernel0 [2][H], bias0)
+    float mid[NL - 1][16];         // layers 1..NL-1, by rotation
+    float tmid[NL - 1][16];        // the transposed access for the reverse sweep: W_l[j][src(s)]
+    float bias[NL - 1];
+    float wo, bo;                  // output layer [H][1], bias
+};
+
+template <int S, int NL>
+__device__ __forceinline__ void row_load_rot(RowWeights<NL>& W, const float* __restrict__ w, int H, int j, bool with_t)
+{
+    const int src = row_rot_i<S>(j);                           // the neuron whose activation rotation S brings here
+    const bool ok = j < H && src < H;
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        const float* __restrict__ k = w + 3 * H + (l - 1) * (H * H + H);      // kernel_l [in][out]
+        W.mid[l - 1][S] = ok ? k[src * H + j] : 0.0f;
+        W.tmid[l - 1][S] = (with_t && ok) ? k[j * H + src] : 0.0f;
+    }
+    if constexpr (S + 1 < 16) row_load_rot<S + 1, NL>(W, w, H, j, with_t);
+}
+
+template <int NL>
+__device__ __forceinline__ RowWeights<NL> row_load_weights(const float* __restrict__ w, int H, int j, bool with_t)
+{
+    RowWeights<NL> W;
+    const bool live = j < H;
+    W.k0a = live ? w[j] : 0.0f;
+    W.k0l = live ? w[H + j] : 0.0f;
+    W.b0 = live ? w[2 * H + j] : 0.0f;
+#pragma unroll
+    for (int l = 1; l < NL; ++l) W.bias[l - 1] = live ? w[3 * H + (l - 1) * (H * H + H) + H * H + j] : 0.0f;
+    const int kWo = 3 * H + (NL - 1) * (H * H + H);
+    W.wo = live ? w[kWo + j] : 0.0f;
+    W.bo = w[kWo + H];
+    row_load_rot<0, NL>(W, w, H, j, with_t);
+    return W;
+}
+
+// acc += sum_s wt[s] * rot_s(h): four partial sums keep the dependent chain at 4 FMAs
+template <int S>
+__device__ __forceinline__ void row_matvec_step(const float (&wt)[16], float h, float (&p)[4])
+{
+    p[S & 3] = fmaf(wt[S], row_rot<S>(h), p[S & 3]);
+    if constexpr (S + 1 < 16) row_matvec_step<S + 1>(wt, h, p);
+}
+__device__ __forceinline__ float row_matvec(const float (&wt)[16], float h, float init)
+{
+    float p[4] = {init, 0.0f, 0.0f, 0.0f};
+    row_matvec_step<0>(wt, h, p);
+    return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+// out = MLP(a, lr) in every lane of the row; act[l] = this lane's activation in layer l
+template <int NL>
+__device__ __forceinline__ float row_mlp_fwd(const RowWeights<NL>& W, float a, float lr, float (&act)[NL])
+{
+    act[0] = tanh_fast(fmaf(lr, W.k0l, fmaf(a, W.k0a, W.b0)));
+#pragma unroll
+    for (int l = 1; l < NL; ++l) act[l] = tanh_fast(row_matvec(W.mid[l - 1], act[l - 1], W.bias[l - 1]));
+    return row_sum(W.wo * act[NL - 1]) + W.bo;
+}
+
+// x, r: [B][T]; y, zstash: [T][B]; w: flat weights of a 2 -> H -> ... -> H -> 1 net, H <= 16
+template <int NL, bool DYN_R>
+__global__ __launch_bounds__(64) void clipper_mlp_row_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
+    const float* __restrict__ w, int H, float fs, float* __restrict__ y, float* __restrict__ zstash,
+    const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T)
+{
+    const int lane = threadIdx.x, j = lane & 15;
+    const int64_t b_raw = (int64_t)blockIdx.x * 4 + (lane >> 4);
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const MlpClipConsts c = mlp_load_consts(theta2, fs);
+    const RowWeights<NL> W = row_load_weights<NL>(w, H, j, false);
+    const float* __restrict__ xp = x + b * T;
+    const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
+    float z = z0 ? z0[b] : 0.0f;
+    float act[NL];
+    for (int64_t t0 = 0; t0 < T; t0 += 16) {
+        // lane j of the row fetches sample t0 + j: one 64-byte read per row and 16 steps
+        const int64_t tj = t0 + j < T ? t0 + j : T - 1;
+        const float xblk = xp[tj];
+        const float rblk = DYN_R ? rp[tj] : 1.0f;
+        const int n = T - t0 < 16 ? (int)(T - t0) : 16;
+        for (int i = 0; i < n; ++i) {
+            const int src = (lane & 48) | i;
+            const float xin = __shfl(xblk, src, 64);
+            float p, Rp, lr;
+            mlp_step_coeffs<DYN_R>(c, DYN_R ? __shfl(rblk, src, 64) : 1.0f, p, Rp, lr);
+            const float b_diff = z - xin;
+            const float b_temp = -p * b_diff;
+            const float a = z + b_temp;
+            const float zn = b_temp - row_mlp_fwd<NL>(W, a, lr, act);       // b_root = -MLP
+            if (j == 0) {
+                const int64_t o = (t0 + i) * B + b;
+                if (zstash) zstash[o] = z;
+                y[o] = 0.5f * (zn + z);
+            }
+            z = zn;
+        }
+    }
+    if (zT && j == 0) zT[b] = z;
+}
+
+}  // namespace wdf

@@ -18,6 +18,11 @@ WDF_X_TIME_MAJOR = 1 << 0
 WDF_PREC_F64 = 1 << 1
 WDF_TP_PACK2 = 1 << 2
 WDF_GENERAL_ROOT = 1 << 3
+WDF_MLP_LANE_PER_SEQUENCE = 1 << 4
+
+# Set True to run the one-lane-per-sequence MLP kernels (csrc/wdf_mlp.h) instead of the default
+# 16-lane row per sequence (csrc/wdf_mlp_row.h): parity tests and A/B timing.
+MLP_LANE_PER_SEQUENCE = False
 
 # Set True to make every clipper call take the general per-step root evaluation (WDF_GENERAL_ROOT):
 # parity tests compare it with the default path, tools time one against the other on the same box.
@@ -373,7 +378,7 @@ def clipper_mlp_fwd(x, theta2, w, hidden, n_tanh, fs, r=None, want_stash=True, z
     zs = torch.empty((T, B), dtype=torch.float32, device=x.device) if want_stash else None
     zT = torch.empty((B,), dtype=torch.float32, device=x.device) if want_zT else None
     rc = lib().wdf_clipper_mlp_fwd(_ptr(x), _ptr(r), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh), float(fs),
-                                   _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, 0, _stream())
+                                   _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, WDF_MLP_LANE_PER_SEQUENCE if MLP_LANE_PER_SEQUENCE else 0, _stream())
     _check(rc, "wdf_clipper_mlp_fwd")
     return y, zs, zT
 

@@ -45,6 +45,8 @@ enum {
     WDF_X_TIME_MAJOR = 1 << 0, /* x (and r) are [T][B] instead of [B][T]                 */
     WDF_PREC_F64     = 1 << 1, /* evaluate the root solve in fp64 (config C5); I/O stays f32 */
     WDF_TP_PACK2     = 1 << 2, /* time-parallel kernels: two sequences per lane, packed v_pk_* math */
+    WDF_MLP_LANE_PER_SEQUENCE = 1 << 4, /* MLP-root kernels: the one-lane-per-sequence variant (csrc/wdf_mlp.h)
+                                  instead of the default 16-lane row per sequence (csrc/wdf_mlp_row.h) */
     WDF_GENERAL_ROOT = 1 << 3  /* always take the general per-step root evaluation (the kernels otherwise
                                   switch, once per launch, to a shorter step when the static port
                                   resistance keeps omega_1 in its series-only region); for parity tests

@@ -50,3 +50,16 @@ for R_kind in ("static 45k", "per-sample pot"):
         plan = mlp_root.segment_plan(B, T, mlp_root.engine.resistance_max(rr) if rr is not None else 45.0e3, 4.7e-9, fs)
         print(f"step {n_tanh - 1}x{hidden} R {R_kind}: sequential {t_seq:.2f} ms, segmented {t_tp:.2f} ms "
               f"(plan K,L,W={plan}, miss={mlp_root.LAST_SEGMENT_MISS['miss']})")
+
+# forward kernel A/B: 16-lane row per sequence (default) vs one lane per sequence
+print("forward kernel, per-sample R, 1340 x 2048:")
+for hidden, n_tanh in ((4, 3), (8, 3), (16, 3), (8, 5)):
+    nw = wb.lib().wdf_mlp_weight_count(hidden, n_tanh)
+    w = (torch.randn(nw, device="cuda") * 0.3).contiguous()
+    res = {}
+    for lane in (False, True):
+        wb.MLP_LANE_PER_SEQUENCE = lane
+        y, _, _ = wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, fs, r=r)
+        res[lane] = (timeit(lambda: wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, fs, r=r)), y)
+    wb.MLP_LANE_PER_SEQUENCE = False
+    print(f"  {n_tanh - 1}x{hidden}: row {res[False][0]:.3f} ms, lane {res[True][0]:.3f} ms, max |dy| {float((res[False][1] - res[True][1]).abs().max()):.2e}")
