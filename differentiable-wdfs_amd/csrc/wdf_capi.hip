@@ -567,6 +567,8 @@ int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, con
     return check_launch("wdf_clipper_mlp_fwd");
 }
 
+size_t wdf_clipper_mlp_bwd_ws_bytes(int64_t B) { return B > 0 ? (size_t)((B + 3) / 4) * 4 * sizeof(double) : 0; }
+
 int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, const float* w, int hidden,
                         int n_tanh_layers, float fs, const float* zstash, const float* gy, float* gb, float* ain,
                         float* lrin, void* ws, float* gtheta2, int64_t B, int64_t T, int flags, void* stream)
@@ -575,9 +577,24 @@ int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, con
     if (rc) return rc;
     if (!zstash || !gy || !gb || !ain || !ws || !gtheta2) return fail(WDF_EINVAL, "null zstash/gy/gb/ain/ws/gtheta2");
     if (r && !lrin) return fail(WDF_EINVAL, "per-sample resistance needs lrin");
-    const unsigned grid = (unsigned)((B + 63) / 64);
+    unsigned grid = (unsigned)((B + 63) / 64);
     const bool dyn = r != nullptr;
-    WDF_MLP_DISPATCH(clipper_mlp_bwd_kernel, x, r, theta2, w, fs, zstash, gy, gb, ain, lrin, (double*)ws, B, T)
+    if (flags & WDF_MLP_LANE_PER_SEQUENCE) {
+        WDF_MLP_DISPATCH(clipper_mlp_bwd_kernel, x, r, theta2, w, fs, zstash, gy, gb, ain, lrin, (double*)ws, B, T)
+    } else {                                      // one 16-lane row per sequence (wdf_mlp_row.h)
+        grid = (unsigned)((B + 3) / 4);
+#define WDF_ROW_BWD(NL_)                                                                                       \
+    if (n_tanh_layers == NL_) {                                                                                \
+        if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_bwd_kernel<NL_, true>), dim3(grid), dim3(64), 0,        \
+                                    (hipStream_t)stream, x, r, theta2, w, hidden, fs, zstash, gy, gb, ain, lrin,  \
+                                    (double*)ws, B, T);                                                        \
+        else hipLaunchKernelGGL((wdf::clipper_mlp_row_bwd_kernel<NL_, false>), dim3(grid), dim3(64), 0,           \
+                                (hipStream_t)stream, x, r, theta2, w, hidden, fs, zstash, gy, gb, ain, lrin,      \
+                                (double*)ws, B, T);                                                            \
+    }
+        WDF_ROW_BWD(3) WDF_ROW_BWD(4) WDF_ROW_BWD(5)
+#undef WDF_ROW_BWD
+    }
     rc = check_launch("wdf_clipper_mlp_bwd");
     if (rc) return rc;
     hipLaunchKernelGGL(wdf::clipper_mlp_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,

@@ -154,4 +154,86 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_kernel(
     if (zT && j == 0) zT[b] = z;
 }
 
+// d out / d a and d out / d lr from the kept activations (every lane of the row gets both):
+//   delta_L[j] = wo[j] (1 - h_L[j]^2) ;  delta_{l-1}[j] = (sum_i W_l[j][i] delta_l[i]) (1 - h_{l-1}[j]^2)
+// -- the transposed product uses the same rotations with the weights gathered the other way round.
+template <int NL>
+__device__ __forceinline__ void row_mlp_grad_in(const RowWeights<NL>& W, const float (&act)[NL], float& da, float& dlr)
+{
+    float d = W.wo * fmaf(-act[NL - 1], act[NL - 1], 1.0f);
+#pragma unroll
+    for (int l = NL - 1; l >= 1; --l) d = row_matvec(W.tmid[l - 1], d, 0.0f) * fmaf(-act[l - 1], act[l - 1], 1.0f);
+    da = row_sum(W.k0a * d);
+    dlr = row_sum(W.k0l * d);
+}
+
+// Reverse sweep, same outputs as clipper_mlp_bwd_kernel: gb, ain (and lrin when DYN_R) [T][B], and
+// per-WAVE partials ws: double[gridDim.x][4] = {S_lr, 0, S_P, 0} over the wave's 4 sequences.
+template <int NL, bool DYN_R>
+__global__ __launch_bounds__(64) void clipper_mlp_row_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
+    const float* __restrict__ w, int H, float fs, const float* __restrict__ zstash, const float* __restrict__ gy,
+    float* __restrict__ gb, float* __restrict__ ain, float* __restrict__ lrin, double* __restrict__ ws,
+    int64_t B, int64_t T)
+{
+    const int lane = threadIdx.x, j = lane & 15;
+    const int64_t b_raw = (int64_t)blockIdx.x * 4 + (lane >> 4);
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    const MlpClipConsts c = mlp_load_consts(theta2, fs);
+    const RowWeights<NL> W = row_load_weights<NL>(w, H, j, true);
+    const float* __restrict__ xp = x + b * T;
+    const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
+    double dLr = 0.0, dP = 0.0;
+    float gz = 0.0f;
+    float act[NL];
+    for (int64_t t1 = T; t1 > 0; t1 -= 16) {                  // blocks of 16 steps, walked backwards
+        const int64_t t0 = t1 >= 16 ? t1 - 16 : 0;
+        const int n = (int)(t1 - t0);
+        // lane j of the row fetches what step t0 + j needs: x, r from the row of the sequence,
+        // state and dL/dy from the time-major arrays
+        const int64_t tj = j < n ? t0 + j : t0;
+        const float xblk = xp[tj];
+        const float rblk = DYN_R ? rp[tj] : 1.0f;
+        const float zblk = zstash[tj * B + b];
+        const float gblk = gy[tj * B + b];
+        for (int i = n - 1; i >= 0; --i) {
+            const int src = (lane & 48) | i;
+            const float xin = __shfl(xblk, src, 64), z = __shfl(zblk, src, 64), g = __shfl(gblk, src, 64);
+            float p, Rp, lr;
+            mlp_step_coeffs<DYN_R>(c, DYN_R ? __shfl(rblk, src, 64) : 1.0f, p, Rp, lr);
+            const float b_diff = z - xin;
+            const float a = fmaf(-p, b_diff, z);
+            (void)row_mlp_fwd<NL>(W, a, lr, act);
+            float da, dlr;
+            row_mlp_grad_in<NL>(W, act, da, dlr);
+            const float Da = -da, Dlr = -dlr;                    // b_root = -MLP
+            const float g_b2n = fmaf(0.5f, g, gz);
+            const float g_a = g_b2n * Da;
+            const float g_lr = g_b2n * Dlr;
+            const float g_bt = g_b2n + g_a;
+            const float g_p = -g_bt * b_diff;
+            if (j == 0) {
+                const int64_t o = (t0 + i) * B + b;
+                gb[o] = g_b2n;
+                ain[o] = a;
+                if constexpr (DYN_R) lrin[o] = lr;
+            }
+            if constexpr (DYN_R) {
+                dP += (double)(Rp * fmaf(g_p, p, g_lr));
+            } else {
+                dP += (double)g_p;
+                dLr += (double)g_lr;
+            }
+            gz = fmaf(-p, g_bt, fmaf(0.5f, g, g_a));
+        }
+    }
+    if (!live || j != 0) { dLr = dP = 0.0; }                   // one lane per sequence contributes
+    dLr = wave_sum(dLr); dP = wave_sum(dP);
+    if (threadIdx.x == 0) {
+        double* o = ws + (int64_t)blockIdx.x * 4;
+        o[0] = dLr; o[1] = 0.0; o[2] = dP; o[3] = 0.0;
+    }
+}
+
 }  // namespace wdf

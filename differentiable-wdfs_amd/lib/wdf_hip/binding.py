@@ -90,6 +90,8 @@ def lib():
     L.wdf_mlp_weight_count.argtypes = [ci, ci]
     L.wdf_clipper_mlp_fwd.restype = ci
     L.wdf_clipper_mlp_fwd.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, i64, i64, ci, vp]
+    L.wdf_clipper_mlp_bwd_ws_bytes.restype = C.c_size_t
+    L.wdf_clipper_mlp_bwd_ws_bytes.argtypes = [i64]
     L.wdf_clipper_mlp_bwd.restype = ci
     L.wdf_clipper_mlp_bwd.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, fp, vp, fp, i64, i64, ci, vp]
     L.wdf_mlp_eval.restype = ci
@@ -134,7 +136,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_asym_root",
-    "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd",
+    "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
     "wdf_omega_f32", "wdf_diode_pair_f32", "wdf_adam_step",
@@ -396,11 +398,11 @@ def clipper_mlp_bwd(x, theta2, w, hidden, n_tanh, fs, zstash, gy, r=None):
     gb = torch.empty((T, B), dtype=torch.float32, device=x.device)
     ain = torch.empty((T, B), dtype=torch.float32, device=x.device)
     lrin = torch.empty((T, B), dtype=torch.float32, device=x.device) if r is not None else None
-    ws = torch.empty((lib().wdf_clipper_bwd_ws_bytes(B),), dtype=torch.uint8, device=x.device)
+    ws = torch.empty((lib().wdf_clipper_mlp_bwd_ws_bytes(B),), dtype=torch.uint8, device=x.device)
     gth = torch.empty((2,), dtype=torch.float32, device=x.device)
     rc = lib().wdf_clipper_mlp_bwd(_ptr(x), _ptr(r), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh), float(fs),
                                    _ptr(zstash), _ptr(gy), _ptr(gb), _ptr(ain), _ptr(lrin), _ptr(ws), _ptr(gth),
-                                   B, T, 0, _stream())
+                                   B, T, WDF_MLP_LANE_PER_SEQUENCE if MLP_LANE_PER_SEQUENCE else 0, _stream())
     _check(rc, "wdf_clipper_mlp_bwd")
     return gth, gb, ain, lrin
 

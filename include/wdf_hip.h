@@ -182,6 +182,7 @@ int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, con
                         int hidden, int n_tanh_layers, float fs,
                         float* y, float* zstash, const float* z0, float* zT,
                         int64_t B, int64_t T, int flags, void* stream);
+size_t wdf_clipper_mlp_bwd_ws_bytes(int64_t B);   /* size of wdf_clipper_mlp_bwd's ws */
 int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, const float* w,
                         int hidden, int n_tanh_layers, float fs,
                         const float* zstash, const float* gy,

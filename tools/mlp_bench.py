@@ -63,3 +63,20 @@ for hidden, n_tanh in ((4, 3), (8, 3), (16, 3), (8, 5)):
         res[lane] = (timeit(lambda: wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, fs, r=r)), y)
     wb.MLP_LANE_PER_SEQUENCE = False
     print(f"  {n_tanh - 1}x{hidden}: row {res[False][0]:.3f} ms, lane {res[True][0]:.3f} ms, max |dy| {float((res[False][1] - res[True][1]).abs().max()):.2e}")
+
+print("reverse-sweep kernel (+ theta reduce), per-sample R, 1340 x 2048:")
+for hidden, n_tanh in ((4, 3), (8, 3), (16, 3), (8, 5)):
+    nw = wb.lib().wdf_mlp_weight_count(hidden, n_tanh)
+    w = (torch.randn(nw, device="cuda") * 0.3).contiguous()
+    y, zs, _ = wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, fs, r=r)
+    gy = torch.randn_like(y) / y.numel()
+    res = {}
+    for lane in (False, True):
+        wb.MLP_LANE_PER_SEQUENCE = lane
+        out = wb.clipper_mlp_bwd(x, th2, w, hidden, n_tanh, fs, zs, gy, r=r)
+        res[lane] = (timeit(lambda: wb.clipper_mlp_bwd(x, th2, w, hidden, n_tanh, fs, zs, gy, r=r)), out)
+    wb.MLP_LANE_PER_SEQUENCE = False
+    a, b = res[False][1], res[True][1]
+    print(f"  {n_tanh - 1}x{hidden}: row {res[False][0]:.3f} ms, lane {res[True][0]:.3f} ms, "
+          f"gtheta rel diff {float(((a[0] - b[0]).abs() / b[0].abs().clamp_min(1e-30)).max()):.1e}, "
+          f"max |d gb| {float((a[1] - b[1]).abs().max()):.1e} of {float(b[1].abs().max()):.1e}")
