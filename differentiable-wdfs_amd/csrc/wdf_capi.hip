@@ -567,6 +567,44 @@ int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, con
     return check_launch("wdf_clipper_mlp_fwd");
 }
 
+int64_t wdf_clipper_mlp_bwd_w_ws_bytes(int hidden, int n_tanh_layers, int64_t B)
+{
+    if (B <= 0 || !mlp_arch_ok(hidden, n_tanh_layers)) return 0;
+    const int64_t nblk = (B + 3) / 4;
+    return nblk * 4 * (int64_t)sizeof(double) + nblk * wdf_mlp_weight_count(hidden, n_tanh_layers) * (int64_t)sizeof(float);
+}
+
+int wdf_clipper_mlp_bwd_w(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                          int n_tanh_layers, float fs, const float* zstash, const float* gy, void* ws, float* gtheta2,
+                          float* gw, int64_t B, int64_t T, int flags, void* stream)
+{
+    int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, 0);
+    if (rc) return rc;
+    if (flags != 0) return fail(WDF_EINVAL, "wdf_clipper_mlp_bwd_w takes flags = 0");
+    if (!zstash || !gy || !ws || !gtheta2 || !gw) return fail(WDF_EINVAL, "null zstash/gy/ws/gtheta2/gw");
+    const unsigned grid = (unsigned)((B + 3) / 4);
+    const bool dyn = r != nullptr;
+    double* wsd = (double*)ws;
+    float* wsw = (float*)((char*)ws + (size_t)grid * 4 * sizeof(double));
+#define WDF_ROW_BWD_W(NL_)                                                                                     \
+    if (n_tanh_layers == NL_) {                                                                                \
+        if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_bwd_w_kernel<NL_, true>), dim3(grid), dim3(64), 0,      \
+                                    (hipStream_t)stream, x, r, theta2, w, hidden, fs, zstash, gy, wsw, wsd, B, T);  \
+        else hipLaunchKernelGGL((wdf::clipper_mlp_row_bwd_w_kernel<NL_, false>), dim3(grid), dim3(64), 0,         \
+                                (hipStream_t)stream, x, r, theta2, w, hidden, fs, zstash, gy, wsw, wsd, B, T);    \
+    }
+    WDF_ROW_BWD_W(3) WDF_ROW_BWD_W(4) WDF_ROW_BWD_W(5)
+#undef WDF_ROW_BWD_W
+    rc = check_launch("wdf_clipper_mlp_bwd_w");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wdf::clipper_mlp_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)wsd, (int)grid, theta2, fs, dyn ? 1 : 0, gtheta2);
+    const int count = wdf_mlp_weight_count(hidden, n_tanh_layers);
+    hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)wsw, (int)grid, count, gw);
+    return check_launch("wdf_clipper_mlp_bwd_w reduce");
+}
+
 size_t wdf_clipper_mlp_bwd_ws_bytes(int64_t B) { return B > 0 ? (size_t)((B + 3) / 4) * 4 * sizeof(double) : 0; }
 
 int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, const float* w, int hidden,

@@ -236,4 +236,152 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_bwd_kernel(
     }
 }
 
+// ---- reverse sweep with the weight gradient folded in ------------------------------------------
+// dL/dW = -sum_n g_b2n[n] dMLP(a[n], lr[n])/dW.  Lane j owns neuron j, so it also owns the gradient
+// of every weight INTO neuron j: with G = -g_b2n and delta_l[j] = d out / d pre_l[j] (the values
+// the input-Jacobian chain passes through anyway),
+//   g wo[j] += G h_L[j] ; g bias_l[j] += G delta_l[j] ; g W_l[src(s)][j] += G delta_l[j] rot_s(h_{l-1})
+//   g k0a[j] += G delta_0[j] a ; g k0l[j] += G delta_0[j] lr ; g b0[j] += G delta_0[j]
+// -- independent accumulations that fill issue slots of a latency-bound step.  No g_b / a / log R
+// arrays are written and no second pass over the samples is needed.
+template <int NL>
+struct RowGrads {
+    float k0a, k0l, b0, wo, bo;
+    float bias[NL - 1];
+    float mid[NL - 1][16];
+};
+
+template <int S>
+__device__ __forceinline__ void row_outer_step(float (&gm)[16], float h, float gd)
+{
+    gm[S] = fmaf(gd, row_rot<S>(h), gm[S]);
+    if constexpr (S + 1 < 16) row_outer_step<S + 1>(gm, h, gd);
+}
+
+template <int NL>
+__device__ __forceinline__ void row_mlp_grad_all(const RowWeights<NL>& W, const float (&act)[NL], float a, float lr,
+                                                 float G, RowGrads<NL>& acc, float& da, float& dlr)
+{
+    acc.wo = fmaf(G, act[NL - 1], acc.wo);
+    acc.bo += G;
+    float d = W.wo * fmaf(-act[NL - 1], act[NL - 1], 1.0f);      // delta_L
+#pragma unroll
+    for (int l = NL - 1; l >= 1; --l) {
+        const float gd = G * d;
+        acc.bias[l - 1] += gd;
+        row_outer_step<0>(acc.mid[l - 1], act[l - 1], gd);
+        d = row_matvec(W.tmid[l - 1], d, 0.0f) * fmaf(-act[l - 1], act[l - 1], 1.0f);
+    }
+    const float gd0 = G * d;
+    acc.k0a = fmaf(gd0, a, acc.k0a);
+    acc.k0l = fmaf(gd0, lr, acc.k0l);
+    acc.b0 += gd0;
+    da = row_sum(W.k0a * d);
+    dlr = row_sum(W.k0l * d);
+}
+
+// sum over the 4 rows of the wave (lanes j, j+16, j+32, j+48), result in every lane
+__device__ __forceinline__ float rows_sum(float v)
+{
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int S, int NL>
+__device__ __forceinline__ void row_store_mid(const RowGrads<NL>& acc, float* __restrict__ o, int H, int j, bool writer)
+{
+    const int src = row_rot_i<S>(j);
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        const float v = rows_sum(acc.mid[l - 1][S]);
+        if (writer && j < H && src < H) o[3 * H + (l - 1) * (H * H + H) + src * H + j] = v;
+    }
+    if constexpr (S + 1 < 16) row_store_mid<S + 1, NL>(acc, o, H, j, writer);
+}
+
+// Outputs: wsw float[gridDim.x][count] = this wave's weight-gradient partial in the flat weight
+// order (every entry written exactly once per wave), ws double[gridDim.x][4] as above.
+template <int NL, bool DYN_R>
+__global__ __launch_bounds__(64) void clipper_mlp_row_bwd_w_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
+    const float* __restrict__ w, int H, float fs, const float* __restrict__ zstash, const float* __restrict__ gy,
+    float* __restrict__ wsw, double* __restrict__ ws, int64_t B, int64_t T)
+{
+    const int lane = threadIdx.x, j = lane & 15;
+    const int64_t b_raw = (int64_t)blockIdx.x * 4 + (lane >> 4);
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    const MlpClipConsts c = mlp_load_consts(theta2, fs);
+    const RowWeights<NL> W = row_load_weights<NL>(w, H, j, true);
+    const float* __restrict__ xp = x + b * T;
+    const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
+    RowGrads<NL> acc;
+    acc.k0a = acc.k0l = acc.b0 = acc.wo = acc.bo = 0.0f;
+#pragma unroll
+    for (int l = 0; l < NL - 1; ++l) {
+        acc.bias[l] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc.mid[l][s] = 0.0f;
+    }
+    double dLr = 0.0, dP = 0.0;
+    float gz = 0.0f;
+    float act[NL];
+    for (int64_t t1 = T; t1 > 0; t1 -= 16) {
+        const int64_t t0 = t1 >= 16 ? t1 - 16 : 0;
+        const int n = (int)(t1 - t0);
+        const int64_t tj = j < n ? t0 + j : t0;
+        const float xblk = xp[tj];
+        const float rblk = DYN_R ? rp[tj] : 1.0f;
+        const float zblk = zstash[tj * B + b];
+        const float gblk = live ? gy[tj * B + b] : 0.0f;        // shadow rows of the last wave add nothing
+        for (int i = n - 1; i >= 0; --i) {
+            const int src = (lane & 48) | i;
+            const float xin = __shfl(xblk, src, 64), z = __shfl(zblk, src, 64), g = __shfl(gblk, src, 64);
+            float p, Rp, lr;
+            mlp_step_coeffs<DYN_R>(c, DYN_R ? __shfl(rblk, src, 64) : 1.0f, p, Rp, lr);
+            const float b_diff = z - xin;
+            const float a = fmaf(-p, b_diff, z);
+            (void)row_mlp_fwd<NL>(W, a, lr, act);
+            const float g_b2n = fmaf(0.5f, g, gz);
+            float da, dlr;
+            row_mlp_grad_all<NL>(W, act, a, lr, -g_b2n, acc, da, dlr);
+            const float g_a = -g_b2n * da;                       // b_root = -MLP
+            const float g_lr = -g_b2n * dlr;
+            const float g_bt = g_b2n + g_a;
+            const float g_p = -g_bt * b_diff;
+            if constexpr (DYN_R) {
+                dP += (double)(Rp * fmaf(g_p, p, g_lr));
+            } else {
+                dP += (double)g_p;
+                dLr += (double)g_lr;
+            }
+            gz = fmaf(-p, g_bt, fmaf(0.5f, g, g_a));
+        }
+    }
+    if (!live || j != 0) { dLr = dP = 0.0; }
+    dLr = wave_sum(dLr); dP = wave_sum(dP);
+    if (threadIdx.x == 0) {
+        double* o = ws + (int64_t)blockIdx.x * 4;
+        o[0] = dLr; o[1] = 0.0; o[2] = dP; o[3] = 0.0;
+    }
+    // weight-gradient partial of this wave (gy was zeroed for shadow rows, so they contribute 0)
+    const int count = 3 * H + (NL - 1) * (H * H + H) + H + 1;
+    float* __restrict__ o = wsw + (int64_t)blockIdx.x * count;
+    const bool writer = lane < 16;
+    const float vk0a = rows_sum(acc.k0a), vk0l = rows_sum(acc.k0l), vb0 = rows_sum(acc.b0), vwo = rows_sum(acc.wo),
+                vbo = rows_sum(acc.bo);
+    if (writer && j < H) {
+        o[j] = vk0a; o[H + j] = vk0l; o[2 * H + j] = vb0;
+        o[3 * H + (NL - 1) * (H * H + H) + j] = vwo;
+    }
+    if (lane == 0) o[count - 1] = vbo;
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        const float vb = rows_sum(acc.bias[l - 1]);
+        if (writer && j < H) o[3 * H + (l - 1) * (H * H + H) + H * H + j] = vb;
+    }
+    row_store_mid<0, NL>(acc, o, H, j, writer);
+}
+
 }  // namespace wdf

@@ -90,6 +90,10 @@ def lib():
     L.wdf_mlp_weight_count.argtypes = [ci, ci]
     L.wdf_clipper_mlp_fwd.restype = ci
     L.wdf_clipper_mlp_fwd.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, i64, i64, ci, vp]
+    L.wdf_clipper_mlp_bwd_w_ws_bytes.restype = i64
+    L.wdf_clipper_mlp_bwd_w_ws_bytes.argtypes = [ci, ci, i64]
+    L.wdf_clipper_mlp_bwd_w.restype = ci
+    L.wdf_clipper_mlp_bwd_w.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, vp, fp, fp, i64, i64, ci, vp]
     L.wdf_clipper_mlp_bwd_ws_bytes.restype = C.c_size_t
     L.wdf_clipper_mlp_bwd_ws_bytes.argtypes = [i64]
     L.wdf_clipper_mlp_bwd.restype = ci
@@ -137,6 +141,7 @@ EXPORTED_SYMBOLS = (
     "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
+    "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
     "wdf_omega_f32", "wdf_diode_pair_f32", "wdf_adam_step",
@@ -405,6 +410,24 @@ def clipper_mlp_bwd(x, theta2, w, hidden, n_tanh, fs, zstash, gy, r=None):
                                    B, T, WDF_MLP_LANE_PER_SEQUENCE if MLP_LANE_PER_SEQUENCE else 0, _stream())
     _check(rc, "wdf_clipper_mlp_bwd")
     return gth, gb, ain, lrin
+
+
+def clipper_mlp_bwd_w(x, theta2, w, hidden, n_tanh, fs, zstash, gy, r=None):
+    """-> gtheta2 [2], gw [wdf_mlp_weight_count]: the reverse sweep with the weight gradient folded in."""
+    require_gpu()
+    x, r, theta2, w = _f32_dev(x, "x"), _f32_dev(r, "r"), _f32_dev(theta2, "theta2"), _f32_dev(w, "w")
+    zstash, gy = _f32_dev(zstash, "zstash"), _f32_dev(gy, "gy")
+    B, T = x.shape
+    nbytes = lib().wdf_clipper_mlp_bwd_w_ws_bytes(int(hidden), int(n_tanh), B)
+    if nbytes <= 0:
+        raise WdfHipError(f"unsupported MLP root: width {hidden}, {n_tanh} tanh layers")
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    gth = torch.empty((2,), dtype=torch.float32, device=x.device)
+    gw = torch.empty((w.numel(),), dtype=torch.float32, device=x.device)
+    rc = lib().wdf_clipper_mlp_bwd_w(_ptr(x), _ptr(r), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh), float(fs),
+                                     _ptr(zstash), _ptr(gy), _ptr(ws), _ptr(gth), _ptr(gw), B, T, 0, _stream())
+    _check(rc, "wdf_clipper_mlp_bwd_w")
+    return gth, gw
 
 
 def mlp_eval(ain, lrin, w, hidden, n_tanh):

@@ -63,9 +63,13 @@ class _ClipperMlpFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         th, wd, x, zs = saved[:4]
         r = saved[4] if has_r else None
-        gth, gb, ain, lrin = binding.clipper_mlp_bwd(x, th, wd, hidden, n_tanh, fs, zs, gy.contiguous(), r=r)
-        # weight gradient: dL/dw = -sum_n gb[n] dMLP(a[n], lr[n])/dw, all B*T samples in parallel
-        gw = binding.clipper_mlp_wgrad(ain, lrin, gb, th, wd, hidden, n_tanh, fs)
+        if binding.MLP_LANE_PER_SEQUENCE:
+            gth, gb, ain, lrin = binding.clipper_mlp_bwd(x, th, wd, hidden, n_tanh, fs, zs, gy.contiguous(), r=r)
+            # weight gradient: dL/dw = -sum_n gb[n] dMLP(a[n], lr[n])/dw, all B*T samples in parallel
+            gw = binding.clipper_mlp_wgrad(ain, lrin, gb, th, wd, hidden, n_tanh, fs)
+        else:
+            # one 16-lane row per sequence; the weight gradient is accumulated in the same sweep
+            gth, gw = binding.clipper_mlp_bwd_w(x, th, wd, hidden, n_tanh, fs, zs, gy.contiguous(), r=r)
         return gth, gw, None, None, None, None, None, None, None, None
 
 
@@ -81,8 +85,10 @@ class _ClipperMlpFn(torch.autograd.Function):
 # forward's).  The state each chunk arrives with is compared with the state the previous chunk
 # ended in; if any differ by more than tol the call is redone sequentially.
 def segment_plan(B, T, R_slowest, C, fs, tol=1.0e-6):
-    """(K, L, W) or None.  W outlasts the slowest (largest-R) sequence's memory; chunks are at
-    least W long (<= 2x redundant work); no more chunks than it takes to fill the chip."""
+    """(K, L, W) or None.  W outlasts the slowest (largest-R) sequence's memory.  The row kernels
+    put 4 sequences in a wave, so a batch is ceil(B/4) waves; segments are added only until there is
+    about one wave per SIMD (1024), and only while a chunk is at least 2 W long (<= 1.5x the work):
+    beyond that the redundant warm-up and the gather / scatter copies cost more than they hide."""
     import math
     Rc = 1.0 / (2.0 * float(C) * float(fs))
     rho = abs(1.0 - 2.0 * Rc / (float(R_slowest) + Rc))
@@ -90,8 +96,11 @@ def segment_plan(B, T, R_slowest, C, fs, tol=1.0e-6):
         return None
     W = 8 if rho <= 0.0 else int(math.ceil(math.log(0.01 * tol) / math.log(rho)))
     W = max(8, -(-W // 8) * 8)
-    waves = max(1, -(-B // 64))
-    K = min(T // max(W, 64), max(1, 2048 // waves))
+    per_wave = 64 if binding.MLP_LANE_PER_SEQUENCE else 4
+    waves = max(1, -(-B // per_wave))
+    if 4 * waves > engine.N_SIMD:           # measured at 335 waves (1340 sequences): segmenting no longer pays
+        return None
+    K = min(T // max(2 * W, 64), -(-engine.N_SIMD // waves))
     if K < 2:
         return None
     L = -(-(-(-T // K)) // 8) * 8

@@ -183,6 +183,14 @@ int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, con
                         float* y, float* zstash, const float* z0, float* zT,
                         int64_t B, int64_t T, int flags, void* stream);
 size_t wdf_clipper_mlp_bwd_ws_bytes(int64_t B);   /* size of wdf_clipper_mlp_bwd's ws */
+/* The reverse sweep with the weight gradient folded in (csrc/wdf_mlp_row.h): gtheta2[2] and
+ * gw[wdf_mlp_weight_count()] in one pass -- no gb / ain / lrin arrays, no wdf_clipper_mlp_wgrad.
+ * What tape.gradient(loss, trainable_variables) returns at clipper_pot.py:181-184.  Deterministic. */
+int64_t wdf_clipper_mlp_bwd_w_ws_bytes(int hidden, int n_tanh_layers, int64_t B);
+int wdf_clipper_mlp_bwd_w(const float* x, const float* r, const float* theta2, const float* w,
+                          int hidden, int n_tanh_layers, float fs,
+                          const float* zstash, const float* gy, void* ws, float* gtheta2, float* gw,
+                          int64_t B, int64_t T, int flags, void* stream);
 int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, const float* w,
                         int hidden, int n_tanh_layers, float fs,
                         const float* zstash, const float* gy,
