@@ -106,6 +106,11 @@ def _scalar(v):
     return None
 
 
+# shared constants: coefficient vectors are never modified in place (every operation builds a new one)
+_EYE = torch.eye(NB, dtype=torch.float64)
+_ZERO = torch.zeros(NB, dtype=torch.float64)
+
+
 class Wave:
     __slots__ = ("rec", "step", "c0", "c1")
     __array_priority__ = 1000
@@ -116,9 +121,7 @@ class Wave:
     # -- construction helpers
     @staticmethod
     def basis(rec, slot):
-        c = torch.zeros(NB, dtype=torch.float64)
-        c[slot] = 1.0
-        return Wave(rec, c)
+        return Wave(rec, _EYE[slot])
 
     def _fresh(self):
         if self.step != self.rec.step:
@@ -133,8 +136,7 @@ class Wave:
         if s is None:
             raise WdfTraceError(f"cannot combine a recorded wave with {type(other).__name__} of shape "
                                 f"{tuple(getattr(other, 'shape', ()))}")
-        c = torch.zeros(NB, dtype=torch.float64)
-        return Wave(self.rec, c + _unit0() * s)
+        return Wave(self.rec, _unit0() * s)
 
     # -- affine arithmetic
     def __add__(self, other):
@@ -166,7 +168,7 @@ class Wave:
                                     "topology of clipper_pot.py is supported)")
             self.rec.dyn_elem = other.elem
             sgn = -1.0 if other.kind == "-p" else 1.0
-            return Wave(self.rec, torch.zeros(NB, dtype=torch.float64), sgn * self.c0)
+            return Wave(self.rec, _ZERO, sgn * self.c0)
         if isinstance(other, Wave):
             raise WdfTraceError("product of two waves outside the root: not a WDF adaptor operation")
         s = _scalar(other)
