@@ -309,3 +309,21 @@ def test_fused_mse_esr_step_matches_autograd_and_oracle(wb, oracle, time_major):
     got = g.cpu().numpy().astype(np.float64)
     assert np.max(np.abs(got - gref) / np.abs(gref)) < 2e-3, (got, gref)
     assert abs(float(step.loss[2]) - float(l64)) <= 1e-4 * float(l64)
+
+
+def test_randomized_plans_and_circuits(wb):
+    """tools/stress_tp.py, 60 cases: random component values over the clip ranges of tf_wdf.py:74,104,
+    random diode parameters and counts, amplitudes, shapes, layouts, chunkings and warm-ups (hopeless
+    ones included).  The time-parallel forward must equal the sequential one to 2e-6 whatever the plan
+    (a third of the cases go through the repair path) and the chunked reverse sweep must agree with the
+    sequential one."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_tp
+    worst_y = worst_g = 0.0
+    repaired = 0
+    for case in range(60):
+        ey, eg, rep = stress_tp.run_case(11, case)
+        worst_y, worst_g, repaired = max(worst_y, ey), max(worst_g, eg), repaired + rep
+    assert worst_y <= 2e-6 and worst_g <= 5e-4, (worst_y, worst_g)
+    assert repaired >= 5

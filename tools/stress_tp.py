@@ -1,0 +1,75 @@
+"""GPU: randomized stress of the time-parallel clipper kernels.  Random component values (over the
+clip ranges of tf_wdf.py:74,104 and wide diode ranges), amplitudes, shapes, diode counts, chunkings
+and warm-ups (including hopeless ones): the time-parallel forward must equal the sequential forward
+within the verified tolerance whatever the plan (repair path), and the chunked reverse sweep must
+equal the sequential one.  usage: python tools/stress_tp.py [n_cases] [seed]   |   --case <seed> <case> (one case, against the fp64 oracle)"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "differentiable-wdfs_amd", "lib"))
+from wdf_hip import binding as wb, workload
+
+def case_params(seed, case):
+    """Everything random about one case, from its own stream (a failing case reruns alone)."""
+    rng = np.random.default_rng([seed, case])
+    return dict(
+        B=int(rng.choice([1, 3, 64, 70, 200, 513])), T=int(rng.choice([32, 100, 257, 1024, 2048, 4100])),
+        Is=10.0 ** rng.uniform(-12, -6), nVt=rng.uniform(0.02, 0.12), R=10.0 ** rng.uniform(2.3, 6.0),
+        C=10.0 ** rng.uniform(-10, -6.5), n_up=int(rng.integers(1, 4)), n_down=int(rng.integers(1, 4)),
+        amp=10.0 ** rng.uniform(-2, 1.2), tm=bool(rng.integers(0, 2)), pack=bool(rng.integers(0, 2)),
+        K=int(rng.choice([2, 3, 8, 16])), W=int(rng.choice([32, 64, 192, 512])), Kb=int(rng.choice([1, 2, 5, 16])))
+
+
+def run_case(seed, case, oracle=None, verbose=False):
+    q = case_params(seed, case)
+    B, T, n_up, n_down, tm, pack = q["B"], q["T"], q["n_up"], q["n_down"], q["tm"], q["pack"]
+    fs = workload.FS
+    xh = (workload.sweep_batch(B, T, seed=case) * q["amp"] / 5.0).astype(np.float32)
+    x = torch.as_tensor(xh, device="cuda")
+    th = torch.tensor([q["Is"], q["nVt"], q["R"], q["C"]], dtype=torch.float32, device="cuda")
+    xin = x.t().contiguous() if tm else x
+    y, zs, zT = wb.clipper_fwd(x, th, fs, n_up=n_up, n_down=n_down, want_zT=True)
+    assert torch.isfinite(y).all(), ("sequential produced non-finite output", case, q)
+    y2, zs2, zT2, st = wb.clipper_fwd_tp(xin, th, fs, q["K"], q["W"], tol=1e-6, n_up=n_up, n_down=n_down, want_zT=True,
+                                         time_major=tm, pack=pack)
+    s = wb.tp_status(st)
+    scale = max(1.0, float(y.abs().max()))
+    ey = float((y2 - y).abs().max()) / scale
+    ez = float((zs2 - zs).abs().max()) / scale
+    assert ey <= 2e-6 and ez <= 4e-6 and float((zT2 - zT).abs().max()) <= 4e-6 * scale, (case, ey, ez, s, q)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(case)
+    gy = torch.randn(T, B, device="cuda", generator=gen) / (B * T)
+    g1, _ = wb.clipper_bwd(x, th, fs, zs, gy, n_up=n_up, n_down=n_down)
+    g2, _ = wb.clipper_bwd_tp(xin, th, fs, zs, gy, q["Kb"], n_up=n_up, n_down=n_down, time_major=tm, pack=pack)
+    assert torch.isfinite(g1).all() and torch.isfinite(g2).all(), (case, g1, g2, q)
+    # per component, against its own size plus 1e-3 of the largest one: a component that is a near-
+    # cancelling sum 1000x below the others carries fp32 rounding of the terms, in either sweep
+    eg = float(((g2 - g1).abs() / (g1.abs() + 1e-30 + 1e-3 * g1.abs().max())).max())
+    if verbose or oracle is not None:
+        print(q)
+        print("sequential sweep:", g1.cpu().numpy(), "\nchunked sweep   :", g2.cpu().numpy(), " mismatch", eg)
+    if oracle is not None:
+        th64 = th.cpu().numpy().astype(np.float64)
+        _, gref = oracle.clipper_fwd_bwd(th64, fs, xh.astype(np.float64), gy.cpu().numpy().astype(np.float64), n_up=n_up, n_down=n_down)
+        print("fp64 oracle     :", gref)
+        for name, g in (("sequential", g1), ("chunked", g2)):
+            print(f"  {name} rel. error vs oracle:", np.abs(g.cpu().numpy() - gref) / np.abs(gref))
+    return ey, eg, int(s["repaired_tiles"] > 0)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--case":                 # python tools/stress_tp.py --case <seed> <case>
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        import oracle as O
+        run_case(int(sys.argv[2]), int(sys.argv[3]), oracle=O)
+        sys.exit(0)
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    worst_y = worst_g = 0.0
+    repaired, bad = 0, []
+    for case in range(n_cases):
+        ey, eg, rep = run_case(seed, case)
+        worst_y, worst_g, repaired = max(worst_y, ey), max(worst_g, eg), repaired + rep
+        if eg > 5e-4:
+            bad.append((case, eg))
+    print(f"{n_cases} cases; worst relative y error {worst_y:.2e}, worst sweep mismatch {worst_g:.2e}; "
+          f"{repaired} cases went through the repair path; sweep mismatches > 5e-4: {bad}")
