@@ -183,3 +183,36 @@ def test_wgrad_kernel_matches_dense_autograd(hidden, n_tanh, dyn):
     want = torch.autograd.grad(-(gb.double() * out).sum(), wd)[0]
     err = float((gw.double() - want).abs().max())
     assert err <= 2e-5 * float(want.abs().max()), (err, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("hidden,n_tanh", [(4, 3), (8, 3), (16, 3), (8, 4), (4, 5), (8, 5)])
+@pytest.mark.parametrize("B,T,dyn", [(1, 16, False), (5, 100, True), (7, 257, False), (130, 515, True)])
+def test_row_kernels_equal_lane_kernels(hidden, n_tanh, B, T, dyn):
+    """The 16-lane-row kernels (default) against the one-lane-per-sequence kernels, random weights,
+    ragged shapes (B not a multiple of 4, T not a multiple of 16), static and per-sample R: forward
+    to 2e-6 of the state's scale, {R, C} and weight gradients to 2e-5 of their largest entry (summation order differs)."""
+    from wdf_hip import binding as wb, workload
+    rng = np.random.default_rng(B * 1000 + T + hidden)
+    x = cuda(workload.sweep_batch(B, T, seed=3) * 0.5)
+    r = cuda(workload.pot_resistance_batch(B, T)) if dyn else None
+    th2 = cuda([45.0e3, 4.7e-9])
+    nw = wb.lib().wdf_mlp_weight_count(hidden, n_tanh)
+    w = cuda(rng.standard_normal(nw) * 0.5)
+    z0 = cuda(rng.uniform(-0.2, 0.2, B))
+    gy = cuda(rng.standard_normal((T, B)) / (B * T))
+    try:
+        wb.MLP_LANE_PER_SEQUENCE = True
+        y_l, zs_l, zT_l = wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, FS, r=r, z0=z0, want_zT=True)
+        gth_l, gb, ain, lrin = wb.clipper_mlp_bwd(x, th2, w, hidden, n_tanh, FS, zs_l, gy, r=r)
+        gw_l = wb.clipper_mlp_wgrad(ain, lrin, gb, th2, w, hidden, n_tanh, FS)
+        wb.MLP_LANE_PER_SEQUENCE = False
+        y_r, zs_r, zT_r = wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, FS, r=r, z0=z0, want_zT=True)
+        gth_r, gw_r = wb.clipper_mlp_bwd_w(x, th2, w, hidden, n_tanh, FS, zs_l, gy, r=r)
+        gth_r2, gb_r, ain_r, _ = wb.clipper_mlp_bwd(x, th2, w, hidden, n_tanh, FS, zs_l, gy, r=r)
+    finally:
+        wb.MLP_LANE_PER_SEQUENCE = False
+    tol = 2e-6 * max(1.0, float(zs_l.abs().max()))           # random 0.5-sigma weights drive |z| to a few volts
+    assert float((y_r - y_l).abs().max()) <= tol and float((zs_r - zs_l).abs().max()) <= tol
+    assert float((zT_r - zT_l).abs().max()) <= tol
+    for a, b in ((gth_r, gth_l), (gth_r2, gth_l), (gw_r, gw_l), (gb_r, gb), (ain_r, ain)):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
