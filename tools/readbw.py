@@ -1,3 +1,5 @@
+"""GPU: what torch's own streaming kernels reach on this box (sum / dot reads, copy, fill): reference
+points for the read / write bandwidth the clipper kernels are compared with in DESIGN.md."""
 import torch, time
 a = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()   # 1 GiB
 b = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
