@@ -27,13 +27,13 @@ template <int S>
 __device__ __forceinline__ float row_rot(float v)
 {
     if constexpr (S == 0) return v;
-    else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + S, 0xf, 0xf, false));
+    else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + S, 0xf, 0xf, true));
 }
 template <int S>
 __device__ __forceinline__ int row_rot_i(int v)
 {
     if constexpr (S == 0) return v;
-    else return __builtin_amdgcn_update_dpp(0, v, 0x120 + S, 0xf, 0xf, false);
+    else return __builtin_amdgcn_update_dpp(0, v, 0x120 + S, 0xf, 0xf, true);
 }
 
 // sum over the 16 lanes of a row, result in every lane: rotations by 8, 4, 2, 1
@@ -112,6 +112,14 @@ __device__ __forceinline__ float row_mlp_fwd(const RowWeights<NL>& W, float a, f
     return row_sum(W.wo * act[NL - 1]) + W.bo;
 }
 
+// v[i] = the value lane i of this lane's row holds, i = 0..15: the 16 ds_bpermutes are issued together
+// at the top of a 16-step block, off the recurrence's critical path.
+__device__ __forceinline__ void row_spread(float blk, int lane, float (&v)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = __shfl(blk, (lane & 48) | i, 64);
+}
+
 // x, r: [B][T]; y, zstash: [T][B]; w: flat weights of a 2 -> H -> ... -> H -> 1 net, H <= 16
 template <int NL, bool DYN_R>
 __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_kernel(
@@ -134,11 +142,15 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_kernel(
         const float xblk = xp[tj];
         const float rblk = DYN_R ? rp[tj] : 1.0f;
         const int n = T - t0 < 16 ? (int)(T - t0) : 16;
-        for (int i = 0; i < n; ++i) {
-            const int src = (lane & 48) | i;
-            const float xin = __shfl(xblk, src, 64);
+        float xs[16], rs[16];
+        row_spread(xblk, lane, xs);
+        if constexpr (DYN_R) row_spread(rblk, lane, rs);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i >= n) break;
+            const float xin = xs[i];
             float p, Rp, lr;
-            mlp_step_coeffs<DYN_R>(c, DYN_R ? __shfl(rblk, src, 64) : 1.0f, p, Rp, lr);
+            mlp_step_coeffs<DYN_R>(c, DYN_R ? rs[i] : 1.0f, p, Rp, lr);
             const float b_diff = z - xin;
             const float b_temp = -p * b_diff;
             const float a = z + b_temp;
@@ -197,11 +209,17 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_bwd_kernel(
         const float rblk = DYN_R ? rp[tj] : 1.0f;
         const float zblk = zstash[tj * B + b];
         const float gblk = gy[tj * B + b];
-        for (int i = n - 1; i >= 0; --i) {
-            const int src = (lane & 48) | i;
-            const float xin = __shfl(xblk, src, 64), z = __shfl(zblk, src, 64), g = __shfl(gblk, src, 64);
+        float xs[16], rs[16], zz[16], gs[16];
+        row_spread(xblk, lane, xs);
+        row_spread(zblk, lane, zz);
+        row_spread(gblk, lane, gs);
+        if constexpr (DYN_R) row_spread(rblk, lane, rs);
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            if (i >= n) continue;
+            const float xin = xs[i], z = zz[i], g = gs[i];
             float p, Rp, lr;
-            mlp_step_coeffs<DYN_R>(c, DYN_R ? __shfl(rblk, src, 64) : 1.0f, p, Rp, lr);
+            mlp_step_coeffs<DYN_R>(c, DYN_R ? rs[i] : 1.0f, p, Rp, lr);
             const float b_diff = z - xin;
             const float a = fmaf(-p, b_diff, z);
             (void)row_mlp_fwd<NL>(W, a, lr, act);
@@ -335,11 +353,17 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_bwd_w_kernel(
         const float rblk = DYN_R ? rp[tj] : 1.0f;
         const float zblk = zstash[tj * B + b];
         const float gblk = live ? gy[tj * B + b] : 0.0f;        // shadow rows of the last wave add nothing
-        for (int i = n - 1; i >= 0; --i) {
-            const int src = (lane & 48) | i;
-            const float xin = __shfl(xblk, src, 64), z = __shfl(zblk, src, 64), g = __shfl(gblk, src, 64);
+        float xs[16], rs[16], zz[16], gs[16];
+        row_spread(xblk, lane, xs);
+        row_spread(zblk, lane, zz);
+        row_spread(gblk, lane, gs);
+        if constexpr (DYN_R) row_spread(rblk, lane, rs);
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            if (i >= n) continue;
+            const float xin = xs[i], z = zz[i], g = gs[i];
             float p, Rp, lr;
-            mlp_step_coeffs<DYN_R>(c, DYN_R ? __shfl(rblk, src, 64) : 1.0f, p, Rp, lr);
+            mlp_step_coeffs<DYN_R>(c, DYN_R ? rs[i] : 1.0f, p, Rp, lr);
             const float b_diff = z - xin;
             const float a = fmaf(-p, b_diff, z);
             (void)row_mlp_fwd<NL>(W, a, lr, act);
