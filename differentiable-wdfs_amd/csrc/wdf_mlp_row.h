@@ -88,18 +88,36 @@ __device__ __forceinline__ RowWeights<NL> row_load_weights(const float* __restri
     return W;
 }
 
-// acc += sum_s wt[s] * rot_s(h): four partial sums keep the dependent chain at 4 FMAs
-template <int S>
-__device__ __forceinline__ void row_matvec_step(const float (&wt)[16], float h, float (&p)[4])
-{
-    p[S & 3] = fmaf(wt[S], row_rot<S>(h), p[S & 3]);
-    if constexpr (S + 1 < 16) row_matvec_step<S + 1>(wt, h, p);
-}
+// acc += sum_s wt[s] * rot_s(h): four partial sums keep the dependent chain at 4 FMAs.  Written as
+// v_fmac_f32_dpp -- the rotation is an operand modifier of the FMA itself -- because the compiler
+// leaves the builtin as v_mov_b32_dpp + v_fmac (twice the instructions).  The leading s_nop covers
+// the VALU-write -> DPP-read hazard on h (2 wait states), which the hazard recogniser does not see
+// inside an asm block.
 __device__ __forceinline__ float row_matvec(const float (&wt)[16], float h, float init)
 {
-    float p[4] = {init, 0.0f, 0.0f, 0.0f};
-    row_matvec_step<0>(wt, h, p);
-    return (p[0] + p[1]) + (p[2] + p[3]);
+    float p0 = init, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_e32 %0, %4, %5\n\t"
+        "v_fmac_f32_dpp %1, %4, %6 row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %4, %7 row_ror:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %4, %8 row_ror:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %0, %4, %9 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %4, %10 row_ror:5 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %4, %11 row_ror:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %4, %12 row_ror:7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %0, %4, %13 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %4, %14 row_ror:9 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %4, %15 row_ror:10 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %4, %16 row_ror:11 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %0, %4, %17 row_ror:12 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %4, %18 row_ror:13 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %4, %19 row_ror:14 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %4, %20 row_ror:15 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
+        : "v"(h), "v"(wt[0]), "v"(wt[1]), "v"(wt[2]), "v"(wt[3]), "v"(wt[4]), "v"(wt[5]), "v"(wt[6]), "v"(wt[7]),
+          "v"(wt[8]), "v"(wt[9]), "v"(wt[10]), "v"(wt[11]), "v"(wt[12]), "v"(wt[13]), "v"(wt[14]), "v"(wt[15]));
+    return (p0 + p1) + (p2 + p3);
 }
 
 // out = MLP(a, lr) in every lane of the row; act[l] = this lane's activation in layer l
@@ -269,11 +287,30 @@ struct RowGrads {
     float mid[NL - 1][16];
 };
 
-template <int S>
-__device__ __forceinline__ void row_outer_step(float (&gm)[16], float h, float gd)
+// gm[s] += gd * rot_s(h), s = 0..15: the rotation as a DPP modifier of the FMA (see row_matvec)
+__device__ __forceinline__ void row_outer(float (&gm)[16], float h, float gd)
 {
-    gm[S] = fmaf(gd, row_rot<S>(h), gm[S]);
-    if constexpr (S + 1 < 16) row_outer_step<S + 1>(gm, h, gd);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_e32 %0, %16, %17\n\t"
+        "v_fmac_f32_dpp %1, %16, %17 row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %16, %17 row_ror:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %16, %17 row_ror:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %4, %16, %17 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %5, %16, %17 row_ror:5 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %6, %16, %17 row_ror:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %7, %16, %17 row_ror:7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %8, %16, %17 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %9, %16, %17 row_ror:9 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %10, %16, %17 row_ror:10 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %11, %16, %17 row_ror:11 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %12, %16, %17 row_ror:12 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %13, %16, %17 row_ror:13 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %14, %16, %17 row_ror:14 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %15, %16, %17 row_ror:15 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(gm[0]), "+v"(gm[1]), "+v"(gm[2]), "+v"(gm[3]), "+v"(gm[4]), "+v"(gm[5]), "+v"(gm[6]), "+v"(gm[7]),
+          "+v"(gm[8]), "+v"(gm[9]), "+v"(gm[10]), "+v"(gm[11]), "+v"(gm[12]), "+v"(gm[13]), "+v"(gm[14]), "+v"(gm[15])
+        : "v"(h), "v"(gd));
 }
 
 template <int NL>
@@ -287,7 +324,7 @@ __device__ __forceinline__ void row_mlp_grad_all(const RowWeights<NL>& W, const 
     for (int l = NL - 1; l >= 1; --l) {
         const float gd = G * d;
         acc.bias[l - 1] += gd;
-        row_outer_step<0>(acc.mid[l - 1], act[l - 1], gd);
+        row_outer(acc.mid[l - 1], act[l - 1], gd);
         d = row_matvec(W.tmid[l - 1], d, 0.0f) * fmaf(-act[l - 1], act[l - 1], 1.0f);
     }
     const float gd0 = G * d;
