@@ -4,9 +4,9 @@
 // is ~600 dependent FMAs per time step, and the reference's 1340 training sequences
 // (clipper_pot.py:58) fill 21 waves of a 1024-SIMD chip.  Here a sequence owns a ROW of 16 lanes,
 // lane j = hidden neuron j (widths 4 and 8 are zero-padded to 16):
-//   * a hidden layer is 16 FMAs per lane, the activations of the previous layer arriving by DPP
-//     row rotation (v_mov_dpp row_ror:s, folded into the FMA where the compiler can) -- no LDS,
-//     no weight traffic: lane j keeps its 16 weights per layer, ordered by rotation, in VGPRs;
+//   * a hidden layer is 16 FMAs per lane, the activations of the previous layer arriving as the
+//     DPP operand of the FMA itself (v_fmac_f32_dpp ... row_ror:s) -- no LDS, no weight traffic:
+//     lane j keeps its 16 weights per layer, ordered by rotation, in VGPRs;
 //   * the output layer is one product per lane and a 4-step row reduction;
 //   * a wave carries 4 sequences, so the same batch is 16x more waves with a ~6x shorter
 //     dependent chain per step.
