@@ -158,7 +158,9 @@ int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta,
                        int64_t B, int64_t T, int n_chunks, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Diode clipper with the tanh-MLP root of clipper_pot.py (csrc/wdf_mlp.h).  Replaces, per call,
+ * Diode clipper with the tanh-MLP root of clipper_pot.py (csrc/wdf_mlp_row.h: one 16-lane row per
+ * sequence, the default; csrc/wdf_mlp.h: one lane per sequence, flags = WDF_MLP_LANE_PER_SEQUENCE;
+ * same results to fp32 rounding).  Replaces, per call,
  * ClipperModel.forward's loop (clipper_pot.py:103-127): P1 = Parallel(Vs, C), model_in =
  * (P1.reflected(), log P1.R) (:119), P1.incident(-model.reflected()) (:121) with
  * DenseRootModel / DenseLayer (layers.py:38-39,72-82).
