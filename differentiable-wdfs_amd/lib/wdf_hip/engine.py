@@ -211,7 +211,7 @@ class MseStep:
         return self.backward(theta, x, target, r)
 
 
-def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=1, reps=3):
+def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=1, reps=7):
     """Refine a TpPlan by timing a few candidates on the actual batch (HIP events on the launch
     stream, a handful of launches each): the chunk counts, and the warm-up -- the planned W
     assumes a 10 V error at the chunk start; on real data the diodes clamp the state to ~1 V, so
@@ -222,13 +222,16 @@ def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1,
         return plan
 
     def timed(fn):
+        """median of `reps` single-call timings (a mean lets one slow launch flip the plan)"""
         fn()
         e0, e1 = binding.Event(), binding.Event()
-        e0.record()
+        ts = []
         for _ in range(reps):
+            e0.record()
             fn()
-        e1.record()
-        return e0.elapsed_ms(e1) / reps
+            e1.record()
+            ts.append(e0.elapsed_ms(e1))
+        return sorted(ts)[len(ts) // 2]
 
     best_f, best_b = plan.k_fwd, plan.k_bwd
     if plan.k_fwd > 1:
