@@ -182,13 +182,16 @@ def main():
         stepper.forward(theta, xk)
         if timed:
             binding.Event.bracket_next(ev[2], ev[3])
-        sse, gtheta = stepper.backward(theta, xk, target)
+        # one rank and plain MSE: the update rides in the sweep's last kernel; otherwise all-reduce, then update
+        fold = adam is not None and world == 1 and args.loss == "mse"
+        sse, gtheta = stepper.backward(theta, xk, target, adam=adam if fold else None)
         buf = stepper.out                              # [SSE, grads]: the kernels wrote it in place
         wdist.allreduce_sum_(buf)
         if adam is not None:
             if not loss_trace:
                 loss_trace.append(buf[0:1].clone())        # SSE of the very first step, for the report
-            adam.apply(theta, buf[1:])
+            if not fold:
+                adam.apply(theta, buf[1:])
         if timed:
             t_fwd.append(ev[0].elapsed_ms(ev[1]))
             t_bwd.append(ev[2].elapsed_ms(ev[3]))

@@ -176,13 +176,14 @@ template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
                    const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
                    float* part, double* ws, float* gz0, int64_t B, int64_t T, TpGeom g, bool pack, const float* gcoef,
-                   int64_t skip, hipStream_t s)
+                   int64_t skip, unsigned* ticket, float* gtheta, int accumulate, float* sse_out, wdf::AdamTail adam,
+                   hipStream_t s)
 {
     const int64_t Bh = pack ? (B + 1) / 2 : B;
     const dim3 grid((unsigned)((Bh + 63) / 64), (unsigned)g.K);
 #define WDF_BWD_TP(MSE_, V_)                                                                               \
     hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, TM, V4, MSE_, V_>), grid, dim3(64), 0, s, x, r, theta, \
-                       fs, n_up, n_down, zstash, gy, target, zT, gscale, part, B, Bh, T, g.L, gcoef, skip)
+                       fs, n_up, n_down, zstash, gy, target, zT, gscale, part, B, Bh, T, g.L, gcoef, skip, ticket)
     {
         EventBracket bracket(s);
         if (gcoef) {
@@ -195,7 +196,7 @@ void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs,
     }
 #undef WDF_BWD_TP
     hipLaunchKernelGGL(wdf::clipper_bwd_tp_combine_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, part, B,
-                       (int64_t)g.K, ws, gz0);
+                       (int64_t)g.K, ws, gz0, ticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam);
 }
 
 // ---- state-space dispatch ------------------------------------------------------------------
@@ -376,12 +377,13 @@ int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta, float
 static int bwd_tp_common(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
                          const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
                          void* ws, float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T,
-                         int n_chunks, int flags, void* stream, const float* gcoef = nullptr, int64_t skip = 0);
+                         int n_chunks, int flags, void* stream, const float* gcoef = nullptr, int64_t skip = 0,
+                         wdf::AdamTail adam = wdf::AdamTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr});
 
 size_t wdf_clipper_bwd_tp_ws_bytes(int64_t B, int n_chunks)
 {
     if (B <= 0 || n_chunks <= 0) return 0;
-    return (size_t)n_chunks * wdf::kTpOut * (size_t)B * sizeof(float) + wdf_clipper_bwd_ws_bytes(B);
+    return (size_t)n_chunks * wdf::kTpOut * (size_t)B * sizeof(float) + wdf_clipper_bwd_ws_bytes(B) + 16;   // + ticket
 }
 
 int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
@@ -406,7 +408,7 @@ int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta, f
 static int bwd_tp_common(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
                          const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
                          void* ws, float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T,
-                         int n_chunks, int flags, void* stream, const float* gcoef, int64_t skip)
+                         int n_chunks, int flags, void* stream, const float* gcoef, int64_t skip, wdf::AdamTail adam)
 {
     int rc = check_common(x, theta, n_up, n_down, B, T, flags);
     if (rc) return rc;
@@ -415,18 +417,28 @@ static int bwd_tp_common(const float* x, const float* r, const float* theta, flo
     if (n_chunks < 1) return fail(WDF_EINVAL, "n_chunks >= 1");
     const TpGeom g = tp_geom(T, n_chunks);
     double* wsd = (double*)ws;                                       // [nparts][4] doubles first (8-byte aligned)
-    float* part = (float*)((char*)ws + wdf_clipper_bwd_ws_bytes(B)); // then [K][8][B] floats
+    float* part = (float*)((char*)ws + wdf_clipper_bwd_ws_bytes(B)); // then [K][9][B] floats
+    unsigned* ticket = (unsigned*)((char*)ws + wdf_clipper_bwd_tp_ws_bytes(B, n_chunks) - 16);   // then the block ticket
     const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    // sweep, then combine -- whose last block also reduces, applies the chain rule and (optionally) Adam
     WDF_DISPATCH4(launch_bwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy, target,
                   zT, gscale, part, wsd, gz0, B, T, g, (flags & WDF_TP_PACK2) != 0 && B >= 2 && !gcoef, gcoef, skip,
-                  (hipStream_t)stream);
-    rc = check_launch("wdf_clipper_bwd_tp");
-    if (rc) return rc;
-    const int nparts = (int)((B + 63) / 64);
-    hipLaunchKernelGGL(wdf::clipper_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)wsd,
-                       nparts, theta, fs, r != nullptr ? 1 : 0, gtheta, accumulate, target ? sse : nullptr);
-    return check_launch("wdf_clipper_grad_reduce");
+                  ticket, gtheta, accumulate, target ? sse : nullptr, adam, (hipStream_t)stream);
+    return check_launch("wdf_clipper_bwd_tp");
+}
+
+int wdf_clipper_bwd_mse_tp_adam(const float* x, const float* r, float* theta, float fs, int n_up, int n_down,
+                                const float* zstash, const float* zT, const float* target, float gscale, void* ws,
+                                float* gtheta, float* sse, int64_t B, int64_t T, int n_chunks, int flags, float* m,
+                                float* v, int32_t* step, const float* lr, float beta1, float beta2, float eps,
+                                const float* lo, const float* hi, void* stream)
+{
+    if (!zT || !target) return fail(WDF_EINVAL, "null zT/target");
+    if (!m || !v || !step || !lr) return fail(WDF_EINVAL, "null m/v/step/lr");
+    const wdf::AdamTail adam{theta, m, v, step, lr, beta1, beta2, eps, lo, hi};
+    return bwd_tp_common(x, r, theta, fs, n_up, n_down, zstash, nullptr, target, zT, gscale, ws, gtheta, sse, nullptr, 0, B,
+                         T, n_chunks, flags, stream, nullptr, 0, adam);
 }
 
 int wdf_clipper_bwd_esr_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,

@@ -327,19 +327,39 @@ __global__ __launch_bounds__(64) void clipper_bwd_kernel(
 //   static R :  dIs = S_L/Is ; dV = S_V - S_L/V ; dR = Rp G1^2 (S_L - S_P (1-p)) ;
 //               dC = -2 fs Rp (S_P p + S_L)
 //   per-sample R : S_P = sum Rp_n (g_p p_n + g_L) ; dR = 0 ; dC = -2 fs S_P
-__global__ __launch_bounds__(256) void clipper_grad_reduce_kernel(
-    const double* __restrict__ ws, int nparts, const float* __restrict__ theta, float fs,
-    int dyn_r, float* __restrict__ gtheta, int accumulate, float* __restrict__ sse_out)
+__device__ __forceinline__ void grad_chain_rule(double SL, double SV, double SP, const float* __restrict__ theta, float fs,
+                                                int dyn_r, float* __restrict__ gtheta, int accumulate)
 {
-    __shared__ double sh[256][4];
+    const double Is = theta[0], V = theta[1], R = theta[2], C = theta[3];
+    const double G1 = 1.0 / R, G2 = C * (2.0 * (double)fs), Rp = 1.0 / (G1 + G2), p = G1 * Rp;
+    double g[4];
+    g[0] = SL / Is;
+    g[1] = SV - SL / V;
+    if (dyn_r) {
+        g[2] = 0.0;
+        g[3] = -2.0 * (double)fs * SP;
+    } else {
+        g[2] = Rp * G1 * G1 * (SL - SP * (1.0 - p));
+        g[3] = -2.0 * (double)fs * Rp * (SP * p + SL);
+    }
+    for (int k = 0; k < 4; ++k) gtheta[k] = (accumulate ? gtheta[k] : 0.0f) + (float)g[k];
+}
+
+// The whole block sums the per-wave partials in a fixed order (thread i takes parts i, i+NT, ...;
+// then a tree); thread 0 applies the chain rule.  NT = blockDim.x.
+template <int NT>
+__device__ __forceinline__ void grad_reduce_block(const double* __restrict__ ws, int nparts, const float* __restrict__ theta,
+                                                  float fs, int dyn_r, float* __restrict__ gtheta, int accumulate,
+                                                  float* __restrict__ sse_out, double (*sh)[4])
+{
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 256) {
+    for (int i = threadIdx.x; i < nparts; i += NT) {
         s0 += ws[(int64_t)i * 4 + 0]; s1 += ws[(int64_t)i * 4 + 1]; s2 += ws[(int64_t)i * 4 + 2];
         s3 += ws[(int64_t)i * 4 + 3];
     }
     sh[threadIdx.x][0] = s0; sh[threadIdx.x][1] = s1; sh[threadIdx.x][2] = s2; sh[threadIdx.x][3] = s3;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = NT / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
             sh[threadIdx.x][0] += sh[threadIdx.x + off][0];
             sh[threadIdx.x][1] += sh[threadIdx.x + off][1];
@@ -350,21 +370,16 @@ __global__ __launch_bounds__(256) void clipper_grad_reduce_kernel(
     }
     if (threadIdx.x == 0) {
         if (sse_out) *sse_out = (float)sh[0][3];
-        const double SL = sh[0][0], SV = sh[0][1], SP = sh[0][2];
-        const double Is = theta[0], V = theta[1], R = theta[2], C = theta[3];
-        const double G1 = 1.0 / R, G2 = C * (2.0 * (double)fs), Rp = 1.0 / (G1 + G2), p = G1 * Rp;
-        double g[4];
-        g[0] = SL / Is;
-        g[1] = SV - SL / V;
-        if (dyn_r) {
-            g[2] = 0.0;
-            g[3] = -2.0 * (double)fs * SP;
-        } else {
-            g[2] = Rp * G1 * G1 * (SL - SP * (1.0 - p));
-            g[3] = -2.0 * (double)fs * Rp * (SP * p + SL);
-        }
-        for (int k = 0; k < 4; ++k) gtheta[k] = (accumulate ? gtheta[k] : 0.0f) + (float)g[k];
+        grad_chain_rule(sh[0][0], sh[0][1], sh[0][2], theta, fs, dyn_r, gtheta, accumulate);
     }
+}
+
+__global__ __launch_bounds__(256) void clipper_grad_reduce_kernel(
+    const double* __restrict__ ws, int nparts, const float* __restrict__ theta, float fs,
+    int dyn_r, float* __restrict__ gtheta, int accumulate, float* __restrict__ sse_out)
+{
+    __shared__ double sh[256][4];
+    grad_reduce_block<256>(ws, nparts, theta, fs, dyn_r, gtheta, accumulate, sse_out, sh);
 }
 
 // ---- MSE + ESR loss (clipper_pot.py:146-156,177) ---------------------------------------------
@@ -829,9 +844,12 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, const float* __restrict__ zstash, const float* __restrict__ gy,
     const float* __restrict__ target, const float* __restrict__ zT, float gscale, float* __restrict__ out,
-    int64_t B, int64_t Bh, int64_t T, int64_t L, const float* __restrict__ gcoef, int64_t skip)
+    int64_t B, int64_t Bh, int64_t T, int64_t L, const float* __restrict__ gcoef, int64_t skip,
+    unsigned* __restrict__ ticket)
 {
     constexpr int N = VT<V>::N;
+    // the combine kernel (next launch on the stream) counts its finished blocks in *ticket: clear it here
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ticket = 0u;
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     float gb = 0.0f;
     if constexpr (MSE == 2) { gscale = gcoef[0]; gb = gcoef[1]; }
@@ -924,11 +942,22 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     }
 }
 
-// Walks the K chunks of each sequence from last to first; ws: double[gridDim.x][4] like
-// clipper_bwd_kernel so the same fixed-order reduce kernel finishes the job.
-__global__ __launch_bounds__(64) void clipper_bwd_tp_combine_kernel(const float* __restrict__ part, int64_t B,
-                                                                    int64_t K, double* __restrict__ ws,
-                                                                    float* __restrict__ gz0)
+// Optional optimizer step folded into the tail of the reverse sweep (single-GPU training loops:
+// with several ranks the gradient all-reduce sits in between and wdf_adam_step runs afterwards).
+struct AdamTail {
+    float* theta;                 // nullptr: no update
+    float* m; float* v; int32_t* step; const float* lr; float b1, b2, eps; const float* lo; const float* hi;
+};
+
+// Walks the K chunks of each sequence from last to first and writes ws: double[gridDim.x][4] per-wave
+// partials like clipper_bwd_kernel.  The LAST block to finish (device-scope ticket, cleared by the
+// sweep kernel before this launch) then does what used to be two more launches: the fixed-order
+// reduction + chain rule (grad_reduce_block) and, if asked, the Adam update of the four components.
+// Which block is last varies; what it computes does not (it re-reads all partials in index order).
+__global__ __launch_bounds__(64) void clipper_bwd_tp_combine_kernel(
+    const float* __restrict__ part, int64_t B, int64_t K, double* __restrict__ ws, float* __restrict__ gz0,
+    unsigned* __restrict__ ticket, const float* theta, float fs, int dyn_r, float* gtheta, int accumulate,
+    float* __restrict__ sse_out, AdamTail adam)
 {
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = b_raw < B;
@@ -961,9 +990,37 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_combine_kernel(const float*
     if (live && gz0) gz0[b] = (float)G;
     if (!live) { dL = dV = dP = dS = 0.0; }
     dL = wave_sum(dL); dV = wave_sum(dV); dP = wave_sum(dP); dS = wave_sum(dS);
+    __shared__ double sh[64][4];
+    __shared__ int is_last;
     if (threadIdx.x == 0) {
         double* o = ws + (int64_t)blockIdx.x * 4;
         o[0] = dL; o[1] = dV; o[2] = dP; o[3] = dS;     // slot 3: sum of squared errors (MSE mode)
+        __threadfence();                                 // the partial is visible device-wide before the ticket moves
+        is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();                                     // acquire: every other block's partial
+    const double* wsr = ws;                              // (read through a pointer without __restrict__'s no-alias promise)
+    grad_reduce_block<64>(wsr, (int)gridDim.x, theta, fs, dyn_r, gtheta, accumulate, sse_out, sh);
+    if (adam.theta != nullptr) {
+        __syncthreads();
+        const int i = threadIdx.x;
+        const int t = *adam.step + 1;
+        __syncthreads();
+        if (i == 0) *adam.step = t;
+        if (i < 4) {
+            const double c1 = 1.0 - pow((double)adam.b1, (double)t), c2 = 1.0 - pow((double)adam.b2, (double)t);
+            const float g = gtheta[i];
+            const float mi = adam.b1 * adam.m[i] + (1.0f - adam.b1) * g;
+            const float vi = adam.b2 * adam.v[i] + (1.0f - adam.b2) * g * g;
+            adam.m[i] = mi;
+            adam.v[i] = vi;
+            float th = adam.theta[i] - (float)((double)adam.lr[i] * sqrt(c2) / c1) * mi / (sqrtf(vi) + adam.eps);
+            if (adam.lo) th = fmaxf(th, adam.lo[i]);
+            if (adam.hi) th = fminf(th, adam.hi[i]);
+            adam.theta[i] = th;
+        }
     }
 }
 

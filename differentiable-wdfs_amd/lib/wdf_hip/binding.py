@@ -74,6 +74,9 @@ def lib():
     L.wdf_clipper_bwd_mse_tp.restype = ci
     L.wdf_clipper_bwd_mse_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, cf, vp, fp, fp, fp, ci, i64, i64, ci,
                                          ci, vp]
+    L.wdf_clipper_bwd_mse_tp_adam.restype = ci
+    L.wdf_clipper_bwd_mse_tp_adam.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, cf, vp, fp, fp, i64, i64, ci, ci,
+                                              fp, fp, vp, fp, cf, cf, cf, fp, fp, vp]
     L.wdf_loss_sums_ws_bytes.restype = i64
     L.wdf_loss_sums.restype = ci
     L.wdf_loss_sums.argtypes = [fp, fp, i64, i64, i64, vp, vp, vp]
@@ -138,7 +141,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_fwd", "wdf_clipper_bwd", "wdf_clipper_bwd_ws_bytes",
     "wdf_clipper_tp_chunks", "wdf_clipper_fwd_tp_ws_bytes", "wdf_clipper_fwd_tp",
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
-    "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
+    "wdf_clipper_bwd_mse_tp_adam", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
@@ -250,6 +253,31 @@ def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_d
                                   (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(), _stream())
     _check(rc, "wdf_clipper_fwd_tp")
     return y, zs, zT, status
+
+
+def clipper_bwd_mse_tp_adam(x, theta, fs, zstash, zT, target, gscale, n_chunks, opt, r=None, n_up=1, n_down=1,
+                            gtheta=None, sse=None, ws=None, time_major=False):
+    """The MSE-fused reverse sweep with the Adam update of theta (in place, `opt` = binding.Adam(4, ...))
+    folded into its last kernel; -> gtheta[4], sse[1]."""
+    require_gpu()
+    x, r, theta = _f32_dev(x, "x"), _f32_dev(r, "r"), _f32_dev(theta, "theta")
+    zstash, zT, target = _f32_dev(zstash, "zstash"), _f32_dev(zT, "zT"), _f32_dev(target, "target")
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+    if opt.n != 4 or theta.numel() != 4:
+        raise WdfHipError("clipper_bwd_mse_tp_adam: theta and the optimizer hold {Is, nVt, R, C}")
+    if ws is None:
+        ws = torch.empty((lib().wdf_clipper_bwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
+    if gtheta is None:
+        gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
+    if sse is None:
+        sse = torch.empty((1,), dtype=torch.float32, device=x.device)
+    rc = lib().wdf_clipper_bwd_mse_tp_adam(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(zstash),
+                                           _ptr(zT), _ptr(target), float(gscale), _ptr(ws), _ptr(gtheta), _ptr(sse), B, T,
+                                           int(n_chunks), (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(),
+                                           _ptr(opt.m), _ptr(opt.v), _ptr(opt.step), _ptr(opt.lr), opt.b1, opt.b2, opt.eps,
+                                           _ptr(opt.lo), _ptr(opt.hi), _stream())
+    _check(rc, "wdf_clipper_bwd_mse_tp_adam")
+    return gtheta, sse
 
 
 def loss_sums(y, target, skip, sums=None, ws=None):

@@ -188,8 +188,15 @@ class MseStep:
                                                            time_major=self.time_major)
         return self.y
 
-    def backward(self, theta, x, target, r=None):
+    def backward(self, theta, x, target, r=None, adam=None):
+        """adam: a binding.Adam(4, ...) to update theta in the sweep's own last kernel (single rank,
+        MSE loss); otherwise the caller applies its optimizer to self.gtheta afterwards."""
         kb = self.tp.k_bwd if self.tp is not None else 1
+        if adam is not None and self.loss_kind == "mse":
+            binding.clipper_bwd_mse_tp_adam(x, theta, self.fs, self.zs, self.zT, target, self.gscale, kb, adam, r=r,
+                                            n_up=self.n_up, n_down=self.n_down, gtheta=self.gtheta, sse=self.sse,
+                                            ws=self.ws_b, time_major=self.time_major)
+            return self.sse, self.gtheta
         if self.loss_kind == "mse+esr":
             # loss sums over this rank's y (one streaming pass), made global, then the two
             # coefficients of dL/dy = ga (y - t) + gb y; the sweep itself is the MSE one

@@ -133,6 +133,17 @@ int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta,
                            void* ws, float* gtheta, float* sse, float* gz0, int accumulate,
                            int64_t B, int64_t T, int n_chunks, int flags, void* stream);
 
+/* wdf_clipper_bwd_mse_tp followed, in the same launches, by the Adam update of theta = {Is, nVt, R, C}
+ * (wdf_adam_step's rule and arguments, n = 4): the whole tail of a single-GPU training step --
+ * combine, reduce, chain rule, update -- is the last block of one kernel.  With several ranks the
+ * gradient all-reduce sits between sweep and update: use wdf_clipper_bwd_mse_tp + wdf_adam_step. */
+int wdf_clipper_bwd_mse_tp_adam(const float* x, const float* r, float* theta, float fs, int n_up, int n_down,
+                                const float* zstash, const float* zT, const float* target, float gscale,
+                                void* ws, float* gtheta, float* sse, int64_t B, int64_t T, int n_chunks,
+                                int flags, float* m, float* v, int32_t* step, const float* lr,
+                                float beta1, float beta2, float eps, const float* lo, const float* hi,
+                                void* stream);
+
 /* MSE + ESR, the training loss of clipper_pot.py (:146-156 esr_loss, :177 loss_func, :232,248
  * evaluated past skip_samples with (outs, target) passed as (target_y, predicted_y), so the energy
  * is the model output's):   loss = S/n + sqrt(S / (E + eps) / n),  S = sum (y-t)^2, E = sum y^2.

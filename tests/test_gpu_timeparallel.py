@@ -327,3 +327,40 @@ def test_randomized_plans_and_circuits(wb):
         worst_y, worst_g, repaired = max(worst_y, ey), max(worst_g, eg), repaired + rep
     assert worst_y <= 2e-6 and worst_g <= 5e-4, (worst_y, worst_g)
     assert repaired >= 5
+
+
+def test_combine_tail_reduce_and_adam(wb):
+    """The reverse sweep's combine kernel finishes the job in its last block (device-scope ticket):
+    fixed-order reduction, chain rule and -- wdf_clipper_bwd_mse_tp_adam -- the Adam update.
+    * 200 repetitions give bit-identical gradients (which block is last varies, the result does not);
+    * they equal the sequential sweep's gradient to 2e-5;
+    * the folded update equals wdf_adam_step applied to that gradient, over 5 consecutive steps."""
+    from wdf_hip import workload
+    B, T, K = 8192, 512, 8
+    x, th = setup(B, T, seed=41)
+    tgt, _, _ = wb.clipper_fwd(x, dev(workload.target_theta()), FS, want_stash=False)
+    y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
+    gscale = 2.0 / y.numel()
+    ws = torch.empty((wb.lib().wdf_clipper_bwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda").fill_(0xAB)
+    g0, sse0 = wb.clipper_bwd_mse_tp(x, th, FS, zs, zT, tgt, gscale, K, ws=ws)
+    g0, sse0 = g0.clone(), sse0.clone()
+    for _ in range(200):
+        g, sse = wb.clipper_bwd_mse_tp(x, th, FS, zs, zT, tgt, gscale, K, ws=ws)
+        assert torch.equal(g, g0) and torch.equal(sse, sse0)
+    g_seq, _ = wb.clipper_bwd(x, th, FS, zs, (gscale * (y - tgt)).contiguous())
+    assert torch.allclose(g0, g_seq, rtol=2e-5, atol=0)
+    assert abs(float(sse0) - float(((y - tgt) ** 2).sum())) <= 1e-5 * float(sse0)
+    # folded Adam vs separate kernel, several steps (theta moves, so each step is a fresh problem)
+    lr = [1e-3 * float(v) for v in workload.clipper_theta()]
+    lo, hi = [1e-15, 1e-3, 180.0, 1e-13], [1e-3, 1.0, 1.0e6, 1.0]
+    th_a, th_b = th.clone(), th.clone()
+    opt_a, opt_b = wb.Adam(4, lr, lo=lo, hi=hi), wb.Adam(4, lr, lo=lo, hi=hi)
+    for _ in range(5):
+        _, zs_a, zT_a = wb.clipper_fwd(x, th_a, FS, want_zT=True)
+        wb.clipper_bwd_mse_tp_adam(x, th_a, FS, zs_a, zT_a, tgt, gscale, K, opt_a, ws=ws)
+        _, zs_b, zT_b = wb.clipper_fwd(x, th_b, FS, want_zT=True)
+        g_b, _ = wb.clipper_bwd_mse_tp(x, th_b, FS, zs_b, zT_b, tgt, gscale, K)
+        opt_b.apply(th_b, g_b)
+    assert int(opt_a.step.cpu()[0]) == 5 and int(opt_b.step.cpu()[0]) == 5
+    assert torch.equal(th_a, th_b), (th_a, th_b)
+    assert not torch.equal(th_a, th)
