@@ -37,7 +37,7 @@ tf.get_logger().setLevel("WARN")
 
 def voltage(wdf):
     '''Voltage across a WDF element: (a + b)/2  (tf_wdf.py:8-10).'''
-    return (wdf.a + wdf.b) * tf.constant(0.5)
+    return (wdf.a + wdf.b) * 0.5
 
 
 class _Element(tf.Module):
@@ -74,7 +74,7 @@ class IdealVoltageSource(_Source, _Element):
     '''Ideal voltage source ROOT: b = -a + 2 Vs  (tf_wdf.py:13-28).'''
 
     def reflected(self):
-        return self._emit(-self.a + tf.constant(2.0) * self.Vs)
+        return self._emit(-self.a + 2.0 * self.Vs)
 
 
 class ResistiveVoltageSource(_Source, _Element):
@@ -123,7 +123,12 @@ class Capacitor(_Element):
         self.z = tf.Variable(initial_value=0.0, name="state", trainable=False)
 
     def calc_impedance(self):
-        self.R = tf.math.reciprocal(self.C * (2.0 * self.FS))
+        # clipper_pot.py:117 calls this every time step with an unchanged C: the same tensor (and autograd
+        # node) is handed back until the variable is written again
+        key = (id(self.C), self.C._version, self.FS)
+        if getattr(self, "_R_key", None) != key:
+            self._R_key, self._R_of_C = key, tf.math.reciprocal(self.C * (2.0 * self.FS))
+        self.R = self._R_of_C
 
     def reset(self):
         self.z = tf.zeros(1)
