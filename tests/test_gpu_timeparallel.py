@@ -364,3 +364,27 @@ def test_combine_tail_reduce_and_adam(wb):
     assert int(opt_a.step.cpu()[0]) == 5 and int(opt_b.step.cpu()[0]) == 5
     assert torch.equal(th_a, th_b), (th_a, th_b)
     assert not torch.equal(th_a, th)
+
+
+def test_fused_mse_esr_with_per_sample_resistance(wb):
+    """The ESR-mode sweep with the per-sample resistance channel of clipper_pot.py:116 against autograd
+    through the plain kernels (gradients w.r.t. Is, nVt, C; R has none when it is streamed)."""
+    from wdf_hip import engine, workload
+    B, T, skip = 70, 1024, 50
+    x, th = setup(B, T, seed=33)
+    r = dev(workload.pot_resistance_batch(B, T))
+    tgt, _, _ = wb.clipper_fwd(x, dev(workload.target_theta()), FS, r=r, want_stash=False)
+    tp = engine.TpPlan(4, 512, 1.0e-6, 4)
+    step = engine.MseStep(B, T, FS, tp, x.device, loss="mse+esr", skip=skip)
+    _, g = step.step(th, x, tgt, r=r)
+    assert wb.tp_status(step.status)["n_bad"] == 0
+    thr = th.clone().requires_grad_(True)
+    y = engine.clipper(thr, x, FS, r=r)
+    o, t = y[skip:], tgt[skip:]
+    S = ((o - t) ** 2).sum()
+    loss = S / o.numel() + torch.sqrt(S / ((o ** 2).sum() + float(np.finfo(float).eps)) / o.numel())
+    loss.backward()
+    assert abs(float(step.loss[2]) - float(loss)) <= 2e-6 * float(loss)
+    assert float(g[2]) == 0.0 and float(thr.grad[2]) == 0.0
+    keep = torch.tensor([0, 1, 3], device="cuda")
+    assert torch.allclose(g[keep], thr.grad[keep], rtol=1e-4, atol=0), (g, thr.grad)
