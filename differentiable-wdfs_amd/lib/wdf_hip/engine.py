@@ -218,7 +218,7 @@ class MseStep:
         return self.backward(theta, x, target, r)
 
 
-def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=1, reps=7):
+def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=1, reps=7, r=None):
     """Refine a TpPlan by timing a few candidates on the actual batch (HIP events on the launch
     stream, a handful of launches each): the chunk counts, and the warm-up -- the planned W
     assumes a 10 V error at the chunk start; on real data the diodes clamp the state to ~1 V, so
@@ -242,26 +242,30 @@ def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1,
 
     best_f, best_b = plan.k_fwd, plan.k_bwd
     if plan.k_fwd > 1:
-        cands = sorted({k for k in (plan.k_fwd // 2, plan.k_fwd, plan.k_fwd * 2) if 2 <= k <= T // max(plan.warmup, 64)})
+        cands = sorted({k for k in (plan.k_fwd // 2, plan.k_fwd, plan.k_fwd * 2) if 2 <= k <= T // max(plan.warmup // 2, 64)})
         times = {}
         for k in cands:
             st = MseStep(B, T, fs, plan._replace(k_fwd=k), x.device, n_up=n_up, n_down=n_down, time_major=time_major)
-            times[k] = timed(lambda: st.forward(theta, x))
+            times[k] = timed(lambda: st.forward(theta, x, r))
         best_f = _pick(times, plan.k_fwd)
-        if plan.warmup >= 96:
+        t_now = times[best_f]
+        for _ in range(8):                                  # shorter warm-ups, 32 steps at a time, while they pay
+            if plan.warmup < 96:
+                break
             shorter = plan._replace(k_fwd=best_f, warmup=plan.warmup - 32)
             st = MseStep(B, T, fs, shorter, x.device, n_up=n_up, n_down=n_down, time_major=time_major)
-            t_short = timed(lambda: st.forward(theta, x))
+            t_short = timed(lambda: st.forward(theta, x, r))
             stat = binding.tp_status(st.status)
-            if stat["n_bad"] == 0 and stat["max_miss"] <= plan.tol / 8.0 and t_short < 0.98 * times[best_f]:
-                plan = shorter
+            if not (stat["n_bad"] == 0 and stat["max_miss"] <= plan.tol / 8.0 and t_short < 0.98 * t_now):
+                break
+            plan, t_now = shorter, t_short
     st = MseStep(B, T, fs, plan._replace(k_fwd=best_f), x.device, n_up=n_up, n_down=n_down, time_major=time_major)
-    st.forward(theta, x)
+    st.forward(theta, x, r)
     times = {}
     for k in sorted({k for k in (plan.k_bwd // 2, plan.k_bwd, plan.k_bwd * 2) if 1 <= k <= max(1, T // 32)}):
         st.tp = plan._replace(k_fwd=best_f, k_bwd=k)
         st.ws_b = torch.empty((binding.lib().wdf_clipper_bwd_tp_ws_bytes(B, k),), dtype=torch.uint8, device=x.device)
-        times[k] = timed(lambda: st.backward(theta, x, target))
+        times[k] = timed(lambda: st.backward(theta, x, target, r))
     # reverse sweep: among the candidates within 2 % of the fastest take the fewest chunks (less
     # combine work and workspace; also keeps the choice stable from run to run)
     t_best = min(times.values())
