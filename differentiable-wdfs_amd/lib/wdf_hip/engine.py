@@ -273,6 +273,29 @@ def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1,
     return plan._replace(k_fwd=best_f, k_bwd=best_b)
 
 
+_TUNED = {}      # (B, T, n_up, n_down, per-sample R?, R and C to 2 digits) -> TpPlan
+
+
+def tuned_plan(theta, x, r, fs, R_plan, C, n_up=1, n_down=1, min_samples=1 << 22):
+    """plan_time_parallel, refined once per (shape, circuit) by autotune_time_parallel when the batch
+    is large enough for the ~0.1 s of set-up to pay (>= 4 M samples); later calls with the same
+    shape and (to two digits) the same R and C reuse the result.  Training moves R and C slowly and
+    every forward is still verified, so a plan tuned at the first epoch stays valid."""
+    B, T = x.shape
+    plan = plan_time_parallel(B, T, R_plan, C, fs)
+    if B * T < min_samples or plan.k_fwd < 2:
+        return plan
+    key = (B, T, n_up, n_down, r is not None, f"{R_plan:.1e}", f"{C:.1e}")
+    if key not in _TUNED:
+        if len(_TUNED) > 32:
+            _TUNED.clear()
+        with torch.no_grad():
+            zero_target = torch.zeros((T, B), dtype=torch.float32, device=x.device)
+            _TUNED[key] = autotune_time_parallel(theta.detach(), x, zero_target, fs, plan, n_up=n_up, n_down=n_down,
+                                                 reps=5, r=r)
+    return _TUNED[key]
+
+
 def _pick(times, planned):
     """The fastest candidate, but the planned one unless another is at least 3 % faster (timing
     noise should not flip the plan between runs)."""

@@ -234,6 +234,6 @@ class Circuit:
             # component values live on the host (tiny CPU variables): planning costs no sync
             # per-sample R: the warm-up must outlast the slowest (largest-R) sequence in the batch
             R_plan = float(parts[2]) if r is None else engine.resistance_max(r)
-            tp = engine.plan_time_parallel(xv.shape[0], xv.shape[1], R_plan, float(cap.C), float(cap.FS))
+            tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, float(cap.C), n_up=dp.N_up, n_down=dp.N_down)
         y = engine.clipper(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp)
         return y.as_subclass(tf.Tensor)
