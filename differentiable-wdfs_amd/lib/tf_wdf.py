@@ -11,7 +11,7 @@ New surface (not in the reference):
   DiodePair(next, Is, Vt=25.85e-3, nDiodes=1, N_up=1, N_down=1, trainable=False)
       analytic Wright-omega diode-pair root (formula diode_pretraining.py:39-60, element
       protocol Toms917DiodePair.h:21-59) with trainable Is and nVt;
-  Circuit(top, root, probe) / run(...)
+  Circuit(top, root, probe) / run(...) / Circuit.mse(x, target)
       the fast tier: lowers the WHOLE per-sample loop the scripts own (lpf.py:39-46,
       clipper_pot.py:113-124) to one HIP kernel launch, and its tape.gradient to one reverse
       sweep.
@@ -123,12 +123,7 @@ class Capacitor(_Element):
         self.z = tf.Variable(initial_value=0.0, name="state", trainable=False)
 
     def calc_impedance(self):
-        # clipper_pot.py:117 calls this every time step with an unchanged C: the same tensor (and autograd
-        # node) is handed back until the variable is written again
-        key = (id(self.C), self.C._version, self.FS)
-        if getattr(self, "_R_key", None) != key:
-            self._R_key, self._R_of_C = key, tf.math.reciprocal(self.C * (2.0 * self.FS))
-        self.R = self._R_of_C
+        self.R = tf.math.reciprocal(self.C * (2.0 * self.FS))
 
     def reset(self):
         self.z = tf.zeros(1)

@@ -273,6 +273,42 @@ def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1,
     return plan._replace(k_fwd=best_f, k_bwd=best_b)
 
 
+class _ClipperMseFn(torch.autograd.Function):
+    """mean((clipper(theta, x) - target)^2) with the loss inside the reverse sweep: forward runs the
+    forward kernel AND the MSE-fused sweep (one stepper per shape, buffers reused), backward only
+    scales the stored gradient -- no y-sized loss temporaries, no dL/dy array."""
+    _steppers = {}
+
+    @staticmethod
+    def forward(ctx, theta, x, r, target, fs, n_up, n_down, tp):
+        B, T = x.shape
+        key = (B, T, float(fs), n_up, n_down, tp, x.device)
+        st = _ClipperMseFn._steppers.get(key)
+        if st is None:
+            if len(_ClipperMseFn._steppers) > 8:
+                _ClipperMseFn._steppers.clear()
+            st = _ClipperMseFn._steppers[key] = MseStep(B, T, fs, tp, x.device, n_up=n_up, n_down=n_down)
+        th = theta.detach().contiguous()
+        st.forward(th, x, r)
+        sse, g = st.backward(th, x, target, r)
+        LAST_TP_STATUS["status"] = st.status
+        ctx.save_for_backward(g.clone())
+        return sse[0] / float(B * T)
+
+    @staticmethod
+    def backward(ctx, gl):
+        (g,) = ctx.saved_tensors
+        return gl * g, None, None, None, None, None, None, None
+
+
+def clipper_mse(theta, x, target, fs, r=None, n_up=1, n_down=1, tp=None):
+    """Scalar mean-squared error of the clipper output against target [T,B], differentiable w.r.t.
+    theta = {Is, nVt, R, C} (float32[4] on the device); the fused path of lpf.py:87-90-style loops."""
+    if tp is None:
+        tp = TpPlan(1, 32, 1.0e-6, 1)
+    return _ClipperMseFn.apply(theta, x, r, target, float(fs), int(n_up), int(n_down), tp)
+
+
 _TUNED = {}      # (B, T, n_up, n_down, per-sample R?, R and C to 2 digits) -> TpPlan
 
 

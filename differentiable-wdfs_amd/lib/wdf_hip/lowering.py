@@ -133,6 +133,32 @@ class Circuit:
             raise ValueError("the circuit has no voltage source")
 
     # -- topology tests
+    def mse(self, x, target):
+        """tf.reduce_mean(tf.square(self(x) - target)) as ONE fused evaluation where the kernels allow
+        it (diode-pair clipper: forward kernel + MSE-fused reverse sweep, the gradient of every
+        trainable component ready when tape.gradient asks); any other circuit takes the plain path.
+        target: [T,B] like the output."""
+        binding.require_gpu()
+        if not (self._is_clipper() and self.root_kind == "DiodePair" and not self.force_generic):
+            y = self(x)
+            return tf.reduce_mean(tf.square(y - target))
+        from . import engine
+        x = torch.as_tensor(x).as_subclass(torch.Tensor)
+        x = (x if x.is_cuda else x.cuda()).float()
+        if x.dim() == 2:
+            x = x.unsqueeze(-1)
+        dp, vs, cap = self.root, self.top.P1, self.top.P2
+        parts = [dp.Is, dp.nVt, vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)), cap.C]
+        theta = torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(x.device)
+        xv, r = engine.split_channels(x, self.per_sample_R is not None)
+        tgt = torch.as_tensor(target).as_subclass(torch.Tensor).to(x.device).float().reshape(xv.shape[1], xv.shape[0]).contiguous()
+        R_plan = float(parts[2]) if r is None else engine.resistance_max(r)
+        tp = self.time_parallel
+        if tp == "auto":
+            tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, float(cap.C), n_up=dp.N_up, n_down=dp.N_down)
+        loss = engine.clipper_mse(theta, xv, tgt, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp)
+        return loss.as_subclass(tf.Tensor)
+
     def _is_clipper(self):
         t = self.top
         return (_kind(t) == "Parallel" and _kind(t.P1) == "ResistiveVoltageSource" and _kind(t.P2) == "Capacitor"

@@ -311,3 +311,50 @@ def test_dataset_shaped_batch_config_c4(wdf, oracle):
     got = np.array([float(v) for v in g2])
     assert rel(got, gref[[0, 1, 3]]) < 3e-3
     assert all(np.isfinite(float(v)) for v in g)
+
+
+def test_circuit_mse_fused_equals_plain_path(wdf):
+    """Circuit.mse(x, target): for the diode-pair clipper the loss lives inside the reverse sweep
+    (engine.clipper_mse); it must give tf.reduce_mean(tf.square(circ(x) - target)) and the same
+    tape.gradient (5e-5: summation order), with and without the per-sample resistance channel; any
+    other circuit silently takes the plain path."""
+    from wdf_hip import workload
+    tf = wdf.tf
+    theta = workload.clipper_theta()
+    B, T = 200, 2048
+    x = workload.sweep_batch(B, T, seed=5)
+    r = workload.pot_resistance_batch(B, T)
+    for with_r in (False, True):
+        Vs = wdf.ResistiveVoltageSource(float(theta[2]), trainable=not with_r)
+        Cap = wdf.Capacitor(float(theta[3]), FS, trainable=True)
+        P1 = wdf.Parallel(Vs, Cap)
+        dp = wdf.DiodePair(P1, float(theta[0]), Vt=float(theta[1]), trainable=True)
+        circ = wdf.Circuit(P1, dp, Cap, per_sample_R=Vs if with_r else None)
+        xin = cuda(np.stack([x, r], axis=-1)) if with_r else cuda(x)
+        tgt = (circ(xin) * 0.9 + 0.01).as_subclass(torch.Tensor).detach()
+        vs = [dp.Is, dp.nVt, Cap.C] + ([] if with_r else [Vs.R])
+        with tf.GradientTape() as tape:
+            l_plain = tf.reduce_mean(tf.square(circ(xin) - tgt))
+        g_plain = [float(v) for v in tape.gradient(l_plain, vs)]
+        with tf.GradientTape() as tape:
+            l_fused = circ.mse(xin, tgt)
+        g_fused = [float(v) for v in tape.gradient(l_fused, vs)]
+        assert abs(float(l_fused) - float(l_plain)) <= 2e-6 * float(l_plain)
+        assert np.allclose(g_fused, g_plain, rtol=5e-5, atol=0), (g_fused, g_plain)
+        assert all(np.isfinite(g_fused)) and any(abs(v) > 0 for v in g_fused)
+    # a circuit without the fused kernels: the RC low-pass of lpf.py
+    R1 = wdf.Resistor(1000.0, True)
+    C1 = wdf.Capacitor(1.0e-6, FS, True)
+    S1 = wdf.Series(R1, C1)
+    I1 = wdf.Inverter(S1)
+    Vin = wdf.IdealVoltageSource()
+    lp = wdf.Circuit(I1, Vin, C1)
+    xs = cuda(x[:4, :256])
+    t2 = lp(xs).as_subclass(torch.Tensor).detach() * 0.5
+    with tf.GradientTape() as tape:
+        l1 = lp.mse(xs, t2)
+    g1 = [float(v) for v in tape.gradient(l1, [R1.R, C1.C])]
+    with tf.GradientTape() as tape:
+        l2 = tf.reduce_mean(tf.square(lp(xs) - t2))
+    g2 = [float(v) for v in tape.gradient(l2, [R1.R, C1.C])]
+    assert float(l1) == float(l2) and g1 == g2
