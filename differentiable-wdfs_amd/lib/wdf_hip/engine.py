@@ -74,19 +74,30 @@ def resistance_max(r):
 _SPLIT_CACHE = {}      # id(x) -> (weakref to x, version, xv, r)
 
 
-def split_channels(x, with_r):
+def split_channels(x, with_r, time_major=False, anchor=None):
     """The kernels' contiguous views of a [B,T,2] script input (Vin, R: clipper_pot.py:68-70):
-    xv = x[..., 0] and r = x[..., 1].  Cached per input tensor object and version -- the reference
-    feeds the same train_X every epoch (clipper_pot.py:245-248), so the two de-interleaving copies
-    (and the planner's look at max R) happen once, not per forward."""
+    xv = x[..., 0] and r = x[..., 1], as [B,T] or -- time_major -- as [T,B].  Cached per input tensor
+    object, version and layout: the reference feeds the same train_X every epoch
+    (clipper_pot.py:245-248), so the de-interleaving (and transposing) copies and the planner's look
+    at max R happen once, not per forward."""
     xt = x.as_subclass(torch.Tensor)
-    hit = _SPLIT_CACHE.get(id(x))
-    if hit is None or hit[0]() is not x or hit[1] != xt._version or (with_r and hit[3] is None):
+    if xt.dim() == 2:
+        xt = xt.unsqueeze(-1)
+    # the cache hangs on the object the CALLER holds (`anchor`: the tensor as the script passed it),
+    # not on the normalised views made from it, which are new objects every call
+    anchor = x if anchor is None else anchor
+    key = (id(anchor), bool(time_major))
+    hit = _SPLIT_CACHE.get(key)
+    ver = getattr(anchor, "_version", None)
+    if hit is None or hit[0]() is not anchor or hit[1] != ver or (with_r and hit[3] is None):
         if len(_SPLIT_CACHE) > 64:
             for k in [k for k, v in _SPLIT_CACHE.items() if v[0]() is None]:
                 del _SPLIT_CACHE[k]
-        hit = (weakref.ref(x), xt._version, xt[:, :, 0].contiguous(), xt[:, :, 1].contiguous() if with_r else None)
-        _SPLIT_CACHE[id(x)] = hit
+        def chan(c):
+            v = xt[:, :, c]
+            return v.t().contiguous() if time_major else v.contiguous()
+        hit = (weakref.ref(anchor), ver, chan(0), chan(1) if with_r else None)
+        _SPLIT_CACHE[key] = hit
     return hit[2], (hit[3] if with_r else None)
 
 
@@ -280,14 +291,15 @@ class _ClipperMseFn(torch.autograd.Function):
     _steppers = {}
 
     @staticmethod
-    def forward(ctx, theta, x, r, target, fs, n_up, n_down, tp):
-        B, T = x.shape
-        key = (B, T, float(fs), n_up, n_down, tp, x.device)
+    def forward(ctx, theta, x, r, target, fs, n_up, n_down, tp, time_major):
+        B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+        key = (B, T, float(fs), n_up, n_down, tp, x.device, time_major)
         st = _ClipperMseFn._steppers.get(key)
         if st is None:
             if len(_ClipperMseFn._steppers) > 8:
                 _ClipperMseFn._steppers.clear()
-            st = _ClipperMseFn._steppers[key] = MseStep(B, T, fs, tp, x.device, n_up=n_up, n_down=n_down)
+            st = _ClipperMseFn._steppers[key] = MseStep(B, T, fs, tp, x.device, n_up=n_up, n_down=n_down,
+                                                        time_major=time_major)
         th = theta.detach().contiguous()
         st.forward(th, x, r)
         sse, g = st.backward(th, x, target, r)
@@ -298,37 +310,38 @@ class _ClipperMseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         (g,) = ctx.saved_tensors
-        return gl * g, None, None, None, None, None, None, None
+        return gl * g, None, None, None, None, None, None, None, None
 
 
-def clipper_mse(theta, x, target, fs, r=None, n_up=1, n_down=1, tp=None):
+def clipper_mse(theta, x, target, fs, r=None, n_up=1, n_down=1, tp=None, time_major=False):
     """Scalar mean-squared error of the clipper output against target [T,B], differentiable w.r.t.
-    theta = {Is, nVt, R, C} (float32[4] on the device); the fused path of lpf.py:87-90-style loops."""
+    theta = {Is, nVt, R, C} (float32[4] on the device); the fused path of lpf.py:87-90-style loops.
+    time_major: x (and r) are [T,B]."""
     if tp is None:
         tp = TpPlan(1, 32, 1.0e-6, 1)
-    return _ClipperMseFn.apply(theta, x, r, target, float(fs), int(n_up), int(n_down), tp)
+    return _ClipperMseFn.apply(theta, x, r, target, float(fs), int(n_up), int(n_down), tp, bool(time_major))
 
 
 _TUNED = {}      # (B, T, n_up, n_down, per-sample R?, R and C to 2 digits) -> TpPlan
 
 
-def tuned_plan(theta, x, r, fs, R_plan, C, n_up=1, n_down=1, min_samples=1 << 22):
+def tuned_plan(theta, x, r, fs, R_plan, C, n_up=1, n_down=1, min_samples=1 << 22, time_major=False):
     """plan_time_parallel, refined once per (shape, circuit) by autotune_time_parallel when the batch
     is large enough for the ~0.1 s of set-up to pay (>= 4 M samples); later calls with the same
     shape and (to two digits) the same R and C reuse the result.  Training moves R and C slowly and
     every forward is still verified, so a plan tuned at the first epoch stays valid."""
-    B, T = x.shape
-    plan = plan_time_parallel(B, T, R_plan, C, fs)
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+    plan = plan_time_parallel(B, T, R_plan, C, fs, time_major=time_major)
     if B * T < min_samples or plan.k_fwd < 2:
         return plan
-    key = (B, T, n_up, n_down, r is not None, f"{R_plan:.1e}", f"{C:.1e}")
+    key = (B, T, n_up, n_down, r is not None, f"{R_plan:.1e}", f"{C:.1e}", time_major)
     if key not in _TUNED:
         if len(_TUNED) > 32:
             _TUNED.clear()
         with torch.no_grad():
             zero_target = torch.zeros((T, B), dtype=torch.float32, device=x.device)
-            _TUNED[key] = autotune_time_parallel(theta.detach(), x, zero_target, fs, plan, n_up=n_up, n_down=n_down,
-                                                 reps=5, r=r)
+            _TUNED[key] = autotune_time_parallel(theta.detach(), x, zero_target, fs, plan, time_major=time_major,
+                                                 n_up=n_up, n_down=n_down, reps=5, r=r)
     return _TUNED[key]
 
 

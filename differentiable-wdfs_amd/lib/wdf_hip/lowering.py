@@ -143,20 +143,22 @@ class Circuit:
             y = self(x)
             return tf.reduce_mean(tf.square(y - target))
         from . import engine
+        anchor = x if isinstance(x, torch.Tensor) else None
         x = torch.as_tensor(x).as_subclass(torch.Tensor)
         x = (x if x.is_cuda else x.cuda()).float()
-        if x.dim() == 2:
-            x = x.unsqueeze(-1)
         dp, vs, cap = self.root, self.top.P1, self.top.P2
         parts = [dp.Is, dp.nVt, vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)), cap.C]
         theta = torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(x.device)
-        xv, r = engine.split_channels(x, self.per_sample_R is not None)
-        tgt = torch.as_tensor(target).as_subclass(torch.Tensor).to(x.device).float().reshape(xv.shape[1], xv.shape[0]).contiguous()
+        # the sweep reads its inputs time-major: the transposed copy is made once per input tensor
+        xv, r = engine.split_channels(x, self.per_sample_R is not None, time_major=True, anchor=anchor)
+        tgt = torch.as_tensor(target).as_subclass(torch.Tensor).to(x.device).float().reshape(xv.shape).contiguous()
         R_plan = float(parts[2]) if r is None else engine.resistance_max(r)
         tp = self.time_parallel
         if tp == "auto":
-            tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, float(cap.C), n_up=dp.N_up, n_down=dp.N_down)
-        loss = engine.clipper_mse(theta, xv, tgt, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp)
+            tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, float(cap.C), n_up=dp.N_up, n_down=dp.N_down,
+                                   time_major=True)
+        loss = engine.clipper_mse(theta, xv, tgt, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp,
+                                  time_major=True)
         return loss.as_subclass(tf.Tensor)
 
     def _is_clipper(self):
@@ -208,6 +210,7 @@ class Circuit:
         """x: [B,T] or [B,T,n_in] float32 CUDA tensor (batch-major, the reference's
         input[:, i, c] layout).  Returns y [T,B] (and the final capacitor states [ns,B])."""
         binding.require_gpu()
+        self._anchor = x if isinstance(x, torch.Tensor) else None      # the caller's object: cache key for its copies
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(x)
         x = x.as_subclass(torch.Tensor)
@@ -249,7 +252,7 @@ class Circuit:
         dev = x.device
         parts = [dp.Is, dp.nVt, vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)), cap.C]
         theta = torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(dev)
-        xv, r = engine.split_channels(x, self.per_sample_R is not None)
+        xv, r = engine.split_channels(x, self.per_sample_R is not None, anchor=getattr(self, "_anchor", None))
         if z0 is not None or return_state:
             z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(-1).contiguous()
             y, zT = engine.clipper_stateful(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, z0=z0t)

@@ -168,7 +168,7 @@ def run_clipper_mlp(circ, x, z0, return_state):
     theta2 = torch.stack([Rv.as_subclass(torch.Tensor).float().reshape(()),
                           cap.C.as_subclass(torch.Tensor).float().reshape(())]).to(dev)
     w = flat_weights(dense).float().to(dev)
-    xv, r = engine.split_channels(x, circ.per_sample_R is not None)
+    xv, r = engine.split_channels(x, circ.per_sample_R is not None, anchor=getattr(circ, "_anchor", None))
     z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(-1).contiguous()
     y, zT = clipper_mlp(theta2, w, xv, r, z0t, float(cap.FS), hidden, n_tanh, float(cap.C), R_static=Rv,
                         time_parallel=getattr(circ, "time_parallel", None))
