@@ -125,6 +125,9 @@ def main():
                     help="pin the time-parallel plan (forward chunks, warm-up steps, reverse chunks) instead of "
                          "autotuning it; used to profile one configuration across several rocprofv3 passes")
     ap.add_argument("--sequential", action="store_true", help="one lane per sequence, no time-parallel chunks")
+    ap.add_argument("--cold-forward", action="store_true",
+                    help="every forward warms its chunks up from z = 0 (no state kept between steps) instead of "
+                         "starting them from the previous step's snapshots")
     ap.add_argument("--x-batch-major", action="store_true",
                     help="hand the kernels x as [B,T] (the reference scripts' layout) instead of the engine's "
                          "resident time-major copy")
@@ -161,7 +164,7 @@ def main():
     elif tp is not None:                    # part of the untimed set-up: pick chunk counts on this box
         tp = engine.autotune_time_parallel(theta, xk, target, fs, tp, time_major=tm)
     stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global, time_major=tm, loss=args.loss, skip=skip,
-                             sums_allreduce=wdist.allreduce_sum_ if world > 1 else None)
+                             sums_allreduce=wdist.allreduce_sum_ if world > 1 else None, warm=not args.cold_forward)
 
     # the update that closes a training step (lpf.py:93-94: one Adam per component, its learning
     # rate scaled to the component; tf_wdf.py:74,104 clip constraints), on the device
@@ -252,7 +255,8 @@ def main():
                                    "region)" if tm else "batch-major [B,T] as the reference scripts hold it",
                        "time_parallel": None if tp is None else
                        {"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup, "verify_tol": tp.tol,
-                        "bwd_chunks": tp.k_bwd, "verify_status": tp_stat}},
+                        "bwd_chunks": tp.k_bwd, "verify_status": tp_stat,
+                        "warm_start": None if stepper.warm is None else stepper.warm.info()}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,

@@ -1,0 +1,334 @@
+// wdf_capi_clipper.hip -- C ABI part 2 of 4: the diode-clipper sequence kernels (sequential and
+// time-parallel forward / reverse sweep).  Argument checking, template dispatch and launches.
+// 
+#include "wdf_capi_common.h"
+#include "wdf_clipper.h"
+using namespace wdfcapi;
+
+namespace {
+
+template <bool DYN_R, bool SYM, bool TM, bool V4>
+void launch_fwd(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
+                float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int general, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    EventBracket bracket(s);
+    if (zstash)
+        hipLaunchKernelGGL((wdf::clipper_fwd_kernel<DYN_R, SYM, TM, V4, true>), dim3(grid), dim3(64), 0, s, x, r, theta,
+                           fs, n_up, n_down, y, zstash, z0, zT, B, T, general);
+    else
+        hipLaunchKernelGGL((wdf::clipper_fwd_kernel<DYN_R, SYM, TM, V4, false>), dim3(grid), dim3(64), 0, s, x, r,
+                           theta, fs, n_up, n_down, y, zstash, z0, zT, B, T, general);
+}
+
+template <bool DYN_R, bool SYM, bool TM, bool V4>
+void launch_bwd(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                const float* zstash, const float* gy, double* ws, float* gz0, int64_t B, int64_t T, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    EventBracket bracket(s);
+    hipLaunchKernelGGL((wdf::clipper_bwd_kernel<DYN_R, SYM, TM, V4>), dim3(grid), dim3(64), 0, s, x, r, theta, fs,
+                       n_up, n_down, zstash, gy, ws, gz0, B, T);
+}
+
+// expands the 4 boolean template parameters from runtime flags
+#define WDF_DISPATCH4(FN, dyn, sym, tm, v4, ...)                                                      \
+    do {                                                                                              \
+        const int key = ((dyn) ? 8 : 0) | ((sym) ? 4 : 0) | ((tm) ? 2 : 0) | ((v4) ? 1 : 0);          \
+        switch (key) {                                                                                \
+        case 0: FN<false, false, false, false>(__VA_ARGS__); break;                                   \
+        case 1: FN<false, false, false, true>(__VA_ARGS__); break;                                    \
+        case 2: FN<false, false, true, false>(__VA_ARGS__); break;                                    \
+        case 4: FN<false, true, false, false>(__VA_ARGS__); break;                                    \
+        case 5: FN<false, true, false, true>(__VA_ARGS__); break;                                     \
+        case 6: FN<false, true, true, false>(__VA_ARGS__); break;                                     \
+        case 8: FN<true, false, false, false>(__VA_ARGS__); break;                                    \
+        case 9: FN<true, false, false, true>(__VA_ARGS__); break;                                     \
+        case 10: FN<true, false, true, false>(__VA_ARGS__); break;                                    \
+        case 12: FN<true, true, false, false>(__VA_ARGS__); break;                                    \
+        case 13: FN<true, true, false, true>(__VA_ARGS__); break;                                     \
+        case 14: FN<true, true, true, false>(__VA_ARGS__); break;                                     \
+        default: FN<false, false, false, false>(__VA_ARGS__); break;                                  \
+        }                                                                                             \
+    } while (0)
+
+int check_common(const float* x, const float* theta, int n_up, int n_down, int64_t B, int64_t T, int flags)
+{
+    if (!x || !theta) return fail(WDF_EINVAL, "null x/theta");
+    if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "B and T must be positive (got B=%lld T=%lld)", (long long)B, (long long)T);
+    if (B > (int64_t)64 * 0x7fffffff) return fail(WDF_EINVAL, "B too large");
+    if (n_up < 1 || n_down < 1 || n_up > 16 || n_down > 16) return fail(WDF_EINVAL, "n_up/n_down must be in [1,16]");
+    if (flags & ~(WDF_X_TIME_MAJOR | WDF_PREC_F64 | WDF_GENERAL_ROOT)) return fail(WDF_EINVAL, "unknown flag bits 0x%x", flags);
+    if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 is not available for the Wright-omega clipper");
+    return WDF_OK;
+}
+
+// ---- time-parallel clipper dispatch -----------------------------------------------------------
+#define WDF_DISPATCH3(FN, dyn, sym, v4, ...)                                                     \
+    do {                                                                                         \
+        const int key3 = ((dyn) ? 4 : 0) | ((sym) ? 2 : 0) | ((v4) ? 1 : 0);                     \
+        switch (key3) {                                                                          \
+        case 0: FN<false, false, false>(__VA_ARGS__); break;                                     \
+        case 1: FN<false, false, true>(__VA_ARGS__); break;                                      \
+        case 2: FN<false, true, false>(__VA_ARGS__); break;                                      \
+        case 3: FN<false, true, true>(__VA_ARGS__); break;                                       \
+        case 4: FN<true, false, false>(__VA_ARGS__); break;                                      \
+        case 5: FN<true, false, true>(__VA_ARGS__); break;                                       \
+        case 6: FN<true, true, false>(__VA_ARGS__); break;                                       \
+        default: FN<true, true, true>(__VA_ARGS__); break;                                       \
+        }                                                                                        \
+    } while (0)
+
+struct TpGeom { int64_t L; int K; };
+
+TpGeom tp_geom(int64_t T, int n_chunks)
+{
+    if (n_chunks < 1) n_chunks = 1;
+    int64_t L = (T + n_chunks - 1) / n_chunks;
+    L = (L + wdf::kTile - 1) / wdf::kTile * wdf::kTile;
+    return {L, (int)((T + L - 1) / L)};
+}
+
+// state: nullptr (stateless, cold every call) or the caller's persistent warm-start buffer
+// [TpCtl][snapshot ring kTpRing x J x K x B floats]
+struct TpWarm { wdf::TpCtl* ctl; float* snap; int J; };
+
+template <bool DYN_R, bool SYM, bool TM, bool V4>
+void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
+                   float* zstash, const float* z0, float* zT, float* zwarm, float* zend, wdf::TpStatus* status,
+                   float tol, int64_t B, int64_t T, TpGeom g, int64_t W, TpWarm warm, int general, hipStream_t s)
+{
+    const unsigned gseq = (unsigned)((B + 63) / 64);
+    const dim3 grid(gseq, (unsigned)g.K);
+#define WDF_FWD_TP(STASH_)                                                                                   \
+    hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, TM, V4, STASH_, float>), grid, dim3(64), 0, s, x, r, theta, \
+                       fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, status, warm.ctl, warm.snap, warm.J, B, B, T,   \
+                       g.L, W, general)
+    {
+        EventBracket bracket(s);
+        if (zstash) WDF_FWD_TP(true); else WDF_FWD_TP(false);
+    }
+#undef WDF_FWD_TP
+    if (g.K > 1) {
+#define WDF_VERIFY(STASH_)                                                                                   \
+    hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, TM, STASH_>), dim3(gseq), dim3(64), 0, s, x, r,   \
+                       theta, fs, n_up, n_down, y, zstash, zT, zwarm, zend, B, T, (int64_t)g.K, g.L, W, tol, status,     \
+                       warm.ctl, warm.snap, warm.J, general)
+        if (zstash) WDF_VERIFY(true); else WDF_VERIFY(false);
+#undef WDF_VERIFY
+    }
+}
+
+template <bool DYN_R, bool SYM, bool TM, bool V4>
+void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                   const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
+                   float* part, double* ws, float* gz0, int64_t B, int64_t T, TpGeom g, const float* gcoef,
+                   int64_t skip, unsigned* ticket, float* gtheta, int accumulate, float* sse_out, wdf::AdamTail adam,
+                   hipStream_t s)
+{
+    const int64_t Bh = B;
+    const dim3 grid((unsigned)((Bh + 63) / 64), (unsigned)g.K);
+#define WDF_BWD_TP(MSE_, V_)                                                                               \
+    hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, TM, V4, MSE_, V_>), grid, dim3(64), 0, s, x, r, theta, \
+                       fs, n_up, n_down, zstash, gy, target, zT, gscale, part, B, Bh, T, g.L, gcoef, skip, ticket)
+    {
+        EventBracket bracket(s);
+        if (gcoef) WDF_BWD_TP(2, float);                     // MSE + ESR
+        else if (target) WDF_BWD_TP(1, float);
+        else WDF_BWD_TP(0, float);
+    }
+#undef WDF_BWD_TP
+    hipLaunchKernelGGL(wdf::clipper_bwd_tp_combine_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, part, B,
+                       (int64_t)g.K, ws, gz0, ticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam);
+}
+
+}  // namespace
+
+extern "C" {
+
+int wdf_clipper_fwd(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
+                    float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int flags, void* stream)
+{
+    int rc = check_common(x, theta, n_up, n_down, B, T, flags);
+    if (rc) return rc;
+    if (!y) return fail(WDF_EINVAL, "null y");
+    if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
+    const bool tm = flags & WDF_X_TIME_MAJOR;
+    const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    WDF_DISPATCH4(launch_fwd, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
+                  B, T, (flags & WDF_GENERAL_ROOT) ? 1 : 0, (hipStream_t)stream);
+    return check_launch("wdf_clipper_fwd");
+}
+
+size_t wdf_clipper_bwd_ws_bytes(int64_t B) { return B > 0 ? (size_t)((B + 63) / 64) * 4 * sizeof(double) : 0; }
+
+int wdf_clipper_bwd(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                    const float* zstash, const float* gy, void* ws, float* gtheta, float* gz0, int accumulate,
+                    int64_t B, int64_t T, int flags, void* stream)
+{
+    int rc = check_common(x, theta, n_up, n_down, B, T, flags);
+    if (rc) return rc;
+    if (!zstash || !gy || !ws || !gtheta) return fail(WDF_EINVAL, "null zstash/gy/ws/gtheta");
+    if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
+    const bool tm = flags & WDF_X_TIME_MAJOR;
+    const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    WDF_DISPATCH4(launch_bwd, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy,
+                  (double*)ws, gz0, B, T, (hipStream_t)stream);
+    rc = check_launch("wdf_clipper_bwd");
+    if (rc) return rc;
+    const int nparts = (int)((B + 63) / 64);
+    hipLaunchKernelGGL(wdf::clipper_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)ws, nparts, theta, fs, r != nullptr ? 1 : 0, gtheta, accumulate,
+                       (float*)nullptr);
+    return check_launch("wdf_clipper_grad_reduce");
+}
+
+int wdf_clipper_tp_chunks(int64_t T, int n_chunks) { return T > 0 ? tp_geom(T, n_chunks).K : 0; }
+
+size_t wdf_clipper_fwd_tp_ws_bytes(int64_t B, int n_chunks)
+{
+    return (B > 0 && n_chunks > 0) ? (size_t)2 * (size_t)n_chunks * (size_t)B * sizeof(float) : 0;
+}
+
+static int fwd_tp_common(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
+                         float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup,
+                         float tol, void* ws, void* status, void* state, int max_warm_tiles, int flags, void* stream)
+{
+    int rc = check_common(x, theta, n_up, n_down, B, T, flags);
+    if (rc) return rc;
+    if (!y || !ws || !status) return fail(WDF_EINVAL, "null y/ws/status");
+    if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
+    if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
+    if (B >= ((int64_t)1 << 30)) return fail(WDF_EINVAL, "time-parallel kernels address a [B] row with 32-bit byte offsets: B < 2^30");
+    const TpGeom g = tp_geom(T, n_chunks);
+    const int64_t W = ((int64_t)warmup + wdf::kTile - 1) / wdf::kTile * wdf::kTile;
+    float* zwarm = (float*)ws;
+    float* zend = zwarm + (size_t)g.K * (size_t)B;
+    TpWarm warm{nullptr, nullptr, 1};
+    if (state) {
+        if (max_warm_tiles < 1 || max_warm_tiles > wdf::kTpMaxWarmTiles)
+            return fail(WDF_EINVAL, "max_warm_tiles must be in 1..%d", wdf::kTpMaxWarmTiles);
+        if (g.K >= (1 << 20)) return fail(WDF_EINVAL, "too many chunks for a warm-start state");
+        warm = TpWarm{(wdf::TpCtl*)state, (float*)((char*)state + sizeof(wdf::TpCtl)), max_warm_tiles + 1};
+    }
+    const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
+    const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    WDF_DISPATCH4(launch_fwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
+                  zwarm, zend, (wdf::TpStatus*)status, tol, B, T, g, W, warm, (flags & WDF_GENERAL_ROOT) ? 1 : 0,
+                  (hipStream_t)stream);
+    return check_launch("wdf_clipper_fwd_tp");
+}
+
+int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
+                       float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup,
+                       float tol, void* ws, void* status, int flags, void* stream)
+{
+    return fwd_tp_common(x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, B, T, n_chunks, warmup, tol, ws, status,
+                         nullptr, 0, flags, stream);
+}
+
+size_t wdf_clipper_fwd_tp_state_bytes(int64_t B, int n_chunks, int max_warm_tiles)
+{
+    if (B <= 0 || n_chunks <= 0 || max_warm_tiles < 1 || max_warm_tiles > wdf::kTpMaxWarmTiles) return 0;
+    return sizeof(wdf::TpCtl) + (size_t)wdf::kTpRing * (size_t)(max_warm_tiles + 1) * (size_t)n_chunks * (size_t)B * sizeof(float);
+}
+
+int wdf_clipper_fwd_tp_state_reset(void* state, void* stream)
+{
+    if (!state) return fail(WDF_EINVAL, "null state");
+    const hipError_t e = hipMemsetAsync(state, 0, sizeof(wdf::TpCtl), (hipStream_t)stream);
+    return e == hipSuccess ? WDF_OK : fail(WDF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+}
+
+int wdf_clipper_fwd_tp_warm(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
+                            float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup,
+                            float tol, void* ws, void* status, void* state, int max_warm_tiles, int flags, void* stream)
+{
+    if (!state) return fail(WDF_EINVAL, "null state");
+    const TpGeom g = tp_geom(T, n_chunks > 0 ? n_chunks : 1);
+    if ((int64_t)max_warm_tiles * wdf::kTile > g.L)
+        return fail(WDF_EINVAL, "max_warm_tiles * 32 must not exceed the chunk length (%lld)", (long long)g.L);
+    return fwd_tp_common(x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, B, T, n_chunks, warmup, tol, ws, status, state,
+                         max_warm_tiles, flags, stream);
+}
+
+static int bwd_tp_common(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                         const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
+                         void* ws, float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T,
+                         int n_chunks, int flags, void* stream, const float* gcoef = nullptr, int64_t skip = 0,
+                         wdf::AdamTail adam = wdf::AdamTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr});
+
+size_t wdf_clipper_bwd_tp_ws_bytes(int64_t B, int n_chunks)
+{
+    if (B <= 0 || n_chunks <= 0) return 0;
+    return (size_t)n_chunks * wdf::kTpOut * (size_t)B * sizeof(float) + wdf_clipper_bwd_ws_bytes(B) + 16;   // + ticket
+}
+
+int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                       const float* zstash, const float* gy, void* ws, float* gtheta, float* gz0, int accumulate,
+                       int64_t B, int64_t T, int n_chunks, int flags, void* stream)
+{
+    if (!gy) return fail(WDF_EINVAL, "null gy");
+    return bwd_tp_common(x, r, theta, fs, n_up, n_down, zstash, gy, nullptr, nullptr, 0.0f, ws, gtheta, nullptr, gz0,
+                         accumulate, B, T, n_chunks, flags, stream);
+}
+
+int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                           const float* zstash, const float* zT, const float* target, float gscale, void* ws,
+                           float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T, int n_chunks,
+                           int flags, void* stream)
+{
+    if (!zT || !target) return fail(WDF_EINVAL, "null zT/target");
+    return bwd_tp_common(x, r, theta, fs, n_up, n_down, zstash, nullptr, target, zT, gscale, ws, gtheta, sse, gz0,
+                         accumulate, B, T, n_chunks, flags, stream);
+}
+
+static int bwd_tp_common(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                         const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
+                         void* ws, float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T,
+                         int n_chunks, int flags, void* stream, const float* gcoef, int64_t skip, wdf::AdamTail adam)
+{
+    int rc = check_common(x, theta, n_up, n_down, B, T, flags);
+    if (rc) return rc;
+    if (!zstash || !ws || !gtheta) return fail(WDF_EINVAL, "null zstash/ws/gtheta");
+    if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
+    if (n_chunks < 1) return fail(WDF_EINVAL, "n_chunks >= 1");
+    if (B >= ((int64_t)1 << 30)) return fail(WDF_EINVAL, "time-parallel kernels address a [B] row with 32-bit byte offsets: B < 2^30");
+    const TpGeom g = tp_geom(T, n_chunks);
+    double* wsd = (double*)ws;                                       // [nparts][4] doubles first (8-byte aligned)
+    float* part = (float*)((char*)ws + wdf_clipper_bwd_ws_bytes(B)); // then [K][9][B] floats
+    unsigned* ticket = (unsigned*)((char*)ws + wdf_clipper_bwd_tp_ws_bytes(B, n_chunks) - 16);   // then the block ticket
+    const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
+    const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    // sweep, then combine -- whose last block also reduces, applies the chain rule and (optionally) Adam
+    WDF_DISPATCH4(launch_bwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy, target,
+                  zT, gscale, part, wsd, gz0, B, T, g, gcoef, skip,
+                  ticket, gtheta, accumulate, target ? sse : nullptr, adam, (hipStream_t)stream);
+    return check_launch("wdf_clipper_bwd_tp");
+}
+
+int wdf_clipper_bwd_mse_tp_adam(const float* x, const float* r, float* theta, float fs, int n_up, int n_down,
+                                const float* zstash, const float* zT, const float* target, float gscale, void* ws,
+                                float* gtheta, float* sse, int64_t B, int64_t T, int n_chunks, int flags, float* m,
+                                float* v, int32_t* step, const float* lr, float beta1, float beta2, float eps,
+                                const float* lo, const float* hi, void* stream)
+{
+    if (!zT || !target) return fail(WDF_EINVAL, "null zT/target");
+    if (!m || !v || !step || !lr) return fail(WDF_EINVAL, "null m/v/step/lr");
+    const wdf::AdamTail adam{theta, m, v, step, lr, beta1, beta2, eps, lo, hi};
+    return bwd_tp_common(x, r, theta, fs, n_up, n_down, zstash, nullptr, target, zT, gscale, ws, gtheta, sse, nullptr, 0, B,
+                         T, n_chunks, flags, stream, nullptr, 0, adam);
+}
+
+int wdf_clipper_bwd_esr_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
+                           const float* zstash, const float* zT, const float* target, const float* gcoef, int64_t skip,
+                           void* ws, float* gtheta, float* sse, float* gz0, int accumulate, int64_t B, int64_t T,
+                           int n_chunks, int flags, void* stream)
+{
+    if (!zT || !target || !gcoef) return fail(WDF_EINVAL, "null zT/target/gcoef");
+    if (skip < 0 || skip > T) return fail(WDF_EINVAL, "skip must be in 0..T");
+    return bwd_tp_common(x, r, theta, fs, n_up, n_down, zstash, nullptr, target, zT, 0.0f, ws, gtheta, sse, gz0,
+                         accumulate, B, T, n_chunks, flags, stream, gcoef, skip);
+}
+
+}  // extern "C"

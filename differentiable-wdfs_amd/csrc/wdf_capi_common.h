@@ -1,0 +1,56 @@
+// wdf_capi_common.h -- shared by the translation units of libwdf_hip.so: error string, launch
+// check, the one-shot event bracket.  No algorithm lives here.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/wdf_hip.h"
+
+namespace wdfcapi {
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int check_launch(const char* what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(WDF_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return WDF_OK;
+}
+
+// wdf_event_bracket_next(): events to record immediately before / after the next RECURRENCE
+// kernel launched from this thread (the forward or reverse sweep itself, not the verify /
+// combine / reduce helpers that share its C call), so a harness can time exactly the kernel
+// rocprofv3 reports.  One-shot.
+extern thread_local hipEvent_t g_ev0, g_ev1;
+
+struct EventBracket {
+    hipStream_t s;
+    hipEvent_t e1;
+    explicit EventBracket(hipStream_t stream) : s(stream), e1(g_ev1)
+    {
+        if (g_ev0) (void)hipEventRecord(g_ev0, s);
+        g_ev0 = g_ev1 = nullptr;
+    }
+    ~EventBracket()
+    {
+        if (e1) (void)hipEventRecord(e1, s);
+    }
+};
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace wdfcapi

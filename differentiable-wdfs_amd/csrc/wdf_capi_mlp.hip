@@ -1,0 +1,225 @@
+// wdf_capi_mlp.hip -- C ABI part 4 of 4: the tanh-MLP root (layers.py DenseRootModel) kernels.
+// Argument checking, template dispatch and launches.
+// 
+#include "wdf_capi_common.h"
+#include "wdf_mlp.h"
+#include "wdf_mlp_row.h"
+using namespace wdfcapi;
+
+extern "C" {
+
+// the architectures the MLP kernels are instantiated for (every one among the reference's model files)
+static bool mlp_arch_ok(int hidden, int n_tanh_layers)
+{
+    return ((hidden == 4 || hidden == 8 || hidden == 16) && n_tanh_layers == 3) ||
+           ((hidden == 4 || hidden == 8) && (n_tanh_layers == 4 || n_tanh_layers == 5));
+}
+
+int wdf_mlp_weight_count(int hidden, int n_tanh_layers)
+{
+    if (hidden < 1 || n_tanh_layers < 1) return 0;
+    return 2 * hidden + hidden + (n_tanh_layers - 1) * (hidden * hidden + hidden) + hidden + 1;
+}
+
+#define WDF_MLP_CASE(H_, NL_, DYN_, KERNEL, ...)                                                              \
+    if (hidden == H_ && n_tanh_layers == NL_ && dyn == DYN_)                                                  \
+        hipLaunchKernelGGL((wdf::KERNEL<H_, NL_, DYN_>), dim3(grid), dim3(64), 0, (hipStream_t)stream, __VA_ARGS__);
+#define WDF_MLP_DISPATCH(KERNEL, ...)                                                                         \
+    WDF_MLP_CASE(4, 3, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(4, 3, true, KERNEL, __VA_ARGS__)              \
+    WDF_MLP_CASE(8, 3, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(8, 3, true, KERNEL, __VA_ARGS__)              \
+    WDF_MLP_CASE(16, 3, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(16, 3, true, KERNEL, __VA_ARGS__)            \
+    WDF_MLP_CASE(4, 5, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(4, 5, true, KERNEL, __VA_ARGS__)              \
+    WDF_MLP_CASE(8, 5, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(8, 5, true, KERNEL, __VA_ARGS__)              \
+    WDF_MLP_CASE(4, 4, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(4, 4, true, KERNEL, __VA_ARGS__)              \
+    WDF_MLP_CASE(8, 4, false, KERNEL, __VA_ARGS__) WDF_MLP_CASE(8, 4, true, KERNEL, __VA_ARGS__)
+
+static int mlp_check(const float* x, const float* theta2, const float* w, int hidden, int n_tanh_layers, float fs,
+                     int64_t B, int64_t T, int flags)
+{
+    if (!x || !theta2 || !w) return fail(WDF_EINVAL, "null x/theta2/w");
+    if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "B and T must be positive");
+    if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
+    if (flags & ~WDF_MLP_LANE_PER_SEQUENCE) return fail(WDF_EINVAL, "MLP-root kernels take flags = 0 or WDF_MLP_LANE_PER_SEQUENCE");
+    if (!mlp_arch_ok(hidden, n_tanh_layers))
+        return fail(WDF_EUNSUPPORTED,
+                    "MLP root: hidden in {4,8,16} with 3 tanh layers or {4,8} with 4 or 5 (got width %d, %d tanh layers)",
+                    hidden, n_tanh_layers);
+    return WDF_OK;
+}
+
+int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                        int n_tanh_layers, float fs, float* y, float* zstash, const float* z0, float* zT, int64_t B,
+                        int64_t T, int flags, void* stream)
+{
+    int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, flags);
+    if (rc) return rc;
+    if (!y) return fail(WDF_EINVAL, "null y");
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    const bool dyn = r != nullptr;
+    if (flags & WDF_MLP_LANE_PER_SEQUENCE) {
+        WDF_MLP_DISPATCH(clipper_mlp_fwd_kernel, x, r, theta2, w, fs, y, zstash, z0, zT, B, T)
+    } else {                                      // one 16-lane row per sequence (wdf_mlp_row.h)
+        const unsigned grow = (unsigned)((B + 3) / 4);
+#define WDF_ROW_FWD(NL_)                                                                                       \
+    if (n_tanh_layers == NL_) {                                                                                \
+        if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, true>), dim3(grow), dim3(64), 0,        \
+                                    (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, B, T);   \
+        else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, false>), dim3(grow), dim3(64), 0,           \
+                                (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, B, T);       \
+    }
+        WDF_ROW_FWD(3) WDF_ROW_FWD(4) WDF_ROW_FWD(5)
+#undef WDF_ROW_FWD
+    }
+    return check_launch("wdf_clipper_mlp_fwd");
+}
+
+int64_t wdf_clipper_mlp_bwd_w_ws_bytes(int hidden, int n_tanh_layers, int64_t B)
+{
+    if (B <= 0 || !mlp_arch_ok(hidden, n_tanh_layers)) return 0;
+    const int64_t nblk = (B + 3) / 4;
+    return nblk * 4 * (int64_t)sizeof(double) + nblk * wdf_mlp_weight_count(hidden, n_tanh_layers) * (int64_t)sizeof(float);
+}
+
+int wdf_clipper_mlp_bwd_w(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                          int n_tanh_layers, float fs, const float* zstash, const float* gy, void* ws, float* gtheta2,
+                          float* gw, int64_t B, int64_t T, int flags, void* stream)
+{
+    int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, 0);
+    if (rc) return rc;
+    if (flags != 0) return fail(WDF_EINVAL, "wdf_clipper_mlp_bwd_w takes flags = 0");
+    if (!zstash || !gy || !ws || !gtheta2 || !gw) return fail(WDF_EINVAL, "null zstash/gy/ws/gtheta2/gw");
+    const unsigned grid = (unsigned)((B + 3) / 4);
+    const bool dyn = r != nullptr;
+    double* wsd = (double*)ws;
+    float* wsw = (float*)((char*)ws + (size_t)grid * 4 * sizeof(double));
+#define WDF_ROW_BWD_W(NL_)                                                                                     \
+    if (n_tanh_layers == NL_) {                                                                                \
+        if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_bwd_w_kernel<NL_, true>), dim3(grid), dim3(64), 0,      \
+                                    (hipStream_t)stream, x, r, theta2, w, hidden, fs, zstash, gy, wsw, wsd, B, T);  \
+        else hipLaunchKernelGGL((wdf::clipper_mlp_row_bwd_w_kernel<NL_, false>), dim3(grid), dim3(64), 0,         \
+                                (hipStream_t)stream, x, r, theta2, w, hidden, fs, zstash, gy, wsw, wsd, B, T);    \
+    }
+    WDF_ROW_BWD_W(3) WDF_ROW_BWD_W(4) WDF_ROW_BWD_W(5)
+#undef WDF_ROW_BWD_W
+    rc = check_launch("wdf_clipper_mlp_bwd_w");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wdf::clipper_mlp_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)wsd, (int)grid, theta2, fs, dyn ? 1 : 0, gtheta2);
+    const int count = wdf_mlp_weight_count(hidden, n_tanh_layers);
+    hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)wsw, (int)grid, count, gw);
+    return check_launch("wdf_clipper_mlp_bwd_w reduce");
+}
+
+size_t wdf_clipper_mlp_bwd_ws_bytes(int64_t B) { return B > 0 ? (size_t)((B + 3) / 4) * 4 * sizeof(double) : 0; }
+
+int wdf_clipper_mlp_bwd(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                        int n_tanh_layers, float fs, const float* zstash, const float* gy, float* gb, float* ain,
+                        float* lrin, void* ws, float* gtheta2, int64_t B, int64_t T, int flags, void* stream)
+{
+    int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, flags);
+    if (rc) return rc;
+    if (!zstash || !gy || !gb || !ain || !ws || !gtheta2) return fail(WDF_EINVAL, "null zstash/gy/gb/ain/ws/gtheta2");
+    if (r && !lrin) return fail(WDF_EINVAL, "per-sample resistance needs lrin");
+    unsigned grid = (unsigned)((B + 63) / 64);
+    const bool dyn = r != nullptr;
+    if (flags & WDF_MLP_LANE_PER_SEQUENCE) {
+        WDF_MLP_DISPATCH(clipper_mlp_bwd_kernel, x, r, theta2, w, fs, zstash, gy, gb, ain, lrin, (double*)ws, B, T)
+    } else {                                      // one 16-lane row per sequence (wdf_mlp_row.h)
+        grid = (unsigned)((B + 3) / 4);
+#define WDF_ROW_BWD(NL_)                                                                                       \
+    if (n_tanh_layers == NL_) {                                                                                \
+        if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_bwd_kernel<NL_, true>), dim3(grid), dim3(64), 0,        \
+                                    (hipStream_t)stream, x, r, theta2, w, hidden, fs, zstash, gy, gb, ain, lrin,  \
+                                    (double*)ws, B, T);                                                        \
+        else hipLaunchKernelGGL((wdf::clipper_mlp_row_bwd_kernel<NL_, false>), dim3(grid), dim3(64), 0,           \
+                                (hipStream_t)stream, x, r, theta2, w, hidden, fs, zstash, gy, gb, ain, lrin,      \
+                                (double*)ws, B, T);                                                            \
+    }
+        WDF_ROW_BWD(3) WDF_ROW_BWD(4) WDF_ROW_BWD(5)
+#undef WDF_ROW_BWD
+    }
+    rc = check_launch("wdf_clipper_mlp_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wdf::clipper_mlp_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)ws, (int)grid, theta2, fs, dyn ? 1 : 0, gtheta2);
+    return check_launch("wdf_clipper_mlp_grad_reduce");
+}
+
+static unsigned mlp_wgrad_blocks(int64_t S)
+{
+    const int64_t want = (S + 63) / 64;
+    return (unsigned)(want < 2048 ? want : 2048);
+}
+
+int64_t wdf_clipper_mlp_wgrad_ws_bytes(int hidden, int n_tanh_layers, int64_t S)
+{
+    const int64_t count = wdf_mlp_weight_count(hidden, n_tanh_layers);
+    if (count <= 0 || S <= 0 || !mlp_arch_ok(hidden, n_tanh_layers)) return 0;
+    return (int64_t)mlp_wgrad_blocks(S) * count * (int64_t)sizeof(float);
+}
+
+#define WDF_WGRAD_CASE(H_, NL_)                                                                               \
+    if (hidden == H_ && n_tanh_layers == NL_)                                                                 \
+        hipLaunchKernelGGL((wdf::mlp_wgrad_kernel<H_, NL_>), dim3(nblk, wdf::Mlp<H_, NL_>::kParts), dim3(64), 0, (hipStream_t)stream, ain,  \
+                           lrin, gb, theta2, w, fs, (float*)ws, S);
+
+int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb, const float* theta2, const float* w,
+                          int hidden, int n_tanh_layers, float fs, void* ws, float* gw, int64_t S, void* stream)
+{
+    if (!ain || !gb || !w || !ws || !gw) return fail(WDF_EINVAL, "null ain/gb/w/ws/gw");
+    if (!lrin && !theta2) return fail(WDF_EINVAL, "theta2 is needed when lrin is NULL");
+    if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
+    const int count = wdf_mlp_weight_count(hidden, n_tanh_layers);
+    if (!mlp_arch_ok(hidden, n_tanh_layers))
+        return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
+    const unsigned nblk = mlp_wgrad_blocks(S);
+    WDF_WGRAD_CASE(4, 3) WDF_WGRAD_CASE(8, 3) WDF_WGRAD_CASE(16, 3) WDF_WGRAD_CASE(4, 4) WDF_WGRAD_CASE(8, 4)
+    WDF_WGRAD_CASE(4, 5) WDF_WGRAD_CASE(8, 5)
+    int rc = check_launch("wdf_clipper_mlp_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)ws, (int)nblk, count, gw);
+    return check_launch("wdf_clipper_mlp_wgrad_reduce");
+}
+
+#define WDF_EVAL_CASE(H_, NL_)                                                                                \
+    if (hidden == H_ && n_tanh_layers == NL_)                                                                 \
+        hipLaunchKernelGGL((wdf::mlp_eval_kernel<H_, NL_>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, ain, lrin, w, \
+                           out, S);
+
+int wdf_mlp_eval(const float* ain, const float* lrin, const float* w, int hidden, int n_tanh_layers, float* out,
+                 int64_t S, void* stream)
+{
+    if (!ain || !lrin || !w || !out) return fail(WDF_EINVAL, "null ain/lrin/w/out");
+    if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
+    if (!mlp_arch_ok(hidden, n_tanh_layers))
+        return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
+    const unsigned nblk = mlp_wgrad_blocks(S);
+    WDF_EVAL_CASE(4, 3) WDF_EVAL_CASE(8, 3) WDF_EVAL_CASE(16, 3) WDF_EVAL_CASE(4, 4) WDF_EVAL_CASE(8, 4)
+    WDF_EVAL_CASE(4, 5) WDF_EVAL_CASE(8, 5)
+    return check_launch("wdf_mlp_eval");
+}
+
+#define WDF_FIT_CASE(H_, NL_)                                                                                 \
+    if (hidden == H_ && n_tanh_layers == NL_)                                                                 \
+        hipLaunchKernelGGL((wdf::mlp_fit_epoch_kernel<H_, NL_>), dim3(1), dim3(64 * wdf::Mlp<H_, NL_>::kParts), 0,   \
+                           (hipStream_t)stream, xa, xl, ys, S, batch, w, m, v, step, lr, beta1, beta2, eps, esr_n,   \
+                           eps_energy, loss_sum);
+
+int wdf_mlp_fit_epoch(const float* xa, const float* xl, const float* ys, int64_t S, int batch, float* w, float* m,
+                      float* v, int32_t* step, float lr, float beta1, float beta2, float eps, float esr_n,
+                      float eps_energy, double* loss_sum, int hidden, int n_tanh_layers, void* stream)
+{
+    if (!xa || !xl || !ys || !w || !m || !v || !step || !loss_sum) return fail(WDF_EINVAL, "null argument");
+    if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
+    if (batch < 1 || batch > 64) return fail(WDF_EUNSUPPORTED, "wdf_mlp_fit_epoch: batch must be in 1..64 (got %d)", batch);
+    if (!(esr_n > 0.0f)) return fail(WDF_EINVAL, "esr_n must be positive");
+    if (!mlp_arch_ok(hidden, n_tanh_layers))
+        return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
+    WDF_FIT_CASE(4, 3) WDF_FIT_CASE(8, 3) WDF_FIT_CASE(16, 3) WDF_FIT_CASE(4, 4) WDF_FIT_CASE(8, 4)
+    WDF_FIT_CASE(4, 5) WDF_FIT_CASE(8, 5)
+    return check_launch("wdf_mlp_fit_epoch");
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// wdf_capi_ss.hip -- C ABI part 3 of 4: the generic state-space tree kernels and the
+// two-different-diode (asymmetric) root.  Argument checking, template dispatch and launches.
+// 
+#include "wdf_capi_common.h"
+#include "wdf_statespace.h"
+#include "wdf_asym.h"
+using namespace wdfcapi;
+
+namespace {
+
+// ---- state-space dispatch ------------------------------------------------------------------
+template <int NS, int NI, int ROOT, bool V4>
+void ss_launch_fwd(const float* x, const float* coef, const float* rootp, int n_up, int n_down, float* y,
+                   float* zstash, const float* z0, float* zT, int64_t B, int64_t T, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    hipLaunchKernelGGL((wdf::ss_fwd_kernel<NS, NI, ROOT, false, V4>), dim3(grid), dim3(64), 0, s, x, coef, rootp,
+                       n_up, n_down, y, zstash, z0, zT, B, T);
+}
+
+template <int NS, int NI, int ROOT, bool V4>
+void ss_launch_bwd(const float* x, const float* coef, const float* rootp, int n_up, int n_down, const float* zstash,
+                   const float* gy, double* ws, float* gz0, int64_t B, int64_t T, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    hipLaunchKernelGGL((wdf::ss_bwd_kernel<NS, NI, ROOT, false, V4>), dim3(grid), dim3(64), 0, s, x, coef, rootp,
+                       n_up, n_down, zstash, gy, ws, gz0, B, T);
+}
+
+#define WDF_SS_CASE(FN, NS_, NI_, ...)                                                           \
+    if (ns == NS_ && ni == NI_) {                                                                \
+        if (root == wdf::kRootNone) {                                                            \
+            if (v4) FN<NS_, NI_, wdf::kRootNone, true>(__VA_ARGS__);                             \
+            else FN<NS_, NI_, wdf::kRootNone, false>(__VA_ARGS__);                               \
+        } else {                                                                                 \
+            if (v4) FN<NS_, NI_, wdf::kRootDiode, true>(__VA_ARGS__);                            \
+            else FN<NS_, NI_, wdf::kRootDiode, false>(__VA_ARGS__);                              \
+        }                                                                                        \
+    }
+#define WDF_SS_DISPATCH(FN, ...)                                                                 \
+    do {                                                                                         \
+        WDF_SS_CASE(FN, 0, 1, __VA_ARGS__) WDF_SS_CASE(FN, 1, 1, __VA_ARGS__)                    \
+        WDF_SS_CASE(FN, 2, 1, __VA_ARGS__) WDF_SS_CASE(FN, 3, 1, __VA_ARGS__)                    \
+        WDF_SS_CASE(FN, 0, 2, __VA_ARGS__) WDF_SS_CASE(FN, 1, 2, __VA_ARGS__)                    \
+        WDF_SS_CASE(FN, 2, 2, __VA_ARGS__) WDF_SS_CASE(FN, 3, 2, __VA_ARGS__)                    \
+    } while (0)
+
+int ss_check(const float* x, const float* coef, const float* rootp, int ns, int ni, int root, int n_up, int n_down,
+             int64_t B, int64_t T, int flags)
+{
+    if (!x || !coef) return fail(WDF_EINVAL, "null x/coef");
+    if (ns < 0 || ns > 3 || ni < 1 || ni > 2) return fail(WDF_EUNSUPPORTED, "state-space kernels cover ns in [0,3], ni in [1,2] (got ns=%d ni=%d)", ns, ni);
+    if (root != wdf::kRootNone && root != wdf::kRootDiode) return fail(WDF_EINVAL, "unknown root kind %d", root);
+    if (root == wdf::kRootDiode && !rootp) return fail(WDF_EINVAL, "diode root needs rootp = {Is, nVt, R_port}");
+    if (root == wdf::kRootDiode && (n_up < 1 || n_down < 1 || n_up > 16 || n_down > 16)) return fail(WDF_EINVAL, "n_up/n_down must be in [1,16]");
+    if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "B and T must be positive");
+    if (flags != 0) return fail(WDF_EINVAL, "state-space kernels take flags = 0");
+    return WDF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wdf_ss_ncoef(int ns, int ni) { return ns * ns + ns * ni + ns + ns + ni + ns + ni + 1; }
+
+size_t wdf_ss_bwd_ws_bytes(int ns, int ni, int64_t B)
+{
+    return B > 0 ? (size_t)((B + 63) / 64) * (size_t)(wdf_ss_ncoef(ns, ni) + 2) * sizeof(double) : 0;
+}
+
+int wdf_ss_fwd(const float* x, const float* coef, const float* rootp, int ns, int ni, int root, int n_up, int n_down,
+               float* y, float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int flags, void* stream)
+{
+    int rc = ss_check(x, coef, rootp, ns, ni, root, n_up, n_down, B, T, flags);
+    if (rc) return rc;
+    if (!y) return fail(WDF_EINVAL, "null y");
+    const bool v4 = ((T * ni) % 4 == 0) && aligned16(x);
+    WDF_SS_DISPATCH(ss_launch_fwd, x, coef, rootp, n_up, n_down, y, zstash, z0, zT, B, T, (hipStream_t)stream);
+    return check_launch("wdf_ss_fwd");
+}
+
+int wdf_ss_bwd(const float* x, const float* coef, const float* rootp, int ns, int ni, int root, int n_up, int n_down,
+               const float* zstash, const float* gy, void* ws, float* gcoef, float* groot, float* gz0, int64_t B,
+               int64_t T, int flags, void* stream)
+{
+    int rc = ss_check(x, coef, rootp, ns, ni, root, n_up, n_down, B, T, flags);
+    if (rc) return rc;
+    if (!gy || !ws || !gcoef) return fail(WDF_EINVAL, "null gy/ws/gcoef");
+    if (ns > 0 && !zstash) return fail(WDF_EINVAL, "null zstash");
+    if (root == wdf::kRootDiode && !groot) return fail(WDF_EINVAL, "null groot");
+    const bool v4 = ((T * ni) % 4 == 0) && aligned16(x);
+    WDF_SS_DISPATCH(ss_launch_bwd, x, coef, rootp, n_up, n_down, zstash, gy, (double*)ws, gz0, B, T,
+                    (hipStream_t)stream);
+    rc = check_launch("wdf_ss_bwd");
+    if (rc) return rc;
+    const int ncoef = wdf_ss_ncoef(ns, ni);
+    hipLaunchKernelGGL(wdf::ss_grad_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)ws,
+                       (int)((B + 63) / 64), ncoef + 2, ncoef, root == wdf::kRootDiode ? rootp : nullptr, gcoef,
+                       root == wdf::kRootDiode ? groot : nullptr);
+    return check_launch("wdf_ss_grad_reduce");
+}
+
+int wdf_clipper_asym_fwd(const float* x, const float* theta6, float fs, int mode, double tol, int max_iter, float* y,
+                         const float* z0, float* zT, long long* iters, int64_t B, int64_t T, void* stream)
+{
+    if (!x || !theta6 || !y) return fail(WDF_EINVAL, "null x/theta6/y");
+    if (B <= 0 || T <= 0 || !(fs > 0.0f)) return fail(WDF_EINVAL, "B, T, fs must be positive");
+    if (mode != WDF_ASYM_OMEGA_F32 && mode != WDF_ASYM_NEWTON_F64) return fail(WDF_EINVAL, "unknown mode %d", mode);
+    if (mode == WDF_ASYM_NEWTON_F64 && (!(tol > 0.0) || max_iter < 1)) return fail(WDF_EINVAL, "tol > 0, max_iter >= 1");
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    const bool v4 = (T % 4 == 0) && aligned16(x);
+#define WDF_ASYM(NEWTON_, V4_)                                                                                \
+    hipLaunchKernelGGL((wdf::clipper_asym_fwd_kernel<NEWTON_, V4_>), dim3(grid), dim3(64), 0, (hipStream_t)stream, x, \
+                       theta6, fs, y, z0, zT, tol, max_iter, iters, B, T)
+    if (mode == WDF_ASYM_NEWTON_F64) { if (v4) WDF_ASYM(true, true); else WDF_ASYM(true, false); }
+    else { if (v4) WDF_ASYM(false, true); else WDF_ASYM(false, false); }
+#undef WDF_ASYM
+    return check_launch("wdf_clipper_asym_fwd");
+}
+
+int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, double tol, int max_iter, double* b, int64_t n,
+                  void* stream)
+{
+    if (!a || !theta6 || !b || n <= 0) return fail(WDF_EINVAL, "wdf_asym_root: bad arguments");
+    if (mode != WDF_ASYM_OMEGA_F32 && mode != WDF_ASYM_NEWTON_F64) return fail(WDF_EINVAL, "unknown mode %d", mode);
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (mode == WDF_ASYM_NEWTON_F64)
+        hipLaunchKernelGGL((wdf::asym_root_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, theta6, fs, b,
+                           tol, max_iter, n);
+    else
+        hipLaunchKernelGGL((wdf::asym_root_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, theta6, fs, b,
+                           tol, max_iter, n);
+    return check_launch("wdf_asym_root");
+}
+
+}  // extern "C"

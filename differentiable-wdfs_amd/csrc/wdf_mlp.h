@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_bwd_kernel(
 
 // gtheta2 = dL/d{R, C}:  static R: lr = log Rp, so with S_L := S_lr the clipper formulas apply
 //   dR = Rp G1^2 (S_lr - S_P (1-p)) ; dC = -2 fs Rp (S_P p + S_lr);  per-sample R: dR = 0, dC = -2 fs S_P
-__global__ __launch_bounds__(256) void clipper_mlp_grad_reduce_kernel(const double* __restrict__ ws, int nparts,
+static __global__ __launch_bounds__(256) void clipper_mlp_grad_reduce_kernel(const double* __restrict__ ws, int nparts,
                                                                       const float* __restrict__ theta2, float fs,
                                                                       int dyn_r, float* __restrict__ gtheta2)
 {
@@ -545,7 +545,7 @@ __global__ __launch_bounds__((64 * Mlp<H, NL>::kParts)) void mlp_fit_epoch_kerne
     if (threadIdx.x == 0) { *step = t; *loss_sum = loss_acc; }
 }
 
-__global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(const float* __restrict__ ws, int nblk, int count,
+static __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(const float* __restrict__ ws, int nblk, int count,
                                                                float* __restrict__ gw)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;

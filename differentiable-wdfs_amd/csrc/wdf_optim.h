@@ -17,7 +17,7 @@ namespace wdf {
 
 // One thread per parameter; `step` is the shared iteration counter (read by all, bumped by thread 0
 // after a barrier -- n <= 1024, one block).
-__global__ __launch_bounds__(1024) void adam_clip_kernel(float* __restrict__ theta, const float* __restrict__ grad,
+static __global__ __launch_bounds__(1024) void adam_clip_kernel(float* __restrict__ theta, const float* __restrict__ grad,
                                                          float* __restrict__ m, float* __restrict__ v,
                                                          int32_t* __restrict__ step, const float* __restrict__ lr,
                                                          float b1, float b2, float eps, const float* __restrict__ lo,

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64) void ss_bwd_kernel(const float* __restrict__ x,
 
 // Fixed-order sum of the per-wave partials; writes gcoef[kN] and, for the diode root,
 // groot[3] = dL/d{Is, nVt, R_port}  (L = log(R_port Is / nVt)).
-__global__ __launch_bounds__(64) void ss_grad_reduce_kernel(const double* __restrict__ ws, int nparts, int nacc,
+static __global__ __launch_bounds__(64) void ss_grad_reduce_kernel(const double* __restrict__ ws, int nparts, int nacc,
                                                             int ncoef, const float* __restrict__ rootp,
                                                             float* __restrict__ gcoef, float* __restrict__ groot)
 {

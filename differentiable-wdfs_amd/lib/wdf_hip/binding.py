@@ -12,11 +12,11 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwdf_hip.so")
+# WDF_HIP_LIB: another build of the same library (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("WDF_HIP_LIB") or os.path.join(_HERE, "libwdf_hip.so")
 
 WDF_X_TIME_MAJOR = 1 << 0
 WDF_PREC_F64 = 1 << 1
-WDF_TP_PACK2 = 1 << 2
 WDF_GENERAL_ROOT = 1 << 3
 WDF_MLP_LANE_PER_SEQUENCE = 1 << 4
 
@@ -67,6 +67,12 @@ def lib():
     L.wdf_clipper_fwd_tp_ws_bytes.argtypes = [i64, ci]
     L.wdf_clipper_fwd_tp.restype = ci
     L.wdf_clipper_fwd_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, ci, vp]
+    L.wdf_clipper_fwd_tp_state_bytes.restype = C.c_size_t
+    L.wdf_clipper_fwd_tp_state_bytes.argtypes = [i64, ci, ci]
+    L.wdf_clipper_fwd_tp_state_reset.restype = ci
+    L.wdf_clipper_fwd_tp_state_reset.argtypes = [vp, vp]
+    L.wdf_clipper_fwd_tp_warm.restype = ci
+    L.wdf_clipper_fwd_tp_warm.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, vp, ci, ci, vp]
     L.wdf_clipper_bwd_tp_ws_bytes.restype = C.c_size_t
     L.wdf_clipper_bwd_tp_ws_bytes.argtypes = [i64, ci]
     L.wdf_clipper_bwd_tp.restype = ci
@@ -140,6 +146,7 @@ EXPORTED_SYMBOLS = (
     "wdf_abi_version", "wdf_last_error", "wdf_device_info",
     "wdf_clipper_fwd", "wdf_clipper_bwd", "wdf_clipper_bwd_ws_bytes",
     "wdf_clipper_tp_chunks", "wdf_clipper_fwd_tp_ws_bytes", "wdf_clipper_fwd_tp",
+    "wdf_clipper_fwd_tp_state_bytes", "wdf_clipper_fwd_tp_state_reset", "wdf_clipper_fwd_tp_warm",
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_bwd_mse_tp_adam", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_asym_root",
@@ -228,10 +235,37 @@ def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=Fal
     return gtheta, gz0
 
 
+class TpWarmState:
+    """Persistent warm-start state of the time-parallel forward for ONE resident input batch
+    (include/wdf_hip.h, wdf_clipper_fwd_tp_warm): control block + snapshot ring on the device."""
+
+    def __init__(self, B, T, n_chunks, max_warm_tiles, device):
+        L = lib()
+        self.K = L.wdf_clipper_tp_chunks(int(T), int(n_chunks))
+        chunk_len = -(-(-(-int(T) // max(1, int(n_chunks)))) // 32) * 32        # as the library rounds it
+        self.max_warm_tiles = max(1, min(int(max_warm_tiles), 16, chunk_len // 32))
+        self.B, self.T, self.n_chunks = int(B), int(T), int(n_chunks)
+        self.buf = torch.empty((L.wdf_clipper_fwd_tp_state_bytes(self.B, self.K, self.max_warm_tiles),),
+                               dtype=torch.uint8, device=device)
+        self.reset()
+
+    def reset(self):
+        _check(lib().wdf_clipper_fwd_tp_state_reset(_ptr(self.buf), _stream()), "wdf_clipper_fwd_tp_state_reset")
+
+    def info(self):
+        """Host view of the control block (synchronises): snapshot sets available, warm-up tiles the next
+        call will run, tiles the last call ran (-1: cold), its largest boundary miss, calls so far."""
+        c = self.buf[:64].cpu()
+        i, f = c.view(torch.int32), c.view(torch.float32)
+        return {"valid": int(i[0]), "next_warm_tiles": int(i[2]), "last_warm_tiles": int(i[3]),
+                "last_miss": float(f[12]), "n_calls": int(i[13])}
+
+
 def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_down=1, want_stash=True, z0=None,
-                   want_zT=False, ws=None, status=None, pack=False, time_major=False):
+                   want_zT=False, ws=None, status=None, time_major=False, state=None):
     """Time-parallel forward.  Returns y [T,B], zstash | None, zT | None, status (device int32[4]:
-    n_bad, max-miss float bits, fallback_ran, 0 -- read it with tp_status())."""
+    n_bad, max-miss float bits, chunk re-runs, ticket -- read it with tp_status()).
+    state: a TpWarmState kept with this input batch -> warm-started chunks (wdf_clipper_fwd_tp_warm)."""
     require_gpu()
     x = _f32_dev(x, "x")
     r = _f32_dev(r, "r")
@@ -247,10 +281,18 @@ def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_d
         ws = torch.empty((lib().wdf_clipper_fwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
     if status is None:
         status = torch.empty((4,), dtype=torch.int32, device=x.device)
+    flags = (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag()
+    if state is not None:
+        if (state.B, state.T, state.n_chunks) != (B, T, int(n_chunks)) or state.buf.device != x.device:
+            raise WdfHipError("warm-start state was made for another batch shape / chunking / device")
+        rc = lib().wdf_clipper_fwd_tp_warm(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(y),
+                                           _ptr(zs), _ptr(z0), _ptr(zT), B, T, int(n_chunks), int(warmup), float(tol),
+                                           _ptr(ws), _ptr(status), _ptr(state.buf), state.max_warm_tiles, flags, _stream())
+        _check(rc, "wdf_clipper_fwd_tp_warm")
+        return y, zs, zT, status
     rc = lib().wdf_clipper_fwd_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(y),
                                   _ptr(zs), _ptr(z0), _ptr(zT), B, T, int(n_chunks), int(warmup), float(tol),
-                                  _ptr(ws), _ptr(status),
-                                  (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(), _stream())
+                                  _ptr(ws), _ptr(status), flags, _stream())
     _check(rc, "wdf_clipper_fwd_tp")
     return y, zs, zT, status
 
@@ -339,7 +381,7 @@ def tp_status(status):
 
 
 def clipper_bwd_tp(x, theta, fs, zstash, gy, n_chunks, r=None, n_up=1, n_down=1, want_gz0=False, gtheta=None,
-                   accumulate=False, ws=None, pack=False, time_major=False):
+                   accumulate=False, ws=None, time_major=False):
     require_gpu()
     x = _f32_dev(x, "x")
     r = _f32_dev(r, "r")
@@ -358,13 +400,13 @@ def clipper_bwd_tp(x, theta, fs, zstash, gy, n_chunks, r=None, n_up=1, n_down=1,
     rc = lib().wdf_clipper_bwd_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(zstash),
                                   _ptr(gy), _ptr(ws), _ptr(gtheta), _ptr(gz0), 1 if accumulate else 0, B, T,
                                   int(n_chunks),
-                                  (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(), _stream())
+                                  (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(), _stream())
     _check(rc, "wdf_clipper_bwd_tp")
     return gtheta, gz0
 
 
 def clipper_bwd_mse_tp(x, theta, fs, zstash, zT, target, gscale, n_chunks, r=None, n_up=1, n_down=1, gtheta=None,
-                       sse=None, accumulate=False, ws=None, pack=False, time_major=False):
+                       sse=None, accumulate=False, ws=None, time_major=False):
     """MSE-fused reverse sweep: y is rebuilt from the state stash (zstash [T,B], zT [B]) and
     dL/dy = gscale (y - target) is formed in the kernel.
     Returns (gtheta float32[4], sse float32[1] = sum (y - target)^2 over this batch)."""
@@ -391,7 +433,7 @@ def clipper_bwd_mse_tp(x, theta, fs, zstash, zT, target, gscale, n_chunks, r=Non
     rc = lib().wdf_clipper_bwd_mse_tp(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
                                       _ptr(zstash), _ptr(zT), _ptr(target), float(gscale), _ptr(ws), _ptr(gtheta),
                                       _ptr(sse), None, 1 if accumulate else 0, B, T, int(n_chunks),
-                                      (WDF_TP_PACK2 if pack else 0) | (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(),
+                                      (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(),
                                       _stream())
     _check(rc, "wdf_clipper_bwd_mse_tp")
     return gtheta, sse

@@ -158,11 +158,14 @@ class MseStep:
     for all 501 epochs, clipper_pot.py:245-248), giving fully coalesced loads."""
 
     def __init__(self, B, T, fs, tp, device, n_up=1, n_down=1, n_global=None, time_major=False, loss="mse",
-                 skip=0, sums_allreduce=None):
+                 skip=0, sums_allreduce=None, warm=False, max_warm_tiles=8):
         """loss: "mse" (mean over n_global samples) or "mse+esr", the training loss of
         clipper_pot.py:177 evaluated past `skip` samples (:232,248; n_global then counts the samples
         past skip over all ranks).  sums_allreduce: in-place SUM all-reduce for the two float64 loss
-        sums when the batch is sharded (wdf_hip.dist.allreduce_sum_)."""
+        sums when the batch is sharded (wdf_hip.dist.allreduce_sum_).
+        warm: this stepper always sees the SAME resident x (a training set re-visited every epoch,
+        clipper_pot.py:245-269): keep the forward's warm-start state between calls
+        (binding.TpWarmState; call reset_warm() if x changes)."""
         if loss not in ("mse", "mse+esr"):
             raise binding.WdfHipError(f"unknown loss {loss!r}")
         if loss == "mse" and skip:
@@ -186,13 +189,20 @@ class MseStep:
         self.out = torch.zeros((5,), dtype=torch.float32, device=device)
         self.sse, self.gtheta = self.out[0:1], self.out[1:5]
         self.y = self.zs = self.zT = None
+        self.warm = None
+        if warm and tp is not None and tp.k_fwd > 1:
+            self.warm = binding.TpWarmState(B, T, tp.k_fwd, max(max_warm_tiles, -(-tp.warmup // 32)), device)
+
+    def reset_warm(self):
+        if self.warm is not None:
+            self.warm.reset()
 
     def forward(self, theta, x, r=None):
         tp = self.tp
         if tp is not None and tp.k_fwd > 1:
             self.y, self.zs, self.zT, _ = binding.clipper_fwd_tp(
                 x, theta, self.fs, tp.k_fwd, tp.warmup, tp.tol, r=r, n_up=self.n_up, n_down=self.n_down,
-                want_zT=True, ws=self.ws_f, status=self.status, time_major=self.time_major)
+                want_zT=True, ws=self.ws_f, status=self.status, time_major=self.time_major, state=self.warm)
         else:
             self.y, self.zs, self.zT = binding.clipper_fwd(x, theta, self.fs, r=r, n_up=self.n_up,
                                                            n_down=self.n_down, want_zT=True,

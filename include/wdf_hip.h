@@ -44,7 +44,6 @@ enum {
 enum {
     WDF_X_TIME_MAJOR = 1 << 0, /* x (and r) are [T][B] instead of [B][T]                 */
     WDF_PREC_F64     = 1 << 1, /* evaluate the root solve in fp64 (config C5); I/O stays f32 */
-    WDF_TP_PACK2     = 1 << 2, /* time-parallel kernels: two sequences per lane, packed v_pk_* math */
     WDF_MLP_LANE_PER_SEQUENCE = 1 << 4, /* MLP-root kernels: the one-lane-per-sequence variant (csrc/wdf_mlp.h)
                                   instead of the default 16-lane row per sequence (csrc/wdf_mlp_row.h) */
     WDF_GENERAL_ROOT = 1 << 3  /* always take the general per-step root evaluation (the kernels otherwise
@@ -107,11 +106,20 @@ size_t wdf_clipper_bwd_ws_bytes(int64_t B);
  * wdf_clipper_fwd_tp: every chunk starts `warmup` steps early from z = 0; the state it
  *   arrives with is checked on the device against the previous chunk's final state
  *   (|diff| <= tol for every sequence and chunk) by a verify kernel that, where a check
- *   fails, recomputes that wave's 64 sequences sequentially (exact) on the spot.
+ *   fails, re-runs that chunk for the wave's 64 sequences from the correct state on the spot.
  *   Either way the outputs are within tol of wdf_clipper_fwd's, with no host round trip.
- *   status: device int32[4] = {n_bad pairs, max |miss| (float bits), repaired tiles, 0},
+ *   status: device int32[4] = {n_bad pairs, max |miss| (float bits), chunk re-runs, ticket},
  *   written by the call (zeroed first); the caller may read it later to report / adapt
  *   `warmup`.
+ * wdf_clipper_fwd_tp_warm: the same call with a persistent `state` buffer
+ *   (wdf_clipper_fwd_tp_state_bytes; wdf_clipper_fwd_tp_state_reset before the first use and
+ *   whenever x, B, T or the chunking change).  The reference's training loop runs the same
+ *   train_X through the circuit every epoch with slowly moving parameters
+ *   (clipper_pot.py:245-269): each call leaves snapshots of every chunk's state near its end,
+ *   the next call starts its chunks from them (extrapolated along the parameter path from the
+ *   last two calls) and runs only the few warm-up tiles the verify kernel's measured miss asks
+ *   for -- steered on the device, between 0 and max_warm_tiles tiles of 32 steps (the first call
+ *   after a reset is a cold one with `warmup`).  Same verification, same guarantee.
  * ---------------------------------------------------------------------------------- */
 int wdf_clipper_tp_chunks(int64_t T, int n_chunks);
 size_t wdf_clipper_fwd_tp_ws_bytes(int64_t B, int n_chunks);
@@ -120,6 +128,14 @@ int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta,
                        float* y, float* zstash, const float* z0, float* zT,
                        int64_t B, int64_t T, int n_chunks, int warmup, float tol,
                        void* ws, void* status, int flags, void* stream);
+size_t wdf_clipper_fwd_tp_state_bytes(int64_t B, int n_chunks, int max_warm_tiles);
+int wdf_clipper_fwd_tp_state_reset(void* state, void* stream);
+int wdf_clipper_fwd_tp_warm(const float* x, const float* r, const float* theta,
+                            float fs, int n_up, int n_down,
+                            float* y, float* zstash, const float* z0, float* zT,
+                            int64_t B, int64_t T, int n_chunks, int warmup, float tol,
+                            void* ws, void* status, void* state, int max_warm_tiles,
+                            int flags, void* stream);
 size_t wdf_clipper_bwd_tp_ws_bytes(int64_t B, int n_chunks);
 /* MSE-fused reverse sweep (lpf.py:78 / clipper_pot.py:176 loss): `target` [T][B] is the
  * training target and zT [B] the forward's final state; the kernel rebuilds y[n] =

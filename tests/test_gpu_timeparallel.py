@@ -3,7 +3,9 @@
 * reverse sweep: exact up to summation order -> gradients agree to 2e-5 relative;
 * forward: outputs within the verified tolerance of the sequential kernel, status clean; and
   when the warm-up is deliberately too short for the circuit's memory, the on-device
-  verification notices and the gated sequential kernel makes the result exact anyway.
+  verification notices and re-runs the chunks that started wrong;
+* warm-started forward (snapshots of the previous call, device-steered warm-up): a training loop,
+  a parameter jump (repaired), an unchanged theta (bit-exact with zero warm-up).
 """
 import numpy as np
 import pytest
@@ -31,60 +33,58 @@ def setup(B, T, seed=0):
     return dev(x), dev(workload.clipper_theta())
 
 
-@pytest.mark.parametrize("pack", [False, True])
 @pytest.mark.parametrize("B,T,K", [(64, 512, 4), (70, 1001, 7), (130, 2048, 16), (5, 96, 12), (3, 8, 4), (1, 64, 2)])
 @pytest.mark.parametrize("n_up,n_down", [(1, 1), (2, 3)])
-def test_bwd_tp_matches_sequential(wb, B, T, K, n_up, n_down, pack):
+def test_bwd_tp_matches_sequential(wb, B, T, K, n_up, n_down):
     x, th = setup(B, T, seed=B + T)
     y, zs, _ = wb.clipper_fwd(x, th, FS, n_up=n_up, n_down=n_down)
     gy = dev(np.random.default_rng(B).standard_normal((T, B)) / (B * T))
     g_seq, gz_seq = wb.clipper_bwd(x, th, FS, zs, gy, n_up=n_up, n_down=n_down, want_gz0=True)
-    g_tp, gz_tp = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, n_up=n_up, n_down=n_down, want_gz0=True, pack=pack)
+    g_tp, gz_tp = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, n_up=n_up, n_down=n_down, want_gz0=True)
     assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0), (g_tp, g_seq)
     assert torch.allclose(gz_tp, gz_seq, rtol=1e-4, atol=1e-12)
-    g_tp2, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, n_up=n_up, n_down=n_down, pack=pack)
+    g_tp2, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, n_up=n_up, n_down=n_down)
     assert torch.equal(g_tp, g_tp2)                                  # deterministic
 
 
-@pytest.mark.parametrize("pack", [False, True])
-def test_bwd_tp_per_sample_r(wb, pack):
+def test_bwd_tp_per_sample_r(wb):
     B, T, K = 71, 520, 5
     x, th = setup(B, T, seed=3)
     r = dev(45.0e3 * np.exp(0.8 * np.sin(np.arange(T)[None, :] * 0.01 * (1 + np.arange(B)[:, None] % 5))))
     y, zs, _ = wb.clipper_fwd(x, th, FS, r=r)
     gy = dev(np.random.default_rng(1).standard_normal((T, B)) / (B * T))
     g_seq, _ = wb.clipper_bwd(x, th, FS, zs, gy, r=r)
-    g_tp, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, r=r, pack=pack)
+    g_tp, _ = wb.clipper_bwd_tp(x, th, FS, zs, gy, K, r=r)
     assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0)
     # forward with the per-sample resistance channel, time-parallel (r >= 16 kOhm: W = 256 is plenty)
-    y2, _, _, st = wb.clipper_fwd_tp(x, th, FS, 2, 256, r=r, pack=pack)
+    y2, _, _, st = wb.clipper_fwd_tp(x, th, FS, 2, 256, r=r)
     assert wb.tp_status(st)["n_bad"] == 0
     assert float((y2 - y).abs().max()) <= 1e-6
 
 
-@pytest.mark.parametrize("pack", [False, True])
 @pytest.mark.parametrize("B,T,K,W", [(64, 2048, 4, 256), (70, 4096, 16, 256), (131, 1001, 3, 248), (5, 4096, 8, 512),
                                      (1, 2048, 4, 256)])
-def test_fwd_tp_matches_sequential(wb, B, T, K, W, pack):
+def test_fwd_tp_matches_sequential(wb, B, T, K, W):
     x, th = setup(B, T, seed=B + T)
     y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
-    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, K, W, tol=1e-6, want_zT=True, pack=pack)
+    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, K, W, tol=1e-6, want_zT=True)
     s = wb.tp_status(st)
     assert s["n_bad"] == 0 and not s["fallback_ran"], s
     assert s["max_miss"] <= 1e-6
     assert float((y2 - y).abs().max()) <= 1e-6
     assert float((zs2 - zs).abs().max()) <= 2e-6
     assert float((zT2 - zT).abs().max()) <= 2e-6
-    # chunk 0 is the sequential computation itself (same arithmetic when not packed)
+    # chunk 0 is the sequential computation itself (same arithmetic)
     L = -(-T // K)
     L = -(-L // 32) * 32
-    if not pack:
-        assert torch.equal(y2[:L], y[:L])
+    assert torch.equal(y2[:L], y[:L])
 
 
 def test_fwd_tp_falls_back_when_warmup_is_too_short(wb):
     """C = 1 uF: the circuit remembers ~4000 samples, a 64-step warm-up cannot work.  The
-    verification must catch it and the gated kernel must restore the exact result."""
+    verification must catch it at every boundary and the chunk re-runs -- each from the repaired
+    end state of the chunk before, never meeting the speculative stash again -- must restore the
+    sequential kernel's result bit for bit."""
     from wdf_hip import workload
     B, T = 70, 2048
     x = dev(workload.sweep_batch(B, T, seed=11))
@@ -92,9 +92,9 @@ def test_fwd_tp_falls_back_when_warmup_is_too_short(wb):
     theta[3] = 1.0e-6
     th = dev(theta)
     y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
-    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, 8, 64, tol=1e-6, want_zT=True, pack=True)
+    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, 8, 64, tol=1e-6, want_zT=True)
     s = wb.tp_status(st)
-    assert s["n_bad"] > 0 and s["fallback_ran"] and s["repaired_tiles"] == 2, s
+    assert s["n_bad"] > 0 and s["fallback_ran"] and s["repaired_tiles"] == 2 * 7, s      # 2 waves x 7 boundaries
     assert torch.equal(y2, y) and torch.equal(zs2, zs) and torch.equal(zT2, zT)
 
 
@@ -114,7 +114,7 @@ def test_tp_full_size_against_oracle(wb, oracle):
     theta = workload.clipper_theta()
     x = workload.sweep_batch(B, T)
     xd, th = dev(x), dev(theta)
-    y, zs, _, st = wb.clipper_fwd_tp(xd, th, FS, 2 * K, W, pack=True)
+    y, zs, _, st = wb.clipper_fwd_tp(xd, th, FS, 2 * K, W)
     s = wb.tp_status(st)
     assert s["n_bad"] == 0, s
     pick = np.random.default_rng(5).choice(B, 16, replace=False)
@@ -123,9 +123,8 @@ def test_tp_full_size_against_oracle(wb, oracle):
     tgt, _, _ = wb.clipper_fwd(xd, dev(workload.target_theta()), FS, want_stash=False)
     gy = (2.0 * (y - tgt) / y.numel()).contiguous()
     g_seq, _ = wb.clipper_bwd(xd, th, FS, zs, gy)
-    for pack in (False, True):
-        g_tp, _ = wb.clipper_bwd_tp(xd, th, FS, zs, gy, 64, pack=pack)
-        assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0), (pack, g_tp, g_seq)
+    g_tp, _ = wb.clipper_bwd_tp(xd, th, FS, zs, gy, 64)
+    assert torch.allclose(g_tp, g_seq, rtol=2e-5, atol=0), (g_tp, g_seq)
 
 
 def test_fused_mse_step_matches_autograd_path(wb):
@@ -313,8 +312,8 @@ def test_fused_mse_esr_step_matches_autograd_and_oracle(wb, oracle, time_major):
 
 def test_randomized_plans_and_circuits(wb):
     """tools/stress_tp.py, 60 cases: random component values over the clip ranges of tf_wdf.py:74,104,
-    random diode parameters and counts, amplitudes, shapes, layouts, chunkings and warm-ups (hopeless
-    ones included).  The time-parallel forward must equal the sequential one to 2e-6 whatever the plan
+    random diode parameters and counts, amplitudes, shapes, layouts, chunkings, warm-ups (hopeless
+    ones included) and warm starts from snapshots taken at nearby or far-away parameters.  The time-parallel forward must equal the sequential one to 2e-6 whatever the plan
     (a third of the cases go through the repair path) and the chunked reverse sweep must agree with the
     sequential one."""
     import os, sys
@@ -325,7 +324,9 @@ def test_randomized_plans_and_circuits(wb):
     for case in range(60):
         ey, eg, rep = stress_tp.run_case(11, case)
         worst_y, worst_g, repaired = max(worst_y, ey), max(worst_g, eg), repaired + rep
-    assert worst_y <= 2e-6 and worst_g <= 5e-4, (worst_y, worst_g)
+    # sweep mismatch: 1e-3 of a component's own size (+1e-3 of the largest); the worst of these cases is a 10 mV
+    # signal whose dL/dIs is a cancelling sum that BOTH sweeps get only to 2 % of the fp64 oracle (tools/stress_tp.py --case 11 55)
+    assert worst_y <= 2e-6 and worst_g <= 1e-3, (worst_y, worst_g)
     assert repaired >= 5
 
 
@@ -388,3 +389,94 @@ def test_fused_mse_esr_with_per_sample_resistance(wb):
     assert float(g[2]) == 0.0 and float(thr.grad[2]) == 0.0
     keep = torch.tensor([0, 1, 3], device="cuda")
     assert torch.allclose(g[keep], thr.grad[keep], rtol=1e-4, atol=0), (g, thr.grad)
+
+
+# ---- warm-started forward (wdf_clipper_fwd_tp_warm) ------------------------------------------------
+def _theta_path(th0, steps, rel):
+    """theta moving `rel` per step in every component (signs as an optimizer would keep them)"""
+    sign = torch.tensor([1.0, -1.0, -1.0, 1.0], device=th0.device)
+    return [th0 * (1.0 + rel * s * sign) for s in range(steps)]
+
+
+@pytest.mark.parametrize("time_major", [False, True])
+@pytest.mark.parametrize("with_r", [False, True])
+def test_fwd_tp_warm_training_loop(wb, time_major, with_r):
+    """Same inputs every call, theta moving 0.1 % per call (bench.py's Adam step): every call within
+    1e-6 of the sequential kernel, no boundary misses, and after the cold first call the device
+    controller settles at a fraction of the cold warm-up."""
+    from wdf_hip import workload
+    B, T, K, W = 200, 2048, 8, 192
+    x, th0 = setup(B, T, seed=51)
+    r = dev(workload.pot_resistance_batch(B, T)) if with_r else None
+    xin = x.t().contiguous() if time_major else x
+    rin = (r.t().contiguous() if time_major else r) if with_r else None
+    if with_r:
+        W = 448                                              # 99.1 kOhm: slower memory
+    state = wb.TpWarmState(B, T, K, 8, x.device)
+    used = []
+    for th in _theta_path(th0, 10, 1.0e-3):
+        y, zs, zT = wb.clipper_fwd(x, th, FS, r=r, want_zT=True)
+        y2, zs2, zT2, st = wb.clipper_fwd_tp(xin, th, FS, K, W, r=rin, want_zT=True, time_major=time_major, state=state)
+        s, info = wb.tp_status(st), state.info()
+        assert s["n_bad"] == 0 and s["repaired_tiles"] == 0, (s, info)
+        assert float((y2 - y).abs().max()) <= 1e-6 and float((zs2 - zs).abs().max()) <= 2e-6
+        assert float((zT2 - zT).abs().max()) <= 2e-6
+        used.append(info["last_warm_tiles"])
+    assert used[0] == -1 and all(0 <= u < -(-W // 32) for u in used[1:]), used
+    assert state.info()["valid"] == 2 and state.info()["n_calls"] == 10
+
+
+def test_fwd_tp_warm_parameter_jump_is_repaired(wb):
+    """After a few slow steps theta jumps by 20 %: the snapshots are now far off, boundaries miss, the
+    verify kernel re-runs the chunks -- and the output is still the sequential kernel's to 1e-6.
+    The controller answers with more warm-up tiles, and the following calls are clean again."""
+    B, T, K, W = 130, 4096, 16, 192
+    x, th0 = setup(B, T, seed=52)
+    state = wb.TpWarmState(B, T, K, 8, x.device)
+    path = _theta_path(th0, 4, 1.0e-3)
+    for th in path:
+        wb.clipper_fwd_tp(x, th, FS, K, W, state=state)
+    tiles_before = state.info()["next_warm_tiles"]
+    th_jump = path[-1] * torch.tensor([1.2, 0.8, 1.2, 0.8], device=x.device)
+    y, zs, zT = wb.clipper_fwd(x, th_jump, FS, want_zT=True)
+    y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th_jump, FS, K, W, want_zT=True, state=state)
+    s = wb.tp_status(st)
+    assert s["n_bad"] > 0 and s["repaired_tiles"] > 0, s
+    assert float((y2 - y).abs().max()) <= 1e-6 and float((zs2 - zs).abs().max()) <= 2e-6
+    assert float((zT2 - zT).abs().max()) <= 2e-6
+    assert state.info()["next_warm_tiles"] > tiles_before
+    for k in range(1, 4):                                    # small steps again from the new place
+        th = th_jump * (1.0 + 1.0e-3 * k)
+        y, _, _ = wb.clipper_fwd(x, th, FS)
+        y2, _, _, st = wb.clipper_fwd_tp(x, th, FS, K, W, state=state)
+        assert float((y2 - y).abs().max()) <= 1e-6
+    assert wb.tp_status(st)["n_bad"] == 0
+
+
+def test_fwd_tp_warm_unchanged_theta_becomes_exact(wb):
+    """theta does not move (validation passes, autotune loops): the secant factor is 0, the snapshots
+    ARE the states, the controller walks the warm-up down to zero tiles, and with chunks starting
+    from the bit-exact states the output equals the sequential kernel's bit for bit."""
+    B, T, K, W = 70, 2048, 8, 192
+    x, th = setup(B, T, seed=53)
+    state = wb.TpWarmState(B, T, K, 8, x.device)
+    y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
+    for _ in range(8):
+        y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, K, W, want_zT=True, state=state)
+        assert wb.tp_status(st)["n_bad"] == 0
+    info = state.info()
+    assert info["last_warm_tiles"] == 0 and info["last_miss"] == 0.0, info
+    assert torch.equal(y2, y) and torch.equal(zs2, zs) and torch.equal(zT2, zT)
+    state.reset()                                            # and a reset really goes back to a cold call
+    wb.clipper_fwd_tp(x, th, FS, K, W, state=state)
+    assert state.info()["last_warm_tiles"] == -1 and state.info()["n_calls"] == 1
+
+
+def test_fwd_tp_warm_state_is_bound_to_its_shape(wb):
+    x, th = setup(64, 1024, seed=54)
+    state = wb.TpWarmState(64, 1024, 4, 8, x.device)
+    with pytest.raises(wb.WdfHipError):
+        wb.clipper_fwd_tp(x, th, FS, 8, 128, state=state)    # other chunking
+    x2, _ = setup(70, 1024, seed=54)
+    with pytest.raises(wb.WdfHipError):
+        wb.clipper_fwd_tp(x2, th, FS, 4, 128, state=state)   # other batch

@@ -1,6 +1,6 @@
 """GPU: randomized stress of the time-parallel clipper kernels.  Random component values (over the
-clip ranges of tf_wdf.py:74,104 and wide diode ranges), amplitudes, shapes, diode counts, chunkings
-and warm-ups (including hopeless ones): the time-parallel forward must equal the sequential forward
+clip ranges of tf_wdf.py:74,104 and wide diode ranges), amplitudes, shapes, diode counts, chunkings,
+warm-ups (including hopeless ones) and warm starts (snapshots from calls at nearby or far-away parameters): the time-parallel forward must equal the sequential forward
 within the verified tolerance whatever the plan (repair path), and the chunked reverse sweep must
 equal the sequential one.  usage: python tools/stress_tp.py [n_cases] [seed]   |   --case <seed> <case> (one case, against the fp64 oracle)"""
 import os, sys
@@ -15,13 +15,14 @@ def case_params(seed, case):
         B=int(rng.choice([1, 3, 64, 70, 200, 513])), T=int(rng.choice([32, 100, 257, 1024, 2048, 4100])),
         Is=10.0 ** rng.uniform(-12, -6), nVt=rng.uniform(0.02, 0.12), R=10.0 ** rng.uniform(2.3, 6.0),
         C=10.0 ** rng.uniform(-10, -6.5), n_up=int(rng.integers(1, 4)), n_down=int(rng.integers(1, 4)),
-        amp=10.0 ** rng.uniform(-2, 1.2), tm=bool(rng.integers(0, 2)), pack=bool(rng.integers(0, 2)),
+        amp=10.0 ** rng.uniform(-2, 1.2), tm=bool(rng.integers(0, 2)), warm=bool(rng.integers(0, 2)),
+        dth=float(rng.choice([0.0, 1e-4, 1e-2, 0.3])),
         K=int(rng.choice([2, 3, 8, 16])), W=int(rng.choice([32, 64, 192, 512])), Kb=int(rng.choice([1, 2, 5, 16])))
 
 
 def run_case(seed, case, oracle=None, verbose=False):
     q = case_params(seed, case)
-    B, T, n_up, n_down, tm, pack = q["B"], q["T"], q["n_up"], q["n_down"], q["tm"], q["pack"]
+    B, T, n_up, n_down, tm, warm = q["B"], q["T"], q["n_up"], q["n_down"], q["tm"], q["warm"]
     fs = workload.FS
     xh = (workload.sweep_batch(B, T, seed=case) * q["amp"] / 5.0).astype(np.float32)
     x = torch.as_tensor(xh, device="cuda")
@@ -29,8 +30,14 @@ def run_case(seed, case, oracle=None, verbose=False):
     xin = x.t().contiguous() if tm else x
     y, zs, zT = wb.clipper_fwd(x, th, fs, n_up=n_up, n_down=n_down, want_zT=True)
     assert torch.isfinite(y).all(), ("sequential produced non-finite output", case, q)
+    state = None
+    if warm:                # two earlier calls on the same inputs with theta dth and 2 dth away leave the snapshots
+        state = wb.TpWarmState(B, T, q["K"], 8, x.device)
+        for m in (2.0, 1.0):
+            wb.clipper_fwd_tp(xin, th * (1.0 - m * q["dth"]), fs, q["K"], q["W"], tol=1e-6, n_up=n_up, n_down=n_down,
+                              time_major=tm, state=state)
     y2, zs2, zT2, st = wb.clipper_fwd_tp(xin, th, fs, q["K"], q["W"], tol=1e-6, n_up=n_up, n_down=n_down, want_zT=True,
-                                         time_major=tm, pack=pack)
+                                         time_major=tm, state=state)
     s = wb.tp_status(st)
     scale = max(1.0, float(y.abs().max()))
     ey = float((y2 - y).abs().max()) / scale
@@ -39,7 +46,7 @@ def run_case(seed, case, oracle=None, verbose=False):
     gen = torch.Generator(device="cuda"); gen.manual_seed(case)
     gy = torch.randn(T, B, device="cuda", generator=gen) / (B * T)
     g1, _ = wb.clipper_bwd(x, th, fs, zs, gy, n_up=n_up, n_down=n_down)
-    g2, _ = wb.clipper_bwd_tp(xin, th, fs, zs, gy, q["Kb"], n_up=n_up, n_down=n_down, time_major=tm, pack=pack)
+    g2, _ = wb.clipper_bwd_tp(xin, th, fs, zs, gy, q["Kb"], n_up=n_up, n_down=n_down, time_major=tm)
     assert torch.isfinite(g1).all() and torch.isfinite(g2).all(), (case, g1, g2, q)
     # per component, against its own size plus 1e-3 of the largest one: a component that is a near-
     # cancelling sum 1000x below the others carries fp32 rounding of the terms, in either sweep
