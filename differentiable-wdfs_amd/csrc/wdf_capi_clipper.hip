@@ -23,12 +23,13 @@ void launch_fwd(const float* x, const float* r, const float* theta, float fs, in
 
 template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_bwd(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
-                const float* zstash, const float* gy, double* ws, float* gz0, int64_t B, int64_t T, hipStream_t s)
+                const float* zstash, const float* gy, double* ws, float* gz0, const float* gzT, int64_t B, int64_t T,
+                hipStream_t s)
 {
     const unsigned grid = (unsigned)((B + 63) / 64);
     EventBracket bracket(s);
     hipLaunchKernelGGL((wdf::clipper_bwd_kernel<DYN_R, SYM, TM, V4>), dim3(grid), dim3(64), 0, s, x, r, theta, fs,
-                       n_up, n_down, zstash, gy, ws, gz0, B, T);
+                       n_up, n_down, zstash, gy, ws, gz0, gzT, B, T);
 }
 
 // expands the 4 boolean template parameters from runtime flags
@@ -163,8 +164,8 @@ int wdf_clipper_fwd(const float* x, const float* r, const float* theta, float fs
 size_t wdf_clipper_bwd_ws_bytes(int64_t B) { return B > 0 ? (size_t)((B + 63) / 64) * 4 * sizeof(double) : 0; }
 
 int wdf_clipper_bwd(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
-                    const float* zstash, const float* gy, void* ws, float* gtheta, float* gz0, int accumulate,
-                    int64_t B, int64_t T, int flags, void* stream)
+                    const float* zstash, const float* gy, void* ws, float* gtheta, float* gz0, const float* gzT,
+                    int accumulate, int64_t B, int64_t T, int flags, void* stream)
 {
     int rc = check_common(x, theta, n_up, n_down, B, T, flags);
     if (rc) return rc;
@@ -173,7 +174,7 @@ int wdf_clipper_bwd(const float* x, const float* r, const float* theta, float fs
     const bool tm = flags & WDF_X_TIME_MAJOR;
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH4(launch_bwd, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy,
-                  (double*)ws, gz0, B, T, (hipStream_t)stream);
+                  (double*)ws, gz0, gzT, B, T, (hipStream_t)stream);
     rc = check_launch("wdf_clipper_bwd");
     if (rc) return rc;
     const int nparts = (int)((B + 63) / 64);

@@ -267,7 +267,7 @@ template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4>
 __global__ __launch_bounds__(64) void clipper_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, const float* __restrict__ zstash, const float* __restrict__ gy,
-    double* __restrict__ ws, float* __restrict__ gz0, int64_t B, int64_t T)
+    double* __restrict__ ws, float* __restrict__ gz0, const float* __restrict__ gzT, int64_t B, int64_t T)
 {
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = b_raw < B;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) void clipper_bwd_kernel(
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
 
     double dL = 0.0, dV = 0.0, dP = 0.0;
-    float gz = 0.0f;
+    float gz = gzT ? gzT[b] : 0.0f;              // adjoint of the final state (a loss that reads zT)
 
     const int64_t nfull = T / kBlk;
     for (int64_t t = T - 1; t >= nfull * kBlk; --t) {     // tail first (highest t)

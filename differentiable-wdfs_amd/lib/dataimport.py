@@ -116,7 +116,9 @@ def write_csv(path, x, y, fs):
     path.parent.mkdir(parents=True, exist_ok=True)
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
-    header = ["#Synthetic stand-in for a missing measurement (differentiable-wdfs_amd)", "#Format: x,y", "#Channels: 2",
+    # no commas in the header rows: the reference parses them with pandas.read_csv(header=None)
+    # (dataimport.py:26), which wants the same field count on every one of them
+    header = ["#Synthetic stand-in for a missing measurement (differentiable-wdfs_amd)", "#Format: x y", "#Channels: 2",
               "#", f"#Sample rate: {float(fs)}Hz", f"#Samples: {len(x)}", "#", "#", "#"]
     assert len(header) == _HEADER_ROWS
     with open(path, "w") as f:

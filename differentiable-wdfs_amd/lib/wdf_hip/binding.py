@@ -58,7 +58,7 @@ def lib():
     L.wdf_clipper_fwd.restype = ci
     L.wdf_clipper_fwd.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, fp, i64, i64, ci, vp]
     L.wdf_clipper_bwd.restype = ci
-    L.wdf_clipper_bwd.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, vp, fp, fp, ci, i64, i64, ci, vp]
+    L.wdf_clipper_bwd.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, vp, fp, fp, fp, ci, i64, i64, ci, vp]
     L.wdf_clipper_bwd_ws_bytes.restype = C.c_size_t
     L.wdf_clipper_bwd_ws_bytes.argtypes = [i64]
     L.wdf_clipper_tp_chunks.restype = ci
@@ -210,8 +210,9 @@ def clipper_fwd(x, theta, fs, r=None, n_up=1, n_down=1, want_stash=True, z0=None
 
 
 def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=False, time_major=False,
-                gtheta=None, accumulate=False, ws=None):
-    """dL/d{Is, nVt, R, C} as a float32[4] device tensor (and dL/dz0 [B] if requested)."""
+                gtheta=None, accumulate=False, ws=None, gzT=None):
+    """dL/d{Is, nVt, R, C} as a float32[4] device tensor (and dL/dz0 [B] if requested).
+    gzT: optional dL/dzT [B] (a loss that also reads the forward's final state)."""
     require_gpu()
     x = _f32_dev(x, "x")
     r = _f32_dev(r, "r")
@@ -229,7 +230,7 @@ def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=Fal
     gz0 = torch.empty((B,), dtype=torch.float32, device=x.device) if want_gz0 else None
     flags = (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag()
     rc = lib().wdf_clipper_bwd(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
-                               _ptr(zstash), _ptr(gy), _ptr(ws), _ptr(gtheta), _ptr(gz0),
+                               _ptr(zstash), _ptr(gy), _ptr(ws), _ptr(gtheta), _ptr(gz0), _ptr(_f32_dev(gzT, "gzT")),
                                1 if accumulate else 0, B, T, flags, _stream())
     _check(rc, "wdf_clipper_bwd")
     return gtheta, gz0

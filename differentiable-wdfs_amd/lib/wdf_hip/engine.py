@@ -21,9 +21,11 @@ TpPlan = namedtuple("TpPlan", ["k_fwd", "warmup", "tol", "k_bwd"])
 N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
 
 
-def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, time_major=False):
+def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, time_major=False, R_min=None):
     """Choose chunk counts from the batch shape and the circuit's memory.  R: the source
-    resistance; with a per-sample resistance pass the LARGEST value present (slowest memory).
+    resistance; with a per-sample resistance pass the LARGEST value present and the smallest as
+    R_min: the memory |1 - 2p| grows with R above Rc = 1/(2 C fs) and with 1/R below it, so the
+    slowest sequence is at one of the two ends.
 
     Sequential mode gives ceil(B/64) waves for 1024 SIMDs, each a dependent chain (a dependent
     VALU op completes every ~3.3 ns on gfx950 where a SIMD could issue one every ~2 ns: tools/ubench).  The
@@ -37,9 +39,7 @@ def plan_time_parallel(B, T, R, C, fs, tol=1.0e-6, time_major=False):
     """
     waves = max(1, -(-B // 64))
     Rc = 1.0 / (2.0 * float(C) * float(fs))
-    Rv = float(R)
-    p = Rc / (Rv + Rc)
-    rho = abs(1.0 - 2.0 * p)
+    rho = max(abs(1.0 - 2.0 * Rc / (float(Rv) + Rc)) for Rv in ((R,) if R_min is None else (R, R_min)))
     if rho <= 0.0:
         W = 8
     elif rho >= 1.0 - 1e-9:
@@ -66,9 +66,16 @@ def resistance_max(r):
         if len(_R_MAX_CACHE) > 256:
             for k in [k for k, v in _R_MAX_CACHE.items() if v[0]() is None]:
                 del _R_MAX_CACHE[k]
-        hit = (weakref.ref(r), r._version, float(r.max()))
+        lo, hi = torch.aminmax(r)
+        hit = (weakref.ref(r), r._version, float(hi), float(lo))
         _R_MAX_CACHE[id(r)] = hit
     return hit[2]
+
+
+def resistance_min(r):
+    """min of a per-sample resistance tensor (same cache entry as resistance_max)."""
+    resistance_max(r)
+    return _R_MAX_CACHE[id(r)][3]
 
 
 _SPLIT_CACHE = {}      # id(x) -> (weakref to x, version, xv, r)
@@ -145,6 +152,41 @@ def clipper(theta, x, fs, r=None, n_up=1, n_down=1, time_major=False, tp=None):
     device (may require grad); x, r: [B,T] (or [T,B] when time_major).  Returns y [T,B].
     tp: a TpPlan (plan_time_parallel) to run the time-parallel kernels, None = sequential."""
     return _ClipperFn.apply(theta, x, r, float(fs), int(n_up), int(n_down), bool(time_major), tp)
+
+
+class _ClipperStatefulFn(torch.autograd.Function):
+    """(y[T,B], zT[B]) = clipper(theta, x (, r), z0[B]): the sequential kernels with the capacitor
+    state handed in and out -- lpf.py-style loops that never call reset() carry it from one
+    forward() to the next -- differentiable w.r.t. theta and z0 (gradients flow back through zT)."""
+
+    @staticmethod
+    def forward(ctx, theta, x, r, z0, fs, n_up, n_down):
+        th = theta.detach().contiguous()
+        z0d = None if z0 is None else z0.detach().contiguous()
+        need = theta.requires_grad or (z0 is not None and z0.requires_grad)
+        y, zs, zT = binding.clipper_fwd(x, th, fs, r=r, n_up=n_up, n_down=n_down, want_stash=need, z0=z0d, want_zT=True)
+        ctx.cfg = (fs, n_up, n_down)
+        ctx.has_r, ctx.has_z0 = r is not None, z0 is not None
+        if need:
+            ctx.save_for_backward(th, x, zs, *([r] if r is not None else []))
+        return y, zT
+
+    @staticmethod
+    def backward(ctx, gy, gzT):
+        fs, n_up, n_down = ctx.cfg
+        saved = ctx.saved_tensors
+        th, x, zs = saved[0], saved[1], saved[2]
+        r = saved[3] if ctx.has_r else None
+        T, B = zs.shape
+        gy = torch.zeros((T, B), dtype=torch.float32, device=x.device) if gy is None else gy.contiguous()
+        gtheta, gz0 = binding.clipper_bwd(x, th, fs, zs, gy, r=r, n_up=n_up, n_down=n_down, want_gz0=True,
+                                          gzT=None if gzT is None else gzT.contiguous())
+        return gtheta, None, None, (gz0 if ctx.has_z0 else None), None, None, None
+
+
+def clipper_stateful(theta, x, fs, r=None, n_up=1, n_down=1, z0=None):
+    """Diode-clipper loop with explicit capacitor state: -> (y [T,B], zT [B]).  z0 [B] or None (reset)."""
+    return _ClipperStatefulFn.apply(theta, x, r, z0, float(fs), int(n_up), int(n_down))
 
 
 class MseStep:
@@ -312,15 +354,18 @@ class _ClipperMseFn(torch.autograd.Function):
                                                         time_major=time_major)
         th = theta.detach().contiguous()
         st.forward(th, x, r)
-        sse, g = st.backward(th, x, target, r)
         LAST_TP_STATUS["status"] = st.status
+        if not theta.requires_grad:          # validation / no_grad losses: one streaming pass for the sum, no sweep
+            d = st.y - target
+            return torch.sum(d * d) / float(B * T)
+        sse, g = st.backward(th, x, target, r)
         ctx.save_for_backward(g.clone())
         return sse[0] / float(B * T)
 
     @staticmethod
     def backward(ctx, gl):
         (g,) = ctx.saved_tensors
-        return gl * g, None, None, None, None, None, None, None, None
+        return gl * g, None, None, None, None, None, None, None, None     # (never reached when theta needs no grad)
 
 
 def clipper_mse(theta, x, target, fs, r=None, n_up=1, n_down=1, tp=None, time_major=False):
@@ -332,19 +377,21 @@ def clipper_mse(theta, x, target, fs, r=None, n_up=1, n_down=1, tp=None, time_ma
     return _ClipperMseFn.apply(theta, x, r, target, float(fs), int(n_up), int(n_down), tp, bool(time_major))
 
 
-_TUNED = {}      # (B, T, n_up, n_down, per-sample R?, R and C to 2 digits) -> TpPlan
+_TUNED = {}      # (B, T, n_up, n_down, per-sample R?, R, C, Is, nVt to 2 digits, fs, device, layout) -> TpPlan
 
 
-def tuned_plan(theta, x, r, fs, R_plan, C, n_up=1, n_down=1, min_samples=1 << 22, time_major=False):
+def tuned_plan(theta, x, r, fs, R_plan, C, n_up=1, n_down=1, min_samples=1 << 22, time_major=False, R_min=None):
     """plan_time_parallel, refined once per (shape, circuit) by autotune_time_parallel when the batch
     is large enough for the ~0.1 s of set-up to pay (>= 4 M samples); later calls with the same
     shape and (to two digits) the same R and C reuse the result.  Training moves R and C slowly and
     every forward is still verified, so a plan tuned at the first epoch stays valid."""
     B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
-    plan = plan_time_parallel(B, T, R_plan, C, fs, time_major=time_major)
+    plan = plan_time_parallel(B, T, R_plan, C, fs, time_major=time_major, R_min=R_min)
     if B * T < min_samples or plan.k_fwd < 2:
         return plan
-    key = (B, T, n_up, n_down, r is not None, f"{R_plan:.1e}", f"{C:.1e}", time_major)
+    th = [float(v) for v in theta.detach().cpu()]
+    key = (B, T, n_up, n_down, r is not None, f"{R_plan:.1e}", f"{C:.1e}", f"{th[0]:.1e}", f"{th[1]:.1e}", float(fs),
+           str(x.device), time_major)
     if key not in _TUNED:
         if len(_TUNED) > 32:
             _TUNED.clear()

@@ -156,7 +156,7 @@ class Circuit:
         tp = self.time_parallel
         if tp == "auto":
             tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, float(cap.C), n_up=dp.N_up, n_down=dp.N_down,
-                                   time_major=True)
+                                   time_major=True, R_min=None if r is None else engine.resistance_min(r))
         loss = engine.clipper_mse(theta, xv, tgt, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp,
                                   time_major=True)
         return loss.as_subclass(tf.Tensor)
@@ -263,6 +263,7 @@ class Circuit:
             # component values live on the host (tiny CPU variables): planning costs no sync
             # per-sample R: the warm-up must outlast the slowest (largest-R) sequence in the batch
             R_plan = float(parts[2]) if r is None else engine.resistance_max(r)
-            tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, float(cap.C), n_up=dp.N_up, n_down=dp.N_down)
+            tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, float(cap.C), n_up=dp.N_up, n_down=dp.N_down,
+                                   R_min=None if r is None else engine.resistance_min(r))
         y = engine.clipper(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp)
         return y.as_subclass(tf.Tensor)

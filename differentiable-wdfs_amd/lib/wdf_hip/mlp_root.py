@@ -144,7 +144,13 @@ def clipper_mlp_segmented(theta2, w, x, r, fs, hidden, n_tanh, plan, tol=1.0e-6,
 def clipper_mlp(theta2, w, x, r, z0, fs, hidden, n_tanh, C, R_static=None, time_parallel="auto"):
     """The MLP-root clipper over a batch: segmented when the plan allows, else the sequential
     kernels.  Returns (y [T,B], zT [B])."""
-    if time_parallel == "auto":
+    # Segments give the forward the sequential result to a verified 1e-6, but their backward is truncated
+    # BPTT through W warm-up steps whose length comes from the RC network's diode-off contraction, not from
+    # the learned root: "auto" therefore segments evaluation-only calls, training keeps the exact sweep.
+    needs_grad = torch.is_grad_enabled() and (theta2.requires_grad or w.requires_grad)
+    if time_parallel == "auto" and needs_grad:
+        time_parallel = None
+    if time_parallel in ("auto", "force"):
         plan = segment_plan(x.shape[0], x.shape[1], engine.resistance_max(r) if r is not None else float(R_static), float(C), fs)
         if plan is not None:
             y, zT, miss = clipper_mlp_segmented(theta2, w, x, r, fs, hidden, n_tanh, plan, z0=z0)

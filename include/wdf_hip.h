@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WDF_HIP_ABI_VERSION 1
+#define WDF_HIP_ABI_VERSION 2
 
 enum {
     WDF_OK = 0,
@@ -85,11 +85,13 @@ int wdf_clipper_fwd(const float* x, const float* r, const float* theta,
  * ws      workspace of wdf_clipper_bwd_ws_bytes(B) bytes
  * gtheta  device float[4] = dL/d{Is, nVt, R, C}; entry 2 is 0 when r != NULL.
  *         Overwritten (not accumulated) unless accumulate != 0.
- * gz0     optional [B]: dL/d z0 (adjoint of the initial state)                          */
+ * gz0     optional [B]: dL/d z0 (adjoint of the initial state)
+ * gzT     optional [B]: dL/d zT, for a loss that also reads the final state wdf_clipper_fwd
+ *         returned (a state carried into the next call under one tape); NULL = 0            */
 int wdf_clipper_bwd(const float* x, const float* r, const float* theta,
                     float fs, int n_up, int n_down,
                     const float* zstash, const float* gy,
-                    void* ws, float* gtheta, float* gz0, int accumulate,
+                    void* ws, float* gtheta, float* gz0, const float* gzT, int accumulate,
                     int64_t B, int64_t T, int flags, void* stream);
 
 size_t wdf_clipper_bwd_ws_bytes(int64_t B);

@@ -19,10 +19,18 @@ is not installable here) -- see that module's docstring for what this does to th
 Goldens:
   g1_rc_lowpass.npz     lpf.py Model: y, MSE loss, dL/dR, dL/dC  (f32 = reference dtype, and f64)
   g2_voltage_divider.npz
-  g3_mlp_clipper.npz    clipper_pot.py ClipperModel with 2x4 / 2x8 / 2x16 trained weights:
+  g3_mlp_clipper.npz    clipper_pot.py ClipperModel with 2x4 / 2x8 / 2x16 / 4x4 / 4x8 trained weights:
                         y, MSE+ESR loss (with the script's argument swap), all weight grads
   g4_diode_pair.npz     diode_pair_func table over a, R, 6 diode configs
   g5_omega.npz          Wright omega: reference toms917 build, scipy, mpmath(40 digits)
+  g7_recorded_programs.npz   the reference's own Model / ClipperModel classes run through THIS
+                        repo's drop-in tf_wdf with the kernel launch captured: the programs the loop
+                        recorder lowered them to (state-space coefficients + their Jacobian to the
+                        trainable components; MLP-clipper weights / inputs).  The GPU tests launch
+                        the kernels on these programs and compare with g1-g3, so no line of the
+                        reference scripts has to travel to the GPU box.
+  g8_dataimport.npz     the reference's dataimport.createDataset / load_diode_data and clipper_pot's
+                        batch_data run on CSV files written by this repo's synthetic-dataset writer
   g6_diode_clipper.npz  tf_wdf.py Parallel(ResVs, C) tree + diode-pair root:
                         (a) forward from reference pieces only (tf_wdf elements + diode_pair_func)
                         (b) f64 forward + autograd grads wrt Is, nVt, R, C with a torch
@@ -181,6 +189,8 @@ def g3_mlp_clipper():
         "2x8": "1N4148 (1U-1D)_2x8_training_3.json",
         "2x16": "1N4148 (1U-1D)_2x16_training_2000.json",
         "2x16_pre": "pretrained/1N4148 (1U-1D)_2x16_pretrained_model.json",
+        "4x4": "1N4148 (1U-1D)_4x4_training_4.json",
+        "4x8": "1N4148 (1U-1D)_4x8_training_500.json",
     }
     for name, fn in models.items():
         mj = json.load(open(os.path.join(REF, "wdf_py/diode_clipper/models", fn)))
@@ -379,9 +389,154 @@ def g6_diode_clipper():
     np.savez(os.path.join(HERE, "g6_diode_clipper.npz"), **out)
 
 
+def _dropin(fn):
+    """Run fn with THIS repo's drop-in library (not the reference's) as tf_wdf / layers."""
+    lib = os.path.join(REPO, "differentiable-wdfs_amd", "lib")
+    saved_path, saved_mods = list(sys.path), {m: sys.modules.pop(m, None) for m in ("tf_wdf", "layers", "dataimport", "model_utils")}
+    sys.path[:] = [lib] + [q for q in sys.path if os.path.join(REF, "wdf_py") not in q and "_tf_shim" not in q]
+    saved_tf = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "tensorflow" or k.startswith("tensorflow.")}
+    try:
+        return fn()
+    finally:
+        sys.path[:] = saved_path
+        for m in ("tf_wdf", "layers", "dataimport", "model_utils"):
+            sys.modules.pop(m, None)
+            if saved_mods[m] is not None:
+                sys.modules[m] = saved_mods[m]
+        sys.modules.update(saved_tf)
+
+
+def g7_recorded_programs():
+    g1 = np.load(os.path.join(HERE, "g1_rc_lowpass.npz"))
+    g2 = np.load(os.path.join(HERE, "g2_voltage_divider.npz"))
+    g3 = np.load(os.path.join(HERE, "g3_mlp_clipper.npz"))
+
+    def run():
+        import tf_wdf as wdf                      # the drop-in
+        from layers import DenseRootModel
+        from wdf_hip import lowering, mlp_root, trace
+        assert "differentiable-wdfs_amd" in wdf.__file__
+        out, got = {}, {}
+
+        def fake_ss(coef, rootp, x, z0, ns, ni, kind, n_up, n_down, want_zT):
+            got.update(coef=coef, x=x, z0=z0, ns=ns, ni=ni, kind=kind)
+            T, B = x.shape[1], x.shape[0]
+            return (coef.sum() * 0.0 + torch.zeros(T, B)).float(), torch.zeros(ns, B)
+
+        def fake_mlp(theta2, w, x, r, z0, fs, hidden, n_tanh, C, R_static=None, time_parallel="auto"):
+            got.update(theta2=theta2, w=w, x=x, r=r, hidden=hidden, n_tanh=n_tanh, fs=fs, C=C)
+            B, T = x.shape
+            return torch.zeros(T, B) + 0.0 * w.sum(), torch.zeros(B)
+
+        trace._device = lambda: torch.device("cpu")
+        lowering._StateSpaceFn.apply = staticmethod(fake_ss)
+        mlp_root.clipper_mlp = fake_mlp
+        for tag, script, xin, comps in (("lpf", "wdf_py/simple_circuits/lpf.py", g1["x"], ("C1.C", "R1.R")),
+                                        ("vdiv", "wdf_py/simple_circuits/voltage_divider.py", g2["x"], ("R1.R", "R2.R"))):
+            ns = extract(os.path.join(REF, script), {"Model"}, {"tf": wdf.tf, "wdf": wdf, "FS": FS})
+            model = ns["Model"]()
+            got.clear()
+            y = model.forward(np.array([xin]))
+            assert tuple(y.shape) == (len(xin), 1, 1)
+            coef = got["coef"]
+            tv = list(model.trainable_variables)
+            want = [getattr(getattr(model, c.split(".")[0]), c.split(".")[1]) for c in comps]
+            assert all(a is b for a, b in zip(tv, want)), "trainable_variables order"
+            J = np.zeros((coef.numel(), len(tv)))
+            for i in range(coef.numel()):
+                gi = torch.autograd.grad(coef[i], tv, retain_graph=True, allow_unused=True)
+                J[i] = [0.0 if g is None else float(g) for g in gi]
+            out[f"{tag}_coef"] = coef.detach().double().numpy()
+            out[f"{tag}_dcoef_dtheta"] = J
+            out[f"{tag}_x"] = got["x"].detach().numpy()
+            out[f"{tag}_dims"] = np.array([got["ns"], got["ni"], got["kind"]])
+            out[f"{tag}_theta_names"] = np.array(comps)
+            print("g7", tag, "ns/ni/kind", out[f"{tag}_dims"], "coef", out[f"{tag}_coef"])
+        for name, fn in (("2x8", "1N4148 (1U-1D)_2x8_training_3.json"), ("4x8", "1N4148 (1U-1D)_4x8_training_500.json")):
+            mj = json.load(open(os.path.join(REF, "wdf_py/diode_clipper/models", fn)))
+            ns = {"tf": wdf.tf, "wdf": wdf, "FS": FS, "C_val": float(g3["C"]), "DenseRootModel": DenseRootModel}
+            extract(os.path.join(REF, "wdf_py/diode_clipper/clipper_pot.py"), {"ClipperModel"}, ns)
+            model = ns["ClipperModel"](mj)
+            got.clear()
+            y = model.forward(g3["x"])
+            assert tuple(y.shape) == (g3["x"].shape[1], g3["x"].shape[0], 1, 1)
+            out[f"clip{name}_w"] = got["w"].detach().double().numpy()
+            out[f"clip{name}_theta2"] = got["theta2"].detach().double().numpy()
+            out[f"clip{name}_x"] = got["x"].detach().numpy()
+            out[f"clip{name}_r"] = got["r"].detach().numpy()
+            out[f"clip{name}_arch"] = np.array([got["hidden"], got["n_tanh"]])
+            out[f"clip{name}_fs_C"] = np.array([got["fs"], got["C"]])
+            assert np.allclose(out[f"clip{name}_w"], g3[f"{name}_theta"], rtol=1e-6), "flat weight order == golden order"
+            print("g7 clipper", name, out[f"clip{name}_arch"], out[f"clip{name}_w"].shape)
+        return out
+
+    out = _dropin(run)
+    np.savez(os.path.join(HERE, "g7_recorded_programs.npz"), **out)
+
+
+def g8_dataimport():
+    """f1 pinned to the reference loader: CSVs in the reference's format written by the drop-in's
+    write_synthetic_dataset, loaded by the REFERENCE's dataimport (createDataset, load_diode_data:
+    dataimport.py:10-59,82-137) and batched by clipper_pot.py's batch_data (:61-80)."""
+    import tempfile
+    from collections import namedtuple
+    DiodeConfig = namedtuple("DiodeConfig", ["name", "Is", "nabla", "Vt", "N_up", "N_down"])
+    cfg = DiodeConfig("1N4148 (1U-1D)", 4.352e-9, 1.906, 25.85e-3, 1, 1)
+    tmp = tempfile.mkdtemp(prefix="g8_")
+    fs_data, seconds = 48000.0, 2.5 + 0.30
+
+    def write():
+        import dataimport as di                   # the drop-in
+        assert "differentiable-wdfs_amd" in di.__file__
+        sim = lambda x, R: np.tanh(2.0 * x) * (0.3 + 1.0e-6 * R)      # any deterministic "measurement"
+        return [os.path.basename(f) for f in di.write_synthetic_dataset(tmp, sim, fs=fs_data, seconds=seconds)]
+
+    files = _dropin(write)
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.modules.pop("dataimport", None)
+    import dataimport as ref_di                   # the reference's (REF/wdf_py/lib is on sys.path)
+    assert REF in ref_di.__file__
+    cwd = os.getcwd()
+    import contextlib, io
+    # Path.iterdir() order is whatever the file system returns; the fixture is taken with the files
+    # enumerated in sorted order (the order the drop-in loader fixes), nothing else is touched
+    from pathlib import Path
+    real_iterdir = Path.iterdir
+    Path.iterdir = lambda self: iter(sorted(real_iterdir(self)))
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            train_data, train_N, val_data, val_N, FSr = ref_di.load_diode_data(cfg, tmp + os.sep)
+    finally:
+        Path.iterdir = real_iterdir
+    batch = 2048
+    ns = extract(os.path.join(REF, "wdf_py/diode_clipper/clipper_pot.py"), {"batch_data"}, {"np": np, "batch_size": batch})
+    with contextlib.redirect_stdout(io.StringIO()):
+        train_X, train_Y = ns["batch_data"](train_data, train_N)
+        val_X, val_Y = ns["batch_data"](val_data, val_N)
+    os.chdir(cwd)
+    out = {"files": np.array(sorted(files)), "fs": np.array(FSr), "train_N": np.array(train_N), "val_N": np.array(val_N),
+           "seconds": np.array(seconds), "batch": np.array(batch),
+           "train_data_shape": np.array(np.asarray(train_data).shape), "val_data_shape": np.array(np.asarray(val_data).shape),
+           "train_X_shape": np.array(train_X.shape), "train_Y_shape": np.array(train_Y.shape),
+           "val_X_shape": np.array(val_X.shape), "val_Y_shape": np.array(val_Y.shape),
+           "train_X_head": train_X[:, :4, :], "train_X_tail": train_X[:, -4:, :], "train_Y_head": train_Y[:, :4], "train_Y_tail": train_Y[:, -4:],
+           "val_X_head": val_X[:, :4, :], "val_Y_tail": val_Y[:, -4:],
+           "train_X_sum": np.array([train_X[..., 0].astype(np.float64).sum(), train_X[..., 1].astype(np.float64).sum()]),
+           "train_Y_sum": np.array(train_Y.astype(np.float64).sum()),
+           "val_X_sum": np.array([val_X[..., 0].astype(np.float64).sum(), val_X[..., 1].astype(np.float64).sum()]),
+           "val_Y_sum": np.array(val_Y.astype(np.float64).sum()),
+           "train_R_per_sequence": train_X[:, 0, 1], "val_R_per_sequence": val_X[:, 0, 1]}
+    np.savez(os.path.join(HERE, "g8_dataimport.npz"), **out)
+    print("g8", files, "train", train_X.shape, train_Y.shape, "val", val_X.shape, val_Y.shape, "fs", FSr)
+    import shutil
+    shutil.rmtree(tmp)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     fns = {"g1": g1_rc_lowpass, "g2": g2_voltage_divider, "g3": g3_mlp_clipper,
-           "g4": g4_diode_pair, "g5": g5_omega, "g6": g6_diode_clipper}
+           "g4": g4_diode_pair, "g5": g5_omega, "g6": g6_diode_clipper, "g7": g7_recorded_programs,
+           "g8": g8_dataimport}
     for w in which:
         fns[w]()

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.wdf_abi_version() == 1
+    assert lib.wdf_abi_version() == 2
 
 
 def test_argument_validation_without_gpu(lib):
@@ -48,7 +48,7 @@ def test_argument_validation_without_gpu(lib):
     assert f(one, None, one, 48000.0, 1, 1, one, None, None, None, 4, 4, 2, None) == -3   # WDF_PREC_F64
     assert f(one, None, one, -1.0, 1, 1, one, None, None, None, 4, 4, 0, None) == -1
     g = lib.wdf_clipper_bwd
-    assert g(one, None, one, 48000.0, 1, 1, None, one, one, one, None, 0, 4, 4, 0, None) == -1
+    assert g(one, None, one, 48000.0, 1, 1, None, one, one, one, None, None, 0, 4, 4, 0, None) == -1
     assert lib.wdf_clipper_bwd_ws_bytes(8192) == 128 * 4 * 8
     assert lib.wdf_clipper_bwd_ws_bytes(0) == 0
 

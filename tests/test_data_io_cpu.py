@@ -121,3 +121,34 @@ def test_pretraining_module_has_no_cpu_path():
         import pytest
         with pytest.raises(WdfHipError):
             dp.synthetic_table(d)
+
+
+def test_loader_matches_the_reference_loader_fixture(tmp_path, golden):
+    """f1 pinned to the reference: tests/golden/gen_golden.py g8 wrote the five CSVs of 1up1down with
+    THIS writer, loaded them with the REFERENCE's dataimport.createDataset / load_diode_data
+    (dataimport.py:10-59,82-137) and cut them with clipper_pot.py's own batch_data (:61-80).  The drop-in
+    loader, on files written the same way, must return the same arrays: trimmed lengths (2.5 s dropped),
+    R from the file name, the train / validation split, shapes, first and last rows, checksums."""
+    from collections import namedtuple
+    import dataimport as di
+    g = golden("g8_dataimport.npz")
+    cfg = namedtuple("DiodeConfig", ["name", "Is", "nabla", "Vt", "N_up", "N_down"])("1N4148 (1U-1D)", 4.352e-9, 1.906,
+                                                                                    25.85e-3, 1, 1)
+    sim = lambda x, R: np.tanh(2.0 * x) * (0.3 + 1.0e-6 * R)          # the generator's "measurement"
+    files = di.write_synthetic_dataset(tmp_path, sim, fs=float(g["fs"]), seconds=float(g["seconds"]))
+    assert sorted(os.path.basename(str(f)) for f in files) == list(g["files"])
+    train, train_N, val, val_N, FS = di.load_diode_data(cfg, tmp_path)
+    assert FS == float(g["fs"]) and train_N == int(g["train_N"]) and val_N == int(g["val_N"])
+    assert tuple(train.shape) == tuple(g["train_data_shape"]) and tuple(val.shape) == tuple(g["val_data_shape"])
+    batch = int(g["batch"])
+    tX, tY = di.batch_data(train, train_N, batch)
+    vX, vY = di.batch_data(val, val_N, batch)
+    for got, name in ((tX, "train_X"), (tY, "train_Y"), (vX, "val_X"), (vY, "val_Y")):
+        assert tuple(got.shape) == tuple(g[f"{name}_shape"]), name
+    assert np.array_equal(tX[:, :4, :], g["train_X_head"]) and np.array_equal(tX[:, -4:, :], g["train_X_tail"])
+    assert np.array_equal(tY[:, :4], g["train_Y_head"]) and np.array_equal(tY[:, -4:], g["train_Y_tail"])
+    assert np.array_equal(vX[:, :4, :], g["val_X_head"]) and np.array_equal(vY[:, -4:], g["val_Y_tail"])
+    assert np.array_equal(tX[:, 0, 1], g["train_R_per_sequence"]) and np.array_equal(vX[:, 0, 1], g["val_R_per_sequence"])
+    for got, ref in ((tX[..., 0], g["train_X_sum"][0]), (tX[..., 1], g["train_X_sum"][1]), (tY, g["train_Y_sum"]),
+                     (vX[..., 0], g["val_X_sum"][0]), (vX[..., 1], g["val_X_sum"][1]), (vY, g["val_Y_sum"])):
+        assert got.astype(np.float64).sum() == float(ref)
