@@ -5,11 +5,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch: diode-clipper forward over
-B x T samples, MSE against synthetic targets, reverse sweep to dL/d{Is, nVt, R, C}, and (N > 1)
-one RCCL all-reduce of the fused [loss, grads] buffer.  Workload = BASELINE.json configs[2]:
-1N4148 diode clipper fwd+bwd, batch 8192 sequences x 4096 samples @ 48 kHz per GPU
-("scaling": "weak": every rank holds its own 8192-sequence shard of the global batch).
+B x T samples, MSE against synthetic targets, reverse sweep to dL/d{Is, nVt, R, C}, (N > 1)
+one RCCL all-reduce of the fused [loss, grads] buffer, and the on-device Adam update.
+Workload = BASELINE.json configs[2]: 1N4148 diode clipper fwd+bwd, batch 8192 sequences x 4096
+samples @ 48 kHz per GPU ("scaling": "weak": every rank holds its own 8192-sequence shard of the
+global batch; --scaling strong splits ONE 8192-sequence batch over the ranks instead).
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+Besides the contract fields the line carries its own audit: `parity` (the bench path's y and fused
+gradient at full size against the CPU oracle, checked after the timed region), `value_batch_major`
+(the same step with x handed over as [B,T], the reference scripts' layout) and `kernel_ms` (min /
+median / max of the per-step HIP-event times of the two recurrence kernels).
 """
 import argparse
 import json
@@ -27,6 +33,9 @@ from wdf_hip import binding, dist as wdist, engine, workload  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 PMC_TRAFFIC_GLOB = os.path.join(REPO, "profiles", "*_pmc_traffic.json")
+BYTES_FWD = 12                 # x 4 + y 4 + z-stash 4   (SURVEY 8d: fwd 8 B + 4 B stash)
+BYTES_BWD = 12                 # x 4 + z-stash 4 + target 4: the fused-MSE sweep rebuilds y from the stash and forms
+                               # dL/dy from the target itself (SURVEY 8d counts x, z and dL/dy: the same 12 B)
 
 
 def measured_traffic(kernel, cfg):
@@ -43,9 +52,13 @@ def measured_traffic(kernel, cfg):
         except (OSError, ValueError, KeyError, TypeError):
             pass
     return None, None
-BYTES_FWD = 12                 # x 4 + y 4 + z-stash 4   (SURVEY 8d: fwd 8 B + 4 B stash)
-BYTES_BWD = 12                 # x 4 + z 4 + dL/dy 4     (the fused-MSE sweep reads y and target instead of
-                               # dL/dy, 16 B; the algorithmic figure stays SURVEY's 12)
+
+
+def _oracle():
+    """The CPU oracle: CHECKER and reported baseline only (never on the measured path)."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle as O
+    return O
 
 
 def cpu_baseline(T, fs, budget_s=12.0):
@@ -54,8 +67,7 @@ def cpu_baseline(T, fs, budget_s=12.0):
     same workload.  Checker code used as a reported baseline only.  The thread count is
     calibrated (the box may expose more logical CPUs than its cgroup lets run): the best
     throughput found and the threads that gave it are what is reported."""
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import oracle as O
+    O = _oracle()
     avail = len(os.sched_getaffinity(0))
     Bs = max(256, 8 * avail)
     x = workload.sweep_batch(8192, T, b0=0, b1=Bs)
@@ -90,6 +102,28 @@ def cpu_baseline(T, fs, budget_s=12.0):
                       f"samples of the same sweep workload ({dt:.1f} s, OpenMP {best} threads, best of {cands})"}
 
 
+def parity_check(stepper, theta, xk, x_host, target, fs, n_global):
+    """After the timed region: one more forward + fused reverse sweep of the BENCH PATH ITSELF (same
+    stepper, same plan, same warm-start state, no update) at the parameters training has reached, against
+    the fp64 CPU oracle over the whole batch: every output sample and the four gradient components."""
+    O = _oracle()
+    th_host = theta.detach().cpu().numpy().astype(np.float64)
+    stepper.forward(theta, xk)
+    sse, g = stepper.backward(theta, xk, target)
+    torch.cuda.synchronize()
+    y = stepper.y.cpu().numpy()
+    t0 = time.perf_counter()
+    loss_ref, g_ref, y_ref = O.clipper_mse_step(th_host, fs, x_host.astype(np.float64), target.cpu().numpy().astype(np.float64),
+                                                dtype=np.float64, n_threads=len(os.sched_getaffinity(0)))
+    got = g.cpu().numpy().astype(np.float64)
+    return {"max_abs_y": float(np.max(np.abs(y - y_ref))),
+            "max_rel_grad": float(np.max(np.abs(got - g_ref) / np.abs(g_ref))),
+            "rel_loss": float(abs(float(sse) / n_global - loss_ref) / loss_ref),
+            "checked": f"all {y.shape[1]} sequences x {y.shape[0]} samples of the bench path's y and its fused gradient "
+                       f"d(mean squared error)/d(Is,nVt,R,C), vs oracle_clipper_mse_step_f64 at the final theta "
+                       f"({time.perf_counter() - t0:.1f} s of CPU)"}
+
+
 def copy_bandwidth_gbs(dev, nbytes=1 << 29, reps=10):
     """Achievable HBM bandwidth on this box: a device-to-device copy of `nbytes` (read + write
     counted), HIP events on the launch stream.  SURVEY 8d's second roofline denominator."""
@@ -105,31 +139,116 @@ def copy_bandwidth_gbs(dev, nbytes=1 << 29, reps=10):
     return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
+class Trainer:
+    """The step of the training loop on one layout of x."""
+
+    def __init__(self, args, x, target, fs, B, T, n_global, world, dev, time_major):
+        self.args, self.world, self.tm = args, world, time_major
+        self.xk = x.t().contiguous() if time_major else x      # one-off: the engine keeps its training inputs resident time-major
+        th_host = workload.clipper_theta()
+        self.theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
+        self.target = target
+        skip = 50 if args.loss == "mse+esr" else 0               # skip_samples, clipper_pot.py:232
+        tp = None if args.sequential else engine.plan_time_parallel(B, T, th_host[2], th_host[3], fs, time_major=time_major)
+        if tp is not None and args.plan:
+            kf, w, kb = (int(v) for v in args.plan.split(","))
+            tp = tp._replace(k_fwd=kf, warmup=w, k_bwd=kb)
+        elif tp is not None:                    # part of the untimed set-up: pick chunk counts on this box
+            tp = engine.autotune_time_parallel(self.theta, self.xk, target, fs, tp, time_major=time_major)
+        self.tp = tp
+        self.stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global, time_major=time_major, loss=args.loss, skip=skip,
+                                      sums_allreduce=wdist.allreduce_sum_ if (world > 1 or args.force_dist) else None,
+                                      warm=not args.cold_forward)
+        # the update that closes a training step (lpf.py:93-94: one Adam per component, its learning
+        # rate scaled to the component; tf_wdf.py:74,104 clip constraints), on the device
+        self.adam = None if args.no_optimizer else binding.Adam(
+            4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
+        self.first_sse = None
+        self.ev = [binding.Event() for _ in range(4)]
+        self.t_fwd, self.t_bwd = [], []
+
+    def step(self, timed=False):
+        # forward (x -> y, state stash), then the MSE-fused reverse sweep (-> SSE, dSSE-mean/dtheta),
+        # then ONE fused all-reduce of [SSE, grads] (no-op on 1 GPU unless --force-dist)
+        # timed: events bracket exactly the forward / reverse recurrence kernel (what rocprofv3
+        # lists under that name), not the verify / combine / reduce helpers of the same call
+        st, ev, args = self.stepper, self.ev, self.args
+        if timed:
+            binding.Event.bracket_next(ev[0], ev[1])
+        st.forward(self.theta, self.xk)
+        if timed:
+            binding.Event.bracket_next(ev[2], ev[3])
+        # one rank and plain MSE: the update rides in the sweep's last kernel; otherwise all-reduce, then update
+        fold = self.adam is not None and self.world == 1 and args.loss == "mse" and not args.force_dist
+        st.backward(self.theta, self.xk, self.target, adam=self.adam if fold else None)
+        buf = st.out                                   # [SSE, grads]: the kernels wrote it in place
+        wdist.allreduce_sum_(buf)
+        if self.adam is not None:
+            if self.first_sse is None:
+                self.first_sse = buf[0:1].clone()          # SSE of the very first step, for the report
+            if not fold:
+                self.adam.apply(self.theta, buf[1:])
+        if timed:
+            self.t_fwd.append(ev[0].elapsed_ms(ev[1]))
+            self.t_bwd.append(ev[2].elapsed_ms(ev[3]))
+        return buf[0], buf[1:]
+
+    def run(self, warmup, steps, dev):
+        """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
+        for _ in range(warmup):
+            self.step()
+        wdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, grad = self.step()
+        torch.cuda.synchronize()
+        wdist.barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if self.world > 1:
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        return float(tmax), loss, grad
+
+
+def spread(ts):
+    ts = sorted(ts)
+    return {"min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1], "n": len(ts)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8192, help="sequences per GPU")
+    ap.add_argument("--batch", type=int, default=8192, help="sequences per GPU (weak scaling) or in total (strong)")
     ap.add_argument("--seq-len", type=int, default=4096)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch sequences on every rank (default).  strong: ONE batch of --batch sequences "
+                         "split over the ranks (SURVEY 8e: global B = 8192 fixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the after-the-run check of y and the gradient against the oracle")
+    ap.add_argument("--no-batch-major", action="store_true", help="skip the second measurement with x as [B,T]")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="skip the on-device Adam update of {Is, nVt, R, C} that closes every step")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="testing aid: run the multi-rank code path (sharding, all-reduce, max-over-ranks timing) with "
                          "every rank on cuda:0 and the gloo backend, where only one GPU is available")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="world size 1 only: create a one-rank RCCL (nccl) process group and run the fused-buffer "
+                         "all-reduce + separate Adam launch of the N > 1 path, so that branch executes on a one-GPU box")
     ap.add_argument("--loss", default="mse", choices=["mse", "mse+esr"],
                     help="mse: the metric's loss (default). mse+esr: clipper_pot.py's training loss past 50 samples, "
                          "fused the same way (one extra streaming pass for the two loss sums)")
     ap.add_argument("--plan", default=None, metavar="KF,W,KB",
-                    help="pin the time-parallel plan (forward chunks, warm-up steps, reverse chunks) instead of "
+                    help="pin the time-parallel plan (forward chunks, cold warm-up steps, reverse chunks) instead of "
                          "autotuning it; used to profile one configuration across several rocprofv3 passes")
     ap.add_argument("--sequential", action="store_true", help="one lane per sequence, no time-parallel chunks")
     ap.add_argument("--cold-forward", action="store_true",
                     help="every forward warms its chunks up from z = 0 (no state kept between steps) instead of "
                          "starting them from the previous step's snapshots")
     ap.add_argument("--x-batch-major", action="store_true",
-                    help="hand the kernels x as [B,T] (the reference scripts' layout) instead of the engine's "
+                    help="make the [B,T] layout (the reference scripts') the HEADLINE measurement instead of the engine's "
                          "resident time-major copy")
     args = ap.parse_args()
 
@@ -137,126 +256,100 @@ def main():
         os.environ["LOCAL_RANK"] = "0"
         world, rank, local = wdist.init(backend="gloo")
     else:
-        world, rank, local = wdist.init()
+        world, rank, local = wdist.init(backend="nccl" if args.force_dist else None, force=args.force_dist)
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.force_dist and world != 1:
+        raise SystemExit("--force-dist is for world size 1")
     binding.require_gpu()
     dev = torch.device("cuda", local)
-    fs, B, T = workload.FS, args.batch, args.seq_len
-    Bg = B * world
+    fs, T = workload.FS, args.seq_len
+    Bg = args.batch * world if args.scaling == "weak" else args.batch
     b0, b1 = wdist.shard_range(Bg, rank, world)
+    B = b1 - b0
+    if B < 1:
+        raise SystemExit("more ranks than sequences")
 
     # ---- resident inputs ---------------------------------------------------------------
-    x = torch.as_tensor(workload.sweep_batch(Bg, T, b0=b0, b1=b1), device=dev)        # [B,T] as the scripts hold it
-    tm = not args.x_batch_major
-    xk = x.t().contiguous() if tm else x          # one-off: the engine keeps its training inputs resident time-major
-    th_host = workload.clipper_theta()
-    theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
+    x_host = workload.sweep_batch(Bg, T, b0=b0, b1=b1)
+    x = torch.as_tensor(x_host, device=dev)                                           # [B,T] as the scripts hold it
     theta_star = torch.tensor(workload.target_theta(), dtype=torch.float32, device=dev)
     target, _, _ = binding.clipper_fwd(x, theta_star, fs, want_stash=False)
-    skip = 50 if args.loss == "mse+esr" else 0               # skip_samples, clipper_pot.py:232
+    skip = 50 if args.loss == "mse+esr" else 0
     n_global = float(Bg * (T - skip))
-    tp = None if args.sequential else engine.plan_time_parallel(B, T, th_host[2], th_host[3], fs, time_major=tm)
-    if tp is not None and args.plan:
-        kf, w, kb = (int(v) for v in args.plan.split(","))
-        tp = tp._replace(k_fwd=kf, warmup=w, k_bwd=kb)
-    elif tp is not None:                    # part of the untimed set-up: pick chunk counts on this box
-        tp = engine.autotune_time_parallel(theta, xk, target, fs, tp, time_major=tm)
-    stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global, time_major=tm, loss=args.loss, skip=skip,
-                             sums_allreduce=wdist.allreduce_sum_ if world > 1 else None, warm=not args.cold_forward)
+    tm = not args.x_batch_major
 
-    # the update that closes a training step (lpf.py:93-94: one Adam per component, its learning
-    # rate scaled to the component; tf_wdf.py:74,104 clip constraints), on the device
-    adam = None if args.no_optimizer else binding.Adam(
-        4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
-    loss_trace = []
-
-    ev = [binding.Event() for _ in range(4)]
-    t_fwd, t_bwd = [], []
-
-    def step(timed):
-        # forward (x -> y, state stash), then the MSE-fused reverse sweep (-> SSE, dSSE-mean/dtheta),
-        # then ONE fused all-reduce of [SSE, grads] (no-op on 1 GPU)
-        # timed: events bracket exactly the forward / reverse recurrence kernel (what rocprofv3
-        # lists under that name), not the verify / combine / reduce helpers of the same call
-        if timed:
-            binding.Event.bracket_next(ev[0], ev[1])
-        stepper.forward(theta, xk)
-        if timed:
-            binding.Event.bracket_next(ev[2], ev[3])
-        # one rank and plain MSE: the update rides in the sweep's last kernel; otherwise all-reduce, then update
-        fold = adam is not None and world == 1 and args.loss == "mse"
-        sse, gtheta = stepper.backward(theta, xk, target, adam=adam if fold else None)
-        buf = stepper.out                              # [SSE, grads]: the kernels wrote it in place
-        wdist.allreduce_sum_(buf)
-        if adam is not None:
-            if not loss_trace:
-                loss_trace.append(buf[0:1].clone())        # SSE of the very first step, for the report
-            if not fold:
-                adam.apply(theta, buf[1:])
-        if timed:
-            t_fwd.append(ev[0].elapsed_ms(ev[1]))
-            t_bwd.append(ev[2].elapsed_ms(ev[3]))
-        return buf[0], buf[1:]
-
-    for _ in range(args.warmup):
-        step(False)
-    wdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, grad = step(False)
-    torch.cuda.synchronize()
-    wdist.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax)
+    main_run = Trainer(args, x, target, fs, B, T, n_global, world, dev, tm)
+    dt, loss, grad = main_run.run(args.warmup, args.steps, dev)
 
     # per-launch durations (HIP events on the launch stream), outside the timed region so the
     # event synchronisation does not perturb the whole-job number
     for _ in range(min(args.steps, 10)):
-        step(True)
+        main_run.step(timed=True)
     torch.cuda.synchronize()
+    tp, stepper = main_run.tp, main_run.stepper
     tp_stat = binding.tp_status(stepper.status) if tp is not None and tp.k_fwd > 1 else None
     buf_last = stepper.out.clone()
+    theta_final = [float(v) for v in main_run.theta]
+
+    # the other layout, same step, same clock
+    other = None
+    if not args.no_batch_major and args.loss == "mse":
+        alt = Trainer(args, x, target, fs, B, T, n_global, world, dev, not tm)
+        dt_alt, _, _ = alt.run(args.warmup, args.steps, dev)
+        other = Bg * T / (dt_alt / args.steps)
+        del alt
+
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity and args.loss == "mse":
+        parity = parity_check(stepper, main_run.theta, main_run.xk, x_host, target, fs, n_global)
 
     if rank == 0:
         copy_gbs = copy_bandwidth_gbs(dev)
         ms_step = dt / args.steps * 1e3
         value = Bg * T / (dt / args.steps)
+        t_fwd, t_bwd = main_run.t_fwd, main_run.t_bwd
         f_ms, b_ms = float(np.mean(t_fwd)), float(np.mean(t_bwd))
         fname = "clipper_fwd_tp_kernel" if (tp is not None and tp.k_fwd > 1) else "clipper_fwd_kernel"
         dom, dom_ms, dom_bytes = (fname, f_ms, BYTES_FWD) if f_ms >= b_ms else ("clipper_bwd_tp_kernel", b_ms, BYTES_BWD)
         achieved = dom_bytes * B * T / (dom_ms * 1e-3) / 1e9
+        warm = None if stepper.warm is None else stepper.warm.info()
         # a kernel's traffic depends on the batch, the layout and its OWN chunking only
         key = {"B": B, "T": T, "x_layout": "time-major" if tm else "batch-major"}
         if tp is not None:
-            key.update({"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup} if dom.startswith("clipper_fwd")
-                       else {"bwd_chunks": tp.k_bwd})
+            if dom.startswith("clipper_fwd"):
+                key.update({"fwd_chunks": tp.k_fwd,
+                            "fwd_warmup_steps": tp.warmup if warm is None else 32 * max(0, warm["last_warm_tiles"])})
+            else:
+                key.update({"bwd_chunks": tp.k_bwd})
         traffic, traffic_src = (None, None) if tp is None else measured_traffic(dom, key)
+        layout_names = {True: "time-major [T,B] resident copy (one-off transpose at data load, outside the timed region)",
+                        False: "batch-major [B,T] as the reference scripts hold it"}
         out = {
             "metric": "samples/sec fwd+bwd, 1N4148 diode clipper @48kHz batch=8192; 1->8 GPU scaling",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"1N4148 diode clipper fwd+bwd (grads wrt Is,nVt,R,C), {args.loss.upper()} loss, "
                                    f"{B} sequences x {T} samples @ {int(fs)} Hz per GPU (BASELINE configs[2])",
                        "global_batch": Bg, "seq_len": T, "parallelism": f"dp{world}",
+                       "collective": ("RCCL all-reduce of the fused 5-float [SSE, grads] buffer on a one-rank nccl group "
+                                      "(--force-dist)") if args.force_dist else
+                                     (None if world == 1 else "all-reduce of the fused 5-float [SSE, grads] buffer per step"),
                        "loss": float(loss) / n_global, "grad": [float(g) for g in grad],
-                       "optimizer": None if adam is None else
+                       "optimizer": None if main_run.adam is None else
                        {"kind": "Adam on device (wdf_adam_step), lr = 1e-3 x component value, clip constraints",
-                        "loss_first_step": float(loss_trace[0]) / n_global,
+                        "loss_first_step": float(main_run.first_sse) / n_global,
                         "loss_last_step": float(buf_last[0]) / n_global,
-                        "theta_final": [float(v) for v in theta]},
-                       "x_layout": "time-major [T,B] resident copy (one-off transpose at data load, outside the timed "
-                                   "region)" if tm else "batch-major [B,T] as the reference scripts hold it",
+                        "theta_final": theta_final},
+                       "x_layout": layout_names[tm],
                        "time_parallel": None if tp is None else
                        {"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup, "verify_tol": tp.tol,
-                        "bwd_chunks": tp.k_bwd, "verify_status": tp_stat,
-                        "warm_start": None if stepper.warm is None else stepper.warm.info()}},
+                        "bwd_chunks": tp.k_bwd, "verify_status": tp_stat, "warm_start": warm}},
+            "value_batch_major" if tm else "value_time_major": other,
+            "kernel_ms": {"fwd": spread(t_fwd), "bwd": spread(t_bwd)},
+            "parity": parity,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -267,7 +360,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, fs)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         wdist.barrier()                      # rank 0 finishes its report before any communicator goes away
         torch.distributed.destroy_process_group()
 

@@ -19,11 +19,21 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for world size 1).
-    Returns (world, rank, local_rank)."""
+_FORCED = False          # init(force=True): the collective runs even at world size 1
+
+
+def init(backend=None, force=False):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1 unless
+    force: then a one-rank group is created so that the RCCL all-reduce of the fused gradient buffer
+    really executes -- the code path of N > 1 on a one-GPU box).  Returns (world, rank, local_rank)."""
+    global _FORCED
     world, rank, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if force and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        _FORCED = True
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -46,7 +56,7 @@ def shard_range(n_global, rank, world):
 
 def allreduce_sum_(buf):
     """In-place SUM all-reduce of one fused buffer (no-op for world size 1)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCED):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 

@@ -147,7 +147,9 @@ class Circuit:
         x = torch.as_tensor(x).as_subclass(torch.Tensor)
         x = (x if x.is_cuda else x.cuda()).float()
         dp, vs, cap = self.root, self.top.P1, self.top.P2
-        parts = [dp.Is, dp.nVt, vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)), cap.C]
+        # a streamed pot resistance overrides the source's own R (which a recorded loop may have left symbolic)
+        Rv = torch.tensor(1.0) if self.per_sample_R is not None else (vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)))
+        parts = [dp.Is, dp.nVt, Rv, cap.C]
         theta = torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(x.device)
         # the sweep reads its inputs time-major: the transposed copy is made once per input tensor
         xv, r = engine.split_channels(x, self.per_sample_R is not None, time_major=True, anchor=anchor)
@@ -250,7 +252,9 @@ class Circuit:
         from . import engine
         dp, vs, cap = self.root, self.top.P1, self.top.P2
         dev = x.device
-        parts = [dp.Is, dp.nVt, vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)), cap.C]
+        # a streamed pot resistance overrides the source's own R (which a recorded loop may have left symbolic)
+        Rv = torch.tensor(1.0) if self.per_sample_R is not None else (vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)))
+        parts = [dp.Is, dp.nVt, Rv, cap.C]
         theta = torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(dev)
         xv, r = engine.split_channels(x, self.per_sample_R is not None, anchor=getattr(self, "_anchor", None))
         if z0 is not None or return_state:

@@ -1,6 +1,7 @@
 """GPU: the clipper_pot.py workflow end to end on synthetic stand-ins for the missing dataset:
-CSV files in the reference's format and names -> load_diode_data -> batch_data -> ClipperModel
-(the script's own loop, recorded) -> MSE+ESR loss with the script's argument order -> Adam ->
+CSV files in the reference's format and names -> load_diode_data -> batch_data -> the pot clipper
+with an MLP root (a hand-written per-sample loop, recorded: tests/loops.py) -> MSE+ESR loss with the
+script's argument order -> Adam ->
 save the weights as JSON in the plugin's schema.  The "measurement" is the GPU diode-pair
 clipper (north-star root); the model being trained is the reference's tanh-MLP root."""
 import json
@@ -47,57 +48,22 @@ def test_clipper_pot_workflow(tmp_path, golden):
     val_X, val_Y = di.batch_data(val_data, val_N, batch_size)
     assert train_X.shape[1:] == (2048, 2) and val_X.shape[0] >= 1
 
-    # ---- clipper_pot.py:94-127 (the script's ClipperModel, verbatim shape)
-    class ClipperModel(tf.Module):
-        def __init__(self, json):  # noqa: A002
-            super(ClipperModel, self).__init__()
-            self.Vs = wdf.ResistiveVoltageSource(45.0e3)
-            self.C = wdf.Capacitor(C_val, FS)
-            self.P1 = wdf.Parallel(self.Vs, self.C)
-            self.model = DenseRootModel(json)
-
-        def forward(self, input):  # noqa: A002
-            sequence_length = input.shape[1]
-            input = tf.cast(tf.expand_dims(input, axis=-1), dtype=tf.float32)  # noqa: A001
-            output_sequence = tf.TensorArray(dtype=tf.float32, size=sequence_length, clear_after_read=False)
-            self.Vs.reset()
-            self.C.reset()
-            for i in range(sequence_length):
-                self.Vs.set_voltage(input[:, i, 0:1])
-                self.Vs.set_resistance(input[:, i, 1:2])
-                self.P1.calc_impedance()
-                model_in = tf.concat((self.P1.reflected(), tf.math.log(self.P1.R)), axis=1)
-                self.model.incident(tf.transpose(model_in, perm=[0, 2, 1]))
-                self.P1.incident(-1 * self.model.reflected())
-                output = wdf.voltage(self.C)
-                output_sequence = output_sequence.write(i, output)
-            output_sequence = output_sequence.stack()
-            return output_sequence
-
+    # ---- the model: pot clipper with a DenseRootModel root, its loop written by hand (tests/loops.py)
+    from loops import PotClipper, mse_plus_esr
     eps = np.finfo(float).eps
-
-    def esr_loss(target_y, predicted_y):
-        mse = tf.math.reduce_sum(tf.math.square(target_y - predicted_y))
-        energy = tf.math.reduce_sum(tf.math.square(target_y))
-        loss_unnorm = mse / tf.cast(energy + eps, tf.float32)
-        N = tf.cast((tf.shape(target_y)[0] * tf.shape(target_y)[1]), tf.float32)
-        return tf.sqrt(loss_unnorm / N)
-
-    mse_loss = tf.keras.losses.MeanSquaredError()
-    loss_func = lambda target, pred: mse_loss(target, pred) + esr_loss(target, pred)  # noqa: E731
     optimizer = tf.keras.optimizers.Adam(learning_rate=0.0001, beta_1=0.5, beta_2=0.999)   # clipper_pot.py:180
 
     g = golden("g3_mlp_clipper.npz")
-    model = ClipperModel(model_json(g, "2x16_pre"))            # warm start from the PRE-trained weights (clipper_pot.py:132-137)
+    model = PotClipper(wdf, FS, C_val, mlp_json=model_json(g, "2x16_pre"))   # warm start from the PRE-trained weights (clipper_pot.py:132-137)
     skip_samples = 50
     tY, vY = tf.constant(train_Y).cuda(), tf.constant(val_Y).cuda()
     losses = []
-    for epoch in range(8):                                     # clipper_pot.py:245-269
+    for epoch in range(8):                                     # the epoch of clipper_pot.py:245-269: train step + validation pass
         with tf.GradientTape() as tape:
-            outs = tf.transpose(model.forward(train_X)[..., 0], perm=[1, 0, 2])
-            loss = loss_func(outs[:, skip_samples:, :], tY[:, skip_samples:, :])
-        val_outs = tf.transpose(model.forward(val_X)[..., 0], perm=[1, 0, 2])
-        val_loss = loss_func(val_outs[:, skip_samples:, :], vY[:, skip_samples:, :])
+            outs = tf.transpose(model.run(train_X)[..., 0], perm=[1, 0, 2])
+            loss = mse_plus_esr(tf, outs[:, skip_samples:, :], tY[:, skip_samples:, :], eps)
+        val_outs = tf.transpose(model.run(val_X)[..., 0], perm=[1, 0, 2])
+        val_loss = mse_plus_esr(tf, val_outs[:, skip_samples:, :], vY[:, skip_samples:, :], eps)
         grads = tape.gradient(loss, model.trainable_variables)
         optimizer.apply_gradients(zip(grads, model.trainable_variables))
         losses.append((float(loss), float(val_loss)))
@@ -107,11 +73,11 @@ def test_clipper_pot_workflow(tmp_path, golden):
     assert losses[-1][0] < 0.1 * losses[1][0] and losses[-1][1] < 0.1 * losses[1][1], losses
     # ---- clipper_pot.py:298-331: write the trained root as JSON, reload it
     out = tmp_path / "model.json"
-    mu.save_model(model.model, out)
+    mu.save_model(model.mlp, out)
     js = json.load(open(out))
     assert [l["activation"] for l in js["layers"]] == ["tanh", "tanh", "tanh", ""] and js["in_shape"] == [None, 2]
     m2 = DenseRootModel(js)
-    assert np.array_equal(m2.layers[0].kernel.numpy(), model.model.layers[0].kernel.numpy())
+    assert np.array_equal(m2.layers[0].kernel.numpy(), model.mlp.layers[0].kernel.numpy())
 
 
 def test_bench_two_rank_path_rehearsal():
@@ -131,9 +97,52 @@ def test_bench_two_rank_path_rehearsal():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["parity"] is None and d["value_batch_major"] > 0          # parity runs on rank 0 at N = 1 only
+    assert set(d["kernel_ms"]["fwd"]) == {"min", "median", "max", "n"}
     assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2048 * 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["bound"] == "hbm" and 0.0 < d["roofline"]["frac"] < 1.0
     assert "cpu_baseline" not in d                           # rank 0 at N = 1 only
     assert d["config"]["optimizer"]["loss_last_step"] < d["config"]["optimizer"]["loss_first_step"]
+
+
+def _run_bench(extra, launcher=None, timeout=900):
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable] + (launcher or []) + [os.path.join(repo, "bench.py")] + extra
+    out = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_force_dist_runs_the_rccl_branch():
+    """bench.py --force-dist: a one-rank nccl (= RCCL) process group, the fused [SSE, grads] device buffer
+    all-reduced on it every step, Adam as its own launch afterwards -- the N > 1 step on the one GPU of the
+    test box.  Same numbers as the folded single-rank step (the all-reduce of one rank is the identity)."""
+    common = ["--steps", "6", "--warmup", "2", "--batch", "2048", "--seq-len", "2048", "--plan", "8,192,16",
+              "--no-cpu-baseline", "--no-batch-major"]
+    d = _run_bench(common + ["--force-dist"])
+    ref = _run_bench(common)
+    assert "RCCL" in d["config"]["collective"] and ref["config"]["collective"] is None
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak"
+    a, b = np.array(d["config"]["optimizer"]["theta_final"]), np.array(ref["config"]["optimizer"]["theta_final"])
+    assert np.max(np.abs(a - b) / np.abs(b)) < 1e-6, (a, b)
+    assert d["parity"]["max_abs_y"] < 1e-6 and d["parity"]["max_rel_grad"] < 1e-4, d["parity"]
+    assert ref["parity"]["max_abs_y"] < 1e-6 and ref["parity"]["max_rel_grad"] < 1e-4, ref["parity"]
+
+
+def test_bench_strong_scaling_rehearsal():
+    """--scaling strong: ONE batch split over the ranks (two ranks on cuda:0 over gloo here); the line says so
+    and `value` counts the global batch once."""
+    import socket, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    d = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "2048", "--seq-len", "2048", "--scaling", "strong",
+                    "--rehearse-on-one-gpu", "--no-batch-major"], launcher=launcher)
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
+    assert "1024 sequences" in d["config"]["workload"]
+    assert abs(d["value"] - 2048 * 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

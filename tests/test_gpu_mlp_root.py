@@ -29,7 +29,7 @@ def model_json(g, name):
     return {"in_shape": [None, 2], "layers": [{"type": "unknown", "activation": "", "shape": [[None, 2]], "weights": []}] + layers}
 
 
-@pytest.mark.parametrize("name", ["2x4", "2x8", "2x16", "2x16_pre"])
+@pytest.mark.parametrize("name", ["2x4", "2x8", "2x16", "2x16_pre", "4x4", "4x8"])
 def test_clipper_model_forward_loss_grads(golden, name):
     import tf_wdf as wdf
     from tf_wdf import tf
@@ -62,11 +62,16 @@ def test_clipper_model_forward_loss_grads(golden, name):
     for d in dense:
         order += [d.kernel, d.bias]
     grads = tape.gradient(loss, order)
-    assert np.max(np.abs(y.numpy() - g[f"{name}_y_f64"])) < 3e-5
-    assert abs(float(loss) - float(g[f"{name}_loss_f64"])) < 2e-5
+    ey = np.max(np.abs(y.numpy() - g[f"{name}_y_f64"]))
     got = np.concatenate([gr.numpy().ravel() for gr in grads])
     ref = g[f"{name}_grad_f64"]
-    assert np.max(np.abs(got - ref)) < 2e-3 * np.max(np.abs(ref)), np.max(np.abs(got - ref)) / np.max(np.abs(ref))
+    # per component: relative to its own size, plus a floor of 1e-5 of the largest component (weights
+    # whose gradient is a cancelling sum carry the fp32 rounding of its terms)
+    eg = np.max(np.abs(got - ref) / (np.abs(ref) + 1e-1 * np.max(np.abs(ref))))
+    print(f"{name}: max|y - ref| {ey:.2e}, loss diff {abs(float(loss) - float(g[f'{name}_loss_f64'])):.2e}, grad {eg:.2e}")
+    assert ey < 5e-6                                            # observed 1.1e-6 .. 2.1e-6 (fp32 tanh chain)
+    assert abs(float(loss) - float(g[f"{name}_loss_f64"])) < 2e-6
+    assert np.all(np.abs(got - ref) <= 1e-4 * np.abs(ref) + 1e-5 * np.max(np.abs(ref))), eg
 
 
 def test_static_resistance_and_capacitor_gradient(oracle, golden):
@@ -143,7 +148,7 @@ def test_segmented_time_parallel_matches_sequential(golden):
     assert mlp_root.segment_plan(B, T, 99.1e3, float(g["C"]), FS) is not None
     mlp_root.LAST_SEGMENT_MISS["miss"] = None
     y_seq, g_seq = run(None)
-    y_tp, g_tp = run("auto")
+    y_tp, g_tp = run("force")          # "auto" keeps training calls on the exact sweep (segments: truncated BPTT)
     assert mlp_root.LAST_SEGMENT_MISS["miss"] is not None and mlp_root.LAST_SEGMENT_MISS["miss"] <= 1e-6
     assert float((y_tp - y_seq).abs().max()) <= 2e-6
     for a, b in zip(g_tp, g_seq):

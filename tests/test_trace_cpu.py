@@ -35,77 +35,53 @@ def capture(monkeypatch):
     return got
 
 
-def lpf_model(wdf):
-    tf = wdf.tf
-
-    class Model(tf.Module):                       # the shape of lpf.py:20-49
-        def __init__(self):
-            super().__init__()
-            self.Vs = wdf.IdealVoltageSource()
-            self.R1 = wdf.Resistor(1000, True)
-            self.C1 = wdf.Capacitor(1.0e-6, FS, True)
-            self.S1 = wdf.Series(self.R1, self.C1)
-            self.I1 = wdf.Inverter(self.S1)
-
-        def forward(self, input):  # noqa: A002
-            sequence_length = input.shape[1]
-            input = tf.cast(tf.expand_dims(input, axis=-1), dtype=tf.float32)  # noqa: A001
-            output_sequence = tf.TensorArray(dtype=tf.float32, size=sequence_length, clear_after_read=False)
-            self.I1.calc_impedance()
-            for i in range(sequence_length):
-                self.Vs.set_voltage(input[:, i])
-                self.Vs.incident(self.I1.reflected())
-                self.I1.incident(self.Vs.reflected())
-                output = wdf.voltage(self.C1)
-                output_sequence = output_sequence.write(i, output)
-            return output_sequence.stack()
-
-    return Model()
-
-
-def test_recorded_lpf_loop_equals_probed_matrices(capture):
+def test_recorded_ladder_loop_equals_probed_matrices(capture):
+    """A hand-written loop over a two-capacitor ladder (tests/loops.py): what the recorder lowers it to
+    is the state-space program the Circuit probe derives from the same tree."""
     import tf_wdf as wdf
-    m = lpf_model(wdf)
+    from loops import BridgedLadder
+    m = BridgedLadder(wdf, FS)
     x = np.random.default_rng(0).standard_normal((3, 40))
-    out = m.forward(x)
-    assert tuple(out.shape) == (40, 3, 1)                          # TensorArray.stack() layout, lpf.py:48
-    ref, _ = wdf.Circuit(m.I1, m.Vs, m.C1).matrices()
-    assert capture["ns"] == 1 and capture["ni"] == 1 and capture["kind"] == 0
+    out = m.run(x)
+    assert tuple(out.shape) == (40, 3, 1)                          # TensorArray.stack() layout
+    ref, _ = wdf.Circuit(m.top, m.src, m.Cb).matrices()
+    assert capture["ns"] == 2 and capture["ni"] == 1 and capture["kind"] == 0
     assert torch.allclose(capture["coef"].double(), ref, rtol=1e-6, atol=1e-9)
     assert torch.allclose(capture["x"][:, :, 0].double(), torch.as_tensor(x), atol=1e-6)
-    # gradients reach R and C through the recorded coefficients
-    g = torch.autograd.grad(capture["coef"][0], [m.R1.R, m.C1.C])
-    assert all(float(v.abs()) > 0 for v in g)
-    # the capacitor now holds a numeric final state (carried into the next forward, lpf.py quirk)
-    assert isinstance(m.C1.z, torch.Tensor) and tuple(m.C1.z.shape) == (3, 1)
-    m.forward(x)                                                   # second call records again
-    assert capture["z0"] is None or tuple(capture["z0"].shape) == (1, 3)
+    # gradients reach the components through the recorded coefficients
+    g = torch.autograd.grad(capture["coef"][0], m.params, allow_unused=True)
+    assert sum(1 for v in g if v is not None and float(v.abs()) > 0) >= 2
+    # the capacitors now hold numeric final states (carried into the next run unless reset() is called)
+    assert isinstance(m.Cb.z, torch.Tensor) and tuple(m.Cb.z.shape) == (3, 1)
+    m.run(x)                                                       # second run records again
+    assert capture["z0"] is None or tuple(capture["z0"].shape) == (2, 3)
 
 
 def test_recorder_rejects_nonuniform_loops(capture):
     import tf_wdf as wdf
+    from loops import BridgedLadder
     from wdf_hip import trace
     tf = wdf.tf
-    m = lpf_model(wdf)
+    m = BridgedLadder(wdf, FS)
     x = tf.cast(tf.expand_dims(np.ones((2, 4)), axis=-1), dtype=tf.float32)
     ta = tf.TensorArray(dtype=tf.float32, size=4)
-    m.I1.calc_impedance()
+    m.top.calc_impedance()
     with pytest.raises(trace.WdfTraceError):
-        for i in range(4):
-            m.Vs.set_voltage(x[:, i])
-            m.Vs.incident(m.I1.reflected())
-            up = m.Vs.reflected()
-            m.I1.incident(up * (2.0 if i == 2 else 1.0))           # step 2 is a different map
-            ta = ta.write(i, wdf.voltage(m.C1))
+        for n in range(4):
+            m.src.set_voltage(x[:, n])
+            m.src.incident(m.top.reflected())
+            down = m.src.reflected()
+            m.top.incident(down * (2.0 if n == 2 else 1.0))        # step 2 is a different map
+            ta = ta.write(n, wdf.voltage(m.Cb))
         ta.stack()
     trace._current = None
     # a product of two waves is not an adaptor operation
-    m2 = lpf_model(wdf)
-    m2.I1.calc_impedance()
-    m2.Vs.set_voltage(x[:, 0])
-    w = m2.I1.reflected()
+    m2 = BridgedLadder(wdf, FS)
+    m2.top.calc_impedance()
+    m2.src.set_voltage(x[:, 0])
+    w = m2.top.reflected()
     with pytest.raises(trace.WdfTraceError):
-        _ = m2.Vs.reflected() * m2.Vs.reflected() if False else (w + 0.0) * (w + 0.0)
+        _ = (w + 0.0) * (w + 0.0)
     trace._current = None
 
 
