@@ -46,7 +46,7 @@ def test_forward_vs_oracle(oracle, B, T):
     # looser tolerance -> fewer iterations (the ballot stops the wave earlier), still accurate
     y2, _, it2 = wb.clipper_asym_fwd(dev(x), dev(THETA6), FS, wb.ASYM_NEWTON_F64, tol=1e-6, want_iters=True)
     assert float(it2.sum()) <= float(it.sum())
-    assert np.max(np.abs(y2.cpu().numpy() - ref)) < 3e-5
+    assert np.max(np.abs(y2.cpu().numpy() - ref)) < 3e-6
     yw, _, _ = wb.clipper_asym_fwd(dev(x), dev(THETA6), FS, wb.ASYM_OMEGA_F32)
     # MODEL error of the closed form, not rounding: eqn 39 drops the reverse diode's saturation
     # current (Rp Is_down = 4.2 mV at the root); the state recursion amplifies it by ~1/(1-0.9)

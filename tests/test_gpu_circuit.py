@@ -3,7 +3,8 @@ goldens and the oracle's generic tree interpreter.  These read like the referenc
 the circuits are built exactly as lpf.py:20-28, voltage_divider.py:17-25 and
 clipper_pot.py:94-101 build them.
 
-Tolerances: y absolute 3e-5 (2e-6 for the linear trees); gradients relative 2e-3.
+Tolerances: y absolute 3e-6 (observed <= 3.4e-7; 2e-6 for the linear trees); gradients relative 2e-4 / 3e-4
+(observed <= 3e-5) -- about 10x what the kernels deliver on MI355X.
 """
 import numpy as np
 import pytest
@@ -51,8 +52,8 @@ def test_rc_lowpass_forward_and_grads(wdf, golden):
     grads = tape.gradient(loss, [C1.C, R1.R])                    # lpf.py:90,98-99 order
     assert np.max(np.abs(outs.numpy()[:, 0] - g["y_f64"])) < 2e-6
     assert abs(float(loss) - float(g["loss_f64"])) < 1e-6
-    assert rel(grads[0].numpy(), g["dC_f64"]) < 2e-3
-    assert rel(grads[1].numpy(), g["dR_f64"]) < 2e-3
+    assert rel(grads[0].numpy(), g["dC_f64"]) < 2e-4
+    assert rel(grads[1].numpy(), g["dR_f64"]) < 2e-4
 
 
 def test_rc_lowpass_trainable_variables_order(wdf):
@@ -95,8 +96,8 @@ def test_voltage_divider(wdf, golden):
         loss = tf.keras.losses.MeanSquaredError()(outs, cuda(g["target"][:, None]))
     grads = tape.gradient(loss, [R1.R, R2.R])
     assert np.max(np.abs(outs.numpy()[:, 0] - g["x"] * 2000.0 / 2100.0)) < 1e-6      # analytic
-    assert rel(grads[0].numpy(), g["dR1_f64"]) < 2e-3
-    assert rel(grads[1].numpy(), g["dR2_f64"]) < 2e-3
+    assert rel(grads[0].numpy(), g["dR1_f64"]) < 2e-4
+    assert rel(grads[1].numpy(), g["dR2_f64"]) < 2e-4
 
 
 # ---- diode clipper through the element API -----------------------------------------------
@@ -120,9 +121,9 @@ def test_diode_clipper_api(wdf, golden, cfg, n_up, n_down, generic):
         y = circ(cuda(g["x"]))
         loss = tf.reduce_mean(tf.square(y - cuda(g["target"])))
     grads = tape.gradient(loss, [dp.Is, dp.nVt, Vs.R, Cap.C])
-    assert np.max(np.abs(y.numpy() - g[f"y_{cfg}_f64"])) < 3e-5
+    assert np.max(np.abs(y.numpy() - g[f"y_{cfg}_f64"])) < 3e-6
     got = np.array([float(x) for x in grads])
-    assert rel(got, g[f"grad_{cfg}_f64"]) < 2e-3, (got, g[f"grad_{cfg}_f64"])
+    assert rel(got, g[f"grad_{cfg}_f64"]) < 2e-4, (got, g[f"grad_{cfg}_f64"])
 
 
 def test_diode_clipper_pot_channel(wdf, golden):
@@ -135,8 +136,8 @@ def test_diode_clipper_pot_channel(wdf, golden):
         y = circ(cuda(xin))
         loss = tf.reduce_mean(tf.square(y - cuda(g["target"])))
     grads = tape.gradient(loss, [dp.Is, dp.nVt, Cap.C])
-    assert np.max(np.abs(y.numpy() - g["y_1u1d_rpot_f64"])) < 3e-5
-    assert rel(np.array([float(x) for x in grads]), g["grad_1u1d_rpot_f64"]) < 2e-3
+    assert np.max(np.abs(y.numpy() - g["y_1u1d_rpot_f64"])) < 3e-6
+    assert rel(np.array([float(x) for x in grads]), g["grad_1u1d_rpot_f64"]) < 2e-4
 
 
 # ---- trees beyond the two scripts, against the oracle's interpreter ------------------------
@@ -169,13 +170,13 @@ def test_two_capacitor_two_source_tree_vs_oracle(wdf, oracle):
     yref = O.tree_fwd(oc, theta, x.astype(np.float64))
     gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
     y = circ(cuda(x))
-    assert np.max(np.abs(y.numpy() - yref)) < 3e-5
+    assert np.max(np.abs(y.numpy() - yref)) < 3e-6
     loss = tf.reduce_sum(y * cuda(gy))
     params = [Vs1.R, C1.C, R1.R, Vs2.R, C2.C, dp.Is, dp.nVt]
     grads = tf.GradientTape().gradient(loss, params)
     gref = O.tree_grad(oc, theta, x.astype(np.float64), gy.astype(np.float64))
     got = np.array([float(v) for v in grads])
-    assert rel(got, gref) < 3e-3, (got, gref)
+    assert rel(got, gref) < 3e-4, (got, gref)
 
 
 def test_three_state_linear_ladder_vs_oracle(wdf, oracle):
@@ -208,7 +209,7 @@ def test_three_state_linear_ladder_vs_oracle(wdf, oracle):
     gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
     grads = tf.GradientTape().gradient(tf.reduce_sum(y * cuda(gy)), [Ra.R, Ca.C, Rb.R, Cb.C, Rc.R, Cc.C])
     gref = O.tree_grad(oc, theta, x.astype(np.float64), gy.astype(np.float64))
-    assert rel(np.array([float(v) for v in grads]), gref) < 3e-3
+    assert rel(np.array([float(v) for v in grads]), gref) < 3e-4
 
 
 def test_training_loop_rc_lowpass_converges(wdf, golden):
@@ -264,11 +265,11 @@ def test_hpf_clipper_topology_vs_oracle(wdf, oracle):
     theta = np.array([33.0e3, 1.0e3, 22.0e-9, 4.352e-9, 25.85e-3 * 1.906], dtype=np.float32).astype(np.float64)
     yref = O.tree_fwd(oc, theta, x.astype(np.float64))
     y = circ(cuda(x))
-    assert np.max(np.abs(y.numpy() - yref)) < 3e-5
+    assert np.max(np.abs(y.numpy() - yref)) < 3e-6
     gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
     grads = tf.GradientTape().gradient(tf.reduce_sum(y * cuda(gy)), [R.R, Vs.R, C.C, dp.Is, dp.nVt])
     gref = O.tree_grad(oc, theta, x.astype(np.float64), gy.astype(np.float64))
-    assert rel(np.array([float(v) for v in grads]), gref) < 3e-3
+    assert rel(np.array([float(v) for v in grads]), gref) < 3e-4
 
 
 def test_dataset_shaped_batch_config_c4(wdf, oracle):
@@ -300,7 +301,7 @@ def test_dataset_shaped_batch_config_c4(wdf, oracle):
     pick = np.random.default_rng(0).choice(B, 12, replace=False)
     th64 = theta.astype(np.float32).astype(np.float64)
     ref = oracle.clipper_fwd(th64, FS, x[pick].astype(np.float64), r=r[pick].astype(np.float64))
-    assert np.max(np.abs(y.numpy()[:, pick] - ref)) < 3e-5
+    assert np.max(np.abs(y.numpy()[:, pick] - ref)) < 3e-6
     gy = np.zeros((T, B))
     gy[50:] = 2.0 * y.numpy()[50:] / ((T - 50) * B)
     _, gref = oracle.clipper_fwd_bwd(th64, FS, x[pick].astype(np.float64), gy[:, pick], r=r[pick].astype(np.float64))
@@ -309,7 +310,7 @@ def test_dataset_shaped_batch_config_c4(wdf, oracle):
     y2 = circ2(cuda(np.stack([x[pick], r[pick]], axis=-1)))
     g2 = tf.GradientTape().gradient(tf.reduce_sum(y2 * cuda(gy[:, pick])), [dp.Is, dp.nVt, Cap.C])
     got = np.array([float(v) for v in g2])
-    assert rel(got, gref[[0, 1, 3]]) < 3e-3
+    assert rel(got, gref[[0, 1, 3]]) < 3e-4
     assert all(np.isfinite(float(v)) for v in g)
 
 

@@ -119,7 +119,7 @@ def test_tp_full_size_against_oracle(wb, oracle):
     assert s["n_bad"] == 0, s
     pick = np.random.default_rng(5).choice(B, 16, replace=False)
     ref = oracle.clipper_fwd(theta.astype(np.float32).astype(np.float64), FS, x[pick].astype(np.float64))
-    assert np.max(np.abs(y[:, torch.as_tensor(pick, device="cuda")].cpu().numpy() - ref)) < 3e-5
+    assert np.max(np.abs(y[:, torch.as_tensor(pick, device="cuda")].cpu().numpy() - ref)) < 2e-6
     tgt, _, _ = wb.clipper_fwd(xd, dev(workload.target_theta()), FS, want_stash=False)
     gy = (2.0 * (y - tgt) / y.numel()).contiguous()
     g_seq, _ = wb.clipper_bwd(xd, th, FS, zs, gy)
@@ -272,7 +272,7 @@ def test_fused_mse_esr_step_matches_autograd_and_oracle(wb, oracle, time_major):
     (energy of the model output, first 50 samples dropped) fused into the reverse sweep, against
     (a) the same loss written with torch ops on the kernel's y and differentiated by autograd through
     the plain reverse sweep (5e-5 relative), and (b) the fp64 oracle's adjoint fed the fp64 dL/dy of
-    that loss (2e-3 relative, the gradient tolerance of every fp32-vs-fp64 comparison here)."""
+    that loss (1e-4 relative, the gradient tolerance of every fp32-vs-fp64 comparison here)."""
     from wdf_hip import engine, workload
     B, T, skip = 96, 2048, 50
     x, th = setup(B, T, seed=31)
@@ -306,7 +306,7 @@ def test_fused_mse_esr_step_matches_autograd_and_oracle(wb, oracle, time_major):
     (gy64,) = torch.autograd.grad(l64, [y64])
     _, gref = oracle.clipper_fwd_bwd(th64, FS, x64, gy64.numpy())
     got = g.cpu().numpy().astype(np.float64)
-    assert np.max(np.abs(got - gref) / np.abs(gref)) < 2e-3, (got, gref)
+    assert np.max(np.abs(got - gref) / np.abs(gref)) < 1e-4, (got, gref)
     assert abs(float(step.loss[2]) - float(l64)) <= 1e-4 * float(l64)
 
 
@@ -480,3 +480,36 @@ def test_fwd_tp_warm_state_is_bound_to_its_shape(wb):
     x2, _ = setup(70, 1024, seed=54)
     with pytest.raises(wb.WdfHipError):
         wb.clipper_fwd_tp(x2, th, FS, 4, 128, state=state)   # other batch
+
+
+def test_bench_path_at_full_size_against_the_oracle(wb, oracle):
+    """bench.py's own step at its own size -- MseStep(time_major=True, warm=True) forward and the
+    MSE-fused reverse sweep with the Adam update folded into its last kernel, 8192 x 4096 -- checked END
+    TO END against the fp64 oracle's fused step over the whole batch: every y sample (2e-6), the loss and
+    the four gradient components (1e-4; observed 1.4e-7 / 3e-6) at the third step of a training run,
+    i.e. with warm-started chunks and parameters that have moved."""
+    import os
+    from wdf_hip import engine, workload
+    B, T = 8192, 4096
+    xh = workload.sweep_batch(B, T)
+    x = dev(xh)
+    xt = x.t().contiguous()
+    th0 = workload.clipper_theta()
+    theta = dev(th0)
+    tgt, _, _ = wb.clipper_fwd(x, dev(workload.target_theta()), FS, want_stash=False)
+    tp = engine.plan_time_parallel(B, T, th0[2], th0[3], FS, time_major=True)
+    st = engine.MseStep(B, T, FS, tp, x.device, time_major=True, warm=True)
+    adam = wb.Adam(4, lr=[1e-3 * float(v) for v in th0], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0])
+    for _ in range(3):
+        th_before = theta.clone()
+        st.forward(theta, xt)
+        sse, g = st.backward(theta, xt, tgt, adam=adam)
+    assert not torch.equal(theta, th_before) and st.warm.info()["last_warm_tiles"] >= 0
+    assert wb.tp_status(st.status)["n_bad"] == 0
+    loss_ref, g_ref, y_ref = oracle.clipper_mse_step(th_before.cpu().numpy().astype(np.float64), FS, xh.astype(np.float64),
+                                                     tgt.cpu().numpy().astype(np.float64), dtype=np.float64,
+                                                     n_threads=len(os.sched_getaffinity(0)))
+    assert np.max(np.abs(st.y.cpu().numpy() - y_ref)) < 2e-6
+    assert abs(float(sse) / (B * T) - loss_ref) < 1e-4 * loss_ref
+    got = g.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - g_ref) / np.abs(g_ref)) < 1e-4, (got, g_ref)
