@@ -91,32 +91,35 @@ TpGeom tp_geom(int64_t T, int n_chunks)
 }
 
 // state: nullptr (stateless, cold every call) or the caller's persistent warm-start buffer
-// [TpCtl][snapshot ring kTpRing x J x K x B floats]
+// [TpCtl][tile tickets + accumulators][snapshot ring kTpRing x J x K x B floats]
 struct TpWarm { wdf::TpCtl* ctl; float* snap; int J; };
+
+// per-tile tickets, 4 accumulator words, per-tile repair flags
+inline size_t tp_ticket_bytes(int64_t B) { return ((2 * (size_t)((B + 63) / 64) + 4) * sizeof(unsigned) + 63) / 64 * 64; }
 
 template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
                    float* zstash, const float* z0, float* zT, float* zwarm, float* zend, wdf::TpStatus* status,
-                   float tol, int64_t B, int64_t T, TpGeom g, int64_t W, TpWarm warm, int general, hipStream_t s)
+                   float tol, int64_t B, int64_t T, TpGeom g, int64_t W, TpWarm warm, unsigned* tickets, int general,
+                   hipStream_t s)
 {
-    const unsigned gseq = (unsigned)((B + 63) / 64);
-    const dim3 grid(gseq, (unsigned)g.K);
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)g.K);
 #define WDF_FWD_TP(STASH_)                                                                                   \
     hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, TM, V4, STASH_, float>), grid, dim3(64), 0, s, x, r, theta, \
-                       fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, status, warm.ctl, warm.snap, warm.J, B, B, T,   \
-                       g.L, W, general)
+                       fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, status, warm.ctl, warm.snap, warm.J, tickets, tol, \
+                       B, B, T, g.L, W, general)
     {
         EventBracket bracket(s);
         if (zstash) WDF_FWD_TP(true); else WDF_FWD_TP(false);
     }
 #undef WDF_FWD_TP
-    if (g.K > 1) {
-#define WDF_VERIFY(STASH_)                                                                                   \
-    hipLaunchKernelGGL((wdf::clipper_tp_verify_fix_kernel<DYN_R, SYM, TM, STASH_>), dim3(gseq), dim3(64), 0, s, x, r,   \
-                       theta, fs, n_up, n_down, y, zstash, zT, zwarm, zend, B, T, (int64_t)g.K, g.L, W, tol, status,     \
-                       warm.ctl, warm.snap, warm.J, general)
-        if (zstash) WDF_VERIFY(true); else WDF_VERIFY(false);
-#undef WDF_VERIFY
+    if (g.K > 1) {                              // blocks of unflagged tiles (normally all of them) leave at once
+#define WDF_REPAIR(STASH_)                                                                                   \
+    hipLaunchKernelGGL((wdf::clipper_tp_repair_kernel<DYN_R, SYM, TM, STASH_>), dim3(grid.x), dim3(64), 0, s, x, r, theta, \
+                       fs, n_up, n_down, y, zstash, zT, zwarm, zend, B, T, (int64_t)g.K, g.L, tol, status, warm.ctl,       \
+                       warm.snap, warm.J, tickets, general)
+        if (zstash) WDF_REPAIR(true); else WDF_REPAIR(false);
+#undef WDF_REPAIR
     }
 }
 
@@ -124,24 +127,24 @@ template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
                    const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
                    float* part, double* ws, float* gz0, int64_t B, int64_t T, TpGeom g, const float* gcoef,
-                   int64_t skip, unsigned* ticket, float* gtheta, int accumulate, float* sse_out, wdf::AdamTail adam,
+                   int64_t skip, unsigned* tickets, float* gtheta, int accumulate, float* sse_out, wdf::AdamTail adam,
                    hipStream_t s)
 {
-    const int64_t Bh = B;
-    const dim3 grid((unsigned)((Bh + 63) / 64), (unsigned)g.K);
-#define WDF_BWD_TP(MSE_, V_)                                                                               \
-    hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, TM, V4, MSE_, V_>), grid, dim3(64), 0, s, x, r, theta, \
-                       fs, n_up, n_down, zstash, gy, target, zT, gscale, part, B, Bh, T, g.L, gcoef, skip, ticket)
-    {
-        EventBracket bracket(s);
-        if (gcoef) WDF_BWD_TP(2, float);                     // MSE + ESR
-        else if (target) WDF_BWD_TP(1, float);
-        else WDF_BWD_TP(0, float);
-    }
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)g.K);
+    // ONE launch: the sweep; the last chunk wave of every tile combines the tile's chunk records, the last
+    // tile reduces, applies the chain rule and (optionally) Adam
+#define WDF_BWD_TP(MSE_)                                                                                     \
+    hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, TM, V4, MSE_, float>), grid, dim3(64), 0, s, x, r, theta, \
+                       fs, n_up, n_down, zstash, gy, target, zT, gscale, part, B, B, T, g.L, gcoef, skip, tickets, ws,   \
+                       gz0, gtheta, accumulate, sse_out, adam)
+    EventBracket bracket(s);
+    if (gcoef) WDF_BWD_TP(2);                                // MSE + ESR
+    else if (target) WDF_BWD_TP(1);
+    else WDF_BWD_TP(0);
 #undef WDF_BWD_TP
-    hipLaunchKernelGGL(wdf::clipper_bwd_tp_combine_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, part, B,
-                       (int64_t)g.K, ws, gz0, ticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam);
 }
+
+inline size_t bwd_ticket_bytes(int64_t B) { return (((size_t)((B + 63) / 64) + 4) * sizeof(unsigned) + 63) / 64 * 64; }
 
 }  // namespace
 
@@ -188,7 +191,8 @@ int wdf_clipper_tp_chunks(int64_t T, int n_chunks) { return T > 0 ? tp_geom(T, n
 
 size_t wdf_clipper_fwd_tp_ws_bytes(int64_t B, int n_chunks)
 {
-    return (B > 0 && n_chunks > 0) ? (size_t)2 * (size_t)n_chunks * (size_t)B * sizeof(float) : 0;
+    // zwarm [K][B], zend [K][B], then (stateless calls) the tile tickets
+    return (B > 0 && n_chunks > 0) ? (size_t)2 * (size_t)n_chunks * (size_t)B * sizeof(float) + tp_ticket_bytes(B) : 0;
 }
 
 static int fwd_tp_common(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
@@ -206,16 +210,22 @@ static int fwd_tp_common(const float* x, const float* r, const float* theta, flo
     float* zwarm = (float*)ws;
     float* zend = zwarm + (size_t)g.K * (size_t)B;
     TpWarm warm{nullptr, nullptr, 1};
+    unsigned* tickets;
     if (state) {
         if (max_warm_tiles < 1 || max_warm_tiles > wdf::kTpMaxWarmTiles)
             return fail(WDF_EINVAL, "max_warm_tiles must be in 1..%d", wdf::kTpMaxWarmTiles);
         if (g.K >= (1 << 20)) return fail(WDF_EINVAL, "too many chunks for a warm-start state");
-        warm = TpWarm{(wdf::TpCtl*)state, (float*)((char*)state + sizeof(wdf::TpCtl)), max_warm_tiles + 1};
+        tickets = (unsigned*)((char*)state + sizeof(wdf::TpCtl));            // zeroed by the reset, left clean by every launch
+        warm = TpWarm{(wdf::TpCtl*)state, (float*)((char*)tickets + tp_ticket_bytes(B)), max_warm_tiles + 1};
+    } else {                                                                  // the caller's ws holds garbage: clear the tickets
+        tickets = (unsigned*)(zend + (size_t)g.K * (size_t)B);
+        const hipError_t e = hipMemsetAsync(tickets, 0, tp_ticket_bytes(B), (hipStream_t)stream);
+        if (e != hipSuccess) return fail(WDF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
     const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH4(launch_fwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
-                  zwarm, zend, (wdf::TpStatus*)status, tol, B, T, g, W, warm, (flags & WDF_GENERAL_ROOT) ? 1 : 0,
+                  zwarm, zend, (wdf::TpStatus*)status, tol, B, T, g, W, warm, tickets, (flags & WDF_GENERAL_ROOT) ? 1 : 0,
                   (hipStream_t)stream);
     return check_launch("wdf_clipper_fwd_tp");
 }
@@ -231,13 +241,17 @@ int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta, float
 size_t wdf_clipper_fwd_tp_state_bytes(int64_t B, int n_chunks, int max_warm_tiles)
 {
     if (B <= 0 || n_chunks <= 0 || max_warm_tiles < 1 || max_warm_tiles > wdf::kTpMaxWarmTiles) return 0;
-    return sizeof(wdf::TpCtl) + (size_t)wdf::kTpRing * (size_t)(max_warm_tiles + 1) * (size_t)n_chunks * (size_t)B * sizeof(float);
+    return sizeof(wdf::TpCtl) + tp_ticket_bytes(B) +
+           (size_t)wdf::kTpRing * (size_t)(max_warm_tiles + 1) * (size_t)n_chunks * (size_t)B * sizeof(float);
 }
 
-int wdf_clipper_fwd_tp_state_reset(void* state, void* stream)
+int wdf_clipper_fwd_tp_state_reset(void* state, int64_t B, int min_warm_tiles, void* stream)
 {
-    if (!state) return fail(WDF_EINVAL, "null state");
-    const hipError_t e = hipMemsetAsync(state, 0, sizeof(wdf::TpCtl), (hipStream_t)stream);
+    if (!state || B <= 0) return fail(WDF_EINVAL, "null state / bad B");
+    if (min_warm_tiles < 0 || min_warm_tiles > wdf::kTpMaxWarmTiles) return fail(WDF_EINVAL, "min_warm_tiles must be in 0..%d", wdf::kTpMaxWarmTiles);
+    hipError_t e = hipMemsetAsync(state, 0, sizeof(wdf::TpCtl) + tp_ticket_bytes(B), (hipStream_t)stream);
+    if (e == hipSuccess && min_warm_tiles > 0)                                // TpCtl::j_floor is its last 32-bit word
+        e = hipMemsetD32Async((hipDeviceptr_t)((char*)state + sizeof(wdf::TpCtl) - 4), min_warm_tiles, 1, (hipStream_t)stream);
     return e == hipSuccess ? WDF_OK : fail(WDF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
 }
 
@@ -262,7 +276,17 @@ static int bwd_tp_common(const float* x, const float* r, const float* theta, flo
 size_t wdf_clipper_bwd_tp_ws_bytes(int64_t B, int n_chunks)
 {
     if (B <= 0 || n_chunks <= 0) return 0;
-    return (size_t)n_chunks * wdf::kTpOut * (size_t)B * sizeof(float) + wdf_clipper_bwd_ws_bytes(B) + 16;   // + ticket
+    // [tiles][4] doubles, [K][9][B] floats, then the tickets (tiles done + one per tile)
+    const size_t body = ((size_t)n_chunks * wdf::kTpOut * (size_t)B * sizeof(float) + wdf_clipper_bwd_ws_bytes(B) + 63) / 64 * 64;
+    return body + bwd_ticket_bytes(B);
+}
+
+int wdf_clipper_bwd_tp_ws_init(void* ws, int64_t B, int n_chunks, void* stream)
+{
+    const size_t total = wdf_clipper_bwd_tp_ws_bytes(B, n_chunks);
+    if (!ws || total == 0) return fail(WDF_EINVAL, "null ws / bad B, n_chunks");
+    const hipError_t e = hipMemsetAsync((char*)ws + total - bwd_ticket_bytes(B), 0, bwd_ticket_bytes(B), (hipStream_t)stream);
+    return e == hipSuccess ? WDF_OK : fail(WDF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
 }
 
 int wdf_clipper_bwd_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
@@ -298,10 +322,9 @@ static int bwd_tp_common(const float* x, const float* r, const float* theta, flo
     const TpGeom g = tp_geom(T, n_chunks);
     double* wsd = (double*)ws;                                       // [nparts][4] doubles first (8-byte aligned)
     float* part = (float*)((char*)ws + wdf_clipper_bwd_ws_bytes(B)); // then [K][9][B] floats
-    unsigned* ticket = (unsigned*)((char*)ws + wdf_clipper_bwd_tp_ws_bytes(B, n_chunks) - 16);   // then the block ticket
+    unsigned* ticket = (unsigned*)((char*)ws + wdf_clipper_bwd_tp_ws_bytes(B, n_chunks) - bwd_ticket_bytes(B));   // then the tickets
     const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
-    // sweep, then combine -- whose last block also reduces, applies the chain rule and (optionally) Adam
     WDF_DISPATCH4(launch_bwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy, target,
                   zT, gscale, part, wsd, gz0, B, T, g, gcoef, skip,
                   ticket, gtheta, accumulate, target ? sse : nullptr, adam, (hipStream_t)stream);

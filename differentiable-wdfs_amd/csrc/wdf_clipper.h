@@ -392,21 +392,21 @@ static __global__ __launch_bounds__(256) void clipper_grad_reduce_kernel(
 // Reverse sweep -- EXACT.  The adjoint recurrence is linear in the incoming adjoint G of the
 // chunk's last step:  gz_n = alpha_n G + beta_n, and every parameter sum is affine in G:
 // S = A G + Bsum.  Each chunk runs the sweep once carrying (alpha, beta) and the six sums;
-// a tiny second kernel then walks the K chunks of every sequence from last to first
-// (G_{k-1} = alpha_k G_k + beta_k) and adds up the totals.  No approximation, only a
-// different (fixed) summation order.
+// the last of a tile's chunk waves to finish then walks the K chunks of its 64 sequences from last
+// to first (G_{k-1} = alpha_k G_k + beta_k) and adds up the totals (bwd_tp_finish).  No
+// approximation, only a different (fixed) summation order; one launch.
 //
 // Forward -- SPECULATE, VERIFY, (RARELY) REPAIR.  The state recurrence is a contraction
 // (|dz'/dz| = |Da (1-p) - p| < 1; the reference itself discards the first 50 outputs of every
 // 2048-sample sequence to "let state build up", clipper_pot.py:232,248), so chunk k can start a few
 // steps before its own first step from a GUESS of the state there and has forgotten the guess's
 // error when it reaches its own first step.  It records the state it arrives with (zwarm[k]) and
-// the state it ends with (zend[k]); a verify kernel checks |zwarm[k] - zend[k-1]| <= tol for every
+// the state it ends with (zend[k]); the tile's last wave (tp_finish) checks |zwarm[k] - zend[k-1]| <= tol for every
 // sequence and chunk (chunk 0 starts from the true initial state; the step is non-expansive, so a
 // chunk that starts within tol stays within tol, and what it hands on has shrunk by the chunk's own
 // contraction: deviations do not add up unless the circuit barely contracts over a whole chunk,
-// where the bound is the sum of the boundary misses, <= K tol).  Where a boundary fails, the verify
-// kernel re-runs THAT chunk for the wave's 64 sequences from the correct state until the re-run
+// where the bound is the sum of the boundary misses, <= K tol).  Where a boundary fails, that wave
+// re-runs THAT chunk for the wave's 64 sequences from the correct state until the re-run
 // meets what the speculative pass stored (or the chunk ends).  No host sync anywhere.
 //
 // Where the guess comes from:
@@ -418,14 +418,17 @@ static __global__ __launch_bounds__(256) void clipper_grad_reduce_kernel(
 //         previous call's snapshot 32 j steps before t0 -- extrapolated along the parameter path
 //         from the last two sets (secant: the step ratio comes from the theta history) -- and only
 //         has to forget the CHANGE of that state between two optimizer steps (1e-3 .. 1e-5 V, not
-//         1 V).  j is steered on the device from the miss the verify kernel measured: one tile more
-//         when the miss came within 4x of tol, one less when it was 64x below.
+//         1 V).  j is steered on the device from the miss that verification measured: one tile more
+//         when the miss came within 4x of tol, one less when it was 64x below (one tile changes the
+//         miss by ~30x at the headline circuit).  fp32 rounding keeps the measured miss of two converged
+//         trajectories near 3e-8, so with tol = 1e-6 the controller does not probe below the warm-up it
+//         starts from (three tiles under the cold one) unless theta stands still.
 
 struct TpStatus {
     int n_bad;        // number of (sequence, chunk) pairs whose arrival state missed by more than tol
     float max_miss;   // largest |zwarm - zend| seen (bit pattern compared as int: values >= 0)
-    int fallback_ran; // number of (64-sequence tile, chunk) re-runs the verify kernel did
-    unsigned ticket;  // verify-kernel blocks finished; the last one updates the warm-start control block
+    int fallback_ran; // number of (64-sequence tile, chunk) re-runs the verification did
+    unsigned pad;
 };
 
 constexpr int kTpRing = 3;            // snapshot sets: the one being written, the previous call's, the one before
@@ -442,7 +445,7 @@ struct TpCtl {
     float last_miss;  // largest boundary miss of the last call
     int n_calls;
     int geom;         // (K << 8) | J of the calls that wrote the snapshots; a different geometry restarts cold
-    int pad;
+    int j_floor;      // the controller never goes below this many warm-up tiles (host: 0; j_floor = max pins it)
 };
 static_assert(sizeof(TpCtl) == 64, "TpCtl layout");
 
@@ -529,6 +532,21 @@ __device__ __forceinline__ void store_v(float* __restrict__ p, const LaneSeqs<V>
 {
 #pragma unroll
     for (int j = 0; j < VT<V>::N; ++j) p[off + q.b[j]] = vget(v, j);
+}
+
+// Store that another wave of THIS launch will read (the tile's last wave verifies the chunk boundaries):
+// agent-scope relaxed atomic store = write-through `global_store_dword ... sc1`, read back with the
+// matching agent-scope loads (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 on both sides).
+template <typename V>
+__device__ __forceinline__ void publish_v(float* __restrict__ p, const LaneSeqs<V>& q, int64_t off, V v)
+{
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) __hip_atomic_store(p + off + q.b[j], vget(v, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ float load_published(const float* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Row store: `row` is a wave-uniform pointer to a [B] row of a time-major array, the lane adds its
@@ -643,7 +661,7 @@ __device__ __forceinline__ void clipper_fwd_tp_body(
 #pragma unroll
         for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z);
     }
-    store_v<V>(zwarm, q, k * B, z);                         // the state this chunk arrives with at t0
+    publish_v<V>(zwarm, q, k * B, z);                       // the state this chunk arrives with at t0
     for (; t < nfull_end; t += kTile) {                     // ---- owned tiles
 #pragma unroll
         for (int j = 0; j < N; ++j)
@@ -679,62 +697,43 @@ __device__ __forceinline__ void clipper_fwd_tp_body(
         store_row_v<V>(yrow, q, fwd_step<DYN_R, SYM, V, FAST>(c, xin, rin, z));
         yrow += B;
     }
-    store_v<V>(zend, q, k * B, z);
+    publish_v<V>(zend, q, k * B, z);
     if (snapw != nullptr) store_v<V>(snapw, q, 0, z);        // snapshot 0 = the end state
     if (zT && t1 == T) store_v<V>(zT, q, 0, z);
 }
 
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V>
-__global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
-    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
-    float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
-    const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
-    TpStatus* __restrict__ status, const TpCtl* __restrict__ ctl, float* __restrict__ snap, int J, int64_t B,
-    int64_t Bh, int64_t T, int64_t L, int64_t W, int general)
-{
-    // the verify kernel (next launch on the stream) accumulates into the status word: clear it here
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = TpStatus{0, 0.0f, 0, 0u};
-    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    if constexpr (!DYN_R) {
-        if (!general && series_only_omega1(c)) {                        // wave-uniform: every practical diode
-            clipper_fwd_tp_body<DYN_R, SYM, TM, VEC4, STASH, V, true>(c, x, r, y, zstash, z0, zT, zwarm, zend, theta, ctl,
-                                                                      snap, J, B, Bh, T, L, W);
-            return;
-        }
-    }
-    clipper_fwd_tp_body<DYN_R, SYM, TM, VEC4, STASH, V, false>(c, x, r, y, zstash, z0, zT, zwarm, zend, theta, ctl, snap,
-                                                               J, B, Bh, T, L, W);
-}
-
-// Re-run of chunk [t0, t1) for this wave's 64 sequences from the exact state z.  With a stash the
-// re-run stops at the first tile boundary where every lane is back within tol_conv of what the
-// speculative pass stored (everything after that point is then within tol_conv of the exact
-// trajectory already); returns true if it ran to the chunk's end (z = end state then).
+// Re-run of chunk [t0, t1) for this wave's 64 sequences from the exact state z, 8 steps at a time.
+// With a stash (and `may_stop`: the speculative pass's stash is readable from here) the re-run stops
+// at the first 32-step boundary where every lane is back within tol_conv of what the speculative
+// pass stored (everything after that point is then within tol_conv of the exact trajectory
+// already); returns true if it ran to the chunk's end (z = end state then).
 template <bool DYN_R, bool SYM, bool TM, bool STASH, bool FAST>
 __device__ __forceinline__ bool tp_rerun_chunk(const ClipConsts& c, const float* __restrict__ x,
-                                               const float* __restrict__ r, float* __restrict__ y,
-                                               float* __restrict__ zstash, float* __restrict__ snapw, int J, int64_t K,
-                                               int64_t b, int64_t B, int64_t T, int64_t t0, int64_t t1, float tol_conv,
-                                               float& z)
+                                            const float* __restrict__ r, float* __restrict__ y,
+                                            float* __restrict__ zstash, float* __restrict__ snapw, int J, int64_t K,
+                                            int64_t b, int64_t B, int64_t T, int64_t t0, int64_t t1, float tol_conv,
+                                            bool may_stop, float& z)
 {
-    for (int64_t t = t0; t < t1; t += kTile) {
-        if constexpr (STASH) {
-            if (t > t0) {
-                const float zs = zstash[t * B + b];
-                if (__builtin_amdgcn_ballot_w64(!(fabsf(z - zs) <= tol_conv)) == 0) return false;
+    for (int64_t t = t0; t < t1; t += kBlk) {
+        if ((t - t0) % kTile == 0) {
+            if constexpr (STASH) {
+                if (may_stop && t > t0) {
+                    const float zs = zstash[t * B + b];
+                    if (__builtin_amdgcn_ballot_w64(!(fabsf(z - zs) <= tol_conv)) == 0) return false;
+                }
             }
+            if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1) && (t1 - t) % kTile == 0)
+                snapw[((t1 - t) / kTile) * K * B + b] = z;
         }
-        if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1) && (t1 - t) % kTile == 0)
-            snapw[((t1 - t) / kTile) * K * B + b] = z;
-        float xv[kTile], rv[kTile];
+        float xv[kBlk], rv[kBlk];
 #pragma unroll
-        for (int i = 0; i < kTile; ++i) {
+        for (int i = 0; i < kBlk; ++i) {
             const int64_t tt = (t + i < t1) ? t + i : t1 - 1;
             xv[i] = load_one<TM>(x, b, B, T, tt);
             rv[i] = DYN_R ? load_one<TM>(r, b, B, T, tt) : 1.0f;
         }
 #pragma unroll
-        for (int i = 0; i < kTile; ++i) {
+        for (int i = 0; i < kBlk; ++i) {
             if (t + i < t1) {                                   // wave-uniform
                 if constexpr (STASH) zstash[(t + i) * B + b] = z;
                 y[(t + i) * B + b] = fwd_step<DYN_R, SYM, float, FAST>(c, xv[i], rv[i], z);
@@ -745,67 +744,53 @@ __device__ __forceinline__ bool tp_rerun_chunk(const ClipConsts& c, const float*
     return true;
 }
 
-// Verification + chunk-local repair in one launch.  Wave w owns sequences [64 w, 64 w + 64): it
-// walks the chunk boundaries in time order comparing zwarm[k] with the end state of chunk k-1 (the
-// repaired one if that chunk was just re-run); where any of its sequences misses by more than tol
-// the wave re-runs chunk k (tp_rerun_chunk).  The common case is 2 (K-1) coalesced loads and an
-// exit.  The last block to finish (device-scope ticket in the status word) advances the warm-start
-// control block: ring head, theta history and the number of warm-up tiles for the next call.
-template <bool DYN_R, bool SYM, bool TM, bool STASH>
-__global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
-    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
-    float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
-    float* __restrict__ zT, const float* __restrict__ zwarm, float* __restrict__ zend, int64_t B, int64_t T,
-    int64_t K, int64_t L, int64_t W, float tol, TpStatus* __restrict__ status, TpCtl* __restrict__ ctl,
-    float* __restrict__ snap, int J, int general)
+// Ticket area: [TpAcc][per-tile tickets][per-tile repair flags].  TpAcc: what the tiles' verifications add up,
+// and the count of tiles done.
+struct TpAcc { int max_miss_bits; int pad; unsigned tiles_done; unsigned n_bad; };   // {tiles_done, n_bad}: one 8-byte word
+
+// The tail of the forward kernel.  Every wave, once its stores have landed, takes a ticket of its
+// 64-sequence tile; the LAST of the tile's K chunk waves verifies the tile: |zwarm[k] - zend[k-1]| <= tol
+// for every chunk boundary (2 (K-1) loads), adds the tile's result to the totals, and flags the tile
+// when a boundary failed.  The last TILE to finish hands the totals to the host-visible status word
+// and advances the warm-start control block: ring head, theta history and the number of warm-up tiles
+// for the next call.  Repairs are left to clipper_tp_repair_kernel, the next launch on the stream: a
+// re-run rewrites output rows that other waves of THIS launch have written, possibly through another
+// XCD's L2, and only a kernel boundary orders those two writes.
+template <bool DYN_R>
+__device__ __forceinline__ void tp_finish(const float* __restrict__ theta, const float* zwarm, const float* zend,
+                                          TpStatus* __restrict__ status, TpCtl* __restrict__ ctl, int J,
+                                          unsigned* tickets, float tol, int64_t B, int64_t L, int64_t W)
 {
+    const int64_t K = gridDim.y;
+    const unsigned ntiles = gridDim.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's outputs and boundary states have landed
+    unsigned old = 0;
+    if (threadIdx.x == 0) old = atomicAdd(&tickets[4 + blockIdx.x], 1u);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(K - 1)) return;
+    if (threadIdx.x == 0) tickets[4 + blockIdx.x] = 0u;          // left clean for the next launch
+    // (no acquire fence: the boundary states were stored write-through and are read with agent-scope loads)
+
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;
-    const bool stateful = ctl != nullptr && ctl->geom == (int)((K << 8) | J);
-    const int head = stateful ? ctl->head : 0;
     float miss = 0.0f;
-    int nbad = 0, nrep = 0;
-    bool fixed_prev = false;                                    // wave-uniform: chunk k-1 was re-run to its end
-    float ze_fix = 0.0f;
-    // 8 boundaries' 16 loads in flight together: one at a time this loop is K dependent HBM
-    // round trips (measured 8.7 us for K = 16, more than the rest of the kernel's launch)
-    for (int64_t k0 = 1; k0 < K; k0 += 8) {
-        float zw[8], ze[8];
+    int nbad = 0;
+    // 16 boundaries' 32 loads in flight together: one at a time this loop is K dependent round trips
+    constexpr int kBatch = 16;
+    for (int64_t k0 = 1; k0 < K; k0 += kBatch) {
+        float zw[kBatch], ze[kBatch];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < kBatch; ++j) {
             const int64_t k = (k0 + j < K) ? k0 + j : K - 1;   // clamped: re-reads the last boundary
-            zw[j] = zwarm[k * B + b];
-            ze[j] = zend[(k - 1) * B + b];
+            zw[j] = load_published(zwarm + k * B + b);
+            ze[j] = load_published(zend + (k - 1) * B + b);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t k = k0 + j;
-            if (k < K) {                                        // wave-uniform
-                const float e = fixed_prev ? ze_fix : ze[j];
-                const float m = fabsf(zw[j] - e);
-                const bool bad = !(m <= tol);                   // NaN counts as bad
+        for (int j = 0; j < kBatch; ++j) {
+            const float m = fabsf(zw[j] - ze[j]);
+            if (k0 + j < K) {
                 miss = fmaxf(miss, m);
-                nbad += bad ? 1 : 0;
-                fixed_prev = false;
-                if (__builtin_amdgcn_ballot_w64(bad)) {         // cold path: re-run chunk k from the exact state
-                    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-                    const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
-                    float* __restrict__ snapw =
-                        (snap != nullptr && k + 1 < K) ? snap + ((int64_t)((head + 1) % kTpRing) * J * K + k) * B : nullptr;
-                    float z = e;
-                    bool done;
-                    bool fast = false;
-                    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
-                    if (fast) done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, !DYN_R>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, z);
-                    else done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, false>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, z);
-                    if (done) {
-                        zend[k * B + b] = z;
-                        if (zT && t1 == T) zT[b] = z;
-                        ze_fix = z;
-                        fixed_prev = true;
-                    }
-                    ++nrep;
-                }
+                nbad += !(m <= tol) ? 1 : 0;                    // NaN counts as bad
             }
         }
     }
@@ -818,23 +803,31 @@ __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
     }
     if (threadIdx.x != 0) return;
     // Returning atomics: the value coming back means the update has been performed at the device-wide
-    // coherence point, so the ticket (issued after the wait) cannot overtake them -- no cache
-    // write-back fence needed, nothing but these words is handed to the last block.
+    // coherence point, so the tile count (issued after the wait) cannot overtake them.
+    TpAcc* acc = reinterpret_cast<TpAcc*>(tickets);             // 64-byte aligned (the 8-byte atomic needs 8)
+    unsigned* tile_bad = tickets + 4 + ntiles;
     int seen = 0;
-    if (wmax > 0.0f) seen += atomicMax(reinterpret_cast<int*>(&status->max_miss), __float_as_int(wmax));
-    if (wbad) seen += atomicAdd(&status->n_bad, wbad);
-    if (nrep) seen += atomicAdd(&status->fallback_ran, nrep);
-    if (ctl == nullptr) return;
+    if (wmax > 0.0f) seen += atomicMax(&acc->max_miss_bits, __float_as_int(wmax));
+    if (wbad) tile_bad[blockIdx.x] = 1u;
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) : : "memory");
-    if (atomicAdd(&status->ticket, 1u) != gridDim.x - 1) return;
-    // ---- last block: advance the warm-start state
-    const float mm = __int_as_float(atomicMax(reinterpret_cast<int*>(&status->max_miss), 0));
-    const int nb = atomicAdd(&status->n_bad, 0);
+    // one 64-bit add carries the tile count (low word) and this tile's bad pairs (high word)
+    const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&acc->tiles_done),
+                                              1ull | ((unsigned long long)(unsigned)wbad << 32));
+    if ((unsigned)prev != ntiles - 1) return;
+    // ---- last tile: totals to the status word, accumulators left clean, warm-start state advanced
+    const int mm_bits = atomicMax(&acc->max_miss_bits, 0);
+    const int nb = (int)(prev >> 32) + wbad;
+    const float mm = __int_as_float(mm_bits);
+    *status = TpStatus{nb, mm, 0, 0u};
+    *acc = TpAcc{0, 0, 0u, 0u};
+    if (ctl == nullptr) return;
+    const bool stateful = ctl->geom == (int)((K << 8) | J);
+    const int head = stateful ? ctl->head : 0;
     const int valid = stateful ? ctl->valid : 0;
     int j = ctl->j_next;
-    if (valid == 0) {                                           // that was the cold call: start two tiles under its warm-up
-        const int jc = (int)((W + kTile - 1) / kTile);
-        j = jc - 2 < 1 ? 1 : jc - 2;
+    if (valid == 0) {                                           // that was the cold call: start three tiles under its warm-up
+        const int jc = (int)((W + kTile - 1) / kTile);              // (an O(1 V) guess needs ~5 tiles here; a change of 1e-3 V two)
+        j = jc - 3 < 1 ? 1 : jc - 3;
         ctl->j_used = -1;
     } else {
         ctl->j_used = j;
@@ -843,7 +836,8 @@ __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
         else if (mm * 64.0f < tol) j -= 1;
     }
     const int jmax = (int)(L / kTile) < J - 1 ? (int)(L / kTile) : J - 1;
-    ctl->j_next = j < 0 ? 0 : (j > jmax ? jmax : j);
+    const int jmin = ctl->j_floor < jmax ? ctl->j_floor : jmax;
+    ctl->j_next = j < jmin ? jmin : (j > jmax ? jmax : j);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ctl->th2[i] = stateful ? ctl->th1[i] : theta[i]; ctl->th1[i] = theta[i]; }
     ctl->head = (head + 1) % kTpRing;
@@ -851,6 +845,76 @@ __global__ __launch_bounds__(64) void clipper_tp_verify_fix_kernel(
     ctl->geom = (int)((K << 8) | J);
     ctl->last_miss = mm;
     ctl->n_calls = stateful ? ctl->n_calls + 1 : 1;
+}
+
+// Chunk-local repair, launched behind every time-parallel forward; a block leaves at once unless the
+// forward flagged its tile.  For a flagged tile the wave walks the chunk boundaries in time order
+// comparing zwarm[k] with the end state of chunk k-1 (the repaired one if that chunk was just re-run)
+// and re-runs chunk k wherever one of its 64 sequences misses by more than tol (tp_rerun_chunk).
+// `head`: the ring slot the forward wrote its snapshots to is one past ctl->head BEFORE the forward
+// advanced it, i.e. ctl->head itself now.
+template <bool DYN_R, bool SYM, bool TM, bool STASH>
+__global__ __launch_bounds__(64) void clipper_tp_repair_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
+    float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
+    float* __restrict__ zT, const float* __restrict__ zwarm, float* __restrict__ zend, int64_t B, int64_t T,
+    int64_t K, int64_t L, float tol, TpStatus* __restrict__ status, const TpCtl* __restrict__ ctl,
+    float* __restrict__ snap, int J, unsigned* __restrict__ tickets, int general)
+{
+    unsigned* tile_bad = tickets + 4 + gridDim.x;
+    if (tile_bad[blockIdx.x] == 0u) return;                     // the common case
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+    bool fast = false;
+    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
+    const int slot = (ctl != nullptr && snap != nullptr) ? ctl->head : 0;
+    int nrep = 0;
+    bool fixed_prev = false;                                    // wave-uniform: chunk k-1 was re-run to its end
+    float ze_fix = 0.0f;
+    for (int64_t k = 1; k < K; ++k) {
+        const float e = fixed_prev ? ze_fix : zend[(k - 1) * B + b];
+        const float m = fabsf(zwarm[k * B + b] - e);
+        fixed_prev = false;
+        if (__builtin_amdgcn_ballot_w64(!(m <= tol)) == 0) continue;
+        const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+        float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
+        float z = e;
+        bool done;
+        if (fast) done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, !DYN_R>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, true, z);
+        else done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, false>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, true, z);
+        if (done) {
+            zend[k * B + b] = z;
+            if (zT && t1 == T) zT[b] = z;
+            ze_fix = z;
+            fixed_prev = true;
+        }
+        ++nrep;
+    }
+    if (threadIdx.x == 0) {
+        tile_bad[blockIdx.x] = 0u;
+        if (nrep) atomicAdd(&status->fallback_ran, nrep);
+    }
+}
+
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V>
+__global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
+    float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
+    const float* __restrict__ z0, float* __restrict__ zT, float* zwarm, float* zend,
+    TpStatus* __restrict__ status, TpCtl* ctl, float* snap, int J, unsigned* tickets, float tol, int64_t B,
+    int64_t Bh, int64_t T, int64_t L, int64_t W, int general)
+{
+    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+    bool fast = false;
+    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);     // wave-uniform: every practical diode
+    if (fast)
+        clipper_fwd_tp_body<DYN_R, SYM, TM, VEC4, STASH, V, !DYN_R>(c, x, r, y, zstash, z0, zT, zwarm, zend, theta, ctl, snap,
+                                                                    J, B, Bh, T, L, W);
+    else
+        clipper_fwd_tp_body<DYN_R, SYM, TM, VEC4, STASH, V, false>(c, x, r, y, zstash, z0, zT, zwarm, zend, theta, ctl, snap,
+                                                                   J, B, Bh, T, L, W);
+    tp_finish<DYN_R>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
 }
 
 // ---- exact time-parallel reverse sweep ----------------------------------------------------------
@@ -934,6 +998,102 @@ __device__ __forceinline__ V tp_grad_in(V gy, V z, V z_next, V tgt, float gscale
     }
 }
 
+// Optional optimizer step folded into the tail of the reverse sweep (single-GPU training loops:
+// with several ranks the gradient all-reduce sits in between and wdf_adam_step runs afterwards).
+struct AdamTail {
+    float* theta;                 // nullptr: no update
+    float* m; float* v; int32_t* step; const float* lr; float b1, b2, eps; const float* lo; const float* hi;
+};
+
+// The tail of the reverse sweep.  Every chunk wave publishes its record (write-through stores), then
+// takes a ticket of its 64-sequence tile; the LAST of the tile's K chunk waves walks the tile's K
+// records from the last chunk to the first (G_{k-1} = alpha_k G_k + beta_k, every sum affine in G)
+// and publishes the tile's partial sums {S_L, S_V, S_P, SSE} in double.  The last TILE then does the
+// fixed-order reduction over the tiles, the chain rule to {Is, nVt, R, C} and, if asked, the Adam
+// update of the four components.  Which wave is last varies; what it computes does not (records
+// and partials are re-read in index order).  tickets: [tiles_done, 0, 0, 0][per-tile tickets], zero
+// before the first launch and left zero by every launch.
+__device__ __forceinline__ void bwd_tp_finish(const float* part, int64_t B, double* ws, float* __restrict__ gz0,
+                                              unsigned* tickets, const float* theta, float fs, int dyn_r, float* gtheta,
+                                              int accumulate, float* __restrict__ sse_out, const AdamTail& adam,
+                                              double (*sh)[4])
+{
+    const int64_t K = gridDim.y;
+    const unsigned ntiles = gridDim.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's record has landed
+    unsigned old = 0;
+    if (threadIdx.x == 0) old = atomicAdd(&tickets[4 + blockIdx.x], 1u);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(K - 1)) return;
+    if (threadIdx.x == 0) tickets[4 + blockIdx.x] = 0u;          // left clean for the next launch
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    double G = 0.0, dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0;
+    int64_t k = K - 1;
+    for (; k >= 7; k -= 8) {                          // 8 chunks' 72 loads in flight together
+        float v[8][kTpOut];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < kTpOut; ++i) v[j][i] = load_published(part + ((k - j) * kTpOut + i) * B + b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dL += (double)v[j][0] * G + (double)v[j][3];
+            dV += (double)v[j][1] * G + (double)v[j][4];
+            dP += (double)v[j][2] * G + (double)v[j][5];
+            dS += (double)v[j][8];
+            G = (double)v[j][6] * G + (double)v[j][7];
+        }
+    }
+    for (; k >= 0; --k) {
+        const float* o = part + (k * kTpOut) * B + b;
+        dL += (double)load_published(o + 0 * B) * G + (double)load_published(o + 3 * B);
+        dV += (double)load_published(o + 1 * B) * G + (double)load_published(o + 4 * B);
+        dP += (double)load_published(o + 2 * B) * G + (double)load_published(o + 5 * B);
+        dS += (double)load_published(o + 8 * B);
+        G = (double)load_published(o + 6 * B) * G + (double)load_published(o + 7 * B);
+    }
+    if (live && gz0) gz0[b] = (float)G;
+    if (!live) { dL = dV = dP = dS = 0.0; }
+    dL = wave_sum(dL); dV = wave_sum(dV); dP = wave_sum(dP); dS = wave_sum(dS);
+    unsigned done = 0;
+    if (threadIdx.x == 0) {
+        double* o = ws + (int64_t)blockIdx.x * 4;      // slot 3: sum of squared errors (MSE mode)
+        __hip_atomic_store(o + 0, dL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, dV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 2, dP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 3, dS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial has landed before the tile count moves
+        done = atomicAdd(&tickets[0], 1u);
+    }
+    done = __builtin_amdgcn_readfirstlane(done);
+    if (done != ntiles - 1) return;
+    if (threadIdx.x == 0) tickets[0] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // every other tile's partial (this CU's L1 may be stale)
+    const double* wsr = ws;                                  // (read through a pointer without __restrict__'s no-alias promise)
+    grad_reduce_block<64>(wsr, (int)ntiles, theta, fs, dyn_r, gtheta, accumulate, sse_out, sh);
+    if (adam.theta != nullptr) {
+        __syncthreads();
+        const int i = threadIdx.x;
+        const int t = *adam.step + 1;
+        __syncthreads();
+        if (i == 0) *adam.step = t;
+        if (i < 4) {
+            const double c1 = 1.0 - pow((double)adam.b1, (double)t), c2 = 1.0 - pow((double)adam.b2, (double)t);
+            const float g = gtheta[i];
+            const float mi = adam.b1 * adam.m[i] + (1.0f - adam.b1) * g;
+            const float vi = adam.b2 * adam.v[i] + (1.0f - adam.b2) * g * g;
+            adam.m[i] = mi;
+            adam.v[i] = vi;
+            float th = adam.theta[i] - (float)((double)adam.lr[i] * sqrt(c2) / c1) * mi / (sqrtf(vi) + adam.eps);
+            if (adam.lo) th = fmaxf(th, adam.lo[i]);
+            if (adam.hi) th = fminf(th, adam.hi[i]);
+            adam.theta[i] = th;
+        }
+    }
+}
+
 // MSE: `gy` is unused, `target` [T][B] the training target, zT [B] the final state of the forward
 // (needed for y[T-1]); dL/dy = gscale (y - target), gscale = 2/N for a mean over N samples; the
 // kernel also returns sum (y - target)^2.
@@ -941,13 +1101,13 @@ template <bool DYN_R, bool SYM, bool TM, bool VEC4, int MSE, typename V>
 __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, const float* __restrict__ zstash, const float* __restrict__ gy,
-    const float* __restrict__ target, const float* __restrict__ zT, float gscale, float* __restrict__ out,
+    const float* __restrict__ target, const float* __restrict__ zT, float gscale, float* out,
     int64_t B, int64_t Bh, int64_t T, int64_t L, const float* __restrict__ gcoef, int64_t skip,
-    unsigned* __restrict__ ticket)
+    unsigned* tickets, double* ws, float* __restrict__ gz0, float* gtheta, int accumulate, float* __restrict__ sse_out,
+    AdamTail adam)
 {
     constexpr int N = VT<V>::N;
-    // the combine kernel (next launch on the stream) counts its finished blocks in *ticket: clear it here
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ticket = 0u;
+    __shared__ double sh[64][4];
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     float gb = 0.0f;
     if constexpr (MSE == 2) { gscale = gcoef[0]; gb = gcoef[1]; }
@@ -1033,93 +1193,13 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        float* __restrict__ o = out + (k * kTpOut) * B + q.b[j];
-        o[0 * B] = vget(saL, j); o[1 * B] = vget(saV, j); o[2 * B] = vget(saP, j);
-        o[3 * B] = (float)dbL[j]; o[4 * B] = (float)dbV[j]; o[5 * B] = (float)dbP[j];
-        o[6 * B] = vget(alpha, j); o[7 * B] = vget(beta, j); o[8 * B] = (float)dsse[j];
-    }
-}
-
-// Optional optimizer step folded into the tail of the reverse sweep (single-GPU training loops:
-// with several ranks the gradient all-reduce sits in between and wdf_adam_step runs afterwards).
-struct AdamTail {
-    float* theta;                 // nullptr: no update
-    float* m; float* v; int32_t* step; const float* lr; float b1, b2, eps; const float* lo; const float* hi;
-};
-
-// Walks the K chunks of each sequence from last to first and writes ws: double[gridDim.x][4] per-wave
-// partials like clipper_bwd_kernel.  The LAST block to finish (device-scope ticket, cleared by the
-// sweep kernel before this launch) then does what used to be two more launches: the fixed-order
-// reduction + chain rule (grad_reduce_block) and, if asked, the Adam update of the four components.
-// Which block is last varies; what it computes does not (it re-reads all partials in index order).
-static __global__ __launch_bounds__(64) void clipper_bwd_tp_combine_kernel(
-    const float* __restrict__ part, int64_t B, int64_t K, double* __restrict__ ws, float* __restrict__ gz0,
-    unsigned* __restrict__ ticket, const float* theta, float fs, int dyn_r, float* gtheta, int accumulate,
-    float* __restrict__ sse_out, AdamTail adam)
-{
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool live = b_raw < B;
-    const int64_t b = live ? b_raw : B - 1;
-    double G = 0.0, dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0;
-    int64_t k = K - 1;
-    for (; k >= 7; k -= 8) {                          // 8 chunks' 72 loads in flight together
-        float v[8][kTpOut];
+        float* o = out + (k * kTpOut) * B + q.b[j];
+        const float rec[kTpOut] = {vget(saL, j), vget(saV, j), vget(saP, j), (float)dbL[j], (float)dbV[j], (float)dbP[j],
+                                   vget(alpha, j), vget(beta, j), (float)dsse[j]};
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < kTpOut; ++i) v[j][i] = part[((k - j) * kTpOut + i) * B + b];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            dL += (double)v[j][0] * G + (double)v[j][3];
-            dV += (double)v[j][1] * G + (double)v[j][4];
-            dP += (double)v[j][2] * G + (double)v[j][5];
-            dS += (double)v[j][8];
-            G = (double)v[j][6] * G + (double)v[j][7];
-        }
+        for (int i = 0; i < kTpOut; ++i) __hip_atomic_store(o + i * B, rec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    for (; k >= 0; --k) {
-        const float* __restrict__ o = part + (k * kTpOut) * B + b;
-        dL += (double)o[0 * B] * G + (double)o[3 * B];
-        dV += (double)o[1 * B] * G + (double)o[4 * B];
-        dP += (double)o[2 * B] * G + (double)o[5 * B];
-        dS += (double)o[8 * B];
-        G = (double)o[6 * B] * G + (double)o[7 * B];
-    }
-    if (live && gz0) gz0[b] = (float)G;
-    if (!live) { dL = dV = dP = dS = 0.0; }
-    dL = wave_sum(dL); dV = wave_sum(dV); dP = wave_sum(dP); dS = wave_sum(dS);
-    __shared__ double sh[64][4];
-    __shared__ int is_last;
-    if (threadIdx.x == 0) {
-        double* o = ws + (int64_t)blockIdx.x * 4;
-        o[0] = dL; o[1] = dV; o[2] = dP; o[3] = dS;     // slot 3: sum of squared errors (MSE mode)
-        __threadfence();                                 // the partial is visible device-wide before the ticket moves
-        is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();                                     // acquire: every other block's partial
-    const double* wsr = ws;                              // (read through a pointer without __restrict__'s no-alias promise)
-    grad_reduce_block<64>(wsr, (int)gridDim.x, theta, fs, dyn_r, gtheta, accumulate, sse_out, sh);
-    if (adam.theta != nullptr) {
-        __syncthreads();
-        const int i = threadIdx.x;
-        const int t = *adam.step + 1;
-        __syncthreads();
-        if (i == 0) *adam.step = t;
-        if (i < 4) {
-            const double c1 = 1.0 - pow((double)adam.b1, (double)t), c2 = 1.0 - pow((double)adam.b2, (double)t);
-            const float g = gtheta[i];
-            const float mi = adam.b1 * adam.m[i] + (1.0f - adam.b1) * g;
-            const float vi = adam.b2 * adam.v[i] + (1.0f - adam.b2) * g * g;
-            adam.m[i] = mi;
-            adam.v[i] = vi;
-            float th = adam.theta[i] - (float)((double)adam.lr[i] * sqrt(c2) / c1) * mi / (sqrtf(vi) + adam.eps);
-            if (adam.lo) th = fmaxf(th, adam.lo[i]);
-            if (adam.hi) th = fminf(th, adam.hi[i]);
-            adam.theta[i] = th;
-        }
-    }
+    bwd_tp_finish(out, B, ws, gz0, tickets, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);
 }
 
 }  // namespace wdf

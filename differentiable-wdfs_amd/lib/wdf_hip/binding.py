@@ -70,11 +70,13 @@ def lib():
     L.wdf_clipper_fwd_tp_state_bytes.restype = C.c_size_t
     L.wdf_clipper_fwd_tp_state_bytes.argtypes = [i64, ci, ci]
     L.wdf_clipper_fwd_tp_state_reset.restype = ci
-    L.wdf_clipper_fwd_tp_state_reset.argtypes = [vp, vp]
+    L.wdf_clipper_fwd_tp_state_reset.argtypes = [vp, i64, ci, vp]
     L.wdf_clipper_fwd_tp_warm.restype = ci
     L.wdf_clipper_fwd_tp_warm.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, vp, ci, ci, vp]
     L.wdf_clipper_bwd_tp_ws_bytes.restype = C.c_size_t
     L.wdf_clipper_bwd_tp_ws_bytes.argtypes = [i64, ci]
+    L.wdf_clipper_bwd_tp_ws_init.restype = ci
+    L.wdf_clipper_bwd_tp_ws_init.argtypes = [vp, i64, ci, vp]
     L.wdf_clipper_bwd_tp.restype = ci
     L.wdf_clipper_bwd_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, vp, fp, fp, ci, i64, i64, ci, ci, vp]
     L.wdf_clipper_bwd_mse_tp.restype = ci
@@ -147,7 +149,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_fwd", "wdf_clipper_bwd", "wdf_clipper_bwd_ws_bytes",
     "wdf_clipper_tp_chunks", "wdf_clipper_fwd_tp_ws_bytes", "wdf_clipper_fwd_tp",
     "wdf_clipper_fwd_tp_state_bytes", "wdf_clipper_fwd_tp_state_reset", "wdf_clipper_fwd_tp_warm",
-    "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
+    "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp_ws_init", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_bwd_mse_tp_adam", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
@@ -240,18 +242,20 @@ class TpWarmState:
     """Persistent warm-start state of the time-parallel forward for ONE resident input batch
     (include/wdf_hip.h, wdf_clipper_fwd_tp_warm): control block + snapshot ring on the device."""
 
-    def __init__(self, B, T, n_chunks, max_warm_tiles, device):
+    def __init__(self, B, T, n_chunks, max_warm_tiles, device, min_warm_tiles=0):
         L = lib()
         self.K = L.wdf_clipper_tp_chunks(int(T), int(n_chunks))
         chunk_len = -(-(-(-int(T) // max(1, int(n_chunks)))) // 32) * 32        # as the library rounds it
         self.max_warm_tiles = max(1, min(int(max_warm_tiles), 16, chunk_len // 32))
         self.B, self.T, self.n_chunks = int(B), int(T), int(n_chunks)
+        self.min_warm_tiles = max(0, min(int(min_warm_tiles), self.max_warm_tiles))
         self.buf = torch.empty((L.wdf_clipper_fwd_tp_state_bytes(self.B, self.K, self.max_warm_tiles),),
                                dtype=torch.uint8, device=device)
         self.reset()
 
     def reset(self):
-        _check(lib().wdf_clipper_fwd_tp_state_reset(_ptr(self.buf), _stream()), "wdf_clipper_fwd_tp_state_reset")
+        _check(lib().wdf_clipper_fwd_tp_state_reset(_ptr(self.buf), self.B, self.min_warm_tiles, _stream()),
+               "wdf_clipper_fwd_tp_state_reset")
 
     def info(self):
         """Host view of the control block (synchronises): snapshot sets available, warm-up tiles the next
@@ -309,7 +313,7 @@ def clipper_bwd_mse_tp_adam(x, theta, fs, zstash, zT, target, gscale, n_chunks, 
     if opt.n != 4 or theta.numel() != 4:
         raise WdfHipError("clipper_bwd_mse_tp_adam: theta and the optimizer hold {Is, nVt, R, C}")
     if ws is None:
-        ws = torch.empty((lib().wdf_clipper_bwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
+        ws = bwd_tp_workspace(B, int(n_chunks), x.device)
     if gtheta is None:
         gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
     if sse is None:
@@ -361,7 +365,7 @@ def clipper_bwd_esr_tp(x, theta, fs, zstash, zT, target, gcoef, skip, n_chunks, 
     if tuple(target.shape) != (T, B) or tuple(zstash.shape) != (T, B):
         raise WdfHipError(f"target / zstash must be [T,B] = [{T},{B}]")
     if ws is None:
-        ws = torch.empty((lib().wdf_clipper_bwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
+        ws = bwd_tp_workspace(B, int(n_chunks), x.device)
     if gtheta is None:
         gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
     if sse is None:
@@ -372,6 +376,13 @@ def clipper_bwd_esr_tp(x, theta, fs, zstash, zT, target, gcoef, skip, n_chunks, 
                                       _stream())
     _check(rc, "wdf_clipper_bwd_esr_tp")
     return gtheta, sse
+
+
+def bwd_tp_workspace(B, n_chunks, device):
+    """A reverse-sweep workspace with its ticket words cleared (wdf_clipper_bwd_tp_ws_init): allocate once, reuse."""
+    ws = torch.empty((lib().wdf_clipper_bwd_tp_ws_bytes(int(B), int(n_chunks)),), dtype=torch.uint8, device=device)
+    _check(lib().wdf_clipper_bwd_tp_ws_init(_ptr(ws), int(B), int(n_chunks), _stream()), "wdf_clipper_bwd_tp_ws_init")
+    return ws
 
 
 def tp_status(status):
@@ -393,7 +404,7 @@ def clipper_bwd_tp(x, theta, fs, zstash, gy, n_chunks, r=None, n_up=1, n_down=1,
     if tuple(gy.shape) != (T, B) or tuple(zstash.shape) != (T, B):
         raise WdfHipError(f"gy / zstash must be [T,B] = [{T},{B}]")
     if ws is None:
-        ws = torch.empty((lib().wdf_clipper_bwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
+        ws = bwd_tp_workspace(B, int(n_chunks), x.device)
     if gtheta is None:
         gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
         accumulate = False
@@ -425,7 +436,7 @@ def clipper_bwd_mse_tp(x, theta, fs, zstash, zT, target, gscale, n_chunks, r=Non
     if zT.numel() != B:
         raise WdfHipError("zT must hold the B final states of the forward")
     if ws is None:
-        ws = torch.empty((lib().wdf_clipper_bwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
+        ws = bwd_tp_workspace(B, int(n_chunks), x.device)
     if gtheta is None:
         gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
         accumulate = False

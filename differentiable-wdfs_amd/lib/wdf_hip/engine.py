@@ -225,7 +225,7 @@ class MseStep:
         L = binding.lib()
         kf, kb = (tp.k_fwd, tp.k_bwd) if tp is not None else (1, 1)
         self.ws_f = torch.empty((max(16, L.wdf_clipper_fwd_tp_ws_bytes(B, kf)),), dtype=torch.uint8, device=device)
-        self.ws_b = torch.empty((L.wdf_clipper_bwd_tp_ws_bytes(B, kb),), dtype=torch.uint8, device=device)
+        self.ws_b = binding.bwd_tp_workspace(B, kb, device)
         self.status = torch.zeros((4,), dtype=torch.int32, device=device)
         # one fused buffer [sse, dIs, dnVt, dR, dC]: it is also the all-reduce payload
         self.out = torch.zeros((5,), dtype=torch.float32, device=device)
@@ -327,7 +327,7 @@ def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1,
     times = {}
     for k in sorted({k for k in (plan.k_bwd // 2, plan.k_bwd, plan.k_bwd * 2) if 1 <= k <= max(1, T // 32)}):
         st.tp = plan._replace(k_fwd=best_f, k_bwd=k)
-        st.ws_b = torch.empty((binding.lib().wdf_clipper_bwd_tp_ws_bytes(B, k),), dtype=torch.uint8, device=x.device)
+        st.ws_b = binding.bwd_tp_workspace(B, k, x.device)
         times[k] = timed(lambda: st.backward(theta, x, target, r))
     # reverse sweep: among the candidates within 2 % of the fastest take the fewest chunks (less
     # combine work and workspace; also keeps the choice stable from run to run)

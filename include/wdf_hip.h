@@ -103,23 +103,25 @@ size_t wdf_clipper_bwd_ws_bytes(int64_t B);
  * actually used).  x may be batch-major [B][T] or, with WDF_X_TIME_MAJOR, [T][B] (an engine
  * that keeps its training inputs resident in that layout gets fully coalesced loads).
  *
- * wdf_clipper_bwd_tp: EXACT -- the adjoint recurrence is linear, chunk results are combined
- *   by a second tiny kernel; only the (fixed) summation order differs from wdf_clipper_bwd.
+ * wdf_clipper_bwd_tp: EXACT -- the adjoint recurrence is linear; the chunk results of a 64-sequence
+ *   tile are combined by the last of its chunk waves to finish, the tiles by the last tile (one
+ *   launch); only the (fixed) summation order differs from wdf_clipper_bwd.
  * wdf_clipper_fwd_tp: every chunk starts `warmup` steps early from z = 0; the state it
  *   arrives with is checked on the device against the previous chunk's final state
- *   (|diff| <= tol for every sequence and chunk) by a verify kernel that, where a check
- *   fails, re-runs that chunk for the wave's 64 sequences from the correct state on the spot.
+ *   (|diff| <= tol for every sequence and chunk) by the last wave of each 64-sequence tile to
+ *   finish (no second launch), which, where a check fails, re-runs that chunk for its 64
+ *   sequences from the correct state on the spot.
  *   Either way the outputs are within tol of wdf_clipper_fwd's, with no host round trip.
- *   status: device int32[4] = {n_bad pairs, max |miss| (float bits), chunk re-runs, ticket},
- *   written by the call (zeroed first); the caller may read it later to report / adapt
- *   `warmup`.
+ *   status: device int32[4] = {n_bad pairs, max |miss| (float bits), chunk re-runs, 0},
+ *   written by the call's last wave; the caller may read it later to report / adapt `warmup`.
  * wdf_clipper_fwd_tp_warm: the same call with a persistent `state` buffer
  *   (wdf_clipper_fwd_tp_state_bytes; wdf_clipper_fwd_tp_state_reset before the first use and
- *   whenever x, B, T or the chunking change).  The reference's training loop runs the same
+ *   whenever x, B, T or the chunking change; min_warm_tiles: a floor for the device controller,
+ *   min = max pins the warm-up).  The reference's training loop runs the same
  *   train_X through the circuit every epoch with slowly moving parameters
  *   (clipper_pot.py:245-269): each call leaves snapshots of every chunk's state near its end,
  *   the next call starts its chunks from them (extrapolated along the parameter path from the
- *   last two calls) and runs only the few warm-up tiles the verify kernel's measured miss asks
+ *   last two calls) and runs only the few warm-up tiles the measured boundary miss asks
  *   for -- steered on the device, between 0 and max_warm_tiles tiles of 32 steps (the first call
  *   after a reset is a cold one with `warmup`).  Same verification, same guarantee.
  * ---------------------------------------------------------------------------------- */
@@ -131,7 +133,7 @@ int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta,
                        int64_t B, int64_t T, int n_chunks, int warmup, float tol,
                        void* ws, void* status, int flags, void* stream);
 size_t wdf_clipper_fwd_tp_state_bytes(int64_t B, int n_chunks, int max_warm_tiles);
-int wdf_clipper_fwd_tp_state_reset(void* state, void* stream);
+int wdf_clipper_fwd_tp_state_reset(void* state, int64_t B, int min_warm_tiles, void* stream);
 int wdf_clipper_fwd_tp_warm(const float* x, const float* r, const float* theta,
                             float fs, int n_up, int n_down,
                             float* y, float* zstash, const float* z0, float* zT,
@@ -139,6 +141,10 @@ int wdf_clipper_fwd_tp_warm(const float* x, const float* r, const float* theta,
                             void* ws, void* status, void* state, int max_warm_tiles,
                             int flags, void* stream);
 size_t wdf_clipper_bwd_tp_ws_bytes(int64_t B, int n_chunks);
+/* The reverse-sweep workspace ends in a few ticket words that the kernels count in and leave at zero:
+ * call this once after allocating a workspace (and after a launch that was aborted) -- one small
+ * memset on `stream` -- not per step. */
+int wdf_clipper_bwd_tp_ws_init(void* ws, int64_t B, int n_chunks, void* stream);
 /* MSE-fused reverse sweep (lpf.py:78 / clipper_pot.py:176 loss): `target` [T][B] is the
  * training target and zT [B] the forward's final state; the kernel rebuilds y[n] =
  * (z[n+1] + z[n])/2 from the state stash, forms dL/dy = gscale (y - target) itself
@@ -153,7 +159,7 @@ int wdf_clipper_bwd_mse_tp(const float* x, const float* r, const float* theta,
 
 /* wdf_clipper_bwd_mse_tp followed, in the same launches, by the Adam update of theta = {Is, nVt, R, C}
  * (wdf_adam_step's rule and arguments, n = 4): the whole tail of a single-GPU training step --
- * combine, reduce, chain rule, update -- is the last block of one kernel.  With several ranks the
+ * combine, reduce, chain rule, update -- rides in the sweep kernel's last waves.  With several ranks the
  * gradient all-reduce sits between sweep and update: use wdf_clipper_bwd_mse_tp + wdf_adam_step. */
 int wdf_clipper_bwd_mse_tp_adam(const float* x, const float* r, float* theta, float fs, int n_up, int n_down,
                                 const float* zstash, const float* zT, const float* target, float gscale,

@@ -331,9 +331,10 @@ def test_randomized_plans_and_circuits(wb):
 
 
 def test_combine_tail_reduce_and_adam(wb):
-    """The reverse sweep's combine kernel finishes the job in its last block (device-scope ticket):
-    fixed-order reduction, chain rule and -- wdf_clipper_bwd_mse_tp_adam -- the Adam update.
-    * 200 repetitions give bit-identical gradients (which block is last varies, the result does not);
+    """The reverse sweep finishes its own job (device-scope tickets): the last chunk wave of every tile
+    combines the tile's chunk records, the last tile does the fixed-order reduction, the chain rule and
+    -- wdf_clipper_bwd_mse_tp_adam -- the Adam update.
+    * 200 repetitions give bit-identical gradients (which wave is last varies, the result does not);
     * they equal the sequential sweep's gradient to 2e-5;
     * the folded update equals wdf_adam_step applied to that gradient, over 5 consecutive steps."""
     from wdf_hip import workload
@@ -343,6 +344,7 @@ def test_combine_tail_reduce_and_adam(wb):
     y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
     gscale = 2.0 / y.numel()
     ws = torch.empty((wb.lib().wdf_clipper_bwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda").fill_(0xAB)
+    assert wb.lib().wdf_clipper_bwd_tp_ws_init(ws.data_ptr(), B, K, None) == 0          # garbage everywhere but the tickets
     g0, sse0 = wb.clipper_bwd_mse_tp(x, th, FS, zs, zT, tgt, gscale, K, ws=ws)
     g0, sse0 = g0.clone(), sse0.clone()
     for _ in range(200):

@@ -18,7 +18,7 @@ def timeit(fn, n=30):
 K, W, KB = 16, 160, 32
 ws = torch.empty((wb.lib().wdf_clipper_fwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda")
 st = torch.empty(4, dtype=torch.int32, device="cuda")
-wsb = torch.empty((wb.lib().wdf_clipper_bwd_tp_ws_bytes(B, KB),), dtype=torch.uint8, device="cuda")
+wsb = wb.bwd_tp_workspace(B, KB, "cuda")
 g = torch.empty(4, device="cuda"); sse = torch.empty(1, device="cuda")
 res = {}
 for rep in range(2):

@@ -30,7 +30,7 @@ xt = x.t().contiguous()
 gscale = 2.0 / y.numel()
 for tm, xin in ((False, x), (True, xt)):
     for K in (8, 16, 32, 64):
-        ws = torch.empty((wb.lib().wdf_clipper_bwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device="cuda")
+        ws = wb.bwd_tp_workspace(B, K, "cuda")
         g = torch.empty(4, device="cuda"); sse = torch.empty(1, device="cuda")
         ms = timeit(lambda: wb.clipper_bwd_mse_tp(xin, th, fs, zs, zT, tgt, gscale, K, ws=ws, gtheta=g, sse=sse, time_major=tm))
         print(f"bwd_mse_tp time_major={tm} K={K}: {ms:.3f} ms")
