@@ -211,6 +211,103 @@ class Trainer:
         return float(tmax), loss, grad
 
 
+def run_mlp_root(args, world, rank, local):
+    """--root mlp2x16 (and friends): the path clipper_pot.py actually trains -- the pot clipper with a
+    DenseRootModel root -- at the reference's training-set shape (BASELINE configs[3]: 1340 sequences x 2048
+    samples per GPU, pot value per sample in the loader's layout, committed reference weights): forward
+    (time-parallel, verified), MSE + ESR past 50 samples, exact step-parallel reverse sweep to all weights,
+    all-reduce of the weight gradient, Adam(1e-4, beta_1 0.5) on the device.  One JSON line."""
+    from wdf_hip import mlp_root
+    dev = torch.device("cuda", local)
+    fs, T, B = workload.FS, 2048, (args.batch if args.batch != 8192 else 1340)
+    Bg = B * world
+    b0, b1 = wdist.shard_range(Bg, rank, world)
+    x = torch.as_tensor(workload.sweep_batch(Bg, T, b0=b0, b1=b1, seed=4) * 0.6, device=dev)
+    r = torch.as_tensor(workload.dataset_resistance_batch(Bg, T, b0=b0, b1=b1), device=dev)
+    wh, hidden, n_tanh = workload.reference_mlp_weights(args.root[3:] + "_pre" if args.root == "mlp2x16" else args.root[3:])
+    w = torch.tensor(wh, device=dev, requires_grad=True)
+    theta2 = torch.tensor([45.0e3, workload.C_CLIPPER], dtype=torch.float32, device=dev)
+    th4 = torch.tensor(workload.clipper_theta(), dtype=torch.float32, device=dev)
+    target, _, _ = binding.clipper_fwd(x, th4, fs, r=r, want_stash=False)        # "measurement": the analytic diode pair
+    skip, eps = 50, float(np.finfo(float).eps)
+    n_global = float(Bg * (T - skip))
+    plan = None if args.sequential else mlp_root.plan_mlp_time_parallel(B, T, r, None, workload.C_CLIPPER, fs)
+    adam = binding.Adam(w.numel(), lr=1.0e-4, beta_1=0.5, device=dev)
+    buf = torch.zeros(w.numel() + 2, dtype=torch.float32, device=dev)
+    ev = [binding.Event() for _ in range(4)]
+    t_f, t_b = [], []
+
+    def step(timed=False):
+        if timed:                 # events around the whole forward / reverse call (kernels + their helpers)
+            ev[0].record()
+        y, _ = mlp_root.clipper_mlp(theta2, w, x, r, None, fs, hidden, n_tanh, workload.C_CLIPPER, time_parallel=plan)
+        if timed:
+            ev[1].record()
+        o, t = y[skip:], target[skip:]
+        S, E = ((o - t) ** 2).sum(), (o ** 2).sum()
+        sums = torch.stack([S.detach(), E.detach()]).double()
+        wdist.allreduce_sum_(sums)                                    # the two loss sums, global
+        # d loss / d y with the GLOBAL sums (loss = S/n + sqrt(S/(E+eps)/n)): ga (y - t) + gb y
+        esr = torch.sqrt(sums[0] / (sums[1] + eps) / n_global)
+        ga = 2.0 / n_global + 1.0 / (esr * (sums[1] + eps) * n_global)
+        gb = -esr / (sums[1] + eps)
+        gy = torch.zeros_like(y)
+        gy[skip:] = (ga * (o - t) + gb * o).float().detach()
+        if timed:
+            ev[2].record()
+        (gw,) = torch.autograd.grad(y, [w], grad_outputs=gy)
+        if timed:
+            ev[3].record()
+        buf[:-2] = gw
+        buf[-2:] = sums.float()
+        wdist.allreduce_sum_(buf)                                      # one fused buffer: weight gradient (+ the sums again)
+        with torch.no_grad():
+            adam.apply(w, buf[:-2].contiguous())
+        if timed:
+            t_f.append(ev[0].elapsed_ms(ev[1])); t_b.append(ev[2].elapsed_ms(ev[3]))
+        return sums[0] / n_global + esr
+
+    for _ in range(args.warmup):
+        loss0 = step()
+    wdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(); wdist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax)
+    for _ in range(min(args.steps, 10)):
+        step(True)
+    torch.cuda.synchronize()
+    if rank == 0:
+        st = None if mlp_root.LAST_TP_STATUS["status"] is None else binding.mlp_tp_status(mlp_root.LAST_TP_STATUS["status"])
+        f_ms, b_ms = float(np.mean(t_f)), float(np.mean(t_b))
+        achieved = 16 * B * T / (f_ms * 1e-3) / 1e9            # forward: x, r in; y, stash out = 16 B/sample
+        out = {"metric": f"samples/sec fwd+bwd, MLP-root ({args.root[3:]}) pot clipper, clipper_pot.py training-set shape",
+               "value": Bg * T / (dt / args.steps), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"pot clipper with DenseRootModel {args.root[3:]} root (reference weights), MSE+ESR past 50 "
+                                      f"samples, {B} sequences x {T} samples per GPU, pot value per sample (BASELINE configs[3] shape)",
+                          "global_batch": Bg, "seq_len": T, "parallelism": f"dp{world}", "loss": float(loss),
+                          "time_parallel": None if plan is None else {"fwd_chunks": plan.k_fwd, "fwd_warmup_steps_planned": plan.warmup,
+                                                                      "fwd_warmup_steps_used": max(v["warmup"] for v in mlp_root._WARMUP_ADAPT.values()),
+                                                                      "verify_tol": plan.tol, "bwd_chunks": plan.k_bwd,
+                                                                      "verify_status": st}},
+               "call_ms": {"forward": spread(t_f), "reverse": spread(t_b)},
+               "roofline": {"bound": "hbm", "kernel": "clipper_mlp_row_fwd_tp_kernel (+ verify)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "note": "not a bandwidth-bound kernel: ~100 (forward) / ~250 (reverse) VALU instructions per step "
+                                    "and 4-sequence wave at ~2 ns per issued instruction and SIMD is the limit (DESIGN.md)"}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        wdist.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def spread(ts):
     ts = sorted(ts)
     return {"min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1], "n": len(ts)}
@@ -247,6 +344,9 @@ def main():
     ap.add_argument("--cold-forward", action="store_true",
                     help="every forward warms its chunks up from z = 0 (no state kept between steps) instead of "
                          "starting them from the previous step's snapshots")
+    ap.add_argument("--root", default="diode", choices=["diode", "mlp2x16", "mlp2x8", "mlp4x8"],
+                    help="diode: the metric's analytic diode-pair root (default).  mlp*: a secondary line -- the pot clipper "
+                         "with the reference's DenseRootModel root at the training-set shape 1340 x 2048 (--batch to change)")
     ap.add_argument("--x-batch-major", action="store_true",
                     help="make the [B,T] layout (the reference scripts') the HEADLINE measurement instead of the engine's "
                          "resident time-major copy")
@@ -263,6 +363,8 @@ def main():
     if args.force_dist and world != 1:
         raise SystemExit("--force-dist is for world size 1")
     binding.require_gpu()
+    if args.root != "diode":
+        return run_mlp_root(args, world, rank, local)
     dev = torch.device("cuda", local)
     fs, T = workload.FS, args.seq_len
     Bg = args.batch * world if args.scaling == "weak" else args.batch

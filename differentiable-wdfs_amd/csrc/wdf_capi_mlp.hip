@@ -4,6 +4,7 @@
 #include "wdf_capi_common.h"
 #include "wdf_mlp.h"
 #include "wdf_mlp_row.h"
+#include "wdf_mlp_tp.h"
 using namespace wdfcapi;
 
 extern "C" {
@@ -63,9 +64,9 @@ int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, con
 #define WDF_ROW_FWD(NL_)                                                                                       \
     if (n_tanh_layers == NL_) {                                                                                \
         if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, true>), dim3(grow), dim3(64), 0,        \
-                                    (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, B, T);   \
+                                    (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)nullptr);   \
         else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, false>), dim3(grow), dim3(64), 0,           \
-                                (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, B, T);       \
+                                (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)nullptr);       \
     }
         WDF_ROW_FWD(3) WDF_ROW_FWD(4) WDF_ROW_FWD(5)
 #undef WDF_ROW_FWD
@@ -109,6 +110,117 @@ int wdf_clipper_mlp_bwd_w(const float* x, const float* r, const float* theta2, c
     hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float*)wsw, (int)grid, count, gw);
     return check_launch("wdf_clipper_mlp_bwd_w reduce");
+}
+
+// ---- time-parallel MLP-root kernels (wdf_mlp_tp.h) ------------------------------------------------
+struct MlpTpGeom { int64_t L; int K; };
+static MlpTpGeom mlp_tp_geom(int64_t T, int n_chunks)
+{
+    if (n_chunks < 1) n_chunks = 1;
+    int64_t L = (T + n_chunks - 1) / n_chunks;
+    L = (L + 15) / 16 * 16;
+    return {L, (int)((T + L - 1) / L)};
+}
+
+int wdf_clipper_mlp_tp_chunks(int64_t T, int n_chunks) { return T > 0 ? mlp_tp_geom(T, n_chunks).K : 0; }
+
+size_t wdf_clipper_mlp_fwd_tp_ws_bytes(int64_t B, int n_chunks)
+{
+    if (B <= 0 || n_chunks <= 0) return 0;
+    return (size_t)2 * (size_t)n_chunks * (size_t)B * sizeof(float) + (size_t)((B + 3) / 4) * sizeof(unsigned);
+}
+
+int wdf_clipper_mlp_fwd_tp(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                           int n_tanh_layers, float fs, float* y, float* zstash, const float* z0, float* zT, int64_t B,
+                           int64_t T, int n_chunks, int warmup, const int32_t* warmup_per_wave, float tol, void* ws,
+                           void* status, void* stream)
+{
+    int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, 0);
+    if (rc) return rc;
+    if (!y || !ws || !status) return fail(WDF_EINVAL, "null y/ws/status");
+    if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
+    const MlpTpGeom g = mlp_tp_geom(T, n_chunks);
+    const int64_t W = ((int64_t)warmup + 15) / 16 * 16;
+    float* zwarm = (float*)ws;
+    float* zend = zwarm + (size_t)g.K * (size_t)B;
+    unsigned* gate = (unsigned*)(zend + (size_t)g.K * (size_t)B);
+    const dim3 grid((unsigned)((B + 3) / 4), (unsigned)g.K);
+    const bool dyn = r != nullptr;
+    hipStream_t s = (hipStream_t)stream;
+#define WDF_ROW_FWD_TP(NL_)                                                                                      \
+    if (n_tanh_layers == NL_) {                                                                                  \
+        {                                                                                                        \
+            EventBracket bracket(s);                                                                             \
+            if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, true>), grid, dim3(64), 0, s, x, r, theta2, w, \
+                                        hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave,                \
+                                        (wdf::MlpTpStatus*)status, B, T, g.L, W);                                  \
+            else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, false>), grid, dim3(64), 0, s, x, r, theta2, w,    \
+                                    hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave,                    \
+                                    (wdf::MlpTpStatus*)status, B, T, g.L, W);                                      \
+        }                                                                                                        \
+        if (g.K > 1) {                                                                                           \
+            hipLaunchKernelGGL(wdf::mlp_tp_verify_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, zwarm, zend, B, \
+                               (int64_t)g.K, tol, gate, (wdf::MlpTpStatus*)status);                               \
+            if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, true>), dim3(grid.x), dim3(64), 0, s, x, r,  \
+                                        theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)gate);   \
+            else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, false>), dim3(grid.x), dim3(64), 0, s, x, r,     \
+                                    theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)gate);       \
+        }                                                                                                        \
+    }
+    WDF_ROW_FWD_TP(3) WDF_ROW_FWD_TP(4) WDF_ROW_FWD_TP(5)
+#undef WDF_ROW_FWD_TP
+    return check_launch("wdf_clipper_mlp_fwd_tp");
+}
+
+int64_t wdf_clipper_mlp_bwd_w_tp_ws_bytes(int hidden, int n_tanh_layers, int64_t B, int64_t T, int n_chunks)
+{
+    if (B <= 0 || T <= 0 || n_chunks <= 0 || !mlp_arch_ok(hidden, n_tanh_layers)) return 0;
+    const int64_t nparts = (B + 3) / 4 * mlp_tp_geom(T, n_chunks).K;
+    return T * B * (int64_t)sizeof(float) + nparts * 4 * (int64_t)sizeof(double) +
+           nparts * wdf_mlp_weight_count(hidden, n_tanh_layers) * (int64_t)sizeof(float);
+}
+
+int wdf_clipper_mlp_bwd_w_tp(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                             int n_tanh_layers, float fs, const float* zstash, const float* gy, void* ws, float* gtheta2,
+                             float* gw, int64_t B, int64_t T, int n_chunks, void* stream)
+{
+    int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, 0);
+    if (rc) return rc;
+    if (!zstash || !gy || !ws || !gtheta2 || !gw) return fail(WDF_EINVAL, "null zstash/gy/ws/gtheta2/gw");
+    if (n_chunks < 1) return fail(WDF_EINVAL, "n_chunks >= 1");
+    const MlpTpGeom g = mlp_tp_geom(T, n_chunks);
+    const dim3 grid((unsigned)((B + 3) / 4), (unsigned)g.K);
+    const int nparts = (int)(grid.x * grid.y);
+    double* wsd = (double*)ws;                                             // [nparts][4] doubles (8-byte aligned)
+    float* kap = (float*)((char*)ws + (size_t)nparts * 4 * sizeof(double));  // kappa, then g_b2n in place [T][B]
+    float* wsw = kap + (size_t)T * (size_t)B;                              // [nparts][count]
+    const bool dyn = r != nullptr;
+    hipStream_t s = (hipStream_t)stream;
+#define WDF_ROW_BWD_TP(NL_)                                                                                      \
+    if (n_tanh_layers == NL_) {                                                                                  \
+        if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, true>), grid, dim3(64), 0, s, x, r, theta2, w,   \
+                                    hidden, fs, zstash, kap, B, T, g.L);                                          \
+        else hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, false>), grid, dim3(64), 0, s, x, r, theta2, w,      \
+                                hidden, fs, zstash, kap, B, T, g.L);                                              \
+        hipLaunchKernelGGL(wdf::mlp_adjoint_scan_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, kap, gy, kap, B, T); \
+        {                                                                                                        \
+            EventBracket bracket(s);                                                                             \
+            if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_wgrad_tp_kernel<NL_, true>), grid, dim3(64), 0, s, x, r, theta2, \
+                                        w, hidden, fs, zstash, kap, wsw, wsd, B, T, g.L);                         \
+            else hipLaunchKernelGGL((wdf::clipper_mlp_row_wgrad_tp_kernel<NL_, false>), grid, dim3(64), 0, s, x, r, theta2,    \
+                                    w, hidden, fs, zstash, kap, wsw, wsd, B, T, g.L);                             \
+        }                                                                                                        \
+    }
+    WDF_ROW_BWD_TP(3) WDF_ROW_BWD_TP(4) WDF_ROW_BWD_TP(5)
+#undef WDF_ROW_BWD_TP
+    rc = check_launch("wdf_clipper_mlp_bwd_w_tp");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wdf::clipper_mlp_grad_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)wsd, nparts, theta2, fs,
+                       dyn ? 1 : 0, gtheta2);
+    const int count = wdf_mlp_weight_count(hidden, n_tanh_layers);
+    hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_wide_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64, 16), 0, s,
+                       (const float*)wsw, nparts, count, gw);
+    return check_launch("wdf_clipper_mlp_bwd_w_tp reduce");
 }
 
 size_t wdf_clipper_mlp_bwd_ws_bytes(int64_t B) { return B > 0 ? (size_t)((B + 3) / 4) * 4 * sizeof(double) : 0; }

@@ -143,8 +143,10 @@ template <int NL, bool DYN_R>
 __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
     const float* __restrict__ w, int H, float fs, float* __restrict__ y, float* __restrict__ zstash,
-    const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T)
+    const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T, const unsigned* __restrict__ gate)
 {
+    // gate: the repair launch of the time-parallel forward (wdf_mlp_tp.h) -- only flagged waves run
+    if (gate != nullptr && gate[blockIdx.x] == 0u) return;
     const int lane = threadIdx.x, j = lane & 15;
     const int64_t b_raw = (int64_t)blockIdx.x * 4 + (lane >> 4);
     const int64_t b = b_raw < B ? b_raw : B - 1;

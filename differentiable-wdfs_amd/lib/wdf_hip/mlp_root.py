@@ -4,6 +4,10 @@ Function and the data-level time-parallel segmentation.
 The per-lane reverse-sweep kernel returns g_b[n] = dL/d b[n] and the network inputs
 (a[n], log R[n]); the weight gradient  dL/dW = -sum_n g_b[n] dMLP(a[n], lr[n])/dW  is a sum
 over B*T independent samples, done by wdf_clipper_mlp_wgrad (fully parallel HIP kernel)."""
+import math
+import weakref
+from collections import namedtuple
+
 import torch
 
 from . import binding
@@ -37,15 +41,36 @@ def flat_weights(dense):
     return torch.cat(parts)
 
 
+MlpTpPlan = namedtuple("MlpTpPlan", ["k_fwd", "warmup", "warmup_per_wave", "tol", "k_bwd"])
+LAST_TP_STATUS = {"status": None}
+_WARMUP_ADAPT = {}     # (x shape, forward chunks, planned warm-up) -> {"warmup": steps in use, "calls": n}
+
+
 class _ClipperMlpFn(torch.autograd.Function):
-    """y [T,B] = clipper_mlp(theta2 = {R, C}, w, x [B,T] (, r [B,T]))."""
+    """y [T,B] = clipper_mlp(theta2 = {R, C}, w, x [B,T] (, r [B,T])).  tp: an MlpTpPlan -> the
+    in-kernel time-parallel forward (verified) and the all-steps-parallel exact reverse sweep."""
 
     @staticmethod
-    def forward(ctx, theta2, w, x, r, z0, fs, hidden, n_tanh, want_zT, want_stash=False):
+    def forward(ctx, theta2, w, x, r, z0, fs, hidden, n_tanh, want_zT, want_stash=False, tp=None):
         need = theta2.requires_grad or w.requires_grad
         th, wd = theta2.detach().contiguous(), w.detach().contiguous()
-        y, zs, zT = binding.clipper_mlp_fwd(x, th, wd, hidden, n_tanh, fs, r=r, want_stash=need or want_stash,
-                                            z0=z0, want_zT=want_zT)
+        if tp is not None and tp.k_fwd > 1 and not binding.MLP_LANE_PER_SEQUENCE:
+            # The warm-up estimate knows the RC network, not the learned root: the first calls of a shape (and
+            # every 16th later) look at the verification's verdict -- one 16-byte read-back -- and lengthen
+            # the warm-up by half when a wave had to be re-run (a re-run is a whole sequential pass of that wave).
+            ad = _WARMUP_ADAPT.setdefault((x.shape, tp.k_fwd, tp.warmup), {"warmup": tp.warmup, "calls": 0})
+            y, zs, zT, st = binding.clipper_mlp_fwd_tp(x, th, wd, hidden, n_tanh, fs, tp.k_fwd, ad["warmup"], r=r,
+                                                       warmup_per_wave=tp.warmup_per_wave, tol=tp.tol,
+                                                       want_stash=need or want_stash, z0=z0, want_zT=want_zT)
+            LAST_TP_STATUS["status"] = st
+            ad["calls"] += 1
+            if tp.warmup_per_wave is None and (ad["calls"] <= 4 or ad["calls"] % 16 == 0):
+                if binding.mlp_tp_status(st)["gated_waves"] > 0:
+                    ad["warmup"] = min(-(-int(1.5 * ad["warmup"]) // 16) * 16, int(x.shape[1]))
+        else:
+            y, zs, zT = binding.clipper_mlp_fwd(x, th, wd, hidden, n_tanh, fs, r=r, want_stash=need or want_stash,
+                                                z0=z0, want_zT=want_zT)
+        ctx.tp = tp
         ctx.cfg = (fs, hidden, n_tanh, r is not None)
         if need:
             ctx.save_for_backward(th, wd, x, zs, *([r] if r is not None else []))
@@ -63,14 +88,16 @@ class _ClipperMlpFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         th, wd, x, zs = saved[:4]
         r = saved[4] if has_r else None
-        if binding.MLP_LANE_PER_SEQUENCE:
+        if ctx.tp is not None and ctx.tp.k_bwd > 1 and not binding.MLP_LANE_PER_SEQUENCE:
+            gth, gw = binding.clipper_mlp_bwd_w_tp(x, th, wd, hidden, n_tanh, fs, zs, gy.contiguous(), ctx.tp.k_bwd, r=r)
+        elif binding.MLP_LANE_PER_SEQUENCE:
             gth, gb, ain, lrin = binding.clipper_mlp_bwd(x, th, wd, hidden, n_tanh, fs, zs, gy.contiguous(), r=r)
             # weight gradient: dL/dw = -sum_n gb[n] dMLP(a[n], lr[n])/dw, all B*T samples in parallel
             gw = binding.clipper_mlp_wgrad(ain, lrin, gb, th, wd, hidden, n_tanh, fs)
         else:
             # one 16-lane row per sequence; the weight gradient is accumulated in the same sweep
             gth, gw = binding.clipper_mlp_bwd_w(x, th, wd, hidden, n_tanh, fs, zs, gy.contiguous(), r=r)
-        return gth, gw, None, None, None, None, None, None, None, None
+        return gth, gw, None, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------ time-parallel segments
@@ -141,21 +168,90 @@ def clipper_mlp_segmented(theta2, w, x, r, fs, hidden, n_tanh, plan, tol=1.0e-6,
     return y, zT, miss
 
 
+_WROW_CACHE = {}       # id(r) -> (weakref, version, (C, fs, tol), int32 tensor, max)
+
+
+def _warmup_steps(rho, tol):
+    rho = min(max(float(rho), 0.0), 1.0 - 1e-9)
+    if rho <= 0.0:
+        return 16
+    return max(16, -(-int(math.ceil(math.log(0.01 * tol) / math.log(rho))) // 16) * 16)
+
+
+def warmup_per_wave(r, C, fs, tol=1.0e-6):
+    """(Experimental; the planner does not use it -- see plan_mlp_time_parallel.)
+    int32[ceil(B/4)] warm-up steps for the time-parallel forward, one per 4 consecutive sequences, from the
+    slowest memory |1 - 2p| among them (p = Rc/(R+Rc) at the smallest and the largest pot value of the four
+    sequences); cached per resistance tensor (a training set is the same tensor every epoch).  Also the max."""
+    hit = _WROW_CACHE.get(id(r))
+    key = (float(C), float(fs), float(tol))
+    if hit is None or hit[0]() is not r or hit[1] != r._version or hit[2] != key:
+        if len(_WROW_CACHE) > 64:
+            for k in [k for k, v in _WROW_CACHE.items() if v[0]() is None]:
+                del _WROW_CACHE[k]
+        B = r.shape[0]
+        Rc = 1.0 / (2.0 * float(C) * float(fs))
+        lo, hi = r.amin(dim=1), r.amax(dim=1)
+        pad = (-B) % 4
+        if pad:
+            lo, hi = torch.cat([lo, lo[-1:].expand(pad)]), torch.cat([hi, hi[-1:].expand(pad)])
+        lo, hi = lo.reshape(-1, 4).amin(dim=1).double(), hi.reshape(-1, 4).amax(dim=1).double()
+        rho = torch.maximum((1.0 - 2.0 * Rc / (lo + Rc)).abs(), (1.0 - 2.0 * Rc / (hi + Rc)).abs()).clamp(1e-6, 1.0 - 1e-9)
+        W = torch.ceil(math.log(0.01 * tol) / torch.log(rho))
+        W = (torch.ceil(W / 16.0) * 16.0).clamp(min=16.0).to(torch.int32).contiguous()
+        hit = (weakref.ref(r), r._version, key, W, int(W.max()))
+        _WROW_CACHE[id(r)] = hit
+    return hit[3], hit[4]
+
+
+def plan_mlp_time_parallel(B, T, r, R_static, C, fs, tol=2.0e-6):
+    """MlpTpPlan for the in-kernel time-parallel MLP-root kernels, or None when the batch already fills the
+    chip or the circuit remembers more than a chunk.  The row kernels are bound by VALU issue (~100 / ~250
+    instructions per step and wave, forward / reverse), so chunks pay only until every SIMD has work: about
+    two waves per SIMD (measured at 1340 x 2048: 6 chunks best for both sweeps, profiles/r02_mlp_bench.txt).
+    Warm-up: ONE value for the batch, 1.15 x the RC network's diode-off memory at the largest / smallest pot
+    value -- with the reference's trained 2x16 root the slowest sequences still miss by 1.5e-6 after that
+    estimate's 416 steps (the learned root conducts less sharply than the diode it imitates), and a per-wave
+    warm-up from the pot value alone (warmup_per_wave) is wrong for SMALL pots: there the slow mode is the
+    conducting one, d z'/d z -> -1, not the off-state 1 - 2p (measured: 55 of 335 waves re-run).  The device
+    verification covers whatever the estimate gets wrong; tol 2e-6 = the fp32 noise of this path."""
+    waves = max(1, -(-B // 4))
+    if waves >= 2 * engine.N_SIMD or binding.MLP_LANE_PER_SEQUENCE:
+        return None
+    Rc = 1.0 / (2.0 * float(C) * float(fs))
+    ends = (engine.resistance_max(r), engine.resistance_min(r)) if r is not None else (float(R_static),)
+    wmax = max(_warmup_steps(abs(1.0 - 2.0 * Rc / (Rv + Rc)), tol) for Rv in ends)
+    wmax = -(-int(1.15 * wmax) // 16) * 16
+    k_fwd = max(1, min(2 * engine.N_SIMD // waves, T // max(wmax // 2, 64)))
+    k_bwd = max(1, min(2 * engine.N_SIMD // waves, T // 64))
+    if k_fwd < 2 and k_bwd < 2:
+        return None
+    return MlpTpPlan(k_fwd, wmax, None, float(tol), k_bwd)
+
+
 def clipper_mlp(theta2, w, x, r, z0, fs, hidden, n_tanh, C, R_static=None, time_parallel="auto"):
-    """The MLP-root clipper over a batch: segmented when the plan allows, else the sequential
-    kernels.  Returns (y [T,B], zT [B])."""
-    # Segments give the forward the sequential result to a verified 1e-6, but their backward is truncated
-    # BPTT through W warm-up steps whose length comes from the RC network's diode-off contraction, not from
-    # the learned root: "auto" therefore segments evaluation-only calls, training keeps the exact sweep.
-    needs_grad = torch.is_grad_enabled() and (theta2.requires_grad or w.requires_grad)
-    if time_parallel == "auto" and needs_grad:
-        time_parallel = None
-    if time_parallel in ("auto", "force"):
-        plan = segment_plan(x.shape[0], x.shape[1], engine.resistance_max(r) if r is not None else float(R_static), float(C), fs)
-        if plan is not None:
-            y, zT, miss = clipper_mlp_segmented(theta2, w, x, r, fs, hidden, n_tanh, plan, z0=z0)
-            LAST_SEGMENT_MISS["miss"] = miss
-            return y, zT
+    """The MLP-root clipper over a batch.  time_parallel: "auto" / an MlpTpPlan -> the in-kernel time-parallel
+    kernels (verified forward, exact reverse sweep) when the batch leaves the chip idle; None -> sequential;
+    "segments" -> the older data-level segmentation (forward verified, backward truncated: evaluation only).
+    Returns (y [T,B], zT [B])."""
+    if time_parallel == "auto":
+        time_parallel = plan_mlp_time_parallel(x.shape[0], x.shape[1], r, R_static, C, fs)
+    if isinstance(time_parallel, MlpTpPlan):
+        return _ClipperMlpFn.apply(theta2, w, x, r, z0, fs, hidden, n_tanh, True, False, time_parallel)
+    if time_parallel != "segments":
+        return _ClipperMlpFn.apply(theta2, w, x, r, z0, fs, hidden, n_tanh, True)
+    return _clipper_mlp_segments(theta2, w, x, r, z0, fs, hidden, n_tanh, C, R_static)
+
+
+def _clipper_mlp_segments(theta2, w, x, r, z0, fs, hidden, n_tanh, C, R_static=None):
+    """Data-level segmentation (the round-1 path, kept for A/B): the forward is verified to 1e-6, the
+    backward is truncated BPTT through the W warm-up steps -- W comes from the RC network's diode-off
+    contraction, not from the learned root -- so training uses the in-kernel path above instead."""
+    plan = segment_plan(x.shape[0], x.shape[1], engine.resistance_max(r) if r is not None else float(R_static), float(C), fs)
+    if plan is not None:
+        y, zT, miss = clipper_mlp_segmented(theta2, w, x, r, fs, hidden, n_tanh, plan, z0=z0)
+        LAST_SEGMENT_MISS["miss"] = miss
+        return y, zT
     return _ClipperMlpFn.apply(theta2, w, x, r, z0, fs, hidden, n_tanh, True)
 
 

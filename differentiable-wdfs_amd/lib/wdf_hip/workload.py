@@ -49,3 +49,25 @@ def pot_resistance_batch(B_global, T, b0=0, b1=None, dtype=np.float32):
     grid = np.array([10.0e3, 25.2e3, 45.2e3, 75.0e3, 99.1e3])
     r = grid[np.arange(b0, b1) % len(grid)]
     return np.ascontiguousarray(np.repeat(r[:, None], T, axis=1), dtype=dtype)
+
+
+def dataset_resistance_batch(B_global, T, b0=0, b1=None, grid=(10.0e3, 25.2e3, 75.0e3, 99.1e3), dtype=np.float32):
+    """Pot values laid out as the reference's loader leaves them: load_diode_data concatenates the training
+    recordings file by file and batch_data cuts the result into sequences (dataimport.py:82-137,
+    clipper_pot.py:61-80), so the batch is four contiguous blocks of sequences, one pot value each
+    (training files of .MISSING_LARGE_BLOBS:1-5: 10.0k, 25.2k, 75.0k, 99.1k; 45.2k validates)."""
+    b1 = B_global if b1 is None else b1
+    g = np.asarray(grid, dtype=np.float64)
+    idx = np.minimum((np.arange(b0, b1) * len(g)) // max(B_global, 1), len(g) - 1)
+    return np.ascontiguousarray(np.repeat(g[idx][:, None], T, axis=1), dtype=dtype)
+
+
+def reference_mlp_weights(name="2x16"):
+    """(flat weights float32, hidden, n_tanh) of a committed reference network, read from the golden fixture
+    tests/golden/g3_mlp_clipper.npz (weights of wdf_py/diode_clipper/models/*.json, kernel[in][out] then
+    bias[out] per layer)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "..", "tests", "golden", "g3_mlp_clipper.npz")
+    g = np.load(path)
+    sizes = [int(v) for v in g[f"{name}_sizes"]]
+    return g[f"{name}_theta"].astype(np.float32), sizes[1], len(sizes) - 2

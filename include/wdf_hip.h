@@ -321,6 +321,32 @@ int wdf_adam_step(float* theta, const float* grad, float* m, float* v, int32_t* 
                   const float* lr, float beta1, float beta2, float eps,
                   const float* lo, const float* hi, int n, void* stream);
 
+/* Time-parallel variants of the MLP-root calls (csrc/wdf_mlp_tp.h): the reference's 1340 x 2048 training set
+ * (clipper_pot.py:58,232) is only 335 waves when every sequence runs its 2048 steps in one wave.
+ *   wdf_clipper_mlp_fwd_tp   the time axis in n_chunks chunks (length rounded up to a multiple of 16;
+ *       wdf_clipper_mlp_tp_chunks() = the number used); every chunk but the first starts `warmup` steps
+ *       early from z = 0 -- or warmup_per_wave[ceil(B/4)] steps (device int32, multiples of 16: one value
+ *       per 4 consecutive sequences, the pot resistance sets the circuit's memory) -- and a verify kernel
+ *       compares the state each chunk arrives with against the state its predecessor ended in
+ *       (|diff| <= tol); waves with a miss are re-run sequentially by a gated launch of the plain kernel.
+ *       status: device int32[4] = {n_bad, max |miss| (float bits), gated waves, 0}.
+ *   wdf_clipper_mlp_bwd_w_tp  EXACT reverse sweep, parallel over all steps: kappa[n] = d z'/d z of every
+ *       step from the stash (no recurrence), the scalar adjoint recurrence by one lane per sequence, then
+ *       the weight-gradient and {R, C} sums of every step with the known adjoint.  Same outputs as
+ *       wdf_clipper_mlp_bwd_w.                                                                  */
+int wdf_clipper_mlp_tp_chunks(int64_t T, int n_chunks);
+size_t wdf_clipper_mlp_fwd_tp_ws_bytes(int64_t B, int n_chunks);
+int wdf_clipper_mlp_fwd_tp(const float* x, const float* r, const float* theta2, const float* w,
+                           int hidden, int n_tanh_layers, float fs,
+                           float* y, float* zstash, const float* z0, float* zT,
+                           int64_t B, int64_t T, int n_chunks, int warmup, const int32_t* warmup_per_wave,
+                           float tol, void* ws, void* status, void* stream);
+int64_t wdf_clipper_mlp_bwd_w_tp_ws_bytes(int hidden, int n_tanh_layers, int64_t B, int64_t T, int n_chunks);
+int wdf_clipper_mlp_bwd_w_tp(const float* x, const float* r, const float* theta2, const float* w,
+                             int hidden, int n_tanh_layers, float fs,
+                             const float* zstash, const float* gy, void* ws, float* gtheta2, float* gw,
+                             int64_t B, int64_t T, int n_chunks, void* stream);
+
 /* library / device info */
 int wdf_abi_version(void);
 const char* wdf_last_error(void);

@@ -148,7 +148,7 @@ def test_segmented_time_parallel_matches_sequential(golden):
     assert mlp_root.segment_plan(B, T, 99.1e3, float(g["C"]), FS) is not None
     mlp_root.LAST_SEGMENT_MISS["miss"] = None
     y_seq, g_seq = run(None)
-    y_tp, g_tp = run("force")          # "auto" keeps training calls on the exact sweep (segments: truncated BPTT)
+    y_tp, g_tp = run("segments")       # the data-level path (truncated backward); "auto" = the in-kernel path below
     assert mlp_root.LAST_SEGMENT_MISS["miss"] is not None and mlp_root.LAST_SEGMENT_MISS["miss"] <= 1e-6
     assert float((y_tp - y_seq).abs().max()) <= 2e-6
     for a, b in zip(g_tp, g_seq):
@@ -221,3 +221,87 @@ def test_row_kernels_equal_lane_kernels(hidden, n_tanh, B, T, dyn):
     assert float((zT_r - zT_l).abs().max()) <= tol
     for a, b in ((gth_r, gth_l), (gth_r2, gth_l), (gw_r, gw_l), (gb_r, gb), (ain_r, ain)):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
+
+
+# ---- in-kernel time-parallel MLP-root kernels (csrc/wdf_mlp_tp.h) ----------------------------------------
+@pytest.mark.parametrize("hidden,n_tanh", [(8, 3), (16, 3), (4, 5), (8, 5)])
+@pytest.mark.parametrize("B,T,K,dyn", [(5, 100, 3, True), (7, 257, 2, False), (130, 515, 4, True), (96, 2048, 8, True)])
+def test_mlp_time_parallel_kernels_equal_sequential(hidden, n_tanh, B, T, K, dyn):
+    """Forward: chunks warmed up per wave (pot-dependent), verified on the device -> the sequential kernel's y,
+    stash and final state to 2e-6 with a clean status.  Reverse sweep (kappa / adjoint scan / weight gradient,
+    parallel over all steps): EXACT -- {R, C} and weight gradients equal the sequential sweep's to summation
+    order (2e-5 of the largest entry).  Ragged shapes: B not a multiple of 4, T not a multiple of 16."""
+    from wdf_hip import binding as wb, mlp_root, workload
+    rng = np.random.default_rng(B * 1000 + T + hidden)
+    x = cuda(workload.sweep_batch(B, T, seed=5) * 0.5)
+    r = cuda(workload.pot_resistance_batch(B, T)) if dyn else None
+    th2 = cuda([45.0e3, 4.7e-9])
+    nw = wb.lib().wdf_mlp_weight_count(hidden, n_tanh)
+    w = cuda(rng.standard_normal(nw) * 0.3)
+    z0 = cuda(rng.uniform(-0.2, 0.2, B))
+    gy = cuda(rng.standard_normal((T, B)) / (B * T))
+    y, zs, zT = wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, FS, r=r, z0=z0, want_zT=True)
+    gth, gw = wb.clipper_mlp_bwd_w(x, th2, w, hidden, n_tanh, FS, zs, gy, r=r)
+    wrow, wmax = (mlp_root.warmup_per_wave(r, 4.7e-9, FS) if dyn else (None, 448))     # random small weights: fast forgetting
+    y2, zs2, zT2, st = wb.clipper_mlp_fwd_tp(x, th2, w, hidden, n_tanh, FS, K, wmax, r=r, warmup_per_wave=wrow, z0=z0,
+                                             want_zT=True)
+    s = wb.mlp_tp_status(st)
+    assert s["n_bad"] == 0 and s["gated_waves"] == 0 and s["max_miss"] <= 1e-6, s
+    scale = max(1.0, float(zs.abs().max()))
+    assert float((y2 - y).abs().max()) <= 2e-6 * scale and float((zs2 - zs).abs().max()) <= 2e-6 * scale
+    assert float((zT2 - zT).abs().max()) <= 2e-6 * scale
+    gth2, gw2 = wb.clipper_mlp_bwd_w_tp(x, th2, w, hidden, n_tanh, FS, zs, gy, 2 * K, r=r)
+    for a, b in ((gth2, gth), (gw2, gw)):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, (a, b)
+
+
+def test_mlp_time_parallel_forward_repairs_a_short_warmup():
+    """A warm-up far too short for the 99.1 kOhm sequences: the verify kernel gates exactly the waves that
+    missed and the gated sequential launch restores their rows -- the result is the sequential kernel's."""
+    from wdf_hip import binding as wb, workload
+    B, T, K = 40, 1024, 4
+    x = cuda(workload.sweep_batch(B, T, seed=6) * 0.5)
+    r = cuda(workload.dataset_resistance_batch(B, T))            # waves of 10k sequences converge in 32 steps, 99.1k ones do not
+    th2 = cuda([45.0e3, 4.7e-9])
+    wh, hidden, n_tanh = workload.reference_mlp_weights("2x16")  # a trained root: diode-like, slow to forget when off
+    w = cuda(wh)
+    y, zs, zT = wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, FS, r=r, want_zT=True)
+    y2, zs2, zT2, st = wb.clipper_mlp_fwd_tp(x, th2, w, hidden, n_tanh, FS, K, 32, r=r, want_zT=True)
+    s = wb.mlp_tp_status(st)
+    assert s["n_bad"] > 0 and 0 < s["gated_waves"] <= 10, s
+    assert float((y2 - y).abs().max()) <= 2e-6 and float((zs2 - zs).abs().max()) <= 2e-6
+    assert float((zT2 - zT).abs().max()) <= 2e-6
+
+
+def test_mlp_clipper_auto_plan_trains_like_the_sequential_path(golden):
+    """Circuit(..., time_parallel="auto") on a dataset-shaped batch: the planner picks the in-kernel
+    time-parallel kernels; y and every gradient equal the sequential path's."""
+    import tf_wdf as wdf
+    from tf_wdf import tf
+    from layers import DenseRootModel, DenseLayer
+    from wdf_hip import mlp_root, workload, binding as wb
+    g = golden("g3_mlp_clipper.npz")
+    B, T = 96, 2048
+    xin = cuda(np.stack([workload.sweep_batch(B, T, seed=9) * 0.6, workload.pot_resistance_batch(B, T)], axis=-1))
+    gy = cuda(np.random.default_rng(1).standard_normal((T, B)) / (B * T))
+
+    def run(tp):
+        Vs = wdf.ResistiveVoltageSource(45.0e3)
+        C = wdf.Capacitor(float(g["C"]), FS, trainable=True)
+        P1 = wdf.Parallel(Vs, C)
+        model = DenseRootModel(model_json(g, "2x16"))
+        circ = wdf.Circuit(P1, model, C, per_sample_R=Vs, time_parallel=tp)
+        y = circ(xin)
+        dense = [l for l in model.layers if isinstance(l, DenseLayer)]
+        grads = tf.GradientTape().gradient(tf.reduce_sum(y * gy), [C.C] + [d.kernel for d in dense] + [d.bias for d in dense])
+        return y, [gr.numpy().ravel() for gr in grads]
+
+    mlp_root.LAST_TP_STATUS["status"] = None
+    y_seq, g_seq = run(None)
+    assert mlp_root.LAST_TP_STATUS["status"] is None
+    y_tp, g_tp = run("auto")
+    s = wb.mlp_tp_status(mlp_root.LAST_TP_STATUS["status"])
+    assert s["n_bad"] == 0, s
+    assert float((y_tp - y_seq).abs().max()) <= 2e-6
+    for a, b in zip(g_tp, g_seq):
+        assert np.max(np.abs(a - b)) <= 2e-5 * np.max(np.abs(b)) + 1e-12

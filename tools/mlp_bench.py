@@ -80,3 +80,28 @@ for hidden, n_tanh in ((4, 3), (8, 3), (16, 3), (8, 5)):
     print(f"  {n_tanh - 1}x{hidden}: row {res[False][0]:.3f} ms, lane {res[True][0]:.3f} ms, "
           f"gtheta rel diff {float(((a[0] - b[0]).abs() / b[0].abs().clamp_min(1e-30)).max()):.1e}, "
           f"max |d gb| {float((a[1] - b[1]).abs().max()):.1e} of {float(b[1].abs().max()):.1e}")
+
+# in-kernel time-parallel kernels (csrc/wdf_mlp_tp.h): forward (per-wave warm-up, verified) and the exact
+# all-steps-parallel reverse sweep, over chunk counts
+# (pot values in contiguous blocks as the reference's loader leaves them, and the reference's trained weights:
+# random small weights make the circuit forget its state in ~10 steps and flatter every warm-up)
+print("time-parallel kernels, dataset-layout pot channel, reference weights, 1340 x 2048 (whole call: kernels + helpers):")
+r = torch.as_tensor(workload.dataset_resistance_batch(B, T), device="cuda")
+wrow, wmax = mlp_root.warmup_per_wave(r, 4.7e-9, fs)
+print(f"  warm-up per wave: min {int(wrow.min())} mean {float(wrow.float().mean()):.0f} max {wmax}")
+for name in ("2x8", "2x16", "4x8"):
+    wh, hidden, n_tanh = workload.reference_mlp_weights(name)
+    w = torch.as_tensor(wh, device="cuda")
+    y, zs, _ = wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, fs, r=r)
+    gy = torch.randn_like(y) / y.numel()
+    t_seq_f = timeit(lambda: wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, fs, r=r))
+    t_seq_b = timeit(lambda: wb.clipper_mlp_bwd_w(x, th2, w, hidden, n_tanh, fs, zs, gy, r=r))
+    print(f"  {n_tanh - 1}x{hidden}: sequential fwd {t_seq_f:.3f} ms, bwd_w {t_seq_b:.3f} ms")
+    for K in (2, 4, 6, 8, 12, 16):
+        st = torch.zeros(4, dtype=torch.int32, device="cuda")
+        tf_ = timeit(lambda: wb.clipper_mlp_fwd_tp(x, th2, w, hidden, n_tanh, fs, K, wmax, r=r, warmup_per_wave=wrow, status=st))
+        tu_ = timeit(lambda: wb.clipper_mlp_fwd_tp(x, th2, w, hidden, n_tanh, fs, K, wmax, r=r, status=st))
+        s = wb.mlp_tp_status(st)
+        tb_ = timeit(lambda: wb.clipper_mlp_bwd_w_tp(x, th2, w, hidden, n_tanh, fs, zs, gy, K, r=r))
+        tb2 = timeit(lambda: wb.clipper_mlp_bwd_w_tp(x, th2, w, hidden, n_tanh, fs, zs, gy, 2 * K, r=r))
+        print(f"    K={K:2d}: fwd_tp {tf_:.3f} ms (uniform W: {tu_:.3f}; status {s})  bwd_w_tp K {tb_:.3f} / 2K {tb2:.3f} ms")
