@@ -80,6 +80,36 @@ int wdf_ss_fwd(const float* x, const float* coef, const float* rootp, int ns, in
     return check_launch("wdf_ss_fwd");
 }
 
+size_t wdf_ss_fwd_lin_tp_ws_bytes(int ns, int64_t B, int n_chunks)
+{
+    return (ns > 0 && B > 0 && n_chunks > 0) ? (size_t)2 * (size_t)n_chunks * (size_t)ns * (size_t)B * sizeof(float) : 0;
+}
+
+int wdf_ss_fwd_lin_tp(const float* x, const float* coef, int ns, int ni, float* y, float* zstash, const float* z0, float* zT,
+                      int64_t B, int64_t T, int n_chunks, void* ws, void* stream)
+{
+    int rc = ss_check(x, coef, nullptr, ns, ni, wdf::kRootNone, 1, 1, B, T, 0);
+    if (rc) return rc;
+    if (!y || !ws) return fail(WDF_EINVAL, "null y/ws");
+    if (ns < 1) return fail(WDF_EINVAL, "a tree without states has nothing to scan: use wdf_ss_fwd");
+    if (n_chunks < 1) return fail(WDF_EINVAL, "n_chunks >= 1");
+    const int64_t L = (T + n_chunks - 1) / n_chunks;
+    const int K = (int)((T + L - 1) / L);
+    float* zend0 = (float*)ws;
+    float* zstart = zend0 + (size_t)K * (size_t)ns * (size_t)B;
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K), one((unsigned)((B + 63) / 64));
+    hipStream_t s = (hipStream_t)stream;
+#define WDF_LIN(NS_, NI_)                                                                                        \
+    if (ns == NS_ && ni == NI_) {                                                                                \
+        hipLaunchKernelGGL((wdf::ss_lin_zero_state_kernel<NS_, NI_>), grid, dim3(64), 0, s, x, coef, zend0, B, T, L);  \
+        hipLaunchKernelGGL((wdf::ss_lin_starts_kernel<NS_>), one, dim3(64), 0, s, coef, zend0, z0, zstart, B, (int64_t)K, L); \
+        hipLaunchKernelGGL((wdf::ss_lin_chunk_kernel<NS_, NI_>), grid, dim3(64), 0, s, x, coef, zstart, y, zstash, zT, B, T, L); \
+    }
+    WDF_LIN(1, 1) WDF_LIN(2, 1) WDF_LIN(3, 1) WDF_LIN(1, 2) WDF_LIN(2, 2) WDF_LIN(3, 2)
+#undef WDF_LIN
+    return check_launch("wdf_ss_fwd_lin_tp");
+}
+
 int wdf_ss_bwd(const float* x, const float* coef, const float* rootp, int ns, int ni, int root, int n_up, int n_down,
                const float* zstash, const float* gy, void* ws, float* gcoef, float* groot, float* gz0, int64_t B,
                int64_t T, int flags, void* stream)

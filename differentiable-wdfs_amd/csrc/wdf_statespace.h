@@ -177,6 +177,127 @@ __global__ __launch_bounds__(64) void ss_fwd_kernel(const float* __restrict__ x,
     }
 }
 
+// ---- exact time-parallel forward for LINEAR trees (root kind NONE) ------------------------------
+// With an ideal-source root folded in, a step is z' = A z + Bx x, y = cy . z + dy . x: the state at a
+// chunk boundary is an affine function of the state at the previous one,
+//     z(t0 + L) = A^L z(t0) + (response of the chunk's own inputs from a zero state),
+// so no speculation is needed (lpf.py:30-49 and voltage_divider.py:27-46 are such trees):
+//   1. ss_lin_zero_state_kernel  every chunk runs its inputs from z = 0 and keeps only the end state;
+//   2. ss_lin_starts_kernel      one lane per sequence walks the K chunks, z_start[k+1] = A^L z_start[k] + end0[k]
+//                                (A^L by repeated squaring in double, once per lane);
+//   3. ss_lin_chunk_kernel       every chunk runs again from its exact start state and writes y and the stash.
+// Twice the arithmetic of the sequential kernel, K times the parallelism; same result up to fp32 rounding.
+template <int NS, int NI>
+__global__ __launch_bounds__(64) void ss_lin_zero_state_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                               float* __restrict__ zend0, int64_t B, int64_t T, int64_t L)
+{
+    constexpr int NSa = NS > 0 ? NS : 1;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t k = blockIdx.y, t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+    SSCoef<NS, NI> c;
+    c.load(coef);
+    const SSDiode dp = {};
+    float z[NSa];
+#pragma unroll
+    for (int s = 0; s < NSa; ++s) z[s] = 0.0f;
+    for (int64_t t = t0; t < t1; ++t) {
+        float xt[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xt[i] = x[(b * T + t) * NI + i];
+        (void)ss_fwd_step<NS, NI, kRootNone, true>(c, dp, xt, z);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) zend0[(k * NS + s) * B + b] = z[s];
+}
+
+// zstart [K][NS][B]: exact state at the start of every chunk (zstart[0] = z0 or 0)
+template <int NS>
+__global__ __launch_bounds__(64) void ss_lin_starts_kernel(const float* __restrict__ coef, const float* __restrict__ zend0,
+                                                           const float* __restrict__ z0, float* __restrict__ zstart,
+                                                           int64_t B, int64_t K, int64_t L)
+{
+    constexpr int NSa = NS > 0 ? NS : 1;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    double P[NSa][NSa], M[NSa][NSa];                          // P = A^L
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { M[i][j] = (double)coef[i * NS + j]; P[i][j] = i == j ? 1.0 : 0.0; }
+    for (int64_t e = L; e > 0; e >>= 1) {
+        double R[NSa][NSa];
+        if (e & 1) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+#pragma unroll
+                for (int j = 0; j < NS; ++j) { double a = 0.0; for (int q = 0; q < NS; ++q) a += P[i][q] * M[q][j]; R[i][j] = a; }
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+#pragma unroll
+                for (int j = 0; j < NS; ++j) P[i][j] = R[i][j];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) { double a = 0.0; for (int q = 0; q < NS; ++q) a += M[i][q] * M[q][j]; R[i][j] = a; }
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) M[i][j] = R[i][j];
+    }
+    double z[NSa];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) z[s] = z0 ? (double)z0[s * B + b] : 0.0;
+    for (int64_t k = 0; k < K; ++k) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) zstart[(k * NS + s) * B + b] = (float)z[s];
+        double zn[NSa];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            double a = (double)zend0[(k * NS + i) * B + b];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) a += P[i][j] * z[j];
+            zn[i] = a;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) z[s] = zn[s];
+    }
+}
+
+template <int NS, int NI>
+__global__ __launch_bounds__(64) void ss_lin_chunk_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                          const float* __restrict__ zstart, float* __restrict__ y,
+                                                          float* __restrict__ zstash, float* __restrict__ zT, int64_t B,
+                                                          int64_t T, int64_t L)
+{
+    constexpr int NSa = NS > 0 ? NS : 1;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t k = blockIdx.y, t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+    SSCoef<NS, NI> c;
+    c.load(coef);
+    const SSDiode dp = {};
+    float z[NSa];
+#pragma unroll
+    for (int s = 0; s < NSa; ++s) z[s] = (NS > 0) ? zstart[(k * NS + (s < NS ? s : 0)) * B + b] : 0.0f;
+    const bool STASH = (zstash != nullptr) && NS > 0;
+    for (int64_t t = t0; t < t1; ++t) {
+        float xt[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xt[i] = x[(b * T + t) * NI + i];
+        if (STASH) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zstash[(t * NS + s) * B + b] = z[s];
+        }
+        y[t * B + b] = ss_fwd_step<NS, NI, kRootNone, true>(c, dp, xt, z);
+    }
+    if (zT && t1 == T) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) zT[s * B + b] = z[s];
+    }
+}
+
 // ---- reverse sweep -----------------------------------------------------------------------
 // With g = dL/dy[n] and lam[s] = dL/dz'[s] (state after step n):
 //   gb = fy g + E . lam ;  ga = gb D_a(a)

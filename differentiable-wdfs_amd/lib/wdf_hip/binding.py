@@ -131,6 +131,10 @@ def lib():
     L.wdf_ss_ncoef.argtypes = [ci, ci]
     L.wdf_ss_fwd.restype = ci
     L.wdf_ss_fwd.argtypes = [fp, fp, fp, ci, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, ci, vp]
+    L.wdf_ss_fwd_lin_tp_ws_bytes.restype = C.c_size_t
+    L.wdf_ss_fwd_lin_tp_ws_bytes.argtypes = [ci, i64, ci]
+    L.wdf_ss_fwd_lin_tp.restype = ci
+    L.wdf_ss_fwd_lin_tp.argtypes = [fp, fp, ci, ci, fp, fp, fp, fp, i64, i64, ci, vp, vp]
     L.wdf_ss_bwd.restype = ci
     L.wdf_ss_bwd.argtypes = [fp, fp, fp, ci, ci, ci, ci, ci, fp, fp, vp, fp, fp, fp, i64, i64, ci, vp]
     L.wdf_ss_bwd_ws_bytes.restype = C.c_size_t
@@ -167,7 +171,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_tp_chunks", "wdf_clipper_mlp_fwd_tp_ws_bytes", "wdf_clipper_mlp_fwd_tp",
     "wdf_clipper_mlp_bwd_w_tp_ws_bytes", "wdf_clipper_mlp_bwd_w_tp",
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
-    "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes",
+    "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
     "wdf_omega_f32", "wdf_diode_pair_f32", "wdf_adam_step",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy", "wdf_event_bracket_next",
 )
@@ -681,6 +685,23 @@ def ss_fwd(x, coef, ns, ni, root_kind=ROOT_NONE, rootp=None, n_up=1, n_down=1, w
     rc = lib().wdf_ss_fwd(_ptr(x), _ptr(coef), _ptr(rootp), ns, ni, root_kind, int(n_up), int(n_down),
                           _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, 0, _stream())
     _check(rc, "wdf_ss_fwd")
+    return y, zs, zT
+
+
+def ss_fwd_lin_tp(x, coef, ns, ni, n_chunks, want_stash=True, z0=None, want_zT=False):
+    """Exact chunked forward of a linear tree (root kind NONE); same returns as ss_fwd."""
+    require_gpu()
+    x, coef, z0 = _f32_dev(x, "x"), _f32_dev(coef, "coef"), _f32_dev(z0, "z0")
+    B, T = x.shape[0], x.shape[1]
+    if x.numel() != B * T * ni or coef.numel() != lib().wdf_ss_ncoef(ns, ni):
+        raise WdfHipError("ss_fwd_lin_tp: x / coef do not match ns, ni")
+    y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zs = torch.empty((T, ns, B), dtype=torch.float32, device=x.device) if want_stash else None
+    zT = torch.empty((ns, B), dtype=torch.float32, device=x.device) if want_zT else None
+    ws = torch.empty((lib().wdf_ss_fwd_lin_tp_ws_bytes(ns, B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
+    rc = lib().wdf_ss_fwd_lin_tp(_ptr(x), _ptr(coef), ns, ni, _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, int(n_chunks),
+                                 _ptr(ws), _stream())
+    _check(rc, "wdf_ss_fwd_lin_tp")
     return y, zs, zT
 
 

@@ -26,8 +26,13 @@ class _StateSpaceFn(torch.autograd.Function):
         need = coef.requires_grad or (rootp is not None and rootp.requires_grad) or (z0 is not None and z0.requires_grad)
         c = coef.detach().contiguous()
         rp = None if rootp is None else rootp.detach().contiguous()
-        y, zs, zT = binding.ss_fwd(x, c, ns, ni, root_kind, rp, n_up, n_down, want_stash=need,
-                                   z0=None if z0 is None else z0.detach().contiguous(), want_zT=want_zT)
+        z0d = None if z0 is None else z0.detach().contiguous()
+        B, T = x.shape[0], x.shape[1]
+        k_lin = min(T // 64, (2 * 1024) // max(1, -(-B // 64))) if (root_kind == binding.ROOT_NONE and ns > 0) else 0
+        if k_lin >= 2:      # linear tree, few sequences: the exact chunked scan (csrc/wdf_statespace.h) fills the chip
+            y, zs, zT = binding.ss_fwd_lin_tp(x, c, ns, ni, k_lin, want_stash=need, z0=z0d, want_zT=want_zT)
+        else:
+            y, zs, zT = binding.ss_fwd(x, c, ns, ni, root_kind, rp, n_up, n_down, want_stash=need, z0=z0d, want_zT=want_zT)
         ctx.cfg = (ns, ni, root_kind, n_up, n_down, z0 is not None)
         ctx.save_for_backward(c, rp, x, zs)
         if want_zT:

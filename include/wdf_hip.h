@@ -277,6 +277,14 @@ int wdf_ss_fwd(const float* x, const float* coef, const float* rootp,
                int ns, int ni, int root_kind, int n_up, int n_down,
                float* y, float* zstash, const float* z0, float* zT,
                int64_t B, int64_t T, int flags, void* stream);
+
+/* Exact time-parallel forward of a LINEAR tree (root kind NONE: lpf.py:30-49, voltage_divider.py:27-46 with the
+ * ideal source folded into the matrices): chunk end states from a zero state, chunk start states by
+ * z(t0 + L) = A^L z(t0) + end0, then every chunk from its exact start.  Same outputs as wdf_ss_fwd up to fp32
+ * rounding; ws: wdf_ss_fwd_lin_tp_ws_bytes(ns, B, n_chunks). */
+size_t wdf_ss_fwd_lin_tp_ws_bytes(int ns, int64_t B, int n_chunks);
+int wdf_ss_fwd_lin_tp(const float* x, const float* coef, int ns, int ni, float* y, float* zstash,
+                      const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, void* ws, void* stream);
 int wdf_ss_bwd(const float* x, const float* coef, const float* rootp,
                int ns, int ni, int root_kind, int n_up, int n_down,
                const float* zstash, const float* gy,

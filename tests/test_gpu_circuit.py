@@ -359,3 +359,30 @@ def test_circuit_mse_fused_equals_plain_path(wdf):
         l2 = tf.reduce_mean(tf.square(lp(xs) - t2))
     g2 = [float(v) for v in tape.gradient(l2, [R1.R, C1.C])]
     assert float(l1) == float(l2) and g1 == g2
+
+
+@pytest.mark.parametrize("ns", [1, 2, 3])
+@pytest.mark.parametrize("B,T,K", [(1, 1280, 16), (5, 300, 7), (130, 1001, 4)])
+def test_linear_tree_exact_chunked_scan_equals_sequential(golden, ns, B, T, K):
+    """wdf_ss_fwd_lin_tp (zero-state chunk responses, z(t0+L) = A^L z(t0) + end0, chunks re-run from their exact
+    start states) against wdf_ss_fwd on contracting random linear programs with ns = 1, 2, 3 states and an
+    initial state, and on the program recorded from lpf.py's own Model (g7): y, stash and final state to 1e-6."""
+    from wdf_hip import binding as wb
+    rng = np.random.default_rng(ns * 100 + B)
+    ni = 1
+    A = rng.standard_normal((ns, ns))
+    A *= 0.95 / max(1e-9, np.max(np.abs(np.linalg.eigvals(A))))              # spectral radius 0.95
+    coef = np.concatenate([A.ravel(), rng.standard_normal(ns * ni), np.zeros(ns), np.zeros(ns), np.zeros(ni),
+                           rng.standard_normal(ns), rng.standard_normal(ni), [0.0]])
+    x = cuda(rng.standard_normal((B, T, ni)))
+    z0 = cuda(rng.standard_normal((ns, B)))
+    c = cuda(coef)
+    y, zs, zT = wb.ss_fwd(x, c, ns, ni, z0=z0, want_zT=True)
+    y2, zs2, zT2 = wb.ss_fwd_lin_tp(x, c, ns, ni, K, z0=z0, want_zT=True)
+    scale = max(1.0, float(zs.abs().max()))
+    assert float((y2 - y).abs().max()) <= 1e-6 * scale * 4 and float((zs2 - zs).abs().max()) <= 1e-6 * scale
+    assert float((zT2 - zT).abs().max()) <= 1e-6 * scale
+    if ns == 1 and B == 1:
+        p, g = golden("g7_recorded_programs.npz"), golden("g1_rc_lowpass.npz")
+        yl, _, _ = wb.ss_fwd_lin_tp(cuda(p["lpf_x"]), cuda(p["lpf_coef"]), 1, 1, K)
+        assert np.max(np.abs(yl.cpu().numpy()[:, 0] - g["y_f64"])) < 1e-6
