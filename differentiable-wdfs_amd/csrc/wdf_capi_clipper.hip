@@ -3,6 +3,7 @@
 // 
 #include "wdf_capi_common.h"
 #include "wdf_clipper.h"
+#include "wdf_omega64.h"
 using namespace wdfcapi;
 
 namespace {
@@ -60,7 +61,6 @@ int check_common(const float* x, const float* theta, int n_up, int n_down, int64
     if (B > (int64_t)64 * 0x7fffffff) return fail(WDF_EINVAL, "B too large");
     if (n_up < 1 || n_down < 1 || n_up > 16 || n_down > 16) return fail(WDF_EINVAL, "n_up/n_down must be in [1,16]");
     if (flags & ~(WDF_X_TIME_MAJOR | WDF_PREC_F64 | WDF_GENERAL_ROOT)) return fail(WDF_EINVAL, "unknown flag bits 0x%x", flags);
-    if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 is not available for the Wright-omega clipper");
     return WDF_OK;
 }
 
@@ -158,6 +158,15 @@ int wdf_clipper_fwd(const float* x, const float* r, const float* theta, float fs
     if (!y) return fail(WDF_EINVAL, "null y");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
     const bool tm = flags & WDF_X_TIME_MAJOR;
+    if (flags & WDF_PREC_F64) {                  // tree and root in fp64 (csrc/wdf_omega64.h): the on-device accuracy reference
+        const unsigned grid = (unsigned)((B + 63) / 64);
+        hipStream_t s = (hipStream_t)stream;
+        if (r) { if (tm) hipLaunchKernelGGL((wdf::clipper_fwd_f64_kernel<true, true>), dim3(grid), dim3(64), 0, s, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, B, T);
+                 else hipLaunchKernelGGL((wdf::clipper_fwd_f64_kernel<true, false>), dim3(grid), dim3(64), 0, s, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, B, T); }
+        else   { if (tm) hipLaunchKernelGGL((wdf::clipper_fwd_f64_kernel<false, true>), dim3(grid), dim3(64), 0, s, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, B, T);
+                 else hipLaunchKernelGGL((wdf::clipper_fwd_f64_kernel<false, false>), dim3(grid), dim3(64), 0, s, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, B, T); }
+        return check_launch("wdf_clipper_fwd (fp64)");
+    }
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH4(launch_fwd, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
                   B, T, (flags & WDF_GENERAL_ROOT) ? 1 : 0, (hipStream_t)stream);
@@ -174,6 +183,7 @@ int wdf_clipper_bwd(const float* x, const float* r, const float* theta, float fs
     if (rc) return rc;
     if (!zstash || !gy || !ws || !gtheta) return fail(WDF_EINVAL, "null zstash/gy/ws/gtheta");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
+    if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 applies to wdf_clipper_fwd and wdf_omega_f64 only: the reverse sweep runs in fp32");
     const bool tm = flags & WDF_X_TIME_MAJOR;
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH4(launch_bwd, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy,
@@ -205,6 +215,7 @@ static int fwd_tp_common(const float* x, const float* r, const float* theta, flo
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
     if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
     if (B >= ((int64_t)1 << 30)) return fail(WDF_EINVAL, "time-parallel kernels address a [B] row with 32-bit byte offsets: B < 2^30");
+    if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 applies to wdf_clipper_fwd and wdf_omega_f64 only");
     const TpGeom g = tp_geom(T, n_chunks);
     const int64_t W = ((int64_t)warmup + wdf::kTile - 1) / wdf::kTile * wdf::kTile;
     float* zwarm = (float*)ws;
@@ -319,6 +330,7 @@ static int bwd_tp_common(const float* x, const float* r, const float* theta, flo
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
     if (n_chunks < 1) return fail(WDF_EINVAL, "n_chunks >= 1");
     if (B >= ((int64_t)1 << 30)) return fail(WDF_EINVAL, "time-parallel kernels address a [B] row with 32-bit byte offsets: B < 2^30");
+    if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 applies to wdf_clipper_fwd and wdf_omega_f64 only");
     const TpGeom g = tp_geom(T, n_chunks);
     double* wsd = (double*)ws;                                       // [nparts][4] doubles first (8-byte aligned)
     float* part = (float*)((char*)ws + wdf_clipper_bwd_ws_bytes(B)); // then [K][9][B] floats
@@ -353,6 +365,13 @@ int wdf_clipper_bwd_esr_tp(const float* x, const float* r, const float* theta, f
     if (skip < 0 || skip > T) return fail(WDF_EINVAL, "skip must be in 0..T");
     return bwd_tp_common(x, r, theta, fs, n_up, n_down, zstash, nullptr, target, zT, 0.0f, ws, gtheta, sse, gz0,
                          accumulate, B, T, n_chunks, flags, stream, gcoef, skip);
+}
+
+int wdf_omega_f64(const double* x, double* w, int32_t* iters, int64_t n, void* stream)
+{
+    if (!x || !w || n <= 0) return fail(WDF_EINVAL, "wdf_omega_f64: bad arguments");
+    hipLaunchKernelGGL(wdf::omega64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, iters, n);
+    return check_launch("wdf_omega_f64");
 }
 
 }  // extern "C"

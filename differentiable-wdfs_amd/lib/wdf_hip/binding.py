@@ -141,6 +141,8 @@ def lib():
     L.wdf_ss_bwd_ws_bytes.argtypes = [ci, ci, i64]
     L.wdf_omega_f32.restype = ci
     L.wdf_omega_f32.argtypes = [fp, fp, vp, i64, vp]
+    L.wdf_omega_f64.restype = ci
+    L.wdf_omega_f64.argtypes = [vp, vp, vp, i64, vp]
     L.wdf_diode_pair_f32.restype = ci
     L.wdf_diode_pair_f32.argtypes = [fp, fp, cf, cf, ci, ci, fp, i64, vp]
     L.wdf_adam_step.restype = ci
@@ -172,7 +174,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_bwd_w_tp_ws_bytes", "wdf_clipper_mlp_bwd_w_tp",
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
-    "wdf_omega_f32", "wdf_diode_pair_f32", "wdf_adam_step",
+    "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy", "wdf_event_bracket_next",
 )
 
@@ -204,9 +206,21 @@ def require_gpu():
         raise WdfHipError("no HIP device visible: the WDF engine runs on MI355X only (no CPU fallback)")
 
 
+def omega64(x, want_iters=False):
+    """Wright omega in fp64 on the device (toms917's iteration structure); x: float64 device tensor."""
+    require_gpu()
+    if not (x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()):
+        raise WdfHipError("omega64: expected a contiguous float64 device tensor")
+    w = torch.empty_like(x)
+    it = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_iters else None
+    _check(lib().wdf_omega_f64(_ptr(x), _ptr(w), _ptr(it), x.numel(), _stream()), "wdf_omega_f64")
+    return (w, it) if want_iters else w
+
+
 def clipper_fwd(x, theta, fs, r=None, n_up=1, n_down=1, want_stash=True, z0=None, want_zT=False,
-                time_major=False):
-    """x [B,T] (or [T,B] if time_major) -> y [T,B], zstash [T,B] | None, zT [B] | None."""
+                time_major=False, fp64=False):
+    """x [B,T] (or [T,B] if time_major) -> y [T,B], zstash [T,B] | None, zT [B] | None.
+    fp64: tree and root arithmetic in double (WDF_PREC_F64; sequential, the accuracy reference on the device)."""
     require_gpu()
     x = _f32_dev(x, "x")
     r = _f32_dev(r, "r")
@@ -220,7 +234,7 @@ def clipper_fwd(x, theta, fs, r=None, n_up=1, n_down=1, want_stash=True, z0=None
     y = torch.empty((T, B), dtype=torch.float32, device=x.device)
     zs = torch.empty((T, B), dtype=torch.float32, device=x.device) if want_stash else None
     zT = torch.empty((B,), dtype=torch.float32, device=x.device) if want_zT else None
-    flags = (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag()
+    flags = (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag() | (WDF_PREC_F64 if fp64 else 0)
     rc = lib().wdf_clipper_fwd(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
                                _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, flags, _stream())
     _check(rc, "wdf_clipper_fwd")

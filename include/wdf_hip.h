@@ -43,7 +43,9 @@ enum {
 /* flags */
 enum {
     WDF_X_TIME_MAJOR = 1 << 0, /* x (and r) are [T][B] instead of [B][T]                 */
-    WDF_PREC_F64     = 1 << 1, /* evaluate the root solve in fp64 (config C5); I/O stays f32 */
+    WDF_PREC_F64     = 1 << 1, /* wdf_clipper_fwd only: tree and root (Wright omega with toms917's second-iteration
+                                  test, csrc/wdf_omega64.h) in fp64, I/O stays f32 -- the on-device accuracy
+                                  reference of config C5; every other entry point answers WDF_EUNSUPPORTED */
     WDF_MLP_LANE_PER_SEQUENCE = 1 << 4, /* MLP-root kernels: the one-lane-per-sequence variant (csrc/wdf_mlp.h)
                                   instead of the default 16-lane row per sequence (csrc/wdf_mlp_row.h) */
     WDF_GENERAL_ROOT = 1 << 3  /* always take the general per-step root evaluation (the kernels otherwise
@@ -315,6 +317,8 @@ int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, doubl
  * toms917.cpp.  R_port is the port resistance seen by the root (P1.R).
  * iters (optional int32[n]) receives the number of FSC iterations taken per element.     */
 int wdf_omega_f32(const float* x, float* w, int32_t* iters, int64_t n, void* stream);
+/* omega in fp64 with the reference's iteration count (iters: 0 = start value only, 1, 2: toms917.cpp:347-364) */
+int wdf_omega_f64(const double* x, double* w, int32_t* iters, int64_t n, void* stream);
 int wdf_diode_pair_f32(const float* a, const float* R_port, float Is, float nVt,
                        int n_up, int n_down, float* b, int64_t n, void* stream);
 

@@ -292,3 +292,45 @@ def test_error_behaviour_of_the_training_entry_points(wb):
         rc = wb.lib().wdf_clipper_fwd(x.data_ptr(), None, th.data_ptr(), FS, 1, 1, y.data_ptr(), None, None, None, 4, 64,
                                       1 << 9, None)
         wb._check(rc, "wdf_clipper_fwd")
+
+
+# ------------------------------------------------------------------------------- fp64 on the device
+def test_omega_fp64_matches_the_reference_build_and_its_iteration_count(wb, oracle, golden):
+    """wdf_omega_f64 (csrc/wdf_omega64.h) against the goldens of the REAL toms917 build and mpmath (g5), and
+    its iteration count -- the reference's second FSC iteration behind a wavefront ballot -- against the
+    oracle's restatement of toms917.cpp:356-364 on the same arguments."""
+    g = golden("g5_omega.npz")
+    x = torch.as_tensor(g["x"], dtype=torch.float64, device="cuda").contiguous()
+    w, it = wb.omega64(x, want_iters=True)
+    w, it = w.cpu().numpy(), it.cpu().numpy()
+    sel = g["x"] > -700
+    # The FSC residual r = x - w - log w cancels to ~|x| eps wherever log w ~ x (x << 0), in the reference as
+    # here, so two libms differ by ~|x| eps there: bound 2.2e-16 (2 + |x|), observed 3.6e-15 at x = -22 (1.4 |x| eps)
+    bound = 2.2e-16 * (2.0 + np.abs(g["x"]))
+    assert np.all((np.abs(w - g["w_toms917"]) / g["w_toms917"])[sel] <= bound[sel])
+    assert np.all((np.abs(w - g["w_mpmath"]) / g["w_mpmath"])[sel] <= bound[sel])
+    mid = (g["x"] > -2) & (g["x"] < 100)
+    assert np.max(np.abs(w - g["w_mpmath"])[mid] / g["w_mpmath"][mid]) < 1e-15
+    _, it_ref = oracle.wright_omega_iters(g["x"])
+    assert np.array_equal(it[sel], it_ref[sel]) and it.max() == 2 and it.min() >= 1        # the second iteration really runs
+
+
+@pytest.mark.parametrize("cfg,n_up,n_down", [("1u1d", 1, 1), ("2u3d", 2, 3)])
+def test_clipper_forward_fp64_root(wb, oracle, golden, cfg, n_up, n_down):
+    """WDF_PREC_F64: tree and root in double on the device -> the fp64 oracle / golden to output rounding
+    (y is stored as fp32: half an ulp of |y| <= 1 V = 3e-8), 10x closer than the fp32 kernels; the reverse
+    sweep refuses the flag."""
+    g = golden("g6_diode_clipper.npz")
+    th = dev(g["theta"])
+    x = dev(g["x"])
+    y, zs, zT = wb.clipper_fwd(x, th, FS, n_up=n_up, n_down=n_down, want_zT=True, fp64=True)
+    th64 = g["theta"].astype(np.float32).astype(np.float64)
+    ref = oracle.clipper_fwd(th64, FS, g["x"].astype(np.float32).astype(np.float64), n_up=n_up, n_down=n_down)
+    assert np.max(np.abs(y.cpu().numpy() - ref)) < 6e-8
+    assert np.max(np.abs(y.cpu().numpy() - g[f"y_{cfg}_f64"])) < 5e-7                      # golden: unrounded f64 inputs
+    y32, _, _ = wb.clipper_fwd(x, th, FS, n_up=n_up, n_down=n_down)
+    assert float((y32 - y).abs().max()) < Y_TOL
+    r = dev(g["r"])
+    yr, _, _ = wb.clipper_fwd(x, th, FS, r=r, fp64=True)
+    refr = oracle.clipper_fwd(th64, FS, g["x"].astype(np.float32).astype(np.float64), r=g["r"].astype(np.float32).astype(np.float64))
+    assert np.max(np.abs(yr.cpu().numpy() - refr)) < 6e-8
