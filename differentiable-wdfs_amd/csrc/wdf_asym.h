@@ -120,7 +120,8 @@ struct AsymStep<false> {
 template <bool NEWTON, bool VEC4>
 __global__ __launch_bounds__(64) void clipper_asym_fwd_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ theta6, float fs,
-                                                              float* __restrict__ y, const float* __restrict__ z0,
+                                                              float* __restrict__ y, float* __restrict__ zstash,
+                                                              const float* __restrict__ z0,
                                                               float* __restrict__ zT, double tol, int max_iter,
                                                               long long* __restrict__ iters_out, int64_t B, int64_t T)
 {
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(64) void clipper_asym_fwd_kernel(const float* __res
     const int64_t b = b_raw < B ? b_raw : B - 1;
     const AsymConsts c = asym_load(theta6, fs);
     float* __restrict__ yp = y + b;
+    float* __restrict__ zp = zstash ? zstash + b : nullptr;   // state BEFORE each step, for clipper_asym_bwd_kernel
     int iters = 0;
     S z = z0 ? (S)z0[b] : (S)0;
     constexpr int kB = 8;
@@ -153,16 +155,101 @@ __global__ __launch_bounds__(64) void clipper_asym_fwd_kernel(const float* __res
         if (blk + 1 < nfull) load8((blk + 1) * kB, xn);       // one block ahead of the recursion
 #pragma unroll
         for (int k = 0; k < kB; ++k) {
+            if (zp) { *zp = (float)z; zp += B; }
             *yp = AsymStep<NEWTON>::run(c, xc[k], z, tol, max_iter, iters);
             yp += B;
         }
     }
     for (int64_t t = nfull * kB; t < T; ++t) {
+        if (zp) { *zp = (float)z; zp += B; }
         *yp = AsymStep<NEWTON>::run(c, x[b * T + t], z, tol, max_iter, iters);
         yp += B;
     }
     if (zT) zT[b] = (float)z;
     if (iters_out && threadIdx.x == 0) iters_out[blockIdx.x] = iters;   // wave-uniform count
+}
+
+// ---- reverse sweep of the Newton-mode loop ---------------------------------------------------------
+// The root is defined implicitly, F(v; a) = v + Rp i(v) - a = 0, b = 2 v - a.  With F_v = 1 + Rp i'(v):
+//     d b / d a  = 2 / F_v - 1                        (=: Da)
+//     d b / d th = -2 F_th / F_v   for th in {Is1, V1, Is2, V2, Rp}:
+//         F_Is1 = Rp (e1 - 1) ; F_V1 = -Rp Is1 e1 v / V1^2 ; F_Is2 = -Rp (e2 - 1) ; F_V2 = -Rp Is2 e2 v / V2^2 ; F_Rp = i(v)
+//     (e1 = exp(v/V1), e2 = exp(-v/V2)).  The tree around it is the clipper's (wdf_clipper.h bwd_step):
+//     g_b2n = gz + g/2 ; g_a = g_b2n Da ; g_bt = g_b2n + g_a ; S_p += -g_bt b_diff ; gz <- -p g_bt + g/2 + g_a.
+// Per step the root is re-solved from the stashed state (fp64 Newton from the omega closed form, as the
+// forward does).  ws: double[gridDim.x][8] per-wave sums {S_Is1, S_V1, S_Is2, S_V2, S_Rp, S_p, 0, 0}.
+static __global__ __launch_bounds__(64) void clipper_asym_bwd_kernel(const float* __restrict__ x, const float* __restrict__ theta6,
+                                                                     float fs, const float* __restrict__ zstash,
+                                                                     const float* __restrict__ gy, double tol, int max_iter,
+                                                                     double* __restrict__ ws, int64_t B, int64_t T)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    const AsymConsts c = asym_load(theta6, fs);
+    const double Rp = c.Rp, p = c.p, Is1 = c.Is1, Is2 = c.Is2, V1 = c.V1, V2 = c.V2;
+    double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double gz = 0.0;
+    int iters = 0;
+    for (int64_t t = T - 1; t >= 0; --t) {
+        const double z = (double)zstash[t * B + b], xin = (double)x[b * T + t], g = (double)gy[t * B + b];
+        const double b_diff = z - xin;
+        const double a = z - p * b_diff;
+        const float bw = asym_omega_root(c, (float)a);
+        const double br = asym_newton_root(c, a, 0.5 * (a + (double)bw), tol, max_iter, iters);
+        const double v = 0.5 * (a + br);
+        const double e1 = exp(v / V1), e2 = exp(-v / V2);
+        const double iF = 1.0 / (1.0 + Rp * (Is1 / V1 * e1 + Is2 / V2 * e2));
+        const double Da = 2.0 * iF - 1.0;
+        const double g_b2n = gz + 0.5 * g;
+        const double k2 = -2.0 * iF * g_b2n;                              // g_b2n d b / d th = k2 F_th
+        s[0] += k2 * Rp * (e1 - 1.0);
+        s[1] += k2 * (-Rp * Is1 * e1 * v / (V1 * V1));
+        s[2] += k2 * (-Rp * (e2 - 1.0));
+        s[3] += k2 * (-Rp * Is2 * e2 * v / (V2 * V2));
+        s[4] += k2 * (Is1 * (e1 - 1.0) - Is2 * (e2 - 1.0));
+        const double g_a = g_b2n * Da;
+        const double g_bt = g_b2n + g_a;
+        s[5] += -g_bt * b_diff;
+        gz = -p * g_bt + 0.5 * g + g_a;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = live ? s[i] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0) ws[(int64_t)blockIdx.x * 8 + i] = v;
+    }
+}
+
+// fixed-order sum over the waves + chain rule Rp = 1/(G1+G2), p = G1 Rp (G1 = 1/R, G2 = 2 C fs) -> gtheta6
+static __global__ __launch_bounds__(256) void clipper_asym_grad_reduce_kernel(const double* __restrict__ ws, int nparts,
+                                                                              const float* __restrict__ theta6, float fs,
+                                                                              float* __restrict__ gtheta6)
+{
+    __shared__ double sh[256][6];
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nparts; i += 256)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a[q] += ws[(int64_t)i * 8 + q];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) sh[threadIdx.x][q] = a[q];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) sh[threadIdx.x][q] += sh[threadIdx.x + off][q];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double R = theta6[4], C = theta6[5];
+        const double G1 = 1.0 / R, G2 = C * (2.0 * (double)fs), Rp = 1.0 / (G1 + G2), p = G1 * Rp;
+        const double SRp = sh[0][4], Sp = sh[0][5];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gtheta6[q] = (float)sh[0][q];
+        gtheta6[4] = (float)(SRp * Rp * Rp * G1 * G1 - Sp * G1 * G1 * Rp * (1.0 - p));
+        gtheta6[5] = (float)(-2.0 * (double)fs * (SRp * Rp * Rp + Sp * p * Rp));
+    }
 }
 
 // element-wise root, for accuracy sweeps: b[i] = root(a[i])

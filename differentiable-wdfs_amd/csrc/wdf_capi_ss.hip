@@ -132,7 +132,7 @@ int wdf_ss_bwd(const float* x, const float* coef, const float* rootp, int ns, in
 }
 
 int wdf_clipper_asym_fwd(const float* x, const float* theta6, float fs, int mode, double tol, int max_iter, float* y,
-                         const float* z0, float* zT, long long* iters, int64_t B, int64_t T, void* stream)
+                         float* zstash, const float* z0, float* zT, long long* iters, int64_t B, int64_t T, void* stream)
 {
     if (!x || !theta6 || !y) return fail(WDF_EINVAL, "null x/theta6/y");
     if (B <= 0 || T <= 0 || !(fs > 0.0f)) return fail(WDF_EINVAL, "B, T, fs must be positive");
@@ -142,11 +142,27 @@ int wdf_clipper_asym_fwd(const float* x, const float* theta6, float fs, int mode
     const bool v4 = (T % 4 == 0) && aligned16(x);
 #define WDF_ASYM(NEWTON_, V4_)                                                                                \
     hipLaunchKernelGGL((wdf::clipper_asym_fwd_kernel<NEWTON_, V4_>), dim3(grid), dim3(64), 0, (hipStream_t)stream, x, \
-                       theta6, fs, y, z0, zT, tol, max_iter, iters, B, T)
+                       theta6, fs, y, zstash, z0, zT, tol, max_iter, iters, B, T)
     if (mode == WDF_ASYM_NEWTON_F64) { if (v4) WDF_ASYM(true, true); else WDF_ASYM(true, false); }
     else { if (v4) WDF_ASYM(false, true); else WDF_ASYM(false, false); }
 #undef WDF_ASYM
     return check_launch("wdf_clipper_asym_fwd");
+}
+
+size_t wdf_clipper_asym_bwd_ws_bytes(int64_t B) { return B > 0 ? (size_t)((B + 63) / 64) * 8 * sizeof(double) : 0; }
+
+int wdf_clipper_asym_bwd(const float* x, const float* theta6, float fs, double tol, int max_iter, const float* zstash,
+                         const float* gy, void* ws, float* gtheta6, int64_t B, int64_t T, void* stream)
+{
+    if (!x || !theta6 || !zstash || !gy || !ws || !gtheta6) return fail(WDF_EINVAL, "null x/theta6/zstash/gy/ws/gtheta6");
+    if (B <= 0 || T <= 0 || !(fs > 0.0f)) return fail(WDF_EINVAL, "B, T, fs must be positive");
+    if (!(tol > 0.0) || max_iter < 1) return fail(WDF_EINVAL, "tol > 0, max_iter >= 1");
+    const unsigned grid = (unsigned)((B + 63) / 64);
+    hipLaunchKernelGGL(wdf::clipper_asym_bwd_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, x, theta6, fs, zstash, gy, tol,
+                       max_iter, (double*)ws, B, T);
+    hipLaunchKernelGGL(wdf::clipper_asym_grad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
+                       (int)grid, theta6, fs, gtheta6);
+    return check_launch("wdf_clipper_asym_bwd");
 }
 
 int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, double tol, int max_iter, double* b, int64_t n,

@@ -94,7 +94,11 @@ def lib():
     L.wdf_clipper_bwd_esr_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, fp, i64, vp, fp, fp, fp, ci, i64, i64, ci,
                                          ci, vp]
     L.wdf_clipper_asym_fwd.restype = ci
-    L.wdf_clipper_asym_fwd.argtypes = [fp, fp, cf, ci, C.c_double, ci, fp, fp, fp, vp, i64, i64, vp]
+    L.wdf_clipper_asym_fwd.argtypes = [fp, fp, cf, ci, C.c_double, ci, fp, fp, fp, fp, vp, i64, i64, vp]
+    L.wdf_clipper_asym_bwd_ws_bytes.restype = C.c_size_t
+    L.wdf_clipper_asym_bwd_ws_bytes.argtypes = [i64]
+    L.wdf_clipper_asym_bwd.restype = ci
+    L.wdf_clipper_asym_bwd.argtypes = [fp, fp, cf, C.c_double, ci, fp, fp, vp, fp, i64, i64, vp]
     L.wdf_asym_root.restype = ci
     L.wdf_asym_root.argtypes = [fp, fp, cf, ci, C.c_double, ci, vp, i64, vp]
     L.wdf_mlp_weight_count.restype = ci
@@ -167,7 +171,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_fwd_tp_state_bytes", "wdf_clipper_fwd_tp_state_reset", "wdf_clipper_fwd_tp_warm",
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp_ws_init", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_bwd_mse_tp_adam", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
-    "wdf_clipper_asym_fwd", "wdf_asym_root",
+    "wdf_clipper_asym_fwd", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
     "wdf_clipper_mlp_tp_chunks", "wdf_clipper_mlp_fwd_tp_ws_bytes", "wdf_clipper_mlp_fwd_tp",
@@ -648,8 +652,9 @@ def clipper_mlp_wgrad(ain, lrin, gb, theta2, w, hidden, n_tanh, fs):
 ASYM_OMEGA_F32, ASYM_NEWTON_F64 = 0, 1
 
 
-def clipper_asym_fwd(x, theta6, fs, mode, tol=1e-12, max_iter=50, z0=None, want_zT=False, want_iters=False):
-    """Two-different-diode clipper forward.  Returns y [T,B], zT | None, iters (int64 per wave) | None."""
+def clipper_asym_fwd(x, theta6, fs, mode, tol=1e-12, max_iter=50, z0=None, want_zT=False, want_iters=False, want_stash=False):
+    """Two-different-diode clipper forward.  Returns y [T,B], zT | None, iters (int64 per wave) | None
+    (and the state stash [T,B] as a fourth value when want_stash)."""
     require_gpu()
     x = _f32_dev(x, "x")
     theta6 = _f32_dev(theta6, "theta6")
@@ -660,10 +665,26 @@ def clipper_asym_fwd(x, theta6, fs, mode, tol=1e-12, max_iter=50, z0=None, want_
     y = torch.empty((T, B), dtype=torch.float32, device=x.device)
     zT = torch.empty((B,), dtype=torch.float32, device=x.device) if want_zT else None
     it = torch.zeros(((B + 63) // 64,), dtype=torch.int64, device=x.device) if want_iters else None
+    zs = torch.empty((T, B), dtype=torch.float32, device=x.device) if want_stash else None
     rc = lib().wdf_clipper_asym_fwd(_ptr(x), _ptr(theta6), float(fs), int(mode), float(tol), int(max_iter), _ptr(y),
-                                    _ptr(z0), _ptr(zT), _ptr(it), B, T, _stream())
+                                    _ptr(zs), _ptr(z0), _ptr(zT), _ptr(it), B, T, _stream())
     _check(rc, "wdf_clipper_asym_fwd")
-    return y, zT, it
+    return (y, zT, it, zs) if want_stash else (y, zT, it)
+
+
+def clipper_asym_bwd(x, theta6, fs, zstash, gy, tol=1e-12, max_iter=50):
+    """dL/d{Is_up, nVt_up, Is_down, nVt_down, R, C} of the Newton-mode loop for dL/dy = gy [T,B]."""
+    require_gpu()
+    x, theta6, zstash, gy = _f32_dev(x, "x"), _f32_dev(theta6, "theta6"), _f32_dev(zstash, "zstash"), _f32_dev(gy, "gy")
+    B, T = x.shape
+    if tuple(gy.shape) != (T, B) or tuple(zstash.shape) != (T, B):
+        raise WdfHipError(f"gy / zstash must be [T,B] = [{T},{B}]")
+    ws = torch.empty((lib().wdf_clipper_asym_bwd_ws_bytes(B),), dtype=torch.uint8, device=x.device)
+    g = torch.empty((6,), dtype=torch.float32, device=x.device)
+    rc = lib().wdf_clipper_asym_bwd(_ptr(x), _ptr(theta6), float(fs), float(tol), int(max_iter), _ptr(zstash), _ptr(gy),
+                                    _ptr(ws), _ptr(g), B, T, _stream())
+    _check(rc, "wdf_clipper_asym_bwd")
+    return g
 
 
 def asym_root(a, theta6, fs, mode, tol=1e-12, max_iter=50):

@@ -189,6 +189,30 @@ def clipper_stateful(theta, x, fs, r=None, n_up=1, n_down=1, z0=None):
     return _ClipperStatefulFn.apply(theta, x, r, z0, float(fs), int(n_up), int(n_down))
 
 
+class _ClipperAsymFn(torch.autograd.Function):
+    """y [T,B] = clipper with two different antiparallel diodes (fp64 Newton on the exact Shockley pair),
+    differentiable w.r.t. theta6 = {Is_up, nVt_up, Is_down, nVt_down, R, C} (csrc/wdf_asym.h)."""
+
+    @staticmethod
+    def forward(ctx, theta6, x, fs, tol, max_iter):
+        th = theta6.detach().contiguous()
+        y, _, _, zs = binding.clipper_asym_fwd(x, th, fs, binding.ASYM_NEWTON_F64, tol=tol, max_iter=max_iter, want_stash=True)
+        ctx.cfg = (fs, tol, max_iter)
+        ctx.save_for_backward(th, x, zs)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        fs, tol, max_iter = ctx.cfg
+        th, x, zs = ctx.saved_tensors
+        return binding.clipper_asym_bwd(x, th, fs, zs, gy.contiguous(), tol=tol, max_iter=max_iter), None, None, None, None
+
+
+def clipper_asym(theta6, x, fs, tol=1.0e-12, max_iter=50):
+    """Two-different-diode clipper loop (BASELINE config 5), Newton mode, with gradients to all six parameters."""
+    return _ClipperAsymFn.apply(theta6, x, float(fs), float(tol), int(max_iter))
+
+
 class MseStep:
     """Fused training step for the mean-squared-error loss (lpf.py:78, clipper_pot.py:176):
     forward, loss and reverse sweep in two kernel launches + three tiny ones, all buffers

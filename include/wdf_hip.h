@@ -302,12 +302,20 @@ size_t wdf_ss_bwd_ws_bytes(int ns, int ni, int64_t B);
  *         WDF_ASYM_NEWTON_F64: fp64 Newton on the exact Shockley pair, iterated per wave until
  *         every lane meets |dv| <= tol (|v| + nVt) (wavefront ballot) or max_iter.
  * iters   optional device int64[(B+63)/64]: Newton iterations each wave ran (sum / (B T / 64
- *         * ...) gives the mean per sample).  Forward only.
+ *         * ...) gives the mean per sample).
+ * zstash  optional [T][B]: state before each step, for wdf_clipper_asym_bwd.
+ * wdf_clipper_asym_bwd: reverse sweep of the NEWTON-mode loop (the exact model) for a given dL/dy: the root
+ *         is re-solved per step from the stash and differentiated implicitly (F(v; a, theta) = 0);
+ *         gtheta6 = dL/d{Is_up, nVt_up, Is_down, nVt_down, R, C}; ws: wdf_clipper_asym_bwd_ws_bytes(B).
  * wdf_asym_root: b[i] = root(a[i]) (double out) for accuracy sweeps.
  * ---------------------------------------------------------------------------------- */
 enum { WDF_ASYM_OMEGA_F32 = 0, WDF_ASYM_NEWTON_F64 = 1 };
 int wdf_clipper_asym_fwd(const float* x, const float* theta6, float fs, int mode, double tol, int max_iter,
-                         float* y, const float* z0, float* zT, long long* iters,
+                         float* y, float* zstash, const float* z0, float* zT, long long* iters,
+                         int64_t B, int64_t T, void* stream);
+size_t wdf_clipper_asym_bwd_ws_bytes(int64_t B);
+int wdf_clipper_asym_bwd(const float* x, const float* theta6, float fs, double tol, int max_iter,
+                         const float* zstash, const float* gy, void* ws, float* gtheta6,
                          int64_t B, int64_t T, void* stream);
 int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, double tol, int max_iter,
                   double* b, int64_t n, void* stream);

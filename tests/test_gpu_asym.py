@@ -57,3 +57,33 @@ def test_forward_vs_oracle(oracle, B, T):
     ys, _, _ = wb.clipper_asym_fwd(dev(x), dev(th_sym), FS, wb.ASYM_OMEGA_F32)
     yc, _, _ = wb.clipper_fwd(dev(x), dev(th_sym[[0, 1, 4, 5]]), FS, want_stash=False)
     assert float((ys - yc).abs().max()) < 2e-6
+
+
+def test_reverse_sweep_vs_oracle_finite_differences(oracle):
+    """dL/d{Is_up, nVt_up, Is_down, nVt_down, R, C} of L = sum(y gy) through the Newton-mode loop (implicit
+    differentiation of the root, re-solved from the stash) against fp64 central differences of the oracle's
+    forward (relative step 1e-6 per parameter): 2e-4 relative per component (observed <= 3e-5; the parameters
+    themselves are fp32 on the device)."""
+    from wdf_hip import binding as wb, engine, workload
+    B, T = 70, 600
+    x = workload.sweep_batch(B, T, seed=3)
+    rng = np.random.default_rng(0)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    th = dev(THETA6).requires_grad_(True)
+    y = engine.clipper_asym(th, dev(x), FS)
+    (y * dev(gy)).sum().backward()
+    got = th.grad.cpu().numpy().astype(np.float64)
+    t32 = THETA6.astype(np.float32).astype(np.float64)
+    x64, g64 = x.astype(np.float64), gy.astype(np.float64)
+    ref = np.zeros(6)
+    for i in range(6):
+        h = 1e-6 * t32[i]
+        tp, tm = t32.copy(), t32.copy()
+        tp[i] += h
+        tm[i] -= h
+        ref[i] = (np.sum(oracle.clipper_asym_fwd(tp, FS, x64) * g64) - np.sum(oracle.clipper_asym_fwd(tm, FS, x64) * g64)) / (2 * h)
+    err = np.abs(got - ref) / np.abs(ref)
+    assert np.max(err) < 2e-4, (got, ref, err)
+    # and the forward it differentiates is the plain Newton forward
+    y2, _, _ = wb.clipper_asym_fwd(dev(x), dev(THETA6), FS, wb.ASYM_NEWTON_F64, tol=1e-12)
+    assert torch.equal(y.detach(), y2)
