@@ -45,7 +45,73 @@ class Tensor(torch.Tensor):
     def __float__(self):
         return float(self.detach().as_subclass(torch.Tensor))
 
+    # Scalar component arithmetic is MEMOISED while a script's loop is being recorded (wdf_hip.trace): a script
+    # that calls calc_impedance() every time step (clipper_pot.py:117) recomputes 1/(2 C FS), 1/R, -p1R ...
+    # thousands of times from unchanged variables; handing back the SAME result object costs a dictionary
+    # look-up instead of a torch dispatch, and lets the recorder's replay memo recognise the coefficient.
+    # The memo lives in the Recorder -- one forward pass, one autograd graph, gone when the loop is lowered --
+    # and is keyed on operand identity and version.
+    def _scalar_memo(self, name, other, fn):
+        rec = _trace_current()
+        if rec is None:
+            return fn()
+        d = self.__dict__
+        with torch._C.DisableTorchFunctionSubclass():       # plain attribute reads: no subclass dispatch (2 us each)
+            n = d.get("_wdf_n")
+            if n is None:
+                n = d["_wdf_n"] = self.numel()
+            if n != 1:
+                return fn()
+            ver = self._version
+            if isinstance(other, (int, float)):
+                ko = other
+            elif other is None:
+                ko = None
+            elif isinstance(other, torch.Tensor) and other.numel() == 1:
+                ko = (id(other), other._version)
+            else:
+                return fn()
+        key = (id(self), ver, name, ko)
+        hit = rec.scalar_memo.get(key)
+        if hit is None:
+            hit = rec.scalar_memo[key] = (fn(), self, other)     # keeps the operands alive: their ids stay their own
+        return hit[0]
+
+    def __neg__(self):
+        return self._scalar_memo("neg", None, lambda: torch.Tensor.__neg__(self))
+
+    def __mul__(self, other):
+        if isinstance(other, (int, float, torch.Tensor)):
+            return self._scalar_memo("mul", other, lambda: torch.Tensor.__mul__(self, other))
+        return torch.Tensor.__mul__(self, other)
+
+    def __rmul__(self, other):
+        if isinstance(other, (int, float)):
+            return self._scalar_memo("mul", other, lambda: torch.Tensor.__rmul__(self, other))
+        return torch.Tensor.__rmul__(self, other)
+
+    def __truediv__(self, other):
+        if isinstance(other, (int, float, torch.Tensor)):
+            return self._scalar_memo("div", other, lambda: torch.Tensor.__truediv__(self, other))
+        return torch.Tensor.__truediv__(self, other)
+
+    def __rtruediv__(self, other):
+        if isinstance(other, (int, float)):
+            return self._scalar_memo("rdiv", other, lambda: torch.Tensor.__rtruediv__(self, other))
+        return torch.Tensor.__rtruediv__(self, other)
+
+    def __add__(self, other):
+        if isinstance(other, (int, float, torch.Tensor)):
+            return self._scalar_memo("add", other, lambda: torch.Tensor.__add__(self, other))
+        return torch.Tensor.__add__(self, other)
+
     def __getitem__(self, idx):
+        # inside a recorded loop (from its second step on) the slice itself is never looked at: the recorder
+        # needs to know WHICH sample this is, not its values -- hand back a stand-in that materialises on demand
+        if (type(idx) is tuple and len(idx) >= 2 and type(idx[1]) is int and type(idx[0]) is slice and idx[0] == _FULL):
+            rec = _trace_current()
+            if rec is not None and rec.parent is self and rec.step >= 0 and rec.sample_shape is not None:
+                return _LazySample(self, idx)
         out = super().__getitem__(idx)
         # `input[:, i]` / `input[:, i, 0:1]` (lpf.py:40, clipper_pot.py:114-116): remember which
         # sample of which sequence tensor this is, so the loop recorder (wdf_hip.trace) can
@@ -59,6 +125,51 @@ class Tensor(torch.Tensor):
         if self.numel() == 1:
             return format(float(self.detach()), spec)
         return str(self)
+
+
+_FULL = slice(None)
+
+
+_trace_mod = None
+
+
+def _trace_current():
+    global _trace_mod
+    if _trace_mod is None:
+        from . import trace
+        _trace_mod = trace
+    return _trace_mod._current
+
+
+class _LazySample:
+    """`input[:, i(, c)]` inside a recorded loop: carries where the sample comes from (_wdf_src) and its shape;
+    anything else a script asks of it is answered by the real slice, made on first use."""
+    __slots__ = ("_wdf_src", "_parent", "_idx", "_real")
+
+    def __init__(self, parent, idx):
+        self._wdf_src = (parent, idx[1], tuple(idx[2:]))
+        self._parent, self._idx, self._real = parent, idx, None
+
+    def _materialise(self):
+        if self._real is None:
+            self._real = torch.Tensor.__getitem__(self._parent, self._idx)
+            self._real._wdf_src = self._wdf_src
+        return self._real
+
+    @property
+    def shape(self):
+        rec = _trace_current()
+        if rec is not None and rec.parent is self._parent and rec.sample_shape is not None:
+            return rec.sample_shape
+        return self._materialise().shape
+
+    def __getattr__(self, name):
+        return getattr(self._materialise(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        args = tuple(a._materialise() if isinstance(a, _LazySample) else a for a in args)
+        return func(*args, **(kwargs or {}))
 
 
 def _wrap(t):
@@ -294,12 +405,16 @@ def reduce_max(x, axis=None):
 def _reciprocal(x):
     if hasattr(x, "__wdf_reciprocal__"):
         return x.__wdf_reciprocal__()
+    if isinstance(x, Tensor):
+        return x._scalar_memo("recip", None, lambda: _wrap(torch.reciprocal(x)))
     return _wrap(torch.reciprocal(convert(x)))
 
 
 def _log(x):
     if hasattr(x, "__wdf_log__"):
         return x.__wdf_log__()
+    if isinstance(x, Tensor):
+        return x._scalar_memo("log", None, lambda: _wrap(torch.log(x)))
     return _wrap(torch.log(convert(x)))
 
 

@@ -108,6 +108,7 @@ def _scalar(v):
 
 # shared constants: coefficient vectors are never modified in place (every operation builds a new one)
 _EYE = torch.eye(NB, dtype=torch.float64)
+_EYE_ROWS = [_EYE[i] for i in range(NB)]      # ONE object per basis vector: the replay memo keys on identity
 _ZERO = torch.zeros(NB, dtype=torch.float64)
 
 
@@ -121,7 +122,7 @@ class Wave:
     # -- construction helpers
     @staticmethod
     def basis(rec, slot):
-        return Wave(rec, _EYE[slot])
+        return Wave(rec, _EYE_ROWS[slot])
 
     def _fresh(self):
         if self.step != self.rec.step:
@@ -132,24 +133,46 @@ class Wave:
     def _coerce(self, other):
         if isinstance(other, Wave):
             return other._fresh()
+        if isinstance(other, (int, float)):                   # constants: one vector per value (replay memo keys on identity)
+            return Wave(self.rec, self._memo(("const", float(other)), (), lambda: _unit0() * float(other)))
         s = _scalar(other)
         if s is None:
             raise WdfTraceError(f"cannot combine a recorded wave with {type(other).__name__} of shape "
                                 f"{tuple(getattr(other, 'shape', ()))}")
         return Wave(self.rec, _unit0() * s)
 
-    # -- affine arithmetic
+    # -- affine arithmetic.  REPLAY: every time step of a script's loop repeats the first one's operations on
+    # waves whose coefficient vectors are the SAME objects (basis rows are shared, results come out of this
+    # memo), so from the second step on an operation is one dictionary look-up keyed on operand identity
+    # instead of torch arithmetic on 16-vectors.  The memo keeps its operands alive (no id is recycled).
+    def _memo(self, key, keep, make):
+        memo = self.rec.memo
+        hit = memo.get(key)
+        if hit is None:
+            hit = memo[key] = (make(), keep)
+        return hit[0]
+
     def __add__(self, other):
-        o = self._coerce(other)
-        self._fresh()
-        c1 = self.c1 if o.c1 is None else (o.c1 if self.c1 is None else self.c1 + o.c1)
-        return Wave(self.rec, self.c0 + o.c0, c1)
+        if isinstance(other, Wave):
+            o = other
+            if o.step != self.rec.step or self.step != self.rec.step:
+                o._fresh(); self._fresh()
+            hit = self.rec.memo.get(("add", id(self.c0), id(self.c1), id(o.c0), id(o.c1)))
+            if hit is not None:
+                return Wave(self.rec, hit[0][0], hit[0][1])
+            c0, c1 = self._memo(("add", id(self.c0), id(self.c1), id(o.c0), id(o.c1)), (self.c0, self.c1, o.c0, o.c1),
+                                lambda: (self.c0 + o.c0,
+                                         self.c1 if o.c1 is None else (o.c1 if self.c1 is None else self.c1 + o.c1)))
+            return Wave(self.rec, c0, c1)
+        return self + self._coerce(other)
 
     __radd__ = __add__
 
     def __neg__(self):
         self._fresh()
-        return Wave(self.rec, -self.c0, None if self.c1 is None else -self.c1)
+        c0, c1 = self._memo(("neg", id(self.c0), id(self.c1)), (self.c0, self.c1),
+                            lambda: (-self.c0, None if self.c1 is None else -self.c1))
+        return Wave(self.rec, c0, c1)
 
     def __sub__(self, other):
         return self + (-self._coerce(other))
@@ -163,19 +186,32 @@ class Wave:
             if other.kind not in ("p", "-p"):
                 raise WdfTraceError("a wave may only be scaled by the adaptor coefficient p1R of a per-sample "
                                     "resistance (tf_wdf.py:190)")
-            if self.c1 is not None and bool(torch.any(self.c1 != 0)):
+            if self.c1 is not None and self._memo(("deg2", id(self.c1)), (self.c1,), lambda: bool(torch.any(self.c1 != 0))):
                 raise WdfTraceError("per-sample resistance: coefficient of degree 2 in p1R (only the diode-clipper "
                                     "topology of clipper_pot.py is supported)")
             self.rec.dyn_elem = other.elem
             sgn = -1.0 if other.kind == "-p" else 1.0
-            return Wave(self.rec, _ZERO, sgn * self.c0)
+            c1 = self._memo(("mulr", id(self.c0), sgn), (self.c0,), lambda: sgn * self.c0)
+            return Wave(self.rec, _ZERO, c1)
         if isinstance(other, Wave):
             raise WdfTraceError("product of two waves outside the root: not a WDF adaptor operation")
-        s = _scalar(other)
-        if s is None:
-            raise WdfTraceError(f"cannot scale a recorded wave by {type(other).__name__} of shape "
-                                f"{tuple(getattr(other, 'shape', ()))}")
-        return Wave(self.rec, self.c0 * s, None if self.c1 is None else self.c1 * s)
+        if isinstance(other, (int, float)):
+            key, keep = ("mulf", id(self.c0), id(self.c1), float(other)), (self.c0, self.c1)
+            hit = self.rec.memo.get(key)
+            if hit is not None:
+                return Wave(self.rec, hit[0][0], hit[0][1])
+        else:                       # a scalar tensor (a component value / adaptor coefficient): same object, same version
+            key, keep = ("mult", id(self.c0), id(self.c1), id(other), getattr(other, "_version", 0)), (self.c0, self.c1, other)
+
+        def make():
+            s = _scalar(other)
+            if s is None:
+                raise WdfTraceError(f"cannot scale a recorded wave by {type(other).__name__} of shape "
+                                    f"{tuple(getattr(other, 'shape', ()))}")
+            return self.c0 * s, None if self.c1 is None else self.c1 * s
+
+        c0, c1 = self._memo(key, keep, make)
+        return Wave(self.rec, c0, c1)
 
     __rmul__ = __mul__
 
@@ -271,6 +307,8 @@ class Recorder:
         self.canon = None               # signature + waves of the first completed step
         self.pending_out = None
         self.slots = 1
+        self.memo = {}                  # operation memo of the Wave arithmetic (replay)
+        self.scalar_memo = {}           # component arithmetic of this forward pass (compat_tf.Tensor._scalar_memo)
 
     # -- slots
     def _slot(self):
@@ -373,14 +411,24 @@ class Recorder:
             out.append(None if w.c1 is None else tuple(w.c1.tolist()))
         return tuple(out)
 
+    @staticmethod
+    def _ids(waves):
+        return tuple((None if w is None else (id(w.c0), id(w.c1))) for w in waves)
+
     def _close_step(self):
         trans, a, y = self._step_record()
-        sig = self._sig(trans + [a, y])
+        waves = trans + [a, y]
         if self.canon is None:
-            self.canon = (sig, trans, a, y, self.root_lr)
-        elif sig != self.canon[0]:
+            self.canon = (self._sig(waves), trans, a, y, self.root_lr)
+            self.canon_ids = self._ids(waves)
+            return
+        ids = self._ids(waves)
+        if ids == self.canon_ids:                    # replayed from the memo: literally the vectors of a step already checked
+            return
+        if self._sig(waves) != self.canon[0]:
             raise WdfTraceError(f"time step {self.step} is not the same linear map as the first step: the loop "
                                 "cannot be lowered to one recursion")
+        self.canon_ids = ids                         # (the first step differs in identity: its elements still held numbers)
 
     # -- lowering -------------------------------------------------------------------------------
     def lower(self, items):

@@ -142,3 +142,41 @@ def test_reference_clipper_model_runs_unchanged(monkeypatch):
     assert len(model.trainable_variables) == 8
     g = torch.autograd.grad(out.sum(), model.trainable_variables[0], allow_unused=True)
     assert g[0] is not None
+
+
+def test_replay_memo_stops_growing_after_the_second_step(capture, monkeypatch):
+    """Replay: from the second step on every wave operation of a uniform loop is answered from the recorder's
+    memo (same coefficient objects, no torch arithmetic), the memo therefore stops growing, and a step is
+    confirmed by comparing object identities instead of coefficient values -- for a static tree and for the
+    pot clipper, whose calc_impedance() runs every step (scalar component arithmetic memoised per variable
+    version in compat_tf)."""
+    import json
+    import tf_wdf as wdf
+    from loops import BridgedLadder, PotClipper
+    from wdf_hip import mlp_root, trace
+    sizes, by_value = [], []
+    orig_close, orig_sig = trace.Recorder._close_step, trace.Recorder._sig
+
+    def close(self):
+        sizes.append(len(self.memo))
+        return orig_close(self)
+
+    monkeypatch.setattr(trace.Recorder, "_close_step", close)
+    monkeypatch.setattr(trace.Recorder, "_sig", staticmethod(lambda waves: (by_value.append(1), orig_sig(waves))[1]))
+    monkeypatch.setattr(mlp_root, "clipper_mlp",
+                        lambda theta2, w, x, r, z0, fs, hidden, n_tanh, C, R_static=None, time_parallel="auto":
+                        (torch.zeros(x.shape[1], x.shape[0]) + 0.0 * w.sum(), torch.zeros(x.shape[0])))
+    T = 40
+    BridgedLadder(wdf, FS).run(np.random.default_rng(0).standard_normal((2, T)))
+    assert len(sizes) == T and len(set(sizes[1:])) == 1, sizes            # constant from the second step on
+    assert len(by_value) <= 3                                             # steps 0, 1 (and the final check) by value, the rest by identity
+    sizes.clear(); by_value.clear()
+    js = {"in_shape": [None, 2], "layers": [
+        {"type": "dense", "activation": "tanh", "shape": [None, 4], "weights": [np.ones((2, 4)).tolist(), [0.0] * 4]},
+        {"type": "dense", "activation": "tanh", "shape": [None, 4], "weights": [np.eye(4).tolist(), [0.0] * 4]},
+        {"type": "dense", "activation": "tanh", "shape": [None, 4], "weights": [np.eye(4).tolist(), [0.0] * 4]},
+        {"type": "dense", "activation": "", "shape": [None, 1], "weights": [np.ones((4, 1)).tolist(), [0.0]]}]}
+    data = np.stack([np.random.default_rng(1).standard_normal((3, T)), np.full((3, T), 25.2e3)], axis=-1)
+    PotClipper(wdf, FS, 4.7e-9, mlp_json=js).run(data)
+    assert len(sizes) == T and len(set(sizes[2:])) == 1, sizes
+    assert len(by_value) <= 4
