@@ -3,6 +3,7 @@
 // 
 #include "wdf_capi_common.h"
 #include "wdf_clipper.h"
+#include "wdf_clipper_fused.h"
 #include "wdf_omega64.h"
 using namespace wdfcapi;
 
@@ -145,6 +146,47 @@ void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs,
 }
 
 inline size_t bwd_ticket_bytes(int64_t B) { return (((size_t)((B + 63) / 64) + 4) * sizeof(unsigned) + 63) / 64 * 64; }
+
+
+// ---- the one-pass training step (wdf_clipper_fused.h) --------------------------------------------
+struct FusedWs { double* part; float* zwarm; float* zend; float* rec; unsigned* tickets; unsigned* gticket; };
+
+inline size_t fused_body_bytes(int64_t B, int K)
+{
+    const size_t body = wdf_clipper_bwd_ws_bytes(B) + (size_t)(2 + wdf::kFsOut) * (size_t)K * (size_t)B * sizeof(float);
+    return (body + 63) / 64 * 64;
+}
+
+inline FusedWs fused_ws(void* ws, int64_t B, int K)
+{
+    FusedWs w;
+    w.part = (double*)ws;
+    w.zwarm = (float*)((char*)ws + wdf_clipper_bwd_ws_bytes(B));
+    w.zend = w.zwarm + (size_t)K * (size_t)B;
+    w.rec = w.zend + (size_t)K * (size_t)B;
+    w.tickets = (unsigned*)((char*)ws + fused_body_bytes(B, K));
+    w.gticket = (unsigned*)((char*)w.tickets + tp_ticket_bytes(B));
+    return w;
+}
+
+template <bool DYN_R, bool SYM, bool TM, bool V4>
+void launch_fused(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, const float* target,
+                  float hgs, int64_t skip, float* y, const float* z0, float* zT, FusedWs w, wdf::TpStatus* status, float tol,
+                  int64_t B, int64_t T, TpGeom g, int64_t W, TpWarm warm, int general, float* gtheta, int accumulate, float* sse,
+                  wdf::AdamTail adam, hipStream_t s)
+{
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)g.K);
+    {
+        EventBracket bracket(s);
+        hipLaunchKernelGGL((wdf::clipper_fused_tp_kernel<DYN_R, SYM, TM, V4>), grid, dim3(64), 0, s, x, r, theta, fs, n_up, n_down,
+                           target, hgs, skip, y, z0, zT, w.zwarm, w.zend, w.rec, status, warm.ctl, warm.snap, warm.J, w.tickets,
+                           w.gticket, tol, B, T, g.L, W, general, w.part, gtheta, accumulate, sse, adam);
+    }
+    if (g.K > 1)                                // blocks of unflagged tiles (normally all of them) leave at once
+        hipLaunchKernelGGL((wdf::clipper_fused_repair_kernel<DYN_R, SYM, TM>), dim3(grid.x), dim3(64), 0, s, x, r, theta, fs, n_up,
+                           n_down, target, hgs, skip, y, zT, w.zwarm, w.zend, w.rec, B, T, (int64_t)g.K, g.L, tol, status, warm.ctl,
+                           warm.snap, warm.J, w.tickets, w.gticket, general, w.part, gtheta, accumulate, sse, adam);
+}
 
 }  // namespace
 
@@ -365,6 +407,58 @@ int wdf_clipper_bwd_esr_tp(const float* x, const float* r, const float* theta, f
     if (skip < 0 || skip > T) return fail(WDF_EINVAL, "skip must be in 0..T");
     return bwd_tp_common(x, r, theta, fs, n_up, n_down, zstash, nullptr, target, zT, 0.0f, ws, gtheta, sse, gz0,
                          accumulate, B, T, n_chunks, flags, stream, gcoef, skip);
+}
+
+size_t wdf_clipper_step_mse_tp_ws_bytes(int64_t B, int n_chunks)
+{
+    if (B <= 0 || n_chunks <= 0) return 0;
+    return fused_body_bytes(B, n_chunks) + tp_ticket_bytes(B) + 64;
+}
+
+int wdf_clipper_step_mse_tp_ws_init(void* ws, int64_t B, int n_chunks, void* stream)
+{
+    if (!ws || B <= 0 || n_chunks <= 0) return fail(WDF_EINVAL, "null ws / bad B, n_chunks");
+    const hipError_t e = hipMemsetAsync((char*)ws + fused_body_bytes(B, n_chunks), 0, tp_ticket_bytes(B) + 64, (hipStream_t)stream);
+    return e == hipSuccess ? WDF_OK : fail(WDF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+}
+
+int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float fs, int n_up, int n_down,
+                            const float* target, float gscale, int64_t skip, float* y, const float* z0, float* zT,
+                            int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws, void* status, void* state,
+                            int max_warm_tiles, float* gtheta, float* sse, int accumulate, float* m, float* v, int32_t* step,
+                            const float* lr, float beta1, float beta2, float eps, const float* lo, const float* hi, int flags,
+                            void* stream)
+{
+    int rc = check_common(x, theta, n_up, n_down, B, T, flags);
+    if (rc) return rc;
+    if (!target || !y || !ws || !status || !gtheta || !sse) return fail(WDF_EINVAL, "null target/y/ws/status/gtheta/sse");
+    if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
+    if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
+    if (skip < 0 || skip > T) return fail(WDF_EINVAL, "skip must be in 0..T");
+    if (B >= ((int64_t)1 << 30)) return fail(WDF_EINVAL, "time-parallel kernels address a [B] row with 32-bit byte offsets: B < 2^30");
+    if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 applies to wdf_clipper_fwd and wdf_omega_f64 only");
+    if (m && (!v || !step || !lr)) return fail(WDF_EINVAL, "Adam update asked for (m) but v/step/lr missing");
+    const TpGeom g = tp_geom(T, n_chunks);
+    if (g.K != n_chunks) return fail(WDF_EINVAL, "n_chunks = %d does not tile T = %lld in 32-step units: use wdf_clipper_tp_chunks (%d)",
+                                     n_chunks, (long long)T, g.K);
+    const int64_t W = ((int64_t)warmup + wdf::kTile - 1) / wdf::kTile * wdf::kTile;
+    TpWarm warm{nullptr, nullptr, 1};
+    if (state) {
+        if (max_warm_tiles < 1 || max_warm_tiles > wdf::kTpMaxWarmTiles)
+            return fail(WDF_EINVAL, "max_warm_tiles must be in 1..%d", wdf::kTpMaxWarmTiles);
+        if ((int64_t)max_warm_tiles * wdf::kTile > g.L)
+            return fail(WDF_EINVAL, "max_warm_tiles * 32 must not exceed the chunk length (%lld)", (long long)g.L);
+        if (g.K >= (1 << 20)) return fail(WDF_EINVAL, "too many chunks for a warm-start state");
+        // same layout as wdf_clipper_fwd_tp_warm's state: [TpCtl][its ticket area, unused here][snapshot ring]
+        warm = TpWarm{(wdf::TpCtl*)state, (float*)((char*)state + sizeof(wdf::TpCtl) + tp_ticket_bytes(B)), max_warm_tiles + 1};
+    }
+    const wdf::AdamTail adam{m ? theta : nullptr, m, v, step, lr, beta1, beta2, eps, lo, hi};
+    const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
+    const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    WDF_DISPATCH4(launch_fused, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, target, 0.5f * gscale, skip, y,
+                  z0, zT, fused_ws(ws, B, g.K), (wdf::TpStatus*)status, tol, B, T, g, W, warm, (flags & WDF_GENERAL_ROOT) ? 1 : 0,
+                  gtheta, accumulate, sse, adam, (hipStream_t)stream);
+    return check_launch("wdf_clipper_step_mse_tp");
 }
 
 int wdf_omega_f64(const double* x, double* w, int32_t* iters, int64_t n, void* stream)

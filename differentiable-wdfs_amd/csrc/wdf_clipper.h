@@ -756,21 +756,28 @@ struct TpAcc { int max_miss_bits; int pad; unsigned tiles_done; unsigned n_bad; 
 // for the next call.  Repairs are left to clipper_tp_repair_kernel, the next launch on the stream: a
 // re-run rewrites output rows that other waves of THIS launch have written, possibly through another
 // XCD's L2, and only a kernel boundary orders those two writes.
-template <bool DYN_R>
-__device__ __forceinline__ void tp_finish(const float* __restrict__ theta, const float* zwarm, const float* zend,
-                                          TpStatus* __restrict__ status, TpCtl* __restrict__ ctl, int J,
-                                          unsigned* tickets, float tol, int64_t B, int64_t L, int64_t W)
+// True in the LAST of a tile's K chunk waves to get here (device-scope ticket per tile, left clean).
+__device__ __forceinline__ bool tp_tile_last(unsigned* tickets)
 {
     const int64_t K = gridDim.y;
-    const unsigned ntiles = gridDim.x;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's outputs and boundary states have landed
     unsigned old = 0;
     if (threadIdx.x == 0) old = atomicAdd(&tickets[4 + blockIdx.x], 1u);
     old = __builtin_amdgcn_readfirstlane(old);
-    if (old != (unsigned)(K - 1)) return;
+    if (old != (unsigned)(K - 1)) return false;
     if (threadIdx.x == 0) tickets[4 + blockIdx.x] = 0u;          // left clean for the next launch
     // (no acquire fence: the boundary states were stored write-through and are read with agent-scope loads)
+    return true;
+}
 
+// Verification of one tile by its last wave; returns (wave-uniform) whether a boundary of the tile failed.
+template <bool DYN_R>
+__device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, const float* zwarm, const float* zend,
+                                               TpStatus* __restrict__ status, TpCtl* __restrict__ ctl, int J,
+                                               unsigned* tickets, float tol, int64_t B, int64_t L, int64_t W)
+{
+    const int64_t K = gridDim.y;
+    const unsigned ntiles = gridDim.x;
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;
     float miss = 0.0f;
@@ -801,7 +808,8 @@ __device__ __forceinline__ void tp_finish(const float* __restrict__ theta, const
         wmax = fmaxf(wmax, __shfl_down(wmax, off, 64));
         wbad += __shfl_down(wbad, off, 64);
     }
-    if (threadIdx.x != 0) return;
+    const bool tile_failed = __builtin_amdgcn_ballot_w64(nbad != 0) != 0;
+    if (threadIdx.x != 0) return tile_failed;
     // Returning atomics: the value coming back means the update has been performed at the device-wide
     // coherence point, so the tile count (issued after the wait) cannot overtake them.
     TpAcc* acc = reinterpret_cast<TpAcc*>(tickets);             // 64-byte aligned (the 8-byte atomic needs 8)
@@ -813,14 +821,14 @@ __device__ __forceinline__ void tp_finish(const float* __restrict__ theta, const
     // one 64-bit add carries the tile count (low word) and this tile's bad pairs (high word)
     const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&acc->tiles_done),
                                               1ull | ((unsigned long long)(unsigned)wbad << 32));
-    if ((unsigned)prev != ntiles - 1) return;
+    if ((unsigned)prev != ntiles - 1) return tile_failed;
     // ---- last tile: totals to the status word, accumulators left clean, warm-start state advanced
     const int mm_bits = atomicMax(&acc->max_miss_bits, 0);
     const int nb = (int)(prev >> 32) + wbad;
     const float mm = __int_as_float(mm_bits);
     *status = TpStatus{nb, mm, 0, 0u};
     *acc = TpAcc{0, 0, 0u, 0u};
-    if (ctl == nullptr) return;
+    if (ctl == nullptr) return tile_failed;
     const bool stateful = ctl->geom == (int)((K << 8) | J);
     const int head = stateful ? ctl->head : 0;
     const int valid = stateful ? ctl->valid : 0;
@@ -845,6 +853,16 @@ __device__ __forceinline__ void tp_finish(const float* __restrict__ theta, const
     ctl->geom = (int)((K << 8) | J);
     ctl->last_miss = mm;
     ctl->n_calls = stateful ? ctl->n_calls + 1 : 1;
+    return tile_failed;
+}
+
+template <bool DYN_R>
+__device__ __forceinline__ void tp_finish(const float* __restrict__ theta, const float* zwarm, const float* zend,
+                                          TpStatus* __restrict__ status, TpCtl* __restrict__ ctl, int J,
+                                          unsigned* tickets, float tol, int64_t B, int64_t L, int64_t W)
+{
+    if (!tp_tile_last(tickets)) return;
+    (void)tp_verify_tile<DYN_R>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
 }
 
 // Chunk-local repair, launched behind every time-parallel forward; a block leaves at once unless the
@@ -1005,57 +1023,14 @@ struct AdamTail {
     float* m; float* v; int32_t* step; const float* lr; float b1, b2, eps; const float* lo; const float* hi;
 };
 
-// The tail of the reverse sweep.  Every chunk wave publishes its record (write-through stores), then
-// takes a ticket of its 64-sequence tile; the LAST of the tile's K chunk waves walks the tile's K
-// records from the last chunk to the first (G_{k-1} = alpha_k G_k + beta_k, every sum affine in G)
-// and publishes the tile's partial sums {S_L, S_V, S_P, SSE} in double.  The last TILE then does the
-// fixed-order reduction over the tiles, the chain rule to {Is, nVt, R, C} and, if asked, the Adam
-// update of the four components.  Which wave is last varies; what it computes does not (records
-// and partials are re-read in index order).  tickets: [tiles_done, 0, 0, 0][per-tile tickets], zero
-// before the first launch and left zero by every launch.
-__device__ __forceinline__ void bwd_tp_finish(const float* part, int64_t B, double* ws, float* __restrict__ gz0,
-                                              unsigned* tickets, const float* theta, float fs, int dyn_r, float* gtheta,
-                                              int accumulate, float* __restrict__ sse_out, const AdamTail& adam,
-                                              double (*sh)[4])
+// A tile's partial sums {S_L, S_V, S_P, SSE} (per lane, dead lanes zero) -> the tile's slot of ws; the LAST tile
+// to arrive (tickets[0], left clean) does the fixed-order reduction over the tiles, the chain rule to
+// {Is, nVt, R, C} and, if asked, the Adam update of the four components.
+__device__ __forceinline__ void tile_partial_and_finish(double dL, double dV, double dP, double dS, double* ws, unsigned* tickets,
+                                                        const float* theta, float fs, int dyn_r, float* gtheta, int accumulate,
+                                                        float* __restrict__ sse_out, const AdamTail& adam, double (*sh)[4])
 {
-    const int64_t K = gridDim.y;
     const unsigned ntiles = gridDim.x;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's record has landed
-    unsigned old = 0;
-    if (threadIdx.x == 0) old = atomicAdd(&tickets[4 + blockIdx.x], 1u);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old != (unsigned)(K - 1)) return;
-    if (threadIdx.x == 0) tickets[4 + blockIdx.x] = 0u;          // left clean for the next launch
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool live = b_raw < B;
-    const int64_t b = live ? b_raw : B - 1;
-    double G = 0.0, dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0;
-    int64_t k = K - 1;
-    for (; k >= 7; k -= 8) {                          // 8 chunks' 72 loads in flight together
-        float v[8][kTpOut];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < kTpOut; ++i) v[j][i] = load_published(part + ((k - j) * kTpOut + i) * B + b);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            dL += (double)v[j][0] * G + (double)v[j][3];
-            dV += (double)v[j][1] * G + (double)v[j][4];
-            dP += (double)v[j][2] * G + (double)v[j][5];
-            dS += (double)v[j][8];
-            G = (double)v[j][6] * G + (double)v[j][7];
-        }
-    }
-    for (; k >= 0; --k) {
-        const float* o = part + (k * kTpOut) * B + b;
-        dL += (double)load_published(o + 0 * B) * G + (double)load_published(o + 3 * B);
-        dV += (double)load_published(o + 1 * B) * G + (double)load_published(o + 4 * B);
-        dP += (double)load_published(o + 2 * B) * G + (double)load_published(o + 5 * B);
-        dS += (double)load_published(o + 8 * B);
-        G = (double)load_published(o + 6 * B) * G + (double)load_published(o + 7 * B);
-    }
-    if (live && gz0) gz0[b] = (float)G;
-    if (!live) { dL = dV = dP = dS = 0.0; }
     dL = wave_sum(dL); dV = wave_sum(dV); dP = wave_sum(dP); dS = wave_sum(dS);
     unsigned done = 0;
     if (threadIdx.x == 0) {
@@ -1092,6 +1067,59 @@ __device__ __forceinline__ void bwd_tp_finish(const float* part, int64_t B, doub
             adam.theta[i] = th;
         }
     }
+}
+
+// The tail of the reverse sweep.  Every chunk wave publishes its record (write-through stores), then
+// takes a ticket of its 64-sequence tile; the LAST of the tile's K chunk waves walks the tile's K
+// records from the last chunk to the first (G_{k-1} = alpha_k G_k + beta_k, every sum affine in G)
+// and publishes the tile's partial sums {S_L, S_V, S_P, SSE} in double.  The last TILE then does the
+// fixed-order reduction over the tiles, the chain rule to {Is, nVt, R, C} and, if asked, the Adam
+// update of the four components.  Which wave is last varies; what it computes does not (records
+// and partials are re-read in index order).  tickets: [tiles_done, 0, 0, 0][per-tile tickets], zero
+// before the first launch and left zero by every launch.
+__device__ __forceinline__ void bwd_tp_finish(const float* part, int64_t B, double* ws, float* __restrict__ gz0,
+                                              unsigned* tickets, const float* theta, float fs, int dyn_r, float* gtheta,
+                                              int accumulate, float* __restrict__ sse_out, const AdamTail& adam,
+                                              double (*sh)[4])
+{
+    const int64_t K = gridDim.y;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's record has landed
+    unsigned old = 0;
+    if (threadIdx.x == 0) old = atomicAdd(&tickets[4 + blockIdx.x], 1u);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(K - 1)) return;
+    if (threadIdx.x == 0) tickets[4 + blockIdx.x] = 0u;          // left clean for the next launch
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    double G = 0.0, dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0;
+    int64_t k = K - 1;
+    for (; k >= 7; k -= 8) {                          // 8 chunks' 72 loads in flight together
+        float v[8][kTpOut];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < kTpOut; ++i) v[j][i] = load_published(part + ((k - j) * kTpOut + i) * B + b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dL += (double)v[j][0] * G + (double)v[j][3];
+            dV += (double)v[j][1] * G + (double)v[j][4];
+            dP += (double)v[j][2] * G + (double)v[j][5];
+            dS += (double)v[j][8];
+            G = (double)v[j][6] * G + (double)v[j][7];
+        }
+    }
+    for (; k >= 0; --k) {
+        const float* o = part + (k * kTpOut) * B + b;
+        dL += (double)load_published(o + 0 * B) * G + (double)load_published(o + 3 * B);
+        dV += (double)load_published(o + 1 * B) * G + (double)load_published(o + 4 * B);
+        dP += (double)load_published(o + 2 * B) * G + (double)load_published(o + 5 * B);
+        dS += (double)load_published(o + 8 * B);
+        G = (double)load_published(o + 6 * B) * G + (double)load_published(o + 7 * B);
+    }
+    if (live && gz0) gz0[b] = (float)G;
+    if (!live) { dL = dV = dP = dS = 0.0; }
+    tile_partial_and_finish(dL, dV, dP, dS, ws, tickets, theta, fs, dyn_r, gtheta, accumulate, sse_out, adam, sh);
 }
 
 // MSE: `gy` is unused, `target` [T][B] the training target, zT [B] the final state of the forward

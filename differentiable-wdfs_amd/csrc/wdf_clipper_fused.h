@@ -1,0 +1,379 @@
+// wdf_clipper_fused.h -- the diode-clipper TRAINING STEP in one pass over the data (gfx950).
+//
+// What the two-kernel step (clipper_fwd_tp_kernel + clipper_bwd_tp_kernel, wdf_clipper.h) moves through
+// HBM twice -- x, the state stash written by the forward and read back by the reverse sweep, the target --
+// this kernel moves once: x and the target in, y out, 12 B/sample instead of 24, and the root is solved
+// once per sample instead of twice.  It can do that because the loss is known while the forward runs
+// (mean squared error against a resident target: lpf.py:78,87-90, clipper_pot.py:176) and the circuit has
+// only three sufficient statistics for its four parameters {Is, nVt, R, C} (wdf_clipper.h,
+// grad_chain_rule: dL/dL, dL/dV|_L, dL/dp): the parameter gradient is carried FORWARD in time as the
+// tangent of the state,
+//     s_i[n+1] = kappa_n s_i[n] + d_i[n]          kappa = dz'/dz,  d = (dz'/dL, dz'/dV, dz'/dp) at fixed z
+//     dLoss/dtheta_i = sum_n g_n (s_i[n+1] + s_i[n]) / 2     (y = (z' + z)/2, g_n = dLoss/dy_n)
+// which is the same sum the reverse sweep forms (tf.GradientTape's result, lpf.py:87-90), taken in the
+// other order: bwd_step's partials Da, DL, DV, cP are used unchanged, and tests hold the two against each
+// other and against the oracle.  No stash, no second root evaluation, ~12 extra VALU per step.
+//
+// Time-parallel like the other kernels: chunk k of a 64-sequence tile starts from a speculated state
+// (warm start from the previous call's snapshots, or a cold warm-up) and from an UNKNOWN tangent sigma;
+// everything it accumulates is affine in sigma (s = A sigma + c), so the chunk publishes the record
+//     {A_end, c_end[3], GA, G[3], SSE}        (kFsOut floats per sequence)
+// and the tile's last wave -- after verifying the state boundaries exactly as tp_finish does -- walks the K
+// records in time order (sigma_{k+1} = A_end sigma_k + c_end) and adds up the tile's sums; the last tile
+// reduces over tiles, applies the chain rule and (single rank) the Adam update.  A tile with a failed
+// boundary is left to clipper_fused_repair_kernel, the next launch, which re-runs the failing chunks from
+// the exact state (outputs, record) and then does that tile's combine; whichever tile arrives last --
+// in either kernel -- finishes the step.
+#pragma once
+
+#include "wdf_clipper.h"
+
+namespace wdf {
+
+constexpr int kFsOut = 9;       // record floats per (chunk, sequence)
+constexpr int kFusedSchedGroup = 1;   // steps the instruction scheduler may interleave
+
+// Tangent state of one sequence inside a chunk.  G* accumulate sum_n s[n] (hg_n + hg_{n-1}) (summation
+// by parts of sum_n hg_n (s[n+1] + s[n]), hg = g/2): one FMA per statistic and step.
+struct FusedTan {
+    float A, cL, cV, cP;        // s_i = A sigma_i + c_i
+    float GA, GL, GV, GP;       // running sums since the last flush
+    float hg_prev;
+    float sse;                  // hgs x sum of squared errors
+};
+
+// One step: forward (the arithmetic of fwd_step, same expressions) + partials (those of bwd_tp_step) +
+// tangent update.  hgs = gscale / 2 (0 on masked steps).  Returns y.
+template <bool DYN_R, bool SYM, bool FAST>
+__device__ __forceinline__ float fused_step(const ClipConsts& c, float xin, float rin, float tgt, float hgs, float& z,
+                                            FusedTan& s)
+{
+    float p, Rp, L;
+    step_coeffs<DYN_R, float>(c, rin, p, Rp, L);
+    const float b_diff = z - xin;
+    const float b_temp = -p * b_diff;
+    const float a = z + b_temp;
+    const DiodeOut o = diode_pair<SYM, float, FAST>(a, L, c.d);
+    const float zn = o.b + b_temp;
+    const float y = 0.5f * (zn + z);
+    // partials of the root (wdf_clipper.h, bwd_step / bwd_tp_step)
+    const float w0p = o.w0 * vrcp(o.w0 + 1.0f);
+    const float w1p = o.w1 * vrcp(o.w1 + 1.0f);
+    const float l2 = o.lam * o.lam;
+    const float sp = w0p + w1p;
+    const float tl = -2.0f * l2;
+    const float Da = fmaf(tl, sp, 1.0f);
+    float DL, DV;
+    if constexpr (SYM) {
+        const float tvm = c.d.two_v * c.d.m_dn;
+        DL = (-tvm) * (o.lam * (w0p - w1p));
+        DV = fmaf(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * (o.lam * (o.w0 - o.w1)));
+    } else {
+        DL = (-c.d.two_v) * (o.lam * (o.m0 * w0p - o.m1 * w1p));
+        DV = fmaf(tl * a, sp * (-1.0f / c.V), -2.0f * (o.lam * (o.m0 * o.w0 - o.m1 * o.w1)));
+    }
+    const float opd = Da + 1.0f;
+    float cP = -opd * b_diff;
+    if constexpr (DYN_R) cP = Rp * fmaf(cP, p, DL);
+    const float kappa = fmaf(-p, opd, Da);
+    // loss and tangent
+    const float d = y - tgt;
+    const float hg = hgs * d;
+    s.sse = fmaf(hg, d, s.sse);                          // hgs x the squared error (0 on masked steps); no branch here:
+                                                         // a block boundary per step lets LLVM sink every step's tangent
+                                                         // work to the end of the tile (6 live values per step)
+    const float hh = hg + s.hg_prev;
+    s.hg_prev = hg;
+    s.GA = fmaf(hh, s.A, s.GA);
+    s.GL = fmaf(hh, s.cL, s.GL);
+    s.GV = fmaf(hh, s.cV, s.GV);
+    s.GP = fmaf(hh, s.cP, s.GP);
+    s.A = s.A * kappa;
+    s.cL = fmaf(kappa, s.cL, DL);
+    s.cV = fmaf(kappa, s.cV, DV);
+    s.cP = fmaf(kappa, s.cP, cP);
+    z = zn;
+    return y;
+}
+
+// fp64 totals of a chunk; the fp32 running sums are flushed into them every tile of steps
+struct FusedSums {
+    double GA, GL, GV, GP, sse;
+    __device__ __forceinline__ void flush(FusedTan& s)
+    {
+        GA += (double)s.GA; GL += (double)s.GL; GV += (double)s.GV; GP += (double)s.GP; sse += (double)s.sse;
+        s.GA = s.GL = s.GV = s.GP = s.sse = 0.0f;
+    }
+};
+
+// the chunk's record (write-through: another wave of this launch reads it)
+__device__ __forceinline__ void fused_publish_record(float* rec, int64_t k, int64_t b, int64_t B, const FusedTan& s, FusedSums& d,
+                                                     float hgs)
+{
+    // the boundary term of the summation by parts: s[t1] hg_{t1-1}
+    const double h = (double)s.hg_prev;
+    const float v[kFsOut] = {s.A, s.cL, s.cV, s.cP, (float)(d.GA + h * s.A), (float)(d.GL + h * s.cL),
+                             (float)(d.GV + h * s.cV), (float)(d.GP + h * s.cP), hgs != 0.0f ? (float)(d.sse / (double)hgs) : 0.0f};
+    float* o = rec + (k * kFsOut) * B + b;
+#pragma unroll
+    for (int i = 0; i < kFsOut; ++i) __hip_atomic_store(o + i * B, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Chunk geometry as clipper_fwd_tp_body (L, W multiples of kTile); target [T][B]; skip: steps below it carry no loss.
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool FAST>
+__device__ __forceinline__ void clipper_fused_body(
+    const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ target,
+    float* __restrict__ y, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
+    float* __restrict__ zend, float* rec, const float* __restrict__ theta, const TpCtl* __restrict__ ctl,
+    float* __restrict__ snap, int J, int64_t B, int64_t T, int64_t L, int64_t W, float hgs, int64_t skip)
+{
+    using V = float;
+    const LaneSeqs<V> q(B, B);
+    const int64_t k = blockIdx.y, K = gridDim.y;
+    const int64_t t0 = k * L;
+    const int64_t t1 = (t0 + L < T) ? t0 + L : T;
+    int64_t tw = 0;
+    float z = 0.0f;
+    const bool stateful = ctl != nullptr && ctl->geom == (int)((K << 8) | J);
+    const int valid = stateful ? ctl->valid : 0;
+    const int head = stateful ? ctl->head : 0;
+    if (k > 0 && valid > 0) {                               // warm start (see clipper_fwd_tp_body)
+        const int j = ctl->j_next;
+        tw = t0 - (int64_t)kTile * j;
+        const float* __restrict__ s1 = snap + (((int64_t)head * J + j) * K + (k - 1)) * B;
+        z = s1[q.b[0]];
+        if (valid > 1) {
+            const float* __restrict__ s2 = snap + (((int64_t)((head + kTpRing - 1) % kTpRing) * J + j) * K + (k - 1)) * B;
+            const float zo = s2[q.b[0]];
+            z = fmaf(tp_secant_factor(theta, ctl), z - zo, z);
+        }
+    } else {
+        tw = (t0 > W) ? t0 - W : 0;
+        if (tw == 0 && z0) z = z0[q.b[0]];
+    }
+    float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)((head + 1) % kTpRing) * J * K + k) * B : nullptr;
+
+    float xc[1][kTile], xn[1][kTile], rc[1][kTile], rn[1][kTile], gc[1][kTile], gn[1][kTile];
+#pragma unroll
+    for (int i = 0; i < kTile; ++i) { xc[0][i] = xn[0][i] = gc[0][i] = gn[0][i] = 0.0f; rc[0][i] = rn[0][i] = 1.0f; }
+    const int64_t nfull_end = t1 - (t1 - tw) % kTile;
+    if (tw < nfull_end) {
+        load_tile_v<V, TM, VEC4>(x, q, B, T, tw, xn);
+        if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, tw, rn);
+        if (tw >= t0) load_tile_v<V, true, false>(target, q, B, T, tw, gn);
+    }
+    float* __restrict__ yrow = y + t0 * B;
+    int64_t t = tw;
+    for (; t < t0 && t < nfull_end; t += kTile) {           // ---- warm-up tiles: forward only, nothing stored
+#pragma unroll
+        for (int i = 0; i < kTile; ++i) { xc[0][i] = xn[0][i]; if constexpr (DYN_R) rc[0][i] = rn[0][i]; }
+        if (t + kTile < nfull_end) {
+            load_tile_v<V, TM, VEC4>(x, q, B, T, t + kTile, xn);
+            if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, t + kTile, rn);
+            if (t + kTile >= t0) load_tile_v<V, true, false>(target, q, B, T, t + kTile, gn);   // the first owned tile's target
+        }
+#pragma unroll
+        for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, xc[0][i], rc[0][i], z);
+    }
+    publish_v<V>(zwarm, q, k * B, z);
+    FusedTan s = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    FusedSums d = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (; t < nfull_end; t += kTile) {                     // ---- owned tiles
+#pragma unroll
+        for (int i = 0; i < kTile; ++i) { xc[0][i] = xn[0][i]; gc[0][i] = gn[0][i]; if constexpr (DYN_R) rc[0][i] = rn[0][i]; }
+        const bool more = t + kTile < nfull_end;
+        if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1))
+            store_v<V>(snapw, q, ((t1 - t) / kTile) * K * B, z);
+#pragma unroll
+        for (int i = 0; i < kTile; ++i) {
+            if (i == kTile / 2) {                           // prefetch in the middle of the tile (vmcnt, see the forward)
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    load_tile_v<V, TM, VEC4>(x, q, B, T, t + kTile, xn);
+                    if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, t + kTile, rn);
+                    load_tile_v<V, true, false>(target, q, B, T, t + kTile, gn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float hm = (t + i >= skip) ? hgs : 0.0f;  // wave-uniform: the scalar unit's work
+            store_row_v<V>(yrow, q, fused_step<DYN_R, SYM, FAST>(c, xc[0][i], rc[0][i], gc[0][i], hm, z, s));
+            yrow += B;
+            // The tangent updates do not feed the next step's state, so left alone instruction selection
+            // emits the z chain of the whole tile first and keeps every step's partials alive (200 VGPRs,
+            // spills).  Pinning the tangent state (a chained, empty asm) before the scheduling barrier keeps
+            // each group of steps' work inside the group.
+            if (i % kFusedSchedGroup == kFusedSchedGroup - 1) {
+                vpin(s.A); vpin(s.cL); vpin(s.cV); vpin(s.cP); vpin(s.GA); vpin(s.GL); vpin(s.GV); vpin(s.GP); vpin(s.sse);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        d.flush(s);
+    }
+    for (int64_t tt = nfull_end; tt < t1; ++tt) {           // tail of the last chunk (T % 32)
+        const float xin = load_one<TM>(x, q.b[0], B, T, tt);
+        const float rin = DYN_R ? load_one<TM>(r, q.b[0], B, T, tt) : 1.0f;
+        const float tg = target[tt * B + q.b[0]];
+        store_row_v<V>(yrow, q, fused_step<DYN_R, SYM, FAST>(c, xin, rin, tg, tt >= skip ? hgs : 0.0f, z, s));
+        yrow += B;
+    }
+    d.flush(s);
+    publish_v<V>(zend, q, k * B, z);
+    if (snapw != nullptr) store_v<V>(snapw, q, 0, z);
+    if (zT && t1 == T) store_v<V>(zT, q, 0, z);
+    fused_publish_record(rec, k, q.b[0], B, s, d, hgs);
+}
+
+// The tile's K records in time order -> the tile's sums -> (last tile) the step's result.
+__device__ __forceinline__ void fused_combine_tile(const float* rec, int64_t K, int64_t B, double* ws, unsigned* gticket,
+                                                   const float* theta, float fs, int dyn_r, float* gtheta, int accumulate,
+                                                   float* __restrict__ sse_out, const AdamTail& adam, double (*sh)[4])
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    double sL = 0.0, sV = 0.0, sP = 0.0;                  // tangent entering the chunk (z0 does not depend on theta)
+    double dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0;
+    int64_t k = 0;
+    for (; k + 8 <= K; k += 8) {                          // 8 chunks' 72 loads in flight together
+        float v[8][kFsOut];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < kFsOut; ++i) v[j][i] = load_published(rec + ((k + j) * kFsOut + i) * B + b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double A = v[j][0], GA = v[j][4];
+            dL += sL * GA + (double)v[j][5];
+            dV += sV * GA + (double)v[j][6];
+            dP += sP * GA + (double)v[j][7];
+            dS += (double)v[j][8];
+            sL = A * sL + (double)v[j][1];
+            sV = A * sV + (double)v[j][2];
+            sP = A * sP + (double)v[j][3];
+        }
+    }
+    for (; k < K; ++k) {
+        const float* o = rec + (k * kFsOut) * B + b;
+        const double A = load_published(o), GA = load_published(o + 4 * B);
+        dL += sL * GA + (double)load_published(o + 5 * B);
+        dV += sV * GA + (double)load_published(o + 6 * B);
+        dP += sP * GA + (double)load_published(o + 7 * B);
+        dS += (double)load_published(o + 8 * B);
+        sL = A * sL + (double)load_published(o + 1 * B);
+        sV = A * sV + (double)load_published(o + 2 * B);
+        sP = A * sP + (double)load_published(o + 3 * B);
+    }
+    if (!live) { dL = dV = dP = dS = 0.0; }
+    tile_partial_and_finish(dL, dV, dP, dS, ws, gticket, theta, fs, dyn_r, gtheta, accumulate, sse_out, adam, sh);
+}
+
+// tickets: the forward's verification area [TpAcc][per-tile tickets][per-tile repair flags];
+// gticket: [tiles combined, 0, 0, 0] -- both zero before the first launch and left zero by every step.
+template <bool DYN_R, bool SYM, bool TM, bool VEC4>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void clipper_fused_tp_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
+    const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, const float* __restrict__ z0,
+    float* __restrict__ zT, float* zwarm, float* zend, float* rec, TpStatus* __restrict__ status, TpCtl* ctl, float* snap,
+    int J, unsigned* tickets, unsigned* gticket, float tol, int64_t B, int64_t T, int64_t L, int64_t W, int general,
+    double* ws, float* gtheta, int accumulate, float* __restrict__ sse_out, AdamTail adam)
+{
+    __shared__ double sh[64][4];
+    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+    bool fast = false;
+    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
+    if (fast)
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B, T,
+                                                         L, W, hgs, skip);
+    else
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, false>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B, T,
+                                                        L, W, hgs, skip);
+    if (!tp_tile_last(tickets)) return;
+    // the warm-start control block is advanced (by the last tile to verify) BEFORE that tile takes its combine
+    // ticket, hence before the step's last ticket and the Adam update behind it: it records this call's theta
+    const bool failed = tp_verify_tile<DYN_R>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
+    if (failed) return;                                     // left to clipper_fused_repair_kernel
+    fused_combine_tile(rec, gridDim.y, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);
+}
+
+// Re-run of chunk [t0, t1) for this wave's 64 sequences from the exact state z: outputs, snapshots, record.
+template <bool DYN_R, bool SYM, bool TM, bool FAST>
+__device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r,
+                                                  const float* __restrict__ target, float* __restrict__ y, float* rec,
+                                                  float* __restrict__ snapw, int J, int64_t K, int64_t k, int64_t b, int64_t B,
+                                                  int64_t T, int64_t t0, int64_t t1, float hgs, int64_t skip, float& z)
+{
+    FusedTan s = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    FusedSums d = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t t = t0; t < t1; t += kBlk) {
+        if ((t - t0) % kTile == 0) {
+            d.flush(s);
+            if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1) && (t1 - t) % kTile == 0)
+                snapw[((t1 - t) / kTile) * K * B + b] = z;
+        }
+        float xv[kBlk], rv[kBlk], gv[kBlk];
+#pragma unroll
+        for (int i = 0; i < kBlk; ++i) {
+            const int64_t tt = (t + i < t1) ? t + i : t1 - 1;
+            xv[i] = load_one<TM>(x, b, B, T, tt);
+            rv[i] = DYN_R ? load_one<TM>(r, b, B, T, tt) : 1.0f;
+            gv[i] = target[tt * B + b];
+        }
+#pragma unroll
+        for (int i = 0; i < kBlk; ++i) {
+            if (t + i < t1)                                      // wave-uniform
+                y[(t + i) * B + b] = fused_step<DYN_R, SYM, FAST>(c, xv[i], rv[i], gv[i], (t + i >= skip) ? hgs : 0.0f, z, s);
+        }
+    }
+    d.flush(s);
+    if (snapw != nullptr) snapw[b] = z;
+    fused_publish_record(rec, k, b, B, s, d, hgs);
+}
+
+// Launched behind every fused step; a block leaves at once unless the step flagged its tile (the common
+// case).  For a flagged tile: walk the chunk boundaries in time order, re-run every chunk one of whose
+// 64 sequences arrived more than tol off (from the exact state), then combine the tile.
+template <bool DYN_R, bool SYM, bool TM>
+__global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
+    const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, float* __restrict__ zT,
+    const float* zwarm, float* zend, float* rec, int64_t B, int64_t T, int64_t K, int64_t L, float tol,
+    TpStatus* __restrict__ status, const TpCtl* __restrict__ ctl, float* __restrict__ snap, int J, unsigned* tickets,
+    unsigned* gticket, int general, double* ws, float* gtheta, int accumulate, float* __restrict__ sse_out, AdamTail adam)
+{
+    __shared__ double sh[64][4];
+    unsigned* tile_bad = tickets + 4 + gridDim.x;
+    if (tile_bad[blockIdx.x] == 0u) return;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+    bool fast = false;
+    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
+    const int slot = (ctl != nullptr && snap != nullptr) ? ctl->head : 0;     // the step advanced head to the slot it wrote
+    int nrep = 0;
+    bool fixed_prev = false;
+    float ze_fix = 0.0f;
+    for (int64_t k = 1; k < K; ++k) {
+        const float e = fixed_prev ? ze_fix : load_published(zend + (k - 1) * B + b);
+        const float m = fabsf(load_published(zwarm + k * B + b) - e);
+        fixed_prev = false;
+        if (__builtin_amdgcn_ballot_w64(!(m <= tol)) == 0) continue;
+        const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+        float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
+        float z = e;
+        if (fast) fused_rerun_chunk<DYN_R, SYM, TM, !DYN_R>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
+        else fused_rerun_chunk<DYN_R, SYM, TM, false>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
+        zend[k * B + b] = z;
+        if (zT && t1 == T) zT[b] = z;
+        ze_fix = z;
+        fixed_prev = true;
+        ++nrep;
+    }
+    if (threadIdx.x == 0) {
+        tile_bad[blockIdx.x] = 0u;
+        if (nrep) atomicAdd(&status->fallback_ran, nrep);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the re-written records have landed (write-through)
+    fused_combine_tile(rec, K, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);
+}
+
+}  // namespace wdf

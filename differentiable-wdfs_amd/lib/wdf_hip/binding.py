@@ -85,6 +85,13 @@ def lib():
     L.wdf_clipper_bwd_mse_tp_adam.restype = ci
     L.wdf_clipper_bwd_mse_tp_adam.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, cf, vp, fp, fp, i64, i64, ci, ci,
                                               fp, fp, vp, fp, cf, cf, cf, fp, fp, vp]
+    L.wdf_clipper_step_mse_tp_ws_bytes.restype = C.c_size_t
+    L.wdf_clipper_step_mse_tp_ws_bytes.argtypes = [i64, ci]
+    L.wdf_clipper_step_mse_tp_ws_init.restype = ci
+    L.wdf_clipper_step_mse_tp_ws_init.argtypes = [vp, i64, ci, vp]
+    L.wdf_clipper_step_mse_tp.restype = ci
+    L.wdf_clipper_step_mse_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, cf, i64, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, vp,
+                                          ci, fp, fp, ci, fp, fp, vp, fp, cf, cf, cf, fp, fp, ci, vp]
     L.wdf_loss_sums_ws_bytes.restype = i64
     L.wdf_loss_sums.restype = ci
     L.wdf_loss_sums.argtypes = [fp, fp, i64, i64, i64, vp, vp, vp]
@@ -170,7 +177,8 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_tp_chunks", "wdf_clipper_fwd_tp_ws_bytes", "wdf_clipper_fwd_tp",
     "wdf_clipper_fwd_tp_state_bytes", "wdf_clipper_fwd_tp_state_reset", "wdf_clipper_fwd_tp_warm",
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp_ws_init", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
-    "wdf_clipper_bwd_mse_tp_adam", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
+    "wdf_clipper_bwd_mse_tp_adam", "wdf_clipper_step_mse_tp_ws_bytes", "wdf_clipper_step_mse_tp_ws_init",
+    "wdf_clipper_step_mse_tp", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
@@ -359,6 +367,61 @@ def clipper_bwd_mse_tp_adam(x, theta, fs, zstash, zT, target, gscale, n_chunks, 
                                            _ptr(opt.lo), _ptr(opt.hi), _stream())
     _check(rc, "wdf_clipper_bwd_mse_tp_adam")
     return gtheta, sse
+
+
+def step_mse_workspace(B, n_chunks, device):
+    """Workspace of the one-pass training step with its ticket words cleared: allocate once, reuse."""
+    ws = torch.empty((lib().wdf_clipper_step_mse_tp_ws_bytes(int(B), int(n_chunks)),), dtype=torch.uint8, device=device)
+    _check(lib().wdf_clipper_step_mse_tp_ws_init(_ptr(ws), int(B), int(n_chunks), _stream()), "wdf_clipper_step_mse_tp_ws_init")
+    return ws
+
+
+def clipper_step_mse_tp(x, theta, fs, target, gscale, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_down=1, skip=0, y=None,
+                        z0=None, want_zT=False, ws=None, status=None, state=None, gtheta=None, sse=None, accumulate=False,
+                        opt=None, time_major=False):
+    """The whole MSE training step in one pass over the data (include/wdf_hip.h, wdf_clipper_step_mse_tp):
+    forward, loss and d(gscale/2 sum (y - target)^2)/d{Is, nVt, R, C}, x and target read once, y written once, no
+    state stash.  n_chunks: time chunks asked for (rounded like wdf_clipper_tp_chunks does); state: a TpWarmState
+    made for (B, T, n_chunks); opt: a binding.Adam(4, ...) to update theta in the same launch.
+    -> y [T,B], zT [B] | None, gtheta[4], sse[1], status (device int32[4], read with tp_status())."""
+    require_gpu()
+    x, r, theta = _f32_dev(x, "x"), _f32_dev(r, "r"), _f32_dev(theta, "theta")
+    target, z0 = _f32_dev(target, "target"), _f32_dev(z0, "z0")
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+    if theta.numel() != 4:
+        raise WdfHipError("theta must hold {Is, nVt, R, C}")
+    if tuple(target.shape) != (T, B):
+        raise WdfHipError(f"target must be [T,B] = [{T},{B}]")
+    if r is not None and r.shape != x.shape:
+        raise WdfHipError("r must have the shape of x")
+    K = lib().wdf_clipper_tp_chunks(T, int(n_chunks))
+    if y is None:
+        y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zT = torch.empty((B,), dtype=torch.float32, device=x.device) if want_zT else None
+    if ws is None:
+        ws = step_mse_workspace(B, K, x.device)
+    if status is None:
+        status = torch.empty((4,), dtype=torch.int32, device=x.device)
+    if gtheta is None:
+        gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
+        accumulate = False
+    if sse is None:
+        sse = torch.empty((1,), dtype=torch.float32, device=x.device)
+    if state is not None and ((state.B, state.T, state.K) != (B, T, K) or state.buf.device != x.device):
+        raise WdfHipError("warm-start state was made for another batch shape / chunking / device")
+    if opt is not None and opt.n != 4:
+        raise WdfHipError("clipper_step_mse_tp: the optimizer holds {Is, nVt, R, C}")
+    o = opt
+    rc = lib().wdf_clipper_step_mse_tp(
+        _ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(target), float(gscale), int(skip), _ptr(y),
+        _ptr(z0), _ptr(zT), B, T, K, int(warmup), float(tol), _ptr(ws), _ptr(status),
+        None if state is None else _ptr(state.buf), 0 if state is None else state.max_warm_tiles, _ptr(gtheta), _ptr(sse),
+        1 if accumulate else 0, *((None,) * 4 if o is None else (_ptr(o.m), _ptr(o.v), _ptr(o.step), _ptr(o.lr))),
+        0.0 if o is None else o.b1, 0.0 if o is None else o.b2, 0.0 if o is None else o.eps,
+        None if o is None else _ptr(o.lo), None if o is None else _ptr(o.hi),
+        (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(), _stream())
+    _check(rc, "wdf_clipper_step_mse_tp")
+    return y, zT, gtheta, sse, status
 
 
 def loss_sums(y, target, skip, sums=None, ws=None):

@@ -255,6 +255,7 @@ class MseStep:
         self.out = torch.zeros((5,), dtype=torch.float32, device=device)
         self.sse, self.gtheta = self.out[0:1], self.out[1:5]
         self.y = self.zs = self.zT = None
+        self.ws_s, self.ws_s_k = None, None          # workspace of step_fused (made on first use)
         self.warm = None
         if warm and tp is not None and tp.k_fwd > 1:
             self.warm = binding.TpWarmState(B, T, tp.k_fwd, max(max_warm_tiles, -(-tp.warmup // 32)), device)
@@ -303,6 +304,25 @@ class MseStep:
     def step(self, theta, x, target, r=None):
         self.forward(theta, x, r)
         return self.backward(theta, x, target, r)
+
+    def step_fused(self, theta, x, target, r=None, adam=None):
+        """The same step in ONE pass over the data (csrc/wdf_clipper_fused.h, MSE loss): forward, loss and
+        gradient with x and target read once and y written once -- no state stash, one root solve per sample,
+        the gradient carried forward as the state's tangent.  Chunking / verification / warm start as
+        forward(); fills self.y, self.sse, self.gtheta (and, with `adam`, updates theta in the same launch)."""
+        if self.loss_kind != "mse":
+            raise binding.WdfHipError("step_fused: MSE loss only (the MSE + ESR coefficients need the global sums first)")
+        tp = self.tp
+        k = tp.k_fwd if tp is not None else 1
+        if self.ws_s is None or self.ws_s_k != k:
+            self.ws_s, self.ws_s_k = binding.step_mse_workspace(self.B, binding.lib().wdf_clipper_tp_chunks(self.T, k), x.device), k
+            self.y = torch.empty((self.T, self.B), dtype=torch.float32, device=x.device)
+            self.zs = self.zT = None
+        binding.clipper_step_mse_tp(x, theta, self.fs, target, self.gscale, k, tp.warmup if tp is not None else 0,
+                                    tol=tp.tol if tp is not None else 1.0e-6, r=r, n_up=self.n_up, n_down=self.n_down,
+                                    y=self.y, ws=self.ws_s, status=self.status, state=self.warm, gtheta=self.gtheta,
+                                    sse=self.sse, opt=adam, time_major=self.time_major)
+        return self.sse, self.gtheta
 
 
 def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=1, reps=7, r=None):

@@ -170,6 +170,27 @@ int wdf_clipper_bwd_mse_tp_adam(const float* x, const float* r, float* theta, fl
                                 float beta1, float beta2, float eps, const float* lo, const float* hi,
                                 void* stream);
 
+/* The whole MSE training step in ONE pass over the data (csrc/wdf_clipper_fused.h): forward, loss and the
+ * gradient d(mean squared error)/d{Is, nVt, R, C} -- what the reference obtains from the sequence loop under
+ * tf.GradientTape + tape.gradient (lpf.py:30-49,87-90; clipper_pot.py:103-127,246-269) -- with x and `target`
+ * [T][B] read once and y [T][B] written once: 12 B/sample, no state stash, one root solve per sample.  The
+ * gradient is carried forward in time as the state's tangent (three statistics), chunks are time-parallel and
+ * verified like wdf_clipper_fwd_tp_warm's (same `state` buffer and meaning of n_chunks / warmup / tol / status /
+ * max_warm_tiles; state may be NULL: cold warm-up every call), the combine, reduction, chain rule and -- when
+ * m is not NULL -- the Adam update of theta (wdf_adam_step's rule) ride in the kernel's last waves.
+ * dL/dy = gscale (y - target) on steps >= skip (gscale = 2/N, N the GLOBAL number of samples past skip);
+ * *sse receives sum (y - target)^2 over those steps of this call's batch, gtheta[4] the gradient.
+ * n_chunks must be a value wdf_clipper_tp_chunks returns.  ws: wdf_clipper_step_mse_tp_ws_bytes bytes,
+ * initialised ONCE with wdf_clipper_step_mse_tp_ws_init (ticket words the kernels count in and leave at zero). */
+size_t wdf_clipper_step_mse_tp_ws_bytes(int64_t B, int n_chunks);
+int wdf_clipper_step_mse_tp_ws_init(void* ws, int64_t B, int n_chunks, void* stream);
+int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float fs, int n_up, int n_down,
+                            const float* target, float gscale, int64_t skip, float* y, const float* z0, float* zT,
+                            int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws, void* status, void* state,
+                            int max_warm_tiles, float* gtheta, float* sse, int accumulate, float* m, float* v, int32_t* step,
+                            const float* lr, float beta1, float beta2, float eps, const float* lo, const float* hi, int flags,
+                            void* stream);
+
 /* MSE + ESR, the training loss of clipper_pot.py (:146-156 esr_loss, :177 loss_func, :232,248
  * evaluated past skip_samples with (outs, target) passed as (target_y, predicted_y), so the energy
  * is the model output's):   loss = S/n + sqrt(S / (E + eps) / n),  S = sum (y-t)^2, E = sum y^2.

@@ -1,0 +1,249 @@
+"""GPU: the one-pass training step (wdf_clipper_step_mse_tp, csrc/wdf_clipper_fused.h) gives what the
+two-kernel step gives -- the forward's y and the reverse sweep's gradient -- and what the fp64 oracle gives.
+
+The gradient is carried forward in time (tangent of the state) instead of swept backward: same sums, other
+order.  Covered: chunk counts incl. 1, ragged B and T, asymmetric diode counts, the per-sample resistance
+channel, both x layouts, loss masks (skip), an initial state, the warm-started loop, the repair path (a
+parameter jump and a circuit whose memory outlasts the warm-up), the Adam update folded into the launch,
+and the bench shape against the oracle.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+FS = 48000.0
+Y_TOL = 2.0e-6        # volts, vs the sequential kernel / the fp64 oracle (measured ~1e-7)
+G_RTOL = 1.0e-4       # per gradient component (measured ~3e-6)
+
+
+@pytest.fixture(scope="module")
+def wb():
+    from wdf_hip import binding
+    binding.require_gpu()
+    return binding
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
+
+
+def problem(B, T, seed=0):
+    from wdf_hip import workload
+    x = workload.sweep_batch(B, T, seed=seed)
+    th = workload.clipper_theta()
+    return x, th, workload.target_theta()
+
+
+def two_kernel_step(wb, x, th, tgt, gscale, r=None, n_up=1, n_down=1, skip=0, z0=None):
+    """forward + reverse sweep with dL/dy = gscale (y - target) past skip: the reference for the fused step"""
+    y, zs, _ = wb.clipper_fwd(x, th, FS, r=r, n_up=n_up, n_down=n_down, z0=z0)
+    gy = gscale * (y - tgt)
+    gy[:skip] = 0.0
+    g, _ = wb.clipper_bwd(x, th, FS, zs, gy.contiguous(), r=r, n_up=n_up, n_down=n_down)
+    sse = ((y - tgt)[skip:] ** 2).double().sum()
+    return y, g, float(sse)
+
+
+def close_grad(g, g_ref, rtol=G_RTOL):
+    g, g_ref = g.double().cpu().numpy(), g_ref.double().cpu().numpy()
+    return np.all(np.abs(g - g_ref) <= rtol * np.abs(g_ref) + 1e-30), (g, g_ref)
+
+
+@pytest.mark.parametrize("B,T,K,W", [(64, 512, 1, 0), (64, 2048, 4, 256), (70, 1001, 3, 248), (130, 4096, 16, 256),
+                                     (5, 96, 1, 0), (1, 2048, 4, 256), (3, 40, 1, 0)])
+@pytest.mark.parametrize("n_up,n_down", [(1, 1), (2, 3)])
+def test_fused_matches_two_kernel_step(wb, B, T, K, W, n_up, n_down):
+    x, th, ths = problem(B, T, seed=B + T)
+    xd, thd = dev(x), dev(th)
+    tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, n_up=n_up, n_down=n_down, want_stash=False)
+    gscale = 2.0 / (B * T)
+    y_ref, g_ref, sse_ref = two_kernel_step(wb, xd, thd, tgt, gscale, n_up=n_up, n_down=n_down)
+    y, _, g, sse, st = wb.clipper_step_mse_tp(xd, thd, FS, tgt, gscale, K, W, n_up=n_up, n_down=n_down)
+    s = wb.tp_status(st)
+    assert s["n_bad"] == 0 and not s["fallback_ran"], s
+    assert float((y - y_ref).abs().max()) <= Y_TOL
+    ok, info = close_grad(g, g_ref)
+    assert ok, info
+    assert abs(float(sse) - sse_ref) <= 2e-5 * sse_ref
+    # time-major x: same numbers
+    y2, _, g2, sse2, _ = wb.clipper_step_mse_tp(xd.t().contiguous(), thd, FS, tgt, gscale, K, W, n_up=n_up, n_down=n_down,
+                                                time_major=True)
+    assert float((y2 - y).abs().max()) <= 1e-6
+    ok, info = close_grad(g2, g, rtol=2e-5)
+    assert ok, info
+    # deterministic
+    y3, _, g3, sse3, _ = wb.clipper_step_mse_tp(xd, thd, FS, tgt, gscale, K, W, n_up=n_up, n_down=n_down)
+    assert torch.equal(y3, y) and torch.equal(g3, g) and torch.equal(sse3, sse)
+
+
+def test_fused_vs_oracle_f64(wb, oracle):
+    B, T, K, W = 96, 2048, 8, 256
+    x, th, ths = problem(B, T, seed=21)
+    tgt64 = oracle.clipper_fwd(ths.astype(np.float64), FS, x.astype(np.float64))
+    th64 = th.astype(np.float32).astype(np.float64)
+    loss_ref, g_ref, y_ref = oracle.clipper_mse_step(th64, FS, x.astype(np.float64), tgt64.astype(np.float32).astype(np.float64),
+                                                     dtype=np.float64)
+    y, _, g, sse, st = wb.clipper_step_mse_tp(dev(x), dev(th), FS, dev(tgt64), 2.0 / (B * T), K, W)
+    assert wb.tp_status(st)["n_bad"] == 0
+    assert float(np.max(np.abs(y.cpu().numpy() - y_ref))) <= Y_TOL
+    got = g.cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(got - g_ref) <= G_RTOL * np.abs(g_ref)), (got, g_ref)
+    assert abs(float(sse) / (B * T) - loss_ref) <= 1e-5 * loss_ref
+
+
+def test_fused_per_sample_resistance_and_skip(wb):
+    B, T, K, W, skip = 71, 1024, 2, 256, 50
+    x, th, ths = problem(B, T, seed=3)
+    xd, thd = dev(x), dev(th)
+    r = dev(45.0e3 * np.exp(0.8 * np.sin(np.arange(T)[None, :] * 0.01 * (1 + np.arange(B)[:, None] % 5))))
+    tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, r=r, want_stash=False)
+    gscale = 2.0 / (B * (T - skip))
+    y_ref, g_ref, sse_ref = two_kernel_step(wb, xd, thd, tgt, gscale, r=r, skip=skip)
+    y, _, g, sse, st = wb.clipper_step_mse_tp(xd, thd, FS, tgt, gscale, K, W, r=r, skip=skip)
+    assert wb.tp_status(st)["n_bad"] == 0
+    assert float((y - y_ref).abs().max()) <= Y_TOL
+    ok, info = close_grad(g[[0, 1, 3]], g_ref[[0, 1, 3]])            # dL/dR is identically 0 with a streamed resistance
+    assert ok and float(g[2]) == 0.0, info
+    assert abs(float(sse) - sse_ref) <= 2e-5 * sse_ref
+    yt, _, gt, _, _ = wb.clipper_step_mse_tp(xd.t().contiguous(), thd, FS, tgt, gscale, K, W, r=r.t().contiguous(), skip=skip,
+                                             time_major=True)
+    assert float((yt - y).abs().max()) <= 1e-6
+    ok, info = close_grad(gt[[0, 1, 3]], g[[0, 1, 3]], rtol=2e-5)
+    assert ok, info
+
+
+def test_fused_initial_state_general_root_and_accumulate(wb):
+    B, T, K, W = 64, 1024, 4, 256
+    x, th, ths = problem(B, T, seed=2)
+    xd, thd = dev(x), dev(th)
+    z0 = dev(np.random.default_rng(0).uniform(-0.3, 0.3, B))
+    tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, want_stash=False)
+    gscale = 2.0 / (B * T)
+    y_ref, g_ref, _ = two_kernel_step(wb, xd, thd, tgt, gscale, z0=z0)
+    y, zT, g, _, st = wb.clipper_step_mse_tp(xd, thd, FS, tgt, gscale, K, W, z0=z0, want_zT=True)
+    assert wb.tp_status(st)["n_bad"] == 0
+    assert float((y - y_ref).abs().max()) <= Y_TOL
+    ok, info = close_grad(g, g_ref)
+    assert ok, info
+    _, _, zT_ref = wb.clipper_fwd(xd, thd, FS, z0=z0, want_stash=False, want_zT=True)
+    assert float((zT - zT_ref).abs().max()) <= Y_TOL
+    # the general per-step root evaluation gives the same step
+    wb.GENERAL_ROOT = True
+    try:
+        y_g, _, g_g, _, _ = wb.clipper_step_mse_tp(xd, thd, FS, tgt, gscale, K, W, z0=z0)
+    finally:
+        wb.GENERAL_ROOT = False
+    assert float((y_g - y).abs().max()) <= 1e-6
+    ok, info = close_grad(g_g, g, rtol=2e-5)
+    assert ok, info
+    # accumulate: gtheta += gradient
+    acc = g.clone()
+    wb.clipper_step_mse_tp(xd, thd, FS, tgt, gscale, K, W, z0=z0, gtheta=acc, accumulate=True)
+    assert torch.allclose(acc, 2.0 * g, rtol=1e-6, atol=0)
+
+
+def test_fused_repairs_when_warmup_is_too_short(wb):
+    """C = 1 uF: the circuit remembers ~4000 samples, a 64-step warm-up cannot work.  Every boundary must be
+    caught, the chunks re-run from the exact state (outputs AND tangent records), and the step must equal the
+    sequential computation."""
+    from wdf_hip import workload
+    B, T, K = 70, 2048, 8
+    x = workload.sweep_batch(B, T, seed=11)
+    theta = workload.clipper_theta()
+    theta[3] = 1.0e-6
+    ths = workload.target_theta()
+    ths[3] = 1.1e-6
+    xd, thd = dev(x), dev(theta)
+    tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, want_stash=False)
+    gscale = 2.0 / (B * T)
+    y_ref, g_ref, sse_ref = two_kernel_step(wb, xd, thd, tgt, gscale)
+    y, _, g, sse, st = wb.clipper_step_mse_tp(xd, thd, FS, tgt, gscale, K, 64)
+    s = wb.tp_status(st)
+    assert s["n_bad"] > 0 and s["repaired_tiles"] == 2 * 7, s
+    assert float((y - y_ref).abs().max()) <= Y_TOL
+    ok, info = close_grad(g, g_ref, rtol=5e-5)
+    assert ok, info
+    assert abs(float(sse) - sse_ref) <= 2e-5 * sse_ref
+    # and the tickets were left clean: the same workspace serves a good call afterwards
+    ws = wb.step_mse_workspace(B, K, xd.device)
+    for W in (64, 64, 4096):
+        y2, _, g2, _, st2 = wb.clipper_step_mse_tp(xd, thd, FS, tgt, gscale, K, W, ws=ws)
+        assert float((y2 - y_ref).abs().max()) <= Y_TOL
+        ok, info = close_grad(g2, g_ref, rtol=5e-5)
+        assert ok, info
+
+
+def test_fused_warm_started_training_loop_with_adam(wb):
+    """The bench loop in small: resident x, Adam folded into the launch, warm-started chunks.  Every step is
+    compared with the two-kernel step at the SAME theta; then theta jumps (repair), then stands still."""
+    from wdf_hip import workload
+    B, T, K, W = 128, 4096, 16, 256
+    x, th0, ths = problem(B, T, seed=5)
+    xd = dev(x)
+    xt = xd.t().contiguous()
+    tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, want_stash=False)
+    gscale = 2.0 / (B * T)
+    theta = dev(th0)
+    state = wb.TpWarmState(B, T, K, 8, xd.device)
+    ws = wb.step_mse_workspace(B, K, xd.device)
+    lr = [1e-3 * float(v) for v in th0]
+    lo, hi = [1e-15, 1e-3, 180.0, 1e-13], [1e-3, 1.0, 1.0e6, 1.0]
+    opt = wb.Adam(4, lr=lr, lo=lo, hi=hi, device=xd.device)
+    opt_ref = wb.Adam(4, lr=lr, lo=lo, hi=hi, device=xd.device)
+    theta_ref = theta.clone()
+    losses = []
+    for it in range(12):
+        if it == 8:                                                  # a jump the snapshots cannot follow
+            theta *= torch.tensor([1.5, 1.1, 0.6, 1.6], device="cuda")
+            theta_ref.copy_(theta)
+        th_before = theta.clone()
+        y, _, g, sse, st = wb.clipper_step_mse_tp(xt, theta, FS, tgt, gscale, K, W, ws=ws, state=state, opt=opt, time_major=True)
+        s = wb.tp_status(st)
+        y_ref, g_ref, sse_ref = two_kernel_step(wb, xd, th_before, tgt, gscale)
+        assert float((y - y_ref).abs().max()) <= Y_TOL, (it, s)
+        ok, info = close_grad(g, g_ref)
+        assert ok, (it, info)
+        opt_ref.apply(theta_ref, g.clone())
+        assert torch.allclose(theta, theta_ref, rtol=1e-6, atol=0), (it, theta, theta_ref)   # the folded update is wdf_adam_step's
+        theta_ref.copy_(theta)
+        if it == 8:
+            assert s["n_bad"] > 0 and s["repaired_tiles"] > 0, s
+        elif it >= 2:
+            assert s["n_bad"] == 0, (it, s)
+        losses.append(float(sse))
+    assert losses[7] < losses[0]
+    info = state.info()
+    assert info["valid"] == 2 and info["n_calls"] == 12
+    # theta stands still: plain warm start from the snapshots, zero miss
+    for _ in range(3):
+        y, _, g, _, st = wb.clipper_step_mse_tp(xt, theta, FS, tgt, gscale, K, W, ws=ws, state=state, time_major=True)
+    assert wb.tp_status(st)["n_bad"] == 0
+
+
+def test_fused_bench_shape_against_oracle(wb, oracle):
+    """BASELINE configs[2] at full size through engine.MseStep.step_fused (what bench.py times): 16 sequences of y and
+    the whole-batch gradient against the fp64 oracle."""
+    from wdf_hip import engine, workload
+    B, T = 8192, 4096
+    x = workload.sweep_batch(B, T)
+    th, ths = workload.clipper_theta(), workload.target_theta()
+    xd = dev(x)
+    xt = xd.t().contiguous()
+    tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, want_stash=False)
+    plan = engine.plan_time_parallel(B, T, th[2], th[3], FS, time_major=True)
+    st = engine.MseStep(B, T, FS, plan, xd.device, time_major=True, warm=True)
+    theta = dev(th)
+    for _ in range(3):
+        sse, g = st.step_fused(theta, xt, tgt)
+    stat = wb.tp_status(st.status)
+    assert stat["n_bad"] == 0, stat
+    pick = np.sort(np.random.default_rng(5).choice(B, 16, replace=False))
+    y_ref = oracle.clipper_fwd(th.astype(np.float32).astype(np.float64), FS, x[pick].astype(np.float64))
+    assert float(np.max(np.abs(st.y[:, pick].cpu().numpy() - y_ref))) <= Y_TOL
+    loss_ref, g_ref, _ = oracle.clipper_mse_step(th.astype(np.float32).astype(np.float64), FS, x.astype(np.float64),
+                                                 tgt.cpu().numpy().astype(np.float64), dtype=np.float64)
+    got = g.cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(got - g_ref) <= G_RTOL * np.abs(g_ref)), (got, g_ref)
+    assert abs(float(sse) / (B * T) - loss_ref) <= 1e-5 * loss_ref
