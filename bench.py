@@ -5,8 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch: diode-clipper forward over
-B x T samples, MSE against synthetic targets, reverse sweep to dL/d{Is, nVt, R, C}, (N > 1)
-one RCCL all-reduce of the fused [loss, grads] buffer, and the on-device Adam update.
+B x T samples (y written), MSE against synthetic targets, the gradient dL/d{Is, nVt, R, C}, (N > 1)
+one RCCL all-reduce of the fused [loss, grads] buffer, and the on-device Adam update.  By default forward,
+loss and gradient run as ONE pass over the data (wdf_clipper_step_mse_tp: the gradient is carried forward in
+time as the state's tangent, no state stash); --two-kernel runs the forward kernel + reverse-sweep kernel
+pair instead (the only form for --loss mse+esr).
 Workload = BASELINE.json configs[2]: 1N4148 diode clipper fwd+bwd, batch 8192 sequences x 4096
 samples @ 48 kHz per GPU ("scaling": "weak": every rank holds its own 8192-sequence shard of the
 global batch; --scaling strong splits ONE 8192-sequence batch over the ranks instead).
@@ -36,6 +39,8 @@ PMC_TRAFFIC_GLOB = os.path.join(REPO, "profiles", "*_pmc_traffic.json")
 BYTES_FWD = 12                 # x 4 + y 4 + z-stash 4   (fwd 8 B + 4 B stash)
 BYTES_BWD = 12                 # x 4 + z-stash 4 + target 4: the fused-MSE sweep rebuilds y from the stash and forms
                                # dL/dy from the target itself (SURVEY 8d counts x, z and dL/dy: the same 12 B)
+BYTES_STEP = 24                # SURVEY 8d's figure for forward + backward, the unit one launch of the one-pass step processes
+BYTES_STEP_MOVED = 12          # what that kernel itself has to move: x 4 + target 4 + y 4 (no stash, x read once)
 
 
 def measured_traffic(kernel, cfg):
@@ -102,14 +107,17 @@ def cpu_baseline(T, fs, budget_s=12.0):
                       f"samples of the same sweep workload ({dt:.1f} s, OpenMP {best} threads, best of {cands})"}
 
 
-def parity_check(stepper, theta, xk, x_host, target, fs, n_global):
-    """After the timed region: one more forward + fused reverse sweep of the BENCH PATH ITSELF (same
+def parity_check(stepper, theta, xk, x_host, target, fs, n_global, fused):
+    """After the timed region: one more step (no update) of the BENCH PATH ITSELF (same
     stepper, same plan, same warm-start state, no update) at the parameters training has reached, against
     the fp64 CPU oracle over the whole batch: every output sample and the four gradient components."""
     O = _oracle()
     th_host = theta.detach().cpu().numpy().astype(np.float64)
-    stepper.forward(theta, xk)
-    sse, g = stepper.backward(theta, xk, target)
+    if fused:
+        sse, g = stepper.step_fused(theta, xk, target)
+    else:
+        stepper.forward(theta, xk)
+        sse, g = stepper.backward(theta, xk, target)
     torch.cuda.synchronize()
     y = stepper.y.cpu().numpy()
     t0 = time.perf_counter()
@@ -153,7 +161,12 @@ class Trainer:
         if tp is not None and args.plan:
             kf, w, kb = (int(v) for v in args.plan.split(","))
             tp = tp._replace(k_fwd=kf, warmup=w, k_bwd=kb)
-        elif tp is not None:                    # part of the untimed set-up: pick chunk counts on this box
+        self.fused = args.loss == "mse" and not args.two_kernel
+        if tp is not None and args.plan:
+            pass
+        elif tp is not None and self.fused:     # part of the untimed set-up: pick the chunk count on this box
+            tp = engine.autotune_fused(self.theta, self.xk, target, fs, tp, time_major=time_major)
+        elif tp is not None:
             tp = engine.autotune_time_parallel(self.theta, self.xk, target, fs, tp, time_major=time_major)
         self.tp = tp
         self.stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global, time_major=time_major, loss=args.loss, skip=skip,
@@ -168,19 +181,24 @@ class Trainer:
         self.t_fwd, self.t_bwd = [], []
 
     def step(self, timed=False):
-        # forward (x -> y, state stash), then the MSE-fused reverse sweep (-> SSE, dSSE-mean/dtheta),
-        # then ONE fused all-reduce of [SSE, grads] (no-op on 1 GPU unless --force-dist)
-        # timed: events bracket exactly the forward / reverse recurrence kernel (what rocprofv3
-        # lists under that name), not the verify / combine / reduce helpers of the same call
+        # one pass: forward (x -> y), MSE and the gradient in ONE kernel (-> SSE, dSSE-mean/dtheta); or, two kernels:
+        # forward (x -> y, state stash), then the MSE-fused reverse sweep; then ONE fused all-reduce of
+        # [SSE, grads] (no-op on 1 GPU unless --force-dist)
+        # timed: events bracket exactly the recurrence kernel(s) (what rocprofv3 lists under that name)
         st, ev, args = self.stepper, self.ev, self.args
-        if timed:
-            binding.Event.bracket_next(ev[0], ev[1])
-        st.forward(self.theta, self.xk)
-        if timed:
-            binding.Event.bracket_next(ev[2], ev[3])
-        # one rank and plain MSE: the update rides in the sweep's last kernel; otherwise all-reduce, then update
+        # one rank and plain MSE: the update rides in the step's own last waves; otherwise all-reduce, then update
         fold = self.adam is not None and self.world == 1 and args.loss == "mse" and not args.force_dist
-        st.backward(self.theta, self.xk, self.target, adam=self.adam if fold else None)
+        if self.fused:
+            if timed:
+                binding.Event.bracket_next(ev[0], ev[1])
+            st.step_fused(self.theta, self.xk, self.target, adam=self.adam if fold else None)
+        else:
+            if timed:
+                binding.Event.bracket_next(ev[0], ev[1])
+            st.forward(self.theta, self.xk)
+            if timed:
+                binding.Event.bracket_next(ev[2], ev[3])
+            st.backward(self.theta, self.xk, self.target, adam=self.adam if fold else None)
         buf = st.out                                   # [SSE, grads]: the kernels wrote it in place
         wdist.allreduce_sum_(buf)
         if self.adam is not None:
@@ -190,7 +208,8 @@ class Trainer:
                 self.adam.apply(self.theta, buf[1:])
         if timed:
             self.t_fwd.append(ev[0].elapsed_ms(ev[1]))
-            self.t_bwd.append(ev[2].elapsed_ms(ev[3]))
+            if not self.fused:
+                self.t_bwd.append(ev[2].elapsed_ms(ev[3]))
         return buf[0], buf[1:]
 
     def run(self, warmup, steps, dev):
@@ -341,6 +360,9 @@ def main():
                     help="pin the time-parallel plan (forward chunks, cold warm-up steps, reverse chunks) instead of "
                          "autotuning it; used to profile one configuration across several rocprofv3 passes")
     ap.add_argument("--sequential", action="store_true", help="one lane per sequence, no time-parallel chunks")
+    ap.add_argument("--two-kernel", action="store_true",
+                    help="forward kernel + reverse-sweep kernel (24 B/sample through HBM, state stash) instead of the "
+                         "one-pass step (12 B/sample)")
     ap.add_argument("--cold-forward", action="store_true",
                     help="every forward warms its chunks up from z = 0 (no state kept between steps) instead of "
                          "starting them from the previous step's snapshots")
@@ -405,26 +427,33 @@ def main():
 
     parity = None
     if rank == 0 and world == 1 and not args.no_parity and args.loss == "mse":
-        parity = parity_check(stepper, main_run.theta, main_run.xk, x_host, target, fs, n_global)
+        parity = parity_check(stepper, main_run.theta, main_run.xk, x_host, target, fs, n_global, main_run.fused)
 
     if rank == 0:
         copy_gbs = copy_bandwidth_gbs(dev)
         ms_step = dt / args.steps * 1e3
         value = Bg * T / (dt / args.steps)
         t_fwd, t_bwd = main_run.t_fwd, main_run.t_bwd
-        f_ms, b_ms = float(np.mean(t_fwd)), float(np.mean(t_bwd))
-        fname = "clipper_fwd_tp_kernel" if (tp is not None and tp.k_fwd > 1) else "clipper_fwd_kernel"
-        dom, dom_ms, dom_bytes = (fname, f_ms, BYTES_FWD) if f_ms >= b_ms else ("clipper_bwd_tp_kernel", b_ms, BYTES_BWD)
-        achieved = dom_bytes * B * T / (dom_ms * 1e-3) / 1e9
+        fused = main_run.fused
+        f_ms = float(np.mean(t_fwd))
+        b_ms = float(np.mean(t_bwd)) if t_bwd else None
         warm = None if stepper.warm is None else stepper.warm.info()
         # a kernel's traffic depends on the batch, the layout and its OWN chunking only
         key = {"B": B, "T": T, "x_layout": "time-major" if tm else "batch-major"}
-        if tp is not None:
-            if dom.startswith("clipper_fwd"):
-                key.update({"fwd_chunks": tp.k_fwd,
-                            "fwd_warmup_steps": tp.warmup if warm is None else 32 * max(0, warm["last_warm_tiles"])})
-            else:
-                key.update({"bwd_chunks": tp.k_bwd})
+        w_used = None if tp is None else (tp.warmup if warm is None else 32 * max(0, warm["last_warm_tiles"]))
+        if fused:
+            dom, dom_ms, dom_bytes = "clipper_fused_tp_kernel", f_ms, BYTES_STEP
+            if tp is not None:
+                key.update({"fused_chunks": tp.k_fwd, "fwd_warmup_steps": w_used})
+        else:
+            fname = "clipper_fwd_tp_kernel" if (tp is not None and tp.k_fwd > 1) else "clipper_fwd_kernel"
+            dom, dom_ms, dom_bytes = (fname, f_ms, BYTES_FWD) if f_ms >= b_ms else ("clipper_bwd_tp_kernel", b_ms, BYTES_BWD)
+            if tp is not None:
+                if dom.startswith("clipper_fwd"):
+                    key.update({"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": w_used})
+                else:
+                    key.update({"bwd_chunks": tp.k_bwd})
+        achieved = dom_bytes * B * T / (dom_ms * 1e-3) / 1e9
         traffic, traffic_src = (None, None) if tp is None else measured_traffic(dom, key)
         layout_names = {True: "time-major [T,B] resident copy (one-off transpose at data load, outside the timed region)",
                         False: "batch-major [B,T] as the reference scripts hold it"}
@@ -448,17 +477,30 @@ def main():
                        "x_layout": layout_names[tm],
                        "time_parallel": None if tp is None else
                        {"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup, "verify_tol": tp.tol,
-                        "bwd_chunks": tp.k_bwd, "verify_status": tp_stat, "warm_start": warm}},
+                        "bwd_chunks": None if fused else tp.k_bwd, "verify_status": tp_stat, "warm_start": warm}},
             "value_batch_major" if tm else "value_time_major": other,
-            "kernel_ms": {"fwd": spread(t_fwd), "bwd": spread(t_bwd)},
+            "step_kernels": ("one pass: clipper_fused_tp_kernel (forward + loss + tangent-carried gradient + combine / reduce / "
+                             "Adam tail) and its gated repair launch") if fused else
+                            "two kernels: clipper_fwd_tp_kernel (+ gated repair) and clipper_bwd_tp_kernel (MSE-fused reverse sweep)",
+            "kernel_ms": {"fused_step": spread(t_fwd)} if fused else {"fwd": spread(t_fwd), "bwd": spread(t_bwd)},
             "parity": parity,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_sample": dom_bytes,
-                         "fwd_kernel_ms": f_ms, "bwd_kernel_ms": b_ms,
                          "copy_bandwidth": copy_gbs, "frac_of_copy_bandwidth": achieved / copy_gbs},
         }
+        if fused:
+            moved = BYTES_STEP_MOVED * B * T / (dom_ms * 1e-3) / 1e9
+            out["roofline"].update({
+                "step_kernel_ms": f_ms,
+                "bytes_moved_per_sample": BYTES_STEP_MOVED, "moved": moved, "frac_moved": moved / HBM_PEAK_GBS,
+                "note": "`achieved` prices one launch at SURVEY 8d's forward + backward figure (24 B/sample: x, y, stash written, "
+                        "then x, stash, dL/dy read) because one launch does that work; the one-pass kernel itself moves 12 B/sample "
+                        "(x + target in, y out: `moved`, `frac_moved`, and `traffic` when a PMC pass of this configuration is "
+                        "committed) and is bound by VALU issue (~105 instructions per sample-step), not by HBM"})
+        else:
+            out["roofline"].update({"fwd_kernel_ms": f_ms, "bwd_kernel_ms": b_ms})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, fs)
         print(json.dumps(out), flush=True)

@@ -437,6 +437,7 @@ int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float 
     if (skip < 0 || skip > T) return fail(WDF_EINVAL, "skip must be in 0..T");
     if (B >= ((int64_t)1 << 30)) return fail(WDF_EINVAL, "time-parallel kernels address a [B] row with 32-bit byte offsets: B < 2^30");
     if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 applies to wdf_clipper_fwd and wdf_omega_f64 only");
+    if (B >= ((int64_t)1 << 24)) return fail(WDF_EINVAL, "the one-pass step addresses a 32-row tile with 32-bit offsets: B < 2^24");
     if (m && (!v || !step || !lr)) return fail(WDF_EINVAL, "Adam update asked for (m) but v/step/lr missing");
     const TpGeom g = tp_geom(T, n_chunks);
     if (g.K != n_chunks) return fail(WDF_EINVAL, "n_chunks = %d does not tile T = %lld in 32-step units: use wdf_clipper_tp_chunks (%d)",

@@ -33,6 +33,40 @@ namespace wdf {
 constexpr int kFsOut = 9;       // record floats per (chunk, sequence)
 constexpr int kFusedSchedGroup = 1;   // steps the instruction scheduler may interleave
 
+// Rows of the time-major arrays through buffer descriptors: `buffer_load_dword v, voff, s[rsrc], soff offen` takes the
+// row's byte offset from an SGPR and the lane's from one VGPR, so a tile of 32 rows costs no VALU instruction and no
+// SGPR pair per row (with global_load / global_store the compiler either adds 64-bit addresses on the VALU or keeps 32
+// row pointers per stream in SGPRs, spills them to VGPR lanes and reads them back with v_readlane: ~7 of the step's
+// ~105 VALU instructions).  x, target and y share the 32 row offsets i * 4B.  The descriptor is rebuilt per tile from
+// a 64-bit scalar base; offsets inside a tile stay below 2^32 for B < 2^24 (checked by the C ABI).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* row0)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row0), 0, 0xffffffffu, 0x00020000);
+}
+
+template <int N>
+__device__ __forceinline__ void load_rows(const float* row0, uint32_t boff, uint32_t rowb, float (&v)[N])
+{
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc(row0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, boff, i * rowb, 0));
+}
+
+// aux 2: nt (streaming output, not read again by this kernel)
+__device__ __forceinline__ void store_row_nt(float v, __amdgpu_buffer_rsrc_t rs, uint32_t boff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, boff, soff, 2);
+}
+
+// x tile: time-major through the descriptor, batch-major as 16-byte loads of the lane's own row
+template <bool TM, bool VEC4>
+__device__ __forceinline__ void load_x_tile(const float* __restrict__ x, const LaneSeqs<float>& q, int64_t B, int64_t T, int64_t t0,
+                                            uint32_t rowb, float (&v)[kTile])
+{
+    if constexpr (TM) load_rows<kTile>(x + t0 * B, q.boff[0], rowb, v);
+    else load_row<kTile, VEC4>(x, q.b[0], T, t0, v);
+}
+
 // Tangent state of one sequence inside a chunk.  G* accumulate sum_n s[n] (hg_n + hg_{n-1}) (summation
 // by parts of sum_n hg_n (s[n+1] + s[n]), hg = g/2): one FMA per statistic and step.
 struct FusedTan {
@@ -58,19 +92,33 @@ __device__ __forceinline__ float fused_step(const ClipConsts& c, float xin, floa
     const float y = 0.5f * (zn + z);
     // partials of the root (wdf_clipper.h, bwd_step / bwd_tp_step)
     const float w0p = o.w0 * vrcp(o.w0 + 1.0f);
-    const float w1p = o.w1 * vrcp(o.w1 + 1.0f);
-    const float l2 = o.lam * o.lam;
-    const float sp = w0p + w1p;
-    const float tl = -2.0f * l2;
-    const float Da = fmaf(tl, sp, 1.0f);
-    float DL, DV;
-    if constexpr (SYM) {
+    float Da, DL, DV;
+    if constexpr (SYM && FAST) {
+        // omega_1 <= omega(-4) = 0.018 here (series-only region, checked once per kernel): omega/(1 + omega) by
+        // its alternating series to the cubic term (next term 1e-7 relative) instead of a quarter-rate reciprocal.
+        // lam X = copysign(X, a) for the two differences, both >= 0 because omega and omega' are increasing and
+        // both exactly 0 at a = 0 where w0 == w1 bit for bit (diode_pair, FAST); lam^2 = (a != 0).
+        const float w1p = o.w1 * fmaf(-o.w1, fmaf(-o.w1, 1.0f - o.w1, 1.0f), 1.0f);
+        const float sp = w0p + w1p;
+        const float tl = (a != 0.0f) ? -2.0f : 0.0f;                // -2 lam^2
         const float tvm = c.d.two_v * c.d.m_dn;
-        DL = (-tvm) * (o.lam * (w0p - w1p));
-        DV = fmaf(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * (o.lam * (o.w0 - o.w1)));
+        Da = fmaf(tl, sp, 1.0f);
+        DL = (-tvm) * vcopysign(w0p - w1p, a);
+        DV = fmaf(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * vcopysign(o.w0 - o.w1, a));
     } else {
-        DL = (-c.d.two_v) * (o.lam * (o.m0 * w0p - o.m1 * w1p));
-        DV = fmaf(tl * a, sp * (-1.0f / c.V), -2.0f * (o.lam * (o.m0 * o.w0 - o.m1 * o.w1)));
+        const float w1p = o.w1 * vrcp(o.w1 + 1.0f);
+        const float l2 = o.lam * o.lam;
+        const float sp = w0p + w1p;
+        const float tl = -2.0f * l2;
+        Da = fmaf(tl, sp, 1.0f);
+        if constexpr (SYM) {
+            const float tvm = c.d.two_v * c.d.m_dn;
+            DL = (-tvm) * (o.lam * (w0p - w1p));
+            DV = fmaf(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * (o.lam * (o.w0 - o.w1)));
+        } else {
+            DL = (-c.d.two_v) * (o.lam * (o.m0 * w0p - o.m1 * w1p));
+            DV = fmaf(tl * a, sp * (-1.0f / c.V), -2.0f * (o.lam * (o.m0 * o.w0 - o.m1 * o.w1)));
+        }
     }
     const float opd = Da + 1.0f;
     float cP = -opd * b_diff;
@@ -153,51 +201,71 @@ __device__ __forceinline__ void clipper_fused_body(
     }
     float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)((head + 1) % kTpRing) * J * K + k) * B : nullptr;
 
-    float xc[1][kTile], xn[1][kTile], rc[1][kTile], rn[1][kTile], gc[1][kTile], gn[1][kTile];
+    const uint32_t rowb = (uint32_t)B * 4u;
+    const uint32_t boff = q.boff[0];
+    float xc[kTile], xn[kTile], rc[kTile], rn[kTile], gc[kTile], gn[kTile];
 #pragma unroll
-    for (int i = 0; i < kTile; ++i) { xc[0][i] = xn[0][i] = gc[0][i] = gn[0][i] = 0.0f; rc[0][i] = rn[0][i] = 1.0f; }
+    for (int i = 0; i < kTile; ++i) { xc[i] = xn[i] = gc[i] = gn[i] = 0.0f; rc[i] = rn[i] = 1.0f; }
     const int64_t nfull_end = t1 - (t1 - tw) % kTile;
     if (tw < nfull_end) {
-        load_tile_v<V, TM, VEC4>(x, q, B, T, tw, xn);
-        if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, tw, rn);
-        if (tw >= t0) load_tile_v<V, true, false>(target, q, B, T, tw, gn);
+        load_x_tile<TM, VEC4>(x, q, B, T, tw, rowb, xn);
+        if constexpr (DYN_R) load_x_tile<TM, VEC4>(r, q, B, T, tw, rowb, rn);
+        if (tw >= t0) load_rows<kTile>(target + tw * B, boff, rowb, gn);
     }
-    float* __restrict__ yrow = y + t0 * B;
     int64_t t = tw;
     for (; t < t0 && t < nfull_end; t += kTile) {           // ---- warm-up tiles: forward only, nothing stored
 #pragma unroll
-        for (int i = 0; i < kTile; ++i) { xc[0][i] = xn[0][i]; if constexpr (DYN_R) rc[0][i] = rn[0][i]; }
+        for (int i = 0; i < kTile; ++i) { xc[i] = xn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
         if (t + kTile < nfull_end) {
-            load_tile_v<V, TM, VEC4>(x, q, B, T, t + kTile, xn);
-            if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, t + kTile, rn);
-            if (t + kTile >= t0) load_tile_v<V, true, false>(target, q, B, T, t + kTile, gn);   // the first owned tile's target
+            load_x_tile<TM, VEC4>(x, q, B, T, t + kTile, rowb, xn);
+            if constexpr (DYN_R) load_x_tile<TM, VEC4>(r, q, B, T, t + kTile, rowb, rn);
+            if (t + kTile >= t0) load_rows<kTile>(target + (t + kTile) * B, boff, rowb, gn);   // the first owned tile's target
         }
 #pragma unroll
-        for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, xc[0][i], rc[0][i], z);
+        for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, xc[i], rc[i], z);
     }
     publish_v<V>(zwarm, q, k * B, z);
     FusedTan s = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     FusedSums d = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (; t < nfull_end; t += kTile) {                     // ---- owned tiles
 #pragma unroll
-        for (int i = 0; i < kTile; ++i) { xc[0][i] = xn[0][i]; gc[0][i] = gn[0][i]; if constexpr (DYN_R) rc[0][i] = rn[0][i]; }
+        for (int i = 0; i < kTile; ++i) { xc[i] = xn[i]; gc[i] = gn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
         const bool more = t + kTile < nfull_end;
         if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1))
             store_v<V>(snapw, q, ((t1 - t) / kTile) * K * B, z);
+        const __amdgpu_buffer_rsrc_t ry = row_rsrc(y + t * B);
+        if (t < skip) {
+            // A tile with steps below `skip` (they carry no loss): at most two per sequence (skip_samples = 50,
+            // clipper_pot.py:232), so it runs as a compact loop of single steps with its own loads, and the unrolled
+            // path below needs no per-step mask.  The next tile's prefetch is issued first, as on that path.
+            if (more) {
+                load_x_tile<TM, VEC4>(x, q, B, T, t + kTile, rowb, xn);
+                if constexpr (DYN_R) load_x_tile<TM, VEC4>(r, q, B, T, t + kTile, rowb, rn);
+                load_rows<kTile>(target + (t + kTile) * B, boff, rowb, gn);
+            }
+#pragma unroll 1
+            for (int i = 0; i < kTile; ++i) {
+                const int64_t tt = t + i;
+                const float xin = load_one<TM>(x, q.b[0], B, T, tt);
+                const float rin = DYN_R ? load_one<TM>(r, q.b[0], B, T, tt) : 1.0f;
+                const float tg = target[tt * B + q.b[0]];
+                y[tt * B + q.b[0]] = fused_step<DYN_R, SYM, FAST>(c, xin, rin, tg, tt >= skip ? hgs : 0.0f, z, s);
+            }
+            d.flush(s);
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < kTile; ++i) {
             if (i == kTile / 2) {                           // prefetch in the middle of the tile (vmcnt, see the forward)
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
-                    load_tile_v<V, TM, VEC4>(x, q, B, T, t + kTile, xn);
-                    if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, t + kTile, rn);
-                    load_tile_v<V, true, false>(target, q, B, T, t + kTile, gn);
+                    load_x_tile<TM, VEC4>(x, q, B, T, t + kTile, rowb, xn);
+                    if constexpr (DYN_R) load_x_tile<TM, VEC4>(r, q, B, T, t + kTile, rowb, rn);
+                    load_rows<kTile>(target + (t + kTile) * B, boff, rowb, gn);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const float hm = (t + i >= skip) ? hgs : 0.0f;  // wave-uniform: the scalar unit's work
-            store_row_v<V>(yrow, q, fused_step<DYN_R, SYM, FAST>(c, xc[0][i], rc[0][i], gc[0][i], hm, z, s));
-            yrow += B;
+            store_row_nt(fused_step<DYN_R, SYM, FAST>(c, xc[i], rc[i], gc[i], hgs, z, s), ry, boff, i * rowb);
             // The tangent updates do not feed the next step's state, so left alone instruction selection
             // emits the z chain of the whole tile first and keeps every step's partials alive (200 VGPRs,
             // spills).  Pinning the tangent state (a chained, empty asm) before the scheduling barrier keeps
@@ -213,8 +281,7 @@ __device__ __forceinline__ void clipper_fused_body(
         const float xin = load_one<TM>(x, q.b[0], B, T, tt);
         const float rin = DYN_R ? load_one<TM>(r, q.b[0], B, T, tt) : 1.0f;
         const float tg = target[tt * B + q.b[0]];
-        store_row_v<V>(yrow, q, fused_step<DYN_R, SYM, FAST>(c, xin, rin, tg, tt >= skip ? hgs : 0.0f, z, s));
-        yrow += B;
+        y[tt * B + q.b[0]] = fused_step<DYN_R, SYM, FAST>(c, xin, rin, tg, tt >= skip ? hgs : 0.0f, z, s);
     }
     d.flush(s);
     publish_v<V>(zend, q, k * B, z);

@@ -380,6 +380,33 @@ def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1,
     return plan._replace(k_fwd=best_f, k_bwd=best_b)
 
 
+def autotune_fused(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=1, reps=7, r=None):
+    """The chunk count of the one-pass step (MseStep.step_fused), by timing the planned count, half and double
+    on the actual batch (median of single-launch timings; the cold warm-up: the warm start shortens all three alike)."""
+    if plan is None:
+        return plan
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+
+    def timed(fn):
+        fn()
+        e0, e1 = binding.Event(), binding.Event()
+        ts = []
+        for _ in range(reps):
+            e0.record()
+            fn()
+            e1.record()
+            ts.append(e0.elapsed_ms(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    times = {}
+    for k in sorted({k for k in (max(1, plan.k_fwd // 2), plan.k_fwd, plan.k_fwd * 2) if k == 1 or k <= T // max(plan.warmup // 2, 64)}):
+        st = MseStep(B, T, fs, plan._replace(k_fwd=k), x.device, n_up=n_up, n_down=n_down, time_major=time_major, warm=True)
+        times[k] = timed(lambda: st.step_fused(theta, x, target, r))
+        if binding.tp_status(st.status)["n_bad"]:
+            del times[k]                     # a chunking whose speculation fails on this data is not a candidate
+    return plan._replace(k_fwd=_pick(times, plan.k_fwd)) if times else plan
+
+
 class _ClipperMseFn(torch.autograd.Function):
     """mean((clipper(theta, x) - target)^2) with the loss inside the reverse sweep: forward runs the
     forward kernel AND the MSE-fused sweep (one stepper per shape, buffers reused), backward only

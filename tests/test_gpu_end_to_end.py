@@ -98,7 +98,7 @@ def test_bench_two_rank_path_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["parity"] is None and d["value_batch_major"] > 0          # parity runs on rank 0 at N = 1 only
-    assert set(d["kernel_ms"]["fwd"]) == {"min", "median", "max", "n"}
+    assert d["step_kernels"].startswith("one pass") and set(d["kernel_ms"]["fused_step"]) == {"min", "median", "max", "n"}
     assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2048 * 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
@@ -132,6 +132,12 @@ def test_bench_force_dist_runs_the_rccl_branch():
     assert np.max(np.abs(a - b) / np.abs(b)) < 1e-6, (a, b)
     assert d["parity"]["max_abs_y"] < 1e-6 and d["parity"]["max_rel_grad"] < 1e-4, d["parity"]
     assert ref["parity"]["max_abs_y"] < 1e-6 and ref["parity"]["max_rel_grad"] < 1e-4, ref["parity"]
+    # and the two-kernel form of the same step (forward kernel + reverse-sweep kernel) trains to the same parameters
+    two = _run_bench(common + ["--two-kernel"])
+    assert two["step_kernels"].startswith("two kernels") and set(two["kernel_ms"]) == {"fwd", "bwd"}
+    c = np.array(two["config"]["optimizer"]["theta_final"])
+    assert np.max(np.abs(c - b) / np.abs(b)) < 1e-5, (c, b)
+    assert two["parity"]["max_abs_y"] < 1e-6 and two["parity"]["max_rel_grad"] < 1e-4, two["parity"]
 
 
 def test_bench_strong_scaling_rehearsal():

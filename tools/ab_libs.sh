@@ -2,5 +2,5 @@
 ARGS="$1"; shift
 for round in 1 2; do for L in "$@"; do
   WDF_HIP_LIB=$PWD/differentiable-wdfs_amd/lib/wdf_hip/$L python bench.py --no-cpu-baseline $ARGS 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); tp=d['config']['time_parallel']; print('$L', 'G/s %.1f'%(d['value']/1e9), 'step %.4f'%d['ms_per_step'], 'fwd %.4f'%d['roofline']['fwd_kernel_ms'], 'bwd %.4f'%d['roofline']['bwd_kernel_ms'])"
+import json,sys; d=json.loads(sys.stdin.read()); tp=d['config']['time_parallel']; print('$L', 'G/s %.1f'%(d['value']/1e9), 'step %.4f'%d['ms_per_step'], 'kernel_ms', {k: round(v['median'], 4) for k, v in d['kernel_ms'].items()})"
 done; done

@@ -21,9 +21,10 @@ for log in glob.glob(os.path.join(root, f"pmc_{tag}_*.log")):
         if line.startswith("{") and '"metric"' in line:
             d = json.loads(line)
             tp = d["config"]["time_parallel"]
+            fused = str(d.get("step_kernels", "")).startswith("one pass")
             cfg = {"B": d["config"]["global_batch"] // d["n_gpus"], "T": d["config"]["seq_len"],
                    "x_layout": "time-major" if d["config"]["x_layout"].startswith("time-major") else "batch-major",
-                   "fwd_chunks": tp["fwd_chunks"], "bwd_chunks": tp["bwd_chunks"],
+                   **({"fused_chunks": tp["fwd_chunks"]} if fused else {"fwd_chunks": tp["fwd_chunks"], "bwd_chunks": tp["bwd_chunks"]}),
                    # warm-started forward: the warm-up the device controller settled at, not the cold one
                    "fwd_warmup_steps": tp["fwd_warmup_steps"] if not tp.get("warm_start") else 32 * max(0, tp["warm_start"]["last_warm_tiles"])}
 out = {"_doc": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_* (separate passes, --kernel-trace) of `python bench.py "
