@@ -445,7 +445,7 @@ struct TpCtl {
     float last_miss;  // largest boundary miss of the last call
     int n_calls;
     int geom;         // (K << 8) | J of the calls that wrote the snapshots; a different geometry restarts cold
-    int j_floor;      // the controller never goes below this many warm-up tiles (host: 0; j_floor = max pins it)
+    int j_floor;      // low byte: the controller never goes below this many warm-up tiles (host: 0; = max pins it); above: hold counter
 };
 static_assert(sizeof(TpCtl) == 64, "TpCtl layout");
 
@@ -833,19 +833,29 @@ __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, 
     const int head = stateful ? ctl->head : 0;
     const int valid = stateful ? ctl->valid : 0;
     int j = ctl->j_next;
+    const int jfloor = ctl->j_floor & 0xff;                     // host's floor (low byte); the rest of the word: hold counter
+    int hold = ctl->j_floor >> 8;
     if (valid == 0) {                                           // that was the cold call: start three tiles under its warm-up
         const int jc = (int)((W + kTile - 1) / kTile);              // (an O(1 V) guess needs ~5 tiles here; a change of 1e-3 V two)
         j = jc - 3 < 1 ? 1 : jc - 3;
+        hold = 0;
         ctl->j_used = -1;
     } else {
+        // One tile changes the miss by ~25x at the headline circuit, and two converged fp32 trajectories still
+        // differ by ~3e-8: grow when the miss comes within 2x of tol (or a boundary failed), shrink -- once the
+        // secant extrapolation is running -- while it stays 8x below, and after growing do not probe lower
+        // again for 32 calls.  Measured in the bench loop (tools/warm_pin_probe.py): 1 tile misses by <= 3e-7,
+        // 2 tiles by <= 7e-8, 3 tiles sit at the rounding floor.
         ctl->j_used = j;
-        if (nb > 0) j += 2;
-        else if (mm * 4.0f > tol) j += 1;
-        else if (mm * 64.0f < tol) j -= 1;
+        if (nb > 0) { j += 2; hold = 32; }
+        else if (mm * 2.0f > tol) { j += 1; hold = 32; }
+        else if (hold > 0) --hold;
+        else if (valid > 1 && mm * 8.0f < tol && (j > 1 || mm == 0.0f)) j -= 1;
     }
     const int jmax = (int)(L / kTile) < J - 1 ? (int)(L / kTile) : J - 1;
-    const int jmin = ctl->j_floor < jmax ? ctl->j_floor : jmax;
+    const int jmin = jfloor < jmax ? jfloor : jmax;
     ctl->j_next = j < jmin ? jmin : (j > jmax ? jmax : j);
+    ctl->j_floor = jfloor | (hold << 8);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ctl->th2[i] = stateful ? ctl->th1[i] : theta[i]; ctl->th1[i] = theta[i]; }
     ctl->head = (head + 1) % kTpRing;

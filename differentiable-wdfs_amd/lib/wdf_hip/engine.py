@@ -408,9 +408,9 @@ def autotune_fused(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=
 
 
 class _ClipperMseFn(torch.autograd.Function):
-    """mean((clipper(theta, x) - target)^2) with the loss inside the reverse sweep: forward runs the
-    forward kernel AND the MSE-fused sweep (one stepper per shape, buffers reused), backward only
-    scales the stored gradient -- no y-sized loss temporaries, no dL/dy array."""
+    """mean((clipper(theta, x) - target)^2) as the one-pass training step (MseStep.step_fused: forward, loss
+    and gradient in one kernel, one stepper per shape, buffers reused); backward only scales the stored
+    gradient -- no y-sized loss temporaries, no dL/dy array, no state stash."""
     _steppers = {}
 
     @staticmethod
@@ -424,12 +424,12 @@ class _ClipperMseFn(torch.autograd.Function):
             st = _ClipperMseFn._steppers[key] = MseStep(B, T, fs, tp, x.device, n_up=n_up, n_down=n_down,
                                                         time_major=time_major)
         th = theta.detach().contiguous()
-        st.forward(th, x, r)
         LAST_TP_STATUS["status"] = st.status
-        if not theta.requires_grad:          # validation / no_grad losses: one streaming pass for the sum, no sweep
+        if not theta.requires_grad:          # validation / no_grad losses: forward + one streaming pass for the sum
+            st.forward(th, x, r)
             d = st.y - target
             return torch.sum(d * d) / float(B * T)
-        sse, g = st.backward(th, x, target, r)
+        sse, g = st.step_fused(th, x, target, r)      # forward, loss and gradient in one pass over the data
         ctx.save_for_backward(g.clone())
         return sse[0] / float(B * T)
 

@@ -28,3 +28,17 @@ for tm in (False, True):
         ms = e0.elapsed_ms(e1) / 20
         s = wb.tp_status(st.status) if kf > 1 else None
         print(f"time_major={tm} {name}: fwd chunks {kf} (W={plan_used.warmup}) bwd chunks {kb}: {ms:.3f} ms/step = {B * T / ms / 1e6:.1f} G samples/s  {s}")
+    # the one-pass step (wdf_clipper_step_mse_tp) on the same batch, cold and warm-started
+    for k in sorted({max(1, tuned.k_fwd // 2), tuned.k_fwd, tuned.k_fwd * 2}):
+        for warm in (False, True):
+            st = engine.MseStep(B, T, fs, tuned._replace(k_fwd=k), "cuda", time_major=tm, warm=warm, max_warm_tiles=16)
+            for _ in range(4):
+                st.step_fused(th, xin, tgt, r=rin)
+            e0, e1 = wb.Event(), wb.Event()
+            e0.record()
+            for _ in range(20):
+                st.step_fused(th, xin, tgt, r=rin)
+            e1.record()
+            ms = e0.elapsed_ms(e1) / 20
+            print(f"time_major={tm} one-pass step: chunks {k} (W={tuned.warmup}) warm={warm}: {ms:.3f} ms/step = {B * T / ms / 1e6:.1f} G samples/s  "
+                  f"{wb.tp_status(st.status)} {st.warm.info() if st.warm is not None else ''}")
