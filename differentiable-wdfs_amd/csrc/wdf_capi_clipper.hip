@@ -172,25 +172,35 @@ inline FusedWs fused_ws(void* ws, int64_t B, int K)
 template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_fused(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, const float* target,
                   float hgs, int64_t skip, float* y, const float* z0, float* zT, FusedWs w, wdf::TpStatus* status, float tol,
-                  int64_t B, int64_t T, TpGeom g, int64_t W, TpWarm warm, int general, float* gtheta, int accumulate, float* sse,
-                  wdf::AdamTail adam, hipStream_t s)
+                  int64_t B, int64_t T, TpGeom g, int64_t W, TpWarm warm, int general, bool pairs, float* gtheta, int accumulate,
+                  float* sse, wdf::AdamTail adam, hipStream_t s)
 {
-    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)g.K);
+    // pairs: two adjacent sequences per lane, packed fp32 arithmetic (wdf_clipper_fused.h); a tile is then 128 sequences
+    const int per_tile = pairs ? 128 : 64;
+    const dim3 grid((unsigned)((B + per_tile - 1) / per_tile), (unsigned)g.K);
+#define WDF_FUSED(V_)                                                                                                            \
+    hipLaunchKernelGGL((wdf::clipper_fused_tp_kernel<DYN_R, SYM, TM, V4, V_>), grid, dim3(64), 0, s, x, r, theta, fs, n_up, n_down, \
+                       target, hgs, skip, y, z0, zT, w.zwarm, w.zend, w.rec, status, warm.ctl, warm.snap, warm.J, w.tickets,    \
+                       w.gticket, tol, B, T, g.L, W, general, w.part, gtheta, accumulate, sse, adam)
+#define WDF_FUSED_REPAIR(N_)                                                                                                     \
+    hipLaunchKernelGGL((wdf::clipper_fused_repair_kernel<DYN_R, SYM, TM, N_>), dim3(grid.x), dim3(64), 0, s, x, r, theta, fs, n_up, \
+                       n_down, target, hgs, skip, y, zT, w.zwarm, w.zend, w.rec, B, T, (int64_t)g.K, g.L, tol, status, warm.ctl, \
+                       warm.snap, warm.J, w.tickets, w.gticket, general, w.part, gtheta, accumulate, sse, adam)
     {
         EventBracket bracket(s);
-        hipLaunchKernelGGL((wdf::clipper_fused_tp_kernel<DYN_R, SYM, TM, V4>), grid, dim3(64), 0, s, x, r, theta, fs, n_up, n_down,
-                           target, hgs, skip, y, z0, zT, w.zwarm, w.zend, w.rec, status, warm.ctl, warm.snap, warm.J, w.tickets,
-                           w.gticket, tol, B, T, g.L, W, general, w.part, gtheta, accumulate, sse, adam);
+        if (pairs) WDF_FUSED(wdf::v2f); else WDF_FUSED(float);
     }
-    if (g.K > 1)                                // blocks of unflagged tiles (normally all of them) leave at once
-        hipLaunchKernelGGL((wdf::clipper_fused_repair_kernel<DYN_R, SYM, TM>), dim3(grid.x), dim3(64), 0, s, x, r, theta, fs, n_up,
-                           n_down, target, hgs, skip, y, zT, w.zwarm, w.zend, w.rec, B, T, (int64_t)g.K, g.L, tol, status, warm.ctl,
-                           warm.snap, warm.J, w.tickets, w.gticket, general, w.part, gtheta, accumulate, sse, adam);
+    if (g.K > 1) {                              // blocks of unflagged tiles (normally all of them) leave at once
+        if (pairs) WDF_FUSED_REPAIR(2); else WDF_FUSED_REPAIR(1);
+    }
+#undef WDF_FUSED
+#undef WDF_FUSED_REPAIR
 }
 
 }  // namespace
 
 extern "C" {
+int wdf_debug_set_times(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(wdf::g_dbg_times), &p, sizeof(p)); }
 
 int wdf_clipper_fwd(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
                     float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int flags, void* stream)
@@ -429,7 +439,7 @@ int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float 
                             const float* lr, float beta1, float beta2, float eps, const float* lo, const float* hi, int flags,
                             void* stream)
 {
-    int rc = check_common(x, theta, n_up, n_down, B, T, flags);
+    int rc = check_common(x, theta, n_up, n_down, B, T, flags & ~WDF_ONE_SEQUENCE_PER_LANE);
     if (rc) return rc;
     if (!target || !y || !ws || !status || !gtheta || !sse) return fail(WDF_EINVAL, "null target/y/ws/status/gtheta/sse");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
@@ -456,9 +466,12 @@ int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float 
     const wdf::AdamTail adam{m ? theta : nullptr, m, v, step, lr, beta1, beta2, eps, lo, hi};
     const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    // two adjacent sequences per lane (8-byte row accesses, packed arithmetic) whenever the rows allow it
+    const bool pairs = !(flags & WDF_ONE_SEQUENCE_PER_LANE) && (B % 2 == 0) && aligned8(x) && aligned8(target) && aligned8(y) &&
+                       (!r || aligned8(r));
     WDF_DISPATCH4(launch_fused, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, target, 0.5f * gscale, skip, y,
                   z0, zT, fused_ws(ws, B, g.K), (wdf::TpStatus*)status, tol, B, T, g, W, warm, (flags & WDF_GENERAL_ROOT) ? 1 : 0,
-                  gtheta, accumulate, sse, adam, (hipStream_t)stream);
+                  pairs, gtheta, accumulate, sse, adam, (hipStream_t)stream);
     return check_launch("wdf_clipper_step_mse_tp");
 }
 

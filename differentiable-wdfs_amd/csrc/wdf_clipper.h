@@ -771,33 +771,38 @@ __device__ __forceinline__ bool tp_tile_last(unsigned* tickets)
 }
 
 // Verification of one tile by its last wave; returns (wave-uniform) whether a boundary of the tile failed.
-template <bool DYN_R>
+// NSEQ: adjacent sequences per lane (a tile is 64 NSEQ sequences).
+template <bool DYN_R, int NSEQ = 1>
 __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, const float* zwarm, const float* zend,
                                                TpStatus* __restrict__ status, TpCtl* __restrict__ ctl, int J,
                                                unsigned* tickets, float tol, int64_t B, int64_t L, int64_t W)
 {
     const int64_t K = gridDim.y;
     const unsigned ntiles = gridDim.x;
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t b_raw = ((int64_t)blockIdx.x * 64 + threadIdx.x) * NSEQ;
+    const int64_t b_first = b_raw < B ? b_raw : B - NSEQ;
     float miss = 0.0f;
     int nbad = 0;
     // 16 boundaries' 32 loads in flight together: one at a time this loop is K dependent round trips
     constexpr int kBatch = 16;
-    for (int64_t k0 = 1; k0 < K; k0 += kBatch) {
-        float zw[kBatch], ze[kBatch];
+#pragma unroll 1
+    for (int h = 0; h < NSEQ; ++h) {
+        const int64_t b = b_first + h;
+        for (int64_t k0 = 1; k0 < K; k0 += kBatch) {
+            float zw[kBatch], ze[kBatch];
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int64_t k = (k0 + j < K) ? k0 + j : K - 1;   // clamped: re-reads the last boundary
-            zw[j] = load_published(zwarm + k * B + b);
-            ze[j] = load_published(zend + (k - 1) * B + b);
-        }
+            for (int j = 0; j < kBatch; ++j) {
+                const int64_t k = (k0 + j < K) ? k0 + j : K - 1;   // clamped: re-reads the last boundary
+                zw[j] = load_published(zwarm + k * B + b);
+                ze[j] = load_published(zend + (k - 1) * B + b);
+            }
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const float m = fabsf(zw[j] - ze[j]);
-            if (k0 + j < K) {
-                miss = fmaxf(miss, m);
-                nbad += !(m <= tol) ? 1 : 0;                    // NaN counts as bad
+            for (int j = 0; j < kBatch; ++j) {
+                const float m = fabsf(zw[j] - ze[j]);
+                if (k0 + j < K) {
+                    miss = fmaxf(miss, m);
+                    nbad += !(m <= tol) ? 1 : 0;                    // NaN counts as bad
+                }
             }
         }
     }

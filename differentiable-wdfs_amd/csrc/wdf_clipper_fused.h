@@ -24,311 +24,429 @@
 // boundary is left to clipper_fused_repair_kernel, the next launch, which re-runs the failing chunks from
 // the exact state (outputs, record) and then does that tile's combine; whichever tile arrives last --
 // in either kernel -- finishes the step.
+//
+// TWO SEQUENCES PER LANE.  The kernel is bound by VALU issue (~88 instructions per sample-step against 12 bytes), and
+// a CDNA4 SIMD issues a packed v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two fp32 operations per lane) in the slot of
+// one plain instruction.  Written over the value type V (wdf_vec.h), with V = v2f a lane owns the ADJACENT sequences
+// 2l and 2l + 1: every add / mul / fma of the step packs (69 of the 109 instructions two sequences take, no register
+// shuffles: the pair lives in an aligned VGPR pair from its 8-byte load to its 8-byte store), transcendentals, compares
+// and selects stay per component.  54 issue slots per sample-step instead of 88.  Needs an even B; V = float is the
+// same code for odd batches and for A/B.
 #pragma once
 
 #include "wdf_clipper.h"
 
 namespace wdf {
 
+__device__ unsigned long long* g_dbg_times = nullptr;
 constexpr int kFsOut = 9;       // record floats per (chunk, sequence)
 constexpr int kFusedSchedGroup = 1;   // steps the instruction scheduler may interleave
+#ifndef WDF_FUSED_ROWS
+#define WDF_FUSED_ROWS 32
+#endif
+#ifndef WDF_FUSED_WAVES
+#define WDF_FUSED_WAVES 2
+#endif
+constexpr int kFusedRows = WDF_FUSED_ROWS;
 
-// Rows of the time-major arrays through buffer descriptors: `buffer_load_dword v, voff, s[rsrc], soff offen` takes the
-// row's byte offset from an SGPR and the lane's from one VGPR, so a tile of 32 rows costs no VALU instruction and no
+// Steps per load burst: the 32-step chunk-geometry tile with one sequence per lane and a static resistance, half of
+// it with two sequences per lane, half again with the per-sample resistance channel (the tile buffers are the bulk of
+// the VGPRs: x, target and r, current and next, and the kernel is held to two waves per SIMD).
+template <typename V, bool DYN_R> struct FusedTile { static constexpr int NR = kFusedRows / VT<V>::N / (DYN_R ? 2 : 1); };
+
+// hgs on the steps that carry loss, 0 on the first n_masked steps of a tile: two SALU instructions, written out because
+// the compiler otherwise forms the per-step mask on the VALU (v_cmp_lt_i64 + v_cndmask, 2 of the step's instructions).
+__device__ __forceinline__ float step_loss_scale(int i, int n_masked, float hgs)
+{
+    float hm;
+    asm("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, 0, %3" : "=s"(hm) : "s"(i), "s"(n_masked), "s"(hgs) : "scc");
+    return hm;
+}
+
+// The lane's sequences: N = VT<V>::N adjacent ones starting at b (B is a multiple of N: the C ABI picks V).
+// Lanes past the end shadow the last group (same values to the same addresses).
+template <typename V>
+struct LaneOwn {
+    static constexpr int N = VT<V>::N;
+    int64_t b;
+    uint32_t boff;           // b * 4: byte offset inside a [B] row (B < 2^24)
+    bool live;
+    __device__ __forceinline__ explicit LaneOwn(int64_t B)
+    {
+        const int64_t raw = ((int64_t)blockIdx.x * 64 + threadIdx.x) * N;
+        live = raw < B;
+        b = live ? raw : B - N;
+        boff = (uint32_t)b * 4u;
+    }
+};
+
+// Rows of the time-major arrays through buffer descriptors: `buffer_load_dword[x2] v, voff, s[rsrc], soff offen` takes
+// the row's byte offset from an SGPR and the lane's from one VGPR, so a tile of rows costs no VALU instruction and no
 // SGPR pair per row (with global_load / global_store the compiler either adds 64-bit addresses on the VALU or keeps 32
 // row pointers per stream in SGPRs, spills them to VGPR lanes and reads them back with v_readlane: ~7 of the step's
-// ~105 VALU instructions).  x, target and y share the 32 row offsets i * 4B.  The descriptor is rebuilt per tile from
+// ~105 VALU instructions).  x, target and y share the row offsets i * 4B.  The descriptor is rebuilt per tile from
 // a 64-bit scalar base; offsets inside a tile stay below 2^32 for B < 2^24 (checked by the C ABI).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* row0)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row0), 0, 0xffffffffu, 0x00020000);
 }
 
-template <int N>
-__device__ __forceinline__ void load_rows(const float* row0, uint32_t boff, uint32_t rowb, float (&v)[N])
-{
-    const __amdgpu_buffer_rsrc_t rs = row_rsrc(row0);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, boff, i * rowb, 0));
-}
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ void buf_load(float& v, __amdgpu_buffer_rsrc_t rs, uint32_t boff, uint32_t soff)
+{
+    v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, boff, soff, 0));
+}
+__device__ __forceinline__ void buf_load(v2f& v, __amdgpu_buffer_rsrc_t rs, uint32_t boff, uint32_t soff)
+{
+    v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, boff, soff, 0));
+}
 // aux 2: nt (streaming output, not read again by this kernel)
-__device__ __forceinline__ void store_row_nt(float v, __amdgpu_buffer_rsrc_t rs, uint32_t boff, uint32_t soff)
+__device__ __forceinline__ void buf_store_nt(float v, __amdgpu_buffer_rsrc_t rs, uint32_t boff, uint32_t soff)
 {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, boff, soff, 2);
 }
-
-// x tile: time-major through the descriptor, batch-major as 16-byte loads of the lane's own row
-template <bool TM, bool VEC4>
-__device__ __forceinline__ void load_x_tile(const float* __restrict__ x, const LaneSeqs<float>& q, int64_t B, int64_t T, int64_t t0,
-                                            uint32_t rowb, float (&v)[kTile])
+__device__ __forceinline__ void buf_store_nt(v2f v, __amdgpu_buffer_rsrc_t rs, uint32_t boff, uint32_t soff)
 {
-    if constexpr (TM) load_rows<kTile>(x + t0 * B, q.boff[0], rowb, v);
-    else load_row<kTile, VEC4>(x, q.b[0], T, t0, v);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), rs, boff, soff, 2);
 }
 
-// Tangent state of one sequence inside a chunk.  G* accumulate sum_n s[n] (hg_n + hg_{n-1}) (summation
+template <typename V, int NR>
+__device__ __forceinline__ void load_rows(const float* row0, uint32_t boff, uint32_t rowb, V (&v)[NR])
+{
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc(row0);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) buf_load(v[i], rs, boff, i * rowb);
+}
+
+// x tile: time-major through the descriptor, batch-major as 16-byte loads of each sequence's own row
+template <typename V, bool TM, bool VEC4, int NR>
+__device__ __forceinline__ void load_x_tile(const float* __restrict__ x, const LaneOwn<V>& q, int64_t B, int64_t T, int64_t t0,
+                                            uint32_t rowb, V (&v)[NR])
+{
+    if constexpr (TM) {
+        load_rows<V, NR>(x + t0 * B, q.boff, rowb, v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < VT<V>::N; ++j) {
+            float tmp[NR];
+            load_row<NR, VEC4>(x, q.b + j, T, t0, tmp);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) vset(v[i], j, tmp[i]);
+        }
+    }
+}
+
+// the lane's N adjacent elements of a [B] row (plain / published)
+template <typename V>
+__device__ __forceinline__ V load_own(const float* row, const LaneOwn<V>& q)
+{
+    V r = vsplat<V>(0.0f);
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) vset(r, j, row[q.b + j]);
+    return r;
+}
+template <typename V>
+__device__ __forceinline__ void store_own(float* row, const LaneOwn<V>& q, V v)
+{
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) row[q.b + j] = vget(v, j);
+}
+template <typename V>
+__device__ __forceinline__ void publish_own(float* row, const LaneOwn<V>& q, V v)
+{
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) __hip_atomic_store(row + q.b + j, vget(v, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one step's input of the lane's sequences (tail / masked tiles)
+template <typename V, bool TM>
+__device__ __forceinline__ V load_step(const float* __restrict__ x, const LaneOwn<V>& q, int64_t B, int64_t T, int64_t t)
+{
+    V r = vsplat<V>(0.0f);
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) vset(r, j, load_one<TM>(x, q.b + j, B, T, t));
+    return r;
+}
+
+__device__ __forceinline__ float vsel_nonzero(float a, float x, float y) { return a != 0.0f ? x : y; }
+__device__ __forceinline__ v2f vsel_nonzero(v2f a, float x, float y) { return v2f{a.x != 0.0f ? x : y, a.y != 0.0f ? x : y}; }
+
+// Tangent state of the lane's sequences inside a chunk.  G* accumulate sum_n s[n] (hg_n + hg_{n-1}) (summation
 // by parts of sum_n hg_n (s[n+1] + s[n]), hg = g/2): one FMA per statistic and step.
+template <typename V>
 struct FusedTan {
-    float A, cL, cV, cP;        // s_i = A sigma_i + c_i
-    float GA, GL, GV, GP;       // running sums since the last flush
-    float hg_prev;
-    float sse;                  // hgs x sum of squared errors
+    V A, cL, cV, cP;            // s_i = A sigma_i + c_i
+    V GA, GL, GV, GP;           // running sums since the last flush
+    V hg_prev;
+    V sse;                      // hgs x sum of squared errors
+    __device__ __forceinline__ void init()
+    {
+        A = vsplat<V>(1.0f);
+        cL = cV = cP = GA = GL = GV = GP = hg_prev = sse = vsplat<V>(0.0f);
+    }
+    __device__ __forceinline__ void pin()
+    {
+        vpin(A); vpin(cL); vpin(cV); vpin(cP); vpin(GA); vpin(GL); vpin(GV); vpin(GP); vpin(sse);
+    }
 };
 
 // One step: forward (the arithmetic of fwd_step, same expressions) + partials (those of bwd_tp_step) +
 // tangent update.  hgs = gscale / 2 (0 on masked steps).  Returns y.
-template <bool DYN_R, bool SYM, bool FAST>
-__device__ __forceinline__ float fused_step(const ClipConsts& c, float xin, float rin, float tgt, float hgs, float& z,
-                                            FusedTan& s)
+template <bool DYN_R, bool SYM, bool FAST, typename V>
+__device__ __forceinline__ V fused_step(const ClipConsts& c, V xin, V rin, V tgt, float hgs, V& z, FusedTan<V>& s)
 {
-    float p, Rp, L;
-    step_coeffs<DYN_R, float>(c, rin, p, Rp, L);
-    const float b_diff = z - xin;
-    const float b_temp = -p * b_diff;
-    const float a = z + b_temp;
-    const DiodeOut o = diode_pair<SYM, float, FAST>(a, L, c.d);
-    const float zn = o.b + b_temp;
-    const float y = 0.5f * (zn + z);
+    V p, Rp, L;
+    step_coeffs<DYN_R, V>(c, rin, p, Rp, L);
+    const V b_diff = z - xin;
+    const V b_temp = -p * b_diff;
+    const V a = z + b_temp;
+    const DiodeOutT<V> o = diode_pair<SYM, V, FAST>(a, L, c.d);
+    const V zn = o.b + b_temp;
+    const V y = 0.5f * (zn + z);
     // partials of the root (wdf_clipper.h, bwd_step / bwd_tp_step)
-    const float w0p = o.w0 * vrcp(o.w0 + 1.0f);
-    float Da, DL, DV;
+    const V w0p = o.w0 * vrcp(o.w0 + 1.0f);
+    V Da, DL, DV;
     if constexpr (SYM && FAST) {
         // omega_1 <= omega(-4) = 0.018 here (series-only region, checked once per kernel): omega/(1 + omega) by
-        // its alternating series to the cubic term (next term 1e-7 relative) instead of a quarter-rate reciprocal.
+        // its alternating series to the cubic term (next term 1e-7 relative) instead of a reciprocal.
         // lam X = copysign(X, a) for the two differences, both >= 0 because omega and omega' are increasing and
         // both exactly 0 at a = 0 where w0 == w1 bit for bit (diode_pair, FAST); lam^2 = (a != 0).
-        const float w1p = o.w1 * fmaf(-o.w1, fmaf(-o.w1, 1.0f - o.w1, 1.0f), 1.0f);
-        const float sp = w0p + w1p;
-        const float tl = (a != 0.0f) ? -2.0f : 0.0f;                // -2 lam^2
+        const V w1p = o.w1 * vfma(-o.w1, vfma(-o.w1, 1.0f - o.w1, 1.0f), 1.0f);
+        const V sp = w0p + w1p;
+        const V tl = vsel_nonzero(a, -2.0f, 0.0f);                  // -2 lam^2
         const float tvm = c.d.two_v * c.d.m_dn;
-        Da = fmaf(tl, sp, 1.0f);
+        Da = vfma(tl, sp, 1.0f);
         DL = (-tvm) * vcopysign(w0p - w1p, a);
-        DV = fmaf(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * vcopysign(o.w0 - o.w1, a));
+        DV = vfma(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * vcopysign(o.w0 - o.w1, a));
     } else {
-        const float w1p = o.w1 * vrcp(o.w1 + 1.0f);
-        const float l2 = o.lam * o.lam;
-        const float sp = w0p + w1p;
-        const float tl = -2.0f * l2;
-        Da = fmaf(tl, sp, 1.0f);
+        const V w1p = o.w1 * vrcp(o.w1 + 1.0f);
+        const V l2 = o.lam * o.lam;
+        const V sp = w0p + w1p;
+        const V tl = -2.0f * l2;
+        Da = vfma(tl, sp, 1.0f);
         if constexpr (SYM) {
             const float tvm = c.d.two_v * c.d.m_dn;
             DL = (-tvm) * (o.lam * (w0p - w1p));
-            DV = fmaf(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * (o.lam * (o.w0 - o.w1)));
+            DV = vfma(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * (o.lam * (o.w0 - o.w1)));
         } else {
             DL = (-c.d.two_v) * (o.lam * (o.m0 * w0p - o.m1 * w1p));
-            DV = fmaf(tl * a, sp * (-1.0f / c.V), -2.0f * (o.lam * (o.m0 * o.w0 - o.m1 * o.w1)));
+            DV = vfma(tl * a, sp * (-1.0f / c.V), -2.0f * (o.lam * (o.m0 * o.w0 - o.m1 * o.w1)));
         }
     }
-    const float opd = Da + 1.0f;
-    float cP = -opd * b_diff;
-    if constexpr (DYN_R) cP = Rp * fmaf(cP, p, DL);
-    const float kappa = fmaf(-p, opd, Da);
+    const V opd = Da + 1.0f;
+    V cP = -opd * b_diff;
+    if constexpr (DYN_R) cP = Rp * vfma(cP, p, DL);
+    const V kappa = vfma(-p, opd, Da);
     // loss and tangent
-    const float d = y - tgt;
-    const float hg = hgs * d;
-    s.sse = fmaf(hg, d, s.sse);                          // hgs x the squared error (0 on masked steps); no branch here:
+    const V d = y - tgt;
+    const V hg = hgs * d;
+    s.sse = vfma(hg, d, s.sse);                          // hgs x the squared error (0 on masked steps); no branch here:
                                                          // a block boundary per step lets LLVM sink every step's tangent
                                                          // work to the end of the tile (6 live values per step)
-    const float hh = hg + s.hg_prev;
+    const V hh = hg + s.hg_prev;
     s.hg_prev = hg;
-    s.GA = fmaf(hh, s.A, s.GA);
-    s.GL = fmaf(hh, s.cL, s.GL);
-    s.GV = fmaf(hh, s.cV, s.GV);
-    s.GP = fmaf(hh, s.cP, s.GP);
+    s.GA = vfma(hh, s.A, s.GA);
+    s.GL = vfma(hh, s.cL, s.GL);
+    s.GV = vfma(hh, s.cV, s.GV);
+    s.GP = vfma(hh, s.cP, s.GP);
     s.A = s.A * kappa;
-    s.cL = fmaf(kappa, s.cL, DL);
-    s.cV = fmaf(kappa, s.cV, DV);
-    s.cP = fmaf(kappa, s.cP, cP);
+    s.cL = vfma(kappa, s.cL, DL);
+    s.cV = vfma(kappa, s.cV, DV);
+    s.cP = vfma(kappa, s.cP, cP);
     z = zn;
     return y;
 }
 
-// fp64 totals of a chunk; the fp32 running sums are flushed into them every tile of steps
+// fp64 totals of a chunk, per sequence; the fp32 running sums are flushed into them every tile of steps
+template <typename V>
 struct FusedSums {
-    double GA, GL, GV, GP, sse;
-    __device__ __forceinline__ void flush(FusedTan& s)
+    static constexpr int N = VT<V>::N;
+    double GA[N], GL[N], GV[N], GP[N], sse[N];
+    __device__ __forceinline__ void init()
     {
-        GA += (double)s.GA; GL += (double)s.GL; GV += (double)s.GV; GP += (double)s.GP; sse += (double)s.sse;
-        s.GA = s.GL = s.GV = s.GP = s.sse = 0.0f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) GA[j] = GL[j] = GV[j] = GP[j] = sse[j] = 0.0;
+    }
+    __device__ __forceinline__ void flush(FusedTan<V>& s)
+    {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            GA[j] += (double)vget(s.GA, j); GL[j] += (double)vget(s.GL, j); GV[j] += (double)vget(s.GV, j);
+            GP[j] += (double)vget(s.GP, j); sse[j] += (double)vget(s.sse, j);
+        }
+        s.GA = s.GL = s.GV = s.GP = s.sse = vsplat<V>(0.0f);
     }
 };
 
 // the chunk's record (write-through: another wave of this launch reads it)
-__device__ __forceinline__ void fused_publish_record(float* rec, int64_t k, int64_t b, int64_t B, const FusedTan& s, FusedSums& d,
-                                                     float hgs)
+template <typename V>
+__device__ __forceinline__ void fused_publish_record(float* rec, int64_t k, int64_t b, int64_t B, const FusedTan<V>& s,
+                                                     const FusedSums<V>& d, float hgs)
 {
-    // the boundary term of the summation by parts: s[t1] hg_{t1-1}
-    const double h = (double)s.hg_prev;
-    const float v[kFsOut] = {s.A, s.cL, s.cV, s.cP, (float)(d.GA + h * s.A), (float)(d.GL + h * s.cL),
-                             (float)(d.GV + h * s.cV), (float)(d.GP + h * s.cP), hgs != 0.0f ? (float)(d.sse / (double)hgs) : 0.0f};
-    float* o = rec + (k * kFsOut) * B + b;
 #pragma unroll
-    for (int i = 0; i < kFsOut; ++i) __hip_atomic_store(o + i * B, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < VT<V>::N; ++j) {
+        // the boundary term of the summation by parts: s[t1] hg_{t1-1}
+        const double h = (double)vget(s.hg_prev, j);
+        const float A = vget(s.A, j), cL = vget(s.cL, j), cV = vget(s.cV, j), cP = vget(s.cP, j);
+        const float v[kFsOut] = {A, cL, cV, cP, (float)(d.GA[j] + h * A), (float)(d.GL[j] + h * cL), (float)(d.GV[j] + h * cV),
+                                 (float)(d.GP[j] + h * cP), hgs != 0.0f ? (float)(d.sse[j] / (double)hgs) : 0.0f};
+        float* o = rec + (k * kFsOut) * B + b + j;
+#pragma unroll
+        for (int i = 0; i < kFsOut; ++i) __hip_atomic_store(o + i * B, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Chunk geometry as clipper_fwd_tp_body (L, W multiples of kTile); target [T][B]; skip: steps below it carry no loss.
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool FAST>
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool FAST, typename V>
 __device__ __forceinline__ void clipper_fused_body(
     const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ target,
     float* __restrict__ y, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
     float* __restrict__ zend, float* rec, const float* __restrict__ theta, const TpCtl* __restrict__ ctl,
     float* __restrict__ snap, int J, int64_t B, int64_t T, int64_t L, int64_t W, float hgs, int64_t skip)
 {
-    using V = float;
-    const LaneSeqs<V> q(B, B);
+    constexpr int NR = FusedTile<V, DYN_R>::NR;
+    const LaneOwn<V> q(B);
     const int64_t k = blockIdx.y, K = gridDim.y;
     const int64_t t0 = k * L;
     const int64_t t1 = (t0 + L < T) ? t0 + L : T;
     int64_t tw = 0;
-    float z = 0.0f;
+    V z = vsplat<V>(0.0f);
     const bool stateful = ctl != nullptr && ctl->geom == (int)((K << 8) | J);
     const int valid = stateful ? ctl->valid : 0;
     const int head = stateful ? ctl->head : 0;
     if (k > 0 && valid > 0) {                               // warm start (see clipper_fwd_tp_body)
         const int j = ctl->j_next;
         tw = t0 - (int64_t)kTile * j;
-        const float* __restrict__ s1 = snap + (((int64_t)head * J + j) * K + (k - 1)) * B;
-        z = s1[q.b[0]];
+        z = load_own<V>(snap + (((int64_t)head * J + j) * K + (k - 1)) * B, q);
         if (valid > 1) {
-            const float* __restrict__ s2 = snap + (((int64_t)((head + kTpRing - 1) % kTpRing) * J + j) * K + (k - 1)) * B;
-            const float zo = s2[q.b[0]];
-            z = fmaf(tp_secant_factor(theta, ctl), z - zo, z);
+            const V zo = load_own<V>(snap + (((int64_t)((head + kTpRing - 1) % kTpRing) * J + j) * K + (k - 1)) * B, q);
+            z = vfma(vsplat<V>(tp_secant_factor(theta, ctl)), z - zo, z);
         }
     } else {
         tw = (t0 > W) ? t0 - W : 0;
-        if (tw == 0 && z0) z = z0[q.b[0]];
+        if (tw == 0 && z0) z = load_own<V>(z0, q);
     }
     float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)((head + 1) % kTpRing) * J * K + k) * B : nullptr;
 
     const uint32_t rowb = (uint32_t)B * 4u;
-    const uint32_t boff = q.boff[0];
-    float xc[kTile], xn[kTile], rc[kTile], rn[kTile], gc[kTile], gn[kTile];
+    const uint32_t boff = q.boff;
+    V xc[NR], xn[NR], rc[NR], rn[NR], gc[NR], gn[NR];
 #pragma unroll
-    for (int i = 0; i < kTile; ++i) { xc[i] = xn[i] = gc[i] = gn[i] = 0.0f; rc[i] = rn[i] = 1.0f; }
-    const int64_t nfull_end = t1 - (t1 - tw) % kTile;
+    for (int i = 0; i < NR; ++i) { xc[i] = xn[i] = gc[i] = gn[i] = vsplat<V>(0.0f); rc[i] = rn[i] = vsplat<V>(1.0f); }
+    const int64_t nfull_end = t1 - (t1 - tw) % NR;
     if (tw < nfull_end) {
-        load_x_tile<TM, VEC4>(x, q, B, T, tw, rowb, xn);
-        if constexpr (DYN_R) load_x_tile<TM, VEC4>(r, q, B, T, tw, rowb, rn);
-        if (tw >= t0) load_rows<kTile>(target + tw * B, boff, rowb, gn);
+        load_x_tile<V, TM, VEC4, NR>(x, q, B, T, tw, rowb, xn);
+        if constexpr (DYN_R) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, tw, rowb, rn);
+        if (tw >= t0) load_rows<V, NR>(target + tw * B, boff, rowb, gn);
     }
     int64_t t = tw;
-    for (; t < t0 && t < nfull_end; t += kTile) {           // ---- warm-up tiles: forward only, nothing stored
+    for (; t < t0 && t < nfull_end; t += NR) {              // ---- warm-up tiles: forward only, nothing stored
 #pragma unroll
-        for (int i = 0; i < kTile; ++i) { xc[i] = xn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
-        if (t + kTile < nfull_end) {
-            load_x_tile<TM, VEC4>(x, q, B, T, t + kTile, rowb, xn);
-            if constexpr (DYN_R) load_x_tile<TM, VEC4>(r, q, B, T, t + kTile, rowb, rn);
-            if (t + kTile >= t0) load_rows<kTile>(target + (t + kTile) * B, boff, rowb, gn);   // the first owned tile's target
+        for (int i = 0; i < NR; ++i) { xc[i] = xn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
+        if (t + NR < nfull_end) {
+            load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
+            if constexpr (DYN_R) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, t + NR, rowb, rn);
+            if (t + NR >= t0) load_rows<V, NR>(target + (t + NR) * B, boff, rowb, gn);   // the first owned tile's target
         }
 #pragma unroll
-        for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, xc[i], rc[i], z);
+        for (int i = 0; i < NR; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, xc[i], rc[i], z);
     }
-    publish_v<V>(zwarm, q, k * B, z);
-    FusedTan s = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    FusedSums d = {0.0, 0.0, 0.0, 0.0, 0.0};
-    for (; t < nfull_end; t += kTile) {                     // ---- owned tiles
+    publish_own<V>(zwarm + k * B, q, z);
+    FusedTan<V> s;
+    s.init();
+    FusedSums<V> d;
+    d.init();
+    for (; t < nfull_end; t += NR) {                        // ---- owned tiles
 #pragma unroll
-        for (int i = 0; i < kTile; ++i) { xc[i] = xn[i]; gc[i] = gn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
-        const bool more = t + kTile < nfull_end;
-        if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1))
-            store_v<V>(snapw, q, ((t1 - t) / kTile) * K * B, z);
+        for (int i = 0; i < NR; ++i) { xc[i] = xn[i]; gc[i] = gn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
+        const bool more = t + NR < nfull_end;
+        if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1) && (t1 - t) % kTile == 0)
+            store_own<V>(snapw + ((t1 - t) / kTile) * K * B, q, z);       // snapshot 32 j steps before the chunk's end
         const __amdgpu_buffer_rsrc_t ry = row_rsrc(y + t * B);
-        if (t < skip) {
-            // A tile with steps below `skip` (they carry no loss): at most two per sequence (skip_samples = 50,
-            // clipper_pot.py:232), so it runs as a compact loop of single steps with its own loads, and the unrolled
-            // path below needs no per-step mask.  The next tile's prefetch is issued first, as on that path.
-            if (more) {
-                load_x_tile<TM, VEC4>(x, q, B, T, t + kTile, rowb, xn);
-                if constexpr (DYN_R) load_x_tile<TM, VEC4>(r, q, B, T, t + kTile, rowb, rn);
-                load_rows<kTile>(target + (t + kTile) * B, boff, rowb, gn);
-            }
-#pragma unroll 1
-            for (int i = 0; i < kTile; ++i) {
-                const int64_t tt = t + i;
-                const float xin = load_one<TM>(x, q.b[0], B, T, tt);
-                const float rin = DYN_R ? load_one<TM>(r, q.b[0], B, T, tt) : 1.0f;
-                const float tg = target[tt * B + q.b[0]];
-                y[tt * B + q.b[0]] = fused_step<DYN_R, SYM, FAST>(c, xin, rin, tg, tt >= skip ? hgs : 0.0f, z, s);
-            }
-            d.flush(s);
-            continue;
-        }
+        // steps of this tile below `skip` carry no loss (skip_samples = 50, clipper_pot.py:232): their number, a scalar
+        const int64_t below = skip - t;
+        const int n_masked = __builtin_amdgcn_readfirstlane((int)(below < 0 ? 0 : (below > NR ? NR : below)));
 #pragma unroll
-        for (int i = 0; i < kTile; ++i) {
-            if (i == kTile / 2) {                           // prefetch in the middle of the tile (vmcnt, see the forward)
+        for (int i = 0; i < NR; ++i) {
+            if (i == NR / 2) {                              // prefetch in the middle of the tile (vmcnt, see the forward)
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
-                    load_x_tile<TM, VEC4>(x, q, B, T, t + kTile, rowb, xn);
-                    if constexpr (DYN_R) load_x_tile<TM, VEC4>(r, q, B, T, t + kTile, rowb, rn);
-                    load_rows<kTile>(target + (t + kTile) * B, boff, rowb, gn);
+                    load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
+                    if constexpr (DYN_R) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, t + NR, rowb, rn);
+                    load_rows<V, NR>(target + (t + NR) * B, boff, rowb, gn);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            store_row_nt(fused_step<DYN_R, SYM, FAST>(c, xc[i], rc[i], gc[i], hgs, z, s), ry, boff, i * rowb);
+            buf_store_nt(fused_step<DYN_R, SYM, FAST, V>(c, xc[i], rc[i], gc[i], step_loss_scale(i, n_masked, hgs), z, s), ry, boff,
+                         i * rowb);
             // The tangent updates do not feed the next step's state, so left alone instruction selection
             // emits the z chain of the whole tile first and keeps every step's partials alive (200 VGPRs,
             // spills).  Pinning the tangent state (a chained, empty asm) before the scheduling barrier keeps
             // each group of steps' work inside the group.
             if (i % kFusedSchedGroup == kFusedSchedGroup - 1) {
-                vpin(s.A); vpin(s.cL); vpin(s.cV); vpin(s.cP); vpin(s.GA); vpin(s.GL); vpin(s.GV); vpin(s.GP); vpin(s.sse);
+                s.pin();
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         d.flush(s);
     }
-    for (int64_t tt = nfull_end; tt < t1; ++tt) {           // tail of the last chunk (T % 32)
-        const float xin = load_one<TM>(x, q.b[0], B, T, tt);
-        const float rin = DYN_R ? load_one<TM>(r, q.b[0], B, T, tt) : 1.0f;
-        const float tg = target[tt * B + q.b[0]];
-        y[tt * B + q.b[0]] = fused_step<DYN_R, SYM, FAST>(c, xin, rin, tg, tt >= skip ? hgs : 0.0f, z, s);
+    for (int64_t tt = nfull_end; tt < t1; ++tt) {           // tail of the last chunk (T % NR)
+        const V xin = load_step<V, TM>(x, q, B, T, tt);
+        const V rin = DYN_R ? load_step<V, TM>(r, q, B, T, tt) : vsplat<V>(1.0f);
+        const V tg = load_own<V>(target + tt * B, q);
+        store_own<V>(y + tt * B, q, fused_step<DYN_R, SYM, FAST, V>(c, xin, rin, tg, tt >= skip ? hgs : 0.0f, z, s));
     }
     d.flush(s);
-    publish_v<V>(zend, q, k * B, z);
-    if (snapw != nullptr) store_v<V>(snapw, q, 0, z);
-    if (zT && t1 == T) store_v<V>(zT, q, 0, z);
-    fused_publish_record(rec, k, q.b[0], B, s, d, hgs);
+    publish_own<V>(zend + k * B, q, z);
+    if (snapw != nullptr) store_own<V>(snapw, q, z);
+    if (zT && t1 == T) store_own<V>(zT, q, z);
+    fused_publish_record<V>(rec, k, q.b, B, s, d, hgs);
 }
 
-// The tile's K records in time order -> the tile's sums -> (last tile) the step's result.
+// The tile's K records in time order -> the tile's sums -> (last tile) the step's result.  NSEQ: sequences per lane.
+template <int NSEQ>
 __device__ __forceinline__ void fused_combine_tile(const float* rec, int64_t K, int64_t B, double* ws, unsigned* gticket,
                                                    const float* theta, float fs, int dyn_r, float* gtheta, int accumulate,
                                                    float* __restrict__ sse_out, const AdamTail& adam, double (*sh)[4])
 {
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool live = b_raw < B;
-    const int64_t b = live ? b_raw : B - 1;
-    double sL = 0.0, sV = 0.0, sP = 0.0;                  // tangent entering the chunk (z0 does not depend on theta)
+    const int64_t raw = ((int64_t)blockIdx.x * 64 + threadIdx.x) * NSEQ;
+    const bool live = raw < B;
+    const int64_t b0 = live ? raw : B - NSEQ;
     double dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0;
-    int64_t k = 0;
-    for (; k + 8 <= K; k += 8) {                          // 8 chunks' 72 loads in flight together
-        float v[8][kFsOut];
+#pragma unroll 1
+    for (int h = 0; h < NSEQ; ++h) {
+        const int64_t b = b0 + h;
+        double sL = 0.0, sV = 0.0, sP = 0.0;              // tangent entering the chunk (z0 does not depend on theta)
+        int64_t k = 0;
+        for (; k + 8 <= K; k += 8) {                      // 8 chunks' 72 loads in flight together
+            float v[8][kFsOut];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int i = 0; i < kFsOut; ++i) v[j][i] = load_published(rec + ((k + j) * kFsOut + i) * B + b);
+                for (int i = 0; i < kFsOut; ++i) v[j][i] = load_published(rec + ((k + j) * kFsOut + i) * B + b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double A = v[j][0], GA = v[j][4];
-            dL += sL * GA + (double)v[j][5];
-            dV += sV * GA + (double)v[j][6];
-            dP += sP * GA + (double)v[j][7];
-            dS += (double)v[j][8];
-            sL = A * sL + (double)v[j][1];
-            sV = A * sV + (double)v[j][2];
-            sP = A * sP + (double)v[j][3];
+            for (int j = 0; j < 8; ++j) {
+                const double A = v[j][0], GA = v[j][4];
+                dL += sL * GA + (double)v[j][5];
+                dV += sV * GA + (double)v[j][6];
+                dP += sP * GA + (double)v[j][7];
+                dS += (double)v[j][8];
+                sL = A * sL + (double)v[j][1];
+                sV = A * sV + (double)v[j][2];
+                sP = A * sP + (double)v[j][3];
+            }
         }
-    }
-    for (; k < K; ++k) {
-        const float* o = rec + (k * kFsOut) * B + b;
-        const double A = load_published(o), GA = load_published(o + 4 * B);
-        dL += sL * GA + (double)load_published(o + 5 * B);
-        dV += sV * GA + (double)load_published(o + 6 * B);
-        dP += sP * GA + (double)load_published(o + 7 * B);
-        dS += (double)load_published(o + 8 * B);
-        sL = A * sL + (double)load_published(o + 1 * B);
-        sV = A * sV + (double)load_published(o + 2 * B);
-        sP = A * sP + (double)load_published(o + 3 * B);
+        for (; k < K; ++k) {
+            const float* o = rec + (k * kFsOut) * B + b;
+            const double A = load_published(o), GA = load_published(o + 4 * B);
+            dL += sL * GA + (double)load_published(o + 5 * B);
+            dV += sV * GA + (double)load_published(o + 6 * B);
+            dP += sP * GA + (double)load_published(o + 7 * B);
+            dS += (double)load_published(o + 8 * B);
+            sL = A * sL + (double)load_published(o + 1 * B);
+            sV = A * sV + (double)load_published(o + 2 * B);
+            sP = A * sP + (double)load_published(o + 3 * B);
+        }
     }
     if (!live) { dL = dV = dP = dS = 0.0; }
     tile_partial_and_finish(dL, dV, dP, dS, ws, gticket, theta, fs, dyn_r, gtheta, accumulate, sse_out, adam, sh);
@@ -336,8 +454,9 @@ __device__ __forceinline__ void fused_combine_tile(const float* rec, int64_t K, 
 
 // tickets: the forward's verification area [TpAcc][per-tile tickets][per-tile repair flags];
 // gticket: [tiles combined, 0, 0, 0] -- both zero before the first launch and left zero by every step.
-template <bool DYN_R, bool SYM, bool TM, bool VEC4>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void clipper_fused_tp_kernel(
+// A tile is the 64 * VT<V>::N sequences of one wave.
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, typename V>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WAVES, WDF_FUSED_WAVES))) void clipper_fused_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, const float* __restrict__ z0,
     float* __restrict__ zT, float* zwarm, float* zend, float* rec, TpStatus* __restrict__ status, TpCtl* ctl, float* snap,
@@ -345,32 +464,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double* ws, float* gtheta, int accumulate, float* __restrict__ sse_out, AdamTail adam)
 {
     __shared__ double sh[64][4];
+    const unsigned long long dbg_t0 = wall_clock64();
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
     if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
     if (fast)
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B, T,
-                                                         L, W, hgs, skip);
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R, V>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
+                                                            T, L, W, hgs, skip);
     else
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, false>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B, T,
-                                                        L, W, hgs, skip);
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
+                                                           T, L, W, hgs, skip);
+    if (threadIdx.x == 0 && g_dbg_times) {
+        unsigned long long* o = g_dbg_times + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        o[0] = dbg_t0; o[1] = wall_clock64();
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        o[2] = hw; o[3] = __builtin_amdgcn_s_memtime();
+    }
     if (!tp_tile_last(tickets)) return;
     // the warm-start control block is advanced (by the last tile to verify) BEFORE that tile takes its combine
     // ticket, hence before the step's last ticket and the Adam update behind it: it records this call's theta
-    const bool failed = tp_verify_tile<DYN_R>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
+    const bool failed = tp_verify_tile<DYN_R, VT<V>::N>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
     if (failed) return;                                     // left to clipper_fused_repair_kernel
-    fused_combine_tile(rec, gridDim.y, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);
+    fused_combine_tile<VT<V>::N>(rec, gridDim.y, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);
 }
 
-// Re-run of chunk [t0, t1) for this wave's 64 sequences from the exact state z: outputs, snapshots, record.
+// Re-run of chunk [t0, t1) for 64 sequences (one per lane, index b) from the exact state z: outputs, snapshots, record.
 template <bool DYN_R, bool SYM, bool TM, bool FAST>
 __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r,
                                                   const float* __restrict__ target, float* __restrict__ y, float* rec,
                                                   float* __restrict__ snapw, int J, int64_t K, int64_t k, int64_t b, int64_t B,
                                                   int64_t T, int64_t t0, int64_t t1, float hgs, int64_t skip, float& z)
 {
-    FusedTan s = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    FusedSums d = {0.0, 0.0, 0.0, 0.0, 0.0};
+    FusedTan<float> s;
+    s.init();
+    FusedSums<float> d;
+    d.init();
     for (int64_t t = t0; t < t1; t += kBlk) {
         if ((t - t0) % kTile == 0) {
             d.flush(s);
@@ -388,18 +516,19 @@ __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const flo
 #pragma unroll
         for (int i = 0; i < kBlk; ++i) {
             if (t + i < t1)                                      // wave-uniform
-                y[(t + i) * B + b] = fused_step<DYN_R, SYM, FAST>(c, xv[i], rv[i], gv[i], (t + i >= skip) ? hgs : 0.0f, z, s);
+                y[(t + i) * B + b] = fused_step<DYN_R, SYM, FAST, float>(c, xv[i], rv[i], gv[i], (t + i >= skip) ? hgs : 0.0f, z, s);
         }
     }
     d.flush(s);
     if (snapw != nullptr) snapw[b] = z;
-    fused_publish_record(rec, k, b, B, s, d, hgs);
+    fused_publish_record<float>(rec, k, b, B, s, d, hgs);
 }
 
 // Launched behind every fused step; a block leaves at once unless the step flagged its tile (the common
-// case).  For a flagged tile: walk the chunk boundaries in time order, re-run every chunk one of whose
-// 64 sequences arrived more than tol off (from the exact state), then combine the tile.
-template <bool DYN_R, bool SYM, bool TM>
+// case).  For a flagged tile (64 NSEQ sequences; each of its NSEQ interleaved sets of 64 in turn): walk the chunk
+// boundaries in time order, re-run every chunk one of whose sequences arrived more than tol off (from the exact
+// state, one sequence per lane), then combine the tile.
+template <bool DYN_R, bool SYM, bool TM, int NSEQ>
 __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, float* __restrict__ zT,
@@ -410,37 +539,41 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
     __shared__ double sh[64][4];
     unsigned* tile_bad = tickets + 4 + gridDim.x;
     if (tile_bad[blockIdx.x] == 0u) return;
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t raw = ((int64_t)blockIdx.x * 64 + threadIdx.x) * NSEQ;
+    const int64_t b0 = raw < B ? raw : B - NSEQ;
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
     if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
     const int slot = (ctl != nullptr && snap != nullptr) ? ctl->head : 0;     // the step advanced head to the slot it wrote
     int nrep = 0;
-    bool fixed_prev = false;
-    float ze_fix = 0.0f;
-    for (int64_t k = 1; k < K; ++k) {
-        const float e = fixed_prev ? ze_fix : load_published(zend + (k - 1) * B + b);
-        const float m = fabsf(load_published(zwarm + k * B + b) - e);
-        fixed_prev = false;
-        if (__builtin_amdgcn_ballot_w64(!(m <= tol)) == 0) continue;
-        const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
-        float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
-        float z = e;
-        if (fast) fused_rerun_chunk<DYN_R, SYM, TM, !DYN_R>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
-        else fused_rerun_chunk<DYN_R, SYM, TM, false>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
-        zend[k * B + b] = z;
-        if (zT && t1 == T) zT[b] = z;
-        ze_fix = z;
-        fixed_prev = true;
-        ++nrep;
+#pragma unroll 1
+    for (int h = 0; h < NSEQ; ++h) {
+        const int64_t b = b0 + h;
+        bool fixed_prev = false;
+        float ze_fix = 0.0f;
+        for (int64_t k = 1; k < K; ++k) {
+            const float e = fixed_prev ? ze_fix : load_published(zend + (k - 1) * B + b);
+            const float m = fabsf(load_published(zwarm + k * B + b) - e);
+            fixed_prev = false;
+            if (__builtin_amdgcn_ballot_w64(!(m <= tol)) == 0) continue;
+            const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+            float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
+            float z = e;
+            if (fast) fused_rerun_chunk<DYN_R, SYM, TM, !DYN_R>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
+            else fused_rerun_chunk<DYN_R, SYM, TM, false>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
+            zend[k * B + b] = z;
+            if (zT && t1 == T) zT[b] = z;
+            ze_fix = z;
+            fixed_prev = true;
+            ++nrep;
+        }
     }
     if (threadIdx.x == 0) {
         tile_bad[blockIdx.x] = 0u;
         if (nrep) atomicAdd(&status->fallback_ran, nrep);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the re-written records have landed (write-through)
-    fused_combine_tile(rec, K, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);
+    fused_combine_tile<NSEQ>(rec, K, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);
 }
 
 }  // namespace wdf

@@ -19,10 +19,14 @@ WDF_X_TIME_MAJOR = 1 << 0
 WDF_PREC_F64 = 1 << 1
 WDF_GENERAL_ROOT = 1 << 3
 WDF_MLP_LANE_PER_SEQUENCE = 1 << 4
+WDF_ONE_SEQUENCE_PER_LANE = 1 << 5
 
 # Set True to run the one-lane-per-sequence MLP kernels (csrc/wdf_mlp.h) instead of the default
 # 16-lane row per sequence (csrc/wdf_mlp_row.h): parity tests and A/B timing.
 MLP_LANE_PER_SEQUENCE = False
+
+# Set True to run the one-pass step with one sequence per lane even for even batches (WDF_ONE_SEQUENCE_PER_LANE)
+ONE_SEQUENCE_PER_LANE = os.environ.get("WDF_ONE_SEQUENCE_PER_LANE", "") not in ("", "0")     # (env: A/B runs of bench.py)
 
 # Set True to make every clipper call take the general per-step root evaluation (WDF_GENERAL_ROOT):
 # parity tests compare it with the default path, tools time one against the other on the same box.
@@ -419,7 +423,8 @@ def clipper_step_mse_tp(x, theta, fs, target, gscale, n_chunks, warmup, tol=1e-6
         1 if accumulate else 0, *((None,) * 4 if o is None else (_ptr(o.m), _ptr(o.v), _ptr(o.step), _ptr(o.lr))),
         0.0 if o is None else o.b1, 0.0 if o is None else o.b2, 0.0 if o is None else o.eps,
         None if o is None else _ptr(o.lo), None if o is None else _ptr(o.hi),
-        (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag(), _stream())
+        (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag() | (WDF_ONE_SEQUENCE_PER_LANE if ONE_SEQUENCE_PER_LANE else 0),
+        _stream())
     _check(rc, "wdf_clipper_step_mse_tp")
     return y, zT, gtheta, sse, status
 

@@ -48,10 +48,13 @@ enum {
                                   reference of config C5; every other entry point answers WDF_EUNSUPPORTED */
     WDF_MLP_LANE_PER_SEQUENCE = 1 << 4, /* MLP-root kernels: the one-lane-per-sequence variant (csrc/wdf_mlp.h)
                                   instead of the default 16-lane row per sequence (csrc/wdf_mlp_row.h) */
-    WDF_GENERAL_ROOT = 1 << 3  /* always take the general per-step root evaluation (the kernels otherwise
+    WDF_GENERAL_ROOT = 1 << 3, /* always take the general per-step root evaluation (the kernels otherwise
                                   switch, once per launch, to a shorter step when the static port
                                   resistance keeps omega_1 in its series-only region); for parity tests
                                   and A/B timing -- results agree to fp32 rounding */
+    WDF_ONE_SEQUENCE_PER_LANE = 1 << 5 /* wdf_clipper_step_mse_tp: one sequence per lane even when the batch is even
+                                  (by default a lane then runs two adjacent sequences with packed fp32
+                                  arithmetic); for parity tests and A/B timing */
 };
 
 /* ------------------------------------------------------------------------------------

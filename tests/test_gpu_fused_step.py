@@ -2,7 +2,7 @@
 two-kernel step gives -- the forward's y and the reverse sweep's gradient -- and what the fp64 oracle gives.
 
 The gradient is carried forward in time (tangent of the state) instead of swept backward: same sums, other
-order.  Covered: chunk counts incl. 1, ragged B and T, asymmetric diode counts, the per-sample resistance
+order.  Both forms of the kernel run every test: two adjacent sequences per lane with packed arithmetic, and one.  Covered: chunk counts incl. 1, ragged B and T, asymmetric diode counts, the per-sample resistance
 channel, both x layouts, loss masks (skip), an initial state, the warm-started loop, the repair path (a
 parameter jump and a circuit whose memory outlasts the warm-up), the Adam update folded into the launch,
 and the bench shape against the oracle.
@@ -23,6 +23,15 @@ def wb():
     from wdf_hip import binding
     binding.require_gpu()
     return binding
+
+
+@pytest.fixture(autouse=True, params=["two sequences per lane", "one sequence per lane"])
+def lanes(request, wb):
+    """Every test runs both forms of the kernel: a lane owning two adjacent sequences with packed fp32 arithmetic (the
+    default for an even batch) and one sequence per lane (odd batches; forced here with WDF_ONE_SEQUENCE_PER_LANE)."""
+    wb.ONE_SEQUENCE_PER_LANE = request.param.startswith("one")
+    yield request.param
+    wb.ONE_SEQUENCE_PER_LANE = False
 
 
 def dev(a):
@@ -52,7 +61,7 @@ def close_grad(g, g_ref, rtol=G_RTOL):
 
 
 @pytest.mark.parametrize("B,T,K,W", [(64, 512, 1, 0), (64, 2048, 4, 256), (70, 1001, 3, 248), (130, 4096, 16, 256),
-                                     (5, 96, 1, 0), (1, 2048, 4, 256), (3, 40, 1, 0)])
+                                     (5, 96, 1, 0), (1, 2048, 4, 256), (3, 40, 1, 0), (2, 64, 2, 32), (258, 1000, 2, 256)])
 @pytest.mark.parametrize("n_up,n_down", [(1, 1), (2, 3)])
 def test_fused_matches_two_kernel_step(wb, B, T, K, W, n_up, n_down):
     x, th, ths = problem(B, T, seed=B + T)
@@ -161,7 +170,7 @@ def test_fused_repairs_when_warmup_is_too_short(wb):
     y_ref, g_ref, sse_ref = two_kernel_step(wb, xd, thd, tgt, gscale)
     y, _, g, sse, st = wb.clipper_step_mse_tp(xd, thd, FS, tgt, gscale, K, 64)
     s = wb.tp_status(st)
-    assert s["n_bad"] > 0 and s["repaired_tiles"] == 2 * 7, s
+    assert s["n_bad"] > 0 and s["repaired_tiles"] == 2 * 7, s     # 7 boundaries x (2 waves | 2 interleaved halves of one wave)
     assert float((y - y_ref).abs().max()) <= Y_TOL
     ok, info = close_grad(g, g_ref, rtol=5e-5)
     assert ok, info

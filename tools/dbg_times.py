@@ -1,0 +1,45 @@
+import os, sys, ctypes as C
+sys.path.insert(0, "differentiable-wdfs_amd/lib")
+import numpy as np, torch
+from wdf_hip import binding, engine, workload
+one = len(sys.argv) > 1 and sys.argv[1] == "one"
+binding.ONE_SEQUENCE_PER_LANE = one
+B, T, fs, K = 8192, 4096, workload.FS, 16
+dev = torch.device("cuda", 0)
+x = torch.as_tensor(workload.sweep_batch(B, T), device=dev); xt = x.t().contiguous()
+th_host = workload.clipper_theta()
+tgt, _, _ = binding.clipper_fwd(x, torch.tensor(workload.target_theta(), dtype=torch.float32, device=dev), fs, want_stash=False)
+st = engine.MseStep(B, T, fs, engine.TpPlan(K, 160, 1e-6, 32), dev, time_major=True, warm=True)
+theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
+adam = binding.Adam(4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
+nw = (B // (64 if one else 128)) * K
+buf = torch.zeros(4 * nw, dtype=torch.int64, device=dev)
+L = binding.lib(); L.wdf_debug_set_times.argtypes = [C.c_void_p]
+for _ in range(6): st.step_fused(theta, xt, tgt, adam=adam)
+assert L.wdf_debug_set_times(buf.data_ptr()) == 0
+e0, e1 = binding.Event(), binding.Event()
+binding.Event.bracket_next(e0, e1)
+st.step_fused(theta, xt, tgt, adam=adam)
+torch.cuda.synchronize()
+ms = e0.elapsed_ms(e1)
+L.wdf_debug_set_times(None)
+a = buf.cpu().numpy().reshape(nw, 4)
+t0, t1 = a[:, 0].astype(np.float64), a[:, 1].astype(np.float64)
+base = t0.min()
+tick = 1e-2   # wall_clock64: 100 MHz -> 10 ns = 0.01 us
+print(f"kernel (events) {ms*1e3:.1f} us; waves {nw}")
+print(f"start: min 0, median {np.median(t0-base)*tick:.1f} us, p90 {np.percentile(t0-base,90)*tick:.1f}, max {(t0.max()-base)*tick:.1f} us")
+print(f"end:   min {(t1.min()-base)*tick:.1f}, median {np.median(t1-base)*tick:.1f}, p90 {np.percentile(t1-base,90)*tick:.1f}, max {(t1.max()-base)*tick:.1f} us")
+life = (t1 - t0) * tick
+print(f"lifetime: min {life.min():.1f} median {np.median(life):.1f} p90 {np.percentile(life,90):.1f} max {life.max():.1f} us")
+hw = a[:, 2]
+# HW_ID: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ...
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; se = (hw >> 13) & 7; xcc = (hw >> 16) & 0xf
+key = (((hw >> 4) & 0xfffff))
+import collections
+cnt = collections.Counter(zip(xcc.tolist(), se.tolist(), cu.tolist(), simd.tolist()))
+print("distinct SIMDs used:", len(cnt), "waves per SIMD histogram:", collections.Counter(cnt.values()))
+k = np.arange(nw) // (nw // K)
+for kk in (0, 1, K // 2, K - 1):
+    m = k == kk
+    print(f"chunk {kk}: start median {np.median(t0[m]-base)*tick:.1f} end median {np.median(t1[m]-base)*tick:.1f} life median {np.median(life[m]):.1f}")

@@ -31,10 +31,16 @@ def timed(fn, reps=20):
     return ts[len(ts) // 2], ts[0]
 
 
-for tm in (True, False):
+KS = [int(v) for v in os.environ.get("FUSED_K", "4,8,16,32,64").split(",")]
+MODES = {"tm2": (True, False), "tm1": (True, True), "bm2": (False, False), "bm1": (False, True)}
+for tm, one in [MODES[m] for m in os.environ.get("FUSED_MODES", "tm2,tm1,bm2").split(",")]:
     xk = xt if tm else x
-    for K in (4, 8, 16, 32):
+    binding.ONE_SEQUENCE_PER_LANE = one
+    print(f"--- x {'time' if tm else 'batch'}-major, {'one sequence' if one else 'two sequences'} per lane", flush=True)
+    for K in KS:
         for warm in (False, True):
+            if K >= 43 and not warm:
+                continue
             plan = engine.TpPlan(K, 160, 1e-6, 32)
             st = engine.MseStep(B, T, fs, plan, dev, time_major=tm, warm=warm)
             theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
