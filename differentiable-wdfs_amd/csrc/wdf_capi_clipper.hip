@@ -200,7 +200,9 @@ void launch_fused(const float* x, const float* r, const float* theta, float fs, 
 }  // namespace
 
 extern "C" {
+#ifdef WDF_DBG_TIMES
 int wdf_debug_set_times(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(wdf::g_dbg_times), &p, sizeof(p)); }
+#endif
 
 int wdf_clipper_fwd(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,
                     float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int flags, void* stream)

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "wdf_omega.h"
+#include "wdf_optim.h"
 
 namespace wdf {
 
@@ -819,10 +820,11 @@ __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, 
     // coherence point, so the tile count (issued after the wait) cannot overtake them.
     TpAcc* acc = reinterpret_cast<TpAcc*>(tickets);             // 64-byte aligned (the 8-byte atomic needs 8)
     unsigned* tile_bad = tickets + 4 + ntiles;
-    int seen = 0;
-    if (wmax > 0.0f) seen += atomicMax(&acc->max_miss_bits, __float_as_int(wmax));
+    // The maximum and the tile count live in one 16-byte struct, i.e. one cache line and one L2 channel: this lane's two
+    // atomics reach that channel's atomic unit in issue order, so the count (returning, awaited) cannot be performed
+    // before the maximum and the tile that sees the last count reads a complete maximum -- without a second round trip.
+    if (wmax > 0.0f) (void)atomicMax(&acc->max_miss_bits, __float_as_int(wmax));
     if (wbad) tile_bad[blockIdx.x] = 1u;
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) : : "memory");
     // one 64-bit add carries the tile count (low word) and this tile's bad pairs (high word)
     const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&acc->tiles_done),
                                               1ull | ((unsigned long long)(unsigned)wbad << 32));
@@ -1070,7 +1072,7 @@ __device__ __forceinline__ void tile_partial_and_finish(double dL, double dV, do
         __syncthreads();
         if (i == 0) *adam.step = t;
         if (i < 4) {
-            const double c1 = 1.0 - pow((double)adam.b1, (double)t), c2 = 1.0 - pow((double)adam.b2, (double)t);
+            const double c1 = 1.0 - ipow((double)adam.b1, t), c2 = 1.0 - ipow((double)adam.b2, t);     // (on the step's critical path)
             const float g = gtheta[i];
             const float mi = adam.b1 * adam.m[i] + (1.0f - adam.b1) * g;
             const float vi = adam.b2 * adam.v[i] + (1.0f - adam.b2) * g * g;

@@ -38,12 +38,18 @@
 
 namespace wdf {
 
+#ifdef WDF_DBG_TIMES      // tools/dbg_times.py: per-wave start / end wall clock of the main body (build with -DWDF_DBG_TIMES)
 __device__ unsigned long long* g_dbg_times = nullptr;
+#endif
 constexpr int kFsOut = 9;       // record floats per (chunk, sequence)
 constexpr int kFusedSchedGroup = 1;   // steps the instruction scheduler may interleave
 #ifndef WDF_FUSED_ROWS
-#define WDF_FUSED_ROWS 32
+#define WDF_FUSED_ROWS 16
 #endif
+#ifndef WDF_FUSED_PREFETCH_AT
+#define WDF_FUSED_PREFETCH_AT 0     // 0: top of the tile, 1: middle
+#endif
+constexpr int kFusedPrefetchAt = WDF_FUSED_PREFETCH_AT;
 #ifndef WDF_FUSED_WAVES
 #define WDF_FUSED_WAVES 2
 #endif
@@ -53,6 +59,14 @@ constexpr int kFusedRows = WDF_FUSED_ROWS;
 // it with two sequences per lane, half again with the per-sample resistance channel (the tile buffers are the bulk of
 // the VGPRs: x, target and r, current and next, and the kernel is held to two waves per SIMD).
 template <typename V, bool DYN_R> struct FusedTile { static constexpr int NR = kFusedRows / VT<V>::N / (DYN_R ? 2 : 1); };
+
+// s_waitcnt vmcnt(N) (gfx9 encoding: vmcnt in bits 3:0 and 15:14; expcnt / lgkmcnt fields at "no wait").
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | 0x0F70);
+}
 
 // hgs on the steps that carry loss, 0 on the first n_masked steps of a tile: two SALU instructions, written out because
 // the compiler otherwise forms the per-step mask on the VALU (v_cmp_lt_i64 + v_cndmask, 2 of the step's instructions).
@@ -352,6 +366,7 @@ __device__ __forceinline__ void clipper_fused_body(
         for (int i = 0; i < NR; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, xc[i], rc[i], z);
     }
     publish_own<V>(zwarm + k * B, q, z);
+    wait_vmcnt<0>();                                        // (the first owned tile's loads: see the wait on the back edge below)
     FusedTan<V> s;
     s.init();
     FusedSums<V> d;
@@ -368,7 +383,10 @@ __device__ __forceinline__ void clipper_fused_body(
         const int n_masked = __builtin_amdgcn_readfirstlane((int)(below < 0 ? 0 : (below > NR ? NR : below)));
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            if (i == NR / 2) {                              // prefetch in the middle of the tile (vmcnt, see the forward)
+            if (i == kFusedPrefetchAt * NR / 2) {
+                // The next tile's loads go out at the TOP of this tile, a whole tile before their first use (vmcnt is one
+                // in-order counter for loads and stores: issued later they would sit behind this tile's first stores).
+                // With 16-row tiles a tile's loads + stores (48) stay inside the counter's 6 bits.
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
                     load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
@@ -388,6 +406,11 @@ __device__ __forceinline__ void clipper_fused_body(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // Everything but this tile's NR stores has returned -- in particular the next tile's loads, issued NR steps ago.
+        // Said here, on the loop's back edge: left to the compiler, the wait sits at the loop header, where it must also
+        // hold for the path from the warm-up loop (no stores behind the loads) and so becomes vmcnt(1): every tile would
+        // start by draining the previous tile's stores (measured: 12 % of the waves' cycles parked in s_waitcnt).
+        wait_vmcnt<NR>();
         d.flush(s);
     }
     for (int64_t tt = nfull_end; tt < t1; ++tt) {           // tail of the last chunk (T % NR)
@@ -464,7 +487,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     double* ws, float* gtheta, int accumulate, float* __restrict__ sse_out, AdamTail adam)
 {
     __shared__ double sh[64][4];
+#ifdef WDF_DBG_TIMES
     const unsigned long long dbg_t0 = wall_clock64();
+    const unsigned long long dbg_m0 = __builtin_amdgcn_s_memtime();
+#endif
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
     if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
@@ -474,15 +500,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     else
         clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
                                                            T, L, W, hgs, skip);
+#ifdef WDF_DBG_TIMES
     if (threadIdx.x == 0 && g_dbg_times) {
-        unsigned long long* o = g_dbg_times + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-        o[0] = dbg_t0; o[1] = wall_clock64();
-        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        o[2] = hw; o[3] = __builtin_amdgcn_s_memtime();
+        unsigned long long* dbg_o = g_dbg_times + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        dbg_o[0] = dbg_t0; dbg_o[1] = wall_clock64(); dbg_o[2] = 0; dbg_o[3] = __builtin_amdgcn_s_memtime() - dbg_m0;
     }
+#endif
     if (!tp_tile_last(tickets)) return;
-    // the warm-start control block is advanced (by the last tile to verify) BEFORE that tile takes its combine
-    // ticket, hence before the step's last ticket and the Adam update behind it: it records this call's theta
     const bool failed = tp_verify_tile<DYN_R, VT<V>::N>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
     if (failed) return;                                     // left to clipper_fused_repair_kernel
     fused_combine_tile<VT<V>::N>(rec, gridDim.y, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);

@@ -15,6 +15,17 @@
 
 namespace wdf {
 
+// b^t for a step count t >= 0 by repeated squaring: a few fp64 multiplies instead of pow()'s hundreds of instructions
+__device__ __forceinline__ double ipow(double b, int t)
+{
+    double r = 1.0;
+    for (unsigned n = (unsigned)t; n != 0u; n >>= 1) {
+        if (n & 1u) r *= b;
+        b *= b;
+    }
+    return r;
+}
+
 // One thread per parameter; `step` is the shared iteration counter (read by all, bumped by thread 0
 // after a barrier -- n <= 1024, one block).
 static __global__ __launch_bounds__(1024) void adam_clip_kernel(float* __restrict__ theta, const float* __restrict__ grad,
@@ -28,7 +39,7 @@ static __global__ __launch_bounds__(1024) void adam_clip_kernel(float* __restric
     __syncthreads();
     if (i == 0) *step = t;
     if (i >= n) return;
-    const double c1 = 1.0 - pow((double)b1, (double)t), c2 = 1.0 - pow((double)b2, (double)t);
+    const double c1 = 1.0 - ipow((double)b1, t), c2 = 1.0 - ipow((double)b2, t);
     const float g = grad[i];
     const float mi = b1 * m[i] + (1.0f - b1) * g;
     const float vi = b2 * v[i] + (1.0f - b2) * g * g;

@@ -4,7 +4,7 @@ import numpy as np, torch
 from wdf_hip import binding, engine, workload
 one = len(sys.argv) > 1 and sys.argv[1] == "one"
 binding.ONE_SEQUENCE_PER_LANE = one
-B, T, fs, K = 8192, 4096, workload.FS, 16
+B, T, fs, K = 8192, 4096, workload.FS, int(os.environ.get("DBG_K", "16"))
 dev = torch.device("cuda", 0)
 x = torch.as_tensor(workload.sweep_batch(B, T), device=dev); xt = x.t().contiguous()
 th_host = workload.clipper_theta()
@@ -32,6 +32,17 @@ print(f"start: min 0, median {np.median(t0-base)*tick:.1f} us, p90 {np.percentil
 print(f"end:   min {(t1.min()-base)*tick:.1f}, median {np.median(t1-base)*tick:.1f}, p90 {np.percentile(t1-base,90)*tick:.1f}, max {(t1.max()-base)*tick:.1f} us")
 life = (t1 - t0) * tick
 print(f"lifetime: min {life.min():.1f} median {np.median(life):.1f} p90 {np.percentile(life,90):.1f} max {life.max():.1f} us")
+mt = a[:, 3].astype(np.float64)
+print(f"s_memtime ticks per wall-clock us over the wave's life: median {np.median(mt / ((t1 - t0) * tick)):.1f} (= MHz if s_memtime is the shader clock)")
+k = np.arange(nw) // (nw // K)
+print("chunk: end median us:", " ".join(f"{kk}:{np.median(t1[k == kk]-base)*tick:.0f}" for kk in range(K)))
+sys.exit(0)
+t2, t3 = a[:, 2].astype(np.float64), a[:, 3].astype(np.float64)
+last = t2 > 0
+print(f"tile-last waves: {last.sum()}; verify took median {np.median((t2-t1)[last])*tick:.2f} us max {((t2-t1)[last]).max()*tick:.2f}; "
+      f"combine+finish median {np.median((t3-t2)[last & (t3>0)])*tick:.2f} max {((t3-t2)[last & (t3>0)]).max()*tick:.2f} us; "
+      f"last body end {(t1.max()-base)*tick:.1f} us, last finish end {(t3.max()-base)*tick:.1f} us")
+sys.exit(0)
 hw = a[:, 2]
 # HW_ID: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ...
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; se = (hw >> 13) & 7; xcc = (hw >> 16) & 0xf
