@@ -319,6 +319,10 @@ __device__ __forceinline__ void clipper_fused_body(
     float* __restrict__ snap, int J, int64_t B, int64_t T, int64_t L, int64_t W, float hgs, int64_t skip)
 {
     constexpr int NR = FusedTile<V, DYN_R>::NR;
+#ifdef WDF_DBG_TIMES
+    unsigned long long dbg_p[5];
+    dbg_p[0] = __builtin_amdgcn_s_memtime();
+#endif
     const LaneOwn<V> q(B);
     const int64_t k = blockIdx.y, K = gridDim.y;
     const int64_t t0 = k * L;
@@ -354,6 +358,9 @@ __device__ __forceinline__ void clipper_fused_body(
         if (tw >= t0) load_rows<V, NR>(target + tw * B, boff, rowb, gn);
     }
     int64_t t = tw;
+#ifdef WDF_DBG_TIMES
+    dbg_p[1] = __builtin_amdgcn_s_memtime();
+#endif
     for (; t < t0 && t < nfull_end; t += NR) {              // ---- warm-up tiles: forward only, nothing stored
 #pragma unroll
         for (int i = 0; i < NR; ++i) { xc[i] = xn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
@@ -365,12 +372,21 @@ __device__ __forceinline__ void clipper_fused_body(
 #pragma unroll
         for (int i = 0; i < NR; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, xc[i], rc[i], z);
     }
+#ifdef WDF_DBG_TIMES
+    dbg_p[2] = __builtin_amdgcn_s_memtime();
+#endif
     publish_own<V>(zwarm + k * B, q, z);
-    wait_vmcnt<0>();                                        // (the first owned tile's loads: see the wait on the back edge below)
+    wait_vmcnt<0>();
+#ifdef WDF_DBG_TIMES
+    dbg_p[3] = __builtin_amdgcn_s_memtime();
+#endif                                        // (the first owned tile's loads: see the wait on the back edge below)
     FusedTan<V> s;
     s.init();
     FusedSums<V> d;
     d.init();
+#ifdef WDF_DBG_TIMES
+    unsigned long long dbg_wait = 0;
+#endif
     for (; t < nfull_end; t += NR) {                        // ---- owned tiles
 #pragma unroll
         for (int i = 0; i < NR; ++i) { xc[i] = xn[i]; gc[i] = gn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
@@ -410,7 +426,11 @@ __device__ __forceinline__ void clipper_fused_body(
         // Said here, on the loop's back edge: left to the compiler, the wait sits at the loop header, where it must also
         // hold for the path from the warm-up loop (no stores behind the loads) and so becomes vmcnt(1): every tile would
         // start by draining the previous tile's stores (measured: 12 % of the waves' cycles parked in s_waitcnt).
+#ifdef WDF_DBG_TIMES
+        { const unsigned long long w0 = __builtin_amdgcn_s_memtime(); wait_vmcnt<NR>(); dbg_wait += __builtin_amdgcn_s_memtime() - w0; }
+#else
         wait_vmcnt<NR>();
+#endif
         d.flush(s);
     }
     for (int64_t tt = nfull_end; tt < t1; ++tt) {           // tail of the last chunk (T % NR)
@@ -424,6 +444,14 @@ __device__ __forceinline__ void clipper_fused_body(
     if (snapw != nullptr) store_own<V>(snapw, q, z);
     if (zT && t1 == T) store_own<V>(zT, q, z);
     fused_publish_record<V>(rec, k, q.b, B, s, d, hgs);
+#ifdef WDF_DBG_TIMES
+    dbg_p[4] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && g_dbg_times) {
+        unsigned long long* o = g_dbg_times + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        o[2] = dbg_wait;
+        o[4] = dbg_p[1] - dbg_p[0]; o[5] = dbg_p[2] - dbg_p[1]; o[6] = dbg_p[3] - dbg_p[2]; o[7] = dbg_p[4] - dbg_p[3];
+    }
+#endif
 }
 
 // The tile's K records in time order -> the tile's sums -> (last tile) the step's result.  NSEQ: sequences per lane.
@@ -502,8 +530,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
                                                            T, L, W, hgs, skip);
 #ifdef WDF_DBG_TIMES
     if (threadIdx.x == 0 && g_dbg_times) {
-        unsigned long long* dbg_o = g_dbg_times + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-        dbg_o[0] = dbg_t0; dbg_o[1] = wall_clock64(); dbg_o[2] = 0; dbg_o[3] = __builtin_amdgcn_s_memtime() - dbg_m0;
+        unsigned long long* dbg_o = g_dbg_times + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        dbg_o[0] = dbg_t0; dbg_o[1] = wall_clock64(); dbg_o[3] = __builtin_amdgcn_s_memtime() - dbg_m0;
     }
 #endif
     if (!tp_tile_last(tickets)) return;

@@ -13,7 +13,7 @@ st = engine.MseStep(B, T, fs, engine.TpPlan(K, 160, 1e-6, 32), dev, time_major=T
 theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
 adam = binding.Adam(4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
 nw = (B // (64 if one else 128)) * K
-buf = torch.zeros(4 * nw, dtype=torch.int64, device=dev)
+buf = torch.zeros(8 * nw, dtype=torch.int64, device=dev)
 L = binding.lib(); L.wdf_debug_set_times.argtypes = [C.c_void_p]
 for _ in range(6): st.step_fused(theta, xt, tgt, adam=adam)
 assert L.wdf_debug_set_times(buf.data_ptr()) == 0
@@ -23,7 +23,7 @@ st.step_fused(theta, xt, tgt, adam=adam)
 torch.cuda.synchronize()
 ms = e0.elapsed_ms(e1)
 L.wdf_debug_set_times(None)
-a = buf.cpu().numpy().reshape(nw, 4)
+a = buf.cpu().numpy().reshape(nw, 8)
 t0, t1 = a[:, 0].astype(np.float64), a[:, 1].astype(np.float64)
 base = t0.min()
 tick = 1e-2   # wall_clock64: 100 MHz -> 10 ns = 0.01 us
@@ -34,6 +34,11 @@ life = (t1 - t0) * tick
 print(f"lifetime: min {life.min():.1f} median {np.median(life):.1f} p90 {np.percentile(life,90):.1f} max {life.max():.1f} us")
 mt = a[:, 3].astype(np.float64)
 print(f"s_memtime ticks per wall-clock us over the wave's life: median {np.median(mt / ((t1 - t0) * tick)):.1f} (= MHz if s_memtime is the shader clock)")
+ph = a[:, 4:8].astype(np.float64) / 2100.0
+print("phases (us at 2.1 GHz), median / p90: set-up + first loads issued %.1f / %.1f; warm-up loop %.1f / %.1f; publish + drain %.1f / %.1f; owned loop + record %.1f / %.1f" % tuple(
+    v for i in range(4) for v in (np.median(ph[:, i]), np.percentile(ph[:, i], 90))))
+wt = a[:, 2].astype(np.float64)
+print(f"shader cycles parked in the back-edge s_waitcnt per wave: median {np.median(wt):.0f} of {np.median(mt):.0f} ({100*np.median(wt/mt):.1f} %)")
 k = np.arange(nw) // (nw // K)
 print("chunk: end median us:", " ".join(f"{kk}:{np.median(t1[k == kk]-base)*tick:.0f}" for kk in range(K)))
 sys.exit(0)
