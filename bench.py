@@ -9,7 +9,7 @@ B x T samples (y written), MSE against synthetic targets, the gradient dL/d{Is, 
 one RCCL all-reduce of the fused [loss, grads] buffer, and the on-device Adam update.  By default forward,
 loss and gradient run as ONE pass over the data (wdf_clipper_step_mse_tp: the gradient is carried forward in
 time as the state's tangent, no state stash); --two-kernel runs the forward kernel + reverse-sweep kernel
-pair instead (the only form for --loss mse+esr).
+pair instead.  --loss mse+esr (the scripts' training loss past 50 samples) takes the same one-pass form.
 Workload = BASELINE.json configs[2]: 1N4148 diode clipper fwd+bwd, batch 8192 sequences x 4096
 samples @ 48 kHz per GPU ("scaling": "weak": every rank holds its own 8192-sequence shard of the
 global batch; --scaling strong splits ONE 8192-sequence batch over the ranks instead).
@@ -161,7 +161,7 @@ class Trainer:
         if tp is not None and args.plan:
             kf, w, kb = (int(v) for v in args.plan.split(","))
             tp = tp._replace(k_fwd=kf, warmup=w, k_bwd=kb)
-        self.fused = args.loss == "mse" and not args.two_kernel
+        self.fused = not args.two_kernel
         if tp is not None and args.plan:
             pass
         elif tp is not None and self.fused:     # part of the untimed set-up: pick the chunk count on this box
@@ -186,8 +186,9 @@ class Trainer:
         # [SSE, grads] (no-op on 1 GPU unless --force-dist)
         # timed: events bracket exactly the recurrence kernel(s) (what rocprofv3 lists under that name)
         st, ev, args = self.stepper, self.ev, self.args
-        # one rank and plain MSE: the update rides in the step's own last waves; otherwise all-reduce, then update
-        fold = self.adam is not None and self.world == 1 and args.loss == "mse" and not args.force_dist
+        # one rank: the update rides in the step's own last waves (one-pass step: either loss; kernel pair: plain MSE);
+        # otherwise all-reduce, then update
+        fold = self.adam is not None and self.world == 1 and not args.force_dist and (self.fused or args.loss == "mse")
         if self.fused:
             if timed:
                 binding.Event.bracket_next(ev[0], ev[1])
@@ -200,7 +201,8 @@ class Trainer:
                 binding.Event.bracket_next(ev[2], ev[3])
             st.backward(self.theta, self.xk, self.target, adam=self.adam if fold else None)
         buf = st.out                                   # [SSE, grads]: the kernels wrote it in place
-        wdist.allreduce_sum_(buf)
+        if not (self.fused and args.loss == "mse+esr"):   # (the one-pass MSE + ESR step all-reduces its ten sums itself)
+            wdist.allreduce_sum_(buf)
         if self.adam is not None:
             if self.first_sse is None:
                 self.first_sse = buf[0:1].clone()          # SSE of the very first step, for the report
@@ -354,8 +356,9 @@ def main():
                     help="world size 1 only: create a one-rank RCCL (nccl) process group and run the fused-buffer "
                          "all-reduce + separate Adam launch of the N > 1 path, so that branch executes on a one-GPU box")
     ap.add_argument("--loss", default="mse", choices=["mse", "mse+esr"],
-                    help="mse: the metric's loss (default). mse+esr: clipper_pot.py's training loss past 50 samples, "
-                         "fused the same way (one extra streaming pass for the two loss sums)")
+                    help="mse: the metric's loss (default). mse+esr: clipper_pot.py's training loss past 50 samples "
+                         "(one-pass step: both tangent-weighted sums in the same pass; --two-kernel: one extra streaming "
+                         "pass for the two loss sums)")
     ap.add_argument("--plan", default=None, metavar="KF,W,KB",
                     help="pin the time-parallel plan (forward chunks, cold warm-up steps, reverse chunks) instead of "
                          "autotuning it; used to profile one configuration across several rocprofv3 passes")

@@ -151,20 +151,23 @@ inline size_t bwd_ticket_bytes(int64_t B) { return (((size_t)((B + 63) / 64) + 4
 // ---- the one-pass training step (wdf_clipper_fused.h) --------------------------------------------
 struct FusedWs { double* part; float* zwarm; float* zend; float* rec; unsigned* tickets; unsigned* gticket; };
 
-inline size_t fused_body_bytes(int64_t B, int K)
+// [tiles][8] doubles (MSE uses 4 of them), zwarm / zend [K][B], records [K][nrec][B], then the ticket words
+inline size_t fused_part_bytes(int64_t B) { return (size_t)((B + 63) / 64) * 8 * sizeof(double); }
+
+inline size_t fused_body_bytes(int64_t B, int K, int nrec)
 {
-    const size_t body = wdf_clipper_bwd_ws_bytes(B) + (size_t)(2 + wdf::kFsOut) * (size_t)K * (size_t)B * sizeof(float);
+    const size_t body = fused_part_bytes(B) + (size_t)(2 + nrec) * (size_t)K * (size_t)B * sizeof(float);
     return (body + 63) / 64 * 64;
 }
 
-inline FusedWs fused_ws(void* ws, int64_t B, int K)
+inline FusedWs fused_ws(void* ws, int64_t B, int K, int nrec)
 {
     FusedWs w;
     w.part = (double*)ws;
-    w.zwarm = (float*)((char*)ws + wdf_clipper_bwd_ws_bytes(B));
+    w.zwarm = (float*)((char*)ws + fused_part_bytes(B));
     w.zend = w.zwarm + (size_t)K * (size_t)B;
     w.rec = w.zend + (size_t)K * (size_t)B;
-    w.tickets = (unsigned*)((char*)ws + fused_body_bytes(B, K));
+    w.tickets = (unsigned*)((char*)ws + fused_body_bytes(B, K, nrec));
     w.gticket = (unsigned*)((char*)w.tickets + tp_ticket_bytes(B));
     return w;
 }
@@ -172,29 +175,42 @@ inline FusedWs fused_ws(void* ws, int64_t B, int K)
 template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_fused(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, const float* target,
                   float hgs, int64_t skip, float* y, const float* z0, float* zT, FusedWs w, wdf::TpStatus* status, float tol,
-                  int64_t B, int64_t T, TpGeom g, int64_t W, TpWarm warm, int general, bool pairs, float* gtheta, int accumulate,
-                  float* sse, wdf::AdamTail adam, hipStream_t s)
+                  int64_t B, int64_t T, TpGeom g, int64_t W, TpWarm warm, int general, bool pairs, bool esr, wdf::FusedOut out,
+                  hipStream_t s)
 {
     // pairs: two adjacent sequences per lane, packed fp32 arithmetic (wdf_clipper_fused.h); a tile is then 128 sequences
     const int per_tile = pairs ? 128 : 64;
     const dim3 grid((unsigned)((B + per_tile - 1) / per_tile), (unsigned)g.K);
-#define WDF_FUSED(V_)                                                                                                            \
-    hipLaunchKernelGGL((wdf::clipper_fused_tp_kernel<DYN_R, SYM, TM, V4, V_>), grid, dim3(64), 0, s, x, r, theta, fs, n_up, n_down, \
-                       target, hgs, skip, y, z0, zT, w.zwarm, w.zend, w.rec, status, warm.ctl, warm.snap, warm.J, w.tickets,    \
-                       w.gticket, tol, B, T, g.L, W, general, w.part, gtheta, accumulate, sse, adam)
-#define WDF_FUSED_REPAIR(N_)                                                                                                     \
-    hipLaunchKernelGGL((wdf::clipper_fused_repair_kernel<DYN_R, SYM, TM, N_>), dim3(grid.x), dim3(64), 0, s, x, r, theta, fs, n_up, \
-                       n_down, target, hgs, skip, y, zT, w.zwarm, w.zend, w.rec, B, T, (int64_t)g.K, g.L, tol, status, warm.ctl, \
-                       warm.snap, warm.J, w.tickets, w.gticket, general, w.part, gtheta, accumulate, sse, adam)
+#define WDF_FUSED(V_, LOSS_)                                                                                                     \
+    hipLaunchKernelGGL((wdf::clipper_fused_tp_kernel<DYN_R, SYM, TM, V4, V_, LOSS_>), grid, dim3(64), 0, s, x, r, theta, fs, n_up, \
+                       n_down, target, hgs, skip, y, z0, zT, w.zwarm, w.zend, w.rec, status, warm.ctl, warm.snap, warm.J,        \
+                       w.tickets, w.gticket, tol, B, T, g.L, W, general, w.part, out)
+#define WDF_FUSED_REPAIR(N_, LOSS_)                                                                                              \
+    hipLaunchKernelGGL((wdf::clipper_fused_repair_kernel<DYN_R, SYM, TM, N_, LOSS_>), dim3(grid.x), dim3(64), 0, s, x, r, theta, fs, \
+                       n_up, n_down, target, hgs, skip, y, zT, w.zwarm, w.zend, w.rec, B, T, (int64_t)g.K, g.L, tol, status,     \
+                       warm.ctl, warm.snap, warm.J, w.tickets, w.gticket, general, w.part, out)
     {
         EventBracket bracket(s);
-        if (pairs) WDF_FUSED(wdf::v2f); else WDF_FUSED(float);
+        if (esr) { if (pairs) WDF_FUSED(wdf::v2f, 2); else WDF_FUSED(float, 2); }
+        else { if (pairs) WDF_FUSED(wdf::v2f, 1); else WDF_FUSED(float, 1); }
     }
     if (g.K > 1) {                              // blocks of unflagged tiles (normally all of them) leave at once
-        if (pairs) WDF_FUSED_REPAIR(2); else WDF_FUSED_REPAIR(1);
+        if (esr) { if (pairs) WDF_FUSED_REPAIR(2, 2); else WDF_FUSED_REPAIR(1, 2); }
+        else { if (pairs) WDF_FUSED_REPAIR(2, 1); else WDF_FUSED_REPAIR(1, 1); }
     }
 #undef WDF_FUSED
 #undef WDF_FUSED_REPAIR
+}
+
+// the finish of the MSE + ESR step after the ranks' sums10 have been all-reduced (esr_tile_partial_and_finish's last lines)
+__global__ void esr_finish_kernel(const float* __restrict__ sums10, double n, double eps, float* __restrict__ gtheta,
+                                  float* __restrict__ loss3)
+{
+    const double S = sums10[0], E = (double)sums10[1] + eps;
+    const double mse = S / n, esr = sqrt(S / E / n);
+    const double ga = 2.0 / n + (esr > 0.0 ? 1.0 / (esr * E * n) : 0.0), gb = -esr / E;
+    for (int k = 0; k < 4; ++k) gtheta[k] = (float)(ga * (double)sums10[2 + k] + gb * (double)sums10[6 + k]);
+    if (loss3) { loss3[0] = (float)mse; loss3[1] = (float)esr; loss3[2] = (float)(mse + esr); }
 }
 
 }  // namespace
@@ -424,33 +440,31 @@ int wdf_clipper_bwd_esr_tp(const float* x, const float* r, const float* theta, f
 size_t wdf_clipper_step_mse_tp_ws_bytes(int64_t B, int n_chunks)
 {
     if (B <= 0 || n_chunks <= 0) return 0;
-    return fused_body_bytes(B, n_chunks) + tp_ticket_bytes(B) + 64;
+    return fused_body_bytes(B, n_chunks, wdf::kFsOutEsr) + tp_ticket_bytes(B) + 64;      // (sized for either loss)
 }
 
 int wdf_clipper_step_mse_tp_ws_init(void* ws, int64_t B, int n_chunks, void* stream)
 {
     if (!ws || B <= 0 || n_chunks <= 0) return fail(WDF_EINVAL, "null ws / bad B, n_chunks");
-    const hipError_t e = hipMemsetAsync((char*)ws + fused_body_bytes(B, n_chunks), 0, tp_ticket_bytes(B) + 64, (hipStream_t)stream);
+    // both record sizes put their ticket words inside the allocation: clear from the smaller layout's tickets to the end
+    const size_t from = fused_body_bytes(B, n_chunks, wdf::kFsOut), total = wdf_clipper_step_mse_tp_ws_bytes(B, n_chunks);
+    const hipError_t e = hipMemsetAsync((char*)ws + from, 0, total - from, (hipStream_t)stream);
     return e == hipSuccess ? WDF_OK : fail(WDF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
 }
 
-int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float fs, int n_up, int n_down,
-                            const float* target, float gscale, int64_t skip, float* y, const float* z0, float* zT,
-                            int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws, void* status, void* state,
-                            int max_warm_tiles, float* gtheta, float* sse, int accumulate, float* m, float* v, int32_t* step,
-                            const float* lr, float beta1, float beta2, float eps, const float* lo, const float* hi, int flags,
-                            void* stream)
+static int step_tp_common(const float* x, const float* r, float* theta, float fs, int n_up, int n_down, const float* target,
+                          float hgs, int64_t skip, float* y, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks,
+                          int warmup, float tol, void* ws, void* status, void* state, int max_warm_tiles, bool esr,
+                          wdf::FusedOut out, int flags, void* stream, const char* what)
 {
     int rc = check_common(x, theta, n_up, n_down, B, T, flags & ~WDF_ONE_SEQUENCE_PER_LANE);
     if (rc) return rc;
-    if (!target || !y || !ws || !status || !gtheta || !sse) return fail(WDF_EINVAL, "null target/y/ws/status/gtheta/sse");
+    if (!target || !y || !ws || !status) return fail(WDF_EINVAL, "null target/y/ws/status");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
     if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
     if (skip < 0 || skip > T) return fail(WDF_EINVAL, "skip must be in 0..T");
-    if (B >= ((int64_t)1 << 30)) return fail(WDF_EINVAL, "time-parallel kernels address a [B] row with 32-bit byte offsets: B < 2^30");
-    if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 applies to wdf_clipper_fwd and wdf_omega_f64 only");
     if (B >= ((int64_t)1 << 24)) return fail(WDF_EINVAL, "the one-pass step addresses a 32-row tile with 32-bit offsets: B < 2^24");
-    if (m && (!v || !step || !lr)) return fail(WDF_EINVAL, "Adam update asked for (m) but v/step/lr missing");
+    if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 applies to wdf_clipper_fwd and wdf_omega_f64 only");
     const TpGeom g = tp_geom(T, n_chunks);
     if (g.K != n_chunks) return fail(WDF_EINVAL, "n_chunks = %d does not tile T = %lld in 32-step units: use wdf_clipper_tp_chunks (%d)",
                                      n_chunks, (long long)T, g.K);
@@ -465,16 +479,53 @@ int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float 
         // same layout as wdf_clipper_fwd_tp_warm's state: [TpCtl][its ticket area, unused here][snapshot ring]
         warm = TpWarm{(wdf::TpCtl*)state, (float*)((char*)state + sizeof(wdf::TpCtl) + tp_ticket_bytes(B)), max_warm_tiles + 1};
     }
-    const wdf::AdamTail adam{m ? theta : nullptr, m, v, step, lr, beta1, beta2, eps, lo, hi};
     const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     // two adjacent sequences per lane (8-byte row accesses, packed arithmetic) whenever the rows allow it
     const bool pairs = !(flags & WDF_ONE_SEQUENCE_PER_LANE) && (B % 2 == 0) && aligned8(x) && aligned8(target) && aligned8(y) &&
                        (!r || aligned8(r));
-    WDF_DISPATCH4(launch_fused, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, target, 0.5f * gscale, skip, y,
-                  z0, zT, fused_ws(ws, B, g.K), (wdf::TpStatus*)status, tol, B, T, g, W, warm, (flags & WDF_GENERAL_ROOT) ? 1 : 0,
-                  pairs, gtheta, accumulate, sse, adam, (hipStream_t)stream);
-    return check_launch("wdf_clipper_step_mse_tp");
+    WDF_DISPATCH4(launch_fused, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, target, hgs, skip, y, z0, zT,
+                  fused_ws(ws, B, g.K, esr ? wdf::kFsOutEsr : wdf::kFsOut), (wdf::TpStatus*)status, tol, B, T, g, W, warm,
+                  (flags & WDF_GENERAL_ROOT) ? 1 : 0, pairs, esr, out, (hipStream_t)stream);
+    return check_launch(what);
+}
+
+int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float fs, int n_up, int n_down,
+                            const float* target, float gscale, int64_t skip, float* y, const float* z0, float* zT,
+                            int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws, void* status, void* state,
+                            int max_warm_tiles, float* gtheta, float* sse, int accumulate, float* m, float* v, int32_t* step,
+                            const float* lr, float beta1, float beta2, float eps, const float* lo, const float* hi, int flags,
+                            void* stream)
+{
+    if (!gtheta || !sse) return fail(WDF_EINVAL, "null gtheta/sse");
+    if (m && (!v || !step || !lr)) return fail(WDF_EINVAL, "Adam update asked for (m) but v/step/lr missing");
+    const wdf::AdamTail adam{m ? theta : nullptr, m, v, step, lr, beta1, beta2, eps, lo, hi};
+    const wdf::FusedOut out{gtheta, accumulate, sse, adam, 0.0, 0.0, nullptr, nullptr};
+    return step_tp_common(x, r, theta, fs, n_up, n_down, target, 0.5f * gscale, skip, y, z0, zT, B, T, n_chunks, warmup, tol, ws,
+                          status, state, max_warm_tiles, false, out, flags, stream, "wdf_clipper_step_mse_tp");
+}
+
+int wdf_clipper_step_esr_tp(const float* x, const float* r, float* theta, float fs, int n_up, int n_down,
+                            const float* target, double n_global, double eps_energy, int64_t skip, float* y, const float* z0,
+                            float* zT, int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws, void* status,
+                            void* state, int max_warm_tiles, float* sums10, float* gtheta, float* loss3, float* m, float* v,
+                            int32_t* step, const float* lr, float beta1, float beta2, float eps, const float* lo,
+                            const float* hi, int flags, void* stream)
+{
+    if (!sums10) return fail(WDF_EINVAL, "null sums10");
+    if (!(n_global > 0.0)) return fail(WDF_EINVAL, "n_global must be positive");
+    if (m && (!gtheta || !v || !step || !lr)) return fail(WDF_EINVAL, "Adam update asked for (m) but gtheta/v/step/lr missing");
+    const wdf::AdamTail adam{m ? theta : nullptr, m, v, step, lr, beta1, beta2, eps, lo, hi};
+    const wdf::FusedOut out{gtheta, 0, nullptr, adam, n_global, eps_energy, sums10, loss3};
+    return step_tp_common(x, r, theta, fs, n_up, n_down, target, 0.5f, skip, y, z0, zT, B, T, n_chunks, warmup, tol, ws, status,
+                          state, max_warm_tiles, true, out, flags, stream, "wdf_clipper_step_esr_tp");
+}
+
+int wdf_esr_finish(const float* sums10, double n_global, double eps_energy, float* gtheta, float* loss3, void* stream)
+{
+    if (!sums10 || !gtheta || !(n_global > 0.0)) return fail(WDF_EINVAL, "wdf_esr_finish: null sums10/gtheta or n_global <= 0");
+    hipLaunchKernelGGL(esr_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums10, n_global, eps_energy, gtheta, loss3);
+    return check_launch("wdf_esr_finish");
 }
 
 int wdf_omega_f64(const double* x, double* w, int32_t* iters, int64_t n, void* stream)

@@ -328,12 +328,11 @@ __global__ __launch_bounds__(64) void clipper_bwd_kernel(
 //   static R :  dIs = S_L/Is ; dV = S_V - S_L/V ; dR = Rp G1^2 (S_L - S_P (1-p)) ;
 //               dC = -2 fs Rp (S_P p + S_L)
 //   per-sample R : S_P = sum Rp_n (g_p p_n + g_L) ; dR = 0 ; dC = -2 fs S_P
-__device__ __forceinline__ void grad_chain_rule(double SL, double SV, double SP, const float* __restrict__ theta, float fs,
-                                                int dyn_r, float* __restrict__ gtheta, int accumulate)
+__device__ __forceinline__ void grad_chain_rule_d(double SL, double SV, double SP, const float* __restrict__ theta, float fs,
+                                                  int dyn_r, double (&g)[4])
 {
     const double Is = theta[0], V = theta[1], R = theta[2], C = theta[3];
     const double G1 = 1.0 / R, G2 = C * (2.0 * (double)fs), Rp = 1.0 / (G1 + G2), p = G1 * Rp;
-    double g[4];
     g[0] = SL / Is;
     g[1] = SV - SL / V;
     if (dyn_r) {
@@ -343,6 +342,13 @@ __device__ __forceinline__ void grad_chain_rule(double SL, double SV, double SP,
         g[2] = Rp * G1 * G1 * (SL - SP * (1.0 - p));
         g[3] = -2.0 * (double)fs * Rp * (SP * p + SL);
     }
+}
+
+__device__ __forceinline__ void grad_chain_rule(double SL, double SV, double SP, const float* __restrict__ theta, float fs,
+                                                int dyn_r, float* __restrict__ gtheta, int accumulate)
+{
+    double g[4];
+    grad_chain_rule_d(SL, SV, SP, theta, fs, dyn_r, g);
     for (int k = 0; k < 4; ++k) gtheta[k] = (accumulate ? gtheta[k] : 0.0f) + (float)g[k];
 }
 
@@ -1040,6 +1046,27 @@ struct AdamTail {
     float* m; float* v; int32_t* step; const float* lr; float b1, b2, eps; const float* lo; const float* hi;
 };
 
+// Adam + clip constraints on the four components (wdf_adam_step's rule), by the wave that finished the step.
+__device__ __forceinline__ void adam_tail_apply(const AdamTail& adam, const float* gtheta)
+{
+    const int i = threadIdx.x;
+    const int t = *adam.step + 1;
+    __syncthreads();
+    if (i == 0) *adam.step = t;
+    if (i < 4) {
+        const double c1 = 1.0 - ipow((double)adam.b1, t), c2 = 1.0 - ipow((double)adam.b2, t);     // (on the step's critical path)
+        const float g = gtheta[i];
+        const float mi = adam.b1 * adam.m[i] + (1.0f - adam.b1) * g;
+        const float vi = adam.b2 * adam.v[i] + (1.0f - adam.b2) * g * g;
+        adam.m[i] = mi;
+        adam.v[i] = vi;
+        float th = adam.theta[i] - (float)((double)adam.lr[i] * sqrt(c2) / c1) * mi / (sqrtf(vi) + adam.eps);
+        if (adam.lo) th = fmaxf(th, adam.lo[i]);
+        if (adam.hi) th = fminf(th, adam.hi[i]);
+        adam.theta[i] = th;
+    }
+}
+
 // A tile's partial sums {S_L, S_V, S_P, SSE} (per lane, dead lanes zero) -> the tile's slot of ws; the LAST tile
 // to arrive (tickets[0], left clean) does the fixed-order reduction over the tiles, the chain rule to
 // {Is, nVt, R, C} and, if asked, the Adam update of the four components.
@@ -1067,22 +1094,7 @@ __device__ __forceinline__ void tile_partial_and_finish(double dL, double dV, do
     grad_reduce_block<64>(wsr, (int)ntiles, theta, fs, dyn_r, gtheta, accumulate, sse_out, sh);
     if (adam.theta != nullptr) {
         __syncthreads();
-        const int i = threadIdx.x;
-        const int t = *adam.step + 1;
-        __syncthreads();
-        if (i == 0) *adam.step = t;
-        if (i < 4) {
-            const double c1 = 1.0 - ipow((double)adam.b1, t), c2 = 1.0 - ipow((double)adam.b2, t);     // (on the step's critical path)
-            const float g = gtheta[i];
-            const float mi = adam.b1 * adam.m[i] + (1.0f - adam.b1) * g;
-            const float vi = adam.b2 * adam.v[i] + (1.0f - adam.b2) * g * g;
-            adam.m[i] = mi;
-            adam.v[i] = vi;
-            float th = adam.theta[i] - (float)((double)adam.lr[i] * sqrt(c2) / c1) * mi / (sqrtf(vi) + adam.eps);
-            if (adam.lo) th = fmaxf(th, adam.lo[i]);
-            if (adam.hi) th = fminf(th, adam.hi[i]);
-            adam.theta[i] = th;
-        }
+        adam_tail_apply(adam, gtheta);
     }
 }
 

@@ -41,7 +41,9 @@ namespace wdf {
 #ifdef WDF_DBG_TIMES      // tools/dbg_times.py: per-wave start / end wall clock of the main body (build with -DWDF_DBG_TIMES)
 __device__ unsigned long long* g_dbg_times = nullptr;
 #endif
-constexpr int kFsOut = 9;       // record floats per (chunk, sequence)
+constexpr int kFsOut = 9;       // record floats per (chunk, sequence), MSE: {A, c[3], GA, G[3], SSE}
+constexpr int kFsOutEsr = 14;   // MSE + ESR adds the y-weighted sums {HA, H[3], SYY}
+template <int LOSS> struct FusedRec { static constexpr int N = LOSS == 2 ? kFsOutEsr : kFsOut; };
 constexpr int kFusedSchedGroup = 1;   // steps the instruction scheduler may interleave
 #ifndef WDF_FUSED_ROWS
 #define WDF_FUSED_ROWS 16
@@ -193,20 +195,29 @@ struct FusedTan {
     V GA, GL, GV, GP;           // running sums since the last flush
     V hg_prev;
     V sse;                      // hgs x sum of squared errors
+    // MSE + ESR (LOSS = 2) only: the same sums weighted by y instead of (y - target), and hgs x sum y^2
+    V HA, HL, HV, HP, hy_prev, syy;
     __device__ __forceinline__ void init()
     {
         A = vsplat<V>(1.0f);
         cL = cV = cP = GA = GL = GV = GP = hg_prev = sse = vsplat<V>(0.0f);
+        HA = HL = HV = HP = hy_prev = syy = vsplat<V>(0.0f);
     }
+    template <int LOSS>
     __device__ __forceinline__ void pin()
     {
         vpin(A); vpin(cL); vpin(cV); vpin(cP); vpin(GA); vpin(GL); vpin(GV); vpin(GP); vpin(sse);
+        if constexpr (LOSS == 2) { vpin(HA); vpin(HL); vpin(HV); vpin(HP); vpin(syy); }
     }
 };
 
 // One step: forward (the arithmetic of fwd_step, same expressions) + partials (those of bwd_tp_step) +
 // tangent update.  hgs = gscale / 2 (0 on masked steps).  Returns y.
-template <bool DYN_R, bool SYM, bool FAST, typename V>
+// LOSS = 2 (MSE + ESR, clipper_pot.py:146-156,177): dLoss/dy = ga (y - target) + gb y with ga, gb functions of the GLOBAL
+// sums S = sum (y - t)^2 and E = sum y^2, known only after the pass -- so the pass carries BOTH tangent-weighted sums,
+// P_i = sum (y - t) dy/dtheta_i and Q_i = sum y dy/dtheta_i (hgs = 1/2 on live steps), and the last tile forms
+// ga P + gb Q.  Seven more VALU per step.
+template <bool DYN_R, bool SYM, bool FAST, typename V, int LOSS = 1>
 __device__ __forceinline__ V fused_step(const ClipConsts& c, V xin, V rin, V tgt, float hgs, V& z, FusedTan<V>& s)
 {
     V p, Rp, L;
@@ -263,6 +274,16 @@ __device__ __forceinline__ V fused_step(const ClipConsts& c, V xin, V rin, V tgt
     s.GL = vfma(hh, s.cL, s.GL);
     s.GV = vfma(hh, s.cV, s.GV);
     s.GP = vfma(hh, s.cP, s.GP);
+    if constexpr (LOSS == 2) {
+        const V hy = hgs * y;
+        s.syy = vfma(hy, y, s.syy);
+        const V h2 = hy + s.hy_prev;
+        s.hy_prev = hy;
+        s.HA = vfma(h2, s.A, s.HA);
+        s.HL = vfma(h2, s.cL, s.HL);
+        s.HV = vfma(h2, s.cV, s.HV);
+        s.HP = vfma(h2, s.cP, s.HP);
+    }
     s.A = s.A * kappa;
     s.cL = vfma(kappa, s.cL, DL);
     s.cV = vfma(kappa, s.cV, DV);
@@ -276,42 +297,53 @@ template <typename V>
 struct FusedSums {
     static constexpr int N = VT<V>::N;
     double GA[N], GL[N], GV[N], GP[N], sse[N];
+    double HA[N], HL[N], HV[N], HP[N], syy[N];       // LOSS = 2 only
     __device__ __forceinline__ void init()
     {
 #pragma unroll
-        for (int j = 0; j < N; ++j) GA[j] = GL[j] = GV[j] = GP[j] = sse[j] = 0.0;
+        for (int j = 0; j < N; ++j) GA[j] = GL[j] = GV[j] = GP[j] = sse[j] = HA[j] = HL[j] = HV[j] = HP[j] = syy[j] = 0.0;
     }
+    template <int LOSS>
     __device__ __forceinline__ void flush(FusedTan<V>& s)
     {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             GA[j] += (double)vget(s.GA, j); GL[j] += (double)vget(s.GL, j); GV[j] += (double)vget(s.GV, j);
             GP[j] += (double)vget(s.GP, j); sse[j] += (double)vget(s.sse, j);
+            if constexpr (LOSS == 2) {
+                HA[j] += (double)vget(s.HA, j); HL[j] += (double)vget(s.HL, j); HV[j] += (double)vget(s.HV, j);
+                HP[j] += (double)vget(s.HP, j); syy[j] += (double)vget(s.syy, j);
+            }
         }
         s.GA = s.GL = s.GV = s.GP = s.sse = vsplat<V>(0.0f);
+        if constexpr (LOSS == 2) s.HA = s.HL = s.HV = s.HP = s.syy = vsplat<V>(0.0f);
     }
 };
 
 // the chunk's record (write-through: another wave of this launch reads it)
-template <typename V>
+template <typename V, int LOSS>
 __device__ __forceinline__ void fused_publish_record(float* rec, int64_t k, int64_t b, int64_t B, const FusedTan<V>& s,
                                                      const FusedSums<V>& d, float hgs)
 {
+    constexpr int NREC = FusedRec<LOSS>::N;
+    const double inv = hgs != 0.0f ? 1.0 / (double)hgs : 0.0;
 #pragma unroll
     for (int j = 0; j < VT<V>::N; ++j) {
         // the boundary term of the summation by parts: s[t1] hg_{t1-1}
-        const double h = (double)vget(s.hg_prev, j);
+        const double h = (double)vget(s.hg_prev, j), h2 = (double)vget(s.hy_prev, j);
         const float A = vget(s.A, j), cL = vget(s.cL, j), cV = vget(s.cV, j), cP = vget(s.cP, j);
-        const float v[kFsOut] = {A, cL, cV, cP, (float)(d.GA[j] + h * A), (float)(d.GL[j] + h * cL), (float)(d.GV[j] + h * cV),
-                                 (float)(d.GP[j] + h * cP), hgs != 0.0f ? (float)(d.sse[j] / (double)hgs) : 0.0f};
-        float* o = rec + (k * kFsOut) * B + b + j;
+        const float v[kFsOutEsr] = {A, cL, cV, cP, (float)(d.GA[j] + h * A), (float)(d.GL[j] + h * cL), (float)(d.GV[j] + h * cV),
+                                    (float)(d.GP[j] + h * cP), (float)(d.sse[j] * inv),
+                                    (float)(d.HA[j] + h2 * A), (float)(d.HL[j] + h2 * cL), (float)(d.HV[j] + h2 * cV),
+                                    (float)(d.HP[j] + h2 * cP), (float)(d.syy[j] * inv)};
+        float* o = rec + (k * NREC) * B + b + j;
 #pragma unroll
-        for (int i = 0; i < kFsOut; ++i) __hip_atomic_store(o + i * B, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < NREC; ++i) __hip_atomic_store(o + i * B, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 // Chunk geometry as clipper_fwd_tp_body (L, W multiples of kTile); target [T][B]; skip: steps below it carry no loss.
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool FAST, typename V>
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool FAST, typename V, int LOSS>
 __device__ __forceinline__ void clipper_fused_body(
     const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ target,
     float* __restrict__ y, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
@@ -411,14 +443,14 @@ __device__ __forceinline__ void clipper_fused_body(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            buf_store_nt(fused_step<DYN_R, SYM, FAST, V>(c, xc[i], rc[i], gc[i], step_loss_scale(i, n_masked, hgs), z, s), ry, boff,
+            buf_store_nt(fused_step<DYN_R, SYM, FAST, V, LOSS>(c, xc[i], rc[i], gc[i], step_loss_scale(i, n_masked, hgs), z, s), ry, boff,
                          i * rowb);
             // The tangent updates do not feed the next step's state, so left alone instruction selection
             // emits the z chain of the whole tile first and keeps every step's partials alive (200 VGPRs,
             // spills).  Pinning the tangent state (a chained, empty asm) before the scheduling barrier keeps
             // each group of steps' work inside the group.
             if (i % kFusedSchedGroup == kFusedSchedGroup - 1) {
-                s.pin();
+                s.template pin<LOSS>();
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -431,19 +463,19 @@ __device__ __forceinline__ void clipper_fused_body(
 #else
         wait_vmcnt<NR>();
 #endif
-        d.flush(s);
+        d.template flush<LOSS>(s);
     }
     for (int64_t tt = nfull_end; tt < t1; ++tt) {           // tail of the last chunk (T % NR)
         const V xin = load_step<V, TM>(x, q, B, T, tt);
         const V rin = DYN_R ? load_step<V, TM>(r, q, B, T, tt) : vsplat<V>(1.0f);
         const V tg = load_own<V>(target + tt * B, q);
-        store_own<V>(y + tt * B, q, fused_step<DYN_R, SYM, FAST, V>(c, xin, rin, tg, tt >= skip ? hgs : 0.0f, z, s));
+        store_own<V>(y + tt * B, q, fused_step<DYN_R, SYM, FAST, V, LOSS>(c, xin, rin, tg, tt >= skip ? hgs : 0.0f, z, s));
     }
-    d.flush(s);
+    d.template flush<LOSS>(s);
     publish_own<V>(zend + k * B, q, z);
     if (snapw != nullptr) store_own<V>(snapw, q, z);
     if (zT && t1 == T) store_own<V>(zT, q, z);
-    fused_publish_record<V>(rec, k, q.b, B, s, d, hgs);
+    fused_publish_record<V, LOSS>(rec, k, q.b, B, s, d, hgs);
 #ifdef WDF_DBG_TIMES
     dbg_p[4] = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0 && g_dbg_times) {
@@ -454,65 +486,145 @@ __device__ __forceinline__ void clipper_fused_body(
 #endif
 }
 
-// The tile's K records in time order -> the tile's sums -> (last tile) the step's result.  NSEQ: sequences per lane.
-template <int NSEQ>
-__device__ __forceinline__ void fused_combine_tile(const float* rec, int64_t K, int64_t B, double* ws, unsigned* gticket,
-                                                   const float* theta, float fs, int dyn_r, float* gtheta, int accumulate,
-                                                   float* __restrict__ sse_out, const AdamTail& adam, double (*sh)[4])
+// What the step hands back.  MSE: gtheta[4] (+=), sse.  MSE + ESR: sums10 = {S, E, gP[4], gQ[4]} of THIS rank (the chain
+// rule applied to both tangent-weighted sums: what ranks all-reduce); and, when gtheta is not null, the step finished as
+// a single rank: loss coefficients from S and E (esr_coef_kernel's formulas), gtheta = ga gP + gb gQ,
+// loss3 = {mse, esr, mse + esr}, Adam.
+struct FusedOut {
+    float* gtheta; int accumulate; float* sse_out; AdamTail adam;
+    double n_global, eps; float* sums10; float* loss3;
+};
+
+// MSE + ESR: the tile's eight sums -> its slot of ws (8 doubles per tile); the LAST tile reduces over the tiles in a fixed
+// order (lane i takes tiles i, i + 64, ...; then the wave's shuffle tree), applies the chain rule to P and Q and finishes.
+__device__ __forceinline__ void esr_tile_partial_and_finish(const double (&v)[8], double* ws, unsigned* gticket, const float* theta,
+                                                            float fs, int dyn_r, const FusedOut& out)
 {
+    const unsigned ntiles = gridDim.x;
+    double w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = wave_sum(v[i]);
+    unsigned done = 0;
+    if (threadIdx.x == 0) {
+        double* o = ws + (int64_t)blockIdx.x * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) __hip_atomic_store(o + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial has landed before the tile count moves
+        done = atomicAdd(&gticket[0], 1u);
+    }
+    done = __builtin_amdgcn_readfirstlane(done);
+    if (done != ntiles - 1) return;
+    if (threadIdx.x == 0) gticket[0] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const double* wsr = ws;
+    double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (unsigned i = threadIdx.x; i < ntiles; i += 64)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] += wsr[(int64_t)i * 8 + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = wave_sum(t[j]);
+    if (threadIdx.x == 0) {
+        // t = {P_L, P_V, P_P, S, Q_L, Q_V, Q_P, E}
+        double gP[4], gQ[4];
+        grad_chain_rule_d(t[0], t[1], t[2], theta, fs, dyn_r, gP);
+        grad_chain_rule_d(t[4], t[5], t[6], theta, fs, dyn_r, gQ);
+        out.sums10[0] = (float)t[3];
+        out.sums10[1] = (float)t[7];
+        for (int k = 0; k < 4; ++k) { out.sums10[2 + k] = (float)gP[k]; out.sums10[6 + k] = (float)gQ[k]; }
+        if (out.gtheta != nullptr) {
+            const double n = out.n_global, S = t[3], E = t[7] + out.eps;
+            const double mse = S / n, esr = sqrt(S / E / n);
+            const double ga = 2.0 / n + (esr > 0.0 ? 1.0 / (esr * E * n) : 0.0), gb = -esr / E;
+            for (int k = 0; k < 4; ++k)
+                out.gtheta[k] = (out.accumulate ? out.gtheta[k] : 0.0f) + (float)(ga * gP[k] + gb * gQ[k]);
+            if (out.loss3) { out.loss3[0] = (float)mse; out.loss3[1] = (float)esr; out.loss3[2] = (float)(mse + esr); }
+        }
+    }
+    if (out.gtheta != nullptr && out.adam.theta != nullptr) {
+        __syncthreads();                                     // (one-wave workgroup: orders lane 0's gtheta with the readers)
+        adam_tail_apply(out.adam, out.gtheta);
+    }
+}
+
+// The tile's K records in time order -> the tile's sums -> (last tile) the step's result.  NSEQ: sequences per lane.
+template <int NSEQ, int LOSS>
+__device__ __forceinline__ void fused_combine_tile(const float* rec, int64_t K, int64_t B, double* ws, unsigned* gticket,
+                                                   const float* theta, float fs, int dyn_r, const FusedOut& out, double (*sh)[4])
+{
+    constexpr int NREC = FusedRec<LOSS>::N;
     const int64_t raw = ((int64_t)blockIdx.x * 64 + threadIdx.x) * NSEQ;
     const bool live = raw < B;
     const int64_t b0 = live ? raw : B - NSEQ;
-    double dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0;
+    double dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0, qL = 0.0, qV = 0.0, qP = 0.0, qE = 0.0;
 #pragma unroll 1
     for (int h = 0; h < NSEQ; ++h) {
         const int64_t b = b0 + h;
         double sL = 0.0, sV = 0.0, sP = 0.0;              // tangent entering the chunk (z0 does not depend on theta)
+        constexpr int kAhead = LOSS == 2 ? 4 : 8;         // chunks whose records are in flight together
         int64_t k = 0;
-        for (; k + 8 <= K; k += 8) {                      // 8 chunks' 72 loads in flight together
-            float v[8][kFsOut];
+        for (; k + kAhead <= K; k += kAhead) {
+            float v[kAhead][NREC];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < kAhead; ++j)
 #pragma unroll
-                for (int i = 0; i < kFsOut; ++i) v[j][i] = load_published(rec + ((k + j) * kFsOut + i) * B + b);
+                for (int i = 0; i < NREC; ++i) v[j][i] = load_published(rec + ((k + j) * NREC + i) * B + b);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kAhead; ++j) {
                 const double A = v[j][0], GA = v[j][4];
                 dL += sL * GA + (double)v[j][5];
                 dV += sV * GA + (double)v[j][6];
                 dP += sP * GA + (double)v[j][7];
                 dS += (double)v[j][8];
+                if constexpr (LOSS == 2) {
+                    const double HA = v[j][9];
+                    qL += sL * HA + (double)v[j][10];
+                    qV += sV * HA + (double)v[j][11];
+                    qP += sP * HA + (double)v[j][12];
+                    qE += (double)v[j][13];
+                }
                 sL = A * sL + (double)v[j][1];
                 sV = A * sV + (double)v[j][2];
                 sP = A * sP + (double)v[j][3];
             }
         }
         for (; k < K; ++k) {
-            const float* o = rec + (k * kFsOut) * B + b;
+            const float* o = rec + (k * NREC) * B + b;
             const double A = load_published(o), GA = load_published(o + 4 * B);
             dL += sL * GA + (double)load_published(o + 5 * B);
             dV += sV * GA + (double)load_published(o + 6 * B);
             dP += sP * GA + (double)load_published(o + 7 * B);
             dS += (double)load_published(o + 8 * B);
+            if constexpr (LOSS == 2) {
+                const double HA = load_published(o + 9 * B);
+                qL += sL * HA + (double)load_published(o + 10 * B);
+                qV += sV * HA + (double)load_published(o + 11 * B);
+                qP += sP * HA + (double)load_published(o + 12 * B);
+                qE += (double)load_published(o + 13 * B);
+            }
             sL = A * sL + (double)load_published(o + 1 * B);
             sV = A * sV + (double)load_published(o + 2 * B);
             sP = A * sP + (double)load_published(o + 3 * B);
         }
     }
-    if (!live) { dL = dV = dP = dS = 0.0; }
-    tile_partial_and_finish(dL, dV, dP, dS, ws, gticket, theta, fs, dyn_r, gtheta, accumulate, sse_out, adam, sh);
+    if (!live) { dL = dV = dP = dS = qL = qV = qP = qE = 0.0; }
+    if constexpr (LOSS == 2) {
+        const double v8[8] = {dL, dV, dP, dS, qL, qV, qP, qE};
+        esr_tile_partial_and_finish(v8, ws, gticket, theta, fs, dyn_r, out);
+    } else {
+        tile_partial_and_finish(dL, dV, dP, dS, ws, gticket, theta, fs, dyn_r, out.gtheta, out.accumulate, out.sse_out, out.adam, sh);
+    }
 }
 
 // tickets: the forward's verification area [TpAcc][per-tile tickets][per-tile repair flags];
 // gticket: [tiles combined, 0, 0, 0] -- both zero before the first launch and left zero by every step.
 // A tile is the 64 * VT<V>::N sequences of one wave.
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, typename V>
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, typename V, int LOSS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WAVES, WDF_FUSED_WAVES))) void clipper_fused_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, const float* __restrict__ z0,
     float* __restrict__ zT, float* zwarm, float* zend, float* rec, TpStatus* __restrict__ status, TpCtl* ctl, float* snap,
     int J, unsigned* tickets, unsigned* gticket, float tol, int64_t B, int64_t T, int64_t L, int64_t W, int general,
-    double* ws, float* gtheta, int accumulate, float* __restrict__ sse_out, AdamTail adam)
+    double* ws, FusedOut out)
 {
     __shared__ double sh[64][4];
 #ifdef WDF_DBG_TIMES
@@ -523,10 +635,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     bool fast = false;
     if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
     if (fast)
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R, V>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R, V, LOSS>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
                                                             T, L, W, hgs, skip);
     else
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, LOSS>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
                                                            T, L, W, hgs, skip);
 #ifdef WDF_DBG_TIMES
     if (threadIdx.x == 0 && g_dbg_times) {
@@ -537,11 +649,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     if (!tp_tile_last(tickets)) return;
     const bool failed = tp_verify_tile<DYN_R, VT<V>::N>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
     if (failed) return;                                     // left to clipper_fused_repair_kernel
-    fused_combine_tile<VT<V>::N>(rec, gridDim.y, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);
+    fused_combine_tile<VT<V>::N, LOSS>(rec, gridDim.y, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, out, sh);
 }
 
 // Re-run of chunk [t0, t1) for 64 sequences (one per lane, index b) from the exact state z: outputs, snapshots, record.
-template <bool DYN_R, bool SYM, bool TM, bool FAST>
+template <bool DYN_R, bool SYM, bool TM, bool FAST, int LOSS>
 __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r,
                                                   const float* __restrict__ target, float* __restrict__ y, float* rec,
                                                   float* __restrict__ snapw, int J, int64_t K, int64_t k, int64_t b, int64_t B,
@@ -553,7 +665,7 @@ __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const flo
     d.init();
     for (int64_t t = t0; t < t1; t += kBlk) {
         if ((t - t0) % kTile == 0) {
-            d.flush(s);
+            d.template flush<LOSS>(s);
             if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1) && (t1 - t) % kTile == 0)
                 snapw[((t1 - t) / kTile) * K * B + b] = z;
         }
@@ -568,25 +680,25 @@ __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const flo
 #pragma unroll
         for (int i = 0; i < kBlk; ++i) {
             if (t + i < t1)                                      // wave-uniform
-                y[(t + i) * B + b] = fused_step<DYN_R, SYM, FAST, float>(c, xv[i], rv[i], gv[i], (t + i >= skip) ? hgs : 0.0f, z, s);
+                y[(t + i) * B + b] = fused_step<DYN_R, SYM, FAST, float, LOSS>(c, xv[i], rv[i], gv[i], (t + i >= skip) ? hgs : 0.0f, z, s);
         }
     }
-    d.flush(s);
+    d.template flush<LOSS>(s);
     if (snapw != nullptr) snapw[b] = z;
-    fused_publish_record<float>(rec, k, b, B, s, d, hgs);
+    fused_publish_record<float, LOSS>(rec, k, b, B, s, d, hgs);
 }
 
 // Launched behind every fused step; a block leaves at once unless the step flagged its tile (the common
 // case).  For a flagged tile (64 NSEQ sequences; each of its NSEQ interleaved sets of 64 in turn): walk the chunk
 // boundaries in time order, re-run every chunk one of whose sequences arrived more than tol off (from the exact
 // state, one sequence per lane), then combine the tile.
-template <bool DYN_R, bool SYM, bool TM, int NSEQ>
+template <bool DYN_R, bool SYM, bool TM, int NSEQ, int LOSS>
 __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, float* __restrict__ zT,
     const float* zwarm, float* zend, float* rec, int64_t B, int64_t T, int64_t K, int64_t L, float tol,
     TpStatus* __restrict__ status, const TpCtl* __restrict__ ctl, float* __restrict__ snap, int J, unsigned* tickets,
-    unsigned* gticket, int general, double* ws, float* gtheta, int accumulate, float* __restrict__ sse_out, AdamTail adam)
+    unsigned* gticket, int general, double* ws, FusedOut out)
 {
     __shared__ double sh[64][4];
     unsigned* tile_bad = tickets + 4 + gridDim.x;
@@ -611,8 +723,8 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
             const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
             float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
             float z = e;
-            if (fast) fused_rerun_chunk<DYN_R, SYM, TM, !DYN_R>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
-            else fused_rerun_chunk<DYN_R, SYM, TM, false>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
+            if (fast) fused_rerun_chunk<DYN_R, SYM, TM, !DYN_R, LOSS>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
+            else fused_rerun_chunk<DYN_R, SYM, TM, false, LOSS>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
             zend[k * B + b] = z;
             if (zT && t1 == T) zT[b] = z;
             ze_fix = z;
@@ -625,7 +737,7 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
         if (nrep) atomicAdd(&status->fallback_ran, nrep);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the re-written records have landed (write-through)
-    fused_combine_tile<NSEQ>(rec, K, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);
+    fused_combine_tile<NSEQ, LOSS>(rec, K, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, out, sh);
 }
 
 }  // namespace wdf

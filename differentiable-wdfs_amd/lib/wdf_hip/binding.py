@@ -96,6 +96,11 @@ def lib():
     L.wdf_clipper_step_mse_tp.restype = ci
     L.wdf_clipper_step_mse_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, cf, i64, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, vp,
                                           ci, fp, fp, ci, fp, fp, vp, fp, cf, cf, cf, fp, fp, ci, vp]
+    L.wdf_clipper_step_esr_tp.restype = ci
+    L.wdf_clipper_step_esr_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, C.c_double, C.c_double, i64, fp, fp, fp, i64, i64, ci, ci, cf,
+                                          vp, vp, vp, ci, fp, fp, fp, fp, fp, vp, fp, cf, cf, cf, fp, fp, ci, vp]
+    L.wdf_esr_finish.restype = ci
+    L.wdf_esr_finish.argtypes = [fp, C.c_double, C.c_double, fp, fp, vp]
     L.wdf_loss_sums_ws_bytes.restype = i64
     L.wdf_loss_sums.restype = ci
     L.wdf_loss_sums.argtypes = [fp, fp, i64, i64, i64, vp, vp, vp]
@@ -182,7 +187,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_fwd_tp_state_bytes", "wdf_clipper_fwd_tp_state_reset", "wdf_clipper_fwd_tp_warm",
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp_ws_init", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_bwd_mse_tp_adam", "wdf_clipper_step_mse_tp_ws_bytes", "wdf_clipper_step_mse_tp_ws_init",
-    "wdf_clipper_step_mse_tp", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
+    "wdf_clipper_step_mse_tp", "wdf_clipper_step_esr_tp", "wdf_esr_finish", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
@@ -427,6 +432,69 @@ def clipper_step_mse_tp(x, theta, fs, target, gscale, n_chunks, warmup, tol=1e-6
         _stream())
     _check(rc, "wdf_clipper_step_mse_tp")
     return y, zT, gtheta, sse, status
+
+
+def clipper_step_esr_tp(x, theta, fs, target, n_global, eps_energy, skip, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_down=1,
+                        y=None, z0=None, want_zT=False, ws=None, status=None, state=None, sums10=None, gtheta=None, loss3=None,
+                        finish=True, opt=None, time_major=False):
+    """The one-pass training step for the scripts' loss MSE + ESR past `skip` (include/wdf_hip.h, wdf_clipper_step_esr_tp).
+    finish=True: the kernel finishes the step as a single rank -> gtheta[4], loss3 = {mse, esr, mse + esr} (and the Adam
+    update of theta with `opt`).  finish=False: only sums10 = {S, E, gP[4], gQ[4]} of this batch comes back -- all-reduce it
+    and call esr_finish.  -> y [T,B], zT | None, sums10, gtheta | None, loss3 | None, status."""
+    require_gpu()
+    x, r, theta = _f32_dev(x, "x"), _f32_dev(r, "r"), _f32_dev(theta, "theta")
+    target, z0 = _f32_dev(target, "target"), _f32_dev(z0, "z0")
+    B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
+    if theta.numel() != 4:
+        raise WdfHipError("theta must hold {Is, nVt, R, C}")
+    if tuple(target.shape) != (T, B):
+        raise WdfHipError(f"target must be [T,B] = [{T},{B}]")
+    if r is not None and r.shape != x.shape:
+        raise WdfHipError("r must have the shape of x")
+    K = lib().wdf_clipper_tp_chunks(T, int(n_chunks))
+    dev = x.device
+    if y is None:
+        y = torch.empty((T, B), dtype=torch.float32, device=dev)
+    zT = torch.empty((B,), dtype=torch.float32, device=dev) if want_zT else None
+    if ws is None:
+        ws = step_mse_workspace(B, K, dev)
+    if status is None:
+        status = torch.empty((4,), dtype=torch.int32, device=dev)
+    if sums10 is None:
+        sums10 = torch.empty((10,), dtype=torch.float32, device=dev)
+    if finish:
+        gtheta = torch.empty((4,), dtype=torch.float32, device=dev) if gtheta is None else gtheta
+        loss3 = torch.empty((3,), dtype=torch.float32, device=dev) if loss3 is None else loss3
+    else:
+        gtheta = loss3 = opt = None
+    if state is not None and ((state.B, state.T, state.K) != (B, T, K) or state.buf.device != dev):
+        raise WdfHipError("warm-start state was made for another batch shape / chunking / device")
+    o = opt
+    if o is not None and o.n != 4:
+        raise WdfHipError("clipper_step_esr_tp: the optimizer holds {Is, nVt, R, C}")
+    rc = lib().wdf_clipper_step_esr_tp(
+        _ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down), _ptr(target), float(n_global), float(eps_energy),
+        int(skip), _ptr(y), _ptr(z0), _ptr(zT), B, T, K, int(warmup), float(tol), _ptr(ws), _ptr(status),
+        None if state is None else _ptr(state.buf), 0 if state is None else state.max_warm_tiles, _ptr(sums10), _ptr(gtheta),
+        _ptr(loss3), *((None,) * 4 if o is None else (_ptr(o.m), _ptr(o.v), _ptr(o.step), _ptr(o.lr))),
+        0.0 if o is None else o.b1, 0.0 if o is None else o.b2, 0.0 if o is None else o.eps,
+        None if o is None else _ptr(o.lo), None if o is None else _ptr(o.hi),
+        (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag() | (WDF_ONE_SEQUENCE_PER_LANE if ONE_SEQUENCE_PER_LANE else 0),
+        _stream())
+    _check(rc, "wdf_clipper_step_esr_tp")
+    return y, zT, sums10, gtheta, loss3, status
+
+
+def esr_finish(sums10, n_global, eps_energy, gtheta=None, loss3=None):
+    """(gtheta[4], loss3 = {mse, esr, mse + esr}) from the all-reduced sums10 of clipper_step_esr_tp(finish=False)."""
+    require_gpu()
+    sums10 = _f32_dev(sums10, "sums10")
+    if gtheta is None:
+        gtheta = torch.empty((4,), dtype=torch.float32, device=sums10.device)
+    if loss3 is None:
+        loss3 = torch.empty((3,), dtype=torch.float32, device=sums10.device)
+    _check(lib().wdf_esr_finish(_ptr(sums10), float(n_global), float(eps_energy), _ptr(gtheta), _ptr(loss3), _stream()), "wdf_esr_finish")
+    return gtheta, loss3
 
 
 def loss_sums(y, target, skip, sums=None, ws=None):

@@ -246,6 +246,7 @@ class MseStep:
             self.sums = torch.zeros((2,), dtype=torch.float64, device=device)
             self.gcoef = torch.zeros((2,), dtype=torch.float32, device=device)
             self.loss = torch.zeros((3,), dtype=torch.float32, device=device)      # mse, esr, mse + esr
+            self.sums10 = torch.zeros((10,), dtype=torch.float32, device=device)   # one-pass step: {S, E, gP[4], gQ[4]}
         L = binding.lib()
         kf, kb = (tp.k_fwd, tp.k_bwd) if tp is not None else (1, 1)
         self.ws_f = torch.empty((max(16, L.wdf_clipper_fwd_tp_ws_bytes(B, kf)),), dtype=torch.uint8, device=device)
@@ -306,22 +307,33 @@ class MseStep:
         return self.backward(theta, x, target, r)
 
     def step_fused(self, theta, x, target, r=None, adam=None):
-        """The same step in ONE pass over the data (csrc/wdf_clipper_fused.h, MSE loss): forward, loss and
-        gradient with x and target read once and y written once -- no state stash, one root solve per sample,
-        the gradient carried forward as the state's tangent.  Chunking / verification / warm start as
-        forward(); fills self.y, self.sse, self.gtheta (and, with `adam`, updates theta in the same launch)."""
-        if self.loss_kind != "mse":
-            raise binding.WdfHipError("step_fused: MSE loss only (the MSE + ESR coefficients need the global sums first)")
+        """The same step in ONE pass over the data (csrc/wdf_clipper_fused.h): forward, loss and gradient with x and target
+        read once and y written once -- no state stash, one root solve per sample, the gradient carried forward as the
+        state's tangent.  Chunking / verification / warm start as forward(); fills self.y, self.sse, self.gtheta (for
+        "mse+esr" also self.loss = {mse, esr, mse + esr}) and, with `adam` on a single rank, updates theta in the same launch.
+        With sums_allreduce set (sharded batch, "mse+esr") the ten sums are all-reduced between the pass and its finish."""
         tp = self.tp
         k = tp.k_fwd if tp is not None else 1
         if self.ws_s is None or self.ws_s_k != k:
             self.ws_s, self.ws_s_k = binding.step_mse_workspace(self.B, binding.lib().wdf_clipper_tp_chunks(self.T, k), x.device), k
             self.y = torch.empty((self.T, self.B), dtype=torch.float32, device=x.device)
             self.zs = self.zT = None
-        binding.clipper_step_mse_tp(x, theta, self.fs, target, self.gscale, k, tp.warmup if tp is not None else 0,
-                                    tol=tp.tol if tp is not None else 1.0e-6, r=r, n_up=self.n_up, n_down=self.n_down,
-                                    y=self.y, ws=self.ws_s, status=self.status, state=self.warm, gtheta=self.gtheta,
-                                    sse=self.sse, opt=adam, time_major=self.time_major)
+        W, tol = (tp.warmup, tp.tol) if tp is not None else (0, 1.0e-6)
+        if self.loss_kind == "mse":
+            binding.clipper_step_mse_tp(x, theta, self.fs, target, self.gscale, k, W, tol=tol, r=r, n_up=self.n_up,
+                                        n_down=self.n_down, y=self.y, ws=self.ws_s, status=self.status, state=self.warm,
+                                        gtheta=self.gtheta, sse=self.sse, opt=adam, time_major=self.time_major)
+            return self.sse, self.gtheta
+        eps = float(torch.finfo(torch.float64).eps)
+        local = self.sums_allreduce is None
+        binding.clipper_step_esr_tp(x, theta, self.fs, target, self.n_global, eps, self.skip, k, W, tol=tol, r=r, n_up=self.n_up,
+                                    n_down=self.n_down, y=self.y, ws=self.ws_s, status=self.status, state=self.warm,
+                                    sums10=self.sums10, gtheta=self.gtheta, loss3=self.loss, finish=local,
+                                    opt=adam if local else None, time_major=self.time_major)
+        if not local:
+            self.sums_allreduce(self.sums10)
+            binding.esr_finish(self.sums10, self.n_global, eps, gtheta=self.gtheta, loss3=self.loss)
+        self.sse.copy_(self.sums10[0:1])
         return self.sse, self.gtheta
 
 

@@ -194,6 +194,21 @@ int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float 
                             const float* lr, float beta1, float beta2, float eps, const float* lo, const float* hi, int flags,
                             void* stream);
 
+/* The same one-pass step for the scripts' training loss, MSE + ESR on the samples past `skip` (loss_func = MSE + esr_loss with
+ * the scripts' argument order, clipper_pot.py:146-156,177,232,248):  loss = S/n + sqrt(S / (E + eps_energy) / n),
+ * S = sum (y - target)^2, E = sum y^2, n = n_global.  dLoss/dy = ga (y - target) + gb y needs the GLOBAL S and E, so the pass
+ * carries both tangent-weighted sums and hands back sums10 = {S, E, gP[4], gQ[4]} of this call's batch (gP = d(S/2)/dtheta,
+ * gQ = d(E/2)/dtheta): with several ranks all-reduce the ten floats and call wdf_esr_finish (-> gtheta = ga gP + gb gQ and
+ * loss3 = {mse, esr, mse + esr}), then wdf_adam_step.  With gtheta != NULL the kernel finishes the step itself as a single
+ * rank (same formulas; loss3 optional; Adam when m != NULL).  Workspace and state as wdf_clipper_step_mse_tp (same sizes). */
+int wdf_clipper_step_esr_tp(const float* x, const float* r, float* theta, float fs, int n_up, int n_down,
+                            const float* target, double n_global, double eps_energy, int64_t skip, float* y, const float* z0,
+                            float* zT, int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws, void* status,
+                            void* state, int max_warm_tiles, float* sums10, float* gtheta, float* loss3, float* m, float* v,
+                            int32_t* step, const float* lr, float beta1, float beta2, float eps, const float* lo,
+                            const float* hi, int flags, void* stream);
+int wdf_esr_finish(const float* sums10, double n_global, double eps_energy, float* gtheta, float* loss3, void* stream);
+
 /* MSE + ESR, the training loss of clipper_pot.py (:146-156 esr_loss, :177 loss_func, :232,248
  * evaluated past skip_samples with (outs, target) passed as (target_y, predicted_y), so the energy
  * is the model output's):   loss = S/n + sqrt(S / (E + eps) / n),  S = sum (y-t)^2, E = sum y^2.

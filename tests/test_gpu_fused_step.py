@@ -256,3 +256,90 @@ def test_fused_bench_shape_against_oracle(wb, oracle):
     got = g.cpu().numpy().astype(np.float64)
     assert np.all(np.abs(got - g_ref) <= G_RTOL * np.abs(g_ref)), (got, g_ref)
     assert abs(float(sse) / (B * T) - loss_ref) <= 1e-5 * loss_ref
+
+
+def _esr_reference(wb, xd, thd, tgt, skip, r=None, n_up=1, n_down=1):
+    """MSE + ESR past skip (clipper_pot.py:146-156,177 with the scripts' argument order) through the kernel pair + torch
+    autograd: the loss values and d loss / d{Is, nVt, R, C}."""
+    from wdf_hip import engine
+    th = thd.clone().requires_grad_(True)
+    y = engine.clipper(th, xd, FS, r=r, n_up=n_up, n_down=n_down)
+    o, t = y[skip:].double(), tgt[skip:].double()
+    S, E = ((o - t) ** 2).sum(), (o ** 2).sum()
+    n = o.numel()
+    mse, esr = S / n, torch.sqrt(S / (E + float(np.finfo(float).eps)) / n)
+    (mse + esr).backward()
+    return y.detach(), th.grad.detach(), float(mse.detach()), float(esr.detach()), float(S.detach()), float(E.detach())
+
+
+@pytest.mark.parametrize("B,T,K,W,with_r", [(64, 1024, 2, 256, False), (70, 1000, 3, 248, False), (130, 2048, 8, 256, False),
+                                            (71, 1024, 2, 256, True), (96, 2048, 4, 512, True)])
+def test_fused_esr_step_matches_autograd(wb, B, T, K, W, with_r):
+    """The scripts' training loss in one pass: both tangent-weighted sums carried, coefficients applied by the last tile."""
+    skip = 50
+    x, th, ths = problem(B, T, seed=B + T + 1)
+    xd, thd = dev(x), dev(th)
+    r = dev(45.0e3 * np.exp(0.8 * np.sin(np.arange(T)[None, :] * 0.01 * (1 + np.arange(B)[:, None] % 5)))) if with_r else None
+    tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, r=r, want_stash=False)
+    y_ref, g_ref, mse, esr, S, E = _esr_reference(wb, xd, thd, tgt, skip, r=r)
+    n = B * (T - skip)
+    eps = float(np.finfo(float).eps)
+    y, _, sums10, g, loss3, st = wb.clipper_step_esr_tp(xd, thd, FS, tgt, n, eps, skip, K, W, r=r)
+    assert wb.tp_status(st)["n_bad"] == 0
+    assert float((y - y_ref).abs().max()) <= Y_TOL
+    idx = [0, 1, 3] if with_r else [0, 1, 2, 3]
+    ok, info = close_grad(g[idx], g_ref[idx])
+    assert ok, info
+    if with_r:
+        assert float(g[2]) == 0.0
+    l = loss3.cpu().numpy()
+    assert abs(l[0] - mse) <= 2e-5 * mse and abs(l[1] - esr) <= 2e-5 * esr and abs(l[2] - (mse + esr)) <= 2e-5 * (mse + esr)
+    s10 = sums10.cpu().numpy()
+    assert abs(s10[0] - S) <= 2e-5 * S and abs(s10[1] - E) <= 2e-5 * E
+    # the two-stage form (what several ranks run: sums out, all-reduce, finish) gives the same numbers
+    _, _, sums_b, g_none, l_none, _ = wb.clipper_step_esr_tp(xd, thd, FS, tgt, n, eps, skip, K, W, r=r, finish=False)
+    assert g_none is None and l_none is None and torch.equal(sums_b, sums10)
+    g2, l2 = wb.esr_finish(sums_b, n, eps)
+    assert torch.allclose(g2, g, rtol=1e-6, atol=0) and torch.allclose(l2, loss3, rtol=1e-6, atol=0)
+    # time-major inputs
+    yt, _, _, gt, lt, _ = wb.clipper_step_esr_tp(xd.t().contiguous(), thd, FS, tgt, n, eps, skip, K, W,
+                                                 r=None if r is None else r.t().contiguous(), time_major=True)
+    assert float((yt - y).abs().max()) <= 1e-6
+    ok, info = close_grad(gt[idx], g[idx], rtol=2e-5)
+    assert ok, info
+
+
+def test_fused_esr_engine_step_with_adam_and_warm_start(wb):
+    """engine.MseStep(loss="mse+esr").step_fused: the bench's --loss mse+esr step; against the kernel-pair stepper at the
+    same parameters, Adam folded into the launch, warm-started chunks."""
+    from wdf_hip import engine
+    B, T, skip = 256, 4096, 50
+    x, th0, ths = problem(B, T, seed=9)
+    xd = dev(x)
+    xt = xd.t().contiguous()
+    tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, want_stash=False)
+    plan = engine.TpPlan(16, 192, 1e-6, 16)
+    one = engine.MseStep(B, T, FS, plan, xd.device, time_major=True, loss="mse+esr", skip=skip, warm=True)
+    pair = engine.MseStep(B, T, FS, plan, xd.device, time_major=True, loss="mse+esr", skip=skip)
+    theta = dev(th0)
+    lr = [1e-3 * float(v) for v in th0]
+    opt = wb.Adam(4, lr=lr, lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=xd.device)
+    opt_ref = wb.Adam(4, lr=lr, lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=xd.device)
+    theta_ref = theta.clone()
+    first = None
+    for it in range(8):
+        th_before = theta.clone()
+        one.step_fused(theta, xt, tgt, adam=opt)
+        pair.forward(th_before, xt)
+        _, g_ref = pair.backward(th_before, xt, tgt)
+        assert float((one.y - pair.y).abs().max()) <= Y_TOL, it
+        ok, info = close_grad(one.gtheta, g_ref)
+        assert ok, (it, info)
+        assert torch.allclose(one.loss, pair.loss, rtol=2e-5, atol=0), (it, one.loss, pair.loss)
+        opt_ref.apply(theta_ref, one.gtheta.clone())
+        assert torch.allclose(theta, theta_ref, rtol=1e-6, atol=0)
+        theta_ref.copy_(theta)
+        if it >= 2:
+            assert wb.tp_status(one.status)["n_bad"] == 0
+        first = float(one.loss[2]) if first is None else first
+    assert float(one.loss[2]) < first
