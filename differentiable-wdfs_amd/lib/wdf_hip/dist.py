@@ -91,3 +91,14 @@ def esr_sums_allreduce(S_local, E_local):
     buf = torch.tensor([float(S_local), float(E_local)], dtype=torch.float64)
     allreduce_sum_(buf)
     return float(buf[0]), float(buf[1])
+
+
+def esr_step_allreduce(S_local, E_local, gP_local, gQ_local, n_global, eps):
+    """The one-pass MSE + ESR step's single exchange (wdf_clipper_step_esr_tp, finish=False): every rank contributes
+    sums10 = {S, E, gP[4], gQ[4]} of its shard (gP = d(S/2)/dtheta, gQ = d(E/2)/dtheta); after ONE all-reduce of the ten
+    numbers every rank forms the global loss and gradient (wdf_esr_finish's formulas).  -> (mse + esr, grad[4])."""
+    buf = torch.cat([torch.as_tensor([float(S_local), float(E_local)], dtype=torch.float64),
+                     torch.as_tensor(gP_local, dtype=torch.float64).reshape(-1), torch.as_tensor(gQ_local, dtype=torch.float64).reshape(-1)])
+    allreduce_sum_(buf)
+    ga, gb, mse, esr = esr_coefficients(float(buf[0]), float(buf[1]), n_global, eps)
+    return mse + esr, ga * buf[2:6] + gb * buf[6:10]

@@ -74,8 +74,35 @@ def _worker_esr(rank, world, port, B, T, skip, out):
     torch.distributed.destroy_process_group()
 
 
+def _worker_esr_one_exchange(rank, world, port, B, T, skip, out):
+    """The one-pass MSE + ESR step (wdf_clipper_step_esr_tp): ONE exchange of ten numbers per step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    for p in (os.path.join(REPO, "oracle"), os.path.join(REPO, "differentiable-wdfs_amd", "lib")):
+        sys.path.insert(0, p)
+    import oracle as O
+    from wdf_hip import dist as wdist, workload
+    wdist.init(backend="gloo")
+    b0, b1 = wdist.shard_range(B, rank, world)
+    x = workload.sweep_batch(B, T, b0=b0, b1=b1, dtype=np.float64)
+    theta, fs = workload.clipper_theta(), workload.FS
+    tgt = O.clipper_fwd(workload.target_theta(), fs, x)
+    y = O.clipper_fwd(theta, fs, x)
+    d, yy = y - tgt, y.copy()
+    d[:skip] = 0.0
+    yy[:skip] = 0.0
+    _, gP = O.clipper_fwd_bwd(theta, fs, x, d)                           # d(S_local / 2)/dtheta
+    _, gQ = O.clipper_fwd_bwd(theta, fs, x, yy)                          # d(E_local / 2)/dtheta
+    loss, grad = wdist.esr_step_allreduce(np.sum(d * d), np.sum(yy * yy), gP, gQ, float(B * (T - skip)), np.finfo(float).eps)
+    if rank == 0:
+        out.put((float(loss), grad.numpy().copy()))
+    wdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_mse_esr_matches_single_rank(oracle):
+@pytest.mark.parametrize("worker", [_worker_esr, _worker_esr_one_exchange])
+def test_two_rank_gloo_mse_esr_matches_single_rank(oracle, worker):
     """Sharded MSE + ESR == the unsharded loss and gradient (torch float64 autograd of the loss as the
     script writes it, through the oracle's adjoint)."""
     from wdf_hip import workload
@@ -83,7 +110,7 @@ def test_two_rank_gloo_mse_esr_matches_single_rank(oracle):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_esr, args=(r, world, port, B, T, skip, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, B, T, skip, q)) for r in range(world)]
     for p in procs:
         p.start()
     loss, grad = q.get(timeout=240)
