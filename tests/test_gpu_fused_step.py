@@ -343,3 +343,21 @@ def test_fused_esr_engine_step_with_adam_and_warm_start(wb):
             assert wb.tp_status(one.status)["n_bad"] == 0
         first = float(one.loss[2]) if first is None else first
     assert float(one.loss[2]) < first
+
+
+def test_fused_randomized_plans_and_circuits(wb):
+    """tools/stress_tp.py's random cases through the one-pass step: random component values over the clip ranges of
+    tf_wdf.py:74,104, diode parameters and counts, amplitudes, shapes, layouts, chunkings, warm-ups (hopeless ones
+    included), warm starts from nearby or far-away parameters, one or two sequences per lane.  y must equal the
+    sequential forward to 2e-6 whatever the plan (repairs included), the tangent-carried gradient must agree with the
+    sequential reverse sweep."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_tp
+    worst_y = worst_g = worst_s = 0.0
+    repaired = 0
+    for case in range(60):
+        ey, eg, es, rep = stress_tp.run_case_one_pass(11, case)
+        worst_y, worst_g, worst_s, repaired = max(worst_y, ey), max(worst_g, eg), max(worst_s, es), repaired + rep
+    assert worst_y <= 2e-6 and worst_g <= 1e-3 and worst_s <= 1e-4, (worst_y, worst_g, worst_s)
+    assert repaired >= 5

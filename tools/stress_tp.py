@@ -63,6 +63,47 @@ def run_case(seed, case, oracle=None, verbose=False):
     return ey, eg, int(s["repaired_tiles"] > 0)
 
 
+def run_case_one_pass(seed, case):
+    """The one-pass training step (wdf_clipper_step_mse_tp) on the same random case: y against the sequential forward,
+    the tangent-carried gradient against the sequential reverse sweep with dL/dy = gscale (y - target), whatever the plan
+    (repairs included), one or two sequences per lane, warm-started or cold."""
+    q = case_params(seed, case)
+    B, T, n_up, n_down, tm, warm = q["B"], q["T"], q["n_up"], q["n_down"], q["tm"], q["warm"]
+    fs = workload.FS
+    xh = (workload.sweep_batch(B, T, seed=case) * q["amp"] / 5.0).astype(np.float32)
+    x = torch.as_tensor(xh, device="cuda")
+    th = torch.tensor([q["Is"], q["nVt"], q["R"], q["C"]], dtype=torch.float32, device="cuda")
+    xin = x.t().contiguous() if tm else x
+    tgt, _, _ = wb.clipper_fwd(x, th * torch.tensor([1.2, 0.95, 0.9, 1.1], device="cuda"), fs, n_up=n_up, n_down=n_down, want_stash=False)
+    y, zs, _ = wb.clipper_fwd(x, th, fs, n_up=n_up, n_down=n_down)
+    gscale = 2.0 / (B * T)
+    wb.ONE_SEQUENCE_PER_LANE = bool(case & 1)
+    try:
+        state = None
+        if warm:
+            state = wb.TpWarmState(B, T, q["K"], 8, x.device)
+            for m in (2.0, 1.0):
+                wb.clipper_step_mse_tp(xin, th * (1.0 - m * q["dth"]), fs, tgt, gscale, q["K"], q["W"], n_up=n_up, n_down=n_down,
+                                       time_major=tm, state=state)
+        y2, _, g2, sse, st = wb.clipper_step_mse_tp(xin, th, fs, tgt, gscale, q["K"], q["W"], n_up=n_up, n_down=n_down,
+                                                    time_major=tm, state=state)
+    finally:
+        wb.ONE_SEQUENCE_PER_LANE = False
+    s = wb.tp_status(st)
+    scale = max(1.0, float(y.abs().max()))
+    ey = float((y2 - y).abs().max()) / scale
+    assert ey <= 2e-6, (case, ey, s, q)
+    assert torch.isfinite(g2).all(), (case, g2, q)
+    # The reference sweep takes dL/dy from the one-pass step's OWN y: a speculative forward may differ from the sequential
+    # one by the verified tolerance, and where y - target is itself of that size (10 mV signals into a megohm) the loss and
+    # its gradient move by per cent with it -- in either form of the step.  What is compared here is the tangent machinery.
+    g1, _ = wb.clipper_bwd(x, th, fs, zs, (gscale * (y2 - tgt)).contiguous(), n_up=n_up, n_down=n_down)
+    eg = float(((g2 - g1).abs() / (g1.abs() + 1e-30 + 1e-3 * g1.abs().max())).max())
+    sse_ref = float(((y2 - tgt) ** 2).double().sum())
+    es = abs(float(sse) - sse_ref) / max(sse_ref, 1e-30)
+    return ey, eg, es, int(s["repaired_tiles"] > 0)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--case":                 # python tools/stress_tp.py --case <seed> <case>
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
@@ -80,3 +121,12 @@ if __name__ == "__main__":
             bad.append((case, eg))
     print(f"{n_cases} cases; worst relative y error {worst_y:.2e}, worst sweep mismatch {worst_g:.2e}; "
           f"{repaired} cases went through the repair path; sweep mismatches > 5e-4: {bad}")
+    worst_y = worst_g = worst_s = 0.0
+    repaired, bad = 0, []
+    for case in range(n_cases):
+        ey, eg, es, rep = run_case_one_pass(seed, case)
+        worst_y, worst_g, worst_s, repaired = max(worst_y, ey), max(worst_g, eg), max(worst_s, es), repaired + rep
+        if eg > 5e-4:
+            bad.append((case, eg))
+    print(f"one-pass step, {n_cases} cases; worst relative y error {worst_y:.2e}, worst gradient mismatch vs the sequential sweep "
+          f"{worst_g:.2e}, worst SSE mismatch {worst_s:.2e}; {repaired} cases went through the repair path; mismatches > 5e-4: {bad}")
