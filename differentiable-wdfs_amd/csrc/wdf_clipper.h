@@ -556,6 +556,20 @@ __device__ __forceinline__ float load_published(const float* p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// N adjacent published floats (N = 2: one 8-byte load; p 8-byte aligned)
+template <int N>
+__device__ __forceinline__ void load_published_n(const float* p, float (&v)[N])
+{
+    if constexpr (N == 2) {
+        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[0] = __uint_as_float((unsigned)u);
+        v[1] = __uint_as_float((unsigned)(u >> 32));
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = load_published(p + i);
+    }
+}
+
 // Row store: `row` is a wave-uniform pointer to a [B] row of a time-major array, the lane adds its
 // 32-bit byte offset.  Written this way the store is `global_store_dword voff, vdata, s[row]`: the
 // row pointer advances on the scalar unit and the step spends no VALU instruction on addresses
@@ -790,28 +804,27 @@ __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, 
     const int64_t b_first = b_raw < B ? b_raw : B - NSEQ;
     float miss = 0.0f;
     int nbad = 0;
-    // 16 boundaries' 32 loads in flight together: one at a time this loop is K dependent round trips
+    // 16 boundaries' loads in flight together (the lane's NSEQ adjacent sequences in one load each): one at a time this
+    // loop is K dependent round trips
     constexpr int kBatch = 16;
-#pragma unroll 1
-    for (int h = 0; h < NSEQ; ++h) {
-        const int64_t b = b_first + h;
-        for (int64_t k0 = 1; k0 < K; k0 += kBatch) {
-            float zw[kBatch], ze[kBatch];
+    for (int64_t k0 = 1; k0 < K; k0 += kBatch) {
+        float zw[kBatch][NSEQ], ze[kBatch][NSEQ];
 #pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                const int64_t k = (k0 + j < K) ? k0 + j : K - 1;   // clamped: re-reads the last boundary
-                zw[j] = load_published(zwarm + k * B + b);
-                ze[j] = load_published(zend + (k - 1) * B + b);
-            }
+        for (int j = 0; j < kBatch; ++j) {
+            const int64_t k = (k0 + j < K) ? k0 + j : K - 1;   // clamped: re-reads the last boundary
+            load_published_n<NSEQ>(zwarm + k * B + b_first, zw[j]);
+            load_published_n<NSEQ>(zend + (k - 1) * B + b_first, ze[j]);
+        }
 #pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                const float m = fabsf(zw[j] - ze[j]);
+        for (int j = 0; j < kBatch; ++j)
+#pragma unroll
+            for (int h = 0; h < NSEQ; ++h) {
+                const float m = fabsf(zw[j][h] - ze[j][h]);
                 if (k0 + j < K) {
                     miss = fmaxf(miss, m);
                     nbad += !(m <= tol) ? 1 : 0;                    // NaN counts as bad
                 }
             }
-        }
     }
     float wmax = miss;
     int wbad = nbad;

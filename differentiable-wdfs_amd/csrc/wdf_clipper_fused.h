@@ -556,55 +556,47 @@ __device__ __forceinline__ void fused_combine_tile(const float* rec, int64_t K, 
     const bool live = raw < B;
     const int64_t b0 = live ? raw : B - NSEQ;
     double dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0, qL = 0.0, qV = 0.0, qP = 0.0, qE = 0.0;
-#pragma unroll 1
-    for (int h = 0; h < NSEQ; ++h) {
-        const int64_t b = b0 + h;
-        double sL = 0.0, sV = 0.0, sP = 0.0;              // tangent entering the chunk (z0 does not depend on theta)
-        constexpr int kAhead = LOSS == 2 ? 4 : 8;         // chunks whose records are in flight together
-        int64_t k = 0;
-        for (; k + kAhead <= K; k += kAhead) {
-            float v[kAhead][NREC];
+    double sL[NSEQ], sV[NSEQ], sP[NSEQ];                  // tangent entering the chunk (z0 does not depend on theta)
 #pragma unroll
-            for (int j = 0; j < kAhead; ++j)
+    for (int h = 0; h < NSEQ; ++h) sL[h] = sV[h] = sP[h] = 0.0;
+    // records of kAhead chunks in flight together, the lane's NSEQ adjacent sequences in one load each: the walk is
+    // K / kAhead dependent round trips on the step's critical path (the last tile's tail)
+    constexpr int kAhead = (LOSS == 2 ? 4 : 8) / (NSEQ == 2 && LOSS == 2 ? 1 : 1);
+    auto step = [&](const float (&v)[NREC][NSEQ]) {
 #pragma unroll
-                for (int i = 0; i < NREC; ++i) v[j][i] = load_published(rec + ((k + j) * NREC + i) * B + b);
-#pragma unroll
-            for (int j = 0; j < kAhead; ++j) {
-                const double A = v[j][0], GA = v[j][4];
-                dL += sL * GA + (double)v[j][5];
-                dV += sV * GA + (double)v[j][6];
-                dP += sP * GA + (double)v[j][7];
-                dS += (double)v[j][8];
-                if constexpr (LOSS == 2) {
-                    const double HA = v[j][9];
-                    qL += sL * HA + (double)v[j][10];
-                    qV += sV * HA + (double)v[j][11];
-                    qP += sP * HA + (double)v[j][12];
-                    qE += (double)v[j][13];
-                }
-                sL = A * sL + (double)v[j][1];
-                sV = A * sV + (double)v[j][2];
-                sP = A * sP + (double)v[j][3];
-            }
-        }
-        for (; k < K; ++k) {
-            const float* o = rec + (k * NREC) * B + b;
-            const double A = load_published(o), GA = load_published(o + 4 * B);
-            dL += sL * GA + (double)load_published(o + 5 * B);
-            dV += sV * GA + (double)load_published(o + 6 * B);
-            dP += sP * GA + (double)load_published(o + 7 * B);
-            dS += (double)load_published(o + 8 * B);
+        for (int h = 0; h < NSEQ; ++h) {
+            const double A = v[0][h], GA = v[4][h];
+            dL += sL[h] * GA + (double)v[5][h];
+            dV += sV[h] * GA + (double)v[6][h];
+            dP += sP[h] * GA + (double)v[7][h];
+            dS += (double)v[8][h];
             if constexpr (LOSS == 2) {
-                const double HA = load_published(o + 9 * B);
-                qL += sL * HA + (double)load_published(o + 10 * B);
-                qV += sV * HA + (double)load_published(o + 11 * B);
-                qP += sP * HA + (double)load_published(o + 12 * B);
-                qE += (double)load_published(o + 13 * B);
+                const double HA = v[9][h];
+                qL += sL[h] * HA + (double)v[10][h];
+                qV += sV[h] * HA + (double)v[11][h];
+                qP += sP[h] * HA + (double)v[12][h];
+                qE += (double)v[13][h];
             }
-            sL = A * sL + (double)load_published(o + 1 * B);
-            sV = A * sV + (double)load_published(o + 2 * B);
-            sP = A * sP + (double)load_published(o + 3 * B);
+            sL[h] = A * sL[h] + (double)v[1][h];
+            sV[h] = A * sV[h] + (double)v[2][h];
+            sP[h] = A * sP[h] + (double)v[3][h];
         }
+    };
+    int64_t k = 0;
+    for (; k + kAhead <= K; k += kAhead) {
+        float v[kAhead][NREC][NSEQ];
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j)
+#pragma unroll
+            for (int i = 0; i < NREC; ++i) load_published_n<NSEQ>(rec + ((k + j) * NREC + i) * B + b0, v[j][i]);
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) step(v[j]);
+    }
+    for (; k < K; ++k) {
+        float v[NREC][NSEQ];
+#pragma unroll
+        for (int i = 0; i < NREC; ++i) load_published_n<NSEQ>(rec + (k * NREC + i) * B + b0, v[i]);
+        step(v);
     }
     if (!live) { dL = dV = dP = dS = qL = qV = qP = qE = 0.0; }
     if constexpr (LOSS == 2) {
