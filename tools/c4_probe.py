@@ -42,3 +42,24 @@ for tm in (False, True):
             ms = e0.elapsed_ms(e1) / 20
             print(f"time_major={tm} one-pass step: chunks {k} (W={tuned.warmup}) warm={warm}: {ms:.3f} ms/step = {B * T / ms / 1e6:.1f} G samples/s  "
                   f"{wb.tp_status(st.status)} {st.warm.info() if st.warm is not None else ''}")
+
+# the training loop itself at this shape: MSE + ESR past 50 samples in one pass, Adam on {Is, nVt, C} in the launch (the pot
+# resistance is data), parameters moving every step -- what the warm start has to cope with at 99.1 kOhm
+th_host = workload.clipper_theta()
+for tm in (True,):
+    xin, rin = (x.t().contiguous(), r.t().contiguous()) if tm else (x, r)
+    for k in (8, 16, 32):
+        theta = torch.tensor(th_host, dtype=torch.float32, device="cuda")
+        adam = wb.Adam(4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device="cuda")
+        plan = engine.TpPlan(k, 448, 1e-6, 16)
+        st = engine.MseStep(B, T, fs, plan, "cuda", time_major=tm, loss="mse+esr", skip=50, warm=True, max_warm_tiles=16)
+        for _ in range(12):
+            st.step_fused(theta, xin, tgt, r=rin, adam=adam)
+        e0, e1 = wb.Event(), wb.Event()
+        e0.record()
+        for _ in range(20):
+            st.step_fused(theta, xin, tgt, r=rin, adam=adam)
+        e1.record()
+        ms = e0.elapsed_ms(e1) / 20
+        print(f"training loop (MSE + ESR, Adam in the launch), one-pass step, chunks {k}: {ms:.3f} ms/step = {B * T / ms / 1e6:.1f} G samples/s  "
+              f"{wb.tp_status(st.status)} {st.warm.info()} loss {[float(v) for v in st.loss]}")
