@@ -284,7 +284,7 @@ static int fwd_tp_common(const float* x, const float* r, const float* theta, flo
     if (!y || !ws || !status) return fail(WDF_EINVAL, "null y/ws/status");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
     if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
-    if (B >= ((int64_t)1 << 30)) return fail(WDF_EINVAL, "time-parallel kernels address a [B] row with 32-bit byte offsets: B < 2^30");
+    if (B >= ((int64_t)1 << 24)) return fail(WDF_EINVAL, "the time-parallel forward addresses a 16-row tile with 32-bit offsets: B < 2^24");
     if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 applies to wdf_clipper_fwd and wdf_omega_f64 only");
     const TpGeom g = tp_geom(T, n_chunks);
     const int64_t W = ((int64_t)warmup + wdf::kTile - 1) / wdf::kTile * wdf::kTile;

@@ -618,110 +618,7 @@ __device__ __forceinline__ V gather_t(const float (&v)[VT<V>::N][kTile], int i)
     return r;
 }
 
-// Chunk geometry: L and W are multiples of kTile (host guarantees it).  TM: x and r are [T][B].
-// ctl / snap: warm-start control block and snapshot ring [kTpRing][J][K][B] (nullptr: stateless, cold).
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V, bool FAST>
-__device__ __forceinline__ void clipper_fwd_tp_body(
-    const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r, float* __restrict__ y,
-    float* __restrict__ zstash, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
-    float* __restrict__ zend, const float* __restrict__ theta, const TpCtl* __restrict__ ctl, float* __restrict__ snap,
-    int J, int64_t B, int64_t Bh, int64_t T, int64_t L, int64_t W)
-{
-    constexpr int N = VT<V>::N;
-    const LaneSeqs<V> q(B, Bh);
-    const int64_t k = blockIdx.y, K = gridDim.y;
-    const int64_t t0 = k * L;                               // first owned step (multiple of kTile)
-    const int64_t t1 = (t0 + L < T) ? t0 + L : T;           // one past the last owned step
-    int64_t tw = 0;                                         // first step run (multiple of kTile)
-    V z = vsplat<V>(0.0f);
-    const bool stateful = ctl != nullptr && ctl->geom == (int)((K << 8) | J);
-    const int valid = stateful ? ctl->valid : 0;
-    const int head = stateful ? ctl->head : 0;
-    if (k > 0 && valid > 0) {                               // warm: the last call's state 32 j steps before t0
-        const int j = ctl->j_next;
-        tw = t0 - (int64_t)kTile * j;
-        const float* __restrict__ s1 = snap + (((int64_t)head * J + j) * K + (k - 1)) * B;
-        z = load_one_v<V>(s1, q, 1, 0, 0);
-        if (valid > 1) {                                    // ... extrapolated along the parameter path
-            const float* __restrict__ s2 = snap + (((int64_t)((head + kTpRing - 1) % kTpRing) * J + j) * K + (k - 1)) * B;
-            const V zo = load_one_v<V>(s2, q, 1, 0, 0);
-            z = vfma(vsplat<V>(tp_secant_factor(theta, ctl)), z - zo, z);
-        }
-    } else {                                                // cold: W steps early from z = 0
-        tw = (t0 > W) ? t0 - W : 0;
-        if (tw == 0 && z0) z = load_one_v<V>(z0, q, 1, 0, 0);
-    }
-    // this call's snapshots go to the next ring slot; the last chunk has no successor
-    float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)((head + 1) % kTpRing) * J * K + k) * B : nullptr;
-
-    float xc[N][kTile], xn[N][kTile], rc[N][kTile], rn[N][kTile];
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-#pragma unroll
-        for (int i = 0; i < kTile; ++i) { xc[j][i] = xn[j][i] = 0.0f; rc[j][i] = rn[j][i] = 1.0f; }
-    const int64_t nfull_end = t1 - (t1 - tw) % kTile;       // full tiles cover [tw, nfull_end)
-    if (tw < nfull_end) {
-        load_tile_v<V, TM, VEC4>(x, q, B, T, tw, xn);
-        if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, tw, rn);
-    }
-    float* __restrict__ yrow = y + t0 * B;                   // wave-uniform row pointers
-    float* __restrict__ zrow = STASH ? zstash + t0 * B : nullptr;
-    // Two loops, not one loop with a branch: the s_waitcnt the compiler places before the tile
-    // copy has to hold for every path into it, and behind the store-free warm-up path only
-    // vmcnt(0) does -- which, on the owned path, would drain all of a tile's stores.
-    int64_t t = tw;
-    for (; t < t0 && t < nfull_end; t += kTile) {           // ---- warm-up tiles: nothing stored
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-#pragma unroll
-            for (int i = 0; i < kTile; ++i) { xc[j][i] = xn[j][i]; if constexpr (DYN_R) rc[j][i] = rn[j][i]; }
-        if (t + kTile < nfull_end) {                        // next tile: one whole line per lane, a tile ahead
-            load_tile_v<V, TM, VEC4>(x, q, B, T, t + kTile, xn);
-            if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, t + kTile, rn);
-        }
-#pragma unroll
-        for (int i = 0; i < kTile; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z);
-    }
-    publish_v<V>(zwarm, q, k * B, z);                       // the state this chunk arrives with at t0
-    for (; t < nfull_end; t += kTile) {                     // ---- owned tiles
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-#pragma unroll
-            for (int i = 0; i < kTile; ++i) { xc[j][i] = xn[j][i]; if constexpr (DYN_R) rc[j][i] = rn[j][i]; }
-        const bool more = t + kTile < nfull_end;
-        if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1))       // snapshot 32 j steps before the chunk's end
-            store_v<V>(snapw, q, ((t1 - t) / kTile) * K * B, z);
-        // The prefetch goes in the MIDDLE of the tile: vmcnt counts loads and stores in one queue
-        // (6 bits), so with the loads issued first the 64 stores of a tile behind them cannot be
-        // expressed and the latch waits for vmcnt(0), draining every store once per tile
-        // (measured: 16 % of the kernel).  Issued after half the steps, only 32 stores are younger
-        // than the loads and the latch waits for the loads alone.
-#pragma unroll
-        for (int i = 0; i < kTile; ++i) {
-            if (i == kTile / 2) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    load_tile_v<V, TM, VEC4>(x, q, B, T, t + kTile, xn);
-                    if constexpr (DYN_R) load_tile_v<V, TM, VEC4>(r, q, B, T, t + kTile, rn);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (STASH) { store_row_v<V>(zrow, q, z); zrow += B; }
-            store_row_v<V>(yrow, q, fwd_step<DYN_R, SYM, V, FAST>(c, gather_t<V>(xc, i), gather_t<V>(rc, i), z));
-            yrow += B;
-        }
-    }
-    for (int64_t t = nfull_end; t < t1; ++t) {              // tail of the last chunk (T % 32)
-        const V xin = load_one_v<V>(x, q, TM ? 1 : T, TM ? B : 1, t);
-        const V rin = DYN_R ? load_one_v<V>(r, q, TM ? 1 : T, TM ? B : 1, t) : vsplat<V>(1.0f);
-        if constexpr (STASH) { store_row_v<V>(zrow, q, z); zrow += B; }
-        store_row_v<V>(yrow, q, fwd_step<DYN_R, SYM, V, FAST>(c, xin, rin, z));
-        yrow += B;
-    }
-    publish_v<V>(zend, q, k * B, z);
-    if (snapw != nullptr) store_v<V>(snapw, q, 0, z);        // snapshot 0 = the end state
-    if (zT && t1 == T) store_v<V>(zT, q, 0, z);
-}
+// (The time-parallel forward itself -- chunk body and kernel -- lives in wdf_clipper_fused.h, on the one-pass step's body.)
 
 // Re-run of chunk [t0, t1) for this wave's 64 sequences from the exact state z, 8 steps at a time.
 // With a stash (and `may_stop`: the speculative pass's stash is readable from here) the re-run stops
@@ -949,26 +846,6 @@ __global__ __launch_bounds__(64) void clipper_tp_repair_kernel(
         tile_bad[blockIdx.x] = 0u;
         if (nrep) atomicAdd(&status->fallback_ran, nrep);
     }
-}
-
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V>
-__global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
-    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
-    float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
-    const float* __restrict__ z0, float* __restrict__ zT, float* zwarm, float* zend,
-    TpStatus* __restrict__ status, TpCtl* ctl, float* snap, int J, unsigned* tickets, float tol, int64_t B,
-    int64_t Bh, int64_t T, int64_t L, int64_t W, int general)
-{
-    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    bool fast = false;
-    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);     // wave-uniform: every practical diode
-    if (fast)
-        clipper_fwd_tp_body<DYN_R, SYM, TM, VEC4, STASH, V, !DYN_R>(c, x, r, y, zstash, z0, zT, zwarm, zend, theta, ctl, snap,
-                                                                    J, B, Bh, T, L, W);
-    else
-        clipper_fwd_tp_body<DYN_R, SYM, TM, VEC4, STASH, V, false>(c, x, r, y, zstash, z0, zT, zwarm, zend, theta, ctl, snap,
-                                                                   J, B, Bh, T, L, W);
-    tp_finish<DYN_R>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
 }
 
 // ---- exact time-parallel reverse sweep ----------------------------------------------------------

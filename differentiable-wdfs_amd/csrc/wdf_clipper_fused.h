@@ -343,10 +343,12 @@ __device__ __forceinline__ void fused_publish_record(float* rec, int64_t k, int6
 }
 
 // Chunk geometry as clipper_fwd_tp_body (L, W multiples of kTile); target [T][B]; skip: steps below it carry no loss.
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool FAST, typename V, int LOSS>
+// LOSS = 0: the plain time-parallel forward (no target, no tangent, no record; STASH: the state before every step goes to
+// zstash [T][B] for the reverse sweep) -- clipper_fwd_tp_kernel below runs this same body.
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool FAST, typename V, int LOSS, bool STASH = false>
 __device__ __forceinline__ void clipper_fused_body(
     const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ target,
-    float* __restrict__ y, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
+    float* __restrict__ y, float* __restrict__ zstash, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
     float* __restrict__ zend, float* rec, const float* __restrict__ theta, const TpCtl* __restrict__ ctl,
     float* __restrict__ snap, int J, int64_t B, int64_t T, int64_t L, int64_t W, float hgs, int64_t skip)
 {
@@ -387,7 +389,7 @@ __device__ __forceinline__ void clipper_fused_body(
     if (tw < nfull_end) {
         load_x_tile<V, TM, VEC4, NR>(x, q, B, T, tw, rowb, xn);
         if constexpr (DYN_R) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, tw, rowb, rn);
-        if (tw >= t0) load_rows<V, NR>(target + tw * B, boff, rowb, gn);
+        if constexpr (LOSS != 0) { if (tw >= t0) load_rows<V, NR>(target + tw * B, boff, rowb, gn); }
     }
     int64_t t = tw;
 #ifdef WDF_DBG_TIMES
@@ -399,7 +401,7 @@ __device__ __forceinline__ void clipper_fused_body(
         if (t + NR < nfull_end) {
             load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
             if constexpr (DYN_R) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, t + NR, rowb, rn);
-            if (t + NR >= t0) load_rows<V, NR>(target + (t + NR) * B, boff, rowb, gn);   // the first owned tile's target
+            if constexpr (LOSS != 0) { if (t + NR >= t0) load_rows<V, NR>(target + (t + NR) * B, boff, rowb, gn); }   // the first owned tile's target
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) (void)fwd_step<DYN_R, SYM, V, FAST>(c, xc[i], rc[i], z);
@@ -426,6 +428,7 @@ __device__ __forceinline__ void clipper_fused_body(
         if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1) && (t1 - t) % kTile == 0)
             store_own<V>(snapw + ((t1 - t) / kTile) * K * B, q, z);       // snapshot 32 j steps before the chunk's end
         const __amdgpu_buffer_rsrc_t ry = row_rsrc(y + t * B);
+        const __amdgpu_buffer_rsrc_t rz = row_rsrc(STASH ? zstash + t * B : y + t * B);
         // steps of this tile below `skip` carry no loss (skip_samples = 50, clipper_pot.py:232): their number, a scalar
         const int64_t below = skip - t;
         const int n_masked = __builtin_amdgcn_readfirstlane((int)(below < 0 ? 0 : (below > NR ? NR : below)));
@@ -439,9 +442,14 @@ __device__ __forceinline__ void clipper_fused_body(
                 if (more) {
                     load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
                     if constexpr (DYN_R) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, t + NR, rowb, rn);
-                    load_rows<V, NR>(target + (t + NR) * B, boff, rowb, gn);
+                    if constexpr (LOSS != 0) load_rows<V, NR>(target + (t + NR) * B, boff, rowb, gn);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (LOSS == 0) {
+                if constexpr (STASH) buf_store_nt(z, rz, boff, i * rowb);
+                buf_store_nt(fwd_step<DYN_R, SYM, V, FAST>(c, xc[i], rc[i], z), ry, boff, i * rowb);
+                continue;
             }
             buf_store_nt(fused_step<DYN_R, SYM, FAST, V, LOSS>(c, xc[i], rc[i], gc[i], step_loss_scale(i, n_masked, hgs), z, s), ry, boff,
                          i * rowb);
@@ -461,13 +469,18 @@ __device__ __forceinline__ void clipper_fused_body(
 #ifdef WDF_DBG_TIMES
         { const unsigned long long w0 = __builtin_amdgcn_s_memtime(); wait_vmcnt<NR>(); dbg_wait += __builtin_amdgcn_s_memtime() - w0; }
 #else
-        wait_vmcnt<NR>();
+        wait_vmcnt<NR * (STASH ? 2 : 1)>();
 #endif
         d.template flush<LOSS>(s);
     }
     for (int64_t tt = nfull_end; tt < t1; ++tt) {           // tail of the last chunk (T % NR)
         const V xin = load_step<V, TM>(x, q, B, T, tt);
         const V rin = DYN_R ? load_step<V, TM>(r, q, B, T, tt) : vsplat<V>(1.0f);
+        if constexpr (LOSS == 0) {
+            if constexpr (STASH) store_own<V>(zstash + tt * B, q, z);
+            store_own<V>(y + tt * B, q, fwd_step<DYN_R, SYM, V, FAST>(c, xin, rin, z));
+            continue;
+        }
         const V tg = load_own<V>(target + tt * B, q);
         store_own<V>(y + tt * B, q, fused_step<DYN_R, SYM, FAST, V, LOSS>(c, xin, rin, tg, tt >= skip ? hgs : 0.0f, z, s));
     }
@@ -475,7 +488,7 @@ __device__ __forceinline__ void clipper_fused_body(
     publish_own<V>(zend + k * B, q, z);
     if (snapw != nullptr) store_own<V>(snapw, q, z);
     if (zT && t1 == T) store_own<V>(zT, q, z);
-    fused_publish_record<V, LOSS>(rec, k, q.b, B, s, d, hgs);
+    if constexpr (LOSS != 0) fused_publish_record<V, LOSS>(rec, k, q.b, B, s, d, hgs);
 #ifdef WDF_DBG_TIMES
     dbg_p[4] = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0 && g_dbg_times) {
@@ -627,10 +640,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     bool fast = false;
     if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
     if (fast)
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R, V, LOSS>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
                                                             T, L, W, hgs, skip);
     else
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, LOSS>(c, x, r, target, y, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
                                                            T, L, W, hgs, skip);
 #ifdef WDF_DBG_TIMES
     if (threadIdx.x == 0 && g_dbg_times) {
@@ -642,6 +655,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     const bool failed = tp_verify_tile<DYN_R, VT<V>::N>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
     if (failed) return;                                     // left to clipper_fused_repair_kernel
     fused_combine_tile<VT<V>::N, LOSS>(rec, gridDim.y, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, out, sh);
+}
+
+// The time-parallel FORWARD (wdf_clipper_fwd_tp / _warm: y and the state stash for a reverse sweep that arbitrary losses
+// drive) on the same body: buffer-descriptor rows, 16-row tiles prefetched a tile ahead, the wait on the back edge.
+// Verification and warm-start steering in its last waves (tp_finish), repairs in clipper_tp_repair_kernel (wdf_clipper.h).
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V>
+__global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
+    float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
+    const float* __restrict__ z0, float* __restrict__ zT, float* zwarm, float* zend,
+    TpStatus* __restrict__ status, TpCtl* ctl, float* snap, int J, unsigned* tickets, float tol, int64_t B,
+    int64_t Bh, int64_t T, int64_t L, int64_t W, int general)
+{
+    static_assert(VT<V>::N == 1, "one sequence per lane (the repair kernel and tp_finish index tiles of 64)");
+    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+    bool fast = false;
+    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);     // wave-uniform: every practical diode
+    if (fast)
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
+                                                                      ctl, snap, J, B, T, L, W, 0.0f, 0);
+    else
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
+                                                                     ctl, snap, J, B, T, L, W, 0.0f, 0);
+    tp_finish<DYN_R>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
 }
 
 // Re-run of chunk [t0, t1) for 64 sequences (one per lane, index b) from the exact state z: outputs, snapshots, record.
