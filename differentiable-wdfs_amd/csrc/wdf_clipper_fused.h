@@ -45,21 +45,22 @@ constexpr int kFsOut = 9;       // record floats per (chunk, sequence), MSE: {A,
 constexpr int kFsOutEsr = 14;   // MSE + ESR adds the y-weighted sums {HA, H[3], SYY}
 template <int LOSS> struct FusedRec { static constexpr int N = LOSS == 2 ? kFsOutEsr : kFsOut; };
 constexpr int kFusedSchedGroup = 1;   // steps the instruction scheduler may interleave
+// Build-time knobs of the A/B runs recorded in DESIGN.md (tools/ab_libs.sh builds variants with -D...)
 #ifndef WDF_FUSED_ROWS
-#define WDF_FUSED_ROWS 16
+#define WDF_FUSED_ROWS 16           // rows per load burst with one sequence per lane and a static resistance
 #endif
 #ifndef WDF_FUSED_PREFETCH_AT
-#define WDF_FUSED_PREFETCH_AT 0     // 0: top of the tile, 1: middle
+#define WDF_FUSED_PREFETCH_AT 0     // 0: the next tile's loads at the top of the tile, 1: in its middle
+#endif
+#ifndef WDF_FUSED_WAVES
+#define WDF_FUSED_WAVES 2           // waves per SIMD the one-pass kernel's register allocation is held to
 #endif
 constexpr int kFusedPrefetchAt = WDF_FUSED_PREFETCH_AT;
-#ifndef WDF_FUSED_WAVES
-#define WDF_FUSED_WAVES 2
-#endif
 constexpr int kFusedRows = WDF_FUSED_ROWS;
 
-// Steps per load burst: the 32-step chunk-geometry tile with one sequence per lane and a static resistance, half of
-// it with two sequences per lane, half again with the per-sample resistance channel (the tile buffers are the bulk of
-// the VGPRs: x, target and r, current and next, and the kernel is held to two waves per SIMD).
+// Steps per load burst: 16 with one sequence per lane and a static resistance, half of that with two sequences per
+// lane, half again with the per-sample resistance channel (the tile buffers are the bulk of the VGPRs: x, target and r,
+// current and next; a tile's loads + stores must also stay inside vmcnt's 6 bits).
 template <typename V, bool DYN_R> struct FusedTile { static constexpr int NR = kFusedRows / VT<V>::N / (DYN_R ? 2 : 1); };
 
 // s_waitcnt vmcnt(N) (gfx9 encoding: vmcnt in bits 3:0 and 15:14; expcnt / lgkmcnt fields at "no wait").
@@ -574,7 +575,7 @@ __device__ __forceinline__ void fused_combine_tile(const float* rec, int64_t K, 
     for (int h = 0; h < NSEQ; ++h) sL[h] = sV[h] = sP[h] = 0.0;
     // records of kAhead chunks in flight together, the lane's NSEQ adjacent sequences in one load each: the walk is
     // K / kAhead dependent round trips on the step's critical path (the last tile's tail)
-    constexpr int kAhead = (LOSS == 2 ? 4 : 8) / (NSEQ == 2 && LOSS == 2 ? 1 : 1);
+    constexpr int kAhead = LOSS == 2 ? 4 : 8;
     auto step = [&](const float (&v)[NREC][NSEQ]) {
 #pragma unroll
         for (int h = 0; h < NSEQ; ++h) {
