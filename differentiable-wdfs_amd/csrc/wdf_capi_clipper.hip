@@ -129,7 +129,7 @@ void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs,
                    const float* zstash, const float* gy, const float* target, const float* zT, float gscale,
                    float* part, double* ws, float* gz0, int64_t B, int64_t T, TpGeom g, const float* gcoef,
                    int64_t skip, unsigned* tickets, float* gtheta, int accumulate, float* sse_out, wdf::AdamTail adam,
-                   hipStream_t s)
+                   int general, hipStream_t s)
 {
     const dim3 grid((unsigned)((B + 63) / 64), (unsigned)g.K);
     // ONE launch: the sweep; the last chunk wave of every tile combines the tile's chunk records, the last
@@ -137,7 +137,7 @@ void launch_bwd_tp(const float* x, const float* r, const float* theta, float fs,
 #define WDF_BWD_TP(MSE_)                                                                                     \
     hipLaunchKernelGGL((wdf::clipper_bwd_tp_kernel<DYN_R, SYM, TM, V4, MSE_, float>), grid, dim3(64), 0, s, x, r, theta, \
                        fs, n_up, n_down, zstash, gy, target, zT, gscale, part, B, B, T, g.L, gcoef, skip, tickets, ws,   \
-                       gz0, gtheta, accumulate, sse_out, adam)
+                       gz0, gtheta, accumulate, sse_out, adam, general)
     EventBracket bracket(s);
     if (gcoef) WDF_BWD_TP(2);                                // MSE + ESR
     else if (target) WDF_BWD_TP(1);
@@ -409,7 +409,7 @@ static int bwd_tp_common(const float* x, const float* r, const float* theta, flo
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH4(launch_bwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy, target,
                   zT, gscale, part, wsd, gz0, B, T, g, gcoef, skip,
-                  ticket, gtheta, accumulate, target ? sse : nullptr, adam, (hipStream_t)stream);
+                  ticket, gtheta, accumulate, target ? sse : nullptr, adam, (flags & WDF_GENERAL_ROOT) ? 1 : 0, (hipStream_t)stream);
     return check_launch("wdf_clipper_bwd_tp");
 }
 

@@ -863,7 +863,14 @@ struct TpAccT {
 // (The forward's FAST variant was tried here too: 10 % fewer VALU instructions, no change in run
 // time -- the sweep is not bound by instruction issue, see DESIGN.md -- so the reverse sweep keeps
 // the one general step.)
-template <bool DYN_R, bool SYM, typename V>
+__device__ __forceinline__ float vsel_nonzero(float a, float x, float y) { return a != 0.0f ? x : y; }
+__device__ __forceinline__ v2f vsel_nonzero(v2f a, float x, float y) { return v2f{a.x != 0.0f ? x : y, a.y != 0.0f ? x : y}; }
+
+// FAST (static port resistance, omega_1 in its series-only region: the same wave-uniform test as the forward): the root
+// is recomputed with the forward's own shorter arithmetic and, for a symmetric pair, the partials take the one-pass
+// step's cheaper forms (wdf_clipper_fused.h, fused_step).  The sweep at 4 waves per SIMD is bound by VALU issue since the
+// loads stopped being the limit, so the ~40 % fewer instructions count.
+template <bool DYN_R, bool SYM, typename V, bool FAST = false>
 __device__ __forceinline__ void bwd_tp_step(const ClipConsts& c, V xin, V rin, V z, V g, V& alpha, V& beta,
                                             TpAccT<V>& acc)
 {
@@ -871,14 +878,22 @@ __device__ __forceinline__ void bwd_tp_step(const ClipConsts& c, V xin, V rin, V
     step_coeffs<DYN_R, V>(c, rin, p, Rp, L);
     const V b_diff = z - xin;
     const V a = z - p * b_diff;
-    const DiodeOutT<V> o = diode_pair<SYM, V>(a, L, c.d);
+    const DiodeOutT<V> o = diode_pair<SYM, V, FAST>(a, L, c.d);
     const V w0p = o.w0 * vrcp(o.w0 + 1.0f);
+    V Da, DL, DV;
+    if constexpr (SYM && FAST) {
+        const V w1p = o.w1 * vfma(-o.w1, vfma(-o.w1, 1.0f - o.w1, 1.0f), 1.0f);   // omega_1 <= 0.018: series of w/(1+w)
+        const V sp = w0p + w1p;
+        const V tl = vsel_nonzero(a, -2.0f, 0.0f);                                  // -2 lam^2
+        Da = vfma(tl, sp, 1.0f);
+        DL = (-(c.d.two_v * c.d.m_dn)) * vcopysign(w0p - w1p, a);
+        DV = vfma(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * vcopysign(o.w0 - o.w1, a));
+    } else {
     const V w1p = o.w1 * vrcp(o.w1 + 1.0f);
     const V l2 = o.lam * o.lam;
     const V sp = w0p + w1p;
     const V tl = -2.0f * l2;
-    const V Da = vfma(tl, sp, 1.0f);
-    V DL, DV;
+    Da = vfma(tl, sp, 1.0f);
     if constexpr (SYM) {
         const float tvm = c.d.two_v * c.d.m_dn;
         DL = (-tvm) * (o.lam * (w0p - w1p));
@@ -886,6 +901,7 @@ __device__ __forceinline__ void bwd_tp_step(const ClipConsts& c, V xin, V rin, V
     } else {
         DL = (-c.d.two_v) * (o.lam * (o.m0 * w0p - o.m1 * w1p));
         DV = vfma(tl * a, sp * (-1.0f / c.V), -2.0f * (o.lam * (o.m0 * o.w0 - o.m1 * o.w1)));
+    }
     }
     const V opd = Da + 1.0f;
     V cP = -opd * b_diff;
@@ -1044,18 +1060,48 @@ __device__ __forceinline__ void bwd_tp_finish(const float* part, int64_t B, doub
 // MSE: `gy` is unused, `target` [T][B] the training target, zT [B] the final state of the forward
 // (needed for y[T-1]); dL/dy = gscale (y - target), gscale = 2/N for a mean over N samples; the
 // kernel also returns sum (y - target)^2.
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, int MSE, typename V>
-__global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
-    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
-    float fs, int n_up, int n_down, const float* __restrict__ zstash, const float* __restrict__ gy,
+// Time steps per register block of the time-parallel reverse sweep (three read streams prefetched one block ahead).
+// 8: measured against 16 and 32 (tools/ab_libs.sh, -DWDF_BWD_BLOCK=...): the longer prefetch distance costs the
+// registers of two / three waves per SIMD and loses (0.110 / 0.121 / 0.133 ms on one box) -- the sweep hides its
+// latencies with waves, not with distance.
+#ifndef WDF_BWD_BLOCK
+#define WDF_BWD_BLOCK 8
+#endif
+constexpr int kBwdBlk = WDF_BWD_BLOCK;
+
+template <typename V, bool TIME_MAJOR, bool VEC4, int NB>
+__device__ __forceinline__ void load_blockn_v(const float* __restrict__ x, const LaneSeqs<V>& q, int64_t B, int64_t T,
+                                              int64_t t0, float (&v)[VT<V>::N][NB])
+{
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) {
+        if constexpr (TIME_MAJOR) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) v[j][k] = load_row_elem(x + (t0 + k) * B, q.boff[j]);
+        } else {
+            load_row<NB, VEC4>(x, q.b[j], T, t0, v[j]);
+        }
+    }
+}
+
+template <typename V, int NB>
+__device__ __forceinline__ V gathern(const float (&v)[VT<V>::N][NB], int i)
+{
+    V r = vsplat<V>(0.0f);
+#pragma unroll
+    for (int j = 0; j < VT<V>::N; ++j) vset(r, j, v[j][i]);
+    return r;
+}
+
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, int MSE, typename V, bool FAST>
+__device__ __forceinline__ void clipper_bwd_tp_body(
+    const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r,
+    const float* __restrict__ zstash, const float* __restrict__ gy,
     const float* __restrict__ target, const float* __restrict__ zT, float gscale, float* out,
-    int64_t B, int64_t Bh, int64_t T, int64_t L, const float* __restrict__ gcoef, int64_t skip,
-    unsigned* tickets, double* ws, float* __restrict__ gz0, float* gtheta, int accumulate, float* __restrict__ sse_out,
-    AdamTail adam)
+    int64_t B, int64_t Bh, int64_t T, int64_t L, const float* __restrict__ gcoef, int64_t skip)
 {
     constexpr int N = VT<V>::N;
-    __shared__ double sh[64][4];
-    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+    constexpr int NB = kBwdBlk;
     float gb = 0.0f;
     if constexpr (MSE == 2) { gscale = gcoef[0]; gb = gcoef[1]; }
     const LaneSeqs<V> q(B, Bh);
@@ -1063,7 +1109,7 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     const int64_t t0 = k * L;
     const int64_t t1 = (t0 + L < T) ? t0 + L : T;
     V alpha = vsplat<V>(1.0f), beta = vsplat<V>(0.0f);
-    // constant parts: fp64 across 8-step blocks; G-coefficients decay geometrically: fp32 is enough
+    // constant parts: fp64 across register blocks; G-coefficients decay geometrically: fp32 is enough
     double dbL[N], dbV[N], dbP[N], dsse[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) dbL[j] = dbV[j] = dbP[j] = dsse[j] = 0.0;
@@ -1072,7 +1118,7 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     V z_next = zero;                                          // state after the step being processed
     if constexpr (MSE) z_next = (t1 < T) ? load_one_v<V>(zstash, q, 1, B, t1) : load_one_v<V>(zT, q, 1, 0, 0);
 
-    const int64_t nfull_end = t1 - (t1 - t0) % kBlk;
+    const int64_t nfull_end = t1 - (t1 - t0) % NB;
     for (int64_t t = t1 - 1; t >= nfull_end; --t) {          // tail of the last chunk first (highest t)
         TpAccT<V> acc = {zero, zero, zero, zero, zero, zero};
         const V xin = load_one_v<V>(x, q, TM ? 1 : T, TM ? B : 1, t);
@@ -1082,7 +1128,7 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
         const V tg = MSE ? load_one_v<V>(target, q, 1, B, t) : zero;
         const V gin = MSE ? zero : load_one_v<V>(gy, q, 1, B, t);
         const V g = tp_grad_in<MSE, V>(gin, zv, z_next, tg, gscale, gb, t >= skip ? 1.0f : 0.0f, sse1);
-        bwd_tp_step<DYN_R, SYM, V>(c, xin, rin, zv, g, alpha, beta, acc);
+        bwd_tp_step<DYN_R, SYM, V, FAST>(c, xin, rin, zv, g, alpha, beta, acc);
         z_next = zv;
         saL += acc.aL; saV += acc.aV; saP += acc.aP;
 #pragma unroll
@@ -1091,44 +1137,44 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
             dsse[j] += vget(sse1, j);
         }
     }
-    float xc[N][kBlk], xn[N][kBlk], rc[N][kBlk], rn[N][kBlk], zc[N][kBlk], zn[N][kBlk], gc[N][kBlk], gn[N][kBlk];
+    float xc[N][NB], xn[N][NB], rc[N][NB], rn[N][NB], zc[N][NB], zn[N][NB], gc[N][NB], gn[N][NB];
 #pragma unroll
     for (int j = 0; j < N; ++j)
 #pragma unroll
-        for (int i = 0; i < kBlk; ++i) {
+        for (int i = 0; i < NB; ++i) {
             xc[j][i] = xn[j][i] = zc[j][i] = zn[j][i] = gc[j][i] = gn[j][i] = 0.0f;
             rc[j][i] = rn[j][i] = 1.0f;
         }
     const float* __restrict__ gsrc = MSE ? target : gy;       // the third stream: target (MSE) or dL/dy
     if (nfull_end > t0) {
-        const int64_t tb = nfull_end - kBlk;
-        load_block_v<V, TM, VEC4>(x, q, B, T, tb, xn);
-        if constexpr (DYN_R) load_block_v<V, TM, VEC4>(r, q, B, T, tb, rn);
-        load_block_v<V, true, false>(zstash, q, B, T, tb, zn);
-        load_block_v<V, true, false>(gsrc, q, B, T, tb, gn);
+        const int64_t tb = nfull_end - NB;
+        load_blockn_v<V, TM, VEC4, NB>(x, q, B, T, tb, xn);
+        if constexpr (DYN_R) load_blockn_v<V, TM, VEC4, NB>(r, q, B, T, tb, rn);
+        load_blockn_v<V, true, false, NB>(zstash, q, B, T, tb, zn);
+        load_blockn_v<V, true, false, NB>(gsrc, q, B, T, tb, gn);
     }
-    for (int64_t tb = nfull_end - kBlk; tb >= t0; tb -= kBlk) {
+    for (int64_t tb = nfull_end - NB; tb >= t0; tb -= NB) {
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-            for (int i = 0; i < kBlk; ++i) {
+            for (int i = 0; i < NB; ++i) {
                 xc[j][i] = xn[j][i]; zc[j][i] = zn[j][i]; gc[j][i] = gn[j][i];
                 if constexpr (DYN_R) rc[j][i] = rn[j][i];
             }
-        if (tb - kBlk >= t0) {
-            load_block_v<V, TM, VEC4>(x, q, B, T, tb - kBlk, xn);
-            if constexpr (DYN_R) load_block_v<V, TM, VEC4>(r, q, B, T, tb - kBlk, rn);
-            load_block_v<V, true, false>(zstash, q, B, T, tb - kBlk, zn);
-            load_block_v<V, true, false>(gsrc, q, B, T, tb - kBlk, gn);
+        if (tb - NB >= t0) {
+            load_blockn_v<V, TM, VEC4, NB>(x, q, B, T, tb - NB, xn);
+            if constexpr (DYN_R) load_blockn_v<V, TM, VEC4, NB>(r, q, B, T, tb - NB, rn);
+            load_blockn_v<V, true, false, NB>(zstash, q, B, T, tb - NB, zn);
+            load_blockn_v<V, true, false, NB>(gsrc, q, B, T, tb - NB, gn);
         }
         TpAccT<V> acc = {zero, zero, zero, zero, zero, zero};
         V sse8 = zero;
 #pragma unroll
-        for (int i = kBlk - 1; i >= 0; --i) {
-            const V zv = gather<V>(zc, i);
-            const V g = tp_grad_in<MSE, V>(gather<V>(gc, i), zv, z_next, gather<V>(gc, i), gscale, gb,
+        for (int i = NB - 1; i >= 0; --i) {
+            const V zv = gathern<V, NB>(zc, i);
+            const V g = tp_grad_in<MSE, V>(gathern<V, NB>(gc, i), zv, z_next, gathern<V, NB>(gc, i), gscale, gb,
                                           tb + i >= skip ? 1.0f : 0.0f, sse8);
-            bwd_tp_step<DYN_R, SYM, V>(c, gather<V>(xc, i), gather<V>(rc, i), zv, g, alpha, beta, acc);
+            bwd_tp_step<DYN_R, SYM, V, FAST>(c, gathern<V, NB>(xc, i), gathern<V, NB>(rc, i), zv, g, alpha, beta, acc);
             z_next = zv;
         }
         saL += acc.aL; saV += acc.aV; saP += acc.aP;
@@ -1146,6 +1192,25 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
 #pragma unroll
         for (int i = 0; i < kTpOut; ++i) __hip_atomic_store(o + i * B, rec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, int MSE, typename V>
+__global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
+    float fs, int n_up, int n_down, const float* __restrict__ zstash, const float* __restrict__ gy,
+    const float* __restrict__ target, const float* __restrict__ zT, float gscale, float* out,
+    int64_t B, int64_t Bh, int64_t T, int64_t L, const float* __restrict__ gcoef, int64_t skip,
+    unsigned* tickets, double* ws, float* __restrict__ gz0, float* gtheta, int accumulate, float* __restrict__ sse_out,
+    AdamTail adam, int general)
+{
+    __shared__ double sh[64][4];
+    const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+    bool fast = false;
+    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);     // wave-uniform, as in the forward
+    if (fast)
+        clipper_bwd_tp_body<DYN_R, SYM, TM, VEC4, MSE, V, !DYN_R>(c, x, r, zstash, gy, target, zT, gscale, out, B, Bh, T, L, gcoef, skip);
+    else
+        clipper_bwd_tp_body<DYN_R, SYM, TM, VEC4, MSE, V, false>(c, x, r, zstash, gy, target, zT, gscale, out, B, Bh, T, L, gcoef, skip);
     bwd_tp_finish(out, B, ws, gz0, tickets, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);
 }
 

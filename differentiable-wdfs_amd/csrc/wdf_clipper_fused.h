@@ -185,9 +185,6 @@ __device__ __forceinline__ V load_step(const float* __restrict__ x, const LaneOw
     return r;
 }
 
-__device__ __forceinline__ float vsel_nonzero(float a, float x, float y) { return a != 0.0f ? x : y; }
-__device__ __forceinline__ v2f vsel_nonzero(v2f a, float x, float y) { return v2f{a.x != 0.0f ? x : y, a.y != 0.0f ? x : y}; }
-
 // Tangent state of the lane's sequences inside a chunk.  G* accumulate sum_n s[n] (hg_n + hg_{n-1}) (summation
 // by parts of sum_n hg_n (s[n+1] + s[n]), hg = g/2): one FMA per statistic and step.
 template <typename V>
