@@ -53,6 +53,38 @@ def test_argument_validation_without_gpu(lib):
     assert lib.wdf_clipper_bwd_ws_bytes(0) == 0
 
 
+def test_one_pass_step_argument_validation_without_gpu(lib):
+    """wdf_clipper_step_mse_tp / _esr_tp / wdf_esr_finish: every rejection happens before any HIP call."""
+    one = C.c_void_p(16)
+    E = -1
+    mse = lib.wdf_clipper_step_mse_tp
+
+    def call_mse(x=one, target=one, y=one, ws=one, status=one, gtheta=one, sse=one, B=128, T=256, K=2, warmup=32, tol=1e-6, skip=0,
+                 state=None, mwt=0, m=None, flags=0):
+        return mse(x, None, one, 48000.0, 1, 1, target, 1.0, skip, y, None, None, B, T, K, warmup, tol, ws, status, state, mwt, gtheta, sse,
+                   0, m, None, None, None, 0.9, 0.999, 1e-7, None, None, flags, None)
+
+    assert call_mse(x=None) == E and b"null" in lib.wdf_last_error()
+    assert call_mse(target=None) == E and call_mse(y=None) == E and call_mse(ws=None) == E and call_mse(gtheta=None) == E
+    assert call_mse(skip=-1) == E and call_mse(skip=257) == E
+    assert call_mse(B=1 << 24) == E and b"2^24" in lib.wdf_last_error()
+    assert call_mse(K=5) == E and b"wdf_clipper_tp_chunks" in lib.wdf_last_error()      # 5 chunks do not tile 256 steps in 32-step units (4 do)
+    assert call_mse(tol=-1.0) == E and call_mse(warmup=-1) == E
+    assert call_mse(state=one, mwt=0) == E and call_mse(state=one, mwt=17) == E and call_mse(state=one, mwt=8) == E   # 8 tiles > the 128-step chunk
+    assert call_mse(m=one) == E and b"Adam" in lib.wdf_last_error()
+    assert call_mse(flags=2) == -3                                                         # WDF_PREC_F64
+    esr = lib.wdf_clipper_step_esr_tp
+
+    def call_esr(sums=one, n=1000.0, m=None, gtheta=None):
+        return esr(one, None, one, 48000.0, 1, 1, one, n, 2.2e-16, 50, one, None, None, 128, 256, 2, 32, 1e-6, one, one, None, 0, sums, gtheta,
+                   None, m, None, None, None, 0.9, 0.999, 1e-7, None, None, 0, None)
+
+    assert call_esr(sums=None) == E and call_esr(n=0.0) == E and call_esr(m=one) == E
+    assert lib.wdf_esr_finish(None, 10.0, 0.0, one, None, None) == E and lib.wdf_esr_finish(one, 0.0, 0.0, one, None, None) == E
+    assert lib.wdf_clipper_step_mse_tp_ws_bytes(0, 4) == 0 and lib.wdf_clipper_step_mse_tp_ws_bytes(8192, 16) > 16 * 16 * 8192 * 4
+    assert lib.wdf_clipper_step_mse_tp_ws_init(None, 8192, 16, None) == E
+
+
 def test_product_does_not_touch_the_oracle():
     """The product package must never import / load anything under oracle/."""
     root = os.path.join(REPO, "differentiable-wdfs_amd")
