@@ -52,7 +52,7 @@ def measured_traffic(kernel, cfg):
     for path in sorted(glob.glob(PMC_TRAFFIC_GLOB), reverse=True):
         try:
             d = json.load(open(path))
-            if all(d["config"].get(k) == v for k, v in cfg.items()) and kernel in d["kernels"]:
+            if all(d["config"].get(k, "mse" if k == "loss" else None) == v for k, v in cfg.items()) and kernel in d["kernels"]:
                 return d["kernels"][kernel]["traffic_bytes"], os.path.relpath(path, REPO)
         except (OSError, ValueError, KeyError, TypeError):
             pass
@@ -442,7 +442,7 @@ def main():
         b_ms = float(np.mean(t_bwd)) if t_bwd else None
         warm = None if stepper.warm is None else stepper.warm.info()
         # a kernel's traffic depends on the batch, the layout and its OWN chunking only
-        key = {"B": B, "T": T, "x_layout": "time-major" if tm else "batch-major"}
+        key = {"B": B, "T": T, "x_layout": "time-major" if tm else "batch-major", "loss": args.loss}
         w_used = None if tp is None else (tp.warmup if warm is None else 32 * max(0, warm["last_warm_tiles"]))
         if fused:
             dom, dom_ms, dom_bytes = "clipper_fused_tp_kernel", f_ms, BYTES_STEP

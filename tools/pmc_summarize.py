@@ -24,6 +24,7 @@ for log in glob.glob(os.path.join(root, f"pmc_{tag}_*.log")):
             fused = str(d.get("step_kernels", "")).startswith("one pass")
             cfg = {"B": d["config"]["global_batch"] // d["n_gpus"], "T": d["config"]["seq_len"],
                    "x_layout": "time-major" if d["config"]["x_layout"].startswith("time-major") else "batch-major",
+                   "loss": "mse+esr" if "MSE+ESR" in d["config"]["workload"] else "mse",
                    **({"fused_chunks": tp["fwd_chunks"]} if fused else {"fwd_chunks": tp["fwd_chunks"], "bwd_chunks": tp["bwd_chunks"]}),
                    # warm-started forward: the warm-up the device controller settled at, not the cold one
                    "fwd_warmup_steps": tp["fwd_warmup_steps"] if not tp.get("warm_start") else 32 * max(0, tp["warm_start"]["last_warm_tiles"])}
