@@ -361,3 +361,25 @@ def test_fused_randomized_plans_and_circuits(wb):
         worst_y, worst_g, worst_s, repaired = max(worst_y, ey), max(worst_g, eg), max(worst_s, es), repaired + rep
     assert worst_y <= 2e-6 and worst_g <= 1e-3 and worst_s <= 1e-4, (worst_y, worst_g, worst_s)
     assert repaired >= 5
+
+
+def test_fused_step_is_bit_reproducible(wb):
+    """Which wave finishes a tile / the step varies from launch to launch; what they compute does not (records and partials
+    are re-read in index order, fixed-order reductions): 100 launches, bit-identical y, gradient, SSE and status."""
+    B, T, K, W = 1024, 2048, 16, 256
+    x, th, ths = problem(B, T, seed=77)
+    xd, thd = dev(x).t().contiguous(), dev(th)
+    tgt, _, _ = wb.clipper_fwd(dev(x), dev(ths), FS, want_stash=False)
+    ws = wb.step_mse_workspace(B, K, xd.device)
+    y0, _, g0, s0, st0 = wb.clipper_step_mse_tp(xd, thd, FS, tgt, 2.0 / (B * T), K, W, ws=ws, time_major=True)
+    y0, g0, s0, st0 = y0.clone(), g0.clone(), s0.clone(), st0.clone()
+    for _ in range(100):
+        y, _, g, s, st = wb.clipper_step_mse_tp(xd, thd, FS, tgt, 2.0 / (B * T), K, W, ws=ws, time_major=True)
+        assert torch.equal(g, g0) and torch.equal(s, s0) and torch.equal(st, st0)
+    assert torch.equal(y, y0)
+    eps = float(np.finfo(float).eps)
+    r0 = wb.clipper_step_esr_tp(xd, thd, FS, tgt, B * (T - 50), eps, 50, K, W, ws=ws, time_major=True)
+    g0, l0, s10 = r0[3].clone(), r0[4].clone(), r0[2].clone()
+    for _ in range(50):
+        r = wb.clipper_step_esr_tp(xd, thd, FS, tgt, B * (T - 50), eps, 50, K, W, ws=ws, time_major=True)
+        assert torch.equal(r[3], g0) and torch.equal(r[4], l0) and torch.equal(r[2], s10)
