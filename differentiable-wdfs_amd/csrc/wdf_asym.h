@@ -123,9 +123,11 @@ __global__ __launch_bounds__(64) void clipper_asym_fwd_kernel(const float* __res
                                                               float* __restrict__ y, float* __restrict__ zstash,
                                                               const float* __restrict__ z0,
                                                               float* __restrict__ zT, double tol, int max_iter,
-                                                              long long* __restrict__ iters_out, int64_t B, int64_t T)
+                                                              long long* __restrict__ iters_out, int64_t B, int64_t T,
+                                                              const unsigned* __restrict__ gate = nullptr)
 {
     using S = typename AsymStep<NEWTON>::S;
+    if (gate != nullptr && gate[blockIdx.x] == 0u) return;    // sequential re-run behind a time-parallel pass: flagged waves only
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;
     const AsymConsts c = asym_load(theta6, fs);
@@ -167,6 +169,93 @@ __global__ __launch_bounds__(64) void clipper_asym_fwd_kernel(const float* __res
     }
     if (zT) zT[b] = (float)z;
     if (iters_out && threadIdx.x == 0) iters_out[blockIdx.x] = iters;   // wave-uniform count
+}
+
+// ---- time-parallel forward ------------------------------------------------------------------------------
+// 8192 sequences are 128 waves for 1024 SIMDs, and a Newton step is a long fp64 chain: the time axis is cut into K chunks
+// (grid.y), chunk k starts W steps early from z = 0 (the step contracts: the diode-off rate 1 - 2p bounds the memory, as
+// for the symmetric pair), records the state it arrives with and the state it ends with; asym_tp_verify_kernel compares
+// them across every boundary and raises a per-wave gate where one misses by more than tol; the sequential kernel is then
+// launched GATED and re-runs exactly those waves.  L and W are multiples of 8.
+struct AsymTpStatus { int n_bad; float max_miss; int gated_waves; int pad; };
+
+template <bool NEWTON>
+__global__ __launch_bounds__(64) void clipper_asym_fwd_tp_kernel(const float* __restrict__ x, const float* __restrict__ theta6,
+                                                                 float fs, float* __restrict__ y, float* __restrict__ zstash,
+                                                                 const float* __restrict__ z0, float* __restrict__ zT,
+                                                                 float* __restrict__ zwarm, float* __restrict__ zend, double tol,
+                                                                 int max_iter, AsymTpStatus* __restrict__ status, int64_t B,
+                                                                 int64_t T, int64_t L, int64_t W)
+{
+    using S = typename AsymStep<NEWTON>::S;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = AsymTpStatus{0, 0.0f, 0, 0};   // the verify kernel adds
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t k = blockIdx.y;
+    const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const int64_t tw = (k > 0 && t0 > W) ? t0 - W : 0;
+    const AsymConsts c = asym_load(theta6, fs);
+    const float* __restrict__ xp = x + b * T;
+    int iters = 0;
+    S z = (tw == 0 && z0) ? (S)z0[b] : (S)0;
+    constexpr int kB = 8;
+    float xc[kB], xn[kB];
+    auto load8 = [&](int64_t t, float(&v)[kB]) {
+#pragma unroll
+        for (int i = 0; i < kB; ++i) v[i] = xp[t + i < T ? t + i : T - 1];
+    };
+    load8(tw, xn);
+    for (int64_t tb = tw; tb < t1; tb += kB) {
+        if (tb == t0) zwarm[k * B + b] = (float)z;              // the state this chunk arrives with
+#pragma unroll
+        for (int i = 0; i < kB; ++i) xc[i] = xn[i];
+        if (tb + kB < t1) load8(tb + kB, xn);
+        const bool owned = tb >= t0;
+#pragma unroll
+        for (int i = 0; i < kB; ++i) {
+            if (tb + i < t1) {                                   // wave-uniform (the last chunk's ragged end)
+                const S zb = z;
+                const float yv = AsymStep<NEWTON>::run(c, xc[i], z, tol, max_iter, iters);
+                if (owned) {
+                    if (zstash) zstash[(tb + i) * B + b] = (float)zb;
+                    y[(tb + i) * B + b] = yv;
+                }
+            }
+        }
+    }
+    zend[k * B + b] = (float)z;
+    if (zT && t1 == T) zT[b] = (float)z;
+}
+
+// one lane per sequence: every chunk boundary; gate[wave] = 1 where any of the wave's 64 sequences missed
+static __global__ __launch_bounds__(64) void asym_tp_verify_kernel(const float* __restrict__ zwarm, const float* __restrict__ zend,
+                                                                   int64_t B, int64_t K, float tol, unsigned* __restrict__ gate,
+                                                                   AsymTpStatus* __restrict__ status)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    float miss = 0.0f;
+    int nbad = 0;
+    for (int64_t k = 1; k < K; ++k) {
+        const float m = fabsf(zwarm[k * B + b] - zend[(k - 1) * B + b]);
+        miss = fmaxf(miss, m);
+        nbad += !(m <= tol) ? 1 : 0;
+    }
+    if (b_raw >= B) nbad = 0;
+    const bool any = __builtin_amdgcn_ballot_w64(nbad > 0) != 0;
+    float wmax = miss;
+    int wbad = nbad;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        wmax = fmaxf(wmax, __shfl_down(wmax, off, 64));
+        wbad += __shfl_down(wbad, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        gate[blockIdx.x] = any ? 1u : 0u;
+        if (wmax > 0.0f) atomicMax(reinterpret_cast<int*>(&status->max_miss), __float_as_int(wmax));
+        if (wbad) atomicAdd(&status->n_bad, wbad);
+        if (any) atomicAdd(&status->gated_waves, 1);
+    }
 }
 
 // ---- reverse sweep of the Newton-mode loop ---------------------------------------------------------

@@ -149,6 +149,51 @@ int wdf_clipper_asym_fwd(const float* x, const float* theta6, float fs, int mode
     return check_launch("wdf_clipper_asym_fwd");
 }
 
+size_t wdf_clipper_asym_fwd_tp_ws_bytes(int64_t B, int n_chunks)
+{
+    if (B <= 0 || n_chunks <= 0) return 0;
+    return (size_t)2 * (size_t)n_chunks * (size_t)B * sizeof(float) + (size_t)((B + 63) / 64) * sizeof(unsigned);
+}
+
+int wdf_clipper_asym_fwd_tp(const float* x, const float* theta6, float fs, int mode, double tol, int max_iter, float* y,
+                            float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup,
+                            float verify_tol, void* ws, void* status, void* stream)
+{
+    if (!x || !theta6 || !y || !ws || !status) return fail(WDF_EINVAL, "null x/theta6/y/ws/status");
+    if (B <= 0 || T <= 0 || !(fs > 0.0f)) return fail(WDF_EINVAL, "B, T, fs must be positive");
+    if (mode != WDF_ASYM_OMEGA_F32 && mode != WDF_ASYM_NEWTON_F64) return fail(WDF_EINVAL, "unknown mode %d", mode);
+    if (mode == WDF_ASYM_NEWTON_F64 && (!(tol > 0.0) || max_iter < 1)) return fail(WDF_EINVAL, "tol > 0, max_iter >= 1");
+    if (n_chunks < 1 || warmup < 0 || !(verify_tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, verify_tol >= 0");
+    int64_t L = (T + n_chunks - 1) / n_chunks;
+    L = (L + 7) / 8 * 8;
+    const int K = (int)((T + L - 1) / L);
+    if (K != n_chunks) return fail(WDF_EINVAL, "n_chunks = %d does not tile T = %lld in 8-step units (%d does)", n_chunks, (long long)T, K);
+    const int64_t W = ((int64_t)warmup + 7) / 8 * 8;
+    float* zwarm = (float*)ws;
+    float* zend = zwarm + (size_t)K * (size_t)B;
+    unsigned* gate = (unsigned*)(zend + (size_t)K * (size_t)B);
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K);
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = (T % 4 == 0) && aligned16(x);
+    if (mode == WDF_ASYM_NEWTON_F64)
+        hipLaunchKernelGGL((wdf::clipper_asym_fwd_tp_kernel<true>), grid, dim3(64), 0, s, x, theta6, fs, y, zstash, z0, zT, zwarm, zend,
+                           tol, max_iter, (wdf::AsymTpStatus*)status, B, T, L, W);
+    else
+        hipLaunchKernelGGL((wdf::clipper_asym_fwd_tp_kernel<false>), grid, dim3(64), 0, s, x, theta6, fs, y, zstash, z0, zT, zwarm, zend,
+                           tol, max_iter, (wdf::AsymTpStatus*)status, B, T, L, W);
+    if (K > 1) {
+        hipLaunchKernelGGL(wdf::asym_tp_verify_kernel, dim3(grid.x), dim3(64), 0, s, zwarm, zend, B, (int64_t)K, verify_tol, gate,
+                           (wdf::AsymTpStatus*)status);
+#define WDF_ASYM_GATED(NEWTON_, V4_)                                                                                       \
+        hipLaunchKernelGGL((wdf::clipper_asym_fwd_kernel<NEWTON_, V4_>), dim3(grid.x), dim3(64), 0, s, x, theta6, fs, y, zstash, z0, \
+                           zT, tol, max_iter, (long long*)nullptr, B, T, (const unsigned*)gate)
+        if (mode == WDF_ASYM_NEWTON_F64) { if (v4) WDF_ASYM_GATED(true, true); else WDF_ASYM_GATED(true, false); }
+        else { if (v4) WDF_ASYM_GATED(false, true); else WDF_ASYM_GATED(false, false); }
+#undef WDF_ASYM_GATED
+    }
+    return check_launch("wdf_clipper_asym_fwd_tp");
+}
+
 size_t wdf_clipper_asym_bwd_ws_bytes(int64_t B) { return B > 0 ? (size_t)((B + 63) / 64) * 8 * sizeof(double) : 0; }
 
 int wdf_clipper_asym_bwd(const float* x, const float* theta6, float fs, double tol, int max_iter, const float* zstash,

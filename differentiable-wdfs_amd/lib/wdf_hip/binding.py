@@ -111,6 +111,10 @@ def lib():
                                          ci, vp]
     L.wdf_clipper_asym_fwd.restype = ci
     L.wdf_clipper_asym_fwd.argtypes = [fp, fp, cf, ci, C.c_double, ci, fp, fp, fp, fp, vp, i64, i64, vp]
+    L.wdf_clipper_asym_fwd_tp_ws_bytes.restype = C.c_size_t
+    L.wdf_clipper_asym_fwd_tp_ws_bytes.argtypes = [i64, ci]
+    L.wdf_clipper_asym_fwd_tp.restype = ci
+    L.wdf_clipper_asym_fwd_tp.argtypes = [fp, fp, cf, ci, C.c_double, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, vp]
     L.wdf_clipper_asym_bwd_ws_bytes.restype = C.c_size_t
     L.wdf_clipper_asym_bwd_ws_bytes.argtypes = [i64]
     L.wdf_clipper_asym_bwd.restype = ci
@@ -188,7 +192,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp_ws_init", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_bwd_mse_tp_adam", "wdf_clipper_step_mse_tp_ws_bytes", "wdf_clipper_step_mse_tp_ws_init",
     "wdf_clipper_step_mse_tp", "wdf_clipper_step_esr_tp", "wdf_esr_finish", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
-    "wdf_clipper_asym_fwd", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd", "wdf_asym_root",
+    "wdf_clipper_asym_fwd", "wdf_clipper_asym_fwd_tp_ws_bytes", "wdf_clipper_asym_fwd_tp", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
     "wdf_clipper_mlp_tp_chunks", "wdf_clipper_mlp_fwd_tp_ws_bytes", "wdf_clipper_mlp_fwd_tp",
@@ -806,6 +810,28 @@ def clipper_asym_fwd(x, theta6, fs, mode, tol=1e-12, max_iter=50, z0=None, want_
                                     _ptr(zs), _ptr(z0), _ptr(zT), _ptr(it), B, T, _stream())
     _check(rc, "wdf_clipper_asym_fwd")
     return (y, zT, it, zs) if want_stash else (y, zT, it)
+
+
+def clipper_asym_fwd_tp(x, theta6, fs, mode, n_chunks, warmup, tol=1e-12, max_iter=50, verify_tol=1e-6, z0=None, want_zT=False,
+                        want_stash=False):
+    """Time-parallel two-different-diode clipper forward (wdf_clipper_asym_fwd_tp).  n_chunks is rounded to a count that
+    tiles T in 8-step units.  -> y [T,B], zT | None, zstash | None, status (int32[4]; read with mlp_tp_status())."""
+    require_gpu()
+    x, theta6, z0 = _f32_dev(x, "x"), _f32_dev(theta6, "theta6"), _f32_dev(z0, "z0")
+    if theta6.numel() != 6:
+        raise WdfHipError("theta6 must hold {Is_up, nVt_up, Is_down, nVt_down, R, C}")
+    B, T = x.shape
+    Lc = -(-(-(-T // max(1, int(n_chunks)))) // 8) * 8
+    K = -(-T // Lc)
+    y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zs = torch.empty((T, B), dtype=torch.float32, device=x.device) if want_stash else None
+    zT = torch.empty((B,), dtype=torch.float32, device=x.device) if want_zT else None
+    ws = torch.empty((lib().wdf_clipper_asym_fwd_tp_ws_bytes(B, K),), dtype=torch.uint8, device=x.device)
+    status = torch.empty((4,), dtype=torch.int32, device=x.device)
+    rc = lib().wdf_clipper_asym_fwd_tp(_ptr(x), _ptr(theta6), float(fs), int(mode), float(tol), int(max_iter), _ptr(y), _ptr(zs),
+                                       _ptr(z0), _ptr(zT), B, T, K, int(warmup), float(verify_tol), _ptr(ws), _ptr(status), _stream())
+    _check(rc, "wdf_clipper_asym_fwd_tp")
+    return y, zT, zs, status
 
 
 def clipper_asym_bwd(x, theta6, fs, zstash, gy, tol=1e-12, max_iter=50):

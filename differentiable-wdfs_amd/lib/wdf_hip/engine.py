@@ -194,9 +194,14 @@ class _ClipperAsymFn(torch.autograd.Function):
     differentiable w.r.t. theta6 = {Is_up, nVt_up, Is_down, nVt_down, R, C} (csrc/wdf_asym.h)."""
 
     @staticmethod
-    def forward(ctx, theta6, x, fs, tol, max_iter):
+    def forward(ctx, theta6, x, fs, tol, max_iter, tp):
         th = theta6.detach().contiguous()
-        y, _, _, zs = binding.clipper_asym_fwd(x, th, fs, binding.ASYM_NEWTON_F64, tol=tol, max_iter=max_iter, want_stash=True)
+        if tp is not None and tp.k_fwd > 1:      # time chunks, verified on the device (wdf_clipper_asym_fwd_tp)
+            y, _, zs, st = binding.clipper_asym_fwd_tp(x, th, fs, binding.ASYM_NEWTON_F64, tp.k_fwd, tp.warmup, tol=tol,
+                                                       max_iter=max_iter, verify_tol=tp.tol, want_stash=True)
+            LAST_TP_STATUS["status"] = st
+        else:
+            y, _, _, zs = binding.clipper_asym_fwd(x, th, fs, binding.ASYM_NEWTON_F64, tol=tol, max_iter=max_iter, want_stash=True)
         ctx.cfg = (fs, tol, max_iter)
         ctx.save_for_backward(th, x, zs)
         return y
@@ -205,12 +210,13 @@ class _ClipperAsymFn(torch.autograd.Function):
     def backward(ctx, gy):
         fs, tol, max_iter = ctx.cfg
         th, x, zs = ctx.saved_tensors
-        return binding.clipper_asym_bwd(x, th, fs, zs, gy.contiguous(), tol=tol, max_iter=max_iter), None, None, None, None
+        return binding.clipper_asym_bwd(x, th, fs, zs, gy.contiguous(), tol=tol, max_iter=max_iter), None, None, None, None, None
 
 
-def clipper_asym(theta6, x, fs, tol=1.0e-12, max_iter=50):
-    """Two-different-diode clipper loop (BASELINE config 5), Newton mode, with gradients to all six parameters."""
-    return _ClipperAsymFn.apply(theta6, x, float(fs), float(tol), int(max_iter))
+def clipper_asym(theta6, x, fs, tol=1.0e-12, max_iter=50, tp=None):
+    """Two-different-diode clipper loop (BASELINE config 5), Newton mode, with gradients to all six parameters.
+    tp: a TpPlan (plan_time_parallel with the circuit's R, C) -> the forward runs in time chunks."""
+    return _ClipperAsymFn.apply(theta6, x, float(fs), float(tol), int(max_iter), tp)
 
 
 class MseStep:

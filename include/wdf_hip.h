@@ -352,6 +352,15 @@ enum { WDF_ASYM_OMEGA_F32 = 0, WDF_ASYM_NEWTON_F64 = 1 };
 int wdf_clipper_asym_fwd(const float* x, const float* theta6, float fs, int mode, double tol, int max_iter,
                          float* y, float* zstash, const float* z0, float* zT, long long* iters,
                          int64_t B, int64_t T, void* stream);
+
+/* Time-parallel form: the time axis in n_chunks chunks (a count that tiles T in 8-step units), every chunk but the first
+ * starting `warmup` steps early from z = 0; the device verifies every chunk boundary to verify_tol and re-runs, sequentially,
+ * exactly the 64-sequence waves where one missed (status: int32 {n_bad, max-miss float bits, gated waves, 0}).  The result is
+ * the sequential kernel's to verify_tol; 128 waves become 128 n_chunks.  ws: wdf_clipper_asym_fwd_tp_ws_bytes bytes. */
+size_t wdf_clipper_asym_fwd_tp_ws_bytes(int64_t B, int n_chunks);
+int wdf_clipper_asym_fwd_tp(const float* x, const float* theta6, float fs, int mode, double tol, int max_iter, float* y,
+                            float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup,
+                            float verify_tol, void* ws, void* status, void* stream);
 size_t wdf_clipper_asym_bwd_ws_bytes(int64_t B);
 int wdf_clipper_asym_bwd(const float* x, const float* theta6, float fs, double tol, int max_iter,
                          const float* zstash, const float* gy, void* ws, float* gtheta6,

@@ -87,3 +87,42 @@ def test_reverse_sweep_vs_oracle_finite_differences(oracle):
     # and the forward it differentiates is the plain Newton forward
     y2, _, _ = wb.clipper_asym_fwd(dev(x), dev(THETA6), FS, wb.ASYM_NEWTON_F64, tol=1e-12)
     assert torch.equal(y.detach(), y2)
+    # the same gradient with the forward cut into time chunks (the stash then comes from the verified chunks)
+    th2 = dev(THETA6).requires_grad_(True)
+    y3 = engine.clipper_asym(th2, dev(x), FS, tp=engine.TpPlan(3, 192, 1e-6, 1))
+    (y3 * dev(gy)).sum().backward()
+    assert wb.mlp_tp_status(engine.LAST_TP_STATUS["status"])["n_bad"] == 0
+    assert float((y3.detach() - y2).abs().max()) <= 1e-6
+    assert np.max(np.abs(th2.grad.cpu().numpy() - got) / np.abs(got)) < 2e-5
+
+
+@pytest.mark.parametrize("mode_name", ["newton", "omega"])
+@pytest.mark.parametrize("B,T,K,W", [(70, 1000, 4, 192), (256, 2048, 8, 192), (64, 4096, 16, 192), (5, 130, 2, 64)])
+def test_time_parallel_forward_equals_sequential(B, T, K, W, mode_name):
+    """wdf_clipper_asym_fwd_tp: chunks warmed up from z = 0, verified on the device -> the sequential kernel's y, stash and
+    final state within the verified tolerance, clean status; ragged B and T."""
+    from wdf_hip import binding as wb, workload
+    mode = wb.ASYM_NEWTON_F64 if mode_name == "newton" else wb.ASYM_OMEGA_F32
+    x = dev(workload.sweep_batch(B, T, seed=B + T))
+    th = dev(THETA6)
+    z0 = dev(np.random.default_rng(B).uniform(-0.2, 0.2, B))
+    y, zT, _, zs = wb.clipper_asym_fwd(x, th, FS, mode, tol=1e-12, max_iter=50, z0=z0, want_zT=True, want_stash=True)
+    y2, zT2, zs2, st = wb.clipper_asym_fwd_tp(x, th, FS, mode, K, W, tol=1e-12, max_iter=50, z0=z0, want_zT=True, want_stash=True)
+    s = wb.mlp_tp_status(st)
+    assert s["n_bad"] == 0 and s["gated_waves"] == 0 and s["max_miss"] <= 1e-6, s
+    assert float((y2 - y).abs().max()) <= 1e-6 and float((zs2 - zs).abs().max()) <= 2e-6
+    assert float((zT2 - zT).abs().max()) <= 2e-6
+
+
+def test_time_parallel_forward_repairs_a_short_warmup():
+    """A warm-up of 8 steps cannot work (the RC network remembers ~150): the verification gates every wave and the gated
+    sequential launch restores the sequential result."""
+    from wdf_hip import binding as wb, workload
+    B, T = 130, 2048
+    x = dev(workload.sweep_batch(B, T, seed=3))
+    th = dev(THETA6)
+    y, _, _, zs = wb.clipper_asym_fwd(x, th, FS, wb.ASYM_NEWTON_F64, want_stash=True)
+    y2, _, zs2, st = wb.clipper_asym_fwd_tp(x, th, FS, wb.ASYM_NEWTON_F64, 8, 8, want_stash=True)
+    s = wb.mlp_tp_status(st)
+    assert s["n_bad"] > 0 and s["gated_waves"] == 3, s
+    assert torch.equal(y2, y) and torch.equal(zs2, zs)

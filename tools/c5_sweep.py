@@ -45,5 +45,29 @@ for tol in (1e-4, 1e-6, 1e-8, 1e-10, 1e-12, 1e-14):
     ms, err, iters = run(wb.ASYM_NEWTON_F64, tol, 50)
     rows.append({"root": f"fp64 Newton tol={tol:g}", "ms": ms, "samples_per_s": B * T / ms * 1e3, "max_abs_err_vs_exact": err,
                  "mean_newton_iters_per_wave_step": iters})
+
+
+def run_tp(mode, tol, max_iter, K, W=192):
+    """the same forward cut into K time chunks (wdf_clipper_asym_fwd_tp: verified on the device)"""
+    wb.clipper_asym_fwd_tp(xd, th, FS, mode, K, W, tol=tol, max_iter=max_iter)
+    torch.cuda.synchronize()
+    e0, e1 = wb.Event(), wb.Event()
+    e0.record()
+    n = 5
+    for _ in range(n):
+        y, _, _, st = wb.clipper_asym_fwd_tp(xd, th, FS, mode, K, W, tol=tol, max_iter=max_iter)
+    e1.record()
+    ms = e0.elapsed_ms(e1) / n
+    return ms, float(np.max(np.abs(y[:, pk].cpu().numpy() - ref))), wb.mlp_tp_status(st)
+
+
+for K in (4, 8, 16, 32):
+    ms, err, st = run_tp(wb.ASYM_OMEGA_F32, 1e-12, 1, K)
+    rows.append({"root": f"fp32 Wright-omega closed form, {K} time chunks", "ms": ms, "samples_per_s": B * T / ms * 1e3,
+                 "max_abs_err_vs_exact": err, "verify": st})
+    for tol in (1e-6, 1e-12):
+        ms, err, st = run_tp(wb.ASYM_NEWTON_F64, tol, 50, K)
+        rows.append({"root": f"fp64 Newton tol={tol:g}, {K} time chunks", "ms": ms, "samples_per_s": B * T / ms * 1e3,
+                     "max_abs_err_vs_exact": err, "verify": st})
 for r in rows:
     print(json.dumps(r))
