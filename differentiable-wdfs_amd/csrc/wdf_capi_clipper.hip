@@ -1,6 +1,9 @@
 // wdf_capi_clipper.hip -- C ABI part 2 of 4: the diode-clipper sequence kernels (sequential and
 // time-parallel forward / reverse sweep).  Argument checking, template dispatch and launches.
 // 
+#include <cstdlib>
+#include <cstring>
+
 #include "wdf_capi_common.h"
 #include "wdf_clipper.h"
 #include "wdf_clipper_fused.h"
@@ -172,11 +175,31 @@ inline FusedWs fused_ws(void* ws, int64_t B, int K, int nrec)
     return w;
 }
 
+// Skewed chunk spans (wdf_clipper_fused.h, chunk_span): only when the launch puts about two chunk waves on every SIMD --
+// that is the situation the skew answers -- the chunk count is even, the ragged last chunk keeps more than `skew` steps and
+// the shorter chunks still hold the warm-start snapshots.  WDF_FUSED_SKEW=0 switches it off, =force applies it whenever
+// the geometry allows (tests).
+inline int64_t fused_skew(int64_t n_waves, int K, int64_t L, int64_t T, int max_warm_tiles)
+{
+    static const int mode = []() { const char* e = getenv("WDF_FUSED_SKEW"); return !e ? 1 : (strcmp(e, "force") == 0 ? 2 : atoi(e) != 0); }();
+    if (mode == 0 || K < 2 || (K & 1)) return 0;
+    if (mode == 1) {
+        static const int n_simd = []() { int dev = 0, cus = 256; (void)hipGetDevice(&dev);
+                                         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return 4 * cus; }();
+        if (2 * n_waves <= 3 * (int64_t)n_simd || 2 * n_waves > 5 * (int64_t)n_simd) return 0;
+    }
+    const int64_t skew = L / 4 / wdf::kTile * wdf::kTile;
+    if (skew <= 0) return 0;
+    if (T - (int64_t)(K - 1) * L <= skew) return 0;                                   // the last chunk would be empty
+    if ((int64_t)max_warm_tiles * wdf::kTile > L - skew) return 0;                      // snapshots reach further back than the short chunks
+    return skew;
+}
+
 template <bool DYN_R, bool SYM, bool TM, bool V4>
 void launch_fused(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, const float* target,
                   float hgs, int64_t skip, float* y, const float* z0, float* zT, FusedWs w, wdf::TpStatus* status, float tol,
                   int64_t B, int64_t T, TpGeom g, int64_t W, TpWarm warm, int general, bool pairs, bool esr, wdf::FusedOut out,
-                  hipStream_t s)
+                  int64_t skew, hipStream_t s)
 {
     // pairs: two adjacent sequences per lane, packed fp32 arithmetic (wdf_clipper_fused.h); a tile is then 128 sequences
     const int per_tile = pairs ? 128 : 64;
@@ -184,11 +207,11 @@ void launch_fused(const float* x, const float* r, const float* theta, float fs, 
 #define WDF_FUSED(V_, LOSS_)                                                                                                     \
     hipLaunchKernelGGL((wdf::clipper_fused_tp_kernel<DYN_R, SYM, TM, V4, V_, LOSS_>), grid, dim3(64), 0, s, x, r, theta, fs, n_up, \
                        n_down, target, hgs, skip, y, z0, zT, w.zwarm, w.zend, w.rec, status, warm.ctl, warm.snap, warm.J,        \
-                       w.tickets, w.gticket, tol, B, T, g.L, W, general, w.part, out)
+                       w.tickets, w.gticket, tol, B, T, g.L, W, general, w.part, out, skew)
 #define WDF_FUSED_REPAIR(N_, LOSS_)                                                                                              \
     hipLaunchKernelGGL((wdf::clipper_fused_repair_kernel<DYN_R, SYM, TM, N_, LOSS_>), dim3(grid.x), dim3(64), 0, s, x, r, theta, fs, \
                        n_up, n_down, target, hgs, skip, y, zT, w.zwarm, w.zend, w.rec, B, T, (int64_t)g.K, g.L, tol, status,     \
-                       warm.ctl, warm.snap, warm.J, w.tickets, w.gticket, general, w.part, out)
+                       warm.ctl, warm.snap, warm.J, w.tickets, w.gticket, general, w.part, out, skew)
     {
         EventBracket bracket(s);
         if (esr) { if (pairs) WDF_FUSED(wdf::v2f, 2); else WDF_FUSED(float, 2); }
@@ -484,9 +507,10 @@ static int step_tp_common(const float* x, const float* r, float* theta, float fs
     // two adjacent sequences per lane (8-byte row accesses, packed arithmetic) whenever the rows allow it
     const bool pairs = !(flags & WDF_ONE_SEQUENCE_PER_LANE) && (B % 2 == 0) && aligned8(x) && aligned8(target) && aligned8(y) &&
                        (!r || aligned8(r));
+    const int64_t skew = fused_skew((B + (pairs ? 127 : 63)) / (pairs ? 128 : 64) * (int64_t)g.K, g.K, g.L, T, state ? max_warm_tiles : 0);
     WDF_DISPATCH4(launch_fused, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, target, hgs, skip, y, z0, zT,
                   fused_ws(ws, B, g.K, esr ? wdf::kFsOutEsr : wdf::kFsOut), (wdf::TpStatus*)status, tol, B, T, g, W, warm,
-                  (flags & WDF_GENERAL_ROOT) ? 1 : 0, pairs, esr, out, (hipStream_t)stream);
+                  (flags & WDF_GENERAL_ROOT) ? 1 : 0, pairs, esr, out, skew, (hipStream_t)stream);
     return check_launch(what);
 }
 

@@ -97,6 +97,21 @@ struct LaneOwn {
     }
 };
 
+// Chunk spans.  skew = 0: K equal chunks of L steps.  skew > 0 (K even): the first K/2 chunks own L + skew steps, the other
+// K/2 own L - skew.  Why: with two chunk waves per SIMD the hardware issues oldest-first, so the wave dispatched first (the
+// lower chunk index: workgroups are dispatched in grid order) runs at ~3.7 steps/us, its younger partner at ~2.3, and after
+// the older one has finished the younger runs alone at the single-wave rate for a third of the kernel (tools/dbg_times.py).
+// Giving the older wave the longer chunk lets both finish together: -5 % (one sequence per lane, 16 chunks) / -3.5 % (two
+// per lane, 32 chunks) on the same box.  The host applies it only when the launch is ~2 waves per SIMD (wdf_capi_clipper.hip).
+__device__ __forceinline__ void chunk_span(int64_t k, int64_t K, int64_t L, int64_t skew, int64_t T, int64_t& t0, int64_t& t1)
+{
+    const int64_t half = K / 2;
+    const bool first = k < half;
+    t0 = first ? k * (L + skew) : half * (L + skew) + (k - half) * (L - skew);
+    const int64_t len = skew == 0 ? L : (first ? L + skew : L - skew);
+    t1 = (t0 + len < T) ? t0 + len : T;
+}
+
 // Rows of the time-major arrays through buffer descriptors: `buffer_load_dword[x2] v, voff, s[rsrc], soff offen` takes
 // the row's byte offset from an SGPR and the lane's from one VGPR, so a tile of rows costs no VALU instruction and no
 // SGPR pair per row (with global_load / global_store the compiler either adds 64-bit addresses on the VALU or keeps 32
@@ -348,7 +363,7 @@ __device__ __forceinline__ void clipper_fused_body(
     const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ target,
     float* __restrict__ y, float* __restrict__ zstash, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
     float* __restrict__ zend, float* rec, const float* __restrict__ theta, const TpCtl* __restrict__ ctl,
-    float* __restrict__ snap, int J, int64_t B, int64_t T, int64_t L, int64_t W, float hgs, int64_t skip)
+    float* __restrict__ snap, int J, int64_t B, int64_t T, int64_t L, int64_t W, float hgs, int64_t skip, int64_t skew = 0)
 {
     constexpr int NR = FusedTile<V, DYN_R>::NR;
 #ifdef WDF_DBG_TIMES
@@ -357,8 +372,8 @@ __device__ __forceinline__ void clipper_fused_body(
 #endif
     const LaneOwn<V> q(B);
     const int64_t k = blockIdx.y, K = gridDim.y;
-    const int64_t t0 = k * L;
-    const int64_t t1 = (t0 + L < T) ? t0 + L : T;
+    int64_t t0, t1;
+    chunk_span(k, K, L, skew, T, t0, t1);
     int64_t tw = 0;
     V z = vsplat<V>(0.0f);
     const bool stateful = ctl != nullptr && ctl->geom == (int)((K << 8) | J);
@@ -627,7 +642,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, const float* __restrict__ z0,
     float* __restrict__ zT, float* zwarm, float* zend, float* rec, TpStatus* __restrict__ status, TpCtl* ctl, float* snap,
     int J, unsigned* tickets, unsigned* gticket, float tol, int64_t B, int64_t T, int64_t L, int64_t W, int general,
-    double* ws, FusedOut out)
+    double* ws, FusedOut out, int64_t skew)
 {
     __shared__ double sh[64][4];
 #ifdef WDF_DBG_TIMES
@@ -639,10 +654,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
     if (fast)
         clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
-                                                            T, L, W, hgs, skip);
+                                                            T, L, W, hgs, skip, skew);
     else
         clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
-                                                           T, L, W, hgs, skip);
+                                                           T, L, W, hgs, skip, skew);
 #ifdef WDF_DBG_TIMES
     if (threadIdx.x == 0 && g_dbg_times) {
         unsigned long long* dbg_o = g_dbg_times + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
@@ -725,7 +740,7 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, float* __restrict__ zT,
     const float* zwarm, float* zend, float* rec, int64_t B, int64_t T, int64_t K, int64_t L, float tol,
     TpStatus* __restrict__ status, const TpCtl* __restrict__ ctl, float* __restrict__ snap, int J, unsigned* tickets,
-    unsigned* gticket, int general, double* ws, FusedOut out)
+    unsigned* gticket, int general, double* ws, FusedOut out, int64_t skew)
 {
     __shared__ double sh[64][4];
     unsigned* tile_bad = tickets + 4 + gridDim.x;
@@ -747,7 +762,8 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
             const float m = fabsf(load_published(zwarm + k * B + b) - e);
             fixed_prev = false;
             if (__builtin_amdgcn_ballot_w64(!(m <= tol)) == 0) continue;
-            const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+            int64_t t0, t1;
+            chunk_span(k, K, L, skew, T, t0, t1);
             float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
             float z = e;
             if (fast) fused_rerun_chunk<DYN_R, SYM, TM, !DYN_R, LOSS>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);

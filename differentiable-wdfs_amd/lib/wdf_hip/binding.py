@@ -301,7 +301,9 @@ class TpWarmState:
         L = lib()
         self.K = L.wdf_clipper_tp_chunks(int(T), int(n_chunks))
         chunk_len = -(-(-(-int(T) // max(1, int(n_chunks)))) // 32) * 32        # as the library rounds it
-        self.max_warm_tiles = max(1, min(int(max_warm_tiles), 16, chunk_len // 32))
+        # snapshots reach back at most three quarters of a chunk: the one-pass step may shorten the younger chunks by a quarter
+        # (skewed spans, csrc/wdf_clipper_fused.h chunk_span) and they must still hold every snapshot
+        self.max_warm_tiles = max(1, min(int(max_warm_tiles), 16, (3 * chunk_len // 4) // 32))
         self.B, self.T, self.n_chunks = int(B), int(T), int(n_chunks)
         self.min_warm_tiles = max(0, min(int(min_warm_tiles), self.max_warm_tiles))
         self.buf = torch.empty((L.wdf_clipper_fwd_tp_state_bytes(self.B, self.K, self.max_warm_tiles),),

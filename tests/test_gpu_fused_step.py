@@ -383,3 +383,20 @@ def test_fused_step_is_bit_reproducible(wb):
     for _ in range(50):
         r = wb.clipper_step_esr_tp(xd, thd, FS, tgt, B * (T - 50), eps, 50, K, W, ws=ws, time_major=True)
         assert torch.equal(r[3], g0) and torch.equal(r[4], l0) and torch.equal(r[2], s10)
+
+
+def test_fused_step_with_skewed_chunk_spans():
+    """Skewed chunk spans (the older wave of a SIMD pair gets the longer chunk: csrc/wdf_clipper_fused.h, chunk_span) are
+    applied by the library only for launches of about two waves per SIMD; WDF_FUSED_SKEW=force applies them wherever the
+    geometry allows, so the same tests -- repairs, warm starts, ragged shapes, both losses -- run over them in a
+    subprocess (the switch is read once per process)."""
+    import os, subprocess, sys
+    env = dict(os.environ, WDF_FUSED_SKEW="force")
+    here = os.path.abspath(__file__)
+    sel = ("test_fused_matches_two_kernel_step or test_fused_repairs_when_warmup_is_too_short or "
+           "test_fused_warm_started_training_loop_with_adam or test_fused_esr_step_matches_autograd or "
+           "test_fused_randomized_plans_and_circuits")
+    out = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-k", sel], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert " passed" in out.stdout
