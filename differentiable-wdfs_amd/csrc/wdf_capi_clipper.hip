@@ -188,8 +188,9 @@ inline int64_t fused_skew(int64_t n_waves, int K, int64_t L, int64_t T, int max_
                                          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return 4 * cus; }();
         if (2 * n_waves <= 3 * (int64_t)n_simd || 2 * n_waves > 5 * (int64_t)n_simd) return 0;
     }
-    const int64_t skew = L / 4 / wdf::kTile * wdf::kTile;
-    if (skew <= 0) return 0;
+    static const int64_t steps = []() { const char* e = getenv("WDF_FUSED_SKEW_STEPS"); return e ? (int64_t)atoi(e) : (int64_t)-1; }();   // (A/B runs)
+    const int64_t skew = (steps >= 0 ? steps : L / 4) / wdf::kTile * wdf::kTile;
+    if (skew <= 0 || skew >= L) return 0;
     if (T - (int64_t)(K - 1) * L <= skew) return 0;                                   // the last chunk would be empty
     if ((int64_t)max_warm_tiles * wdf::kTile > L - skew) return 0;                      // snapshots reach further back than the short chunks
     return skew;

@@ -41,8 +41,8 @@ for tm, one in [MODES[m] for m in os.environ.get("FUSED_MODES", "tm2,tm1,bm2").s
         for warm in (False, True):
             if K >= 43 and not warm:
                 continue
-            plan = engine.TpPlan(K, 160, 1e-6, 32)
-            st = engine.MseStep(B, T, fs, plan, dev, time_major=tm, warm=warm)
+            plan = engine.TpPlan(K, int(os.environ.get("FUSED_W", "160")), 1e-6, 32)
+            st = engine.MseStep(B, T, fs, plan, dev, time_major=tm, warm=warm, max_warm_tiles=int(os.environ.get("FUSED_MWT", "8")))
             theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
             adam = binding.Adam(4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
             med, best = timed(lambda: st.step_fused(theta, xk, tgt, adam=adam))
