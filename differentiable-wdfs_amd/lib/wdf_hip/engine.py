@@ -400,13 +400,14 @@ def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1,
 
 def autotune_fused(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=1, reps=7, r=None):
     """The chunk count of the one-pass step (MseStep.step_fused), by timing the planned count, half and double
-    on the actual batch (median of single-launch timings; the cold warm-up: the warm start shortens all three alike)."""
+    on the actual batch (median of single-launch timings of the warm-started step, as the training loop will run it)."""
     if plan is None:
         return plan
     B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
 
     def timed(fn):
-        fn()
+        for _ in range(8):                   # past the cold call and the warm-start controller's descent (one tile per call)
+            fn()
         e0, e1 = binding.Event(), binding.Event()
         ts = []
         for _ in range(reps):
@@ -416,13 +417,17 @@ def autotune_fused(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=
             ts.append(e0.elapsed_ms(e1))
         return sorted(ts)[len(ts) // 2]
 
+    # plan_time_parallel counts one sequence per lane (two waves per SIMD at k_fwd chunks); with an even batch the one-pass
+    # step runs two per lane, i.e. half the waves: the planned count is doubled to keep two waves per SIMD
+    k_cap = T // max(plan.warmup // 2, 64)
+    planned = plan.k_fwd * 2 if (B % 2 == 0 and not binding.ONE_SEQUENCE_PER_LANE and plan.k_fwd * 2 <= k_cap) else plan.k_fwd
     times = {}
-    for k in sorted({k for k in (max(1, plan.k_fwd // 2), plan.k_fwd, plan.k_fwd * 2) if k == 1 or k <= T // max(plan.warmup // 2, 64)}):
+    for k in sorted({k for k in (max(1, planned // 2), planned, planned * 2) if k == 1 or k <= k_cap}):
         st = MseStep(B, T, fs, plan._replace(k_fwd=k), x.device, n_up=n_up, n_down=n_down, time_major=time_major, warm=True)
         times[k] = timed(lambda: st.step_fused(theta, x, target, r))
         if binding.tp_status(st.status)["n_bad"]:
             del times[k]                     # a chunking whose speculation fails on this data is not a candidate
-    return plan._replace(k_fwd=_pick(times, plan.k_fwd)) if times else plan
+    return plan._replace(k_fwd=_pick(times, planned)) if times else plan
 
 
 class _ClipperMseFn(torch.autograd.Function):
