@@ -129,10 +129,20 @@ __device__ __forceinline__ bool series_only_omega1(const ClipConsts& c)
     return c.L - fminf(c.d.l_up, c.d.l_dn) <= kSeriesOnlyBelow;
 }
 
+// The same test with a per-sample resistance: L_n = log(Rp_n Is / nVt) varies per lane, but the port resistance of
+// Parallel(Vs, C) never exceeds the capacitor's, Rp_n < 1/G2, whatever the pot value -- so L_n < log(Is / (nVt G2)), a
+// wave-uniform bound, and the fast step is as safe for the dataset's streamed pot resistance as for a static one.
+template <bool DYN_R>
+__device__ __forceinline__ bool fast_root_ok(const ClipConsts& c, int general)
+{
+    if (general) return false;
+    if constexpr (DYN_R) return (c.lIV - logf(c.G2)) - fminf(c.d.l_up, c.d.l_dn) <= kSeriesOnlyBelow;
+    else return series_only_omega1(c);
+}
+
 template <bool DYN_R, bool SYM, typename V, bool FAST = false>
 __device__ __forceinline__ V fwd_step(const ClipConsts& c, V xin, V rin, V& z)
 {
-    static_assert(!(FAST && DYN_R), "FAST needs a wave-uniform L");
     V p, Rp, L;
     step_coeffs<DYN_R, V>(c, rin, p, Rp, L);
     const V b_diff = z - xin;
@@ -202,11 +212,9 @@ __global__ __launch_bounds__(64) void clipper_fwd_kernel(
     const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T, int general)
 {
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    if constexpr (!DYN_R) {
-        if (!general && series_only_omega1(c)) {
-            clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, true>(c, x, r, y, zstash, z0, zT, B, T);
-            return;
-        }
+    if (fast_root_ok<DYN_R>(c, general)) {
+        clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, true>(c, x, r, y, zstash, z0, zT, B, T);
+        return;
     }
     clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, false>(c, x, r, y, zstash, z0, zT, B, T);
 }
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(64) void clipper_tp_repair_kernel(
     const int64_t b = b_raw < B ? b_raw : B - 1;
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
-    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
+    fast = fast_root_ok<DYN_R>(c, general);
     const int slot = (ctl != nullptr && snap != nullptr) ? ctl->head : 0;
     int nrep = 0;
     bool fixed_prev = false;                                    // wave-uniform: chunk k-1 was re-run to its end
@@ -832,7 +840,7 @@ __global__ __launch_bounds__(64) void clipper_tp_repair_kernel(
         float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
         float z = e;
         bool done;
-        if (fast) done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, !DYN_R>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, true, z);
+        if (fast) done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, true>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, true, z);
         else done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, false>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, true, z);
         if (done) {
             zend[k * B + b] = z;
@@ -1206,9 +1214,9 @@ __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     __shared__ double sh[64][4];
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
-    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);     // wave-uniform, as in the forward
+    fast = fast_root_ok<DYN_R>(c, general);                             // wave-uniform, as in the forward
     if (fast)
-        clipper_bwd_tp_body<DYN_R, SYM, TM, VEC4, MSE, V, !DYN_R>(c, x, r, zstash, gy, target, zT, gscale, out, B, Bh, T, L, gcoef, skip);
+        clipper_bwd_tp_body<DYN_R, SYM, TM, VEC4, MSE, V, true>(c, x, r, zstash, gy, target, zT, gscale, out, B, Bh, T, L, gcoef, skip);
     else
         clipper_bwd_tp_body<DYN_R, SYM, TM, VEC4, MSE, V, false>(c, x, r, zstash, gy, target, zT, gscale, out, B, Bh, T, L, gcoef, skip);
     bwd_tp_finish(out, B, ws, gz0, tickets, theta, fs, DYN_R ? 1 : 0, gtheta, accumulate, sse_out, adam, sh);

@@ -651,9 +651,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
 #endif
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
-    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
+    fast = fast_root_ok<DYN_R>(c, general);
     if (fast)
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, true, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
                                                             T, L, W, hgs, skip, skew);
     else
         clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
@@ -684,9 +684,9 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
     static_assert(VT<V>::N == 1, "one sequence per lane (the repair kernel and tp_finish index tiles of 64)");
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
-    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);     // wave-uniform: every practical diode
+    fast = fast_root_ok<DYN_R>(c, general);                             // wave-uniform: every practical diode
     if (fast)
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, !DYN_R, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
+        clipper_fused_body<DYN_R, SYM, TM, VEC4, true, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
                                                                       ctl, snap, J, B, T, L, W, 0.0f, 0);
     else
         clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
     const int64_t b0 = raw < B ? raw : B - NSEQ;
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
-    if constexpr (!DYN_R) fast = !general && series_only_omega1(c);
+    fast = fast_root_ok<DYN_R>(c, general);
     const int slot = (ctl != nullptr && snap != nullptr) ? ctl->head : 0;     // the step advanced head to the slot it wrote
     int nrep = 0;
 #pragma unroll 1
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
             chunk_span(k, K, L, skew, T, t0, t1);
             float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
             float z = e;
-            if (fast) fused_rerun_chunk<DYN_R, SYM, TM, !DYN_R, LOSS>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
+            if (fast) fused_rerun_chunk<DYN_R, SYM, TM, true, LOSS>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
             else fused_rerun_chunk<DYN_R, SYM, TM, false, LOSS>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
             zend[k * B + b] = z;
             if (zT && t1 == T) zT[b] = z;
