@@ -139,8 +139,21 @@ int wdf_clipper_mlp_fwd_tp(const float* x, const float* r, const float* theta2, 
     if (rc) return rc;
     if (!y || !ws || !status) return fail(WDF_EINVAL, "null y/ws/status");
     if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
-    const MlpTpGeom g = mlp_tp_geom(T, n_chunks);
+    MlpTpGeom g = mlp_tp_geom(T, n_chunks);
     const int64_t W = ((int64_t)warmup + 15) / 16 * 16;
+    // Chunk 0 needs no warm-up: left equal, its waves finish after L steps while every other wave runs L + W.  Balance
+    // them: L0 = (T + (K-1) W) / K for chunk 0, the rest shared by the other K - 1 chunks -- all waves then run ~L0 steps
+    // (one warm-up value for the batch only; with per-wave warm-ups the chunks stay equal).
+    int64_t L0 = g.L;
+    if (g.K >= 3 && warmup_per_wave == nullptr && W > 0) {
+        int64_t l0 = ((T + (int64_t)(g.K - 1) * W) / g.K + 15) / 16 * 16;
+        const int64_t lmax = T - 16 * (int64_t)(g.K - 1);
+        if (l0 > lmax) l0 = lmax;
+        if (l0 > g.L) {
+            const int64_t rest = ((T - l0 + (g.K - 1) - 1) / (g.K - 1) + 15) / 16 * 16;
+            if (rest >= 16 && l0 + (int64_t)(g.K - 2) * rest < T) { L0 = l0; g.L = rest; }   // (every chunk non-empty)
+        }
+    }
     float* zwarm = (float*)ws;
     float* zend = zwarm + (size_t)g.K * (size_t)B;
     unsigned* gate = (unsigned*)(zend + (size_t)g.K * (size_t)B);
@@ -153,10 +166,10 @@ int wdf_clipper_mlp_fwd_tp(const float* x, const float* r, const float* theta2, 
             EventBracket bracket(s);                                                                             \
             if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, true>), grid, dim3(64), 0, s, x, r, theta2, w, \
                                         hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave,                \
-                                        (wdf::MlpTpStatus*)status, B, T, g.L, W);                                  \
+                                        (wdf::MlpTpStatus*)status, B, T, g.L, W, L0);                              \
             else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, false>), grid, dim3(64), 0, s, x, r, theta2, w,    \
                                     hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave,                    \
-                                    (wdf::MlpTpStatus*)status, B, T, g.L, W);                                      \
+                                    (wdf::MlpTpStatus*)status, B, T, g.L, W, L0);                                  \
         }                                                                                                        \
         if (g.K > 1) {                                                                                           \
             hipLaunchKernelGGL(wdf::mlp_tp_verify_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, zwarm, zend, B, \

@@ -47,14 +47,17 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
     const float* __restrict__ w, int H, float fs, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
-    const int* __restrict__ wrow, MlpTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W)
+    const int* __restrict__ wrow, MlpTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W, int64_t L0)
 {
+    // L0: length of chunk 0, the only chunk without a warm-up: chunk k > 0 owns [L0 + (k-1) L, L0 + k L).  With L0 = L + W
+    // every wave runs about the same number of steps (the host balances it, wdf_capi_mlp.hip); L0 = L: equal chunks.
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = MlpTpStatus{0, 0.0f, 0, 0};   // the verify kernel adds
     const int lane = threadIdx.x, j = lane & 15;
     const int64_t b_raw = (int64_t)blockIdx.x * 4 + (lane >> 4);
     const int64_t b = b_raw < B ? b_raw : B - 1;
     const int64_t k = blockIdx.y;
-    const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const int64_t t0 = k == 0 ? 0 : L0 + (k - 1) * L;
+    const int64_t t1 = k == 0 ? (L0 < T ? L0 : T) : ((t0 + L < T) ? t0 + L : T);
     const int64_t Wq = wrow ? (int64_t)wrow[blockIdx.x] : W;
     const int64_t tw = (k > 0 && t0 > Wq) ? t0 - Wq : 0;
     const MlpClipConsts c = mlp_load_consts(theta2, fs);
