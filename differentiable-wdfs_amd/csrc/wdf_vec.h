@@ -1,11 +1,11 @@
 // wdf_vec.h -- one-or-two-wide fp32 value types for the WDF kernels.
 //
-// The recursion is VALU-issue bound on MI355X (rocprof: ~85 % VALU busy at 2 waves/SIMD), and
-// a CDNA4 SIMD retires a packed v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two fp32 lanes-ops
-// per lane) at the cost of one plain VALU op.  So the kernels are written once over a value
-// type V: V = float runs one sequence per lane; V = v2f runs TWO independent sequences per lane
-// and lets the compiler pack every add / mul / fma of the step.  Transcendentals, compares
-// and selects stay per component.
+// The kernels are written once over a value type V: V = float runs one sequence per lane; V = v2f runs TWO independent
+// sequences per lane and lets the compiler pack every add / mul / fma of the step into v_pk_* instructions
+// (transcendentals, compares and selects stay per component).  On gfx950 a packed fp32 instruction costs TWO plain ones
+// (tools/ubench/valu_rate.hip: 1.05 vs 2.0 ns per instruction and SIMD), so packing buys no arithmetic; what it buys is
+// half the memory / scalar / addressing instructions per sequence and two independent chains per wave -- worth ~5 % in
+// the VALU-bound one-pass step (wdf_clipper_fused.h), nothing in the memory-co-bound kernel pair (which stays at float).
 #pragma once
 
 #include <hip/hip_runtime.h>
