@@ -130,16 +130,20 @@ size_t wdf_clipper_mlp_fwd_tp_ws_bytes(int64_t B, int n_chunks)
     return (size_t)2 * (size_t)n_chunks * (size_t)B * sizeof(float) + (size_t)((B + 3) / 4) * sizeof(unsigned);
 }
 
-int wdf_clipper_mlp_fwd_tp(const float* x, const float* r, const float* theta2, const float* w, int hidden,
-                           int n_tanh_layers, float fs, float* y, float* zstash, const float* z0, float* zT, int64_t B,
-                           int64_t T, int n_chunks, int warmup, const int32_t* warmup_per_wave, float tol, void* ws,
-                           void* status, void* stream)
+// kappa != nullptr: the forward also leaves kappa[T][B] (the adjoint recurrence's coefficient) for
+// wdf_clipper_mlp_bwd_w_tp_kappa; the waves the sequential kernel re-runs get theirs from the stash afterwards.
+static int mlp_fwd_tp_common(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                             int n_tanh_layers, float fs, float* y, float* zstash, const float* z0, float* zT, int64_t B,
+                             int64_t T, int n_chunks, int warmup, const int32_t* warmup_per_wave, float tol, void* ws,
+                             void* status, float* kappa, bool want_kappa, void* stream)
 {
     int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, 0);
     if (rc) return rc;
     if (!y || !ws || !status) return fail(WDF_EINVAL, "null y/ws/status");
+    if (want_kappa && (!kappa || !zstash)) return fail(WDF_EINVAL, "null kappa/zstash");
     if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
     MlpTpGeom g = mlp_tp_geom(T, n_chunks);
+    const MlpTpGeom gu = g;                                    // equal chunks: the gated kappa pass's grid
     const int64_t W = ((int64_t)warmup + 15) / 16 * 16;
     // Chunk 0 needs no warm-up: left equal, its waves finish after L steps while every other wave runs L + W.  Balance
     // them: L0 = (T + (K-1) W) / K for chunk 0, the rest shared by the other K - 1 chunks -- all waves then run ~L0 steps
@@ -147,7 +151,7 @@ int wdf_clipper_mlp_fwd_tp(const float* x, const float* r, const float* theta2, 
     int64_t L0 = g.L;
     if (g.K >= 3 && warmup_per_wave == nullptr && W > 0) {
         int64_t l0 = ((T + (int64_t)(g.K - 1) * W) / g.K + 15) / 16 * 16;
-        const int64_t lmax = T - 16 * (int64_t)(g.K - 1);
+        const int64_t lmax = (T - 16 * (int64_t)(g.K - 1)) / 16 * 16;   // (chunk starts stay multiples of 16)
         if (l0 > lmax) l0 = lmax;
         if (l0 > g.L) {
             const int64_t rest = ((T - l0 + (g.K - 1) - 1) / (g.K - 1) + 15) / 16 * 16;
@@ -160,16 +164,21 @@ int wdf_clipper_mlp_fwd_tp(const float* x, const float* r, const float* theta2, 
     const dim3 grid((unsigned)((B + 3) / 4), (unsigned)g.K);
     const bool dyn = r != nullptr;
     hipStream_t s = (hipStream_t)stream;
+#define WDF_ROW_FWD_TP_LAUNCH(NL_, DYN_, KAP_)                                                                     \
+    hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, DYN_, KAP_>), grid, dim3(64), 0, s, x, r, theta2, w,     \
+                       hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave, (wdf::MlpTpStatus*)status, B, T,  \
+                       g.L, W, L0, kappa)
 #define WDF_ROW_FWD_TP(NL_)                                                                                      \
     if (n_tanh_layers == NL_) {                                                                                  \
         {                                                                                                        \
             EventBracket bracket(s);                                                                             \
-            if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, true>), grid, dim3(64), 0, s, x, r, theta2, w, \
-                                        hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave,                \
-                                        (wdf::MlpTpStatus*)status, B, T, g.L, W, L0);                              \
-            else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, false>), grid, dim3(64), 0, s, x, r, theta2, w,    \
-                                    hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave,                    \
-                                    (wdf::MlpTpStatus*)status, B, T, g.L, W, L0);                                  \
+            if (want_kappa) {                                                                                    \
+                if (dyn) WDF_ROW_FWD_TP_LAUNCH(NL_, true, true);                                                 \
+                else WDF_ROW_FWD_TP_LAUNCH(NL_, false, true);                                                    \
+            } else {                                                                                             \
+                if (dyn) WDF_ROW_FWD_TP_LAUNCH(NL_, true, false);                                                \
+                else WDF_ROW_FWD_TP_LAUNCH(NL_, false, false);                                                   \
+            }                                                                                                    \
         }                                                                                                        \
         if (g.K > 1) {                                                                                           \
             hipLaunchKernelGGL(wdf::mlp_tp_verify_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, zwarm, zend, B, \
@@ -178,11 +187,39 @@ int wdf_clipper_mlp_fwd_tp(const float* x, const float* r, const float* theta2, 
                                         theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)gate);   \
             else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, false>), dim3(grid.x), dim3(64), 0, s, x, r,     \
                                     theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)gate);       \
+            if (want_kappa) {                                                                                    \
+                const dim3 kgrid(grid.x, (unsigned)gu.K);                                                        \
+                if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, true>), kgrid, dim3(64), 0, s, x, r,   \
+                                            theta2, w, hidden, fs, (const float*)zstash, kappa, B, T, gu.L,       \
+                                            (const unsigned*)gate);                                              \
+                else hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, false>), kgrid, dim3(64), 0, s, x, r,      \
+                                        theta2, w, hidden, fs, (const float*)zstash, kappa, B, T, gu.L,           \
+                                        (const unsigned*)gate);                                                  \
+            }                                                                                                    \
         }                                                                                                        \
     }
     WDF_ROW_FWD_TP(3) WDF_ROW_FWD_TP(4) WDF_ROW_FWD_TP(5)
+#undef WDF_ROW_FWD_TP_LAUNCH
 #undef WDF_ROW_FWD_TP
     return check_launch("wdf_clipper_mlp_fwd_tp");
+}
+
+int wdf_clipper_mlp_fwd_tp(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                           int n_tanh_layers, float fs, float* y, float* zstash, const float* z0, float* zT, int64_t B,
+                           int64_t T, int n_chunks, int warmup, const int32_t* warmup_per_wave, float tol, void* ws,
+                           void* status, void* stream)
+{
+    return mlp_fwd_tp_common(x, r, theta2, w, hidden, n_tanh_layers, fs, y, zstash, z0, zT, B, T, n_chunks, warmup,
+                             warmup_per_wave, tol, ws, status, nullptr, false, stream);
+}
+
+int wdf_clipper_mlp_fwd_tp_kappa(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                                 int n_tanh_layers, float fs, float* y, float* zstash, float* kappa, const float* z0,
+                                 float* zT, int64_t B, int64_t T, int n_chunks, int warmup,
+                                 const int32_t* warmup_per_wave, float tol, void* ws, void* status, void* stream)
+{
+    return mlp_fwd_tp_common(x, r, theta2, w, hidden, n_tanh_layers, fs, y, zstash, z0, zT, B, T, n_chunks, warmup,
+                             warmup_per_wave, tol, ws, status, kappa, true, stream);
 }
 
 int64_t wdf_clipper_mlp_bwd_w_tp_ws_bytes(int hidden, int n_tanh_layers, int64_t B, int64_t T, int n_chunks)
@@ -193,13 +230,16 @@ int64_t wdf_clipper_mlp_bwd_w_tp_ws_bytes(int hidden, int n_tanh_layers, int64_t
            nparts * wdf_mlp_weight_count(hidden, n_tanh_layers) * (int64_t)sizeof(float);
 }
 
-int wdf_clipper_mlp_bwd_w_tp(const float* x, const float* r, const float* theta2, const float* w, int hidden,
-                             int n_tanh_layers, float fs, const float* zstash, const float* gy, void* ws, float* gtheta2,
-                             float* gw, int64_t B, int64_t T, int n_chunks, void* stream)
+// kappa_in != nullptr: pass (A) is skipped, the scan reads the forward's kappa (wdf_clipper_mlp_fwd_tp_kappa).
+static int mlp_bwd_w_tp_common(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                               int n_tanh_layers, float fs, const float* zstash, const float* kappa_in, bool have_kappa,
+                               const float* gy, void* ws, float* gtheta2, float* gw, int64_t B, int64_t T, int n_chunks,
+                               void* stream)
 {
     int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, 0);
     if (rc) return rc;
     if (!zstash || !gy || !ws || !gtheta2 || !gw) return fail(WDF_EINVAL, "null zstash/gy/ws/gtheta2/gw");
+    if (have_kappa && !kappa_in) return fail(WDF_EINVAL, "null kappa");
     if (n_chunks < 1) return fail(WDF_EINVAL, "n_chunks >= 1");
     const MlpTpGeom g = mlp_tp_geom(T, n_chunks);
     const dim3 grid((unsigned)((B + 3) / 4), (unsigned)g.K);
@@ -211,11 +251,14 @@ int wdf_clipper_mlp_bwd_w_tp(const float* x, const float* r, const float* theta2
     hipStream_t s = (hipStream_t)stream;
 #define WDF_ROW_BWD_TP(NL_)                                                                                      \
     if (n_tanh_layers == NL_) {                                                                                  \
-        if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, true>), grid, dim3(64), 0, s, x, r, theta2, w,   \
-                                    hidden, fs, zstash, kap, B, T, g.L);                                          \
-        else hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, false>), grid, dim3(64), 0, s, x, r, theta2, w,      \
-                                hidden, fs, zstash, kap, B, T, g.L);                                              \
-        hipLaunchKernelGGL(wdf::mlp_adjoint_scan_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, kap, gy, kap, B, T); \
+        if (!have_kappa) {                                                                                       \
+            if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, true>), grid, dim3(64), 0, s, x, r, theta2,  \
+                                        w, hidden, fs, zstash, kap, B, T, g.L, (const unsigned*)nullptr);        \
+            else hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, false>), grid, dim3(64), 0, s, x, r, theta2,     \
+                                    w, hidden, fs, zstash, kap, B, T, g.L, (const unsigned*)nullptr);            \
+        }                                                                                                        \
+        hipLaunchKernelGGL(wdf::mlp_adjoint_scan_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s,             \
+                           have_kappa ? kappa_in : (const float*)kap, gy, kap, B, T);                            \
         {                                                                                                        \
             EventBracket bracket(s);                                                                             \
             if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_wgrad_tp_kernel<NL_, true>), grid, dim3(64), 0, s, x, r, theta2, \
@@ -234,6 +277,22 @@ int wdf_clipper_mlp_bwd_w_tp(const float* x, const float* r, const float* theta2
     hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_wide_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64, 16), 0, s,
                        (const float*)wsw, nparts, count, gw);
     return check_launch("wdf_clipper_mlp_bwd_w_tp reduce");
+}
+
+int wdf_clipper_mlp_bwd_w_tp(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                             int n_tanh_layers, float fs, const float* zstash, const float* gy, void* ws, float* gtheta2,
+                             float* gw, int64_t B, int64_t T, int n_chunks, void* stream)
+{
+    return mlp_bwd_w_tp_common(x, r, theta2, w, hidden, n_tanh_layers, fs, zstash, nullptr, false, gy, ws, gtheta2, gw,
+                               B, T, n_chunks, stream);
+}
+
+int wdf_clipper_mlp_bwd_w_tp_kappa(const float* x, const float* r, const float* theta2, const float* w, int hidden,
+                                   int n_tanh_layers, float fs, const float* zstash, const float* kappa, const float* gy,
+                                   void* ws, float* gtheta2, float* gw, int64_t B, int64_t T, int n_chunks, void* stream)
+{
+    return mlp_bwd_w_tp_common(x, r, theta2, w, hidden, n_tanh_layers, fs, zstash, kappa, true, gy, ws, gtheta2, gw, B,
+                               T, n_chunks, stream);
 }
 
 size_t wdf_clipper_mlp_bwd_ws_bytes(int64_t B) { return B > 0 ? (size_t)((B + 3) / 4) * 4 * sizeof(double) : 0; }

@@ -42,12 +42,15 @@ struct MlpTpStatus {
 };
 
 // zwarm, zend: [K][B].  wrow: per-wave warm-up steps (multiple of 16) or nullptr (W for all).
-template <int NL, bool DYN_R>
+// KAP: the owned steps also evaluate the network's input Jacobian and store kappa[n] = Da - p (1 + Da) [T][B] -- what
+// pass (A) of the reverse sweep would recompute from the stash with a second network evaluation per step.
+template <int NL, bool DYN_R, bool KAP>
 __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
     const float* __restrict__ w, int H, float fs, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
-    const int* __restrict__ wrow, MlpTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W, int64_t L0)
+    const int* __restrict__ wrow, MlpTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W, int64_t L0,
+    float* __restrict__ kappa)
 {
     // L0: length of chunk 0, the only chunk without a warm-up: chunk k > 0 owns [L0 + (k-1) L, L0 + k L).  With L0 = L + W
     // every wave runs about the same number of steps (the host balances it, wdf_capi_mlp.hip); L0 = L: equal chunks.
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_tp_kernel(
     const int64_t Wq = wrow ? (int64_t)wrow[blockIdx.x] : W;
     const int64_t tw = (k > 0 && t0 > Wq) ? t0 - Wq : 0;
     const MlpClipConsts c = mlp_load_consts(theta2, fs);
-    const RowWeights<NL> Wt = row_load_weights<NL>(w, H, j, false);
+    const RowWeights<NL> Wt = row_load_weights<NL>(w, H, j, KAP);
     const float* __restrict__ xp = x + b * T;
     const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
     float z = (tw == 0 && z0) ? z0[b] : 0.0f;
@@ -69,6 +72,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_tp_kernel(
     for (int64_t tb = tw; tb < t1; tb += 16) {
         if (tb == t0 && j == 0) zwarm[k * B + b] = z;          // the state this chunk arrives with
         const bool owned = tb >= t0;
+        float kp = 0.0f;                                        // (KAP) lane i of the row keeps step i's kappa
         const int64_t tj = tb + j < T ? tb + j : T - 1;
         const float xblk = xp[tj];
         const float rblk = DYN_R ? rp[tj] : 1.0f;
@@ -85,12 +89,24 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_tp_kernel(
             const float b_temp = -p * b_diff;
             const float a = z + b_temp;
             const float zn = b_temp - row_mlp_fwd<NL>(Wt, a, lr, act);     // b_root = -MLP
+            if constexpr (KAP) {
+                if (owned) {                                             // (wave-uniform)
+                    float da, dlr;
+                    row_mlp_grad_in<NL>(Wt, act, da, dlr);
+                    const float Da = -da;
+                    const float kv = Da - p * (1.0f + Da);
+                    kp = (j == i) ? kv : kp;
+                }
+            }
             if (owned && j == 0) {
                 const int64_t o = (tb + i) * B + b;
                 if (zstash) zstash[o] = z;
                 y[o] = 0.5f * (zn + z);
             }
             z = zn;
+        }
+        if constexpr (KAP) {
+            if (owned && j < n) kappa[(tb + j) * B + b] = kp;
         }
     }
     if (j == 0) {
@@ -138,8 +154,9 @@ template <int NL, bool DYN_R>
 __global__ __launch_bounds__(64) void clipper_mlp_row_kappa_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
     const float* __restrict__ w, int H, float fs, const float* __restrict__ zstash, float* __restrict__ kappa,
-    int64_t B, int64_t T, int64_t L)
+    int64_t B, int64_t T, int64_t L, const unsigned* __restrict__ gate = nullptr)
 {
+    if (gate != nullptr && gate[blockIdx.x] == 0u) return;      // behind a forward that stored kappa itself: re-run waves only
     const int lane = threadIdx.x, j = lane & 15;
     const int64_t b_raw = (int64_t)blockIdx.x * 4 + (lane >> 4);
     const int64_t b = b_raw < B ? b_raw : B - 1;

@@ -139,6 +139,10 @@ def lib():
     L.wdf_clipper_mlp_bwd_w_tp_ws_bytes.argtypes = [ci, ci, i64, i64, ci]
     L.wdf_clipper_mlp_bwd_w_tp.restype = ci
     L.wdf_clipper_mlp_bwd_w_tp.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, vp, fp, fp, i64, i64, ci, vp]
+    L.wdf_clipper_mlp_fwd_tp_kappa.restype = ci
+    L.wdf_clipper_mlp_fwd_tp_kappa.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, fp, i64, i64, ci, ci, vp, cf, vp, vp, vp]
+    L.wdf_clipper_mlp_bwd_w_tp_kappa.restype = ci
+    L.wdf_clipper_mlp_bwd_w_tp_kappa.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, vp, fp, fp, i64, i64, ci, vp]
     L.wdf_clipper_mlp_bwd_ws_bytes.restype = C.c_size_t
     L.wdf_clipper_mlp_bwd_ws_bytes.argtypes = [i64]
     L.wdf_clipper_mlp_bwd.restype = ci
@@ -197,6 +201,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
     "wdf_clipper_mlp_tp_chunks", "wdf_clipper_mlp_fwd_tp_ws_bytes", "wdf_clipper_mlp_fwd_tp",
     "wdf_clipper_mlp_bwd_w_tp_ws_bytes", "wdf_clipper_mlp_bwd_w_tp",
+    "wdf_clipper_mlp_fwd_tp_kappa", "wdf_clipper_mlp_bwd_w_tp_kappa",
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
     "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step",
@@ -689,10 +694,11 @@ def clipper_mlp_bwd_w(x, theta2, w, hidden, n_tanh, fs, zstash, gy, r=None):
 
 
 def clipper_mlp_fwd_tp(x, theta2, w, hidden, n_tanh, fs, n_chunks, warmup, r=None, warmup_per_wave=None, tol=1e-6,
-                       want_stash=True, z0=None, want_zT=False, ws=None, status=None):
+                       want_stash=True, z0=None, want_zT=False, ws=None, status=None, want_kappa=False):
     """Time-parallel MLP-root forward (csrc/wdf_mlp_tp.h).  warmup_per_wave: int32[ceil(B/4)] device tensor
     (multiples of 16) or None.  -> y [T,B], zstash | None, zT | None, status (int32[4]: n_bad, max-miss bits,
-    gated waves, 0; read with mlp_tp_status())."""
+    gated waves, 0; read with mlp_tp_status()).  want_kappa: the forward also stores the adjoint recurrence's
+    coefficient kappa [T,B] (for clipper_mlp_bwd_w_tp(kappa=...)); returned as a fifth value."""
     require_gpu()
     x, r, theta2, w, z0 = _f32_dev(x, "x"), _f32_dev(r, "r"), _f32_dev(theta2, "theta2"), _f32_dev(w, "w"), _f32_dev(z0, "z0")
     if w.numel() != lib().wdf_mlp_weight_count(int(hidden), int(n_tanh)):
@@ -708,6 +714,16 @@ def clipper_mlp_fwd_tp(x, theta2, w, hidden, n_tanh, fs, n_chunks, warmup, r=Non
         ws = torch.empty((lib().wdf_clipper_mlp_fwd_tp_ws_bytes(B, int(n_chunks)),), dtype=torch.uint8, device=x.device)
     if status is None:
         status = torch.empty((4,), dtype=torch.int32, device=x.device)
+    if want_kappa:
+        if zs is None:
+            raise WdfHipError("want_kappa needs the stash (want_stash=True)")
+        kap = torch.empty((T, B), dtype=torch.float32, device=x.device)
+        rc = lib().wdf_clipper_mlp_fwd_tp_kappa(_ptr(x), _ptr(r), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh), float(fs),
+                                                _ptr(y), _ptr(zs), _ptr(kap), _ptr(z0), _ptr(zT), B, T, int(n_chunks),
+                                                int(warmup), _ptr(warmup_per_wave), float(tol), _ptr(ws), _ptr(status),
+                                                _stream())
+        _check(rc, "wdf_clipper_mlp_fwd_tp_kappa")
+        return y, zs, zT, status, kap
     rc = lib().wdf_clipper_mlp_fwd_tp(_ptr(x), _ptr(r), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh), float(fs), _ptr(y),
                                       _ptr(zs), _ptr(z0), _ptr(zT), B, T, int(n_chunks), int(warmup), _ptr(warmup_per_wave),
                                       float(tol), _ptr(ws), _ptr(status), _stream())
@@ -720,8 +736,9 @@ def mlp_tp_status(status):
     return {"n_bad": int(s[0]), "max_miss": float(s[1:2].view(torch.float32)[0]), "gated_waves": int(s[2])}
 
 
-def clipper_mlp_bwd_w_tp(x, theta2, w, hidden, n_tanh, fs, zstash, gy, n_chunks, r=None, ws=None):
-    """Exact reverse sweep parallel over all steps (kappa / adjoint scan / weight-gradient kernels) -> gtheta2 [2], gw."""
+def clipper_mlp_bwd_w_tp(x, theta2, w, hidden, n_tanh, fs, zstash, gy, n_chunks, r=None, ws=None, kappa=None):
+    """Exact reverse sweep parallel over all steps (kappa / adjoint scan / weight-gradient kernels) -> gtheta2 [2], gw.
+    kappa [T,B]: the coefficient a want_kappa forward left -- the kappa pass is skipped."""
     require_gpu()
     x, r, theta2, w = _f32_dev(x, "x"), _f32_dev(r, "r"), _f32_dev(theta2, "theta2"), _f32_dev(w, "w")
     zstash, gy = _f32_dev(zstash, "zstash"), _f32_dev(gy, "gy")
@@ -733,6 +750,15 @@ def clipper_mlp_bwd_w_tp(x, theta2, w, hidden, n_tanh, fs, zstash, gy, n_chunks,
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     gth = torch.empty((2,), dtype=torch.float32, device=x.device)
     gw = torch.empty((w.numel(),), dtype=torch.float32, device=x.device)
+    if kappa is not None:
+        kappa = _f32_dev(kappa, "kappa")
+        if tuple(kappa.shape) != (T, B):
+            raise WdfHipError(f"kappa: expected [{T}, {B}], got {tuple(kappa.shape)}")
+        rc = lib().wdf_clipper_mlp_bwd_w_tp_kappa(_ptr(x), _ptr(r), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh), float(fs),
+                                                  _ptr(zstash), _ptr(kappa), _ptr(gy), _ptr(ws), _ptr(gth), _ptr(gw), B, T,
+                                                  int(n_chunks), _stream())
+        _check(rc, "wdf_clipper_mlp_bwd_w_tp_kappa")
+        return gth, gw
     rc = lib().wdf_clipper_mlp_bwd_w_tp(_ptr(x), _ptr(r), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh), float(fs),
                                         _ptr(zstash), _ptr(gy), _ptr(ws), _ptr(gth), _ptr(gw), B, T, int(n_chunks), _stream())
     _check(rc, "wdf_clipper_mlp_bwd_w_tp")

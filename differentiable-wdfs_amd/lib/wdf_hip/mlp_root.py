@@ -4,6 +4,7 @@ Function and the data-level time-parallel segmentation.
 The per-lane reverse-sweep kernel returns g_b[n] = dL/d b[n] and the network inputs
 (a[n], log R[n]); the weight gradient  dL/dW = -sum_n g_b[n] dMLP(a[n], lr[n])/dW  is a sum
 over B*T independent samples, done by wdf_clipper_mlp_wgrad (fully parallel HIP kernel)."""
+import os
 import math
 import weakref
 from collections import namedtuple
@@ -43,6 +44,7 @@ def flat_weights(dense):
 
 MlpTpPlan = namedtuple("MlpTpPlan", ["k_fwd", "warmup", "warmup_per_wave", "tol", "k_bwd"])
 LAST_TP_STATUS = {"status": None}
+KAPPA_FROM_FORWARD = os.environ.get("WDF_MLP_KAPPA_FROM_FORWARD", "1") != "0"   # 0: the reverse sweep recomputes kappa
 _WARMUP_ADAPT = {}     # (x shape, forward chunks, planned warm-up) -> {"warmup": steps in use, "calls": n}
 
 
@@ -54,14 +56,20 @@ class _ClipperMlpFn(torch.autograd.Function):
     def forward(ctx, theta2, w, x, r, z0, fs, hidden, n_tanh, want_zT, want_stash=False, tp=None):
         need = theta2.requires_grad or w.requires_grad
         th, wd = theta2.detach().contiguous(), w.detach().contiguous()
+        kap = None
         if tp is not None and tp.k_fwd > 1 and not binding.MLP_LANE_PER_SEQUENCE:
             # The warm-up estimate knows the RC network, not the learned root: the first calls of a shape (and
             # every 16th later) look at the verification's verdict -- one 16-byte read-back -- and lengthen
             # the warm-up by half when a wave had to be re-run (a re-run is a whole sequential pass of that wave).
             ad = _WARMUP_ADAPT.setdefault((x.shape, tp.k_fwd, tp.warmup), {"warmup": tp.warmup, "calls": 0})
-            y, zs, zT, st = binding.clipper_mlp_fwd_tp(x, th, wd, hidden, n_tanh, fs, tp.k_fwd, ad["warmup"], r=r,
-                                                       warmup_per_wave=tp.warmup_per_wave, tol=tp.tol,
-                                                       want_stash=need or want_stash, z0=z0, want_zT=want_zT)
+            # a training call also takes kappa from the forward (the reverse sweep then skips its first pass)
+            use_kappa = need and tp.k_bwd > 1 and KAPPA_FROM_FORWARD
+            out = binding.clipper_mlp_fwd_tp(x, th, wd, hidden, n_tanh, fs, tp.k_fwd, ad["warmup"], r=r,
+                                             warmup_per_wave=tp.warmup_per_wave, tol=tp.tol,
+                                             want_stash=need or want_stash, z0=z0, want_zT=want_zT,
+                                             want_kappa=use_kappa)
+            y, zs, zT, st = out[:4]
+            kap = out[4] if use_kappa else None
             LAST_TP_STATUS["status"] = st
             ad["calls"] += 1
             if tp.warmup_per_wave is None and (ad["calls"] <= 4 or ad["calls"] % 16 == 0):
@@ -72,8 +80,10 @@ class _ClipperMlpFn(torch.autograd.Function):
                                                 z0=z0, want_zT=want_zT)
         ctx.tp = tp
         ctx.cfg = (fs, hidden, n_tanh, r is not None)
+        ctx.kappa = None
         if need:
             ctx.save_for_backward(th, wd, x, zs, *([r] if r is not None else []))
+            ctx.kappa = kap                                  # (not an input or output: a plain attribute)
         if want_zT:
             ctx.mark_non_differentiable(zT)
         if want_stash:
@@ -89,7 +99,8 @@ class _ClipperMlpFn(torch.autograd.Function):
         th, wd, x, zs = saved[:4]
         r = saved[4] if has_r else None
         if ctx.tp is not None and ctx.tp.k_bwd > 1 and not binding.MLP_LANE_PER_SEQUENCE:
-            gth, gw = binding.clipper_mlp_bwd_w_tp(x, th, wd, hidden, n_tanh, fs, zs, gy.contiguous(), ctx.tp.k_bwd, r=r)
+            gth, gw = binding.clipper_mlp_bwd_w_tp(x, th, wd, hidden, n_tanh, fs, zs, gy.contiguous(), ctx.tp.k_bwd, r=r,
+                                                   kappa=ctx.kappa)
         elif binding.MLP_LANE_PER_SEQUENCE:
             gth, gb, ain, lrin = binding.clipper_mlp_bwd(x, th, wd, hidden, n_tanh, fs, zs, gy.contiguous(), r=r)
             # weight gradient: dL/dw = -sum_n gb[n] dMLP(a[n], lr[n])/dw, all B*T samples in parallel

@@ -414,6 +414,19 @@ int wdf_clipper_mlp_bwd_w_tp(const float* x, const float* r, const float* theta2
                              int hidden, int n_tanh_layers, float fs,
                              const float* zstash, const float* gy, void* ws, float* gtheta2, float* gw,
                              int64_t B, int64_t T, int n_chunks, void* stream);
+/* The same pair with the adjoint recurrence's coefficient handed across: the forward's owned steps also evaluate the
+ * network's input Jacobian (the activations are in registers there) and store kappa[n] = d z[n+1]/d z[n] [T][B]
+ * (waves the sequential kernel re-runs get theirs from the stash by a gated pass); the reverse sweep then starts at
+ * the scan -- one network evaluation per step less.  Same y, stash, gradients as the pair above.  zstash is required. */
+int wdf_clipper_mlp_fwd_tp_kappa(const float* x, const float* r, const float* theta2, const float* w,
+                                 int hidden, int n_tanh_layers, float fs,
+                                 float* y, float* zstash, float* kappa, const float* z0, float* zT,
+                                 int64_t B, int64_t T, int n_chunks, int warmup, const int32_t* warmup_per_wave,
+                                 float tol, void* ws, void* status, void* stream);
+int wdf_clipper_mlp_bwd_w_tp_kappa(const float* x, const float* r, const float* theta2, const float* w,
+                                   int hidden, int n_tanh_layers, float fs,
+                                   const float* zstash, const float* kappa, const float* gy, void* ws,
+                                   float* gtheta2, float* gw, int64_t B, int64_t T, int n_chunks, void* stream);
 
 /* library / device info */
 int wdf_abi_version(void);
