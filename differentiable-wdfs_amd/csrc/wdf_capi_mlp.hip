@@ -5,6 +5,7 @@
 #include "wdf_mlp.h"
 #include "wdf_mlp_row.h"
 #include "wdf_mlp_tp.h"
+#include "wdf_mlp_mfma.h"
 using namespace wdfcapi;
 
 extern "C" {
@@ -48,6 +49,16 @@ static int mlp_check(const float* x, const float* theta2, const float* w, int hi
     return WDF_OK;
 }
 
+// Which forward kernel: the row kernel (4 sequences per wave, DPP; the shorter dependent chain per step: 0.31 us against
+// 0.55 us) while the batch leaves SIMDs idle, the matrix-core kernel (16 per wave, wdf_mlp_mfma.h; 1.5x the row
+// kernel's throughput) once the row kernel would stack three waves on a SIMD.  WDF_MLP_FWD_ROW = 1 / 0 forces one.
+static bool mlp_fwd_on_matrix_cores(int64_t B)
+{
+    const char* e = getenv("WDF_MLP_FWD_ROW");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '0';
+    return B >= 12288;
+}
+
 int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, const float* w, int hidden,
                         int n_tanh_layers, float fs, float* y, float* zstash, const float* z0, float* zT, int64_t B,
                         int64_t T, int flags, void* stream)
@@ -59,6 +70,22 @@ int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, con
     const bool dyn = r != nullptr;
     if (flags & WDF_MLP_LANE_PER_SEQUENCE) {
         WDF_MLP_DISPATCH(clipper_mlp_fwd_kernel, x, r, theta2, w, fs, y, zstash, z0, zT, B, T)
+    } else if (mlp_fwd_on_matrix_cores(B)) {      // 16 sequences per wave, one chunk (wdf_mlp_mfma.h)
+        const dim3 gm((unsigned)((B + 15) / 16), 1u);
+        const int64_t Lp = (T + 15) / 16 * 16;
+#define WDF_MFMA_FWD(NL_)                                                                                      \
+    if (n_tanh_layers == NL_) {                                                                                \
+        if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_mfma_fwd_tp_kernel<NL_, true, false>), gm, dim3(64), 0,     \
+                                    (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, (float*)nullptr, \
+                                    (float*)nullptr, (const int*)nullptr, (wdf::MlpTpStatus*)nullptr, B, T, Lp,     \
+                                    (int64_t)0, Lp, (float*)nullptr);                                           \
+        else hipLaunchKernelGGL((wdf::clipper_mlp_mfma_fwd_tp_kernel<NL_, false, false>), gm, dim3(64), 0,        \
+                                (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, (float*)nullptr, \
+                                (float*)nullptr, (const int*)nullptr, (wdf::MlpTpStatus*)nullptr, B, T, Lp,         \
+                                (int64_t)0, Lp, (float*)nullptr);                                               \
+    }
+        WDF_MFMA_FWD(3) WDF_MFMA_FWD(4) WDF_MFMA_FWD(5)
+#undef WDF_MFMA_FWD
     } else {                                      // one 16-lane row per sequence (wdf_mlp_row.h)
         const unsigned grow = (unsigned)((B + 3) / 4);
 #define WDF_ROW_FWD(NL_)                                                                                       \
@@ -161,34 +188,43 @@ static int mlp_fwd_tp_common(const float* x, const float* r, const float* theta2
     float* zwarm = (float*)ws;
     float* zend = zwarm + (size_t)g.K * (size_t)B;
     unsigned* gate = (unsigned*)(zend + (size_t)g.K * (size_t)B);
-    const dim3 grid((unsigned)((B + 3) / 4), (unsigned)g.K);
+    // The chunks run on the row kernel or on the matrix cores (mlp_fwd_on_matrix_cores: by batch size; shapes that
+    // want chunks at all are small, so normally the row kernel).  The verify / sequential / kappa launches keep the row grid.
+    const bool use_row = !mlp_fwd_on_matrix_cores(B);
+    const unsigned grid_row = (unsigned)((B + 3) / 4);
+    const dim3 grid(use_row ? grid_row : (unsigned)((B + 15) / 16), (unsigned)g.K);
     const bool dyn = r != nullptr;
     hipStream_t s = (hipStream_t)stream;
 #define WDF_ROW_FWD_TP_LAUNCH(NL_, DYN_, KAP_)                                                                     \
-    hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, DYN_, KAP_>), grid, dim3(64), 0, s, x, r, theta2, w,     \
-                       hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave, (wdf::MlpTpStatus*)status, B, T,  \
-                       g.L, W, L0, kappa)
+    if (use_row)                                                                                                 \
+        hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, DYN_, KAP_>), grid, dim3(64), 0, s, x, r, theta2, w, \
+                           hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave, (wdf::MlpTpStatus*)status, B, \
+                           T, g.L, W, L0, kappa);                                                                 \
+    else                                                                                                         \
+        hipLaunchKernelGGL((wdf::clipper_mlp_mfma_fwd_tp_kernel<NL_, DYN_, KAP_>), grid, dim3(64), 0, s, x, r, theta2,   \
+                           w, hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave, (wdf::MlpTpStatus*)status, \
+                           B, T, g.L, W, L0, kappa)
 #define WDF_ROW_FWD_TP(NL_)                                                                                      \
     if (n_tanh_layers == NL_) {                                                                                  \
         {                                                                                                        \
             EventBracket bracket(s);                                                                             \
             if (want_kappa) {                                                                                    \
-                if (dyn) WDF_ROW_FWD_TP_LAUNCH(NL_, true, true);                                                 \
-                else WDF_ROW_FWD_TP_LAUNCH(NL_, false, true);                                                    \
+                if (dyn) { WDF_ROW_FWD_TP_LAUNCH(NL_, true, true); }                                             \
+                else { WDF_ROW_FWD_TP_LAUNCH(NL_, false, true); }                                                \
             } else {                                                                                             \
-                if (dyn) WDF_ROW_FWD_TP_LAUNCH(NL_, true, false);                                                \
-                else WDF_ROW_FWD_TP_LAUNCH(NL_, false, false);                                                   \
+                if (dyn) { WDF_ROW_FWD_TP_LAUNCH(NL_, true, false); }                                            \
+                else { WDF_ROW_FWD_TP_LAUNCH(NL_, false, false); }                                               \
             }                                                                                                    \
         }                                                                                                        \
         if (g.K > 1) {                                                                                           \
             hipLaunchKernelGGL(wdf::mlp_tp_verify_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, zwarm, zend, B, \
                                (int64_t)g.K, tol, gate, (wdf::MlpTpStatus*)status);                               \
-            if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, true>), dim3(grid.x), dim3(64), 0, s, x, r,  \
+            if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, true>), dim3(grid_row), dim3(64), 0, s, x, r, \
                                         theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)gate);   \
-            else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, false>), dim3(grid.x), dim3(64), 0, s, x, r,     \
+            else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, false>), dim3(grid_row), dim3(64), 0, s, x, r,    \
                                     theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)gate);       \
             if (want_kappa) {                                                                                    \
-                const dim3 kgrid(grid.x, (unsigned)gu.K);                                                        \
+                const dim3 kgrid(grid_row, (unsigned)gu.K);                                                      \
                 if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, true>), kgrid, dim3(64), 0, s, x, r,   \
                                             theta2, w, hidden, fs, (const float*)zstash, kappa, B, T, gu.L,       \
                                             (const unsigned*)gate);                                              \

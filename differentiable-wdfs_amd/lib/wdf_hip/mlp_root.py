@@ -238,6 +238,8 @@ def plan_mlp_time_parallel(B, T, r, R_static, C, fs, tol=4.0e-6):
     wmax = -(-int(1.15 * wmax) // 16) * 16
     k_fwd = max(1, min(2 * engine.N_SIMD // waves, T // max(wmax // 2, 64)))
     k_bwd = max(1, min(2 * engine.N_SIMD // waves, T // 64))
+    if os.environ.get("WDF_MLP_K_FWD"):
+        k_fwd = int(os.environ["WDF_MLP_K_FWD"])
     if k_fwd < 2 and k_bwd < 2:
         return None
     return MlpTpPlan(k_fwd, wmax, None, float(tol), k_bwd)
