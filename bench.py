@@ -315,7 +315,9 @@ def run_mlp_root(args, world, rank, local):
                                       f"samples, {B} sequences x {T} samples per GPU, pot value per sample (BASELINE configs[3] shape)",
                           "global_batch": Bg, "seq_len": T, "parallelism": f"dp{world}", "loss": float(loss),
                           "time_parallel": None if plan is None else {"fwd_chunks": plan.k_fwd, "fwd_warmup_steps_planned": plan.warmup,
-                                                                      "fwd_warmup_steps_used": max(v["warmup"] for v in mlp_root._WARMUP_ADAPT.values()),
+                                                                      "fwd_warmup_steps_used": mlp_root.LAST_TP_STATUS.get("warmup_used", max(v["warmup"] for v in mlp_root._WARMUP_ADAPT.values())),
+                                                                      "fwd_warmup_steps_cold": max(v["warmup"] for v in mlp_root._WARMUP_ADAPT.values()),
+                                                                      "fwd_warm_start": bool(mlp_root._WARM_START),
                                                                       "verify_tol": plan.tol, "bwd_chunks": plan.k_bwd,
                                                                       "verify_status": st}},
                "call_ms": {"forward": spread(t_f), "reverse": spread(t_b)},

@@ -78,11 +78,11 @@ int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, con
         if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_mfma_fwd_tp_kernel<NL_, true, false>), gm, dim3(64), 0,     \
                                     (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, (float*)nullptr, \
                                     (float*)nullptr, (const int*)nullptr, (wdf::MlpTpStatus*)nullptr, B, T, Lp,     \
-                                    (int64_t)0, Lp, (float*)nullptr);                                           \
+                                    (int64_t)0, Lp, (float*)nullptr, (const float*)nullptr);                   \
         else hipLaunchKernelGGL((wdf::clipper_mlp_mfma_fwd_tp_kernel<NL_, false, false>), gm, dim3(64), 0,        \
                                 (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, (float*)nullptr, \
                                 (float*)nullptr, (const int*)nullptr, (wdf::MlpTpStatus*)nullptr, B, T, Lp,         \
-                                (int64_t)0, Lp, (float*)nullptr);                                               \
+                                (int64_t)0, Lp, (float*)nullptr, (const float*)nullptr);                       \
     }
         WDF_MFMA_FWD(3) WDF_MFMA_FWD(4) WDF_MFMA_FWD(5)
 #undef WDF_MFMA_FWD
@@ -149,6 +149,39 @@ static MlpTpGeom mlp_tp_geom(int64_t T, int n_chunks)
     return {L, (int)((T + L - 1) / L)};
 }
 
+// Chunk 0 needs no warm-up: left equal, its waves finish after L steps while every other wave runs L + W.  Balance
+// them: L0 = (T + (K-1) W) / K for chunk 0, the rest shared by the other K - 1 chunks -- all waves then run ~L0 steps
+// (one warm-up value for the batch only; with per-wave warm-ups the chunks stay equal).  -> L0; g.L = the others' length.
+static int64_t mlp_tp_balance(int64_t T, int64_t W, bool one_warmup, MlpTpGeom& g)
+{
+    int64_t L0 = g.L;
+    if (g.K >= 3 && one_warmup && W > 0) {
+        int64_t l0 = ((T + (int64_t)(g.K - 1) * W) / g.K + 15) / 16 * 16;
+        const int64_t lmax = (T - 16 * (int64_t)(g.K - 1)) / 16 * 16;   // (chunk starts stay multiples of 16)
+        if (l0 > lmax) l0 = lmax;
+        if (l0 > g.L) {
+            const int64_t rest = ((T - l0 + (g.K - 1) - 1) / (g.K - 1) + 15) / 16 * 16;
+            if (rest >= 16 && l0 + (int64_t)(g.K - 2) * rest < T) { L0 = l0; g.L = rest; }   // (every chunk non-empty)
+        }
+    }
+    return L0;
+}
+
+// starts[k] = the sample chunk k's wave begins at (its warm-up included), k < wdf_clipper_mlp_tp_chunks(T, n_chunks),
+// for ONE warm-up value: where a warm-started call (zinit) wants the previous call's states from.  Host only.
+int wdf_clipper_mlp_tp_starts(int64_t T, int n_chunks, int warmup, int64_t* starts)
+{
+    if (T <= 0 || n_chunks < 1 || warmup < 0 || !starts) return fail(WDF_EINVAL, "T > 0, n_chunks >= 1, warmup >= 0, starts");
+    MlpTpGeom g = mlp_tp_geom(T, n_chunks);
+    const int64_t W = ((int64_t)warmup + 15) / 16 * 16;
+    const int64_t L0 = mlp_tp_balance(T, W, true, g);
+    for (int k = 0; k < g.K; ++k) {
+        const int64_t t0 = k == 0 ? 0 : L0 + (int64_t)(k - 1) * g.L;
+        starts[k] = t0 > W ? t0 - W : 0;
+    }
+    return WDF_OK;
+}
+
 int wdf_clipper_mlp_tp_chunks(int64_t T, int n_chunks) { return T > 0 ? mlp_tp_geom(T, n_chunks).K : 0; }
 
 size_t wdf_clipper_mlp_fwd_tp_ws_bytes(int64_t B, int n_chunks)
@@ -162,7 +195,7 @@ size_t wdf_clipper_mlp_fwd_tp_ws_bytes(int64_t B, int n_chunks)
 static int mlp_fwd_tp_common(const float* x, const float* r, const float* theta2, const float* w, int hidden,
                              int n_tanh_layers, float fs, float* y, float* zstash, const float* z0, float* zT, int64_t B,
                              int64_t T, int n_chunks, int warmup, const int32_t* warmup_per_wave, float tol, void* ws,
-                             void* status, float* kappa, bool want_kappa, void* stream)
+                             void* status, float* kappa, bool want_kappa, const float* zinit, void* stream)
 {
     int rc = mlp_check(x, theta2, w, hidden, n_tanh_layers, fs, B, T, 0);
     if (rc) return rc;
@@ -172,19 +205,7 @@ static int mlp_fwd_tp_common(const float* x, const float* r, const float* theta2
     MlpTpGeom g = mlp_tp_geom(T, n_chunks);
     const MlpTpGeom gu = g;                                    // equal chunks: the gated kappa pass's grid
     const int64_t W = ((int64_t)warmup + 15) / 16 * 16;
-    // Chunk 0 needs no warm-up: left equal, its waves finish after L steps while every other wave runs L + W.  Balance
-    // them: L0 = (T + (K-1) W) / K for chunk 0, the rest shared by the other K - 1 chunks -- all waves then run ~L0 steps
-    // (one warm-up value for the batch only; with per-wave warm-ups the chunks stay equal).
-    int64_t L0 = g.L;
-    if (g.K >= 3 && warmup_per_wave == nullptr && W > 0) {
-        int64_t l0 = ((T + (int64_t)(g.K - 1) * W) / g.K + 15) / 16 * 16;
-        const int64_t lmax = (T - 16 * (int64_t)(g.K - 1)) / 16 * 16;   // (chunk starts stay multiples of 16)
-        if (l0 > lmax) l0 = lmax;
-        if (l0 > g.L) {
-            const int64_t rest = ((T - l0 + (g.K - 1) - 1) / (g.K - 1) + 15) / 16 * 16;
-            if (rest >= 16 && l0 + (int64_t)(g.K - 2) * rest < T) { L0 = l0; g.L = rest; }   // (every chunk non-empty)
-        }
-    }
+    const int64_t L0 = mlp_tp_balance(T, W, warmup_per_wave == nullptr, g);
     float* zwarm = (float*)ws;
     float* zend = zwarm + (size_t)g.K * (size_t)B;
     unsigned* gate = (unsigned*)(zend + (size_t)g.K * (size_t)B);
@@ -199,11 +220,11 @@ static int mlp_fwd_tp_common(const float* x, const float* r, const float* theta2
     if (use_row)                                                                                                 \
         hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, DYN_, KAP_>), grid, dim3(64), 0, s, x, r, theta2, w, \
                            hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave, (wdf::MlpTpStatus*)status, B, \
-                           T, g.L, W, L0, kappa);                                                                 \
+                           T, g.L, W, L0, kappa, zinit);                                                          \
     else                                                                                                         \
         hipLaunchKernelGGL((wdf::clipper_mlp_mfma_fwd_tp_kernel<NL_, DYN_, KAP_>), grid, dim3(64), 0, s, x, r, theta2,   \
                            w, hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave, (wdf::MlpTpStatus*)status, \
-                           B, T, g.L, W, L0, kappa)
+                           B, T, g.L, W, L0, kappa, zinit)
 #define WDF_ROW_FWD_TP(NL_)                                                                                      \
     if (n_tanh_layers == NL_) {                                                                                  \
         {                                                                                                        \
@@ -246,16 +267,17 @@ int wdf_clipper_mlp_fwd_tp(const float* x, const float* r, const float* theta2, 
                            void* status, void* stream)
 {
     return mlp_fwd_tp_common(x, r, theta2, w, hidden, n_tanh_layers, fs, y, zstash, z0, zT, B, T, n_chunks, warmup,
-                             warmup_per_wave, tol, ws, status, nullptr, false, stream);
+                             warmup_per_wave, tol, ws, status, nullptr, false, nullptr, stream);
 }
 
 int wdf_clipper_mlp_fwd_tp_kappa(const float* x, const float* r, const float* theta2, const float* w, int hidden,
                                  int n_tanh_layers, float fs, float* y, float* zstash, float* kappa, const float* z0,
-                                 float* zT, int64_t B, int64_t T, int n_chunks, int warmup,
+                                 float* zT, const float* zinit, int64_t B, int64_t T, int n_chunks, int warmup,
                                  const int32_t* warmup_per_wave, float tol, void* ws, void* status, void* stream)
 {
+    if (zinit && warmup_per_wave) return fail(WDF_EINVAL, "zinit goes with one warm-up value (wdf_clipper_mlp_tp_starts)");
     return mlp_fwd_tp_common(x, r, theta2, w, hidden, n_tanh_layers, fs, y, zstash, z0, zT, B, T, n_chunks, warmup,
-                             warmup_per_wave, tol, ws, status, kappa, true, stream);
+                             warmup_per_wave, tol, ws, status, kappa, true, zinit, stream);
 }
 
 int64_t wdf_clipper_mlp_bwd_w_tp_ws_bytes(int hidden, int n_tanh_layers, int64_t B, int64_t T, int n_chunks)

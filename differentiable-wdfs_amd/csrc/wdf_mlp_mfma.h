@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_mfma_fwd_tp_kernel(
     const float* __restrict__ w, int H, float fs, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
     const int* __restrict__ wrow, MlpTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W, int64_t L0,
-    float* __restrict__ kappa)
+    float* __restrict__ kappa, const float* __restrict__ zinit)
 {
     // zwarm / zend / status may be null: the plain sequential call (one chunk, nothing to verify)
     if (status && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = MlpTpStatus{0, 0.0f, 0, 0};   // the verify kernel adds
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_mfma_fwd_tp_kernel(
     const MfmaWeights<NL> Wt = mfma_load_weights<NL>(w, H, lane, KAP);
     const float* __restrict__ xp = x + b * T;
     const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
-    float z = (tw == 0 && z0) ? z0[b] : 0.0f;
+    float z = tw == 0 ? (z0 ? z0[b] : 0.0f) : (zinit ? zinit[k * B + b] : 0.0f);
     mfma_v4f act[NL];
     for (int64_t tb = tw; tb < t1; tb += 16) {
         if (zwarm && tb == t0 && g == 0 && live) zwarm[k * B + b] = z;   // the state this chunk arrives with

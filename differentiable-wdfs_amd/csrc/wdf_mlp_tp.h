@@ -50,8 +50,10 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_tp_kernel(
     const float* __restrict__ w, int H, float fs, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
     const int* __restrict__ wrow, MlpTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W, int64_t L0,
-    float* __restrict__ kappa)
+    float* __restrict__ kappa, const float* __restrict__ zinit)
 {
+    // zinit [K][B] (or null: z = 0): the state chunk k > 0 starts its warm-up from -- the previous call's state at the
+    // same sample, when the caller trains on the same batch (the verification still decides).
     // L0: length of chunk 0, the only chunk without a warm-up: chunk k > 0 owns [L0 + (k-1) L, L0 + k L).  With L0 = L + W
     // every wave runs about the same number of steps (the host balances it, wdf_capi_mlp.hip); L0 = L: equal chunks.
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = MlpTpStatus{0, 0.0f, 0, 0};   // the verify kernel adds
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_tp_kernel(
     const RowWeights<NL> Wt = row_load_weights<NL>(w, H, j, KAP);
     const float* __restrict__ xp = x + b * T;
     const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
-    float z = (tw == 0 && z0) ? z0[b] : 0.0f;
+    float z = tw == 0 ? (z0 ? z0[b] : 0.0f) : (zinit ? zinit[k * B + b] : 0.0f);
     float act[NL];
     for (int64_t tb = tw; tb < t1; tb += 16) {
         if (tb == t0 && j == 0) zwarm[k * B + b] = z;          // the state this chunk arrives with

@@ -140,7 +140,9 @@ def lib():
     L.wdf_clipper_mlp_bwd_w_tp.restype = ci
     L.wdf_clipper_mlp_bwd_w_tp.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, vp, fp, fp, i64, i64, ci, vp]
     L.wdf_clipper_mlp_fwd_tp_kappa.restype = ci
-    L.wdf_clipper_mlp_fwd_tp_kappa.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, fp, i64, i64, ci, ci, vp, cf, vp, vp, vp]
+    L.wdf_clipper_mlp_fwd_tp_kappa.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, fp, fp, fp, i64, i64, ci, ci, vp, cf, vp, vp, vp]
+    L.wdf_clipper_mlp_tp_starts.restype = ci
+    L.wdf_clipper_mlp_tp_starts.argtypes = [i64, ci, ci, C.POINTER(C.c_int64)]
     L.wdf_clipper_mlp_bwd_w_tp_kappa.restype = ci
     L.wdf_clipper_mlp_bwd_w_tp_kappa.argtypes = [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, vp, fp, fp, i64, i64, ci, vp]
     L.wdf_clipper_mlp_bwd_ws_bytes.restype = C.c_size_t
@@ -201,7 +203,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
     "wdf_clipper_mlp_tp_chunks", "wdf_clipper_mlp_fwd_tp_ws_bytes", "wdf_clipper_mlp_fwd_tp",
     "wdf_clipper_mlp_bwd_w_tp_ws_bytes", "wdf_clipper_mlp_bwd_w_tp",
-    "wdf_clipper_mlp_fwd_tp_kappa", "wdf_clipper_mlp_bwd_w_tp_kappa",
+    "wdf_clipper_mlp_fwd_tp_kappa", "wdf_clipper_mlp_bwd_w_tp_kappa", "wdf_clipper_mlp_tp_starts",
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
     "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step",
@@ -694,11 +696,12 @@ def clipper_mlp_bwd_w(x, theta2, w, hidden, n_tanh, fs, zstash, gy, r=None):
 
 
 def clipper_mlp_fwd_tp(x, theta2, w, hidden, n_tanh, fs, n_chunks, warmup, r=None, warmup_per_wave=None, tol=1e-6,
-                       want_stash=True, z0=None, want_zT=False, ws=None, status=None, want_kappa=False):
+                       want_stash=True, z0=None, want_zT=False, ws=None, status=None, want_kappa=False, zinit=None):
     """Time-parallel MLP-root forward (csrc/wdf_mlp_tp.h).  warmup_per_wave: int32[ceil(B/4)] device tensor
     (multiples of 16) or None.  -> y [T,B], zstash | None, zT | None, status (int32[4]: n_bad, max-miss bits,
     gated waves, 0; read with mlp_tp_status()).  want_kappa: the forward also stores the adjoint recurrence's
-    coefficient kappa [T,B] (for clipper_mlp_bwd_w_tp(kappa=...)); returned as a fifth value."""
+    coefficient kappa [T,B] (for clipper_mlp_bwd_w_tp(kappa=...)); returned as a fifth value.  zinit [chunks,B]
+    (with want_kappa): the states the chunks start their warm-up from (mlp_tp_starts() names the samples)."""
     require_gpu()
     x, r, theta2, w, z0 = _f32_dev(x, "x"), _f32_dev(r, "r"), _f32_dev(theta2, "theta2"), _f32_dev(w, "w"), _f32_dev(z0, "z0")
     if w.numel() != lib().wdf_mlp_weight_count(int(hidden), int(n_tanh)):
@@ -718,8 +721,12 @@ def clipper_mlp_fwd_tp(x, theta2, w, hidden, n_tanh, fs, n_chunks, warmup, r=Non
         if zs is None:
             raise WdfHipError("want_kappa needs the stash (want_stash=True)")
         kap = torch.empty((T, B), dtype=torch.float32, device=x.device)
+        if zinit is not None:
+            zinit = _f32_dev(zinit, "zinit")
+            if tuple(zinit.shape) != (lib().wdf_clipper_mlp_tp_chunks(T, int(n_chunks)), B) or warmup_per_wave is not None:
+                raise WdfHipError("zinit: expected [chunks, B] and no warmup_per_wave")
         rc = lib().wdf_clipper_mlp_fwd_tp_kappa(_ptr(x), _ptr(r), _ptr(theta2), _ptr(w), int(hidden), int(n_tanh), float(fs),
-                                                _ptr(y), _ptr(zs), _ptr(kap), _ptr(z0), _ptr(zT), B, T, int(n_chunks),
+                                                _ptr(y), _ptr(zs), _ptr(kap), _ptr(z0), _ptr(zT), _ptr(zinit), B, T, int(n_chunks),
                                                 int(warmup), _ptr(warmup_per_wave), float(tol), _ptr(ws), _ptr(status),
                                                 _stream())
         _check(rc, "wdf_clipper_mlp_fwd_tp_kappa")
@@ -729,6 +736,14 @@ def clipper_mlp_fwd_tp(x, theta2, w, hidden, n_tanh, fs, n_chunks, warmup, r=Non
                                       float(tol), _ptr(ws), _ptr(status), _stream())
     _check(rc, "wdf_clipper_mlp_fwd_tp")
     return y, zs, zT, status
+
+
+def mlp_tp_starts(T, n_chunks, warmup):
+    """The sample every chunk's wave begins at (warm-up included) for one warm-up value -> list of ints."""
+    K = lib().wdf_clipper_mlp_tp_chunks(int(T), int(n_chunks))
+    out = (C.c_int64 * K)()
+    _check(lib().wdf_clipper_mlp_tp_starts(int(T), int(n_chunks), int(warmup), out), "wdf_clipper_mlp_tp_starts")
+    return list(out)
 
 
 def mlp_tp_status(status):

@@ -44,6 +44,9 @@ def flat_weights(dense):
 
 MlpTpPlan = namedtuple("MlpTpPlan", ["k_fwd", "warmup", "warmup_per_wave", "tol", "k_bwd"])
 LAST_TP_STATUS = {"status": None}
+WARM_START = os.environ.get("WDF_MLP_WARM_START", "1") != "0"        # 0: every call warms its chunks up from z = 0
+SECANT_WARM_START = os.environ.get("WDF_MLP_WARM_SECANT", "1") != "0"
+_WARM_START = {}       # (x address, shape, chunks, planned warm-up, r address) -> controller + the previous call's states
 KAPPA_FROM_FORWARD = os.environ.get("WDF_MLP_KAPPA_FROM_FORWARD", "1") != "0"   # 0: the reverse sweep recomputes kappa
 _WARMUP_ADAPT = {}     # (x shape, forward chunks, planned warm-up) -> {"warmup": steps in use, "calls": n}
 
@@ -64,17 +67,63 @@ class _ClipperMlpFn(torch.autograd.Function):
             ad = _WARMUP_ADAPT.setdefault((x.shape, tp.k_fwd, tp.warmup), {"warmup": tp.warmup, "calls": 0})
             # a training call also takes kappa from the forward (the reverse sweep then skips its first pass)
             use_kappa = need and tp.k_bwd > 1 and KAPPA_FROM_FORWARD
-            out = binding.clipper_mlp_fwd_tp(x, th, wd, hidden, n_tanh, fs, tp.k_fwd, ad["warmup"], r=r,
+            # ... and, the second time it sees a batch, starts every chunk from the state the previous call had there
+            # (the weights moved by one optimizer step): a fraction of the warm-up closes that gap.  Keyed by the
+            # batch's address and shape; other data at the same address is caught by the verification like any miss.
+            warm = None
+            if use_kappa and WARM_START and tp.warmup_per_wave is None and z0 is None:
+                wkey = (x.data_ptr(), tuple(x.shape), tp.k_fwd, tp.warmup, None if r is None else r.data_ptr())
+                warm = _WARM_START.get(wkey)
+                if warm is None:
+                    if len(_WARM_START) >= 8:
+                        _WARM_START.clear()
+                    warm = _WARM_START[wkey] = {"warmup": 0, "calls": 0, "rows": None, "prev": None, "idx": None}
+            hot = warm is not None and warm["rows"] is not None
+            if hot and warm.get("pending") is not None and warm["pending"][1].query():
+                # the verdict of an earlier warm call, copied to pinned memory behind its forward: no wait here
+                buf, _ = warm["pending"]
+                warm["pending"] = None
+                if int(buf[2]) > 0:                              # gated waves: a chunk arrived too far off
+                    warm["warmup"] = min(-(-int(1.25 * warm["warmup"]) // 16) * 16, ad["warmup"])
+                    starts = binding.mlp_tp_starts(int(x.shape[1]), tp.k_fwd, warm["warmup"])   # the chunks start elsewhere
+                    warm["idx"] = torch.tensor(starts, dtype=torch.int64, device=x.device)
+                    warm["rows"], warm["prev"] = warm["zs"].index_select(0, warm["idx"]), None
+            zinit = None
+            if hot:
+                zinit = warm["rows"] if warm["prev"] is None else 2.0 * warm["rows"] - warm["prev"]    # secant in call count
+            w_used = warm["warmup"] if hot else ad["warmup"]
+            out = binding.clipper_mlp_fwd_tp(x, th, wd, hidden, n_tanh, fs, tp.k_fwd, w_used, r=r,
                                              warmup_per_wave=tp.warmup_per_wave, tol=tp.tol,
                                              want_stash=need or want_stash, z0=z0, want_zT=want_zT,
-                                             want_kappa=use_kappa)
+                                             want_kappa=use_kappa, zinit=zinit)
             y, zs, zT, st = out[:4]
             kap = out[4] if use_kappa else None
             LAST_TP_STATUS["status"] = st
-            ad["calls"] += 1
-            if tp.warmup_per_wave is None and (ad["calls"] <= 4 or ad["calls"] % 16 == 0):
-                if binding.mlp_tp_status(st)["gated_waves"] > 0:
-                    ad["warmup"] = min(-(-int(1.5 * ad["warmup"]) // 16) * 16, int(x.shape[1]))
+            LAST_TP_STATUS["warmup_used"] = w_used
+            if hot:
+                if warm.get("pending") is None:                  # (one verdict in flight at a time)
+                    if warm.get("pin") is None:
+                        warm["pin"] = torch.empty((4,), dtype=torch.int32, pin_memory=True)
+                    warm["pin"].copy_(st, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    warm["pending"] = (warm["pin"], ev)
+            else:
+                ad["calls"] += 1
+                if tp.warmup_per_wave is None and (ad["calls"] <= 4 or ad["calls"] % 16 == 0):
+                    if binding.mlp_tp_status(st)["gated_waves"] > 0:
+                        ad["warmup"] = min(-(-int(1.5 * ad["warmup"]) // 16) * 16, int(x.shape[1]))
+            if warm is not None:
+                if warm["warmup"] == 0:
+                    warm["warmup"] = max(64, -(-(ad["warmup"] // 4) // 16) * 16)
+                fresh = warm["idx"] is None
+                if fresh:
+                    starts = binding.mlp_tp_starts(int(x.shape[1]), tp.k_fwd, warm["warmup"])
+                    warm["idx"] = torch.tensor(starts, dtype=torch.int64, device=x.device)
+                rows = zs.index_select(0, warm["idx"])           # the verified trajectory at the next call's chunk starts
+                warm["prev"] = None if (fresh or not SECANT_WARM_START) else warm["rows"]
+                warm["rows"] = rows
+                warm["zs"] = zs                                  # (kept for a change of the warm-up: the rows move)
         else:
             y, zs, zT = binding.clipper_mlp_fwd(x, th, wd, hidden, n_tanh, fs, r=r, want_stash=need or want_stash,
                                                 z0=z0, want_zT=want_zT)

@@ -418,9 +418,14 @@ int wdf_clipper_mlp_bwd_w_tp(const float* x, const float* r, const float* theta2
  * network's input Jacobian (the activations are in registers there) and store kappa[n] = d z[n+1]/d z[n] [T][B]
  * (waves the sequential kernel re-runs get theirs from the stash by a gated pass); the reverse sweep then starts at
  * the scan -- one network evaluation per step less.  Same y, stash, gradients as the pair above.  zstash is required. */
+/* zinit [chunks][B] or NULL: the state every chunk but the first starts its warm-up from instead of 0 -- the stash of
+ * the previous call on the same batch at the samples wdf_clipper_mlp_tp_starts() names (a training loop: the weights
+ * moved a little, so a short warm-up closes the gap; the verification decides as before).  One warm-up value only
+ * (warmup_per_wave must be NULL with zinit).  wdf_clipper_mlp_tp_starts is a host function (no GPU work). */
+int wdf_clipper_mlp_tp_starts(int64_t T, int n_chunks, int warmup, int64_t* starts);
 int wdf_clipper_mlp_fwd_tp_kappa(const float* x, const float* r, const float* theta2, const float* w,
                                  int hidden, int n_tanh_layers, float fs,
-                                 float* y, float* zstash, float* kappa, const float* z0, float* zT,
+                                 float* y, float* zstash, float* kappa, const float* z0, float* zT, const float* zinit,
                                  int64_t B, int64_t T, int n_chunks, int warmup, const int32_t* warmup_per_wave,
                                  float tol, void* ws, void* status, void* stream);
 int wdf_clipper_mlp_bwd_w_tp_kappa(const float* x, const float* r, const float* theta2, const float* w,

@@ -344,6 +344,40 @@ def test_mlp_forward_stored_kappa_equals_the_recomputed_one(hidden, n_tanh, B, T
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, (a, b)
 
 
+def test_mlp_warm_started_chunks_follow_a_training_loop():
+    """A training loop on one batch: from the second call on every chunk starts from the previous call's state at
+    its first sample (secant-extrapolated from the third), with a fraction of the cold warm-up; the weights move by
+    3e-5 per step (sign steps on every weight).  Every call's y stays within 1e-5 of the sequential
+    kernel's for the same weights -- arrival states are verified to 4e-6, and a learned root is not a strict
+    contraction: inside the chunk the miss was seen to grow to 1.6x (6.3e-6) before it decays; the kernels themselves
+    sit 3-5e-6 from fp64 -- and its weight gradient within 2e-5 of the sequential sweep's."""
+    from wdf_hip import binding as wb, mlp_root, workload
+    B, T = 96, 2048
+    x = cuda(workload.sweep_batch(B, T, seed=11) * 0.6)
+    r = cuda(workload.dataset_resistance_batch(B, T))
+    th2 = cuda([45.0e3, workload.C_CLIPPER])
+    wh, hidden, n_tanh = workload.reference_mlp_weights("2x16_pre")
+    w = cuda(wh).requires_grad_(True)
+    gy = cuda(np.random.default_rng(2).standard_normal((T, B)) / (B * T))
+    plan = mlp_root.plan_mlp_time_parallel(B, T, r, None, workload.C_CLIPPER, FS)
+    assert plan is not None and plan.k_fwd > 1
+    mlp_root._WARM_START.clear()
+    used = []
+    for it in range(10):
+        y, _ = mlp_root.clipper_mlp(th2, w, x, r, None, FS, hidden, n_tanh, workload.C_CLIPPER, time_parallel=plan)
+        used.append(mlp_root.LAST_TP_STATUS["warmup_used"])
+        (gw,) = torch.autograd.grad(y, [w], grad_outputs=gy)
+        y_seq, zs, _ = wb.clipper_mlp_fwd(x, th2, w.detach(), hidden, n_tanh, FS, r=r)
+        _, gw_seq = wb.clipper_mlp_bwd_w(x, th2, w.detach(), hidden, n_tanh, FS, zs, gy, r=r)
+        assert float((y.detach() - y_seq).abs().max()) <= 1e-5, (it, float((y.detach() - y_seq).abs().max()))
+        assert float((gw - gw_seq).abs().max()) <= 2e-5 * float(gw_seq.abs().max()), it
+        with torch.no_grad():
+            w -= 3.0e-5 * torch.sign(gw)
+    # warm calls ran a shorter warm-up (the controller lengthens it by a quarter whenever a wave had to be re-run)
+    assert used[0] >= plan.warmup and used[1] < used[0] and sorted(used[1:])[len(used) // 2] < used[0], used
+    mlp_root._WARM_START.clear()
+
+
 def test_mlp_clipper_auto_plan_trains_like_the_sequential_path(golden):
     """Circuit(..., time_parallel="auto") on a dataset-shaped batch: the planner picks the in-kernel
     time-parallel kernels; y and every gradient equal the sequential path's."""
