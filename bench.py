@@ -318,6 +318,7 @@ def run_mlp_root(args, world, rank, local):
                                                                       "fwd_warmup_steps_used": mlp_root.LAST_TP_STATUS.get("warmup_used", max(v["warmup"] for v in mlp_root._WARMUP_ADAPT.values())),
                                                                       "fwd_warmup_steps_cold": max(v["warmup"] for v in mlp_root._WARMUP_ADAPT.values()),
                                                                       "fwd_warm_start": bool(mlp_root._WARM_START),
+                                                                      **({"fwd_warmup_trace": [w for w, _ in mlp_root._TRACE_WARMUP]} if mlp_root._TRACE_WARMUP else {}),
                                                                       "verify_tol": plan.tol, "bwd_chunks": plan.k_bwd,
                                                                       "verify_status": st}},
                "call_ms": {"forward": spread(t_f), "reverse": spread(t_b)},

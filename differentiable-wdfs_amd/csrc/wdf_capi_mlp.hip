@@ -150,13 +150,16 @@ static MlpTpGeom mlp_tp_geom(int64_t T, int n_chunks)
 }
 
 // Chunk 0 needs no warm-up: left equal, its waves finish after L steps while every other wave runs L + W.  Balance
-// them: L0 = (T + (K-1) W) / K for chunk 0, the rest shared by the other K - 1 chunks -- all waves then run ~L0 steps
+// them by COST: a warm-up step costs rho owned steps (rho = 1 for the plain forward; 0.7 when the owned steps also
+// evaluate the input Jacobian for kappa -- tools/mlp_chunk_probe.py: 0.76 / 1.02 us on the matrix cores, 0.49 / 0.72 us
+// on the row kernel), so L0 = L + rho W with L0 + (K-1) L = T: every wave then takes about as long as chunk 0's
 // (one warm-up value for the batch only; with per-wave warm-ups the chunks stay equal).  -> L0; g.L = the others' length.
-static int64_t mlp_tp_balance(int64_t T, int64_t W, bool one_warmup, MlpTpGeom& g)
+static int64_t mlp_tp_balance(int64_t T, int64_t W, bool one_warmup, bool with_kappa, MlpTpGeom& g)
 {
     int64_t L0 = g.L;
     if (g.K >= 3 && one_warmup && W > 0) {
-        int64_t l0 = ((T + (int64_t)(g.K - 1) * W) / g.K + 15) / 16 * 16;
+        const int64_t Wc = with_kappa ? (7 * W + 9) / 10 : W;            // the warm-up in owned-step units
+        int64_t l0 = ((T + (int64_t)(g.K - 1) * Wc) / g.K + 15) / 16 * 16;
         const int64_t lmax = (T - 16 * (int64_t)(g.K - 1)) / 16 * 16;   // (chunk starts stay multiples of 16)
         if (l0 > lmax) l0 = lmax;
         if (l0 > g.L) {
@@ -170,11 +173,11 @@ static int64_t mlp_tp_balance(int64_t T, int64_t W, bool one_warmup, MlpTpGeom& 
 // starts[k] = the sample chunk k's wave begins at (its warm-up included), k < wdf_clipper_mlp_tp_chunks(T, n_chunks),
 // for ONE warm-up value: where a warm-started call (zinit) wants the previous call's states from.  Host only.
 int wdf_clipper_mlp_tp_starts(int64_t T, int n_chunks, int warmup, int64_t* starts)
-{
+{   // (the geometry of wdf_clipper_mlp_fwd_tp_kappa: the only entry point that takes zinit)
     if (T <= 0 || n_chunks < 1 || warmup < 0 || !starts) return fail(WDF_EINVAL, "T > 0, n_chunks >= 1, warmup >= 0, starts");
     MlpTpGeom g = mlp_tp_geom(T, n_chunks);
     const int64_t W = ((int64_t)warmup + 15) / 16 * 16;
-    const int64_t L0 = mlp_tp_balance(T, W, true, g);
+    const int64_t L0 = mlp_tp_balance(T, W, true, true, g);
     for (int k = 0; k < g.K; ++k) {
         const int64_t t0 = k == 0 ? 0 : L0 + (int64_t)(k - 1) * g.L;
         starts[k] = t0 > W ? t0 - W : 0;
@@ -205,7 +208,7 @@ static int mlp_fwd_tp_common(const float* x, const float* r, const float* theta2
     MlpTpGeom g = mlp_tp_geom(T, n_chunks);
     const MlpTpGeom gu = g;                                    // equal chunks: the gated kappa pass's grid
     const int64_t W = ((int64_t)warmup + 15) / 16 * 16;
-    const int64_t L0 = mlp_tp_balance(T, W, warmup_per_wave == nullptr, g);
+    const int64_t L0 = mlp_tp_balance(T, W, warmup_per_wave == nullptr, want_kappa, g);
     float* zwarm = (float*)ws;
     float* zend = zwarm + (size_t)g.K * (size_t)B;
     unsigned* gate = (unsigned*)(zend + (size_t)g.K * (size_t)B);

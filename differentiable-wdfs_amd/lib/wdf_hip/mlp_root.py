@@ -46,6 +46,7 @@ MlpTpPlan = namedtuple("MlpTpPlan", ["k_fwd", "warmup", "warmup_per_wave", "tol"
 LAST_TP_STATUS = {"status": None}
 WARM_START = os.environ.get("WDF_MLP_WARM_START", "1") != "0"        # 0: every call warms its chunks up from z = 0
 SECANT_WARM_START = os.environ.get("WDF_MLP_WARM_SECANT", "1") != "0"
+_TRACE_WARMUP = [] if os.environ.get("WDF_MLP_TRACE_WARMUP") else None    # (probing) per call: (warm-up steps, warm-started?)
 _WARM_START = {}       # (x address, shape, chunks, planned warm-up, r address) -> controller + the previous call's states
 KAPPA_FROM_FORWARD = os.environ.get("WDF_MLP_KAPPA_FROM_FORWARD", "1") != "0"   # 0: the reverse sweep recomputes kappa
 _WARMUP_ADAPT = {}     # (x shape, forward chunks, planned warm-up) -> {"warmup": steps in use, "calls": n}
@@ -100,6 +101,8 @@ class _ClipperMlpFn(torch.autograd.Function):
             kap = out[4] if use_kappa else None
             LAST_TP_STATUS["status"] = st
             LAST_TP_STATUS["warmup_used"] = w_used
+            if _TRACE_WARMUP is not None:
+                _TRACE_WARMUP.append((w_used, hot))
             if hot:
                 if warm.get("pending") is None:                  # (one verdict in flight at a time)
                     if warm.get("pin") is None:
@@ -116,6 +119,8 @@ class _ClipperMlpFn(torch.autograd.Function):
             if warm is not None:
                 if warm["warmup"] == 0:
                     warm["warmup"] = max(64, -(-(ad["warmup"] // 4) // 16) * 16)
+                    if os.environ.get("WDF_MLP_WARM_W"):         # (probing: start the controller elsewhere)
+                        warm["warmup"] = int(os.environ["WDF_MLP_WARM_W"])
                 fresh = warm["idx"] is None
                 if fresh:
                     starts = binding.mlp_tp_starts(int(x.shape[1]), tp.k_fwd, warm["warmup"])
