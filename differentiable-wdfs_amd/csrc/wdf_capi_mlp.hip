@@ -287,8 +287,10 @@ int64_t wdf_clipper_mlp_bwd_w_tp_ws_bytes(int hidden, int n_tanh_layers, int64_t
 {
     if (B <= 0 || T <= 0 || n_chunks <= 0 || !mlp_arch_ok(hidden, n_tanh_layers)) return 0;
     const int64_t nparts = (B + 3) / 4 * mlp_tp_geom(T, n_chunks).K;
+    const int64_t scan_chunks = (T + wdf::kScanChunk - 1) / wdf::kScanChunk;
     return T * B * (int64_t)sizeof(float) + nparts * 4 * (int64_t)sizeof(double) +
-           nparts * wdf_mlp_weight_count(hidden, n_tanh_layers) * (int64_t)sizeof(float);
+           nparts * wdf_mlp_weight_count(hidden, n_tanh_layers) * (int64_t)sizeof(float) +
+           scan_chunks * B * (int64_t)sizeof(float2) + 8;
 }
 
 // kappa_in != nullptr: pass (A) is skipped, the scan reads the forward's kappa (wdf_clipper_mlp_fwd_tp_kappa).
@@ -308,6 +310,10 @@ static int mlp_bwd_w_tp_common(const float* x, const float* r, const float* thet
     double* wsd = (double*)ws;                                             // [nparts][4] doubles (8-byte aligned)
     float* kap = (float*)((char*)ws + (size_t)nparts * 4 * sizeof(double));  // kappa, then g_b2n in place [T][B]
     float* wsw = kap + (size_t)T * (size_t)B;                              // [nparts][count]
+    const int count_w = wdf_mlp_weight_count(hidden, n_tanh_layers);
+    const unsigned scan_chunks = (unsigned)((T + wdf::kScanChunk - 1) / wdf::kScanChunk);
+    float2* smap = (float2*)(((uintptr_t)(wsw + (size_t)nparts * (size_t)count_w) + 7) & ~(uintptr_t)7);   // [scan_chunks][B]
+    const dim3 sgrid((unsigned)((B + 63) / 64), scan_chunks);
     const bool dyn = r != nullptr;
     hipStream_t s = (hipStream_t)stream;
 #define WDF_ROW_BWD_TP(NL_)                                                                                      \
@@ -318,8 +324,15 @@ static int mlp_bwd_w_tp_common(const float* x, const float* r, const float* thet
             else hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, false>), grid, dim3(64), 0, s, x, r, theta2,     \
                                     w, hidden, fs, zstash, kap, B, T, g.L, (const unsigned*)nullptr);            \
         }                                                                                                        \
-        hipLaunchKernelGGL(wdf::mlp_adjoint_scan_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s,             \
-                           have_kappa ? kappa_in : (const float*)kap, gy, kap, B, T);                            \
+        if (scan_chunks > 1) {                                                                                   \
+            hipLaunchKernelGGL(wdf::mlp_adjoint_chunk_map_kernel, sgrid, dim3(64), 0, s,                         \
+                               have_kappa ? kappa_in : (const float*)kap, gy, smap, B, T);                       \
+            hipLaunchKernelGGL(wdf::mlp_adjoint_scan_chunked_kernel, sgrid, dim3(64), 0, s,                      \
+                               have_kappa ? kappa_in : (const float*)kap, gy, (const float2*)smap, kap, B, T);   \
+        } else {                                                                                                 \
+            hipLaunchKernelGGL(wdf::mlp_adjoint_scan_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s,         \
+                               have_kappa ? kappa_in : (const float*)kap, gy, kap, B, T);                        \
+        }                                                                                                        \
         {                                                                                                        \
             EventBracket bracket(s);                                                                             \
             if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_wgrad_tp_kernel<NL_, true>), grid, dim3(64), 0, s, x, r, theta2, \

@@ -224,6 +224,73 @@ static __global__ __launch_bounds__(64) void mlp_adjoint_scan_kernel(const float
     }
 }
 
+// (B) in chunks of kScanChunk steps -- the recurrence is affine in the adjoint that comes in from the future,
+//   gz_out = kappa gz_in + (kappa + 1) gy / 2 per step, so a chunk is a map gz_out = A gz_in + C:
+//   (B1) every (sequence, chunk) composes its map; (B2) every (sequence, chunk) composes the maps of the chunks
+//   after it (at most T / kScanChunk - 1 FMAs) for its incoming adjoint and runs its own steps, writing g_b2n.
+// 2048 dependent steps per lane become 128 + 15 + 128; the arrays are read twice (the sweep is latency bound, not
+// bandwidth bound).  Same values as the one-lane scan up to the rounding of the incoming adjoint.  gb2n may alias kappa.
+constexpr int kScanChunk = 128;
+
+static __global__ __launch_bounds__(64) void mlp_adjoint_chunk_map_kernel(const float* __restrict__ kappa,
+                                                                          const float* __restrict__ gy, float2* __restrict__ map,
+                                                                          int64_t B, int64_t T)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t t0 = (int64_t)blockIdx.y * kScanChunk;
+    int64_t t = (t0 + kScanChunk < T) ? t0 + kScanChunk : T;
+    float A = 1.0f, Cc = 0.0f;
+    for (; t >= t0 + 8; t -= 8) {
+        float kv[8], gv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kv[i] = kappa[(t - 1 - i) * B + b]; gv[i] = gy[(t - 1 - i) * B + b]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            Cc = fmaf(kv[i], Cc, 0.5f * (kv[i] + 1.0f) * gv[i]);
+            A *= kv[i];
+        }
+    }
+    for (; t > t0; --t) {
+        const float kv = kappa[(t - 1) * B + b], gv = gy[(t - 1) * B + b];
+        Cc = fmaf(kv, Cc, 0.5f * (kv + 1.0f) * gv);
+        A *= kv;
+    }
+    if (b_raw < B) map[(int64_t)blockIdx.y * B + b] = make_float2(A, Cc);
+}
+
+static __global__ __launch_bounds__(64) void mlp_adjoint_scan_chunked_kernel(const float* kappa, const float* __restrict__ gy,
+                                                                             const float2* __restrict__ map, float* gb2n,
+                                                                             int64_t B, int64_t T)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t t0 = (int64_t)blockIdx.y * kScanChunk;
+    int64_t t = (t0 + kScanChunk < T) ? t0 + kScanChunk : T;
+    float gz = 0.0f;                                            // the adjoint that arrives from the chunks after this one
+    for (int kk = (int)gridDim.y - 1; kk > (int)blockIdx.y; --kk) {
+        const float2 m = map[(int64_t)kk * B + b];
+        gz = fmaf(m.x, gz, m.y);
+    }
+    for (; t >= t0 + 8; t -= 8) {
+        float kv[8], gv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kv[i] = kappa[(t - 1 - i) * B + b]; gv[i] = gy[(t - 1 - i) * B + b]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float g2 = fmaf(0.5f, gv[i], gz);
+            gb2n[(t - 1 - i) * B + b] = g2;
+            gz = fmaf(kv[i], g2, 0.5f * gv[i]);
+        }
+    }
+    for (; t > t0; --t) {
+        const float kv = kappa[(t - 1) * B + b], gv = gy[(t - 1) * B + b];
+        const float g2 = fmaf(0.5f, gv, gz);
+        gb2n[(t - 1) * B + b] = g2;
+        gz = fmaf(kv, g2, 0.5f * gv);
+    }
+}
+
 // (C) weight-gradient and {R, C} sums of chunk (w, k) with g_b2n known.  Outputs per wave
 // (index blockIdx.y * gridDim.x + blockIdx.x), the layout of clipper_mlp_row_bwd_w_kernel's.
 template <int NL, bool DYN_R>
