@@ -254,7 +254,10 @@ def run_mlp_root(args, world, rank, local):
     n_global = float(Bg * (T - skip))
     plan = None if args.sequential else mlp_root.plan_mlp_time_parallel(B, T, r, None, workload.C_CLIPPER, fs)
     adam = binding.Adam(w.numel(), lr=1.0e-4, beta_1=0.5, device=dev)
-    buf = torch.zeros(w.numel() + 2, dtype=torch.float32, device=dev)
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    gcoef, loss3 = torch.zeros(2, dtype=torch.float32, device=dev), torch.zeros(3, dtype=torch.float32, device=dev)
+    loss_ws = torch.empty((binding.lib().wdf_loss_sums_ws_bytes(),), dtype=torch.uint8, device=dev)
+    gy_buf = torch.empty((T, B), dtype=torch.float32, device=dev)
     ev = [binding.Event() for _ in range(4)]
     t_f, t_b = [], []
 
@@ -264,29 +267,24 @@ def run_mlp_root(args, world, rank, local):
         y, _ = mlp_root.clipper_mlp(theta2, w, x, r, None, fs, hidden, n_tanh, workload.C_CLIPPER, time_parallel=plan)
         if timed:
             ev[1].record()
-        o, t = y[skip:], target[skip:]
-        S, E = ((o - t) ** 2).sum(), (o ** 2).sum()
-        sums = torch.stack([S.detach(), E.detach()]).double()
-        wdist.allreduce_sum_(sums)                                    # the two loss sums, global
-        # d loss / d y with the GLOBAL sums (loss = S/n + sqrt(S/(E+eps)/n)): ga (y - t) + gb y
-        esr = torch.sqrt(sums[0] / (sums[1] + eps) / n_global)
-        ga = 2.0 / n_global + 1.0 / (esr * (sums[1] + eps) * n_global)
-        gb = -esr / (sums[1] + eps)
-        gy = torch.zeros_like(y)
-        gy[skip:] = (ga * (o - t) + gb * o).float().detach()
+        # the loss on the device (include/wdf_hip.h: wdf_loss_sums / wdf_esr_coef / wdf_loss_esr_grad): the two sums,
+        # global; then loss = S/n + sqrt(S/(E+eps)/n) and d loss / d y = ga (y - t) + gb y past `skip`
+        yd = y.detach()
+        binding.loss_sums(yd, target, skip, sums=sums, ws=loss_ws)
+        wdist.allreduce_sum_(sums)
+        binding.esr_coef(sums, n_global, eps, gcoef=gcoef, loss=loss3)
+        gy = binding.loss_esr_grad(yd, target, gcoef, skip, gy=gy_buf)
         if timed:
             ev[2].record()
         (gw,) = torch.autograd.grad(y, [w], grad_outputs=gy)
         if timed:
             ev[3].record()
-        buf[:-2] = gw
-        buf[-2:] = sums.float()
-        wdist.allreduce_sum_(buf)                                      # one fused buffer: weight gradient (+ the sums again)
+        wdist.allreduce_sum_(gw)                                       # the weight gradient, global
         with torch.no_grad():
-            adam.apply(w, buf[:-2].contiguous())
+            adam.apply(w, gw)
         if timed:
             t_f.append(ev[0].elapsed_ms(ev[1])); t_b.append(ev[2].elapsed_ms(ev[3]))
-        return sums[0] / n_global + esr
+        return loss3[2]
 
     for _ in range(args.warmup):
         loss0 = step()

@@ -52,6 +52,16 @@ int wdf_loss_sums(const float* y, const float* target, int64_t B, int64_t T, int
     return check_launch("wdf_loss_sums");
 }
 
+int wdf_loss_esr_grad(const float* y, const float* target, const float* gcoef, int64_t B, int64_t T, int64_t skip,
+                      float* gy, void* stream)
+{
+    if (!y || !target || !gcoef || !gy) return fail(WDF_EINVAL, "null y/target/gcoef/gy");
+    if (B <= 0 || T <= 0 || skip < 0 || skip >= T) return fail(WDF_EINVAL, "need B, T > 0 and 0 <= skip < T");
+    hipLaunchKernelGGL(wdf::loss_esr_grad_kernel, dim3(loss_blocks(T * B)), dim3(256), 0, (hipStream_t)stream, y, target,
+                       gcoef, skip * B, T * B, gy);
+    return check_launch("wdf_loss_esr_grad");
+}
+
 int wdf_esr_coef(const double* sums, double n, double eps, float* gcoef, float* loss, void* stream)
 {
     if (!sums || !gcoef || !loss) return fail(WDF_EINVAL, "null sums/gcoef/loss");

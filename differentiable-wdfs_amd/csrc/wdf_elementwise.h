@@ -60,6 +60,19 @@ static __global__ void esr_coef_kernel(const double* __restrict__ sums, double n
     loss[0] = (float)mse; loss[1] = (float)esr; loss[2] = (float)(mse + esr);
 }
 
+// dL/dy [T][B] of that loss for a reverse sweep that takes an upstream gradient (the MLP-root sweep): zero before
+// skip, ga (y - t) + gb y after, with {ga, gb} read from the device (esr_coef_kernel's output).
+static __global__ __launch_bounds__(256) void loss_esr_grad_kernel(const float* __restrict__ y, const float* __restrict__ target,
+                                                                   const float* __restrict__ gcoef, int64_t n0, int64_t n1,
+                                                                   float* __restrict__ gy)
+{
+    const float ga = gcoef[0], gb = gcoef[1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n1; i += (int64_t)gridDim.x * 256) {
+        const float yv = y[i];
+        gy[i] = i < n0 ? 0.0f : fmaf(ga, yv - target[i], gb * yv);
+    }
+}
+
 // ---- element-wise building blocks (parity tests) ----------------------------------------
 static __global__ void omega_kernel(const float* __restrict__ x, float* __restrict__ w, int32_t* __restrict__ iters, int64_t n)
 {

@@ -106,6 +106,8 @@ def lib():
     L.wdf_loss_sums.argtypes = [fp, fp, i64, i64, i64, vp, vp, vp]
     L.wdf_esr_coef.restype = ci
     L.wdf_esr_coef.argtypes = [vp, C.c_double, C.c_double, fp, fp, vp]
+    L.wdf_loss_esr_grad.restype = ci
+    L.wdf_loss_esr_grad.argtypes = [fp, fp, fp, i64, i64, i64, fp, vp]
     L.wdf_clipper_bwd_esr_tp.restype = ci
     L.wdf_clipper_bwd_esr_tp.argtypes = [fp, fp, fp, cf, ci, ci, fp, fp, fp, fp, i64, vp, fp, fp, fp, ci, i64, i64, ci,
                                          ci, vp]
@@ -197,7 +199,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_fwd_tp_state_bytes", "wdf_clipper_fwd_tp_state_reset", "wdf_clipper_fwd_tp_warm",
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp_ws_init", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_bwd_mse_tp_adam", "wdf_clipper_step_mse_tp_ws_bytes", "wdf_clipper_step_mse_tp_ws_init",
-    "wdf_clipper_step_mse_tp", "wdf_clipper_step_esr_tp", "wdf_esr_finish", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_clipper_bwd_esr_tp",
+    "wdf_clipper_step_mse_tp", "wdf_clipper_step_esr_tp", "wdf_esr_finish", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_loss_esr_grad", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_clipper_asym_fwd_tp_ws_bytes", "wdf_clipper_asym_fwd_tp", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
@@ -536,6 +538,19 @@ def esr_coef(sums, n, eps, gcoef=None, loss=None):
         loss = torch.empty((3,), dtype=torch.float32, device=sums.device)
     _check(lib().wdf_esr_coef(_ptr(sums), float(n), float(eps), _ptr(gcoef), _ptr(loss), _stream()), "wdf_esr_coef")
     return gcoef, loss
+
+
+def loss_esr_grad(y, target, gcoef, skip, gy=None):
+    """dL/dy [T,B] of MSE + ESR past `skip` from the device coefficients of esr_coef()."""
+    require_gpu()
+    y, target, gcoef = _f32_dev(y, "y"), _f32_dev(target, "target"), _f32_dev(gcoef, "gcoef")
+    T, B = y.shape
+    if tuple(target.shape) != (T, B) or gcoef.numel() != 2:
+        raise WdfHipError("target must have y's shape [T,B]; gcoef = {ga, gb}")
+    if gy is None:
+        gy = torch.empty_like(y)
+    _check(lib().wdf_loss_esr_grad(_ptr(y), _ptr(target), _ptr(gcoef), B, T, int(skip), _ptr(gy), _stream()), "wdf_loss_esr_grad")
+    return gy
 
 
 def clipper_bwd_esr_tp(x, theta, fs, zstash, zT, target, gcoef, skip, n_chunks, r=None, n_up=1, n_down=1, gtheta=None,

@@ -222,6 +222,10 @@ int64_t wdf_loss_sums_ws_bytes(void);
 int wdf_loss_sums(const float* y, const float* target, int64_t B, int64_t T, int64_t skip, void* ws,
                   double* sums, void* stream);
 int wdf_esr_coef(const double* sums, double n, double eps, float* gcoef, float* loss, void* stream);
+/* dL/dy [T][B] of that loss as an array, for a reverse sweep that takes an upstream gradient (wdf_clipper_mlp_bwd_w*):
+ * rows before skip 0, then gcoef[0] (y - target) + gcoef[1] y; gcoef on the device (wdf_esr_coef's output). */
+int wdf_loss_esr_grad(const float* y, const float* target, const float* gcoef, int64_t B, int64_t T, int64_t skip,
+                      float* gy, void* stream);
 int wdf_clipper_bwd_esr_tp(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down,
                            const float* zstash, const float* zT, const float* target,
                            const float* gcoef, int64_t skip, void* ws, float* gtheta, float* sse,

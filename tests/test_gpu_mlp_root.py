@@ -344,6 +344,31 @@ def test_mlp_forward_stored_kappa_equals_the_recomputed_one(hidden, n_tanh, B, T
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, (a, b)
 
 
+def test_device_loss_kernels_equal_autograd_of_the_loss():
+    """wdf_loss_sums -> wdf_esr_coef -> wdf_loss_esr_grad (the MLP-root training loop's loss, bench.py --root mlp*):
+    loss and d loss / d y equal torch autograd of  mse + esr  past `skip` in float64 (clipper_pot.py:146-156,177,232)
+    to 1e-6 relative; the rows before skip get exactly 0."""
+    from wdf_hip import binding as wb
+    rng = np.random.default_rng(8)
+    T, B, skip = 300, 37, 50
+    y = cuda(rng.standard_normal((T, B)) * 0.3)
+    t = cuda(rng.standard_normal((T, B)) * 0.3)
+    n, eps = float(B * (T - skip)), float(np.finfo(float).eps)
+    sums = wb.loss_sums(y, t, skip)
+    gcoef, loss3 = wb.esr_coef(sums, n, eps)
+    gy = wb.loss_esr_grad(y, t, gcoef, skip)
+    with pytest.raises(wb.WdfHipError, match="skip"):
+        wb.loss_esr_grad(y, t, gcoef, T)
+    yd = y.double().requires_grad_(True)
+    o, tt = yd[skip:], t.double()[skip:]
+    S, E = ((o - tt) ** 2).sum(), (o ** 2).sum()
+    loss = S / n + torch.sqrt(S / (E + eps) / n)
+    (g_ref,) = torch.autograd.grad(loss, [yd])
+    assert abs(float(loss3[2]) - float(loss)) <= 1e-6 * float(loss)
+    assert float(gy[:skip].abs().max()) == 0.0
+    assert float((gy.double() - g_ref).abs().max()) <= 1e-6 * float(g_ref.abs().max())
+
+
 def test_mlp_warm_started_chunks_follow_a_training_loop():
     """A training loop on one batch: from the second call on every chunk starts from the previous call's state at
     its first sample (secant-extrapolated from the third), with a fraction of the cold warm-up; the weights move by
