@@ -252,7 +252,7 @@ def run_mlp_root(args, world, rank, local):
     target, _, _ = binding.clipper_fwd(x, th4, fs, r=r, want_stash=False)        # "measurement": the analytic diode pair
     skip, eps = 50, float(np.finfo(float).eps)
     n_global = float(Bg * (T - skip))
-    plan = None if args.sequential else mlp_root.plan_mlp_time_parallel(B, T, r, None, workload.C_CLIPPER, fs)
+    plan = None if args.sequential else mlp_root.plan_mlp_time_parallel(B, T, r, None, workload.C_CLIPPER, fs, hidden=hidden, n_tanh=n_tanh)
     adam = binding.Adam(w.numel(), lr=1.0e-4, beta_1=0.5, device=dev)
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
     gcoef, loss3 = torch.zeros(2, dtype=torch.float32, device=dev), torch.zeros(3, dtype=torch.float32, device=dev)

@@ -52,11 +52,19 @@ static int mlp_check(const float* x, const float* theta2, const float* w, int hi
 // Which forward kernel: the row kernel (4 sequences per wave, DPP; the shorter dependent chain per step: 0.31 us against
 // 0.55 us) while the batch leaves SIMDs idle, the matrix-core kernel (16 per wave, wdf_mlp_mfma.h; 1.5x the row
 // kernel's throughput) once the row kernel would stack three waves on a SIMD.  WDF_MLP_FWD_ROW = 1 / 0 forces one.
-static bool mlp_fwd_on_matrix_cores(int64_t B)
+// n_chunks > 1 (the time-parallel entry points), width-16 nets with three tanh layers: also when the matrix-core waves,
+// one per SIMD, cover a chunk count the row kernel could only reach with more than two waves per SIMD -- the
+// reference's 1340 sequences in 12 chunks are 1008 waves of 16 against 4020 of 4 (bench.py --root mlp2x16, warm-started
+// training loop: forward call 0.336 vs 0.386 ms at 6 row chunks).  Narrower nets are zero-padded to 16 on the matrix
+// cores and deeper ones lengthen the MFMA chain: 2x8 0.83 vs 0.75 ms per step, 4x8 1.66 vs 1.29 -- those stay on the rows.
+static bool mlp_fwd_on_matrix_cores(int64_t B, int n_chunks = 1, int hidden = 0, int n_tanh_layers = 0)
 {
     const char* e = getenv("WDF_MLP_FWD_ROW");
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '0';
-    return B >= 12288;
+    if (B >= 12288) return true;
+    constexpr int64_t kSimd = 1024;                            // MI355X: 256 CUs x 4
+    return n_chunks > 1 && hidden == 16 && n_tanh_layers == 3 && (B + 15) / 16 * n_chunks <= kSimd &&
+           (B + 3) / 4 * n_chunks > 2 * kSimd;
 }
 
 int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, const float* w, int hidden,
@@ -214,7 +222,7 @@ static int mlp_fwd_tp_common(const float* x, const float* r, const float* theta2
     unsigned* gate = (unsigned*)(zend + (size_t)g.K * (size_t)B);
     // The chunks run on the row kernel or on the matrix cores (mlp_fwd_on_matrix_cores: by batch size; shapes that
     // want chunks at all are small, so normally the row kernel).  The verify / sequential / kappa launches keep the row grid.
-    const bool use_row = !mlp_fwd_on_matrix_cores(B);
+    const bool use_row = !mlp_fwd_on_matrix_cores(B, g.K, hidden, n_tanh_layers);
     const unsigned grid_row = (unsigned)((B + 3) / 4);
     const dim3 grid(use_row ? grid_row : (unsigned)((B + 15) / 16), (unsigned)g.K);
     const bool dyn = r != nullptr;

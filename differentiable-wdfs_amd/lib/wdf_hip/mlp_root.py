@@ -269,7 +269,7 @@ def warmup_per_wave(r, C, fs, tol=1.0e-6):
     return hit[3], hit[4]
 
 
-def plan_mlp_time_parallel(B, T, r, R_static, C, fs, tol=4.0e-6):
+def plan_mlp_time_parallel(B, T, r, R_static, C, fs, tol=4.0e-6, hidden=None, n_tanh=None):
     """MlpTpPlan for the in-kernel time-parallel MLP-root kernels, or None when the batch already fills the
     chip or the circuit remembers more than a chunk.  The row kernels are bound by VALU issue (~100 / ~250
     instructions per step and wave, forward / reverse), so chunks pay only until every SIMD has work: about
@@ -291,6 +291,14 @@ def plan_mlp_time_parallel(B, T, r, R_static, C, fs, tol=4.0e-6):
     wmax = max(_warmup_steps(abs(1.0 - 2.0 * Rc / (Rv + Rc)), tol) for Rv in ends)
     wmax = -(-int(1.15 * wmax) // 16) * 16
     k_fwd = max(1, min(2 * engine.N_SIMD // waves, T // max(wmax // 2, 64)))
+    # The matrix-core forward carries 16 sequences per wave: one wave per SIMD reaches twice the chunks (shorter chunks,
+    # and with warm-started chunks the warm-up no longer dominates) -- the library picks that kernel by itself when the
+    # row kernel could not cover the chunk count with two waves per SIMD (csrc/wdf_capi_mlp.hip, mlp_fwd_on_matrix_cores).
+    # Width 16, three tanh layers only (narrower nets are padded there, deeper ones lengthen the MFMA chain: measured worse).
+    k_mfma = min(engine.N_SIMD // max(1, -(-B // 16)), T // 128)
+    if (hidden, n_tanh) == (16, 3) and k_mfma > k_fwd and waves * k_mfma > 2 * engine.N_SIMD \
+            and os.environ.get("WDF_MLP_FWD_ROW") != "1":
+        k_fwd = k_mfma
     k_bwd = max(1, min(2 * engine.N_SIMD // waves, T // 64))
     if os.environ.get("WDF_MLP_K_FWD"):
         k_fwd = int(os.environ["WDF_MLP_K_FWD"])
@@ -305,7 +313,7 @@ def clipper_mlp(theta2, w, x, r, z0, fs, hidden, n_tanh, C, R_static=None, time_
     "segments" -> the older data-level segmentation (forward verified, backward truncated: evaluation only).
     Returns (y [T,B], zT [B])."""
     if time_parallel == "auto":
-        time_parallel = plan_mlp_time_parallel(x.shape[0], x.shape[1], r, R_static, C, fs)
+        time_parallel = plan_mlp_time_parallel(x.shape[0], x.shape[1], r, R_static, C, fs, hidden=hidden, n_tanh=n_tanh)
     if isinstance(time_parallel, MlpTpPlan):
         return _ClipperMlpFn.apply(theta2, w, x, r, z0, fs, hidden, n_tanh, True, False, time_parallel)
     if time_parallel != "segments":
