@@ -32,8 +32,6 @@
 
 namespace wdf {
 
-typedef float mfma_v4f __attribute__((ext_vector_type(4)));
-
 template <int NL>
 struct MfmaWeights {
     float k0a[4], k0l[4], b0[4];   // layer 0, unit 4 g + v
@@ -71,10 +69,7 @@ __device__ __forceinline__ MfmaWeights<NL> mfma_load_weights(const float* __rest
     return W;
 }
 
-__device__ __forceinline__ mfma_v4f mfma4(float a, float b, mfma_v4f c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
+// (mfma_v4f, mfma4: wdf_mlp_row.h)
 
 // out[n] = MLP(a[n], lr[n]) in every lane of sequence n; act[l] = the lane's four activations of layer l
 template <int NL>

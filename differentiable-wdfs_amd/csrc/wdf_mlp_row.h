@@ -282,38 +282,25 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_bwd_kernel(
 //   g k0a[j] += G delta_0[j] a ; g k0l[j] += G delta_0[j] lr ; g b0[j] += G delta_0[j]
 // -- independent accumulations that fill issue slots of a latency-bound step.  No g_b / a / log R
 // arrays are written and no second pass over the samples is needed.
+typedef float mfma_v4f __attribute__((ext_vector_type(4)));
+
+// D = A B + C of v_mfma_f32_16x16x4_f32: A[i][k] in lane 16 k + i, B[k][n] in lane 16 k + n, D[i][n] in VGPR v of
+// lane 16 g + n with i = 4 g + v
+__device__ __forceinline__ mfma_v4f mfma4(float a, float b, mfma_v4f c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// The hidden layers' kernel gradients are outer products summed over steps AND over the wave's four sequences:
+// with lane 16 q + j holding (G delta)_q[j] as A[j][q] and h_q[j] as B[q][j], ONE MFMA per layer and step adds
+// sum_q (G delta)_q[i] h_q[n] to mid[l] = dK_l[in n][out i] in the D layout (was 16 DPP-FMAs per lane into 16
+// accumulators per layer, plus a sum over the four rows at the end).
 template <int NL>
 struct RowGrads {
     float k0a, k0l, b0, wo, bo;
     float bias[NL - 1];
-    float mid[NL - 1][16];
+    mfma_v4f mid[NL - 1];
 };
-
-// gm[s] += gd * rot_s(h), s = 0..15: the rotation as a DPP modifier of the FMA (see row_matvec)
-__device__ __forceinline__ void row_outer(float (&gm)[16], float h, float gd)
-{
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_fmac_f32_e32 %0, %16, %17\n\t"
-        "v_fmac_f32_dpp %1, %16, %17 row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %2, %16, %17 row_ror:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %3, %16, %17 row_ror:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %4, %16, %17 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %5, %16, %17 row_ror:5 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %6, %16, %17 row_ror:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %7, %16, %17 row_ror:7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %8, %16, %17 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %9, %16, %17 row_ror:9 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %10, %16, %17 row_ror:10 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %11, %16, %17 row_ror:11 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %12, %16, %17 row_ror:12 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %13, %16, %17 row_ror:13 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %14, %16, %17 row_ror:14 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %15, %16, %17 row_ror:15 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "+v"(gm[0]), "+v"(gm[1]), "+v"(gm[2]), "+v"(gm[3]), "+v"(gm[4]), "+v"(gm[5]), "+v"(gm[6]), "+v"(gm[7]),
-          "+v"(gm[8]), "+v"(gm[9]), "+v"(gm[10]), "+v"(gm[11]), "+v"(gm[12]), "+v"(gm[13]), "+v"(gm[14]), "+v"(gm[15])
-        : "v"(h), "v"(gd));
-}
 
 template <int NL>
 __device__ __forceinline__ void row_mlp_grad_all(const RowWeights<NL>& W, const float (&act)[NL], float a, float lr,
@@ -326,7 +313,7 @@ __device__ __forceinline__ void row_mlp_grad_all(const RowWeights<NL>& W, const 
     for (int l = NL - 1; l >= 1; --l) {
         const float gd = G * d;
         acc.bias[l - 1] += gd;
-        row_outer(acc.mid[l - 1], act[l - 1], gd);
+        acc.mid[l - 1] = mfma4(gd, act[l - 1], acc.mid[l - 1]);
         d = row_matvec(W.tmid[l - 1], d, 0.0f) * fmaf(-act[l - 1], act[l - 1], 1.0f);
     }
     const float gd0 = G * d;
@@ -345,16 +332,20 @@ __device__ __forceinline__ float rows_sum(float v)
     return v;
 }
 
-template <int S, int NL>
-__device__ __forceinline__ void row_store_mid(const RowGrads<NL>& acc, float* __restrict__ o, int H, int j, bool writer)
+// mid[l] (D layout: VGPR v of lane 16 g + n = dK_l[in n][out 4 g + v], the wave's four sequences already summed)
+// -> the flat weight order, kernel_l [in][out]
+template <int NL>
+__device__ __forceinline__ void row_store_mid(const RowGrads<NL>& acc, float* __restrict__ o, int H, int lane)
 {
-    const int src = row_rot_i<S>(j);
+    const int n = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int l = 1; l < NL; ++l) {
-        const float v = rows_sum(acc.mid[l - 1][S]);
-        if (writer && j < H && src < H) o[3 * H + (l - 1) * (H * H + H) + src * H + j] = v;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = 4 * g + v;
+            if (n < H && i < H) o[3 * H + (l - 1) * (H * H + H) + n * H + i] = acc.mid[l - 1][v];
+        }
     }
-    if constexpr (S + 1 < 16) row_store_mid<S + 1, NL>(acc, o, H, j, writer);
 }
 
 // Outputs: wsw float[gridDim.x][count] = this wave's weight-gradient partial in the flat weight
@@ -378,8 +369,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_bwd_w_kernel(
 #pragma unroll
     for (int l = 0; l < NL - 1; ++l) {
         acc.bias[l] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc.mid[l][s] = 0.0f;
+        acc.mid[l] = mfma_v4f{0.0f, 0.0f, 0.0f, 0.0f};
     }
     double dLr = 0.0, dP = 0.0;
     float gz = 0.0f;
@@ -444,7 +434,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_bwd_w_kernel(
         const float vb = rows_sum(acc.bias[l - 1]);
         if (writer && j < H) o[3 * H + (l - 1) * (H * H + H) + H * H + j] = vb;
     }
-    row_store_mid<0, NL>(acc, o, H, j, writer);
+    row_store_mid<NL>(acc, o, H, lane);
 }
 
 }  // namespace wdf

@@ -314,8 +314,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_wgrad_tp_kernel(
 #pragma unroll
     for (int l = 0; l < NL - 1; ++l) {
         acc.bias[l] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc.mid[l][s] = 0.0f;
+        acc.mid[l] = mfma_v4f{0.0f, 0.0f, 0.0f, 0.0f};
     }
     double dLr = 0.0, dP = 0.0;
     float act[NL];
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_wgrad_tp_kernel(
         const float vb = rows_sum(acc.bias[l - 1]);
         if (writer && j < H) o[3 * H + (l - 1) * (H * H + H) + H * H + j] = vb;
     }
-    row_store_mid<0, NL>(acc, o, H, j, writer);
+    row_store_mid<NL>(acc, o, H, lane);
 }
 
 // Fixed-order sum of many per-wave weight-gradient partials [nblk][count]: block (64, 16) -- thread (i, s)
