@@ -320,7 +320,7 @@ def run_mlp_root(args, world, rank, local):
                                                                       "verify_tol": plan.tol, "bwd_chunks": plan.k_bwd,
                                                                       "verify_status": st}},
                "call_ms": {"forward": spread(t_f), "reverse": spread(t_b)},
-               "roofline": {"bound": "hbm", "kernel": "clipper_mlp_row_fwd_tp_kernel (+ verify)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+               "roofline": {"bound": "hbm", "kernel": "time-parallel MLP-root forward (matrix-core kernel for 2x16, row kernel otherwise: csrc/wdf_capi_mlp.hip) + verify", "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                             "note": "not a bandwidth-bound kernel: ~100 (forward) / ~250 (reverse) VALU instructions per step "
                                     "and 4-sequence wave at ~2 ns per issued instruction and SIMD is the limit (DESIGN.md)"}}

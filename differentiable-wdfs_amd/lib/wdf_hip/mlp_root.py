@@ -300,8 +300,10 @@ def plan_mlp_time_parallel(B, T, r, R_static, C, fs, tol=4.0e-6, hidden=None, n_
             and os.environ.get("WDF_MLP_FWD_ROW") != "1":
         k_fwd = k_mfma
     k_bwd = max(1, min(2 * engine.N_SIMD // waves, T // 64))
-    if os.environ.get("WDF_MLP_K_FWD"):
+    if os.environ.get("WDF_MLP_K_FWD"):                      # (probing)
         k_fwd = int(os.environ["WDF_MLP_K_FWD"])
+    if os.environ.get("WDF_MLP_K_BWD"):
+        k_bwd = int(os.environ["WDF_MLP_K_BWD"])
     if k_fwd < 2 and k_bwd < 2:
         return None
     return MlpTpPlan(k_fwd, wmax, None, float(tol), k_bwd)
