@@ -86,11 +86,11 @@ int wdf_clipper_mlp_fwd(const float* x, const float* r, const float* theta2, con
         if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_mfma_fwd_tp_kernel<NL_, true, false>), gm, dim3(64), 0,     \
                                     (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, (float*)nullptr, \
                                     (float*)nullptr, (const int*)nullptr, (wdf::MlpTpStatus*)nullptr, B, T, Lp,     \
-                                    (int64_t)0, Lp, (float*)nullptr, (const float*)nullptr);                   \
+                                    (int64_t)0, Lp, (float*)nullptr, (const float*)nullptr, (const unsigned*)nullptr);                   \
         else hipLaunchKernelGGL((wdf::clipper_mlp_mfma_fwd_tp_kernel<NL_, false, false>), gm, dim3(64), 0,        \
                                 (hipStream_t)stream, x, r, theta2, w, hidden, fs, y, zstash, z0, zT, (float*)nullptr, \
                                 (float*)nullptr, (const int*)nullptr, (wdf::MlpTpStatus*)nullptr, B, T, Lp,         \
-                                (int64_t)0, Lp, (float*)nullptr, (const float*)nullptr);                       \
+                                (int64_t)0, Lp, (float*)nullptr, (const float*)nullptr, (const unsigned*)nullptr);                       \
     }
         WDF_MFMA_FWD(3) WDF_MFMA_FWD(4) WDF_MFMA_FWD(5)
 #undef WDF_MFMA_FWD
@@ -198,7 +198,8 @@ int wdf_clipper_mlp_tp_chunks(int64_t T, int n_chunks) { return T > 0 ? mlp_tp_g
 size_t wdf_clipper_mlp_fwd_tp_ws_bytes(int64_t B, int n_chunks)
 {
     if (B <= 0 || n_chunks <= 0) return 0;
-    return (size_t)2 * (size_t)n_chunks * (size_t)B * sizeof(float) + (size_t)((B + 3) / 4) * sizeof(unsigned);
+    // arrival and end states of the first pass and of the chunk-local repair pass, the two gates
+    return (size_t)4 * (size_t)n_chunks * (size_t)B * sizeof(float) + (size_t)2 * (size_t)((B + 3) / 4) * sizeof(unsigned);
 }
 
 // kappa != nullptr: the forward also leaves kappa[T][B] (the adjoint recurrence's coefficient) for
@@ -219,7 +220,11 @@ static int mlp_fwd_tp_common(const float* x, const float* r, const float* theta2
     const int64_t L0 = mlp_tp_balance(T, W, warmup_per_wave == nullptr, want_kappa, g);
     float* zwarm = (float*)ws;
     float* zend = zwarm + (size_t)g.K * (size_t)B;
-    unsigned* gate = (unsigned*)(zend + (size_t)g.K * (size_t)B);
+    float* zwarm2 = zend + (size_t)g.K * (size_t)B;
+    float* zend2 = zwarm2 + (size_t)g.K * (size_t)B;
+    unsigned* gate = (unsigned*)(zend2 + (size_t)g.K * (size_t)B);
+    unsigned* gate2 = gate + (size_t)((B + 3) / 4);
+    const float* zprev = zend - B;                             // zprev[k][b] = zend[k-1][b]: where chunk k's predecessor ended
     // The chunks run on the row kernel or on the matrix cores (mlp_fwd_on_matrix_cores: by batch size; shapes that
     // want chunks at all are small, so normally the row kernel).  The verify / sequential / kappa launches keep the row grid.
     const bool use_row = !mlp_fwd_on_matrix_cores(B, g.K, hidden, n_tanh_layers);
@@ -227,15 +232,20 @@ static int mlp_fwd_tp_common(const float* x, const float* r, const float* theta2
     const dim3 grid(use_row ? grid_row : (unsigned)((B + 15) / 16), (unsigned)g.K);
     const bool dyn = r != nullptr;
     hipStream_t s = (hipStream_t)stream;
-#define WDF_ROW_FWD_TP_LAUNCH(NL_, DYN_, KAP_)                                                                     \
+#define WDF_ROW_FWD_TP_LAUNCH_(NL_, DYN_, KAP_, ZW_, ZE_, WROW_, ST_, WW_, ZI_, GATE_)                                \
     if (use_row)                                                                                                 \
         hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_tp_kernel<NL_, DYN_, KAP_>), grid, dim3(64), 0, s, x, r, theta2, w, \
-                           hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave, (wdf::MlpTpStatus*)status, B, \
-                           T, g.L, W, L0, kappa, zinit);                                                          \
+                           hidden, fs, y, zstash, z0, zT, ZW_, ZE_, WROW_, (wdf::MlpTpStatus*)(ST_), B, T, g.L,      \
+                           (int64_t)(WW_), L0, kappa, ZI_, (const unsigned*)(GATE_));                             \
     else                                                                                                         \
         hipLaunchKernelGGL((wdf::clipper_mlp_mfma_fwd_tp_kernel<NL_, DYN_, KAP_>), grid, dim3(64), 0, s, x, r, theta2,   \
-                           w, hidden, fs, y, zstash, z0, zT, zwarm, zend, warmup_per_wave, (wdf::MlpTpStatus*)status, \
-                           B, T, g.L, W, L0, kappa, zinit)
+                           w, hidden, fs, y, zstash, z0, zT, ZW_, ZE_, WROW_, (wdf::MlpTpStatus*)(ST_), B, T, g.L,   \
+                           (int64_t)(WW_), L0, kappa, ZI_, (const unsigned*)(GATE_))
+#define WDF_ROW_FWD_TP_LAUNCH(NL_, DYN_, KAP_)                                                                     \
+    WDF_ROW_FWD_TP_LAUNCH_(NL_, DYN_, KAP_, zwarm, zend, warmup_per_wave, status, W, zinit, nullptr)
+// the chunk-local repair: the flagged waves again, every chunk from the state its predecessor ended in, no warm-up
+#define WDF_ROW_FWD_TP_REPAIR(NL_, DYN_, KAP_)                                                                     \
+    WDF_ROW_FWD_TP_LAUNCH_(NL_, DYN_, KAP_, zwarm2, zend2, (const int32_t*)nullptr, nullptr, 0, zprev, gate)
 #define WDF_ROW_FWD_TP(NL_)                                                                                      \
     if (n_tanh_layers == NL_) {                                                                                  \
         {                                                                                                        \
@@ -250,24 +260,36 @@ static int mlp_fwd_tp_common(const float* x, const float* r, const float* theta2
         }                                                                                                        \
         if (g.K > 1) {                                                                                           \
             hipLaunchKernelGGL(wdf::mlp_tp_verify_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, zwarm, zend, B, \
-                               (int64_t)g.K, tol, gate, (wdf::MlpTpStatus*)status);                               \
+                               (int64_t)g.K, tol, gate, (wdf::MlpTpStatus*)status, (const unsigned*)nullptr);     \
+            if (want_kappa) {                                                                                    \
+                if (dyn) { WDF_ROW_FWD_TP_REPAIR(NL_, true, true); }                                             \
+                else { WDF_ROW_FWD_TP_REPAIR(NL_, false, true); }                                                \
+            } else {                                                                                             \
+                if (dyn) { WDF_ROW_FWD_TP_REPAIR(NL_, true, false); }                                            \
+                else { WDF_ROW_FWD_TP_REPAIR(NL_, false, false); }                                               \
+            }                                                                                                    \
+            hipLaunchKernelGGL(wdf::mlp_tp_verify_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s,            \
+                               (const float*)zwarm2, (const float*)zend2, B, (int64_t)g.K, tol, gate2,           \
+                               (wdf::MlpTpStatus*)status, (const unsigned*)gate);                                \
             if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, true>), dim3(grid_row), dim3(64), 0, s, x, r, \
-                                        theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)gate);   \
+                                        theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)gate2);  \
             else hipLaunchKernelGGL((wdf::clipper_mlp_row_fwd_kernel<NL_, false>), dim3(grid_row), dim3(64), 0, s, x, r,    \
-                                    theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)gate);       \
+                                    theta2, w, hidden, fs, y, zstash, z0, zT, B, T, (const unsigned*)gate2);      \
             if (want_kappa) {                                                                                    \
                 const dim3 kgrid(grid_row, (unsigned)gu.K);                                                      \
                 if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, true>), kgrid, dim3(64), 0, s, x, r,   \
                                             theta2, w, hidden, fs, (const float*)zstash, kappa, B, T, gu.L,       \
-                                            (const unsigned*)gate);                                              \
+                                            (const unsigned*)gate2);                                             \
                 else hipLaunchKernelGGL((wdf::clipper_mlp_row_kappa_kernel<NL_, false>), kgrid, dim3(64), 0, s, x, r,      \
                                         theta2, w, hidden, fs, (const float*)zstash, kappa, B, T, gu.L,           \
-                                        (const unsigned*)gate);                                                  \
+                                        (const unsigned*)gate2);                                                 \
             }                                                                                                    \
         }                                                                                                        \
     }
     WDF_ROW_FWD_TP(3) WDF_ROW_FWD_TP(4) WDF_ROW_FWD_TP(5)
 #undef WDF_ROW_FWD_TP_LAUNCH
+#undef WDF_ROW_FWD_TP_REPAIR
+#undef WDF_ROW_FWD_TP_LAUNCH_
 #undef WDF_ROW_FWD_TP
     return check_launch("wdf_clipper_mlp_fwd_tp");
 }

@@ -120,8 +120,18 @@ __global__ __launch_bounds__(64) void clipper_mlp_mfma_fwd_tp_kernel(
     const float* __restrict__ w, int H, float fs, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
     const int* __restrict__ wrow, MlpTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W, int64_t L0,
-    float* __restrict__ kappa, const float* __restrict__ zinit)
+    float* __restrict__ kappa, const float* __restrict__ zinit, const unsigned* __restrict__ gate)
 {
+    if (gate != nullptr) {                                      // the chunk-local repair pass: flagged waves only
+        const int64_t nw = (B + 3) / 4;
+        unsigned any = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t wi = (int64_t)blockIdx.x * 4 + q;
+            any |= gate[wi < nw ? wi : nw - 1];
+        }
+        if (any == 0u) return;
+    }
     // zwarm / zend / status may be null: the plain sequential call (one chunk, nothing to verify)
     if (status && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = MlpTpStatus{0, 0.0f, 0, 0};   // the verify kernel adds
     const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;

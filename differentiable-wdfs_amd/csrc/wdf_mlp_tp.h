@@ -37,8 +37,8 @@ namespace wdf {
 struct MlpTpStatus {
     int n_bad;        // (sequence, chunk) pairs whose arrival state missed by more than tol
     float max_miss;   // largest |zwarm - zend| (bit pattern compared as int: values >= 0)
-    int gated_waves;  // 4-sequence waves handed to the sequential re-run
-    int pad;
+    int gated_waves;  // 4-sequence waves with a miss: re-run from their predecessors' end states (chunk-local repair)
+    int sequential_waves;   // ... of those, the waves that still missed and went to the sequential kernel
 };
 
 // zwarm, zend: [K][B].  wrow: per-wave warm-up steps (multiple of 16) or nullptr (W for all).
@@ -50,13 +50,15 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_tp_kernel(
     const float* __restrict__ w, int H, float fs, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm, float* __restrict__ zend,
     const int* __restrict__ wrow, MlpTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W, int64_t L0,
-    float* __restrict__ kappa, const float* __restrict__ zinit)
+    float* __restrict__ kappa, const float* __restrict__ zinit, const unsigned* __restrict__ gate)
 {
+    // gate (or null): the chunk-local repair pass -- only the waves the verification flagged run (again)
+    if (gate != nullptr && gate[blockIdx.x] == 0u) return;
     // zinit [K][B] (or null: z = 0): the state chunk k > 0 starts its warm-up from -- the previous call's state at the
     // same sample, when the caller trains on the same batch (the verification still decides).
     // L0: length of chunk 0, the only chunk without a warm-up: chunk k > 0 owns [L0 + (k-1) L, L0 + k L).  With L0 = L + W
     // every wave runs about the same number of steps (the host balances it, wdf_capi_mlp.hip); L0 = L: equal chunks.
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = MlpTpStatus{0, 0.0f, 0, 0};   // the verify kernel adds
+    if (status && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = MlpTpStatus{0, 0.0f, 0, 0};   // the verify kernel adds
     const int lane = threadIdx.x, j = lane & 15;
     const int64_t b_raw = (int64_t)blockIdx.x * 4 + (lane >> 4);
     const int64_t b = b_raw < B ? b_raw : B - 1;
@@ -119,18 +121,23 @@ __global__ __launch_bounds__(64) void clipper_mlp_row_fwd_tp_kernel(
 
 // One lane per sequence: every chunk boundary of the sequence; gate[b / 4] = 1 where any of a wave's four
 // sequences missed (the gated sequential kernel re-runs that wave), 0 otherwise.
+// only (or null): the second verification, after the chunk-local repair -- just the waves flagged there are looked
+// at (the others did not run again) and the count goes to status->sequential_waves.
 static __global__ __launch_bounds__(64) void mlp_tp_verify_kernel(const float* __restrict__ zwarm, const float* __restrict__ zend,
                                                                   int64_t B, int64_t K, float tol, unsigned* __restrict__ gate,
-                                                                  MlpTpStatus* __restrict__ status)
+                                                                  MlpTpStatus* __restrict__ status,
+                                                                  const unsigned* __restrict__ only = nullptr)
 {
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;
     float miss = 0.0f;
     int nbad = 0;
-    for (int64_t k = 1; k < K; ++k) {
-        const float m = fabsf(zwarm[k * B + b] - zend[(k - 1) * B + b]);
-        miss = fmaxf(miss, m);
-        nbad += !(m <= tol) ? 1 : 0;
+    if (only == nullptr || only[b >> 2] != 0u) {
+        for (int64_t k = 1; k < K; ++k) {
+            const float m = fabsf(zwarm[k * B + b] - zend[(k - 1) * B + b]);
+            miss = fmaxf(miss, m);
+            nbad += !(m <= tol) ? 1 : 0;
+        }
     }
     int any = nbad > 0 ? 1 : 0;
     any |= __shfl_xor(any, 1, 64);
@@ -145,9 +152,13 @@ static __global__ __launch_bounds__(64) void mlp_tp_verify_kernel(const float* _
         wg += __shfl_down(wg, off, 64);
     }
     if (threadIdx.x == 0) {
-        if (wmax > 0.0f) atomicMax(reinterpret_cast<int*>(&status->max_miss), __float_as_int(wmax));
-        if (wbad) atomicAdd(&status->n_bad, wbad);
-        if (wg) atomicAdd(&status->gated_waves, wg);
+        if (only != nullptr) {
+            if (wg) atomicAdd(&status->sequential_waves, wg);
+        } else {
+            if (wmax > 0.0f) atomicMax(reinterpret_cast<int*>(&status->max_miss), __float_as_int(wmax));
+            if (wbad) atomicAdd(&status->n_bad, wbad);
+            if (wg) atomicAdd(&status->gated_waves, wg);
+        }
     }
 }
 

@@ -763,7 +763,10 @@ def mlp_tp_starts(T, n_chunks, warmup):
 
 def mlp_tp_status(status):
     s = status.cpu()
-    return {"n_bad": int(s[0]), "max_miss": float(s[1:2].view(torch.float32)[0]), "gated_waves": int(s[2])}
+    # gated_waves: 4-sequence waves with a miss at the first pass (re-run chunk-locally from their predecessors' end
+    # states); sequential_waves: those that still missed and went through the sequential kernel
+    return {"n_bad": int(s[0]), "max_miss": float(s[1:2].view(torch.float32)[0]), "gated_waves": int(s[2]),
+            "sequential_waves": int(s[3])}
 
 
 def clipper_mlp_bwd_w_tp(x, theta2, w, hidden, n_tanh, fs, zstash, gy, n_chunks, r=None, ws=None, kappa=None):

@@ -400,8 +400,11 @@ int wdf_adam_step(float* theta, const float* grad, float* m, float* v, int32_t* 
  *       early from z = 0 -- or warmup_per_wave[ceil(B/4)] steps (device int32, multiples of 16: one value
  *       per 4 consecutive sequences, the pot resistance sets the circuit's memory) -- and a verify kernel
  *       compares the state each chunk arrives with against the state its predecessor ended in
- *       (|diff| <= tol); waves with a miss are re-run sequentially by a gated launch of the plain kernel.
- *       status: device int32[4] = {n_bad, max |miss| (float bits), gated waves, 0}.
+ *       (|diff| <= tol); waves with a miss run once more, every chunk from the state its predecessor ended in and
+ *       without warm-up (a chunk-local repair: one chunk's steps instead of T), are verified again, and only what
+ *       still misses is re-run sequentially by a gated launch of the plain kernel.
+ *       status: device int32[4] = {n_bad, max |miss| (float bits), waves with a miss at the first pass,
+ *       waves that went through the sequential kernel}.
  *   wdf_clipper_mlp_bwd_w_tp  EXACT reverse sweep, parallel over all steps: kappa[n] = d z'/d z of every
  *       step from the stash (no recurrence), the scalar adjoint recurrence by one lane per sequence, then
  *       the weight-gradient and {R, C} sums of every step with the known adjoint.  Same outputs as

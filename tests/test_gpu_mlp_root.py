@@ -304,7 +304,7 @@ def test_mlp_time_parallel_forward_repairs_a_short_warmup(forward_kernel):
     y, zs, zT = wb.clipper_mlp_fwd(x, th2, w, hidden, n_tanh, FS, r=r, want_zT=True)
     y2, zs2, zT2, st = wb.clipper_mlp_fwd_tp(x, th2, w, hidden, n_tanh, FS, K, 32, r=r, want_zT=True)
     s = wb.mlp_tp_status(st)
-    assert s["n_bad"] > 0 and 0 < s["gated_waves"] <= 10, s
+    assert s["n_bad"] > 0 and 0 < s["gated_waves"] <= 10 and 0 <= s["sequential_waves"] <= s["gated_waves"], s
     # chunks on the matrix cores against the sequential ROW kernel: two fp32 evaluations, each 3-5e-6 from fp64
     tol = 1e-5 if forward_kernel == "matrix-cores" else 2e-6
     assert float((y2 - y).abs().max()) <= tol and float((zs2 - zs).abs().max()) <= tol
@@ -333,9 +333,13 @@ def test_mlp_forward_stored_kappa_equals_the_recomputed_one(hidden, n_tanh, B, T
     y, zs, zT, st = wb.clipper_mlp_fwd_tp(x, th2, w, hidden, n_tanh, FS, K, warm, r=r, want_zT=True)
     y2, zs2, zT2, st2, kap = wb.clipper_mlp_fwd_tp(x, th2, w, hidden, n_tanh, FS, K, warm, r=r, want_zT=True, want_kappa=True)
     scale = max(1.0, float(zs.abs().max()))
+    # warm = 32: the flagged waves of BOTH calls went through the chunk-local repair, which is verified to tol (1e-6
+    # here) rather than exact -- two such results may sit 2 tol + rounding apart
+    lim = (4e-6 if warm == 32 else 2e-6) * scale
     for a, b in ((y, y2), (zs, zs2), (zT, zT2)):
-        assert float((a - b).abs().max()) <= 2e-6 * scale, float((a - b).abs().max())
+        assert float((a - b).abs().max()) <= lim, float((a - b).abs().max())
     s, s2 = wb.mlp_tp_status(st), wb.mlp_tp_status(st2)
+    assert s["sequential_waves"] <= s["gated_waves"]
     assert s["gated_waves"] == s2["gated_waves"] and (s["gated_waves"] > 0) == (warm == 32), (s, s2)
     assert bool(torch.isfinite(kap).all()) and float(kap.abs().max()) < 1.0      # |dz'/dz| < 1: the circuit forgets
     gth, gw = wb.clipper_mlp_bwd_w_tp(x, th2, w, hidden, n_tanh, FS, zs, gy, 2 * K, r=r)
