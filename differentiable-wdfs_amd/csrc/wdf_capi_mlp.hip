@@ -344,6 +344,22 @@ static int mlp_bwd_w_tp_common(const float* x, const float* r, const float* thet
     const unsigned scan_chunks = (unsigned)((T + wdf::kScanChunk - 1) / wdf::kScanChunk);
     float2* smap = (float2*)(((uintptr_t)(wsw + (size_t)nparts * (size_t)count_w) + 7) & ~(uintptr_t)7);   // [scan_chunks][B]
     const dim3 sgrid((unsigned)((B + 63) / 64), scan_chunks);
+    // (C) on the matrix cores (wdf_mlp_mfma.h, 16 sequences per wave) when that fills at least half the chip: two waves
+    // per SIMD for three tanh layers, one for deeper nets (their MFMA chain per step already keeps the pipe busy) --
+    // bench.py --root mlp2x16 / 2x8 / 4x8: step 0.655 -> 0.618, 0.663 -> 0.644, 1.170 -> 1.018 ms.
+    // WDF_MLP_WGRAD_MFMA = a chunk count forces it, 0 switches it off.
+    int wm_chunks = 0;
+    {
+        const int64_t w16 = (B + 15) / 16, kmax = T / 64 > 1 ? T / 64 : 1;
+        int64_t kw = (n_tanh_layers == 3 ? 2048 : 1024) / w16;
+        kw = kw > kmax ? kmax : (kw < 1 ? 1 : kw);
+        if (w16 * kw >= 512) wm_chunks = (int)kw;
+    }
+    if (const char* e = getenv("WDF_MLP_WGRAD_MFMA")) wm_chunks = atoi(e);
+    const MlpTpGeom gm = mlp_tp_geom(T, wm_chunks > 0 ? wm_chunks : 1);
+    const dim3 wmgrid((unsigned)((B + 15) / 16), (unsigned)gm.K);
+    if (wm_chunks > 0 && (int64_t)wmgrid.x * wmgrid.y > (int64_t)nparts) wm_chunks = 0;     // (the partial buffers are sized for the row grid)
+    const int rparts = wm_chunks > 0 ? (int)(wmgrid.x * wmgrid.y) : nparts;
     const bool dyn = r != nullptr;
     hipStream_t s = (hipStream_t)stream;
 #define WDF_ROW_BWD_TP(NL_)                                                                                      \
@@ -365,21 +381,28 @@ static int mlp_bwd_w_tp_common(const float* x, const float* r, const float* thet
         }                                                                                                        \
         {                                                                                                        \
             EventBracket bracket(s);                                                                             \
-            if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_wgrad_tp_kernel<NL_, true>), grid, dim3(64), 0, s, x, r, theta2, \
-                                        w, hidden, fs, zstash, kap, wsw, wsd, B, T, g.L);                         \
-            else hipLaunchKernelGGL((wdf::clipper_mlp_row_wgrad_tp_kernel<NL_, false>), grid, dim3(64), 0, s, x, r, theta2,    \
-                                    w, hidden, fs, zstash, kap, wsw, wsd, B, T, g.L);                             \
+            if (wm_chunks > 0) {                                                                                 \
+                if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_mfma_wgrad_tp_kernel<NL_, true>), wmgrid, dim3(64), 0, s, x, r,  \
+                                            theta2, w, hidden, fs, zstash, kap, wsw, wsd, B, T, gm.L);            \
+                else hipLaunchKernelGGL((wdf::clipper_mlp_mfma_wgrad_tp_kernel<NL_, false>), wmgrid, dim3(64), 0, s, x, r,     \
+                                        theta2, w, hidden, fs, zstash, kap, wsw, wsd, B, T, gm.L);                \
+            } else {                                                                                             \
+                if (dyn) hipLaunchKernelGGL((wdf::clipper_mlp_row_wgrad_tp_kernel<NL_, true>), grid, dim3(64), 0, s, x, r,     \
+                                            theta2, w, hidden, fs, zstash, kap, wsw, wsd, B, T, g.L);             \
+                else hipLaunchKernelGGL((wdf::clipper_mlp_row_wgrad_tp_kernel<NL_, false>), grid, dim3(64), 0, s, x, r,        \
+                                        theta2, w, hidden, fs, zstash, kap, wsw, wsd, B, T, g.L);                 \
+            }                                                                                                    \
         }                                                                                                        \
     }
     WDF_ROW_BWD_TP(3) WDF_ROW_BWD_TP(4) WDF_ROW_BWD_TP(5)
 #undef WDF_ROW_BWD_TP
     rc = check_launch("wdf_clipper_mlp_bwd_w_tp");
     if (rc) return rc;
-    hipLaunchKernelGGL(wdf::clipper_mlp_grad_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)wsd, nparts, theta2, fs,
+    hipLaunchKernelGGL(wdf::clipper_mlp_grad_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)wsd, rparts, theta2, fs,
                        dyn ? 1 : 0, gtheta2);
     const int count = wdf_mlp_weight_count(hidden, n_tanh_layers);
     hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_wide_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64, 16), 0, s,
-                       (const float*)wsw, nparts, count, gw);
+                       (const float*)wsw, rparts, count, gw);
     return check_launch("wdf_clipper_mlp_bwd_w_tp reduce");
 }
 

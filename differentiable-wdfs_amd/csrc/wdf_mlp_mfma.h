@@ -205,4 +205,154 @@ __global__ __launch_bounds__(64) void clipper_mlp_mfma_fwd_tp_kernel(
     }
 }
 
+// ---- (C) of the reverse sweep on the matrix cores ---------------------------------------------------------------
+// The weight-gradient pass with 16 sequences per wave: network forward and layer deltas as above; the kernel
+// gradient dK_l[in n][out i] = sum over steps and sequences of (G delta_l)[i][s] h_{l-1}[n][s] contracts over the
+// SEQUENCE index, which the D layout keeps in the lane -- so both factors are transposed first, by the matrix cores
+// themselves: with register v of X (units {4 g + v}) as the A operand, A[s][g] = X[4 g + v][s], and the constant
+// selector E_v[g][n] = (n == 4 g + v) as B, four accumulated MFMAs give D[s][n] = X[n][s] exactly (products by 1
+// and sums of zeros).  Register r of the transposed pair then is a valid (A, B) for the sequences {r, 4 + r, ...}:
+// four more MFMAs add the outer products of all 16 sequences.  Per step and wave 4 (NL-1) (1 + 1 + 4 + 1) + 3 MFMAs.
+__device__ __forceinline__ mfma_v4f mfma_transpose(const mfma_v4f& X, const float (&E)[4])
+{
+    mfma_v4f t = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) t = mfma4(X[v], E[v], t);
+    return t;
+}
+
+// Same outputs as clipper_mlp_row_wgrad_tp_kernel (wdf_mlp_tp.h): wsw float[parts][count], ws double[parts][4],
+// part = blockIdx.y * gridDim.x + blockIdx.x; grid (ceil(B / 16), chunks of L steps).
+template <int NL, bool DYN_R>
+__global__ __launch_bounds__(64) void clipper_mlp_mfma_wgrad_tp_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta2,
+    const float* __restrict__ w, int H, float fs, const float* __restrict__ zstash, const float* __restrict__ gb2n,
+    float* __restrict__ wsw, double* __restrict__ ws, int64_t B, int64_t T, int64_t L)
+{
+    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+    const int64_t b_raw = (int64_t)blockIdx.x * 16 + n;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    const int64_t t0 = (int64_t)blockIdx.y * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const int64_t part = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const MlpClipConsts c = mlp_load_consts(theta2, fs);
+    const MfmaWeights<NL> Wt = mfma_load_weights<NL>(w, H, lane, true);
+    float E[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) E[v] = (n == 4 * g + v) ? 1.0f : 0.0f;
+    const float* __restrict__ xp = x + b * T;
+    const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
+    float gk0a[4] = {0, 0, 0, 0}, gk0l[4] = {0, 0, 0, 0}, gb0[4] = {0, 0, 0, 0}, gwo[4] = {0, 0, 0, 0}, gbo = 0.0f;
+    float gbias[NL - 1][4];
+    mfma_v4f gK[NL - 1];
+#pragma unroll
+    for (int l = 0; l < NL - 1; ++l) {
+        gK[l] = mfma_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gbias[l][v] = 0.0f;
+    }
+    double dLr = 0.0, dP = 0.0;
+    mfma_v4f act[NL];
+    for (int64_t tb = t0; tb < t1; tb += 16) {
+        const int nst = t1 - tb < 16 ? (int)(t1 - tb) : 16;
+        float xs[16], rs[16], zz[16], gs[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t ti = i < nst ? tb + i : tb;
+            xs[i] = xp[ti];
+            rs[i] = DYN_R ? rp[ti] : 1.0f;
+            zz[i] = zstash[ti * B + b];
+            gs[i] = (live && i < nst) ? gb2n[ti * B + b] : 0.0f;  // shadow sequences / steps past the end add nothing
+        }
+        float sLr = 0.0f, sP = 0.0f;                            // fp32 within a block, fp64 across blocks
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i >= nst) break;
+            float p, Rp, lr;
+            mlp_step_coeffs<DYN_R>(c, rs[i], p, Rp, lr);
+            const float z = zz[i], g_b2n = gs[i], G = -g_b2n;   // b_root = -MLP
+            const float b_diff = z - xs[i];
+            const float a = fmaf(-p, b_diff, z);
+            (void)mfma_mlp_fwd<NL>(Wt, a, lr, act);
+            gbo += G;
+            mfma_v4f d;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                gwo[v] = fmaf(G, act[NL - 1][v], gwo[v]);
+                d[v] = Wt.wo[v] * fmaf(-act[NL - 1][v], act[NL - 1][v], 1.0f);
+            }
+#pragma unroll
+            for (int l = NL - 1; l >= 1; --l) {
+                mfma_v4f gd;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { gd[v] = G * d[v]; gbias[l - 1][v] += gd[v]; }
+                const mfma_v4f gdT = mfma_transpose(gd, E), hT = mfma_transpose(act[l - 1], E);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gK[l - 1] = mfma4(gdT[q], hT[q], gK[l - 1]);
+                mfma_v4f nd = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) nd = mfma4(Wt.at[l - 1][v], d[v], nd);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) d[v] = nd[v] * fmaf(-act[l - 1][v], act[l - 1][v], 1.0f);
+            }
+            float pa = 0.0f, pl = 0.0f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float gd0 = G * d[v];
+                gk0a[v] = fmaf(gd0, a, gk0a[v]);
+                gk0l[v] = fmaf(gd0, lr, gk0l[v]);
+                gb0[v] += gd0;
+                pa = fmaf(Wt.k0a[v], d[v], pa);
+                pl = fmaf(Wt.k0l[v], d[v], pl);
+            }
+            const float da = mfma4(1.0f, pa, mfma_v4f{0.0f, 0.0f, 0.0f, 0.0f})[0];
+            const float dlr = mfma4(1.0f, pl, mfma_v4f{0.0f, 0.0f, 0.0f, 0.0f})[0];
+            const float g_a = G * da, g_lr = G * dlr;
+            const float g_p = -(g_b2n + g_a) * b_diff;
+            if constexpr (DYN_R) {
+                sP = fmaf(Rp, fmaf(g_p, p, g_lr), sP);
+            } else {
+                sP += g_p;
+                sLr += g_lr;
+            }
+        }
+        dLr += (double)sLr;
+        dP += (double)sP;
+    }
+    if (!live || g != 0) { dLr = dP = 0.0; }                    // (the four lane groups carry the same sequences)
+    dLr = wave_sum(dLr); dP = wave_sum(dP);
+    if (threadIdx.x == 0) {
+        double* o = ws + part * 4;
+        o[0] = dLr; o[1] = 0.0; o[2] = dP; o[3] = 0.0;
+    }
+    // per-lane partials are per (unit 4 g + v, sequence n): sum over the 16 sequences of the lane group
+    const int count = 3 * H + (NL - 1) * (H * H + H) + H + 1;
+    float* __restrict__ o = wsw + part * count;
+    const float vbo = row_sum(gbo);
+    if (lane == 0) o[count - 1] = vbo;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int u = 4 * g + v;
+        const float a0 = row_sum(gk0a[v]), a1 = row_sum(gk0l[v]), a2 = row_sum(gb0[v]), a3 = row_sum(gwo[v]);
+        if (n == 0 && u < H) {
+            o[u] = a0; o[H + u] = a1; o[2 * H + u] = a2;
+            o[3 * H + (NL - 1) * (H * H + H) + u] = a3;
+        }
+#pragma unroll
+        for (int l = 1; l < NL; ++l) {
+            const float vb = row_sum(gbias[l - 1][v]);
+            if (n == 0 && u < H) o[3 * H + (l - 1) * (H * H + H) + H * H + u] = vb;
+        }
+    }
+    // gK[l] (D layout: VGPR v of lane 16 g + n = dK_l[in n][out 4 g + v], all 16 sequences summed) -> kernel_l [in][out]
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = 4 * g + v;
+            if (n < H && i < H) o[3 * H + (l - 1) * (H * H + H) + n * H + i] = gK[l - 1][v];
+        }
+    }
+}
+
 }  // namespace wdf
