@@ -1,4 +1,5 @@
-// wdf_mlp_mfma.h -- the time-parallel MLP-root forward with the hidden layers on the matrix cores, gfx950.
+// wdf_mlp_mfma.h -- the MLP-root forward (time-parallel chunks or one sequential chunk) and the weight-gradient pass of
+// the reverse sweep with the hidden layers on the matrix cores, gfx950.
 //
 // The row kernels (wdf_mlp_row.h) give a sequence 16 lanes and do a 16 x 16 layer as 16 DPP-FMAs per lane:
 // ~45 VALU instructions per layer for the 4 sequences of a wave.  Here a wave carries 16 sequences and a
