@@ -344,14 +344,13 @@ static int mlp_bwd_w_tp_common(const float* x, const float* r, const float* thet
     const unsigned scan_chunks = (unsigned)((T + wdf::kScanChunk - 1) / wdf::kScanChunk);
     float2* smap = (float2*)(((uintptr_t)(wsw + (size_t)nparts * (size_t)count_w) + 7) & ~(uintptr_t)7);   // [scan_chunks][B]
     const dim3 sgrid((unsigned)((B + 63) / 64), scan_chunks);
-    // (C) on the matrix cores (wdf_mlp_mfma.h, 16 sequences per wave) when that fills at least half the chip: two waves
-    // per SIMD for three tanh layers, one for deeper nets (their MFMA chain per step already keeps the pipe busy) --
-    // bench.py --root mlp2x16 / 2x8 / 4x8: step 0.655 -> 0.618, 0.663 -> 0.644, 1.170 -> 1.018 ms.
+    // (C) on the matrix cores (wdf_mlp_mfma.h, 16 sequences per wave) when that fills at least half the chip, two waves
+    // per SIMD -- bench.py --root mlp2x16 / 2x8 / 4x8: step 0.655 -> 0.578, 0.663 -> 0.596, 1.170 -> 0.978 ms.
     // WDF_MLP_WGRAD_MFMA = a chunk count forces it, 0 switches it off.
     int wm_chunks = 0;
     {
         const int64_t w16 = (B + 15) / 16, kmax = T / 64 > 1 ? T / 64 : 1;
-        int64_t kw = (n_tanh_layers == 3 ? 2048 : 1024) / w16;
+        int64_t kw = 2048 / w16;
         kw = kw > kmax ? kmax : (kw < 1 ? 1 : kw);
         if (w16 * kw >= 512) wm_chunks = (int)kw;
     }

@@ -209,11 +209,13 @@ __global__ __launch_bounds__(64) void clipper_mlp_mfma_fwd_tp_kernel(
 // ---- (C) of the reverse sweep on the matrix cores ---------------------------------------------------------------
 // The weight-gradient pass with 16 sequences per wave: network forward and layer deltas as above; the kernel
 // gradient dK_l[in n][out i] = sum over steps and sequences of (G delta_l)[i][s] h_{l-1}[n][s] contracts over the
-// SEQUENCE index, which the D layout keeps in the lane -- so both factors are transposed first, by the matrix cores
+// SEQUENCE index, which the D layout keeps in the lane -- so both factors are transposed first; register r of the
+// transposed pair then is a valid (A, B) for the sequences {r, 4 + r, 8 + r, 12 + r}, and four MFMAs add the outer
+// products of all 16 sequences.  The transposes go through LDS (a 16 x 17 tile each, 4 writes + 4 reads per lane;
+// the block is one wave).  -DWDF_MLP_WGRAD_MFMA_TRANSPOSE keeps the first version, the matrix cores transposing by
 // themselves: with register v of X (units {4 g + v}) as the A operand, A[s][g] = X[4 g + v][s], and the constant
-// selector E_v[g][n] = (n == 4 g + v) as B, four accumulated MFMAs give D[s][n] = X[n][s] exactly (products by 1
-// and sums of zeros).  Register r of the transposed pair then is a valid (A, B) for the sequences {r, 4 + r, ...}:
-// four more MFMAs add the outer products of all 16 sequences.  Per step and wave 4 (NL-1) (1 + 1 + 4 + 1) + 3 MFMAs.
+// selector E_v[g][n] = (n == 4 g + v) as B, four accumulated MFMAs give D[s][n] = X[n][s] exactly -- neat, but 16 of
+// that version's 43 MFMAs per step sat in the one pipe the kernel is bound by (training step 0.596 vs 0.554 ms).
 __device__ __forceinline__ mfma_v4f mfma_transpose(const mfma_v4f& X, const float (&E)[4])
 {
     mfma_v4f t = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -241,6 +243,9 @@ __global__ __launch_bounds__(64) void clipper_mlp_mfma_wgrad_tp_kernel(
     float E[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) E[v] = (n == 4 * g + v) ? 1.0f : 0.0f;
+#ifndef WDF_MLP_WGRAD_MFMA_TRANSPOSE
+    __shared__ float tbuf[2][16 * 17];
+#endif
     const float* __restrict__ xp = x + b * T;
     const float* __restrict__ rp = DYN_R ? r + b * T : nullptr;
     float gk0a[4] = {0, 0, 0, 0}, gk0l[4] = {0, 0, 0, 0}, gb0[4] = {0, 0, 0, 0}, gwo[4] = {0, 0, 0, 0}, gbo = 0.0f;
@@ -287,7 +292,24 @@ __global__ __launch_bounds__(64) void clipper_mlp_mfma_wgrad_tp_kernel(
                 mfma_v4f gd;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) { gd[v] = G * d[v]; gbias[l - 1][v] += gd[v]; }
+#ifndef WDF_MLP_WGRAD_MFMA_TRANSPOSE
+                // the two transposes through LDS (one 16 x 17 tile each; the block is one wave)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    tbuf[0][(4 * g + v) * 17 + n] = gd[v];
+                    tbuf[1][(4 * g + v) * 17 + n] = act[l - 1][v];
+                }
+                __syncthreads();
+                mfma_v4f gdT, hT;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    gdT[q] = tbuf[0][n * 17 + 4 * g + q];
+                    hT[q] = tbuf[1][n * 17 + 4 * g + q];
+                }
+                __syncthreads();
+#else
                 const mfma_v4f gdT = mfma_transpose(gd, E), hT = mfma_transpose(act[l - 1], E);
+#endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q) gK[l - 1] = mfma4(gdT[q], hT[q], gK[l - 1]);
                 mfma_v4f nd = {0.0f, 0.0f, 0.0f, 0.0f};
