@@ -101,7 +101,8 @@ class _ClipperMlpFn(torch.autograd.Function):
                     warm["rows"], warm["prev"] = warm["zs"].index_select(0, warm["idx"]), None
             zinit = None
             if hot:
-                zinit = warm["rows"] if warm["prev"] is None else 2.0 * warm["rows"] - warm["prev"]    # secant in call count
+                # secant in call count: 2 rows - prev (one launch)
+                zinit = warm["rows"] if warm["prev"] is None else torch.lerp(warm["prev"], warm["rows"], 2.0)
             w_used = warm["warmup"] if hot else ad["warmup"]
             out = binding.clipper_mlp_fwd_tp(x, th, wd, hidden, n_tanh, fs, tp.k_fwd, w_used, r=r,
                                              warmup_per_wave=tp.warmup_per_wave, tol=tp.tol,
