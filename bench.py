@@ -132,6 +132,68 @@ def parity_check(stepper, theta, xk, x_host, target, fs, n_global, fused):
                        f"({time.perf_counter() - t0:.1f} s of CPU)"}
 
 
+def mlp_components(hidden, n_tanh, stride):
+    """Indices into the flat weight vector: every bias, the whole first and last layer, every `stride`-th entry of the
+    hidden kernels (the oracle differentiates by complex step: one pass over the picked sequences per component)."""
+    idx, o, n_in = [], 0, 2
+    for layer in range(n_tanh):
+        nk = n_in * hidden
+        idx += list(range(o, o + nk, 1 if layer == 0 else stride))
+        idx += list(range(o + nk, o + nk + hidden))
+        o += nk + hidden
+        n_in = hidden
+    return np.array(idx + list(range(o, o + hidden + 1)))
+
+
+def mlp_parity_check(run_step, w, theta2, x, r, x_host, r_host, target, fs, hidden, n_tanh, skip, n_global, eps):
+    """After the timed region, at the weights training has reached: one more forward + loss + reverse sweep of the BENCH
+    PATH ITSELF (same plan, same warm start, same kernels; no update), checked three ways --
+      y of EVERY sequence and the loss against the fp64 oracle (generic tree interpreter, MLP root: clipper_pot.py:94-127);
+      the gradient of the loss restricted to 8 picked sequences (dLoss/dy of the real loss, zeroed elsewhere) against the
+        oracle's complex-step derivative, per component;
+      the whole-batch gradient against the sequential row sweep (another kernel family: no chunks, no matrix cores)."""
+    O = _oracle()
+    B, T = x.shape
+    t0 = time.perf_counter()
+    y, gy, loss3 = run_step()                                   # y keeps its autograd graph
+    (gw,) = torch.autograd.grad(y, [w], grad_outputs=gy, retain_graph=True)
+    pick = np.unique(np.linspace(0, B - 1, 8).astype(np.int64))
+    mask = torch.zeros((1, B), dtype=torch.float32, device=x.device)
+    mask[0, torch.as_tensor(pick, device=x.device)] = 1.0
+    (gw_pick,) = torch.autograd.grad(y, [w], grad_outputs=gy * mask)
+    wd = w.detach()
+    y_seq, zs_seq, _ = binding.clipper_mlp_fwd(x, theta2, wd, hidden, n_tanh, fs, r=r)
+    _, gw_seq = binding.clipper_mlp_bwd_w(x, theta2, wd, hidden, n_tanh, fs, zs_seq, gy, r=r)
+    torch.cuda.synchronize()
+    sizes, acts = [2] + [hidden] * n_tanh + [1], [O.ACT_TANH] * n_tanh + [O.ACT_NONE]
+    oc = O.clipper_mlp_circuit(fs, sizes, acts)
+    theta = np.concatenate([theta2.cpu().numpy().astype(np.float64), wd.cpu().numpy().astype(np.float64)])
+    y_ref = O.tree_fwd(oc, theta, np.stack([x_host.astype(np.float64), r_host.astype(np.float64)], axis=-1))
+    o, t = y_ref[skip:], target.cpu().numpy().astype(np.float64)[skip:]
+    S, E = float(np.sum((o - t) ** 2)), float(np.sum(o ** 2)) + eps
+    loss_ref = S / n_global + float(np.sqrt(S / E / n_global))
+    comp = mlp_components(hidden, n_tanh, 8)
+    gy_host = gy.cpu().numpy().astype(np.float64)[:, pick]
+    xin = np.stack([x_host[pick].astype(np.float64), r_host[pick].astype(np.float64)], axis=-1)
+    g_ref = O.tree_grad(oc, theta, xin, gy_host, params=list(2 + comp))
+    got = gw_pick.cpu().numpy().astype(np.float64)[comp]
+    yh = y.detach().cpu().numpy()
+    return {"max_abs_y": float(np.max(np.abs(yh - y_ref))),
+            "rel_loss": abs(float(loss3[2]) - loss_ref) / loss_ref,
+            "max_grad_err_vs_oracle": float(np.max(np.abs(got - g_ref) / (np.abs(g_ref) + 0.1 * np.max(np.abs(g_ref))))),
+            "max_grad_err_vs_sequential_sweep": float((gw - gw_seq).abs().max() / gw_seq.abs().max()),
+            "max_abs_y_vs_sequential_kernel": float((y.detach() - y_seq).abs().max()),
+            "checked": f"y of all {B} x {T} samples and the MSE+ESR loss vs the fp64 oracle (tree interpreter, MLP root); "
+                       f"d loss/d w restricted to sequences {pick.tolist()} vs the oracle's complex-step derivative on "
+                       f"{len(comp)} of {w.numel()} components (all biases, first and last layer, every 8th hidden-kernel "
+                       f"entry; error relative to |component| + 0.1 max|component|); the whole-batch gradient, all components, "
+                       f"vs the sequential row sweep (error relative to the largest component) "
+                       f"({time.perf_counter() - t0:.1f} s)"}
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at 64 FLOP/clk/SIMD (= the fp32 vector rate)
+
+
 def copy_bandwidth_gbs(dev, nbytes=1 << 29, reps=10):
     """Achievable HBM bandwidth on this box: a device-to-device copy of `nbytes` (read + write
     counted), HIP events on the launch stream.  SURVEY 8d's second roofline denominator."""
@@ -258,12 +320,23 @@ def run_mlp_root(args, world, rank, local):
     gcoef, loss3 = torch.zeros(2, dtype=torch.float32, device=dev), torch.zeros(3, dtype=torch.float32, device=dev)
     loss_ws = torch.empty((binding.lib().wdf_loss_sums_ws_bytes(),), dtype=torch.uint8, device=dev)
     gy_buf = torch.empty((T, B), dtype=torch.float32, device=dev)
-    ev = [binding.Event() for _ in range(4)]
-    t_f, t_b = [], []
+    ev = [binding.Event() for _ in range(8)]
+    t_f, t_b, t_fk, t_wk = [], [], [], []
+
+    def forward_and_loss():
+        """forward -> (y with its autograd graph, dLoss/dy, the three loss values); the loss on the device
+        (include/wdf_hip.h: wdf_loss_sums / wdf_esr_coef / wdf_loss_esr_grad)"""
+        y, _ = mlp_root.clipper_mlp(theta2, w, x, r, None, fs, hidden, n_tanh, workload.C_CLIPPER, time_parallel=plan)
+        yd = y.detach()
+        binding.loss_sums(yd, target, skip, sums=sums, ws=loss_ws)
+        wdist.allreduce_sum_(sums)
+        binding.esr_coef(sums, n_global, eps, gcoef=gcoef, loss=loss3)
+        return y, binding.loss_esr_grad(yd, target, gcoef, skip, gy=gy_buf), loss3
 
     def step(timed=False):
-        if timed:                 # events around the whole forward / reverse call (kernels + their helpers)
-            ev[0].record()
+        if timed:                 # events around the whole forward / reverse call (kernels + their helpers), and
+            ev[0].record()        # brackets around the forward kernel and the weight-gradient kernel alone
+            binding.Event.bracket_next(ev[4], ev[5])
         y, _ = mlp_root.clipper_mlp(theta2, w, x, r, None, fs, hidden, n_tanh, workload.C_CLIPPER, time_parallel=plan)
         if timed:
             ev[1].record()
@@ -276,6 +349,7 @@ def run_mlp_root(args, world, rank, local):
         gy = binding.loss_esr_grad(yd, target, gcoef, skip, gy=gy_buf)
         if timed:
             ev[2].record()
+            binding.Event.bracket_next(ev[6], ev[7])
         (gw,) = torch.autograd.grad(y, [w], grad_outputs=gy)
         if timed:
             ev[3].record()
@@ -284,6 +358,7 @@ def run_mlp_root(args, world, rank, local):
             adam.apply(w, gw)
         if timed:
             t_f.append(ev[0].elapsed_ms(ev[1])); t_b.append(ev[2].elapsed_ms(ev[3]))
+            t_fk.append(ev[4].elapsed_ms(ev[5])); t_wk.append(ev[6].elapsed_ms(ev[7]))
         return loss3[2]
 
     for _ in range(args.warmup):
@@ -301,10 +376,27 @@ def run_mlp_root(args, world, rank, local):
     for _ in range(min(args.steps, 10)):
         step(True)
     torch.cuda.synchronize()
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity:
+        x_host = workload.sweep_batch(Bg, T, b0=b0, b1=b1, seed=4) * 0.6
+        r_host = workload.dataset_resistance_batch(Bg, T, b0=b0, b1=b1)
+        parity = mlp_parity_check(forward_and_loss, w, theta2, x, r, x_host, r_host, target, fs, hidden, n_tanh, skip, n_global, eps)
     if rank == 0:
         st = None if mlp_root.LAST_TP_STATUS["status"] is None else binding.mlp_tp_status(mlp_root.LAST_TP_STATUS["status"])
         f_ms, b_ms = float(np.mean(t_f)), float(np.mean(t_b))
-        achieved = 16 * B * T / (f_ms * 1e-3) / 1e9            # forward: x, r in; y, stash out = 16 B/sample
+        fk_ms, wk_ms = float(np.mean(t_fk)), float(np.mean(t_wk))
+        # The dominant kernels: the forward (a latency chain: steps x (MFMA chain + tanh), one wave per SIMD) and the
+        # weight-gradient pass of the reverse sweep.  On the matrix cores (16-sequence waves, csrc/wdf_mlp_mfma.h) the
+        # latter issues, per wave and step, (NL - 1) x 4 + 1 forward MFMAs, the same again transposed for the deltas and
+        # 4 outer-product MFMAs per layer: 27 v_mfma_f32_16x16x4_f32 (2048 flop each) for three tanh layers.
+        # (the library's own dispatch rule, csrc/wdf_capi_mlp.hip: 16-sequence waves must fill half the chip)
+        w16 = (B + 15) // 16
+        wg_env = os.environ.get("WDF_MLP_WGRAD_MFMA")
+        wg_mfma = plan is not None and plan.k_bwd > 1 and \
+            (int(wg_env) > 0 if wg_env else w16 * min(max(2048 // w16, 1), max(1, T // 64)) >= 512)
+        n_mfma = 12 * (n_tanh - 1) + 3     # forward 4 (NL-1) + 1, deltas + outer products 8 (NL-1), d/da and d/dlr sums 2
+        flops = (B + 15) // 16 * T * n_mfma * 2048
+        achieved_tf = flops / (wk_ms * 1e-3) / 1e12
         out = {"metric": f"samples/sec fwd+bwd, MLP-root ({args.root[3:]}) pot clipper, clipper_pot.py training-set shape",
                "value": Bg * T / (dt / args.steps), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -320,10 +412,19 @@ def run_mlp_root(args, world, rank, local):
                                                                       "verify_tol": plan.tol, "bwd_chunks": plan.k_bwd,
                                                                       "verify_status": st}},
                "call_ms": {"forward": spread(t_f), "reverse": spread(t_b)},
-               "roofline": {"bound": "hbm", "kernel": "time-parallel MLP-root forward (matrix-core kernel for 2x16, row kernel otherwise: csrc/wdf_capi_mlp.hip) + verify", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                            "note": "not a bandwidth-bound kernel: ~100 (forward) / ~250 (reverse) VALU instructions per step "
-                                    "and 4-sequence wave at ~2 ns per issued instruction and SIMD is the limit (DESIGN.md)"}}
+               "kernel_ms": {"forward_chunks": spread(t_fk), "weight_gradient": spread(t_wk)},
+               "parity": parity,
+               "roofline": ({"bound": "mfma", "kernel": "clipper_mlp_mfma_wgrad_tp_kernel", "achieved": achieved_tf,
+                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_F32_PEAK_TFLOPS,
+                             "traffic": None,
+                             "mfma_per_wave_step": n_mfma,
+                             "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32, 2048 flop, 32 cycles per SIMD): issued MFMA flops "
+                                     "of the weight-gradient pass / its kernel time / the fp32 matrix peak.  The forward "
+                                     "kernel is a latency chain (dependent MFMAs + tanh per step, one wave per SIMD), "
+                                     "not a throughput-bound kernel: see kernel_ms"} if wg_mfma else
+                            {"bound": "valu", "kernel": "clipper_mlp_row_wgrad_tp_kernel", "achieved": None, "peak": None,
+                             "unit": "instr/s", "frac": None, "traffic": None,
+                             "note": "row kernels: VALU-issue bound (~250 instructions per step and 4-sequence wave)"})}
         print(json.dumps(out), flush=True)
     if world > 1:
         wdist.barrier()

@@ -274,8 +274,10 @@ def _esr_reference(wb, xd, thd, tgt, skip, r=None, n_up=1, n_down=1):
 
 @pytest.mark.parametrize("B,T,K,W,with_r", [(64, 1024, 2, 256, False), (70, 1000, 3, 248, False), (130, 2048, 8, 256, False),
                                             (71, 1024, 2, 256, True), (96, 2048, 4, 512, True)])
-def test_fused_esr_step_matches_autograd(wb, B, T, K, W, with_r):
-    """The scripts' training loss in one pass: both tangent-weighted sums carried, coefficients applied by the last tile."""
+def test_fused_esr_step_matches_autograd(wb, oracle, B, T, K, W, with_r):
+    """The scripts' training loss in one pass: both tangent-weighted sums carried, coefficients applied by the last tile.
+    Held against torch autograd through the kernel pair AND, directly, against the fp64 oracle (y, the three loss values
+    and every gradient component: clipper_pot.py:146-156,177 evaluated on the oracle's own y)."""
     skip = 50
     x, th, ths = problem(B, T, seed=B + T + 1)
     xd, thd = dev(x), dev(th)
@@ -296,6 +298,22 @@ def test_fused_esr_step_matches_autograd(wb, B, T, K, W, with_r):
     assert abs(l[0] - mse) <= 2e-5 * mse and abs(l[1] - esr) <= 2e-5 * esr and abs(l[2] - (mse + esr)) <= 2e-5 * (mse + esr)
     s10 = sums10.cpu().numpy()
     assert abs(s10[0] - S) <= 2e-5 * S and abs(s10[1] - E) <= 2e-5 * E
+    # ... and the oracle itself, nothing of ours in between: fp64 forward, the loss of the scripts on ITS y, dLoss/dy =
+    # ga (y - t) + gb y past skip, the oracle's reverse sweep
+    th64 = th.astype(np.float32).astype(np.float64)
+    r64 = None if r is None else r.cpu().numpy().astype(np.float64)
+    t64 = tgt.cpu().numpy().astype(np.float64)
+    y64 = oracle.clipper_fwd(th64, FS, x.astype(np.float64), r=r64)
+    o64, tt64 = y64[skip:], t64[skip:]
+    S64, E64 = float(np.sum((o64 - tt64) ** 2)), float(np.sum(o64 ** 2)) + eps
+    mse64, esr64 = S64 / n, float(np.sqrt(S64 / E64 / n))
+    gy64 = np.zeros_like(y64)
+    gy64[skip:] = (2.0 / n + 1.0 / (esr64 * E64 * n)) * (o64 - tt64) - (esr64 / E64) * o64
+    _, g64 = oracle.clipper_fwd_bwd(th64, FS, x.astype(np.float64), gy64, r=r64)
+    assert float(np.max(np.abs(y.cpu().numpy() - y64))) <= Y_TOL
+    ok, info = close_grad(g[idx], torch.as_tensor(g64[idx]))
+    assert ok, info
+    assert abs(l[0] - mse64) <= 2e-5 * mse64 and abs(l[1] - esr64) <= 2e-5 * esr64
     # the two-stage form (what several ranks run: sums out, all-reduce, finish) gives the same numbers
     _, _, sums_b, g_none, l_none, _ = wb.clipper_step_esr_tp(xd, thd, FS, tgt, n, eps, skip, K, W, r=r, finish=False)
     assert g_none is None and l_none is None and torch.equal(sums_b, sums10)

@@ -234,6 +234,18 @@ def forward_kernel(request, monkeypatch):
     return request.param
 
 
+@pytest.fixture(params=["by-grid-size", "matrix-cores"])
+def wgrad_kernel(request, monkeypatch):
+    """The weight-gradient pass (C) of the step-parallel reverse sweep: chosen by grid size (the row kernel at the small
+    batches of these tests) and forced onto the matrix-core kernel clipper_mlp_mfma_wgrad_tp_kernel (csrc/wdf_mlp_mfma.h;
+    WDF_MLP_WGRAD_MFMA = its chunk count), which by itself only runs once 16-sequence waves fill half the chip."""
+    if request.param == "matrix-cores":
+        monkeypatch.setenv("WDF_MLP_WGRAD_MFMA", "4")
+    else:
+        monkeypatch.delenv("WDF_MLP_WGRAD_MFMA", raising=False)
+    return request.param
+
+
 def test_mlp_forward_on_matrix_cores_equals_the_row_kernel_at_a_large_batch(monkeypatch):
     """B = 12300 >= 12288: wdf_clipper_mlp_fwd runs the matrix-core kernel by itself; y, stash and final state
     equal the row kernel's (forced by WDF_MLP_FWD_ROW = 1) to 1e-5: the two sum a layer in different orders, and
@@ -262,7 +274,7 @@ def test_mlp_forward_on_matrix_cores_equals_the_row_kernel_at_a_large_batch(monk
 # ---- in-kernel time-parallel MLP-root kernels (csrc/wdf_mlp_tp.h) ----------------------------------------
 @pytest.mark.parametrize("hidden,n_tanh", [(8, 3), (16, 3), (4, 5), (8, 5)])
 @pytest.mark.parametrize("B,T,K,dyn", [(5, 100, 3, True), (7, 257, 2, False), (130, 515, 4, True), (96, 2048, 8, True)])
-def test_mlp_time_parallel_kernels_equal_sequential(hidden, n_tanh, B, T, K, dyn):
+def test_mlp_time_parallel_kernels_equal_sequential(hidden, n_tanh, B, T, K, dyn, wgrad_kernel, monkeypatch):
     """Forward: chunks warmed up per wave (pot-dependent), verified on the device -> the sequential kernel's y,
     stash and final state to 2e-6 with a clean status.  Reverse sweep (kappa / adjoint scan / weight gradient,
     parallel over all steps): EXACT -- {R, C} and weight gradients equal the sequential sweep's to summation
@@ -289,6 +301,11 @@ def test_mlp_time_parallel_kernels_equal_sequential(hidden, n_tanh, B, T, K, dyn
     gth2, gw2 = wb.clipper_mlp_bwd_w_tp(x, th2, w, hidden, n_tanh, FS, zs, gy, 2 * K, r=r)
     for a, b in ((gth2, gth), (gw2, gw)):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, (a, b)
+    if wgrad_kernel == "matrix-cores":                       # (another kernel did run: the row pass sums in another order)
+        monkeypatch.setenv("WDF_MLP_WGRAD_MFMA", "0")
+        _, gw_row = wb.clipper_mlp_bwd_w_tp(x, th2, w, hidden, n_tanh, FS, zs, gy, 2 * K, r=r)
+        assert not torch.equal(gw_row, gw2)
+        assert float((gw_row - gw2).abs().max()) <= 2e-5 * float(gw_row.abs().max()) + 1e-12
 
 
 def test_mlp_time_parallel_forward_repairs_a_short_warmup(forward_kernel):
@@ -314,7 +331,7 @@ def test_mlp_time_parallel_forward_repairs_a_short_warmup(forward_kernel):
 @pytest.mark.parametrize("hidden,n_tanh", [(8, 3), (16, 3), (8, 5)])
 @pytest.mark.parametrize("B,T,K,dyn,warm", [(5, 100, 3, True, 448), (7, 257, 2, False, 448), (130, 515, 4, True, 448),
                                             (96, 2048, 8, True, 448), (40, 1024, 4, True, 32)])
-def test_mlp_forward_stored_kappa_equals_the_recomputed_one(hidden, n_tanh, B, T, K, dyn, warm):
+def test_mlp_forward_stored_kappa_equals_the_recomputed_one(hidden, n_tanh, B, T, K, dyn, warm, wgrad_kernel):
     """wdf_clipper_mlp_fwd_tp_kappa / wdf_clipper_mlp_bwd_w_tp_kappa: the same y, stash and verdict as the plain
     pair (2e-6: the compiler contracts the two instantiations differently), and gradients equal to the recomputing sweep's to 2e-5 of the
     largest entry (kappa from the forward's registers vs from the stored stash: the same formula, a few ulps).
@@ -373,7 +390,7 @@ def test_device_loss_kernels_equal_autograd_of_the_loss():
     assert float((gy.double() - g_ref).abs().max()) <= 1e-6 * float(g_ref.abs().max())
 
 
-def test_mlp_warm_started_chunks_follow_a_training_loop():
+def test_mlp_warm_started_chunks_follow_a_training_loop(wgrad_kernel):
     """A training loop on one batch: from the second call on every chunk starts from the previous call's state at
     its first sample (secant-extrapolated from the third), with a fraction of the cold warm-up; the weights move by
     3e-5 per step (sign steps on every weight).  Every call's y stays within 1e-5 of the sequential
@@ -407,7 +424,7 @@ def test_mlp_warm_started_chunks_follow_a_training_loop():
     mlp_root._WARM_START.clear()
 
 
-def test_mlp_clipper_auto_plan_trains_like_the_sequential_path(golden):
+def test_mlp_clipper_auto_plan_trains_like_the_sequential_path(golden, wgrad_kernel):
     """Circuit(..., time_parallel="auto") on a dataset-shaped batch: the planner picks the in-kernel
     time-parallel kernels; y and every gradient equal the sequential path's."""
     import tf_wdf as wdf
@@ -441,3 +458,94 @@ def test_mlp_clipper_auto_plan_trains_like_the_sequential_path(golden):
     assert float((y_tp - y_seq).abs().max()) <= 4e-6
     for a, b in zip(g_tp, g_seq):
         assert np.max(np.abs(a - b)) <= 2e-5 * np.max(np.abs(b)) + 1e-12
+
+
+# ---- the reference's own training shape: the kernels the default dispatch picks there -----------------------------
+def _oracle_mlp_problem(oracle, net, pick, x, r, C):
+    from wdf_hip import workload
+    wh, hidden, n_tanh = workload.reference_mlp_weights(net)
+    sizes, acts = [2] + [hidden] * n_tanh + [1], [oracle.ACT_TANH] * n_tanh + [oracle.ACT_NONE]
+    oc = oracle.clipper_mlp_circuit(FS, sizes, acts)
+    theta = np.concatenate([[45.0e3, float(np.float32(C))], wh.astype(np.float32).astype(np.float64)])
+    xin = np.stack([x[pick].astype(np.float64), r[pick].astype(np.float64)], axis=-1)
+    return oc, theta, xin
+
+
+def mlp_components(hidden, n_tanh, stride=4):
+    """Indices into the flat weight vector: every bias, the whole first and last layer, every `stride`-th entry of the
+    hidden kernels (the oracle differentiates by complex step, one pass per component)."""
+    idx, o, n_in = [], 0, 2
+    for layer in range(n_tanh):
+        nk = n_in * hidden
+        idx += list(range(o, o + nk, 1 if layer == 0 else stride))
+        idx += list(range(o + nk, o + nk + hidden))
+        o += nk + hidden
+        n_in = hidden
+    idx += list(range(o, o + hidden + 1))
+    return np.array(idx)
+
+
+@pytest.mark.parametrize("net", ["2x16_pre", "2x8"])
+def test_training_step_at_the_reference_shape_against_the_oracle(oracle, forward_kernel, monkeypatch, net):
+    """clipper_pot.py's training set: 1340 sequences x 2048 samples, the pot value per sample (clipper_pot.py:58,94-127,
+    245-269).  At THIS shape the default dispatch leaves the row kernels: for the 2x16 net the forward's 12 chunks run on
+    the matrix cores (clipper_mlp_mfma_fwd_tp_kernel) and, for every net, the weight-gradient pass of the reverse sweep
+    does (clipper_mlp_mfma_wgrad_tp_kernel: 84 x 22 waves of 16 sequences).  Checked: (1) those kernels did run (their
+    results are not bit-equal to the row kernels'); (2) y, dL/dC and dL/dw of 8 picked sequences (two per pot value)
+    against the fp64 oracle -- ORC_ROOT_MLP, complex-step derivative per component; (3) the whole-batch gradient against
+    the sequential row sweep (another kernel family, no chunks, no stored kappa)."""
+    if forward_kernel != "by-batch-size":
+        pytest.skip("this test pins what the DEFAULT dispatch runs")
+    from wdf_hip import binding as wb, mlp_root, workload
+    monkeypatch.delenv("WDF_MLP_WGRAD_MFMA", raising=False)
+    B, T, C = 1340, 2048, workload.C_CLIPPER
+    x = workload.sweep_batch(B, T, seed=4) * 0.6
+    r = workload.dataset_resistance_batch(B, T)
+    xd, rd = cuda(x), cuda(r)
+    wh, hidden, n_tanh = workload.reference_mlp_weights(net)
+    th2 = cuda([45.0e3, C]).requires_grad_(True)
+    w = cuda(wh).requires_grad_(True)
+    plan = mlp_root.plan_mlp_time_parallel(B, T, rd, None, C, FS, hidden=hidden, n_tanh=n_tanh)
+    assert plan is not None and plan.k_bwd == 6 and plan.k_fwd == (12 if hidden == 16 else 6), plan
+    pick = np.array([3, 200, 401, 640, 700, 1000, 1100, 1339])
+    rng = np.random.default_rng(12)
+    gy_pick = np.zeros((T, B), dtype=np.float32)
+    gy_pick[:, pick] = rng.standard_normal((T, len(pick))) / (len(pick) * T)
+    gy_all = cuda(rng.standard_normal((T, B)) / (B * T))
+    mlp_root._WARM_START.clear()
+    y, _ = mlp_root.clipper_mlp(th2, w, xd, rd, None, FS, hidden, n_tanh, C, time_parallel=plan)
+    s = wb.mlp_tp_status(mlp_root.LAST_TP_STATUS["status"])
+    assert s["n_bad"] == 0 or s["sequential_waves"] <= s["gated_waves"], s
+    gth_p, gw_p = torch.autograd.grad(y, [th2, w], grad_outputs=cuda(gy_pick), retain_graph=True)
+    gth_a, gw_a = torch.autograd.grad(y, [th2, w], grad_outputs=gy_all)
+    mlp_root._WARM_START.clear()
+    # (1) which kernels: the sequential row forward / the row weight-gradient pass give other bits
+    y_seq, zs_seq, _ = wb.clipper_mlp_fwd(xd, th2.detach(), w.detach(), hidden, n_tanh, FS, r=rd)
+    e_seq = float((y.detach() - y_seq).abs().max())
+    if hidden == 16:
+        assert not torch.equal(y.detach(), y_seq)
+    monkeypatch.setenv("WDF_MLP_WGRAD_MFMA", "0")
+    gth_r, gw_r = wb.clipper_mlp_bwd_w_tp(xd, th2.detach(), w.detach(), hidden, n_tanh, FS, zs_seq, gy_all, plan.k_bwd, r=rd)
+    monkeypatch.delenv("WDF_MLP_WGRAD_MFMA")
+    gth_m, gw_m = wb.clipper_mlp_bwd_w_tp(xd, th2.detach(), w.detach(), hidden, n_tanh, FS, zs_seq, gy_all, plan.k_bwd, r=rd)
+    assert not torch.equal(gw_m, gw_r)
+    e_mr = float((gw_m - gw_r).abs().max() / gw_r.abs().max())
+    # (3) the whole batch against the sequential sweep
+    gth_s, gw_s = wb.clipper_mlp_bwd_w(xd, th2.detach(), w.detach(), hidden, n_tanh, FS, zs_seq, gy_all, r=rd)
+    e_ws = float((gw_a - gw_s).abs().max() / gw_s.abs().max())
+    e_cs = abs(float(gth_a[1] - gth_s[1])) / abs(float(gth_s[1]))
+    # (2) the oracle on the picked sequences
+    oc, theta, xin = _oracle_mlp_problem(oracle, net, pick, x, r, C)
+    y_ref = oracle.tree_fwd(oc, theta, xin)
+    e_y = float(np.max(np.abs(y.detach()[:, pick].cpu().numpy() - y_ref)))
+    comp = mlp_components(hidden, n_tanh)
+    g_ref = oracle.tree_grad(oc, theta, xin, gy_pick[:, pick].astype(np.float64), params=[1] + list(2 + comp))
+    got = np.concatenate([[float(gth_p[1])], gw_p.cpu().numpy()[comp].astype(np.float64)])
+    e_g = float(np.max(np.abs(got - g_ref) / (np.abs(g_ref) + 1e-1 * np.max(np.abs(g_ref[1:])))))
+    print(f"{net}: |y - seq| {e_seq:.2e}  |y - oracle| {e_y:.2e}  grad vs oracle {e_g:.2e} ({len(comp) + 1} components)  "
+          f"matrix-core vs row wgrad {e_mr:.2e}  whole batch vs sequential sweep: w {e_ws:.2e}, C {e_cs:.2e}")
+    assert e_seq <= 1e-5 and e_y <= 1e-5                       # each fp32 path sits 3-5e-6 from fp64 with the trained roots
+    assert e_mr <= 2e-5 and e_ws <= 5e-5 and e_cs <= 1e-4
+    # per component: relative to its own size, plus 1e-5 of the largest weight-gradient component (as the g3 test)
+    assert np.all(np.abs(got[1:] - g_ref[1:]) <= 1e-4 * np.abs(g_ref[1:]) + 1e-5 * np.max(np.abs(g_ref[1:]))), e_g
+    assert abs(got[0] - g_ref[0]) <= 3e-3 * abs(g_ref[0]), (got[0], g_ref[0])   # dL/dC: as test_static_resistance_and_capacitor_gradient
