@@ -10,7 +10,7 @@ using namespace wdfcapi;
 
 namespace wdfcapi {
 thread_local char g_err[512] = "";
-thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+std::atomic<hipEvent_t> g_ev0{nullptr}, g_ev1{nullptr};
 }
 
 extern "C" {
@@ -120,8 +120,8 @@ int wdf_event_elapsed_ms(void* start, void* stop, float* ms)
 
 void wdf_event_bracket_next(void* start, void* stop)
 {
-    g_ev0 = (hipEvent_t)start;
-    g_ev1 = (hipEvent_t)stop;
+    g_ev0.store((hipEvent_t)start);
+    g_ev1.store((hipEvent_t)stop);
 }
 
 void wdf_event_destroy(void* ev)

@@ -1,6 +1,7 @@
 // wdf_capi_common.h -- shared by the translation units of libwdf_hip.so: error string, launch
 // check, the one-shot event bracket.  No algorithm lives here.
 #pragma once
+#include <atomic>
 
 #include <hip/hip_runtime.h>
 
@@ -32,18 +33,18 @@ inline int check_launch(const char* what)
 }
 
 // wdf_event_bracket_next(): events to record immediately before / after the next RECURRENCE
-// kernel launched from this thread (the forward or reverse sweep itself, not the verify /
-// combine / reduce helpers that share its C call), so a harness can time exactly the kernel
-// rocprofv3 reports.  One-shot.
-extern thread_local hipEvent_t g_ev0, g_ev1;
+// kernel the library launches (the forward or reverse sweep itself, not the verify / combine /
+// reduce helpers that share its C call), so a harness can time exactly the kernel rocprofv3
+// reports.  One-shot, process-wide: the call that consumes it may come from another thread
+// than the one that armed it (torch's autograd engine runs a backward on its own thread).
+extern std::atomic<hipEvent_t> g_ev0, g_ev1;
 
 struct EventBracket {
     hipStream_t s;
     hipEvent_t e1;
-    explicit EventBracket(hipStream_t stream) : s(stream), e1(g_ev1)
+    explicit EventBracket(hipStream_t stream) : s(stream), e1(g_ev1.exchange(nullptr))
     {
-        if (g_ev0) (void)hipEventRecord(g_ev0, s);
-        g_ev0 = g_ev1 = nullptr;
+        if (hipEvent_t e0 = g_ev0.exchange(nullptr)) (void)hipEventRecord(e0, s);
     }
     ~EventBracket()
     {

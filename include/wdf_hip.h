@@ -451,7 +451,8 @@ int wdf_device_info(int device, char* name, int cap);
 void* wdf_event_create(void);
 int wdf_event_record(void* ev, void* stream);
 int wdf_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
-/* One-shot: record `start` / `stop` immediately around the next recurrence kernel this thread
+/* One-shot, process-wide (the consuming call may run on another thread, e.g. an autograd
+ * backward): record `start` / `stop` immediately around the next recurrence kernel the library
  * launches through wdf_clipper_fwd / _bwd / _fwd_tp / _bwd_tp / _bwd_mse_tp (the sweep itself,
  * not the verify / combine / reduce helpers of the same call): the duration rocprofv3 reports
  * for that kernel.                                                                        */
