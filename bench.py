@@ -41,6 +41,9 @@ BYTES_BWD = 12                 # x 4 + z-stash 4 + target 4: the fused-MSE sweep
                                # dL/dy from the target itself (SURVEY 8d counts x, z and dL/dy: the same 12 B)
 BYTES_STEP = 24                # SURVEY 8d's figure for forward + backward, the unit one launch of the one-pass step processes
 BYTES_STEP_MOVED = 12          # what that kernel itself has to move: x 4 + target 4 + y 4 (no stash, x read once)
+N_SIMD = 1024                  # 256 CUs x 4
+VALU_CLOCK_GHZ = 2.4           # MI355X_MICROARCH.md: peak engine clock (the chip sustains ~1.9-2.0 under this kernel: DVFS)
+SQ_GLOB = os.path.join(REPO, "profiles", "*_sq_counters.json")
 
 
 def measured_traffic(kernel, cfg):
@@ -54,6 +57,22 @@ def measured_traffic(kernel, cfg):
             d = json.load(open(path))
             if all(d["config"].get(k, "mse" if k == "loss" else None) == v for k, v in cfg.items()) and kernel in d["kernels"]:
                 return d["kernels"][kernel]["traffic_bytes"], os.path.relpath(path, REPO)
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
+    return None, None
+
+
+def measured_valu_cycles(kernel, cfg):
+    """(VALU-active cycles per launch of `kernel`, summed over all waves; source file) from the committed SQ pass of this
+    command (profiles/*_sq_counters.json, tools/pmc_sq.sh: SQ_ACTIVE_INST_VALU counts quad-cycles) on the configuration
+    being run; otherwise (None, None)."""
+    import glob
+    for path in sorted(glob.glob(SQ_GLOB), reverse=True):
+        try:
+            d = json.load(open(path))
+            c = d.get("config")
+            if c and all(c.get(k, "mse" if k == "loss" else None) == v for k, v in cfg.items()) and kernel in d["kernels"]:
+                return 4.0 * d["kernels"][kernel]["SQ_ACTIVE_INST_VALU"], os.path.relpath(path, REPO)
         except (OSError, ValueError, KeyError, TypeError):
             pass
     return None, None
@@ -107,7 +126,7 @@ def cpu_baseline(T, fs, budget_s=12.0):
                       f"samples of the same sweep workload ({dt:.1f} s, OpenMP {best} threads, best of {cands})"}
 
 
-def parity_check(stepper, theta, xk, x_host, target, fs, n_global, fused):
+def parity_check(stepper, theta, xk, x_host, target, fs, n_global, fused, g_first=None):
     """After the timed region: one more step (no update) of the BENCH PATH ITSELF (same
     stepper, same plan, same warm-start state, no update) at the parameters training has reached, against
     the fp64 CPU oracle over the whole batch: every output sample and the four gradient components."""
@@ -124,8 +143,13 @@ def parity_check(stepper, theta, xk, x_host, target, fs, n_global, fused):
     loss_ref, g_ref, y_ref = O.clipper_mse_step(th_host, fs, x_host.astype(np.float64), target.cpu().numpy().astype(np.float64),
                                                 dtype=np.float64, n_threads=len(os.sched_getaffinity(0)))
     got = g.cpu().numpy().astype(np.float64)
+    # max_rel_grad: every component against its OWN magnitude at the final theta -- after a long run the gradient has shrunk
+    # towards 0 (the loss is near its minimum) and this ratio grows with the cancellation in the sum;
+    # max_grad_err_vs_first_step: the same absolute errors against the components' magnitudes at the run's first step
     return {"max_abs_y": float(np.max(np.abs(y - y_ref))),
             "max_rel_grad": float(np.max(np.abs(got - g_ref) / np.abs(g_ref))),
+            "max_grad_err_vs_first_step": None if g_first is None else float(np.max(np.abs(got - g_ref) / np.abs(g_first))),
+            "grad_shrunk_to": None if g_first is None else [float(v) for v in np.abs(g_ref) / np.abs(g_first)],
             "rel_loss": float(abs(float(sse) / n_global - loss_ref) / loss_ref),
             "checked": f"all {y.shape[1]} sequences x {y.shape[0]} samples of the bench path's y and its fused gradient "
                        f"d(mean squared error)/d(Is,nVt,R,C), vs oracle_clipper_mse_step_f64 at the final theta "
@@ -212,8 +236,9 @@ def copy_bandwidth_gbs(dev, nbytes=1 << 29, reps=10):
 class Trainer:
     """The step of the training loop on one layout of x."""
 
-    def __init__(self, args, x, target, fs, B, T, n_global, world, dev, time_major):
+    def __init__(self, args, x, target, fs, B, T, n_global, world, dev, time_major, cold=None):
         self.args, self.world, self.tm = args, world, time_major
+        cold = args.cold_forward if cold is None else cold
         self.xk = x.t().contiguous() if time_major else x      # one-off: the engine keeps its training inputs resident time-major
         th_host = workload.clipper_theta()
         self.theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
@@ -227,13 +252,13 @@ class Trainer:
         if tp is not None and args.plan:
             pass
         elif tp is not None and self.fused:     # part of the untimed set-up: pick the chunk count on this box
-            tp = engine.autotune_fused(self.theta, self.xk, target, fs, tp, time_major=time_major)
+            tp = engine.autotune_fused(self.theta, self.xk, target, fs, tp, time_major=time_major, warm=not cold)
         elif tp is not None:
             tp = engine.autotune_time_parallel(self.theta, self.xk, target, fs, tp, time_major=time_major)
         self.tp = tp
         self.stepper = engine.MseStep(B, T, fs, tp, dev, n_global=n_global, time_major=time_major, loss=args.loss, skip=skip,
                                       sums_allreduce=wdist.allreduce_sum_ if (world > 1 or args.force_dist) else None,
-                                      warm=not args.cold_forward)
+                                      warm=not cold)
         # the update that closes a training step (lpf.py:93-94: one Adam per component, its learning
         # rate scaled to the component; tf_wdf.py:74,104 clip constraints), on the device
         self.adam = None if args.no_optimizer else binding.Adam(
@@ -241,13 +266,18 @@ class Trainer:
         self.first_sse = None
         self.ev = [binding.Event() for _ in range(4)]
         self.t_fwd, self.t_bwd = [], []
+        self.loop_events = []          # (start, stop[, start, stop]) around the recurrence kernel(s) of every 4th timed step
 
-    def step(self, timed=False):
+    def step(self, timed=False, ev=None):
         # one pass: forward (x -> y), MSE and the gradient in ONE kernel (-> SSE, dSSE-mean/dtheta); or, two kernels:
         # forward (x -> y, state stash), then the MSE-fused reverse sweep; then ONE fused all-reduce of
         # [SSE, grads] (no-op on 1 GPU unless --force-dist)
         # timed: events bracket exactly the recurrence kernel(s) (what rocprofv3 lists under that name)
-        st, ev, args = self.stepper, self.ev, self.args
+        # ev: events of the caller's own (no read-back here: the timed loop collects them after its closing synchronize)
+        st, args = self.stepper, self.args
+        read_back = timed and ev is None               # (timed=True: bracket with the trainer's own events and wait for them)
+        timed = timed or ev is not None
+        ev = self.ev if ev is None else ev
         # one rank: the update rides in the step's own last waves (one-pass step: either loss; kernel pair: plain MSE);
         # otherwise all-reduce, then update
         fold = self.adam is not None and self.world == 1 and not args.force_dist and (self.fused or args.loss == "mse")
@@ -268,9 +298,10 @@ class Trainer:
         if self.adam is not None:
             if self.first_sse is None:
                 self.first_sse = buf[0:1].clone()          # SSE of the very first step, for the report
+                self.first_grad = buf[1:].clone()
             if not fold:
                 self.adam.apply(self.theta, buf[1:])
-        if timed:
+        if read_back:
             self.t_fwd.append(ev[0].elapsed_ms(ev[1]))
             if not self.fused:
                 self.t_bwd.append(ev[2].elapsed_ms(ev[3]))
@@ -280,14 +311,23 @@ class Trainer:
         """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
         for _ in range(warmup):
             self.step()
+        # HIP events around the recurrence kernel of every 4th step, recorded INSIDE the timed region on the launch stream
+        # and read only after its closing synchronize (no host wait in between): kernel time and step time from one loop
+        n_ev = 2 if self.fused else 4
+        evs = [[binding.Event() for _ in range(n_ev)] if i % 4 == 0 else None for i in range(steps)]
         wdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            loss, grad = self.step()
+        for i in range(steps):
+            loss, grad = self.step(ev=evs[i])
         torch.cuda.synchronize()
         wdist.barrier()
         dt = time.perf_counter() - t0
+        for e in evs:
+            if e is not None:
+                self.t_fwd.append(e[0].elapsed_ms(e[1]))
+                if not self.fused:
+                    self.t_bwd.append(e[2].elapsed_ms(e[3]))
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if self.world > 1:
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -439,8 +479,9 @@ def spread(ts):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 200: at ~0.1 ms per step a 20-step region is one scheduler hiccup wide)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 20)")
     ap.add_argument("--batch", type=int, default=8192, help="sequences per GPU (weak scaling) or in total (strong)")
     ap.add_argument("--seq-len", type=int, default=4096)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -449,6 +490,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the after-the-run check of y and the gradient against the oracle")
     ap.add_argument("--no-batch-major", action="store_true", help="skip the second measurement with x as [B,T]")
+    ap.add_argument("--no-cold", action="store_true", help="skip the third measurement: the stateless step (value_cold)")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="skip the on-device Adam update of {Is, nVt, R, C} that closes every step")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -478,6 +520,8 @@ def main():
                     help="make the [B,T] layout (the reference scripts') the HEADLINE measurement instead of the engine's "
                          "resident time-major copy")
     args = ap.parse_args()
+    args.steps = 200 if args.steps is None else args.steps
+    args.warmup = 20 if args.warmup is None else args.warmup
 
     if args.rehearse_on_one_gpu:
         os.environ["LOCAL_RANK"] = "0"
@@ -512,11 +556,7 @@ def main():
     main_run = Trainer(args, x, target, fs, B, T, n_global, world, dev, tm)
     dt, loss, grad = main_run.run(args.warmup, args.steps, dev)
 
-    # per-launch durations (HIP events on the launch stream), outside the timed region so the
-    # event synchronisation does not perturb the whole-job number
-    for _ in range(min(args.steps, 10)):
-        main_run.step(timed=True)
-    torch.cuda.synchronize()
+    # (per-launch durations: HIP events recorded inside the timed loop, Trainer.run)
     tp, stepper = main_run.tp, main_run.stepper
     tp_stat = binding.tp_status(stepper.status) if tp is not None and tp.k_fwd > 1 else None
     buf_last = stepper.out.clone()
@@ -532,7 +572,18 @@ def main():
 
     parity = None
     if rank == 0 and world == 1 and not args.no_parity and args.loss == "mse":
-        parity = parity_check(stepper, main_run.theta, main_run.xk, x_host, target, fs, n_global, main_run.fused)
+        g_first = None if main_run.first_sse is None else main_run.first_grad.cpu().numpy().astype(np.float64)
+        parity = parity_check(stepper, main_run.theta, main_run.xk, x_host, target, fs, n_global, main_run.fused, g_first)
+
+    # the STATELESS step: nothing carried from call to call, every chunk warms up from z = 0 (what a loop that presents
+    # other data every step gets); same step otherwise, its own autotuned chunk count
+    cold = None
+    if not args.no_cold and not args.cold_forward and not args.sequential and main_run.fused:
+        cr = Trainer(args, x, target, fs, B, T, n_global, world, dev, tm, cold=True)
+        dt_c, _, _ = cr.run(args.warmup, args.steps, dev)
+        cold = {"value": Bg * T / (dt_c / args.steps), "ms_per_step": dt_c / args.steps * 1e3,
+                "chunks": None if cr.tp is None else cr.tp.k_fwd, "warmup_steps": None if cr.tp is None else cr.tp.warmup}
+        del cr
 
     if rank == 0:
         copy_gbs = copy_bandwidth_gbs(dev)
@@ -545,7 +596,7 @@ def main():
         warm = None if stepper.warm is None else stepper.warm.info()
         # a kernel's traffic depends on the batch, the layout and its OWN chunking only
         key = {"B": B, "T": T, "x_layout": "time-major" if tm else "batch-major", "loss": args.loss}
-        w_used = None if tp is None else (tp.warmup if warm is None else 32 * max(0, warm["last_warm_tiles"]))
+        w_used = None if tp is None else (tp.warmup if warm is None else warm["warm_unit_steps"] * max(0, warm["last_warm_tiles"]))
         if fused:
             dom, dom_ms, dom_bytes = "clipper_fused_tp_kernel", f_ms, BYTES_STEP
             if tp is not None:
@@ -589,6 +640,8 @@ def main():
                             "two kernels: clipper_fwd_tp_kernel (+ gated repair) and clipper_bwd_tp_kernel (MSE-fused reverse sweep)",
             "kernel_ms": {"fused_step": spread(t_fwd)} if fused else {"fwd": spread(t_fwd), "bwd": spread(t_bwd)},
             "parity": parity,
+            "value_cold": None if cold is None else cold["value"],
+            "cold": cold,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -596,14 +649,29 @@ def main():
                          "copy_bandwidth": copy_gbs, "frac_of_copy_bandwidth": achieved / copy_gbs},
         }
         if fused:
+            # The one-pass step is bound by VALU issue, not by HBM: `frac` is the fraction of the chip's VALU issue cycles
+            # (1024 SIMDs x the 2.4 GHz peak clock x the kernel's duration) in which a VALU instruction was executing, from
+            # the committed SQ pass of this configuration.  The HBM side stays in the block: what the kernel itself moves
+            # (12 B/sample) and, demoted, SURVEY 8d's forward + backward equivalent (24 B/sample: the work one launch does).
             moved = BYTES_STEP_MOVED * B * T / (dom_ms * 1e-3) / 1e9
-            out["roofline"].update({
-                "step_kernel_ms": f_ms,
-                "bytes_moved_per_sample": BYTES_STEP_MOVED, "moved": moved, "frac_moved": moved / HBM_PEAK_GBS,
-                "note": "`achieved` prices one launch at SURVEY 8d's forward + backward figure (24 B/sample: x, y, stash written, "
-                        "then x, stash, dL/dy read) because one launch does that work; the one-pass kernel itself moves 12 B/sample "
-                        "(x + target in, y out: `moved`, `frac_moved`, and `traffic` when a PMC pass of this configuration is "
-                        "committed) and is bound by VALU issue (~105 instructions per sample-step), not by HBM"})
+            valu, valu_src = (None, None) if tp is None else measured_valu_cycles(dom, key)
+            peak = N_SIMD * VALU_CLOCK_GHZ
+            ach = None if valu is None else valu / (dom_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "valu", "kernel": dom, "achieved": ach, "peak": peak, "unit": "G VALU-active cycles/s (chip)",
+                "frac": None if ach is None else ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "valu_source": valu_src, "step_kernel_ms": f_ms,
+                "hbm": {"bytes_moved_per_sample": BYTES_STEP_MOVED, "moved": moved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac_moved": moved / HBM_PEAK_GBS,
+                        "frac_traffic": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "copy_bandwidth": copy_gbs},
+                "equivalent_two_pass": {"algorithmic_bytes_per_sample": BYTES_STEP, "achieved": achieved, "unit": "GB/s",
+                                        "frac": achieved / HBM_PEAK_GBS,
+                                        "note": "SURVEY 8d prices forward + backward at 24 B/sample (x, y, stash written; x, stash, "
+                                                "dL/dy read); one launch of the one-pass step does that work moving 12"},
+                "note": "VALU-bound: ~110 instructions per two sample-steps (69 packed) at 2 waves per SIMD; `frac` uses the "
+                        "peak clock, the chip sustains ~1.9-2.0 GHz under this kernel (frac / 0.8 is the share of the "
+                        "cycles it actually had)"}
         else:
             out["roofline"].update({"fwd_kernel_ms": f_ms, "bwd_kernel_ms": b_ms})
         if world == 1 and not args.no_cpu_baseline:

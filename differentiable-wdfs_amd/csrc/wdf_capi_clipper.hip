@@ -152,25 +152,32 @@ inline size_t bwd_ticket_bytes(int64_t B) { return (((size_t)((B + 63) / 64) + 4
 
 
 // ---- the one-pass training step (wdf_clipper_fused.h) --------------------------------------------
-struct FusedWs { double* part; float* zwarm; float* zend; float* rec; unsigned* tickets; unsigned* gticket; };
+struct FusedWs { double* part; double* wpart; float* zwarm; float* zend; float* rec; unsigned* tickets; unsigned* gticket; };
 
-// [tiles][8] doubles (MSE uses 4 of them), zwarm / zend [K][B], records [K][nrec][B], then the ticket words
-inline size_t fused_part_bytes(int64_t B) { return (size_t)((B + 63) / 64) * 8 * sizeof(double); }
+// ONE layout for both losses (sized for the larger, MSE + ESR; a workspace may serve either from call to call):
+// [tiles][8] doubles (the tiles' sums; MSE uses 4 of them), [tiles][K][slots][8] doubles (the chunk waves' own sums, one set
+// per sequence slot of a lane), zwarm / zend [K][B], the record granules, then the ticket words.
+inline size_t fused_tiles(int64_t B) { return (size_t)((B + 63) / 64) + 1; }      // >= tiles x slots for either lane form
+inline size_t fused_part_bytes(int64_t B) { return fused_tiles(B) * 8 * sizeof(double); }
+inline size_t fused_wpart_bytes(int64_t B, int K) { return fused_tiles(B) * (size_t)K * wdf::kFsPartEsr * sizeof(double); }
 
-inline size_t fused_body_bytes(int64_t B, int K, int nrec)
+inline size_t fused_body_bytes(int64_t B, int K)
 {
-    const size_t body = fused_part_bytes(B) + (size_t)(2 + nrec) * (size_t)K * (size_t)B * sizeof(float);
+    // zwarm / zend [K][B] floats; records: 16-byte granules [K][3][lanes], lanes <= 64 x ceil(B / 64)
+    const size_t body = fused_part_bytes(B) + fused_wpart_bytes(B, K) + (size_t)2 * (size_t)K * (size_t)B * sizeof(float) +
+                        (size_t)K * wdf::kFsQuads * (size_t)((B + 63) / 64 * 64) * 16;
     return (body + 63) / 64 * 64;
 }
 
-inline FusedWs fused_ws(void* ws, int64_t B, int K, int nrec)
+inline FusedWs fused_ws(void* ws, int64_t B, int K)
 {
     FusedWs w;
     w.part = (double*)ws;
-    w.zwarm = (float*)((char*)ws + fused_part_bytes(B));
+    w.wpart = (double*)((char*)ws + fused_part_bytes(B));
+    w.zwarm = (float*)((char*)ws + fused_part_bytes(B) + fused_wpart_bytes(B, K));
     w.zend = w.zwarm + (size_t)K * (size_t)B;
     w.rec = w.zend + (size_t)K * (size_t)B;
-    w.tickets = (unsigned*)((char*)ws + fused_body_bytes(B, K, nrec));
+    w.tickets = (unsigned*)((char*)ws + fused_body_bytes(B, K));
     w.gticket = (unsigned*)((char*)w.tickets + tp_ticket_bytes(B));
     return w;
 }
@@ -192,7 +199,7 @@ inline int64_t fused_skew(int64_t n_waves, int K, int64_t L, int64_t T, int max_
     const int64_t skew = (steps >= 0 ? steps : L / 4) / wdf::kTile * wdf::kTile;
     if (skew <= 0 || skew >= L) return 0;
     if (T - (int64_t)(K - 1) * L <= skew) return 0;                                   // the last chunk would be empty
-    if ((int64_t)max_warm_tiles * wdf::kTile > L - skew) return 0;                      // snapshots reach further back than the short chunks
+    if ((int64_t)max_warm_tiles * wdf::kWarmStep > L - skew) return 0;                      // snapshots reach further back than the short chunks
     return skew;
 }
 
@@ -208,11 +215,11 @@ void launch_fused(const float* x, const float* r, const float* theta, float fs, 
 #define WDF_FUSED(V_, LOSS_)                                                                                                     \
     hipLaunchKernelGGL((wdf::clipper_fused_tp_kernel<DYN_R, SYM, TM, V4, V_, LOSS_>), grid, dim3(64), 0, s, x, r, theta, fs, n_up, \
                        n_down, target, hgs, skip, y, z0, zT, w.zwarm, w.zend, w.rec, status, warm.ctl, warm.snap, warm.J,        \
-                       w.tickets, w.gticket, tol, B, T, g.L, W, general, w.part, out, skew)
+                       w.tickets, w.gticket, tol, B, T, g.L, W, general, w.part, out, skew, w.wpart)
 #define WDF_FUSED_REPAIR(N_, LOSS_)                                                                                              \
     hipLaunchKernelGGL((wdf::clipper_fused_repair_kernel<DYN_R, SYM, TM, N_, LOSS_>), dim3(grid.x), dim3(64), 0, s, x, r, theta, fs, \
                        n_up, n_down, target, hgs, skip, y, zT, w.zwarm, w.zend, w.rec, B, T, (int64_t)g.K, g.L, tol, status,     \
-                       warm.ctl, warm.snap, warm.J, w.tickets, w.gticket, general, w.part, out, skew)
+                       warm.ctl, warm.snap, warm.J, w.tickets, w.gticket, general, w.part, out, skew, w.wpart, W)
     {
         EventBracket bracket(s);
         if (esr) { if (pairs) WDF_FUSED(wdf::v2f, 2); else WDF_FUSED(float, 2); }
@@ -292,6 +299,7 @@ int wdf_clipper_bwd(const float* x, const float* r, const float* theta, float fs
 }
 
 int wdf_clipper_tp_chunks(int64_t T, int n_chunks) { return T > 0 ? tp_geom(T, n_chunks).K : 0; }
+int wdf_clipper_tp_warm_unit(void) { return wdf::kWarmStep; }
 
 size_t wdf_clipper_fwd_tp_ws_bytes(int64_t B, int n_chunks)
 {
@@ -366,8 +374,8 @@ int wdf_clipper_fwd_tp_warm(const float* x, const float* r, const float* theta, 
 {
     if (!state) return fail(WDF_EINVAL, "null state");
     const TpGeom g = tp_geom(T, n_chunks > 0 ? n_chunks : 1);
-    if ((int64_t)max_warm_tiles * wdf::kTile > g.L)
-        return fail(WDF_EINVAL, "max_warm_tiles * 32 must not exceed the chunk length (%lld)", (long long)g.L);
+    if ((int64_t)max_warm_tiles * wdf::kWarmStep > g.L)
+        return fail(WDF_EINVAL, "max_warm_tiles * 16 must not exceed the chunk length (%lld)", (long long)g.L);
     return fwd_tp_common(x, r, theta, fs, n_up, n_down, y, zstash, z0, zT, B, T, n_chunks, warmup, tol, ws, status, state,
                          max_warm_tiles, flags, stream);
 }
@@ -464,14 +472,13 @@ int wdf_clipper_bwd_esr_tp(const float* x, const float* r, const float* theta, f
 size_t wdf_clipper_step_mse_tp_ws_bytes(int64_t B, int n_chunks)
 {
     if (B <= 0 || n_chunks <= 0) return 0;
-    return fused_body_bytes(B, n_chunks, wdf::kFsOutEsr) + tp_ticket_bytes(B) + 64;      // (sized for either loss)
+    return fused_body_bytes(B, n_chunks) + tp_ticket_bytes(B) + 64;      // (one layout for either loss)
 }
 
 int wdf_clipper_step_mse_tp_ws_init(void* ws, int64_t B, int n_chunks, void* stream)
 {
     if (!ws || B <= 0 || n_chunks <= 0) return fail(WDF_EINVAL, "null ws / bad B, n_chunks");
-    // both record sizes put their ticket words inside the allocation: clear from the smaller layout's tickets to the end
-    const size_t from = fused_body_bytes(B, n_chunks, wdf::kFsOut), total = wdf_clipper_step_mse_tp_ws_bytes(B, n_chunks);
+    const size_t from = fused_body_bytes(B, n_chunks), total = wdf_clipper_step_mse_tp_ws_bytes(B, n_chunks);
     const hipError_t e = hipMemsetAsync((char*)ws + from, 0, total - from, (hipStream_t)stream);
     return e == hipSuccess ? WDF_OK : fail(WDF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
 }
@@ -497,8 +504,8 @@ static int step_tp_common(const float* x, const float* r, float* theta, float fs
     if (state) {
         if (max_warm_tiles < 1 || max_warm_tiles > wdf::kTpMaxWarmTiles)
             return fail(WDF_EINVAL, "max_warm_tiles must be in 1..%d", wdf::kTpMaxWarmTiles);
-        if ((int64_t)max_warm_tiles * wdf::kTile > g.L)
-            return fail(WDF_EINVAL, "max_warm_tiles * 32 must not exceed the chunk length (%lld)", (long long)g.L);
+        if ((int64_t)max_warm_tiles * wdf::kWarmStep > g.L)
+            return fail(WDF_EINVAL, "max_warm_tiles * 16 must not exceed the chunk length (%lld)", (long long)g.L);
         if (g.K >= (1 << 20)) return fail(WDF_EINVAL, "too many chunks for a warm-start state");
         // same layout as wdf_clipper_fwd_tp_warm's state: [TpCtl][its ticket area, unused here][snapshot ring]
         warm = TpWarm{(wdf::TpCtl*)state, (float*)((char*)state + sizeof(wdf::TpCtl) + tp_ticket_bytes(B)), max_warm_tiles + 1};
@@ -510,7 +517,7 @@ static int step_tp_common(const float* x, const float* r, float* theta, float fs
                        (!r || aligned8(r));
     const int64_t skew = fused_skew((B + (pairs ? 127 : 63)) / (pairs ? 128 : 64) * (int64_t)g.K, g.K, g.L, T, state ? max_warm_tiles : 0);
     WDF_DISPATCH4(launch_fused, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, target, hgs, skip, y, z0, zT,
-                  fused_ws(ws, B, g.K, esr ? wdf::kFsOutEsr : wdf::kFsOut), (wdf::TpStatus*)status, tol, B, T, g, W, warm,
+                  fused_ws(ws, B, g.K), (wdf::TpStatus*)status, tol, B, T, g, W, warm,
                   (flags & WDF_GENERAL_ROOT) ? 1 : 0, pairs, esr, out, skew, (hipStream_t)stream);
     return check_launch(what);
 }
@@ -525,7 +532,7 @@ int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float 
     if (!gtheta || !sse) return fail(WDF_EINVAL, "null gtheta/sse");
     if (m && (!v || !step || !lr)) return fail(WDF_EINVAL, "Adam update asked for (m) but v/step/lr missing");
     const wdf::AdamTail adam{m ? theta : nullptr, m, v, step, lr, beta1, beta2, eps, lo, hi};
-    const wdf::FusedOut out{gtheta, accumulate, sse, adam, 0.0, 0.0, nullptr, nullptr};
+    const wdf::FusedOut out{gtheta, accumulate, sse, adam, 0.0, 0.0, nullptr, nullptr, wdf::TpFinishCtx{nullptr, nullptr, 0, nullptr, 0.0f, 0, 0, 0}};
     return step_tp_common(x, r, theta, fs, n_up, n_down, target, 0.5f * gscale, skip, y, z0, zT, B, T, n_chunks, warmup, tol, ws,
                           status, state, max_warm_tiles, false, out, flags, stream, "wdf_clipper_step_mse_tp");
 }
@@ -541,7 +548,7 @@ int wdf_clipper_step_esr_tp(const float* x, const float* r, float* theta, float 
     if (!(n_global > 0.0)) return fail(WDF_EINVAL, "n_global must be positive");
     if (m && (!gtheta || !v || !step || !lr)) return fail(WDF_EINVAL, "Adam update asked for (m) but gtheta/v/step/lr missing");
     const wdf::AdamTail adam{m ? theta : nullptr, m, v, step, lr, beta1, beta2, eps, lo, hi};
-    const wdf::FusedOut out{gtheta, 0, nullptr, adam, n_global, eps_energy, sums10, loss3};
+    const wdf::FusedOut out{gtheta, 0, nullptr, adam, n_global, eps_energy, sums10, loss3, wdf::TpFinishCtx{nullptr, nullptr, 0, nullptr, 0.0f, 0, 0, 0}};
     return step_tp_common(x, r, theta, fs, n_up, n_down, target, 0.5f, skip, y, z0, zT, B, T, n_chunks, warmup, tol, ws, status,
                           state, max_warm_tiles, true, out, flags, stream, "wdf_clipper_step_esr_tp");
 }

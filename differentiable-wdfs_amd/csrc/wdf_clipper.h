@@ -23,11 +23,22 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "wdf_omega.h"
 #include "wdf_optim.h"
 
 namespace wdf {
+
+#ifdef WDF_DBG_TIMES      // tools/dbg_times.py: per-wave start / end wall clock of the main body, and stamps along the tile's tail
+__device__ unsigned long long* g_dbg_times = nullptr;
+// stamp i of this tile's tail (the tile's last wave): [8 * waves + 8 * tile + i]
+#define WDF_DBG_STAMP(i)                                                                                     \
+    do { if (threadIdx.x == 0 && g_dbg_times)                                                                \
+             g_dbg_times[8 * ((size_t)gridDim.x * gridDim.y) + 8 * (size_t)blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define WDF_DBG_STAMP(i) do {} while (0)
+#endif
 
 constexpr int kBlk = 8;   // time steps per register block (2 x 16-byte loads per lane)
 
@@ -271,6 +282,53 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// The same sum (to every lane, in a fixed order) without LDS traffic: DPP moves inside the 16-lane rows, v_readlane across
+// the four rows.  __shfl_down on a double is two ds_bpermute per step, six dependent steps: ~1 us for a handful of sums,
+// which the tails of the time-parallel kernels pay on the step's critical path; this is ~25 plain instructions per sum.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double lane_value(double v, int lane)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+}
+// 32-bit forms (the verification's maximum miss and bad-pair count): result in every lane
+__device__ __forceinline__ float wave_max_dpp(float v)      // v >= 0 (0 fills the disabled lanes)
+{
+    auto mv = [](float x, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false)); };
+    v = fmaxf(v, mv(v, std::integral_constant<int, 0xB1>{}));
+    v = fmaxf(v, mv(v, std::integral_constant<int, 0x4E>{}));
+    v = fmaxf(v, mv(v, std::integral_constant<int, 0x141>{}));
+    v = fmaxf(v, mv(v, std::integral_constant<int, 0x140>{}));
+    auto rl = [](float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); };
+    return fmaxf(fmaxf(rl(v, 0), rl(v, 16)), fmaxf(rl(v, 32), rl(v, 48)));
+}
+__device__ __forceinline__ int wave_sum_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]: pairs
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]: quads
+    v += dpp_move<0x141>(v);     // row_half_mirror: 8 lanes
+    v += dpp_move<0x140>(v);     // row_mirror: the row's 16 lanes, in every lane of the row
+    return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
+}
+
 // ws: double[gridDim.x][4] per-wave partial sums {S_L, S_V, S_P, 0}
 template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4>
 __global__ __launch_bounds__(64) void clipper_bwd_kernel(
@@ -447,13 +505,18 @@ struct TpStatus {
 };
 
 constexpr int kTpRing = 3;            // snapshot sets: the one being written, the previous call's, the one before
-constexpr int kTpMaxWarmTiles = 16;   // snapshots reach back at most 16 * 32 steps
+// The unit of a warm start: snapshots are kept every kWarmStep steps before a chunk's end and a warm call starts j units
+// early.  16 steps (round 2: 32): at the headline circuit 16 steps shrink a boundary miss ~5x, and the training loop's
+// warm-up settles at ONE unit -- a whole one-pass step then runs (128 + 16) / 128 of its owned steps instead of
+// (128 + 32) / 128, ~5 % less arithmetic in a kernel that is bound by VALU issue.  ("Warm tile" in names = this unit.)
+constexpr int kWarmStep = 16;
+constexpr int kTpMaxWarmTiles = 32;   // snapshots reach back at most 32 * 16 steps
 
 // Warm-start control block (64 bytes at the head of the caller's persistent state buffer).
 struct TpCtl {
     int valid;        // snapshot sets left by earlier calls: 0 (next call is cold), 1, 2
     int head;         // ring slot of the most recent set
-    int j_next;       // warm-up tiles (32 steps each) the next warm call runs
+    int j_next;       // warm-up units (kWarmStep steps each) the next warm call runs
     int j_used;       // what the last call ran (-1: cold)
     float th1[4];     // theta of the most recent call
     float th2[4];     // theta of the call before
@@ -641,15 +704,15 @@ __device__ __forceinline__ bool tp_rerun_chunk(const ClipConsts& c, const float*
                                             bool may_stop, float& z)
 {
     for (int64_t t = t0; t < t1; t += kBlk) {
-        if ((t - t0) % kTile == 0) {
+        if ((t - t0) % kWarmStep == 0) {
             if constexpr (STASH) {
                 if (may_stop && t > t0) {
                     const float zs = zstash[t * B + b];
                     if (__builtin_amdgcn_ballot_w64(!(fabsf(z - zs) <= tol_conv)) == 0) return false;
                 }
             }
-            if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1) && (t1 - t) % kTile == 0)
-                snapw[((t1 - t) / kTile) * K * B + b] = z;
+            if (snapw != nullptr && t1 - t <= (int64_t)kWarmStep * (J - 1) && (t1 - t) % kWarmStep == 0)
+                snapw[((t1 - t) / kWarmStep) * K * B + b] = z;
         }
         float xv[kBlk], rv[kBlk];
 #pragma unroll
@@ -696,9 +759,62 @@ __device__ __forceinline__ bool tp_tile_last(unsigned* tickets)
     return true;
 }
 
+// What the step's finishing wave does with the tiles' verification results: totals to the host-visible status word,
+// accumulators left clean, warm-start control block advanced (ring head, theta history, warm-up units for the next call).
+// One lane.  nb, mm: bad (sequence, chunk) pairs and the largest miss of the whole call.
+__device__ __forceinline__ void tp_publish_status_and_steer(const float* __restrict__ theta, TpStatus* __restrict__ status,
+                                                            TpCtl* __restrict__ ctl, int J, unsigned* tickets, float tol, int64_t K,
+                                                            int64_t L, int64_t W, int nb, float mm, bool keep_fallback_count)
+{
+    TpAcc* acc = reinterpret_cast<TpAcc*>(tickets);
+    if (keep_fallback_count) { status->n_bad = nb; status->max_miss = mm; }      // (fallback_ran: the repair launch adds to it)
+    else *status = TpStatus{nb, mm, 0, 0u};
+    *acc = TpAcc{0, 0, 0u, 0u};
+    if (ctl == nullptr) return;
+    const bool stateful = ctl->geom == (int)((K << 8) | J);
+    const int head = stateful ? ctl->head : 0;
+    const int valid = stateful ? ctl->valid : 0;
+    int j = ctl->j_next;
+    const int jfloor = ctl->j_floor & 0xff;                     // host's floor (low byte); the rest of the word: hold counter
+    int hold = ctl->j_floor >> 8;
+    if (valid == 0) {                                           // that was the cold call: start 96 steps under its warm-up
+        const int jc = (int)((W + kWarmStep - 1) / kWarmStep);      // (an O(1 V) guess needs ~160 steps here; a change of 1e-3 V ~64)
+        j = jc - 6 < 1 ? 1 : jc - 6;
+        hold = 0;
+        ctl->j_used = -1;
+    } else {
+        // One unit (16 steps) changes the miss by ~5x at the headline circuit, and two converged fp32 trajectories still
+        // differ by ~3e-8: grow when the miss comes within 2x of tol (or a boundary failed), shrink -- once the
+        // secant extrapolation is running -- while it stays 12x below (one unit less must still leave 2x), and after
+        // growing do not probe lower again for 32 calls.  Measured in the bench loop (tools/warm_pin_probe.py, 32-step
+        // units): 32 steps miss by <= 3e-7, 64 by <= 7e-8, 96 sit at the rounding floor.
+        ctl->j_used = j;
+        if (nb > 0) { j += 4; hold = 32; }
+        else if (mm * 2.0f > tol) { j += 1; hold = 32; }
+        else if (hold > 0) --hold;
+        else if (valid > 1 && mm * 64.0f < tol && (j > 2 || mm == 0.0f)) j -= 2;     // (two units: ~25x)
+        else if (valid > 1 && mm * 12.0f < tol && (j > 1 || mm == 0.0f)) j -= 1;
+    }
+    const int jmax = (int)(L / kWarmStep) < J - 1 ? (int)(L / kWarmStep) : J - 1;
+    const int jmin = jfloor < jmax ? jfloor : jmax;
+    ctl->j_next = j < jmin ? jmin : (j > jmax ? jmax : j);
+    ctl->j_floor = jfloor | (hold << 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ctl->th2[i] = stateful ? ctl->th1[i] : theta[i]; ctl->th1[i] = theta[i]; }
+    ctl->head = (head + 1) % kTpRing;
+    ctl->valid = valid < 2 ? valid + 1 : 2;
+    ctl->geom = (int)((K << 8) | J);
+    ctl->last_miss = mm;
+    ctl->n_calls = stateful ? ctl->n_calls + 1 : 1;
+}
+
 // Verification of one tile by its last wave; returns (wave-uniform) whether a boundary of the tile failed.
 // NSEQ: adjacent sequences per lane (a tile is 64 NSEQ sequences).
-template <bool DYN_R, int NSEQ = 1>
+// DEFER (the one-pass step): the tile only ADDS its result to the accumulators (two fire-and-forget atomics) and flags itself
+// when a boundary failed; the step's finishing wave -- the last tile through the combine, in the step or in its repair
+// launch -- reads the totals and calls tp_publish_status_and_steer.  Otherwise (the forward kernel: nothing follows the
+// verification) the last tile to verify does it here, found by a returning count.
+template <bool DYN_R, int NSEQ = 1, bool DEFER = false>
 __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, const float* zwarm, const float* zend,
                                                TpStatus* __restrict__ status, TpCtl* __restrict__ ctl, int J,
                                                unsigned* tickets, float tol, int64_t B, int64_t L, int64_t W)
@@ -709,9 +825,9 @@ __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, 
     const int64_t b_first = b_raw < B ? b_raw : B - NSEQ;
     float miss = 0.0f;
     int nbad = 0;
-    // 16 boundaries' loads in flight together (the lane's NSEQ adjacent sequences in one load each): one at a time this
-    // loop is K dependent round trips
-    constexpr int kBatch = 16;
+    // 31 boundaries' loads in flight together (the lane's NSEQ adjacent sequences in one load each; a wave holds at most 63
+    // outstanding memory instructions, and 31 boundaries are 62): at the headline's 32 chunks ONE round trip
+    constexpr int kBatch = 31;
     for (int64_t k0 = 1; k0 < K; k0 += kBatch) {
         float zw[kBatch][NSEQ], ze[kBatch][NSEQ];
 #pragma unroll
@@ -731,24 +847,23 @@ __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, 
                 }
             }
     }
-    float wmax = miss;
-    int wbad = nbad;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        wmax = fmaxf(wmax, __shfl_down(wmax, off, 64));
-        wbad += __shfl_down(wbad, off, 64);
-    }
+    const float wmax = wave_max_dpp(miss);
+    const int wbad = wave_sum_dpp(nbad);
     const bool tile_failed = __builtin_amdgcn_ballot_w64(nbad != 0) != 0;
     if (threadIdx.x != 0) return tile_failed;
-    // Returning atomics: the value coming back means the update has been performed at the device-wide
-    // coherence point, so the tile count (issued after the wait) cannot overtake them.
     TpAcc* acc = reinterpret_cast<TpAcc*>(tickets);             // 64-byte aligned (the 8-byte atomic needs 8)
     unsigned* tile_bad = tickets + 4 + ntiles;
+    if (wmax > 0.0f) (void)atomicMax(&acc->max_miss_bits, __float_as_int(wmax));
+    if (wbad) tile_bad[blockIdx.x] = 1u;
+    if constexpr (DEFER) {
+        if (wbad) (void)atomicAdd(&acc->n_bad, (unsigned)wbad);   // (performed before this wave's next awaited access: the
+        return tile_failed;                                       //  partial's s_waitcnt vmcnt(0), then the step ticket)
+    }
+    // Returning atomics: the value coming back means the update has been performed at the device-wide
+    // coherence point, so the tile count (issued after the wait) cannot overtake them.
     // The maximum and the tile count live in one 16-byte struct, i.e. one cache line and one L2 channel: this lane's two
     // atomics reach that channel's atomic unit in issue order, so the count (returning, awaited) cannot be performed
     // before the maximum and the tile that sees the last count reads a complete maximum -- without a second round trip.
-    if (wmax > 0.0f) (void)atomicMax(&acc->max_miss_bits, __float_as_int(wmax));
-    if (wbad) tile_bad[blockIdx.x] = 1u;
     // one 64-bit add carries the tile count (low word) and this tile's bad pairs (high word)
     const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&acc->tiles_done),
                                               1ull | ((unsigned long long)(unsigned)wbad << 32));
@@ -756,44 +871,7 @@ __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, 
     // ---- last tile: totals to the status word, accumulators left clean, warm-start state advanced
     const int mm_bits = atomicMax(&acc->max_miss_bits, 0);
     const int nb = (int)(prev >> 32) + wbad;
-    const float mm = __int_as_float(mm_bits);
-    *status = TpStatus{nb, mm, 0, 0u};
-    *acc = TpAcc{0, 0, 0u, 0u};
-    if (ctl == nullptr) return tile_failed;
-    const bool stateful = ctl->geom == (int)((K << 8) | J);
-    const int head = stateful ? ctl->head : 0;
-    const int valid = stateful ? ctl->valid : 0;
-    int j = ctl->j_next;
-    const int jfloor = ctl->j_floor & 0xff;                     // host's floor (low byte); the rest of the word: hold counter
-    int hold = ctl->j_floor >> 8;
-    if (valid == 0) {                                           // that was the cold call: start three tiles under its warm-up
-        const int jc = (int)((W + kTile - 1) / kTile);              // (an O(1 V) guess needs ~5 tiles here; a change of 1e-3 V two)
-        j = jc - 3 < 1 ? 1 : jc - 3;
-        hold = 0;
-        ctl->j_used = -1;
-    } else {
-        // One tile changes the miss by ~25x at the headline circuit, and two converged fp32 trajectories still
-        // differ by ~3e-8: grow when the miss comes within 2x of tol (or a boundary failed), shrink -- once the
-        // secant extrapolation is running -- while it stays 8x below, and after growing do not probe lower
-        // again for 32 calls.  Measured in the bench loop (tools/warm_pin_probe.py): 1 tile misses by <= 3e-7,
-        // 2 tiles by <= 7e-8, 3 tiles sit at the rounding floor.
-        ctl->j_used = j;
-        if (nb > 0) { j += 2; hold = 32; }
-        else if (mm * 2.0f > tol) { j += 1; hold = 32; }
-        else if (hold > 0) --hold;
-        else if (valid > 1 && mm * 8.0f < tol && (j > 1 || mm == 0.0f)) j -= 1;
-    }
-    const int jmax = (int)(L / kTile) < J - 1 ? (int)(L / kTile) : J - 1;
-    const int jmin = jfloor < jmax ? jfloor : jmax;
-    ctl->j_next = j < jmin ? jmin : (j > jmax ? jmax : j);
-    ctl->j_floor = jfloor | (hold << 8);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { ctl->th2[i] = stateful ? ctl->th1[i] : theta[i]; ctl->th1[i] = theta[i]; }
-    ctl->head = (head + 1) % kTpRing;
-    ctl->valid = valid < 2 ? valid + 1 : 2;
-    ctl->geom = (int)((K << 8) | J);
-    ctl->last_miss = mm;
-    ctl->n_calls = stateful ? ctl->n_calls + 1 : 1;
+    tp_publish_status_and_steer(theta, status, ctl, J, tickets, tol, K, L, W, nb, __int_as_float(mm_bits), false);
     return tile_failed;
 }
 
@@ -961,24 +1039,51 @@ struct AdamTail {
 };
 
 // Adam + clip constraints on the four components (wdf_adam_step's rule), by the wave that finished the step.
-__device__ __forceinline__ void adam_tail_apply(const AdamTail& adam, const float* gtheta)
+// The state the update needs is FETCHED FIRST (adam_tail_fetch, as soon as a wave knows it finishes the step) and used after
+// the reduction: fetched where it is used, the loads -- m, v, theta, lr, bounds, step: two dependent round trips -- sat
+// behind the reduction on the step's critical path (2.3-3.0 us of a ~16 us tail, tools/dbg_times.py).
+struct AdamFetched { float m, v, theta, lr, lo, hi; int t; };
+
+__device__ __forceinline__ AdamFetched adam_tail_fetch(const AdamTail& adam)
+{
+    AdamFetched f{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, INFINITY, 0};
+    if (adam.theta == nullptr) return f;
+    const int i = threadIdx.x < 4 ? threadIdx.x : 3;
+    f.t = *adam.step + 1;
+    f.m = adam.m[i]; f.v = adam.v[i]; f.theta = adam.theta[i]; f.lr = adam.lr[i];
+    if (adam.lo) f.lo = adam.lo[i];
+    if (adam.hi) f.hi = adam.hi[i];
+    return f;
+}
+
+__device__ __forceinline__ void adam_tail_apply(const AdamTail& adam, const AdamFetched& f, float g)
 {
     const int i = threadIdx.x;
-    const int t = *adam.step + 1;
-    __syncthreads();
-    if (i == 0) *adam.step = t;
+    if (i == 0) *adam.step = f.t;
     if (i < 4) {
-        const double c1 = 1.0 - ipow((double)adam.b1, t), c2 = 1.0 - ipow((double)adam.b2, t);     // (on the step's critical path)
-        const float g = gtheta[i];
-        const float mi = adam.b1 * adam.m[i] + (1.0f - adam.b1) * g;
-        const float vi = adam.b2 * adam.v[i] + (1.0f - adam.b2) * g * g;
+        const double c1 = 1.0 - ipow((double)adam.b1, f.t), c2 = 1.0 - ipow((double)adam.b2, f.t);
+        const float mi = adam.b1 * f.m + (1.0f - adam.b1) * g;
+        const float vi = adam.b2 * f.v + (1.0f - adam.b2) * g * g;
         adam.m[i] = mi;
         adam.v[i] = vi;
-        float th = adam.theta[i] - (float)((double)adam.lr[i] * sqrt(c2) / c1) * mi / (sqrtf(vi) + adam.eps);
-        if (adam.lo) th = fmaxf(th, adam.lo[i]);
-        if (adam.hi) th = fminf(th, adam.hi[i]);
+        float th = f.theta - (float)((double)f.lr * sqrt(c2) / c1) * mi / (sqrtf(vi) + adam.eps);
+        th = fminf(fmaxf(th, f.lo), f.hi);
         adam.theta[i] = th;
     }
+}
+
+// The verification's deferred half (one-pass step, tp_verify_tile<..., DEFER>): what the finishing wave needs to publish the
+// status and steer the warm start.  status == nullptr: nothing deferred (the reverse sweep).
+struct TpFinishCtx { TpStatus* status; TpCtl* ctl; int J; unsigned* tickets; float tol; int64_t K, L, W; };
+
+__device__ __forceinline__ void tp_finish_deferred(const TpFinishCtx& fc, const float* theta)
+{
+    if (fc.status == nullptr || threadIdx.x != 0) return;
+    TpAcc* acc = reinterpret_cast<TpAcc*>(fc.tickets);
+    // (atomic loads: the totals were formed by other tiles' device-scope atomics)
+    const int mm_bits = __hip_atomic_load(&acc->max_miss_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nb = (int)__hip_atomic_load(&acc->n_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tp_publish_status_and_steer(theta, fc.status, fc.ctl, fc.J, fc.tickets, fc.tol, fc.K, fc.L, fc.W, nb, __int_as_float(mm_bits), true);
 }
 
 // A tile's partial sums {S_L, S_V, S_P, SSE} (per lane, dead lanes zero) -> the tile's slot of ws; the LAST tile
@@ -986,10 +1091,11 @@ __device__ __forceinline__ void adam_tail_apply(const AdamTail& adam, const floa
 // {Is, nVt, R, C} and, if asked, the Adam update of the four components.
 __device__ __forceinline__ void tile_partial_and_finish(double dL, double dV, double dP, double dS, double* ws, unsigned* tickets,
                                                         const float* theta, float fs, int dyn_r, float* gtheta, int accumulate,
-                                                        float* __restrict__ sse_out, const AdamTail& adam, double (*sh)[4])
+                                                        float* __restrict__ sse_out, const AdamTail& adam, double (*sh)[4],
+                                                        const TpFinishCtx& fc = TpFinishCtx{nullptr, nullptr, 0, nullptr, 0.0f, 0, 0, 0})
 {
     const unsigned ntiles = gridDim.x;
-    dL = wave_sum(dL); dV = wave_sum(dV); dP = wave_sum(dP); dS = wave_sum(dS);
+    dL = wave_sum_dpp(dL); dV = wave_sum_dpp(dV); dP = wave_sum_dpp(dP); dS = wave_sum_dpp(dS);
     unsigned done = 0;
     if (threadIdx.x == 0) {
         double* o = ws + (int64_t)blockIdx.x * 4;      // slot 3: sum of squared errors (MSE mode)
@@ -997,19 +1103,34 @@ __device__ __forceinline__ void tile_partial_and_finish(double dL, double dV, do
         __hip_atomic_store(o + 1, dV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(o + 2, dP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(o + 3, dS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial has landed before the tile count moves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial (and the verification's atomics) have landed
+        WDF_DBG_STAMP(4);                                    // before the tile count moves
         done = atomicAdd(&tickets[0], 1u);
     }
     done = __builtin_amdgcn_readfirstlane(done);
+    WDF_DBG_STAMP(5);
     if (done != ntiles - 1) return;
     if (threadIdx.x == 0) tickets[0] = 0u;
+    const AdamFetched af = adam_tail_fetch(adam);            // (in flight under the reduction)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // every other tile's partial (this CU's L1 may be stale)
     const double* wsr = ws;                                  // (read through a pointer without __restrict__'s no-alias promise)
-    grad_reduce_block<64>(wsr, (int)ntiles, theta, fs, dyn_r, gtheta, accumulate, sse_out, sh);
-    if (adam.theta != nullptr) {
-        __syncthreads();
-        adam_tail_apply(adam, gtheta);
+    // one wave: lane i takes tiles i, i + 64, ... in order, then the fixed-order wave sum; every lane forms the chain rule
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (unsigned i = threadIdx.x; i < ntiles; i += 64) {
+        s0 += wsr[(int64_t)i * 4 + 0]; s1 += wsr[(int64_t)i * 4 + 1]; s2 += wsr[(int64_t)i * 4 + 2]; s3 += wsr[(int64_t)i * 4 + 3];
     }
+    s0 = wave_sum_dpp(s0); s1 = wave_sum_dpp(s1); s2 = wave_sum_dpp(s2); s3 = wave_sum_dpp(s3);
+    double g[4];
+    grad_chain_rule_d(s0, s1, s2, theta, fs, dyn_r, g);
+    const int c = threadIdx.x < 4 ? threadIdx.x : 3;
+    const float gi = (accumulate ? gtheta[c] : 0.0f) + (float)(c == 0 ? g[0] : (c == 1 ? g[1] : (c == 2 ? g[2] : g[3])));
+    if (threadIdx.x < 4) gtheta[threadIdx.x] = gi;
+    if (threadIdx.x == 0 && sse_out) *sse_out = (float)s3;
+    (void)sh;
+    tp_finish_deferred(fc, theta);                           // (reads theta: before the update below)
+    WDF_DBG_STAMP(6);
+    if (adam.theta != nullptr) adam_tail_apply(adam, af, gi);
+    WDF_DBG_STAMP(7);
 }
 
 // The tail of the reverse sweep.  Every chunk wave publishes its record (write-through stores), then

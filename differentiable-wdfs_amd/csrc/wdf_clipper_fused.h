@@ -38,12 +38,27 @@
 
 namespace wdf {
 
-#ifdef WDF_DBG_TIMES      // tools/dbg_times.py: per-wave start / end wall clock of the main body (build with -DWDF_DBG_TIMES)
-__device__ unsigned long long* g_dbg_times = nullptr;
-#endif
-constexpr int kFsOut = 9;       // record floats per (chunk, sequence), MSE: {A, c[3], GA, G[3], SSE}
-constexpr int kFsOutEsr = 14;   // MSE + ESR adds the y-weighted sums {HA, H[3], SYY}
-template <int LOSS> struct FusedRec { static constexpr int N = LOSS == 2 ? kFsOutEsr : kFsOut; };
+// What a chunk hands to its tile's combine.  Per (chunk, sequence) -- the part that depends on the tangent sigma entering
+// the chunk, which is only known once the chunks before it have been walked: the record {A, c[3], GA} (MSE + ESR: + HA).
+// Per (chunk, tile) -- everything that does not: {G[3], SSE} (MSE + ESR: + {H[3], SYY}) summed over the wave's sequences by
+// the chunk wave itself, in double, one set per sequence slot of a lane (so that a repair can replace one slot's share).
+// (Round 2 kept all nine / fourteen values per sequence: the walk of the tile's last wave, on the step's critical path,
+// moved 9 K floats per sequence in four dependent round trips at K = 32; now 5 K in two.)
+constexpr int kFsOut = 5;       // record floats per (chunk, sequence), MSE: {A, c[3], GA}
+constexpr int kFsOutEsr = 6;    // MSE + ESR adds HA
+constexpr int kFsPart = 4;      // per-wave sums, MSE: {G[3], SSE}
+constexpr int kFsPartEsr = 8;   // MSE + ESR adds {H[3], SYY}
+template <int LOSS> struct FusedRec {
+    static constexpr int N = LOSS == 2 ? kFsOutEsr : kFsOut;
+    static constexpr int NP = LOSS == 2 ? kFsPartEsr : kFsPart;
+};
+// The records live in 16-byte granules, one lane's sequences back to back: float4 [K][kFsQuads][lanes], lanes = 64 x tiles of
+// the launch.  A lane stores / loads its chunk record with <= 3 instructions (two sequences x 5 or 6 floats = 10 or 12), and
+// the walk of a tile's 32 chunks is 96 loads in flight in two batches -- a wave holds at most 63 outstanding memory
+// instructions, which is what made the dword layout's 288 (round 2) and 160 loads four round trips.
+constexpr int kFsQuads = 3;
+template <int NSEQ, int LOSS> struct FusedQuads { static constexpr int NQ = (NSEQ * FusedRec<LOSS>::N + 3) / 4; };
+__device__ __forceinline__ float* rec_chunk(float* rec, int64_t k) { return rec + (size_t)k * kFsQuads * ((size_t)gridDim.x * 64) * 4; }
 constexpr int kFusedSchedGroup = 1;   // steps the instruction scheduler may interleave
 // Build-time knobs of the A/B runs recorded in DESIGN.md (tools/ab_libs.sh builds variants with -D...)
 #ifndef WDF_FUSED_ROWS
@@ -134,13 +149,29 @@ __device__ __forceinline__ void buf_load(v2f& v, __amdgpu_buffer_rsrc_t rs, uint
     v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, boff, soff, 0));
 }
 // aux 2: nt (streaming output, not read again by this kernel)
+#ifndef WDF_FUSED_Y_AUX
+#define WDF_FUSED_Y_AUX 2           // (A/B: 16 = sc1, write-through at agent scope; 18 = nt | sc1)
+#endif
 __device__ __forceinline__ void buf_store_nt(float v, __amdgpu_buffer_rsrc_t rs, uint32_t boff, uint32_t soff)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, boff, soff, 2);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, boff, soff, WDF_FUSED_Y_AUX);
 }
 __device__ __forceinline__ void buf_store_nt(v2f v, __amdgpu_buffer_rsrc_t rs, uint32_t boff, uint32_t soff)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), rs, boff, soff, 2);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), rs, boff, soff, WDF_FUSED_Y_AUX);
+}
+
+// 16-byte write-through store / load at agent scope (`buffer_store_dwordx4 ... sc1` / `buffer_load_dwordx4 ... sc1`): how a
+// wave hands data to another wave of the same launch (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 on both sides).
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void publish_quad(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, const float (&f)[4])
+{
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])},
+                                           rs, voff, soff, 16);
+}
+__device__ __forceinline__ v4u load_published_quad(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16);
 }
 
 template <typename V, int NR>
@@ -333,25 +364,53 @@ struct FusedSums {
     }
 };
 
-// the chunk's record (write-through: another wave of this launch reads it)
-template <typename V, int LOSS>
-__device__ __forceinline__ void fused_publish_record(float* rec, int64_t k, int64_t b, int64_t B, const FusedTan<V>& s,
-                                                     const FusedSums<V>& d, float hgs)
+// The chunk's hand-over (write-through: another wave of this launch reads it): the per-sequence record and the wave's own
+// sums.  wpart: double [tiles][K][NSEQ][NP]; `slot0`: the first sequence slot this call covers (the repair re-runs one slot
+// of 64 sequences at a time with V = float).  Dead lanes (past the end of the batch) add nothing to the sums and keep a
+// record slot of their own.
+template <typename V, int LOSS, int NSEQ>
+__device__ __forceinline__ void fused_publish_record(float* rec, double* wpart, int64_t k, int64_t K, bool live,
+                                                     int slot0, const FusedTan<V>& s, const FusedSums<V>& d, float hgs)
 {
-    constexpr int NREC = FusedRec<LOSS>::N;
+    constexpr int NREC = FusedRec<LOSS>::N, NP = FusedRec<LOSS>::NP, NQ = FusedQuads<NSEQ, LOSS>::NQ;
     const double inv = hgs != 0.0f ? 1.0 / (double)hgs : 0.0;
+    const uint32_t lanes = gridDim.x * 64u, lane = blockIdx.x * 64u + threadIdx.x;
+    float* chunk = rec_chunk(rec, k);
+    float f[NQ * 4];
+#pragma unroll
+    for (int i = 0; i < NQ * 4; ++i) f[i] = 0.0f;
 #pragma unroll
     for (int j = 0; j < VT<V>::N; ++j) {
         // the boundary term of the summation by parts: s[t1] hg_{t1-1}
         const double h = (double)vget(s.hg_prev, j), h2 = (double)vget(s.hy_prev, j);
         const float A = vget(s.A, j), cL = vget(s.cL, j), cV = vget(s.cV, j), cP = vget(s.cP, j);
-        const float v[kFsOutEsr] = {A, cL, cV, cP, (float)(d.GA[j] + h * A), (float)(d.GL[j] + h * cL), (float)(d.GV[j] + h * cV),
-                                    (float)(d.GP[j] + h * cP), (float)(d.sse[j] * inv),
-                                    (float)(d.HA[j] + h2 * A), (float)(d.HL[j] + h2 * cL), (float)(d.HV[j] + h2 * cV),
-                                    (float)(d.HP[j] + h2 * cP), (float)(d.syy[j] * inv)};
-        float* o = rec + (k * NREC) * B + b + j;
+        const float v[kFsOutEsr] = {A, cL, cV, cP, (float)(d.GA[j] + h * A), (float)(d.HA[j] + h2 * A)};
+        if constexpr (VT<V>::N == NSEQ) {
 #pragma unroll
-        for (int i = 0; i < NREC; ++i) __hip_atomic_store(o + i * B, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < NREC; ++i) f[j * NREC + i] = v[i];
+        } else {                                             // one slot of the lane's granules (the repair's re-run)
+#pragma unroll
+            for (int i = 0; i < NREC; ++i) {
+                const int e = (slot0 + j) * NREC + i;
+                __hip_atomic_store(chunk + ((size_t)(e >> 2) * lanes + lane) * 4 + (e & 3), v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        double p[kFsPartEsr] = {d.GL[j] + h * cL, d.GV[j] + h * cV, d.GP[j] + h * cP, d.sse[j] * inv,
+                                d.HL[j] + h2 * cL, d.HV[j] + h2 * cV, d.HP[j] + h2 * cP, d.syy[j] * inv};
+        double* w = wpart + (((int64_t)blockIdx.x * K + k) * NSEQ + slot0 + j) * NP;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const double t = wave_sum_dpp(live ? p[i] : 0.0);
+            if (threadIdx.x == 0) __hip_atomic_store(w + i, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (VT<V>::N == NSEQ) {
+        const __amdgpu_buffer_rsrc_t rs = row_rsrc(chunk);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float g[4] = {f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
+            publish_quad(rs, lane * 16u, (uint32_t)q * lanes * 16u, g);
+        }
     }
 }
 
@@ -363,7 +422,8 @@ __device__ __forceinline__ void clipper_fused_body(
     const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ target,
     float* __restrict__ y, float* __restrict__ zstash, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
     float* __restrict__ zend, float* rec, const float* __restrict__ theta, const TpCtl* __restrict__ ctl,
-    float* __restrict__ snap, int J, int64_t B, int64_t T, int64_t L, int64_t W, float hgs, int64_t skip, int64_t skew = 0)
+    float* __restrict__ snap, int J, int64_t B, int64_t T, int64_t L, int64_t W, float hgs, int64_t skip, int64_t skew = 0,
+    double* wpart = nullptr)
 {
     constexpr int NR = FusedTile<V, DYN_R>::NR;
 #ifdef WDF_DBG_TIMES
@@ -381,7 +441,7 @@ __device__ __forceinline__ void clipper_fused_body(
     const int head = stateful ? ctl->head : 0;
     if (k > 0 && valid > 0) {                               // warm start (see clipper_fwd_tp_body)
         const int j = ctl->j_next;
-        tw = t0 - (int64_t)kTile * j;
+        tw = t0 - (int64_t)kWarmStep * j;
         z = load_own<V>(snap + (((int64_t)head * J + j) * K + (k - 1)) * B, q);
         if (valid > 1) {
             const V zo = load_own<V>(snap + (((int64_t)((head + kTpRing - 1) % kTpRing) * J + j) * K + (k - 1)) * B, q);
@@ -438,8 +498,8 @@ __device__ __forceinline__ void clipper_fused_body(
 #pragma unroll
         for (int i = 0; i < NR; ++i) { xc[i] = xn[i]; gc[i] = gn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
         const bool more = t + NR < nfull_end;
-        if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1) && (t1 - t) % kTile == 0)
-            store_own<V>(snapw + ((t1 - t) / kTile) * K * B, q, z);       // snapshot 32 j steps before the chunk's end
+        if (snapw != nullptr && t1 - t <= (int64_t)kWarmStep * (J - 1) && (t1 - t) % kWarmStep == 0)
+            store_own<V>(snapw + ((t1 - t) / kWarmStep) * K * B, q, z);   // snapshot kWarmStep j steps before the chunk's end
         const __amdgpu_buffer_rsrc_t ry = row_rsrc(y + t * B);
         const __amdgpu_buffer_rsrc_t rz = row_rsrc(STASH ? zstash + t * B : y + t * B);
         // steps of this tile below `skip` carry no loss (skip_samples = 50, clipper_pot.py:232): their number, a scalar
@@ -501,7 +561,7 @@ __device__ __forceinline__ void clipper_fused_body(
     publish_own<V>(zend + k * B, q, z);
     if (snapw != nullptr) store_own<V>(snapw, q, z);
     if (zT && t1 == T) store_own<V>(zT, q, z);
-    if constexpr (LOSS != 0) fused_publish_record<V, LOSS>(rec, k, q.b, B, s, d, hgs);
+    if constexpr (LOSS != 0) fused_publish_record<V, LOSS, VT<V>::N>(rec, wpart, k, K, q.live, 0, s, d, hgs);
 #ifdef WDF_DBG_TIMES
     dbg_p[4] = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0 && g_dbg_times) {
@@ -519,6 +579,7 @@ __device__ __forceinline__ void clipper_fused_body(
 struct FusedOut {
     float* gtheta; int accumulate; float* sse_out; AdamTail adam;
     double n_global, eps; float* sums10; float* loss3;
+    TpFinishCtx fc;             // filled in by the kernels: the verification's deferred half
 };
 
 // MSE + ESR: the tile's eight sums -> its slot of ws (8 doubles per tile); the LAST tile reduces over the tiles in a fixed
@@ -529,7 +590,7 @@ __device__ __forceinline__ void esr_tile_partial_and_finish(const double (&v)[8]
     const unsigned ntiles = gridDim.x;
     double w[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = wave_sum(v[i]);
+    for (int i = 0; i < 8; ++i) w[i] = wave_sum_dpp(v[i]);
     unsigned done = 0;
     if (threadIdx.x == 0) {
         double* o = ws + (int64_t)blockIdx.x * 8;
@@ -541,6 +602,7 @@ __device__ __forceinline__ void esr_tile_partial_and_finish(const double (&v)[8]
     done = __builtin_amdgcn_readfirstlane(done);
     if (done != ntiles - 1) return;
     if (threadIdx.x == 0) gticket[0] = 0u;
+    const AdamFetched af = adam_tail_fetch(out.gtheta != nullptr ? out.adam : AdamTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, 0.0f, nullptr, nullptr});
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const double* wsr = ws;
     double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -548,88 +610,121 @@ __device__ __forceinline__ void esr_tile_partial_and_finish(const double (&v)[8]
 #pragma unroll
         for (int j = 0; j < 8; ++j) t[j] += wsr[(int64_t)i * 8 + j];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = wave_sum(t[j]);
-    if (threadIdx.x == 0) {
-        // t = {P_L, P_V, P_P, S, Q_L, Q_V, Q_P, E}
-        double gP[4], gQ[4];
-        grad_chain_rule_d(t[0], t[1], t[2], theta, fs, dyn_r, gP);
-        grad_chain_rule_d(t[4], t[5], t[6], theta, fs, dyn_r, gQ);
-        out.sums10[0] = (float)t[3];
-        out.sums10[1] = (float)t[7];
-        for (int k = 0; k < 4; ++k) { out.sums10[2 + k] = (float)gP[k]; out.sums10[6 + k] = (float)gQ[k]; }
-        if (out.gtheta != nullptr) {
-            const double n = out.n_global, S = t[3], E = t[7] + out.eps;
-            const double mse = S / n, esr = sqrt(S / E / n);
-            const double ga = 2.0 / n + (esr > 0.0 ? 1.0 / (esr * E * n) : 0.0), gb = -esr / E;
-            for (int k = 0; k < 4; ++k)
-                out.gtheta[k] = (out.accumulate ? out.gtheta[k] : 0.0f) + (float)(ga * gP[k] + gb * gQ[k]);
-            if (out.loss3) { out.loss3[0] = (float)mse; out.loss3[1] = (float)esr; out.loss3[2] = (float)(mse + esr); }
-        }
+    for (int j = 0; j < 8; ++j) t[j] = wave_sum_dpp(t[j]);
+    // t = {P_L, P_V, P_P, S, Q_L, Q_V, Q_P, E}; every lane forms the chain rule, lanes 0..3 keep their component
+    double gP[4], gQ[4];
+    grad_chain_rule_d(t[0], t[1], t[2], theta, fs, dyn_r, gP);
+    grad_chain_rule_d(t[4], t[5], t[6], theta, fs, dyn_r, gQ);
+    const int c = threadIdx.x < 4 ? threadIdx.x : 3;
+    const double gPc = c == 0 ? gP[0] : (c == 1 ? gP[1] : (c == 2 ? gP[2] : gP[3]));
+    const double gQc = c == 0 ? gQ[0] : (c == 1 ? gQ[1] : (c == 2 ? gQ[2] : gQ[3]));
+    if (threadIdx.x == 0) { out.sums10[0] = (float)t[3]; out.sums10[1] = (float)t[7]; }
+    if (threadIdx.x < 4) { out.sums10[2 + threadIdx.x] = (float)gPc; out.sums10[6 + threadIdx.x] = (float)gQc; }
+    float gi = 0.0f;
+    if (out.gtheta != nullptr) {
+        const double n = out.n_global, S = t[3], E = t[7] + out.eps;
+        const double mse = S / n, esr = sqrt(S / E / n);
+        const double ga = 2.0 / n + (esr > 0.0 ? 1.0 / (esr * E * n) : 0.0), gb = -esr / E;
+        gi = (out.accumulate ? out.gtheta[c] : 0.0f) + (float)(ga * gPc + gb * gQc);
+        if (threadIdx.x < 4) out.gtheta[threadIdx.x] = gi;
+        if (threadIdx.x == 0 && out.loss3) { out.loss3[0] = (float)mse; out.loss3[1] = (float)esr; out.loss3[2] = (float)(mse + esr); }
     }
-    if (out.gtheta != nullptr && out.adam.theta != nullptr) {
-        __syncthreads();                                     // (one-wave workgroup: orders lane 0's gtheta with the readers)
-        adam_tail_apply(out.adam, out.gtheta);
-    }
+    tp_finish_deferred(out.fc, theta);                       // (reads theta: before the update below)
+    if (out.gtheta != nullptr && out.adam.theta != nullptr) adam_tail_apply(out.adam, af, gi);
 }
 
 // The tile's K records in time order -> the tile's sums -> (last tile) the step's result.  NSEQ: sequences per lane.
 template <int NSEQ, int LOSS>
-__device__ __forceinline__ void fused_combine_tile(const float* rec, int64_t K, int64_t B, double* ws, unsigned* gticket,
-                                                   const float* theta, float fs, int dyn_r, const FusedOut& out, double (*sh)[4])
+__device__ __forceinline__ void fused_combine_tile(float* rec, double* wpart, int64_t K, int64_t B, double* ws,
+                                                   unsigned* gticket, const float* theta, float fs, int dyn_r, const FusedOut& out,
+                                                   double (*sh)[4])
 {
-    constexpr int NREC = FusedRec<LOSS>::N;
+    constexpr int NREC = FusedRec<LOSS>::N, NP = FusedRec<LOSS>::NP, NQ = FusedQuads<NSEQ, LOSS>::NQ;
     const int64_t raw = ((int64_t)blockIdx.x * 64 + threadIdx.x) * NSEQ;
     const bool live = raw < B;
-    const int64_t b0 = live ? raw : B - NSEQ;
+    const uint32_t lanes = gridDim.x * 64u, lane = blockIdx.x * 64u + threadIdx.x;
     double dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0, qL = 0.0, qV = 0.0, qP = 0.0, qE = 0.0;
     double sL[NSEQ], sV[NSEQ], sP[NSEQ];                  // tangent entering the chunk (z0 does not depend on theta)
 #pragma unroll
     for (int h = 0; h < NSEQ; ++h) sL[h] = sV[h] = sP[h] = 0.0;
-    // records of kAhead chunks in flight together, the lane's NSEQ adjacent sequences in one load each: the walk is
-    // K / kAhead dependent round trips on the step's critical path (the last tile's tail)
-    constexpr int kAhead = LOSS == 2 ? 4 : 8;
-    auto step = [&](const float (&v)[NREC][NSEQ]) {
+    // The chunk waves' own sums (no dependence on sigma): lane i takes chunk i -- fetched FIRST, in flight under the walk.
+    constexpr int NW = NSEQ * NP / 2;                     // 16-byte loads per chunk
+    const __amdgpu_buffer_rsrc_t rw = row_rsrc(reinterpret_cast<float*>(wpart + (int64_t)blockIdx.x * K * NSEQ * NP));
+    v4u wq[NW];
+    const uint32_t kk0 = threadIdx.x < K ? threadIdx.x : (uint32_t)K - 1;      // (lanes past K re-read the last chunk, unused)
+#pragma unroll
+    for (int i = 0; i < NW; ++i) wq[i] = load_published_quad(rw, kk0 * (uint32_t)(NSEQ * NP * 8) + 16u * i, 0);
+    auto add_part = [&](const v4u (&w)[NW]) {
 #pragma unroll
         for (int h = 0; h < NSEQ; ++h) {
-            const double A = v[0][h], GA = v[4][h];
-            dL += sL[h] * GA + (double)v[5][h];
-            dV += sV[h] * GA + (double)v[6][h];
-            dP += sP[h] * GA + (double)v[7][h];
-            dS += (double)v[8][h];
-            if constexpr (LOSS == 2) {
-                const double HA = v[9][h];
-                qL += sL[h] * HA + (double)v[10][h];
-                qV += sV[h] * HA + (double)v[11][h];
-                qP += sP[h] * HA + (double)v[12][h];
-                qE += (double)v[13][h];
+            double p[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int e = h * NP + i;                 // double e of the chunk's block = dwords 2e, 2e + 1
+                p[i] = __hiloint2double((int)w[e / 2][(e % 2) * 2 + 1], (int)w[e / 2][(e % 2) * 2]);
             }
-            sL[h] = A * sL[h] + (double)v[1][h];
-            sV[h] = A * sV[h] + (double)v[2][h];
-            sP[h] = A * sP[h] + (double)v[3][h];
+            dL += p[0]; dV += p[1]; dP += p[2]; dS += p[3];
+            if constexpr (LOSS == 2) { qL += p[4]; qV += p[5]; qP += p[6]; qE += p[7]; }
+        }
+    };
+    // records of kAhead chunks in flight together (3 x 16 bytes per lane and chunk: 48 loads + the sums' <= 8): the walk is
+    // K / kAhead dependent round trips on the step's critical path (the last tile's tail)
+    constexpr int kAhead = 16;
+    auto step = [&](const v4u (&g)[NQ]) {
+        float v[NQ * 4];
+#pragma unroll
+        for (int i = 0; i < NQ * 4; ++i) v[i] = __uint_as_float(g[i / 4][i % 4]);
+#pragma unroll
+        for (int h = 0; h < NSEQ; ++h) {
+            const float* r = v + h * NREC;
+            const double A = r[0], GA = r[4];
+            dL += sL[h] * GA;
+            dV += sV[h] * GA;
+            dP += sP[h] * GA;
+            if constexpr (LOSS == 2) {
+                const double HA = r[5];
+                qL += sL[h] * HA;
+                qV += sV[h] * HA;
+                qP += sP[h] * HA;
+            }
+            sL[h] = A * sL[h] + (double)r[1];
+            sV[h] = A * sV[h] + (double)r[2];
+            sP[h] = A * sP[h] + (double)r[3];
         }
     };
     int64_t k = 0;
     for (; k + kAhead <= K; k += kAhead) {
-        float v[kAhead][NREC][NSEQ];
+        v4u g[kAhead][NQ];
 #pragma unroll
-        for (int j = 0; j < kAhead; ++j)
+        for (int j = 0; j < kAhead; ++j) {
+            const __amdgpu_buffer_rsrc_t rs = row_rsrc(rec_chunk(rec, k + j));
 #pragma unroll
-            for (int i = 0; i < NREC; ++i) load_published_n<NSEQ>(rec + ((k + j) * NREC + i) * B + b0, v[j][i]);
+            for (int q = 0; q < NQ; ++q) g[j][q] = load_published_quad(rs, lane * 16u, (uint32_t)q * lanes * 16u);
+        }
 #pragma unroll
-        for (int j = 0; j < kAhead; ++j) step(v[j]);
+        for (int j = 0; j < kAhead; ++j) step(g[j]);
     }
     for (; k < K; ++k) {
-        float v[NREC][NSEQ];
+        v4u g[NQ];
+        const __amdgpu_buffer_rsrc_t rs = row_rsrc(rec_chunk(rec, k));
 #pragma unroll
-        for (int i = 0; i < NREC; ++i) load_published_n<NSEQ>(rec + (k * NREC + i) * B + b0, v[i]);
-        step(v);
+        for (int q = 0; q < NQ; ++q) g[q] = load_published_quad(rs, lane * 16u, (uint32_t)q * lanes * 16u);
+        step(g);
     }
+    WDF_DBG_STAMP(3);
     if (!live) { dL = dV = dP = dS = qL = qV = qP = qE = 0.0; }
+    if (threadIdx.x < K) add_part(wq);
+    for (int64_t kk = threadIdx.x + 64; kk < K; kk += 64) {   // (more than 64 chunks: the rest, one round trip each)
+        v4u w2[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w2[i] = load_published_quad(rw, (uint32_t)kk * (uint32_t)(NSEQ * NP * 8) + 16u * i, 0);
+        add_part(w2);
+    }
     if constexpr (LOSS == 2) {
         const double v8[8] = {dL, dV, dP, dS, qL, qV, qP, qE};
         esr_tile_partial_and_finish(v8, ws, gticket, theta, fs, dyn_r, out);
     } else {
-        tile_partial_and_finish(dL, dV, dP, dS, ws, gticket, theta, fs, dyn_r, out.gtheta, out.accumulate, out.sse_out, out.adam, sh);
+        tile_partial_and_finish(dL, dV, dP, dS, ws, gticket, theta, fs, dyn_r, out.gtheta, out.accumulate, out.sse_out, out.adam, sh, out.fc);
     }
 }
 
@@ -642,32 +737,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, const float* __restrict__ z0,
     float* __restrict__ zT, float* zwarm, float* zend, float* rec, TpStatus* __restrict__ status, TpCtl* ctl, float* snap,
     int J, unsigned* tickets, unsigned* gticket, float tol, int64_t B, int64_t T, int64_t L, int64_t W, int general,
-    double* ws, FusedOut out, int64_t skew)
+    double* ws, FusedOut out, int64_t skew, double* wpart)
 {
     __shared__ double sh[64][4];
 #ifdef WDF_DBG_TIMES
     const unsigned long long dbg_t0 = wall_clock64();
     const unsigned long long dbg_m0 = __builtin_amdgcn_s_memtime();
 #endif
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { status->fallback_ran = 0; status->pad = 0u; }   // (the repair launch counts)
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
     fast = fast_root_ok<DYN_R>(c, general);
     if (fast)
         clipper_fused_body<DYN_R, SYM, TM, VEC4, true, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
-                                                            T, L, W, hgs, skip, skew);
+                                                            T, L, W, hgs, skip, skew, wpart);
     else
         clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
-                                                           T, L, W, hgs, skip, skew);
+                                                           T, L, W, hgs, skip, skew, wpart);
 #ifdef WDF_DBG_TIMES
     if (threadIdx.x == 0 && g_dbg_times) {
         unsigned long long* dbg_o = g_dbg_times + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
         dbg_o[0] = dbg_t0; dbg_o[1] = wall_clock64(); dbg_o[3] = __builtin_amdgcn_s_memtime() - dbg_m0;
     }
 #endif
+    WDF_DBG_STAMP(0);
     if (!tp_tile_last(tickets)) return;
-    const bool failed = tp_verify_tile<DYN_R, VT<V>::N>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
+    WDF_DBG_STAMP(1);
+    // the tile adds its verification result to the accumulators; the status word and the warm-start steering are left to
+    // the wave that finishes the STEP (out.fc), here or in the repair launch
+    const bool failed = tp_verify_tile<DYN_R, VT<V>::N, true>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
+    WDF_DBG_STAMP(2);
     if (failed) return;                                     // left to clipper_fused_repair_kernel
-    fused_combine_tile<VT<V>::N, LOSS>(rec, gridDim.y, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, out, sh);
+    out.fc = TpFinishCtx{status, ctl, J, tickets, tol, (int64_t)gridDim.y, L, W};
+    fused_combine_tile<VT<V>::N, LOSS>(rec, wpart, gridDim.y, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, out, sh);
 }
 
 // The time-parallel FORWARD (wdf_clipper_fwd_tp / _warm: y and the state stash for a reverse sweep that arbitrary losses
@@ -695,21 +797,22 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
 }
 
 // Re-run of chunk [t0, t1) for 64 sequences (one per lane, index b) from the exact state z: outputs, snapshots, record.
-template <bool DYN_R, bool SYM, bool TM, bool FAST, int LOSS>
+template <bool DYN_R, bool SYM, bool TM, bool FAST, int LOSS, int NSEQ>
 __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r,
-                                                  const float* __restrict__ target, float* __restrict__ y, float* rec,
+                                                  const float* __restrict__ target, float* __restrict__ y, float* rec, double* wpart,
                                                   float* __restrict__ snapw, int J, int64_t K, int64_t k, int64_t b, int64_t B,
-                                                  int64_t T, int64_t t0, int64_t t1, float hgs, int64_t skip, float& z)
+                                                  bool live, int slot, int64_t T, int64_t t0, int64_t t1, float hgs, int64_t skip,
+                                                  float& z)
 {
     FusedTan<float> s;
     s.init();
     FusedSums<float> d;
     d.init();
     for (int64_t t = t0; t < t1; t += kBlk) {
-        if ((t - t0) % kTile == 0) {
+        if ((t - t0) % kWarmStep == 0) {
             d.template flush<LOSS>(s);
-            if (snapw != nullptr && t1 - t <= (int64_t)kTile * (J - 1) && (t1 - t) % kTile == 0)
-                snapw[((t1 - t) / kTile) * K * B + b] = z;
+            if (snapw != nullptr && t1 - t <= (int64_t)kWarmStep * (J - 1) && (t1 - t) % kWarmStep == 0)
+                snapw[((t1 - t) / kWarmStep) * K * B + b] = z;
         }
         float xv[kBlk], rv[kBlk], gv[kBlk];
 #pragma unroll
@@ -727,7 +830,7 @@ __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const flo
     }
     d.template flush<LOSS>(s);
     if (snapw != nullptr) snapw[b] = z;
-    fused_publish_record<float, LOSS>(rec, k, b, B, s, d, hgs);
+    fused_publish_record<float, LOSS, NSEQ>(rec, wpart, k, K, live, slot, s, d, hgs);
 }
 
 // Launched behind every fused step; a block leaves at once unless the step flagged its tile (the common
@@ -739,18 +842,22 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, float* __restrict__ zT,
     const float* zwarm, float* zend, float* rec, int64_t B, int64_t T, int64_t K, int64_t L, float tol,
-    TpStatus* __restrict__ status, const TpCtl* __restrict__ ctl, float* __restrict__ snap, int J, unsigned* tickets,
-    unsigned* gticket, int general, double* ws, FusedOut out, int64_t skew)
+    TpStatus* __restrict__ status, TpCtl* ctl, float* __restrict__ snap, int J, unsigned* tickets,
+    unsigned* gticket, int general, double* ws, FusedOut out, int64_t skew, double* wpart, int64_t W)
 {
     __shared__ double sh[64][4];
     unsigned* tile_bad = tickets + 4 + gridDim.x;
     if (tile_bad[blockIdx.x] == 0u) return;
     const int64_t raw = ((int64_t)blockIdx.x * 64 + threadIdx.x) * NSEQ;
-    const int64_t b0 = raw < B ? raw : B - NSEQ;
+    const bool live = raw < B;
+    const int64_t b0 = live ? raw : B - NSEQ;
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
     fast = fast_root_ok<DYN_R>(c, general);
-    const int slot = (ctl != nullptr && snap != nullptr) ? ctl->head : 0;     // the step advanced head to the slot it wrote
+    // The ring slot the step wrote its snapshots to.  The control block is advanced by the wave that FINISHES the step, and with
+    // a flagged tile that wave is the last of THIS launch's blocks to combine -- after every block has read this:
+    int slot = 0;
+    if (ctl != nullptr && snap != nullptr) slot = ((ctl->geom == (int)((K << 8) | J) ? ctl->head : 0) + 1) % kTpRing;
     int nrep = 0;
 #pragma unroll 1
     for (int h = 0; h < NSEQ; ++h) {
@@ -766,8 +873,8 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
             chunk_span(k, K, L, skew, T, t0, t1);
             float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
             float z = e;
-            if (fast) fused_rerun_chunk<DYN_R, SYM, TM, true, LOSS>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
-            else fused_rerun_chunk<DYN_R, SYM, TM, false, LOSS>(c, x, r, target, y, rec, snapw, J, K, k, b, B, T, t0, t1, hgs, skip, z);
+            if (fast) fused_rerun_chunk<DYN_R, SYM, TM, true, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+            else fused_rerun_chunk<DYN_R, SYM, TM, false, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
             zend[k * B + b] = z;
             if (zT && t1 == T) zT[b] = z;
             ze_fix = z;
@@ -780,7 +887,8 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
         if (nrep) atomicAdd(&status->fallback_ran, nrep);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the re-written records have landed (write-through)
-    fused_combine_tile<NSEQ, LOSS>(rec, K, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, out, sh);
+    out.fc = TpFinishCtx{status, ctl, J, tickets, tol, K, L, W};
+    fused_combine_tile<NSEQ, LOSS>(rec, wpart, K, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, out, sh);
 }
 
 }  // namespace wdf

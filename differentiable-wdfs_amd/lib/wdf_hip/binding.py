@@ -67,6 +67,9 @@ def lib():
     L.wdf_clipper_bwd_ws_bytes.argtypes = [i64]
     L.wdf_clipper_tp_chunks.restype = ci
     L.wdf_clipper_tp_chunks.argtypes = [i64, ci]
+    if hasattr(L, "wdf_clipper_tp_warm_unit"):            # (absent from round-2 builds kept around for A/B runs: WDF_HIP_LIB)
+        L.wdf_clipper_tp_warm_unit.restype = ci
+        L.wdf_clipper_tp_warm_unit.argtypes = []
     L.wdf_clipper_fwd_tp_ws_bytes.restype = C.c_size_t
     L.wdf_clipper_fwd_tp_ws_bytes.argtypes = [i64, ci]
     L.wdf_clipper_fwd_tp.restype = ci
@@ -195,7 +198,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "wdf_abi_version", "wdf_last_error", "wdf_device_info",
     "wdf_clipper_fwd", "wdf_clipper_bwd", "wdf_clipper_bwd_ws_bytes",
-    "wdf_clipper_tp_chunks", "wdf_clipper_fwd_tp_ws_bytes", "wdf_clipper_fwd_tp",
+    "wdf_clipper_tp_chunks", "wdf_clipper_tp_warm_unit", "wdf_clipper_fwd_tp_ws_bytes", "wdf_clipper_fwd_tp",
     "wdf_clipper_fwd_tp_state_bytes", "wdf_clipper_fwd_tp_state_reset", "wdf_clipper_fwd_tp_warm",
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp_ws_init", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_bwd_mse_tp_adam", "wdf_clipper_step_mse_tp_ws_bytes", "wdf_clipper_step_mse_tp_ws_init",
@@ -307,12 +310,14 @@ class TpWarmState:
     (include/wdf_hip.h, wdf_clipper_fwd_tp_warm): control block + snapshot ring on the device."""
 
     def __init__(self, B, T, n_chunks, max_warm_tiles, device, min_warm_tiles=0):
+        """max_warm_tiles / min_warm_tiles: in warm-start units of warm_unit() steps (16)."""
         L = lib()
         self.K = L.wdf_clipper_tp_chunks(int(T), int(n_chunks))
         chunk_len = -(-(-(-int(T) // max(1, int(n_chunks)))) // 32) * 32        # as the library rounds it
         # snapshots reach back at most three quarters of a chunk: the one-pass step may shorten the younger chunks by a quarter
         # (skewed spans, csrc/wdf_clipper_fused.h chunk_span) and they must still hold every snapshot
-        self.max_warm_tiles = max(1, min(int(max_warm_tiles), 16, (3 * chunk_len // 4) // 32))
+        self.unit = warm_unit()
+        self.max_warm_tiles = max(1, min(int(max_warm_tiles), 32, (3 * chunk_len // 4) // self.unit))
         self.B, self.T, self.n_chunks = int(B), int(T), int(n_chunks)
         self.min_warm_tiles = max(0, min(int(min_warm_tiles), self.max_warm_tiles))
         self.buf = torch.empty((L.wdf_clipper_fwd_tp_state_bytes(self.B, self.K, self.max_warm_tiles),),
@@ -329,7 +334,13 @@ class TpWarmState:
         c = self.buf[:64].cpu()
         i, f = c.view(torch.int32), c.view(torch.float32)
         return {"valid": int(i[0]), "next_warm_tiles": int(i[2]), "last_warm_tiles": int(i[3]),
-                "last_miss": float(f[12]), "n_calls": int(i[13])}
+                "last_miss": float(f[12]), "n_calls": int(i[13]), "warm_unit_steps": self.unit}
+
+
+def warm_unit():
+    """Steps per warm-start unit ("warm tile") of the time-parallel clipper kernels."""
+    L = lib()
+    return int(L.wdf_clipper_tp_warm_unit()) if hasattr(L, "wdf_clipper_tp_warm_unit") else 32
 
 
 def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_down=1, want_stash=True, z0=None,

@@ -230,7 +230,7 @@ class MseStep:
     for all 501 epochs, clipper_pot.py:245-248), giving fully coalesced loads."""
 
     def __init__(self, B, T, fs, tp, device, n_up=1, n_down=1, n_global=None, time_major=False, loss="mse",
-                 skip=0, sums_allreduce=None, warm=False, max_warm_tiles=8):
+                 skip=0, sums_allreduce=None, warm=False, max_warm_tiles=16):
         """loss: "mse" (mean over n_global samples) or "mse+esr", the training loss of
         clipper_pot.py:177 evaluated past `skip` samples (:232,248; n_global then counts the samples
         past skip over all ranks).  sums_allreduce: in-place SUM all-reduce for the two float64 loss
@@ -265,7 +265,7 @@ class MseStep:
         self.ws_s, self.ws_s_k = None, None          # workspace of step_fused (made on first use)
         self.warm = None
         if warm and tp is not None and tp.k_fwd > 1:
-            self.warm = binding.TpWarmState(B, T, tp.k_fwd, max(max_warm_tiles, -(-tp.warmup // 32)), device)
+            self.warm = binding.TpWarmState(B, T, tp.k_fwd, max(max_warm_tiles, -(-tp.warmup // binding.warm_unit())), device)
 
     def reset_warm(self):
         if self.warm is not None:
@@ -398,7 +398,7 @@ def autotune_time_parallel(theta, x, target, fs, plan, time_major=False, n_up=1,
     return plan._replace(k_fwd=best_f, k_bwd=best_b)
 
 
-def autotune_fused(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=1, reps=7, r=None):
+def autotune_fused(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=1, reps=7, r=None, warm=True):
     """The chunk count of the one-pass step (MseStep.step_fused), by timing the planned count, half and double
     on the actual batch (median of single-launch timings of the warm-started step, as the training loop will run it)."""
     if plan is None:
@@ -423,7 +423,7 @@ def autotune_fused(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=
     planned = plan.k_fwd * 2 if (B % 2 == 0 and not binding.ONE_SEQUENCE_PER_LANE and plan.k_fwd * 2 <= k_cap) else plan.k_fwd
     times = {}
     for k in sorted({k for k in (max(1, planned // 2), planned, planned * 2) if k == 1 or k <= k_cap}):
-        st = MseStep(B, T, fs, plan._replace(k_fwd=k), x.device, n_up=n_up, n_down=n_down, time_major=time_major, warm=True)
+        st = MseStep(B, T, fs, plan._replace(k_fwd=k), x.device, n_up=n_up, n_down=n_down, time_major=time_major, warm=warm)
         times[k] = timed(lambda: st.step_fused(theta, x, target, r))
         if binding.tp_status(st.status)["n_bad"]:
             del times[k]                     # a chunking whose speculation fails on this data is not a candidate
@@ -471,29 +471,33 @@ def clipper_mse(theta, x, target, fs, r=None, n_up=1, n_down=1, tp=None, time_ma
     return _ClipperMseFn.apply(theta, x, r, target, float(fs), int(n_up), int(n_down), tp, bool(time_major))
 
 
-_TUNED = {}      # (B, T, n_up, n_down, per-sample R?, R, C, Is, nVt to 2 digits, fs, device, layout) -> TpPlan
+_TUNED = {}      # (B, T, n_up, n_down, per-sample R?, R, C to 2 digits, fs, device, layout, consumer) -> TpPlan
 
 
-def tuned_plan(theta, x, r, fs, R_plan, C, n_up=1, n_down=1, min_samples=1 << 22, time_major=False, R_min=None):
-    """plan_time_parallel, refined once per (shape, circuit) by autotune_time_parallel when the batch
-    is large enough for the ~0.1 s of set-up to pay (>= 4 M samples); later calls with the same
-    shape and (to two digits) the same R and C reuse the result.  Training moves R and C slowly and
-    every forward is still verified, so a plan tuned at the first epoch stays valid."""
+def tuned_plan(theta, x, r, fs, R_plan, C, n_up=1, n_down=1, min_samples=1 << 22, time_major=False, R_min=None, fused=False):
+    """plan_time_parallel, refined once per (shape, circuit) by timing candidates on the batch when it is large enough for
+    the ~0.1 s of set-up to pay (>= 4 M samples); later calls with the same shape and (to two digits) the same R and C
+    reuse the result.  fused: the consumer is the one-pass training step (clipper_mse) -- its chunk count is what is
+    tuned (autotune_fused); otherwise the forward / reverse-sweep pair (autotune_time_parallel).
+    The key is built from values the caller holds on the HOST (R_plan, C: floats); theta is a device tensor and is only
+    handed to the kernels on a miss -- a hit costs no device-to-host copy, no synchronisation.  The diode's own
+    parameters are not part of the key: they do not enter the warm-up estimate, training moves them slowly, and every
+    forward is verified whatever the plan."""
     B, T = (x.shape[1], x.shape[0]) if time_major else x.shape
     plan = plan_time_parallel(B, T, R_plan, C, fs, time_major=time_major, R_min=R_min)
     if B * T < min_samples or plan.k_fwd < 2:
         return plan
-    th = [float(v) for v in theta.detach().cpu()]
-    key = (B, T, n_up, n_down, r is not None, f"{R_plan:.1e}", f"{C:.1e}", f"{th[0]:.1e}", f"{th[1]:.1e}", float(fs),
-           str(x.device), time_major)
-    if key not in _TUNED:
+    key = (B, T, n_up, n_down, r is not None, f"{R_plan:.1e}", f"{C:.1e}", float(fs), str(x.device), time_major, bool(fused))
+    hit = _TUNED.get(key)
+    if hit is None:
         if len(_TUNED) > 32:
             _TUNED.clear()
         with torch.no_grad():
             zero_target = torch.zeros((T, B), dtype=torch.float32, device=x.device)
-            _TUNED[key] = autotune_time_parallel(theta.detach(), x, zero_target, fs, plan, time_major=time_major,
-                                                 n_up=n_up, n_down=n_down, reps=5, r=r)
-    return _TUNED[key]
+            tune = autotune_fused if fused else autotune_time_parallel
+            hit = _TUNED[key] = tune(theta.detach(), x, zero_target, fs, plan, time_major=time_major,
+                                     n_up=n_up, n_down=n_down, reps=5, r=r)
+    return hit
 
 
 def _pick(times, planned):

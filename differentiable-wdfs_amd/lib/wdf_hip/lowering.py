@@ -163,7 +163,7 @@ class Circuit:
         tp = self.time_parallel
         if tp == "auto":
             tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, float(cap.C), n_up=dp.N_up, n_down=dp.N_down,
-                                   time_major=True, R_min=None if r is None else engine.resistance_min(r))
+                                   time_major=True, R_min=None if r is None else engine.resistance_min(r), fused=True)
         loss = engine.clipper_mse(theta, xv, tgt, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp,
                                   time_major=True)
         return loss.as_subclass(tf.Tensor)

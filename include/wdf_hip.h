@@ -127,10 +127,12 @@ size_t wdf_clipper_bwd_ws_bytes(int64_t B);
  *   (clipper_pot.py:245-269): each call leaves snapshots of every chunk's state near its end,
  *   the next call starts its chunks from them (extrapolated along the parameter path from the
  *   last two calls) and runs only the few warm-up tiles the measured boundary miss asks
- *   for -- steered on the device, between 0 and max_warm_tiles tiles of 32 steps (the first call
- *   after a reset is a cold one with `warmup`).  Same verification, same guarantee.
+ *   for -- steered on the device, between 0 and max_warm_tiles units of wdf_clipper_tp_warm_unit()
+ *   steps (16; max_warm_tiles <= 32; the first call after a reset is a cold one with `warmup`).
+ *   Same verification, same guarantee.
  * ---------------------------------------------------------------------------------- */
 int wdf_clipper_tp_chunks(int64_t T, int n_chunks);
+int wdf_clipper_tp_warm_unit(void);    /* steps per warm-start unit ("warm tile") */
 size_t wdf_clipper_fwd_tp_ws_bytes(int64_t B, int n_chunks);
 int wdf_clipper_fwd_tp(const float* x, const float* r, const float* theta,
                        float fs, int n_up, int n_down,

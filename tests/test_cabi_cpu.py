@@ -70,7 +70,7 @@ def test_one_pass_step_argument_validation_without_gpu(lib):
     assert call_mse(B=1 << 24) == E and b"2^24" in lib.wdf_last_error()
     assert call_mse(K=5) == E and b"wdf_clipper_tp_chunks" in lib.wdf_last_error()      # 5 chunks do not tile 256 steps in 32-step units (4 do)
     assert call_mse(tol=-1.0) == E and call_mse(warmup=-1) == E
-    assert call_mse(state=one, mwt=0) == E and call_mse(state=one, mwt=17) == E and call_mse(state=one, mwt=8) == E   # 8 tiles > the 128-step chunk
+    assert call_mse(state=one, mwt=0) == E and call_mse(state=one, mwt=33) == E and call_mse(state=one, mwt=9) == E   # 9 units of 16 steps > the 128-step chunk
     assert call_mse(m=one) == E and b"Adam" in lib.wdf_last_error()
     assert call_mse(flags=2) == -3                                                         # WDF_PREC_F64
     esr = lib.wdf_clipper_step_esr_tp
@@ -81,7 +81,7 @@ def test_one_pass_step_argument_validation_without_gpu(lib):
 
     assert call_esr(sums=None) == E and call_esr(n=0.0) == E and call_esr(m=one) == E
     assert lib.wdf_esr_finish(None, 10.0, 0.0, one, None, None) == E and lib.wdf_esr_finish(one, 0.0, 0.0, one, None, None) == E
-    assert lib.wdf_clipper_step_mse_tp_ws_bytes(0, 4) == 0 and lib.wdf_clipper_step_mse_tp_ws_bytes(8192, 16) > 16 * 16 * 8192 * 4
+    assert lib.wdf_clipper_step_mse_tp_ws_bytes(0, 4) == 0 and lib.wdf_clipper_step_mse_tp_ws_bytes(8192, 16) > (2 + 6) * 16 * 8192 * 4   # zwarm, zend, 6-float records
     assert lib.wdf_clipper_step_mse_tp_ws_init(None, 8192, 16, None) == E
 
 

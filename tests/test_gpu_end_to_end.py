@@ -102,7 +102,8 @@ def test_bench_two_rank_path_rehearsal():
     assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2048 * 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert d["roofline"]["bound"] == "hbm" and 0.0 < d["roofline"]["frac"] < 1.0
+    assert d["roofline"]["bound"] == "valu" and 0.0 < d["roofline"]["hbm"]["frac_moved"] < 1.0
+    assert d["roofline"]["frac"] is None or 0.0 < d["roofline"]["frac"] < 1.0      # (needs a committed SQ pass of this shape)
     assert "cpu_baseline" not in d                           # rank 0 at N = 1 only
     assert d["config"]["optimizer"]["loss_last_step"] < d["config"]["optimizer"]["loss_first_step"]
 

@@ -195,7 +195,7 @@ def test_fused_warm_started_training_loop_with_adam(wb):
     tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, want_stash=False)
     gscale = 2.0 / (B * T)
     theta = dev(th0)
-    state = wb.TpWarmState(B, T, K, 8, xd.device)
+    state = wb.TpWarmState(B, T, K, 256 // wb.warm_unit(), xd.device)
     ws = wb.step_mse_workspace(B, K, xd.device)
     lr = [1e-3 * float(v) for v in th0]
     lo, hi = [1e-15, 1e-3, 180.0, 1e-13], [1e-3, 1.0, 1.0e6, 1.0]

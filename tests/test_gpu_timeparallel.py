@@ -414,7 +414,7 @@ def test_fwd_tp_warm_training_loop(wb, time_major, with_r):
     rin = (r.t().contiguous() if time_major else r) if with_r else None
     if with_r:
         W = 448                                              # 99.1 kOhm: slower memory
-    state = wb.TpWarmState(B, T, K, 8, x.device)
+    state = wb.TpWarmState(B, T, K, 256 // wb.warm_unit(), x.device)
     used = []
     for th in _theta_path(th0, 10, 1.0e-3):
         y, zs, zT = wb.clipper_fwd(x, th, FS, r=r, want_zT=True)
@@ -424,7 +424,7 @@ def test_fwd_tp_warm_training_loop(wb, time_major, with_r):
         assert float((y2 - y).abs().max()) <= 1e-6 and float((zs2 - zs).abs().max()) <= 2e-6
         assert float((zT2 - zT).abs().max()) <= 2e-6
         used.append(info["last_warm_tiles"])
-    assert used[0] == -1 and all(0 <= u < -(-W // 32) for u in used[1:]), used
+    assert used[0] == -1 and all(0 <= u < -(-W // wb.warm_unit()) for u in used[1:]), used
     assert state.info()["valid"] == 2 and state.info()["n_calls"] == 10
 
 
@@ -434,7 +434,7 @@ def test_fwd_tp_warm_parameter_jump_is_repaired(wb):
     The controller answers with more warm-up tiles, and the following calls are clean again."""
     B, T, K, W = 130, 4096, 16, 192
     x, th0 = setup(B, T, seed=52)
-    state = wb.TpWarmState(B, T, K, 8, x.device)
+    state = wb.TpWarmState(B, T, K, 256 // wb.warm_unit(), x.device)
     path = _theta_path(th0, 4, 1.0e-3)
     for th in path:
         wb.clipper_fwd_tp(x, th, FS, K, W, state=state)
@@ -461,7 +461,7 @@ def test_fwd_tp_warm_unchanged_theta_becomes_exact(wb):
     from the bit-exact states the output equals the sequential kernel's bit for bit."""
     B, T, K, W = 70, 2048, 8, 192
     x, th = setup(B, T, seed=53)
-    state = wb.TpWarmState(B, T, K, 8, x.device)
+    state = wb.TpWarmState(B, T, K, 256 // wb.warm_unit(), x.device)
     y, zs, zT = wb.clipper_fwd(x, th, FS, want_zT=True)
     for _ in range(8):
         y2, zs2, zT2, st = wb.clipper_fwd_tp(x, th, FS, K, W, want_zT=True, state=state)
@@ -476,7 +476,7 @@ def test_fwd_tp_warm_unchanged_theta_becomes_exact(wb):
 
 def test_fwd_tp_warm_state_is_bound_to_its_shape(wb):
     x, th = setup(64, 1024, seed=54)
-    state = wb.TpWarmState(64, 1024, 4, 8, x.device)
+    state = wb.TpWarmState(64, 1024, 4, 256 // wb.warm_unit(), x.device)
     with pytest.raises(wb.WdfHipError):
         wb.clipper_fwd_tp(x, th, FS, 8, 128, state=state)    # other chunking
     x2, _ = setup(70, 1024, seed=54)

@@ -13,9 +13,10 @@ st = engine.MseStep(B, T, fs, engine.TpPlan(K, 160, 1e-6, 32), dev, time_major=T
 theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
 adam = binding.Adam(4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
 nw = (B // (64 if one else 128)) * K
-buf = torch.zeros(8 * nw, dtype=torch.int64, device=dev)
+ntile = B // (64 if one else 128)
+buf = torch.zeros(8 * nw + 8 * ntile, dtype=torch.int64, device=dev)
 L = binding.lib(); L.wdf_debug_set_times.argtypes = [C.c_void_p]
-for _ in range(6): st.step_fused(theta, xt, tgt, adam=adam)
+for _ in range(int(os.environ.get("DBG_CALLS", "6"))): st.step_fused(theta, xt, tgt, adam=adam)
 assert L.wdf_debug_set_times(buf.data_ptr()) == 0
 e0, e1 = binding.Event(), binding.Event()
 binding.Event.bracket_next(e0, e1)
@@ -23,7 +24,9 @@ st.step_fused(theta, xt, tgt, adam=adam)
 torch.cuda.synchronize()
 ms = e0.elapsed_ms(e1)
 L.wdf_debug_set_times(None)
-a = buf.cpu().numpy().reshape(nw, 8)
+allv = buf.cpu().numpy()
+a = allv[:8 * nw].reshape(nw, 8)
+tail = allv[8 * nw:].reshape(ntile, 8).astype(np.float64)
 t0, t1 = a[:, 0].astype(np.float64), a[:, 1].astype(np.float64)
 base = t0.min()
 tick = 1e-2   # wall_clock64: 100 MHz -> 10 ns = 0.01 us
@@ -41,6 +44,13 @@ wt = a[:, 2].astype(np.float64)
 print(f"shader cycles parked in the back-edge s_waitcnt per wave: median {np.median(wt):.0f} of {np.median(mt):.0f} ({100*np.median(wt/mt):.1f} %)")
 k = np.arange(nw) // (nw // K)
 print("chunk: end median us:", " ".join(f"{kk}:{np.median(t1[k == kk]-base)*tick:.0f}" for kk in range(K)))
+if tail[:, 7].max() > 0:      # stamps along the tile's tail (the build has them): the tile that finished the step = latest stamp 7
+    fin = int(np.argmax(tail[:, 7]))
+    names = ["last body end", "tile ticket", "verified", "records walked", "partial landed", "step ticket", "reduced + chain rule", "Adam done"]
+    tl = (tail - base) * tick
+    print("finishing tile %d, us from kernel start: " % fin + "; ".join(f"{n} {tl[fin, i]:.1f}" for i, n in enumerate(names)))
+    print("all tiles, median us: " + "; ".join(f"{n} {np.median(tl[:, i]):.1f}" for i, n in enumerate(names[:6])))
+    print(f"events {ms*1e3:.1f} us vs kernel-start -> Adam done {tl[fin, 7]:.1f} us: launch + drain = {ms*1e3 - tl[fin, 7]:.1f} us")
 sys.exit(0)
 t2, t3 = a[:, 2].astype(np.float64), a[:, 3].astype(np.float64)
 last = t2 > 0

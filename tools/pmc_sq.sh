@@ -14,9 +14,22 @@ for f in glob.glob(f"gpurun_out/pmc_{tag}_sq*/**/*counter_collection.csv", recur
         m = re.search(r"wdf::(\w+)", row["Kernel_Name"])
         if m:
             per.setdefault(m.group(1), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-out = {k: {n: statistics.median(v) for n, v in c.items()} for k, c in per.items()}
+kernels = {k: {n: statistics.median(v) for n, v in c.items()} for k, c in per.items()}
+cfg = None                                    # the configuration the profiled run used (bench.py matches on it)
+for line in open(f"gpurun_out/pmc_{tag}_sq1.log"):
+    if line.startswith("{") and '"metric"' in line:
+        d = json.loads(line)
+        tp = d["config"]["time_parallel"]
+        ws = tp.get("warm_start")
+        cfg = {"B": d["config"]["global_batch"] // d["n_gpus"], "T": d["config"]["seq_len"],
+               "x_layout": "time-major" if d["config"]["x_layout"].startswith("time-major") else "batch-major",
+               "loss": "mse+esr" if "MSE+ESR" in d["config"]["workload"] else "mse", "fused_chunks": tp["fwd_chunks"],
+               "fwd_warmup_steps": tp["fwd_warmup_steps"] if not ws else ws.get("warm_unit_steps", 32) * max(0, ws["last_warm_tiles"])}
+out = {"_doc": "rocprofv3 --pmc SQ_* (two passes, --kernel-trace) of `python bench.py --steps 5 --warmup 2 ...` on MI355X "
+               "(tools/pmc_sq.sh); median per launch.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed "
+               "over waves (MI355X_MICROARCH.md).", "config": cfg, "kernels": kernels}
 json.dump(out, open(f"gpurun_out/{tag}_sq_counters.json", "w"), indent=1)
-for k, c in out.items():
+for k, c in kernels.items():
     if "fused_tp" in k or "fwd_tp" in k or "bwd_tp" in k:
         print(k, json.dumps(c))
 PY

@@ -27,7 +27,7 @@ for log in glob.glob(os.path.join(root, f"pmc_{tag}_*.log")):
                    "loss": "mse+esr" if "MSE+ESR" in d["config"]["workload"] else "mse",
                    **({"fused_chunks": tp["fwd_chunks"]} if fused else {"fwd_chunks": tp["fwd_chunks"], "bwd_chunks": tp["bwd_chunks"]}),
                    # warm-started forward: the warm-up the device controller settled at, not the cold one
-                   "fwd_warmup_steps": tp["fwd_warmup_steps"] if not tp.get("warm_start") else 32 * max(0, tp["warm_start"]["last_warm_tiles"])}
+                   "fwd_warmup_steps": tp["fwd_warmup_steps"] if not tp.get("warm_start") else tp["warm_start"].get("warm_unit_steps", 32) * max(0, tp["warm_start"]["last_warm_tiles"])}
 out = {"_doc": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_* (separate passes, --kernel-trace) of `python bench.py "
                "--steps 5 --warmup 2 --no-cpu-baseline` on MI355X (tools/pmc_traffic.sh); median per launch. Units KiB. "
                "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE reports exactly half the bytes on this box "

@@ -32,7 +32,7 @@ def run_case(seed, case, oracle=None, verbose=False):
     assert torch.isfinite(y).all(), ("sequential produced non-finite output", case, q)
     state = None
     if warm:                # two earlier calls on the same inputs with theta dth and 2 dth away leave the snapshots
-        state = wb.TpWarmState(B, T, q["K"], 8, x.device)
+        state = wb.TpWarmState(B, T, q["K"], 256 // wb.warm_unit(), x.device)
         for m in (2.0, 1.0):
             wb.clipper_fwd_tp(xin, th * (1.0 - m * q["dth"]), fs, q["K"], q["W"], tol=1e-6, n_up=n_up, n_down=n_down,
                               time_major=tm, state=state)
@@ -81,7 +81,7 @@ def run_case_one_pass(seed, case):
     try:
         state = None
         if warm:
-            state = wb.TpWarmState(B, T, q["K"], 8, x.device)
+            state = wb.TpWarmState(B, T, q["K"], 256 // wb.warm_unit(), x.device)
             for m in (2.0, 1.0):
                 wb.clipper_step_mse_tp(xin, th * (1.0 - m * q["dth"]), fs, tgt, gscale, q["K"], q["W"], n_up=n_up, n_down=n_down,
                                        time_major=tm, state=state)
