@@ -761,51 +761,56 @@ __device__ __forceinline__ bool tp_tile_last(unsigned* tickets)
 
 // What the step's finishing wave does with the tiles' verification results: totals to the host-visible status word,
 // accumulators left clean, warm-start control block advanced (ring head, theta history, warm-up units for the next call).
-// One lane.  nb, mm: bad (sequence, chunk) pairs and the largest miss of the whole call.
+// One lane.  nb, mm: bad (sequence, chunk) pairs and the largest miss of the whole call.  c0: the control block as it was
+// read (the caller may have fetched it ahead of time: read field by field where it is used, every field is a round trip).
 __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restrict__ theta, TpStatus* __restrict__ status,
-                                                            TpCtl* __restrict__ ctl, int J, unsigned* tickets, float tol, int64_t K,
-                                                            int64_t L, int64_t W, int nb, float mm, bool keep_fallback_count)
+                                                            TpCtl* __restrict__ ctl, const TpCtl& c0, int J, unsigned* tickets,
+                                                            float tol, int64_t K, int64_t L, int64_t W, int nb, float mm,
+                                                            bool keep_fallback_count)
 {
     TpAcc* acc = reinterpret_cast<TpAcc*>(tickets);
     if (keep_fallback_count) { status->n_bad = nb; status->max_miss = mm; }      // (fallback_ran: the repair launch adds to it)
     else *status = TpStatus{nb, mm, 0, 0u};
     *acc = TpAcc{0, 0, 0u, 0u};
     if (ctl == nullptr) return;
-    const bool stateful = ctl->geom == (int)((K << 8) | J);
-    const int head = stateful ? ctl->head : 0;
-    const int valid = stateful ? ctl->valid : 0;
-    int j = ctl->j_next;
-    const int jfloor = ctl->j_floor & 0xff;                     // host's floor (low byte); the rest of the word: hold counter
-    int hold = ctl->j_floor >> 8;
+    TpCtl c = c0;
+    const bool stateful = c.geom == (int)((K << 8) | J);
+    const int head = stateful ? c.head : 0;
+    const int valid = stateful ? c.valid : 0;
+    int j = c.j_next;
+    const int jfloor = c.j_floor & 0xff;                        // host's floor (low byte); the rest of the word: hold counter
+    int hold = c.j_floor >> 8;
     if (valid == 0) {                                           // that was the cold call: start 96 steps under its warm-up
         const int jc = (int)((W + kWarmStep - 1) / kWarmStep);      // (an O(1 V) guess needs ~160 steps here; a change of 1e-3 V ~64)
         j = jc - 6 < 1 ? 1 : jc - 6;
         hold = 0;
-        ctl->j_used = -1;
+        c.j_used = -1;
     } else {
         // One unit (16 steps) changes the miss by ~5x at the headline circuit, and two converged fp32 trajectories still
         // differ by ~3e-8: grow when the miss comes within 2x of tol (or a boundary failed), shrink -- once the
         // secant extrapolation is running -- while it stays 12x below (one unit less must still leave 2x), and after
         // growing do not probe lower again for 32 calls.  Measured in the bench loop (tools/warm_pin_probe.py, 32-step
         // units): 32 steps miss by <= 3e-7, 64 by <= 7e-8, 96 sit at the rounding floor.
-        ctl->j_used = j;
+        c.j_used = j;
         if (nb > 0) { j += 4; hold = 32; }
         else if (mm * 2.0f > tol) { j += 1; hold = 32; }
         else if (hold > 0) --hold;
         else if (valid > 1 && mm * 64.0f < tol && (j > 2 || mm == 0.0f)) j -= 2;     // (two units: ~25x)
-        else if (valid > 1 && mm * 12.0f < tol && (j > 1 || mm == 0.0f)) j -= 1;
+        else if (valid > 1 && mm * 12.0f < tol) j -= 1;         // (down to NO warm-up: the chunk then starts from the
+                                                                //  extrapolated snapshot itself, and the check is the same)
     }
     const int jmax = (int)(L / kWarmStep) < J - 1 ? (int)(L / kWarmStep) : J - 1;
     const int jmin = jfloor < jmax ? jfloor : jmax;
-    ctl->j_next = j < jmin ? jmin : (j > jmax ? jmax : j);
-    ctl->j_floor = jfloor | (hold << 8);
+    c.j_next = j < jmin ? jmin : (j > jmax ? jmax : j);
+    c.j_floor = jfloor | (hold << 8);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ctl->th2[i] = stateful ? ctl->th1[i] : theta[i]; ctl->th1[i] = theta[i]; }
-    ctl->head = (head + 1) % kTpRing;
-    ctl->valid = valid < 2 ? valid + 1 : 2;
-    ctl->geom = (int)((K << 8) | J);
-    ctl->last_miss = mm;
-    ctl->n_calls = stateful ? ctl->n_calls + 1 : 1;
+    for (int i = 0; i < 4; ++i) { c.th2[i] = stateful ? c.th1[i] : theta[i]; c.th1[i] = theta[i]; }
+    c.head = (head + 1) % kTpRing;
+    c.valid = valid < 2 ? valid + 1 : 2;
+    c.geom = (int)((K << 8) | J);
+    c.last_miss = mm;
+    c.n_calls = stateful ? c.n_calls + 1 : 1;
+    *ctl = c;
 }
 
 // Verification of one tile by its last wave; returns (wave-uniform) whether a boundary of the tile failed.
@@ -871,7 +876,9 @@ __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, 
     // ---- last tile: totals to the status word, accumulators left clean, warm-start state advanced
     const int mm_bits = atomicMax(&acc->max_miss_bits, 0);
     const int nb = (int)(prev >> 32) + wbad;
-    tp_publish_status_and_steer(theta, status, ctl, J, tickets, tol, K, L, W, nb, __int_as_float(mm_bits), false);
+    TpCtl c0{};
+    if (ctl != nullptr) c0 = *ctl;
+    tp_publish_status_and_steer(theta, status, ctl, c0, J, tickets, tol, K, L, W, nb, __int_as_float(mm_bits), false);
     return tile_failed;
 }
 
@@ -1076,14 +1083,26 @@ __device__ __forceinline__ void adam_tail_apply(const AdamTail& adam, const Adam
 // status and steer the warm start.  status == nullptr: nothing deferred (the reverse sweep).
 struct TpFinishCtx { TpStatus* status; TpCtl* ctl; int J; unsigned* tickets; float tol; int64_t K, L, W; };
 
-__device__ __forceinline__ void tp_finish_deferred(const TpFinishCtx& fc, const float* theta)
+// Fetched as soon as a wave knows it finishes the step (every tile has added its share by then: the adds were awaited before
+// each tile's step ticket), used after the reduction.
+struct TpFinishFetched { TpCtl c; int mm_bits; int nb; };
+
+__device__ __forceinline__ TpFinishFetched tp_finish_fetch(const TpFinishCtx& fc)
 {
-    if (fc.status == nullptr || threadIdx.x != 0) return;
+    TpFinishFetched f{};
+    if (fc.status == nullptr) return f;
     TpAcc* acc = reinterpret_cast<TpAcc*>(fc.tickets);
     // (atomic loads: the totals were formed by other tiles' device-scope atomics)
-    const int mm_bits = __hip_atomic_load(&acc->max_miss_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int nb = (int)__hip_atomic_load(&acc->n_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tp_publish_status_and_steer(theta, fc.status, fc.ctl, fc.J, fc.tickets, fc.tol, fc.K, fc.L, fc.W, nb, __int_as_float(mm_bits), true);
+    f.mm_bits = __hip_atomic_load(&acc->max_miss_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f.nb = (int)__hip_atomic_load(&acc->n_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fc.ctl != nullptr) f.c = *fc.ctl;
+    return f;
+}
+
+__device__ __forceinline__ void tp_finish_deferred(const TpFinishCtx& fc, const TpFinishFetched& f, const float* theta)
+{
+    if (fc.status == nullptr || threadIdx.x != 0) return;
+    tp_publish_status_and_steer(theta, fc.status, fc.ctl, f.c, fc.J, fc.tickets, fc.tol, fc.K, fc.L, fc.W, f.nb, __int_as_float(f.mm_bits), true);
 }
 
 // A tile's partial sums {S_L, S_V, S_P, SSE} (per lane, dead lanes zero) -> the tile's slot of ws; the LAST tile
@@ -1107,27 +1126,40 @@ __device__ __forceinline__ void tile_partial_and_finish(double dL, double dV, do
         WDF_DBG_STAMP(4);                                    // before the tile count moves
         done = atomicAdd(&tickets[0], 1u);
     }
+    // (theta's part of the chain rule: fp64 divisions, formed while the ticket is on its way)
+    double unit[4][4];
+    {
+        const double e[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) grad_chain_rule_d(e[q][0], e[q][1], e[q][2], theta, fs, dyn_r, unit[q]);
+    }
     done = __builtin_amdgcn_readfirstlane(done);
     WDF_DBG_STAMP(5);
     if (done != ntiles - 1) return;
     if (threadIdx.x == 0) tickets[0] = 0u;
-    const AdamFetched af = adam_tail_fetch(adam);            // (in flight under the reduction)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // every other tile's partial (this CU's L1 may be stale)
-    const double* wsr = ws;                                  // (read through a pointer without __restrict__'s no-alias promise)
-    // one wave: lane i takes tiles i, i + 64, ... in order, then the fixed-order wave sum; every lane forms the chain rule
+    // Everything the finish needs is requested at once -- the other tiles' partials (agent-scope loads: written through by
+    // waves on other CUs), the optimizer's state, the verification totals and the warm-start control block -- and used below:
+    // ONE round trip where reading each item at its use made five.
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (unsigned i = threadIdx.x; i < ntiles; i += 64) {
-        s0 += wsr[(int64_t)i * 4 + 0]; s1 += wsr[(int64_t)i * 4 + 1]; s2 += wsr[(int64_t)i * 4 + 2]; s3 += wsr[(int64_t)i * 4 + 3];
+    for (unsigned i = threadIdx.x; i < ntiles; i += 64) {    // lane i takes tiles i, i + 64, ... in order
+        const double* o = ws + (int64_t)i * 4;
+        s0 += __hip_atomic_load(o + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s1 += __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s2 += __hip_atomic_load(o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s3 += __hip_atomic_load(o + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    const AdamFetched af = adam_tail_fetch(adam);
+    const TpFinishFetched ff = tp_finish_fetch(fc);
     s0 = wave_sum_dpp(s0); s1 = wave_sum_dpp(s1); s2 = wave_sum_dpp(s2); s3 = wave_sum_dpp(s3);
-    double g[4];
-    grad_chain_rule_d(s0, s1, s2, theta, fs, dyn_r, g);
+    double g[4];                                             // (the chain rule is linear in the three sums)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = s0 * unit[0][q] + s1 * unit[1][q] + s2 * unit[2][q];
     const int c = threadIdx.x < 4 ? threadIdx.x : 3;
     const float gi = (accumulate ? gtheta[c] : 0.0f) + (float)(c == 0 ? g[0] : (c == 1 ? g[1] : (c == 2 ? g[2] : g[3])));
     if (threadIdx.x < 4) gtheta[threadIdx.x] = gi;
     if (threadIdx.x == 0 && sse_out) *sse_out = (float)s3;
     (void)sh;
-    tp_finish_deferred(fc, theta);                           // (reads theta: before the update below)
+    tp_finish_deferred(fc, ff, theta);                       // (reads theta: before the update below)
     WDF_DBG_STAMP(6);
     if (adam.theta != nullptr) adam_tail_apply(adam, af, gi);
     WDF_DBG_STAMP(7);

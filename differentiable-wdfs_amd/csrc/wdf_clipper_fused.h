@@ -602,13 +602,13 @@ __device__ __forceinline__ void esr_tile_partial_and_finish(const double (&v)[8]
     done = __builtin_amdgcn_readfirstlane(done);
     if (done != ntiles - 1) return;
     if (threadIdx.x == 0) gticket[0] = 0u;
-    const AdamFetched af = adam_tail_fetch(out.gtheta != nullptr ? out.adam : AdamTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, 0.0f, nullptr, nullptr});
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const double* wsr = ws;
+    // (everything the finish needs requested at once, as tile_partial_and_finish does)
     double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (unsigned i = threadIdx.x; i < ntiles; i += 64)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] += wsr[(int64_t)i * 8 + j];
+        for (int j = 0; j < 8; ++j) t[j] += __hip_atomic_load(ws + (int64_t)i * 8 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const AdamFetched af = adam_tail_fetch(out.gtheta != nullptr ? out.adam : AdamTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, 0.0f, nullptr, nullptr});
+    const TpFinishFetched ff = tp_finish_fetch(out.fc);
 #pragma unroll
     for (int j = 0; j < 8; ++j) t[j] = wave_sum_dpp(t[j]);
     // t = {P_L, P_V, P_P, S, Q_L, Q_V, Q_P, E}; every lane forms the chain rule, lanes 0..3 keep their component
@@ -629,7 +629,7 @@ __device__ __forceinline__ void esr_tile_partial_and_finish(const double (&v)[8]
         if (threadIdx.x < 4) out.gtheta[threadIdx.x] = gi;
         if (threadIdx.x == 0 && out.loss3) { out.loss3[0] = (float)mse; out.loss3[1] = (float)esr; out.loss3[2] = (float)(mse + esr); }
     }
-    tp_finish_deferred(out.fc, theta);                       // (reads theta: before the update below)
+    tp_finish_deferred(out.fc, ff, theta);                   // (reads theta: before the update below)
     if (out.gtheta != nullptr && out.adam.theta != nullptr) adam_tail_apply(out.adam, af, gi);
 }
 
