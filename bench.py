@@ -314,15 +314,40 @@ class Trainer:
         # HIP events around the recurrence kernel of every 4th step, recorded INSIDE the timed region on the launch stream
         # and read only after its closing synchronize (no host wait in between): kernel time and step time from one loop
         n_ev = 2 if self.fused else 4
-        evs = [[binding.Event() for _ in range(n_ev)] if i % 4 == 0 else None for i in range(steps)]
+        graph = None
+        if self.args.graph:
+            # One training step -- kernel(s), (N > 1) the RCCL all-reduce, the update -- captured once as a HIP graph and
+            # replayed: the host then spends one launch per step instead of 2..5 plus torch.distributed's dispatch (which,
+            # not the GPU, bounds the multi-rank step when driven eagerly).  Everything a step reads or writes lives in
+            # device buffers that do not move (theta, Adam moments and step count, warm-start state, workspaces).
+            if warmup < 1:
+                self.step()                                    # (first-use allocations happen outside the capture)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    loss, grad = self.step()
+            torch.cuda.current_stream().wait_stream(side)
+            self.step_graph = graph
+        evs = [[binding.Event() for _ in range(n_ev)] if (i % 4 == 0 and graph is None) else None for i in range(steps)]
         wdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            loss, grad = self.step(ev=evs[i])
+        if graph is not None:
+            for i in range(steps):
+                graph.replay()
+        else:
+            for i in range(steps):
+                loss, grad = self.step(ev=evs[i])
         torch.cuda.synchronize()
         wdist.barrier()
         dt = time.perf_counter() - t0
+        if graph is not None:                                  # kernel durations: a few eager, bracketed steps behind the timed region
+            for _ in range(min(steps, 10)):
+                self.step(timed=True)
+            torch.cuda.synchronize()
         for e in evs:
             if e is not None:
                 self.t_fwd.append(e[0].elapsed_ms(e[1]))
@@ -491,6 +516,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the after-the-run check of y and the gradient against the oracle")
     ap.add_argument("--no-batch-major", action="store_true", help="skip the second measurement with x as [B,T]")
     ap.add_argument("--no-cold", action="store_true", help="skip the third measurement: the stateless step (value_cold)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="capture one training step (kernels, all-reduce, update) as a HIP graph and replay it in the timed loop. "
+                         "auto: on when the step contains a collective (N > 1 or --force-dist), off for the single-rank step")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="skip the on-device Adam update of {Is, nVt, R, C} that closes every step")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -520,6 +548,7 @@ def main():
                     help="make the [B,T] layout (the reference scripts') the HEADLINE measurement instead of the engine's "
                          "resident time-major copy")
     args = ap.parse_args()
+    args.graph = (args.graph == "on") or (args.graph == "auto" and (args.gpus > 1 or args.force_dist) and not args.rehearse_on_one_gpu)
     args.steps = 200 if args.steps is None else args.steps
     args.warmup = 20 if args.warmup is None else args.warmup
 
@@ -635,6 +664,7 @@ def main():
                        {"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup, "verify_tol": tp.tol,
                         "bwd_chunks": None if fused else tp.k_bwd, "verify_status": tp_stat, "warm_start": warm}},
             "value_batch_major" if tm else "value_time_major": other,
+            "step_launch": "one HIP-graph replay per step" if args.graph else "eager launches",
             "step_kernels": ("one pass: clipper_fused_tp_kernel (forward + loss + tangent-carried gradient + combine / reduce / "
                              "Adam tail) and its gated repair launch") if fused else
                             "two kernels: clipper_fwd_tp_kernel (+ gated repair) and clipper_bwd_tp_kernel (MSE-fused reverse sweep)",

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <cstddef>
 #include "wdf_capi_common.h"
 #include "wdf_clipper.h"
 #include "wdf_clipper_fused.h"
@@ -284,11 +285,19 @@ int wdf_clipper_bwd(const float* x, const float* r, const float* theta, float fs
     if (rc) return rc;
     if (!zstash || !gy || !ws || !gtheta) return fail(WDF_EINVAL, "null zstash/gy/ws/gtheta");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
-    if (flags & WDF_PREC_F64) return fail(WDF_EUNSUPPORTED, "WDF_PREC_F64 applies to wdf_clipper_fwd and wdf_omega_f64 only: the reverse sweep runs in fp32");
     const bool tm = flags & WDF_X_TIME_MAJOR;
-    const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
-    WDF_DISPATCH4(launch_bwd, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy,
-                  (double*)ws, gz0, gzT, B, T, (hipStream_t)stream);
+    if (flags & WDF_PREC_F64) {                  // the adjoint in fp64 (csrc/wdf_omega64.h): the on-device accuracy reference
+        const unsigned grid = (unsigned)((B + 63) / 64);
+        hipStream_t s = (hipStream_t)stream;
+        if (r) { if (tm) hipLaunchKernelGGL((wdf::clipper_bwd_f64_kernel<true, true>), dim3(grid), dim3(64), 0, s, x, r, theta, fs, n_up, n_down, zstash, gy, (double*)ws, gz0, gzT, B, T);
+                 else hipLaunchKernelGGL((wdf::clipper_bwd_f64_kernel<true, false>), dim3(grid), dim3(64), 0, s, x, r, theta, fs, n_up, n_down, zstash, gy, (double*)ws, gz0, gzT, B, T); }
+        else   { if (tm) hipLaunchKernelGGL((wdf::clipper_bwd_f64_kernel<false, true>), dim3(grid), dim3(64), 0, s, x, r, theta, fs, n_up, n_down, zstash, gy, (double*)ws, gz0, gzT, B, T);
+                 else hipLaunchKernelGGL((wdf::clipper_bwd_f64_kernel<false, false>), dim3(grid), dim3(64), 0, s, x, r, theta, fs, n_up, n_down, zstash, gy, (double*)ws, gz0, gzT, B, T); }
+    } else {
+        const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+        WDF_DISPATCH4(launch_bwd, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, zstash, gy,
+                      (double*)ws, gz0, gzT, B, T, (hipStream_t)stream);
+    }
     rc = check_launch("wdf_clipper_bwd");
     if (rc) return rc;
     const int nparts = (int)((B + 63) / 64);
@@ -364,7 +373,7 @@ int wdf_clipper_fwd_tp_state_reset(void* state, int64_t B, int min_warm_tiles, v
     if (min_warm_tiles < 0 || min_warm_tiles > wdf::kTpMaxWarmTiles) return fail(WDF_EINVAL, "min_warm_tiles must be in 0..%d", wdf::kTpMaxWarmTiles);
     hipError_t e = hipMemsetAsync(state, 0, sizeof(wdf::TpCtl) + tp_ticket_bytes(B), (hipStream_t)stream);
     if (e == hipSuccess && min_warm_tiles > 0)                                // TpCtl::j_floor is its last 32-bit word
-        e = hipMemsetD32Async((hipDeviceptr_t)((char*)state + sizeof(wdf::TpCtl) - 4), min_warm_tiles, 1, (hipStream_t)stream);
+        e = hipMemsetD32Async((hipDeviceptr_t)((char*)state + offsetof(wdf::TpCtl, j_floor)), min_warm_tiles, 1, (hipStream_t)stream);
     return e == hipSuccess ? WDF_OK : fail(WDF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
 }
 

@@ -504,7 +504,7 @@ struct TpStatus {
     unsigned pad;
 };
 
-constexpr int kTpRing = 3;            // snapshot sets: the one being written, the previous call's, the one before
+constexpr int kTpRing = 4;            // snapshot sets: the one being written and the last three calls'
 // The unit of a warm start: snapshots are kept every kWarmStep steps before a chunk's end and a warm call starts j units
 // early.  16 steps (round 2: 32): at the headline circuit 16 steps shrink a boundary miss ~5x, and the training loop's
 // warm-up settles at ONE unit -- a whole one-pass step then runs (128 + 16) / 128 of its owned steps instead of
@@ -514,7 +514,7 @@ constexpr int kTpMaxWarmTiles = 32;   // snapshots reach back at most 32 * 16 st
 
 // Warm-start control block (64 bytes at the head of the caller's persistent state buffer).
 struct TpCtl {
-    int valid;        // snapshot sets left by earlier calls: 0 (next call is cold), 1, 2
+    int valid;        // snapshot sets left by earlier calls: 0 (next call is cold), 1, 2, 3
     int head;         // ring slot of the most recent set
     int j_next;       // warm-up units (kWarmStep steps each) the next warm call runs
     int j_used;       // what the last call ran (-1: cold)
@@ -524,24 +524,52 @@ struct TpCtl {
     int n_calls;
     int geom;         // (K << 8) | J of the calls that wrote the snapshots; a different geometry restarts cold
     int j_floor;      // low byte: the controller never goes below this many warm-up tiles (host: 0; = max pins it); above: hold counter
+    float th3[4];     // theta of the call before th2's (the quadratic extrapolation's third point)
+    int pad[12];
 };
-static_assert(sizeof(TpCtl) == 64, "TpCtl layout");
+static_assert(sizeof(TpCtl) == 128, "TpCtl layout");
 
-// Secant step ratio along the parameter path: lam = <d1, d0> / <d0, d0>, d1 = theta/th1 - 1 (this call
-// against the last), d0 = th1/th2 - 1 (the last against the one before).  Equal optimizer steps give 1,
-// an unchanged theta 0 (plain warm start, exact).
-__device__ __forceinline__ float tp_secant_factor(const float* __restrict__ theta, const TpCtl* __restrict__ ctl)
+// Where a chunk starts from: the snapshots of the last calls, extrapolated ALONG THE PARAMETER PATH to this call's theta.
+// With d1 = theta/th1 - 1 (this call against the last), d0 = th1/th2 - 1, d00 = th2/th3 - 1 (relative steps, 4-vectors) the
+// calls sit at the scalar path positions  s = <d1, d0>/|d0| (this call), 0, -|d0|, -|d0| - <d00, d0>/|d0|  (projections on the
+// last step's direction), and the start state is the Lagrange polynomial through the snapshots there:
+//   valid == 1: the last snapshot itself;   valid == 2: the secant (linear), z1 + lam (z1 - z2), lam = s / |d0|;
+//   valid >= 3: the parabola through the last three.  An unchanged theta gives the last snapshot exactly (weights 1, 0, 0),
+//   equal optimizer steps give 3 z1 - 3 z2 + z3.  The secant leaves the SECOND difference of the state along the path --
+//   ~1e-6 V early in training, when Adam still takes full-size steps: 32 warm-up steps to get under the tolerance -- the
+//   parabola leaves the third.  Degenerate history (a step of zero length, a wild ratio) falls back to the lower order.
+struct TpExtrap { float w1, w2, w3; };      // z = w1 z1 + w2 z2 + w3 z3   (z1 the most recent)
+
+__device__ __forceinline__ TpExtrap tp_extrapolation(const float* __restrict__ theta, const TpCtl* __restrict__ ctl, int valid)
 {
-    float num = 0.0f, den = 0.0f;
+    TpExtrap e{1.0f, 0.0f, 0.0f};
+    if (valid < 2) return e;
+    float n10 = 0.0f, n00 = 0.0f, nq0 = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float d1 = theta[i] / ctl->th1[i] - 1.0f, d0 = ctl->th1[i] / ctl->th2[i] - 1.0f;
-        num = fmaf(d1, d0, num);
-        den = fmaf(d0, d0, den);
+        const float d1 = theta[i] / ctl->th1[i] - 1.0f, d0 = ctl->th1[i] / ctl->th2[i] - 1.0f, dq = ctl->th2[i] / ctl->th3[i] - 1.0f;
+        n10 = fmaf(d1, d0, n10);
+        n00 = fmaf(d0, d0, n00);
+        nq0 = fmaf(dq, d0, nq0);
     }
-    float lam = den > 1.0e-30f ? num / den : 0.0f;
+    if (!(n00 > 1.0e-30f)) return e;                          // the last step had no length: the last snapshot
+    float lam = n10 / n00;                                     // s / |d0|
     lam = fminf(fmaxf(lam, -1.0f), 2.0f);
-    return lam == lam ? lam : 0.0f;
+    if (!(lam == lam)) return e;
+    e.w1 = 1.0f + lam;                                         // secant
+    e.w2 = -lam;
+    // The parabola weighs the three snapshots (3, -3, 1): it amplifies their fp32 rounding (~3e-8 each) to ~2e-7, the secant
+    // (2, -1) to ~1e-7.  Worth it while the second difference it removes is larger than that -- parameter steps above
+    // ~0.06 % (the first tens of Adam steps at the bench's rate); later the secant alone already allows NO warm-up.
+    if (valid < 3 || !(n00 > 4.0e-7f)) return e;
+    const float mu = nq0 / n00;                                // (s2 - s3) / |d0|: the step before, in units of the last
+    if (!(mu > 0.25f && mu < 4.0f)) return e;                  // (a turn, a stall or a jump in the history: stay linear)
+    // positions in units of |d0|: s = lam, s1 = 0, s2 = -1, s3 = -1 - mu
+    const float s3 = -1.0f - mu;
+    e.w1 = (lam + 1.0f) * (lam - s3) / (1.0f * (0.0f - s3));
+    e.w2 = lam * (lam - s3) / ((-1.0f) * (-1.0f - s3));
+    e.w3 = lam * (lam + 1.0f) / ((s3 - 0.0f) * (s3 + 1.0f));
+    return e;
 }
 
 // Lanes of the time-parallel kernels run VT<V>::N sequences each (wdf_vec.h): lane l of tile
@@ -788,7 +816,7 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
     } else {
         // One unit (16 steps) changes the miss by ~5x at the headline circuit, and two converged fp32 trajectories still
         // differ by ~3e-8: grow when the miss comes within 2x of tol (or a boundary failed), shrink -- once the
-        // secant extrapolation is running -- while it stays 12x below (one unit less must still leave 2x), and after
+        // secant extrapolation is running -- while it stays 10x below (one unit less must still leave 2x), and after
         // growing do not probe lower again for 32 calls.  Measured in the bench loop (tools/warm_pin_probe.py, 32-step
         // units): 32 steps miss by <= 3e-7, 64 by <= 7e-8, 96 sit at the rounding floor.
         c.j_used = j;
@@ -796,7 +824,7 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
         else if (mm * 2.0f > tol) { j += 1; hold = 32; }
         else if (hold > 0) --hold;
         else if (valid > 1 && mm * 64.0f < tol && (j > 2 || mm == 0.0f)) j -= 2;     // (two units: ~25x)
-        else if (valid > 1 && mm * 12.0f < tol) j -= 1;         // (down to NO warm-up: the chunk then starts from the
+        else if (valid > 1 && mm * 10.0f < tol) j -= 1;         // (down to NO warm-up: the chunk then starts from the
                                                                 //  extrapolated snapshot itself, and the check is the same)
     }
     const int jmax = (int)(L / kWarmStep) < J - 1 ? (int)(L / kWarmStep) : J - 1;
@@ -804,9 +832,13 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
     c.j_next = j < jmin ? jmin : (j > jmax ? jmax : j);
     c.j_floor = jfloor | (hold << 8);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { c.th2[i] = stateful ? c.th1[i] : theta[i]; c.th1[i] = theta[i]; }
+    for (int i = 0; i < 4; ++i) {
+        c.th3[i] = stateful ? c.th2[i] : theta[i];
+        c.th2[i] = stateful ? c.th1[i] : theta[i];
+        c.th1[i] = theta[i];
+    }
     c.head = (head + 1) % kTpRing;
-    c.valid = valid < 2 ? valid + 1 : 2;
+    c.valid = valid < 3 ? valid + 1 : 3;
     c.geom = (int)((K << 8) | J);
     c.last_miss = mm;
     c.n_calls = stateful ? c.n_calls + 1 : 1;

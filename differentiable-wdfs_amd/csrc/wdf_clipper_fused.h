@@ -443,9 +443,13 @@ __device__ __forceinline__ void clipper_fused_body(
         const int j = ctl->j_next;
         tw = t0 - (int64_t)kWarmStep * j;
         z = load_own<V>(snap + (((int64_t)head * J + j) * K + (k - 1)) * B, q);
-        if (valid > 1) {
-            const V zo = load_own<V>(snap + (((int64_t)((head + kTpRing - 1) % kTpRing) * J + j) * K + (k - 1)) * B, q);
-            z = vfma(vsplat<V>(tp_secant_factor(theta, ctl)), z - zo, z);
+        if (valid > 1) {                                    // extrapolated along the parameter path (tp_extrapolation)
+            const TpExtrap e = tp_extrapolation(theta, ctl, valid);
+            const V z2 = load_own<V>(snap + (((int64_t)((head + kTpRing - 1) % kTpRing) * J + j) * K + (k - 1)) * B, q);
+            V z3 = z2;
+            if (valid > 2) z3 = load_own<V>(snap + (((int64_t)((head + kTpRing - 2) % kTpRing) * J + j) * K + (k - 1)) * B, q);
+            // (written around z1 so that weights (1, 0, 0) return the snapshot bit for bit)
+            z = vfma(vsplat<V>(e.w3), z3 - z, vfma(vsplat<V>(e.w2), z2 - z, z));
         }
     } else {
         tw = (t0 > W) ? t0 - W : 0;

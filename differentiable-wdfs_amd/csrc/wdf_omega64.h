@@ -105,4 +105,66 @@ __global__ __launch_bounds__(64) void clipper_fwd_f64_kernel(
     if (zT) zT[b] = (float)z;
 }
 
+// The reverse sweep of that loop in fp64 (flag WDF_PREC_F64 on wdf_clipper_bwd): the adjoint of wdf_clipper.h's bwd_step with
+// the root recomputed from the stashed state by wright_omega64 and every partial in double (omega' = omega / (1 + omega)).
+// Inputs, stash and dL/dy stay fp32 as the forward left them; per-wave partial sums {S_L, S_V, S_P, 0} in double, reduced by
+// clipper_grad_reduce_kernel like the fp32 sweep's.  Sequential, one lane per sequence: the accuracy reference on the device
+// for the gradient (tests hold it against the oracle's fp64 adjoint), not a fast path.
+template <bool DYN_R, bool TIME_MAJOR>
+__global__ __launch_bounds__(64) void clipper_bwd_f64_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta, float fs, int n_up,
+    int n_down, const float* __restrict__ zstash, const float* __restrict__ gy, double* __restrict__ ws,
+    float* __restrict__ gz0, const float* __restrict__ gzT, int64_t B, int64_t T)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    const double Is = theta[0], V = theta[1], R = theta[2], C = theta[3];
+    const double G2 = C * (2.0 * (double)fs);
+    double Rp = 1.0 / (1.0 / R + G2), p = (1.0 / R) * Rp, L = log(Rp * Is / V);
+    double dL = 0.0, dV = 0.0, dP = 0.0;
+    double gz = gzT ? (double)gzT[b] : 0.0;
+    for (int64_t t = T - 1; t >= 0; --t) {
+        const double xin = TIME_MAJOR ? x[t * B + b] : x[b * T + t];
+        if constexpr (DYN_R) {
+            const double G1 = 1.0 / (double)(TIME_MAJOR ? r[t * B + b] : r[b * T + t]);
+            Rp = 1.0 / (G1 + G2);
+            p = G1 * Rp;
+            L = log(Rp * Is / V);
+        }
+        const double z = zstash[t * B + b], g = gy[t * B + b];
+        const double b_diff = z - xin;
+        const double a = z - p * b_diff;
+        const double lam = (a > 0.0) ? 1.0 : ((a < 0.0) ? -1.0 : 0.0);
+        const double m0 = (a >= 0.0) ? (double)n_down : (double)n_up, m1 = (a >= 0.0) ? (double)n_up : (double)n_down;
+        const double aa = fabs(a);
+        const double w0 = wright_omega64(L - log(m0) + aa / (m0 * V));
+        const double w1 = wright_omega64(L - log(m1) - aa / (m1 * V));
+        const double w0p = w0 / (1.0 + w0), w1p = w1 / (1.0 + w1);
+        const double l2 = lam * lam, sp = w0p + w1p;
+        const double Da = 1.0 - 2.0 * l2 * sp;
+        const double DL = -2.0 * V * lam * (m0 * w0p - m1 * w1p);
+        const double DV = 2.0 * l2 * a * sp / V - 2.0 * lam * (m0 * w0 - m1 * w1);
+        const double g_b2n = gz + 0.5 * g;
+        const double g_a = g_b2n * Da, g_L = g_b2n * DL;
+        const double g_bt = g_b2n + g_a;
+        const double g_p = -g_bt * b_diff;
+        dL += g_L;
+        dV += g_b2n * DV;
+        if constexpr (DYN_R) dP += Rp * (g_p * p + g_L);
+        else dP += g_p;
+        gz = 0.5 * g + g_a - p * g_bt;
+    }
+    if (live && gz0) gz0[b] = (float)gz;
+    if (!live) { dL = dV = dP = 0.0; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dL += __shfl_down(dL, off, 64); dV += __shfl_down(dV, off, 64); dP += __shfl_down(dP, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        double* o = ws + (int64_t)blockIdx.x * 4;
+        o[0] = dL; o[1] = dV; o[2] = dP; o[3] = 0.0;
+    }
+}
+
 }  // namespace wdf

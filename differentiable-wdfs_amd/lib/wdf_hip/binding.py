@@ -279,9 +279,10 @@ def clipper_fwd(x, theta, fs, r=None, n_up=1, n_down=1, want_stash=True, z0=None
 
 
 def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=False, time_major=False,
-                gtheta=None, accumulate=False, ws=None, gzT=None):
+                gtheta=None, accumulate=False, ws=None, gzT=None, fp64=False):
     """dL/d{Is, nVt, R, C} as a float32[4] device tensor (and dL/dz0 [B] if requested).
-    gzT: optional dL/dzT [B] (a loss that also reads the forward's final state)."""
+    gzT: optional dL/dzT [B] (a loss that also reads the forward's final state).
+    fp64: the adjoint in double (WDF_PREC_F64; sequential, the accuracy reference on the device)."""
     require_gpu()
     x = _f32_dev(x, "x")
     r = _f32_dev(r, "r")
@@ -297,7 +298,7 @@ def clipper_bwd(x, theta, fs, zstash, gy, r=None, n_up=1, n_down=1, want_gz0=Fal
         gtheta = torch.empty((4,), dtype=torch.float32, device=x.device)
         accumulate = False
     gz0 = torch.empty((B,), dtype=torch.float32, device=x.device) if want_gz0 else None
-    flags = (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag()
+    flags = (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag() | (WDF_PREC_F64 if fp64 else 0)
     rc = lib().wdf_clipper_bwd(_ptr(x), _ptr(r), _ptr(theta), float(fs), int(n_up), int(n_down),
                                _ptr(zstash), _ptr(gy), _ptr(ws), _ptr(gtheta), _ptr(gz0), _ptr(_f32_dev(gzT, "gzT")),
                                1 if accumulate else 0, B, T, flags, _stream())

@@ -43,9 +43,10 @@ enum {
 /* flags */
 enum {
     WDF_X_TIME_MAJOR = 1 << 0, /* x (and r) are [T][B] instead of [B][T]                 */
-    WDF_PREC_F64     = 1 << 1, /* wdf_clipper_fwd only: tree and root (Wright omega with toms917's second-iteration
-                                  test, csrc/wdf_omega64.h) in fp64, I/O stays f32 -- the on-device accuracy
-                                  reference of config C5; every other entry point answers WDF_EUNSUPPORTED */
+    WDF_PREC_F64     = 1 << 1, /* wdf_clipper_fwd and wdf_clipper_bwd (the sequential pair; static or per-sample R): tree,
+                                  root (Wright omega with toms917's second-iteration test, csrc/wdf_omega64.h) and
+                                  adjoint in fp64, I/O stays f32 -- the on-device accuracy reference of config C5,
+                                  not a fast path; every other entry point answers WDF_EUNSUPPORTED */
     WDF_MLP_LANE_PER_SEQUENCE = 1 << 4, /* MLP-root kernels: the one-lane-per-sequence variant (csrc/wdf_mlp.h)
                                   instead of the default 16-lane row per sequence (csrc/wdf_mlp_row.h) */
     WDF_GENERAL_ROOT = 1 << 3, /* always take the general per-step root evaluation (the kernels otherwise

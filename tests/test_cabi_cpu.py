@@ -48,7 +48,7 @@ def test_argument_validation_without_gpu(lib):
     assert f(one, None, one, -1.0, 1, 1, one, None, None, None, 4, 4, 0, None) == -1
     g = lib.wdf_clipper_bwd
     assert g(one, None, one, 48000.0, 1, 1, None, one, one, one, None, None, 0, 4, 4, 0, None) == -1
-    assert g(one, None, one, 48000.0, 1, 1, one, one, one, one, None, None, 0, 4, 4, 2, None) == -3   # WDF_PREC_F64: forward only
+    assert lib.wdf_clipper_bwd_tp(one, None, one, 48000.0, 1, 1, one, one, one, one, None, 0, 64, 64, 2, 2, None) == -3   # WDF_PREC_F64: the sequential pair only
     assert lib.wdf_clipper_bwd_ws_bytes(8192) == 128 * 4 * 8
     assert lib.wdf_clipper_bwd_ws_bytes(0) == 0
 

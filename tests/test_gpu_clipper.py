@@ -318,8 +318,7 @@ def test_omega_fp64_matches_the_reference_build_and_its_iteration_count(wb, orac
 @pytest.mark.parametrize("cfg,n_up,n_down", [("1u1d", 1, 1), ("2u3d", 2, 3)])
 def test_clipper_forward_fp64_root(wb, oracle, golden, cfg, n_up, n_down):
     """WDF_PREC_F64: tree and root in double on the device -> the fp64 oracle / golden to output rounding
-    (y is stored as fp32: half an ulp of |y| <= 1 V = 3e-8), 10x closer than the fp32 kernels; the reverse
-    sweep refuses the flag."""
+    (y is stored as fp32: half an ulp of |y| <= 1 V = 3e-8), 10x closer than the fp32 kernels."""
     g = golden("g6_diode_clipper.npz")
     th = dev(g["theta"])
     x = dev(g["x"])
@@ -334,3 +333,31 @@ def test_clipper_forward_fp64_root(wb, oracle, golden, cfg, n_up, n_down):
     yr, _, _ = wb.clipper_fwd(x, th, FS, r=r, fp64=True)
     refr = oracle.clipper_fwd(th64, FS, g["x"].astype(np.float32).astype(np.float64), r=g["r"].astype(np.float32).astype(np.float64))
     assert np.max(np.abs(yr.cpu().numpy() - refr)) < 6e-8
+
+
+@pytest.mark.parametrize("n_up,n_down,with_r,time_major", [(1, 1, False, False), (2, 3, False, True), (1, 1, True, False), (1, 2, True, True)])
+def test_clipper_reverse_sweep_fp64(wb, oracle, golden, n_up, n_down, with_r, time_major):
+    """WDF_PREC_F64 on wdf_clipper_bwd: the adjoint in double on the device (root recomputed by the fp64 Wright omega from
+    the stashed state) against the oracle's fp64 reverse sweep -- 2e-6 relative per component (what the fp32 stash and
+    dL/dy leave: the fp32 sweep sits at 3e-6 .. 1e-5 on the same data), and dL/dz0."""
+    g = golden("g6_diode_clipper.npz")
+    th, x = dev(g["theta"]), dev(g["x"])
+    r = dev(g["r"]) if with_r else None
+    B, T = x.shape
+    rng = np.random.default_rng(n_up * 10 + n_down)
+    gy = dev(rng.standard_normal((T, B)) / (B * T))
+    xin, rin = (x.t().contiguous(), None if r is None else r.t().contiguous()) if time_major else (x, r)
+    y, zs, _ = wb.clipper_fwd(xin, th, FS, r=rin, n_up=n_up, n_down=n_down, time_major=time_major, fp64=True)
+    gth, gz0 = wb.clipper_bwd(xin, th, FS, zs, gy, r=rin, n_up=n_up, n_down=n_down, want_gz0=True, time_major=time_major, fp64=True)
+    th64 = g["theta"].astype(np.float32).astype(np.float64)
+    r64 = None if r is None else g["r"].astype(np.float32).astype(np.float64)
+    _, g_ref = oracle.clipper_fwd_bwd(th64, FS, g["x"].astype(np.float32).astype(np.float64), gy.cpu().numpy().astype(np.float64),
+                                      r=r64, n_up=n_up, n_down=n_down)
+    got = gth.cpu().numpy().astype(np.float64)
+    idx = [0, 1, 3] if with_r else [0, 1, 2, 3]
+    err = np.abs(got[idx] - g_ref[idx]) / np.abs(g_ref[idx])
+    g32, _ = wb.clipper_bwd(xin, th, FS, zs, gy, r=rin, n_up=n_up, n_down=n_down, time_major=time_major)
+    err32 = np.abs(g32.cpu().numpy().astype(np.float64)[idx] - g_ref[idx]) / np.abs(g_ref[idx])
+    print(f"fp64 sweep {err.max():.2e}  fp32 sweep {err32.max():.2e}")
+    assert err.max() <= 2e-6, (got, g_ref)
+    assert bool(torch.isfinite(gz0).all())

@@ -224,7 +224,7 @@ def test_fused_warm_started_training_loop_with_adam(wb):
         losses.append(float(sse))
     assert losses[7] < losses[0]
     info = state.info()
-    assert info["valid"] == 2 and info["n_calls"] == 12
+    assert info["valid"] == 3 and info["n_calls"] == 12
     # theta stands still: plain warm start from the snapshots, zero miss
     for _ in range(3):
         y, _, g, _, st = wb.clipper_step_mse_tp(xt, theta, FS, tgt, gscale, K, W, ws=ws, state=state, time_major=True)

@@ -425,7 +425,7 @@ def test_fwd_tp_warm_training_loop(wb, time_major, with_r):
         assert float((zT2 - zT).abs().max()) <= 2e-6
         used.append(info["last_warm_tiles"])
     assert used[0] == -1 and all(0 <= u < -(-W // wb.warm_unit()) for u in used[1:]), used
-    assert state.info()["valid"] == 2 and state.info()["n_calls"] == 10
+    assert state.info()["valid"] == 3 and state.info()["n_calls"] == 10
 
 
 def test_fwd_tp_warm_parameter_jump_is_repaired(wb):

@@ -11,7 +11,7 @@ th_host = workload.clipper_theta()
 tgt, _, _ = binding.clipper_fwd(x, torch.tensor(workload.target_theta(), dtype=torch.float32, device=dev), fs, want_stash=False)
 st = engine.MseStep(B, T, fs, engine.TpPlan(K, 160, 1e-6, 32), dev, time_major=True, warm=True)
 theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
-adam = binding.Adam(4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
+adam = None if os.environ.get("DBG_NO_ADAM") else binding.Adam(4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
 nw = (B // (64 if one else 128)) * K
 ntile = B // (64 if one else 128)
 buf = torch.zeros(8 * nw + 8 * ntile, dtype=torch.int64, device=dev)
