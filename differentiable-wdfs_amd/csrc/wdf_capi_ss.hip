@@ -131,6 +131,123 @@ int wdf_ss_bwd(const float* x, const float* coef, const float* rootp, int ns, in
     return check_launch("wdf_ss_grad_reduce");
 }
 
+// ---- time-parallel state-space kernels (wdf_statespace.h, second half) --------------------------------------
+static void ss_tp_geom(int64_t T, int n_chunks, int64_t& L, int& K)
+{
+    if (n_chunks < 1) n_chunks = 1;
+    L = (T + n_chunks - 1) / n_chunks;
+    L = (L + 7) / 8 * 8;
+    K = (int)((T + L - 1) / L);
+}
+
+int wdf_ss_tp_chunks(int64_t T, int n_chunks)
+{
+    int64_t L; int K;
+    if (T <= 0) return 0;
+    ss_tp_geom(T, n_chunks, L, K);
+    return K;
+}
+
+size_t wdf_ss_fwd_tp_ws_bytes(int ns, int64_t B, int n_chunks)
+{
+    if (ns < 1 || B <= 0 || n_chunks <= 0) return 0;
+    return (size_t)2 * (size_t)n_chunks * (size_t)ns * (size_t)B * sizeof(float) + (size_t)((B + 63) / 64) * sizeof(unsigned);
+}
+
+int wdf_ss_fwd_tp(const float* x, const float* coef, const float* rootp, int ns, int ni, int n_up, int n_down, float* y,
+                  float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws,
+                  void* status, void* stream)
+{
+    int rc = ss_check(x, coef, rootp, ns, ni, wdf::kRootDiode, n_up, n_down, B, T, 0);
+    if (rc) return rc;
+    if (!y || !ws || !status) return fail(WDF_EINVAL, "null y/ws/status");
+    if (ns < 1) return fail(WDF_EINVAL, "a tree without states has nothing to speculate about: use wdf_ss_fwd");
+    if (n_chunks < 1 || warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "n_chunks >= 1, warmup >= 0, tol >= 0");
+    int64_t L; int K;
+    ss_tp_geom(T, n_chunks, L, K);
+    if (K != n_chunks) return fail(WDF_EINVAL, "n_chunks = %d does not tile T = %lld in 8-step units: use wdf_ss_tp_chunks (%d)", n_chunks, (long long)T, K);
+    float* zwarm = (float*)ws;
+    float* zend = zwarm + (size_t)K * (size_t)ns * (size_t)B;
+    unsigned* gate = (unsigned*)(zend + (size_t)K * (size_t)ns * (size_t)B);
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K);
+    hipStream_t s = (hipStream_t)stream;
+    const bool sym = n_up == n_down;
+    const bool v4 = ((T * ni) % 4 == 0) && aligned16(x);
+#define WDF_SS_TP(NS_, NI_)                                                                                                  \
+    if (ns == NS_ && ni == NI_) {                                                                                            \
+        {                                                                                                                    \
+            EventBracket bracket(s);                                                                                         \
+            if (sym) hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y, \
+                                        zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, (int64_t)warmup);    \
+            else hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y,   \
+                                    zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, (int64_t)warmup);        \
+        }                                                                                                                    \
+        if (K > 1) {                                                                                                         \
+            hipLaunchKernelGGL(wdf::ss_tp_verify_kernel, dim3(grid.x), dim3(64), 0, s, (const float*)zwarm, (const float*)zend, ns, B,  \
+                               (int64_t)K, tol, gate, (wdf::SsTpStatus*)status);                                             \
+            if (v4) hipLaunchKernelGGL((wdf::ss_fwd_kernel<NS_, NI_, wdf::kRootDiode, false, true>), dim3(grid.x), dim3(64), 0, s, x,   \
+                                       coef, rootp, n_up, n_down, y, zstash, z0, zT, B, T, (const unsigned*)gate);           \
+            else hipLaunchKernelGGL((wdf::ss_fwd_kernel<NS_, NI_, wdf::kRootDiode, false, false>), dim3(grid.x), dim3(64), 0, s, x,    \
+                                    coef, rootp, n_up, n_down, y, zstash, z0, zT, B, T, (const unsigned*)gate);              \
+        }                                                                                                                    \
+    }
+    WDF_SS_TP(1, 1) WDF_SS_TP(2, 1) WDF_SS_TP(3, 1) WDF_SS_TP(1, 2) WDF_SS_TP(2, 2) WDF_SS_TP(3, 2)
+#undef WDF_SS_TP
+    return check_launch("wdf_ss_fwd_tp");
+}
+
+static int ss_tp_rec(int ns, int ni) { const int nacc = wdf_ss_ncoef(ns, ni) + 2; return ns * ns + ns + nacc * (ns + 1); }
+
+size_t wdf_ss_bwd_tp_ws_bytes(int ns, int ni, int64_t B, int n_chunks)
+{
+    if (ns < 1 || B <= 0 || n_chunks <= 0) return 0;
+    return wdf_ss_bwd_ws_bytes(ns, ni, B) + (size_t)n_chunks * (size_t)ss_tp_rec(ns, ni) * (size_t)B * sizeof(float);
+}
+
+int wdf_ss_bwd_tp(const float* x, const float* coef, const float* rootp, int ns, int ni, int root, int n_up, int n_down,
+                  const float* zstash, const float* gy, void* ws, float* gcoef, float* groot, float* gz0, int64_t B, int64_t T,
+                  int n_chunks, void* stream)
+{
+    int rc = ss_check(x, coef, rootp, ns, ni, root, n_up, n_down, B, T, 0);
+    if (rc) return rc;
+    if (!gy || !ws || !gcoef || !zstash) return fail(WDF_EINVAL, "null gy/ws/gcoef/zstash");
+    if (ns < 1) return fail(WDF_EINVAL, "a tree without states has no adjoint to scan: use wdf_ss_bwd");
+    if (root == wdf::kRootDiode && !groot) return fail(WDF_EINVAL, "null groot");
+    int64_t L; int K;
+    ss_tp_geom(T, n_chunks, L, K);
+    if (K != n_chunks) return fail(WDF_EINVAL, "n_chunks = %d does not tile T = %lld in 8-step units: use wdf_ss_tp_chunks (%d)", n_chunks, (long long)T, K);
+    double* part = (double*)ws;
+    float* rec = (float*)((char*)ws + wdf_ss_bwd_ws_bytes(ns, ni, B));
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K);
+    hipStream_t s = (hipStream_t)stream;
+    const bool sym = n_up == n_down;
+#define WDF_SS_BTP(NS_, NI_)                                                                                                 \
+    if (ns == NS_ && ni == NI_) {                                                                                            \
+        {                                                                                                                    \
+            EventBracket bracket(s);                                                                                         \
+            if (root == wdf::kRootNone)                                                                                      \
+                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootNone, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up,  \
+                                   n_down, zstash, gy, rec, B, T, L);                                                        \
+            else if (sym)                                                                                                    \
+                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootDiode, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up, \
+                                   n_down, zstash, gy, rec, B, T, L);                                                        \
+            else                                                                                                             \
+                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootDiode, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, \
+                                   n_down, zstash, gy, rec, B, T, L);                                                        \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((wdf::ss_bwd_tp_combine_kernel<NS_, NI_>), dim3(grid.x), dim3(64), 0, s, (const float*)rec, part, gz0, B,   \
+                           (int64_t)K);                                                                                      \
+    }
+    WDF_SS_BTP(1, 1) WDF_SS_BTP(2, 1) WDF_SS_BTP(3, 1) WDF_SS_BTP(1, 2) WDF_SS_BTP(2, 2) WDF_SS_BTP(3, 2)
+#undef WDF_SS_BTP
+    rc = check_launch("wdf_ss_bwd_tp");
+    if (rc) return rc;
+    const int ncoef = wdf_ss_ncoef(ns, ni);
+    hipLaunchKernelGGL(wdf::ss_grad_reduce_kernel, dim3(1), dim3(64), 0, s, (const double*)part, (int)((B + 63) / 64), ncoef + 2, ncoef,
+                       root == wdf::kRootDiode ? rootp : nullptr, gcoef, root == wdf::kRootDiode ? groot : nullptr);
+    return check_launch("wdf_ss_grad_reduce");
+}
+
 int wdf_clipper_asym_fwd(const float* x, const float* theta6, float fs, int mode, double tol, int max_iter, float* y,
                          float* zstash, const float* z0, float* zT, long long* iters, int64_t B, int64_t T, void* stream)
 {

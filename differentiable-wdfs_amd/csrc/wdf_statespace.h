@@ -123,9 +123,10 @@ __global__ __launch_bounds__(64) void ss_fwd_kernel(const float* __restrict__ x,
                                                     const float* __restrict__ rootp, int n_up, int n_down,
                                                     float* __restrict__ y, float* __restrict__ zstash,
                                                     const float* __restrict__ z0, float* __restrict__ zT,
-                                                    int64_t B, int64_t T)
+                                                    int64_t B, int64_t T, const unsigned* __restrict__ gate = nullptr)
 {
     constexpr int NSa = NS > 0 ? NS : 1;
+    if (gate != nullptr && gate[blockIdx.x] == 0u) return;      // (behind the time-parallel forward: flagged waves only)
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;     // dead lanes shadow the last sequence
     SSCoef<NS, NI> c;
@@ -456,6 +457,267 @@ static __global__ __launch_bounds__(64) void ss_grad_reduce_kernel(const double*
         groot[0] = (float)(sL / Is);
         groot[1] = (float)(sV - sL / V);
         groot[2] = (float)(sL / Rp);
+    }
+}
+
+// =========================================================================================================
+// Time-parallel kernels for trees with a NONLINEAR root (HPFDiodeClipper.h:28-32's Parallel(R, Series(Vs, C)) + diode pair,
+// multi-state trees): B sequences are B / 64 waves on a 1024-SIMD chip, each one long dependent chain; the time axis is
+// cut into K chunks like the clipper kernels' (wdf_clipper.h).
+//
+// Forward -- speculate, verify, re-run what missed.  The tree + diode map contracts the state (the reference itself
+// discards the first 50 outputs, clipper_pot.py:232), so chunk k starts W steps early from z = 0, records the state it
+// arrives with and the state it ends with; ss_tp_verify_kernel compares the boundaries per 64-sequence wave and gates
+// the SEQUENTIAL kernel, launched behind it, onto the waves with a miss (normally none: the gated launch leaves at once).
+// Outputs are within tol of the sequential kernel's or ARE the sequential kernel's.  W comes from the host (the spectral
+// radius of the step's Jacobian at both ends of the diode's slope, lowering.plan_ss_time_parallel).
+struct SsTpStatus { int n_bad; float max_miss; int gated_waves; int pad; };
+
+template <int NS, int NI, bool SYM>
+__global__ __launch_bounds__(64) void ss_fwd_tp_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                       const float* __restrict__ rootp, int n_up, int n_down,
+                                                       float* __restrict__ y, float* __restrict__ zstash,
+                                                       const float* __restrict__ z0, float* __restrict__ zT,
+                                                       float* __restrict__ zwarm, float* __restrict__ zend,
+                                                       SsTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W)
+{
+    static_assert(NS >= 1, "a tree without states has nothing to speculate about");
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = SsTpStatus{0, 0.0f, 0, 0};   // (the verify kernel adds)
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t k = blockIdx.y, t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const int64_t tw = (t0 > W) ? t0 - W : 0;
+    SSCoef<NS, NI> c;
+    c.load(coef);
+    SSDiode dp = {};
+    dp.load(rootp, n_up, n_down);
+    float z[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) z[s] = (tw == 0 && z0) ? z0[s * B + b] : 0.0f;
+    const float* __restrict__ xp = x + b * T * NI;
+    for (int64_t t = tw; t < t0; ++t) {                         // warm-up: nothing stored
+        float xt[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xt[i] = xp[t * NI + i];
+        (void)ss_fwd_step<NS, NI, kRootDiode, SYM>(c, dp, xt, z);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) zwarm[(k * NS + s) * B + b] = z[s];
+    const bool STASH = zstash != nullptr;
+    for (int64_t t = t0; t < t1; ++t) {
+        float xt[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xt[i] = xp[t * NI + i];
+        if (STASH) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zstash[(t * NS + s) * B + b] = z[s];
+        }
+        y[t * B + b] = ss_fwd_step<NS, NI, kRootDiode, SYM>(c, dp, xt, z);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) zend[(k * NS + s) * B + b] = z[s];
+    if (zT && t1 == T) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) zT[s * B + b] = z[s];
+    }
+}
+
+// gate[wave] = 1 where one of the wave's sequences arrived at a chunk more than tol away from where its predecessor ended
+static __global__ __launch_bounds__(64) void ss_tp_verify_kernel(const float* __restrict__ zwarm, const float* __restrict__ zend,
+                                                                 int ns, int64_t B, int64_t K, float tol, unsigned* __restrict__ gate,
+                                                                 SsTpStatus* __restrict__ status)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    float miss = 0.0f;
+    int nbad = 0;
+    for (int64_t k = 1; k < K; ++k)
+        for (int s = 0; s < ns; ++s) {
+            const float m = fabsf(zwarm[(k * ns + s) * B + b] - zend[((k - 1) * ns + s) * B + b]);
+            miss = fmaxf(miss, m);
+            nbad += !(m <= tol) ? 1 : 0;
+        }
+    if (b_raw >= B) nbad = 0;
+    const bool any = __builtin_amdgcn_ballot_w64(nbad != 0) != 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        miss = fmaxf(miss, __shfl_down(miss, off, 64));
+        nbad += __shfl_down(nbad, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        gate[blockIdx.x] = any ? 1u : 0u;
+        if (nbad) atomicAdd(&status->n_bad, nbad);
+        atomicMax(reinterpret_cast<int*>(&status->max_miss), __float_as_int(miss));
+        if (any) atomicAdd(&status->gated_waves, 1);
+    }
+}
+
+// Reverse sweep -- EXACT.  The adjoint recurrence is linear in the adjoint LAM that enters a chunk from the future:
+// lam_n = Phi_n LAM + beta_n (Phi: NS x NS), and every accumulator is affine in LAM: acc = P LAM + q.  A chunk runs the step's
+// linear part 1 + NS times (the actual adjoint with dL/dy, and one homogeneous run per unit vector of LAM; the root --
+// omega, its partials -- is evaluated once per step) and leaves the record {Phi, beta, P, q}; ss_bwd_tp_combine_kernel walks
+// a sequence's chunks from the last to the first (LAM_{k-1} = Phi_k LAM_k + beta_k), adds up P LAM + q in double and leaves
+// the per-wave partial sums ss_grad_reduce_kernel expects.  Only the summation order differs from ss_bwd_kernel.
+template <int NS, int NI> struct SsTpRec { static constexpr int NACC = SSCoef<NS, NI>::kN + 2, N = NS * NS + NS + NACC * (NS + 1); };
+
+// the linear part of ss_bwd_step for one adjoint vector (g = 0 for the homogeneous runs)
+template <int NS, int NI>
+__device__ __forceinline__ void ss_bwd_linear(const SSCoef<NS, NI>& c, const float (&x)[NI], const float (&z)[NS], float b, float Da,
+                                              float DL, float DV, float g, float (&lam)[NS], float (&acc)[SSCoef<NS, NI>::kN + 2])
+{
+    using C = SSCoef<NS, NI>;
+    float gb = c.v[C::oFy] * g;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) gb = fmaf(c.v[C::oE + s], lam[s], gb);
+    const float ga = gb * Da;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) acc[C::oA + s * NS + s2] = fmaf(lam[s], z[s2], acc[C::oA + s * NS + s2]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[C::oB + s * NI + i] = fmaf(lam[s], x[i], acc[C::oB + s * NI + i]);
+        acc[C::oE + s] = fmaf(lam[s], b, acc[C::oE + s]);
+        acc[C::oCa + s] = fmaf(ga, z[s], acc[C::oCa + s]);
+        acc[C::oCy + s] = fmaf(g, z[s], acc[C::oCy + s]);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        acc[C::oDa + i] = fmaf(ga, x[i], acc[C::oDa + i]);
+        acc[C::oDy + i] = fmaf(g, x[i], acc[C::oDy + i]);
+    }
+    acc[C::oFy] = fmaf(g, b, acc[C::oFy]);
+    acc[C::kN + 0] = fmaf(gb, DL, acc[C::kN + 0]);
+    acc[C::kN + 1] = fmaf(gb, DV, acc[C::kN + 1]);
+    float ln[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+        float v = fmaf(c.v[C::oCa + s2], ga, c.v[C::oCy + s2] * g);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v = fmaf(c.v[C::oA + s * NS + s2], lam[s], v);
+        ln[s2] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) lam[s] = ln[s];
+}
+
+// rec: float [K][SsTpRec::N][B] = {Phi[NS][NS] (row r = lam component, column = LAM component), beta[NS], P[NS][NACC], q[NACC]}
+template <int NS, int NI, int ROOT, bool SYM>
+__global__ __launch_bounds__(64) void ss_bwd_tp_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                       const float* __restrict__ rootp, int n_up, int n_down,
+                                                       const float* __restrict__ zstash, const float* __restrict__ gy,
+                                                       float* __restrict__ rec, int64_t B, int64_t T, int64_t L)
+{
+    using C = SSCoef<NS, NI>;
+    constexpr int NACC = C::kN + 2;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t k = blockIdx.y, t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+    C c;
+    c.load(coef);
+    SSDiode dp = {};
+    if constexpr (ROOT == kRootDiode) dp.load(rootp, n_up, n_down);
+    // run 0: the actual adjoint (beta, q); runs 1..NS: homogeneous, LAM = e_{r-1} (Phi's column, P's row)
+    float lam[NS + 1][NS], acc[NS + 1][NACC];
+#pragma unroll
+    for (int r = 0; r <= NS; ++r) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) lam[r][s] = (r > 0 && s == r - 1) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[r][i] = 0.0f;
+    }
+    const float* __restrict__ xp = x + b * T * NI;
+    for (int64_t t = t1 - 1; t >= t0; --t) {
+        float xt[NI], zt[NS];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xt[i] = xp[t * NI + i];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) zt[s] = zstash[(t * NS + s) * B + b];
+        float bb = 0.0f, Da = 0.0f, DL = 0.0f, DV = 0.0f;
+        if constexpr (ROOT == kRootDiode) {
+            float a = 0.0f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) a = fmaf(c.v[C::oCa + s], zt[s], a);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) a = fmaf(c.v[C::oDa + i], xt[i], a);
+            const DiodeOut o = diode_pair<SYM>(a, dp.L, dp.d);
+            bb = o.b;
+            const float w0p = o.w0 * fast_rcp(1.0f + o.w0), w1p = o.w1 * fast_rcp(1.0f + o.w1);
+            const float l2 = o.lam * o.lam, sp = w0p + w1p;
+            Da = fmaf(-2.0f * l2, sp, 1.0f);
+            DL = -dp.d.two_v * o.lam * (o.m0 * w0p - o.m1 * w1p);
+            DV = fmaf(2.0f * l2 * a, sp * fast_rcp(dp.V), -2.0f * o.lam * (o.m0 * o.w0 - o.m1 * o.w1));
+        }
+        const float g = gy[t * B + b];
+#pragma unroll
+        for (int r = 0; r <= NS; ++r) ss_bwd_linear<NS, NI>(c, xt, zt, bb, Da, DL, DV, r == 0 ? g : 0.0f, lam[r], acc[r]);
+    }
+    float* __restrict__ o = rec + (size_t)k * SsTpRec<NS, NI>::N * B + b;
+    int e = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 1; r <= NS; ++r) o[(size_t)(e++) * B] = lam[r][s];       // Phi[s][r-1]
+#pragma unroll
+    for (int s = 0; s < NS; ++s) o[(size_t)(e++) * B] = lam[0][s];             // beta
+#pragma unroll
+    for (int r = 1; r <= NS; ++r)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) o[(size_t)(e++) * B] = acc[r][i];       // P[r-1][i]
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) o[(size_t)(e++) * B] = acc[0][i];           // q
+}
+
+// ws: double[gridDim.x][NACC] per-wave partial sums, as ss_bwd_kernel leaves them
+template <int NS, int NI>
+__global__ __launch_bounds__(64) void ss_bwd_tp_combine_kernel(const float* __restrict__ rec, double* __restrict__ ws,
+                                                               float* __restrict__ gz0, int64_t B, int64_t K)
+{
+    constexpr int NACC = SSCoef<NS, NI>::kN + 2, NREC = SsTpRec<NS, NI>::N;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    double LAM[NS], tot[NACC];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) LAM[s] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) tot[i] = 0.0;
+    for (int64_t k = K - 1; k >= 0; --k) {
+        const float* __restrict__ o = rec + (size_t)k * NREC * B + b;
+        float v[NREC];
+#pragma unroll
+        for (int i = 0; i < NREC; ++i) v[i] = o[(size_t)i * B];
+        const float* Phi = v;
+        const float* beta = v + NS * NS;
+        const float* P = beta + NS;
+        const float* q = P + NS * NACC;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            double a = (double)q[i];
+#pragma unroll
+            for (int r = 0; r < NS; ++r) a += (double)P[r * NACC + i] * LAM[r];
+            tot[i] += a;
+        }
+        double nl[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            double a = (double)beta[s];
+#pragma unroll
+            for (int r = 0; r < NS; ++r) a += (double)Phi[s * NS + r] * LAM[r];
+            nl[s] = a;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) LAM[s] = nl[s];
+    }
+    if (live && gz0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) gz0[s * B + b] = (float)LAM[s];
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        double v = live ? tot[i] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0) ws[(int64_t)blockIdx.x * NACC + i] = v;
     }
 }
 

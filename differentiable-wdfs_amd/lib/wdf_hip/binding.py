@@ -172,6 +172,17 @@ def lib():
     L.wdf_ss_fwd_lin_tp.argtypes = [fp, fp, ci, ci, fp, fp, fp, fp, i64, i64, ci, vp, vp]
     L.wdf_ss_bwd.restype = ci
     L.wdf_ss_bwd.argtypes = [fp, fp, fp, ci, ci, ci, ci, ci, fp, fp, vp, fp, fp, fp, i64, i64, ci, vp]
+    if hasattr(L, "wdf_ss_fwd_tp"):                              # (absent from round-2 builds kept around for A/B runs)
+        L.wdf_ss_tp_chunks.restype = ci
+        L.wdf_ss_tp_chunks.argtypes = [i64, ci]
+        L.wdf_ss_fwd_tp_ws_bytes.restype = C.c_size_t
+        L.wdf_ss_fwd_tp_ws_bytes.argtypes = [ci, i64, ci]
+        L.wdf_ss_fwd_tp.restype = ci
+        L.wdf_ss_fwd_tp.argtypes = [fp, fp, fp, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, vp]
+        L.wdf_ss_bwd_tp_ws_bytes.restype = C.c_size_t
+        L.wdf_ss_bwd_tp_ws_bytes.argtypes = [ci, ci, i64, ci]
+        L.wdf_ss_bwd_tp.restype = ci
+        L.wdf_ss_bwd_tp.argtypes = [fp, fp, fp, ci, ci, ci, ci, ci, fp, fp, vp, fp, fp, fp, i64, i64, ci, vp]
     L.wdf_ss_bwd_ws_bytes.restype = C.c_size_t
     L.wdf_ss_bwd_ws_bytes.argtypes = [ci, ci, i64]
     L.wdf_omega_f32.restype = ci
@@ -211,6 +222,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_fwd_tp_kappa", "wdf_clipper_mlp_bwd_w_tp_kappa", "wdf_clipper_mlp_tp_starts",
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
+    "wdf_ss_tp_chunks", "wdf_ss_fwd_tp_ws_bytes", "wdf_ss_fwd_tp", "wdf_ss_bwd_tp_ws_bytes", "wdf_ss_bwd_tp",
     "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy", "wdf_event_bracket_next",
 )
@@ -994,6 +1006,52 @@ def ss_bwd(x, coef, ns, ni, zstash, gy, root_kind=ROOT_NONE, rootp=None, n_up=1,
     rc = lib().wdf_ss_bwd(_ptr(x), _ptr(coef), _ptr(rootp), ns, ni, root_kind, int(n_up), int(n_down),
                           _ptr(zstash), _ptr(gy), _ptr(ws), _ptr(gcoef), _ptr(groot), _ptr(gz0), B, T, 0, _stream())
     _check(rc, "wdf_ss_bwd")
+    return gcoef, groot, gz0
+
+
+def ss_fwd_tp(x, coef, ns, ni, rootp, n_chunks, warmup, tol=1e-6, n_up=1, n_down=1, want_stash=True, z0=None, want_zT=False):
+    """Time-parallel forward of a tree with a diode-pair root (include/wdf_hip.h, wdf_ss_fwd_tp): chunks warmed up from
+    z = 0, boundaries verified on the device, missed waves re-run sequentially behind a gate.
+    -> y [T,B], zstash [T,ns,B] | None, zT [ns,B] | None, status (device int32[4]: read with ss_tp_status)."""
+    require_gpu()
+    x, coef, rootp, z0 = _f32_dev(x, "x"), _f32_dev(coef, "coef"), _f32_dev(rootp, "rootp"), _f32_dev(z0, "z0")
+    B, T = x.shape[0], x.shape[1]
+    if x.numel() != B * T * ni or coef.numel() != lib().wdf_ss_ncoef(ns, ni):
+        raise WdfHipError("ss_fwd_tp: x / coef do not match ns, ni")
+    K = lib().wdf_ss_tp_chunks(T, int(n_chunks))
+    y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zs = torch.empty((T, ns, B), dtype=torch.float32, device=x.device) if want_stash else None
+    zT = torch.empty((ns, B), dtype=torch.float32, device=x.device) if want_zT else None
+    ws = torch.empty((lib().wdf_ss_fwd_tp_ws_bytes(ns, B, K),), dtype=torch.uint8, device=x.device)
+    status = torch.empty((4,), dtype=torch.int32, device=x.device)
+    rc = lib().wdf_ss_fwd_tp(_ptr(x), _ptr(coef), _ptr(rootp), ns, ni, int(n_up), int(n_down), _ptr(y), _ptr(zs), _ptr(z0),
+                             _ptr(zT), B, T, K, int(warmup), float(tol), _ptr(ws), _ptr(status), _stream())
+    _check(rc, "wdf_ss_fwd_tp")
+    return y, zs, zT, status
+
+
+def ss_tp_status(status):
+    s = status.cpu()
+    return {"n_bad": int(s[0]), "max_miss": float(s[1:2].view(torch.float32)[0]), "gated_waves": int(s[2])}
+
+
+def ss_bwd_tp(x, coef, ns, ni, zstash, gy, n_chunks, root_kind=ROOT_NONE, rootp=None, n_up=1, n_down=1, want_gz0=False):
+    """Exact chunked reverse sweep (wdf_ss_bwd_tp); same returns as ss_bwd."""
+    require_gpu()
+    x, coef, rootp = _f32_dev(x, "x"), _f32_dev(coef, "coef"), _f32_dev(rootp, "rootp")
+    zstash, gy = _f32_dev(zstash, "zstash"), _f32_dev(gy, "gy")
+    B, T = x.shape[0], x.shape[1]
+    if tuple(gy.shape) != (T, B):
+        raise WdfHipError(f"gy must be [T,B] = [{T},{B}]")
+    K = lib().wdf_ss_tp_chunks(T, int(n_chunks))
+    ncoef = lib().wdf_ss_ncoef(ns, ni)
+    ws = torch.empty((lib().wdf_ss_bwd_tp_ws_bytes(ns, ni, B, K),), dtype=torch.uint8, device=x.device)
+    gcoef = torch.empty((ncoef,), dtype=torch.float32, device=x.device)
+    groot = torch.empty((3,), dtype=torch.float32, device=x.device) if root_kind == ROOT_DIODE_PAIR else None
+    gz0 = torch.empty((ns, B), dtype=torch.float32, device=x.device) if want_gz0 else None
+    rc = lib().wdf_ss_bwd_tp(_ptr(x), _ptr(coef), _ptr(rootp), ns, ni, root_kind, int(n_up), int(n_down), _ptr(zstash),
+                             _ptr(gy), _ptr(ws), _ptr(gcoef), _ptr(groot), _ptr(gz0), B, T, K, _stream())
+    _check(rc, "wdf_ss_bwd_tp")
     return gcoef, groot, gz0
 
 

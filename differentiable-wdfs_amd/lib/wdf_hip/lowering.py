@@ -11,6 +11,10 @@ the matrices carry the autograd graph back to R and C: the reverse-sweep kernel 
 dL/d(matrices) and torch chains it to the component values -- which is what
 tape.gradient(loss, model.trainable_variables) is in the reference (lpf.py:87-90).
 """
+import math
+from collections import namedtuple
+
+import numpy as np
 import torch
 
 from . import binding
@@ -18,11 +22,42 @@ from . import compat_tf as tf
 
 
 # ------------------------------------------------------------------------------ autograd glue
+SsTpPlan = namedtuple("SsTpPlan", ["k_fwd", "warmup", "tol", "k_bwd"])
+LAST_SS_TP_STATUS = {"status": None}
+N_SIMD = 1024            # MI355X: 256 CUs x 4
+
+
+def plan_ss_time_parallel(coef64, ns, ni, root_kind, B, T, tol=1.0e-6):
+    """SsTpPlan for the time-parallel state-space kernels (csrc/wdf_statespace.h), or None when the batch already fills the
+    chip / the tree has no state.  Host arithmetic on the step's small matrices only (no device work, no sync).
+    Reverse sweep: exact, so chunks are added until every SIMD holds ~4 waves.  Forward with a diode root: a chunk warms up
+    from z = 0 for W steps; W outlasts the slowest mode of the step's Jacobian  A + Da E ca^T  at both ends of the diode's
+    slope Da in [-1, 1] (off and fully conducting), with the same 0.01 tol margin as the clipper planner; chunks only while
+    a chunk is at least as long as its warm-up.  The device verifies every boundary whatever the estimate."""
+    if ns < 1:
+        return None
+    waves = max(1, -(-B // 64))
+    k_bwd = min(T // 64, (4 * N_SIMD) // waves)
+    k_fwd, W = 1, 0
+    if root_kind == binding.ROOT_DIODE_PAIR:
+        c = coef64.detach().double().cpu().numpy()
+        A = c[:ns * ns].reshape(ns, ns)
+        oE = ns * ns + ns * ni
+        E, ca = c[oE:oE + ns], c[oE + ns:oE + 2 * ns]
+        rho = max(float(np.max(np.abs(np.linalg.eigvals(A + sgn * np.outer(E, ca))))) for sgn in (1.0, -1.0))
+        if rho < 1.0 - 1e-9:
+            W = 16 if rho <= 0.0 else max(16, -(-int(math.ceil(math.log(0.01 * tol) / math.log(rho))) // 8) * 8)
+            k_fwd = min(T // max(W, 64), (2 * N_SIMD) // waves)
+    if k_fwd < 2 and k_bwd < 2:
+        return None
+    return SsTpPlan(max(1, k_fwd), W, float(tol), max(1, k_bwd))
+
+
 class _StateSpaceFn(torch.autograd.Function):
-    """y [T,B] = statespace(coef, rootp, x [B,T,ni], z0)."""
+    """y [T,B] = statespace(coef, rootp, x [B,T,ni], z0).  tp: an SsTpPlan (time-parallel kernels) or None."""
 
     @staticmethod
-    def forward(ctx, coef, rootp, x, z0, ns, ni, root_kind, n_up, n_down, want_zT):
+    def forward(ctx, coef, rootp, x, z0, ns, ni, root_kind, n_up, n_down, want_zT, tp=None):
         need = coef.requires_grad or (rootp is not None and rootp.requires_grad) or (z0 is not None and z0.requires_grad)
         c = coef.detach().contiguous()
         rp = None if rootp is None else rootp.detach().contiguous()
@@ -31,9 +66,14 @@ class _StateSpaceFn(torch.autograd.Function):
         k_lin = min(T // 64, (2 * 1024) // max(1, -(-B // 64))) if (root_kind == binding.ROOT_NONE and ns > 0) else 0
         if k_lin >= 2:      # linear tree, few sequences: the exact chunked scan (csrc/wdf_statespace.h) fills the chip
             y, zs, zT = binding.ss_fwd_lin_tp(x, c, ns, ni, k_lin, want_stash=need, z0=z0d, want_zT=want_zT)
+        elif tp is not None and tp.k_fwd >= 2 and root_kind == binding.ROOT_DIODE_PAIR:
+            # nonlinear root: chunks warmed up from z = 0, verified on the device, missed waves re-run sequentially
+            y, zs, zT, st = binding.ss_fwd_tp(x, c, ns, ni, rp, tp.k_fwd, tp.warmup, tp.tol, n_up, n_down, want_stash=need,
+                                              z0=z0d, want_zT=want_zT)
+            LAST_SS_TP_STATUS["status"] = st
         else:
             y, zs, zT = binding.ss_fwd(x, c, ns, ni, root_kind, rp, n_up, n_down, want_stash=need, z0=z0d, want_zT=want_zT)
-        ctx.cfg = (ns, ni, root_kind, n_up, n_down, z0 is not None)
+        ctx.cfg = (ns, ni, root_kind, n_up, n_down, z0 is not None, tp)
         ctx.save_for_backward(c, rp, x, zs)
         if want_zT:
             ctx.mark_non_differentiable(zT)
@@ -42,11 +82,15 @@ class _StateSpaceFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gzT):
-        ns, ni, root_kind, n_up, n_down, has_z0 = ctx.cfg
+        ns, ni, root_kind, n_up, n_down, has_z0, tp = ctx.cfg
         c, rp, x, zs = ctx.saved_tensors
-        gcoef, groot, gz0 = binding.ss_bwd(x, c, ns, ni, zs, gy.contiguous(), root_kind, rp, n_up, n_down,
-                                           want_gz0=has_z0)
-        return gcoef, groot, None, gz0, None, None, None, None, None, None
+        if tp is not None and tp.k_bwd >= 2 and ns >= 1:      # exact chunked reverse sweep (any root)
+            gcoef, groot, gz0 = binding.ss_bwd_tp(x, c, ns, ni, zs, gy.contiguous(), tp.k_bwd, root_kind, rp, n_up, n_down,
+                                                  want_gz0=has_z0)
+        else:
+            gcoef, groot, gz0 = binding.ss_bwd(x, c, ns, ni, zs, gy.contiguous(), root_kind, rp, n_up, n_down,
+                                               want_gz0=has_z0)
+        return gcoef, groot, None, gz0, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------ tree walking
@@ -248,8 +292,13 @@ class Circuit:
         else:
             rootp, kind, n_up, n_down = None, binding.ROOT_NONE, 1, 1
         z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(self.ns, -1).contiguous()
+        tp = getattr(self, "time_parallel", None)
+        if tp == "auto":
+            tp = plan_ss_time_parallel(coef64, self.ns, self.ni, kind, x.shape[0], x.shape[1])
+        elif not isinstance(tp, SsTpPlan):
+            tp = None
         y, zT = _StateSpaceFn.apply(coef, rootp, x.contiguous(), z0t, self.ns, self.ni, kind, n_up, n_down,
-                                    bool(return_state))
+                                    bool(return_state), tp)
         y = y.as_subclass(tf.Tensor)
         return (y, zT) if return_state else y
 

@@ -386,3 +386,96 @@ def test_linear_tree_exact_chunked_scan_equals_sequential(golden, ns, B, T, K):
         p, g = golden("g7_recorded_programs.npz"), golden("g1_rc_lowpass.npz")
         yl, _, _ = wb.ss_fwd_lin_tp(cuda(p["lpf_x"]), cuda(p["lpf_coef"]), 1, 1, K)
         assert np.max(np.abs(yl.cpu().numpy()[:, 0] - g["y_f64"])) < 1e-6
+
+
+# ---- time-parallel state-space kernels (csrc/wdf_statespace.h, second half) -------------------------------------
+def _hpf_clipper(wdf, time_parallel, n_up=2, n_down=3):
+    """HPFDiodeClipper.h:28-32: Parallel(R, Series(Vs, C)) + diode pair."""
+    R = wdf.Resistor(33.0e3, True)
+    Vs = wdf.ResistiveVoltageSource(1.0e3, trainable=True)
+    C = wdf.Capacitor(22.0e-9, FS, True)
+    top = wdf.Parallel(R, wdf.Series(Vs, C))
+    dp = wdf.DiodePair(top, 4.352e-9, Vt=25.85e-3, nDiodes=1.906, N_up=n_up, N_down=n_down, trainable=True)
+    return wdf.Circuit(top, dp, R, time_parallel=time_parallel), [R.R, Vs.R, C.C, dp.Is, dp.nVt]
+
+
+def _two_state_clipper(wdf, time_parallel):
+    Vs1 = wdf.ResistiveVoltageSource(22.0e3, trainable=True)
+    C1 = wdf.Capacitor(4.7e-9, FS, trainable=True)
+    R1 = wdf.Resistor(3.3e3, True)
+    Vs2 = wdf.ResistiveVoltageSource(10.0e3, trainable=True)
+    C2 = wdf.Capacitor(10.0e-9, FS, trainable=True)
+    top = wdf.Series(wdf.Parallel(Vs1, C1), wdf.Parallel(wdf.Series(R1, Vs2), C2))
+    dp = wdf.DiodePair(top, 4.352e-9, Vt=0.0493, trainable=True)
+    return wdf.Circuit(top, dp, C2, time_parallel=time_parallel), [Vs1.R, C1.C, R1.R, Vs2.R, C2.C, dp.Is, dp.nVt]
+
+
+@pytest.mark.parametrize("build,ni,B,T", [(_hpf_clipper, 1, 200, 2048), (_hpf_clipper, 1, 70, 1000), (_two_state_clipper, 2, 130, 1536)])
+def test_state_space_time_parallel_kernels_equal_sequential(wdf, build, ni, B, T):
+    """Generic trees with a diode root through the chunked kernels (planner's own plan, time_parallel="auto"): the forward
+    (chunks warmed up from z = 0, verified on the device) within 2e-6 of the sequential kernel with a clean verdict, the exact
+    chunked reverse sweep equal to the sequential sweep up to summation order (2e-5 of each gradient)."""
+    from wdf_hip import lowering, binding as wb
+    tf = wdf.tf
+    rng = np.random.default_rng(B + T)
+    x = (rng.standard_normal((B, T, ni)) * 1.2).astype(np.float32)
+    x = x[:, :, 0] if ni == 1 else x
+    gy = cuda(rng.standard_normal((T, B)) / (B * T))
+
+    def run(tp):
+        circ, params = build(wdf, tp)
+        y = circ(cuda(x))
+        grads = tf.GradientTape().gradient(tf.reduce_sum(y * gy), params)
+        return circ, y, np.array([float(v) for v in grads])
+
+    _, y_seq, g_seq = run(None)
+    lowering.LAST_SS_TP_STATUS["status"] = None
+    circ, y_tp, g_tp = run("auto")
+    coef64, _ = circ.matrices()
+    plan = lowering.plan_ss_time_parallel(coef64, circ.ns, circ.ni, wb.ROOT_DIODE_PAIR, B, T)
+    # (the HPF clipper forgets slowly -- (R + Rs) C = 36 samples, 664 warm-up steps: 1000 samples are ONE forward chunk)
+    # the two-state tree's Jacobian reaches |eigenvalue| >= 1 at the conducting end of the diode's slope: no speculation there
+    assert plan is not None and plan.k_bwd >= 2 and (plan.k_fwd >= 2) == (build is _hpf_clipper and T == 2048), plan
+    if plan.k_fwd >= 2:
+        st = wb.ss_tp_status(lowering.LAST_SS_TP_STATUS["status"])
+        assert st["n_bad"] == 0 and st["gated_waves"] == 0 and st["max_miss"] <= 1e-6, (st, plan)
+    assert float((y_tp - y_seq).abs().max()) <= 2e-6
+    assert rel(g_tp, g_seq) <= 2e-5, (g_tp, g_seq)
+
+
+def test_state_space_time_parallel_forward_reruns_what_missed(wdf):
+    """A warm-up far too short: the verification gates the waves with a miss and the sequential kernel behind it restores
+    them -- the result IS the sequential kernel's."""
+    from wdf_hip import lowering, binding as wb
+    B, T = 200, 2048
+    x = (np.random.default_rng(3).standard_normal((B, T)) * 1.2).astype(np.float32)
+    _, y_seq = _run_forward(wdf, x, None)
+    lowering.LAST_SS_TP_STATUS["status"] = None
+    _, y_tp = _run_forward(wdf, x, lowering.SsTpPlan(8, 8, 1.0e-6, 8))
+    st = wb.ss_tp_status(lowering.LAST_SS_TP_STATUS["status"])
+    assert st["n_bad"] > 0 and st["gated_waves"] == 4, st          # every 64-sequence wave has a sequence that missed
+    assert torch.equal(y_tp.as_subclass(torch.Tensor), y_seq.as_subclass(torch.Tensor))
+
+
+def _run_forward(wdf, x, tp):
+    circ, _ = _hpf_clipper(wdf, tp)
+    return circ, circ(cuda(x))
+
+
+@pytest.mark.parametrize("B,T,K", [(5, 100, 3), (64, 1280, 8), (130, 1000, 16)])
+def test_linear_tree_exact_chunked_reverse_sweep(wdf, B, T, K):
+    """lpf.py's RC lowpass (ideal-source root folded into the matrices): wdf_ss_bwd_tp == wdf_ss_bwd up to summation order,
+    ragged B and T, dL/dz0 included."""
+    from wdf_hip import binding as wb
+    rng = np.random.default_rng(B + T)
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    coef64, _ = wdf.Circuit(I1, Vs, C1).matrices()
+    coef = coef64.detach().float().cuda()
+    x = cuda(rng.standard_normal((B, T)))
+    z0 = cuda(rng.uniform(-0.3, 0.3, (1, B)))
+    gy = cuda(rng.standard_normal((T, B)) / (B * T))
+    y, zs, _ = wb.ss_fwd(x, coef, 1, 1, z0=z0)
+    g_seq, _, gz_seq = wb.ss_bwd(x, coef, 1, 1, zs, gy, want_gz0=True)
+    g_tp, _, gz_tp = wb.ss_bwd_tp(x, coef, 1, 1, zs, gy, K, want_gz0=True)
+    assert float((g_tp - g_seq).abs().max()) <= 2e-5 * float(g_seq.abs().max())
+    assert float((gz_tp - gz_seq).abs().max()) <= 2e-5 * float(gz_seq.abs().max()) + 1e-12
