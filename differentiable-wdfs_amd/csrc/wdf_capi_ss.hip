@@ -173,14 +173,19 @@ int wdf_ss_fwd_tp(const float* x, const float* coef, const float* rootp, int ns,
     hipStream_t s = (hipStream_t)stream;
     const bool sym = n_up == n_down;
     const bool v4 = ((T * ni) % 4 == 0) && aligned16(x);
+    const int64_t W = ((int64_t)warmup + 7) / 8 * 8;
 #define WDF_SS_TP(NS_, NI_)                                                                                                  \
     if (ns == NS_ && ni == NI_) {                                                                                            \
         {                                                                                                                    \
             EventBracket bracket(s);                                                                                         \
-            if (sym) hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y, \
-                                        zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, (int64_t)warmup);    \
-            else hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y,   \
-                                    zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, (int64_t)warmup);        \
+            if (sym && v4) hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, true, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y, \
+                                              zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W);             \
+            else if (sym) hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, true, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y, \
+                                             zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W);              \
+            else if (v4) hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, false, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y,  \
+                                            zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W);               \
+            else hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, false, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y,        \
+                                    zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W);                       \
         }                                                                                                                    \
         if (K > 1) {                                                                                                         \
             hipLaunchKernelGGL(wdf::ss_tp_verify_kernel, dim3(grid.x), dim3(64), 0, s, (const float*)zwarm, (const float*)zend, ns, B,  \
@@ -221,18 +226,28 @@ int wdf_ss_bwd_tp(const float* x, const float* coef, const float* rootp, int ns,
     const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K);
     hipStream_t s = (hipStream_t)stream;
     const bool sym = n_up == n_down;
+    const bool v4 = ((T * ni) % 4 == 0) && aligned16(x);
 #define WDF_SS_BTP(NS_, NI_)                                                                                                 \
     if (ns == NS_ && ni == NI_) {                                                                                            \
         {                                                                                                                    \
             EventBracket bracket(s);                                                                                         \
-            if (root == wdf::kRootNone)                                                                                      \
-                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootNone, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up,  \
+            if (root == wdf::kRootNone && v4)                                                                                \
+                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootNone, true, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up,  \
+                                   n_down, zstash, gy, rec, B, T, L);                                                        \
+            else if (root == wdf::kRootNone)                                                                                 \
+                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootNone, true, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, \
+                                   n_down, zstash, gy, rec, B, T, L);                                                        \
+            else if (sym && v4)                                                                                              \
+                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootDiode, true, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up, \
                                    n_down, zstash, gy, rec, B, T, L);                                                        \
             else if (sym)                                                                                                    \
-                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootDiode, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up, \
+                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootDiode, true, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, \
+                                   n_down, zstash, gy, rec, B, T, L);                                                        \
+            else if (v4)                                                                                                     \
+                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootDiode, false, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up, \
                                    n_down, zstash, gy, rec, B, T, L);                                                        \
             else                                                                                                             \
-                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootDiode, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, \
+                hipLaunchKernelGGL((wdf::ss_bwd_tp_kernel<NS_, NI_, wdf::kRootDiode, false, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, \
                                    n_down, zstash, gy, rec, B, T, L);                                                        \
         }                                                                                                                    \
         hipLaunchKernelGGL((wdf::ss_bwd_tp_combine_kernel<NS_, NI_>), dim3(grid.x), dim3(64), 0, s, (const float*)rec, part, gz0, B,   \

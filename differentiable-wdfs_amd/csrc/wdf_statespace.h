@@ -473,7 +473,7 @@ static __global__ __launch_bounds__(64) void ss_grad_reduce_kernel(const double*
 // radius of the step's Jacobian at both ends of the diode's slope, lowering.plan_ss_time_parallel).
 struct SsTpStatus { int n_bad; float max_miss; int gated_waves; int pad; };
 
-template <int NS, int NI, bool SYM>
+template <int NS, int NI, bool SYM, bool VEC4>
 __global__ __launch_bounds__(64) void ss_fwd_tp_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                        const float* __restrict__ rootp, int n_up, int n_down,
                                                        float* __restrict__ y, float* __restrict__ zstash,
@@ -494,17 +494,41 @@ __global__ __launch_bounds__(64) void ss_fwd_tp_kernel(const float* __restrict__
     float z[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) z[s] = (tw == 0 && z0) ? z0[s * B + b] : 0.0f;
+    // the lane streams its own row of x in 8-step blocks (16-byte loads), one block ahead; tw, t0 and L are multiples of 8
     const float* __restrict__ xp = x + b * T * NI;
-    for (int64_t t = tw; t < t0; ++t) {                         // warm-up: nothing stored
-        float xt[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) xt[i] = xp[t * NI + i];
-        (void)ss_fwd_step<NS, NI, kRootDiode, SYM>(c, dp, xt, z);
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) zwarm[(k * NS + s) * B + b] = z[s];
+    const int64_t tfull = t1 - (t1 - tw) % kBlkSS;
+    float xc[kBlkSS][NI], xn[kBlkSS][NI];
+    if (tw < tfull) ss_load_block<NI, VEC4>(x, b, T, tw, xn);
     const bool STASH = zstash != nullptr;
-    for (int64_t t = t0; t < t1; ++t) {
+    for (int64_t t = tw; t < tfull; t += kBlkSS) {
+#pragma unroll
+        for (int q = 0; q < kBlkSS; ++q)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) xc[q][i] = xn[q][i];
+        if (t + kBlkSS < tfull) ss_load_block<NI, VEC4>(x, b, T, t + kBlkSS, xn);
+        if (t < t0) {                                           // warm-up block: nothing stored
+#pragma unroll
+            for (int q = 0; q < kBlkSS; ++q) (void)ss_fwd_step<NS, NI, kRootDiode, SYM>(c, dp, xc[q], z);
+            continue;
+        }
+        if (t == t0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zwarm[(k * NS + s) * B + b] = z[s];
+        }
+#pragma unroll
+        for (int q = 0; q < kBlkSS; ++q) {
+            if (STASH) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) zstash[((t + q) * NS + s) * B + b] = z[s];
+            }
+            y[(t + q) * B + b] = ss_fwd_step<NS, NI, kRootDiode, SYM>(c, dp, xc[q], z);
+        }
+    }
+    if (tfull <= t0) {                                          // (a chunk shorter than a block: only the last one can be)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) zwarm[(k * NS + s) * B + b] = z[s];
+    }
+    for (int64_t t = (tfull > t0 ? tfull : t0); t < t1; ++t) { // tail of the last chunk (T % 8)
         float xt[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) xt[i] = xp[t * NI + i];
@@ -601,7 +625,7 @@ __device__ __forceinline__ void ss_bwd_linear(const SSCoef<NS, NI>& c, const flo
 }
 
 // rec: float [K][SsTpRec::N][B] = {Phi[NS][NS] (row r = lam component, column = LAM component), beta[NS], P[NS][NACC], q[NACC]}
-template <int NS, int NI, int ROOT, bool SYM>
+template <int NS, int NI, int ROOT, bool SYM, bool VEC4>
 __global__ __launch_bounds__(64) void ss_bwd_tp_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                        const float* __restrict__ rootp, int n_up, int n_down,
                                                        const float* __restrict__ zstash, const float* __restrict__ gy,
@@ -626,12 +650,7 @@ __global__ __launch_bounds__(64) void ss_bwd_tp_kernel(const float* __restrict__
         for (int i = 0; i < NACC; ++i) acc[r][i] = 0.0f;
     }
     const float* __restrict__ xp = x + b * T * NI;
-    for (int64_t t = t1 - 1; t >= t0; --t) {
-        float xt[NI], zt[NS];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) xt[i] = xp[t * NI + i];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) zt[s] = zstash[(t * NS + s) * B + b];
+    auto one_step = [&](const float (&xt)[NI], const float (&zt)[NS], float g) {
         float bb = 0.0f, Da = 0.0f, DL = 0.0f, DV = 0.0f;
         if constexpr (ROOT == kRootDiode) {
             float a = 0.0f;
@@ -647,9 +666,41 @@ __global__ __launch_bounds__(64) void ss_bwd_tp_kernel(const float* __restrict__
             DL = -dp.d.two_v * o.lam * (o.m0 * w0p - o.m1 * w1p);
             DV = fmaf(2.0f * l2 * a, sp * fast_rcp(dp.V), -2.0f * o.lam * (o.m0 * o.w0 - o.m1 * o.w1));
         }
-        const float g = gy[t * B + b];
 #pragma unroll
         for (int r = 0; r <= NS; ++r) ss_bwd_linear<NS, NI>(c, xt, zt, bb, Da, DL, DV, r == 0 ? g : 0.0f, lam[r], acc[r]);
+    };
+    const int64_t tfull = t1 - (t1 - t0) % kBlkSS;              // t0 and L are multiples of 8: only the last chunk has a tail
+    for (int64_t t = t1 - 1; t >= tfull; --t) {                 // tail first (highest t)
+        float xt[NI], zt[NS];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xt[i] = xp[t * NI + i];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) zt[s] = zstash[(t * NS + s) * B + b];
+        one_step(xt, zt, gy[t * B + b]);
+    }
+    float xc[kBlkSS][NI], xn[kBlkSS][NI], zc[kBlkSS][NS], zn[kBlkSS][NS], gc[kBlkSS], gn[kBlkSS];
+    auto load_blk = [&](int64_t tb, float (&xv)[kBlkSS][NI], float (&zv)[kBlkSS][NS], float (&gv)[kBlkSS]) {
+        ss_load_block<NI, VEC4>(x, b, T, tb, xv);
+#pragma unroll
+        for (int q = 0; q < kBlkSS; ++q) {
+            gv[q] = gy[(tb + q) * B + b];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zv[q][s] = zstash[((tb + q) * NS + s) * B + b];
+        }
+    };
+    if (tfull > t0) load_blk(tfull - kBlkSS, xn, zn, gn);
+    for (int64_t tb = tfull - kBlkSS; tb >= t0; tb -= kBlkSS) {  // 8-step blocks, the next one (earlier in time) in flight
+#pragma unroll
+        for (int q = 0; q < kBlkSS; ++q) {
+            gc[q] = gn[q];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) xc[q][i] = xn[q][i];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zc[q][s] = zn[q][s];
+        }
+        if (tb - kBlkSS >= t0) load_blk(tb - kBlkSS, xn, zn, gn);
+#pragma unroll
+        for (int q = kBlkSS - 1; q >= 0; --q) one_step(xc[q], zc[q], gc[q]);
     }
     float* __restrict__ o = rec + (size_t)k * SsTpRec<NS, NI>::N * B + b;
     int e = 0;
