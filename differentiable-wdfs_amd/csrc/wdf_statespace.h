@@ -448,8 +448,17 @@ static __global__ __launch_bounds__(64) void ss_grad_reduce_kernel(const double*
     // one lane per accumulator column (nacc <= 64)
     const int i = threadIdx.x;
     double s = 0.0;
-    if (i < nacc)
-        for (int p = 0; p < nparts; ++p) s += ws[(int64_t)p * nacc + i];
+    if (i < nacc) {
+        int p = 0;
+        for (; p + 8 <= nparts; p += 8) {                      // eight loads in flight, added in index order
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ws[(int64_t)(p + q) * nacc + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; p < nparts; ++p) s += ws[(int64_t)p * nacc + i];
+    }
     if (i < ncoef) gcoef[i] = (float)s;
     const double sL = __shfl(s, ncoef, 64), sV = __shfl(s, ncoef + 1, 64);
     if (i == 0 && groot && rootp) {
