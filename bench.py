@@ -51,31 +51,35 @@ def measured_traffic(kernel, cfg):
     this same command (profiles/*_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, see their _doc,
     collected by tools/pmc_traffic.sh) -- only from a file taken on the configuration being run;
     otherwise (None, None)."""
-    import glob
-    for path in sorted(glob.glob(PMC_TRAFFIC_GLOB), reverse=True):
-        try:
-            d = json.load(open(path))
-            if all(d["config"].get(k, "mse" if k == "loss" else None) == v for k, v in cfg.items()) and kernel in d["kernels"]:
-                return d["kernels"][kernel]["traffic_bytes"], os.path.relpath(path, REPO)
-        except (OSError, ValueError, KeyError, TypeError):
-            pass
-    return None, None
+    return _committed_pass(PMC_TRAFFIC_GLOB, kernel, cfg, lambda k: k["traffic_bytes"])
 
 
 def measured_valu_cycles(kernel, cfg):
     """(VALU-active cycles per launch of `kernel`, summed over all waves; source file) from the committed SQ pass of this
     command (profiles/*_sq_counters.json, tools/pmc_sq.sh: SQ_ACTIVE_INST_VALU counts quad-cycles) on the configuration
     being run; otherwise (None, None)."""
+    return _committed_pass(SQ_GLOB, kernel, cfg, lambda k: 4.0 * k["SQ_ACTIVE_INST_VALU"])
+
+
+def _committed_pass(pattern, kernel, cfg, value):
+    """The newest committed counter file whose configuration is the one being run: batch, layout, loss and the kernel's own
+    chunk count must match; among those the one whose warm-up (the device controller moves it by a few 16-step units from
+    run to run: < 3 % of the kernel's work) is closest."""
     import glob
-    for path in sorted(glob.glob(SQ_GLOB), reverse=True):
+    best = None
+    for path in sorted(glob.glob(pattern), reverse=True):
         try:
             d = json.load(open(path))
             c = d.get("config")
-            if c and all(c.get(k, "mse" if k == "loss" else None) == v for k, v in cfg.items()) and kernel in d["kernels"]:
-                return 4.0 * d["kernels"][kernel]["SQ_ACTIVE_INST_VALU"], os.path.relpath(path, REPO)
+            if not c or kernel not in d["kernels"]:
+                continue
+            if all(c.get(k, "mse" if k == "loss" else None) == v for k, v in cfg.items() if k != "fwd_warmup_steps"):
+                dist = abs((c.get("fwd_warmup_steps") or 0) - (cfg.get("fwd_warmup_steps") or 0))
+                if best is None or dist < best[0]:
+                    best = (dist, value(d["kernels"][kernel]), os.path.relpath(path, REPO))
         except (OSError, ValueError, KeyError, TypeError):
             pass
-    return None, None
+    return (None, None) if best is None else (best[1], best[2])
 
 
 def _oracle():
