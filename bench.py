@@ -313,19 +313,25 @@ class Trainer:
 
     def run(self, warmup, steps, dev):
         """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
-        for _ in range(warmup):
-            self.step()
+        n_ev = 2 if self.fused else 4
+        warm_evs = []
+        for i in range(warmup):
+            # (graph mode: the replayed steps cannot carry per-kernel events, so the kernel durations reported are those of
+            #  the warm-up steps' kernels, recorded here and read after the timed region)
+            e = [binding.Event() for _ in range(n_ev)] if self.args.graph else None
+            warm_evs.append(e)
+            self.step(ev=e)
         # HIP events around the recurrence kernel of every 4th step, recorded INSIDE the timed region on the launch stream
         # and read only after its closing synchronize (no host wait in between): kernel time and step time from one loop
-        n_ev = 2 if self.fused else 4
         graph = None
         if self.args.graph:
             # One training step -- kernel(s), (N > 1) the RCCL all-reduce, the update -- captured once as a HIP graph and
             # replayed: the host then spends one launch per step instead of 2..5 plus torch.distributed's dispatch (which,
             # not the GPU, bounds the multi-rank step when driven eagerly).  Everything a step reads or writes lives in
             # device buffers that do not move (theta, Adam moments and step count, warm-start state, workspaces).
-            if warmup < 1:
-                self.step()                                    # (first-use allocations happen outside the capture)
+            if warmup < 1:                                     # (first-use allocations happen outside the capture)
+                warm_evs.append([binding.Event() for _ in range(n_ev)])
+                self.step(ev=warm_evs[-1])
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
@@ -348,10 +354,8 @@ class Trainer:
         torch.cuda.synchronize()
         wdist.barrier()
         dt = time.perf_counter() - t0
-        if graph is not None:                                  # kernel durations: a few eager, bracketed steps behind the timed region
-            for _ in range(min(steps, 10)):
-                self.step(timed=True)
-            torch.cuda.synchronize()
+        if graph is not None:                                  # kernel durations: the warm-up steps' (their last ones: past the cold call)
+            evs = [e for e in warm_evs if e is not None][-8:] + evs
         for e in evs:
             if e is not None:
                 self.t_fwd.append(e[0].elapsed_ms(e[1]))

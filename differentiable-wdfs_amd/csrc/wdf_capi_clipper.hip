@@ -541,7 +541,7 @@ int wdf_clipper_step_mse_tp(const float* x, const float* r, float* theta, float 
     if (!gtheta || !sse) return fail(WDF_EINVAL, "null gtheta/sse");
     if (m && (!v || !step || !lr)) return fail(WDF_EINVAL, "Adam update asked for (m) but v/step/lr missing");
     const wdf::AdamTail adam{m ? theta : nullptr, m, v, step, lr, beta1, beta2, eps, lo, hi};
-    const wdf::FusedOut out{gtheta, accumulate, sse, adam, 0.0, 0.0, nullptr, nullptr, wdf::TpFinishCtx{nullptr, nullptr, 0, nullptr, 0.0f, 0, 0, 0}};
+    const wdf::FusedOut out{gtheta, accumulate, sse, adam, 0.0, 0.0, nullptr, nullptr, wdf::TpFinishCtx{nullptr, nullptr, 0, nullptr, 0.0f, 0, 0, 0, false}};
     return step_tp_common(x, r, theta, fs, n_up, n_down, target, 0.5f * gscale, skip, y, z0, zT, B, T, n_chunks, warmup, tol, ws,
                           status, state, max_warm_tiles, false, out, flags, stream, "wdf_clipper_step_mse_tp");
 }
@@ -557,7 +557,7 @@ int wdf_clipper_step_esr_tp(const float* x, const float* r, float* theta, float 
     if (!(n_global > 0.0)) return fail(WDF_EINVAL, "n_global must be positive");
     if (m && (!gtheta || !v || !step || !lr)) return fail(WDF_EINVAL, "Adam update asked for (m) but gtheta/v/step/lr missing");
     const wdf::AdamTail adam{m ? theta : nullptr, m, v, step, lr, beta1, beta2, eps, lo, hi};
-    const wdf::FusedOut out{gtheta, 0, nullptr, adam, n_global, eps_energy, sums10, loss3, wdf::TpFinishCtx{nullptr, nullptr, 0, nullptr, 0.0f, 0, 0, 0}};
+    const wdf::FusedOut out{gtheta, 0, nullptr, adam, n_global, eps_energy, sums10, loss3, wdf::TpFinishCtx{nullptr, nullptr, 0, nullptr, 0.0f, 0, 0, 0, false}};
     return step_tp_common(x, r, theta, fs, n_up, n_down, target, 0.5f, skip, y, z0, zT, B, T, n_chunks, warmup, tol, ws, status,
                           state, max_warm_tiles, true, out, flags, stream, "wdf_clipper_step_esr_tp");
 }

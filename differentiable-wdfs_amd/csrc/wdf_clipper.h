@@ -522,12 +522,17 @@ struct TpCtl {
     float th2[4];     // theta of the call before
     float last_miss;  // largest boundary miss of the last call
     int n_calls;
-    int geom;         // (K << 8) | J of the calls that wrote the snapshots; a different geometry restarts cold
+    int geom;         // tp_geom_tag(K, J, skewed spans?) of the calls that wrote the snapshots; another geometry restarts cold
     int j_floor;      // low byte: the controller never goes below this many warm-up tiles (host: 0; = max pins it); above: hold counter
     float th3[4];     // theta of the call before th2's (the quadratic extrapolation's third point)
     int pad[12];
 };
 static_assert(sizeof(TpCtl) == 128, "TpCtl layout");
+
+// What identifies the chunk boundaries the snapshots were taken at: chunk count, snapshot depth, and whether the one-pass
+// step's skewed spans (wdf_clipper_fused.h, chunk_span) were in force -- the forward kernel always runs equal spans, so a
+// state shared between the two kernels restarts cold instead of loading snapshots from the other kernel's boundaries.
+__device__ __forceinline__ int tp_geom_tag(int64_t K, int J, bool skewed) { return (int)((K << 8) | J) | (skewed ? (1 << 30) : 0); }
 
 // Where a chunk starts from: the snapshots of the last calls, extrapolated ALONG THE PARAMETER PATH to this call's theta.
 // With d1 = theta/th1 - 1 (this call against the last), d0 = th1/th2 - 1, d00 = th2/th3 - 1 (relative steps, 4-vectors) the
@@ -794,7 +799,7 @@ __device__ __forceinline__ bool tp_tile_last(unsigned* tickets)
 __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restrict__ theta, TpStatus* __restrict__ status,
                                                             TpCtl* __restrict__ ctl, const TpCtl& c0, int J, unsigned* tickets,
                                                             float tol, int64_t K, int64_t L, int64_t W, int nb, float mm,
-                                                            bool keep_fallback_count)
+                                                            bool keep_fallback_count, bool skewed = false)
 {
     TpAcc* acc = reinterpret_cast<TpAcc*>(tickets);
     if (keep_fallback_count) { status->n_bad = nb; status->max_miss = mm; }      // (fallback_ran: the repair launch adds to it)
@@ -802,7 +807,7 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
     *acc = TpAcc{0, 0, 0u, 0u};
     if (ctl == nullptr) return;
     TpCtl c = c0;
-    const bool stateful = c.geom == (int)((K << 8) | J);
+    const bool stateful = c.geom == tp_geom_tag(K, J, skewed);
     const int head = stateful ? c.head : 0;
     const int valid = stateful ? c.valid : 0;
     int j = c.j_next;
@@ -839,7 +844,7 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
     }
     c.head = (head + 1) % kTpRing;
     c.valid = valid < 3 ? valid + 1 : 3;
-    c.geom = (int)((K << 8) | J);
+    c.geom = tp_geom_tag(K, J, skewed);
     c.last_miss = mm;
     c.n_calls = stateful ? c.n_calls + 1 : 1;
     *ctl = c;
@@ -1113,7 +1118,7 @@ __device__ __forceinline__ void adam_tail_apply(const AdamTail& adam, const Adam
 
 // The verification's deferred half (one-pass step, tp_verify_tile<..., DEFER>): what the finishing wave needs to publish the
 // status and steer the warm start.  status == nullptr: nothing deferred (the reverse sweep).
-struct TpFinishCtx { TpStatus* status; TpCtl* ctl; int J; unsigned* tickets; float tol; int64_t K, L, W; };
+struct TpFinishCtx { TpStatus* status; TpCtl* ctl; int J; unsigned* tickets; float tol; int64_t K, L, W; bool skewed = false; };
 
 // Fetched as soon as a wave knows it finishes the step (every tile has added its share by then: the adds were awaited before
 // each tile's step ticket), used after the reduction.
@@ -1134,7 +1139,8 @@ __device__ __forceinline__ TpFinishFetched tp_finish_fetch(const TpFinishCtx& fc
 __device__ __forceinline__ void tp_finish_deferred(const TpFinishCtx& fc, const TpFinishFetched& f, const float* theta)
 {
     if (fc.status == nullptr || threadIdx.x != 0) return;
-    tp_publish_status_and_steer(theta, fc.status, fc.ctl, f.c, fc.J, fc.tickets, fc.tol, fc.K, fc.L, fc.W, f.nb, __int_as_float(f.mm_bits), true);
+    tp_publish_status_and_steer(theta, fc.status, fc.ctl, f.c, fc.J, fc.tickets, fc.tol, fc.K, fc.L, fc.W, f.nb, __int_as_float(f.mm_bits), true,
+                                fc.skewed);
 }
 
 // A tile's partial sums {S_L, S_V, S_P, SSE} (per lane, dead lanes zero) -> the tile's slot of ws; the LAST tile
@@ -1143,7 +1149,7 @@ __device__ __forceinline__ void tp_finish_deferred(const TpFinishCtx& fc, const 
 __device__ __forceinline__ void tile_partial_and_finish(double dL, double dV, double dP, double dS, double* ws, unsigned* tickets,
                                                         const float* theta, float fs, int dyn_r, float* gtheta, int accumulate,
                                                         float* __restrict__ sse_out, const AdamTail& adam, double (*sh)[4],
-                                                        const TpFinishCtx& fc = TpFinishCtx{nullptr, nullptr, 0, nullptr, 0.0f, 0, 0, 0})
+                                                        const TpFinishCtx& fc = TpFinishCtx{nullptr, nullptr, 0, nullptr, 0.0f, 0, 0, 0, false})
 {
     const unsigned ntiles = gridDim.x;
     dL = wave_sum_dpp(dL); dV = wave_sum_dpp(dV); dP = wave_sum_dpp(dP); dS = wave_sum_dpp(dS);

@@ -70,6 +70,7 @@ constexpr int kFusedSchedGroup = 1;   // steps the instruction scheduler may int
 #ifndef WDF_FUSED_WAVES
 #define WDF_FUSED_WAVES 2           // waves per SIMD the one-pass kernel's register allocation is held to
 #endif
+constexpr int kFlushSteps = 32;     // fp32 -> fp64 accumulation granularity of the loss / tangent sums (as the kernel pair's 32-step blocks)
 constexpr int kFusedPrefetchAt = WDF_FUSED_PREFETCH_AT;
 constexpr int kFusedRows = WDF_FUSED_ROWS;
 
@@ -436,7 +437,7 @@ __device__ __forceinline__ void clipper_fused_body(
     chunk_span(k, K, L, skew, T, t0, t1);
     int64_t tw = 0;
     V z = vsplat<V>(0.0f);
-    const bool stateful = ctl != nullptr && ctl->geom == (int)((K << 8) | J);
+    const bool stateful = ctl != nullptr && ctl->geom == tp_geom_tag(K, J, skew != 0);
     const int valid = stateful ? ctl->valid : 0;
     const int head = stateful ? ctl->head : 0;
     if (k > 0 && valid > 0) {                               // warm start (see clipper_fwd_tp_body)
@@ -548,7 +549,9 @@ __device__ __forceinline__ void clipper_fused_body(
 #else
         wait_vmcnt<NR * (STASH ? 2 : 1)>();
 #endif
-        d.template flush<LOSS>(s);
+        // fp32 running sums go to the fp64 totals every kFlushSteps steps (a scalar branch per tile): flushed every tile of
+        // 8 steps the 20 conversions + fp64 adds were 2 % of the kernel's VALU time
+        if constexpr (LOSS != 0) { if ((t + NR - t0) % kFlushSteps == 0) d.template flush<LOSS>(s); }
     }
     for (int64_t tt = nfull_end; tt < t1; ++tt) {           // tail of the last chunk (T % NR)
         const V xin = load_step<V, TM>(x, q, B, T, tt);
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     const bool failed = tp_verify_tile<DYN_R, VT<V>::N, true>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
     WDF_DBG_STAMP(2);
     if (failed) return;                                     // left to clipper_fused_repair_kernel
-    out.fc = TpFinishCtx{status, ctl, J, tickets, tol, (int64_t)gridDim.y, L, W};
+    out.fc = TpFinishCtx{status, ctl, J, tickets, tol, (int64_t)gridDim.y, L, W, skew != 0};
     fused_combine_tile<VT<V>::N, LOSS>(rec, wpart, gridDim.y, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, out, sh);
 }
 
@@ -861,7 +864,7 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
     // The ring slot the step wrote its snapshots to.  The control block is advanced by the wave that FINISHES the step, and with
     // a flagged tile that wave is the last of THIS launch's blocks to combine -- after every block has read this:
     int slot = 0;
-    if (ctl != nullptr && snap != nullptr) slot = ((ctl->geom == (int)((K << 8) | J) ? ctl->head : 0) + 1) % kTpRing;
+    if (ctl != nullptr && snap != nullptr) slot = ((ctl->geom == tp_geom_tag(K, J, skew != 0) ? ctl->head : 0) + 1) % kTpRing;
     int nrep = 0;
 #pragma unroll 1
     for (int h = 0; h < NSEQ; ++h) {
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
         if (nrep) atomicAdd(&status->fallback_ran, nrep);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the re-written records have landed (write-through)
-    out.fc = TpFinishCtx{status, ctl, J, tickets, tol, K, L, W};
+    out.fc = TpFinishCtx{status, ctl, J, tickets, tol, K, L, W, skew != 0};
     fused_combine_tile<NSEQ, LOSS>(rec, wpart, K, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, out, sh);
 }
 

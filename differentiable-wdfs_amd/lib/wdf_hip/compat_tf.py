@@ -73,8 +73,11 @@ class Tensor(torch.Tensor):
                 return fn()
         key = (id(self), ver, name, ko)
         hit = rec.scalar_memo.get(key)
-        if hit is None:
-            hit = rec.scalar_memo[key] = (fn(), self, other)     # keeps the operands alive: their ids stay their own
+        # (a result the script has since modified in place -- `v += ...`, `.mul_()` -- is not the operation's value any more:
+        #  its version moved, compute afresh)
+        if hit is None or hit[0]._version != hit[3]:
+            out = fn()
+            hit = rec.scalar_memo[key] = (out, self, other, out._version)     # keeps the operands alive: their ids stay their own
         return hit[0]
 
     def __neg__(self):

@@ -73,12 +73,19 @@ class _ClipperMlpFn(torch.autograd.Function):
             # batch's address and shape; other data at the same address is caught by the verification like any miss.
             warm = None
             if use_kappa and WARM_START and tp.warmup_per_wave is None and z0 is None:
-                wkey = (x.data_ptr(), tuple(x.shape), tp.k_fwd, tp.warmup, None if r is None else r.data_ptr())
+                # keyed on the batch OBJECT and its version (a weak reference: the entry dies with the tensor, another
+                # tensor that lands at the same address later is another key, in-place changes of x restart cold)
+                wkey = (id(x), x._version, tuple(x.shape), tp.k_fwd, tp.warmup, None if r is None else (id(r), r._version))
                 warm = _WARM_START.get(wkey)
+                if warm is not None and (warm["xref"]() is not x or (r is not None and warm["rref"]() is not r)):
+                    warm = None                                  # (an id reused by another tensor)
                 if warm is None:
+                    for k in [k for k, v in _WARM_START.items() if v["xref"]() is None or (v["rref"] is not None and v["rref"]() is None)]:
+                        del _WARM_START[k]                       # entries whose batch has been freed
                     if len(_WARM_START) >= 8:
                         _WARM_START.clear()
-                    warm = _WARM_START[wkey] = {"warmup": 0, "calls": 0, "rows": None, "prev": None, "idx": None}
+                    warm = _WARM_START[wkey] = {"warmup": 0, "calls": 0, "rows": None, "prev": None, "idx": None,
+                                                "xref": weakref.ref(x), "rref": None if r is None else weakref.ref(r)}
             hot = warm is not None and warm["rows"] is not None
             if hot and warm.get("pending") is not None and warm["pending"][1].query():
                 # the verdict of an earlier warm call, copied to pinned memory behind its forward: no wait here
@@ -95,10 +102,13 @@ class _ClipperMlpFn(torch.autograd.Function):
                     if warm["clean"] >= 64 and warm["warmup"] > warm["floor"]:
                         w_new, warm["clean"] = warm["warmup"] - 16, 0
                 if w_new != warm["warmup"]:
+                    # the chunks start elsewhere: the rows kept belong to the old starts, so THIS call runs from z = 0 with
+                    # the cold warm-up (correct, one slower call) and leaves the rows for the new starts behind it
                     warm["warmup"] = w_new
-                    starts = binding.mlp_tp_starts(int(x.shape[1]), tp.k_fwd, w_new)        # the chunks start elsewhere
+                    starts = binding.mlp_tp_starts(int(x.shape[1]), tp.k_fwd, w_new)
                     warm["idx"] = torch.tensor(starts, dtype=torch.int64, device=x.device)
-                    warm["rows"], warm["prev"] = warm["zs"].index_select(0, warm["idx"]), None
+                    warm["rows"], warm["prev"] = None, None
+                    hot = False
             zinit = None
             if hot:
                 # secant in call count: 2 rows - prev (one launch)
@@ -137,9 +147,8 @@ class _ClipperMlpFn(torch.autograd.Function):
                     starts = binding.mlp_tp_starts(int(x.shape[1]), tp.k_fwd, warm["warmup"])
                     warm["idx"] = torch.tensor(starts, dtype=torch.int64, device=x.device)
                 rows = zs.index_select(0, warm["idx"])           # the verified trajectory at the next call's chunk starts
-                warm["prev"] = None if (fresh or not SECANT_WARM_START) else warm["rows"]
-                warm["rows"] = rows
-                warm["zs"] = zs                                  # (kept for a change of the warm-up: the rows move)
+                warm["prev"] = None if (fresh or not SECANT_WARM_START or warm["rows"] is None) else warm["rows"]
+                warm["rows"] = rows                              # ([chunks, B] floats: the stash itself is not kept alive)
         else:
             y, zs, zT = binding.clipper_mlp_fwd(x, th, wd, hidden, n_tanh, fs, r=r, want_stash=need or want_stash,
                                                 z0=z0, want_zT=want_zT)

@@ -180,3 +180,24 @@ def test_replay_memo_stops_growing_after_the_second_step(capture, monkeypatch):
     PotClipper(wdf, FS, 4.7e-9, mlp_json=js).run(data)
     assert len(sizes) == T and len(set(sizes[2:])) == 1, sizes
     assert len(by_value) <= 4
+
+
+def test_scalar_memo_survives_in_place_mutation_of_a_result():
+    """Scalar component arithmetic is memoised while a loop is being recorded (compat_tf.Tensor._scalar_memo).  A script
+    that modifies a returned value in place must not poison later, identical operations: the entry is recomputed once
+    its result's version has moved."""
+    import types
+    import torch
+    from wdf_hip import compat_tf as ctf, trace
+    rec = types.SimpleNamespace(scalar_memo={})
+    saved, trace._current = trace._current, rec
+    try:
+        r = ctf.constant(4.0)
+        a = r * 2.0
+        assert float(a) == 8.0 and (r * 2.0) is a                  # memoised: the same object comes back
+        a += 1.0                                                   # the script mutates ITS value ...
+        b = r * 2.0
+        assert float(b) == 8.0 and b is not a and float(a) == 9.0  # ... and the operation still means r * 2
+        assert (r * 2.0) is b
+    finally:
+        trace._current = saved
