@@ -543,11 +543,15 @@ __device__ __forceinline__ int tp_geom_tag(int64_t K, int J, bool skewed) { retu
 //   equal optimizer steps give 3 z1 - 3 z2 + z3.  The secant leaves the SECOND difference of the state along the path --
 //   ~1e-6 V early in training, when Adam still takes full-size steps: 32 warm-up steps to get under the tolerance -- the
 //   parabola leaves the third.  Degenerate history (a step of zero length, a wild ratio) falls back to the lower order.
-struct TpExtrap { float w1, w2, w3; };      // z = w1 z1 + w2 z2 + w3 z3   (z1 the most recent)
+//   The parabola weighs the three snapshots (3, -3, 1): it amplifies their fp32 rounding (~3e-8 each) to ~2e-7, the secant
+//   (2, -1) to ~1e-7 -- so the caller adds the parabola's CORRECTION to the secant only where it stands clear of that noise
+//   (tp_extrapolate below): sequences whose state curves along the path get it, the others keep the quieter secant, with
+//   which the late, slow phase of training runs with no warm-up at all.
+struct TpExtrap { float w1, w2, w3; float lam; bool quad; };   // z = w1 z1 + w2 z2 + w3 z3 (z1 the most recent); lam: the secant's factor
 
 __device__ __forceinline__ TpExtrap tp_extrapolation(const float* __restrict__ theta, const TpCtl* __restrict__ ctl, int valid)
 {
-    TpExtrap e{1.0f, 0.0f, 0.0f};
+    TpExtrap e{1.0f, 0.0f, 0.0f, 0.0f, false};
     if (valid < 2) return e;
     float n10 = 0.0f, n00 = 0.0f, nq0 = 0.0f;
 #pragma unroll
@@ -561,12 +565,10 @@ __device__ __forceinline__ TpExtrap tp_extrapolation(const float* __restrict__ t
     float lam = n10 / n00;                                     // s / |d0|
     lam = fminf(fmaxf(lam, -1.0f), 2.0f);
     if (!(lam == lam)) return e;
+    e.lam = lam;
     e.w1 = 1.0f + lam;                                         // secant
     e.w2 = -lam;
-    // The parabola weighs the three snapshots (3, -3, 1): it amplifies their fp32 rounding (~3e-8 each) to ~2e-7, the secant
-    // (2, -1) to ~1e-7.  Worth it while the second difference it removes is larger than that -- parameter steps above
-    // ~0.06 % (the first tens of Adam steps at the bench's rate); later the secant alone already allows NO warm-up.
-    if (valid < 3 || !(n00 > 4.0e-7f)) return e;
+    if (valid < 3) return e;
     const float mu = nq0 / n00;                                // (s2 - s3) / |d0|: the step before, in units of the last
     if (!(mu > 0.25f && mu < 4.0f)) return e;                  // (a turn, a stall or a jump in the history: stay linear)
     // positions in units of |d0|: s = lam, s1 = 0, s2 = -1, s3 = -1 - mu
@@ -574,6 +576,7 @@ __device__ __forceinline__ TpExtrap tp_extrapolation(const float* __restrict__ t
     e.w1 = (lam + 1.0f) * (lam - s3) / (1.0f * (0.0f - s3));
     e.w2 = lam * (lam - s3) / ((-1.0f) * (-1.0f - s3));
     e.w3 = lam * (lam + 1.0f) / ((s3 - 0.0f) * (s3 + 1.0f));
+    e.quad = true;
     return e;
 }
 
@@ -826,7 +829,8 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
         // units): 32 steps miss by <= 3e-7, 64 by <= 7e-8, 96 sit at the rounding floor.
         c.j_used = j;
         if (nb > 0) { j += 4; hold = 32; }
-        else if (mm * 2.0f > tol) { j += 1; hold = 32; }
+        else if (mm * 2.0f > tol) { j += 1; hold = j == 1 ? 8 : 32; }   // (from NO warm-up: an excursion of the extrapolation's
+                                                                        //  noise, over in a call or two -- try again soon)
         else if (hold > 0) --hold;
         else if (valid > 1 && mm * 64.0f < tol && (j > 2 || mm == 0.0f)) j -= 2;     // (two units: ~25x)
         else if (valid > 1 && mm * 10.0f < tol) j -= 1;         // (down to NO warm-up: the chunk then starts from the

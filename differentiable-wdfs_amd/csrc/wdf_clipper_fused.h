@@ -449,8 +449,15 @@ __device__ __forceinline__ void clipper_fused_body(
             const V z2 = load_own<V>(snap + (((int64_t)((head + kTpRing - 1) % kTpRing) * J + j) * K + (k - 1)) * B, q);
             V z3 = z2;
             if (valid > 2) z3 = load_own<V>(snap + (((int64_t)((head + kTpRing - 2) % kTpRing) * J + j) * K + (k - 1)) * B, q);
-            // (written around z1 so that weights (1, 0, 0) return the snapshot bit for bit)
-            z = vfma(vsplat<V>(e.w3), z3 - z, vfma(vsplat<V>(e.w2), z2 - z, z));
+            // (written around z1 so that an unchanged theta returns the snapshot bit for bit)
+            const V zs = vfma(vsplat<V>(e.lam), z - z2, z);                       // secant
+            if (e.quad) {
+                const V zq = vfma(vsplat<V>(e.w3), z3 - z, vfma(vsplat<V>(e.w2), z2 - z, z));
+                const V c = zq - zs;                                              // what the parabola adds: kept where it is signal
+                z = zs + vsel(vgt_c(vabs(c), 4.0e-7f), c, vsplat<V>(0.0f));
+            } else {
+                z = zs;
+            }
         }
     } else {
         tw = (t0 > W) ? t0 - W : 0;

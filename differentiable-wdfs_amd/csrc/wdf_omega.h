@@ -64,14 +64,23 @@ __device__ __forceinline__ V omega_series(V x)
     return omega_series_of_exp(vexp2(vmin_c(x, -2.0f) * kLog2e));   // clamp: never overflows
 }
 
-// Start value, branch-free: all three regional series are evaluated (their arguments clamped
-// into their own regions so nothing overflows) and selected per lane.  A wave holds 64+
+// The same series WITHOUT the clamp, for omega_start: above its region the exponential overflows to inf and the series to
+// inf / NaN -- in lanes whose value the region select then discards (a select passes nothing of the operand it does not
+// pick; there are no floating-point traps).  Two instructions per evaluation less.
+template <typename V>
+__device__ __forceinline__ V omega_series_unclamped(V x)
+{
+    return omega_series_of_exp(vexp2(x * kLog2e));
+}
+
+// Start value, branch-free: all three regional series are evaluated (outside its own region a series may
+// overflow or go NaN: the select discards it) and selected per lane.  A wave holds 64+
 // different sequences, so all regions are normally live in a wave anyway, and straight-line
 // code lets the two omega evaluations of a diode pair interleave in the VALU.
 template <typename V>
 __device__ __forceinline__ V omega_start(V x)
 {
-    V wA = omega_series(x);                                    // region 3 (x <= -2)
+    V wA = omega_series_unclamped(x);                          // region 3 (x <= -2); garbage above it, discarded below
     // region 4 (-2 < x <= 1+pi): series about x = 1                   (toms917.cpp:253-261)
     const V q = x - 1.0f;
     const V sB = vfma(q, vfma(q, vfma(q, 13.0f / 61440.0f, -1.0f / 3072.0f), -1.0f / 192.0f), 1.0f / 16.0f);
@@ -82,10 +91,10 @@ __device__ __forceinline__ V omega_start(V x)
     // within 1.1e-2 relative, and the FSC step that always follows is fourth order: what is left
     // is below 2e-8 relative, under fp32 rounding -- while the two orders cost 7 of the step's 68
     // VALU instructions.  |r| stays below kSecondIterResidual (0.044 at the boundary).
-    const V xc = vmax_c(x, kRegion4Hi);
-    const V lg = vlog2(xc);
+    // (no clamp of x into the region: log of a non-positive x is NaN / -inf, in lanes the select discards)
+    const V lg = vlog2(x);
     const V l = lg * kLn2;
-    V wC = vfma(l, vrcp(xc), vfma(lg, -kLn2, xc));
+    V wC = vfma(l, vrcp(x), vfma(lg, -kLn2, x));
     // Pin the three values as computed: without this LLVM turns the selects back into
     // exec-masked branches around the transcendentals, which serialises the two omega
     // evaluations of a step and costs more in exec-mask bookkeeping than it saves.
