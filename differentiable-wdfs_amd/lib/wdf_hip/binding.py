@@ -238,7 +238,8 @@ def _ptr(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # torch's current stream on the current device, as the raw hipStream_t (no Stream object: this runs per launch)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _f32_dev(t, name):

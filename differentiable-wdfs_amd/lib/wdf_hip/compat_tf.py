@@ -219,6 +219,64 @@ class Variable(Tensor, metaclass=_VariableMeta):
         return t
 
 
+class ParamBlock:
+    """Scalar float32 Variables of one circuit kept in ONE device-resident vector (tf_wdf.Circuit.to_device): the kernels
+    read the component values where they live, tape.gradient hands back device scalars and the optimizer updates the
+    block with one kernel launch -- a training step (lpf.py:86-99, clipper_pot.py:245-269) makes no host round trip.
+    Each adopted Variable keeps its identity, name, constraint and autograd leaf; only its storage moves: it becomes a
+    0-dim view of `block`.  `host` is a lagging pinned mirror for decisions that need numbers on the host (the
+    time-parallel plan): refreshed by an asynchronous copy every `refresh_every` peeks, never by a synchronisation."""
+
+    refresh_every = 64
+
+    def __init__(self, values, device):
+        vals = [float(v) for v in values]
+        self.block = torch.tensor(vals, dtype=torch.float32, device=device)
+        self.n = len(vals)
+        self._host_vals = list(vals)
+        self._pinned = torch.empty(self.n, dtype=torch.float32).pin_memory()
+        self._event, self._peeks = None, 0
+        self.members = {}                       # index -> adopted Variable
+
+    def adopt(self, i, v):
+        with torch.no_grad():
+            v.data = self.block[i]
+        v._wdf_block = (self, int(i))
+        self.members[int(i)] = v
+
+    def host_values(self):
+        """The block as python floats, at most a few dozen steps old; costs no synchronisation."""
+        if self._event is not None and self._event.query():
+            self._host_vals = [float(x) for x in self._pinned.tolist()]
+            self._event = None
+        self._peeks += 1
+        if self._event is None and self._peeks % self.refresh_every == 0:
+            self._pinned.copy_(self.block, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        return self._host_vals
+
+
+def clamp_bounds(constraint):
+    """(lo, hi) if `constraint` is an element-wise clamp -- what tf_wdf.py:74,104 give their Variables
+    (`lambda z: tf.clip_by_value(z, lo, hi)`) -- found by probing it; None for anything else (the optimizer then
+    applies the callable as Keras does)."""
+    if constraint is None:
+        return -float("inf"), float("inf")
+    try:
+        f = lambda p: float(convert(constraint(_wrap(torch.tensor(p, dtype=torch.float32)))))  # noqa: E731
+        lo, hi = f(-float("inf")), f(float("inf"))
+        if not lo <= hi:
+            return None
+        for p in (-1.0e30, -1.0e3, -1.0, -1.0e-3, -1.0e-9, -1.0e-20, 0.0, 1.0e-20, 1.0e-14, 1.0e-9, 1.0e-3, 1.0, 1.0e3, 1.0e30):
+            want = float(torch.clamp(torch.tensor(p, dtype=torch.float32), lo, hi))
+            if f(p) != want:
+                return None
+        return lo, hi
+    except Exception:
+        return None
+
+
 class Module:
     """tf.Module: attribute container with TF's variable traversal order."""
 
@@ -505,8 +563,21 @@ class GradientTape:
     def gradient(self, target, sources):
         single = isinstance(sources, torch.Tensor)
         srcs = [sources] if single else list(sources)
-        grads = torch.autograd.grad(target, srcs, allow_unused=True, retain_graph=self._persistent)
-        grads = [None if g is None else _wrap(g) for g in grads]
+        fused = getattr(target, "_wdf_fused", None)
+        with torch._C.DisableTorchFunctionSubclass():           # plain dispatch: no per-call subclass protocol
+            where = None if fused is None else [fused[1].get(id(v)) for v in srcs]
+            if where is not None and all(i is not None for i in where):
+                # the loss of a resident circuit's one-pass step (lowering.Circuit._mse_resident) carries its own gradient:
+                # the pass that produced the loss produced d loss / d Variable with it -- nothing to back-propagate
+                vec = fused[0]
+                grads = []
+                for i in where:
+                    g = vec[1 + i].as_subclass(Tensor)
+                    g._wdf_gvec = (vec, i)                      # _Adam._apply_resident: the update reads the vector itself
+                    grads.append(g)
+            else:
+                grads = torch.autograd.grad(target, srcs, allow_unused=True, retain_graph=self._persistent)
+                grads = [None if g is None else _wrap(g) for g in grads]
         return grads[0] if single else grads
 
 
@@ -526,8 +597,56 @@ class _Adam:
         self.lr, self.b1, self.b2, self.eps = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
         self.iterations = 0
         self._slots = {}
+        self._resident = {}     # ids of a group of block-resident Variables -> (binding.Adam, block, index or slice)
+
+    def _apply_resident(self, gv):
+        """Variables living in a ParamBlock, gradients on the same device: the whole update -- moments, bias correction,
+        step, clip constraints -- is ONE launch of wdf_adam_step on the block (csrc/wdf_optim.h, this class's rule).
+        False when the group does not qualify; the caller then takes the per-Variable path."""
+        if not gv or any(g is None or not g.is_cuda or getattr(v, "_wdf_block", None) is None or id(v) in self._slots
+                         for g, v in gv):
+            return False
+        key = tuple(id(v) for _, v in gv)
+        st = self._resident.get(key)
+        if st is None:
+            if any(id(v) in k for k in self._resident for _, v in gv):
+                return False                                 # the same Variable in another grouping: keep one set of moments
+            pb = gv[0][1]._wdf_block[0]
+            if any(v._wdf_block[0] is not pb for _, v in gv):
+                return False
+            bounds = [clamp_bounds(getattr(v, "constraint", None)) for _, v in gv]
+            if any(b is None for b in bounds):
+                return False
+            from . import binding
+            idx = [v._wdf_block[1] for _, v in gv]
+            opt = binding.Adam(len(idx), self.lr, self.b1, self.b2, self.eps, lo=[b[0] for b in bounds],
+                               hi=[b[1] for b in bounds], device=pb.block.device)
+            if self.iterations:
+                opt.step.fill_(self.iterations)
+            sel = slice(idx[0], idx[0] + len(idx)) if idx == list(range(idx[0], idx[0] + len(idx))) else \
+                torch.tensor(idx, dtype=torch.int64, device=pb.block.device)
+            st = self._resident[key] = (opt, pb, sel, [v for _, v in gv])        # (keeps the Variables' ids their own)
+        opt, pb, sel, _ = st
+        with torch.no_grad(), torch._C.DisableTorchFunctionSubclass():
+            tags = [getattr(g, "_wdf_gvec", None) for g, _ in gv]
+            if isinstance(sel, slice) and all(t is not None and t[0] is tags[0][0] for t in tags) and \
+                    [t[1] for t in tags] == list(range(sel.start, sel.stop)):
+                g = tags[0][0][1 + sel.start:1 + sel.stop]       # the gradients ARE a slice of the one-pass step's output
+            else:
+                g = torch.stack([g.reshape(()) for g, _ in gv]).to(torch.float32)
+            if isinstance(sel, slice):
+                opt.apply(pb.block[sel], g)
+            else:
+                th = pb.block[sel]
+                opt.apply(th, g)
+                pb.block[sel] = th
+        return True
 
     def apply_gradients(self, grads_and_vars):
+        grads_and_vars = list(grads_and_vars)
+        if self._apply_resident(grads_and_vars):
+            self.iterations += 1
+            return
         self.iterations += 1
         t = self.iterations
         lr_t = self.lr * np.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)

@@ -462,6 +462,28 @@ class _ClipperMseFn(torch.autograd.Function):
         return gl * g, None, None, None, None, None, None, None, None     # (never reached when theta needs no grad)
 
 
+class _ResidentMseFn(torch.autograd.Function):
+    """_ClipperMseFn for component values resident in a parameter block (lowering.Circuit.to_device): the one-pass step
+    reads theta straight from the block; the Variables that own its entries are the differentiable inputs, each handed
+    its entry of the gradient as a device scalar.  One stepper per (x, target) pair, with the warm-start state the
+    repeated visits of a training set allow."""
+
+    @staticmethod
+    def forward(ctx, st, block, x, r, target, inv_n, idx, *live):
+        st.step_fused(block, x, target, r)
+        out = st.out.clone()                  # {sse, gtheta[4]} of THIS call (a validation pass may run before backward)
+        ctx.save_for_backward(out)
+        ctx.idx = idx
+        ctx.mark_non_differentiable(out)
+        return out[0] * inv_n, out            # (out: what GradientTape.gradient hands out directly, compat_tf)
+
+    @staticmethod
+    def backward(ctx, gl, _):
+        (out,) = ctx.saved_tensors
+        g = gl * out
+        return (None,) * 7 + tuple(g[1 + i] for i in ctx.idx)
+
+
 def clipper_mse(theta, x, target, fs, r=None, n_up=1, n_down=1, tp=None, time_major=False):
     """Scalar mean-squared error of the clipper output against target [T,B], differentiable w.r.t.
     theta = {Is, nVt, R, C} (float32[4] on the device); the fused path of lpf.py:87-90-style loops.

@@ -181,6 +181,82 @@ class Circuit:
         if self.ni < 1:
             raise ValueError("the circuit has no voltage source")
 
+    # -- device-resident component values
+    def to_device(self, device="cuda"):
+        """Move the circuit's component Variables {Is, nVt, R, C} into one device-resident parameter block
+        (compat_tf.ParamBlock): from here on mse() reads the values where they live, tape.gradient returns device
+        scalars and tf.keras.optimizers.Adam.apply_gradients is one kernel launch -- the training loops of
+        lpf.py:86-99 / clipper_pot.py:245-269 run without a host round trip per step (print / .numpy() / float() on a
+        Variable still work: they copy back on demand).  Diode-clipper topology only: the generic lowering differentiates
+        its float64 probe on the host and needs the Variables there.  Returns self."""
+        binding.require_gpu()
+        if not (self._is_clipper() and self.root_kind == "DiodePair"):
+            raise binding.WdfHipError("Circuit.to_device: only the diode-pair clipper keeps its component values on the device")
+        if getattr(self, "_pblock", None) is not None:
+            return self
+        dp, vs, cap = self.root, self.top.P1, self.top.P2
+        Rv = 1.0 if self.per_sample_R is not None else vs.R
+        parts = [dp.Is, dp.nVt, Rv, cap.C]
+        pb = tf.ParamBlock([float(p) for p in parts], torch.device(device))
+        for i, p in enumerate(parts):
+            if isinstance(p, torch.Tensor) and getattr(p, "_is_tf_variable", False) and p.numel() == 1:
+                pb.adopt(i, p)
+        self._pblock, self._res_cache = pb, {}
+        return self
+
+    def _theta(self, parts, dev):
+        """{Is, nVt, R, C} as one float32[4] on the device, differentiable w.r.t. the Variables among them."""
+        pb = getattr(self, "_pblock", None)
+        if pb is not None:      # resident: the adopted Variables already live on the device, the rest are the block's constants
+            return torch.stack([(pb.members[i] if i in pb.members else pb.block[i]).as_subclass(torch.Tensor).reshape(())
+                                for i in range(4)]).to(dev)
+        return torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(dev)
+
+    def _host_RC(self, parts):
+        """R and C as host numbers for the planner: the Variables themselves when they live on the host, the block's
+        lagging mirror when resident (no synchronisation either way)."""
+        pb = getattr(self, "_pblock", None)
+        if pb is not None:
+            h = pb.host_values()
+            return h[2], h[3]
+        return float(parts[2]), float(parts[3])
+
+    def _mse_resident(self, x, target):
+        """mse() on a resident circuit: inputs prepared once per (x, target) pair -- a training set and a validation set
+        alternate in clipper_pot.py:245-262, each keeps its own stepper and warm-start state -- then one pass of the
+        one-pass training step per call."""
+        from . import engine
+        pb = self._pblock
+        key = (id(x), x._version, tuple(x.shape), id(target), target._version)
+        ent = self._res_cache.get(key)
+        if ent is None:
+            if len(self._res_cache) >= 4:
+                self._res_cache.clear()
+            dp, cap = self.root, self.top.P2
+            xd = x.as_subclass(torch.Tensor).to(pb.block.device).float()
+            xv, r = engine.split_channels(xd, self.per_sample_R is not None, time_major=True, anchor=x)
+            tgt = target.as_subclass(torch.Tensor).to(pb.block.device).float().reshape(xv.shape).contiguous()
+            host = pb.host_values()
+            R_plan = host[2] if r is None else engine.resistance_max(r)
+            tp = self.time_parallel
+            if tp == "auto":
+                tp = engine.tuned_plan(pb.block, xv, r, float(cap.FS), R_plan, host[3], n_up=dp.N_up, n_down=dp.N_down,
+                                       time_major=True, R_min=None if r is None else engine.resistance_min(r), fused=True)
+            T, B = xv.shape
+            st = engine.MseStep(B, T, float(cap.FS), tp, pb.block.device, n_up=dp.N_up, n_down=dp.N_down, time_major=True,
+                                warm=True)
+            live = [(i, v) for i, v in sorted(pb.members.items()) if v.requires_grad]
+            ent = self._res_cache[key] = (st, xv, r, tgt, 1.0 / float(B * T), [i for i, _ in live], [v for _, v in live],
+                                          x, target,                      # (x, target held: their ids stay their own)
+                                          {id(v): i for i, v in live})
+        st, xv, r, tgt, inv_n, idx, live = ent[:7]
+        engine.LAST_TP_STATUS["status"] = st.status
+        loss, out = engine._ResidentMseFn.apply(st, pb.block, xv, r, tgt, inv_n, idx, *live)
+        loss = loss.as_subclass(tf.Tensor)
+        # d loss / d Variable is already known: tape.gradient(loss, ...) on THIS tensor reads it (compat_tf.GradientTape)
+        loss._wdf_fused = (out, ent[9])
+        return loss
+
     # -- topology tests
     def mse(self, x, target):
         """tf.reduce_mean(tf.square(self(x) - target)) as ONE fused evaluation where the kernels allow
@@ -192,6 +268,8 @@ class Circuit:
             y = self(x)
             return tf.reduce_mean(tf.square(y - target))
         from . import engine
+        if getattr(self, "_pblock", None) is not None and isinstance(x, torch.Tensor) and isinstance(target, torch.Tensor):
+            return self._mse_resident(x, target)
         anchor = x if isinstance(x, torch.Tensor) else None
         x = torch.as_tensor(x).as_subclass(torch.Tensor)
         x = (x if x.is_cuda else x.cuda()).float()
@@ -199,14 +277,15 @@ class Circuit:
         # a streamed pot resistance overrides the source's own R (which a recorded loop may have left symbolic)
         Rv = torch.tensor(1.0) if self.per_sample_R is not None else (vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)))
         parts = [dp.Is, dp.nVt, Rv, cap.C]
-        theta = torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(x.device)
+        theta = self._theta(parts, x.device)
         # the sweep reads its inputs time-major: the transposed copy is made once per input tensor
         xv, r = engine.split_channels(x, self.per_sample_R is not None, time_major=True, anchor=anchor)
         tgt = torch.as_tensor(target).as_subclass(torch.Tensor).to(x.device).float().reshape(xv.shape).contiguous()
-        R_plan = float(parts[2]) if r is None else engine.resistance_max(r)
+        R_host, C_host = self._host_RC(parts)
+        R_plan = R_host if r is None else engine.resistance_max(r)
         tp = self.time_parallel
         if tp == "auto":
-            tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, float(cap.C), n_up=dp.N_up, n_down=dp.N_down,
+            tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, C_host, n_up=dp.N_up, n_down=dp.N_down,
                                    time_major=True, R_min=None if r is None else engine.resistance_min(r), fused=True)
         loss = engine.clipper_mse(theta, xv, tgt, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp,
                                   time_major=True)
@@ -309,7 +388,7 @@ class Circuit:
         # a streamed pot resistance overrides the source's own R (which a recorded loop may have left symbolic)
         Rv = torch.tensor(1.0) if self.per_sample_R is not None else (vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R)))
         parts = [dp.Is, dp.nVt, Rv, cap.C]
-        theta = torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(dev)
+        theta = self._theta(parts, dev)
         xv, r = engine.split_channels(x, self.per_sample_R is not None, anchor=getattr(self, "_anchor", None))
         if z0 is not None or return_state:
             z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(-1).contiguous()
@@ -320,8 +399,9 @@ class Circuit:
         if tp == "auto":
             # component values live on the host (tiny CPU variables): planning costs no sync
             # per-sample R: the warm-up must outlast the slowest (largest-R) sequence in the batch
-            R_plan = float(parts[2]) if r is None else engine.resistance_max(r)
-            tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, float(cap.C), n_up=dp.N_up, n_down=dp.N_down,
+            R_host, C_host = self._host_RC(parts)
+            R_plan = R_host if r is None else engine.resistance_max(r)
+            tp = engine.tuned_plan(theta, xv, r, float(cap.FS), R_plan, C_host, n_up=dp.N_up, n_down=dp.N_down,
                                    R_min=None if r is None else engine.resistance_min(r))
         y = engine.clipper(theta, xv, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp)
         return y.as_subclass(tf.Tensor)

@@ -479,3 +479,94 @@ def test_linear_tree_exact_chunked_reverse_sweep(wdf, B, T, K):
     g_tp, _, gz_tp = wb.ss_bwd_tp(x, coef, 1, 1, zs, gy, K, want_gz0=True)
     assert float((g_tp - g_seq).abs().max()) <= 2e-5 * float(g_seq.abs().max())
     assert float((gz_tp - gz_seq).abs().max()) <= 2e-5 * float(gz_seq.abs().max()) + 1e-12
+
+
+def _clipper_circuit(wdf, theta):
+    Vs = wdf.ResistiveVoltageSource(float(theta[2]), trainable=True)
+    Cap = wdf.Capacitor(float(theta[3]), FS, trainable=True)
+    P1 = wdf.Parallel(Vs, Cap)
+    dp = wdf.DiodePair(P1, float(theta[0]), Vt=float(theta[1]), trainable=True)
+    return wdf.Circuit(P1, dp, Cap), [dp.Is, dp.nVt, Vs.R, Cap.C]
+
+
+@pytest.mark.parametrize("optimizers", ["one_per_variable", "one_for_all"])
+def test_resident_circuit_trains_like_host_variables(wdf, optimizers):
+    """Circuit.to_device(): the component Variables become views of one device block; the training loop of
+    lpf.py:86-99 (tape.gradient + one Adam per variable) / clipper_pot.py:245-269 (one Adam for all) then runs on the
+    device -- same losses, gradients and parameter trajectory as the same loop on host Variables (whose update is the
+    per-Variable torch path), clip constraints included; print-style access (float(), .numpy()) still works."""
+    from wdf_hip import workload
+    tf = wdf.tf
+    theta = workload.clipper_theta()
+    B, T = 256, 2048
+    x = cuda(workload.sweep_batch(B, T, seed=9))
+    ref, _ = _clipper_circuit(wdf, workload.target_theta())
+    tgt = ref(x).as_subclass(torch.Tensor).detach()
+
+    def train(resident, steps=12):
+        circ, vs = _clipper_circuit(wdf, theta)
+        if resident:
+            assert circ.to_device() is circ
+            assert all(v.is_cuda and v.requires_grad and v.is_leaf for v in vs)
+        if optimizers == "one_per_variable":
+            opts = [tf.keras.optimizers.Adam(learning_rate=1.0e-3 * float(t)) for t in theta]
+        else:
+            opts = [tf.keras.optimizers.Adam(learning_rate=1.0e-12)]
+        hist = []
+        for _ in range(steps):
+            with tf.GradientTape() as tape:
+                loss = circ.mse(x, tgt)
+            grads = tape.gradient(loss, vs)
+            if resident:
+                assert all(g.is_cuda for g in grads)
+            if len(opts) == 1:
+                opts[0].apply_gradients(zip(grads, vs))
+            else:
+                for o, g, v in zip(opts, grads, vs):
+                    o.apply_gradients([(g, v)])
+            hist.append((float(loss), [float(g) for g in grads], [float(v) for v in vs]))
+        if resident:
+            assert all(o._resident and not o._slots for o in opts)          # every update was the one-launch kind
+        return circ, vs, opts, hist
+
+    _, _, _, host = train(False)
+    circ, vs, opts, dev = train(True)
+    for (lh, gh, vh), (ld, gd, vd) in zip(host, dev):
+        assert abs(lh - ld) <= 2e-5 * abs(lh)
+        assert np.allclose(gd, gh, rtol=3e-4, atol=0), (gd, gh)
+        assert np.allclose(vd, vh, rtol=2e-6, atol=0), (vd, vh)
+    assert host[-1][2] != host[0][2]
+    # the plain forward still works on the resident circuit and agrees with the fused loss
+    with tf.GradientTape() as tape:
+        l_plain = tf.reduce_mean(tf.square(circ(x) - tgt))
+        l_fused = circ.mse(x, tgt)
+    assert abs(float(l_plain) - float(l_fused)) <= 2e-6 * float(l_plain)
+    g_plain = [float(g) for g in tape.gradient(l_plain, vs)]
+    assert np.allclose(g_plain, [float(g) for g in tf.GradientTape().gradient(l_fused, vs)], rtol=3e-4, atol=0)
+    assert isinstance(vs[3].numpy(), np.ndarray)
+    # tape.gradient on the loss tensor itself reads the gradient the pass produced; through any further arithmetic it is
+    # ordinary back-propagation -- the same numbers either way
+    l_a = circ.mse(x, tgt)
+    l_b = circ.mse(x, tgt) * 1.0
+    assert hasattr(l_a, "_wdf_fused") and not hasattr(l_b, "_wdf_fused")
+    g_a, g_b = tf.GradientTape().gradient(l_a, vs), tf.GradientTape().gradient(l_b, vs)
+    assert all(torch.equal(a.as_subclass(torch.Tensor), b.as_subclass(torch.Tensor)) for a, b in zip(g_a, g_b))
+    other = tf.Variable(1.0)
+    g_c = tf.GradientTape().gradient(l_a, [vs[2], other])                                # a source outside the circuit: autograd answers
+    assert g_c[1] is None and torch.equal(g_c[0].as_subclass(torch.Tensor), g_a[2].as_subclass(torch.Tensor))
+    # constraints ride in the fused update: a huge step lands on the clip bound (C in [1e-13, 1], tf_wdf.py:104)
+    big = tf.keras.optimizers.Adam(learning_rate=10.0)
+    with tf.GradientTape() as tape:
+        loss = circ.mse(x, tgt)
+    g = tape.gradient(loss, [vs[3]])
+    big.apply_gradients(zip(g, [vs[3]]))
+    assert big._resident and float(vs[3]) in (1.0, float(np.float32(0.1e-12)))
+
+
+def test_resident_circuit_rejects_other_topologies(wdf):
+    from wdf_hip import binding as wb
+    R1 = wdf.Resistor(1000.0, True)
+    C1 = wdf.Capacitor(1.0e-6, FS, True)
+    lp = wdf.Circuit(wdf.Inverter(wdf.Series(R1, C1)), wdf.IdealVoltageSource(), C1)
+    with pytest.raises(wb.WdfHipError):
+        lp.to_device()

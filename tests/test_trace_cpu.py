@@ -201,3 +201,32 @@ def test_scalar_memo_survives_in_place_mutation_of_a_result():
         assert (r * 2.0) is b
     finally:
         trace._current = saved
+
+
+def test_clamp_bounds_recognises_the_elements_constraints():
+    """compat_tf.clamp_bounds: the constraints tf_wdf gives its Variables (tf_wdf.py:74,104) are clamps the resident
+    optimizer can fold into its kernel; anything else is left to the per-Variable path."""
+    import tf_wdf
+    from wdf_hip import compat_tf as tf
+    res = tf_wdf.Resistor(1000.0, trainable=True)
+    cap = tf_wdf.Capacitor(1.0e-8, FS, trainable=True)
+    assert tf.clamp_bounds(res.R.constraint) == (180.0, 1.0e6)
+    assert tf.clamp_bounds(tf_wdf.ResistiveVoltageSource(1000.0, trainable=True).R.constraint) == (-float("inf"), float("inf"))
+    lo, hi = tf.clamp_bounds(cap.C.constraint)
+    assert lo == float(np.float32(0.1e-12)) and hi == 1.0
+    assert tf.clamp_bounds(None) == (-float("inf"), float("inf"))
+    assert tf.clamp_bounds(lambda z: z * 2.0) is None
+    assert tf.clamp_bounds(lambda z: tf.abs(z)) is None
+    assert tf.clamp_bounds(lambda z: tf.clip_by_value(z, 0.0, float("inf"))) == (0.0, float("inf"))
+
+
+def test_adam_without_resident_variables_takes_the_per_variable_path():
+    """Host Variables never reach the fused update (no GPU here): the optimizer's rule is the Keras one."""
+    from wdf_hip import compat_tf as tf
+    v = tf.Variable(1.0, constraint=lambda z: tf.clip_by_value(z, 0.0, 0.9995))
+    opt = tf.keras.optimizers.Adam(learning_rate=1.0e-3)
+    opt.apply_gradients([(tf.constant(2.0), v)])
+    assert opt.iterations == 1 and not opt._resident
+    assert abs(float(v) - 0.999) < 1e-6          # first Adam step moves by lr whatever the gradient's size
+    opt.apply_gradients([(tf.constant(-2.0), v)])
+    assert float(v) <= 0.9995
