@@ -45,8 +45,9 @@ def flat_weights(dense):
 MlpTpPlan = namedtuple("MlpTpPlan", ["k_fwd", "warmup", "warmup_per_wave", "tol", "k_bwd"])
 LAST_TP_STATUS = {"status": None}
 WARM_START = os.environ.get("WDF_MLP_WARM_START", "1") != "0"        # 0: every call warms its chunks up from z = 0
-SECANT_WARM_START = os.environ.get("WDF_MLP_WARM_SECANT", "1") != "0"
+_WARM_UNIT, _WARM_FLOOR = 16, 32      # warm-started chunks: the controller's step and the least warm-up it will try
 _TRACE_WARMUP = [] if os.environ.get("WDF_MLP_TRACE_WARMUP") else None    # (probing) per call: (warm-up steps, warm-started?)
+_TRACE_VERDICTS = []   # (probing, with _TRACE_WARMUP) per verdict read back: (warm-up, n_bad, max miss, gated waves, sequential waves)
 _WARM_START = {}       # (x address, shape, chunks, planned warm-up, r address) -> controller + the previous call's states
 KAPPA_FROM_FORWARD = os.environ.get("WDF_MLP_KAPPA_FROM_FORWARD", "1") != "0"   # 0: the reverse sweep recomputes kappa
 _WARMUP_ADAPT = {}     # (x shape, forward chunks, planned warm-up) -> {"warmup": steps in use, "calls": n}
@@ -84,35 +85,50 @@ class _ClipperMlpFn(torch.autograd.Function):
                         del _WARM_START[k]                       # entries whose batch has been freed
                     if len(_WARM_START) >= 8:
                         _WARM_START.clear()
-                    warm = _WARM_START[wkey] = {"warmup": 0, "calls": 0, "rows": None, "prev": None, "idx": None,
+                    warm = _WARM_START[wkey] = {"warmup": 0, "calls": 0, "rows": None, "idx": None,
                                                 "xref": weakref.ref(x), "rref": None if r is None else weakref.ref(r)}
             hot = warm is not None and warm["rows"] is not None
+            if warm is not None:
+                warm["calls"] += 1
             if hot and warm.get("pending") is not None and warm["pending"][1].query():
-                # the verdict of an earlier warm call, copied to pinned memory behind its forward: no wait here
-                buf, _ = warm["pending"]
+                # the verdict of an earlier warm call, copied to pinned memory behind its forward: no wait here (the
+                # host runs a dozen calls ahead of the device in a training loop, so verdicts are counted in CALLS)
+                buf, _, issued, w_then = warm["pending"]
                 warm["pending"] = None
-                w_new = warm["warmup"]
-                if int(buf[2]) > 0:                              # gated waves: a chunk arrived too far off
-                    w_new = min(-(-int(1.25 * warm["warmup"]) // 16) * 16, ad["warmup"])
-                    warm["clean"] = 0
+                if _TRACE_WARMUP is not None:
+                    _TRACE_VERDICTS.append((w_then, int(buf[0]), float(buf[1:2].view(torch.float32)[0]), int(buf[2]), int(buf[3])))
+                gated_total = int(buf[4])                        # ... over every call up to that one, not only the sampled ones
+                # (a wave or two now and then is the fp32 floor of this path crossing the tolerance -- plan_mlp_time_parallel's
+                #  note -- which no warm-up cures; a short warm-up sends dozens of waves back at once)
+                missed = gated_total - warm.get("gated_seen", 0) >= 8
+                warm["gated_seen"] = gated_total
+                if missed:                                       # gated waves: a chunk arrived too far off
+                    # (a miss costs one chunk-local repair, ~0.1 ms; the warm-up that failed is remembered for 256 calls)
+                    if w_then >= warm.get("bad", 0):
+                        warm["bad"], warm["bad_at"] = w_then, issued
+                    if w_then >= warm["warmup"]:
+                        warm["want"] = min(w_then + 2 * _WARM_UNIT, ad["warmup"])
+                        warm["since"] = warm["calls"]
                 else:
-                    # 64 clean verdicts in a row: try 16 steps less (a miss costs one chunk-local repair, ~0.2 ms, and
-                    # brings a quarter back) -- a transient early in training must not pin the warm-up for good
-                    warm["clean"] = warm.get("clean", 0) + 1
-                    if warm["clean"] >= 64 and warm["warmup"] > warm["floor"]:
-                        w_new, warm["clean"] = warm["warmup"] - 16, 0
-                if w_new != warm["warmup"]:
-                    # the chunks start elsewhere: the rows kept belong to the old starts, so THIS call runs from z = 0 with
-                    # the cold warm-up (correct, one slower call) and leaves the rows for the new starts behind it
-                    warm["warmup"] = w_new
-                    starts = binding.mlp_tp_starts(int(x.shape[1]), tp.k_fwd, w_new)
-                    warm["idx"] = torch.tensor(starts, dtype=torch.int64, device=x.device)
-                    warm["rows"], warm["prev"] = None, None
-                    hot = False
+                    # clean for 32 calls at this warm-up (the training loops' weights swing with periods of ~16 calls,
+                    # tools/mlp_start_probe.py): try 16 steps less, but not what failed within the last 256 calls
+                    if warm["calls"] - warm.get("bad_at", -10**9) > 256:
+                        warm["bad"] = 0
+                    lower = warm["warmup"] - _WARM_UNIT
+                    if w_then == warm["warmup"] and issued - warm.get("since", 0) >= 32 and lower >= _WARM_FLOOR \
+                            and lower > warm.get("bad", 0):
+                        warm["want"], warm["since"] = lower, warm["calls"]
             zinit = None
             if hot:
-                # secant in call count: 2 rows - prev (one launch)
-                zinit = warm["rows"] if warm["prev"] is None else torch.lerp(warm["prev"], warm["rows"], 2.0)
+                # the previous call's verified states at this call's chunk starts (the weights moved by one optimizer step).
+                # Order 0 on purpose: with Adam(1e-4, beta_1 0.5) on these weights the trajectory jumps by 1e-2 per call and
+                # the jumps change sign irregularly -- secant, parabola and fitted AR(1) predictors all do worse
+                # (tools/mlp_start_probe.py, profiles/r03_mlp_start_probe.txt); the warm-up's contraction closes the gap.
+                want = warm.get("want", warm["warmup"])
+                if want != warm["warmup"] and want in warm["rows"]:
+                    warm["warmup"] = want
+                zinit = warm["rows"].get(warm["warmup"])
+                hot = zinit is not None
             w_used = warm["warmup"] if hot else ad["warmup"]
             out = binding.clipper_mlp_fwd_tp(x, th, wd, hidden, n_tanh, fs, tp.k_fwd, w_used, r=r,
                                              warmup_per_wave=tp.warmup_per_wave, tol=tp.tol,
@@ -125,13 +141,17 @@ class _ClipperMlpFn(torch.autograd.Function):
             if _TRACE_WARMUP is not None:
                 _TRACE_WARMUP.append((w_used, hot))
             if hot:
+                if warm.get("gated") is None:
+                    warm["gated"] = torch.zeros((1,), dtype=torch.int32, device=x.device)
+                warm["gated"].add_(st[2:3])                      # waves repaired so far, summed on the device
                 if warm.get("pending") is None:                  # (one verdict in flight at a time)
                     if warm.get("pin") is None:
-                        warm["pin"] = torch.empty((4,), dtype=torch.int32, pin_memory=True)
-                    warm["pin"].copy_(st, non_blocking=True)
+                        warm["pin"] = torch.empty((5,), dtype=torch.int32, pin_memory=True)
+                    warm["pin"][:4].copy_(st, non_blocking=True)
+                    warm["pin"][4:].copy_(warm["gated"], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record()
-                    warm["pending"] = (warm["pin"], ev)
+                    warm["pending"] = (warm["pin"], ev, warm["calls"], w_used)
             else:
                 ad["calls"] += 1
                 if tp.warmup_per_wave is None and (ad["calls"] <= 4 or ad["calls"] % 16 == 0):
@@ -139,16 +159,22 @@ class _ClipperMlpFn(torch.autograd.Function):
                         ad["warmup"] = min(-(-int(1.5 * ad["warmup"]) // 16) * 16, int(x.shape[1]))
             if warm is not None:
                 if warm["warmup"] == 0:
-                    warm["warmup"] = warm["floor"] = max(64, -(-(ad["warmup"] // 4) // 16) * 16)
+                    warm["warmup"] = max(_WARM_FLOOR, min(-(-(ad["warmup"] // 3) // _WARM_UNIT) * _WARM_UNIT, ad["warmup"]))
                     if os.environ.get("WDF_MLP_WARM_W"):         # (probing: start the controller elsewhere)
-                        warm["warmup"] = warm["floor"] = int(os.environ["WDF_MLP_WARM_W"])
-                fresh = warm["idx"] is None
-                if fresh:
-                    starts = binding.mlp_tp_starts(int(x.shape[1]), tp.k_fwd, warm["warmup"])
-                    warm["idx"] = torch.tensor(starts, dtype=torch.int64, device=x.device)
-                rows = zs.index_select(0, warm["idx"])           # the verified trajectory at the next call's chunk starts
-                warm["prev"] = None if (fresh or not SECANT_WARM_START or warm["rows"] is None) else warm["rows"]
-                warm["rows"] = rows                              # ([chunks, B] floats: the stash itself is not kept alive)
+                        warm["warmup"] = int(os.environ["WDF_MLP_WARM_W"])
+                # the states the NEXT call may start from: this call's verified trajectory at the chunk starts of the
+                # warm-up in use, one unit less and two more (what the controller can ask for) -- one gather, [3][chunks, B]
+                # floats; the stash itself is not kept alive
+                cands = [w_ for w_ in (warm.get("want", warm["warmup"]), warm["warmup"] - _WARM_UNIT, warm["warmup"], warm["warmup"] + 2 * _WARM_UNIT)
+                         if _WARM_FLOOR <= w_ <= ad["warmup"]]
+                cands = list(dict.fromkeys(cands))
+                ck = tuple(cands)
+                if warm.get("idx_key") != ck:
+                    starts = [binding.mlp_tp_starts(int(x.shape[1]), tp.k_fwd, w_) for w_ in cands]
+                    warm["idx"] = torch.tensor([t for s_ in starts for t in s_], dtype=torch.int64, device=x.device)
+                    warm["idx_key"] = ck
+                rows = zs.index_select(0, warm["idx"]).view(len(cands), -1, zs.shape[1])
+                warm["rows"] = {w_: rows[i] for i, w_ in enumerate(cands)}
         else:
             y, zs, zT = binding.clipper_mlp_fwd(x, th, wd, hidden, n_tanh, fs, r=r, want_stash=need or want_stash,
                                                 z0=z0, want_zT=want_zT)
