@@ -154,9 +154,20 @@ size_t wdf_ss_fwd_tp_ws_bytes(int ns, int64_t B, int n_chunks)
     return (size_t)2 * (size_t)n_chunks * (size_t)ns * (size_t)B * sizeof(float) + (size_t)((B + 63) / 64) * sizeof(unsigned);
 }
 
+int wdf_ss_tp_starts(int64_t T, int n_chunks, int warmup, int64_t* starts)
+{
+    if (T <= 0 || n_chunks < 1 || warmup < 0 || !starts) return fail(WDF_EINVAL, "T > 0, n_chunks >= 1, warmup >= 0, starts != NULL");
+    int64_t L; int K;
+    ss_tp_geom(T, n_chunks, L, K);
+    if (K != n_chunks) return fail(WDF_EINVAL, "n_chunks = %d does not tile T = %lld in 8-step units: use wdf_ss_tp_chunks (%d)", n_chunks, (long long)T, K);
+    const int64_t W = ((int64_t)warmup + 7) / 8 * 8;
+    for (int k = 0; k < K; ++k) starts[k] = (k * L > W) ? k * L - W : 0;
+    return WDF_OK;
+}
+
 int wdf_ss_fwd_tp(const float* x, const float* coef, const float* rootp, int ns, int ni, int n_up, int n_down, float* y,
-                  float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws,
-                  void* status, void* stream)
+                  float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup, float tol,
+                  const float* zinit, void* ws, void* status, void* stream)
 {
     int rc = ss_check(x, coef, rootp, ns, ni, wdf::kRootDiode, n_up, n_down, B, T, 0);
     if (rc) return rc;
@@ -179,13 +190,13 @@ int wdf_ss_fwd_tp(const float* x, const float* coef, const float* rootp, int ns,
         {                                                                                                                    \
             EventBracket bracket(s);                                                                                         \
             if (sym && v4) hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, true, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y, \
-                                              zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W);             \
+                                              zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W, zinit);             \
             else if (sym) hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, true, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y, \
-                                             zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W);              \
+                                             zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W, zinit);              \
             else if (v4) hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, false, true>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y,  \
-                                            zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W);               \
+                                            zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W, zinit);               \
             else hipLaunchKernelGGL((wdf::ss_fwd_tp_kernel<NS_, NI_, false, false>), grid, dim3(64), 0, s, x, coef, rootp, n_up, n_down, y,        \
-                                    zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W);                       \
+                                    zstash, z0, zT, zwarm, zend, (wdf::SsTpStatus*)status, B, T, L, W, zinit);                       \
         }                                                                                                                    \
         if (K > 1) {                                                                                                         \
             hipLaunchKernelGGL(wdf::ss_tp_verify_kernel, dim3(grid.x), dim3(64), 0, s, (const float*)zwarm, (const float*)zend, ns, B,  \

@@ -488,8 +488,11 @@ __global__ __launch_bounds__(64) void ss_fwd_tp_kernel(const float* __restrict__
                                                        float* __restrict__ y, float* __restrict__ zstash,
                                                        const float* __restrict__ z0, float* __restrict__ zT,
                                                        float* __restrict__ zwarm, float* __restrict__ zend,
-                                                       SsTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W)
+                                                       SsTpStatus* __restrict__ status, int64_t B, int64_t T, int64_t L, int64_t W,
+                                                       const float* __restrict__ zinit)
 {
+    // zinit [K][NS][B] (or null: z = 0): the states chunk k > 0 starts its warm-up from -- an earlier call's states at the
+    // same samples when the caller re-visits the batch with slightly different coefficients (the verification decides).
     static_assert(NS >= 1, "a tree without states has nothing to speculate about");
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = SsTpStatus{0, 0.0f, 0, 0};   // (the verify kernel adds)
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(64) void ss_fwd_tp_kernel(const float* __restrict__
     dp.load(rootp, n_up, n_down);
     float z[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) z[s] = (tw == 0 && z0) ? z0[s * B + b] : 0.0f;
+    for (int s = 0; s < NS; ++s) z[s] = tw == 0 ? (z0 ? z0[s * B + b] : 0.0f) : (zinit ? zinit[(k * NS + s) * B + b] : 0.0f);
     // the lane streams its own row of x in 8-step blocks (16-byte loads), one block ahead; tw, t0 and L are multiples of 8
     const float* __restrict__ xp = x + b * T * NI;
     const int64_t tfull = t1 - (t1 - tw) % kBlkSS;

@@ -178,7 +178,10 @@ def lib():
         L.wdf_ss_fwd_tp_ws_bytes.restype = C.c_size_t
         L.wdf_ss_fwd_tp_ws_bytes.argtypes = [ci, i64, ci]
         L.wdf_ss_fwd_tp.restype = ci
-        L.wdf_ss_fwd_tp.argtypes = [fp, fp, fp, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, vp]
+        L.wdf_ss_fwd_tp.argtypes = [fp, fp, fp, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, fp, vp, vp, vp]
+        if hasattr(L, "wdf_ss_tp_starts"):
+            L.wdf_ss_tp_starts.restype = ci
+            L.wdf_ss_tp_starts.argtypes = [i64, ci, ci, C.POINTER(C.c_int64)]
         L.wdf_ss_bwd_tp_ws_bytes.restype = C.c_size_t
         L.wdf_ss_bwd_tp_ws_bytes.argtypes = [ci, ci, i64, ci]
         L.wdf_ss_bwd_tp.restype = ci
@@ -222,7 +225,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_fwd_tp_kappa", "wdf_clipper_mlp_bwd_w_tp_kappa", "wdf_clipper_mlp_tp_starts",
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
-    "wdf_ss_tp_chunks", "wdf_ss_fwd_tp_ws_bytes", "wdf_ss_fwd_tp", "wdf_ss_bwd_tp_ws_bytes", "wdf_ss_bwd_tp",
+    "wdf_ss_tp_chunks", "wdf_ss_tp_starts", "wdf_ss_fwd_tp_ws_bytes", "wdf_ss_fwd_tp", "wdf_ss_bwd_tp_ws_bytes", "wdf_ss_bwd_tp",
     "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy", "wdf_event_bracket_next",
 )
@@ -1010,12 +1013,23 @@ def ss_bwd(x, coef, ns, ni, zstash, gy, root_kind=ROOT_NONE, rootp=None, n_up=1,
     return gcoef, groot, gz0
 
 
-def ss_fwd_tp(x, coef, ns, ni, rootp, n_chunks, warmup, tol=1e-6, n_up=1, n_down=1, want_stash=True, z0=None, want_zT=False):
+def ss_tp_starts(T, n_chunks, warmup):
+    """The sample every chunk's wave begins at (warm-up included) -> list of ints (rows of a stash to hand in as zinit)."""
+    K = lib().wdf_ss_tp_chunks(int(T), int(n_chunks))
+    out = (C.c_int64 * K)()
+    _check(lib().wdf_ss_tp_starts(int(T), K, int(warmup), out), "wdf_ss_tp_starts")
+    return list(out)
+
+
+def ss_fwd_tp(x, coef, ns, ni, rootp, n_chunks, warmup, tol=1e-6, n_up=1, n_down=1, want_stash=True, z0=None, want_zT=False,
+              zinit=None):
     """Time-parallel forward of a tree with a diode-pair root (include/wdf_hip.h, wdf_ss_fwd_tp): chunks warmed up from
-    z = 0, boundaries verified on the device, missed waves re-run sequentially behind a gate.
+    z = 0 (or from zinit [chunks, ns, B]: states for the samples ss_tp_starts names), boundaries verified on the device,
+    missed waves re-run sequentially behind a gate.
     -> y [T,B], zstash [T,ns,B] | None, zT [ns,B] | None, status (device int32[4]: read with ss_tp_status)."""
     require_gpu()
     x, coef, rootp, z0 = _f32_dev(x, "x"), _f32_dev(coef, "coef"), _f32_dev(rootp, "rootp"), _f32_dev(z0, "z0")
+    zinit = _f32_dev(zinit, "zinit")
     B, T = x.shape[0], x.shape[1]
     if x.numel() != B * T * ni or coef.numel() != lib().wdf_ss_ncoef(ns, ni):
         raise WdfHipError("ss_fwd_tp: x / coef do not match ns, ni")
@@ -1025,8 +1039,10 @@ def ss_fwd_tp(x, coef, ns, ni, rootp, n_chunks, warmup, tol=1e-6, n_up=1, n_down
     zT = torch.empty((ns, B), dtype=torch.float32, device=x.device) if want_zT else None
     ws = torch.empty((lib().wdf_ss_fwd_tp_ws_bytes(ns, B, K),), dtype=torch.uint8, device=x.device)
     status = torch.empty((4,), dtype=torch.int32, device=x.device)
+    if zinit is not None and tuple(zinit.shape) != (K, ns, B):
+        raise WdfHipError(f"zinit: expected [chunks, ns, B] = [{K},{ns},{B}]")
     rc = lib().wdf_ss_fwd_tp(_ptr(x), _ptr(coef), _ptr(rootp), ns, ni, int(n_up), int(n_down), _ptr(y), _ptr(zs), _ptr(z0),
-                             _ptr(zT), B, T, K, int(warmup), float(tol), _ptr(ws), _ptr(status), _stream())
+                             _ptr(zT), B, T, K, int(warmup), float(tol), _ptr(zinit), _ptr(ws), _ptr(status), _stream())
     _check(rc, "wdf_ss_fwd_tp")
     return y, zs, zT, status
 

@@ -12,6 +12,7 @@ dL/d(matrices) and torch chains it to the component values -- which is what
 tape.gradient(loss, model.trainable_variables) is in the reference (lpf.py:87-90).
 """
 import math
+import weakref
 from collections import namedtuple
 
 import numpy as np
@@ -53,11 +54,99 @@ def plan_ss_time_parallel(coef64, ns, ni, root_kind, B, T, tol=1.0e-6):
     return SsTpPlan(max(1, k_fwd), W, float(tol), max(1, k_bwd))
 
 
+class SsWarmStart:
+    """Warm-started chunks for the time-parallel state-space forward when the SAME batch is visited again with slightly
+    different coefficients (a training loop: lpf.py:86-99 re-runs data_in every epoch): chunk k starts from the state the
+    previous call had at the sample its warm-up begins -- or the secant through the last two calls -- so a fraction of the
+    cold warm-up closes the gap, and with the shorter warm-up more chunks pay.  The device verifies every boundary as
+    always; its verdict comes back through pinned memory behind the forward (no wait) and steers the warm-up in 16-step
+    units.  One object per (batch, circuit); made by Circuit.__call__, keyed on the caller's tensor and its version."""
+
+    UNIT, FLOOR = 16, 16
+
+    def __init__(self, T, B, ns, plan, secant=True):
+        self.T, self.B, self.ns, self.plan, self.secant = int(T), int(B), int(ns), plan, bool(secant)
+        waves = max(1, -(-self.B // 64))
+        self.k_max = max(2, (2 * N_SIMD) // waves)
+        self.W = max(self.FLOOR, min(-(-(plan.warmup // 4) // self.UNIT) * self.UNIT, plan.warmup))
+        self.rows, self.prev = {}, {}
+        self.calls, self.since, self.bad, self.bad_at, self.want = 0, 0, 0, -10**9, None
+        self.gated = self.pin = self.pending = None
+        self.gated_seen = 0
+        self._idx = {}
+        self.trace = []
+
+    def chunks(self, W):
+        return binding.lib().wdf_ss_tp_chunks(self.T, max(2, min(self.T // max(W, 64), self.k_max)))
+
+    def _read_verdict(self):
+        if self.pending is None or not self.pending[0].query():
+            return
+        _, issued, w_then = self.pending
+        self.pending = None
+        total, miss = int(self.pin[0]), float(self.pin[1:2].view(torch.float32)[0])
+        missed, self.gated_seen = total > self.gated_seen, total
+        far = miss * 4.0 < self.plan.tol            # the sampled call's largest miss: far inside the tolerance -> bolder, sooner
+        if missed:
+            if w_then >= self.bad:
+                self.bad, self.bad_at = w_then, issued
+            if w_then >= self.W:
+                self.want, self.since = min(w_then + 2 * self.UNIT, self.plan.warmup), self.calls
+        else:
+            if self.calls - self.bad_at > 256:
+                self.bad = 0
+            lower = max(self.FLOOR, self.W - (2 if far else 1) * self.UNIT)
+            if w_then == self.W and issued - self.since >= (4 if far else 16) and self.bad < lower < self.W:
+                self.want, self.since = lower, self.calls
+
+    def start(self):
+        """-> (chunks, warm-up, zinit) for this call; (plan's, cold, None) when there is nothing to start from yet."""
+        self.calls += 1
+        self._read_verdict()
+        if self.want is not None and self.want in self.rows:
+            self.W, self.want = self.want, None
+        r1 = self.rows.get(self.W)
+        if r1 is None:
+            return self.plan.k_fwd, self.plan.warmup, None
+        r2 = self.prev.get(self.W) if self.secant else None
+        return self.chunks(self.W), self.W, (r1 if r2 is None else torch.lerp(r2, r1, 2.0))
+
+    def finish(self, zs, status, was_warm, w_used):
+        """After the forward: keep this call's states at the chunk starts the next call may use; queue the verdict."""
+        cands = list(dict.fromkeys(w for w in (self.want, max(self.FLOOR, self.W - 2 * self.UNIT), self.W - self.UNIT, self.W,
+                                                self.W + 2 * self.UNIT)
+                                   if w is not None and self.FLOOR <= w <= self.plan.warmup))
+        key = tuple(cands)
+        if key not in self._idx:
+            if len(self._idx) > 16:
+                self._idx.clear()
+            starts = [binding.ss_tp_starts(self.T, self.chunks(w), w) for w in cands]
+            self._idx[key] = (torch.tensor([t for s_ in starts for t in s_], dtype=torch.int64, device=zs.device),
+                              [len(s_) for s_ in starts])
+        idx, lens = self._idx[key]
+        rows = zs.index_select(0, idx).split(lens, 0)            # [sum of chunk counts, ns, B] floats; the stash is not kept
+        self.prev = {w: self.rows[w] for w in cands if w in self.rows and self.rows[w].shape[0] == lens[cands.index(w)]}
+        self.rows = dict(zip(cands, rows))
+        if was_warm:
+            if self.gated is None:
+                self.gated = torch.zeros((1,), dtype=torch.int32, device=zs.device)
+                self.pin = torch.empty((2,), dtype=torch.int32, pin_memory=True)
+            self.gated.add_(status[2:3])
+            if self.pending is None:
+                self.pin[:1].copy_(self.gated, non_blocking=True)
+                self.pin[1:].copy_(status[1:2], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self.pending = (ev, self.calls, w_used)
+        self.trace.append(w_used)
+
+
 class _StateSpaceFn(torch.autograd.Function):
-    """y [T,B] = statespace(coef, rootp, x [B,T,ni], z0).  tp: an SsTpPlan (time-parallel kernels) or None."""
+    """y [T,B] = statespace(coef, rootp, x [B,T,ni], z0).  tp: an SsTpPlan (time-parallel kernels) or None.
+    warm: an SsWarmStart for this batch (training loops) or None."""
 
     @staticmethod
-    def forward(ctx, coef, rootp, x, z0, ns, ni, root_kind, n_up, n_down, want_zT, tp=None):
+    def forward(ctx, coef, rootp, x, z0, ns, ni, root_kind, n_up, n_down, want_zT, tp=None, warm=None):
         need = coef.requires_grad or (rootp is not None and rootp.requires_grad) or (z0 is not None and z0.requires_grad)
         c = coef.detach().contiguous()
         rp = None if rootp is None else rootp.detach().contiguous()
@@ -68,9 +157,13 @@ class _StateSpaceFn(torch.autograd.Function):
             y, zs, zT = binding.ss_fwd_lin_tp(x, c, ns, ni, k_lin, want_stash=need, z0=z0d, want_zT=want_zT)
         elif tp is not None and tp.k_fwd >= 2 and root_kind == binding.ROOT_DIODE_PAIR:
             # nonlinear root: chunks warmed up from z = 0, verified on the device, missed waves re-run sequentially
-            y, zs, zT, st = binding.ss_fwd_tp(x, c, ns, ni, rp, tp.k_fwd, tp.warmup, tp.tol, n_up, n_down, want_stash=need,
-                                              z0=z0d, want_zT=want_zT)
+            k, W, zinit = (tp.k_fwd, tp.warmup, None) if (warm is None or not need or z0d is not None) else warm.start()
+            y, zs, zT, st = binding.ss_fwd_tp(x, c, ns, ni, rp, k, W, tp.tol, n_up, n_down, want_stash=need,
+                                              z0=z0d, want_zT=want_zT, zinit=zinit)
             LAST_SS_TP_STATUS["status"] = st
+            LAST_SS_TP_STATUS["warmup_used"], LAST_SS_TP_STATUS["chunks_used"] = W, k
+            if warm is not None and need and z0d is None:
+                warm.finish(zs, st, zinit is not None, W)
         else:
             y, zs, zT = binding.ss_fwd(x, c, ns, ni, root_kind, rp, n_up, n_down, want_stash=need, z0=z0d, want_zT=want_zT)
         ctx.cfg = (ns, ni, root_kind, n_up, n_down, z0 is not None, tp)
@@ -90,7 +183,7 @@ class _StateSpaceFn(torch.autograd.Function):
         else:
             gcoef, groot, gz0 = binding.ss_bwd(x, c, ns, ni, zs, gy.contiguous(), root_kind, rp, n_up, n_down,
                                                want_gz0=has_z0)
-        return gcoef, groot, None, gz0, None, None, None, None, None, None, None
+        return gcoef, groot, None, gz0, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------ tree walking
@@ -160,9 +253,10 @@ class Circuit:
     topology only.
     """
 
-    def __init__(self, top, root, probe, per_sample_R=None, force_generic=False, time_parallel="auto"):
+    def __init__(self, top, root, probe, per_sample_R=None, force_generic=False, time_parallel="auto", warm_start=True):
         self.top, self.root, self.probe = top, root, probe
         self.time_parallel = time_parallel          # "auto" | None | engine.TpPlan
+        self.warm_start = bool(warm_start)          # generic trees with a diode root: SsWarmStart when a batch is re-visited
         self.force_generic = bool(force_generic)    # tests: run the clipper tree through the generic kernel
         self.elements = _walk(top)
         if probe not in self.elements:
@@ -376,8 +470,22 @@ class Circuit:
             tp = plan_ss_time_parallel(coef64, self.ns, self.ni, kind, x.shape[0], x.shape[1])
         elif not isinstance(tp, SsTpPlan):
             tp = None
+        warm = None
+        if tp is not None and tp.k_fwd >= 2 and kind == binding.ROOT_DIODE_PAIR and self._anchor is not None and self.warm_start:
+            # the caller's tensor object and version name the batch: the same one again -> its chunks start warm
+            ws = self.__dict__.setdefault("_ss_warm", {})
+            wkey = (id(self._anchor), self._anchor._version, tuple(x.shape))
+            hit = ws.get(wkey)
+            if hit is None or hit[0]() is not self._anchor:
+                for k_ in [k_ for k_, v_ in ws.items() if v_[0]() is None]:
+                    del ws[k_]
+                if len(ws) >= 4:
+                    ws.clear()
+                hit = ws[wkey] = (weakref.ref(self._anchor), SsWarmStart(x.shape[1], x.shape[0], self.ns, tp))
+            warm = hit[1]
+            warm.plan = tp                  # (the cold plan follows the components as they train; the warm state stays)
         y, zT = _StateSpaceFn.apply(coef, rootp, x.contiguous(), z0t, self.ns, self.ni, kind, n_up, n_down,
-                                    bool(return_state), tp)
+                                    bool(return_state), tp, warm)
         y = y.as_subclass(tf.Tensor)
         return (y, zT) if return_state else y
 

@@ -341,18 +341,21 @@ int wdf_ss_bwd(const float* x, const float* coef, const float* rootp,
 
 /* Time-parallel forms of the two calls above (csrc/wdf_statespace.h, second half) for trees with >= 1 state; n_chunks
  * must be a value wdf_ss_tp_chunks returns (chunks of a multiple of 8 steps).
- * wdf_ss_fwd_tp (diode root): chunk k starts `warmup` steps early from z = 0; chunk boundaries are verified on the device
- *   (|arrival - predecessor's end| <= tol per state) and the sequential kernel, launched behind it, re-runs exactly the
- *   64-sequence waves that missed.  status: device int32[4] = {n_bad, max |miss| (float bits), gated waves, 0}.
+ * wdf_ss_fwd_tp (diode root): chunk k starts `warmup` steps early from z = 0 -- or, with zinit [n_chunks][ns][B], from
+ *   the states the caller supplies for the samples wdf_ss_tp_starts names (a training loop that re-visits its batch hands
+ *   in the previous call's stash rows: a fraction of the cold warm-up then closes the gap); chunk boundaries are verified
+ *   on the device (|arrival - predecessor's end| <= tol per state) and the sequential kernel, launched behind it, re-runs
+ *   exactly the 64-sequence waves that missed.  status: device int32[4] = {n_bad, max |miss| (float bits), gated waves, 0}.
  *   ws: wdf_ss_fwd_tp_ws_bytes(ns, B, n_chunks) bytes.  Same outputs as wdf_ss_fwd within tol (HPFDiodeClipper.h:28-32).
  * wdf_ss_bwd_tp (any root): EXACT -- the adjoint recurrence is linear in the adjoint entering a chunk, every chunk leaves
  *   an affine record, one walk per sequence composes them; same results as wdf_ss_bwd up to summation order.
  *   ws: wdf_ss_bwd_tp_ws_bytes(ns, ni, B, n_chunks) bytes.                                                            */
 int wdf_ss_tp_chunks(int64_t T, int n_chunks);
 size_t wdf_ss_fwd_tp_ws_bytes(int ns, int64_t B, int n_chunks);
+int wdf_ss_tp_starts(int64_t T, int n_chunks, int warmup, int64_t* starts /* [n_chunks]: first sample each chunk's wave runs */);
 int wdf_ss_fwd_tp(const float* x, const float* coef, const float* rootp, int ns, int ni, int n_up, int n_down, float* y,
-                  float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws,
-                  void* status, void* stream);
+                  float* zstash, const float* z0, float* zT, int64_t B, int64_t T, int n_chunks, int warmup, float tol,
+                  const float* zinit, void* ws, void* status, void* stream);
 size_t wdf_ss_bwd_tp_ws_bytes(int ns, int ni, int64_t B, int n_chunks);
 int wdf_ss_bwd_tp(const float* x, const float* coef, const float* rootp, int ns, int ni, int root, int n_up, int n_down,
                   const float* zstash, const float* gy, void* ws, float* gcoef, float* groot, float* gz0, int64_t B, int64_t T,

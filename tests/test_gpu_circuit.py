@@ -462,6 +462,64 @@ def _run_forward(wdf, x, tp):
     return circ, circ(cuda(x))
 
 
+def test_state_space_forward_warm_starts_when_a_batch_is_visited_again(wdf):
+    """A training loop on the HPF clipper (one Adam per component, lpf.py:86-99 style) through the generic kernels: from
+    the second visit of the batch the chunks start from the previous calls' states (lowering.SsWarmStart: a quarter of
+    the cold warm-up, more chunks), and the loop follows the loop on the sequential kernels -- outputs within the
+    verification tolerance, parameters alike; a direct C-ABI call with zinit = the truth itself verifies exactly."""
+    from wdf_hip import lowering, binding as wb
+    tf = wdf.tf
+    B, T = 256, 4096
+    x = cuda((np.random.default_rng(11).standard_normal((B, T)) * 1.2).astype(np.float32))
+    ref, _ = _hpf_clipper(wdf, None)
+    tgt = (ref(x) * 0.8).as_subclass(torch.Tensor).detach()
+
+    def train(tp, steps=14):
+        circ, params = _hpf_clipper(wdf, tp)
+        opts = [tf.keras.optimizers.Adam(learning_rate=2.0e-3 * float(p)) for p in params]
+        ys, used = [], []
+        for _ in range(steps):
+            with tf.GradientTape() as tape:
+                y = circ(x)
+                loss = tf.reduce_mean(tf.square(y - tgt))
+            grads = tape.gradient(loss, params)
+            for o, g, p in zip(opts, grads, params):
+                o.apply_gradients([(g, p)])
+            ys.append(y.as_subclass(torch.Tensor).detach())
+            used.append((lowering.LAST_SS_TP_STATUS.get("chunks_used"), lowering.LAST_SS_TP_STATUS.get("warmup_used"),
+                         None if tp is None else wb.ss_tp_status(lowering.LAST_SS_TP_STATUS["status"])))
+        return circ, ys, used, [float(p) for p in params]
+
+    fresh, _ = _hpf_clipper(wdf, "auto")
+    plan = lowering.plan_ss_time_parallel(fresh.matrices()[0], fresh.ns, fresh.ni, wb.ROOT_DIODE_PAIR, B, T)
+    assert plan.k_fwd >= 2
+    _, y_seq, _, p_seq = train(None)
+    circ, y_tp, used, p_tp = train("auto")
+    coef64, _ = circ.matrices()
+    warm = next(iter(circ._ss_warm.values()))[1]
+    assert used[0][1] == plan.warmup and used[0][0] == plan.k_fwd                       # the first visit is cold
+    assert all(w <= plan.warmup // 2 and k > plan.k_fwd for k, w, _ in used[1:]), used  # ... the rest start warm
+    assert warm.trace == [w for _, w, _ in used]
+    for a, b in zip(y_tp, y_seq):
+        assert float((a - b).abs().max()) <= 5e-6          # (verified to 1e-6 per boundary; the two loops' parameters drift apart a little)
+    assert np.allclose(p_tp, p_seq, rtol=2e-5, atol=0)
+    # the C ABI directly: zinit = the sequential trajectory at the chunk starts -> every boundary verifies to rounding
+    coef = coef64.detach().float().cuda()
+    dp = circ.root
+    rootp = torch.tensor([float(dp.Is), float(dp.nVt), float(circ.matrices()[1])], dtype=torch.float32, device="cuda")
+    xs = x.unsqueeze(-1).contiguous()
+    y0, zs0, _ = wb.ss_fwd(xs, coef, 1, 1, wb.ROOT_DIODE_PAIR, rootp, dp.N_up, dp.N_down)
+    K = wb.lib().wdf_ss_tp_chunks(T, 16)
+    starts = wb.ss_tp_starts(T, K, 16)
+    assert starts[0] == 0 and starts[1] == T // K - 16
+    zinit = zs0.index_select(0, torch.tensor(starts, device="cuda"))
+    y1, _, _, st = wb.ss_fwd_tp(xs, coef, 1, 1, rootp, K, 16, 1e-6, dp.N_up, dp.N_down, zinit=zinit)
+    st = wb.ss_tp_status(st)
+    assert st["n_bad"] == 0 and st["max_miss"] <= 2e-7 and float((y1 - y0).abs().max()) <= 2e-7, st
+    y2, _, _, st2 = wb.ss_fwd_tp(xs, coef, 1, 1, rootp, K, 16, 1e-6, dp.N_up, dp.N_down)     # the same call cold: 16 steps are far too few
+    assert wb.ss_tp_status(st2)["n_bad"] > 0 and torch.equal(y2, y0)
+
+
 @pytest.mark.parametrize("B,T,K", [(5, 100, 3), (64, 1280, 8), (130, 1000, 16)])
 def test_linear_tree_exact_chunked_reverse_sweep(wdf, B, T, K):
     """lpf.py's RC lowpass (ideal-source root folded into the matrices): wdf_ss_bwd_tp == wdf_ss_bwd up to summation order,

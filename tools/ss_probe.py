@@ -94,3 +94,34 @@ for name, build, kind in (("HPF diode clipper", hpf, binding.ROOT_DIODE_PAIR), (
     print(f"{name} kernels only, {B} x {T}, {plan}: " + ", ".join(f"{k} {v:.3f}" for k, v in res.items()) +
           f" -> best fwd + bwd {best_f + best_b:.3f} ms = {B*T/(best_f+best_b)/1e6:.1f} G samples/s "
           f"(sequential pair {B*T/(res['fwd_seq_ms']+res['bwd_seq_ms'])/1e6:.1f})", flush=True)
+
+
+# ---- a training loop on the HPF clipper (one Adam per component): the recurrence kernels alone, chunks started warm ------
+def training_loop(steps=80, lr_rel=1.0e-3):
+    circ, params = hpf("auto")
+    ref, _ = hpf(None)
+    tgt = (ref(x) * 0.8).as_subclass(torch.Tensor).detach()
+    opts = [tf.keras.optimizers.Adam(learning_rate=lr_rel * float(p)) for p in params]
+    ev = [binding.Event() for _ in range(4)]
+    tf_, tb_, used = [], [], []
+    for it in range(steps):
+        binding.Event.bracket_next(ev[0], ev[1])            # the forward's recurrence kernel
+        with tf.GradientTape() as tape:
+            y = circ(x)
+            loss = tf.reduce_mean(tf.square(y - tgt))
+        binding.Event.bracket_next(ev[2], ev[3])            # the reverse sweep's
+        grads = tape.gradient(loss, params)
+        for o, g, p in zip(opts, grads, params):
+            o.apply_gradients([(g, p)])
+        torch.cuda.synchronize()
+        tf_.append(ev[0].elapsed_ms(ev[1])); tb_.append(ev[2].elapsed_ms(ev[3]))
+        st = binding.ss_tp_status(lowering.LAST_SS_TP_STATUS["status"])
+        used.append((lowering.LAST_SS_TP_STATUS["chunks_used"], lowering.LAST_SS_TP_STATUS["warmup_used"], st["gated_waves"], st["max_miss"]))
+    f, b = float(np.median(tf_[steps // 2:])), float(np.median(tb_[steps // 2:]))
+    print(f"HPF diode clipper, training loop ({steps} Adam steps of {lr_rel:g} relative, chunks started from the previous calls' states): "
+          f"cold call fwd kernel {tf_[0]:.3f} ms; later calls fwd {f:.3f} + bwd {b:.3f} ms = {B*T/(f+b)/1e6:.1f} G samples/s (recurrence kernels)")
+    print("  per call chunks/warm-up/gated waves/max miss: " + "  ".join(f"{k}/{w}/{g}/{m:.0e}" for k, w, g, m in used[::4]))
+
+
+if os.environ.get("SS_LOOP", "1") != "0":
+    training_loop()
