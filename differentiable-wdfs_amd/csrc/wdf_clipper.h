@@ -832,6 +832,8 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
         else if (mm * 2.0f > tol) { j += 1; hold = j == 1 ? 8 : 32; }   // (from NO warm-up: an excursion of the extrapolation's
                                                                         //  noise, over in a call or two -- try again soon)
         else if (hold > 0) --hold;
+        else if (mm * 10.0f < tol && j >= 4) j -= j / 2;        // (far above what is needed -- the calls right after the cold
+                                                                //  one: 6 -> 3 -> 2 -> 1 units instead of one unit per call)
         else if (valid > 1 && mm * 64.0f < tol && (j > 2 || mm == 0.0f)) j -= 2;     // (two units: ~25x)
         else if (valid > 1 && mm * 10.0f < tol) j -= 1;         // (down to NO warm-up: the chunk then starts from the
                                                                 //  extrapolated snapshot itself, and the check is the same)
