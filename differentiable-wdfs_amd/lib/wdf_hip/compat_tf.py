@@ -567,7 +567,7 @@ class GradientTape:
         with torch._C.DisableTorchFunctionSubclass():           # plain dispatch: no per-call subclass protocol
             where = None if fused is None else [fused[1].get(id(v)) for v in srcs]
             if where is not None and all(i is not None for i in where):
-                # the loss of a resident circuit's one-pass step (lowering.Circuit._mse_resident) carries its own gradient:
+                # the loss of a resident circuit's one-pass step (lowering.Circuit._loss_resident) carries its own gradient:
                 # the pass that produced the loss produced d loss / d Variable with it -- nothing to back-propagate
                 vec = fused[0]
                 grads = []

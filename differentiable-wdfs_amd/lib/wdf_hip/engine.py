@@ -471,7 +471,8 @@ class _ResidentMseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, st, block, x, r, target, inv_n, idx, *live):
         st.step_fused(block, x, target, r)
-        out = st.out.clone()                  # {sse, gtheta[4]} of THIS call (a validation pass may run before backward)
+        # {sse | mse + esr, gtheta[4]} of THIS call (a validation pass may run before backward)
+        out = st.out.clone() if st.loss_kind == "mse" else torch.cat((st.loss[2:3], st.gtheta))
         ctx.save_for_backward(out)
         ctx.idx = idx
         ctx.mark_non_differentiable(out)

@@ -315,13 +315,13 @@ class Circuit:
             return h[2], h[3]
         return float(parts[2]), float(parts[3])
 
-    def _mse_resident(self, x, target):
-        """mse() on a resident circuit: inputs prepared once per (x, target) pair -- a training set and a validation set
-        alternate in clipper_pot.py:245-262, each keeps its own stepper and warm-start state -- then one pass of the
-        one-pass training step per call."""
+    def _loss_resident(self, x, target, kind="mse", skip=0):
+        """mse() / mse_esr() on a resident circuit: inputs prepared once per (x, target) pair -- a training set and a
+        validation set alternate in clipper_pot.py:245-262, each keeps its own stepper and warm-start state -- then one pass
+        of the one-pass training step per call."""
         from . import engine
         pb = self._pblock
-        key = (id(x), x._version, tuple(x.shape), id(target), target._version)
+        key = (id(x), x._version, tuple(x.shape), id(target), target._version, kind, int(skip))
         ent = self._res_cache.get(key)
         if ent is None:
             if len(self._res_cache) >= 4:
@@ -338,9 +338,10 @@ class Circuit:
                                        time_major=True, R_min=None if r is None else engine.resistance_min(r), fused=True)
             T, B = xv.shape
             st = engine.MseStep(B, T, float(cap.FS), tp, pb.block.device, n_up=dp.N_up, n_down=dp.N_down, time_major=True,
-                                warm=True)
+                                warm=True, loss=kind, skip=int(skip))
             live = [(i, v) for i, v in sorted(pb.members.items()) if v.requires_grad]
-            ent = self._res_cache[key] = (st, xv, r, tgt, 1.0 / float(B * T), [i for i, _ in live], [v for _, v in live],
+            ent = self._res_cache[key] = (st, xv, r, tgt, 1.0 / float(B * T) if kind == "mse" else 1.0,
+                                          [i for i, _ in live], [v for _, v in live],
                                           x, target,                      # (x, target held: their ids stay their own)
                                           {id(v): i for i, v in live})
         st, xv, r, tgt, inv_n, idx, live = ent[:7]
@@ -350,6 +351,23 @@ class Circuit:
         # d loss / d Variable is already known: tape.gradient(loss, ...) on THIS tensor reads it (compat_tf.GradientTape)
         loss._wdf_fused = (out, ent[9])
         return loss
+
+    def mse_esr(self, x, target, skip=0):
+        """The training loss of clipper_pot.py:146-156,177 on this circuit's output past `skip` samples (:232,248):
+        mean((y - t)^2) + sqrt(sum((y - t)^2) / (sum(y^2) + eps) / n)  -- the scripts call esr_loss(outs, train_Y) on a
+        function declared (target, predicted), so the normalising energy is the OUTPUT's.  target: [T,B] like the output.
+        A resident diode-pair clipper (to_device()) evaluates loss and gradient in one pass over the data
+        (wdf_clipper_step_esr_tp); anything else composes it from the forward."""
+        binding.require_gpu()
+        if (getattr(self, "_pblock", None) is not None and isinstance(x, torch.Tensor) and isinstance(target, torch.Tensor)
+                and not self.force_generic):
+            return self._loss_resident(x, target, "mse+esr", skip)
+        y = self(x)
+        o = y[int(skip):]
+        t = tf.convert(target, device=o.device).reshape(y.shape)[int(skip):]
+        S, E = tf.reduce_sum(tf.square(o - t)), tf.reduce_sum(tf.square(o)) + float(np.finfo(float).eps)
+        n = float(o.numel())
+        return S / n + tf.sqrt(S / E / n)
 
     # -- topology tests
     def mse(self, x, target):
@@ -363,7 +381,7 @@ class Circuit:
             return tf.reduce_mean(tf.square(y - target))
         from . import engine
         if getattr(self, "_pblock", None) is not None and isinstance(x, torch.Tensor) and isinstance(target, torch.Tensor):
-            return self._mse_resident(x, target)
+            return self._loss_resident(x, target)
         anchor = x if isinstance(x, torch.Tensor) else None
         x = torch.as_tensor(x).as_subclass(torch.Tensor)
         x = (x if x.is_cuda else x.cuda()).float()

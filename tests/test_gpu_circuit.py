@@ -621,6 +621,41 @@ def test_resident_circuit_trains_like_host_variables(wdf, optimizers):
     assert big._resident and float(vs[3]) in (1.0, float(np.float32(0.1e-12)))
 
 
+def test_resident_circuit_mse_esr_is_the_scripts_training_loss(wdf):
+    """Circuit.mse_esr(x, target, skip): clipper_pot.py:146-156,177 past skip_samples = 50 (:232).  On a resident circuit it
+    is the one-pass MSE + ESR step (loss and gradient from one launch); held against the same loss composed from the
+    plain forward with torch autograd on host Variables, then a few Adam steps side by side."""
+    from wdf_hip import workload
+    tf = wdf.tf
+    theta = workload.clipper_theta()
+    B, T, skip = 256, 2048, 50
+    x = cuda(workload.sweep_batch(B, T, seed=21))
+    ref, _ = _clipper_circuit(wdf, workload.target_theta())
+    tgt = ref(x).as_subclass(torch.Tensor).detach()
+    host, vh = _clipper_circuit(wdf, theta)
+    dev_, vd = _clipper_circuit(wdf, theta)
+    dev_.to_device()
+    oh, od = tf.keras.optimizers.Adam(learning_rate=1.0e-12), tf.keras.optimizers.Adam(learning_rate=1.0e-12)
+    for _ in range(5):
+        with tf.GradientTape() as tape:
+            lh = host.mse_esr(x, tgt, skip)
+        gh = tape.gradient(lh, vh)
+        with tf.GradientTape() as tape:
+            ld = dev_.mse_esr(x, tgt, skip)
+        gd = tape.gradient(ld, vd)
+        assert hasattr(ld, "_wdf_fused") and all(g.is_cuda for g in gd)
+        assert abs(float(ld) - float(lh)) <= 2e-5 * float(lh)
+        assert np.allclose([float(g) for g in gd], [float(g) for g in gh], rtol=3e-4, atol=0)
+        oh.apply_gradients(zip(gh, vh))
+        od.apply_gradients(zip(gd, vd))
+        assert np.allclose([float(v) for v in vd], [float(v) for v in vh], rtol=2e-6, atol=0)
+    # the loss by hand on the resident circuit's own output
+    y = dev_(x).as_subclass(torch.Tensor).detach().double()[skip:]
+    t = tgt.double()[skip:]
+    S, E, n = float(((y - t) ** 2).sum()), float((y ** 2).sum()) + float(np.finfo(float).eps), y.numel()
+    assert abs(float(dev_.mse_esr(x, tgt, skip)) - (S / n + np.sqrt(S / E / n))) <= 2e-5 * (S / n + np.sqrt(S / E / n))
+
+
 def test_resident_circuit_rejects_other_topologies(wdf):
     from wdf_hip import binding as wb
     R1 = wdf.Resistor(1000.0, True)
