@@ -549,14 +549,15 @@ __device__ __forceinline__ int tp_geom_tag(int64_t K, int J, bool skewed) { retu
 //   which the late, slow phase of training runs with no warm-up at all.
 struct TpExtrap { float w1, w2, w3; float lam; bool quad; };   // z = w1 z1 + w2 z2 + w3 z3 (z1 the most recent); lam: the secant's factor
 
-__device__ __forceinline__ TpExtrap tp_extrapolation(const float* __restrict__ theta, const TpCtl* __restrict__ ctl, int valid)
+// (c: the controller as the caller read it -- one flight of loads at the head of the kernel, see clipper_fused_body)
+__device__ __forceinline__ TpExtrap tp_extrapolation(const float* __restrict__ theta, const TpCtl& c, int valid)
 {
     TpExtrap e{1.0f, 0.0f, 0.0f, 0.0f, false};
     if (valid < 2) return e;
     float n10 = 0.0f, n00 = 0.0f, nq0 = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float d1 = theta[i] / ctl->th1[i] - 1.0f, d0 = ctl->th1[i] / ctl->th2[i] - 1.0f, dq = ctl->th2[i] / ctl->th3[i] - 1.0f;
+        const float d1 = theta[i] / c.th1[i] - 1.0f, d0 = c.th1[i] / c.th2[i] - 1.0f, dq = c.th2[i] / c.th3[i] - 1.0f;
         n10 = fmaf(d1, d0, n10);
         n00 = fmaf(d0, d0, n00);
         nq0 = fmaf(dq, d0, nq0);
@@ -578,6 +579,11 @@ __device__ __forceinline__ TpExtrap tp_extrapolation(const float* __restrict__ t
     e.w3 = lam * (lam + 1.0f) / ((s3 - 0.0f) * (s3 + 1.0f));
     e.quad = true;
     return e;
+}
+
+__device__ __forceinline__ TpExtrap tp_extrapolation(const float* __restrict__ theta, const TpCtl* __restrict__ ctl, int valid)
+{
+    return tp_extrapolation(theta, *ctl, valid);
 }
 
 // Lanes of the time-parallel kernels run VT<V>::N sequences each (wdf_vec.h): lane l of tile

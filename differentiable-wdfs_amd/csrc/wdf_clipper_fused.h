@@ -437,32 +437,20 @@ __device__ __forceinline__ void clipper_fused_body(
     chunk_span(k, K, L, skew, T, t0, t1);
     int64_t tw = 0;
     V z = vsplat<V>(0.0f);
-    const bool stateful = ctl != nullptr && ctl->geom == tp_geom_tag(K, J, skew != 0);
-    const int valid = stateful ? ctl->valid : 0;
-    const int head = stateful ? ctl->head : 0;
-    if (k > 0 && valid > 0) {                               // warm start (see clipper_fwd_tp_body)
-        const int j = ctl->j_next;
-        tw = t0 - (int64_t)kWarmStep * j;
-        z = load_own<V>(snap + (((int64_t)head * J + j) * K + (k - 1)) * B, q);
-        if (valid > 1) {                                    // extrapolated along the parameter path (tp_extrapolation)
-            const TpExtrap e = tp_extrapolation(theta, ctl, valid);
-            const V z2 = load_own<V>(snap + (((int64_t)((head + kTpRing - 1) % kTpRing) * J + j) * K + (k - 1)) * B, q);
-            V z3 = z2;
-            if (valid > 2) z3 = load_own<V>(snap + (((int64_t)((head + kTpRing - 2) % kTpRing) * J + j) * K + (k - 1)) * B, q);
-            // (written around z1 so that an unchanged theta returns the snapshot bit for bit)
-            const V zs = vfma(vsplat<V>(e.lam), z - z2, z);                       // secant
-            if (e.quad) {
-                const V zq = vfma(vsplat<V>(e.w3), z3 - z, vfma(vsplat<V>(e.w2), z2 - z, z));
-                const V c = zq - zs;                                              // what the parabola adds: kept where it is signal
-                z = zs + vsel(vgt_c(vabs(c), 4.0e-7f), c, vsplat<V>(0.0f));
-            } else {
-                z = zs;
-            }
-        }
-    } else {
-        tw = (t0 > W) ? t0 - W : 0;
-        if (tw == 0 && z0) z = load_own<V>(z0, q);
-    }
+    // The controller first, all of it in one flight of loads (geometry tag, ring head, warm-up units, the three parameter
+    // vectors of the extrapolation); then EVERYTHING the wave needs to take its first step in a second flight: the first
+    // tile of x / target and the three snapshots the start state is extrapolated from.  (Read where they were used, these
+    // were four dependent round trips at the head of every chunk.)
+    TpCtl c0 = {};
+    if (ctl != nullptr) c0 = *ctl;
+    __builtin_amdgcn_sched_barrier(0);
+    const bool stateful = ctl != nullptr && c0.geom == tp_geom_tag(K, J, skew != 0);
+    const int valid = stateful ? c0.valid : 0;
+    const int head = stateful ? c0.head : 0;
+    const bool warm_start = k > 0 && valid > 0;             // (see clipper_fwd_tp_body)
+    const int jw = warm_start ? c0.j_next : 0;
+    if (warm_start) tw = t0 - (int64_t)kWarmStep * jw;
+    else tw = (t0 > W) ? t0 - W : 0;
     float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)((head + 1) % kTpRing) * J * K + k) * B : nullptr;
 
     const uint32_t rowb = (uint32_t)B * 4u;
@@ -475,6 +463,29 @@ __device__ __forceinline__ void clipper_fused_body(
         load_x_tile<V, TM, VEC4, NR>(x, q, B, T, tw, rowb, xn);
         if constexpr (DYN_R) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, tw, rowb, rn);
         if constexpr (LOSS != 0) { if (tw >= t0) load_rows<V, NR>(target + tw * B, boff, rowb, gn); }
+    }
+    if (warm_start) {
+        // (valid = 1: one snapshot, taken as it is; 2: secant; 3: + parabola -- the missing ones alias the newest, unused)
+        const int h2 = valid > 1 ? (head + kTpRing - 1) % kTpRing : head;
+        const int h3 = valid > 2 ? (head + kTpRing - 2) % kTpRing : h2;
+        z = load_own<V>(snap + (((int64_t)head * J + jw) * K + (k - 1)) * B, q);
+        const V z2 = load_own<V>(snap + (((int64_t)h2 * J + jw) * K + (k - 1)) * B, q);
+        const V z3 = load_own<V>(snap + (((int64_t)h3 * J + jw) * K + (k - 1)) * B, q);
+        __builtin_amdgcn_sched_barrier(0);                  // (the tile's loads stay above: one flight)
+        if (valid > 1) {                                    // extrapolated along the parameter path (tp_extrapolation)
+            const TpExtrap e = tp_extrapolation(theta, c0, valid);
+            // (written around z1 so that an unchanged theta returns the snapshot bit for bit)
+            const V zs = vfma(vsplat<V>(e.lam), z - z2, z);                       // secant
+            if (e.quad) {
+                const V zq = vfma(vsplat<V>(e.w3), z3 - z, vfma(vsplat<V>(e.w2), z2 - z, z));
+                const V c = zq - zs;                                              // what the parabola adds: kept where it is signal
+                z = zs + vsel(vgt_c(vabs(c), 4.0e-7f), c, vsplat<V>(0.0f));
+            } else {
+                z = zs;
+            }
+        }
+    } else if (tw == 0 && z0) {
+        z = load_own<V>(z0, q);
     }
     int64_t t = tw;
 #ifdef WDF_DBG_TIMES
