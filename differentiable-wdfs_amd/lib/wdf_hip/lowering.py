@@ -20,6 +20,7 @@ import torch
 
 from . import binding
 from . import compat_tf as tf
+from . import warmstart
 
 
 # ------------------------------------------------------------------------------ autograd glue
@@ -57,65 +58,39 @@ def plan_ss_time_parallel(coef64, ns, ni, root_kind, B, T, tol=1.0e-6):
 class SsWarmStart:
     """Warm-started chunks for the time-parallel state-space forward when the SAME batch is visited again with slightly
     different coefficients (a training loop: lpf.py:86-99 re-runs data_in every epoch): chunk k starts from the state the
-    previous call had at the sample its warm-up begins -- or the secant through the last two calls -- so a fraction of the
-    cold warm-up closes the gap, and with the shorter warm-up more chunks pay.  The device verifies every boundary as
-    always; its verdict comes back through pinned memory behind the forward (no wait) and steers the warm-up in 16-step
-    units.  One object per (batch, circuit); made by Circuit.__call__, keyed on the caller's tensor and its version."""
-
-    UNIT, FLOOR = 16, 16
+    previous call had at the sample its warm-up begins -- the secant through the last two calls once there are two -- so a
+    fraction of the cold warm-up closes the gap, and with the shorter warm-up more chunks pay.  The device verifies every
+    boundary as always; warmstart.WarmUpController steers the warm-up from its verdicts.  One object per (batch, circuit);
+    made by Circuit.__call__, keyed on the caller's tensor and its version."""
 
     def __init__(self, T, B, ns, plan, secant=True):
         self.T, self.B, self.ns, self.plan, self.secant = int(T), int(B), int(ns), plan, bool(secant)
-        waves = max(1, -(-self.B // 64))
-        self.k_max = max(2, (2 * N_SIMD) // waves)
-        self.W = max(self.FLOOR, min(-(-(plan.warmup // 4) // self.UNIT) * self.UNIT, plan.warmup))
+        self.k_max = max(2, (2 * N_SIMD) // max(1, -(-self.B // 64)))
+        # (misses here are real -- a diode root contracts -- so one repaired wave counts; far inside the tolerance the
+        #  controller takes two units at a time)
+        self.ctl = warmstart.WarmUpController(plan.warmup, plan.warmup // 4, unit=16, floor=16, miss_waves=1, wait_calls=16,
+                                              bold_below=4.0, tol=plan.tol)
         self.rows, self.prev = {}, {}
-        self.calls, self.since, self.bad, self.bad_at, self.want = 0, 0, 0, -10**9, None
-        self.gated = self.pin = self.pending = None
-        self.gated_seen = 0
         self._idx = {}
         self.trace = []
 
     def chunks(self, W):
         return binding.lib().wdf_ss_tp_chunks(self.T, max(2, min(self.T // max(W, 64), self.k_max)))
 
-    def _read_verdict(self):
-        if self.pending is None or not self.pending[0].query():
-            return
-        _, issued, w_then = self.pending
-        self.pending = None
-        total, miss = int(self.pin[0]), float(self.pin[1:2].view(torch.float32)[0])
-        missed, self.gated_seen = total > self.gated_seen, total
-        far = miss * 4.0 < self.plan.tol            # the sampled call's largest miss: far inside the tolerance -> bolder, sooner
-        if missed:
-            if w_then >= self.bad:
-                self.bad, self.bad_at = w_then, issued
-            if w_then >= self.W:
-                self.want, self.since = min(w_then + 2 * self.UNIT, self.plan.warmup), self.calls
-        else:
-            if self.calls - self.bad_at > 256:
-                self.bad = 0
-            lower = max(self.FLOOR, self.W - (2 if far else 1) * self.UNIT)
-            if w_then == self.W and issued - self.since >= (4 if far else 16) and self.bad < lower < self.W:
-                self.want, self.since = lower, self.calls
-
     def start(self):
         """-> (chunks, warm-up, zinit) for this call; (plan's, cold, None) when there is nothing to start from yet."""
-        self.calls += 1
-        self._read_verdict()
-        if self.want is not None and self.want in self.rows:
-            self.W, self.want = self.want, None
-        r1 = self.rows.get(self.W)
-        if r1 is None:
+        self.ctl.cold = self.plan.warmup
+        W = self.ctl.begin(self.rows)
+        if W is None:
             return self.plan.k_fwd, self.plan.warmup, None
-        r2 = self.prev.get(self.W) if self.secant else None
-        return self.chunks(self.W), self.W, (r1 if r2 is None else torch.lerp(r2, r1, 2.0))
+        r1, r2 = self.rows[W], (self.prev.get(W) if self.secant else None)
+        return self.chunks(W), W, (r1 if r2 is None else torch.lerp(r2, r1, 2.0))
 
     def finish(self, zs, status, was_warm, w_used):
         """After the forward: keep this call's states at the chunk starts the next call may use; queue the verdict."""
-        cands = list(dict.fromkeys(w for w in (self.want, max(self.FLOOR, self.W - 2 * self.UNIT), self.W - self.UNIT, self.W,
-                                                self.W + 2 * self.UNIT)
-                                   if w is not None and self.FLOOR <= w <= self.plan.warmup))
+        if was_warm:
+            self.ctl.end(status, w_used)
+        cands = self.ctl.candidates()
         key = tuple(cands)
         if key not in self._idx:
             if len(self._idx) > 16:
@@ -125,19 +100,8 @@ class SsWarmStart:
                               [len(s_) for s_ in starts])
         idx, lens = self._idx[key]
         rows = zs.index_select(0, idx).split(lens, 0)            # [sum of chunk counts, ns, B] floats; the stash is not kept
-        self.prev = {w: self.rows[w] for w in cands if w in self.rows and self.rows[w].shape[0] == lens[cands.index(w)]}
+        self.prev = {w: self.rows[w] for w, n in zip(cands, lens) if w in self.rows and self.rows[w].shape[0] == n}
         self.rows = dict(zip(cands, rows))
-        if was_warm:
-            if self.gated is None:
-                self.gated = torch.zeros((1,), dtype=torch.int32, device=zs.device)
-                self.pin = torch.empty((2,), dtype=torch.int32, pin_memory=True)
-            self.gated.add_(status[2:3])
-            if self.pending is None:
-                self.pin[:1].copy_(self.gated, non_blocking=True)
-                self.pin[1:].copy_(status[1:2], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                self.pending = (ev, self.calls, w_used)
         self.trace.append(w_used)
 
 

@@ -13,6 +13,7 @@ import torch
 
 from . import binding
 from . import engine
+from . import warmstart
 from . import compat_tf as tf
 
 
@@ -45,10 +46,9 @@ def flat_weights(dense):
 MlpTpPlan = namedtuple("MlpTpPlan", ["k_fwd", "warmup", "warmup_per_wave", "tol", "k_bwd"])
 LAST_TP_STATUS = {"status": None}
 WARM_START = os.environ.get("WDF_MLP_WARM_START", "1") != "0"        # 0: every call warms its chunks up from z = 0
-_WARM_UNIT, _WARM_FLOOR = 16, 32      # warm-started chunks: the controller's step and the least warm-up it will try
 _TRACE_WARMUP = [] if os.environ.get("WDF_MLP_TRACE_WARMUP") else None    # (probing) per call: (warm-up steps, warm-started?)
 _TRACE_VERDICTS = []   # (probing, with _TRACE_WARMUP) per verdict read back: (warm-up, n_bad, max miss, gated waves, sequential waves)
-_WARM_START = {}       # (x address, shape, chunks, planned warm-up, r address) -> controller + the previous call's states
+_WARM_START = {}       # (batch object, version, shape, chunks, planned warm-up, r) -> warmstart.WarmUpController + the previous call's states
 KAPPA_FROM_FORWARD = os.environ.get("WDF_MLP_KAPPA_FROM_FORWARD", "1") != "0"   # 0: the reverse sweep recomputes kappa
 _WARMUP_ADAPT = {}     # (x shape, forward chunks, planned warm-up) -> {"warmup": steps in use, "calls": n}
 
@@ -85,51 +85,24 @@ class _ClipperMlpFn(torch.autograd.Function):
                         del _WARM_START[k]                       # entries whose batch has been freed
                     if len(_WARM_START) >= 8:
                         _WARM_START.clear()
-                    warm = _WARM_START[wkey] = {"warmup": 0, "calls": 0, "rows": None, "idx": None,
+                    # (a wave or two re-run now and then is the fp32 floor of this path crossing the tolerance --
+                    #  plan_mlp_time_parallel's note -- which no warm-up cures: only 8 or more per verdict count as a
+                    #  warm-up too short; the weights swing with periods of ~16 calls, so 32 clean calls before less is tried)
+                    ctl = warmstart.WarmUpController(ad["warmup"], int(os.environ.get("WDF_MLP_WARM_W", ad["warmup"] // 3)),
+                                                     unit=16, floor=32, miss_waves=8, wait_calls=32)
+                    warm = _WARM_START[wkey] = {"ctl": ctl, "rows": {}, "idx": None, "idx_key": None,
                                                 "xref": weakref.ref(x), "rref": None if r is None else weakref.ref(r)}
-            hot = warm is not None and warm["rows"] is not None
+            zinit, w_used = None, ad["warmup"]
             if warm is not None:
-                warm["calls"] += 1
-            if hot and warm.get("pending") is not None and warm["pending"][1].query():
-                # the verdict of an earlier warm call, copied to pinned memory behind its forward: no wait here (the
-                # host runs a dozen calls ahead of the device in a training loop, so verdicts are counted in CALLS)
-                buf, _, issued, w_then = warm["pending"]
-                warm["pending"] = None
-                if _TRACE_WARMUP is not None:
-                    _TRACE_VERDICTS.append((w_then, int(buf[0]), float(buf[1:2].view(torch.float32)[0]), int(buf[2]), int(buf[3])))
-                gated_total = int(buf[4])                        # ... over every call up to that one, not only the sampled ones
-                # (a wave or two now and then is the fp32 floor of this path crossing the tolerance -- plan_mlp_time_parallel's
-                #  note -- which no warm-up cures; a short warm-up sends dozens of waves back at once)
-                missed = gated_total - warm.get("gated_seen", 0) >= 8
-                warm["gated_seen"] = gated_total
-                if missed:                                       # gated waves: a chunk arrived too far off
-                    # (a miss costs one chunk-local repair, ~0.1 ms; the warm-up that failed is remembered for 256 calls)
-                    if w_then >= warm.get("bad", 0):
-                        warm["bad"], warm["bad_at"] = w_then, issued
-                    if w_then >= warm["warmup"]:
-                        warm["want"] = min(w_then + 2 * _WARM_UNIT, ad["warmup"])
-                        warm["since"] = warm["calls"]
-                else:
-                    # clean for 32 calls at this warm-up (the training loops' weights swing with periods of ~16 calls,
-                    # tools/mlp_start_probe.py): try 16 steps less, but not what failed within the last 256 calls
-                    if warm["calls"] - warm.get("bad_at", -10**9) > 256:
-                        warm["bad"] = 0
-                    lower = warm["warmup"] - _WARM_UNIT
-                    if w_then == warm["warmup"] and issued - warm.get("since", 0) >= 32 and lower >= _WARM_FLOOR \
-                            and lower > warm.get("bad", 0):
-                        warm["want"], warm["since"] = lower, warm["calls"]
-            zinit = None
-            if hot:
                 # the previous call's verified states at this call's chunk starts (the weights moved by one optimizer step).
-                # Order 0 on purpose: with Adam(1e-4, beta_1 0.5) on these weights the trajectory jumps by 1e-2 per call and
-                # the jumps change sign irregularly -- secant, parabola and fitted AR(1) predictors all do worse
+                # Order 0 on purpose: with Adam(1e-4, beta_1 0.5) on these weights the trajectory jumps by 1e-2 ... 4e-1 per
+                # call and the jumps change sign irregularly -- secant, parabola and fitted AR(1) predictors all do worse
                 # (tools/mlp_start_probe.py, profiles/r03_mlp_start_probe.txt); the warm-up's contraction closes the gap.
-                want = warm.get("want", warm["warmup"])
-                if want != warm["warmup"] and want in warm["rows"]:
-                    warm["warmup"] = want
-                zinit = warm["rows"].get(warm["warmup"])
-                hot = zinit is not None
-            w_used = warm["warmup"] if hot else ad["warmup"]
+                warm["ctl"].cold = ad["warmup"]
+                w_warm = warm["ctl"].begin(warm["rows"])
+                if w_warm is not None:
+                    zinit, w_used = warm["rows"][w_warm], w_warm
+            hot = zinit is not None
             out = binding.clipper_mlp_fwd_tp(x, th, wd, hidden, n_tanh, fs, tp.k_fwd, w_used, r=r,
                                              warmup_per_wave=tp.warmup_per_wave, tol=tp.tol,
                                              want_stash=need or want_stash, z0=z0, want_zT=want_zT,
@@ -140,39 +113,23 @@ class _ClipperMlpFn(torch.autograd.Function):
             LAST_TP_STATUS["warmup_used"] = w_used
             if _TRACE_WARMUP is not None:
                 _TRACE_WARMUP.append((w_used, hot))
+                if warm is not None:
+                    _TRACE_VERDICTS[:] = warm["ctl"].verdicts
             if hot:
-                if warm.get("gated") is None:
-                    warm["gated"] = torch.zeros((1,), dtype=torch.int32, device=x.device)
-                warm["gated"].add_(st[2:3])                      # waves repaired so far, summed on the device
-                if warm.get("pending") is None:                  # (one verdict in flight at a time)
-                    if warm.get("pin") is None:
-                        warm["pin"] = torch.empty((5,), dtype=torch.int32, pin_memory=True)
-                    warm["pin"][:4].copy_(st, non_blocking=True)
-                    warm["pin"][4:].copy_(warm["gated"], non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    warm["pending"] = (warm["pin"], ev, warm["calls"], w_used)
+                warm["ctl"].end(st, w_used)
             else:
                 ad["calls"] += 1
                 if tp.warmup_per_wave is None and (ad["calls"] <= 4 or ad["calls"] % 16 == 0):
                     if binding.mlp_tp_status(st)["gated_waves"] > 0:
                         ad["warmup"] = min(-(-int(1.5 * ad["warmup"]) // 16) * 16, int(x.shape[1]))
             if warm is not None:
-                if warm["warmup"] == 0:
-                    warm["warmup"] = max(_WARM_FLOOR, min(-(-(ad["warmup"] // 3) // _WARM_UNIT) * _WARM_UNIT, ad["warmup"]))
-                    if os.environ.get("WDF_MLP_WARM_W"):         # (probing: start the controller elsewhere)
-                        warm["warmup"] = int(os.environ["WDF_MLP_WARM_W"])
-                # the states the NEXT call may start from: this call's verified trajectory at the chunk starts of the
-                # warm-up in use, one unit less and two more (what the controller can ask for) -- one gather, [3][chunks, B]
-                # floats; the stash itself is not kept alive
-                cands = [w_ for w_ in (warm.get("want", warm["warmup"]), warm["warmup"] - _WARM_UNIT, warm["warmup"], warm["warmup"] + 2 * _WARM_UNIT)
-                         if _WARM_FLOOR <= w_ <= ad["warmup"]]
-                cands = list(dict.fromkeys(cands))
-                ck = tuple(cands)
-                if warm.get("idx_key") != ck:
+                # the states the NEXT call may start from: this call's verified trajectory at the chunk starts of every
+                # warm-up the controller can ask for -- one gather, [candidates][chunks, B] floats; the stash is not kept alive
+                cands = warm["ctl"].candidates()
+                if warm["idx_key"] != tuple(cands):
                     starts = [binding.mlp_tp_starts(int(x.shape[1]), tp.k_fwd, w_) for w_ in cands]
                     warm["idx"] = torch.tensor([t for s_ in starts for t in s_], dtype=torch.int64, device=x.device)
-                    warm["idx_key"] = ck
+                    warm["idx_key"] = tuple(cands)
                 rows = zs.index_select(0, warm["idx"]).view(len(cands), -1, zs.shape[1])
                 warm["rows"] = {w_: rows[i] for i, w_ in enumerate(cands)}
         else:
