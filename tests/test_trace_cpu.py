@@ -230,3 +230,59 @@ def test_adam_without_resident_variables_takes_the_per_variable_path():
     assert abs(float(v) - 0.999) < 1e-6          # first Adam step moves by lr whatever the gradient's size
     opt.apply_gradients([(tf.constant(-2.0), v)])
     assert float(v) <= 0.9995
+
+
+def test_warm_up_controller_policy():
+    """warmstart.WarmUpController (host side of warm-started chunks, no device here: verdicts are fed by hand): repairs
+    lengthen the warm-up by two units and bar what failed for 256 calls; clean calls shorten it by one unit after
+    `wait_calls`; far inside the tolerance the bolder rule takes two units after four calls; a change only happens once
+    the caller holds start states for the new value."""
+    from wdf_hip import warmstart
+
+    class Done:
+        def query(self):
+            return True
+
+    def verdict(c, w, gated_total, miss=2.0e-6, n_bad=0):
+        c.pin = torch.zeros(5, dtype=torch.int32)
+        c.pin[0], c.pin[2], c.pin[4] = n_bad, 0, gated_total
+        c.pin[1:2] = torch.tensor([miss], dtype=torch.float32).view(torch.int32)
+        c.pending = (Done(), c.calls, w)
+
+    c = warmstart.WarmUpController(cold=672, start=150, unit=16, floor=32, miss_waves=8, wait_calls=32)
+    assert c.W == 160 and c.candidates() == [144, 160, 192]
+    assert c.begin({}) is None                                   # nothing to start from: cold call
+    rows = {w: None for w in c.candidates()}
+    assert c.begin(rows) == 160
+    verdict(c, 160, gated_total=3)                               # a wave or two: the fp32 floor, not a short warm-up
+    assert c.begin(rows) == 160 and c.want is None
+    verdict(c, 160, gated_total=40)                              # dozens of waves: too short
+    assert c.begin(rows) == 192 and c.bad == 160
+    rows = {w: None for w in c.candidates()}
+    for _ in range(40):
+        c.begin(rows)
+    verdict(c, 192, gated_total=40)                              # clean long enough: one unit less -- but 176 > bad = 160 only
+    assert c.begin(rows) == 176
+    rows = {w: None for w in c.candidates()}
+    for _ in range(40):
+        c.begin(rows)
+    verdict(c, 176, gated_total=40)
+    assert c.begin(rows) == 176 and c.want is None               # 160 failed within the last 256 calls: not tried again
+    for _ in range(260):
+        c.begin(rows)
+    verdict(c, 176, gated_total=40)
+    assert c.begin(rows) == 160                                  # ... after 256 calls it is
+    # the bolder rule (state-space forward): far inside the tolerance -> two units after four calls, down to the floor
+    b = warmstart.WarmUpController(cold=664, start=166, unit=16, floor=16, miss_waves=1, wait_calls=16, bold_below=4.0, tol=1.0e-6)
+    assert b.W == 176 and b.candidates() == [144, 160, 176, 208]
+    rows = {w: None for w in b.candidates()}
+    for _ in range(5):
+        b.begin(rows)
+    verdict(b, 176, gated_total=0, miss=1.0e-7)
+    assert b.begin(rows) == 144
+    rows = {w: None for w in b.candidates()}
+    verdict(b, 144, gated_total=1, miss=3.0e-6, n_bad=2)         # one repaired wave counts here
+    assert b.begin(rows) == 176 and b.bad == 144
+    # a wanted value the caller has no states for yet is not taken
+    b.want = 96
+    assert b.begin({176: None}) == 176 and b.want == 96
