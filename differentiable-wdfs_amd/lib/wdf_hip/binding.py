@@ -335,6 +335,8 @@ class TpWarmState:
         # (skewed spans, csrc/wdf_clipper_fused.h chunk_span) and they must still hold every snapshot
         self.unit = warm_unit()
         self.max_warm_tiles = max(1, min(int(max_warm_tiles), 32, (3 * chunk_len // 4) // self.unit))
+        if os.environ.get("WDF_MAX_WARM_TILES"):                # (probing: a shallower snapshot ring, e.g. under WDF_FUSED_SKEW_STEPS)
+            self.max_warm_tiles = max(1, min(self.max_warm_tiles, int(os.environ["WDF_MAX_WARM_TILES"])))
         self.B, self.T, self.n_chunks = int(B), int(T), int(n_chunks)
         self.min_warm_tiles = max(0, min(int(min_warm_tiles), self.max_warm_tiles))
         self.buf = torch.empty((L.wdf_clipper_fwd_tp_state_bytes(self.B, self.K, self.max_warm_tiles),),
