@@ -321,7 +321,7 @@ class Trainer:
             e = [binding.Event() for _ in range(n_ev)] if self.args.graph else None
             warm_evs.append(e)
             self.step(ev=e)
-        # HIP events around the recurrence kernel of every 4th step, recorded INSIDE the timed region on the launch stream
+        # HIP events around the recurrence kernel of every 4th step (every n-th past 4096 steps), recorded INSIDE the timed region on the launch stream
         # and read only after its closing synchronize (no host wait in between): kernel time and step time from one loop
         graph = None
         if self.args.graph:
@@ -341,7 +341,8 @@ class Trainer:
                     loss, grad = self.step()
             torch.cuda.current_stream().wait_stream(side)
             self.step_graph = graph
-        evs = [[binding.Event() for _ in range(n_ev)] if (i % 4 == 0 and graph is None) else None for i in range(steps)]
+        every = max(4, -(-steps // 1024))                    # (at most ~1024 bracketed steps: events are not free in very long runs)
+        evs = [[binding.Event() for _ in range(n_ev)] if (i % every == 0 and graph is None) else None for i in range(steps)]
         wdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
