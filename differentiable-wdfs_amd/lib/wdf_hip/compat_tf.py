@@ -71,14 +71,16 @@ class Tensor(torch.Tensor):
                 ko = (id(other), other._version)
             else:
                 return fn()
-        key = (id(self), ver, name, ko)
-        hit = rec.scalar_memo.get(key)
-        # (a result the script has since modified in place -- `v += ...`, `.mul_()` -- is not the operation's value any more:
-        #  its version moved, compute afresh)
-        if hit is None or hit[0]._version != hit[3]:
-            out = fn()
-            hit = rec.scalar_memo[key] = (out, self, other, out._version)     # keeps the operands alive: their ids stay their own
-        return hit[0]
+            key = (id(self), ver, name, ko)
+            hit = rec.scalar_memo.get(key)
+            # (a result the script has since modified in place -- `v += ...`, `.mul_()` -- is not the operation's value any
+            #  more: its version moved, compute afresh.  Read in here too: a Tensor property outside costs a dispatch)
+            if hit is not None and hit[0]._version == hit[3]:
+                return hit[0]
+        out = fn()
+        with torch._C.DisableTorchFunctionSubclass():
+            rec.scalar_memo[key] = (out, self, other, out._version)           # keeps the operands alive: their ids stay their own
+        return out
 
     def __neg__(self):
         return self._scalar_memo("neg", None, lambda: torch.Tensor.__neg__(self))

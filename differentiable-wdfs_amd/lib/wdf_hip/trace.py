@@ -201,7 +201,9 @@ class Wave:
             if hit is not None:
                 return Wave(self.rec, hit[0][0], hit[0][1])
         else:                       # a scalar tensor (a component value / adaptor coefficient): same object, same version
-            key, keep = ("mult", id(self.c0), id(self.c1), id(other), getattr(other, "_version", 0)), (self.c0, self.c1, other)
+            with torch._C.DisableTorchFunctionSubclass():      # (a Tensor property read through the subclass protocol costs 2 us)
+                ver = getattr(other, "_version", 0)
+            key, keep = ("mult", id(self.c0), id(self.c1), id(other), ver), (self.c0, self.c1, other)
 
         def make():
             s = _scalar(other)
