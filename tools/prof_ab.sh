@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for L in libwdf_base.so libwdf_hip.so; do
+for L in ${AB_LIBS:-libwdf_hip.so}; do
   rm -rf gpurun_out/prof_ab_$L
   WDF_HIP_LIB=$PWD/differentiable-wdfs_amd/lib/wdf_hip/$L rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ab_$L -o p -- python bench.py --steps 200 --warmup 20 --no-optimizer --plan 32,192,32 --no-cpu-baseline --no-parity --no-batch-major --no-cold > /dev/null 2>&1
   python - $L <<'PY'
