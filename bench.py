@@ -333,14 +333,20 @@ class Trainer:
                 warm_evs.append([binding.Event() for _ in range(n_ev)])
                 self.step(ev=warm_evs[-1])
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
-                    loss, grad = self.step()
-            torch.cuda.current_stream().wait_stream(side)
-            self.step_graph = graph
+            try:
+                graph = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(graph, stream=side):
+                        loss, grad = self.step()
+                torch.cuda.current_stream().wait_stream(side)
+                self.step_graph = graph
+            except Exception as exc:        # (a runtime that cannot capture the collective: the same step, launched eagerly)
+                print(f"bench: HIP-graph capture of the step failed ({type(exc).__name__}: {exc}); eager launches instead",
+                      file=sys.stderr, flush=True)
+                graph, self.args.graph = None, False
+                torch.cuda.synchronize()
         every = max(4, -(-steps // 1024))                    # (at most ~1024 bracketed steps: events are not free in very long runs)
         evs = [[binding.Event() for _ in range(n_ev)] if (i % every == 0 and graph is None) else None for i in range(steps)]
         wdist.barrier()
