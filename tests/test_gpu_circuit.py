@@ -663,3 +663,62 @@ def test_resident_circuit_rejects_other_topologies(wdf):
     lp = wdf.Circuit(wdf.Inverter(wdf.Series(R1, C1)), wdf.IdealVoltageSource(), C1)
     with pytest.raises(wb.WdfHipError):
         lp.to_device()
+
+
+def test_resident_circuit_with_pot_channel_and_frozen_diode(wdf):
+    """to_device() on the clipper_pot.py variant: the pot resistance streamed per sample (channel 1 overrides the source's
+    own R, which stays out of the block's trainables) and a diode whose Is / nVt are not trainable -- only C learns.
+    mse and mse_esr against the same losses on a host circuit; the optimizer's one-launch update touches C alone."""
+    from wdf_hip import workload
+    tf = wdf.tf
+    theta = workload.clipper_theta()
+    B, T, skip = 192, 2048, 50
+    xin = cuda(np.stack([workload.sweep_batch(B, T, seed=4), workload.pot_resistance_batch(B, T)], axis=-1))
+
+    def build():
+        Vs = wdf.ResistiveVoltageSource(float(theta[2]), trainable=False)
+        Cap = wdf.Capacitor(float(theta[3]), FS, trainable=True)
+        P1 = wdf.Parallel(Vs, Cap)
+        dp = wdf.DiodePair(P1, float(theta[0]), Vt=float(theta[1]), trainable=False)
+        return wdf.Circuit(P1, dp, Cap, per_sample_R=Vs), dp, Cap
+
+    host, _, cap_h = build()
+    tgt = (host(xin) * 0.9).as_subclass(torch.Tensor).detach()
+    dev_, dp_d, cap_d = build()
+    dev_.to_device()
+    assert cap_d.C.is_cuda and cap_d.C.requires_grad and dp_d.Is.is_cuda and not dp_d.Is.requires_grad
+    for loss_of in (lambda c: c.mse(xin, tgt), lambda c: c.mse_esr(xin, tgt, skip)):
+        with tf.GradientTape() as tape:
+            lh = loss_of(host)
+        gh = tape.gradient(lh, [cap_h.C])
+        with tf.GradientTape() as tape:
+            ld = loss_of(dev_)
+        gd = tape.gradient(ld, [cap_d.C])
+        assert abs(float(ld) - float(lh)) <= 2e-5 * float(lh)
+        assert abs(float(gd[0]) - float(gh[0])) <= 3e-4 * abs(float(gh[0]))
+    is0 = float(dp_d.Is)
+    opt = tf.keras.optimizers.Adam(learning_rate=1.0e-12)
+    c0 = float(cap_d.C)
+    opt.apply_gradients(zip(gd, [cap_d.C]))
+    assert opt._resident and float(cap_d.C) != c0 and float(dp_d.Is) == is0
+
+
+def test_state_space_warm_start_restarts_when_the_batch_changes(wdf):
+    """SsWarmStart is keyed on the caller's tensor AND its version: an in-place change of x starts the next call cold
+    (and the result is the sequential kernel's, as always)."""
+    from wdf_hip import lowering
+    tf = wdf.tf
+    B, T = 128, 4096
+    x = cuda((np.random.default_rng(5).standard_normal((B, T)) * 1.2).astype(np.float32))
+    circ, params = _hpf_clipper(wdf, "auto")
+    used = []
+    for it in range(4):
+        if it == 2:
+            x.mul_(0.5)                                       # same object, new contents
+        y = circ(x)
+        tf.GradientTape().gradient(tf.reduce_sum(y), params)
+        used.append(lowering.LAST_SS_TP_STATUS["warmup_used"])
+    plan_w = used[0]
+    assert used[1] < plan_w and used[2] == plan_w and used[3] < plan_w, used
+    ref, _ = _hpf_clipper(wdf, None)
+    assert float((ref(x) - circ(x)).abs().max()) <= 2e-6
