@@ -722,3 +722,40 @@ def test_state_space_warm_start_restarts_when_the_batch_changes(wdf):
     assert used[1] < plan_w and used[2] == plan_w and used[3] < plan_w, used
     ref, _ = _hpf_clipper(wdf, None)
     assert float((ref(x) - circ(x)).abs().max()) <= 2e-6
+
+
+def test_resident_circuit_alternating_training_and_validation_sets(wdf):
+    """clipper_pot.py:245-262 evaluates a validation batch between the training forward and tape.gradient: on a resident
+    circuit each (x, target) pair keeps its own stepper and warm-start state, the validation pass does not disturb the
+    training pass's gradient, and the loop follows the same loop on host Variables."""
+    from wdf_hip import workload
+    tf = wdf.tf
+    theta = workload.clipper_theta()
+    B, T = 256, 2048
+    xt, xv = cuda(workload.sweep_batch(B, T, seed=31)), cuda(workload.sweep_batch(B // 2, T, seed=32))
+    ref, _ = _clipper_circuit(wdf, workload.target_theta())
+    tt, tv = ref(xt).as_subclass(torch.Tensor).detach(), ref(xv).as_subclass(torch.Tensor).detach()
+
+    def loop(resident):
+        circ, vs = _clipper_circuit(wdf, theta)
+        if resident:
+            circ.to_device()
+        opt = tf.keras.optimizers.Adam(learning_rate=1.0e-12)
+        out = []
+        for _ in range(6):
+            with tf.GradientTape() as tape:
+                loss = circ.mse(xt, tt)
+            val = circ.mse(xv, tv)                              # between the forward and the gradient, as the script does
+            grads = tape.gradient(loss, vs)
+            opt.apply_gradients(zip(grads, vs))
+            out.append((float(loss), float(val), [float(g) for g in grads]))
+        return circ, out
+
+    _, host = loop(False)
+    circ, dev_ = loop(True)
+    assert len(circ._res_cache) == 2
+    for (lh, vh, gh), (ld, vd, gd) in zip(host, dev_):
+        assert abs(lh - ld) <= 2e-5 * lh and abs(vh - vd) <= 2e-5 * vh
+        assert np.allclose(gd, gh, rtol=3e-4, atol=0)
+    steppers = [e[0] for e in circ._res_cache.values()]
+    assert all(s.warm is not None and s.warm.info()["valid"] == 3 for s in steppers)
