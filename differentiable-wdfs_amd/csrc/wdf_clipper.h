@@ -512,7 +512,7 @@ constexpr int kTpRing = 4;            // snapshot sets: the one being written an
 constexpr int kWarmStep = 16;
 constexpr int kTpMaxWarmTiles = 32;   // snapshots reach back at most 32 * 16 steps
 
-// Warm-start control block (64 bytes at the head of the caller's persistent state buffer).
+// Warm-start control block (128 bytes at the head of the caller's persistent state buffer).
 struct TpCtl {
     int valid;        // snapshot sets left by earlier calls: 0 (next call is cold), 1, 2, 3
     int head;         // ring slot of the most recent set

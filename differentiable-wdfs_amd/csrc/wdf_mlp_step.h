@@ -1,0 +1,726 @@
+// wdf_mlp_step.h -- the RESIDENT training step of the MLP-root pot clipper (clipper_pot.py:94-127,141-177,245-269:
+// ClipperModel.forward, MSE + ESR past skip_samples, tape.gradient to the DenseRootModel weights, Adam), gfx950.
+//
+// wdf_mlp_tp.h / wdf_mlp_mfma.h run that step as ~20 launches steered from the host.  Here it is five, all steered
+// on the device (so one HIP graph replays it):
+//
+//   (1) mlp_step_fwd_kernel<MODE 0>   the forward in verified time chunks, 16 sequences per wave on the matrix cores.
+//         A work item is (column of 16 sequences, chunk [t0, t1)): the chunk count is PER COLUMN -- a column of
+//         99.1 kOhm sequences forgets its state in ~260 steps, a 10 kOhm one in ~30 (|1 - 2p| per step), so slow
+//         columns get more, shorter chunks and every wave ends up with about the same number of steps.
+//         A chunk starts W steps early from the state the PREVIOUS call had at that sample (snapshots of every
+//         16th state, by absolute time, two sets ping-pong); W is per column and moves by 16 steps from what the
+//         verification of the last call measured (below).  Owned steps also produce kappa = dz'/dz, the two loss
+//         sums, and per 16-step block the adjoint recurrence's map (A, C1, C2): the adjoint entering the block from
+//         the future leaves it as  A gz + ga C1 + gb C2  (dLoss/dy = ga (y - t) + gb y is linear in the two
+//         coefficients the loss sums decide later).
+//         The last wave of a column to finish (device-scope ticket) verifies the column's chunk boundaries, flags
+//         the chunks that arrived off by more than tol, adds the column's loss sums and steers the column's W:
+//         besides the arrival miss it looks at the miss 16, 32 and 48 steps BEFORE arrival (what a shorter warm-up
+//         would have given), so W shrinks only while there is measured slack and grows before a miss happens.
+//   (2) <MODE 1>  flagged chunks again, from the state their predecessor ended in, no warm-up; the column's last
+//         finisher checks that the re-run chunks end where they ended before (else the successors' starts are stale).
+//   (3) <MODE 2>  what still fails: the whole column sequentially (rare: a wrong result is not an option).
+//   (4) mlp_step_wgrad_kernel   exact reverse sweep: a wave takes (column, chunk), composes the block maps of
+//         everything after its chunk into the adjoint that enters it, then walks its steps LAST TO FIRST running the
+//         scalar adjoint recurrence next to the network's forward / delta chain / outer products (wdf_mlp_mfma.h).
+//         No dL/dy array, no adjoint array, no scan launches.
+//   (5) mlp_step_reduce_adam_kernel   fixed-order sum of the waves' partial gradients, Adam, the three loss values,
+//         call bookkeeping (snapshot parity).
+//
+// Multi-rank: (1)-(3), then the rank's two loss sums -> all-reduce -> (4) with the global sums -> (5) without Adam ->
+// all-reduce of the gradient -> wdf_adam_step.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wdf_mlp_mfma.h"
+#include "wdf_optim.h"
+
+namespace wdf {
+
+constexpr int kStepPre = 3;            // states recorded 16, 32, 48 steps before a chunk's first owned step
+
+struct MlpStepCtl {                    // 128 bytes, device; the host reads it, wdf_clipper_mlp_step_state_init writes it
+    int call;                          // training steps done
+    int parity;                        // snapshot set the next forward READS (it writes the other one)
+    int have_snap;                     // 0: no snapshots yet -> cold chunks (z = 0, cold16 units of warm-up)
+    int cold16;                        // cold warm-up, 16-step units
+    int w_min, w_max;                  // bounds of the per-column warm-up (units)
+    int slack;                         // shrink only when the miss `slack` units before arrival is inside the tolerance (1..3)
+    int cool_miss, cool_shrink;        // calls to wait after a miss / after a shrink before shrinking again
+    float tol;
+    float grow_at;                     // arrival miss above grow_at * tol: one unit more (before it becomes a miss)
+    float shrink_at;                   // ... the slack miss must be below shrink_at * tol
+    int freeze;                        // 1: the controller leaves W alone (profiling one configuration)
+    int pad0[3];
+    // the last call's verdict [parity of the call]: {bad boundaries, max miss bits, columns with a flagged chunk,
+    // columns that went sequential}
+    int status[2][4];
+    int total_flagged, total_sequential;   // since init
+    int pad1[6];
+};
+static_assert(sizeof(MlpStepCtl) == 128, "MlpStepCtl");
+
+struct MlpStepItem { int col, k, t0, t1; };     // chunk k of column col owns steps [t0, t1), both multiples of 16
+struct MlpStepCol { int first, K; };            // the column's items are first .. first + K - 1, in time order
+
+struct MlpStepArgs {
+    const float* x;        // [B][T]
+    const float* p;        // [B][T] (DYN_R) or null: p = G1/(G1+G2) per sample (wdf_clipper_mlp_step_prepare)
+    const float* lr;       // [B][T] (DYN_R) or null: log(1/(G1+G2))
+    const float* theta2;   // {R, C}: static R only
+    const float* w;        // flat weights
+    const float* target;   // [T][B]
+    float* y;              // [T][B]
+    float* zstash;         // [T][B]
+    float* kappa;          // [T][B]
+    float* maps;           // [T/16][3][B]
+    float* snap;           // [2][T/16][B]
+    float* zwarm;          // [items][16]   state at t0
+    float* zend;           // [items][16]   state at t1
+    float* zend2;          // [items][16]   ... of the re-run (MODE 1)
+    float* zpre;           // [items][kStepPre][16]
+    double* losspart;      // [items][2]
+    double* colsum;        // [cols][2]
+    const MlpStepItem* items;
+    const MlpStepCol* cols;
+    int* wcol;             // [cols] warm-up units in use
+    int* cool;             // [cols]
+    unsigned* ticket;      // [cols]   (left 0)
+    unsigned* ticket2;     // [cols]   (left 0)
+    unsigned* flag;        // [items]  boundary missed -> MODE 1 re-runs the item
+    unsigned* nflag;       // [cols]   flagged items of the column
+    unsigned* colseq;      // [cols]   MODE 2 re-runs the column
+    unsigned* hwid;        // [items][2] where the item's wave ran (HW_ID, XCC_ID): placement diagnostics
+    MlpStepCtl* ctl;
+    int64_t B, T, skip;
+    int H, n_items, n_cols;
+    float fs;
+};
+
+template <int ACT> __device__ __forceinline__ float step_act(float x)
+{
+    if constexpr (ACT == 1) return fmaxf(x, 0.0f);               // relu (layers.py:63-65)
+    else return tanh_fast(x);
+}
+// derivative of the activation from its OUTPUT h
+template <int ACT> __device__ __forceinline__ float step_dact(float h)
+{
+    if constexpr (ACT == 1) return h > 0.0f ? 1.0f : 0.0f;
+    else return fmaf(-h, h, 1.0f);
+}
+
+template <int NL, int ACT>
+__device__ __forceinline__ float step_mlp_fwd(const MfmaWeights<NL>& W, float a, float lr, mfma_v4f (&act)[NL])
+{
+#pragma unroll
+    for (int v = 0; v < 4; ++v) act[0][v] = step_act<ACT>(fmaf(lr, W.k0l[v], fmaf(a, W.k0a[v], W.b0[v])));
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        mfma_v4f acc = {W.bias[l - 1][0], W.bias[l - 1][1], W.bias[l - 1][2], W.bias[l - 1][3]};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc = mfma4(W.a[l - 1][v], act[l - 1][v], acc);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) act[l][v] = step_act<ACT>(acc[v]);
+    }
+    const float part = fmaf(W.wo[3], act[NL - 1][3],
+                            fmaf(W.wo[2], act[NL - 1][2], fmaf(W.wo[1], act[NL - 1][1], W.wo[0] * act[NL - 1][0])));
+    const mfma_v4f s = mfma4(1.0f, part, mfma_v4f{W.bo, W.bo, W.bo, W.bo});     // sum over the four lane groups
+    return s[0];
+}
+
+template <int NL, int ACT>
+__device__ __forceinline__ float step_mlp_grad_a(const MfmaWeights<NL>& W, const mfma_v4f (&act)[NL])
+{
+    mfma_v4f d;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) d[v] = W.wo[v] * step_dact<ACT>(act[NL - 1][v]);
+#pragma unroll
+    for (int l = NL - 1; l >= 1; --l) {
+        mfma_v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc = mfma4(W.at[l - 1][v], d[v], acc);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) d[v] = acc[v] * step_dact<ACT>(act[l - 1][v]);
+    }
+    const float part = fmaf(W.k0a[3], d[3], fmaf(W.k0a[2], d[2], fmaf(W.k0a[1], d[1], W.k0a[0] * d[0])));
+    const mfma_v4f s = mfma4(1.0f, part, mfma_v4f{0.0f, 0.0f, 0.0f, 0.0f});
+    return s[0];
+}
+
+__device__ __forceinline__ void step_publish(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float step_published(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void step_publish(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double step_published(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// LDS traffic of ONE wave (a wave's LDS instructions complete in order; the fence keeps the compiler from moving them)
+__device__ __forceinline__ void step_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum over the four lane groups (lanes n, 16 + n, 32 + n, 48 + n), to every lane
+__device__ __forceinline__ float groups_sum(float v)
+{
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// One span of one column: steps [tw, t0) warm up, [t0, t1) are owned (outputs written).  Returns the end state.
+// snap_w: the snapshot set this call writes.  PUBLISH: boundary data for a verifier in the same launch.
+template <int NL, bool DYN_R, int ACT, bool PUBLISH>
+__device__ __forceinline__ float mlp_step_span(const MlpStepArgs& A, const MfmaWeights<NL>& Wt, const MlpClipConsts& c,
+                                               int item, int col, int64_t tw, int64_t t0, int64_t t1, float z,
+                                               float* __restrict__ snap_w, double& lossS, double& lossE)
+{
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int64_t B = A.B, T = A.T;
+    const int64_t b_raw = (int64_t)col * 16 + n;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    const float* __restrict__ xp = A.x + b * T;
+    const float* __restrict__ pp = DYN_R ? A.p + b * T : nullptr;
+    const float* __restrict__ lp = DYN_R ? A.lr + b * T : nullptr;
+    double accS = 0.0, accE = 0.0;
+    mfma_v4f act[NL];
+    for (int64_t tb = tw; tb < t1; tb += 16) {
+        const bool owned = tb >= t0;
+        if (g == 0) {
+            if (tb == t0) {
+                if constexpr (PUBLISH) step_publish(A.zwarm + (int64_t)item * 16 + n, z);
+                else A.zwarm[(int64_t)item * 16 + n] = z;
+            }
+            if (!owned) {
+                const int64_t j = (t0 - tb) >> 4;                 // 16-step units before the first owned step
+                if (j <= kStepPre) step_publish(A.zpre + ((int64_t)item * kStepPre + (j - 1)) * 16 + n, z);
+            } else if (live) {
+                step_publish(snap_w + (tb >> 4) * B + b, z);      // the state a later call may start from (and this call's
+            }                                                     // verifier compares shorter warm-ups against)
+        }
+        float xs[16], ps[16], ls[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp + tb + 4 * q);
+            xs[4 * q] = xv.x; xs[4 * q + 1] = xv.y; xs[4 * q + 2] = xv.z; xs[4 * q + 3] = xv.w;
+            if constexpr (DYN_R) {
+                const float4 pv = *reinterpret_cast<const float4*>(pp + tb + 4 * q);
+                const float4 lv = *reinterpret_cast<const float4*>(lp + tb + 4 * q);
+                ps[4 * q] = pv.x; ps[4 * q + 1] = pv.y; ps[4 * q + 2] = pv.z; ps[4 * q + 3] = pv.w;
+                ls[4 * q] = lv.x; ls[4 * q + 1] = lv.y; ls[4 * q + 2] = lv.z; ls[4 * q + 3] = lv.w;
+            }
+        }
+        float tt[4] = {0.0f, 0.0f, 0.0f, 0.0f};                 // group g looks after the steps i = g (mod 4)
+        if (owned) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tt[q] = A.target[(tb + 4 * q + g) * B + b];
+        }
+        float yk = 0.0f, zk = 0.0f, kk = 0.0f;
+        float Am = 1.0f, C1 = 0.0f, C2 = 0.0f, sS = 0.0f, sE = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = DYN_R ? ps[i] : c.p, lr = DYN_R ? ls[i] : c.lr;
+            const float b_diff = z - xs[i];
+            const float b_temp = -p * b_diff;
+            const float a = z + b_temp;
+            const float zn = b_temp - step_mlp_fwd<NL, ACT>(Wt, a, lr, act);     // b_root = -MLP (clipper_pot.py:121)
+            if (owned) {                                             // (wave-uniform)
+                const float Da = -step_mlp_grad_a<NL, ACT>(Wt, act);
+                const float kap = Da - p * (1.0f + Da);
+                const float yv = 0.5f * (zn + z);
+                const bool mine = (i & 3) == g;
+                if (mine) {
+                    yk = yv; zk = z; kk = kap;
+                    const float msk = (tb + i >= A.skip) ? 1.0f : 0.0f;
+                    const float d = yv - tt[i >> 2];
+                    const float wv = msk * 0.5f * Am * (kap + 1.0f);
+                    sS = fmaf(msk * d, d, sS);
+                    sE = fmaf(msk * yv, yv, sE);
+                    C1 = fmaf(wv, d, C1);
+                    C2 = fmaf(wv, yv, C2);
+                }
+                Am *= kap;
+            }
+            z = zn;
+            if ((i & 3) == 3 && owned && live) {
+                const int64_t o = (tb + (i - 3 + g)) * B + b;
+                A.y[o] = yk;
+                A.zstash[o] = zk;
+                A.kappa[o] = kk;
+            }
+        }
+        if (owned) {
+            C1 = groups_sum(C1);
+            C2 = groups_sum(C2);
+            if (g == 0 && live) {
+                float* __restrict__ m = A.maps + (tb >> 4) * 3 * B + b;
+                m[0] = Am; m[B] = C1; m[2 * B] = C2;
+            }
+            if (live) { accS += (double)sS; accE += (double)sE; }
+        }
+    }
+    lossS = accS; lossE = accE;
+    return z;
+}
+
+// the item's loss sums: every lane holds its own steps of its own sequence -> one value per item
+template <bool PUBLISH>
+__device__ __forceinline__ void mlp_step_store_loss(const MlpStepArgs& A, int item, double lossS, double lossE)
+{
+    lossS = wave_sum(lossS);
+    lossE = wave_sum(lossE);
+    if ((threadIdx.x & 63) == 0) {
+        if constexpr (PUBLISH) {
+            step_publish(A.losspart + 2 * (int64_t)item, lossS);
+            step_publish(A.losspart + 2 * (int64_t)item + 1, lossE);
+        } else {
+            A.losspart[2 * (int64_t)item] = lossS;
+            A.losspart[2 * (int64_t)item + 1] = lossE;
+        }
+    }
+}
+
+// the column's loss sums, items in time order (one lane; PUBLISHED: written by other waves of this launch)
+template <bool PUBLISHED>
+__device__ __forceinline__ void mlp_step_column_loss(const MlpStepArgs& A, int col, const MlpStepCol cinfo)
+{
+    double s = 0.0, e = 0.0;
+    for (int k = 0; k < cinfo.K; ++k) {
+        const int64_t it = cinfo.first + k;
+        s += PUBLISHED ? step_published(A.losspart + 2 * it) : A.losspart[2 * it];
+        e += PUBLISHED ? step_published(A.losspart + 2 * it + 1) : A.losspart[2 * it + 1];
+    }
+    A.colsum[2 * col] = s;
+    A.colsum[2 * col + 1] = e;
+}
+
+// MODE 0: the chunked forward.  MODE 1: flagged chunks again from their predecessors' end states.  MODE 2: flagged
+// columns sequentially.  Grid: MODE 0 / 1: one block (wave) per item; MODE 2: one per column.
+// Workgroups are FOUR waves (four items; MODE 2: four columns): the dispatcher spreads a workgroup's waves over the four
+// SIMDs of its CU, whereas single-wave workgroups land wherever the previous kernel left each CU's SIMD pointer -- with
+// one wave per SIMD wanted, 30 doubled-up SIMDs of 1024 cost the forward +55 % (tools/mlp_step_placement.py).
+template <int NL, bool DYN_R, int ACT, int MODE>
+__global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
+{
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int unit = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);   // item (MODE 0, 1) or column (MODE 2) of this wave
+    if (unit >= (MODE == 2 ? A.n_cols : A.n_items)) return;
+    MlpStepCtl* ctl = A.ctl;
+    const int par = ctl->parity;                                   // this call reads set `par`, writes the other
+    const int64_t nblk = A.T >> 4;
+    float* snap_w = A.snap + (int64_t)(par ^ 1) * nblk * A.B;
+    const float* snap_r = A.snap + (int64_t)par * nblk * A.B;
+    int* st = ctl->status[ctl->call & 1];
+    if constexpr (MODE == 2) {
+        const int col = unit;
+        if (A.colseq[col] == 0u) return;
+        const MlpStepCol cinfo = A.cols[col];
+        const MlpClipConsts c = DYN_R ? MlpClipConsts{} : mlp_load_consts(A.theta2, A.fs);
+        const MfmaWeights<NL> Wt = mfma_load_weights<NL>(A.w, A.H, lane, true);
+        // one item after the other, each from the state the previous one ended in
+        float z = 0.0f;                                            // reset(): clipper_pot.py:110-111
+        for (int k = 0; k < cinfo.K; ++k) {
+            const MlpStepItem it = A.items[cinfo.first + k];
+            double lS, lE;
+            z = mlp_step_span<NL, DYN_R, ACT, false>(A, Wt, c, cinfo.first + k, col, it.t0, it.t0, it.t1, z, snap_w, lS, lE);
+            mlp_step_store_loss<false>(A, cinfo.first + k, lS, lE);
+        }
+        if (lane == 0) {
+            mlp_step_column_loss<false>(A, col, cinfo);
+            A.colseq[col] = 0u;
+            atomicAdd(&st[3], 1);
+            atomicAdd(&ctl->total_sequential, 1);
+        }
+        return;
+    } else {
+        const int item = unit;
+        const MlpStepItem it = A.items[item];
+        const MlpStepCol cinfo = A.cols[it.col];
+        if constexpr (MODE == 0) {
+            if (item == 0 && lane == 0) {                          // the NEXT call's verdict words start clean
+                int* nx = ctl->status[(ctl->call + 1) & 1];
+                nx[0] = 0; nx[1] = 0; nx[2] = 0; nx[3] = 0;
+            }
+        } else {
+            if (A.flag[item] == 0u) return;
+        }
+        if constexpr (MODE == 0) {
+            if (lane == 0) {
+                A.hwid[2 * item] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
+                A.hwid[2 * item + 1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+            }
+        }
+        const MlpClipConsts c = DYN_R ? MlpClipConsts{} : mlp_load_consts(A.theta2, A.fs);
+        const MfmaWeights<NL> Wt = mfma_load_weights<NL>(A.w, A.H, lane, true);
+        const int64_t b_raw = (int64_t)it.col * 16 + n;
+        const bool live = b_raw < A.B;
+        const int64_t b = live ? b_raw : A.B - 1;
+        int64_t tw = it.t0;
+        float z = 0.0f;
+        if constexpr (MODE == 0) {
+            if (it.k > 0) {
+                const int warm = ctl->have_snap;
+                const int64_t W = 16 * (int64_t)(warm ? A.wcol[it.col] : ctl->cold16);
+                tw = it.t0 > W ? it.t0 - W : 0;
+                z = (warm && tw > 0) ? snap_r[(tw >> 4) * A.B + b] : 0.0f;
+            }
+        } else {
+            z = A.zend[(int64_t)(item - 1) * 16 + n];              // (k > 0: only boundaries are flagged)
+        }
+        double lS, lE;
+        z = mlp_step_span<NL, DYN_R, ACT, MODE == 0>(A, Wt, c, item, it.col, tw, it.t0, it.t1, z, snap_w, lS, lE);
+        if (g == 0) {
+            if constexpr (MODE == 0) step_publish(A.zend + (int64_t)item * 16 + n, z);
+            else step_publish(A.zend2 + (int64_t)item * 16 + n, z);
+        }
+        mlp_step_store_loss<true>(A, item, lS, lE);
+        // ---- the column's last finisher
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's outputs and boundary states have landed
+        unsigned* tk = (MODE == 0 ? A.ticket : A.ticket2) + it.col;
+        const unsigned expect = MODE == 0 ? (unsigned)cinfo.K : A.nflag[it.col];
+        unsigned old = 0;
+        if (lane == 0) old = atomicAdd(tk, 1u);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != expect - 1u) return;
+        if (lane == 0) *tk = 0u;                                   // left clean for the next launch
+        const float tol = ctl->tol;
+        if constexpr (MODE == 0) {
+            // every boundary of the column: lane (q, n) takes the boundaries k = 1 + q, 5 + q, ...
+            float m0 = 0.0f, mp[kStepPre] = {0.0f, 0.0f, 0.0f};
+            int nbad = 0;
+            const int warm = ctl->have_snap;
+            const int wc = warm ? A.wcol[it.col] : ctl->cold16;
+            for (int k = 1 + g; k < cinfo.K; k += 4) {
+                const int64_t ik = cinfo.first + k;
+                const float zw = step_published(A.zwarm + ik * 16 + n);
+                const float ze = step_published(A.zend + (ik - 1) * 16 + n);
+                const float m = live ? fabsf(zw - ze) : 0.0f;
+                const bool bad = !(m <= tol);
+                const unsigned long long any = __ballot(bad) >> (16 * g) & 0xffffull;   // (the 16 lanes of this boundary)
+                if (n == 0) A.flag[ik] = any ? 1u : 0u;
+                nbad += (any && n == 0) ? 1 : 0;
+                m0 = fmaxf(m0, m);
+                const int64_t t0k = A.items[ik].t0;
+#pragma unroll
+                for (int j = 1; j <= kStepPre; ++j) {
+                    // the miss a warm-up j units shorter would have arrived with (needs j <= W and the sample to exist)
+                    float mj = 3.0e38f;
+                    if (j <= wc && t0k - 16 * j > 0) {
+                        const float zp = step_published(A.zpre + (ik * kStepPre + (j - 1)) * 16 + n);
+                        const float zt = step_published(snap_w + ((t0k >> 4) - j) * A.B + b);
+                        mj = live ? fabsf(zp - zt) : 0.0f;
+                    }
+                    mp[j - 1] = fmaxf(mp[j - 1], mj);
+                }
+            }
+            m0 = wave_max_dpp(m0);
+#pragma unroll
+            for (int j = 0; j < kStepPre; ++j) mp[j] = wave_max_dpp(mp[j]);
+            nbad = wave_sum_dpp(nbad);
+            if (lane == 0) {
+                if (cinfo.K > 0) A.flag[cinfo.first] = 0u;
+                A.nflag[it.col] = (unsigned)nbad;
+                mlp_step_column_loss<true>(A, it.col, cinfo);
+                if (nbad) { atomicAdd(&st[0], nbad); atomicAdd(&st[2], 1); atomicAdd(&ctl->total_flagged, nbad); }
+                if (m0 > 0.0f) atomicMax(&st[1], __float_as_int(m0));
+                // ---- steer the column's warm-up for the next call
+                if (warm && !ctl->freeze && cinfo.K > 1) {
+                    int W = A.wcol[it.col], cl = A.cool[it.col];
+                    const float ms = mp[ctl->slack - 1];
+                    if (nbad) { W += 2; cl = ctl->cool_miss; }
+                    else if (m0 > ctl->grow_at * tol) { W += 1; cl = cl > ctl->cool_shrink ? cl : ctl->cool_shrink; }
+                    else if (mp[0] > tol) { cl = cl > ctl->cool_shrink ? cl : ctl->cool_shrink; }   // one unit less would miss
+                    else if (cl > 0) { cl -= 1; }
+                    else if (mp[kStepPre - 1] <= ctl->shrink_at * tol && W - 2 >= ctl->w_min) { W -= 2; cl = ctl->cool_shrink; }   // ample slack
+                    else if (ms <= ctl->shrink_at * tol && W > ctl->w_min) { W -= 1; cl = ctl->cool_shrink; }
+                    W = W > ctl->w_max ? ctl->w_max : W;
+                    A.wcol[it.col] = W;
+                    A.cool[it.col] = cl;
+                }
+            }
+        } else {
+            // the re-run chunks must end where they ended before (their successors started from those states)
+            float md = 0.0f;
+            for (int k = 1 + g; k < cinfo.K; k += 4) {
+                const int64_t ik = cinfo.first + k;
+                if (A.flag[ik] == 0u) continue;
+                const float d = fabsf(step_published(A.zend2 + ik * 16 + n) - A.zend[ik * 16 + n]);
+                md = fmaxf(md, live ? d : 0.0f);
+            }
+            md = wave_max_dpp(md);
+            if (lane == 0) {
+                mlp_step_column_loss<true>(A, it.col, cinfo);
+                A.colseq[it.col] = (md <= tol) ? 0u : 1u;
+                for (int k = 1; k < cinfo.K; ++k) A.flag[cinfo.first + k] = 0u;
+                A.nflag[it.col] = 0u;
+            }
+        }
+    }
+}
+
+// ---- (4) the reverse sweep: adjoint recurrence + weight gradient, one wave per (column, chunk of Lw steps) ----------
+// sums: the two GLOBAL loss sums {S, E} (multi-rank: after the all-reduce) or null -> this rank's colsum.
+// wsw: float[parts][count], part = chunk * n_cols + column.  adam_step (or null): bumped once here, so the
+// reduce / Adam kernel behind reads the step count it has to use.
+template <int NL, bool DYN_R, int ACT, int BS = 8>
+__global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A, const double* __restrict__ sums, double n_global,
+                                                             double eps_energy, int64_t Lw, int Kw, float* __restrict__ wsw,
+                                                             float* __restrict__ gcoef_out, int32_t* adam_step)
+{
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int64_t B = A.B, T = A.T;
+    const int64_t part = (int64_t)blockIdx.x * 4 + wv;            // four (column, chunk) parts per workgroup, one per wave
+    if (part >= (int64_t)A.n_cols * Kw) return;
+    const int col = (int)(part % A.n_cols), chunk = (int)(part / A.n_cols);
+    if (adam_step && part == 0 && lane == 0) *adam_step += 1;
+    const int64_t b_raw = (int64_t)col * 16 + n;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    const int64_t t0 = (int64_t)chunk * Lw, t1 = (t0 + Lw < T) ? t0 + Lw : T;
+    // ---- the loss coefficients: dLoss/dy = ga (y - t) + gb y past skip (clipper_pot.py:146-156,177; wdf_elementwise.h)
+    double S, E;
+    if (sums) { S = sums[0]; E = sums[1]; }
+    else {
+        double s = 0.0, e = 0.0;
+        for (int cc = lane; cc < A.n_cols; cc += 64) { s += A.colsum[2 * cc]; e += A.colsum[2 * cc + 1]; }
+        S = wave_sum_dpp(s); E = wave_sum_dpp(e);
+    }
+    E += eps_energy;
+    const double esr = sqrt(S / E / n_global);
+    const float ga = (float)(2.0 / n_global + (esr > 0.0 ? 1.0 / (esr * E * n_global) : 0.0));
+    const float gb = (float)(-esr / E);
+    if (gcoef_out && part == 0 && lane == 0) { gcoef_out[0] = ga; gcoef_out[1] = gb; }
+    const MlpClipConsts c = DYN_R ? MlpClipConsts{} : mlp_load_consts(A.theta2, A.fs);
+    const MfmaWeights<NL> Wt = mfma_load_weights<NL>(A.w, A.H, lane, true);
+    // ---- the adjoint that enters this chunk: the maps of every later 16-step block, last block first
+    float gz = 0.0f;
+    {
+        const int64_t j0 = t1 >> 4, j1 = T >> 4;
+        int64_t j = j1;
+        for (; j - 8 >= j0; j -= 8) {
+            float ma[8], m1[8], m2[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float* __restrict__ m = A.maps + (j - 1 - q) * 3 * B + b;
+                ma[q] = m[0]; m1[q] = m[B]; m2[q] = m[2 * B];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gz = fmaf(ma[q], gz, fmaf(ga, m1[q], gb * m2[q]));
+        }
+        for (; j > j0; --j) {
+            const float* __restrict__ m = A.maps + (j - 1) * 3 * B + b;
+            gz = fmaf(m[0], gz, fmaf(ga, m[B], gb * m[2 * B]));
+        }
+    }
+    __shared__ float tbuf_all[4][2][16 * 17];
+    float (*tbuf)[16 * 17] = tbuf_all[wv];
+    const float* __restrict__ xp = A.x + b * T;
+    const float* __restrict__ pp = DYN_R ? A.p + b * T : nullptr;
+    const float* __restrict__ lp = DYN_R ? A.lr + b * T : nullptr;
+    float gk0a[4] = {0, 0, 0, 0}, gk0l[4] = {0, 0, 0, 0}, gb0[4] = {0, 0, 0, 0}, gwo[4] = {0, 0, 0, 0}, gbo = 0.0f;
+    float gbias[NL - 1][4];
+    mfma_v4f gK[NL - 1];
+#pragma unroll
+    for (int l = 0; l < NL - 1; ++l) {
+        gK[l] = mfma_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gbias[l][v] = 0.0f;
+    }
+    mfma_v4f act[NL];
+    static_assert(BS == 4 || BS == 8 || BS == 16, "staging block");
+    for (int64_t tb = t1 - BS; tb >= t0; tb -= BS) {         // (chunk bounds are multiples of 16)
+        float xs[BS], ps[BS], ls[BS], zz[BS], kp[BS], gs[BS];
+#pragma unroll
+        for (int q = 0; q < BS / 4; ++q) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp + tb + 4 * q);
+            xs[4 * q] = xv.x; xs[4 * q + 1] = xv.y; xs[4 * q + 2] = xv.z; xs[4 * q + 3] = xv.w;
+            if constexpr (DYN_R) {
+                const float4 pv = *reinterpret_cast<const float4*>(pp + tb + 4 * q);
+                const float4 lv = *reinterpret_cast<const float4*>(lp + tb + 4 * q);
+                ps[4 * q] = pv.x; ps[4 * q + 1] = pv.y; ps[4 * q + 2] = pv.z; ps[4 * q + 3] = pv.w;
+                ls[4 * q] = lv.x; ls[4 * q + 1] = lv.y; ls[4 * q + 2] = lv.z; ls[4 * q + 3] = lv.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            const int64_t o = (tb + i) * B + b;
+            zz[i] = A.zstash[o];
+            kp[i] = A.kappa[o];
+            const float yv = A.y[o], tv = A.target[o];
+            gs[i] = (live && tb + i >= A.skip) ? fmaf(ga, yv - tv, gb * yv) : 0.0f;     // dLoss/dy[n]
+        }
+#pragma unroll
+        for (int i = BS - 1; i >= 0; --i) {
+            const float p = DYN_R ? ps[i] : c.p, lr = DYN_R ? ls[i] : c.lr;
+            // adjoint recurrence (wdf_mlp_tp.h):  g_b2n[n] = gz[n+1] + g[n]/2 ;  gz[n] = kappa[n] g_b2n[n] + g[n]/2
+            const float g_b2n = fmaf(0.5f, gs[i], gz);
+            gz = fmaf(kp[i], g_b2n, 0.5f * gs[i]);
+            const float G = live ? -g_b2n : 0.0f;                // b_root = -MLP; shadow sequences add nothing
+            const float z = zz[i];
+            const float a = fmaf(-p, z - xs[i], z);
+            (void)step_mlp_fwd<NL, ACT>(Wt, a, lr, act);
+            gbo += G;
+            mfma_v4f d;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                gwo[v] = fmaf(G, act[NL - 1][v], gwo[v]);
+                d[v] = Wt.wo[v] * step_dact<ACT>(act[NL - 1][v]);
+            }
+#pragma unroll
+            for (int l = NL - 1; l >= 1; --l) {
+                mfma_v4f gd;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { gd[v] = G * d[v]; gbias[l - 1][v] += gd[v]; }
+                // the two transposes through LDS (one 16 x 17 tile each; the block is one wave): wdf_mlp_mfma.h
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    tbuf[0][(4 * g + v) * 17 + n] = gd[v];
+                    tbuf[1][(4 * g + v) * 17 + n] = act[l - 1][v];
+                }
+                step_wave_sync();
+                mfma_v4f gdT, hT;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    gdT[q] = tbuf[0][n * 17 + 4 * g + q];
+                    hT[q] = tbuf[1][n * 17 + 4 * g + q];
+                }
+                step_wave_sync();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gK[l - 1] = mfma4(gdT[q], hT[q], gK[l - 1]);
+                mfma_v4f nd = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) nd = mfma4(Wt.at[l - 1][v], d[v], nd);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) d[v] = nd[v] * step_dact<ACT>(act[l - 1][v]);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float gd0 = G * d[v];
+                gk0a[v] = fmaf(gd0, a, gk0a[v]);
+                gk0l[v] = fmaf(gd0, lr, gk0l[v]);
+                gb0[v] += gd0;
+            }
+        }
+    }
+    // per-lane partials are per (unit 4 g + v, sequence n): sum over the 16 sequences of the lane group
+    const int H = A.H;
+    const int count = 3 * H + (NL - 1) * (H * H + H) + H + 1;
+    float* __restrict__ o = wsw + part * count;
+    // (the four lane groups carry the same sequences: gbo is the same in all of them)
+    const float vbo = row_sum(gbo);
+    if (lane == 0) o[count - 1] = vbo;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int u = 4 * g + v;
+        const float a0 = row_sum(gk0a[v]), a1 = row_sum(gk0l[v]), a2 = row_sum(gb0[v]), a3 = row_sum(gwo[v]);
+        if (n == 0 && u < H) {
+            o[u] = a0; o[H + u] = a1; o[2 * H + u] = a2;
+            o[3 * H + (NL - 1) * (H * H + H) + u] = a3;
+        }
+#pragma unroll
+        for (int l = 1; l < NL; ++l) {
+            const float vb = row_sum(gbias[l - 1][v]);
+            if (n == 0 && u < H) o[3 * H + (l - 1) * (H * H + H) + H * H + u] = vb;
+        }
+    }
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = 4 * g + v;
+            if (n < H && i < H) o[3 * H + (l - 1) * (H * H + H) + n * H + i] = gK[l - 1][v];
+        }
+    }
+}
+
+// ---- (5) fixed-order sum of the waves' partials, Adam, the loss values, call bookkeeping -----------------------------
+// block (64, 16): thread (i, s) adds partials s, s + 16, ... of weight i in double, the 16 slices are then added in
+// order (mlp_wgrad_reduce_wide_kernel's sum).  m == null: no update (multi-rank: all-reduce gw, then wdf_adam_step).
+static __global__ __launch_bounds__(1024) void mlp_step_reduce_adam_kernel(
+    const float* __restrict__ ws, int nblk, int count, float* __restrict__ gw, float* __restrict__ w, float* __restrict__ m,
+    float* __restrict__ v, const int32_t* __restrict__ step, const float* __restrict__ lr, float b1, float b2, float eps,
+    const double* __restrict__ colsum, int n_cols, const double* __restrict__ sums, double n_global, double eps_energy,
+    float* __restrict__ loss3, MlpStepCtl* ctl)
+{
+    __shared__ double sh[16][64];
+    const int i = blockIdx.x * 64 + threadIdx.x, sl = threadIdx.y;
+    double acc = 0.0;
+    if (i < count) {
+        double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int b = sl;
+        for (; b + 7 * 16 < nblk; b += 8 * 16) {
+            float q8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) q8[q] = ws[(int64_t)(b + 16 * q) * count + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += (double)q8[q];
+        }
+        for (; b < nblk; b += 16) a[0] += (double)ws[(int64_t)b * count + i];
+        acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    sh[sl][threadIdx.x] = acc;
+    __syncthreads();
+    if (sl == 0 && i < count) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sh[q][threadIdx.x];
+        const float g = (float)t;
+        gw[i] = g;
+        if (m) {                                                   // tf.keras Adam (wdf_optim.h), step count already bumped
+            const int ts = *step;
+            const double c1 = 1.0 - ipow((double)b1, ts), c2 = 1.0 - ipow((double)b2, ts);
+            const float mi = b1 * m[i] + (1.0f - b1) * g;
+            const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+            m[i] = mi;
+            v[i] = vi;
+            const float lr_t = (float)((double)lr[i] * sqrt(c2) / c1);
+            w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+        }
+    }
+    if (blockIdx.x == 0 && sl == 1) {                              // (another wave of block 0: off the reduction's path)
+        double S, E;
+        if (sums) { S = sums[0]; E = sums[1]; }
+        else {
+            double s = 0.0, e = 0.0;
+            for (int cc = threadIdx.x; cc < n_cols; cc += 64) { s += colsum[2 * cc]; e += colsum[2 * cc + 1]; }
+            S = wave_sum_dpp(s); E = wave_sum_dpp(e);
+        }
+        if (threadIdx.x == 0) {
+            const double mse = S / n_global, esr = sqrt(S / (E + eps_energy) / n_global);
+            if (loss3) { loss3[0] = (float)mse; loss3[1] = (float)esr; loss3[2] = (float)(mse + esr); }
+            ctl->call += 1;
+            ctl->parity ^= 1;
+            ctl->have_snap = 1;
+        }
+    }
+}
+
+// this rank's two loss sums out of the column sums (multi-rank: the all-reduce's payload)
+static __global__ __launch_bounds__(64) void mlp_step_sums_kernel(const double* __restrict__ colsum, int n_cols, double* __restrict__ sums)
+{
+    double s = 0.0, e = 0.0;
+    for (int cc = threadIdx.x; cc < n_cols; cc += 64) { s += colsum[2 * cc]; e += colsum[2 * cc + 1]; }
+    s = wave_sum_dpp(s); e = wave_sum_dpp(e);
+    if (threadIdx.x == 0) { sums[0] = s; sums[1] = e; }
+}
+
+// p = G1/(G1 + G2), lr = log(1/(G1 + G2)) per sample of the resident pot channel: set_resistance + calc_impedance of every
+// step (clipper_pot.py:116-117, tf_wdf.py:168-177) hoisted out of the training loop -- they depend on the data and on C, not
+// on the weights being trained.  Same arithmetic as mlp_step_coeffs<true> (wdf_mlp.h).
+static __global__ __launch_bounds__(256) void mlp_step_prepare_kernel(const float* __restrict__ r, const float* __restrict__ theta2,
+                                                                      float fs, int64_t n, float* __restrict__ p, float* __restrict__ lr)
+{
+    const MlpClipConsts c = mlp_load_consts(theta2, fs);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float pv, Rp, lv;
+        mlp_step_coeffs<true>(c, r[i], pv, Rp, lv);
+        p[i] = pv;
+        lr[i] = lv;
+    }
+}
+
+}  // namespace wdf

@@ -33,6 +33,9 @@ ONE_SEQUENCE_PER_LANE = os.environ.get("WDF_ONE_SEQUENCE_PER_LANE", "") not in (
 GENERAL_ROOT = False
 
 
+ABI_VERSION = 3                # include/wdf_hip.h WDF_HIP_ABI_VERSION
+
+
 def _root_flag():
     return WDF_GENERAL_ROOT if GENERAL_ROOT else 0
 
@@ -56,6 +59,9 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, fp, i64, ci, cf = C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float
     L.wdf_abi_version.restype = ci
+    if L.wdf_abi_version() != ABI_VERSION:
+        raise WdfHipError(f"{LIB_PATH} has ABI version {L.wdf_abi_version()}, this host layer needs {ABI_VERSION}: "
+                          "rebuild it (make -C differentiable-wdfs_amd/csrc)")
     L.wdf_last_error.restype = C.c_char_p
     L.wdf_device_info.restype = ci
     L.wdf_device_info.argtypes = [ci, C.c_char_p, ci]
@@ -67,9 +73,8 @@ def lib():
     L.wdf_clipper_bwd_ws_bytes.argtypes = [i64]
     L.wdf_clipper_tp_chunks.restype = ci
     L.wdf_clipper_tp_chunks.argtypes = [i64, ci]
-    if hasattr(L, "wdf_clipper_tp_warm_unit"):            # (absent from round-2 builds kept around for A/B runs: WDF_HIP_LIB)
-        L.wdf_clipper_tp_warm_unit.restype = ci
-        L.wdf_clipper_tp_warm_unit.argtypes = []
+    L.wdf_clipper_tp_warm_unit.restype = ci
+    L.wdf_clipper_tp_warm_unit.argtypes = []
     L.wdf_clipper_fwd_tp_ws_bytes.restype = C.c_size_t
     L.wdf_clipper_fwd_tp_ws_bytes.argtypes = [i64, ci]
     L.wdf_clipper_fwd_tp.restype = ci
@@ -162,6 +167,22 @@ def lib():
     L.wdf_clipper_mlp_wgrad_ws_bytes.argtypes = [ci, ci, i64]
     L.wdf_clipper_mlp_wgrad.restype = ci
     L.wdf_clipper_mlp_wgrad.argtypes = [fp, fp, fp, fp, fp, ci, ci, cf, vp, fp, i64, vp]
+    i32p = C.POINTER(C.c_int32)
+    L.wdf_clipper_mlp_step_state_bytes.restype = C.c_size_t
+    L.wdf_clipper_mlp_step_state_bytes.argtypes = [ci, ci, i64, i64, ci, ci]
+    L.wdf_clipper_mlp_step_plan.restype = ci
+    L.wdf_clipper_mlp_step_plan.argtypes = [vp, ci, ci, i64, i64, ci, ci, i32p, ci, ci, ci, ci, ci, cf, vp]
+    L.wdf_clipper_mlp_step_read.restype = ci
+    L.wdf_clipper_mlp_step_read.argtypes = [vp, ci, ci, i64, i64, ci, ci, i32p, i32p, i32p, vp]
+    L.wdf_clipper_mlp_step_set.restype = ci
+    L.wdf_clipper_mlp_step_set.argtypes = [vp, ci, C.c_int32, vp]
+    L.wdf_clipper_mlp_step_set_wcol.restype = ci
+    L.wdf_clipper_mlp_step_set_wcol.argtypes = [vp, ci, ci, i64, i64, ci, ci, i32p, vp]
+    L.wdf_clipper_mlp_step_prepare.restype = ci
+    L.wdf_clipper_mlp_step_prepare.argtypes = [fp, fp, cf, i64, i64, fp, fp, vp]
+    L.wdf_clipper_mlp_step.restype = ci
+    L.wdf_clipper_mlp_step.argtypes = [fp, fp, fp, fp, fp, ci, ci, ci, cf, fp, i64, C.c_double, C.c_double, fp, fp, fp, vp, i64, i64,
+                                       ci, ci, ci, vp, fp, fp, fp, fp, fp, vp, fp, cf, cf, cf, vp]
     L.wdf_ss_ncoef.restype = ci
     L.wdf_ss_ncoef.argtypes = [ci, ci]
     L.wdf_ss_fwd.restype = ci
@@ -172,20 +193,18 @@ def lib():
     L.wdf_ss_fwd_lin_tp.argtypes = [fp, fp, ci, ci, fp, fp, fp, fp, i64, i64, ci, vp, vp]
     L.wdf_ss_bwd.restype = ci
     L.wdf_ss_bwd.argtypes = [fp, fp, fp, ci, ci, ci, ci, ci, fp, fp, vp, fp, fp, fp, i64, i64, ci, vp]
-    if hasattr(L, "wdf_ss_fwd_tp"):                              # (absent from round-2 builds kept around for A/B runs)
-        L.wdf_ss_tp_chunks.restype = ci
-        L.wdf_ss_tp_chunks.argtypes = [i64, ci]
-        L.wdf_ss_fwd_tp_ws_bytes.restype = C.c_size_t
-        L.wdf_ss_fwd_tp_ws_bytes.argtypes = [ci, i64, ci]
-        L.wdf_ss_fwd_tp.restype = ci
-        L.wdf_ss_fwd_tp.argtypes = [fp, fp, fp, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, fp, vp, vp, vp]
-        if hasattr(L, "wdf_ss_tp_starts"):
-            L.wdf_ss_tp_starts.restype = ci
-            L.wdf_ss_tp_starts.argtypes = [i64, ci, ci, C.POINTER(C.c_int64)]
-        L.wdf_ss_bwd_tp_ws_bytes.restype = C.c_size_t
-        L.wdf_ss_bwd_tp_ws_bytes.argtypes = [ci, ci, i64, ci]
-        L.wdf_ss_bwd_tp.restype = ci
-        L.wdf_ss_bwd_tp.argtypes = [fp, fp, fp, ci, ci, ci, ci, ci, fp, fp, vp, fp, fp, fp, i64, i64, ci, vp]
+    L.wdf_ss_tp_chunks.restype = ci
+    L.wdf_ss_tp_chunks.argtypes = [i64, ci]
+    L.wdf_ss_fwd_tp_ws_bytes.restype = C.c_size_t
+    L.wdf_ss_fwd_tp_ws_bytes.argtypes = [ci, i64, ci]
+    L.wdf_ss_fwd_tp.restype = ci
+    L.wdf_ss_fwd_tp.argtypes = [fp, fp, fp, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, fp, vp, vp, vp]
+    L.wdf_ss_tp_starts.restype = ci
+    L.wdf_ss_tp_starts.argtypes = [i64, ci, ci, C.POINTER(C.c_int64)]
+    L.wdf_ss_bwd_tp_ws_bytes.restype = C.c_size_t
+    L.wdf_ss_bwd_tp_ws_bytes.argtypes = [ci, ci, i64, ci]
+    L.wdf_ss_bwd_tp.restype = ci
+    L.wdf_ss_bwd_tp.argtypes = [fp, fp, fp, ci, ci, ci, ci, ci, fp, fp, vp, fp, fp, fp, i64, i64, ci, vp]
     L.wdf_ss_bwd_ws_bytes.restype = C.c_size_t
     L.wdf_ss_bwd_ws_bytes.argtypes = [ci, ci, i64]
     L.wdf_omega_f32.restype = ci
@@ -224,6 +243,8 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_bwd_w_tp_ws_bytes", "wdf_clipper_mlp_bwd_w_tp",
     "wdf_clipper_mlp_fwd_tp_kappa", "wdf_clipper_mlp_bwd_w_tp_kappa", "wdf_clipper_mlp_tp_starts",
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
+    "wdf_clipper_mlp_step_state_bytes", "wdf_clipper_mlp_step_plan", "wdf_clipper_mlp_step_read", "wdf_clipper_mlp_step_set",
+    "wdf_clipper_mlp_step_set_wcol", "wdf_clipper_mlp_step_prepare", "wdf_clipper_mlp_step",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
     "wdf_ss_tp_chunks", "wdf_ss_tp_starts", "wdf_ss_fwd_tp_ws_bytes", "wdf_ss_fwd_tp", "wdf_ss_bwd_tp_ws_bytes", "wdf_ss_bwd_tp",
     "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step",
@@ -358,8 +379,7 @@ class TpWarmState:
 
 def warm_unit():
     """Steps per warm-start unit ("warm tile") of the time-parallel clipper kernels."""
-    L = lib()
-    return int(L.wdf_clipper_tp_warm_unit()) if hasattr(L, "wdf_clipper_tp_warm_unit") else 32
+    return int(lib().wdf_clipper_tp_warm_unit())
 
 
 def clipper_fwd_tp(x, theta, fs, n_chunks, warmup, tol=1e-6, r=None, n_up=1, n_down=1, want_stash=True, z0=None,

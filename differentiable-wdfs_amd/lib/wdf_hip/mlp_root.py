@@ -359,3 +359,259 @@ def run_clipper_mlp(circ, x, z0, return_state):
                         time_parallel=getattr(circ, "time_parallel", None))
     y = y.as_subclass(tf.Tensor)
     return (y, zT.reshape(1, -1)) if return_state else y
+
+
+# ------------------------------------------------------------------------------ the resident training step
+# csrc/wdf_mlp_step.h: clipper_pot.py's epoch (forward over the whole training set, MSE + ESR past skip_samples, gradient
+# to the DenseRootModel weights, Adam) as five launches steered on the device.
+import ctypes as _C
+
+import numpy as _np
+
+PHASE_FWD, PHASE_SUMS, PHASE_BWD, PHASE_GLOBAL_SUMS = 1, 2, 4, 8
+WARM_COST = 0.75          # a warm-up step (no input Jacobian, no stores) in owned-step units (tools/mlp_chunk_probe.py)
+
+
+def _column_bounds(T, K, W, cost=WARM_COST):
+    """Chunk boundaries [0, t1, ..., T] of one column for K chunks and a warm-up of W steps: chunk 0 has no warm-up, so it
+    is longer by about the warm-up's cost and every wave of the column runs about the same number of steps (lengths are
+    multiples of 16: the L that minimises the longer of the two)."""
+    if K <= 1:
+        return [0, T]
+    best = None
+    Lc = int((T - cost * W) / K / 16.0) * 16
+    for L in (Lc - 16, Lc, Lc + 16, Lc + 32):
+        L = max(16, min(L, (T - 16) // (K - 1) // 16 * 16))
+        L0 = T - (K - 1) * L
+        c = max(L0, L + cost * W)
+        if best is None or c < best[0]:
+            best = (c, L, L0)
+    _, L, L0 = best
+    return [0] + [L0 + i * L for i in range(K)]
+
+
+def _column_cost(T, K, W, cost=WARM_COST):
+    b = _column_bounds(T, K, W, cost)
+    return max(b[1], (b[2] - b[1] + cost * W) if K > 1 else 0)
+
+
+def plan_step_items(T, wcol_steps, n_items, min_chunk=32):
+    """The work list of the chunked forward: every column (16 sequences) gets its OWN chunk count -- the smallest common
+    bound tau on a wave's steps (owned + the warm-up's cost) such that the columns' chunk counts add up to at most n_items
+    (bisection on tau; a column takes the fewest chunks that meet it).  wcol_steps: warm-up steps per column.
+    -> int32 [n_items, 4] = {column, chunk, t0, t1}."""
+    ncol = len(wcol_steps)
+    kmax = max(1, (T - 16) // min_chunk)
+    table = {}
+
+    def chunks_for(w, tau):
+        key = int(w)
+        if key not in table:
+            table[key] = [_column_cost(T, k, key) for k in range(1, kmax + 1)]
+        for k, c in enumerate(table[key], start=1):
+            if c <= tau:
+                return k
+        return None
+
+    def total(tau):
+        ks = [chunks_for(w, tau) for w in wcol_steps]
+        return None if any(k is None for k in ks) else ks
+
+    lo, hi = 16, T
+    best = total(hi)
+    while hi - lo > 4:
+        mid = (lo + hi) // 2
+        ks = total(mid)
+        if ks is not None and sum(ks) <= n_items:
+            hi, best = mid, ks
+        else:
+            lo = mid
+    # the waves left over go, one at a time, to the column that is slowest now: the plan always has n_items items (the
+    # launch grid of a captured step does not change when the plan does)
+    import heapq
+    heap = [(-table[int(w)][best[c] - 1], c) for c, w in enumerate(wcol_steps)]
+    heapq.heapify(heap)
+    left = int(n_items) - sum(best)
+    while left > 0 and heap:
+        _, c = heapq.heappop(heap)
+        if best[c] < kmax:
+            best[c] += 1
+            left -= 1
+            heapq.heappush(heap, (-table[int(wcol_steps[c])][best[c] - 1], c))
+    items = []
+    for c in range(ncol):
+        b = _column_bounds(T, best[c], wcol_steps[c])
+        items += [(c, k, b[k], b[k + 1]) for k in range(best[c])]
+    return _np.asarray(items, dtype=_np.int32).reshape(-1, 4)
+
+
+class MlpTrainStep:
+    """The resident training step of the MLP-root pot clipper (include/wdf_hip.h: wdf_clipper_mlp_step).
+
+        st = MlpTrainStep(x, r, target, w, hidden, n_layers, fs, C, skip=50, adam=binding.Adam(...))
+        for epoch in ...: st.step()          # w and the Adam moments are updated in place; st.loss3 = {mse, esr, loss}
+
+    x, r [B,T] (r None: static R), target [T,B]: the resident training set.  w: the flat weights (float32, device, updated
+    in place).  Everything a step reads or writes lives in buffers that do not move: capture-safe (HIP graph)."""
+
+    def __init__(self, x, r, target, w, hidden, n_layers, fs, C, R_static=None, skip=50, adam=None, n_global=None,
+                 eps_energy=None, activation="tanh", n_items=None, wgrad_chunks=None, tol=4.0e-6, sums_allreduce=None,
+                 grad_allreduce=None):
+        binding.require_gpu()
+        self.lib = binding.lib()
+        f32 = binding._f32_dev
+        self.x, self.r, self.target, self.w = f32(x, "x"), f32(r, "r"), f32(target, "target"), f32(w, "w")
+        self.B, self.T = (int(v) for v in x.shape)
+        B, T = self.B, self.T
+        if tuple(target.shape) != (T, B):
+            raise binding.WdfHipError(f"target: expected [{T}, {B}] (time-major), got {tuple(target.shape)}")
+        self.hidden, self.n_layers, self.fs = int(hidden), int(n_layers), float(fs)
+        self.act = {"tanh": 0, "relu": 1}[activation]
+        if self.w.numel() != self.lib.wdf_mlp_weight_count(self.hidden, self.n_layers):
+            raise binding.WdfHipError("weight count does not match the network")
+        dev = x.device
+        self.skip = int(skip)
+        self.n_global = float(n_global if n_global is not None else B * (T - self.skip))
+        self.eps_energy = float(_np.finfo(float).eps if eps_energy is None else eps_energy)
+        self.adam, self.sums_allreduce, self.grad_allreduce = adam, sums_allreduce, grad_allreduce
+        self.ncol = (B + 15) // 16
+        Rv = float(R_static) if R_static is not None else 45.0e3
+        self.theta2 = torch.tensor([Rv, float(C)], dtype=torch.float32, device=dev)
+        Rc = 1.0 / (2.0 * float(C) * self.fs)
+        if r is not None:
+            self.p, self.lr = torch.empty_like(self.r), torch.empty_like(self.r)
+            binding._check(self.lib.wdf_clipper_mlp_step_prepare(binding._ptr(self.r), binding._ptr(self.theta2), self.fs, B, T,
+                                                                 binding._ptr(self.p), binding._ptr(self.lr), binding._stream()),
+                           "wdf_clipper_mlp_step_prepare")
+            rmax = self.r.amax(dim=1)
+            pad = (-B) % 16
+            if pad:
+                rmax = torch.cat([rmax, rmax[-1:].expand(pad)])
+            rcol = rmax.reshape(-1, 16).amax(dim=1).double().cpu().numpy()
+        else:
+            self.p = self.lr = None
+            rcol = _np.full(self.ncol, Rv)
+        # the first guess of a column's warm-up: the RC network's diode-off memory |1 - 2p| at its largest pot value, down
+        # to ~1e-5 of the call-to-call change; the device controller takes it from there
+        rho = _np.clip(_np.abs(1.0 - 2.0 * Rc / (rcol + Rc)), 1e-6, 1.0 - 1e-9)
+        self.cold = int(-(-int(1.15 * _np.max(_np.ceil(_np.log(0.01 * tol) / _np.log(rho)))) // 16) * 16)
+        self.cold = min(self.cold, T)
+        self.w_max = max(2, min(self.cold // 16, 40))
+        w0 = _np.clip(_np.ceil(_np.log(1.0e-5) / _np.log(rho) / 16.0), 2, self.w_max).astype(_np.int32)
+        # one wave per SIMD (the forward is a dependent chain per wave; a second wave on a SIMD would just share its issue slots)
+        self.n_items_max = int(n_items) if n_items else max(self.ncol, min(engine.N_SIMD, self.ncol * (T // 64)))
+        self.wgrad_chunks = int(wgrad_chunks) if wgrad_chunks else max(1, min(2 * engine.N_SIMD // self.ncol, T // 64))
+        self.tol = float(tol)
+        self.y = torch.empty((T, B), dtype=torch.float32, device=dev)
+        self.zstash, self.kappa = torch.empty_like(self.y), torch.empty_like(self.y)
+        self.sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.gw = torch.zeros(self.w.numel(), dtype=torch.float32, device=dev)
+        self.loss3 = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.gcoef = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.state = None
+        self._install_plan(w0, reset=True)
+
+    # -- plan ---------------------------------------------------------------------------------------------------
+    def _geom(self):
+        return (self.hidden, self.n_layers, self.B, self.T, self.n_items, self.wgrad_chunks)
+
+    def _install_plan(self, wcol_units, reset):
+        items = plan_step_items(self.T, [16 * int(v) for v in wcol_units], self.n_items_max)
+        n_items = int(items.shape[0])
+        if self.state is None or n_items != getattr(self, "n_items", None):
+            if self.state is not None and not reset:
+                raise binding.WdfHipError("a re-plan must keep the number of work items")   # (unreachable: see replan)
+            self.n_items = n_items
+            nbytes = self.lib.wdf_clipper_mlp_step_state_bytes(*self._geom())
+            if nbytes == 0:
+                raise binding.WdfHipError(self.lib.wdf_last_error().decode())
+            self.state = torch.zeros((nbytes,), dtype=torch.uint8, device=self.x.device)
+        self.items = items
+        arr = _np.ascontiguousarray(items, dtype=_np.int32)
+        rc = self.lib.wdf_clipper_mlp_step_plan(binding._ptr(self.state), *self._geom(),
+                                                arr.ctypes.data_as(_C.POINTER(_C.c_int32)), 1 if reset else 0,
+                                                int(max(wcol_units)), self.cold // 16, 1, self.w_max, self.tol, binding._stream())
+        binding._check(rc, "wdf_clipper_mlp_step_plan")
+        if reset:
+            self.set_wcol(wcol_units)
+
+    def set_wcol(self, wcol_units):
+        arr = _np.ascontiguousarray(wcol_units, dtype=_np.int32)
+        binding._check(self.lib.wdf_clipper_mlp_step_set_wcol(binding._ptr(self.state), *self._geom(),
+                                                              arr.ctypes.data_as(_C.POINTER(_C.c_int32)), binding._stream()),
+                       "wdf_clipper_mlp_step_set_wcol")
+
+    def read(self):
+        """(controller dict, per-column warm-up units) -- synchronises."""
+        ctl = (_C.c_int32 * 32)()
+        wc = (_C.c_int32 * self.ncol)()
+        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), ctl, wc, None, binding._stream()),
+                       "wdf_clipper_mlp_step_read")
+        c = _np.frombuffer(ctl, dtype=_np.int32).copy()
+        last = c[16 + 4 * ((int(c[0]) - 1) & 1):][:4] if c[0] > 0 else c[16:20]
+        d = {"calls": int(c[0]), "have_snap": int(c[2]), "cold_steps": 16 * int(c[3]),
+             "n_bad": int(last[0]), "max_miss": float(last[1:2].view(_np.float32)[0]), "flagged_columns": int(last[2]),
+             "sequential_columns": int(last[3]), "total_flagged": int(c[24]), "total_sequential": int(c[25])}
+        return d, _np.frombuffer(wc, dtype=_np.int32).copy()
+
+    def placement(self):
+        """Where the dispatcher put the forward's waves in the last call: int array [n_items, 3] = (XCD, CU within the XCD
+        (shader engine, array, CU), SIMD).  Diagnostics."""
+        hw = (_C.c_int32 * (2 * self.n_items))()
+        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), None, None, hw, binding._stream()),
+                       "wdf_clipper_mlp_step_read")
+        a = _np.frombuffer(hw, dtype=_np.uint32).reshape(-1, 2)
+        hid, xcc = a[:, 0], a[:, 1] & 0xf
+        simd, cu = (hid >> 4) & 3, (hid >> 8) & 0xff           # cu_id [11:8], sh_id [12], se_id [15:13]
+        return _np.stack([xcc, cu, simd], axis=1).astype(_np.int64)
+
+    def replan(self):
+        """Re-distribute the chunks over the columns with the warm-ups the controller has settled on (host round trip;
+        the number of work items -- the captured grid -- stays)."""
+        _, wc = self.read()
+        items = plan_step_items(self.T, [16 * int(v) + 16 for v in wc], self.n_items_max)   # (one unit of head room)
+        if int(items.shape[0]) != self.n_items:
+            return False
+        self._install_plan(wc, reset=False)
+        return True
+
+    def freeze(self, on=True):
+        binding._check(self.lib.wdf_clipper_mlp_step_set(binding._ptr(self.state), 12, 1 if on else 0, binding._stream()),
+                       "wdf_clipper_mlp_step_set")
+
+    # -- the step -------------------------------------------------------------------------------------------------
+    def _call(self, phase, adam):
+        a = adam
+        rc = self.lib.wdf_clipper_mlp_step(
+            binding._ptr(self.x), binding._ptr(self.p), binding._ptr(self.lr), binding._ptr(self.theta2), binding._ptr(self.w),
+            self.hidden, self.n_layers, self.act, self.fs, binding._ptr(self.target), self.skip, self.n_global, self.eps_energy,
+            binding._ptr(self.y), binding._ptr(self.zstash), binding._ptr(self.kappa), binding._ptr(self.state), self.B, self.T,
+            self.n_items, self.wgrad_chunks, int(phase), binding._ptr(self.sums), binding._ptr(self.gw), binding._ptr(self.loss3),
+            binding._ptr(self.gcoef),
+            None if a is None else binding._ptr(a.m), None if a is None else binding._ptr(a.v),
+            None if a is None else binding._ptr(a.step), None if a is None else binding._ptr(a.lr),
+            0.0 if a is None else a.b1, 0.0 if a is None else a.b2, 0.0 if a is None else a.eps, binding._stream())
+        binding._check(rc, "wdf_clipper_mlp_step")
+
+    def step(self):
+        """One training step.  Single rank: five launches, Adam inside.  With all-reduce hooks (data-parallel ranks):
+        forward -> the rank's two loss sums -> all-reduce -> reverse sweep with the global sums -> all-reduce of the
+        gradient -> Adam."""
+        if self.sums_allreduce is None and self.grad_allreduce is None:
+            self._call(PHASE_FWD | PHASE_BWD, self.adam)
+            return self.loss3
+        self._call(PHASE_FWD | PHASE_SUMS, None)
+        if self.sums_allreduce is not None:
+            self.sums_allreduce(self.sums)
+        self._call(PHASE_BWD | PHASE_GLOBAL_SUMS, None)
+        if self.grad_allreduce is not None:
+            self.grad_allreduce(self.gw)
+        if self.adam is not None:
+            self.adam.apply(self.w, self.gw)
+        return self.loss3
+
+    def forward_only(self):
+        self._call(PHASE_FWD, None)
+
+    def backward_only(self):
+        self._call(PHASE_BWD, self.adam)

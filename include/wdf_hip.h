@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WDF_HIP_ABI_VERSION 2
+#define WDF_HIP_ABI_VERSION 3   /* 3: + wdf_clipper_mlp_step_* (round 4); TpCtl is 128 bytes, warm-up units are 16 steps */
 
 enum {
     WDF_OK = 0,
@@ -300,6 +300,51 @@ int64_t wdf_clipper_mlp_wgrad_ws_bytes(int hidden, int n_tanh_layers, int64_t S)
 int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb,
                           const float* theta2, const float* w, int hidden, int n_tanh_layers,
                           float fs, void* ws, float* gw, int64_t S, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * The RESIDENT training step of the MLP-root pot clipper (csrc/wdf_mlp_step.h): what one epoch of
+ * clipper_pot.py:245-269 does -- ClipperModel.forward (:103-127) over the whole training set, MSE + ESR past
+ * skip_samples with the (outs, target) swap (:141-177,248), tape.gradient to the DenseRootModel weights
+ * (layers.py:72-82), Adam (:180) -- as FIVE launches steered on the device (one HIP graph can replay it):
+ * forward in verified time chunks with per-column chunk counts and warm-ups, two gated repair launches (idle unless
+ * a chunk boundary missed), the exact reverse sweep with the adjoint recurrence run inside the weight-gradient
+ * kernel, and the fixed-order reduction + Adam.  The training set is resident: x [B][T], target [T][B], and the
+ * per-sample adaptor coefficients p, lr [B][T] of the pot channel (wdf_clipper_mlp_step_prepare: set_resistance +
+ * calc_impedance of every step, clipper_pot.py:116-117, hoisted out of the loop -- they do not depend on the weights).
+ * T must be a multiple of 16.  activation: 0 tanh, 1 relu (layers.py:63-65), hidden layers only.
+ *
+ *   state   caller-owned device buffer of wdf_clipper_mlp_step_state_bytes(): plan, per-column warm-up controller,
+ *           snapshots of every 16th state of the last two calls (a chunk starts from the previous call's state at
+ *           its sample), block maps of the adjoint recurrence, partial sums.
+ *   plan    HOST int32[n_items][4] = {column (16 sequences), chunk index in the column, t0, t1}: every column's
+ *           chunks tile [0, T) in multiples of 16; columns in order.  reset != 0: first use of the state.
+ *   phase   WDF_MLP_STEP_FWD | WDF_MLP_STEP_BWD with the Adam buffers: the whole step, single rank.  Multi-rank:
+ *           FWD | SUMS -> all-reduce sums[2] -> BWD | GLOBAL_SUMS without Adam -> all-reduce gw -> wdf_adam_step.
+ *   read    host copies of the controller block (int32[32]: call, parity, have_snap, cold16, w_min, w_max, slack,
+ *           cool_miss, cool_shrink, tol, grow_at, shrink_at, freeze, 3 pad, status[2][4] = {bad boundaries, max miss
+ *           bits, columns flagged, columns sequential} by call parity, total flagged, total sequential) and of the
+ *           per-column warm-ups (16-step units); hwid_out int32[n_items][2]: HW_ID and XCC_ID registers of the wave
+ *           that ran each forward item of the last call (where the dispatcher placed it).  Synchronises.   */
+enum {
+    WDF_MLP_STEP_FWD = 1, WDF_MLP_STEP_SUMS = 2, WDF_MLP_STEP_BWD = 4, WDF_MLP_STEP_GLOBAL_SUMS = 8
+};
+size_t wdf_clipper_mlp_step_state_bytes(int hidden, int n_layers, int64_t B, int64_t T, int n_items, int wgrad_chunks);
+int wdf_clipper_mlp_step_plan(void* state, int hidden, int n_layers, int64_t B, int64_t T, int n_items, int wgrad_chunks,
+                              const int32_t* items, int reset, int warm16, int cold16, int w_min, int w_max, float tol,
+                              void* stream);
+int wdf_clipper_mlp_step_read(const void* state, int hidden, int n_layers, int64_t B, int64_t T, int n_items,
+                              int wgrad_chunks, int32_t* ctl_out, int32_t* wcol_out, int32_t* hwid_out, void* stream);
+int wdf_clipper_mlp_step_set(void* state, int field, int32_t bits, void* stream);
+int wdf_clipper_mlp_step_set_wcol(void* state, int hidden, int n_layers, int64_t B, int64_t T, int n_items, int wgrad_chunks,
+                                  const int32_t* wcol, void* stream);
+int wdf_clipper_mlp_step_prepare(const float* r, const float* theta2, float fs, int64_t B, int64_t T, float* p, float* lr,
+                                 void* stream);
+int wdf_clipper_mlp_step(const float* x, const float* p, const float* lr, const float* theta2, float* w, int hidden,
+                         int n_layers, int activation, float fs, const float* target, int64_t skip, double n_global,
+                         double eps_energy, float* y, float* zstash, float* kappa, void* state, int64_t B, int64_t T,
+                         int n_items, int wgrad_chunks, int phase, double* sums, float* gw, float* loss3, float* gcoef,
+                         float* adam_m, float* adam_v, int32_t* adam_step, const float* adam_lr, float beta1, float beta2,
+                         float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Generic tree + one root, as a state-space recursion (csrc/wdf_statespace.h):
