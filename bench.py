@@ -374,8 +374,201 @@ class Trainer:
         return float(tmax), loss, grad
 
 
+def run_mlp_step(args, world, rank, local):
+    """--root mlp2x16 (and friends), the default form: the path clipper_pot.py actually trains -- the pot clipper with a
+    DenseRootModel root -- at the reference's training-set shape (BASELINE configs[3]: 1340 sequences x 2048 samples per
+    GPU, pot value per sample in the loader's layout, committed reference weights) through the RESIDENT training step
+    (csrc/wdf_mlp_step.h, wdf_clipper_mlp_step): forward in verified time chunks (per-column chunk counts and warm-ups,
+    steered on the device), MSE + ESR past 50 samples, exact reverse sweep to all weights, Adam(1e-4, beta_1 0.5) -- five
+    launches per step; N > 1: the two loss sums and the weight gradient are all-reduced in between.  One JSON line."""
+    from wdf_hip import mlp_root
+    dev = torch.device("cuda", local)
+    fs, T, B = workload.FS, 2048, (args.batch if args.batch != 8192 else 1340)
+    Bg = B * world
+    b0, b1 = wdist.shard_range(Bg, rank, world)
+    x_host = workload.sweep_batch(Bg, T, b0=b0, b1=b1, seed=4) * 0.6
+    r_host = workload.dataset_resistance_batch(Bg, T, b0=b0, b1=b1)
+    x, r = torch.as_tensor(x_host, device=dev), torch.as_tensor(r_host, device=dev)
+    net = args.root[3:] + "_pre" if args.root == "mlp2x16" else args.root[3:]
+    wh, hidden, n_layers = workload.reference_mlp_weights(net)
+    w = torch.tensor(wh, device=dev)
+    th4 = torch.tensor(workload.clipper_theta(), dtype=torch.float32, device=dev)
+    target, _, _ = binding.clipper_fwd(x, th4, fs, r=r, want_stash=False)        # "measurement": the analytic diode pair
+    skip, eps = 50, float(np.finfo(float).eps)
+    n_global = float(Bg * (T - skip))
+    adam = binding.Adam(w.numel(), lr=1.0e-4, beta_1=0.5, device=dev)
+    dist_on = world > 1 or args.force_dist
+    st = mlp_root.MlpTrainStep(x, r, target, w, hidden, n_layers, fs, workload.C_CLIPPER, skip=skip, adam=adam,
+                               n_global=n_global, eps_energy=eps,
+                               sums_allreduce=wdist.allreduce_sum_ if dist_on else None,
+                               grad_allreduce=wdist.allreduce_sum_ if dist_on else None)
+    # untimed: the cold call, the controller settling, one re-plan of the chunk counts from the warm-ups it settled on
+    replan_at = min(40, max(1, args.warmup // 2))
+    for i in range(args.warmup):
+        st.step()
+        if i + 1 == replan_at:
+            st.replan()
+    graph = None
+    if args.graph:
+        torch.cuda.synchronize()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    st.step()
+            torch.cuda.current_stream().wait_stream(side)
+        except Exception as exc:
+            print(f"bench: HIP-graph capture of the step failed ({type(exc).__name__}: {exc}); eager launches instead",
+                  file=sys.stderr, flush=True)
+            graph, args.graph = None, False
+            torch.cuda.synchronize()
+    info0, _ = st.read()
+    wdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if graph is not None:
+        for _ in range(args.steps):
+            graph.replay()
+    else:
+        for _ in range(args.steps):
+            st.step()
+    torch.cuda.synchronize(); wdist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax)
+    info1, wcol = st.read()
+    loss_last = [float(v) for v in st.loss3]
+    # kernel times: the same step launched in its two phases, events around the chunked forward and the reverse sweep
+    ev = [binding.Event() for _ in range(4)]
+    t_fk, t_wk = [], []
+    if not dist_on:
+        for _ in range(min(args.steps, 16)):
+            binding.Event.bracket_next(ev[0], ev[1])
+            st.forward_only()
+            binding.Event.bracket_next(ev[2], ev[3])
+            st.backward_only()
+            torch.cuda.synchronize()
+            t_fk.append(ev[0].elapsed_ms(ev[1])); t_wk.append(ev[2].elapsed_ms(ev[3]))
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity:
+        parity = mlp_step_parity(st, x_host, r_host, target, net, fs, skip, eps)
+    if rank == 0:
+        items = st.items
+        w_steps = 16 * wcol[items[:, 0]].astype(np.int64)
+        run = np.where(items[:, 1] > 0, np.minimum(w_steps, items[:, 2]), 0) + (items[:, 3] - items[:, 2])
+        fk_ms = float(np.mean(t_fk)) if t_fk else None
+        wk_ms = float(np.mean(t_wk)) if t_wk else None
+        # the reverse sweep on the matrix cores: per wave (16 sequences) and step 4 (NL - 1) + 1 forward MFMAs, 4 (NL - 1) for
+        # the delta chain and 4 (NL - 1) outer products (v_mfma_f32_16x16x4_f32, 2048 flop each)
+        n_mfma = 12 * (n_layers - 1) + 1
+        flops = (B + 15) // 16 * T * n_mfma * 2048
+        out = {"metric": f"samples/sec fwd+bwd, MLP-root ({args.root[3:]}) pot clipper, clipper_pot.py training-set shape",
+               "value": Bg * T / (dt / args.steps), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"pot clipper with DenseRootModel {args.root[3:]} root (reference weights), MSE+ESR past 50 "
+                                      f"samples, Adam(1e-4, beta_1 0.5), {B} sequences x {T} samples per GPU, pot value per sample "
+                                      f"(BASELINE configs[3] shape)",
+                          "global_batch": Bg, "seq_len": T, "parallelism": f"dp{world}", "loss": loss_last[2],
+                          "collective": None if not dist_on else "all-reduce of the two loss sums, then of the weight gradient",
+                          "step": "resident training step (wdf_clipper_mlp_step): five launches, steered on the device",
+                          "time_parallel": {"forward_items": int(st.n_items), "reverse_chunks": int(st.wgrad_chunks),
+                                            "chunks_per_column": {"min": int(np.bincount(items[:, 0]).min()), "max": int(np.bincount(items[:, 0]).max())},
+                                            "warmup_steps_per_column": {"min": int(16 * wcol.min()), "mean": float(16 * wcol.mean()), "max": int(16 * wcol.max())},
+                                            "forward_steps_per_wave": {"mean": float(run.mean()), "max": int(run.max()), "owned_mean": float(T * st.ncol / st.n_items)},
+                                            "verify_tol": st.tol,
+                                            "verdict_last_call": {k: info1[k] for k in ("n_bad", "max_miss", "flagged_columns", "sequential_columns")},
+                                            "in_timed_region": {"boundaries_repaired": info1["total_flagged"] - info0["total_flagged"],
+                                                                "columns_sequential": info1["total_sequential"] - info0["total_sequential"]}}},
+               "step_launch": "one HIP-graph replay per step" if graph is not None else "eager launches",
+               "kernel_ms": None if fk_ms is None else {"forward_chunks": spread(t_fk), "reverse_sweep": spread(t_wk)},
+               "parity": parity,
+               "roofline": None if wk_ms is None else
+               {"bound": "mfma", "kernel": "mlp_step_wgrad_kernel", "achieved": flops / (wk_ms * 1e-3) / 1e12,
+                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (wk_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                "traffic": None, "mfma_per_wave_step": n_mfma,
+                "forward": {"kernel": "mlp_step_fwd_kernel", "ms": fk_ms,
+                            "useful_fraction_of_steps": float(T * st.ncol / run.sum()),
+                            "note": "one wave per SIMD, every wave a dependent chain of steps (18 MFMAs + ~150 VALU + 24 transcendentals "
+                                    "per owned step, 9 MFMAs per warm-up step): bound by issue, not by a throughput roof"},
+                "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32, 2048 flop, 32 cycles per SIMD): issued MFMA flops of the reverse "
+                        "sweep / its kernel time / the fp32 matrix peak"}}
+        print(json.dumps(out), flush=True)
+    if world > 1 or args.force_dist:
+        wdist.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def mlp_step_parity(st, x_host, r_host, target, net, fs, skip, eps):
+    """After the timed region, at the weights training has reached, no update: (1) one more step of the BENCH PATH ITSELF
+    (same state, same plan): y of every sequence and the loss against the fp64 oracle (tree interpreter, MLP root:
+    clipper_pot.py:94-127,141-177); its whole-batch gradient against the sequential row sweep (another kernel family: no
+    chunks, no matrix cores) fed with dLoss/dy of that loss; (2) the same kernels on 8 picked sequences as a batch of their
+    own: the gradient of THEIR MSE + ESR loss against the oracle's complex-step derivative, per component."""
+    from wdf_hip import mlp_root
+    O = _oracle()
+    t0 = time.perf_counter()
+    B, T = st.B, st.T
+    adam, st.adam = st.adam, None
+    hooks = (st.sums_allreduce, st.grad_allreduce)
+    st.sums_allreduce = st.grad_allreduce = None
+    st.step()
+    torch.cuda.synchronize()
+    st.adam, (st.sums_allreduce, st.grad_allreduce) = adam, hooks
+    hidden, n_layers = st.hidden, st.n_layers
+    wd = st.w.detach().clone()
+    sizes, acts = [2] + [hidden] * n_layers + [1], [O.ACT_TANH] * n_layers + [O.ACT_NONE]
+    oc = O.clipper_mlp_circuit(fs, sizes, acts)
+    theta = np.concatenate([[45.0e3, float(np.float32(workload.C_CLIPPER))], wd.cpu().numpy().astype(np.float64)])
+    y_ref = O.tree_fwd(oc, theta, np.stack([x_host.astype(np.float64), r_host.astype(np.float64)], axis=-1))
+    tgt = target.cpu().numpy().astype(np.float64)
+
+    def loss_of(yr, tr):
+        o, t = yr[skip:], tr[skip:]
+        n = float(o.size)
+        S, E = float(np.sum((o - t) ** 2)), float(np.sum(o ** 2)) + eps
+        esr = float(np.sqrt(S / E / n))
+        gy = np.zeros_like(yr)
+        gy[skip:] = (2.0 / n + 1.0 / (esr * E * n)) * (o - t) - esr / E * o
+        return S / n + esr, gy
+
+    loss_ref, gy_ref = loss_of(y_ref, tgt)
+    yh = st.y.cpu().numpy()
+    th2 = torch.tensor([45.0e3, workload.C_CLIPPER], dtype=torch.float32, device=st.x.device)
+    gy_own = torch.as_tensor(loss_of(yh.astype(np.float64), tgt)[1].astype(np.float32), device=st.x.device)
+    _, gw_seq = binding.clipper_mlp_bwd_w(st.x, th2, wd, hidden, n_layers, fs, st.zstash, gy_own, r=st.r)
+    # (2) the picked sequences as their own training set
+    pick = np.unique(np.linspace(0, B - 1, 8).astype(np.int64))
+    pk = torch.as_tensor(pick, device=st.x.device)
+    st8 = mlp_root.MlpTrainStep(st.x[pk].contiguous(), st.r[pk].contiguous(), target[:, pk].contiguous(), wd, hidden, n_layers, fs,
+                                workload.C_CLIPPER, skip=skip, adam=None, eps_energy=eps, n_items=16, wgrad_chunks=16)
+    st8.step()
+    st8.step()                                                   # (the second call starts its chunks from snapshots)
+    torch.cuda.synchronize()
+    xin = np.stack([x_host[pick].astype(np.float64), r_host[pick].astype(np.float64)], axis=-1)
+    loss8, gy8 = loss_of(y_ref[:, pick], tgt[:, pick])
+    comp = mlp_components(hidden, n_layers, 8)
+    g_ref = O.tree_grad(oc, theta, xin, gy8, params=list(2 + comp))
+    got = st8.gw.cpu().numpy().astype(np.float64)[comp]
+    return {"max_abs_y": float(np.max(np.abs(yh - y_ref))),
+            "rel_loss": abs(float(st.loss3[2]) - loss_ref) / loss_ref,
+            "max_grad_err_vs_oracle": float(np.max(np.abs(got - g_ref) / (np.abs(g_ref) + 0.1 * np.max(np.abs(g_ref))))),
+            "rel_loss_picked": abs(float(st8.loss3[2]) - loss8) / loss8,
+            "max_grad_err_vs_sequential_sweep": float((st.gw - gw_seq).abs().max() / gw_seq.abs().max()),
+            "checked": f"y of all {B} x {T} samples and the MSE+ESR loss of the bench path's own step vs the fp64 oracle (tree "
+                       f"interpreter, MLP root); its whole-batch gradient, all {wd.numel()} components, vs the sequential row sweep "
+                       f"(error relative to the largest component); the same kernels on sequences {pick.tolist()} as a batch of "
+                       f"their own: d(their MSE+ESR loss)/dw vs the oracle's complex-step derivative on {len(comp)} components "
+                       f"(all biases, first and last layer, every 8th hidden-kernel entry; error relative to |component| + 0.1 "
+                       f"max|component|) ({time.perf_counter() - t0:.1f} s)"}
+
+
 def run_mlp_root(args, world, rank, local):
-    """--root mlp2x16 (and friends): the path clipper_pot.py actually trains -- the pot clipper with a
+    """--mlp-path unfused: the round-2/3 pipeline (~20 launches steered from the host), kept for A/B.
+    --root mlp2x16 (and friends): the path clipper_pot.py actually trains -- the pot clipper with a
     DenseRootModel root -- at the reference's training-set shape (BASELINE configs[3]: 1340 sequences x 2048
     samples per GPU, pot value per sample in the loader's layout, committed reference weights): forward
     (time-parallel, verified), MSE + ESR past 50 samples, exact step-parallel reverse sweep to all weights,
@@ -533,7 +726,8 @@ def main():
     ap.add_argument("--no-cold", action="store_true", help="skip the third measurement: the stateless step (value_cold)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="capture one training step (kernels, all-reduce, update) as a HIP graph and replay it in the timed loop. "
-                         "auto: on when the step contains a collective (N > 1 or --force-dist), off for the single-rank step")
+                         "auto: on when the step contains a collective (N > 1 or --force-dist) and for the five-launch MLP-root step, "
+                         "off for the single-rank one-launch diode step")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="skip the on-device Adam update of {Is, nVt, R, C} that closes every step")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -559,11 +753,14 @@ def main():
     ap.add_argument("--root", default="diode", choices=["diode", "mlp2x16", "mlp2x8", "mlp4x8"],
                     help="diode: the metric's analytic diode-pair root (default).  mlp*: a secondary line -- the pot clipper "
                          "with the reference's DenseRootModel root at the training-set shape 1340 x 2048 (--batch to change)")
+    ap.add_argument("--mlp-path", default="step", choices=["step", "unfused"],
+                    help="--root mlp*: step = the resident training step (five launches, default); unfused = the round-3 pipeline")
     ap.add_argument("--x-batch-major", action="store_true",
                     help="make the [B,T] layout (the reference scripts') the HEADLINE measurement instead of the engine's "
                          "resident time-major copy")
     args = ap.parse_args()
-    args.graph = (args.graph == "on") or (args.graph == "auto" and (args.gpus > 1 or args.force_dist) and not args.rehearse_on_one_gpu)
+    args.graph = (args.graph == "on") or (args.graph == "auto" and not args.rehearse_on_one_gpu and
+                                          (args.gpus > 1 or args.force_dist or (args.root != "diode" and args.mlp_path == "step")))
     args.steps = 200 if args.steps is None else args.steps
     args.warmup = 20 if args.warmup is None else args.warmup
 
@@ -579,7 +776,7 @@ def main():
         raise SystemExit("--force-dist is for world size 1")
     binding.require_gpu()
     if args.root != "diode":
-        return run_mlp_root(args, world, rank, local)
+        return (run_mlp_root if args.mlp_path == "unfused" else run_mlp_step)(args, world, rank, local)
     dev = torch.device("cuda", local)
     fs, T = workload.FS, args.seq_len
     Bg = args.batch * world if args.scaling == "weak" else args.batch

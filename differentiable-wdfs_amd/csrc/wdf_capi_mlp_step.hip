@@ -10,7 +10,7 @@ using namespace wdfcapi;
 namespace {
 
 struct StepLayout {
-    size_t ctl, items, cols, wcol, cool, ticket, ticket2, nflag, colseq, flag, hwid, zwarm, zend, zend2, zpre, losspart, colsum,
+    size_t ctl, items, cols, wcol, cool, ticket, ticket2, nflag, colseq, flag, hwid, colmiss, zwarm, zend, zpre, lossblk, colsum,
         maps, snap, wsw, total;
     int n_cols, kw;
     int64_t lw;
@@ -40,10 +40,10 @@ StepLayout step_layout(int hidden, int n_layers, int64_t B, int64_t T, int n_ite
     L.items = take(ni * sizeof(wdf::MlpStepItem));
     L.cols = take(nc * sizeof(wdf::MlpStepCol));
     L.wcol = take(nc * 4); L.cool = take(nc * 4); L.ticket = take(nc * 4); L.ticket2 = take(nc * 4);
-    L.nflag = take(nc * 4); L.colseq = take(nc * 4); L.flag = take(ni * 4); L.hwid = take(ni * 8);
-    L.zwarm = take(ni * 16 * 4); L.zend = take(ni * 16 * 4); L.zend2 = take(ni * 16 * 4);
+    L.nflag = take(nc * 4); L.colseq = take(nc * 4); L.flag = take(ni * 4); L.hwid = take(ni * 8); L.colmiss = take(nc * 16);
+    L.zwarm = take(ni * 16 * 4); L.zend = take(ni * 16 * 4);
     L.zpre = take(ni * wdf::kStepPre * 16 * 4);
-    L.losspart = take(ni * 2 * 8); L.colsum = take(nc * 2 * 8);
+    L.lossblk = take(nb * nc * 2 * 4); L.colsum = take(nc * 2 * 8);
     L.maps = take(nb * 3 * (size_t)B * 4);
     L.snap = take(2 * nb * (size_t)B * 4);
     L.wsw = take(nc * (size_t)L.kw * (size_t)step_weight_count(hidden, n_layers) * 4);
@@ -126,10 +126,12 @@ int wdf_clipper_mlp_step_plan(void* state, int hidden, int n_layers, int64_t B, 
 }
 
 // Host copies of the controller: ctl_out int32[32] (MlpStepCtl), wcol_out int32[ceil(B/16)], hwid_out int32[n_items][2]
-// (HW_ID and XCC_ID of the wave that ran each forward item in the last call: placement diagnostics); any may be NULL.
+// (HW_ID and XCC_ID of the wave that ran each forward item in the last call: placement diagnostics), colmiss_out
+// float[ceil(B/16)][4] (per column: the last verification's arrival miss and the misses 16, 32, 48 steps before arrival);
+// any may be NULL.
 // Synchronises the stream.
 int wdf_clipper_mlp_step_read(const void* state, int hidden, int n_layers, int64_t B, int64_t T, int n_items, int wgrad_chunks,
-                              int32_t* ctl_out, int32_t* wcol_out, int32_t* hwid_out, void* stream)
+                              int32_t* ctl_out, int32_t* wcol_out, int32_t* hwid_out, float* colmiss_out, void* stream)
 {
     int rc = step_check_shape(hidden, n_layers, 0, B, T, n_items, wgrad_chunks);
     if (rc) return rc;
@@ -140,6 +142,7 @@ int wdf_clipper_mlp_step_read(const void* state, int hidden, int n_layers, int64
     if (ctl_out) e = hipMemcpyAsync(ctl_out, (const char*)state + L.ctl, sizeof(wdf::MlpStepCtl), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && wcol_out) e = hipMemcpyAsync(wcol_out, (const char*)state + L.wcol, (size_t)L.n_cols * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && hwid_out) e = hipMemcpyAsync(hwid_out, (const char*)state + L.hwid, (size_t)n_items * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && colmiss_out) e = hipMemcpyAsync(colmiss_out, (const char*)state + L.colmiss, (size_t)L.n_cols * 16, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(WDF_ELAUNCH, "wdf_clipper_mlp_step_read: %s", hipGetErrorString(e));
     return WDF_OK;
@@ -239,13 +242,13 @@ int wdf_clipper_mlp_step(const float* x, const float* p, const float* lr, const 
     A.x = x; A.p = p; A.lr = lr; A.theta2 = theta2; A.w = w; A.target = target;
     A.y = y; A.zstash = zstash; A.kappa = kappa;
     A.maps = (float*)(base + L.maps); A.snap = (float*)(base + L.snap);
-    A.zwarm = (float*)(base + L.zwarm); A.zend = (float*)(base + L.zend); A.zend2 = (float*)(base + L.zend2);
+    A.zwarm = (float*)(base + L.zwarm); A.zend = (float*)(base + L.zend);
     A.zpre = (float*)(base + L.zpre);
-    A.losspart = (double*)(base + L.losspart); A.colsum = (double*)(base + L.colsum);
+    A.lossblk = (float*)(base + L.lossblk); A.colsum = (double*)(base + L.colsum);
     A.items = (const wdf::MlpStepItem*)(base + L.items); A.cols = (const wdf::MlpStepCol*)(base + L.cols);
     A.wcol = (int*)(base + L.wcol); A.cool = (int*)(base + L.cool);
     A.ticket = (unsigned*)(base + L.ticket); A.ticket2 = (unsigned*)(base + L.ticket2);
-    A.hwid = (unsigned*)(base + L.hwid);
+    A.hwid = (unsigned*)(base + L.hwid); A.colmiss = (float*)(base + L.colmiss);
     A.flag = (unsigned*)(base + L.flag); A.nflag = (unsigned*)(base + L.nflag); A.colseq = (unsigned*)(base + L.colseq);
     A.ctl = (wdf::MlpStepCtl*)(base + L.ctl);
     A.B = B; A.T = T; A.skip = skip; A.H = hidden; A.n_items = n_items; A.n_cols = L.n_cols; A.fs = fs;

@@ -80,9 +80,8 @@ struct MlpStepArgs {
     float* snap;           // [2][T/16][B]
     float* zwarm;          // [items][16]   state at t0
     float* zend;           // [items][16]   state at t1
-    float* zend2;          // [items][16]   ... of the re-run (MODE 1)
     float* zpre;           // [items][kStepPre][16]
-    double* losspart;      // [items][2]
+    float* lossblk;        // [T/16][cols][2]  the two loss sums of every 16-step block of a column
     double* colsum;        // [cols][2]
     const MlpStepItem* items;
     const MlpStepCol* cols;
@@ -93,6 +92,7 @@ struct MlpStepArgs {
     unsigned* flag;        // [items]  boundary missed -> MODE 1 re-runs the item
     unsigned* nflag;       // [cols]   flagged items of the column
     unsigned* colseq;      // [cols]   MODE 2 re-runs the column
+    float* colmiss;        // [cols][4] the last verification's arrival miss and the misses 1, 2, 3 units before arrival
     unsigned* hwid;        // [items][2] where the item's wave ran (HW_ID, XCC_ID): placement diagnostics
     MlpStepCtl* ctl;
     int64_t B, T, skip;
@@ -100,10 +100,28 @@ struct MlpStepArgs {
     float fs;
 };
 
-template <int ACT> __device__ __forceinline__ float step_act(float x)
+// WDF_DBG_STEP (tools/mlp_step_cost.sh; never defined in the product build): kernels with one ingredient removed, to price it
+#ifndef WDF_DBG_STEP
+#define WDF_DBG_STEP 0
+#endif
+
+// tanh costs a third of the forward and a quarter of the reverse sweep (tools/mlp_step_cost.sh).  wdf_mlp.h's tanh_fast is
+//     t = exp2(-2 log2(e) |x|) ;  tanh(x) = copysign((1 - t) rcp(1 + t), x)
+// -- relative accuracy near 0 (1 - t is exact there), which the chunk verification's 4e-6 needs: the cheaper
+// 2 rcp(1 + exp2(s)) - 1 carries an ABSOLUTE error of ~2 ulp of 1 in every small activation, and the warm-ups the
+// controller settles on grow by a third with it (measured).  What can go is the multiplication: the factor 2 log2(e) is
+// folded into the layer's weights and bias when they are loaded, the MFMA chain delivers s = 2 log2(e) x.
+constexpr float kTanhScale = 2.0f * kLog2e;
+
+// act(pre-activation as the MFMA chain delivers it: scaled by kTanhScale for tanh)
+template <int ACT> __device__ __forceinline__ float step_act(float s)
 {
-    if constexpr (ACT == 1) return fmaxf(x, 0.0f);               // relu (layers.py:63-65)
-    else return tanh_fast(x);
+    if constexpr (WDF_DBG_STEP & 1) return s * 0.5f;             // (pricing tanh)
+    if constexpr (ACT == 1) return fmaxf(s, 0.0f);               // relu (layers.py:63-65)
+    else {
+        const float t = __builtin_amdgcn_exp2f(-fabsf(s));        // exp(-2 |x|) in (0, 1]
+        return copysignf((1.0f - t) * fast_rcp(1.0f + t), s);
+    }
 }
 // derivative of the activation from its OUTPUT h
 template <int ACT> __device__ __forceinline__ float step_dact(float h)
@@ -112,27 +130,71 @@ template <int ACT> __device__ __forceinline__ float step_dact(float h)
     else return fmaf(-h, h, 1.0f);
 }
 
+// The weights a lane holds (layout: wdf_mlp_mfma.h).  Forward copies carry the activation's scale; the copies the
+// derivative chains use do not.  Biases and the output bias sit in 4-register tuples: they ARE the C operand of a
+// layer's first MFMA.
+template <int NL>
+struct StepWeights {
+    float k0a[4], k0l[4], b0[4];   // layer 0 (scaled), unit 4 g + v
+    float k0a_u[4];                // ... unscaled (d out / d a)
+    float a[NL - 1][4];            // slice v of layer l (scaled):  A[i][k] = K_l[in 4 k + v][out i]
+    float at[NL - 1][4];           // transposed, unscaled:         A[i][k] = K_l[in i][out 4 k + v]
+    mfma_v4f bias[NL - 1];         // (scaled)
+    float wo[4];
+    mfma_v4f bo;
+};
+
 template <int NL, int ACT>
-__device__ __forceinline__ float step_mlp_fwd(const MfmaWeights<NL>& W, float a, float lr, mfma_v4f (&act)[NL])
+__device__ __forceinline__ StepWeights<NL> step_load_weights(const float* __restrict__ w, int H, int lane)
+{
+    StepWeights<NL> W;
+    const float S = (ACT == 0) ? kTanhScale : 1.0f;
+    const int i = lane & 15, k = lane >> 4;
+    const int kWo = 3 * H + (NL - 1) * (H * H + H);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int u = 4 * k + v;
+        const bool live = u < H;
+        W.k0a_u[v] = live ? w[u] : 0.0f;
+        W.k0a[v] = S * W.k0a_u[v];
+        W.k0l[v] = live ? S * w[H + u] : 0.0f;
+        W.b0[v] = live ? S * w[2 * H + u] : 0.0f;
+        W.wo[v] = live ? w[kWo + u] : 0.0f;
+#pragma unroll
+        for (int l = 1; l < NL; ++l) {
+            const float* __restrict__ kern = w + 3 * H + (l - 1) * (H * H + H);
+            const bool ok = live && i < H;
+            W.a[l - 1][v] = ok ? S * kern[u * H + i] : 0.0f;
+            W.at[l - 1][v] = ok ? kern[i * H + u] : 0.0f;
+            W.bias[l - 1][v] = live ? S * kern[H * H + u] : 0.0f;
+        }
+    }
+    const float bo = w[kWo + H];
+    W.bo = mfma_v4f{bo, bo, bo, bo};
+    return W;
+}
+
+template <int NL, int ACT>
+__device__ __forceinline__ float step_mlp_fwd(const StepWeights<NL>& W, float a, float lr, mfma_v4f (&act)[NL])
 {
 #pragma unroll
     for (int v = 0; v < 4; ++v) act[0][v] = step_act<ACT>(fmaf(lr, W.k0l[v], fmaf(a, W.k0a[v], W.b0[v])));
 #pragma unroll
     for (int l = 1; l < NL; ++l) {
-        mfma_v4f acc = {W.bias[l - 1][0], W.bias[l - 1][1], W.bias[l - 1][2], W.bias[l - 1][3]};
+        mfma_v4f acc = mfma4(W.a[l - 1][0], act[l - 1][0], W.bias[l - 1]);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc = mfma4(W.a[l - 1][v], act[l - 1][v], acc);
+        for (int v = 1; v < 4; ++v) acc = mfma4(W.a[l - 1][v], act[l - 1][v], acc);
 #pragma unroll
         for (int v = 0; v < 4; ++v) act[l][v] = step_act<ACT>(acc[v]);
     }
     const float part = fmaf(W.wo[3], act[NL - 1][3],
                             fmaf(W.wo[2], act[NL - 1][2], fmaf(W.wo[1], act[NL - 1][1], W.wo[0] * act[NL - 1][0])));
-    const mfma_v4f s = mfma4(1.0f, part, mfma_v4f{W.bo, W.bo, W.bo, W.bo});     // sum over the four lane groups
+    const mfma_v4f s = mfma4(1.0f, part, W.bo);                  // sum over the four lane groups
     return s[0];
 }
 
 template <int NL, int ACT>
-__device__ __forceinline__ float step_mlp_grad_a(const MfmaWeights<NL>& W, const mfma_v4f (&act)[NL])
+__device__ __forceinline__ float step_mlp_grad_a(const StepWeights<NL>& W, const mfma_v4f (&act)[NL])
 {
     mfma_v4f d;
 #pragma unroll
@@ -145,7 +207,7 @@ __device__ __forceinline__ float step_mlp_grad_a(const MfmaWeights<NL>& W, const
 #pragma unroll
         for (int v = 0; v < 4; ++v) d[v] = acc[v] * step_dact<ACT>(act[l - 1][v]);
     }
-    const float part = fmaf(W.k0a[3], d[3], fmaf(W.k0a[2], d[2], fmaf(W.k0a[1], d[1], W.k0a[0] * d[0])));
+    const float part = fmaf(W.k0a_u[3], d[3], fmaf(W.k0a_u[2], d[2], fmaf(W.k0a_u[1], d[1], W.k0a_u[0] * d[0])));
     const mfma_v4f s = mfma4(1.0f, part, mfma_v4f{0.0f, 0.0f, 0.0f, 0.0f});
     return s[0];
 }
@@ -163,6 +225,18 @@ __device__ __forceinline__ void step_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// sum over the wave's 64 lanes, fixed order, result in every lane (DPP inside the rows, v_readlane across them)
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    auto mv = [](float x, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false)); };
+    v += mv(v, std::integral_constant<int, 0xB1>{});
+    v += mv(v, std::integral_constant<int, 0x4E>{});
+    v += mv(v, std::integral_constant<int, 0x141>{});
+    v += mv(v, std::integral_constant<int, 0x140>{});
+    auto rl = [](float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); };
+    return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
+}
+
 // sum over the four lane groups (lanes n, 16 + n, 32 + n, 48 + n), to every lane
 __device__ __forceinline__ float groups_sum(float v)
 {
@@ -171,12 +245,97 @@ __device__ __forceinline__ float groups_sum(float v)
     return v;
 }
 
+// Per-wave running values of a span
+struct StepSpan {
+    float z;
+};
+
+// One block of 16 steps.  OWNED: outputs, kappa, loss sums, the block's adjoint map; otherwise a warm-up block: state only.
+// Straight-line code (the whole block is one basic block): the scheduler places step i's kappa chain beside step i + 1's
+// forward chain -- they are independent.
+template <int NL, bool DYN_R, int ACT, bool OWNED>
+__device__ __forceinline__ void mlp_step_block(const MlpStepArgs& A, const StepWeights<NL>& Wt, const MlpClipConsts& c, int64_t tb,
+                                               int col, int64_t b, bool live, int g, const float* __restrict__ xp,
+                                               const float* __restrict__ pp, const float* __restrict__ lp, StepSpan& sp)
+{
+    const int64_t B = A.B;
+    float xs[16], ps[16], ls[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 xv = *reinterpret_cast<const float4*>(xp + tb + 4 * q);
+        xs[4 * q] = xv.x; xs[4 * q + 1] = xv.y; xs[4 * q + 2] = xv.z; xs[4 * q + 3] = xv.w;
+        if constexpr (DYN_R) {
+            const float4 pv = *reinterpret_cast<const float4*>(pp + tb + 4 * q);
+            const float4 lv = *reinterpret_cast<const float4*>(lp + tb + 4 * q);
+            ps[4 * q] = pv.x; ps[4 * q + 1] = pv.y; ps[4 * q + 2] = pv.z; ps[4 * q + 3] = pv.w;
+            ls[4 * q] = lv.x; ls[4 * q + 1] = lv.y; ls[4 * q + 2] = lv.z; ls[4 * q + 3] = lv.w;
+        }
+    }
+    float tt[4] = {0.0f, 0.0f, 0.0f, 0.0f};                     // group g looks after the steps i = g (mod 4)
+    if constexpr (OWNED) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tt[q] = A.target[(tb + 4 * q + g) * B + b];
+    }
+    float z = sp.z;
+    float yk = 0.0f, zk = 0.0f, kk = 0.0f;
+    float Am = 1.0f, C1 = 0.0f, C2 = 0.0f, sS = 0.0f, sE = 0.0f;
+    mfma_v4f act[NL];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float p = DYN_R ? ps[i] : c.p, lr = DYN_R ? ls[i] : c.lr;
+        const float b_diff = z - xs[i];
+        const float b_temp = -p * b_diff;
+        const float a = z + b_temp;
+        const float zn = b_temp - step_mlp_fwd<NL, ACT>(Wt, a, lr, act);     // b_root = -MLP (clipper_pot.py:121)
+        if constexpr (OWNED) {
+            const float Da = (WDF_DBG_STEP & 16) ? act[NL - 1][0] : -step_mlp_grad_a<NL, ACT>(Wt, act);   // (16: pricing the kappa chain)
+            const float kap = Da - p * (1.0f + Da);
+            const float yv = 0.5f * (zn + z);
+            if ((i & 3) == g) {
+                yk = yv; zk = z; kk = kap;
+                const float msk = (tb + i >= A.skip) ? 1.0f : 0.0f;
+                const float d = yv - tt[i >> 2];
+                const float wv = msk * 0.5f * Am * (kap + 1.0f);
+                sS = fmaf(msk * d, d, sS);
+                sE = fmaf(msk * yv, yv, sE);
+                C1 = fmaf(wv, d, C1);
+                C2 = fmaf(wv, yv, C2);
+            }
+            Am *= kap;
+            if ((i & 3) == 3 && live) {
+                const int64_t o = (tb + (i - 3 + g)) * B + b;
+                A.y[o] = yk;
+                A.zstash[o] = zk;
+                A.kappa[o] = kk;
+            }
+        }
+        z = zn;
+    }
+    sp.z = z;
+    if constexpr (OWNED) {
+        C1 = groups_sum(C1);
+        C2 = groups_sum(C2);
+        if (g == 0 && live) {
+            float* __restrict__ m = A.maps + (tb >> 4) * 3 * B + b;
+            m[0] = Am; m[B] = C1; m[2 * B] = C2;
+        }
+        // the block's two loss sums (every lane holds its own steps of its own sequence); published: the column's last
+        // finisher of this launch adds the blocks up
+        const float bS = wave_sum_f32(live ? sS : 0.0f), bE = wave_sum_f32(live ? sE : 0.0f);
+        if ((threadIdx.x & 63) == 0) {
+            float* __restrict__ lb = A.lossblk + ((tb >> 4) * A.n_cols + col) * 2;
+            step_publish(lb, bS);
+            step_publish(lb + 1, bE);
+        }
+    }
+}
+
 // One span of one column: steps [tw, t0) warm up, [t0, t1) are owned (outputs written).  Returns the end state.
 // snap_w: the snapshot set this call writes.  PUBLISH: boundary data for a verifier in the same launch.
 template <int NL, bool DYN_R, int ACT, bool PUBLISH>
-__device__ __forceinline__ float mlp_step_span(const MlpStepArgs& A, const MfmaWeights<NL>& Wt, const MlpClipConsts& c,
+__device__ __forceinline__ float mlp_step_span(const MlpStepArgs& A, const StepWeights<NL>& Wt, const MlpClipConsts& c,
                                                int item, int col, int64_t tw, int64_t t0, int64_t t1, float z,
-                                               float* __restrict__ snap_w, double& lossS, double& lossE)
+                                               float* __restrict__ snap_w)
 {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int64_t B = A.B, T = A.T;
@@ -186,116 +345,38 @@ __device__ __forceinline__ float mlp_step_span(const MlpStepArgs& A, const MfmaW
     const float* __restrict__ xp = A.x + b * T;
     const float* __restrict__ pp = DYN_R ? A.p + b * T : nullptr;
     const float* __restrict__ lp = DYN_R ? A.lr + b * T : nullptr;
-    double accS = 0.0, accE = 0.0;
-    mfma_v4f act[NL];
-    for (int64_t tb = tw; tb < t1; tb += 16) {
-        const bool owned = tb >= t0;
-        if (g == 0) {
-            if (tb == t0) {
-                if constexpr (PUBLISH) step_publish(A.zwarm + (int64_t)item * 16 + n, z);
-                else A.zwarm[(int64_t)item * 16 + n] = z;
-            }
-            if (!owned) {
-                const int64_t j = (t0 - tb) >> 4;                 // 16-step units before the first owned step
-                if (j <= kStepPre) step_publish(A.zpre + ((int64_t)item * kStepPre + (j - 1)) * 16 + n, z);
-            } else if (live) {
-                step_publish(snap_w + (tb >> 4) * B + b, z);      // the state a later call may start from (and this call's
-            }                                                     // verifier compares shorter warm-ups against)
-        }
-        float xs[16], ps[16], ls[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 xv = *reinterpret_cast<const float4*>(xp + tb + 4 * q);
-            xs[4 * q] = xv.x; xs[4 * q + 1] = xv.y; xs[4 * q + 2] = xv.z; xs[4 * q + 3] = xv.w;
-            if constexpr (DYN_R) {
-                const float4 pv = *reinterpret_cast<const float4*>(pp + tb + 4 * q);
-                const float4 lv = *reinterpret_cast<const float4*>(lp + tb + 4 * q);
-                ps[4 * q] = pv.x; ps[4 * q + 1] = pv.y; ps[4 * q + 2] = pv.z; ps[4 * q + 3] = pv.w;
-                ls[4 * q] = lv.x; ls[4 * q + 1] = lv.y; ls[4 * q + 2] = lv.z; ls[4 * q + 3] = lv.w;
-            }
-        }
-        float tt[4] = {0.0f, 0.0f, 0.0f, 0.0f};                 // group g looks after the steps i = g (mod 4)
-        if (owned) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tt[q] = A.target[(tb + 4 * q + g) * B + b];
-        }
-        float yk = 0.0f, zk = 0.0f, kk = 0.0f;
-        float Am = 1.0f, C1 = 0.0f, C2 = 0.0f, sS = 0.0f, sE = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float p = DYN_R ? ps[i] : c.p, lr = DYN_R ? ls[i] : c.lr;
-            const float b_diff = z - xs[i];
-            const float b_temp = -p * b_diff;
-            const float a = z + b_temp;
-            const float zn = b_temp - step_mlp_fwd<NL, ACT>(Wt, a, lr, act);     // b_root = -MLP (clipper_pot.py:121)
-            if (owned) {                                             // (wave-uniform)
-                const float Da = -step_mlp_grad_a<NL, ACT>(Wt, act);
-                const float kap = Da - p * (1.0f + Da);
-                const float yv = 0.5f * (zn + z);
-                const bool mine = (i & 3) == g;
-                if (mine) {
-                    yk = yv; zk = z; kk = kap;
-                    const float msk = (tb + i >= A.skip) ? 1.0f : 0.0f;
-                    const float d = yv - tt[i >> 2];
-                    const float wv = msk * 0.5f * Am * (kap + 1.0f);
-                    sS = fmaf(msk * d, d, sS);
-                    sE = fmaf(msk * yv, yv, sE);
-                    C1 = fmaf(wv, d, C1);
-                    C2 = fmaf(wv, yv, C2);
-                }
-                Am *= kap;
-            }
-            z = zn;
-            if ((i & 3) == 3 && owned && live) {
-                const int64_t o = (tb + (i - 3 + g)) * B + b;
-                A.y[o] = yk;
-                A.zstash[o] = zk;
-                A.kappa[o] = kk;
-            }
-        }
-        if (owned) {
-            C1 = groups_sum(C1);
-            C2 = groups_sum(C2);
-            if (g == 0 && live) {
-                float* __restrict__ m = A.maps + (tb >> 4) * 3 * B + b;
-                m[0] = Am; m[B] = C1; m[2 * B] = C2;
-            }
-            if (live) { accS += (double)sS; accE += (double)sE; }
-        }
+    StepSpan sp{z};
+    for (int64_t tb = tw; tb < t0; tb += 16) {                   // ---- warm-up blocks
+        const int64_t j = (t0 - tb) >> 4;                        // 16-step units before the first owned step
+        if (g == 0 && j <= kStepPre) step_publish(A.zpre + ((int64_t)item * kStepPre + (j - 1)) * 16 + n, sp.z);
+        mlp_step_block<NL, DYN_R, ACT, false>(A, Wt, c, tb, col, b, live, g, xp, pp, lp, sp);
     }
-    lossS = accS; lossE = accE;
-    return z;
+    if (g == 0) {
+        if constexpr (PUBLISH) step_publish(A.zwarm + (int64_t)item * 16 + n, sp.z);
+        else A.zwarm[(int64_t)item * 16 + n] = sp.z;
+    }
+    for (int64_t tb = t0; tb < t1; tb += 16) {                   // ---- owned blocks
+        // the state a later call may start from (and this call's verifier compares shorter warm-ups against)
+        if (g == 0 && live) step_publish(snap_w + (tb >> 4) * B + b, sp.z);
+        mlp_step_block<NL, DYN_R, ACT, true>(A, Wt, c, tb, col, b, live, g, xp, pp, lp, sp);
+    }
+    return sp.z;
 }
 
-// the item's loss sums: every lane holds its own steps of its own sequence -> one value per item
-template <bool PUBLISH>
-__device__ __forceinline__ void mlp_step_store_loss(const MlpStepArgs& A, int item, double lossS, double lossE)
+// the column's loss sums: its blocks in time order, fp64, by the whole wave (fixed order) -> colsum[col]
+__device__ __forceinline__ void mlp_step_column_loss(const MlpStepArgs& A, int col)
 {
-    lossS = wave_sum(lossS);
-    lossE = wave_sum(lossE);
-    if ((threadIdx.x & 63) == 0) {
-        if constexpr (PUBLISH) {
-            step_publish(A.losspart + 2 * (int64_t)item, lossS);
-            step_publish(A.losspart + 2 * (int64_t)item + 1, lossE);
-        } else {
-            A.losspart[2 * (int64_t)item] = lossS;
-            A.losspart[2 * (int64_t)item + 1] = lossE;
-        }
-    }
-}
-
-// the column's loss sums, items in time order (one lane; PUBLISHED: written by other waves of this launch)
-template <bool PUBLISHED>
-__device__ __forceinline__ void mlp_step_column_loss(const MlpStepArgs& A, int col, const MlpStepCol cinfo)
-{
+    const int lane = threadIdx.x & 63;
+    const int64_t nblk = A.T >> 4;
     double s = 0.0, e = 0.0;
-    for (int k = 0; k < cinfo.K; ++k) {
-        const int64_t it = cinfo.first + k;
-        s += PUBLISHED ? step_published(A.losspart + 2 * it) : A.losspart[2 * it];
-        e += PUBLISHED ? step_published(A.losspart + 2 * it + 1) : A.losspart[2 * it + 1];
+    for (int64_t j = lane; j < nblk; j += 64) {
+        const float* lb = A.lossblk + (j * A.n_cols + col) * 2;
+        s += (double)step_published(lb);
+        e += (double)step_published(lb + 1);
     }
-    A.colsum[2 * col] = s;
-    A.colsum[2 * col + 1] = e;
+    s = wave_sum_dpp(s);
+    e = wave_sum_dpp(e);
+    if (lane == 0) { A.colsum[2 * col] = s; A.colsum[2 * col + 1] = e; }
 }
 
 // MODE 0: the chunked forward.  MODE 1: flagged chunks again from their predecessors' end states.  MODE 2: flagged
@@ -320,17 +401,16 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
         if (A.colseq[col] == 0u) return;
         const MlpStepCol cinfo = A.cols[col];
         const MlpClipConsts c = DYN_R ? MlpClipConsts{} : mlp_load_consts(A.theta2, A.fs);
-        const MfmaWeights<NL> Wt = mfma_load_weights<NL>(A.w, A.H, lane, true);
+        const StepWeights<NL> Wt = step_load_weights<NL, ACT>(A.w, A.H, lane);
         // one item after the other, each from the state the previous one ended in
         float z = 0.0f;                                            // reset(): clipper_pot.py:110-111
         for (int k = 0; k < cinfo.K; ++k) {
             const MlpStepItem it = A.items[cinfo.first + k];
-            double lS, lE;
-            z = mlp_step_span<NL, DYN_R, ACT, false>(A, Wt, c, cinfo.first + k, col, it.t0, it.t0, it.t1, z, snap_w, lS, lE);
-            mlp_step_store_loss<false>(A, cinfo.first + k, lS, lE);
+            z = mlp_step_span<NL, DYN_R, ACT, false>(A, Wt, c, cinfo.first + k, col, it.t0, it.t0, it.t1, z, snap_w);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mlp_step_column_loss(A, col);
         if (lane == 0) {
-            mlp_step_column_loss<false>(A, col, cinfo);
             A.colseq[col] = 0u;
             atomicAdd(&st[3], 1);
             atomicAdd(&ctl->total_sequential, 1);
@@ -355,7 +435,7 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
             }
         }
         const MlpClipConsts c = DYN_R ? MlpClipConsts{} : mlp_load_consts(A.theta2, A.fs);
-        const MfmaWeights<NL> Wt = mfma_load_weights<NL>(A.w, A.H, lane, true);
+        const StepWeights<NL> Wt = step_load_weights<NL, ACT>(A.w, A.H, lane);
         const int64_t b_raw = (int64_t)it.col * 16 + n;
         const bool live = b_raw < A.B;
         const int64_t b = live ? b_raw : A.B - 1;
@@ -368,16 +448,39 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
                 tw = it.t0 > W ? it.t0 - W : 0;
                 z = (warm && tw > 0) ? snap_r[(tw >> 4) * A.B + b] : 0.0f;
             }
+            z = mlp_step_span<NL, DYN_R, ACT, true>(A, Wt, c, item, it.col, tw, it.t0, it.t1, z, snap_w);
+            if (g == 0) step_publish(A.zend + (int64_t)item * 16 + n, z);
         } else {
-            z = A.zend[(int64_t)(item - 1) * 16 + n];              // (k > 0: only boundaries are flagged)
+            // The repair: the flagged chunk again from the state its predecessor ended in -- but only as far as it takes:
+            // after every block the new state is held against the OLD trajectory (the stash row of the next step, still
+            // untouched); once they agree to tol the rest of the chunk stands (a miss of a few tol is forgotten within
+            // a few dozen steps).  A chunk that reaches its end still off by more than that carries on into its successor's
+            // steps -- unless the successor is being re-run itself (from a state that is now stale): then the column goes
+            // sequential.
+            const float* __restrict__ xp = A.x + b * A.T;
+            const float* __restrict__ pp = DYN_R ? A.p + b * A.T : nullptr;
+            const float* __restrict__ lp = DYN_R ? A.lr + b * A.T : nullptr;
+            StepSpan sp{A.zend[(int64_t)(item - 1) * 16 + n]};    // (k > 0: only boundaries are flagged)
+            const float eps_c = ctl->tol;                         // (two fp32 runs of this path sit 1-3e-6 apart whatever they started from)
+            int cur = item;                                       // the item whose steps are being rewritten
+            int64_t t_end = it.t1;
+            for (int64_t tb = it.t0; tb < A.T; tb += 16) {
+                if (tb == t_end) {                                // ran through a whole chunk without meeting the old trajectory
+                    const bool last = cur + 1 >= cinfo.first + cinfo.K;
+                    if (!last && A.flag[cur + 1] != 0u) { if (lane == 0) A.colseq[it.col] = 1u; break; }
+                    cur += 1;
+                    t_end = A.items[cur].t1;
+                }
+                if (g == 0 && live) step_publish(snap_w + (tb >> 4) * A.B + b, sp.z);
+                const float z_old_next = (tb + 16 < A.T) ? A.zstash[(tb + 16) * A.B + b] : sp.z;
+                const float z_end_old = A.zend[(int64_t)cur * 16 + n];
+                mlp_step_block<NL, DYN_R, ACT, true>(A, Wt, c, tb, it.col, b, live, g, xp, pp, lp, sp);
+                // (the stash row of step tb + 16 holds the state BEFORE that step; at a chunk's end the recorded end state)
+                const float ref = (tb + 16 == t_end) ? z_end_old : z_old_next;
+                const bool off = live && !(fabsf(sp.z - ref) <= eps_c);
+                if (tb + 16 < A.T && __ballot(off) == 0ull) break;
+            }
         }
-        double lS, lE;
-        z = mlp_step_span<NL, DYN_R, ACT, MODE == 0>(A, Wt, c, item, it.col, tw, it.t0, it.t1, z, snap_w, lS, lE);
-        if (g == 0) {
-            if constexpr (MODE == 0) step_publish(A.zend + (int64_t)item * 16 + n, z);
-            else step_publish(A.zend2 + (int64_t)item * 16 + n, z);
-        }
-        mlp_step_store_loss<true>(A, item, lS, lE);
         // ---- the column's last finisher
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's outputs and boundary states have landed
         unsigned* tk = (MODE == 0 ? A.ticket : A.ticket2) + it.col;
@@ -387,6 +490,7 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
         old = __builtin_amdgcn_readfirstlane(old);
         if (old != expect - 1u) return;
         if (lane == 0) *tk = 0u;                                   // left clean for the next launch
+        mlp_step_column_loss(A, it.col);
         const float tol = ctl->tol;
         if constexpr (MODE == 0) {
             // every boundary of the column: lane (q, n) takes the boundaries k = 1 + q, 5 + q, ...
@@ -408,7 +512,7 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
 #pragma unroll
                 for (int j = 1; j <= kStepPre; ++j) {
                     // the miss a warm-up j units shorter would have arrived with (needs j <= W and the sample to exist)
-                    float mj = 3.0e38f;
+                    float mj = j <= wc ? 0.0f : 3.0e38f;         // (a warm-up that reaches back to t = 0 is exact)
                     if (j <= wc && t0k - 16 * j > 0) {
                         const float zp = step_published(A.zpre + (ik * kStepPre + (j - 1)) * 16 + n);
                         const float zt = step_published(snap_w + ((t0k >> 4) - j) * A.B + b);
@@ -424,7 +528,9 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
             if (lane == 0) {
                 if (cinfo.K > 0) A.flag[cinfo.first] = 0u;
                 A.nflag[it.col] = (unsigned)nbad;
-                mlp_step_column_loss<true>(A, it.col, cinfo);
+                A.colmiss[4 * it.col] = m0;
+#pragma unroll
+                for (int j = 0; j < kStepPre; ++j) A.colmiss[4 * it.col + 1 + j] = mp[j];
                 if (nbad) { atomicAdd(&st[0], nbad); atomicAdd(&st[2], 1); atomicAdd(&ctl->total_flagged, nbad); }
                 if (m0 > 0.0f) atomicMax(&st[1], __float_as_int(m0));
                 // ---- steer the column's warm-up for the next call
@@ -432,8 +538,9 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
                     int W = A.wcol[it.col], cl = A.cool[it.col];
                     const float ms = mp[ctl->slack - 1];
                     if (nbad) { W += 2; cl = ctl->cool_miss; }
-                    else if (m0 > ctl->grow_at * tol) { W += 1; cl = cl > ctl->cool_shrink ? cl : ctl->cool_shrink; }
-                    else if (mp[0] > tol) { cl = cl > ctl->cool_shrink ? cl : ctl->cool_shrink; }   // one unit less would miss
+                    // (a slow column's miss doubles per 16 steps less, and in a swing of the weights it doubles per call: one
+                    //  unit more as soon as TWO units less would miss keeps pace with it)
+                    else if (m0 > ctl->grow_at * tol || mp[1] > tol) { W += 1; cl = cl > ctl->cool_shrink ? cl : ctl->cool_shrink; }
                     else if (cl > 0) { cl -= 1; }
                     else if (mp[kStepPre - 1] <= ctl->shrink_at * tol && W - 2 >= ctl->w_min) { W -= 2; cl = ctl->cool_shrink; }   // ample slack
                     else if (ms <= ctl->shrink_at * tol && W > ctl->w_min) { W -= 1; cl = ctl->cool_shrink; }
@@ -443,18 +550,7 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
                 }
             }
         } else {
-            // the re-run chunks must end where they ended before (their successors started from those states)
-            float md = 0.0f;
-            for (int k = 1 + g; k < cinfo.K; k += 4) {
-                const int64_t ik = cinfo.first + k;
-                if (A.flag[ik] == 0u) continue;
-                const float d = fabsf(step_published(A.zend2 + ik * 16 + n) - A.zend[ik * 16 + n]);
-                md = fmaxf(md, live ? d : 0.0f);
-            }
-            md = wave_max_dpp(md);
             if (lane == 0) {
-                mlp_step_column_loss<true>(A, it.col, cinfo);
-                A.colseq[it.col] = (md <= tol) ? 0u : 1u;
                 for (int k = 1; k < cinfo.K; ++k) A.flag[cinfo.first + k] = 0u;
                 A.nflag[it.col] = 0u;
             }
@@ -495,7 +591,7 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
     const float gb = (float)(-esr / E);
     if (gcoef_out && part == 0 && lane == 0) { gcoef_out[0] = ga; gcoef_out[1] = gb; }
     const MlpClipConsts c = DYN_R ? MlpClipConsts{} : mlp_load_consts(A.theta2, A.fs);
-    const MfmaWeights<NL> Wt = mfma_load_weights<NL>(A.w, A.H, lane, true);
+    const StepWeights<NL> Wt = step_load_weights<NL, ACT>(A.w, A.H, lane);
     // ---- the adjoint that enters this chunk: the maps of every later 16-step block, last block first
     float gz = 0.0f;
     {
@@ -516,8 +612,11 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
             gz = fmaf(m[0], gz, fmaf(ga, m[B], gb * m[2 * B]));
         }
     }
-    __shared__ float tbuf_all[4][2][16 * 17];
-    float (*tbuf)[16 * 17] = tbuf_all[wv];
+    // the transposes' LDS tiles: [wave][step parity][layer][gd | h][sequence][unit, row padded to 20 floats].  A wave's LDS
+    // instructions complete in order, so a write -> read pair of ONE wave needs no barrier, and tiles of their own per
+    // (parity, layer) leave the scheduler free to run a step's transposes under the neighbouring step's matrix work.
+    constexpr int kTile = 16 * 20;
+    __shared__ __attribute__((aligned(16))) float tbuf_all[4][2][NL - 1][2][kTile];
     const float* __restrict__ xp = A.x + b * T;
     const float* __restrict__ pp = DYN_R ? A.p + b * T : nullptr;
     const float* __restrict__ lp = DYN_R ? A.lr + b * T : nullptr;
@@ -575,25 +674,30 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
                 mfma_v4f gd;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) { gd[v] = G * d[v]; gbias[l - 1][v] += gd[v]; }
-                // the two transposes through LDS (one 16 x 17 tile each; the block is one wave): wdf_mlp_mfma.h
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    tbuf[0][(4 * g + v) * 17 + n] = gd[v];
-                    tbuf[1][(4 * g + v) * 17 + n] = act[l - 1][v];
-                }
-                step_wave_sync();
+                // the two transposes through LDS: a lane writes its four units of sequence n as one 16-byte store
+                // (tile[sequence][unit]) and reads, for outer-product MFMA q, unit n of sequence 4 g + q
+                float* __restrict__ tg = tbuf_all[wv][i & 1][l - 1][0];
+                float* __restrict__ th = tbuf_all[wv][i & 1][l - 1][1];
+                *reinterpret_cast<float4*>(tg + n * 20 + 4 * g) = make_float4(gd[0], gd[1], gd[2], gd[3]);
+                *reinterpret_cast<float4*>(th + n * 20 + 4 * g) = make_float4(act[l - 1][0], act[l - 1][1], act[l - 1][2], act[l - 1][3]);
                 mfma_v4f gdT, hT;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    gdT[q] = tbuf[0][n * 17 + 4 * g + q];
-                    hT[q] = tbuf[1][n * 17 + 4 * g + q];
+                    gdT[q] = tg[(4 * g + q) * 20 + n];
+                    hT[q] = th[(4 * g + q) * 20 + n];
                 }
-                step_wave_sync();
+                if constexpr (WDF_DBG_STEP & 2) { gdT = gd; hT = act[l - 1]; }   // (pricing the transposes: the LDS traffic above goes dead)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gK[l - 1] = mfma4(gdT[q], hT[q], gK[l - 1]);
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (WDF_DBG_STEP & 4) gK[l - 1][q] += gdT[q] * hT[q];   // (pricing the outer-product MFMAs)
+                    else gK[l - 1] = mfma4(gdT[q], hT[q], gK[l - 1]);
+                }
                 mfma_v4f nd = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int v = 0; v < 4; ++v) nd = mfma4(Wt.at[l - 1][v], d[v], nd);
+                for (int v = 0; v < 4; ++v) {
+                    if constexpr (WDF_DBG_STEP & 8) nd[v] += Wt.at[l - 1][v] * d[v];    // (pricing the delta chain's MFMAs)
+                    else nd = mfma4(Wt.at[l - 1][v], d[v], nd);
+                }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) d[v] = nd[v] * step_dact<ACT>(act[l - 1][v]);
             }

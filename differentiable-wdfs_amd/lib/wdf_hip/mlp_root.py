@@ -381,7 +381,7 @@ def _column_bounds(T, K, W, cost=WARM_COST):
     best = None
     Lc = int((T - cost * W) / K / 16.0) * 16
     for L in (Lc - 16, Lc, Lc + 16, Lc + 32):
-        L = max(16, min(L, (T - 16) // (K - 1) // 16 * 16))
+        L = max(16, min(L, T // K // 16 * 16))                # (chunk 0 is never the shortest: L0 >= L)
         L0 = T - (K - 1) * L
         c = max(L0, L + cost * W)
         if best is None or c < best[0]:
@@ -545,7 +545,7 @@ class MlpTrainStep:
         """(controller dict, per-column warm-up units) -- synchronises."""
         ctl = (_C.c_int32 * 32)()
         wc = (_C.c_int32 * self.ncol)()
-        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), ctl, wc, None, binding._stream()),
+        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), ctl, wc, None, None, binding._stream()),
                        "wdf_clipper_mlp_step_read")
         c = _np.frombuffer(ctl, dtype=_np.int32).copy()
         last = c[16 + 4 * ((int(c[0]) - 1) & 1):][:4] if c[0] > 0 else c[16:20]
@@ -558,12 +558,19 @@ class MlpTrainStep:
         """Where the dispatcher put the forward's waves in the last call: int array [n_items, 3] = (XCD, CU within the XCD
         (shader engine, array, CU), SIMD).  Diagnostics."""
         hw = (_C.c_int32 * (2 * self.n_items))()
-        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), None, None, hw, binding._stream()),
+        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), None, None, hw, None, binding._stream()),
                        "wdf_clipper_mlp_step_read")
         a = _np.frombuffer(hw, dtype=_np.uint32).reshape(-1, 2)
         hid, xcc = a[:, 0], a[:, 1] & 0xf
         simd, cu = (hid >> 4) & 3, (hid >> 8) & 0xff           # cu_id [11:8], sh_id [12], se_id [15:13]
         return _np.stack([xcc, cu, simd], axis=1).astype(_np.int64)
+
+    def column_misses(self):
+        """float [ncol, 4]: per column the last verification's arrival miss and the misses 16, 32, 48 steps before arrival."""
+        cm = (_C.c_float * (4 * self.ncol))()
+        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), None, None, None, cm, binding._stream()),
+                       "wdf_clipper_mlp_step_read")
+        return _np.frombuffer(cm, dtype=_np.float32).reshape(-1, 4).copy()
 
     def replan(self):
         """Re-distribute the chunks over the columns with the warm-ups the controller has settled on (host round trip;

@@ -324,7 +324,9 @@ int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb,
  *           cool_miss, cool_shrink, tol, grow_at, shrink_at, freeze, 3 pad, status[2][4] = {bad boundaries, max miss
  *           bits, columns flagged, columns sequential} by call parity, total flagged, total sequential) and of the
  *           per-column warm-ups (16-step units); hwid_out int32[n_items][2]: HW_ID and XCC_ID registers of the wave
- *           that ran each forward item of the last call (where the dispatcher placed it).  Synchronises.   */
+ *           that ran each forward item of the last call (where the dispatcher placed it); colmiss_out float[cols][4]:
+ *           per column the last verification's arrival miss and the misses 16, 32, 48 steps before arrival (what the
+ *           controller steers the warm-up by).  Synchronises.                                          */
 enum {
     WDF_MLP_STEP_FWD = 1, WDF_MLP_STEP_SUMS = 2, WDF_MLP_STEP_BWD = 4, WDF_MLP_STEP_GLOBAL_SUMS = 8
 };
@@ -333,7 +335,8 @@ int wdf_clipper_mlp_step_plan(void* state, int hidden, int n_layers, int64_t B, 
                               const int32_t* items, int reset, int warm16, int cold16, int w_min, int w_max, float tol,
                               void* stream);
 int wdf_clipper_mlp_step_read(const void* state, int hidden, int n_layers, int64_t B, int64_t T, int n_items,
-                              int wgrad_chunks, int32_t* ctl_out, int32_t* wcol_out, int32_t* hwid_out, void* stream);
+                              int wgrad_chunks, int32_t* ctl_out, int32_t* wcol_out, int32_t* hwid_out, float* colmiss_out,
+                              void* stream);
 int wdf_clipper_mlp_step_set(void* state, int field, int32_t bits, void* stream);
 int wdf_clipper_mlp_step_set_wcol(void* state, int hidden, int n_layers, int64_t B, int64_t T, int n_items, int wgrad_chunks,
                                   const int32_t* wcol, void* stream);

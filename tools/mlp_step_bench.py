@@ -30,6 +30,8 @@ if os.environ.get("KW"):
     kw["wgrad_chunks"] = int(os.environ["KW"])
 st = mlp_root.MlpTrainStep(x, r, target, w, hidden, n_layers, fs, workload.C_CLIPPER, skip=skip, adam=adam, **kw)
 print(f"net {net}: {B} x {T}, items {st.n_items}, wgrad chunks {st.wgrad_chunks}, cold warm-up {st.cold}")
+if os.environ.get("FREEZE") == "1":                      # the controller leaves the first-guess warm-ups alone
+    st.freeze(True)
 
 
 def chunks_per_class():

@@ -42,6 +42,10 @@ for i in range(calls):
     if i < 12 or i % 10 == 0 or info["n_bad"]:
         print(f"{i:4d} {ms[-1]:.3f} ms  bad {info['n_bad']:3d} cols {info['flagged_columns']:2d} seq {info['sequential_columns']}  "
               f"miss {info['max_miss']:.1e}  W {[int(wc[c]) for c in q]} (mean {wc.mean():.1f})")
+    if os.environ.get("DUMP_COLS") and i in (int(v) for v in os.environ["DUMP_COLS"].split(",")):
+        cm = st.column_misses()
+        for c in range(st.ncol):
+            print(f"      col {c:2d} K {int((st.items[:, 0] == c).sum()):2d} W {int(wc[c]):2d}  m0 {cm[c, 0]:.1e}  -1: {cm[c, 1]:.1e}  -2: {cm[c, 2]:.1e}  -3: {cm[c, 3]:.1e}")
     if i == replan_at:
         print("re-plan:", st.replan(), [int((st.items[:, 0] == c).sum()) for c in q])
 h = calls // 2
