@@ -265,7 +265,7 @@ int wdf_clipper_mlp_step(const float* x, const float* p, const float* lr, const 
     if (phase & WDF_MLP_STEP_BWD) {
         const int count = step_weight_count(hidden, n_layers);
         hipLaunchKernelGGL(wdf::mlp_step_reduce_adam_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64, 16), 0, s,
-                           (const float*)wsw, L.n_cols * L.kw, count, gw, w, adam_m, adam_v, (const int32_t*)adam_step, adam_lr,
+                           (const float*)wsw, (L.n_cols * L.kw + 3) / 4, count, gw, w, adam_m, adam_v, (const int32_t*)adam_step, adam_lr,
                            beta1, beta2, eps, (const double*)A.colsum, L.n_cols, gsums, n_global, eps_energy, loss3, A.ctl);
         rc = check_launch("wdf_clipper_mlp_step reduce");
     }

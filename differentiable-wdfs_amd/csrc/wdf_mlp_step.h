@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
 
 // ---- (4) the reverse sweep: adjoint recurrence + weight gradient, one wave per (column, chunk of Lw steps) ----------
 // sums: the two GLOBAL loss sums {S, E} (multi-rank: after the all-reduce) or null -> this rank's colsum.
-// wsw: float[parts][count], part = chunk * n_cols + column.  adam_step (or null): bumped once here, so the
+// wsw: float[workgroups][count] (a workgroup = four consecutive parts, part = chunk * n_cols + column).  adam_step (or null): bumped once here, so the
 // reduce / Adam kernel behind reads the step count it has to use.
 template <int NL, bool DYN_R, int ACT, int BS = 8>
 __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A, const double* __restrict__ sums, double n_global,
@@ -569,14 +569,16 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
 {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     const int64_t B = A.B, T = A.T;
-    const int64_t part = (int64_t)blockIdx.x * 4 + wv;            // four (column, chunk) parts per workgroup, one per wave
-    if (part >= (int64_t)A.n_cols * Kw) return;
+    const int64_t nparts = (int64_t)A.n_cols * Kw;
+    const int64_t part_raw = (int64_t)blockIdx.x * 4 + wv;        // four (column, chunk) parts per workgroup, one per wave
+    const bool active = part_raw < nparts;                        // (a wave past the end runs the last part again, adds nothing)
+    const int64_t part = active ? part_raw : nparts - 1;
     const int col = (int)(part % A.n_cols), chunk = (int)(part / A.n_cols);
-    if (adam_step && part == 0 && lane == 0) *adam_step += 1;
+    if (adam_step && part_raw == 0 && lane == 0) *adam_step += 1;
     const int64_t b_raw = (int64_t)col * 16 + n;
     const bool live = b_raw < B;
     const int64_t b = live ? b_raw : B - 1;
-    const int64_t t0 = (int64_t)chunk * Lw, t1 = (t0 + Lw < T) ? t0 + Lw : T;
+    const int64_t t0 = (int64_t)chunk * Lw, t1 = !active ? t0 : ((t0 + Lw < T) ? t0 + Lw : T);
     // ---- the loss coefficients: dLoss/dy = ga (y - t) + gb y past skip (clipper_pot.py:146-156,177; wdf_elementwise.h)
     double S, E;
     if (sums) { S = sums[0]; E = sums[1]; }
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
     const double esr = sqrt(S / E / n_global);
     const float ga = (float)(2.0 / n_global + (esr > 0.0 ? 1.0 / (esr * E * n_global) : 0.0));
     const float gb = (float)(-esr / E);
-    if (gcoef_out && part == 0 && lane == 0) { gcoef_out[0] = ga; gcoef_out[1] = gb; }
+    if (gcoef_out && part_raw == 0 && lane == 0) { gcoef_out[0] = ga; gcoef_out[1] = gb; }
     const MlpClipConsts c = DYN_R ? MlpClipConsts{} : mlp_load_consts(A.theta2, A.fs);
     const StepWeights<NL> Wt = step_load_weights<NL, ACT>(A.w, A.H, lane);
     // ---- the adjoint that enters this chunk: the maps of every later 16-step block, last block first
@@ -616,7 +618,8 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
     // instructions complete in order, so a write -> read pair of ONE wave needs no barrier, and tiles of their own per
     // (parity, layer) leave the scheduler free to run a step's transposes under the neighbouring step's matrix work.
     constexpr int kTile = 16 * 20;
-    __shared__ __attribute__((aligned(16))) float tbuf_all[4][2][NL - 1][2][kTile];
+    constexpr int kWaveLds = 2 * (NL - 1) * 2 * kTile;            // floats per wave
+    __shared__ __attribute__((aligned(16))) float tbuf_all[4 * kWaveLds];
     const float* __restrict__ xp = A.x + b * T;
     const float* __restrict__ pp = DYN_R ? A.p + b * T : nullptr;
     const float* __restrict__ lp = DYN_R ? A.lr + b * T : nullptr;
@@ -676,8 +679,8 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
                 for (int v = 0; v < 4; ++v) { gd[v] = G * d[v]; gbias[l - 1][v] += gd[v]; }
                 // the two transposes through LDS: a lane writes its four units of sequence n as one 16-byte store
                 // (tile[sequence][unit]) and reads, for outer-product MFMA q, unit n of sequence 4 g + q
-                float* __restrict__ tg = tbuf_all[wv][i & 1][l - 1][0];
-                float* __restrict__ th = tbuf_all[wv][i & 1][l - 1][1];
+                float* __restrict__ tg = tbuf_all + wv * kWaveLds + (((i & 1) * (NL - 1) + (l - 1)) * 2) * kTile;
+                float* __restrict__ th = tg + kTile;
                 *reinterpret_cast<float4*>(tg + n * 20 + 4 * g) = make_float4(gd[0], gd[1], gd[2], gd[3]);
                 *reinterpret_cast<float4*>(th + n * 20 + 4 * g) = make_float4(act[l - 1][0], act[l - 1][1], act[l - 1][2], act[l - 1][3]);
                 mfma_v4f gdT, hT;
@@ -713,7 +716,9 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
     // per-lane partials are per (unit 4 g + v, sequence n): sum over the 16 sequences of the lane group
     const int H = A.H;
     const int count = 3 * H + (NL - 1) * (H * H + H) + H + 1;
-    float* __restrict__ o = wsw + part * count;
+    // the wave's partial goes to LDS (its own transposes' tiles are free now), the workgroup's four are added there, in
+    // wave order, and ONE partial per workgroup goes out: wsw float[workgroups][count]
+    float* __restrict__ o = tbuf_all + wv * kWaveLds;
     // (the four lane groups carry the same sequences: gbo is the same in all of them)
     const float vbo = row_sum(gbo);
     if (lane == 0) o[count - 1] = vbo;
@@ -738,6 +743,14 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
             const int i = 4 * g + v;
             if (n < H && i < H) o[3 * H + (l - 1) * (H * H + H) + n * H + i] = gK[l - 1][v];
         }
+    }
+    __syncthreads();
+    float* __restrict__ og = wsw + (int64_t)blockIdx.x * count;
+    for (int idx = threadIdx.x; idx < count; idx += 256) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += tbuf_all[q * kWaveLds + idx];
+        og[idx] = t;
     }
 }
 
