@@ -402,12 +402,16 @@ def run_mlp_step(args, world, rank, local):
                                n_global=n_global, eps_energy=eps,
                                sums_allreduce=wdist.allreduce_sum_ if dist_on else None,
                                grad_allreduce=wdist.allreduce_sum_ if dist_on else None)
-    # untimed: the cold call, the controller settling, one re-plan of the chunk counts from the warm-ups it settled on
-    replan_at = min(40, max(1, args.warmup // 2))
+    # untimed set-up (as the diode line autotunes its chunk count): the cold call and the controller settling (24 steps), then
+    # the chunk plan picked by measurement among six candidates, 16 training steps each (MlpTrainStep.autotune); then the
+    # contract's W untimed steps
+    tuned = None
+    if not args.plan:
+        for _ in range(24):
+            st.step()
+        tuned = st.autotune()
     for i in range(args.warmup):
         st.step()
-        if i + 1 == replan_at:
-            st.replan()
     graph = None
     if args.graph:
         torch.cuda.synchronize()
@@ -476,6 +480,7 @@ def run_mlp_step(args, world, rank, local):
                           "collective": None if not dist_on else "all-reduce of the two loss sums, then of the weight gradient",
                           "step": "resident training step (wdf_clipper_mlp_step): five launches, steered on the device",
                           "time_parallel": {"forward_items": int(st.n_items), "reverse_chunks": int(st.wgrad_chunks),
+                                            "plan": None if tuned is None else {"picked": tuned[0], "ms_per_step_while_tuning": tuned[1]},
                                             "chunks_per_column": {"min": int(np.bincount(items[:, 0]).min()), "max": int(np.bincount(items[:, 0]).max())},
                                             "warmup_steps_per_column": {"min": int(16 * wcol.min()), "mean": float(16 * wcol.mean()), "max": int(16 * wcol.max())},
                                             "forward_steps_per_wave": {"mean": float(run.mean()), "max": int(run.max()), "owned_mean": float(T * st.ncol / st.n_items)},

@@ -10,7 +10,7 @@ using namespace wdfcapi;
 namespace {
 
 struct StepLayout {
-    size_t ctl, items, cols, wcol, cool, ticket, ticket2, nflag, colseq, flag, hwid, colmiss, zwarm, zend, zpre, lossblk, colsum,
+    size_t ctl, items, cols, wcol, cool, wpeak, ticket, ticket2, nflag, colseq, flag, hwid, colmiss, zwarm, zend, zpre, lossblk, colsum,
         maps, snap, wsw, total;
     int n_cols, kw;
     int64_t lw;
@@ -39,7 +39,7 @@ StepLayout step_layout(int hidden, int n_layers, int64_t B, int64_t T, int n_ite
     L.ctl = take(sizeof(wdf::MlpStepCtl));
     L.items = take(ni * sizeof(wdf::MlpStepItem));
     L.cols = take(nc * sizeof(wdf::MlpStepCol));
-    L.wcol = take(nc * 4); L.cool = take(nc * 4); L.ticket = take(nc * 4); L.ticket2 = take(nc * 4);
+    L.wcol = take(nc * 4); L.cool = take(nc * 4); L.wpeak = take(nc * 4); L.ticket = take(nc * 4); L.ticket2 = take(nc * 4);
     L.nflag = take(nc * 4); L.colseq = take(nc * 4); L.flag = take(ni * 4); L.hwid = take(ni * 8); L.colmiss = take(nc * 16);
     L.zwarm = take(ni * 16 * 4); L.zend = take(ni * 16 * 4);
     L.zpre = take(ni * wdf::kStepPre * 16 * 4);
@@ -109,7 +109,7 @@ int wdf_clipper_mlp_step_plan(void* state, int hidden, int n_layers, int64_t B, 
     auto ok = [&e](hipError_t r) { if (e == hipSuccess) e = r; };
     ok(hipMemcpyAsync(base + L.items, items, (size_t)n_items * sizeof(wdf::MlpStepItem), hipMemcpyHostToDevice, s));
     ok(hipMemcpyAsync(base + L.cols, cols.data(), cols.size() * sizeof(wdf::MlpStepCol), hipMemcpyHostToDevice, s));
-    ok(hipMemsetAsync(base + L.ticket, 0, L.flag + (size_t)n_items * 4 - L.ticket, s));      // tickets, flags, gates
+    ok(hipMemsetAsync(base + L.wpeak, 0, L.flag + (size_t)n_items * 4 - L.wpeak, s));        // warm-up peaks, tickets, flags, gates
     if (reset) {
         wdf::MlpStepCtl c{};
         c.cold16 = cold16; c.w_min = w_min; c.w_max = w_max; c.slack = 2; c.cool_miss = 8; c.cool_shrink = 2;
@@ -125,13 +125,14 @@ int wdf_clipper_mlp_step_plan(void* state, int hidden, int n_layers, int64_t B, 
     return WDF_OK;
 }
 
-// Host copies of the controller: ctl_out int32[32] (MlpStepCtl), wcol_out int32[ceil(B/16)], hwid_out int32[n_items][2]
+// Host copies of the controller: ctl_out int32[32] (MlpStepCtl), wcol_out int32[ceil(B/16)], wpeak_out int32[ceil(B/16)] (the
+// largest warm-up each column has run with since the plan was installed), hwid_out int32[n_items][2]
 // (HW_ID and XCC_ID of the wave that ran each forward item in the last call: placement diagnostics), colmiss_out
 // float[ceil(B/16)][4] (per column: the last verification's arrival miss and the misses 16, 32, 48 steps before arrival);
 // any may be NULL.
 // Synchronises the stream.
 int wdf_clipper_mlp_step_read(const void* state, int hidden, int n_layers, int64_t B, int64_t T, int n_items, int wgrad_chunks,
-                              int32_t* ctl_out, int32_t* wcol_out, int32_t* hwid_out, float* colmiss_out, void* stream)
+                              int32_t* ctl_out, int32_t* wcol_out, int32_t* wpeak_out, int32_t* hwid_out, float* colmiss_out, void* stream)
 {
     int rc = step_check_shape(hidden, n_layers, 0, B, T, n_items, wgrad_chunks);
     if (rc) return rc;
@@ -141,6 +142,7 @@ int wdf_clipper_mlp_step_read(const void* state, int hidden, int n_layers, int64
     hipError_t e = hipSuccess;
     if (ctl_out) e = hipMemcpyAsync(ctl_out, (const char*)state + L.ctl, sizeof(wdf::MlpStepCtl), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && wcol_out) e = hipMemcpyAsync(wcol_out, (const char*)state + L.wcol, (size_t)L.n_cols * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && wpeak_out) e = hipMemcpyAsync(wpeak_out, (const char*)state + L.wpeak, (size_t)L.n_cols * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && hwid_out) e = hipMemcpyAsync(hwid_out, (const char*)state + L.hwid, (size_t)n_items * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && colmiss_out) e = hipMemcpyAsync(colmiss_out, (const char*)state + L.colmiss, (size_t)L.n_cols * 16, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -246,7 +248,7 @@ int wdf_clipper_mlp_step(const float* x, const float* p, const float* lr, const 
     A.zpre = (float*)(base + L.zpre);
     A.lossblk = (float*)(base + L.lossblk); A.colsum = (double*)(base + L.colsum);
     A.items = (const wdf::MlpStepItem*)(base + L.items); A.cols = (const wdf::MlpStepCol*)(base + L.cols);
-    A.wcol = (int*)(base + L.wcol); A.cool = (int*)(base + L.cool);
+    A.wcol = (int*)(base + L.wcol); A.cool = (int*)(base + L.cool); A.wpeak = (int*)(base + L.wpeak);
     A.ticket = (unsigned*)(base + L.ticket); A.ticket2 = (unsigned*)(base + L.ticket2);
     A.hwid = (unsigned*)(base + L.hwid); A.colmiss = (float*)(base + L.colmiss);
     A.flag = (unsigned*)(base + L.flag); A.nflag = (unsigned*)(base + L.nflag); A.colseq = (unsigned*)(base + L.colseq);

@@ -87,6 +87,7 @@ struct MlpStepArgs {
     const MlpStepCol* cols;
     int* wcol;             // [cols] warm-up units in use
     int* cool;             // [cols]
+    int* wpeak;            // [cols] the largest warm-up the column has run with since the plan was installed
     unsigned* ticket;      // [cols]   (left 0)
     unsigned* ticket2;     // [cols]   (left 0)
     unsigned* flag;        // [items]  boundary missed -> MODE 1 re-runs the item
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
                     else if (mp[kStepPre - 1] <= ctl->shrink_at * tol && W - 2 >= ctl->w_min) { W -= 2; cl = ctl->cool_shrink; }   // ample slack
                     else if (ms <= ctl->shrink_at * tol && W > ctl->w_min) { W -= 1; cl = ctl->cool_shrink; }
                     W = W > ctl->w_max ? ctl->w_max : W;
+                    if (wc > A.wpeak[it.col]) A.wpeak[it.col] = wc;
                     A.wcol[it.col] = W;
                     A.cool[it.col] = cl;
                 }

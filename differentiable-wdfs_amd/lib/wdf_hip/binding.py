@@ -173,7 +173,7 @@ def lib():
     L.wdf_clipper_mlp_step_plan.restype = ci
     L.wdf_clipper_mlp_step_plan.argtypes = [vp, ci, ci, i64, i64, ci, ci, i32p, ci, ci, ci, ci, ci, cf, vp]
     L.wdf_clipper_mlp_step_read.restype = ci
-    L.wdf_clipper_mlp_step_read.argtypes = [vp, ci, ci, i64, i64, ci, ci, i32p, i32p, i32p, C.POINTER(C.c_float), vp]
+    L.wdf_clipper_mlp_step_read.argtypes = [vp, ci, ci, i64, i64, ci, ci, i32p, i32p, i32p, i32p, C.POINTER(C.c_float), vp]
     L.wdf_clipper_mlp_step_set.restype = ci
     L.wdf_clipper_mlp_step_set.argtypes = [vp, ci, C.c_int32, vp]
     L.wdf_clipper_mlp_step_set_wcol.restype = ci

@@ -373,12 +373,13 @@ WARM_COST = float(os.environ.get("WDF_MLP_WARM_COST", 0.55))   # a warm-up step 
 #   swept on the reference shape (0.45 .. 0.9): 0.55 gives the shortest step (0.397 ms against 0.414 at 0.75)
 
 
-def _column_bounds(T, K, W, cost=WARM_COST):
+def _column_bounds(T, K, W, cost=None):
     """Chunk boundaries [0, t1, ..., T] of one column for K chunks and a warm-up of W steps: chunk 0 has no warm-up, so it
     is longer by about the warm-up's cost and every wave of the column runs about the same number of steps (lengths are
     multiples of 16: the L that minimises the longer of the two)."""
     if K <= 1:
         return [0, T]
+    cost = WARM_COST if cost is None else cost
     best = None
     Lc = int((T - cost * W) / K / 16.0) * 16
     for L in (Lc - 16, Lc, Lc + 16, Lc + 32):
@@ -391,7 +392,8 @@ def _column_bounds(T, K, W, cost=WARM_COST):
     return [0] + [L0 + i * L for i in range(K)]
 
 
-def _column_cost(T, K, W, cost=WARM_COST):
+def _column_cost(T, K, W, cost=None):
+    cost = WARM_COST if cost is None else cost
     b = _column_bounds(T, K, W, cost)
     return max(b[1], (b[2] - b[1] + cost * W) if K > 1 else 0)
 
@@ -516,8 +518,9 @@ class MlpTrainStep:
     def _geom(self):
         return (self.hidden, self.n_layers, self.B, self.T, self.n_items, self.wgrad_chunks)
 
-    def _install_plan(self, wcol_units, reset):
-        items = plan_step_items(self.T, [16 * int(v) for v in wcol_units], self.n_items_max)
+    def _install_plan(self, wcol_units, reset, items=None):
+        if items is None:
+            items = plan_step_items(self.T, [16 * int(v) for v in wcol_units], self.n_items_max)
         n_items = int(items.shape[0])
         if self.state is None or n_items != getattr(self, "n_items", None):
             if self.state is not None and not reset:
@@ -531,7 +534,8 @@ class MlpTrainStep:
         arr = _np.ascontiguousarray(items, dtype=_np.int32)
         rc = self.lib.wdf_clipper_mlp_step_plan(binding._ptr(self.state), *self._geom(),
                                                 arr.ctypes.data_as(_C.POINTER(_C.c_int32)), 1 if reset else 0,
-                                                int(max(wcol_units)), self.cold // 16, 1, self.w_max, self.tol, binding._stream())
+                                                0 if wcol_units is None else int(max(wcol_units)), self.cold // 16, 1, self.w_max,
+                                                self.tol, binding._stream())
         binding._check(rc, "wdf_clipper_mlp_step_plan")
         if reset:
             self.set_wcol(wcol_units)
@@ -546,7 +550,7 @@ class MlpTrainStep:
         """(controller dict, per-column warm-up units) -- synchronises."""
         ctl = (_C.c_int32 * 32)()
         wc = (_C.c_int32 * self.ncol)()
-        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), ctl, wc, None, None, binding._stream()),
+        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), ctl, wc, None, None, None, binding._stream()),
                        "wdf_clipper_mlp_step_read")
         c = _np.frombuffer(ctl, dtype=_np.int32).copy()
         last = c[16 + 4 * ((int(c[0]) - 1) & 1):][:4] if c[0] > 0 else c[16:20]
@@ -559,7 +563,7 @@ class MlpTrainStep:
         """Where the dispatcher put the forward's waves in the last call: int array [n_items, 3] = (XCD, CU within the XCD
         (shader engine, array, CU), SIMD).  Diagnostics."""
         hw = (_C.c_int32 * (2 * self.n_items))()
-        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), None, None, hw, None, binding._stream()),
+        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), None, None, None, hw, None, binding._stream()),
                        "wdf_clipper_mlp_step_read")
         a = _np.frombuffer(hw, dtype=_np.uint32).reshape(-1, 2)
         hid, xcc = a[:, 0], a[:, 1] & 0xf
@@ -569,19 +573,62 @@ class MlpTrainStep:
     def column_misses(self):
         """float [ncol, 4]: per column the last verification's arrival miss and the misses 16, 32, 48 steps before arrival."""
         cm = (_C.c_float * (4 * self.ncol))()
-        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), None, None, None, cm, binding._stream()),
+        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), None, None, None, None, cm, binding._stream()),
                        "wdf_clipper_mlp_step_read")
         return _np.frombuffer(cm, dtype=_np.float32).reshape(-1, 4).copy()
 
-    def replan(self):
-        """Re-distribute the chunks over the columns with the warm-ups the controller has settled on (host round trip;
-        the number of work items -- the captured grid -- stays)."""
+    def warmup_peaks(self):
+        wp = (_C.c_int32 * self.ncol)()
+        binding._check(self.lib.wdf_clipper_mlp_step_read(binding._ptr(self.state), *self._geom(), None, None, wp, None, None, binding._stream()),
+                       "wdf_clipper_mlp_step_read")
+        return _np.frombuffer(wp, dtype=_np.int32).copy()
+
+    def replan(self, by=None):
+        """Re-distribute the chunks over the columns with the warm-ups the controller has been running (host round trip;
+        the number of work items -- the captured grid -- stays).  by: "peak" (default: the largest warm-up of each column
+        since the last plan: the plan is balanced for the calls in which the weights swing) or "current"."""
+        by = by or os.environ.get("WDF_MLP_PLAN_BY", "peak")
         _, wc = self.read()
-        items = plan_step_items(self.T, [16 * int(v) + 16 for v in wc], self.n_items_max)   # (one unit of head room)
+        wp = _np.maximum(self.warmup_peaks(), wc) if by == "peak" else wc + 1
+        items = plan_step_items(self.T, [16 * int(v) for v in wp], self.n_items_max)
         if int(items.shape[0]) != self.n_items:
             return False
-        self._install_plan(wc, reset=False)
+        self._install_plan(wp, reset=False)
         return True
+
+    def autotune(self, calls=16, verbose=False):
+        """Pick the chunk plan by MEASURING: a handful of candidate plans (the columns' peak / current warm-ups, with and
+        without head room, three values of the planner's warm-up cost) are each run for `calls` training steps -- one
+        swing of the weights under Adam(beta_1 0.5) -- and the one with the shortest mean step is installed.  The steps are
+        real training steps (part of a loop's warm-up).  -> (label, ms per step) of the winner."""
+        global WARM_COST
+        e0, e1 = binding.Event(), binding.Event()
+        cost0 = WARM_COST
+        results = []
+        _, wc = self.read()
+        wp = _np.maximum(self.warmup_peaks(), wc)
+        cands = [("peak", wp, cost0), ("peak+1", wp + 1, cost0), ("current+1", wc + 1, cost0),
+                 ("peak, cost 0.45", wp, 0.45), ("peak, cost 0.65", wp, 0.65), ("peak+2, cost 0.45", wp + 2, 0.45)]
+        for label, wprof, cost in cands:
+            WARM_COST = cost
+            items = plan_step_items(self.T, [16 * int(v) for v in wprof], self.n_items_max)
+            if int(items.shape[0]) != self.n_items:
+                continue
+            self._install_plan(wprof, reset=False, items=items)
+            e0.record()
+            for _ in range(calls):
+                self.step()
+            e1.record()
+            torch.cuda.synchronize()
+            results.append((e0.elapsed_ms(e1) / calls, label, items))
+            if verbose:
+                print(f"  plan {label}: {results[-1][0]:.4f} ms per step")
+        WARM_COST = cost0
+        if not results:
+            return None
+        ms, label, items = min(results, key=lambda r_: r_[0])
+        self._install_plan(None, reset=False, items=items)
+        return label, ms
 
     def freeze(self, on=True):
         binding._check(self.lib.wdf_clipper_mlp_step_set(binding._ptr(self.state), 12, 1 if on else 0, binding._stream()),

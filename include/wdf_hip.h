@@ -323,7 +323,7 @@ int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb,
  *   read    host copies of the controller block (int32[32]: call, parity, have_snap, cold16, w_min, w_max, slack,
  *           cool_miss, cool_shrink, tol, grow_at, shrink_at, freeze, 3 pad, status[2][4] = {bad boundaries, max miss
  *           bits, columns flagged, columns sequential} by call parity, total flagged, total sequential) and of the
- *           per-column warm-ups (16-step units); hwid_out int32[n_items][2]: HW_ID and XCC_ID registers of the wave
+ *           per-column warm-ups (16-step units; wpeak_out: the largest each column ran with since the plan); hwid_out int32[n_items][2]: HW_ID and XCC_ID registers of the wave
  *           that ran each forward item of the last call (where the dispatcher placed it); colmiss_out float[cols][4]:
  *           per column the last verification's arrival miss and the misses 16, 32, 48 steps before arrival (what the
  *           controller steers the warm-up by).  Synchronises.                                          */
@@ -335,7 +335,8 @@ int wdf_clipper_mlp_step_plan(void* state, int hidden, int n_layers, int64_t B, 
                               const int32_t* items, int reset, int warm16, int cold16, int w_min, int w_max, float tol,
                               void* stream);
 int wdf_clipper_mlp_step_read(const void* state, int hidden, int n_layers, int64_t B, int64_t T, int n_items,
-                              int wgrad_chunks, int32_t* ctl_out, int32_t* wcol_out, int32_t* hwid_out, float* colmiss_out,
+                              int wgrad_chunks, int32_t* ctl_out, int32_t* wcol_out, int32_t* wpeak_out, int32_t* hwid_out,
+                              float* colmiss_out,
                               void* stream);
 int wdf_clipper_mlp_step_set(void* state, int field, int32_t bits, void* stream);
 int wdf_clipper_mlp_step_set_wcol(void* state, int hidden, int n_layers, int64_t B, int64_t T, int n_items, int wgrad_chunks,

@@ -46,9 +46,25 @@ for i in range(calls):
         cm = st.column_misses()
         for c in range(st.ncol):
             print(f"      col {c:2d} K {int((st.items[:, 0] == c).sum()):2d} W {int(wc[c]):2d}  m0 {cm[c, 0]:.1e}  -1: {cm[c, 1]:.1e}  -2: {cm[c, 2]:.1e}  -3: {cm[c, 3]:.1e}")
-    if i == replan_at:
+    if i == replan_at and os.environ.get("AUTOTUNE"):
+        print("autotune:", st.autotune(verbose=True))
+    elif i == replan_at:
         print("re-plan:", st.replan(), [int((st.items[:, 0] == c).sum()) for c in q])
+        wp = st.warmup_peaks()
+        print("   plan K per column:", np.bincount(st.items[:, 0]).tolist())
+        print("   W at plan        :", wc.tolist())
 h = calls // 2
 clean = [m for m, b in zip(ms[h:], bad[h:]) if b == 0]
 print(f"second half: mean {np.mean(ms[h:]):.4f} ms, median {np.median(ms[h:]):.4f}; calls with a flagged boundary {sum(b > 0 for b in bad[h:])}/{calls - h}, "
       f"sequential {sum(seq[h:])}; clean calls {np.mean(clean):.4f} ms")
+
+ev = [binding.Event() for _ in range(4)]
+tf, tb = [], []
+for _ in range(12):
+    binding.Event.bracket_next(ev[0], ev[1]); st.forward_only()
+    binding.Event.bracket_next(ev[2], ev[3]); st.backward_only()
+    torch.cuda.synchronize()
+    tf.append(ev[0].elapsed_ms(ev[1])); tb.append(ev[2].elapsed_ms(ev[3]))
+pl = st.placement()
+from collections import Counter
+print(f"kernels: forward {np.median(tf):.4f} ms, reverse sweep {np.median(tb):.4f} ms; forward waves per SIMD {sorted(Counter(Counter(map(tuple, pl)).values()).items())}")
