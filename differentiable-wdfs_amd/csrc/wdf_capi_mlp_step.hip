@@ -113,7 +113,7 @@ int wdf_clipper_mlp_step_plan(void* state, int hidden, int n_layers, int64_t B, 
     if (reset) {
         wdf::MlpStepCtl c{};
         c.cold16 = cold16; c.w_min = w_min; c.w_max = w_max; c.slack = 2; c.cool_miss = 8; c.cool_shrink = 2;
-        c.tol = tol; c.grow_at = 0.6f; c.shrink_at = 0.6f;
+        c.tol = tol; c.grow_at = 0.6f; c.shrink_at = 0.6f; c.repair_at = 1.0f;
         ok(hipMemcpyAsync(base + L.ctl, &c, sizeof(c), hipMemcpyHostToDevice, s));
         std::vector<int32_t> w0((size_t)L.n_cols, warm16 > w_max ? w_max : warm16);
         ok(hipMemcpyAsync(base + L.wcol, w0.data(), w0.size() * 4, hipMemcpyHostToDevice, s));
@@ -151,10 +151,10 @@ int wdf_clipper_mlp_step_read(const void* state, int hidden, int n_layers, int64
 }
 
 // Controller knobs of a live state (device-side writes on the stream, no synchronisation): field = index into
-// MlpStepCtl as int32 words (6 slack, 7 cool_miss, 8 cool_shrink, 9 tol, 10 grow_at, 11 shrink_at, 12 freeze).
+// MlpStepCtl as int32 words (6 slack, 7 cool_miss, 8 cool_shrink, 9 tol, 10 grow_at, 11 shrink_at, 12 freeze, 13 repair_at).
 int wdf_clipper_mlp_step_set(void* state, int field, int32_t bits, void* stream)
 {
-    if (!state || field < 3 || field > 12) return fail(WDF_EINVAL, "wdf_clipper_mlp_step_set: field 3..12");
+    if (!state || field < 3 || field > 13) return fail(WDF_EINVAL, "wdf_clipper_mlp_step_set: field 3..13");
     const hipError_t e = hipMemcpyAsync((char*)state + 4 * (size_t)field, &bits, 4, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e != hipSuccess) return fail(WDF_ELAUNCH, "wdf_clipper_mlp_step_set: %s", hipGetErrorString(e));
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? WDF_OK : fail(WDF_ELAUNCH, "wdf_clipper_mlp_step_set: sync");

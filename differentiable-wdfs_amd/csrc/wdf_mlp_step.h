@@ -54,7 +54,8 @@ struct MlpStepCtl {                    // 128 bytes, device; the host reads it, 
     float grow_at;                     // arrival miss above grow_at * tol: one unit more (before it becomes a miss)
     float shrink_at;                   // ... the slack miss must be below shrink_at * tol
     int freeze;                        // 1: the controller leaves W alone (profiling one configuration)
-    int pad0[3];
+    float repair_at;                   // a re-run chunk has met the old trajectory when they agree to repair_at * tol
+    int pad0[2];
     // the last call's verdict [parity of the call]: {bad boundaries, max miss bits, columns with a flagged chunk,
     // columns that went sequential}
     int status[2][4];
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
         } else {
             // The repair: the flagged chunk again from the state its predecessor ended in -- but only as far as it takes:
             // after every block the new state is held against the OLD trajectory (the stash row of the next step, still
-            // untouched); once they agree to tol the rest of the chunk stands (a miss of a few tol is forgotten within
+            // untouched); once they agree to repair_at x tol the rest of the chunk stands (a miss of a few tol is forgotten within
             // a few dozen steps).  A chunk that reaches its end still off by more than that carries on into its successor's
             // steps -- unless the successor is being re-run itself (from a state that is now stale): then the column goes
             // sequential.
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
             const float* __restrict__ pp = DYN_R ? A.p + b * A.T : nullptr;
             const float* __restrict__ lp = DYN_R ? A.lr + b * A.T : nullptr;
             StepSpan sp{A.zend[(int64_t)(item - 1) * 16 + n]};    // (k > 0: only boundaries are flagged)
-            const float eps_c = ctl->tol;                         // (two fp32 runs of this path sit 1-3e-6 apart whatever they started from)
+            const float eps_c = ctl->repair_at * ctl->tol;       // (two fp32 runs of this path sit 1-3e-6 apart whatever they started from)
             int cur = item;                                       // the item whose steps are being rewritten
             int64_t t_end = it.t1;
             for (int64_t tb = it.t0; tb < A.T; tb += 16) {

@@ -102,3 +102,19 @@ def esr_step_allreduce(S_local, E_local, gP_local, gQ_local, n_global, eps):
     allreduce_sum_(buf)
     ga, gb, mse, esr = esr_coefficients(float(buf[0]), float(buf[1]), n_global, eps)
     return mse + esr, ga * buf[2:6] + gb * buf[6:10]
+
+
+def esr_two_exchange(forward_sums, backward, allreduce=None):
+    """The protocol of a sharded MSE + ESR step whose gradient is a long vector (the MLP-root step, mlp_root.MlpTrainStep: 609
+    weights -- the one-exchange form above would double the reverse sweep's matrix work to save one 16-byte message):
+        sums = forward_sums()        this rank's {S, E} (tensor [2], float64) after its forward
+        all-reduce(sums)             16 bytes
+        grad = backward(sums)        the reverse sweep with the GLOBAL sums (they decide dLoss/dy = ga (y - t) + gb y)
+        all-reduce(grad)             the weight gradient
+    -> (sums, grad), both global.  allreduce: the in-place SUM (default: allreduce_sum_)."""
+    ar = allreduce_sum_ if allreduce is None else allreduce
+    sums = forward_sums()
+    ar(sums)
+    grad = backward(sums)
+    ar(grad)
+    return sums, grad

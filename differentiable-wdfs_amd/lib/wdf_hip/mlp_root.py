@@ -655,12 +655,18 @@ class MlpTrainStep:
         if self.sums_allreduce is None and self.grad_allreduce is None:
             self._call(PHASE_FWD | PHASE_BWD, self.adam)
             return self.loss3
-        self._call(PHASE_FWD | PHASE_SUMS, None)
-        if self.sums_allreduce is not None:
-            self.sums_allreduce(self.sums)
-        self._call(PHASE_BWD | PHASE_GLOBAL_SUMS, None)
-        if self.grad_allreduce is not None:
-            self.grad_allreduce(self.gw)
+        from . import dist as wdist
+
+        def fwd():
+            self._call(PHASE_FWD | PHASE_SUMS, None)
+            return self.sums
+
+        def bwd(_sums):
+            self._call(PHASE_BWD | PHASE_GLOBAL_SUMS, None)
+            return self.gw
+
+        ar_s, ar_g = self.sums_allreduce or (lambda t: t), self.grad_allreduce or (lambda t: t)
+        wdist.esr_two_exchange(fwd, bwd, allreduce=lambda t: (ar_s if t is self.sums else ar_g)(t))
         if self.adam is not None:
             self.adam.apply(self.w, self.gw)
         return self.loss3

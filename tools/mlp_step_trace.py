@@ -13,6 +13,7 @@ import torch  # noqa: E402
 from wdf_hip import binding, mlp_root, workload  # noqa: E402
 
 net = sys.argv[1] if len(sys.argv) > 1 else "2x16_pre"
+net = {"2x16": "2x16_pre"}.get(net, net) if os.environ.get("PRE", "1") == "1" else net
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 B, T, fs, skip = 1340, 2048, workload.FS, 50
 dev = torch.device("cuda", 0)
@@ -25,7 +26,7 @@ target, _, _ = binding.clipper_fwd(x, th4, fs, r=r, want_stash=False)
 adam = binding.Adam(w.numel(), lr=1.0e-4, beta_1=0.5, device=dev)
 st = mlp_root.MlpTrainStep(x, r, target, w, hidden, n_layers, fs, workload.C_CLIPPER, skip=skip, adam=adam)
 f2i = lambda v: struct.unpack("i", struct.pack("f", float(v)))[0]  # noqa: E731
-for name, field, conv in (("SLACK", 6, int), ("COOL_MISS", 7, int), ("COOL_SHRINK", 8, int), ("GROW_AT", 10, f2i), ("SHRINK_AT", 11, f2i)):
+for name, field, conv in (("SLACK", 6, int), ("COOL_MISS", 7, int), ("COOL_SHRINK", 8, int), ("GROW_AT", 10, f2i), ("SHRINK_AT", 11, f2i), ("REPAIR_AT", 13, f2i)):
     if os.environ.get(name):
         binding._check(st.lib.wdf_clipper_mlp_step_set(binding._ptr(st.state), field, conv(os.environ[name]), binding._stream()), name)
 replan_at = int(os.environ.get("REPLAN_AT", 40))
