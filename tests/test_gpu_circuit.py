@@ -759,3 +759,87 @@ def test_resident_circuit_alternating_training_and_validation_sets(wdf):
         assert np.allclose(gd, gh, rtol=3e-4, atol=0)
     steppers = [e[0] for e in circ._res_cache.values()]
     assert all(s.warm is not None and s.warm.info()["valid"] == 3 for s in steppers)
+
+
+def _oracle_hpf(O, n_up=2, n_down=3):
+    nodes = [(O.NODE_RESISTOR, -1, -1, 0, -1, -1), (O.NODE_RES_VSOURCE, -1, -1, 1, 0, -1),
+             (O.NODE_CAPACITOR, -1, -1, 2, -1, -1), (O.NODE_SERIES, 1, 2, -1, -1, -1), (O.NODE_PARALLEL, 0, 3, -1, -1, -1)]
+    return O.Circuit(nodes, top=4, probe=0, n_in=1, root_kind=O.ROOT_DIODE_PAIR, fs=FS, p_is=3, p_nvt=4, n_up=n_up, n_down=n_down)
+
+
+def test_state_space_chunked_kernels_at_size_against_the_oracle(wdf, oracle):
+    """The time-parallel state-space kernels pinned DIRECTLY, at size: the HPF clipper (HPFDiodeClipper.h:28-32) at
+    2048 sequences x 4096 samples through time_parallel="auto" -- ss_fwd_tp_kernel with k_fwd >= 2 (asserted), cold, and
+    again warm-started after an Adam step (lowering.SsWarmStart: more chunks, a fraction of the warm-up) -- y of 16 picked
+    sequences and the five gradients (dLoss/dy non-zero on the picked sequences only, so the oracle's complex-step pass
+    over those sequences IS the whole gradient) against oracle.tree_fwd / tree_grad at the parameters of each call."""
+    from wdf_hip import lowering, binding as wb
+    tf = wdf.tf
+    O = oracle
+    B, T = 2048, 4096
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((B, T)) * 1.2).astype(np.float32)
+    pick = np.unique(np.linspace(0, B - 1, 16).astype(np.int64))
+    gy = np.zeros((T, B), dtype=np.float32)
+    gy[:, pick] = rng.standard_normal((T, len(pick))) / (len(pick) * T)
+    xd, gyd = cuda(x), cuda(gy)
+    circ, params = _hpf_clipper(wdf, "auto")
+    plan = lowering.plan_ss_time_parallel(circ.matrices()[0], circ.ns, circ.ni, wb.ROOT_DIODE_PAIR, B, T)
+    assert plan is not None and plan.k_fwd >= 2 and plan.k_bwd >= 2, plan
+    oc = _oracle_hpf(O)
+    opts = [tf.keras.optimizers.Adam(learning_rate=2.0e-3 * float(p)) for p in params]
+    seen = []
+    for call in range(3):
+        theta = np.array([float(p) for p in params], dtype=np.float32).astype(np.float64)
+        lowering.LAST_SS_TP_STATUS["status"] = None
+        with tf.GradientTape() as tape:
+            y = circ(xd)
+            loss = tf.reduce_sum(y * gyd)
+        grads = tape.gradient(loss, params)
+        st = wb.ss_tp_status(lowering.LAST_SS_TP_STATUS["status"])
+        k_used, w_used = lowering.LAST_SS_TP_STATUS.get("chunks_used"), lowering.LAST_SS_TP_STATUS.get("warmup_used")
+        seen.append((k_used, w_used))
+        assert k_used >= 2, (st, k_used)
+        yref = O.tree_fwd(oc, theta, x[pick].astype(np.float64))
+        e_y = float(np.max(np.abs(y.as_subclass(torch.Tensor).detach()[:, torch.as_tensor(pick, device="cuda")].cpu().numpy() - yref)))
+        gref = O.tree_grad(oc, theta, x[pick].astype(np.float64), gy[:, pick].astype(np.float64))
+        got = np.array([float(v) for v in grads])
+        print(f"call {call}: chunks {k_used}, warm-up {w_used}, verdict {st}; |y - oracle| {e_y:.2e}, gradient {rel(got, gref):.2e}")
+        assert e_y <= 4e-6                                        # (test_hpf_clipper_topology_vs_oracle: 3e-6 sequentially, + the 1e-6 boundary tolerance)
+        assert rel(got, gref) <= 3e-4
+        for o, g, p in zip(opts, grads, params):                  # the parameters move: the next call starts warm
+            o.apply_gradients([(g, p)])
+    assert seen[0] == (plan.k_fwd, plan.warmup)                   # cold, as planned
+    assert all(k > plan.k_fwd and w < plan.warmup for k, w in seen[1:]), seen   # warm-started: more chunks, less warm-up
+
+
+def test_two_state_chunked_reverse_sweep_at_size_against_the_oracle(wdf, oracle):
+    """The two-state clipper (no forward speculation: its Jacobian reaches |eigenvalue| 1) at 2048 x 4096: ss_bwd_tp_kernel
+    with k_bwd >= 2 -- y of the picked sequences and the seven gradients against the oracle."""
+    from wdf_hip import lowering, binding as wb
+    tf = wdf.tf
+    O = oracle
+    B, T = 2048, 4096
+    rng = np.random.default_rng(78)
+    x = (rng.standard_normal((B, T, 2)) * 1.2).astype(np.float32)
+    pick = np.unique(np.linspace(0, B - 1, 8).astype(np.int64))
+    gy = np.zeros((T, B), dtype=np.float32)
+    gy[:, pick] = rng.standard_normal((T, len(pick))) / (len(pick) * T)
+    circ, params = _two_state_clipper(wdf, "auto")
+    plan = lowering.plan_ss_time_parallel(circ.matrices()[0], circ.ns, circ.ni, wb.ROOT_DIODE_PAIR, B, T)
+    assert plan is not None and plan.k_bwd >= 2, plan
+    with tf.GradientTape() as tape:
+        y = circ(cuda(x))
+        loss = tf.reduce_sum(y * cuda(gy))
+    grads = tape.gradient(loss, params)
+    nodes = [(O.NODE_RES_VSOURCE, -1, -1, 0, 0, -1), (O.NODE_CAPACITOR, -1, -1, 1, -1, -1), (O.NODE_PARALLEL, 0, 1, -1, -1, -1),
+             (O.NODE_RESISTOR, -1, -1, 2, -1, -1), (O.NODE_RES_VSOURCE, -1, -1, 3, 1, -1), (O.NODE_SERIES, 3, 4, -1, -1, -1),
+             (O.NODE_CAPACITOR, -1, -1, 4, -1, -1), (O.NODE_PARALLEL, 5, 6, -1, -1, -1), (O.NODE_SERIES, 2, 7, -1, -1, -1)]
+    oc = O.Circuit(nodes, top=8, probe=6, n_in=2, root_kind=O.ROOT_DIODE_PAIR, fs=FS, p_is=5, p_nvt=6)
+    theta = np.array([float(p) for p in params], dtype=np.float32).astype(np.float64)
+    yref = O.tree_fwd(oc, theta, x[pick].astype(np.float64))
+    e_y = float(np.max(np.abs(y.as_subclass(torch.Tensor).detach()[:, torch.as_tensor(pick, device="cuda")].cpu().numpy() - yref)))
+    gref = O.tree_grad(oc, theta, x[pick].astype(np.float64), gy[:, pick].astype(np.float64))
+    got = np.array([float(v) for v in grads])
+    print(f"two-state clipper: plan {plan}; |y - oracle| {e_y:.2e}, gradient {rel(got, gref):.2e}")
+    assert e_y <= 4e-6 and rel(got, gref) <= 3e-4
