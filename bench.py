@@ -347,7 +347,7 @@ class Trainer:
                       file=sys.stderr, flush=True)
                 graph, self.args.graph = None, False
                 torch.cuda.synchronize()
-        every = max(4, -(-steps // 1024))                    # (at most ~1024 bracketed steps: events are not free in very long runs)
+        every = 1 if steps <= 64 else max(4, -(-steps // 1024))   # every step of a short run; at most ~1024 bracketed steps of a long one
         evs = [[binding.Event() for _ in range(n_ev)] if (i % every == 0 and graph is None) else None for i in range(steps)]
         wdist.barrier()
         torch.cuda.synchronize()
@@ -372,6 +372,85 @@ class Trainer:
         if self.world > 1:
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         return float(tmax), loss, grad
+
+
+def sustained_rate(trainer, Bg, T, ms_step, seconds=2.5):
+    """The same training loop kept running for `seconds` (the headline's timed region is a few milliseconds: the chip is
+    still cool and at its boost clock there).  Two clock stamps (s_memtime, read by a one-lane kernel on the launch stream)
+    bracket the loop: shader cycles / elapsed time = the clock the chip sustained."""
+    dev = trainer.theta.device
+    n = max(200, int(seconds / (ms_step * 1e-3)))
+    s0 = torch.zeros(2, dtype=torch.int64, device=dev)
+    s1 = torch.zeros(2, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    binding.clock_stamp(s0)
+    for _ in range(n):
+        trainer.step()
+    binding.clock_stamp(s1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    a, b = s0.cpu().numpy(), s1.cpu().numpy()
+    wall = float(b[1] - a[1]) / 100.0e6                         # s_memrealtime: 100 MHz
+    return {"value": Bg * T / (dt / n), "ms_per_step": dt / n * 1e3, "steps": n, "seconds": dt,
+            "shader_clock_mhz": None if wall <= 0 else float(b[0] - a[0]) / wall / 1e6,
+            "note": "the headline loop continued (same trainer, same state) for this long; clock = s_memtime ticks / s_memrealtime"}
+
+
+def forward_only(args, dev, fs, B=1024, T=4096, steps=100, warmup=10):
+    """BASELINE configs[1]: 1N4148 diode clipper FORWARD ONLY, 1024 sequences x 4096 samples: y written, no stash, nothing
+    carried between calls (every call warms its chunks up from z = 0: inference sees other data every call).  The chunk
+    count is picked by timing; y of the whole batch is checked against the fp64 oracle."""
+    x_host = workload.sweep_batch(B, T, seed=3)
+    x = torch.as_tensor(x_host, device=dev)
+    xk = x.t().contiguous()                                       # the engine's resident layout
+    theta = torch.tensor(workload.clipper_theta(), dtype=torch.float32, device=dev)
+    th_host = workload.clipper_theta()
+    plan = engine.plan_time_parallel(B, T, th_host[2], th_host[3], fs, time_major=True)
+    e0, e1 = binding.Event(), binding.Event()
+
+    def timed(k, n):
+        ws = torch.empty((max(16, binding.lib().wdf_clipper_fwd_tp_ws_bytes(B, k)),), dtype=torch.uint8, device=dev)
+        st = torch.zeros((4,), dtype=torch.int32, device=dev)
+        run = lambda: binding.clipper_fwd_tp(xk, theta, fs, k, plan.warmup, plan.tol, want_stash=False, ws=ws, status=st, time_major=True)  # noqa: E731
+        for _ in range(3):
+            out = run()
+        e0.record()
+        for _ in range(n):
+            out = run()
+        e1.record()
+        return e0.elapsed_ms(e1) / n, out[0], st
+
+    # (1024 sequences are 8 waves per chunk on a 1024-SIMD chip: the call is a latency chain of T / k + W steps, so many short chunks)
+    cands = sorted({k for k in (plan.k_fwd // 2, plan.k_fwd, plan.k_fwd * 2, plan.k_fwd * 4, plan.k_fwd * 8) if 2 <= k <= T // 32})
+    times = {k: timed(k, 10)[0] for k in cands}
+    k = min(times, key=times.get)
+    for _ in range(warmup):
+        binding.clipper_fwd_tp(xk, theta, fs, k, plan.warmup, plan.tol, want_stash=False, time_major=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_ev, y, st = timed(k, steps)
+    torch.cuda.synchronize()
+    out = {"value": B * T / (ms_ev * 1e-3), "unit": "samples/s", "ms_per_call": ms_ev, "chunks": k, "warmup_steps": plan.warmup,
+           "chunk_sweep_ms": {str(kk): v for kk, v in times.items()}, "verify_status": binding.tp_status(st),
+           "bytes_per_sample": 8, "hbm_frac": 8.0 * B * T / (ms_ev * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "workload": f"1N4148 diode clipper forward only, {B} sequences x {T} samples @ {int(fs)} Hz (BASELINE configs[1]); x resident "
+                       f"time-major, y written, stateless calls"}
+    if not args.no_parity:
+        O = _oracle()
+        y_ref = O.clipper_fwd(th_host.astype(np.float32).astype(np.float64), fs, x_host.astype(np.float64))
+        out["max_abs_y_vs_oracle"] = float(np.max(np.abs(y.cpu().numpy() - y_ref)))
+    return out
+
+
+def valu_cycle_model(B, T, k, w_used):
+    """VALU-active cycles per launch of the one-pass kernel when no committed SQ pass matches the autotuned plan: the count
+    is deterministic in the work -- a wave (128 sequences, two per lane) runs T / k + W steps per chunk -- and the committed
+    passes (profiles/r03_c_sq_counters.json: 32 chunks; r03_c16: 16 chunks; warm-up 16 steps both) fit
+        SQ_ACTIVE_INST_VALU = 124.65 quad-cycles per wave-step + 210 per wave
+    to better than 0.1 %."""
+    waves = (B + 127) // 128 * k
+    return 4.0 * (124.65 * waves * (T / k + w_used) + 210.0 * waves)
 
 
 def run_mlp_step(args, world, rank, local):
@@ -729,6 +808,10 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the after-the-run check of y and the gradient against the oracle")
     ap.add_argument("--no-batch-major", action="store_true", help="skip the second measurement with x as [B,T]")
     ap.add_argument("--no-cold", action="store_true", help="skip the third measurement: the stateless step (value_cold)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip value_sustained: the headline loop kept running for ~2.5 s")
+    ap.add_argument("--no-fwd-1024", action="store_true", help="skip value_fwd_1024: BASELINE configs[1], forward only at 1024 x 4096")
+    ap.add_argument("--config", default=None, choices=["c2"],
+                    help="c2: ONLY BASELINE configs[1] (1N4148 diode clipper forward-only, 1024 sequences x 4096 samples), its own JSON line")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="capture one training step (kernels, all-reduce, update) as a HIP graph and replay it in the timed loop. "
                          "auto: on when the step contains a collective (N > 1 or --force-dist) and for the five-launch MLP-root step, "
@@ -780,6 +863,20 @@ def main():
     if args.force_dist and world != 1:
         raise SystemExit("--force-dist is for world size 1")
     binding.require_gpu()
+    if args.config == "c2":
+        dev = torch.device("cuda", local)
+        r_ = forward_only(args, dev, workload.FS, steps=args.steps, warmup=args.warmup)
+        if rank == 0:
+            print(json.dumps({"metric": "samples/sec forward-only, 1N4148 diode clipper @48kHz, 1024 sequences x 4096 samples (BASELINE configs[1])",
+                              "value": r_["value"], "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": r_["ms_per_call"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "f32", "data": "synthetic", "config": {"workload": r_["workload"], "chunks": r_["chunks"],
+                                                                            "warmup_steps": r_["warmup_steps"]},
+                              "parity": {"max_abs_y": r_.get("max_abs_y_vs_oracle")},
+                              "roofline": {"bound": "hbm", "kernel": "clipper_fwd_tp_kernel", "achieved": 8.0 * r_["value"] / 1e9,
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_["hbm_frac"], "traffic": None},
+                              "detail": r_}), flush=True)
+        return
     if args.root != "diode":
         return (run_mlp_root if args.mlp_path == "unfused" else run_mlp_step)(args, world, rank, local)
     dev = torch.device("cuda", local)
@@ -830,6 +927,13 @@ def main():
         cold = {"value": Bg * T / (dt_c / args.steps), "ms_per_step": dt_c / args.steps * 1e3,
                 "chunks": None if cr.tp is None else cr.tp.k_fwd, "warmup_steps": None if cr.tp is None else cr.tp.warmup}
         del cr
+
+    # the loop kept running (after the headline's burst of a few milliseconds), and BASELINE configs[1] (forward only)
+    sustained = fwd1024 = None
+    if rank == 0 and world == 1 and not args.no_sustained and main_run.fused and not args.graph:
+        sustained = sustained_rate(main_run, Bg, T, dt / args.steps * 1e3)
+    if rank == 0 and world == 1 and not args.no_fwd_1024 and args.loss == "mse":
+        fwd1024 = forward_only(args, dev, fs)
 
     if rank == 0:
         copy_gbs = copy_bandwidth_gbs(dev)
@@ -889,6 +993,10 @@ def main():
             "parity": parity,
             "value_cold": None if cold is None else cold["value"],
             "cold": cold,
+            "value_sustained": None if sustained is None else sustained["value"],
+            "sustained": sustained,
+            "value_fwd_1024": None if fwd1024 is None else fwd1024["value"],
+            "fwd_1024": fwd1024,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -902,12 +1010,16 @@ def main():
             # (12 B/sample) and, demoted, SURVEY 8d's forward + backward equivalent (24 B/sample: the work one launch does).
             moved = BYTES_STEP_MOVED * B * T / (dom_ms * 1e-3) / 1e9
             valu, valu_src = (None, None) if tp is None else measured_valu_cycles(dom, key)
+            frac_kind = "VALU-active cycles of a COMMITTED counter pass of this configuration / this run's kernel time"
+            if valu is None and tp is not None and key.get("x_layout") == "time-major" and args.loss == "mse":
+                valu, valu_src = valu_cycle_model(B, T, tp.k_fwd, w_used or 0), "instruction-count model (bench.py valu_cycle_model)"
+                frac_kind = "VALU-active cycles from the instruction-count model fitted to the committed passes / this run's kernel time"
             peak = N_SIMD * VALU_CLOCK_GHZ
             ach = None if valu is None else valu / (dom_ms * 1e-3) / 1e9
             out["roofline"] = {
                 "bound": "valu", "kernel": dom, "achieved": ach, "peak": peak, "unit": "G VALU-active cycles/s (chip)",
                 "frac": None if ach is None else ach / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "valu_source": valu_src, "step_kernel_ms": f_ms,
+                "valu_source": valu_src, "frac_kind": frac_kind, "step_kernel_ms": f_ms,
                 "hbm": {"bytes_moved_per_sample": BYTES_STEP_MOVED, "moved": moved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac_moved": moved / HBM_PEAK_GBS,
                         "frac_traffic": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -124,6 +124,21 @@ void wdf_event_bracket_next(void* start, void* stop)
     g_ev1.store((hipEvent_t)stop);
 }
 
+// out[0] = the shader clock counter (s_memtime), out[1] = the constant-rate counter (s_memrealtime, 100 MHz), read by a
+// one-lane kernel on `stream`: two stamps around a stretch of work give the clock the chip ran at while doing it.
+static __global__ void clock_stamp_kernel(unsigned long long* out)
+{
+    out[0] = (unsigned long long)clock64();
+    out[1] = (unsigned long long)wall_clock64();
+}
+
+int wdf_clock_stamp(uint64_t* out, void* stream)
+{
+    if (!out) return fail(WDF_EINVAL, "null out");
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)out);
+    return check_launch("wdf_clock_stamp");
+}
+
 void wdf_event_destroy(void* ev)
 {
     if (ev) (void)hipEventDestroy((hipEvent_t)ev);

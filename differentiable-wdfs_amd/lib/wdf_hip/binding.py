@@ -222,6 +222,8 @@ def lib():
     L.wdf_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.wdf_event_destroy.restype = None
     L.wdf_event_destroy.argtypes = [vp]
+    L.wdf_clock_stamp.restype = ci
+    L.wdf_clock_stamp.argtypes = [vp, vp]
     L.wdf_event_bracket_next.restype = None
     L.wdf_event_bracket_next.argtypes = [vp, vp]
     _lib = L
@@ -249,6 +251,7 @@ EXPORTED_SYMBOLS = (
     "wdf_ss_tp_chunks", "wdf_ss_tp_starts", "wdf_ss_fwd_tp_ws_bytes", "wdf_ss_fwd_tp", "wdf_ss_bwd_tp_ws_bytes", "wdf_ss_bwd_tp",
     "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy", "wdf_event_bracket_next",
+    "wdf_clock_stamp",
 )
 
 
@@ -1140,6 +1143,11 @@ class Adam:
         rc = lib().wdf_adam_step(_ptr(theta), _ptr(grad), _ptr(self.m), _ptr(self.v), _ptr(self.step), _ptr(self.lr),
                                  self.b1, self.b2, self.eps, _ptr(self.lo), _ptr(self.hi), self.n, _stream())
         _check(rc, "wdf_adam_step")
+
+
+def clock_stamp(out):
+    """out: int64 device tensor [2] <- {shader clock counter, 100 MHz counter} when the stream gets here."""
+    _check(lib().wdf_clock_stamp(_ptr(out), _stream()), "wdf_clock_stamp")
 
 
 def device_info(device=0):

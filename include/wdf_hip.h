@@ -532,6 +532,10 @@ int wdf_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on
  * for that kernel.                                                                        */
 void wdf_event_bracket_next(void* start, void* stop);
 void wdf_event_destroy(void* ev);
+/* out (device uint64[2]) <- {shader clock counter (s_memtime), constant-rate counter (s_memrealtime, 100 MHz)} when the
+ * stream reaches this point: two stamps around a stretch of work give the clock the chip sustained over it
+ * (bench.py value_sustained).                                                                */
+int wdf_clock_stamp(uint64_t* out, void* stream);
 
 #ifdef __cplusplus
 }
