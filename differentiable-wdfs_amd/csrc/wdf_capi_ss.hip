@@ -3,6 +3,7 @@
 // 
 #include "wdf_capi_common.h"
 #include "wdf_statespace.h"
+#include "wdf_ss_step.h"
 #include "wdf_asym.h"
 using namespace wdfcapi;
 
@@ -366,6 +367,73 @@ int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, doubl
         hipLaunchKernelGGL((wdf::asym_root_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, theta6, fs, b,
                            tol, max_iter, n);
     return check_launch("wdf_asym_root");
+}
+
+// ---- the one-pass MSE step of linear trees (wdf_ss_step.h) -------------------------------------------------------------
+int wdf_ss_probe(const int32_t* tape, int n_ops, const double* consts, const float* params, int n_params, const int32_t* outs,
+                 int n_out, float* coef, double* coef64, double* jac, void* stream)
+{
+    if (!tape || !consts || !params || !outs || !coef || !coef64 || !jac) return fail(WDF_EINVAL, "null argument");
+    if (n_ops < 1 || n_ops > wdf::kProbeMaxOps) return fail(WDF_EUNSUPPORTED, "wdf_ss_probe: 1..%d operations (got %d)", wdf::kProbeMaxOps, n_ops);
+    if (n_params < 1 || n_params > wdf::kProbeMaxParams) return fail(WDF_EUNSUPPORTED, "wdf_ss_probe: 1..%d parameters (got %d)", wdf::kProbeMaxParams, n_params);
+    if (n_out < 1) return fail(WDF_EINVAL, "n_out >= 1");
+    hipLaunchKernelGGL(wdf::ss_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tape, n_ops, consts, params, n_params, outs,
+                       n_out, coef, coef64, jac);
+    return check_launch("wdf_ss_probe");
+}
+
+static bool lin_step_ok(int ns, int ni) { return ns >= 0 && ns <= 2 && ni >= 1 && ni <= 2; }
+static int lin_step_d(int ns, int ni) { return ns * (1 + ns * ns + ns * ni); }
+static int lin_step_g(int ns, int ni) { return ns * ns + ns * ni + ns + ni; }
+static void lin_step_geom(int64_t T, int n_chunks, int64_t& L, int& K)
+{
+    if (n_chunks < 1) n_chunks = 1;
+    L = (T + n_chunks - 1) / n_chunks;
+    L = (L + 31) / 32 * 32;
+    K = (int)((T + L - 1) / L);
+}
+
+size_t wdf_ss_lin_step_ws_bytes(int ns, int ni, int64_t B, int64_t T, int n_chunks)
+{
+    if (!lin_step_ok(ns, ni) || B <= 0 || T <= 0 || n_chunks < 1) return 0;
+    int64_t L; int K;
+    lin_step_geom(T, n_chunks, L, K);
+    const size_t waves = (size_t)((B + 63) / 64) * (size_t)K;
+    return 256 + (size_t)2 * (size_t)K * (size_t)lin_step_d(ns, ni) * (size_t)B * sizeof(float) + 256 +
+           waves * (size_t)(lin_step_g(ns, ni) + 1) * sizeof(double);
+}
+
+// x: [T][ni][B] time-major (the resident training set); coef / jac: wdf_ss_probe's outputs; target, y: [T][B].
+// ws: wdf_ss_lin_step_ws_bytes() bytes, ZERO before the first call (the step leaves it clean).
+// out: float [1 + n_params] = {sum of squared errors, d(gscale/2 x that sum)/d component value}; gcoef_out: float
+// [ns^2 + ns ni + ns + ni] (dLoss/d{A, Bx, cy, dy}) or NULL.
+int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, int n_params, int ns, int ni, const float* target,
+                        float gscale, float* y, void* ws, float* out, float* gcoef_out, int64_t B, int64_t T, int n_chunks,
+                        void* stream)
+{
+    if (!x || !coef || !jac || !target || !y || !ws || !out) return fail(WDF_EINVAL, "null argument");
+    if (!lin_step_ok(ns, ni)) return fail(WDF_EUNSUPPORTED, "wdf_ss_lin_step_mse: ns in 0..2, ni in 1..2 (got %d, %d)", ns, ni);
+    if (B <= 0 || T <= 0 || n_chunks < 1 || n_params < 1 || n_params > wdf::kProbeMaxParams) return fail(WDF_EINVAL, "B, T, n_chunks >= 1, 1..7 parameters");
+    int64_t L; int K;
+    lin_step_geom(T, n_chunks, L, K);
+    const int D = lin_step_d(ns, ni);
+    unsigned* ticket = (unsigned*)ws;
+    float* uend0 = (float*)((char*)ws + 256);
+    float* ustart = uend0 + (size_t)K * (size_t)D * (size_t)B;
+    double* part = (double*)(((uintptr_t)(ustart + (size_t)K * (size_t)D * (size_t)B) + 255) & ~(uintptr_t)255);
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K), one((unsigned)((B + 63) / 64));
+    hipStream_t s = (hipStream_t)stream;
+#define WDF_LIN_STEP(NS_, NI_)                                                                                     \
+    if (ns == NS_ && ni == NI_) {                                                                                  \
+        if (NS_ > 0 && K > 1)                                                                                      \
+            hipLaunchKernelGGL((wdf::ss_lin_step_zero_kernel<NS_, NI_>), grid, dim3(64), 0, s, x, coef, uend0, B, T, L);   \
+        EventBracket bracket(s);                                                                                   \
+        hipLaunchKernelGGL((wdf::ss_lin_step_kernel<NS_, NI_>), grid, dim3(64), 0, s, x, coef, (const float*)nullptr, (const float*)uend0, \
+                           target, gscale, y, part, ticket, jac, n_params, out, gcoef_out, B, T, L);               \
+    }
+    WDF_LIN_STEP(0, 1) WDF_LIN_STEP(0, 2) WDF_LIN_STEP(1, 1) WDF_LIN_STEP(1, 2) WDF_LIN_STEP(2, 1) WDF_LIN_STEP(2, 2)
+#undef WDF_LIN_STEP
+    return check_launch("wdf_ss_lin_step_mse");
 }
 
 }  // extern "C"

@@ -1,0 +1,459 @@
+// wdf_ss_step.h -- the one-pass MSE training step for LINEAR state-space trees (lpf.py:20-49,86-99: the RC lowpass with
+// its ideal-source root folded in; voltage_divider.py:19-46), gfx950.
+//
+//     z' = A z + Bx x ;  y = cy . z + dy . x          (csrc/wdf_statespace.h with E = ca = da = fy = 0)
+//
+// wdf_statespace.h runs forward + stash, then a reverse sweep, and torch chains dLoss/d(coefficients) to the component
+// values through the host probe (lowering.Circuit.matrices): 28 G samples/s through the element API, host-bound.  Here
+// the step is the diode clipper's one-pass idea on the simpler recursion:
+//
+//   * the gradient is carried FORWARD: S_c = dz/dc for every state coefficient c in {A, Bx} obeys
+//         S_c' = A S_c + (dz'/dc explicit) ,   dLoss/dc = sum_n g_n cy . S_c[n] ,   g_n = 2 (y_n - t_n) / N
+//     (cy, dy: direct).  No stash, no second pass over the time axis, x read once per pass;
+//   * chunks in time are EXACT, not speculated: the joint recursion u = (z, S_A.., S_B..) is linear,
+//         u(t0 + L) = Phi u(t0) + (response of the chunk's inputs from u = 0) ,   Phi = {A^L, G_c}
+//     so pass 1 runs every chunk from u = 0 (x only), one lane per sequence walks the chunks, and pass 2 runs every chunk
+//     again from its exact start with the loss: 16 B per sample through HBM (x twice, target, y) -- an RC lowpass needs
+//     760 steps of warm-up to forget its state, speculation would be hopeless;
+//   * the chain rule to the component values happens on the device: ss_probe_kernel evaluates the probed step
+//     (lib/wdf_hip/probe_tape.py: the elements' own calc_impedance / reflected / incident code, recorded once) in float64
+//     with forward-mode tangents -> coefficients and their Jacobian; the step's finishing wave contracts it with the
+//     coefficient gradient.  The component values never leave the device (Circuit.to_device).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wdf_statespace.h"
+#include "wdf_clipper.h"      // wave_sum_dpp
+
+namespace wdf {
+
+constexpr int kProbeMaxOps = 384, kProbeMaxParams = 7, kProbeLanes = 8;
+enum { kOpConst = 0, kOpParam, kOpAdd, kOpSub, kOpMul, kOpDiv, kOpNeg, kOpRecip };
+
+// tape: int32 [n_ops][3] = {op, a, b}; consts: double; params: the float32 block the component values live in.
+// outs: node of every output (the coefficient vector, then the port resistance).  -> coef (float32 and float64) and
+// jac double [n_out][n_params].  One wave: lane p carries the tangent w.r.t. parameter p (values are computed by all).
+static __global__ __launch_bounds__(64) void ss_probe_kernel(const int32_t* __restrict__ tape, int n_ops, const double* __restrict__ consts,
+                                                             const float* __restrict__ params, int n_params, const int32_t* __restrict__ outs,
+                                                             int n_out, float* __restrict__ coef, double* __restrict__ coef64,
+                                                             double* __restrict__ jac)
+{
+    __shared__ double val[kProbeMaxOps][kProbeLanes], tan[kProbeMaxOps][kProbeLanes];
+    __shared__ int ops[kProbeMaxOps * 3];
+    __shared__ double leaf[kProbeMaxOps];                         // the value of every CONST / PARAM node
+    for (int i = threadIdx.x; i < 3 * n_ops; i += 64) ops[i] = tape[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_ops; i += 64) {               // (all leaves fetched at once: no dependent global loads below)
+        const int op = ops[3 * i], a = ops[3 * i + 1];
+        leaf[i] = op == kOpConst ? consts[a] : (op == kOpParam ? (double)params[a] : 0.0);
+    }
+    __syncthreads();
+    const int p = threadIdx.x;
+    if (p >= kProbeLanes) return;
+    int nop = ops[0], na = ops[1], nb = ops[2];
+    for (int i = 0; i < n_ops; ++i) {
+        const int op = nop, a = na, b = nb;
+        if (i + 1 < n_ops) { nop = ops[3 * i + 3]; na = ops[3 * i + 4]; nb = ops[3 * i + 5]; }   // (the next instruction is fetched under this one)
+        double v = 0.0, t = 0.0;
+        switch (op) {
+        case kOpConst: v = leaf[i]; break;
+        case kOpParam: v = leaf[i]; t = (a == p) ? 1.0 : 0.0; break;
+        case kOpAdd: v = val[a][p] + val[b][p]; t = tan[a][p] + tan[b][p]; break;
+        case kOpSub: v = val[a][p] - val[b][p]; t = tan[a][p] - tan[b][p]; break;
+        case kOpMul: v = val[a][p] * val[b][p]; t = tan[a][p] * val[b][p] + val[a][p] * tan[b][p]; break;
+        case kOpDiv: { const double q = val[a][p] / val[b][p]; v = q; t = (tan[a][p] - q * tan[b][p]) / val[b][p]; break; }
+        case kOpNeg: v = -val[a][p]; t = -tan[a][p]; break;
+        case kOpRecip: { const double r = 1.0 / val[a][p]; v = r; t = -r * r * tan[a][p]; break; }
+        }
+        val[i][p] = v;
+        tan[i][p] = t;
+    }
+    for (int o = 0; o < n_out; ++o) {
+        const int nd = outs[o];
+        if (p == 0) { coef[o] = (float)val[nd][0]; coef64[o] = val[nd][0]; }
+        if (p < n_params) jac[o * n_params + p] = tan[nd][p];
+    }
+}
+
+// ---- the joint recursion ------------------------------------------------------------------------------------------------
+template <int NS, int NI>
+struct LinU {
+    static constexpr int nA = NS * NS, nB = NS * NI;
+    static constexpr int kD = NS * (1 + nA + nB);                // floats per sequence: z, S_A[nA][NS], S_B[nB][NS]
+    static constexpr int kG = nA + nB + NS + NI;                 // gradient entries: A, Bx, cy, dy
+    float z[NS > 0 ? NS : 1];
+    float SA[nA > 0 ? nA : 1][NS > 0 ? NS : 1];
+    float SB[nB > 0 ? nB : 1][NS > 0 ? NS : 1];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) z[s] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < nA; ++c)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) SA[c][s] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < nB; ++c)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) SB[c][s] = 0.0f;
+    }
+    // [kD][B] planes at p (p already points at this lane's column)
+    __device__ __forceinline__ void store(float* __restrict__ p, int64_t B) const
+    {
+        int o = 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) p[(o++) * B] = z[s];
+#pragma unroll
+        for (int c = 0; c < nA; ++c)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) p[(o++) * B] = SA[c][s];
+#pragma unroll
+        for (int c = 0; c < nB; ++c)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) p[(o++) * B] = SB[c][s];
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ p, int64_t B)
+    {
+        int o = 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) z[s] = p[(o++) * B];
+#pragma unroll
+        for (int c = 0; c < nA; ++c)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) SA[c][s] = p[(o++) * B];
+#pragma unroll
+        for (int c = 0; c < nB; ++c)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) SB[c][s] = p[(o++) * B];
+    }
+};
+
+// one step of u = (z, S_A, S_B) with input x
+template <int NS, int NI>
+__device__ __forceinline__ void lin_u_step(const SSCoef<NS, NI>& c, const float (&x)[NI], LinU<NS, NI>& u)
+{
+    using C = SSCoef<NS, NI>;
+    float zn[NS > 0 ? NS : 1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a = fmaf(c.v[C::oB + s * NI + i], x[i], a);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) a = fmaf(c.v[C::oA + s * NS + q], u.z[q], a);
+        zn[s] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {                            // S_{A_ij}' = A S + e_i z_j
+            float sn[NS > 0 ? NS : 1];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float a = (s == i) ? u.z[j] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) a = fmaf(c.v[C::oA + s * NS + q], u.SA[i * NS + j][q], a);
+                sn[s] = a;
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) u.SA[i * NS + j][s] = sn[s];
+        }
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {                            // S_{Bx_ij}' = A S + e_i x_j
+            float sn[NS > 0 ? NS : 1];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float a = (s == i) ? x[j] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) a = fmaf(c.v[C::oA + s * NS + q], u.SB[i * NI + j][q], a);
+                sn[s] = a;
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) u.SB[i * NI + j][s] = sn[s];
+        }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) u.z[s] = zn[s];
+}
+
+constexpr int kLinBlk = 8;                                         // steps whose loads are issued together
+
+// x: [T][NI][B] (time-major: the engine's resident training set); loads kLinBlk steps of lane b
+template <int NI>
+__device__ __forceinline__ void lin_load_x(const float* __restrict__ x, int64_t B, int64_t b, int64_t t, int n, float (&xs)[kLinBlk][NI])
+{
+#pragma unroll
+    for (int k = 0; k < kLinBlk; ++k)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xs[k][i] = (k < n) ? x[((t + k) * NI + i) * B + b] : 0.0f;
+}
+
+// ---- pass 1: every chunk from u = 0 -> uend0 [K][kD][B] ------------------------------------------------------------------
+template <int NS, int NI>
+__global__ __launch_bounds__(64) void ss_lin_step_zero_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                              float* __restrict__ uend0, int64_t B, int64_t T, int64_t L)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t k = blockIdx.y, t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+    if (t1 == T) return;                                          // (nothing comes after the last chunk)
+    SSCoef<NS, NI> c;
+    c.load(coef);
+    LinU<NS, NI> u;
+    u.zero();
+    for (int64_t tb = t0; tb < t1; tb += kLinBlk) {
+        const int n = t1 - tb < kLinBlk ? (int)(t1 - tb) : kLinBlk;
+        float xs[kLinBlk][NI];
+        lin_load_x<NI>(x, B, b, tb, n, xs);
+#pragma unroll
+        for (int i = 0; i < kLinBlk; ++i)
+            if (i < n) lin_u_step<NS, NI>(c, xs[i], u);
+    }
+    if (b_raw < B) u.store(uend0 + (k * LinU<NS, NI>::kD) * B + b, B);
+}
+
+// ---- the walk: ustart [K][kD][B], exact ----------------------------------------------------------------------------------
+// Phi: a chunk run from z = e_j (S = 0, no input) ends in z = A^L e_j, S_{A c} = G_c e_j; S_B's homogeneous part is A^L too.
+template <int NS, int NI>
+__global__ __launch_bounds__(64) void ss_lin_step_starts_kernel(const float* __restrict__ coef, const float* __restrict__ uend0,
+                                                                float* __restrict__ ustart, int64_t B, int64_t K, int64_t L)
+{
+    using U = LinU<NS, NI>;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    SSCoef<NS, NI> c;
+    c.load(coef);
+    float AL[NS > 0 ? NS : 1][NS > 0 ? NS : 1], G[U::nA > 0 ? U::nA : 1][NS > 0 ? NS : 1][NS > 0 ? NS : 1];
+    const float zero_x[NI] = {};
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        U h;
+        h.zero();
+        h.z[j] = 1.0f;
+        for (int64_t t = 0; t < L; ++t) lin_u_step<NS, NI>(c, zero_x, h);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) AL[s][j] = h.z[s];
+#pragma unroll
+        for (int cc = 0; cc < U::nA; ++cc)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) G[cc][s][j] = h.SA[cc][s];
+    }
+    U u;
+    u.zero();                                                     // reset(): zero initial state (Circuit.__call__'s default)
+    for (int64_t k = 0; k < K; ++k) {
+        if (b_raw < B) u.store(ustart + (k * U::kD) * B + b, B);
+        if (k + 1 == K) break;
+        U p;
+        p.load(uend0 + (k * U::kD) * B + b, B);
+        U n;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float a = p.z[s];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) a = fmaf(AL[s][q], u.z[q], a);
+            n.z[s] = a;
+        }
+#pragma unroll
+        for (int cc = 0; cc < U::nA; ++cc)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float a = p.SA[cc][s];
+#pragma unroll
+                for (int q = 0; q < NS; ++q) a = fmaf(AL[s][q], u.SA[cc][q], fmaf(G[cc][s][q], u.z[q], a));
+                n.SA[cc][s] = a;
+            }
+#pragma unroll
+        for (int cc = 0; cc < U::nB; ++cc)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float a = p.SB[cc][s];
+#pragma unroll
+                for (int q = 0; q < NS; ++q) a = fmaf(AL[s][q], u.SB[cc][q], a);
+                n.SB[cc][s] = a;
+            }
+        u = n;
+    }
+}
+
+// u <- the exact joint state at the start of chunk k (zero initial state), from the zero-state chunk ends uend0 [K][kD][B]
+template <int NS, int NI>
+__device__ __forceinline__ void lin_walk_to(const SSCoef<NS, NI>& c, const float* __restrict__ uend0, int64_t B, int64_t b,
+                                            int64_t k, int64_t L, LinU<NS, NI>& u)
+{
+    using U = LinU<NS, NI>;
+    float AL[NS > 0 ? NS : 1][NS > 0 ? NS : 1], G[U::nA > 0 ? U::nA : 1][NS > 0 ? NS : 1][NS > 0 ? NS : 1];
+    const float zero_x[NI] = {};
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        U h;
+        h.zero();
+        h.z[j] = 1.0f;
+        for (int64_t t = 0; t < L; ++t) lin_u_step<NS, NI>(c, zero_x, h);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) AL[s][j] = h.z[s];
+#pragma unroll
+        for (int cc = 0; cc < U::nA; ++cc)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) G[cc][s][j] = h.SA[cc][s];
+    }
+    U p;
+    p.load(uend0 + b, B);
+    for (int64_t q = 0; q < k; ++q) {
+        U pn = p;
+        if (q + 1 < k) pn.load(uend0 + ((q + 1) * U::kD) * B + b, B);   // (the next chunk's end is on its way while this one is applied)
+        U n;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float a = p.z[s];
+#pragma unroll
+            for (int r = 0; r < NS; ++r) a = fmaf(AL[s][r], u.z[r], a);
+            n.z[s] = a;
+        }
+#pragma unroll
+        for (int cc = 0; cc < U::nA; ++cc)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float a = p.SA[cc][s];
+#pragma unroll
+                for (int r = 0; r < NS; ++r) a = fmaf(AL[s][r], u.SA[cc][r], fmaf(G[cc][s][r], u.z[r], a));
+                n.SA[cc][s] = a;
+            }
+#pragma unroll
+        for (int cc = 0; cc < U::nB; ++cc)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float a = p.SB[cc][s];
+#pragma unroll
+                for (int r = 0; r < NS; ++r) a = fmaf(AL[s][r], u.SB[cc][r], a);
+                n.SB[cc][s] = a;
+            }
+        u = n;
+        p = pn;
+    }
+}
+
+// ---- pass 2: every chunk from its exact start: y, the squared error, the coefficient gradient; the last wave finishes ------
+// part: double [waves][kG + 1] = {gA.., gBx.., gcy.., gdy.., SSE}; ticket: one word, left 0.
+// jac: double [ncoef (+1)][n_params] of ss_probe_kernel (rows in SSCoef order).  out: float [1 + n_params] = {SSE, dLoss/dparam}.
+template <int NS, int NI>
+__global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                         const float* __restrict__ ustart, const float* __restrict__ uend0,
+                                                         const float* __restrict__ target,
+                                                         float gscale, float* __restrict__ y, double* __restrict__ part,
+                                                         unsigned* __restrict__ ticket, const double* __restrict__ jac, int n_params,
+                                                         float* __restrict__ out, float* __restrict__ gcoef_out, int64_t B, int64_t T,
+                                                         int64_t L)
+{
+    using U = LinU<NS, NI>;
+    using C = SSCoef<NS, NI>;
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    const int64_t k = blockIdx.y, t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+    SSCoef<NS, NI> c;
+    c.load(coef);
+    U u;
+    if (ustart != nullptr) {
+        u.load(ustart + (k * U::kD) * B + b, B);
+    } else {
+        // the chunk's exact start, by this wave itself: Phi = {A^L, G_c} from L homogeneous steps, then the walk over the
+        // chunks before it (their zero-state ends: pass 1) -- a launch and its latency less than the separate walk
+        u.zero();
+        if (NS > 0 && k > 0) lin_walk_to<NS, NI>(c, uend0, B, b, k, L, u);
+    }
+    double acc[U::kG + 1];
+#pragma unroll
+    for (int i = 0; i <= U::kG; ++i) acc[i] = 0.0;
+    for (int64_t tb = t0; tb < t1; tb += 4 * kLinBlk) {           // fp32 sums within 32 steps, fp64 across
+        float f[U::kG + 1];
+#pragma unroll
+        for (int i = 0; i <= U::kG; ++i) f[i] = 0.0f;
+#pragma unroll 1
+        for (int64_t ts = tb; ts < tb + 4 * kLinBlk && ts < t1; ts += kLinBlk) {
+            const int n = t1 - ts < kLinBlk ? (int)(t1 - ts) : kLinBlk;
+            float xs[kLinBlk][NI], tg[kLinBlk];
+            lin_load_x<NI>(x, B, b, ts, n, xs);
+#pragma unroll
+            for (int i = 0; i < kLinBlk; ++i) tg[i] = (i < n) ? target[(ts + i) * B + b] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < kLinBlk; ++i) {
+                if (i >= n) break;
+                float yv = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) yv = fmaf(c.v[C::oDy + j], xs[i][j], yv);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) yv = fmaf(c.v[C::oCy + s], u.z[s], yv);
+                const float e = yv - tg[i];
+                const float g = live ? gscale * e : 0.0f;
+                if (live) __builtin_nontemporal_store(yv, y + (ts + i) * B + b);
+                f[U::kG] = fmaf(live ? e : 0.0f, e, f[U::kG]);
+#pragma unroll
+                for (int cc = 0; cc < U::nA; ++cc) {
+                    float d = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) d = fmaf(c.v[C::oCy + s], u.SA[cc][s], d);
+                    f[cc] = fmaf(g, d, f[cc]);
+                }
+#pragma unroll
+                for (int cc = 0; cc < U::nB; ++cc) {
+                    float d = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) d = fmaf(c.v[C::oCy + s], u.SB[cc][s], d);
+                    f[U::nA + cc] = fmaf(g, d, f[U::nA + cc]);
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) f[U::nA + U::nB + s] = fmaf(g, u.z[s], f[U::nA + U::nB + s]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) f[U::nA + U::nB + NS + j] = fmaf(g, xs[i][j], f[U::nA + U::nB + NS + j]);
+                lin_u_step<NS, NI>(c, xs[i], u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i <= U::kG; ++i) acc[i] += (double)f[i];
+    }
+    // ---- this wave's partial; the last wave of the launch adds them up in a fixed order and applies the chain rule
+    const int64_t wave = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwaves = (int64_t)gridDim.x * gridDim.y;
+#pragma unroll
+    for (int i = 0; i <= U::kG; ++i) {
+        const double s = wave_sum_dpp(acc[i]);
+        if (threadIdx.x == 0) __hip_atomic_store(part + wave * (U::kG + 1) + i, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned old = 0;
+    if (threadIdx.x == 0) old = atomicAdd(ticket, 1u);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(nwaves - 1)) return;
+    if (threadIdx.x == 0) *ticket = 0u;
+    double tot[U::kG + 1];
+#pragma unroll
+    for (int i = 0; i <= U::kG; ++i) {
+        double s = 0.0;
+        for (int64_t w = threadIdx.x; w < nwaves; w += 64)
+            s += __hip_atomic_load(part + w * (U::kG + 1) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[i] = wave_sum_dpp(s);
+    }
+    // coefficient index (SSCoef order) of gradient entry i
+    const int p = threadIdx.x;
+    if (p < n_params) {
+        double gp = 0.0;
+#pragma unroll
+        for (int i = 0; i < U::kG; ++i) {
+            const int row = i < U::nA ? C::oA + i : (i < U::nA + U::nB ? C::oB + (i - U::nA)
+                                                     : (i < U::nA + U::nB + NS ? C::oCy + (i - U::nA - U::nB) : C::oDy + (i - U::nA - U::nB - NS)));
+            gp += tot[i] * jac[row * n_params + p];
+        }
+        out[1 + p] = (float)gp;
+    }
+    if (p == 0) {
+        out[0] = (float)tot[U::kG];
+        if (gcoef_out) {
+#pragma unroll
+            for (int i = 0; i < U::kG; ++i) gcoef_out[i] = (float)tot[i];
+        }
+    }
+}
+
+}  // namespace wdf

@@ -183,6 +183,12 @@ def lib():
     L.wdf_clipper_mlp_step.restype = ci
     L.wdf_clipper_mlp_step.argtypes = [fp, fp, fp, fp, fp, ci, ci, ci, cf, fp, i64, C.c_double, C.c_double, fp, fp, fp, vp, i64, i64,
                                        ci, ci, ci, vp, fp, fp, fp, fp, fp, vp, fp, cf, cf, cf, vp]
+    L.wdf_ss_probe.restype = ci
+    L.wdf_ss_probe.argtypes = [vp, ci, vp, fp, ci, vp, ci, fp, vp, vp, vp]
+    L.wdf_ss_lin_step_ws_bytes.restype = C.c_size_t
+    L.wdf_ss_lin_step_ws_bytes.argtypes = [ci, ci, i64, i64, ci]
+    L.wdf_ss_lin_step_mse.restype = ci
+    L.wdf_ss_lin_step_mse.argtypes = [fp, fp, vp, ci, ci, ci, fp, cf, fp, vp, fp, fp, i64, i64, ci, vp]
     L.wdf_ss_ncoef.restype = ci
     L.wdf_ss_ncoef.argtypes = [ci, ci]
     L.wdf_ss_fwd.restype = ci
@@ -247,6 +253,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
     "wdf_clipper_mlp_step_state_bytes", "wdf_clipper_mlp_step_plan", "wdf_clipper_mlp_step_read", "wdf_clipper_mlp_step_set",
     "wdf_clipper_mlp_step_set_wcol", "wdf_clipper_mlp_step_prepare", "wdf_clipper_mlp_step",
+    "wdf_ss_probe", "wdf_ss_lin_step_ws_bytes", "wdf_ss_lin_step_mse",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
     "wdf_ss_tp_chunks", "wdf_ss_tp_starts", "wdf_ss_fwd_tp_ws_bytes", "wdf_ss_fwd_tp", "wdf_ss_bwd_tp_ws_bytes", "wdf_ss_bwd_tp",
     "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step",

@@ -150,6 +150,111 @@ class _StateSpaceFn(torch.autograd.Function):
         return gcoef, groot, None, gz0, None, None, None, None, None, None, None, None
 
 
+# ------------------------------------------------------------------------------ resident linear trees
+class _LinResident:
+    """A linear tree (ideal-source root) whose component values live on the device: the probed step as a device tape
+    (probe_tape.py), and per (x, target) pair the buffers of the one-pass MSE step (csrc/wdf_ss_step.h)."""
+
+    def __init__(self, circ, device):
+        from . import probe_tape
+        self.circ = circ
+        own = {"Resistor": "R", "ResistiveVoltageSource": "R", "Capacitor": "C"}
+        self.params = []                                          # (element, attribute) of every component value, tree order
+        for e in circ.elements:
+            name = own.get(_kind(e))
+            if name is not None:
+                self.params.append((e, name))
+        pvars = [e.__dict__[n] for e, n in self.params]
+        if not 1 <= len(pvars) <= probe_tape.MAX_PARAMS:
+            raise binding.WdfHipError(f"Circuit.to_device: 1..{probe_tape.MAX_PARAMS} component values (this tree has {len(pvars)})")
+        self.pb = tf.ParamBlock([float(v) for v in pvars], torch.device(device))
+        for i, v in enumerate(pvars):
+            if isinstance(v, torch.Tensor) and getattr(v, "_is_tf_variable", False) and v.numel() == 1:
+                if getattr(v, "_wdf_block", None) is not None:
+                    raise binding.WdfHipError("Circuit.to_device: a component Variable already lives in another circuit's block")
+                self.pb.adopt(i, v)
+        self.adopted = {i: v for i, v in self.pb.members.items()}
+        tape, outs, rport = probe_tape.record(circ, pvars)
+        ops, consts = tape.packed()
+        dev = self.pb.block.device
+        self.n_ops, self.n_out = int(ops.shape[0]), len(outs) + 1
+        self.tape = torch.as_tensor(ops, device=dev).contiguous()
+        self.consts = torch.as_tensor(consts if len(consts) else np.zeros(1), device=dev)
+        self.outs = torch.as_tensor(np.asarray(outs + [rport], dtype=np.int32), device=dev)
+        self.coef = torch.zeros(self.n_out, dtype=torch.float32, device=dev)
+        self.coef64 = torch.zeros(self.n_out, dtype=torch.float64, device=dev)
+        self.jac = torch.zeros((self.n_out, self.pb.n), dtype=torch.float64, device=dev)
+        self.cache = {}
+
+    def check(self):
+        """The adopted Variables must still be the elements' component values and still live in the block."""
+        for i, (e, n) in enumerate(self.params):
+            v = e.__dict__.get(n)
+            if i in self.adopted and (v is not self.adopted[i] or getattr(v, "_wdf_block", (None,))[0] is not self.pb):
+                raise binding.WdfHipError(f"Circuit.to_device: {type(e).__name__}.{n} was replaced after to_device(); build a new Circuit")
+
+    def probe(self):
+        L = binding.lib()
+        binding._check(L.wdf_ss_probe(binding._ptr(self.tape), self.n_ops, binding._ptr(self.consts), binding._ptr(self.pb.block),
+                                      self.pb.n, binding._ptr(self.outs), self.n_out, binding._ptr(self.coef),
+                                      binding._ptr(self.coef64), binding._ptr(self.jac), binding._stream()), "wdf_ss_probe")
+
+    def entry(self, x, target):
+        key = (id(x), x._version, tuple(x.shape), id(target), target._version)
+        ent = self.cache.get(key)
+        if ent is None:
+            if len(self.cache) >= 4:
+                self.cache.pop(next(iter(self.cache)))            # oldest out (a training and a validation set alternate)
+            circ, dev = self.circ, self.pb.block.device
+            xd = x.as_subclass(torch.Tensor).to(dev).float()
+            if xd.dim() == 2:
+                xd = xd.unsqueeze(-1)
+            B, T, ni = xd.shape
+            if ni != circ.ni:
+                raise binding.WdfHipError(f"x must be [B,T,{circ.ni}] (or [B,T] for one channel), got {tuple(x.shape)}")
+            x_tm = xd.permute(1, 2, 0).contiguous()               # [T][ni][B]: once per training set
+            tgt = target.as_subclass(torch.Tensor).to(dev).float().reshape(T, B).contiguous()
+            k = max(1, min(T // 64, (2 * N_SIMD) // max(1, -(-B // 64))))
+            nbytes = binding.lib().wdf_ss_lin_step_ws_bytes(circ.ns, circ.ni, B, T, k)
+            if nbytes == 0:
+                raise binding.WdfHipError(binding.lib().wdf_last_error().decode() or "wdf_ss_lin_step_ws_bytes: unsupported tree")
+            ent = self.cache[key] = {"x": x_tm, "t": tgt, "y": torch.empty((T, B), dtype=torch.float32, device=dev),
+                                     "ws": torch.zeros((nbytes,), dtype=torch.uint8, device=dev),
+                                     "out": torch.zeros((1 + self.pb.n,), dtype=torch.float32, device=dev),
+                                     "B": B, "T": T, "k": k, "hold": (x, target)}
+        return ent
+
+    def step(self, ent):
+        """probe + one-pass step -> ent["out"] = {SSE, d(mean squared error)/d component value}."""
+        circ = self.circ
+        self.probe()
+        B, T = ent["B"], ent["T"]
+        rc = binding.lib().wdf_ss_lin_step_mse(binding._ptr(ent["x"]), binding._ptr(self.coef), binding._ptr(self.jac), self.pb.n,
+                                               circ.ns, circ.ni, binding._ptr(ent["t"]), 2.0 / float(B * T), binding._ptr(ent["y"]),
+                                               binding._ptr(ent["ws"]), binding._ptr(ent["out"]), None, B, T, ent["k"],
+                                               binding._stream())
+        binding._check(rc, "wdf_ss_lin_step_mse")
+        return ent["out"]
+
+
+class _LinResidentMseFn(torch.autograd.Function):
+    """loss = mean((y - target)^2) of a resident linear tree: the one-pass step produced d loss / d Variable with it."""
+
+    @staticmethod
+    def forward(ctx, res, ent, inv_n, idx, *live):
+        out = res.step(ent).clone()                              # (a validation pass may run before backward)
+        ctx.save_for_backward(out)
+        ctx.idx = idx
+        ctx.mark_non_differentiable(out)
+        return out[0] * inv_n, out
+
+    @staticmethod
+    def backward(ctx, gl, _):
+        (out,) = ctx.saved_tensors
+        g = gl * out
+        return (None,) * 4 + tuple(g[1 + i] for i in ctx.idx)
+
+
 # ------------------------------------------------------------------------------ tree walking
 def _kind(e):
     return type(e).__name__
@@ -248,17 +353,30 @@ class Circuit:
         Variable still work: they copy back on demand).  Diode-clipper topology only: the generic lowering differentiates
         its float64 probe on the host and needs the Variables there.  Returns self."""
         binding.require_gpu()
-        if not (self._is_clipper() and self.root_kind == "DiodePair"):
-            raise binding.WdfHipError("Circuit.to_device: only the diode-pair clipper keeps its component values on the device")
-        if getattr(self, "_pblock", None) is not None:
+        if getattr(self, "_lin", None) is not None or getattr(self, "_pblock", None) is not None:
             return self
+        if self.root_kind == "IdealVoltageSource" and self.ns <= 2 and self.ni <= 2 and self.per_sample_R is None:
+            # a linear tree (lpf.py, voltage_divider.py): the probed step becomes a device tape, mse() the one-pass step
+            self._lin = _LinResident(self, device)
+            return self
+        if not (self._is_clipper() and self.root_kind == "DiodePair"):
+            raise binding.WdfHipError("Circuit.to_device: the diode-pair clipper and linear trees (ideal-source root, at most two "
+                                      "capacitors and two sources) keep their component values on the device")
         dp, vs, cap = self.root, self.top.P1, self.top.P2
         Rv = 1.0 if self.per_sample_R is not None else vs.R
         parts = [dp.Is, dp.nVt, Rv, cap.C]
+        for p in parts:
+            if isinstance(p, torch.Tensor) and not getattr(p, "_is_tf_variable", False) and (p.requires_grad or p.grad_fn is not None):
+                raise binding.WdfHipError("Circuit.to_device: a component value is a tensor computed from other Variables; the "
+                                          "resident step would freeze it -- keep this circuit on the host path")
+            if isinstance(p, torch.Tensor) and getattr(p, "_wdf_block", None) is not None:
+                raise binding.WdfHipError("Circuit.to_device: a component Variable already lives in another circuit's block")
         pb = tf.ParamBlock([float(p) for p in parts], torch.device(device))
+        self._adopted_parts = {}
         for i, p in enumerate(parts):
             if isinstance(p, torch.Tensor) and getattr(p, "_is_tf_variable", False) and p.numel() == 1:
                 pb.adopt(i, p)
+                self._adopted_parts[i] = p
         self._pblock, self._res_cache = pb, {}
         return self
 
@@ -285,11 +403,17 @@ class Circuit:
         of the one-pass training step per call."""
         from . import engine
         pb = self._pblock
+        dp_, vs_, cap_ = self.root, self.top.P1, self.top.P2
+        now = [dp_.Is, dp_.nVt, (1.0 if self.per_sample_R is not None else vs_.R), cap_.C]
+        for i, v in getattr(self, "_adopted_parts", {}).items():
+            if now[i] is not v or getattr(v, "_wdf_block", (None,))[0] is not pb:
+                raise binding.WdfHipError("Circuit.to_device: a component Variable was replaced (set_resistance?) or moved to another "
+                                          "block after to_device(); build a new Circuit")
         key = (id(x), x._version, tuple(x.shape), id(target), target._version, kind, int(skip))
         ent = self._res_cache.get(key)
         if ent is None:
             if len(self._res_cache) >= 4:
-                self._res_cache.clear()
+                self._res_cache.pop(next(iter(self._res_cache)))   # oldest out
             dp, cap = self.root, self.top.P2
             xd = x.as_subclass(torch.Tensor).to(pb.block.device).float()
             xv, r = engine.split_channels(xd, self.per_sample_R is not None, time_major=True, anchor=x)
@@ -340,6 +464,16 @@ class Circuit:
         trainable component ready when tape.gradient asks); any other circuit takes the plain path.
         target: [T,B] like the output."""
         binding.require_gpu()
+        lin = getattr(self, "_lin", None)
+        if lin is not None and isinstance(x, torch.Tensor) and isinstance(target, torch.Tensor):
+            lin.check()
+            ent = lin.entry(x, target)
+            live = [(i, v) for i, v in sorted(lin.pb.members.items()) if v.requires_grad]
+            loss, out = _LinResidentMseFn.apply(lin, ent, 1.0 / float(ent["B"] * ent["T"]), [i for i, _ in live], *[v for _, v in live])
+            loss = loss.as_subclass(tf.Tensor)
+            loss._wdf_fused = (out, {id(v): i for i, v in live})
+            self.last_output = ent["y"]                          # the forward's y [T,B] of this call (TensorArray.stack() layout)
+            return loss
         if not (self._is_clipper() and self.root_kind == "DiodePair" and not self.force_generic):
             y = self(x)
             return tf.reduce_mean(tf.square(y - target))

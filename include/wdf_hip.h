@@ -302,6 +302,25 @@ int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb,
                           float fs, void* ws, float* gw, int64_t S, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * The one-pass MSE training step of LINEAR trees (csrc/wdf_ss_step.h): what one epoch of lpf.py:86-99 /
+ * voltage_divider.py:69-93 does -- Model.forward over the batch (lpf.py:30-49), MeanSquaredError (:78), tape.gradient to
+ * the component values through calc_impedance (:38,87-90) -- with the component values resident on the device.
+ *   wdf_ss_probe          evaluates the probed step recorded once on the host (lib/wdf_hip/probe_tape.py: the elements'
+ *                         own calc_impedance / reflected / incident arithmetic as a tape of + - * / neg recip, int32
+ *                         [n_ops][3] = {op, a, b}) in float64 with forward-mode tangents: coef (the coefficient vector in
+ *                         wdf_ss_fwd's layout, float32 and float64) and jac = d coef / d params, double [n_out][n_params].
+ *   wdf_ss_lin_step_mse   forward, squared error and the gradient carried forward in time (no stash, no reverse sweep),
+ *                         in EXACT time chunks (a pass from zero state, a walk over the chunk boundaries, the pass itself);
+ *                         its last wave contracts dLoss/d coef with jac: out = {SSE, dLoss/d params}.  x is TIME-major
+ *                         [T][ni][B].  ns <= 2, ni <= 2, zero initial state.                                   */
+int wdf_ss_probe(const int32_t* tape, int n_ops, const double* consts, const float* params, int n_params,
+                 const int32_t* outs, int n_out, float* coef, double* coef64, double* jac, void* stream);
+size_t wdf_ss_lin_step_ws_bytes(int ns, int ni, int64_t B, int64_t T, int n_chunks);
+int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, int n_params, int ns, int ni,
+                        const float* target, float gscale, float* y, void* ws, float* out, float* gcoef_out,
+                        int64_t B, int64_t T, int n_chunks, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * The RESIDENT training step of the MLP-root pot clipper (csrc/wdf_mlp_step.h): what one epoch of
  * clipper_pot.py:245-269 does -- ClipperModel.forward (:103-127) over the whole training set, MSE + ESR past
  * skip_samples with the (outs, target) swap (:141-177,248), tape.gradient to the DenseRootModel weights

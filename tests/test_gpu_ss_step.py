@@ -1,0 +1,174 @@
+"""GPU: the one-pass MSE training step of LINEAR trees with the component values resident on the device
+(csrc/wdf_ss_step.h, Circuit.to_device() + Circuit.mse()): lpf.py:20-49,77-99 and voltage_divider.py:19-46,69-93 -- against
+the goldens recorded from the reference's own Model classes (g1, g2), against the fp64 oracle, and against the host-probe path."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+FS = 48000
+
+
+def cuda(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b) / np.abs(b)))
+
+
+@pytest.fixture
+def wdf():
+    import tf_wdf
+    return tf_wdf
+
+
+def build_lpf(wdf):
+    Vs = wdf.IdealVoltageSource()
+    R1 = wdf.Resistor(1000, True)
+    C1 = wdf.Capacitor(1.0e-6, FS, True)
+    I1 = wdf.Inverter(wdf.Series(R1, C1))
+    return Vs, R1, C1, I1
+
+
+def test_resident_rc_lowpass_against_the_reference_golden(wdf, golden):
+    """lpf.py's Model on its own sweep (g1: the reference's Model.forward and tape.gradient executed): y, loss, dMSE/dC,
+    dMSE/dR from ONE pass, the component values on the device."""
+    tf = wdf.tf
+    g = golden("g1_rc_lowpass.npz")
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    circ = wdf.Circuit(I1, Vs, C1).to_device()
+    x, tgt = cuda(g["x"][None, :]), cuda(g["target"][:, None])
+    with tf.GradientTape() as tape:
+        loss = circ.mse(x, tgt)
+    grads = tape.gradient(loss, [C1.C, R1.R])                    # lpf.py:90,98-99 order
+    assert C1.C.is_cuda and R1.R.is_cuda
+    assert np.max(np.abs(circ.last_output.cpu().numpy()[:, 0] - g["y_f64"])) < 2e-6
+    assert abs(float(loss) - float(g["loss_f64"])) < 1e-6
+    assert rel(grads[0].cpu().numpy(), g["dC_f64"]) < 2e-4
+    assert rel(grads[1].cpu().numpy(), g["dR_f64"]) < 2e-4
+
+
+def test_resident_voltage_divider_against_the_reference_golden(wdf, golden):
+    tf = wdf.tf
+    g = golden("g2_voltage_divider.npz")
+    Vs = wdf.IdealVoltageSource()
+    R1, R2 = wdf.Resistor(2.0e3, True), wdf.Resistor(100.0, True)
+    circ = wdf.Circuit(wdf.Inverter(wdf.Series(R1, R2)), Vs, R1).to_device()
+    assert circ.ns == 0
+    with tf.GradientTape() as tape:
+        loss = circ.mse(cuda(g["x"][None, :]), cuda(g["target"][:, None]))
+    grads = tape.gradient(loss, [R1.R, R2.R])
+    assert np.max(np.abs(circ.last_output.cpu().numpy()[:, 0] - g["x"] * 2000.0 / 2100.0)) < 1e-6      # analytic
+    assert rel(grads[0].cpu().numpy(), g["dR1_f64"]) < 2e-4
+    assert rel(grads[1].cpu().numpy(), g["dR2_f64"]) < 2e-4
+
+
+@pytest.mark.parametrize("B,T", [(1, 40), (70, 1000), (300, 4096)])
+def test_resident_rc_lowpass_against_the_oracle(wdf, oracle, B, T):
+    """Ragged batches and chunk counts: y, the loss and both gradients against the oracle (tree interpreter, fp64,
+    complex-step derivative)."""
+    tf = wdf.tf
+    O = oracle
+    rng = np.random.default_rng(B + T)
+    x = rng.standard_normal((B, T)).astype(np.float32)
+    tgt = (0.5 * rng.standard_normal((T, B))).astype(np.float32)
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    circ = wdf.Circuit(I1, Vs, C1).to_device()
+    with tf.GradientTape() as tape:
+        loss = circ.mse(cuda(x), cuda(tgt))
+    grads = tape.gradient(loss, [R1.R, C1.C])
+    nodes = [(O.NODE_RESISTOR, -1, -1, 0, -1, -1), (O.NODE_CAPACITOR, -1, -1, 1, -1, -1), (O.NODE_SERIES, 0, 1, -1, -1, -1),
+             (O.NODE_INVERTER, 2, -1, -1, -1, -1)]
+    oc = O.Circuit(nodes, top=3, probe=1, n_in=1, root_kind=O.ROOT_IDEAL_VSOURCE, fs=FS, root_vin=0)
+    theta = np.array([1000.0, 1.0e-6], dtype=np.float32).astype(np.float64)
+    yref = O.tree_fwd(oc, theta, x.astype(np.float64))
+    gy = 2.0 * (yref - tgt) / (B * T)
+    gref = O.tree_grad(oc, theta, x.astype(np.float64), gy)
+    e_y = float(np.max(np.abs(circ.last_output.cpu().numpy() - yref)))
+    got = np.array([float(v) for v in grads])
+    print(f"B {B} T {T}: |y - oracle| {e_y:.2e}, loss {float(loss):.6e} vs {np.mean((yref - tgt) ** 2):.6e}, grads {rel(got, gref):.2e}")
+    assert e_y < 3e-6
+    assert abs(float(loss) - np.mean((yref - tgt) ** 2)) < 1e-5 * np.mean((yref - tgt) ** 2)
+    assert rel(got, gref) < 2e-4
+
+
+def test_resident_two_state_ladder_two_sources_against_the_host_probe_path(wdf):
+    """ns = 2, ni = 2 (a resistive source inside the ladder and the ideal-source root): the resident one-pass step against the plain path (host probe, forward + reverse-sweep kernels, torch autograd)."""
+    tf = wdf.tf
+    rng = np.random.default_rng(5)
+    B, T = 130, 1500
+    x = rng.standard_normal((B, T, 2)).astype(np.float32)
+    tgt = (0.3 * rng.standard_normal((T, B))).astype(np.float32)
+
+    def build():
+        Ra = wdf.Resistor(1.0e3, True)
+        Vr = wdf.ResistiveVoltageSource(2.2e3, trainable=True)
+        Ca, Cb = wdf.Capacitor(1.0e-7, FS, True), wdf.Capacitor(2.2e-7, FS, True)
+        top = wdf.Inverter(wdf.Series(Ra, wdf.Parallel(Ca, wdf.Series(Vr, Cb))))
+        return wdf.Circuit(top, wdf.IdealVoltageSource(), Cb), [Ra.R, Vr.R, Ca.C, Cb.C]
+
+    ref, pr = build()
+    assert (ref.ns, ref.ni) == (2, 2)
+    with tf.GradientTape() as tape:
+        y = ref(cuda(x))
+        l0 = tf.reduce_mean(tf.square(y - cuda(tgt)))
+    g0 = np.array([float(v) for v in tape.gradient(l0, pr)])
+    circ, p = build()
+    circ.to_device()
+    with tf.GradientTape() as tape:
+        l1 = circ.mse(cuda(x), cuda(tgt))
+    g1 = np.array([float(v) for v in tape.gradient(l1, p)])
+    print(f"loss {float(l0):.6e} / {float(l1):.6e}; grads {g0} / {g1}")
+    assert float((circ.last_output - y.as_subclass(torch.Tensor).detach()).abs().max()) < 3e-6
+    assert abs(float(l1) - float(l0)) < 1e-5 * float(l0)
+    assert rel(g1, g0) < 3e-4
+
+
+def test_resident_rc_lowpass_training_loop_follows_the_host_loop(wdf):
+    """lpf.py:77-99: two Adam optimizers (R and C), 30 epochs: the resident loop (no host round trip) and the plain loop end
+    at the same component values."""
+    tf = wdf.tf
+    rng = np.random.default_rng(2)
+    B, T = 64, 2048
+    x = cuda(rng.standard_normal((B, T)))
+    # target: the same circuit at the values lpf.py aims for (fc = 720 Hz)
+    tr = wdf.Circuit(*(lambda Vs, R1, C1, I1: (I1, Vs, C1))(*build_lpf(wdf)))
+    Vs_, R_, C_, I_ = build_lpf(wdf)
+    with torch.no_grad():
+        R_.R.fill_(315.0)
+        C_.C.fill_(0.7e-6)
+    tgt = wdf.Circuit(I_, Vs_, C_)(x).as_subclass(torch.Tensor).detach()
+    ends = []
+    for resident in (False, True):
+        Vs, R1, C1, I1 = build_lpf(wdf)
+        circ = wdf.Circuit(I1, Vs, C1)
+        if resident:
+            circ.to_device()
+        oR, oC = tf.keras.optimizers.Adam(learning_rate=25.0), tf.keras.optimizers.Adam(learning_rate=1.0e-8)   # lpf.py:79-80
+        losses = []
+        for _ in range(30):
+            with tf.GradientTape() as tape:
+                loss = circ.mse(x, tgt)
+            gC, gR = tape.gradient(loss, [C1.C, R1.R])
+            oC.apply_gradients([(gC, C1.C)])
+            oR.apply_gradients([(gR, R1.R)])
+            losses.append(float(loss))
+        ends.append((float(R1.R), float(C1.C), losses))
+    (R0, C0, l0), (R1_, C1_, l1) = ends
+    print(f"R {R0:.3f} / {R1_:.3f}  C {C0:.4e} / {C1_:.4e}  loss {l0[0]:.4e} -> {l0[-1]:.4e} / {l1[-1]:.4e}")
+    assert l1[-1] < 0.5 * l1[0]
+    assert abs(R1_ - R0) < 2e-3 * R0 and abs(C1_ - C0) < 2e-3 * C0
+
+
+def test_resident_linear_tree_refuses_a_replaced_component(wdf):
+    from wdf_hip import binding as wb
+    tf = wdf.tf
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    circ = wdf.Circuit(I1, Vs, C1).to_device()
+    x, t = cuda(np.zeros((2, 64))), cuda(np.zeros((64, 2)))
+    circ.mse(x, t)
+    R1.set_resistance(tf.constant(500.0))                         # tf_wdf.py:51-52 style replacement
+    with pytest.raises(wb.WdfHipError):
+        circ.mse(x, t)
