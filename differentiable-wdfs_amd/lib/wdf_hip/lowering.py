@@ -165,6 +165,10 @@ class _LinResident:
             if name is not None:
                 self.params.append((e, name))
         pvars = [e.__dict__[n] for e, n in self.params]
+        self.n_tree = len(pvars)                                  # the component values the tape sees; then the root's own
+        if circ.root_kind == "DiodePair":
+            self.params += [(circ.root, "Is"), (circ.root, "nVt")]
+            pvars += [circ.root.Is, circ.root.nVt]
         if not 1 <= len(pvars) <= probe_tape.MAX_PARAMS:
             raise binding.WdfHipError(f"Circuit.to_device: 1..{probe_tape.MAX_PARAMS} component values (this tree has {len(pvars)})")
         self.pb = tf.ParamBlock([float(v) for v in pvars], torch.device(device))
@@ -174,7 +178,8 @@ class _LinResident:
                     raise binding.WdfHipError("Circuit.to_device: a component Variable already lives in another circuit's block")
                 self.pb.adopt(i, v)
         self.adopted = {i: v for i, v in self.pb.members.items()}
-        tape, outs, rport = probe_tape.record(circ, pvars)
+        tape, outs, rport = probe_tape.record(circ, pvars[:self.n_tree])
+        self.host_tape, self.host_outs = tape, outs + [rport]
         ops, consts = tape.packed()
         dev = self.pb.block.device
         self.n_ops, self.n_out = int(ops.shape[0]), len(outs) + 1
@@ -183,7 +188,7 @@ class _LinResident:
         self.outs = torch.as_tensor(np.asarray(outs + [rport], dtype=np.int32), device=dev)
         self.coef = torch.zeros(self.n_out, dtype=torch.float32, device=dev)
         self.coef64 = torch.zeros(self.n_out, dtype=torch.float64, device=dev)
-        self.jac = torch.zeros((self.n_out, self.pb.n), dtype=torch.float64, device=dev)
+        self.jac = torch.zeros((self.n_out, self.n_tree), dtype=torch.float64, device=dev)
         self.cache = {}
 
     def check(self):
@@ -196,8 +201,17 @@ class _LinResident:
     def probe(self):
         L = binding.lib()
         binding._check(L.wdf_ss_probe(binding._ptr(self.tape), self.n_ops, binding._ptr(self.consts), binding._ptr(self.pb.block),
-                                      self.pb.n, binding._ptr(self.outs), self.n_out, binding._ptr(self.coef),
+                                      self.n_tree, binding._ptr(self.outs), self.n_out, binding._ptr(self.coef),
                                       binding._ptr(self.coef64), binding._ptr(self.jac), binding._stream()), "wdf_ss_probe")
+
+    def host_coef(self):
+        """The coefficient vector (float64 numpy, and the port resistance) at the block's lagging host mirror: what the
+        time-parallel planner needs, without a synchronisation."""
+        hv = tuple(self.pb.host_values()[:self.n_tree])
+        if getattr(self, "_hc_key", None) != hv:                  # (the mirror moves every few dozen steps: evaluated then only)
+            vals, _ = self.host_tape.evaluate(hv, self.host_outs)
+            self._hc_key, self._hc_val, self.plans = hv, (vals[:-1], float(vals[-1])), {}
+        return self._hc_val
 
     def entry(self, x, target):
         key = (id(x), x._version, tuple(x.shape), id(target), target._version)
@@ -235,6 +249,34 @@ class _LinResident:
                                                binding._stream())
         binding._check(rc, "wdf_ss_lin_step_mse")
         return ent["out"]
+
+
+class _ProbeFn(torch.autograd.Function):
+    """(coef float32 [ncoef], rootp float32 [3] | None) of a resident tree from its parameter block, on the device
+    (wdf_ss_probe); backward contracts dLoss/d coef with the probe's Jacobian -- calc_impedance's chain rule
+    (tf_wdf.py:114-115,139-145,168-177) without the host."""
+
+    @staticmethod
+    def forward(ctx, res, idx, *live):
+        res.probe()
+        ncoef = res.n_out - 1
+        coef = res.coef[:ncoef].clone()
+        ctx.res, ctx.idx, ctx.ncoef = res, idx, ncoef
+        ctx.save_for_backward(res.jac.clone())
+        if res.circ.root_kind == "DiodePair":
+            rootp = torch.cat([res.pb.block[res.n_tree:res.n_tree + 2], res.coef[ncoef:ncoef + 1]])
+            return coef, rootp
+        return coef, coef.new_zeros(3)
+
+    @staticmethod
+    def backward(ctx, gcoef, grootp):
+        (jac,) = ctx.saved_tensors
+        res = ctx.res
+        g = torch.cat([gcoef, grootp[2:3]]).double() @ jac                    # [n_tree]
+        if res.circ.root_kind == "DiodePair":
+            g = torch.cat([g, grootp[0:2].double()])
+        g = g.float()
+        return (None, None) + tuple(g[i] for i in ctx.idx)
 
 
 class _LinResidentMseFn(torch.autograd.Function):
@@ -353,11 +395,17 @@ class Circuit:
         Variable still work: they copy back on demand).  Diode-clipper topology only: the generic lowering differentiates
         its float64 probe on the host and needs the Variables there.  Returns self."""
         binding.require_gpu()
-        if getattr(self, "_lin", None) is not None or getattr(self, "_pblock", None) is not None:
+        if getattr(self, "_lin", None) is not None or getattr(self, "_pblock", None) is not None or getattr(self, "_tree", None) is not None:
             return self
         if self.root_kind == "IdealVoltageSource" and self.ns <= 2 and self.ni <= 2 and self.per_sample_R is None:
             # a linear tree (lpf.py, voltage_divider.py): the probed step becomes a device tape, mse() the one-pass step
             self._lin = _LinResident(self, device)
+            return self
+        if self.root_kind in ("IdealVoltageSource", "DiodePair") and self.per_sample_R is None and \
+                not (self._is_clipper() and self.root_kind == "DiodePair"):
+            # any other tree the state-space kernels run (HPFDiodeClipper.h:28-32 ...): the probe moves to the device, the
+            # forward / reverse-sweep kernels stay -- __call__ no longer touches the host per step
+            self._tree = _LinResident(self, device)
             return self
         if not (self._is_clipper() and self.root_kind == "DiodePair"):
             raise binding.WdfHipError("Circuit.to_device: the diode-pair clipper and linear trees (ideal-source root, at most two "
@@ -573,19 +621,38 @@ class Circuit:
             from . import mlp_root
             return mlp_root.run_clipper_mlp(self, x, z0, return_state)
 
-        coef64, r_port = self.matrices()
-        coef = coef64.to(device=dev, dtype=torch.float32)
-        if self.root_kind == "DiodePair":
-            dp = self.root
-            rootp = torch.stack([dp.Is.as_subclass(torch.Tensor).double().reshape(()),
-                                 dp.nVt.as_subclass(torch.Tensor).double().reshape(()),
-                                 r_port.double().reshape(())]).to(device=dev, dtype=torch.float32)
-            kind, n_up, n_down = binding.ROOT_DIODE_PAIR, dp.N_up, dp.N_down
+        res = getattr(self, "_tree", None) or getattr(self, "_lin", None)
+        if res is not None:
+            # resident component values: coefficients (and their chain rule) from the device probe, the plan from the
+            # block's lagging host mirror
+            res.check()
+            live = [(i, v) for i, v in sorted(res.pb.members.items()) if v.requires_grad]
+            coef, rootp_r = _ProbeFn.apply(res, [i for i, _ in live], *[v for _, v in live])
+            c64, _ = res.host_coef()
+            coef64 = torch.as_tensor(c64)
+            if self.root_kind == "DiodePair":
+                rootp, kind, n_up, n_down = rootp_r, binding.ROOT_DIODE_PAIR, self.root.N_up, self.root.N_down
+            else:
+                rootp, kind, n_up, n_down = None, binding.ROOT_NONE, 1, 1
         else:
-            rootp, kind, n_up, n_down = None, binding.ROOT_NONE, 1, 1
+            coef64, r_port = self.matrices()
+            coef = coef64.to(device=dev, dtype=torch.float32)
+            if self.root_kind == "DiodePair":
+                dp = self.root
+                rootp = torch.stack([dp.Is.as_subclass(torch.Tensor).double().reshape(()),
+                                     dp.nVt.as_subclass(torch.Tensor).double().reshape(()),
+                                     r_port.double().reshape(())]).to(device=dev, dtype=torch.float32)
+                kind, n_up, n_down = binding.ROOT_DIODE_PAIR, dp.N_up, dp.N_down
+            else:
+                rootp, kind, n_up, n_down = None, binding.ROOT_NONE, 1, 1
         z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(self.ns, -1).contiguous()
         tp = getattr(self, "time_parallel", None)
-        if tp == "auto":
+        if tp == "auto" and res is not None:                      # (the plan follows the host mirror: cached with it)
+            pkey = (kind, int(x.shape[0]), int(x.shape[1]))
+            tp = res.plans.get(pkey, "miss")
+            if tp == "miss":
+                tp = res.plans[pkey] = plan_ss_time_parallel(coef64, self.ns, self.ni, kind, x.shape[0], x.shape[1])
+        elif tp == "auto":
             tp = plan_ss_time_parallel(coef64, self.ns, self.ni, kind, x.shape[0], x.shape[1])
         elif not isinstance(tp, SsTpPlan):
             tp = None

@@ -172,3 +172,65 @@ def test_resident_linear_tree_refuses_a_replaced_component(wdf):
     R1.set_resistance(tf.constant(500.0))                         # tf_wdf.py:51-52 style replacement
     with pytest.raises(wb.WdfHipError):
         circ.mse(x, t)
+
+
+def _hpf(wdf, n_up=2, n_down=3):
+    """HPFDiodeClipper.h:28-32: Parallel(R, Series(Vs, C)) + diode pair."""
+    R = wdf.Resistor(33.0e3, True)
+    Vs = wdf.ResistiveVoltageSource(1.0e3, trainable=True)
+    C = wdf.Capacitor(22.0e-9, FS, True)
+    top = wdf.Parallel(R, wdf.Series(Vs, C))
+    dp = wdf.DiodePair(top, 4.352e-9, Vt=25.85e-3, nDiodes=1.906, N_up=n_up, N_down=n_down, trainable=True)
+    return wdf.Circuit(top, dp, R), [R.R, Vs.R, C.C, dp.Is, dp.nVt]
+
+
+def test_resident_hpf_clipper_against_the_oracle(wdf, oracle):
+    """A diode-root tree with its component values on the device: the probe (coefficients, port resistance and their
+    chain rule to R, Rs, C) runs there; forward and the five gradients against the oracle."""
+    tf = wdf.tf
+    O = oracle
+    rng = np.random.default_rng(12)
+    B, T = 40, 700
+    x = (rng.standard_normal((B, T)) * 1.2).astype(np.float32)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    circ, params = _hpf(wdf)
+    circ.to_device()
+    assert all(p.is_cuda for p in params)
+    with tf.GradientTape() as tape:
+        y = circ(cuda(x))
+        loss = tf.reduce_sum(y * cuda(gy))
+    grads = tape.gradient(loss, params)
+    nodes = [(O.NODE_RESISTOR, -1, -1, 0, -1, -1), (O.NODE_RES_VSOURCE, -1, -1, 1, 0, -1),
+             (O.NODE_CAPACITOR, -1, -1, 2, -1, -1), (O.NODE_SERIES, 1, 2, -1, -1, -1), (O.NODE_PARALLEL, 0, 3, -1, -1, -1)]
+    oc = O.Circuit(nodes, top=4, probe=0, n_in=1, root_kind=O.ROOT_DIODE_PAIR, fs=FS, p_is=3, p_nvt=4, n_up=2, n_down=3)
+    theta = np.array([33.0e3, 1.0e3, 22.0e-9, 4.352e-9, 25.85e-3 * 1.906], dtype=np.float32).astype(np.float64)
+    yref = O.tree_fwd(oc, theta, x.astype(np.float64))
+    gref = O.tree_grad(oc, theta, x.astype(np.float64), gy.astype(np.float64))
+    got = np.array([float(v) for v in grads])
+    e_y = float(np.max(np.abs(y.as_subclass(torch.Tensor).detach().cpu().numpy() - yref)))
+    print(f"resident HPF clipper: |y - oracle| {e_y:.2e}, gradients {rel(got, gref):.2e}")
+    assert e_y < 3e-6 and rel(got, gref) < 3e-4
+
+
+def test_resident_hpf_clipper_training_loop_follows_the_host_loop(wdf):
+    tf = wdf.tf
+    B, T = 256, 2048
+    x = cuda((np.random.default_rng(11).standard_normal((B, T)) * 1.2))
+    ref, _ = _hpf(wdf)
+    tgt = (ref(x) * 0.8).as_subclass(torch.Tensor).detach()
+    ends = []
+    for resident in (False, True):
+        circ, params = _hpf(wdf)
+        if resident:
+            circ.to_device()
+        opts = [tf.keras.optimizers.Adam(learning_rate=2.0e-3 * float(p)) for p in params]
+        for _ in range(12):
+            with tf.GradientTape() as tape:
+                loss = circ.mse(x, tgt)
+            grads = tape.gradient(loss, params)
+            for o, g, p in zip(opts, grads, params):
+                o.apply_gradients([(g, p)])
+        ends.append(([float(p) for p in params], float(loss)))
+    (p0, l0), (p1, l1) = ends
+    print(f"host loop {p0} loss {l0:.4e}\\nresident  {p1} loss {l1:.4e}")
+    assert np.allclose(p1, p0, rtol=5e-4, atol=0) and abs(l1 - l0) < 1e-3 * l0

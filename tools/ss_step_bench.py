@@ -19,7 +19,7 @@ B, T = int(os.environ.get("B", 8192)), int(os.environ.get("T", 4096))
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 x = torch.randn((B, T), device="cuda")
 tgt = torch.randn((T, B), device="cuda") * 0.3
-for resident in (False, True):
+for resident in ((True,) if os.environ.get("ONLY_RESIDENT") else (False, True)):
     Vs = wdf.IdealVoltageSource()
     R1, C1 = wdf.Resistor(1000, True), wdf.Capacitor(1.0e-6, FS, True)
     circ = wdf.Circuit(wdf.Inverter(wdf.Series(R1, C1)), Vs, C1)
@@ -52,3 +52,36 @@ for resident in (False, True):
     print(f"{'resident one-pass step' if resident else 'plain path            '}: {dt / steps * 1e3:.4f} ms per step = {B * T / (dt / steps) / 1e9:.1f} G samples/s "
           f"(host side {t_host / steps * 1e3:.4f} ms; step kernel {k_ms:.4f} ms = {16.0 * B * T / (k_ms * 1e-3) / 1e12 if resident else float('nan'):.2f} TB/s of its 16 B/sample); "
           f"loss {float(loss):.5e}, R {float(R1.R):.2f}, C {float(C1.C):.4e}")
+
+
+# ---- the HPF diode clipper (HPFDiodeClipper.h:28-32) in the same loop shape: host probe against the device probe -------
+x2 = torch.randn((B, T), device="cuda") * 1.2
+for resident in ((True,) if os.environ.get("ONLY_RESIDENT") else (False, True)):
+    R = wdf.Resistor(33.0e3, True); Vs2 = wdf.ResistiveVoltageSource(1.0e3, trainable=True); C = wdf.Capacitor(22.0e-9, FS, True)
+    top = wdf.Parallel(R, wdf.Series(Vs2, C))
+    dp = wdf.DiodePair(top, 4.352e-9, Vt=25.85e-3, nDiodes=1.906, trainable=True)
+    circ = wdf.Circuit(top, dp, R)
+    params = [R.R, Vs2.R, C.C, dp.Is, dp.nVt]
+    if resident:
+        circ.to_device()
+    opts = [tf.keras.optimizers.Adam(learning_rate=1.0e-3 * float(p)) for p in params]
+
+    def step2():
+        with tf.GradientTape() as tape:
+            loss = circ.mse(x2, tgt)
+        grads = tape.gradient(loss, params)
+        for o, g, p in zip(opts, grads, params):
+            o.apply_gradients([(g, p)])
+        return loss
+
+    for _ in range(10):
+        step2()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step2()
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"HPF clipper, {'resident (device probe)' if resident else 'plain path (host probe) '}: {dt / steps * 1e3:.4f} ms per step = "
+          f"{B * T / (dt / steps) / 1e9:.1f} G samples/s (host side {t_host / steps * 1e3:.4f} ms); loss {float(loss):.5e}")
