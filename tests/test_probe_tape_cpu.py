@@ -1,0 +1,75 @@
+"""CPU: the probed step as a tape (lib/wdf_hip/probe_tape.py) against the host probe (lowering.Circuit.matrices: the elements'
+own calc_impedance / reflected / incident code on float64 torch scalars with autograd) -- values and Jacobian; and the
+chunk planner of the MLP-root training step (mlp_root.plan_step_items)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+FS = 48000
+
+
+def _lpf(wdf):
+    Vs, R1, C1 = wdf.IdealVoltageSource(), wdf.Resistor(1000.0, True), wdf.Capacitor(1.0e-6, FS, True)
+    return wdf.Circuit(wdf.Inverter(wdf.Series(R1, C1)), Vs, C1), [C1.C, R1.R]            # lpf.py:20-28
+
+
+def _divider(wdf):
+    R1, R2 = wdf.Resistor(2.0e3, True), wdf.Resistor(100.0, True)
+    return wdf.Circuit(wdf.Inverter(wdf.Series(R1, R2)), wdf.IdealVoltageSource(), R1), [R1.R, R2.R]   # voltage_divider.py:19-26
+
+
+def _hpf(wdf):
+    R, Vs, C = wdf.Resistor(33.0e3, True), wdf.ResistiveVoltageSource(1.0e3, trainable=True), wdf.Capacitor(22.0e-9, FS, True)
+    top = wdf.Parallel(R, wdf.Series(Vs, C))                                              # HPFDiodeClipper.h:28-32
+    return wdf.Circuit(top, wdf.DiodePair(top, 4.352e-9, Vt=25.85e-3, nDiodes=1.906, trainable=True), R), [R.R, Vs.R, C.C]
+
+
+def _ladder(wdf):
+    Ra, Rb = wdf.Resistor(1.0e3, True), wdf.Resistor(2.2e3, True)
+    Ca, Cb = wdf.Capacitor(1.0e-7, FS, True), wdf.Capacitor(2.2e-7, FS, True)
+    top = wdf.Inverter(wdf.Series(Ra, wdf.Parallel(Ca, wdf.Series(Rb, Cb))))
+    return wdf.Circuit(top, wdf.IdealVoltageSource(), Cb), [Ra.R, Rb.R, Ca.C, Cb.C]
+
+
+@pytest.mark.parametrize("build", [_lpf, _divider, _hpf, _ladder])
+def test_tape_reproduces_the_host_probe(build):
+    import tf_wdf as wdf
+    from wdf_hip import probe_tape
+    circ, params = build(wdf)
+    before = [(e, dict(e.__dict__)) for e in circ.elements]
+    tape, outs, rport = probe_tape.record(circ, params)
+    for e, d in before:                                          # recording leaves the elements as it found them
+        assert all(e.__dict__.get(k) is v for k, v in d.items() if k in ("R", "C", "z", "a", "b", "Vs"))
+    assert len(tape.ops) <= probe_tape.MAX_OPS
+    val, jac = tape.evaluate([float(p) for p in params], outs + [rport])
+    coef, r_port = circ.matrices()
+    ref = np.concatenate([coef.detach().numpy(), [float(r_port)]])
+    # (the host probe does part of its arithmetic in float32 -- the Variables' own dtype; the tape is float64 throughout)
+    assert np.allclose(val, ref, rtol=2e-6, atol=1e-12)
+    rows = []
+    for c in list(coef) + [r_port]:
+        g = torch.autograd.grad(c, params, retain_graph=True, allow_unused=True) if c.requires_grad else [None] * len(params)
+        rows.append([0.0 if gi is None else float(gi) for gi in g])
+    ref_j = np.array(rows)
+    assert np.allclose(jac, ref_j, rtol=2e-5, atol=1e-9 * np.max(np.abs(ref_j)))
+    ops, consts = tape.packed()
+    assert ops.dtype == np.int32 and ops.shape[1] == 3 and consts.dtype == np.float64
+
+
+def test_step_plan_tiles_every_column_and_balances_the_waves():
+    from wdf_hip import mlp_root
+    T = 2048
+    w = [32] * 21 + [64] * 21 + [192] * 21 + [256] * 21          # warm-up steps per column: four pot values
+    items = mlp_root.plan_step_items(T, w, 1024)
+    assert items.shape == (1024, 4)
+    cost = []
+    for c in range(84):
+        rows = items[items[:, 0] == c]
+        assert list(rows[:, 1]) == list(range(len(rows))) and rows[0, 2] == 0 and rows[-1, 3] == T
+        assert np.all(rows[1:, 2] == rows[:-1, 3]) and np.all(rows[:, 2:] % 16 == 0)
+        assert rows[0, 3] - rows[0, 2] >= max(rows[1:, 3] - rows[1:, 2])          # chunk 0 (no warm-up) is the longest
+        cost.append(max(rows[0, 3], (rows[1, 3] - rows[1, 2]) + mlp_root.WARM_COST * w[c]))
+    k = [int((items[:, 0] == c).sum()) for c in (0, 21, 42, 63)]
+    assert k[0] <= k[1] <= k[2] <= k[3] and k[3] >= k[0] + 6     # slow columns get more, shorter chunks
+    assert max(cost) <= 1.25 * min(cost)                         # ... and every wave about the same number of steps
