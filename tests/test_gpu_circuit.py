@@ -656,13 +656,18 @@ def test_resident_circuit_mse_esr_is_the_scripts_training_loss(wdf):
     assert abs(float(dev_.mse_esr(x, tgt, skip)) - (S / n + np.sqrt(S / E / n))) <= 2e-5 * (S / n + np.sqrt(S / E / n))
 
 
-def test_resident_circuit_rejects_other_topologies(wdf):
+def test_resident_circuit_rejects_what_it_cannot_keep_on_the_device(wdf):
+    """to_device() covers the diode-pair clipper, linear trees and diode-root trees (round 4: tests/test_gpu_ss_step.py);
+    the MLP root's own resident path is mlp_root.MlpTrainStep, and a Variable lives in ONE circuit's block."""
     from wdf_hip import binding as wb
     R1 = wdf.Resistor(1000.0, True)
     C1 = wdf.Capacitor(1.0e-6, FS, True)
-    lp = wdf.Circuit(wdf.Inverter(wdf.Series(R1, C1)), wdf.IdealVoltageSource(), C1)
+    lp = wdf.Circuit(wdf.Inverter(wdf.Series(R1, C1)), wdf.IdealVoltageSource(), C1).to_device()
+    assert R1.R.is_cuda and C1.C.is_cuda
+    again = wdf.Circuit(wdf.Inverter(wdf.Series(R1, C1)), wdf.IdealVoltageSource(), C1)   # the same Variables in a second circuit
     with pytest.raises(wb.WdfHipError):
-        lp.to_device()
+        again.to_device()
+    assert lp.to_device() is lp
 
 
 def test_resident_circuit_with_pot_channel_and_frozen_diode(wdf):
