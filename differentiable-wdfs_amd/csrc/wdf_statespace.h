@@ -700,8 +700,19 @@ __global__ __launch_bounds__(64) void ss_bwd_tp_kernel(const float* __restrict__
             for (int s = 0; s < NS; ++s) zv[q][s] = zstash[((tb + q) * NS + s) * B + b];
         }
     };
+    // the chunk's own sums (run 0) leave fp32 every 32 steps, as the sequential sweep's do every 8: a chunk is hundreds to
+    // thousands of steps long, and fp32 all the way would lose sqrt(L) .. L x 6e-8 of them
+    double q64[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) q64[i] = 0.0;
+    int since = 0;
     if (tfull > t0) load_blk(tfull - kBlkSS, xn, zn, gn);
     for (int64_t tb = tfull - kBlkSS; tb >= t0; tb -= kBlkSS) {  // 8-step blocks, the next one (earlier in time) in flight
+        if (++since == 4) {
+            since = 0;
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) { q64[i] += (double)acc[0][i]; acc[0][i] = 0.0f; }
+        }
 #pragma unroll
         for (int q = 0; q < kBlkSS; ++q) {
             gc[q] = gn[q];
@@ -727,7 +738,7 @@ __global__ __launch_bounds__(64) void ss_bwd_tp_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < NACC; ++i) o[(size_t)(e++) * B] = acc[r][i];       // P[r-1][i]
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) o[(size_t)(e++) * B] = acc[0][i];           // q
+    for (int i = 0; i < NACC; ++i) o[(size_t)(e++) * B] = (float)(q64[i] + (double)acc[0][i]);   // q
 }
 
 // ws: double[gridDim.x][NACC] per-wave partial sums, as ss_bwd_kernel leaves them

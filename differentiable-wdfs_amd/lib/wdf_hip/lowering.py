@@ -11,6 +11,7 @@ the matrices carry the autograd graph back to R and C: the reverse-sweep kernel 
 dL/d(matrices) and torch chains it to the component values -- which is what
 tape.gradient(loss, model.trainable_variables) is in the reference (lpf.py:87-90).
 """
+import collections
 import math
 import weakref
 from collections import namedtuple
@@ -72,7 +73,7 @@ class SsWarmStart:
                                               bold_below=4.0, tol=plan.tol)
         self.rows, self.prev = {}, {}
         self._idx = {}
-        self.trace = []
+        self.trace = collections.deque(maxlen=256)      # warm-up used by the last calls (probing)
 
     def chunks(self, W):
         return binding.lib().wdf_ss_tp_chunks(self.T, max(2, min(self.T // max(W, 64), self.k_max)))
@@ -666,7 +667,7 @@ class Circuit:
                 for k_ in [k_ for k_, v_ in ws.items() if v_[0]() is None]:
                     del ws[k_]
                 if len(ws) >= 4:
-                    ws.clear()
+                    ws.pop(next(iter(ws)))                         # oldest out
                 hit = ws[wkey] = (weakref.ref(self._anchor), SsWarmStart(x.shape[1], x.shape[0], self.ns, tp))
             warm = hit[1]
             warm.plan = tp                  # (the cold plan follows the components as they train; the warm state stays)

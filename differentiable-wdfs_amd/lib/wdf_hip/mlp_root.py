@@ -84,7 +84,7 @@ class _ClipperMlpFn(torch.autograd.Function):
                     for k in [k for k, v in _WARM_START.items() if v["xref"]() is None or (v["rref"] is not None and v["rref"]() is None)]:
                         del _WARM_START[k]                       # entries whose batch has been freed
                     if len(_WARM_START) >= 8:
-                        _WARM_START.clear()
+                        _WARM_START.pop(next(iter(_WARM_START)))     # oldest out
                     # (a wave or two re-run now and then is the fp32 floor of this path crossing the tolerance --
                     #  plan_mlp_time_parallel's note -- which no warm-up cures: only 8 or more per verdict count as a
                     #  warm-up too short; the weights swing with periods of ~16 calls, so 32 clean calls before less is tried)
@@ -114,7 +114,7 @@ class _ClipperMlpFn(torch.autograd.Function):
             if _TRACE_WARMUP is not None:
                 _TRACE_WARMUP.append((w_used, hot))
                 if warm is not None:
-                    _TRACE_VERDICTS[:] = warm["ctl"].verdicts
+                    _TRACE_VERDICTS[:] = list(warm["ctl"].verdicts)
             if hot:
                 warm["ctl"].end(st, w_used)
             else:

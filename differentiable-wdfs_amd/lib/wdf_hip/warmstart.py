@@ -13,6 +13,8 @@ policy counts CALLS, not verdicts):
                                        inside the tolerance).
 The caller keeps start states for the warm-ups candidates() names, so a change never costs a cold call.
 """
+import collections
+
 import torch
 
 
@@ -28,7 +30,7 @@ class WarmUpController:
         self.calls, self.since, self.bad, self.bad_at = 0, 0, 0, -10**9
         self.gated = self.pin = self.pending = None
         self.gated_seen = 0
-        self.verdicts = []          # (probing) every verdict read: (warm-up, n_bad, max miss, gated waves, sequential waves)
+        self.verdicts = collections.deque(maxlen=256)   # (probing) the last verdicts read: (warm-up, n_bad, max miss, gated waves, sequential waves)
 
     def _read_verdict(self):
         if self.pending is None or not self.pending[0].query():

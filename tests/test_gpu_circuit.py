@@ -499,7 +499,7 @@ def test_state_space_forward_warm_starts_when_a_batch_is_visited_again(wdf):
     warm = next(iter(circ._ss_warm.values()))[1]
     assert used[0][1] == plan.warmup and used[0][0] == plan.k_fwd                       # the first visit is cold
     assert all(w <= plan.warmup // 2 and k > plan.k_fwd for k, w, _ in used[1:]), used  # ... the rest start warm
-    assert warm.trace == [w for _, w, _ in used]
+    assert list(warm.trace) == [w for _, w, _ in used]
     for a, b in zip(y_tp, y_seq):
         assert float((a - b).abs().max()) <= 5e-6          # (verified to 1e-6 per boundary; the two loops' parameters drift apart a little)
     assert np.allclose(p_tp, p_seq, rtol=2e-5, atol=0)
