@@ -574,7 +574,10 @@ class GradientTape:
                 vec = fused[0]
                 grads = []
                 for i in where:
-                    g = vec[1 + i].as_subclass(Tensor)
+                    if isinstance(i, tuple):                    # a tensor Variable living in a flat vector: (offset, count, shape)
+                        g = vec[1 + i[0]:1 + i[0] + i[1]].view(i[2]).as_subclass(Tensor)
+                    else:
+                        g = vec[1 + i].as_subclass(Tensor)
                     g._wdf_gvec = (vec, i)                      # _Adam._apply_resident: the update reads the vector itself
                     grads.append(g)
             else:
@@ -644,9 +647,39 @@ class _Adam:
                 pb.block[sel] = th
         return True
 
+    def _apply_flat(self, gv):
+        """The weights of a network that lives in one flat device vector (mlp_root.MlpResident), their gradients slices of
+        one gradient vector, all of them: the whole update is ONE launch of wdf_adam_step on the vector."""
+        if not gv or any(g is None or getattr(v, "_wdf_flat", None) is None or id(v) in self._slots for g, v in gv):
+            return False
+        res = gv[0][1]._wdf_flat[0]
+        tags = [getattr(g, "_wdf_gvec", None) for g, _ in gv]
+        if any(v._wdf_flat[0] is not res for _, v in gv) or any(t is None or t[0] is not tags[0][0] for t in tags):
+            return False
+        spans = [(v._wdf_flat[1], v._wdf_flat[2]) for _, v in gv]
+        if any(not isinstance(t[1], tuple) or (t[1][0], t[1][1]) != sp for t, sp in zip(tags, spans)):
+            return False
+        o = 0
+        for off, n in sorted(spans):                            # together they cover the vector, whatever the order
+            if off != o:                                        # (tf.Module lists bias before kernel)
+                return False
+            o += n
+        if o != res.w.numel():
+            return False
+        st = self._resident.get(("flat", id(res)))
+        if st is None:
+            from . import binding
+            opt = binding.Adam(o, self.lr, self.b1, self.b2, self.eps, device=res.w.device)
+            if self.iterations:
+                opt.step.fill_(self.iterations)
+            st = self._resident[("flat", id(res))] = (opt, res)
+        with torch.no_grad(), torch._C.DisableTorchFunctionSubclass():
+            st[0].apply(res.w, tags[0][0][1:1 + o])
+        return True
+
     def apply_gradients(self, grads_and_vars):
         grads_and_vars = list(grads_and_vars)
-        if self._apply_resident(grads_and_vars):
+        if self._apply_flat(grads_and_vars) or self._apply_resident(grads_and_vars):
             self.iterations += 1
             return
         self.iterations += 1

@@ -396,7 +396,13 @@ class Circuit:
         Variable still work: they copy back on demand).  Diode-clipper topology only: the generic lowering differentiates
         its float64 probe on the host and needs the Variables there.  Returns self."""
         binding.require_gpu()
-        if getattr(self, "_lin", None) is not None or getattr(self, "_pblock", None) is not None or getattr(self, "_tree", None) is not None:
+        if any(getattr(self, a, None) is not None for a in ("_lin", "_pblock", "_tree", "_mlp")):
+            return self
+        if self.root_kind == "DenseRootModel":
+            if not self._is_clipper():
+                raise binding.WdfHipError("the MLP root is supported on the diode-clipper topology (clipper_pot.py:94-101)")
+            from . import mlp_root
+            self._mlp = mlp_root.MlpResident(self, device)       # clipper_pot.py's model: weights in one device vector
             return self
         if self.root_kind == "IdealVoltageSource" and self.ns <= 2 and self.ni <= 2 and self.per_sample_R is None:
             # a linear tree (lpf.py, voltage_divider.py): the probed step becomes a device tape, mse() the one-pass step
@@ -496,6 +502,17 @@ class Circuit:
         A resident diode-pair clipper (to_device()) evaluates loss and gradient in one pass over the data
         (wdf_clipper_step_esr_tp); anything else composes it from the forward."""
         binding.require_gpu()
+        mres = getattr(self, "_mlp", None)
+        if mres is not None and isinstance(x, torch.Tensor) and isinstance(target, torch.Tensor):
+            from . import mlp_root
+            if int(x.shape[1]) % 16 == 0:                        # (the resident step's blocks are 16 steps)
+                ent = mres.entry(x, target, skip)
+                live = [v for v in mres.vars if v.requires_grad]
+                loss, out = mlp_root.MlpResidentFn.apply(mres, ent, *live)
+                loss = loss.as_subclass(tf.Tensor)
+                loss._wdf_fused = (out, {id(v): mres.spec[id(v)] for v in live})
+                self.last_output = ent["st"].y
+                return loss
         if (getattr(self, "_pblock", None) is not None and isinstance(x, torch.Tensor) and isinstance(target, torch.Tensor)
                 and not self.force_generic):
             return self._loss_resident(x, target, "mse+esr", skip)

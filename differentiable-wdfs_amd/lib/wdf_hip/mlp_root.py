@@ -17,7 +17,7 @@ from . import warmstart
 from . import compat_tf as tf
 
 
-def describe(model):
+def describe(model, with_activation=False):
     """(dense layers, hidden width, number of tanh layers) of a layers.DenseRootModel; raises
     for anything the kernels do not cover."""
     dense = [l for l in model.layers if type(l).__name__ == "DenseLayer"]
@@ -27,11 +27,16 @@ def describe(model):
             nxt = model.layers[i + 1] if i + 1 < len(model.layers) else None
             acts.append("tanh" if nxt is tf.nn.tanh else ("relu" if nxt is tf.nn.relu else ""))
     if len(dense) < 2 or acts[-1] != "" or any(a != "tanh" for a in acts[:-1]):
-        raise binding.WdfHipError(f"MLP root: expected tanh hidden layers and a linear output, got {acts}")
+        if with_activation and len(dense) >= 2 and acts[-1] == "" and all(a == "relu" for a in acts[:-1]):
+            pass                                                  # relu hidden layers (layers.py:63-65): the resident step's kernels carry them
+        else:
+            raise binding.WdfHipError(f"MLP root: expected tanh hidden layers and a linear output, got {acts}")
     sizes = [int(dense[0].kernel.shape[1])] + [int(d.kernel.shape[2]) for d in dense]
     hidden = sizes[1]
     if sizes[0] != 2 or sizes[-1] != 1 or any(s != hidden for s in sizes[1:-1]):
         raise binding.WdfHipError(f"MLP root: expected 2 -> H -> ... -> H -> 1, got {sizes}")
+    if with_activation:
+        return dense, hidden, len(dense) - 1, acts[0]
     return dense, hidden, len(dense) - 1
 
 
@@ -676,3 +681,77 @@ class MlpTrainStep:
 
     def backward_only(self):
         self._call(PHASE_BWD, self.adam)
+
+
+# ------------------------------------------------------------------------------ the resident step behind the element API
+class MlpResident:
+    """tf_wdf.Circuit(P1, DenseRootModel, C, per_sample_R=Vs).to_device(): the network's kernels and biases move into ONE
+    flat device vector (each Variable becomes a view of its slice: same object, same shape, same autograd leaf), and
+    circ.mse_esr(x, target, skip) -- the loss of clipper_pot.py:141-177,248 -- is one resident training step
+    (MlpTrainStep, csrc/wdf_mlp_step.h) whose weight gradient tape.gradient hands out; tf.keras.optimizers.Adam updates
+    the flat vector with one launch (compat_tf._Adam).  The loop of clipper_pot.py:245-269 then runs at the speed of
+    `bench.py --root mlp2x16`, written the way the script writes it."""
+
+    def __init__(self, circ, device):
+        self.circ = circ
+        self.dense, self.hidden, self.n_layers, self.act = describe(circ.root, with_activation=True)
+        cap = circ.top.P2
+        if getattr(cap.C, "requires_grad", False):
+            raise binding.WdfHipError("Circuit.to_device with a DenseRootModel root trains the network's weights; the capacitor must "
+                                      "not be trainable (clipper_pot.py:96-101)")
+        self.fs, self.C = float(cap.FS), float(cap.C)
+        vs = circ.top.P1
+        self.R_static = None if circ.per_sample_R is not None else float(vs.R)
+        flat = flat_weights(self.dense).detach().float().to(device).contiguous()
+        self.w = flat
+        self.vars, o = [], 0
+        for d in self.dense:
+            for v in (d.kernel, d.bias):
+                n = v.numel()
+                if getattr(v, "_wdf_flat", None) is not None:
+                    raise binding.WdfHipError("Circuit.to_device: this network's weights already live in another circuit's vector")
+                with torch.no_grad():
+                    v.data = self.w[o:o + n].view(v.shape)
+                v._wdf_flat = (self, o, n)
+                self.vars.append(v)
+                o += n
+        self.spec = {id(v): v._wdf_flat[1:] + (tuple(v.shape),) for v in self.vars}
+        self.cache = {}
+
+    def entry(self, x, target, skip):
+        key = (id(x), x._version, tuple(x.shape), id(target), target._version, int(skip))
+        ent = self.cache.get(key)
+        if ent is None:
+            if len(self.cache) >= 4:
+                self.cache.pop(next(iter(self.cache)))
+            circ, dev = self.circ, self.w.device
+            xd = x.as_subclass(torch.Tensor).to(dev).float()
+            xv, r = engine.split_channels(xd, circ.per_sample_R is not None, anchor=x)
+            B, T = xv.shape
+            tgt = target.as_subclass(torch.Tensor).to(dev).float().reshape(T, B).contiguous()
+            st = MlpTrainStep(xv, r, tgt, self.w, self.hidden, self.n_layers, self.fs, self.C, R_static=self.R_static,
+                              skip=int(skip), adam=None, activation=self.act)
+            ent = self.cache[key] = {"st": st, "hold": (x, target), "calls": 0}
+        return ent
+
+
+class MlpResidentFn(torch.autograd.Function):
+    """loss = MSE + ESR of the resident MLP-root clipper; the step that produced it produced d loss / d weights."""
+
+    @staticmethod
+    def forward(ctx, res, ent, *variables):
+        st = ent["st"]
+        st.step()
+        ent["calls"] += 1
+        if ent["calls"] == 24:                                   # the controller has settled: one measured re-plan
+            st.replan()
+        out = torch.cat((st.loss3[2:3], st.gw))                  # (a validation pass may run before backward)
+        ctx.save_for_backward(out)
+        ctx.spec = [res.spec[id(v)] for v in variables]
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, gl, _):
+        (out,) = ctx.saved_tensors
+        return (None, None) + tuple((gl * out[1 + o:1 + o + n]).view(shape) for o, n, shape in ctx.spec)

@@ -276,3 +276,64 @@ def test_step_rejects_what_it_does_not_cover():
     x, r, xd, rd, wh, hidden, n_layers, target = problem(16, 40, "2x16_pre")   # T not a multiple of 16
     with pytest.raises(wb.WdfHipError):
         mlp_root.MlpTrainStep(xd, rd, target, cuda(wh), hidden, n_layers, FS, workload.C_CLIPPER)
+
+
+def _clipper_pot_model(name="2x16_pre"):
+    """clipper_pot.py:94-101 with a committed reference network (weights from the golden fixture)."""
+    import tf_wdf as wdf
+    from layers import DenseRootModel
+    from wdf_hip import workload
+    wh, hidden, n_layers = workload.reference_mlp_weights(name)
+    layers_json, o, n_in = [], 0, 2
+    sizes = [2] + [hidden] * n_layers + [1]
+    for i in range(len(sizes) - 1):
+        ni, no = sizes[i], sizes[i + 1]
+        k = wh[o:o + ni * no].reshape(ni, no); o += ni * no
+        b = wh[o:o + no]; o += no
+        layers_json.append({"type": "dense", "activation": "tanh" if i < len(sizes) - 2 else "", "shape": [None, no],
+                            "weights": [k.tolist(), b.tolist()]})
+    Vs = wdf.ResistiveVoltageSource(45.0e3)
+    C = wdf.Capacitor(workload.C_CLIPPER, FS)
+    P1 = wdf.Parallel(Vs, C)
+    model = DenseRootModel({"in_shape": [None, 2], "layers": layers_json})
+    return wdf, wdf.Circuit(P1, model, C, per_sample_R=Vs), model
+
+
+def test_clipper_pot_loop_through_the_element_api_on_the_resident_step():
+    """clipper_pot.py:245-269 as the script writes it -- GradientTape, the MSE + ESR loss past 50 samples, tape.gradient over
+    model.trainable_variables, Adam(1e-4, beta_1 0.5).apply_gradients -- on a circuit moved to the device: every epoch is
+    one resident training step + one Adam launch; the weights follow the loop on the plain path."""
+    from wdf_hip import workload, binding as wb
+    B, T, skip = 96, 1024, 50
+    x = workload.sweep_batch(B, T, seed=4) * 0.6
+    r = workload.dataset_resistance_batch(B, T)
+    xin = cuda(np.stack([x, r], axis=-1))                       # [B,T,2]: Vin, R (clipper_pot.py:68-70)
+    target, _, _ = wb.clipper_fwd(cuda(x), cuda(workload.clipper_theta()), FS, r=cuda(r), want_stash=False)
+    ends = []
+    for resident in (False, True):
+        wdf, circ, model = _clipper_pot_model()
+        tf = wdf.tf
+        if resident:
+            circ.to_device()
+        opt = tf.keras.optimizers.Adam(learning_rate=1.0e-4, beta_1=0.5)          # clipper_pot.py:180
+        tv = model.trainable_variables
+        assert len(tv) == 8
+        w_init = torch.cat([v.as_subclass(torch.Tensor).detach().reshape(-1).cuda() for v in tv]).clone()
+        losses = []
+        for _ in range(12):
+            with tf.GradientTape() as tape:
+                loss = circ.mse_esr(xin, target, skip)
+            grads = tape.gradient(loss, tv)
+            opt.apply_gradients(zip(grads, tv))
+            losses.append(float(loss))
+        if resident:
+            assert all(v.is_cuda for v in tv) and ("flat", id(circ._mlp)) in opt._resident      # one Adam launch per epoch
+            assert next(iter(circ._mlp.cache.values()))["st"].read()[0]["calls"] == 12
+            y_val = circ(xin)                                    # a validation forward reads the same (moved) weights
+            assert y_val.shape == (T, B)
+        ends.append((torch.cat([v.as_subclass(torch.Tensor).detach().reshape(-1).cuda() for v in tv]), losses, w_init))
+    (w0, l0, wi), (w1, l1, _) = ends
+    moved = float((w0 - wi).abs().max())
+    print(f"loss {l0[0]:.5e} -> {l0[-1]:.5e} (plain) / {l1[-1]:.5e} (resident); |w - w'| {float((w0 - w1).abs().max()):.2e} of {moved:.2e}")
+    assert all(abs(a - b) <= 5e-3 * a for a, b in zip(l0, l1))
+    assert float((w0 - w1).abs().max()) <= 0.05 * moved
