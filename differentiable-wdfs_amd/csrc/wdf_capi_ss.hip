@@ -399,7 +399,7 @@ size_t wdf_ss_lin_step_ws_bytes(int ns, int ni, int64_t B, int64_t T, int n_chun
     int64_t L; int K;
     lin_step_geom(T, n_chunks, L, K);
     const size_t waves = (size_t)((B + 63) / 64) * (size_t)K;
-    return 256 + (size_t)2 * (size_t)K * (size_t)lin_step_d(ns, ni) * (size_t)B * sizeof(float) + 256 +
+    return 256 + (size_t)K * (size_t)lin_step_d(ns, ni) * (size_t)B * sizeof(float) + 256 +
            waves * (size_t)(lin_step_g(ns, ni) + 1) * sizeof(double);
 }
 
@@ -419,20 +419,27 @@ int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, in
     const int D = lin_step_d(ns, ni);
     unsigned* ticket = (unsigned*)ws;
     float* uend0 = (float*)((char*)ws + 256);
-    float* ustart = uend0 + (size_t)K * (size_t)D * (size_t)B;
-    double* part = (double*)(((uintptr_t)(ustart + (size_t)K * (size_t)D * (size_t)B) + 255) & ~(uintptr_t)255);
-    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K), one((unsigned)((B + 63) / 64));
+    double* part = (double*)(((uintptr_t)(uend0 + (size_t)K * (size_t)D * (size_t)B) + 255) & ~(uintptr_t)255);
+    // two sequences per lane (8-byte loads and stores) when the rows of x, target, y and the workspace allow it
+    const bool pair = (B % 2 == 0) && ((((uintptr_t)x | (uintptr_t)target | (uintptr_t)y | (uintptr_t)ws) & 7u) == 0);
+    const int64_t per_wave = pair ? 128 : 64;
+    const dim3 grid((unsigned)((B + per_wave - 1) / per_wave), (unsigned)K);
     hipStream_t s = (hipStream_t)stream;
+#define WDF_LIN_STEP_V(NS_, NI_, V_)                                                                               \
+    {                                                                                                              \
+        if (NS_ > 0 && K > 1)                                                                                      \
+            hipLaunchKernelGGL((wdf::ss_lin_step_zero_kernel<NS_, NI_, V_>), grid, dim3(64), 0, s, x, coef, uend0, B, T, L);   \
+        EventBracket bracket(s);                                                                                   \
+        hipLaunchKernelGGL((wdf::ss_lin_step_kernel<NS_, NI_, V_>), grid, dim3(64), 0, s, x, coef, (const float*)uend0, \
+                           target, gscale, y, part, ticket, jac, n_params, out, gcoef_out, B, T, L);               \
+    }
 #define WDF_LIN_STEP(NS_, NI_)                                                                                     \
     if (ns == NS_ && ni == NI_) {                                                                                  \
-        if (NS_ > 0 && K > 1)                                                                                      \
-            hipLaunchKernelGGL((wdf::ss_lin_step_zero_kernel<NS_, NI_>), grid, dim3(64), 0, s, x, coef, uend0, B, T, L);   \
-        EventBracket bracket(s);                                                                                   \
-        hipLaunchKernelGGL((wdf::ss_lin_step_kernel<NS_, NI_>), grid, dim3(64), 0, s, x, coef, (const float*)nullptr, (const float*)uend0, \
-                           target, gscale, y, part, ticket, jac, n_params, out, gcoef_out, B, T, L);               \
+        if (pair) WDF_LIN_STEP_V(NS_, NI_, wdf::v2f) else WDF_LIN_STEP_V(NS_, NI_, float)                          \
     }
     WDF_LIN_STEP(0, 1) WDF_LIN_STEP(0, 2) WDF_LIN_STEP(1, 1) WDF_LIN_STEP(1, 2) WDF_LIN_STEP(2, 1) WDF_LIN_STEP(2, 2)
 #undef WDF_LIN_STEP
+#undef WDF_LIN_STEP_V
     return check_launch("wdf_ss_lin_step_mse");
 }
 

@@ -26,6 +26,7 @@
 
 #include "wdf_statespace.h"
 #include "wdf_clipper.h"      // wave_sum_dpp
+#include "wdf_vec.h"
 
 namespace wdf {
 
@@ -78,83 +79,91 @@ static __global__ __launch_bounds__(64) void ss_probe_kernel(const int32_t* __re
 }
 
 // ---- the joint recursion ------------------------------------------------------------------------------------------------
-template <int NS, int NI>
+// V = float: one sequence per lane; V = v2f: two adjacent sequences (8-byte loads and stores: half the memory instructions)
+template <typename V> __device__ __forceinline__ V lin_ld(const float* p) { return *reinterpret_cast<const V*>(p); }
+template <typename V> __device__ __forceinline__ void lin_st(float* p, V v) { *reinterpret_cast<V*>(p) = v; }
+template <typename V> __device__ __forceinline__ void lin_st_nt(float* p, V v) { __builtin_nontemporal_store(v, reinterpret_cast<V*>(p)); }
+__device__ __forceinline__ double lin_hsum(float v) { return (double)v; }
+__device__ __forceinline__ double lin_hsum(v2f v) { return (double)v.x + (double)v.y; }
+
+template <int NS, int NI, typename V>
 struct LinU {
     static constexpr int nA = NS * NS, nB = NS * NI;
     static constexpr int kD = NS * (1 + nA + nB);                // floats per sequence: z, S_A[nA][NS], S_B[nB][NS]
     static constexpr int kG = nA + nB + NS + NI;                 // gradient entries: A, Bx, cy, dy
-    float z[NS > 0 ? NS : 1];
-    float SA[nA > 0 ? nA : 1][NS > 0 ? NS : 1];
-    float SB[nB > 0 ? nB : 1][NS > 0 ? NS : 1];
+    V z[NS > 0 ? NS : 1];
+    V SA[nA > 0 ? nA : 1][NS > 0 ? NS : 1];
+    V SB[nB > 0 ? nB : 1][NS > 0 ? NS : 1];
     __device__ __forceinline__ void zero()
     {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) z[s] = 0.0f;
+        for (int s = 0; s < NS; ++s) z[s] = vsplat<V>(0.0f);
 #pragma unroll
         for (int c = 0; c < nA; ++c)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) SA[c][s] = 0.0f;
+            for (int s = 0; s < NS; ++s) SA[c][s] = vsplat<V>(0.0f);
 #pragma unroll
         for (int c = 0; c < nB; ++c)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) SB[c][s] = 0.0f;
+            for (int s = 0; s < NS; ++s) SB[c][s] = vsplat<V>(0.0f);
     }
     // [kD][B] planes at p (p already points at this lane's column)
     __device__ __forceinline__ void store(float* __restrict__ p, int64_t B) const
     {
         int o = 0;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) p[(o++) * B] = z[s];
+        for (int s = 0; s < NS; ++s) lin_st<V>(p + (o++) * B, z[s]);
 #pragma unroll
         for (int c = 0; c < nA; ++c)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) p[(o++) * B] = SA[c][s];
+            for (int s = 0; s < NS; ++s) lin_st<V>(p + (o++) * B, SA[c][s]);
 #pragma unroll
         for (int c = 0; c < nB; ++c)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) p[(o++) * B] = SB[c][s];
+            for (int s = 0; s < NS; ++s) lin_st<V>(p + (o++) * B, SB[c][s]);
     }
     __device__ __forceinline__ void load(const float* __restrict__ p, int64_t B)
     {
         int o = 0;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) z[s] = p[(o++) * B];
+        for (int s = 0; s < NS; ++s) z[s] = lin_ld<V>(p + (o++) * B);
 #pragma unroll
         for (int c = 0; c < nA; ++c)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) SA[c][s] = p[(o++) * B];
+            for (int s = 0; s < NS; ++s) SA[c][s] = lin_ld<V>(p + (o++) * B);
 #pragma unroll
         for (int c = 0; c < nB; ++c)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) SB[c][s] = p[(o++) * B];
+            for (int s = 0; s < NS; ++s) SB[c][s] = lin_ld<V>(p + (o++) * B);
     }
 };
 
 // one step of u = (z, S_A, S_B) with input x
-template <int NS, int NI>
-__device__ __forceinline__ void lin_u_step(const SSCoef<NS, NI>& c, const float (&x)[NI], LinU<NS, NI>& u)
+template <int NS, int NI, typename V>
+__device__ __forceinline__ void lin_u_step(const SSCoef<NS, NI>& c, const V (&x)[NI], LinU<NS, NI, V>& u)
 {
     using C = SSCoef<NS, NI>;
-    float zn[NS > 0 ? NS : 1];
+    const V zero = vsplat<V>(0.0f);
+    V zn[NS > 0 ? NS : 1];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        float a = 0.0f;
+        V a = zero;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) a = fmaf(c.v[C::oB + s * NI + i], x[i], a);
+        for (int i = 0; i < NI; ++i) a = vfma(c.v[C::oB + s * NI + i], x[i], a);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) a = fmaf(c.v[C::oA + s * NS + q], u.z[q], a);
+        for (int q = 0; q < NS; ++q) a = vfma(c.v[C::oA + s * NS + q], u.z[q], a);
         zn[s] = a;
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
         for (int j = 0; j < NS; ++j) {                            // S_{A_ij}' = A S + e_i z_j
-            float sn[NS > 0 ? NS : 1];
+            V sn[NS > 0 ? NS : 1];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                float a = (s == i) ? u.z[j] : 0.0f;
+                V a = (s == i) ? u.z[j] : zero;
 #pragma unroll
-                for (int q = 0; q < NS; ++q) a = fmaf(c.v[C::oA + s * NS + q], u.SA[i * NS + j][q], a);
+                for (int q = 0; q < NS; ++q) a = vfma(c.v[C::oA + s * NS + q], u.SA[i * NS + j][q], a);
                 sn[s] = a;
             }
 #pragma unroll
@@ -164,12 +173,12 @@ __device__ __forceinline__ void lin_u_step(const SSCoef<NS, NI>& c, const float 
     for (int i = 0; i < NS; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {                            // S_{Bx_ij}' = A S + e_i x_j
-            float sn[NS > 0 ? NS : 1];
+            V sn[NS > 0 ? NS : 1];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                float a = (s == i) ? x[j] : 0.0f;
+                V a = (s == i) ? x[j] : zero;
 #pragma unroll
-                for (int q = 0; q < NS; ++q) a = fmaf(c.v[C::oA + s * NS + q], u.SB[i * NI + j][q], a);
+                for (int q = 0; q < NS; ++q) a = vfma(c.v[C::oA + s * NS + q], u.SB[i * NI + j][q], a);
                 sn[s] = a;
             }
 #pragma unroll
@@ -182,116 +191,60 @@ __device__ __forceinline__ void lin_u_step(const SSCoef<NS, NI>& c, const float 
 constexpr int kLinBlk = 8;                                         // steps whose loads are issued together
 
 // x: [T][NI][B] (time-major: the engine's resident training set); loads kLinBlk steps of lane b
-template <int NI>
-__device__ __forceinline__ void lin_load_x(const float* __restrict__ x, int64_t B, int64_t b, int64_t t, int n, float (&xs)[kLinBlk][NI])
+template <int NI, typename V>
+__device__ __forceinline__ void lin_load_x(const float* __restrict__ x, int64_t B, int64_t b, int64_t t, int n, V (&xs)[kLinBlk][NI])
 {
 #pragma unroll
     for (int k = 0; k < kLinBlk; ++k)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) xs[k][i] = (k < n) ? x[((t + k) * NI + i) * B + b] : 0.0f;
+        for (int i = 0; i < NI; ++i) xs[k][i] = (k < n) ? lin_ld<V>(x + ((t + k) * NI + i) * B + b) : vsplat<V>(0.0f);
 }
 
+template <typename V> struct LinWidth { static constexpr int w = 1; };
+template <> struct LinWidth<v2f> { static constexpr int w = 2; };
+
 // ---- pass 1: every chunk from u = 0 -> uend0 [K][kD][B] ------------------------------------------------------------------
-template <int NS, int NI>
+// (V = v2f: B even; a lane holds sequences b, b + 1)
+template <int NS, int NI, typename V>
 __global__ __launch_bounds__(64) void ss_lin_step_zero_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                               float* __restrict__ uend0, int64_t B, int64_t T, int64_t L)
 {
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int64_t b = b_raw < B ? b_raw : B - 1;
+    constexpr int W = LinWidth<V>::w;
+    const int64_t b_raw = ((int64_t)blockIdx.x * 64 + threadIdx.x) * W;
+    const int64_t b = b_raw < B ? b_raw : B - W;
     const int64_t k = blockIdx.y, t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
     if (t1 == T) return;                                          // (nothing comes after the last chunk)
     SSCoef<NS, NI> c;
     c.load(coef);
-    LinU<NS, NI> u;
+    LinU<NS, NI, V> u;
     u.zero();
     for (int64_t tb = t0; tb < t1; tb += kLinBlk) {
         const int n = t1 - tb < kLinBlk ? (int)(t1 - tb) : kLinBlk;
-        float xs[kLinBlk][NI];
-        lin_load_x<NI>(x, B, b, tb, n, xs);
+        V xs[kLinBlk][NI];
+        lin_load_x<NI, V>(x, B, b, tb, n, xs);
 #pragma unroll
         for (int i = 0; i < kLinBlk; ++i)
-            if (i < n) lin_u_step<NS, NI>(c, xs[i], u);
+            if (i < n) lin_u_step<NS, NI, V>(c, xs[i], u);
     }
-    if (b_raw < B) u.store(uend0 + (k * LinU<NS, NI>::kD) * B + b, B);
-}
-
-// ---- the walk: ustart [K][kD][B], exact ----------------------------------------------------------------------------------
-// Phi: a chunk run from z = e_j (S = 0, no input) ends in z = A^L e_j, S_{A c} = G_c e_j; S_B's homogeneous part is A^L too.
-template <int NS, int NI>
-__global__ __launch_bounds__(64) void ss_lin_step_starts_kernel(const float* __restrict__ coef, const float* __restrict__ uend0,
-                                                                float* __restrict__ ustart, int64_t B, int64_t K, int64_t L)
-{
-    using U = LinU<NS, NI>;
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int64_t b = b_raw < B ? b_raw : B - 1;
-    SSCoef<NS, NI> c;
-    c.load(coef);
-    float AL[NS > 0 ? NS : 1][NS > 0 ? NS : 1], G[U::nA > 0 ? U::nA : 1][NS > 0 ? NS : 1][NS > 0 ? NS : 1];
-    const float zero_x[NI] = {};
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        U h;
-        h.zero();
-        h.z[j] = 1.0f;
-        for (int64_t t = 0; t < L; ++t) lin_u_step<NS, NI>(c, zero_x, h);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) AL[s][j] = h.z[s];
-#pragma unroll
-        for (int cc = 0; cc < U::nA; ++cc)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) G[cc][s][j] = h.SA[cc][s];
-    }
-    U u;
-    u.zero();                                                     // reset(): zero initial state (Circuit.__call__'s default)
-    for (int64_t k = 0; k < K; ++k) {
-        if (b_raw < B) u.store(ustart + (k * U::kD) * B + b, B);
-        if (k + 1 == K) break;
-        U p;
-        p.load(uend0 + (k * U::kD) * B + b, B);
-        U n;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            float a = p.z[s];
-#pragma unroll
-            for (int q = 0; q < NS; ++q) a = fmaf(AL[s][q], u.z[q], a);
-            n.z[s] = a;
-        }
-#pragma unroll
-        for (int cc = 0; cc < U::nA; ++cc)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                float a = p.SA[cc][s];
-#pragma unroll
-                for (int q = 0; q < NS; ++q) a = fmaf(AL[s][q], u.SA[cc][q], fmaf(G[cc][s][q], u.z[q], a));
-                n.SA[cc][s] = a;
-            }
-#pragma unroll
-        for (int cc = 0; cc < U::nB; ++cc)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                float a = p.SB[cc][s];
-#pragma unroll
-                for (int q = 0; q < NS; ++q) a = fmaf(AL[s][q], u.SB[cc][q], a);
-                n.SB[cc][s] = a;
-            }
-        u = n;
-    }
+    if (b_raw < B) u.store(uend0 + (k * LinU<NS, NI, V>::kD) * B + b, B);
 }
 
 // u <- the exact joint state at the start of chunk k (zero initial state), from the zero-state chunk ends uend0 [K][kD][B]
-template <int NS, int NI>
+// Phi: a chunk run from z = e_j (S = 0, no input) ends in z = A^L e_j, S_{A c} = G_c e_j; S_B's homogeneous part is A^L too.
+template <int NS, int NI, typename V>
 __device__ __forceinline__ void lin_walk_to(const SSCoef<NS, NI>& c, const float* __restrict__ uend0, int64_t B, int64_t b,
-                                            int64_t k, int64_t L, LinU<NS, NI>& u)
+                                            int64_t k, int64_t L, LinU<NS, NI, V>& u)
 {
-    using U = LinU<NS, NI>;
+    using U = LinU<NS, NI, V>;
+    using H = LinU<NS, NI, float>;
     float AL[NS > 0 ? NS : 1][NS > 0 ? NS : 1], G[U::nA > 0 ? U::nA : 1][NS > 0 ? NS : 1][NS > 0 ? NS : 1];
     const float zero_x[NI] = {};
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        U h;
+        H h;
         h.zero();
         h.z[j] = 1.0f;
-        for (int64_t t = 0; t < L; ++t) lin_u_step<NS, NI>(c, zero_x, h);
+        for (int64_t t = 0; t < L; ++t) lin_u_step<NS, NI, float>(c, zero_x, h);
 #pragma unroll
         for (int s = 0; s < NS; ++s) AL[s][j] = h.z[s];
 #pragma unroll
@@ -307,27 +260,27 @@ __device__ __forceinline__ void lin_walk_to(const SSCoef<NS, NI>& c, const float
         U n;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            float a = p.z[s];
+            V a = p.z[s];
 #pragma unroll
-            for (int r = 0; r < NS; ++r) a = fmaf(AL[s][r], u.z[r], a);
+            for (int r = 0; r < NS; ++r) a = vfma(AL[s][r], u.z[r], a);
             n.z[s] = a;
         }
 #pragma unroll
         for (int cc = 0; cc < U::nA; ++cc)
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                float a = p.SA[cc][s];
+                V a = p.SA[cc][s];
 #pragma unroll
-                for (int r = 0; r < NS; ++r) a = fmaf(AL[s][r], u.SA[cc][r], fmaf(G[cc][s][r], u.z[r], a));
+                for (int r = 0; r < NS; ++r) a = vfma(AL[s][r], u.SA[cc][r], vfma(G[cc][s][r], u.z[r], a));
                 n.SA[cc][s] = a;
             }
 #pragma unroll
         for (int cc = 0; cc < U::nB; ++cc)
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                float a = p.SB[cc][s];
+                V a = p.SB[cc][s];
 #pragma unroll
-                for (int r = 0; r < NS; ++r) a = fmaf(AL[s][r], u.SB[cc][r], a);
+                for (int r = 0; r < NS; ++r) a = vfma(AL[s][r], u.SB[cc][r], a);
                 n.SB[cc][s] = a;
             }
         u = n;
@@ -336,83 +289,81 @@ __device__ __forceinline__ void lin_walk_to(const SSCoef<NS, NI>& c, const float
 }
 
 // ---- pass 2: every chunk from its exact start: y, the squared error, the coefficient gradient; the last wave finishes ------
+// The chunk's exact start is made by the wave itself: Phi = {A^L, G_c} from L homogeneous steps, then the walk over the chunks
+// before it (their zero-state ends: pass 1) -- no separate walk launch.
 // part: double [waves][kG + 1] = {gA.., gBx.., gcy.., gdy.., SSE}; ticket: one word, left 0.
 // jac: double [ncoef (+1)][n_params] of ss_probe_kernel (rows in SSCoef order).  out: float [1 + n_params] = {SSE, dLoss/dparam}.
-template <int NS, int NI>
+template <int NS, int NI, typename V>
 __global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict__ x, const float* __restrict__ coef,
-                                                         const float* __restrict__ ustart, const float* __restrict__ uend0,
-                                                         const float* __restrict__ target,
+                                                         const float* __restrict__ uend0, const float* __restrict__ target,
                                                          float gscale, float* __restrict__ y, double* __restrict__ part,
                                                          unsigned* __restrict__ ticket, const double* __restrict__ jac, int n_params,
                                                          float* __restrict__ out, float* __restrict__ gcoef_out, int64_t B, int64_t T,
                                                          int64_t L)
 {
-    using U = LinU<NS, NI>;
+    using U = LinU<NS, NI, V>;
     using C = SSCoef<NS, NI>;
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    constexpr int W = LinWidth<V>::w;
+    const V zero = vsplat<V>(0.0f);
+    const int64_t b_raw = ((int64_t)blockIdx.x * 64 + threadIdx.x) * W;
     const bool live = b_raw < B;
-    const int64_t b = live ? b_raw : B - 1;
+    const int64_t b = live ? b_raw : B - W;
     const int64_t k = blockIdx.y, t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
     SSCoef<NS, NI> c;
     c.load(coef);
     U u;
-    if (ustart != nullptr) {
-        u.load(ustart + (k * U::kD) * B + b, B);
-    } else {
-        // the chunk's exact start, by this wave itself: Phi = {A^L, G_c} from L homogeneous steps, then the walk over the
-        // chunks before it (their zero-state ends: pass 1) -- a launch and its latency less than the separate walk
-        u.zero();
-        if (NS > 0 && k > 0) lin_walk_to<NS, NI>(c, uend0, B, b, k, L, u);
-    }
+    u.zero();
+    if (NS > 0 && k > 0) lin_walk_to<NS, NI, V>(c, uend0, B, b, k, L, u);
+    const float gs = live ? gscale : 0.0f, lv = live ? 1.0f : 0.0f;
     double acc[U::kG + 1];
 #pragma unroll
     for (int i = 0; i <= U::kG; ++i) acc[i] = 0.0;
     for (int64_t tb = t0; tb < t1; tb += 4 * kLinBlk) {           // fp32 sums within 32 steps, fp64 across
-        float f[U::kG + 1];
+        V f[U::kG + 1];
 #pragma unroll
-        for (int i = 0; i <= U::kG; ++i) f[i] = 0.0f;
+        for (int i = 0; i <= U::kG; ++i) f[i] = zero;
 #pragma unroll 1
         for (int64_t ts = tb; ts < tb + 4 * kLinBlk && ts < t1; ts += kLinBlk) {
             const int n = t1 - ts < kLinBlk ? (int)(t1 - ts) : kLinBlk;
-            float xs[kLinBlk][NI], tg[kLinBlk];
-            lin_load_x<NI>(x, B, b, ts, n, xs);
+            V xs[kLinBlk][NI], tg[kLinBlk];
+            lin_load_x<NI, V>(x, B, b, ts, n, xs);
 #pragma unroll
-            for (int i = 0; i < kLinBlk; ++i) tg[i] = (i < n) ? target[(ts + i) * B + b] : 0.0f;
+            for (int i = 0; i < kLinBlk; ++i) tg[i] = (i < n) ? lin_ld<V>(target + (ts + i) * B + b) : zero;
 #pragma unroll
             for (int i = 0; i < kLinBlk; ++i) {
                 if (i >= n) break;
-                float yv = 0.0f;
+                V yv = zero;
 #pragma unroll
-                for (int j = 0; j < NI; ++j) yv = fmaf(c.v[C::oDy + j], xs[i][j], yv);
+                for (int j = 0; j < NI; ++j) yv = vfma(c.v[C::oDy + j], xs[i][j], yv);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) yv = fmaf(c.v[C::oCy + s], u.z[s], yv);
-                const float e = yv - tg[i];
-                const float g = live ? gscale * e : 0.0f;
-                if (live) __builtin_nontemporal_store(yv, y + (ts + i) * B + b);
-                f[U::kG] = fmaf(live ? e : 0.0f, e, f[U::kG]);
+                for (int s = 0; s < NS; ++s) yv = vfma(c.v[C::oCy + s], u.z[s], yv);
+                const V e = yv - tg[i];
+                const V g = e * gs;
+                if (live) lin_st_nt<V>(y + (ts + i) * B + b, yv);
+                f[U::kG] = vfma(e * lv, e, f[U::kG]);
 #pragma unroll
                 for (int cc = 0; cc < U::nA; ++cc) {
-                    float d = 0.0f;
+                    V d = zero;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) d = fmaf(c.v[C::oCy + s], u.SA[cc][s], d);
-                    f[cc] = fmaf(g, d, f[cc]);
+                    for (int s = 0; s < NS; ++s) d = vfma(c.v[C::oCy + s], u.SA[cc][s], d);
+                    f[cc] = vfma(g, d, f[cc]);
                 }
 #pragma unroll
                 for (int cc = 0; cc < U::nB; ++cc) {
-                    float d = 0.0f;
+                    V d = zero;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) d = fmaf(c.v[C::oCy + s], u.SB[cc][s], d);
-                    f[U::nA + cc] = fmaf(g, d, f[U::nA + cc]);
+                    for (int s = 0; s < NS; ++s) d = vfma(c.v[C::oCy + s], u.SB[cc][s], d);
+                    f[U::nA + cc] = vfma(g, d, f[U::nA + cc]);
                 }
 #pragma unroll
-                for (int s = 0; s < NS; ++s) f[U::nA + U::nB + s] = fmaf(g, u.z[s], f[U::nA + U::nB + s]);
+                for (int s = 0; s < NS; ++s) f[U::nA + U::nB + s] = vfma(g, u.z[s], f[U::nA + U::nB + s]);
 #pragma unroll
-                for (int j = 0; j < NI; ++j) f[U::nA + U::nB + NS + j] = fmaf(g, xs[i][j], f[U::nA + U::nB + NS + j]);
-                lin_u_step<NS, NI>(c, xs[i], u);
+                for (int j = 0; j < NI; ++j) f[U::nA + U::nB + NS + j] = vfma(g, xs[i][j], f[U::nA + U::nB + NS + j]);
+                lin_u_step<NS, NI, V>(c, xs[i], u);
             }
         }
 #pragma unroll
-        for (int i = 0; i <= U::kG; ++i) acc[i] += (double)f[i];
+        for (int i = 0; i <= U::kG; ++i) acc[i] += lin_hsum(f[i]);
     }
     // ---- this wave's partial; the last wave of the launch adds them up in a fixed order and applies the chain rule
     const int64_t wave = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwaves = (int64_t)gridDim.x * gridDim.y;

@@ -13,6 +13,7 @@ tape.gradient(loss, model.trainable_variables) is in the reference (lpf.py:87-90
 """
 import collections
 import math
+import os
 import weakref
 from collections import namedtuple
 
@@ -152,6 +153,9 @@ class _StateSpaceFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------ resident linear trees
+_LIN_OCC = int(os.environ.get("WDF_LIN_OCC", "2"))       # chunks are cut so that every SIMD gets this many waves
+
+
 class _LinResident:
     """A linear tree (ideal-source root) whose component values live on the device: the probed step as a device tape
     (probe_tape.py), and per (x, target) pair the buffers of the one-pass MSE step (csrc/wdf_ss_step.h)."""
@@ -229,7 +233,8 @@ class _LinResident:
                 raise binding.WdfHipError(f"x must be [B,T,{circ.ni}] (or [B,T] for one channel), got {tuple(x.shape)}")
             x_tm = xd.permute(1, 2, 0).contiguous()               # [T][ni][B]: once per training set
             tgt = target.as_subclass(torch.Tensor).to(dev).float().reshape(T, B).contiguous()
-            k = max(1, min(T // 64, (2 * N_SIMD) // max(1, -(-B // 64))))
+            per_wave = 128 if B % 2 == 0 else 64                  # (two sequences per lane when the rows pair up)
+            k = max(1, min(T // 64, (_LIN_OCC * N_SIMD) // max(1, -(-B // per_wave))))
             nbytes = binding.lib().wdf_ss_lin_step_ws_bytes(circ.ns, circ.ni, B, T, k)
             if nbytes == 0:
                 raise binding.WdfHipError(binding.lib().wdf_last_error().decode() or "wdf_ss_lin_step_ws_bytes: unsupported tree")
