@@ -1,4 +1,4 @@
-// wdf_capi_mlp_step.hip -- C ABI part 5 of 5: the resident training step of the MLP-root pot clipper
+// wdf_capi_mlp_step.hip -- C ABI part 5 of 6: the resident training step of the MLP-root pot clipper
 // (csrc/wdf_mlp_step.h): state layout, plan upload, template dispatch and the five launches of a step.
 #include <cstdlib>
 #include <vector>

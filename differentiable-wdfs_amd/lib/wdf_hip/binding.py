@@ -33,7 +33,7 @@ ONE_SEQUENCE_PER_LANE = os.environ.get("WDF_ONE_SEQUENCE_PER_LANE", "") not in (
 GENERAL_ROOT = False
 
 
-ABI_VERSION = 3                # include/wdf_hip.h WDF_HIP_ABI_VERSION
+ABI_VERSION = 4                # include/wdf_hip.h WDF_HIP_ABI_VERSION
 
 
 def _root_flag():
@@ -189,6 +189,18 @@ def lib():
     L.wdf_ss_lin_step_ws_bytes.argtypes = [ci, ci, i64, i64, ci]
     L.wdf_ss_lin_step_mse.restype = ci
     L.wdf_ss_lin_step_mse.argtypes = [fp, fp, vp, ci, ci, ci, fp, cf, fp, vp, fp, fp, i64, i64, ci, vp]
+    L.wdf_ss_nl_step_ws_bytes.restype = C.c_size_t
+    L.wdf_ss_nl_step_ws_bytes.argtypes = [ci, ci, i64, i64, ci]
+    L.wdf_ss_nl_step_chunk_len.restype = ci
+    L.wdf_ss_nl_step_chunk_len.argtypes = [i64, ci]
+    L.wdf_ss_nl_step_plan.restype = ci
+    L.wdf_ss_nl_step_plan.argtypes = [vp, ci, ci, i64, i64, ci, ci, ci, ci, ci, cf, vp]
+    L.wdf_ss_nl_step_set.restype = ci
+    L.wdf_ss_nl_step_set.argtypes = [vp, ci, C.c_double, vp]
+    L.wdf_ss_nl_step_read.restype = ci
+    L.wdf_ss_nl_step_read.argtypes = [vp, vp, vp]
+    L.wdf_ss_nl_step_mse.restype = ci
+    L.wdf_ss_nl_step_mse.argtypes = [fp, fp, fp, vp, ci, ci, ci, ci, ci, fp, cf, fp, vp, fp, i64, i64, ci, vp]
     L.wdf_ss_ncoef.restype = ci
     L.wdf_ss_ncoef.argtypes = [ci, ci]
     L.wdf_ss_fwd.restype = ci
@@ -254,6 +266,8 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_step_state_bytes", "wdf_clipper_mlp_step_plan", "wdf_clipper_mlp_step_read", "wdf_clipper_mlp_step_set",
     "wdf_clipper_mlp_step_set_wcol", "wdf_clipper_mlp_step_prepare", "wdf_clipper_mlp_step",
     "wdf_ss_probe", "wdf_ss_lin_step_ws_bytes", "wdf_ss_lin_step_mse",
+    "wdf_ss_nl_step_ws_bytes", "wdf_ss_nl_step_chunk_len", "wdf_ss_nl_step_plan", "wdf_ss_nl_step_set", "wdf_ss_nl_step_read",
+    "wdf_ss_nl_step_mse",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
     "wdf_ss_tp_chunks", "wdf_ss_tp_starts", "wdf_ss_fwd_tp_ws_bytes", "wdf_ss_fwd_tp", "wdf_ss_bwd_tp_ws_bytes", "wdf_ss_bwd_tp",
     "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step",

@@ -154,6 +154,8 @@ class _StateSpaceFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------ resident linear trees
 _LIN_OCC = int(os.environ.get("WDF_LIN_OCC", "2"))       # chunks are cut so that every SIMD gets this many waves
+_NL_OCC = int(os.environ.get("WDF_NL_OCC", "1"))
+NL_TOL = 1.0e-6                                          # boundary tolerance of the diode-root one-pass step (plan_ss_time_parallel's)
 
 
 class _LinResident:
@@ -234,21 +236,68 @@ class _LinResident:
             x_tm = xd.permute(1, 2, 0).contiguous()               # [T][ni][B]: once per training set
             tgt = target.as_subclass(torch.Tensor).to(dev).float().reshape(T, B).contiguous()
             per_wave = 128 if B % 2 == 0 else 64                  # (two sequences per lane when the rows pair up)
-            k = max(1, min(T // 64, (_LIN_OCC * N_SIMD) // max(1, -(-B // per_wave))))
-            nbytes = binding.lib().wdf_ss_lin_step_ws_bytes(circ.ns, circ.ni, B, T, k)
-            if nbytes == 0:
-                raise binding.WdfHipError(binding.lib().wdf_last_error().decode() or "wdf_ss_lin_step_ws_bytes: unsupported tree")
-            ent = self.cache[key] = {"x": x_tm, "t": tgt, "y": torch.empty((T, B), dtype=torch.float32, device=dev),
-                                     "ws": torch.zeros((nbytes,), dtype=torch.uint8, device=dev),
+            L_ = binding.lib()
+            y = torch.empty((T, B), dtype=torch.float32, device=dev)
+            if circ.root_kind == "DiodePair":
+                # the tangent-carried step of a diode-pair root: chunks no shorter than 64 steps, one wave per SIMD and up
+                k = max(1, min(T // 64, (_NL_OCC * N_SIMD) // max(1, -(-B // per_wave))))
+                nbytes = L_.wdf_ss_nl_step_ws_bytes(circ.ns, circ.ni, B, T, k)
+                if nbytes == 0:
+                    raise binding.WdfHipError(L_.wdf_last_error().decode() or "wdf_ss_nl_step_ws_bytes: unsupported tree")
+                ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+                Lc = L_.wdf_ss_nl_step_chunk_len(T, k)
+                cold = self.cold_warmup()
+                warm = max(16, min(Lc // 16 * 16, 64))
+                binding._check(L_.wdf_ss_nl_step_plan(binding._ptr(ws), circ.ns, circ.ni, B, T, k, cold, warm, 16,
+                                                      max(16, Lc // 16 * 16), float(NL_TOL), binding._stream()), "wdf_ss_nl_step_plan")
+            else:
+                k = max(1, min(T // 64, (_LIN_OCC * N_SIMD) // max(1, -(-B // per_wave))))
+                nbytes = L_.wdf_ss_lin_step_ws_bytes(circ.ns, circ.ni, B, T, k)
+                if nbytes == 0:
+                    raise binding.WdfHipError(L_.wdf_last_error().decode() or "wdf_ss_lin_step_ws_bytes: unsupported tree")
+                ws = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
+            ent = self.cache[key] = {"x": x_tm, "t": tgt, "y": y, "ws": ws,
                                      "out": torch.zeros((1 + self.pb.n,), dtype=torch.float32, device=dev),
                                      "B": B, "T": T, "k": k, "hold": (x, target)}
         return ent
+
+    def cold_warmup(self):
+        """Warm-up of a chunk that starts from z = 0 (the first call on a batch): outlasts the slowest mode of the step's
+        Jacobian A + Da E ca^T over the diode's slope Da in [-1, 1] (plan_ss_time_parallel's estimate), from the host mirror."""
+        c, _ = self.host_coef()
+        ns, ni = self.circ.ns, self.circ.ni
+        A = np.asarray(c[:ns * ns]).reshape(ns, ns)
+        oE = ns * ns + ns * ni
+        E, ca = np.asarray(c[oE:oE + ns]), np.asarray(c[oE + ns:oE + 2 * ns])
+        rho = max(float(np.max(np.abs(np.linalg.eigvals(A + sgn * np.outer(E, ca))))) for sgn in (1.0, -1.0))
+        if rho <= 0.0:
+            return 16
+        if rho >= 1.0 - 1e-9:
+            return 4096
+        return int(min(4096, max(16, -(-int(math.ceil(math.log(0.01 * NL_TOL) / math.log(rho))) // 16) * 16)))
+
+    def read_ctl(self, ent):
+        """The step's control block (csrc/wdf_ss_nl_step.h, NlStepCtl) as a dict -- synchronises."""
+        raw = np.zeros(32, dtype=np.int32)
+        binding._check(binding.lib().wdf_ss_nl_step_read(binding._ptr(ent["ws"]), raw.ctypes.data, binding._stream()), "wdf_ss_nl_step_read")
+        f = raw.view(np.float32)
+        return {"call": int(raw[0]), "parity": int(raw[1]), "have_snap": int(raw[2]), "w_cur": int(raw[3]), "w_snap": int(raw[4]),
+                "w_min": int(raw[5]), "w_max": int(raw[6]), "cool": int(raw[7]), "tol": float(f[8]), "n_bad": int(raw[12]),
+                "max_miss": float(f[13]), "gated_groups": int(raw[14]), "total_gated": int(raw[15]), "w_used": int(raw[19])}
 
     def step(self, ent):
         """probe + one-pass step -> ent["out"] = {SSE, d(mean squared error)/d component value}."""
         circ = self.circ
         self.probe()
         B, T = ent["B"], ent["T"]
+        if circ.root_kind == "DiodePair":
+            rc = binding.lib().wdf_ss_nl_step_mse(binding._ptr(ent["x"]), binding._ptr(self.coef), binding._ptr(self.pb.block),
+                                                  binding._ptr(self.jac), self.n_tree, circ.ns, circ.ni, int(circ.root.N_up),
+                                                  int(circ.root.N_down), binding._ptr(ent["t"]), 2.0 / float(B * T),
+                                                  binding._ptr(ent["y"]), binding._ptr(ent["ws"]), binding._ptr(ent["out"]), B, T,
+                                                  ent["k"], binding._stream())
+            binding._check(rc, "wdf_ss_nl_step_mse")
+            return ent["out"]
         rc = binding.lib().wdf_ss_lin_step_mse(binding._ptr(ent["x"]), binding._ptr(self.coef), binding._ptr(self.jac), self.pb.n,
                                                circ.ns, circ.ni, binding._ptr(ent["t"]), 2.0 / float(B * T), binding._ptr(ent["y"]),
                                                binding._ptr(ent["ws"]), binding._ptr(ent["out"]), None, B, T, ent["k"],
@@ -536,6 +585,9 @@ class Circuit:
         target: [T,B] like the output."""
         binding.require_gpu()
         lin = getattr(self, "_lin", None)
+        if lin is None and getattr(self, "_tree", None) is not None and self.root_kind == "DiodePair" and 1 <= self.ns <= 2 \
+                and 1 <= self.ni <= 2 and not self.force_generic:
+            lin = self._tree                                     # diode-pair root: the tangent-carried step (csrc/wdf_ss_nl_step.h)
         if lin is not None and isinstance(x, torch.Tensor) and isinstance(target, torch.Tensor):
             lin.check()
             ent = lin.entry(x, target)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WDF_HIP_ABI_VERSION 3   /* 3: + wdf_clipper_mlp_step_* (round 4); TpCtl is 128 bytes, warm-up units are 16 steps */
+#define WDF_HIP_ABI_VERSION 4   /* 3: + wdf_clipper_mlp_step_* (round 4); TpCtl is 128 bytes, warm-up units are 16 steps.  4: + wdf_ss_nl_step_*; the linear step's workspace shrank */
 
 enum {
     WDF_OK = 0,
@@ -319,6 +319,35 @@ size_t wdf_ss_lin_step_ws_bytes(int ns, int ni, int64_t B, int64_t T, int n_chun
 int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, int n_params, int ns, int ni,
                         const float* target, float gscale, float* y, void* ws, float* out, float* gcoef_out,
                         int64_t B, int64_t T, int n_chunks, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * The one-pass MSE training step of small trees with a DIODE-PAIR root (csrc/wdf_ss_nl_step.h): the same epoch
+ * (forward, MeanSquaredError, tape.gradient to the component values and to the root's Is / nVt -- tf_wdf.py:179-214,
+ * HPFDiodeClipper.h:28-32's circuit) with the state's forward-mode tangents carried next to the state: no state
+ * stash, no dLoss/dy array, no reverse sweep -- 12 bytes per sample.  Time chunks: the tangents are exact (linear
+ * given the trajectory: chunk records + a walk); the state of chunk k starts w steps early from the PREVIOUS call's
+ * state at that sample moved along its tangents by the change of the coefficients, every boundary is verified on the
+ * device (tol) and a group of sequences that missed is re-run sequentially by its finishing wave; w is steered on the
+ * device.  Two launches.  ns 1..2, ni 1..2, zero initial state, x TIME-major [T][ni][B].
+ *   wdf_ss_nl_step_plan   zeroes the control part of ws and sets the warm-ups (multiples of 16): cold_warmup for the
+ *                         first call (from z = 0), warm_warmup where it takes the snapshots for the second; afterwards
+ *                         the device moves it inside [w_min, min(w_max, chunk length)].
+ *   wdf_ss_nl_step_mse    coef: wdf_ss_probe's float32 outputs (coefficients, then the port resistance the root sees);
+ *                         params: the component values on the device with Is, nVt at [n_tree], [n_tree + 1];
+ *                         jac: double [ncoef + 1][n_tree].  out: float [1 + n_tree + 2] = {SSE, d(gscale/2 SSE)/d{component
+ *                         values, Is, nVt}}.
+ *   wdf_ss_nl_step_read   the 32-word control block {call, parity, have_snap, w_cur, w_snap, w_min, w_max, cool, tol,
+ *                         grow_at, shrink_at, cool_miss, n_bad, max_miss, gated_groups, total_gated, ..., w_used at [19]}
+ *                         (synchronises).  wdf_ss_nl_step_set: field 2..11 of it (tests, tuning).                  */
+size_t wdf_ss_nl_step_ws_bytes(int ns, int ni, int64_t B, int64_t T, int n_chunks);
+int wdf_ss_nl_step_chunk_len(int64_t T, int n_chunks);
+int wdf_ss_nl_step_plan(void* ws, int ns, int ni, int64_t B, int64_t T, int n_chunks, int cold_warmup, int warm_warmup,
+                        int w_min, int w_max, float tol, void* stream);
+int wdf_ss_nl_step_set(void* ws, int field, double value, void* stream);
+int wdf_ss_nl_step_read(const void* ws, int32_t* ctl_out, void* stream);
+int wdf_ss_nl_step_mse(const float* x, const float* coef, const float* params, const double* jac, int n_tree, int ns,
+                       int ni, int n_up, int n_down, const float* target, float gscale, float* y, void* ws, float* out,
+                       int64_t B, int64_t T, int n_chunks, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * The RESIDENT training step of the MLP-root pot clipper (csrc/wdf_mlp_step.h): what one epoch of

@@ -1,0 +1,198 @@
+"""GPU: the one-pass MSE training step of small trees with a DIODE-PAIR root and resident component values
+(csrc/wdf_ss_nl_step.h through Circuit.to_device() + Circuit.mse()): HPFDiodeClipper.h:28-32's circuit in lpf.py:77-99's loop
+shape -- forward, loss and the five gradients against the fp64 oracle (cold chunks, predicted warm starts, forced misses that
+the finishing waves repair sequentially), a two-state tree against the host-probe path, and the device's warm-up control."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+FS = 48000
+THETA = np.array([33.0e3, 1.0e3, 22.0e-9, 4.352e-9, 25.85e-3 * 1.906], dtype=np.float32).astype(np.float64)
+
+
+def cuda(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b) / np.abs(b)))
+
+
+@pytest.fixture
+def wdf():
+    import tf_wdf
+    return tf_wdf
+
+
+def hpf(wdf, n_up=2, n_down=3, theta=THETA):
+    """HPFDiodeClipper.h:28-32: Parallel(R, Series(Vs, C)) + diode pair."""
+    R = wdf.Resistor(float(theta[0]), True)
+    Vs = wdf.ResistiveVoltageSource(float(theta[1]), trainable=True)
+    C = wdf.Capacitor(float(theta[2]), FS, True)
+    top = wdf.Parallel(R, wdf.Series(Vs, C))
+    dp = wdf.DiodePair(top, float(theta[3]), Vt=float(theta[4]), nDiodes=1.0, N_up=n_up, N_down=n_down, trainable=True)
+    return wdf.Circuit(top, dp, R), [R.R, Vs.R, C.C, dp.Is, dp.nVt]
+
+
+def oracle_hpf(O, theta, x, tgt, n_up, n_down):
+    """-> (y [T,B], mean squared error, its gradient w.r.t. {R, Rs, C, Is, nVt}) in float64."""
+    nodes = [(O.NODE_RESISTOR, -1, -1, 0, -1, -1), (O.NODE_RES_VSOURCE, -1, -1, 1, 0, -1),
+             (O.NODE_CAPACITOR, -1, -1, 2, -1, -1), (O.NODE_SERIES, 1, 2, -1, -1, -1), (O.NODE_PARALLEL, 0, 3, -1, -1, -1)]
+    oc = O.Circuit(nodes, top=4, probe=0, n_in=1, root_kind=O.ROOT_DIODE_PAIR, fs=FS, p_is=3, p_nvt=4, n_up=n_up, n_down=n_down)
+    y = O.tree_fwd(oc, theta, x.astype(np.float64))
+    e = y - tgt.astype(np.float64)
+    gy = 2.0 * e / e.size
+    return y, float(np.mean(e * e)), O.tree_grad(oc, theta, x.astype(np.float64), gy)
+
+
+def one_call(wdf, circ, params, x, tgt):
+    tf = wdf.tf
+    with tf.GradientTape() as tape:
+        loss = circ.mse(x, tgt)
+    g = np.array([float(v) for v in tape.gradient(loss, params)])
+    return float(loss), g, circ.last_output.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("B,T,n_up,n_down", [(1, 40, 2, 3), (70, 1000, 2, 3), (130, 1501, 1, 1), (300, 4096, 2, 2), (64, 8192, 1, 2)])
+def test_first_call_against_the_oracle(wdf, oracle, B, T, n_up, n_down):
+    """Cold: chunks warmed up from z = 0 for the planner's estimate; odd batches take the one-sequence-per-lane kernels,
+    T % 8 != 0 the tail, N_up != N_down the per-sign diode constants."""
+    rng = np.random.default_rng(B + T)
+    x = (rng.standard_normal((B, T)) * 1.2).astype(np.float32)
+    tgt = (0.3 * rng.standard_normal((T, B))).astype(np.float32)
+    circ, params = hpf(wdf, n_up, n_down)
+    circ.to_device()
+    loss, g, y = one_call(wdf, circ, params, cuda(x), cuda(tgt))
+    yref, lref, gref = oracle_hpf(oracle, THETA, x, tgt, n_up, n_down)
+    ctl = circ._tree.read_ctl(next(iter(circ._tree.cache.values())))
+    print(f"B {B} T {T}: |y - oracle| {np.max(np.abs(y - yref)):.2e}, loss {loss:.6e} / {lref:.6e}, gradients {rel(g, gref):.2e}; {ctl}")
+    assert np.max(np.abs(y - yref)) < 3e-6
+    assert abs(loss - lref) < 2e-6 * lref
+    assert rel(g, gref) < 3e-4
+
+
+def test_training_loop_against_the_oracle_every_step(wdf, oracle):
+    """lpf.py:86-99's loop on the HPF clipper, five optimizers: every step's output, loss and gradients against the oracle AT THE
+    PARAMETERS OF THAT STEP (the chunks of step n start from step n - 1's states moved along their tangents); the warm-up
+    the device settles on is a fraction of the cold one and no group needs the sequential repair."""
+    tf = wdf.tf
+    rng = np.random.default_rng(3)
+    B, T = 128, 4096
+    x = (rng.standard_normal((B, T)) * 1.2).astype(np.float32)
+    ref, _ = hpf(wdf)
+    tgt = (ref(cuda(x)) * 0.8).as_subclass(torch.Tensor).detach().cpu().numpy()
+    circ, params = hpf(wdf)
+    circ.to_device()
+    opts = [tf.keras.optimizers.Adam(learning_rate=1.0e-3 * float(p)) for p in params]
+    xd, td = cuda(x), cuda(tgt)
+    worst_y = worst_g = 0.0
+    used, gated = [], 0
+    for step in range(24):
+        theta = np.array([float(p) for p in params], dtype=np.float32).astype(np.float64)
+        with tf.GradientTape() as tape:
+            loss = circ.mse(xd, td)
+        grads = tape.gradient(loss, params)
+        g = np.array([float(v) for v in grads])
+        y = circ.last_output.detach().cpu().numpy()
+        ent = next(iter(circ._tree.cache.values()))
+        ctl = circ._tree.read_ctl(ent)
+        used.append(ctl["w_used"])
+        gated += ctl["gated_groups"]
+        if step in (0, 1, 2, 5, 11, 23):
+            yref, lref, gref = oracle_hpf(oracle, theta, x, tgt, 2, 3)
+            worst_y = max(worst_y, float(np.max(np.abs(y - yref))))
+            worst_g = max(worst_g, rel(g, gref))
+            assert abs(float(loss) - lref) < 1e-5 * lref, (step, float(loss), lref)
+        for o, gr, p in zip(opts, grads, params):
+            o.apply_gradients([(gr, p)])
+    print(f"warm-ups used {used}; groups repaired {gated}; worst |y - oracle| {worst_y:.2e}, worst gradient error {worst_g:.2e}")
+    assert worst_y < 4e-6 and worst_g < 5e-4
+    assert used[0] >= 256 and max(used[2:]) <= 128
+    assert gated == 0
+
+
+def test_missed_boundaries_are_repaired_sequentially(wdf, oracle):
+    """A tolerance no prediction can meet (negative: an unchanged circuit arrives bit for bit where its predecessor ended):
+    every group's finishing wave runs its sequences again from t = 0 -- the sequential recursion itself (states, tangents,
+    sums)."""
+    rng = np.random.default_rng(8)
+    B, T = 200, 2048
+    x = (rng.standard_normal((B, T)) * 1.2).astype(np.float32)
+    tgt = (0.3 * rng.standard_normal((T, B))).astype(np.float32)
+    circ, params = hpf(wdf)
+    circ.to_device()
+    xd, td = cuda(x), cuda(tgt)
+    one_call(wdf, circ, params, xd, td)
+    ent = next(iter(circ._tree.cache.values()))
+    from wdf_hip import binding
+    binding._check(binding.lib().wdf_ss_nl_step_set(binding._ptr(ent["ws"]), 8, -1.0, binding._stream()), "set")
+    loss, g, y = one_call(wdf, circ, params, xd, td)
+    ctl = circ._tree.read_ctl(ent)
+    yref, lref, gref = oracle_hpf(oracle, THETA, x, tgt, 2, 3)
+    print(f"{ctl}; |y - oracle| {np.max(np.abs(y - yref)):.2e}, gradients {rel(g, gref):.2e}")
+    assert ctl["gated_groups"] == 2 and ctl["n_bad"] > 0              # 200 sequences, two per lane: two groups
+    assert np.max(np.abs(y - yref)) < 3e-6 and abs(loss - lref) < 2e-6 * lref and rel(g, gref) < 3e-4
+    # and the call after it starts from the repaired call's snapshots
+    binding._check(binding.lib().wdf_ss_nl_step_set(binding._ptr(ent["ws"]), 8, 1.0e-6, binding._stream()), "set")
+    loss2, g2, y2 = one_call(wdf, circ, params, xd, td)
+    ctl2 = circ._tree.read_ctl(ent)
+    print(ctl2)
+    assert ctl2["gated_groups"] == 0
+    assert np.max(np.abs(y2 - yref)) < 3e-6 and rel(g2, gref) < 3e-4
+
+
+def test_a_jump_of_the_components_is_caught(wdf, oracle):
+    """The snapshots predict the next call's states to first order; a component assigned a very different value between two
+    calls breaks the prediction -- the boundaries miss, the groups are repaired, the answer is the oracle's."""
+    rng = np.random.default_rng(9)
+    B, T = 128, 4096
+    x = (rng.standard_normal((B, T)) * 1.2).astype(np.float32)
+    tgt = (0.3 * rng.standard_normal((T, B))).astype(np.float32)
+    circ, params = hpf(wdf)
+    circ.to_device()
+    xd, td = cuda(x), cuda(tgt)
+    for _ in range(3):
+        one_call(wdf, circ, params, xd, td)
+    params[2].assign(40.0e-9)                                       # C: 22 nF -> 40 nF
+    params[0].assign(20.0e3)
+    theta = np.array([float(p) for p in params], dtype=np.float32).astype(np.float64)
+    loss, g, y = one_call(wdf, circ, params, xd, td)
+    ctl = circ._tree.read_ctl(next(iter(circ._tree.cache.values())))
+    yref, lref, gref = oracle_hpf(oracle, theta, x, tgt, 2, 3)
+    print(f"{ctl}; |y - oracle| {np.max(np.abs(y - yref)):.2e}, gradients {rel(g, gref):.2e}")
+    assert np.max(np.abs(y - yref)) < 4e-6 and abs(loss - lref) < 1e-5 * lref and rel(g, gref) < 5e-4
+
+
+def test_two_state_diode_tree_against_the_host_probe_path(wdf):
+    """ns = 2, ni = 1 with a diode-pair root: 13 tangents of two components each, 2 x 2 Psi."""
+    tf = wdf.tf
+    rng = np.random.default_rng(6)
+    B, T = 96, 3000
+    x = (rng.standard_normal((B, T)) * 1.5).astype(np.float32)
+    tgt = (0.3 * rng.standard_normal((T, B))).astype(np.float32)
+
+    def build():
+        Ra = wdf.Resistor(4.7e3, True)
+        Vr = wdf.ResistiveVoltageSource(1.0e3, trainable=True)
+        Ca, Cb = wdf.Capacitor(4.7e-8, FS, True), wdf.Capacitor(2.2e-8, FS, True)
+        top = wdf.Parallel(wdf.Series(Ra, Ca), wdf.Series(Vr, Cb))
+        dp = wdf.DiodePair(top, 2.52e-9, Vt=25.85e-3, nDiodes=1.752, trainable=True)
+        return wdf.Circuit(top, dp, Ra), [Ra.R, Vr.R, Ca.C, Cb.C, dp.Is, dp.nVt]
+
+    ref, pr = build()
+    assert (ref.ns, ref.ni) == (2, 1)
+    with tf.GradientTape() as tape:
+        y = ref(cuda(x))
+        l0 = tf.reduce_mean(tf.square(y - cuda(tgt)))
+    g0 = np.array([float(v) for v in tape.gradient(l0, pr)])
+    circ, p = build()
+    circ.to_device()
+    xd, td = cuda(x), cuda(tgt)
+    for call in range(3):                                          # cold, then twice from the snapshots
+        l1, g1, y1 = one_call(wdf, circ, p, xd, td)
+        ctl = circ._tree.read_ctl(next(iter(circ._tree.cache.values())))
+        e_y = float(np.max(np.abs(y1 - y.as_subclass(torch.Tensor).detach().cpu().numpy())))
+        print(f"call {call}: loss {float(l0):.6e} / {l1:.6e}; |y - host path| {e_y:.2e}; gradients {rel(g1, g0):.2e}; {ctl}")
+        assert e_y < 4e-6 and abs(l1 - float(l0)) < 1e-5 * float(l0) and rel(g1, g0) < 5e-4
