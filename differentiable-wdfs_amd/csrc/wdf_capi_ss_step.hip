@@ -172,7 +172,7 @@ int wdf_ss_nl_step_mse(const float* x, const float* coef, const float* params, c
             EventBracket bracket(s);                                                                               \
             hipLaunchKernelGGL((wdf::ss_nl_step_kernel<NS_, NI_, SYM_, V_>), grid, dim3(256), 0, s, a);            \
         }                                                                                                          \
-        hipLaunchKernelGGL((wdf::ss_nl_step_finish_kernel<NS_, NI_, SYM_, WD_>), dim3(a.groups), dim3(64), 0, s, a); \
+        hipLaunchKernelGGL((wdf::ss_nl_step_finish_kernel<NS_, NI_, SYM_, WD_>), dim3(a.groups), dim3(64 * WD_ * wdf::NlTile<NS_, WD_>::n), 0, s, a); \
     }
 #define WDF_NL(NS_, NI_)                                                                                           \
     if (ns == NS_ && ni == NI_) {                                                                                  \

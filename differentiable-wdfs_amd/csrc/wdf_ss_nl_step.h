@@ -104,7 +104,7 @@ __device__ __forceinline__ void nl_load_diode(const NlStepArgs& a, SSDiode& dp)
 }
 
 // the state alone (warm-up)
-template <int NS, int NI, bool SYM, typename V>
+template <int NS, int NI, bool SYM, typename V, bool FAST = false>
 __device__ __forceinline__ void nl_z_step(const SSCoef<NS, NI>& c, const SSDiode& dp, const V (&x)[NI], V (&z)[NS])
 {
     using C = SSCoef<NS, NI>;
@@ -113,7 +113,7 @@ __device__ __forceinline__ void nl_z_step(const SSCoef<NS, NI>& c, const SSDiode
     for (int s = 0; s < NS; ++s) a = vfma(c.v[C::oCa + s], z[s], a);
 #pragma unroll
     for (int i = 0; i < NI; ++i) a = vfma(c.v[C::oDa + i], x[i], a);
-    const V b = diode_pair<SYM, V>(a, vsplat<V>(dp.L), dp.d).b;
+    const V b = diode_pair<SYM, V, FAST>(a, vsplat<V>(dp.L), dp.d).b;
     V zn[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -129,7 +129,8 @@ __device__ __forceinline__ void nl_z_step(const SSCoef<NS, NI>& c, const SSDiode
 }
 
 // one step with tangents -> y.  gs = gscale (0 on a padding lane), lv = 1 (0 on a padding lane).
-template <int NS, int NI, bool SYM, typename V, bool PSI>
+// FAST (with SYM): the kernel has checked that omega_1's argument never leaves the series-only region (diode_pair, wdf_omega.h).
+template <int NS, int NI, bool SYM, typename V, bool PSI, bool FAST = false>
 __device__ __forceinline__ V nl_step(const SSCoef<NS, NI>& c, const SSDiode& dp, const V (&x)[NI], V tgt, float gs, float lv,
                                      NlU<NS, NI, V, PSI>& u, V (&G)[NlDims<NS, NI>::nG], V (&H)[NS], V& sse)
 {
@@ -141,14 +142,25 @@ __device__ __forceinline__ V nl_step(const SSCoef<NS, NI>& c, const SSDiode& dp,
     for (int s = 0; s < NS; ++s) a = vfma(c.v[C::oCa + s], u.z[s], a);
 #pragma unroll
     for (int i = 0; i < NI; ++i) a = vfma(c.v[C::oDa + i], x[i], a);
-    const DiodeOutT<V> o = diode_pair<SYM, V>(a, vsplat<V>(dp.L), dp.d);
+    const DiodeOutT<V> o = diode_pair<SYM, V, FAST>(a, vsplat<V>(dp.L), dp.d);
     const V b = o.b;
     // the root's partials (wdf_statespace.h, ss_bwd_tp_kernel's one_step): Da = db/da, DL = db/dL, DV = db/dV
     const V w0p = o.w0 * vrcp(o.w0 + 1.0f), w1p = o.w1 * vrcp(o.w1 + 1.0f);
-    const V l2 = o.lam * o.lam, sp = w0p + w1p;
-    const V Da = vfma(l2 * -2.0f, sp, 1.0f);
-    const V DL = (o.lam * (o.m0 * w0p - o.m1 * w1p)) * (-dp.d.two_v);
-    const V DV = vfma((l2 * 2.0f) * a, sp * fast_rcp(dp.V), (o.lam * (o.m0 * o.w0 - o.m1 * o.w1)) * -2.0f);
+    const V sp = w0p + w1p;
+    V Da, DL, DV;
+    if constexpr (SYM && FAST) {
+        // lam (w0p - w1p) = copysign(w0p - w1p, a): omega is increasing, and at a = 0 both are the same series of the same
+        // argument (diode_pair); -2 m lam (w0 - w1) = (b - a) / V; lam^2 = (a != 0)
+        const V l2 = vsel(vgt_c(vabs(a), 0.0f), 1.0f, 0.0f);
+        Da = vfma(l2 * -2.0f, sp, 1.0f);
+        DL = vcopysign(w0p - w1p, a) * (-dp.d.two_v * dp.d.m_dn);
+        DV = vfma((l2 * 2.0f) * a, sp, b - a) * fast_rcp(dp.V);
+    } else {
+        const V l2 = o.lam * o.lam;
+        Da = vfma(l2 * -2.0f, sp, 1.0f);
+        DL = (o.lam * (o.m0 * w0p - o.m1 * w1p)) * (-dp.d.two_v);
+        DV = vfma((l2 * 2.0f) * a, sp * fast_rcp(dp.V), (o.lam * (o.m0 * o.w0 - o.m1 * o.w1)) * -2.0f);
+    }
     V yv = b * c.v[C::oFy];
 #pragma unroll
     for (int s = 0; s < NS; ++s) yv = vfma(c.v[C::oCy + s], u.z[s], yv);
@@ -231,8 +243,8 @@ __device__ __forceinline__ V nl_step(const SSCoef<NS, NI>& c, const SSDiode& dp,
 
 // ---- the chunks ------------------------------------------------------------------------------------------------------
 // 256-thread workgroups (four chunks of four neighbouring groups): single-wave workgroups land unevenly on the SIMDs.
-template <int NS, int NI, bool SYM, typename V>
-__global__ __launch_bounds__(256) void ss_nl_step_kernel(const NlStepArgs a)
+template <int NS, int NI, bool SYM, typename V, bool FAST>
+__device__ __forceinline__ void nl_chunk(const NlStepArgs& a, const SSCoef<NS, NI>& c, const SSDiode& dp)
 {
     using C = SSCoef<NS, NI>;
     using D = NlDims<NS, NI>;
@@ -249,10 +261,6 @@ __global__ __launch_bounds__(256) void ss_nl_step_kernel(const NlStepArgs a)
     const int w_cur = a.ctl->w_cur, w_snap = a.ctl->w_snap, have_snap = a.ctl->have_snap, par = a.ctl->parity;
     const int64_t tw = t0 > w_cur ? t0 - w_cur : 0;
     const int64_t tsnap = (k + 1 < a.K && t1 - w_snap >= t0) ? t1 - w_snap : -1;
-    C c;
-    c.load(a.coef);
-    SSDiode dp = {};
-    nl_load_diode(a, dp);
     NlU<NS, NI, V, true> u;
     if (tw == 0 || !have_snap) {
 #pragma unroll
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256) void ss_nl_step_kernel(const NlStepArgs a)
         if (ts + kLinBlk < t1) load_blk(ts + kLinBlk);
         if (ts < t0) {                                            // warm-up (t0 - tw is a multiple of 8)
 #pragma unroll
-            for (int i = 0; i < kLinBlk; ++i) nl_z_step<NS, NI, SYM, V>(c, dp, xc[i], u.z);
+            for (int i = 0; i < kLinBlk; ++i) nl_z_step<NS, NI, SYM, V, FAST>(c, dp, xc[i], u.z);
             continue;
         }
         if (ts == t0 && live) {
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(256) void ss_nl_step_kernel(const NlStepArgs a)
 #pragma unroll
         for (int i = 0; i < kLinBlk; ++i) {
             if (i >= n) break;
-            const V yv = nl_step<NS, NI, SYM, V, true>(c, dp, xc[i], tc[i], gs, lv, u, G, H, sse);
+            const V yv = nl_step<NS, NI, SYM, V, true, FAST>(c, dp, xc[i], tc[i], gs, lv, u, G, H, sse);
             if (live) lin_st_nt<V>(a.y + (ts + i) * B + b, yv);
         }
         if (++since == 4) {                                       // fp32 sums within 32 steps, fp64 across
@@ -361,61 +369,71 @@ __global__ __launch_bounds__(256) void ss_nl_step_kernel(const NlStepArgs a)
     }
 }
 
-// ---- the finish: verify the boundaries, walk the tangents, re-run what missed, reduce, chain rule, steer -----------------
-// One wave per group of 64 WD sequences (WD: sequences per lane of the chunk kernel -- its waves and these cover the same ones).
-template <int NS, int NI, bool SYM, int WD>
-__global__ __launch_bounds__(64) void ss_nl_step_finish_kernel(const NlStepArgs a)
+template <int NS, int NI, bool SYM, typename V>
+__global__ __launch_bounds__(256) void ss_nl_step_kernel(const NlStepArgs a)
 {
+    SSCoef<NS, NI> c;
+    c.load(a.coef);
+    SSDiode dp = {};
+    nl_load_diode(a, dp);
+    if constexpr (SYM) {
+        // the series-only evaluation of omega_1 and no per-step ballot when its argument can never leave that region
+        // (u1 <= L - log N: a fact about the circuit, the same for every lane)
+        if (dp.L - dp.d.l_dn <= kSeriesOnlyBelow) {
+            nl_chunk<NS, NI, SYM, V, true>(a, c, dp);
+            return;
+        }
+    }
+    nl_chunk<NS, NI, SYM, V, false>(a, c, dp);
+}
+
+// ---- the finish: verify the boundaries, walk the tangents, re-run what missed, reduce, chain rule, steer -----------------
+// One workgroup per group of 64 WD sequences (WD: sequences per lane of the chunk kernel -- its waves and these cover the same
+// ones): wave q = (h, slot) takes sequence h of every lane's WD and the chunks k = slot (mod the tile), lane l the l-th lane's
+// sequences.  A tile of chunk records goes through LDS (one round trip to memory per tile instead of one per chunk, and the
+// next tile's loads are in flight while this one is walked); every thread walks the whole tile -- a few dozen FMAs -- and
+// keeps the start of its own chunk.  Wave 0 finishes: the repair of a group that missed, the sums, the ticket.
+template <int NS, int WD> struct NlTile { static constexpr int n = (NS == 1 ? 8 : 4) / WD; };   // (at most 512 threads: 256 VGPRs for the repair path; the records fit 64 KB of LDS)
+
+template <int NS, int NI, bool SYM, int WD>
+__global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_finish_kernel(const NlStepArgs a)
+{
+    constexpr int kNlTile = NlTile<NS, WD>::n, kWaves = WD * kNlTile;
     using C = SSCoef<NS, NI>;
     using D = NlDims<NS, NI>;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, q = wv % kNlTile, hq = wv / kNlTile;
     const int64_t grp = blockIdx.x, B = a.B;
     const int K = a.K;
     const float tol = a.ctl->tol;
     const int w_snap = a.ctl->w_snap, par = a.ctl->parity;
+    __shared__ float recs[WD][kNlTile][D::nRec][64];
+    __shared__ double red[kWaves][D::nG + 1];
+    __shared__ int rbad[kWaves];
+    __shared__ float rmiss[kWaves];
     double tot[D::nG + 1];
 #pragma unroll
     for (int i = 0; i <= D::nG; ++i) tot[i] = 0.0;
     float miss = 0.0f;
     int nbad = 0;
-    for (int h = 0; h < WD; ++h) {
-        const int64_t b_raw = (grp * 64 + lane) * WD + h;
+    {
+        const int64_t b_raw = (grp * 64 + lane) * WD + hq;
         const bool live = b_raw < B;
         const int64_t b = live ? b_raw : B - 1;
-        float Ss[D::nT][NS], zprev[NS];
+        float carry[D::nT][NS], zcarry[NS];                       // S_start and the predecessor's end at the tile's first chunk
 #pragma unroll
         for (int cc = 0; cc < D::nT; ++cc)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) Ss[cc][s] = 0.0f;
+            for (int s = 0; s < NS; ++s) carry[cc][s] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) zprev[s] = 0.0f;
-        for (int k = 0; k < K; ++k) {
+        for (int s = 0; s < NS; ++s) zcarry[s] = 0.0f;
+        // chunk k's record, and the snapshot it took for the next call
+        auto fetch = [&](int k, float (&v)[D::nRec], float (&psi)[NS][NS], float (&s0)[D::nT][NS]) {
+            if (k >= K) return;
             const float* rk = a.rec + ((size_t)k * D::nRec) * B + b;
-            float v[D::nRec];
 #pragma unroll
             for (int i = 0; i < D::nRec; ++i) v[i] = rk[(size_t)i * B];
-            if (k > 0) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const float m = fabsf(v[D::oZw + s] - zprev[s]);
-                    miss = fmaxf(miss, live ? m : 0.0f);
-                    nbad += (live && !(m <= tol)) ? 1 : 0;
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) zprev[s] = v[D::oZe + s];
-            // what the chunk's start adds to its sums: H . S_start
-#pragma unroll
-            for (int cc = 0; cc < D::nT; ++cc) {
-                float d = 0.0f;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) d = fmaf(v[D::oH + s], Ss[cc][s], d);
-                tot[D::gidx(cc)] += live ? (double)d : 0.0;
-            }
-            // the snapshot this chunk took for the next call: S0 + Psi S_start, in place
             if (k + 1 < K && live && w_snap <= a.L) {
-                float* sp = a.snap + (((size_t)par * K + (k + 1)) * D::nSnap) * B + b;
-                float psi[NS][NS];
+                const float* sp = a.snap + (((size_t)par * K + (k + 1)) * D::nSnap) * B + b;
 #pragma unroll
                 for (int j = 0; j < NS; ++j)
 #pragma unroll
@@ -423,38 +441,123 @@ __global__ __launch_bounds__(64) void ss_nl_step_finish_kernel(const NlStepArgs 
 #pragma unroll
                 for (int cc = 0; cc < D::nT; ++cc)
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        float sv = sp[(size_t)(D::sS + cc * NS + s) * B];
-#pragma unroll
-                        for (int j = 0; j < NS; ++j) sv = fmaf(psi[j][s], Ss[cc][j], sv);
-                        sp[(size_t)(D::sS + cc * NS + s) * B] = sv;
-                    }
+                    for (int s = 0; s < NS; ++s) s0[cc][s] = sp[(size_t)(D::sS + cc * NS + s) * B];
             }
-            // S_start of the next chunk
+        };
+        constexpr int kAhead = NS == 1 ? 4 : 2;                   // tiles whose records are fetched together (registers)
+        for (int ks = 0; ks < K; ks += kNlTile * kAhead) {
+        float vv[kAhead][D::nRec], psiv[kAhead][NS][NS], s0v[kAhead][D::nT][NS];
 #pragma unroll
-            for (int cc = 0; cc < D::nT; ++cc) {
-                float sn[NS];
+        for (int r = 0; r < kAhead; ++r) fetch(ks + r * kNlTile + q, vv[r], psiv[r], s0v[r]);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    float sv = v[D::oS + cc * NS + s];
+        for (int r = 0; r < kAhead; ++r) {
+            const int k0 = ks + r * kNlTile;
+            if (k0 >= K) break;
+            const int k = k0 + q, nt = K - k0 < kNlTile ? K - k0 : kNlTile;
+            if (k0 > 0) __syncthreads();                          // (the tile before this one has been read)
+            float (&psic)[NS][NS] = psiv[r];
+            float (&s0c)[D::nT][NS] = s0v[r];
+            if (k < K) {
 #pragma unroll
-                    for (int j = 0; j < NS; ++j) sv = fmaf(v[D::oPsi + j * NS + s], Ss[cc][j], sv);
-                    sn[s] = sv;
+                for (int i = 0; i < D::nRec; ++i) recs[hq][q][i][lane] = vv[r][i];
+            }
+            __syncthreads();
+            const bool fix = k + 1 < K && live && w_snap <= a.L;
+            float Ss[D::nT][NS], zprev[NS];                       // ... of MY chunk
+#pragma unroll
+            for (int j = 0; j < kNlTile; ++j) {
+                if (j < nt) {
+                    if (j == q) {
+#pragma unroll
+                        for (int cc = 0; cc < D::nT; ++cc)
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) Ss[cc][s] = carry[cc][s];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) zprev[s] = zcarry[s];
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < D::nT; ++cc) {
+                        float sn[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            float sv = recs[hq][j][D::oS + cc * NS + s][lane];
+#pragma unroll
+                            for (int jj = 0; jj < NS; ++jj) sv = fmaf(recs[hq][j][D::oPsi + jj * NS + s][lane], carry[cc][jj], sv);
+                            sn[s] = sv;
+                        }
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) carry[cc][s] = sn[s];
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) zcarry[s] = recs[hq][j][D::oZe + s][lane];
                 }
+            }
+            if (k < K) {
+                if (k > 0) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) Ss[cc][s] = sn[s];
+                    for (int s = 0; s < NS; ++s) {
+                        const float m = fabsf(recs[hq][q][D::oZw + s][lane] - zprev[s]);
+                        miss = fmaxf(miss, live ? m : 0.0f);
+                        nbad += (live && !(m <= tol)) ? 1 : 0;
+                    }
+                }
+                // what the chunk's start adds to its sums: H . S_start
+#pragma unroll
+                for (int cc = 0; cc < D::nT; ++cc) {
+                    float d = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) d = fmaf(recs[hq][q][D::oH + s][lane], Ss[cc][s], d);
+                    tot[D::gidx(cc)] += live ? (double)d : 0.0;
+                }
+                if (fix) {                                        // S0 + Psi S_start, in place
+                    float* sp = a.snap + (((size_t)par * K + (k + 1)) * D::nSnap) * B + b;
+#pragma unroll
+                    for (int cc = 0; cc < D::nT; ++cc)
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            float sv = s0c[cc][s];
+#pragma unroll
+                            for (int j = 0; j < NS; ++j) sv = fmaf(psic[j][s], Ss[cc][j], sv);
+                            sp[(size_t)(D::sS + cc * NS + s) * B] = sv;
+                        }
+                }
             }
         }
+        }
     }
-    const int wbad = wave_sum_dpp(nbad);
-    const float wmiss = wave_max_dpp(miss);
+    // ---- the workgroup's verdict and sums -> wave 0
+    {
+        const int wb = wave_sum_dpp(nbad);
+        const float wm = wave_max_dpp(miss);
+#pragma unroll
+        for (int i = 0; i <= D::nG; ++i) {
+            const double s = wave_sum_dpp(tot[i]);
+            if (lane == 0) red[wv][i] = s;
+        }
+        if (lane == 0) { rbad[wv] = wb; rmiss[wv] = wm; }
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    int nbad_all = 0;
+    float miss_all = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kWaves; ++j) { nbad_all += rbad[j]; miss_all = fmaxf(miss_all, rmiss[j]); }
+#pragma unroll
+    for (int i = 0; i <= D::nG; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < kWaves; ++j) s += red[j][i];
+        tot[i] = s;                                               // (the same value in every lane)
+    }
+    const int wbad = nbad_all;
+    const float wmiss = miss_all;
     if (wbad == 0) {
         // the chunks' own sums of this group (lanes over chunks), then one value per accumulator in every lane
 #pragma unroll
         for (int i = 0; i <= D::nG; ++i) {
-            double s = tot[i];
+            double s = 0.0;
             for (int k = lane; k < K; k += 64) s += a.gpart[((size_t)k * a.groups + grp) * (D::nG + 1) + i];
-            tot[i] = wave_sum_dpp(s);
+            tot[i] += wave_sum_dpp(s);
         }
     } else {
         // a boundary missed: this group again, sequentially -- exact (states, tangents, sums, the snapshots)
