@@ -241,15 +241,7 @@ class _LinResident:
             if circ.root_kind == "DiodePair":
                 # the tangent-carried step of a diode-pair root: chunks no shorter than 64 steps, one wave per SIMD and up
                 k = max(1, min(T // 64, (_NL_OCC * N_SIMD) // max(1, -(-B // per_wave))))
-                nbytes = L_.wdf_ss_nl_step_ws_bytes(circ.ns, circ.ni, B, T, k)
-                if nbytes == 0:
-                    raise binding.WdfHipError(L_.wdf_last_error().decode() or "wdf_ss_nl_step_ws_bytes: unsupported tree")
-                ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-                Lc = L_.wdf_ss_nl_step_chunk_len(T, k)
-                cold = self.cold_warmup()
-                warm = max(16, min(Lc // 16 * 16, 64))
-                binding._check(L_.wdf_ss_nl_step_plan(binding._ptr(ws), circ.ns, circ.ni, B, T, k, cold, warm, 16,
-                                                      max(16, Lc // 16 * 16), float(NL_TOL), binding._stream()), "wdf_ss_nl_step_plan")
+                ws = self._plan_nl(B, T, k, dev)
             else:
                 k = max(1, min(T // 64, (_LIN_OCC * N_SIMD) // max(1, -(-B // per_wave))))
                 nbytes = L_.wdf_ss_lin_step_ws_bytes(circ.ns, circ.ni, B, T, k)
@@ -258,8 +250,51 @@ class _LinResident:
                 ws = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
             ent = self.cache[key] = {"x": x_tm, "t": tgt, "y": y, "ws": ws,
                                      "out": torch.zeros((1 + self.pb.n,), dtype=torch.float32, device=dev),
-                                     "B": B, "T": T, "k": k, "hold": (x, target)}
+                                     "B": B, "T": T, "k": k, "hold": (x, target), "calls": 0, "watch": None, "replans": 0}
         return ent
+
+    def _plan_nl(self, B, T, k, dev, cold_floor=0):
+        """Workspace of the diode-root step for k chunks, planned: cold first call, then the device steers the warm-up."""
+        L_ = binding.lib()
+        circ = self.circ
+        nbytes = L_.wdf_ss_nl_step_ws_bytes(circ.ns, circ.ni, B, T, k)
+        if nbytes == 0:
+            raise binding.WdfHipError(L_.wdf_last_error().decode() or "wdf_ss_nl_step_ws_bytes: unsupported tree")
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        Lc = L_.wdf_ss_nl_step_chunk_len(T, k)
+        cold = min(4096, max(self.cold_warmup(), int(cold_floor) // 16 * 16))
+        warm = max(16, min(Lc // 16 * 16, 64))
+        binding._check(L_.wdf_ss_nl_step_plan(binding._ptr(ws), circ.ns, circ.ni, B, T, k, cold, warm, 16,
+                                              max(16, Lc // 16 * 16), float(NL_TOL), binding._stream()), "wdf_ss_nl_step_plan")
+        return ws
+
+    def _watch(self, ent):
+        """Every 16th call, WITHOUT a synchronisation: look at the control block as it was 16 calls ago.  Groups that keep
+        missing although the warm-up already is as long as a chunk (a circuit whose memory outlasts the chunks: every miss
+        costs a sequential pass of its group) -> half as many chunks, twice the room; down to one chunk, which has no
+        boundary to miss."""
+        ent["calls"] += 1
+        if ent["calls"] % 16:
+            return
+        w = ent["watch"]
+        if w is None:
+            w = ent["watch"] = {"buf": torch.zeros(32, dtype=torch.int32).pin_memory(), "event": None, "last": 0}
+        if w["event"] is not None:
+            if not w["event"].query():
+                return
+            raw = w["buf"].numpy()
+            total, w_snap, w_max = int(raw[15]), int(raw[4]), int(raw[6])
+            delta, w["last"] = total - w["last"], total
+            w["event"] = None
+            Lc = binding.lib().wdf_ss_nl_step_chunk_len(ent["T"], ent["k"])
+            if delta >= 2 and w_snap >= min(w_max, Lc // 16 * 16) and ent["k"] > 1:
+                ent["k"] = max(1, ent["k"] // 2)
+                ent["ws"] = self._plan_nl(ent["B"], ent["T"], ent["k"], ent["ws"].device, cold_floor=4 * w_snap)
+                ent["watch"], ent["replans"] = None, ent["replans"] + 1
+                return
+        w["buf"].copy_(ent["ws"][:128].view(torch.int32), non_blocking=True)
+        w["event"] = torch.cuda.Event()
+        w["event"].record()
 
     def cold_warmup(self):
         """Warm-up of a chunk that starts from z = 0 (the first call on a batch): outlasts the slowest mode of the step's
@@ -297,6 +332,7 @@ class _LinResident:
                                                   binding._ptr(ent["y"]), binding._ptr(ent["ws"]), binding._ptr(ent["out"]), B, T,
                                                   ent["k"], binding._stream())
             binding._check(rc, "wdf_ss_nl_step_mse")
+            self._watch(ent)
             return ent["out"]
         rc = binding.lib().wdf_ss_lin_step_mse(binding._ptr(ent["x"]), binding._ptr(self.coef), binding._ptr(self.jac), self.pb.n,
                                                circ.ns, circ.ni, binding._ptr(ent["t"]), 2.0 / float(B * T), binding._ptr(ent["y"]),

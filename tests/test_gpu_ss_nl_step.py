@@ -196,3 +196,42 @@ def test_two_state_diode_tree_against_the_host_probe_path(wdf):
         e_y = float(np.max(np.abs(y1 - y.as_subclass(torch.Tensor).detach().cpu().numpy())))
         print(f"call {call}: loss {float(l0):.6e} / {l1:.6e}; |y - host path| {e_y:.2e}; gradients {rel(g1, g0):.2e}; {ctl}")
         assert e_y < 4e-6 and abs(l1 - float(l0)) < 1e-5 * float(l0) and rel(g1, g0) < 5e-4
+
+
+def test_persistent_misses_halve_the_chunk_count(wdf, oracle, monkeypatch):
+    """A tolerance below fp32's resolution of the states: every call of a training loop misses although the warm-up is as long
+    as a chunk.  The host looks at the control block every 16 calls (16 calls late, no synchronisation) and plans half as many
+    chunks (down to one, which has no boundary, if need be); results stay the oracle's throughout (missed groups are repaired)."""
+    from wdf_hip import lowering
+    monkeypatch.setattr(lowering, "NL_TOL", 1.0e-12)
+    tf = wdf.tf
+    rng = np.random.default_rng(21)
+    B, T = 128, 2048
+    x = (rng.standard_normal((B, T)) * 1.2).astype(np.float32)
+    tgt = (0.3 * rng.standard_normal((T, B))).astype(np.float32)
+    circ, params = hpf(wdf)
+    circ.to_device()
+    opts = [tf.keras.optimizers.Adam(learning_rate=1.0e-4 * float(p)) for p in params]
+    xd, td = cuda(x), cuda(tgt)
+    ks = []
+    for step in range(224):
+        theta = np.array([float(p) for p in params], dtype=np.float32).astype(np.float64) if step % 56 == 55 else None
+        with tf.GradientTape() as tape:
+            loss = circ.mse(xd, td)
+        grads = tape.gradient(loss, params)
+        ent = next(iter(circ._tree.cache.values()))
+        ks.append(ent["k"])
+        if theta is not None:
+            torch.cuda.synchronize()
+            yref, lref, gref = oracle_hpf(oracle, theta, x, tgt, 2, 3)
+            g = np.array([float(v) for v in grads])
+            assert np.max(np.abs(circ.last_output.detach().cpu().numpy() - yref)) < 3e-6 and rel(g, gref) < 3e-4
+            assert abs(float(loss) - lref) < 2e-6 * lref
+        for o, gr, p in zip(opts, grads, params):
+            o.apply_gradients([(gr, p)])
+        if step % 16 == 15:
+            torch.cuda.synchronize()                               # (so that the 16-call-old copy has landed when it is looked at)
+    print(f"chunks per call: {sorted(set(ks), reverse=True)}; re-plans {ent['replans']}")
+    # (it stops halving where the longer chunks' warm-up brings a chunk to its predecessor's end BIT FOR BIT)
+    assert ks[0] == 32 and ks[-1] < 32 and all(b <= a for a, b in zip(ks, ks[1:])) and 2 ** ent["replans"] == ks[0] // ks[-1]
+    assert circ._tree.read_ctl(ent)["gated_groups"] == 0
