@@ -444,7 +444,7 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
                     for (int s = 0; s < NS; ++s) s0[cc][s] = sp[(size_t)(D::sS + cc * NS + s) * B];
             }
         };
-        constexpr int kAhead = NS == 1 ? 4 : 2;                   // tiles whose records are fetched together (registers)
+        constexpr int kAhead = NS == 1 ? 2 : 1;                   // tiles whose records are fetched together (registers)
         for (int ks = 0; ks < K; ks += kNlTile * kAhead) {
         float vv[kAhead][D::nRec], psiv[kAhead][NS][NS], s0v[kAhead][D::nT][NS];
 #pragma unroll
@@ -537,6 +537,7 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
         if (lane == 0) { rbad[wv] = wb; rmiss[wv] = wm; }
     }
     __syncthreads();
+    if (wv != 0) return;
     int nbad_all = 0;
     float miss_all = 0.0f;
 #pragma unroll
@@ -548,10 +549,9 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
         for (int j = 0; j < kWaves; ++j) s += red[j][i];
         tot[i] = s;                                               // (the same value in every lane)
     }
-    const int wbad = nbad_all;                                    // (every wave of the workgroup knows)
+    const int wbad = nbad_all;
     const float wmiss = miss_all;
     if (wbad == 0) {
-        if (wv != 0) return;
         // the chunks' own sums of this group (lanes over chunks), then one value per accumulator in every lane
 #pragma unroll
         for (int i = 0; i <= D::nG; ++i) {
@@ -567,8 +567,8 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
         nl_load_diode(a, dp);
 #pragma unroll
         for (int i = 0; i <= D::nG; ++i) tot[i] = 0.0;
-        if (wv < WD) {                                            // wave h: sequence h of every lane's WD
-            const int h = wv;
+        for (int h = 0; h < WD; ++h) {                            // (one wave: a miss is rare, and the registers of the walk
+                                                                  //  above would not survive a second copy of this loop's)
             const int64_t b_raw = (grp * 64 + lane) * WD + h;
             const bool live = b_raw < B;
             const int64_t b = live ? b_raw : B - 1;
@@ -615,23 +615,8 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
             for (int i = 0; i < D::nG; ++i) tot[i] += (double)G[i];
             tot[D::nG] += (double)sse;
         }
-        __syncthreads();                                          // (red has been read by every wave)
-        if (wv < WD) {
 #pragma unroll
-            for (int i = 0; i <= D::nG; ++i) {
-                const double sw = wave_sum_dpp(tot[i]);
-                if (lane == 0) red[wv][i] = sw;
-            }
-        }
-        __syncthreads();
-        if (wv != 0) return;
-#pragma unroll
-        for (int i = 0; i <= D::nG; ++i) {
-            double sw = 0.0;
-#pragma unroll
-            for (int j = 0; j < WD; ++j) sw += red[j][i];
-            tot[i] = sw;
-        }
+        for (int i = 0; i <= D::nG; ++i) tot[i] = wave_sum_dpp(tot[i]);
     }
     // ---- this group's partial; the last wave adds them up in a fixed order
     if (lane == 0) {
