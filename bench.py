@@ -798,6 +798,123 @@ def run_mlp_root(args, world, rank, local):
         torch.distributed.destroy_process_group()
 
 
+def run_tree_step(args, rank, local, kind):
+    """--config lpf | hpf: a secondary line -- lpf.py:86-99's training loop (GradientTape -> circ.mse -> tape.gradient -> one
+    Adam per component) through the element API with the component values resident on the device (Circuit.to_device()):
+    the one-pass step of a LINEAR tree (lpf: RC lowpass, lpf.py:20-49; csrc/wdf_ss_step.h) or of a DIODE-ROOT tree (hpf:
+    HPFDiodeClipper.h:28-32's circuit; csrc/wdf_ss_nl_step.h) at --batch x --seq-len."""
+    import tf_wdf as wdf
+    from tf_wdf import tf
+    dev = torch.device("cuda", local)
+    fs, B, T = 48000, args.batch, args.seq_len
+    g = torch.Generator(device="cpu").manual_seed(1234)
+
+    def build(values):
+        if kind == "lpf":
+            R1, C1 = wdf.Resistor(values[0], True), wdf.Capacitor(values[1], fs, True)
+            return wdf.Circuit(wdf.Inverter(wdf.Series(R1, C1)), wdf.IdealVoltageSource(), C1), [R1.R, C1.C]
+        R = wdf.Resistor(values[0], True); Vs = wdf.ResistiveVoltageSource(values[1], trainable=True)   # noqa: E702
+        C = wdf.Capacitor(values[2], fs, True)
+        top = wdf.Parallel(R, wdf.Series(Vs, C))
+        dp = wdf.DiodePair(top, values[3], Vt=values[4], nDiodes=1.0, trainable=True)
+        return wdf.Circuit(top, dp, R), [R.R, Vs.R, C.C, dp.Is, dp.nVt]
+
+    start = [1000.0, 1.0e-6] if kind == "lpf" else [33.0e3, 1.0e3, 22.0e-9, 4.352e-9, 25.85e-3 * 1.906]
+    teacher = [1800.0, 0.6e-6] if kind == "lpf" else [39.0e3, 1.5e3, 15.0e-9, 2.52e-9, 25.85e-3 * 1.752]
+    x = (torch.randn((B, T), generator=g) * (1.0 if kind == "lpf" else 1.2)).to(dev)
+    with torch.no_grad():
+        tgt = build(teacher)[0](x).as_subclass(torch.Tensor).detach().clone()      # [T,B]: the same circuit, other components
+    circ, params = build(start)
+    circ.to_device()
+    opts = [tf.keras.optimizers.Adam(learning_rate=1.0e-3 * float(p)) for p in params]
+    res = getattr(circ, "_lin", None) or circ._tree
+
+    def step():
+        with tf.GradientTape() as tape:
+            loss = circ.mse(x, tgt)
+        grads = tape.gradient(loss, params)
+        for o, gr, p in zip(opts, grads, params):
+            o.apply_gradients([(gr, p)])
+        return loss
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    every = max(1, min(4, args.steps)) if args.steps <= 64 else max(4, -(-args.steps // 1024))
+    evs = [(binding.Event(), binding.Event()) if i % every == 0 else None for i in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if evs[i] is not None:
+            binding.Event.bracket_next(evs[i][0], evs[i][1])
+        loss = step()
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k_ms = [e[0].elapsed_ms(e[1]) for e in evs if e is not None]
+    ms = dt / args.steps * 1e3
+    ent = next(iter(res.cache.values()))
+    ctl = res.read_ctl(ent) if kind == "hpf" else None
+
+    # ---- parity: y of 64 sequences of the last timed step, and a cold step on 256 sequences at the final components ----
+    parity = None
+    if not args.no_parity:
+        O = _oracle()
+        theta_end = np.array([float(p) for p in params], dtype=np.float32).astype(np.float64)
+        if kind == "lpf":
+            nodes = [(O.NODE_RESISTOR, -1, -1, 0, -1, -1), (O.NODE_CAPACITOR, -1, -1, 1, -1, -1), (O.NODE_SERIES, 0, 1, -1, -1, -1),
+                     (O.NODE_INVERTER, 2, -1, -1, -1, -1)]
+            oc = O.Circuit(nodes, top=3, probe=1, n_in=1, root_kind=O.ROOT_IDEAL_VSOURCE, fs=fs, root_vin=0)
+        else:
+            nodes = [(O.NODE_RESISTOR, -1, -1, 0, -1, -1), (O.NODE_RES_VSOURCE, -1, -1, 1, 0, -1), (O.NODE_CAPACITOR, -1, -1, 2, -1, -1),
+                     (O.NODE_SERIES, 1, 2, -1, -1, -1), (O.NODE_PARALLEL, 0, 3, -1, -1, -1)]
+            oc = O.Circuit(nodes, top=4, probe=0, n_in=1, root_kind=O.ROOT_DIODE_PAIR, fs=fs, p_is=3, p_nvt=4, n_up=1, n_down=1)
+        nb = min(B, 256)
+        xs = x[:nb].cpu().numpy().astype(np.float64)
+        # (against a target the circuit cannot meet: near the teacher the residual is at fp32's resolution of y and the
+        #  gradient a sum of cancelling terms -- no measure of the kernels)
+        tpar = (0.3 * torch.randn((T, nb), generator=g)).to(dev)
+        ts = tpar.cpu().numpy().astype(np.float64)
+        c2, p2 = build([float(v) for v in theta_end])
+        c2.to_device()
+        with tf.GradientTape() as tape:
+            l2 = c2.mse(x[:nb].contiguous(), tpar)
+        g2 = np.array([float(v) for v in tape.gradient(l2, p2)])
+        yref = O.tree_fwd(oc, theta_end, xs)
+        e = yref - ts
+        gref = O.tree_grad(oc, theta_end, xs, 2.0 * e / e.size)
+        y2 = c2.last_output.detach().cpu().numpy()
+        parity = {"sequences": nb, "max_abs_y": float(np.max(np.abs(y2 - yref))),
+                  "loss_rel": abs(float(l2) - float(np.mean(e * e))) / float(np.mean(e * e)),
+                  "grad_max_rel": float(np.max(np.abs(g2 - gref) / np.abs(gref))),
+                  "note": "the same kernels on the first 256 sequences at the components the timed loop ended with (a cold call, "
+                          "noise target of 0.3 rms), vs oracle tree_fwd / tree_grad in fp64"}
+    if rank != 0:
+        return
+    n = B * T
+    kname = "ss_lin_step_kernel" if kind == "lpf" else "ss_nl_step_kernel"
+    kmean = float(np.mean(k_ms))
+    out = {"metric": f"samples/sec training step (forward + MSE + gradient + Adam per component), "
+                     f"{'RC lowpass (lpf.py:20-49)' if kind == 'lpf' else 'HPF diode clipper (HPFDiodeClipper.h:28-32)'} @48kHz "
+                     f"through Circuit.to_device() / circ.mse",
+           "value": n / (dt / args.steps), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 2),
+           "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{kind}: {B} sequences x {T} samples, {len(params)} trainable components, target = the same circuit "
+                                  f"with other component values", "chunks": ent["k"]},
+           "host_ms_per_step": t_host / args.steps * 1e3,
+           "kernel_ms": {kname: spread(k_ms)},
+           "parity": parity,
+           "roofline": {"bound": "hbm" if kind == "lpf" else "valu", "kernel": kname,
+                        "achieved": 12.0 * n / (kmean * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": 12.0 * n / (kmean * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "algorithmic bytes of this kernel: x, target read, y written = 12 B per sample" +
+                                ("" if kind == "lpf" else "; the kernel is VALU-issue-bound (171 instructions per step of two "
+                                                          "sequences at one wave per SIMD), the HBM fraction is what it moves")}}
+    if ctl is not None:
+        out["control"] = {k_: ctl[k_] for k_ in ("call", "w_used", "w_snap", "max_miss", "gated_groups", "total_gated")}
+        out["control"]["replans"] = ent["replans"]
+    print(json.dumps(out), flush=True)
+
+
 def spread(ts):
     ts = sorted(ts)
     return {"min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1], "n": len(ts)}
@@ -820,8 +937,10 @@ def main():
     ap.add_argument("--no-cold", action="store_true", help="skip the third measurement: the stateless step (value_cold)")
     ap.add_argument("--no-sustained", action="store_true", help="skip value_sustained: the headline loop kept running for ~2.5 s")
     ap.add_argument("--no-fwd-1024", action="store_true", help="skip value_fwd_1024: BASELINE configs[1], forward only at 1024 x 4096")
-    ap.add_argument("--config", default=None, choices=["c2"],
-                    help="c2: ONLY BASELINE configs[1] (1N4148 diode clipper forward-only, 1024 sequences x 4096 samples), its own JSON line")
+    ap.add_argument("--config", default=None, choices=["c2", "lpf", "hpf"],
+                    help="c2: ONLY BASELINE configs[1] (1N4148 diode clipper forward-only, 1024 sequences x 4096 samples), its own JSON line.  "
+                         "lpf / hpf: secondary lines -- lpf.py's training loop through the element API with resident components "
+                         "(RC lowpass: linear one-pass step; HPF diode clipper: diode-root one-pass step)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="capture one training step (kernels, all-reduce, update) as a HIP graph and replay it in the timed loop. "
                          "auto: on when the step contains a collective (N > 1 or --force-dist) and for the five-launch MLP-root step, "
@@ -887,6 +1006,8 @@ def main():
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_["hbm_frac"], "traffic": None},
                               "detail": r_}), flush=True)
         return
+    if args.config in ("lpf", "hpf"):
+        return run_tree_step(args, rank, local, args.config)
     if args.root != "diode":
         return (run_mlp_root if args.mlp_path == "unfused" else run_mlp_step)(args, world, rank, local)
     dev = torch.device("cuda", local)
