@@ -153,3 +153,16 @@ def test_bench_strong_scaling_rehearsal():
     assert d["scaling"] == "strong" and d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
     assert "1024 sequences" in d["config"]["workload"]
     assert abs(d["value"] - 2048 * 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("kind", ["lpf", "hpf"])
+def test_bench_tree_step_lines(kind):
+    """bench.py --config lpf / hpf: lpf.py's loop through the element API with resident components, as a bench line; the
+    parity block holds the same kernels against the fp64 oracle."""
+    d = _run_bench(["--config", kind, "--batch", "512", "--seq-len", "2048", "--steps", "6", "--warmup", "3"])
+    assert d["unit"] == "samples/s" and d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert kind in d["config"]["workload"] and len(d["kernel_ms"]) == 1
+    p = d["parity"]
+    assert p["max_abs_y"] < 3e-6 and p["loss_rel"] < 2e-6 and p["grad_max_rel"] < 3e-4, p
+    if kind == "hpf":
+        assert d["control"]["gated_groups"] == 0
