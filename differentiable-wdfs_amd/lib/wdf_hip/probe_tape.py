@@ -21,6 +21,7 @@ class Tape:
         self.consts = []
         self._const_node = {}
         self._param_node = {}
+        self._seen = {}
 
     def const(self, v):
         v = float(v)
@@ -38,9 +39,76 @@ class Tape:
             n = self._param_node[p] = len(self.ops) - 1
         return PVal(self, n)
 
+    def _const_of(self, n):
+        op, a, _ = self.ops[n]
+        return self.consts[a] if op == OP_CONST else None
+
     def emit(self, op, a, b=0):
-        self.ops.append((op, int(a), int(b)))
-        return PVal(self, len(self.ops) - 1)
+        """A new node -- or an existing one: the probe runs on unit vectors, so most of its arithmetic is with 0 and 1.
+        Constants fold, x + 0 / x - 0 / x * 1 / x / 1 return x, x * 0 is 0, and an operation seen before is not repeated
+        (the device evaluates the tape one dependent operation after the other: every node saved is ~100 ns of the probe)."""
+        a, b = int(a), int(b)
+        ca = self._const_of(a)
+        cb = self._const_of(b) if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV) else None
+        if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
+            if ca is not None and cb is not None and not (op == OP_DIV and cb == 0.0):
+                return self.const({OP_ADD: ca + cb, OP_SUB: ca - cb, OP_MUL: ca * cb}[op] if op != OP_DIV else ca / cb)
+            if op == OP_ADD and ca == 0.0:
+                return PVal(self, b)
+            if op in (OP_ADD, OP_SUB) and cb == 0.0:
+                return PVal(self, a)
+            if op == OP_SUB and ca == 0.0:
+                return self.emit(OP_NEG, b)
+            if op == OP_MUL and (ca == 0.0 or cb == 0.0):
+                return self.const(0.0)
+            if op == OP_MUL and ca == 1.0:
+                return PVal(self, b)
+            if op in (OP_MUL, OP_DIV) and cb == 1.0:
+                return PVal(self, a)
+            if op == OP_DIV and ca == 0.0:
+                return self.const(0.0)
+            if op in (OP_ADD, OP_MUL) and a > b:
+                a, b = b, a                                       # (commutative: one key for both orders)
+        elif op == OP_NEG:
+            if ca is not None:
+                return self.const(-ca)
+            if self.ops[a][0] == OP_NEG:
+                return PVal(self, self.ops[a][1])
+        elif op == OP_RECIP and ca is not None and ca != 0.0:
+            return self.const(1.0 / ca)
+        key = (op, a, b)
+        n = self._seen.get(key)
+        if n is None:
+            self.ops.append(key)
+            n = self._seen[key] = len(self.ops) - 1
+        return PVal(self, n)
+
+    def pruned(self, outputs):
+        """(Tape, outputs) with only the nodes the outputs depend on, renumbered."""
+        keep = set()
+        stack = [int(o) for o in outputs]
+        while stack:
+            n = stack.pop()
+            if n in keep:
+                continue
+            keep.add(n)
+            op, a, b = self.ops[n]
+            if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
+                stack += [a, b]
+            elif op in (OP_NEG, OP_RECIP):
+                stack.append(a)
+        t = Tape()
+        new = {}
+        for n in sorted(keep):
+            op, a, b = self.ops[n]
+            if op == OP_CONST:
+                new[n] = t.const(self.consts[a]).n
+            elif op == OP_PARAM:
+                new[n] = t.param(a).n
+            else:
+                t.ops.append((op, new[a], new[b] if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV) else 0))
+                new[n] = len(t.ops) - 1
+        return t, [new[int(o)] for o in outputs]
 
     def evaluate(self, params, outputs):
         """Host reference of the device kernel: float64 values of the output nodes and their Jacobian [len(outputs), P]."""
@@ -191,11 +259,15 @@ def record(circ, param_vars):
         dy = [dy[i] - fy * da[i] + (fy * er[i]) * 2.0 for i in range(ni)]
         E, ca, da, fy = [zero] * ns, [zero] * ns, [zero] * ni, zero
     flat = [v for row in A for v in row] + [v for row in Bx for v in row] + E + ca + da + cy + dy + [fy]
+    n_recorded = len(tape.ops)
+    tape, nodes = tape.pruned([v.n for v in flat] + [r_port.n])
+    tape.n_recorded = n_recorded
+    flat_n, rport_n = nodes[:-1], nodes[-1]
     if len(tape.ops) > MAX_OPS or len(param_vars) > MAX_PARAMS:
         from . import binding
         raise binding.WdfHipError(f"the probed step needs {len(tape.ops)} operations on {len(param_vars)} component values; "
                                   f"the device probe holds {MAX_OPS} on {MAX_PARAMS}")
-    return tape, [v.n for v in flat], r_port.n
+    return tape, flat_n, rport_n
 
 
 def _c_of(self, v):
