@@ -368,9 +368,12 @@ class Trainer:
             evs = [e for e in warm_evs if e is not None][-8:] + evs
         elif steps <= 64:                                      # (untimed: the same loop continued, every step bracketed)
             post = [[binding.Event() for _ in range(n_ev)] for _ in range(steps)]
+            keep = [t.clone() for t in ([self.theta] + ([self.adam.m, self.adam.v, self.adam.step] if self.adam is not None else []))]
             for e in post:
                 self.step(ev=e)
             torch.cuda.synchronize()
+            for t, k in zip([self.theta] + ([self.adam.m, self.adam.v, self.adam.step] if self.adam is not None else []), keep):
+                t.copy_(k)                                     # (the report's loss / theta are those of the timed steps)
             self.n_in_region = sum(1 for e in evs if e is not None)
             evs = evs + post
         for e in evs:
@@ -1120,10 +1123,11 @@ def main():
             "step_kernels": ("one pass: clipper_fused_tp_kernel (forward + loss + tangent-carried gradient + combine / reduce / "
                              "Adam tail) and its gated repair launch") if fused else
                             "two kernels: clipper_fwd_tp_kernel (+ gated repair) and clipper_bwd_tp_kernel (MSE-fused reverse sweep)",
-            "kernel_ms": dict({"fused_step": spread(t_fwd)} if fused else {"fwd": spread(t_fwd), "bwd": spread(t_bwd)},
-                              **({"bracketed_in_timed_region": main_run.n_in_region,
-                                  "note": "runs of <= 64 steps: every 4th timed step carries events, then the loop continues untimed "
-                                          "with every step bracketed"} if getattr(main_run, "n_in_region", None) is not None else {})),
+            "kernel_ms": {"fused_step": spread(t_fwd)} if fused else {"fwd": spread(t_fwd), "bwd": spread(t_bwd)},
+            "kernel_ms_sampling": ({"bracketed_in_timed_region": main_run.n_in_region,
+                                    "note": "runs of <= 64 steps: every 4th timed step carries events, then the same loop continues untimed "
+                                            "with every step bracketed (parameters and optimizer state restored afterwards)"}
+                                   if getattr(main_run, "n_in_region", None) is not None else None),
             "parity": parity,
             "value_cold": None if cold is None else cold["value"],
             "cold": cold,

@@ -98,6 +98,21 @@ int wdf_adam_step(float* theta, const float* grad, float* m, float* v, int32_t* 
     return check_launch("wdf_adam_step");
 }
 
+int wdf_adam_step_multi(const wdf_adam_job* jobs, int n_jobs, void* stream)
+{
+    if (!jobs) return fail(WDF_EINVAL, "null jobs");
+    if (n_jobs < 1 || n_jobs > WDF_ADAM_MULTI_MAX) return fail(WDF_EINVAL, "wdf_adam_step_multi: 1..%d jobs (got %d)", WDF_ADAM_MULTI_MAX, n_jobs);
+    wdf::AdamJobs a{};
+    for (int i = 0; i < n_jobs; ++i) {
+        const wdf_adam_job& j = jobs[i];
+        if (!j.theta || !j.grad || !j.m || !j.v || !j.step || !j.lr) return fail(WDF_EINVAL, "job %d: null theta/grad/m/v/step/lr", i);
+        if (j.n <= 0 || j.n > 1024) return fail(WDF_EINVAL, "job %d: n must be in 1..1024 (got %d)", i, j.n);
+        a.j[i] = wdf::AdamJob{j.theta, j.grad, j.m, j.v, j.step, j.lr, j.lo, j.hi, j.beta1, j.beta2, j.eps, j.n};
+    }
+    hipLaunchKernelGGL(wdf::adam_clip_multi_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("wdf_adam_step_multi");
+}
+
 void* wdf_event_create(void)
 {
     hipEvent_t e = nullptr;

@@ -405,10 +405,11 @@ size_t wdf_ss_lin_step_ws_bytes(int ns, int ni, int64_t B, int64_t T, int n_chun
 
 // x: [T][ni][B] time-major (the resident training set); coef / jac: wdf_ss_probe's outputs; target, y: [T][B].
 // ws: wdf_ss_lin_step_ws_bytes() bytes, ZERO before the first call (the step leaves it clean).
-// out: float [1 + n_params] = {sum of squared errors, d(gscale/2 x that sum)/d component value}; gcoef_out: float
+// out: float [1 + n_params] = {sum of squared errors, d(gscale/2 x that sum)/d component value}; loss_out: (or NULL) <- gscale/2 x
+// that sum; gcoef_out: float
 // [ns^2 + ns ni + ns + ni] (dLoss/d{A, Bx, cy, dy}) or NULL.
 int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, int n_params, int ns, int ni, const float* target,
-                        float gscale, float* y, void* ws, float* out, float* gcoef_out, int64_t B, int64_t T, int n_chunks,
+                        float gscale, float* y, void* ws, float* out, float* loss_out, float* gcoef_out, int64_t B, int64_t T, int n_chunks,
                         void* stream)
 {
     if (!x || !coef || !jac || !target || !y || !ws || !out) return fail(WDF_EINVAL, "null argument");
@@ -431,7 +432,7 @@ int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, in
             hipLaunchKernelGGL((wdf::ss_lin_step_zero_kernel<NS_, NI_, V_>), grid, dim3(64), 0, s, x, coef, uend0, B, T, L);   \
         EventBracket bracket(s);                                                                                   \
         hipLaunchKernelGGL((wdf::ss_lin_step_kernel<NS_, NI_, V_>), grid, dim3(64), 0, s, x, coef, (const float*)uend0, \
-                           target, gscale, y, part, ticket, jac, n_params, out, gcoef_out, B, T, L);               \
+                           target, gscale, y, part, ticket, jac, n_params, out, loss_out, gcoef_out, B, T, L);               \
     }
 #define WDF_LIN_STEP(NS_, NI_)                                                                                     \
     if (ns == NS_ && ni == NI_) {                                                                                  \

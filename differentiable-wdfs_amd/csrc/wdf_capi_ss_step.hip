@@ -137,9 +137,10 @@ int wdf_ss_nl_step_read(const void* ws, int32_t* ctl_out, void* stream)
 // x: [T][ni][B] time-major; coef: the probe's outputs (SSCoef order, then the port resistance the root sees); params: the
 // component values on the device, the root's Is and nVt at [n_tree], [n_tree + 1]; jac: double [ncoef + 1][n_tree];
 // target, y: [T][B]; ws: planned by wdf_ss_nl_step_plan.
-// out: float [1 + n_tree + 2] = {sum of squared errors, d(gscale / 2 x that sum) / d{component values, Is, nVt}}.
+// out: float [1 + n_tree + 2] = {sum of squared errors, d(gscale / 2 x that sum) / d{component values, Is, nVt}}; loss_out (or NULL)
+// <- gscale / 2 x that sum.
 int wdf_ss_nl_step_mse(const float* x, const float* coef, const float* params, const double* jac, int n_tree, int ns, int ni, int n_up,
-                       int n_down, const float* target, float gscale, float* y, void* ws, float* out, int64_t B, int64_t T,
+                       int n_down, const float* target, float gscale, float* y, void* ws, float* out, float* loss_out, int64_t B, int64_t T,
                        int n_chunks, void* stream)
 {
     if (!x || !coef || !params || !jac || !target || !y || !ws || !out) return fail(WDF_EINVAL, "null argument");
@@ -159,7 +160,7 @@ int wdf_ss_nl_step_mse(const float* x, const float* coef, const float* params, c
     a.snap = (float*)((char*)ws + l.snap);
     a.gpart = (double*)((char*)ws + l.gpart);
     a.part = (double*)((char*)ws + l.part);
-    a.jac = jac; a.out = out;
+    a.jac = jac; a.out = out; a.loss = loss_out;
     a.B = B; a.T = T; a.L = l.L; a.K = l.K;
     a.groups = (int)((B + (pair ? 127 : 63)) / (pair ? 128 : 64));
     a.n_tree = n_tree; a.n_up = n_up; a.n_down = n_down; a.gscale = gscale;

@@ -52,4 +52,34 @@ static __global__ __launch_bounds__(1024) void adam_clip_kernel(float* __restric
     theta[i] = th;
 }
 
+// Several independent optimizers in ONE launch (lpf.py:79-80,93-94 keeps one Adam per component: five launches a step for
+// the HPF clipper's five components when each goes out on its own).  One workgroup per job, adam_clip_kernel's rule.
+constexpr int kAdamMultiMax = 8;
+struct AdamJob {
+    float* theta; const float* grad; float* m; float* v; int32_t* step; const float* lr; const float* lo; const float* hi;
+    float b1, b2, eps; int n;
+};
+struct AdamJobs { AdamJob j[kAdamMultiMax]; };
+
+static __global__ __launch_bounds__(256) void adam_clip_multi_kernel(const AdamJobs jobs)
+{
+    const AdamJob& q = jobs.j[blockIdx.x];
+    const int t = *q.step + 1;
+    __syncthreads();
+    if (threadIdx.x == 0) *q.step = t;
+    const double c1 = 1.0 - ipow((double)q.b1, t), c2 = 1.0 - ipow((double)q.b2, t);
+    for (int i = threadIdx.x; i < q.n; i += blockDim.x) {
+        const float g = q.grad[i];
+        const float mi = q.b1 * q.m[i] + (1.0f - q.b1) * g;
+        const float vi = q.b2 * q.v[i] + (1.0f - q.b2) * g * g;
+        q.m[i] = mi;
+        q.v[i] = vi;
+        const float lr_t = (float)((double)q.lr[i] * sqrt(c2) / c1);
+        float th = q.theta[i] - lr_t * mi / (sqrtf(vi) + q.eps);
+        if (q.lo) th = fmaxf(th, q.lo[i]);
+        if (q.hi) th = fminf(th, q.hi[i]);
+        q.theta[i] = th;
+    }
+}
+
 }  // namespace wdf

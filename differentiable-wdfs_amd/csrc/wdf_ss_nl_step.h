@@ -69,6 +69,7 @@ struct NlStepArgs {
     unsigned* ticket;
     const double* jac;         // [kN + 1][n_tree] (row kN: the port resistance)
     float* out;                // [1 + n_tree + 2]
+    float* loss;               // (or null) <- gscale / 2 x the sum of squared errors: the mean squared error when gscale = 2 / (B T)
     int64_t B, T, L;
     int K, groups, n_tree, n_up, n_down;
     float gscale;
@@ -655,6 +656,7 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
     }
     if (lane == 0) {
         a.out[0] = (float)sum[D::nG];
+        if (a.loss) *a.loss = (float)(0.5 * (double)a.gscale * sum[D::nG]);
         a.out[1 + a.n_tree] = (float)(sL / Is);
         a.out[2 + a.n_tree] = (float)(sV - sL / Vv);
         // what the snapshots of this call were taken with

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict
                                                          const float* __restrict__ uend0, const float* __restrict__ target,
                                                          float gscale, float* __restrict__ y, double* __restrict__ part,
                                                          unsigned* __restrict__ ticket, const double* __restrict__ jac, int n_params,
-                                                         float* __restrict__ out, float* __restrict__ gcoef_out, int64_t B, int64_t T,
+                                                         float* __restrict__ out, float* __restrict__ loss_out, float* __restrict__ gcoef_out, int64_t B, int64_t T,
                                                          int64_t L)
 {
     using U = LinU<NS, NI, V>;
@@ -400,6 +400,7 @@ __global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict
     }
     if (p == 0) {
         out[0] = (float)tot[U::kG];
+        if (loss_out) *loss_out = (float)(0.5 * (double)gscale * tot[U::kG]);   // the mean squared error when gscale = 2 / (B T)
         if (gcoef_out) {
 #pragma unroll
             for (int i = 0; i < U::kG; ++i) gcoef_out[i] = (float)tot[i];

@@ -188,7 +188,7 @@ def lib():
     L.wdf_ss_lin_step_ws_bytes.restype = C.c_size_t
     L.wdf_ss_lin_step_ws_bytes.argtypes = [ci, ci, i64, i64, ci]
     L.wdf_ss_lin_step_mse.restype = ci
-    L.wdf_ss_lin_step_mse.argtypes = [fp, fp, vp, ci, ci, ci, fp, cf, fp, vp, fp, fp, i64, i64, ci, vp]
+    L.wdf_ss_lin_step_mse.argtypes = [fp, fp, vp, ci, ci, ci, fp, cf, fp, vp, fp, fp, fp, i64, i64, ci, vp]
     L.wdf_ss_nl_step_ws_bytes.restype = C.c_size_t
     L.wdf_ss_nl_step_ws_bytes.argtypes = [ci, ci, i64, i64, ci]
     L.wdf_ss_nl_step_chunk_len.restype = ci
@@ -200,7 +200,7 @@ def lib():
     L.wdf_ss_nl_step_read.restype = ci
     L.wdf_ss_nl_step_read.argtypes = [vp, vp, vp]
     L.wdf_ss_nl_step_mse.restype = ci
-    L.wdf_ss_nl_step_mse.argtypes = [fp, fp, fp, vp, ci, ci, ci, ci, ci, fp, cf, fp, vp, fp, i64, i64, ci, vp]
+    L.wdf_ss_nl_step_mse.argtypes = [fp, fp, fp, vp, ci, ci, ci, ci, ci, fp, cf, fp, vp, fp, fp, i64, i64, ci, vp]
     L.wdf_ss_ncoef.restype = ci
     L.wdf_ss_ncoef.argtypes = [ci, ci]
     L.wdf_ss_fwd.restype = ci
@@ -233,6 +233,8 @@ def lib():
     L.wdf_diode_pair_f32.argtypes = [fp, fp, cf, cf, ci, ci, fp, i64, vp]
     L.wdf_adam_step.restype = ci
     L.wdf_adam_step.argtypes = [fp, fp, fp, fp, vp, fp, cf, cf, cf, fp, fp, ci, vp]
+    L.wdf_adam_step_multi.restype = ci
+    L.wdf_adam_step_multi.argtypes = [vp, ci, vp]
     L.wdf_event_create.restype = vp
     L.wdf_event_record.restype = ci
     L.wdf_event_record.argtypes = [vp, vp]
@@ -270,7 +272,7 @@ EXPORTED_SYMBOLS = (
     "wdf_ss_nl_step_mse",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
     "wdf_ss_tp_chunks", "wdf_ss_tp_starts", "wdf_ss_fwd_tp_ws_bytes", "wdf_ss_fwd_tp", "wdf_ss_bwd_tp_ws_bytes", "wdf_ss_bwd_tp",
-    "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step",
+    "wdf_omega_f32", "wdf_omega_f64", "wdf_diode_pair_f32", "wdf_adam_step", "wdf_adam_step_multi",
     "wdf_event_create", "wdf_event_record", "wdf_event_elapsed_ms", "wdf_event_destroy", "wdf_event_bracket_next",
     "wdf_clock_stamp",
 )
@@ -1164,6 +1166,30 @@ class Adam:
         rc = lib().wdf_adam_step(_ptr(theta), _ptr(grad), _ptr(self.m), _ptr(self.v), _ptr(self.step), _ptr(self.lr),
                                  self.b1, self.b2, self.eps, _ptr(self.lo), _ptr(self.hi), self.n, _stream())
         _check(rc, "wdf_adam_step")
+
+
+class _AdamJob(C.Structure):                       # include/wdf_hip.h: wdf_adam_job
+    _fields_ = [("theta", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p),
+                ("lr", C.c_void_p), ("lo", C.c_void_p), ("hi", C.c_void_p), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("n", C.c_int)]
+
+
+ADAM_MULTI_MAX = 8
+
+
+def adam_step_multi(jobs):
+    """jobs: [(Adam, theta, grad), ...] (at most ADAM_MULTI_MAX, distinct optimizers): every update in ONE launch."""
+    if len(jobs) == 1:
+        jobs[0][0].apply(jobs[0][1], jobs[0][2])
+        return
+    arr = (_AdamJob * len(jobs))()
+    for a, (opt, theta, grad) in zip(arr, jobs):
+        theta, grad = _f32_dev(theta, "theta"), _f32_dev(grad, "grad")
+        if theta.numel() != opt.n or grad.numel() != opt.n:
+            raise WdfHipError(f"Adam: expected {opt.n} parameters")
+        a.theta, a.grad, a.m, a.v, a.step, a.lr = _ptr(theta), _ptr(grad), _ptr(opt.m), _ptr(opt.v), _ptr(opt.step), _ptr(opt.lr)
+        a.lo, a.hi, a.beta1, a.beta2, a.eps, a.n = _ptr(opt.lo), _ptr(opt.hi), opt.b1, opt.b2, opt.eps, opt.n
+    _check(lib().wdf_adam_step_multi(C.cast(arr, C.c_void_p), len(jobs), _stream()), "wdf_adam_step_multi")
 
 
 def clock_stamp(out):

@@ -30,9 +30,20 @@ def _dtype(d):
     return _DEFAULT if d is None else d
 
 
+_PENDING = []      # ParamBlocks with deferred optimizer updates (ParamBlock.defer)
+
+
 class Tensor(torch.Tensor):
     """torch.Tensor with the two TF-isms the scripts use on results: .numpy() on tensors that
     require grad, and .assign() on variables."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        # (Variables are instances of this class; one adopted by a ParamBlock may have optimizer updates queued: a value is
+        #  about to be read or written, so they go out first)
+        if _PENDING:
+            flush_pending()
+        return super().__torch_function__(func, types, args, kwargs or {})
 
     def numpy(self):
         return torch.Tensor.numpy(self.detach().cpu().as_subclass(torch.Tensor))
@@ -221,6 +232,11 @@ class Variable(Tensor, metaclass=_VariableMeta):
         return t
 
 
+def flush_pending():
+    for pb in list(_PENDING):
+        pb.flush()
+
+
 class ParamBlock:
     """Scalar float32 Variables of one circuit kept in ONE device-resident vector (tf_wdf.Circuit.to_device): the kernels
     read the component values where they live, tape.gradient hands back device scalars and the optimizer updates the
@@ -239,6 +255,28 @@ class ParamBlock:
         self._pinned = torch.empty(self.n, dtype=torch.float32).pin_memory()
         self._event, self._peeks = None, 0
         self.members = {}                       # index -> adopted Variable
+        self.pending = []                       # deferred optimizer updates: (binding.Adam, theta view, gradient)
+
+    def defer(self, opt, theta, grad):
+        """Queue one optimizer's update of (a slice of) the block instead of launching it: a script with one Adam per
+        component (lpf.py:79-80,93-94) then pays ONE launch for all of them -- sent (flush) before anything reads the values:
+        the next step's kernels, a torch operation on an adopted Variable, the host mirror."""
+        from . import binding
+        if len(self.pending) >= binding.ADAM_MULTI_MAX or any(j[0] is opt for j in self.pending):
+            self.flush()
+        self.pending.append((opt, theta, grad))
+        if self not in _PENDING:
+            _PENDING.append(self)
+
+    def flush(self):
+        if not self.pending:
+            return
+        from . import binding
+        jobs, self.pending = self.pending, []
+        if self in _PENDING:
+            _PENDING.remove(self)
+        with torch.no_grad(), torch._C.DisableTorchFunctionSubclass():
+            binding.adam_step_multi(jobs)
 
     def adopt(self, i, v):
         with torch.no_grad():
@@ -248,6 +286,7 @@ class ParamBlock:
 
     def host_values(self):
         """The block as python floats, at most a few dozen steps old; costs no synchronisation."""
+        self.flush()
         if self._event is not None and self._event.query():
             self._host_vals = [float(x) for x in self._pinned.tolist()]
             self._event = None
@@ -640,8 +679,9 @@ class _Adam:
             else:
                 g = torch.stack([g.reshape(()) for g, _ in gv]).to(torch.float32)
             if isinstance(sel, slice):
-                opt.apply(pb.block[sel], g)
+                pb.defer(opt, pb.block[sel], g)
             else:
+                pb.flush()
                 th = pb.block[sel]
                 opt.apply(th, g)
                 pb.block[sel] = th
@@ -679,7 +719,9 @@ class _Adam:
 
     def apply_gradients(self, grads_and_vars):
         grads_and_vars = list(grads_and_vars)
-        if self._apply_flat(grads_and_vars) or self._apply_resident(grads_and_vars):
+        with torch._C.DisableTorchFunctionSubclass():       # (looking at .is_cuda etc. must not send the queued updates)
+            done = self._apply_flat(grads_and_vars) or self._apply_resident(grads_and_vars)
+        if done:
             self.iterations += 1
             return
         self.iterations += 1

@@ -207,6 +207,7 @@ class _LinResident:
 
     def probe(self):
         L = binding.lib()
+        self.pb.flush()                                          # (queued optimizer updates of the block go out first)
         binding._check(L.wdf_ss_probe(binding._ptr(self.tape), self.n_ops, binding._ptr(self.consts), binding._ptr(self.pb.block),
                                       self.n_tree, binding._ptr(self.outs), self.n_out, binding._ptr(self.coef),
                                       binding._ptr(self.coef64), binding._ptr(self.jac), binding._stream()), "wdf_ss_probe")
@@ -248,8 +249,10 @@ class _LinResident:
                 if nbytes == 0:
                     raise binding.WdfHipError(L_.wdf_last_error().decode() or "wdf_ss_lin_step_ws_bytes: unsupported tree")
                 ws = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
+            # results of a call: {SSE, gradients} and the loss, in one of eight rows taken in turn (a call's results stay valid
+            # while up to seven more calls on this batch run: no copy per call)
             ent = self.cache[key] = {"x": x_tm, "t": tgt, "y": y, "ws": ws,
-                                     "out": torch.zeros((1 + self.pb.n,), dtype=torch.float32, device=dev),
+                                     "ring": torch.zeros((8, 2 + self.pb.n), dtype=torch.float32, device=dev), "turn": 0,
                                      "B": B, "T": T, "k": k, "hold": (x, target), "calls": 0, "watch": None, "replans": 0}
         return ent
 
@@ -321,25 +324,29 @@ class _LinResident:
                 "max_miss": float(f[13]), "gated_groups": int(raw[14]), "total_gated": int(raw[15]), "w_used": int(raw[19])}
 
     def step(self, ent):
-        """probe + one-pass step -> ent["out"] = {SSE, d(mean squared error)/d component value}."""
+        """probe + one-pass step -> (out = {SSE, d(mean squared error)/d component value}, loss = the mean squared error): views
+        of this call's row of the entry's result ring."""
         circ = self.circ
         self.probe()
-        B, T = ent["B"], ent["T"]
+        B, T, n = ent["B"], ent["T"], self.pb.n
+        row = ent["ring"][ent["turn"]]
+        ent["turn"] = (ent["turn"] + 1) % ent["ring"].shape[0]
+        out, loss = row[:1 + n], row[1 + n]
         if circ.root_kind == "DiodePair":
             rc = binding.lib().wdf_ss_nl_step_mse(binding._ptr(ent["x"]), binding._ptr(self.coef), binding._ptr(self.pb.block),
                                                   binding._ptr(self.jac), self.n_tree, circ.ns, circ.ni, int(circ.root.N_up),
                                                   int(circ.root.N_down), binding._ptr(ent["t"]), 2.0 / float(B * T),
-                                                  binding._ptr(ent["y"]), binding._ptr(ent["ws"]), binding._ptr(ent["out"]), B, T,
-                                                  ent["k"], binding._stream())
+                                                  binding._ptr(ent["y"]), binding._ptr(ent["ws"]), binding._ptr(out),
+                                                  binding._ptr(loss), B, T, ent["k"], binding._stream())
             binding._check(rc, "wdf_ss_nl_step_mse")
             self._watch(ent)
-            return ent["out"]
+            return out, loss
         rc = binding.lib().wdf_ss_lin_step_mse(binding._ptr(ent["x"]), binding._ptr(self.coef), binding._ptr(self.jac), self.pb.n,
                                                circ.ns, circ.ni, binding._ptr(ent["t"]), 2.0 / float(B * T), binding._ptr(ent["y"]),
-                                               binding._ptr(ent["ws"]), binding._ptr(ent["out"]), None, B, T, ent["k"],
+                                               binding._ptr(ent["ws"]), binding._ptr(out), binding._ptr(loss), None, B, T, ent["k"],
                                                binding._stream())
         binding._check(rc, "wdf_ss_lin_step_mse")
-        return ent["out"]
+        return out, loss
 
 
 class _ProbeFn(torch.autograd.Function):
@@ -375,11 +382,11 @@ class _LinResidentMseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, res, ent, inv_n, idx, *live):
-        out = res.step(ent).clone()                              # (a validation pass may run before backward)
+        out, loss = res.step(ent)                                # (this call's row of the result ring: nothing to copy)
         ctx.save_for_backward(out)
         ctx.idx = idx
         ctx.mark_non_differentiable(out)
-        return out[0] * inv_n, out
+        return loss, out
 
     @staticmethod
     def backward(ctx, gl, _):
@@ -529,6 +536,7 @@ class Circuit:
         """{Is, nVt, R, C} as one float32[4] on the device, differentiable w.r.t. the Variables among them."""
         pb = getattr(self, "_pblock", None)
         if pb is not None:      # resident: the adopted Variables already live on the device, the rest are the block's constants
+            pb.flush()
             return torch.stack([(pb.members[i] if i in pb.members else pb.block[i]).as_subclass(torch.Tensor).reshape(())
                                 for i in range(4)]).to(dev)
         return torch.stack([p.as_subclass(torch.Tensor).float().reshape(()) for p in parts]).to(dev)
@@ -548,6 +556,7 @@ class Circuit:
         of the one-pass training step per call."""
         from . import engine
         pb = self._pblock
+        pb.flush()                                               # (queued optimizer updates of the block go out first)
         dp_, vs_, cap_ = self.root, self.top.P1, self.top.P2
         now = [dp_.Is, dp_.nVt, (1.0 if self.per_sample_R is not None else vs_.R), cap_.C]
         for i, v in getattr(self, "_adopted_parts", {}).items():

@@ -311,14 +311,14 @@ int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb,
  *                         wdf_ss_fwd's layout, float32 and float64) and jac = d coef / d params, double [n_out][n_params].
  *   wdf_ss_lin_step_mse   forward, squared error and the gradient carried forward in time (no stash, no reverse sweep),
  *                         in EXACT time chunks (a pass from zero state, a walk over the chunk boundaries, the pass itself);
- *                         its last wave contracts dLoss/d coef with jac: out = {SSE, dLoss/d params}.  x is TIME-major
+ *                         its last wave contracts dLoss/d coef with jac: out = {SSE, dLoss/d params}, *loss_out (optional) = gscale/2 SSE.  x is TIME-major
  *                         [T][ni][B].  ns <= 2, ni <= 2, zero initial state.                                   */
 int wdf_ss_probe(const int32_t* tape, int n_ops, const double* consts, const float* params, int n_params,
                  const int32_t* outs, int n_out, float* coef, double* coef64, double* jac, void* stream);
 size_t wdf_ss_lin_step_ws_bytes(int ns, int ni, int64_t B, int64_t T, int n_chunks);
 int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, int n_params, int ns, int ni,
-                        const float* target, float gscale, float* y, void* ws, float* out, float* gcoef_out,
-                        int64_t B, int64_t T, int n_chunks, void* stream);
+                        const float* target, float gscale, float* y, void* ws, float* out, float* loss_out,
+                        float* gcoef_out, int64_t B, int64_t T, int n_chunks, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * The one-pass MSE training step of small trees with a DIODE-PAIR root (csrc/wdf_ss_nl_step.h): the same epoch
@@ -347,7 +347,7 @@ int wdf_ss_nl_step_set(void* ws, int field, double value, void* stream);
 int wdf_ss_nl_step_read(const void* ws, int32_t* ctl_out, void* stream);
 int wdf_ss_nl_step_mse(const float* x, const float* coef, const float* params, const double* jac, int n_tree, int ns,
                        int ni, int n_up, int n_down, const float* target, float gscale, float* y, void* ws, float* out,
-                       int64_t B, int64_t T, int n_chunks, void* stream);
+                       float* loss_out, int64_t B, int64_t T, int n_chunks, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * The RESIDENT training step of the MLP-root pot clipper (csrc/wdf_mlp_step.h): what one epoch of
@@ -514,6 +514,15 @@ int wdf_diode_pair_f32(const float* a, const float* R_port, float Is, float nVt,
 int wdf_adam_step(float* theta, const float* grad, float* m, float* v, int32_t* step,
                   const float* lr, float beta1, float beta2, float eps,
                   const float* lo, const float* hi, int n, void* stream);
+
+/* Up to WDF_ADAM_MULTI_MAX independent wdf_adam_step updates in ONE launch (one Adam per component, lpf.py:79-80,93-94: the
+ * host layer queues the apply_gradients calls of a training step and sends them together before anything reads the values). */
+#define WDF_ADAM_MULTI_MAX 8
+typedef struct wdf_adam_job {
+    float* theta; const float* grad; float* m; float* v; int32_t* step; const float* lr; const float* lo; const float* hi;
+    float beta1, beta2, eps; int n;
+} wdf_adam_job;
+int wdf_adam_step_multi(const wdf_adam_job* jobs, int n_jobs, void* stream);
 
 /* Time-parallel variants of the MLP-root calls (csrc/wdf_mlp_tp.h): the reference's 1340 x 2048 training set
  * (clipper_pot.py:58,232) is only 335 waves when every sequence runs its 2048 steps in one wave.

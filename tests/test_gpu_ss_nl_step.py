@@ -235,3 +235,40 @@ def test_persistent_misses_halve_the_chunk_count(wdf, oracle, monkeypatch):
     # (it stops halving where the longer chunks' warm-up brings a chunk to its predecessor's end BIT FOR BIT)
     assert ks[0] == 32 and ks[-1] < 32 and all(b <= a for a, b in zip(ks, ks[1:])) and 2 ** ent["replans"] == ks[0] // ks[-1]
     assert circ._tree.read_ctl(ent)["gated_groups"] == 0
+
+
+def test_one_launch_for_the_optimizers_of_a_step(wdf):
+    """One Adam per component (lpf.py:79-80,93-94): the updates of a step are queued on the parameter block and go out as ONE
+    launch before anything reads the values -- same numbers as five separate launches, in the order they were asked for."""
+    tf = wdf.tf
+    rng = np.random.default_rng(4)
+    B, T = 64, 1024
+    x, tgt = cuda(rng.standard_normal((B, T)) * 1.2), cuda(0.3 * rng.standard_normal((T, B)))
+    ends = []
+    for deferred in (True, False):
+        circ, params = hpf(wdf)
+        circ.to_device()
+        pb = circ._tree.pb
+        opts = [tf.keras.optimizers.Adam(learning_rate=2.0e-3 * float(p)) for p in params]
+        for step in range(6):
+            with tf.GradientTape() as tape:
+                loss = circ.mse(x, tgt)
+            grads = tape.gradient(loss, params)
+            for o, g, p in zip(opts, grads, params):
+                o.apply_gradients([(g, p)])
+                if not deferred:
+                    pb.flush()
+            if deferred:
+                assert len(pb.pending) == 5
+                if step == 2:
+                    opts[0].apply_gradients([(grads[0], params[0])])   # the same optimizer again: the queue goes out first
+                    assert len(pb.pending) == 1
+                if step == 3:
+                    v = float(params[2])                                # a read sends them
+                    assert len(pb.pending) == 0 and v != THETA[2]
+            elif step == 2:
+                opts[0].apply_gradients([(grads[0], params[0])])
+                pb.flush()
+        ends.append(([float(p) for p in params], float(loss)))
+        assert len(pb.pending) == 0
+    assert ends[0] == ends[1], ends
