@@ -370,16 +370,37 @@ int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, doubl
 }
 
 // ---- the one-pass MSE step of linear trees (wdf_ss_step.h) -------------------------------------------------------------
+static int probe_launch(const wdf_adam_job* jobs, int n_jobs, const int32_t* tape, int n_ops, const double* consts, const float* params,
+                        int n_params, const int32_t* outs, int n_out, float* coef, double* coef64, double* jac, void* stream, const char* what)
+{
+    if (!tape || !consts || !params || !outs || !coef || !coef64 || !jac) return fail(WDF_EINVAL, "null argument");
+    if (n_ops < 1 || n_ops > wdf::kProbeMaxOps) return fail(WDF_EUNSUPPORTED, "%s: 1..%d operations (got %d)", what, wdf::kProbeMaxOps, n_ops);
+    if (n_params < 1 || n_params > wdf::kProbeMaxParams) return fail(WDF_EUNSUPPORTED, "%s: 1..%d parameters (got %d)", what, wdf::kProbeMaxParams, n_params);
+    if (n_out < 1) return fail(WDF_EINVAL, "n_out >= 1");
+    if (n_jobs < 0 || n_jobs > WDF_ADAM_MULTI_MAX || (n_jobs > 0 && !jobs)) return fail(WDF_EINVAL, "%s: 0..%d jobs", what, WDF_ADAM_MULTI_MAX);
+    wdf::AdamJobs a{};
+    for (int i = 0; i < n_jobs; ++i) {
+        const wdf_adam_job& j = jobs[i];
+        if (!j.theta || !j.grad || !j.m || !j.v || !j.step || !j.lr) return fail(WDF_EINVAL, "job %d: null theta/grad/m/v/step/lr", i);
+        if (j.n <= 0 || j.n > 1024) return fail(WDF_EINVAL, "job %d: n must be in 1..1024 (got %d)", i, j.n);
+        a.j[i] = wdf::AdamJob{j.theta, j.grad, j.m, j.v, j.step, j.lr, j.lo, j.hi, j.beta1, j.beta2, j.eps, j.n};
+    }
+    hipLaunchKernelGGL(wdf::ss_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tape, n_ops, consts, params, n_params, outs,
+                       n_out, coef, coef64, jac, a, n_jobs);
+    return check_launch(what);
+}
+
 int wdf_ss_probe(const int32_t* tape, int n_ops, const double* consts, const float* params, int n_params, const int32_t* outs,
                  int n_out, float* coef, double* coef64, double* jac, void* stream)
 {
-    if (!tape || !consts || !params || !outs || !coef || !coef64 || !jac) return fail(WDF_EINVAL, "null argument");
-    if (n_ops < 1 || n_ops > wdf::kProbeMaxOps) return fail(WDF_EUNSUPPORTED, "wdf_ss_probe: 1..%d operations (got %d)", wdf::kProbeMaxOps, n_ops);
-    if (n_params < 1 || n_params > wdf::kProbeMaxParams) return fail(WDF_EUNSUPPORTED, "wdf_ss_probe: 1..%d parameters (got %d)", wdf::kProbeMaxParams, n_params);
-    if (n_out < 1) return fail(WDF_EINVAL, "n_out >= 1");
-    hipLaunchKernelGGL(wdf::ss_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tape, n_ops, consts, params, n_params, outs,
-                       n_out, coef, coef64, jac);
-    return check_launch("wdf_ss_probe");
+    return probe_launch(nullptr, 0, tape, n_ops, consts, params, n_params, outs, n_out, coef, coef64, jac, stream, "wdf_ss_probe");
+}
+
+// wdf_adam_step_multi(jobs) followed by wdf_ss_probe, in ONE launch: the jobs update (slices of) `params`.
+int wdf_ss_probe_adam(const wdf_adam_job* jobs, int n_jobs, const int32_t* tape, int n_ops, const double* consts, const float* params,
+                      int n_params, const int32_t* outs, int n_out, float* coef, double* coef64, double* jac, void* stream)
+{
+    return probe_launch(jobs, n_jobs, tape, n_ops, consts, params, n_params, outs, n_out, coef, coef64, jac, stream, "wdf_ss_probe_adam");
 }
 
 static bool lin_step_ok(int ns, int ni) { return ns >= 0 && ns <= 2 && ni >= 1 && ni <= 2; }

@@ -27,6 +27,7 @@
 #include "wdf_statespace.h"
 #include "wdf_clipper.h"      // wave_sum_dpp
 #include "wdf_vec.h"
+#include "wdf_optim.h"
 
 namespace wdf {
 
@@ -36,11 +37,40 @@ enum { kOpConst = 0, kOpParam, kOpAdd, kOpSub, kOpMul, kOpDiv, kOpNeg, kOpRecip 
 // tape: int32 [n_ops][3] = {op, a, b}; consts: double; params: the float32 block the component values live in.
 // outs: node of every output (the coefficient vector, then the port resistance).  -> coef (float32 and float64) and
 // jac double [n_out][n_params].  One wave: lane p carries the tangent w.r.t. parameter p (values are computed by all).
+// jobs (n_jobs >= 0): optimizer updates of `params` queued by the host (wdf_optim.h, adam_clip_multi_kernel's rule) -- applied
+// by this workgroup BEFORE the probe reads the values: a training step's optimizers and its probe in one launch.
 static __global__ __launch_bounds__(64) void ss_probe_kernel(const int32_t* __restrict__ tape, int n_ops, const double* __restrict__ consts,
-                                                             const float* __restrict__ params, int n_params, const int32_t* __restrict__ outs,
+                                                             const float* params, int n_params, const int32_t* __restrict__ outs,
                                                              int n_out, float* __restrict__ coef, double* __restrict__ coef64,
-                                                             double* __restrict__ jac)
+                                                             double* __restrict__ jac, const AdamJobs jobs, int n_jobs)
 {
+    if (n_jobs > 0) {                                            // eight lanes per job, all jobs side by side
+        const int jb = threadIdx.x >> 3, li = threadIdx.x & 7;
+        const bool mine = jb < n_jobs;
+        const AdamJob q = jobs.j[mine ? jb : 0];
+        const int t = *q.step + 1;
+        if (mine) {
+            const double c1 = 1.0 - ipow((double)q.b1, t), c2 = 1.0 - ipow((double)q.b2, t);
+            for (int i = li; i < q.n; i += 8) {
+                const float g = q.grad[i];
+                const float mi = q.b1 * q.m[i] + (1.0f - q.b1) * g;
+                const float vi = q.b2 * q.v[i] + (1.0f - q.b2) * g * g;
+                q.m[i] = mi;
+                q.v[i] = vi;
+                const float lr_t = (float)((double)q.lr[i] * sqrt(c2) / c1);
+                float th = q.theta[i] - lr_t * mi / (sqrtf(vi) + q.eps);
+                if (q.lo) th = fmaxf(th, q.lo[i]);
+                if (q.hi) th = fminf(th, q.hi[i]);
+                __hip_atomic_store(q.theta + i, th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();                                          // (every lane has read its job's step count)
+        if (mine && li == 0) *q.step = t;
+    }
+    if (n_jobs > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     __shared__ double val[kProbeMaxOps][kProbeLanes], tan[kProbeMaxOps][kProbeLanes];
     __shared__ int ops[kProbeMaxOps * 3];
     __shared__ double leaf[kProbeMaxOps];                         // the value of every CONST / PARAM node
@@ -48,7 +78,7 @@ static __global__ __launch_bounds__(64) void ss_probe_kernel(const int32_t* __re
     __syncthreads();
     for (int i = threadIdx.x; i < n_ops; i += 64) {               // (all leaves fetched at once: no dependent global loads below)
         const int op = ops[3 * i], a = ops[3 * i + 1];
-        leaf[i] = op == kOpConst ? consts[a] : (op == kOpParam ? (double)params[a] : 0.0);
+        leaf[i] = op == kOpConst ? consts[a] : (op == kOpParam ? (double)__hip_atomic_load(params + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0);
     }
     __syncthreads();
     const int p = threadIdx.x;

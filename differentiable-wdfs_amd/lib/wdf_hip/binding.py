@@ -185,6 +185,8 @@ def lib():
                                        ci, ci, ci, vp, fp, fp, fp, fp, fp, vp, fp, cf, cf, cf, vp]
     L.wdf_ss_probe.restype = ci
     L.wdf_ss_probe.argtypes = [vp, ci, vp, fp, ci, vp, ci, fp, vp, vp, vp]
+    L.wdf_ss_probe_adam.restype = ci
+    L.wdf_ss_probe_adam.argtypes = [vp, ci, vp, ci, vp, fp, ci, vp, ci, fp, vp, vp, vp]
     L.wdf_ss_lin_step_ws_bytes.restype = C.c_size_t
     L.wdf_ss_lin_step_ws_bytes.argtypes = [ci, ci, i64, i64, ci]
     L.wdf_ss_lin_step_mse.restype = ci
@@ -267,7 +269,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_mlp_wgrad_ws_bytes", "wdf_clipper_mlp_wgrad", "wdf_mlp_eval", "wdf_mlp_fit_epoch",
     "wdf_clipper_mlp_step_state_bytes", "wdf_clipper_mlp_step_plan", "wdf_clipper_mlp_step_read", "wdf_clipper_mlp_step_set",
     "wdf_clipper_mlp_step_set_wcol", "wdf_clipper_mlp_step_prepare", "wdf_clipper_mlp_step",
-    "wdf_ss_probe", "wdf_ss_lin_step_ws_bytes", "wdf_ss_lin_step_mse",
+    "wdf_ss_probe", "wdf_ss_probe_adam", "wdf_ss_lin_step_ws_bytes", "wdf_ss_lin_step_mse",
     "wdf_ss_nl_step_ws_bytes", "wdf_ss_nl_step_chunk_len", "wdf_ss_nl_step_plan", "wdf_ss_nl_step_set", "wdf_ss_nl_step_read",
     "wdf_ss_nl_step_mse",
     "wdf_ss_ncoef", "wdf_ss_fwd", "wdf_ss_bwd", "wdf_ss_bwd_ws_bytes", "wdf_ss_fwd_lin_tp_ws_bytes", "wdf_ss_fwd_lin_tp",
@@ -1177,11 +1179,8 @@ class _AdamJob(C.Structure):                       # include/wdf_hip.h: wdf_adam
 ADAM_MULTI_MAX = 8
 
 
-def adam_step_multi(jobs):
-    """jobs: [(Adam, theta, grad), ...] (at most ADAM_MULTI_MAX, distinct optimizers): every update in ONE launch."""
-    if len(jobs) == 1:
-        jobs[0][0].apply(jobs[0][1], jobs[0][2])
-        return
+def adam_jobs(jobs):
+    """[(Adam, theta, grad), ...] -> the C array of wdf_adam_job."""
     arr = (_AdamJob * len(jobs))()
     for a, (opt, theta, grad) in zip(arr, jobs):
         theta, grad = _f32_dev(theta, "theta"), _f32_dev(grad, "grad")
@@ -1189,6 +1188,15 @@ def adam_step_multi(jobs):
             raise WdfHipError(f"Adam: expected {opt.n} parameters")
         a.theta, a.grad, a.m, a.v, a.step, a.lr = _ptr(theta), _ptr(grad), _ptr(opt.m), _ptr(opt.v), _ptr(opt.step), _ptr(opt.lr)
         a.lo, a.hi, a.beta1, a.beta2, a.eps, a.n = _ptr(opt.lo), _ptr(opt.hi), opt.b1, opt.b2, opt.eps, opt.n
+    return arr
+
+
+def adam_step_multi(jobs):
+    """jobs: [(Adam, theta, grad), ...] (at most ADAM_MULTI_MAX, distinct optimizers): every update in ONE launch."""
+    if len(jobs) == 1:
+        jobs[0][0].apply(jobs[0][1], jobs[0][2])
+        return
+    arr = adam_jobs(jobs)
     _check(lib().wdf_adam_step_multi(C.cast(arr, C.c_void_p), len(jobs), _stream()), "wdf_adam_step_multi")
 
 

@@ -41,8 +41,8 @@ class Tensor(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         # (Variables are instances of this class; one adopted by a ParamBlock may have optimizer updates queued: a value is
         #  about to be read or written, so they go out first)
-        if _PENDING:
-            flush_pending()
+        if _PENDING and not getattr(getattr(func, "__self__", None), "_wdf_sends_pending", False):
+            flush_pending()                                  # (an autograd Function marked so sends them with its own first launch)
         return super().__torch_function__(func, types, args, kwargs or {})
 
     def numpy(self):
@@ -268,13 +268,18 @@ class ParamBlock:
         if self not in _PENDING:
             _PENDING.append(self)
 
+    def take_pending(self):
+        """The queued updates, for a caller that sends them with its own launch (the device probe, lowering._LinResident)."""
+        jobs, self.pending = self.pending, []
+        if self in _PENDING:
+            _PENDING.remove(self)
+        return jobs
+
     def flush(self):
         if not self.pending:
             return
         from . import binding
-        jobs, self.pending = self.pending, []
-        if self in _PENDING:
-            _PENDING.remove(self)
+        jobs = self.take_pending()
         with torch.no_grad(), torch._C.DisableTorchFunctionSubclass():
             binding.adam_step_multi(jobs)
 

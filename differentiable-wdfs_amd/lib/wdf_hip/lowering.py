@@ -12,6 +12,7 @@ dL/d(matrices) and torch chains it to the component values -- which is what
 tape.gradient(loss, model.trainable_variables) is in the reference (lpf.py:87-90).
 """
 import collections
+import ctypes
 import math
 import os
 import weakref
@@ -206,11 +207,17 @@ class _LinResident:
                 raise binding.WdfHipError(f"Circuit.to_device: {type(e).__name__}.{n} was replaced after to_device(); build a new Circuit")
 
     def probe(self):
+        """The step's coefficients and their Jacobian from the block, on the device -- behind the optimizer updates the
+        script queued since the last step (compat_tf.ParamBlock.defer), in the SAME launch."""
         L = binding.lib()
-        self.pb.flush()                                          # (queued optimizer updates of the block go out first)
-        binding._check(L.wdf_ss_probe(binding._ptr(self.tape), self.n_ops, binding._ptr(self.consts), binding._ptr(self.pb.block),
-                                      self.n_tree, binding._ptr(self.outs), self.n_out, binding._ptr(self.coef),
-                                      binding._ptr(self.coef64), binding._ptr(self.jac), binding._stream()), "wdf_ss_probe")
+        jobs = self.pb.take_pending()
+        with torch.no_grad(), torch._C.DisableTorchFunctionSubclass():
+            arr = binding.adam_jobs(jobs) if jobs else None
+            rc = L.wdf_ss_probe_adam(None if arr is None else ctypes.cast(arr, ctypes.c_void_p), len(jobs), binding._ptr(self.tape),
+                                     self.n_ops, binding._ptr(self.consts), binding._ptr(self.pb.block), self.n_tree,
+                                     binding._ptr(self.outs), self.n_out, binding._ptr(self.coef), binding._ptr(self.coef64),
+                                     binding._ptr(self.jac), binding._stream())
+        binding._check(rc, "wdf_ss_probe_adam")
 
     def host_coef(self):
         """The coefficient vector (float64 numpy, and the port resistance) at the block's lagging host mirror: what the
@@ -353,6 +360,7 @@ class _ProbeFn(torch.autograd.Function):
     """(coef float32 [ncoef], rootp float32 [3] | None) of a resident tree from its parameter block, on the device
     (wdf_ss_probe); backward contracts dLoss/d coef with the probe's Jacobian -- calc_impedance's chain rule
     (tf_wdf.py:114-115,139-145,168-177) without the host."""
+    _wdf_sends_pending = True        # (res.probe() carries the queued optimizer updates: compat_tf.Tensor.__torch_function__)
 
     @staticmethod
     def forward(ctx, res, idx, *live):
@@ -379,6 +387,7 @@ class _ProbeFn(torch.autograd.Function):
 
 class _LinResidentMseFn(torch.autograd.Function):
     """loss = mean((y - target)^2) of a resident linear tree: the one-pass step produced d loss / d Variable with it."""
+    _wdf_sends_pending = True        # (res.step() begins with res.probe(), which carries the queued optimizer updates)
 
     @staticmethod
     def forward(ctx, res, ent, inv_n, idx, *live):
@@ -634,9 +643,10 @@ class Circuit:
                 and 1 <= self.ni <= 2 and not self.force_generic:
             lin = self._tree                                     # diode-pair root: the tangent-carried step (csrc/wdf_ss_nl_step.h)
         if lin is not None and isinstance(x, torch.Tensor) and isinstance(target, torch.Tensor):
-            lin.check()
-            ent = lin.entry(x, target)
-            live = [(i, v) for i, v in sorted(lin.pb.members.items()) if v.requires_grad]
+            with torch._C.DisableTorchFunctionSubclass():        # (asking a tensor for its version or requires_grad must not
+                lin.check()                                      #  send the queued optimizer updates: the probe carries them)
+                ent = lin.entry(x, target)
+                live = [(i, v) for i, v in sorted(lin.pb.members.items()) if v.requires_grad]
             loss, out = _LinResidentMseFn.apply(lin, ent, 1.0 / float(ent["B"] * ent["T"]), [i for i, _ in live], *[v for _, v in live])
             loss = loss.as_subclass(tf.Tensor)
             loss._wdf_fused = (out, {id(v): i for i, v in live})

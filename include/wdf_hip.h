@@ -315,6 +315,11 @@ int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb,
  *                         [T][ni][B].  ns <= 2, ni <= 2, zero initial state.                                   */
 int wdf_ss_probe(const int32_t* tape, int n_ops, const double* consts, const float* params, int n_params,
                  const int32_t* outs, int n_out, float* coef, double* coef64, double* jac, void* stream);
+/* wdf_adam_step_multi(jobs, n_jobs) (below: the optimizers' updates of `params`) and wdf_ss_probe in ONE launch. */
+struct wdf_adam_job;
+int wdf_ss_probe_adam(const struct wdf_adam_job* jobs, int n_jobs, const int32_t* tape, int n_ops, const double* consts,
+                      const float* params, int n_params, const int32_t* outs, int n_out, float* coef, double* coef64,
+                      double* jac, void* stream);
 size_t wdf_ss_lin_step_ws_bytes(int ns, int ni, int64_t B, int64_t T, int n_chunks);
 int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, int n_params, int ns, int ni,
                         const float* target, float gscale, float* y, void* ws, float* out, float* loss_out,
