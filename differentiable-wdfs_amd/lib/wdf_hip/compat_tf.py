@@ -31,6 +31,7 @@ def _dtype(d):
 
 
 _PENDING = []      # ParamBlocks with deferred optimizer updates (ParamBlock.defer)
+_TORCH_FUNCTION = torch.Tensor.__torch_function__.__func__      # (the default dispatch, without a super() object per call)
 
 
 class Tensor(torch.Tensor):
@@ -43,7 +44,7 @@ class Tensor(torch.Tensor):
         #  about to be read or written, so they go out first)
         if _PENDING and not getattr(getattr(func, "__self__", None), "_wdf_sends_pending", False):
             flush_pending()                                  # (an autograd Function marked so sends them with its own first launch)
-        return super().__torch_function__(func, types, args, kwargs or {})
+        return _TORCH_FUNCTION(cls, func, types, args, kwargs or {})
 
     def numpy(self):
         return torch.Tensor.numpy(self.detach().cpu().as_subclass(torch.Tensor))
