@@ -272,3 +272,42 @@ def test_one_launch_for_the_optimizers_of_a_step(wdf):
         ends.append(([float(p) for p in params], float(loss)))
         assert len(pb.pending) == 0
     assert ends[0] == ends[1], ends
+
+
+def test_full_size_step_against_the_two_pass_path(wdf):
+    """8192 x 4096 (the bench shape): the one-pass step -- cold, then two calls from the snapshots across Adam steps -- against
+    the plain path on the same components (host probe, ss_fwd_tp + verified chunks, torch's loss, ss_bwd_tp): outputs of every
+    sequence, loss and the five gradients; and linearity of the loss in the target: L(t) - 2 L((t + t2) / 2) + L(t2) =
+    mean((t - t2)^2) / 2 whatever the circuit does."""
+    tf = wdf.tf
+    g = torch.Generator(device="cpu").manual_seed(77)
+    B, T = 8192, 4096
+    x = (torch.randn((B, T), generator=g) * 1.2).cuda()
+    tgt = (0.3 * torch.randn((T, B), generator=g)).cuda()
+    circ, params = hpf(wdf, 1, 1)
+    circ.to_device()
+    opts = [tf.keras.optimizers.Adam(learning_rate=1.0e-3 * float(p)) for p in params]
+    for call in range(3):
+        theta = [float(p) for p in params]
+        with tf.GradientTape() as tape:
+            loss = circ.mse(x, tgt)
+        grads = tape.gradient(loss, params)
+        g1 = np.array([float(v) for v in grads])
+        ref, pr = hpf(wdf, 1, 1, theta=np.array(theta))
+        with tf.GradientTape() as tape:
+            y0 = ref(x)
+            l0 = tf.reduce_mean(tf.square(y0 - tgt))
+        g0 = np.array([float(v) for v in tape.gradient(l0, pr)])
+        e_y = float((circ.last_output - y0.as_subclass(torch.Tensor).detach()).abs().max())
+        ctl = circ._tree.read_ctl(next(iter(circ._tree.cache.values())))
+        print(f"call {call}: |y - two-pass| {e_y:.2e}, loss {float(loss):.7e} / {float(l0):.7e}, gradients {rel(g1, g0):.2e}, "
+              f"warm-up {ctl['w_used']}, miss {ctl['max_miss']:.1e}, repaired {ctl['gated_groups']}")
+        assert e_y < 4e-6 and abs(float(loss) - float(l0)) < 2e-6 * float(l0) and rel(g1, g0) < 3e-4
+        assert ctl["gated_groups"] == 0
+        for o, gr, p in zip(opts, grads, params):
+            o.apply_gradients([(gr, p)])
+    t2 = (0.3 * torch.randn((T, B), generator=g)).cuda()
+    la, lb, lm = float(circ.mse(x, tgt)), float(circ.mse(x, t2)), float(circ.mse(x, ((tgt + t2) * 0.5).contiguous()))
+    want = float(((tgt - t2) ** 2).mean()) * 0.5
+    print(f"L(t) - 2 L(mid) + L(t2) = {la - 2.0 * lm + lb:.7e}, mean((t - t2)^2) / 2 = {want:.7e}")
+    assert abs((la - 2.0 * lm + lb) - want) < 2e-5 * want
