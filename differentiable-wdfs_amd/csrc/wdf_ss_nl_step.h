@@ -331,11 +331,21 @@ __device__ __forceinline__ void nl_chunk(const NlStepArgs& a, const SSCoef<NS, N
 #pragma unroll
                 for (int s = 0; s < NS; ++s) lin_st<V>(sp + (size_t)(D::sPsi + j * NS + s) * B, u.P[j][s]);
         }
+        if (n == kLinBlk) {
+            // a whole block, straight-line: the tangent arithmetic of one step fills the transcendental latencies of the
+            // next step's diode pair (a padding lane repeats the last sequence: its stores write the same values again)
 #pragma unroll
-        for (int i = 0; i < kLinBlk; ++i) {
-            if (i >= n) break;
-            const V yv = nl_step<NS, NI, SYM, V, true, FAST>(c, dp, xc[i], tc[i], gs, lv, u, G, H, sse);
-            if (live) lin_st_nt<V>(a.y + (ts + i) * B + b, yv);
+            for (int i = 0; i < kLinBlk; ++i) {
+                const V yv = nl_step<NS, NI, SYM, V, true, FAST>(c, dp, xc[i], tc[i], gs, lv, u, G, H, sse);
+                lin_st_nt<V>(a.y + (ts + i) * B + b, yv);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kLinBlk; ++i) {
+                if (i >= n) break;
+                const V yv = nl_step<NS, NI, SYM, V, true, FAST>(c, dp, xc[i], tc[i], gs, lv, u, G, H, sse);
+                if (live) lin_st_nt<V>(a.y + (ts + i) * B + b, yv);
+            }
         }
         if (++since == 4) {                                       // fp32 sums within 32 steps, fp64 across
             since = 0;
