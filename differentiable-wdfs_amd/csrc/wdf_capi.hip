@@ -10,7 +10,7 @@ using namespace wdfcapi;
 
 namespace wdfcapi {
 thread_local char g_err[512] = "";
-std::atomic<hipEvent_t> g_ev0{nullptr}, g_ev1{nullptr};
+std::atomic<EventPair*> g_bracket{nullptr};
 }
 
 extern "C" {
@@ -135,8 +135,7 @@ int wdf_event_elapsed_ms(void* start, void* stop, float* ms)
 
 void wdf_event_bracket_next(void* start, void* stop)
 {
-    g_ev0.store((hipEvent_t)start);
-    g_ev1.store((hipEvent_t)stop);
+    delete g_bracket.exchange(new EventPair{(hipEvent_t)start, (hipEvent_t)stop});   // (re-arming drops a pair nobody consumed)
 }
 
 // out[0] = the shader clock counter (s_memtime), out[1] = the constant-rate counter (s_memrealtime, 100 MHz), read by a

@@ -37,18 +37,22 @@ inline int check_launch(const char* what)
 // reduce helpers that share its C call), so a harness can time exactly the kernel rocprofv3
 // reports.  One-shot, process-wide: the call that consumes it may come from another thread
 // than the one that armed it (torch's autograd engine runs a backward on its own thread).
-extern std::atomic<hipEvent_t> g_ev0, g_ev1;
+struct EventPair { hipEvent_t e0, e1; };
+extern std::atomic<EventPair*> g_bracket;          // armed pair or null: ONE word, so a start never goes without its stop
 
 struct EventBracket {
     hipStream_t s;
-    hipEvent_t e1;
-    explicit EventBracket(hipStream_t stream) : s(stream), e1(g_ev1.exchange(nullptr))
+    EventPair* p;
+    explicit EventBracket(hipStream_t stream) : s(stream), p(g_bracket.exchange(nullptr))
     {
-        if (hipEvent_t e0 = g_ev0.exchange(nullptr)) (void)hipEventRecord(e0, s);
+        if (p && p->e0) (void)hipEventRecord(p->e0, s);
     }
     ~EventBracket()
     {
-        if (e1) (void)hipEventRecord(e1, s);
+        if (p) {
+            if (p->e1) (void)hipEventRecord(p->e1, s);
+            delete p;
+        }
     }
 };
 

@@ -42,7 +42,7 @@ NlLayout nl_layout(int ns, int ni, int64_t B, int64_t T, int n_chunks)
     l.snap = up(l.rec + (size_t)l.K * nl_nrec(ns, ni) * (size_t)B * sizeof(float), 256);
     l.gpart = up(l.snap + (size_t)2 * l.K * nl_nsnap(ns, ni) * (size_t)B * sizeof(float), 256);
     l.part = up(l.gpart + (size_t)l.K * l.groups_max * ng1 * sizeof(double), 256);
-    l.total = up(l.part + (size_t)l.groups_max * ng1 * sizeof(double), 256);
+    l.total = up(l.part + (size_t)l.groups_max * (ng1 + 2) * sizeof(double), 256);   // (+ bad boundaries, largest miss)
     return l;
 }
 

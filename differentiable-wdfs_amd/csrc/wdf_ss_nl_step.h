@@ -415,8 +415,23 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, q = wv % kNlTile, hq = wv / kNlTile;
     const int64_t grp = blockIdx.x, B = a.B;
     const int K = a.K;
-    const float tol = a.ctl->tol;
-    const int w_snap = a.ctl->w_snap, par = a.ctl->parity;
+    const NlStepCtl c0 = *a.ctl;                                  // (only the launch's last wave writes it, after everyone has read)
+    const float tol = c0.tol;
+    const int w_snap = c0.w_snap, par = c0.parity;
+    // what the launch's LAST wave needs for the chain rule, fetched now by everybody's wave 0 (a round trip to memory the tail
+    // does not wait for): the probe's Jacobian column of lane p, the root's values, the coefficients
+    struct { double jac[C::kN + 1]; float coef[C::kN]; double Is, V, Rp; } pre;
+    if (wv == 0) {
+#pragma unroll
+        for (int i = 0; i <= C::kN; ++i) pre.jac[i] = lane < a.n_tree ? a.jac[(size_t)i * a.n_tree + lane] : 0.0;
+#pragma unroll
+        for (int i = 0; i < C::kN; ++i) pre.coef[i] = a.coef[i];
+        pre.Is = *a.pIs; pre.V = *a.pV; pre.Rp = *a.pRp;
+    }
+    double gpre[D::nG + 1];                                       // the chunks' own sums of this group (lane k: chunk k)
+#pragma unroll
+    for (int i = 0; i <= D::nG; ++i)
+        gpre[i] = (wv == 0 && lane < a.K) ? a.gpart[((size_t)lane * a.groups + grp) * (D::nG + 1) + i] : 0.0;
     __shared__ float recs[WD][kNlTile][D::nRec][64];
     __shared__ double red[kWaves][D::nG + 1];
     __shared__ int rbad[kWaves];
@@ -566,8 +581,8 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
         // the chunks' own sums of this group (lanes over chunks), then one value per accumulator in every lane
 #pragma unroll
         for (int i = 0; i <= D::nG; ++i) {
-            double s = 0.0;
-            for (int k = lane; k < K; k += 64) s += a.gpart[((size_t)k * a.groups + grp) * (D::nG + 1) + i];
+            double s = gpre[i];
+            for (int k = lane + 64; k < K; k += 64) s += a.gpart[((size_t)k * a.groups + grp) * (D::nG + 1) + i];
             tot[i] += wave_sum_dpp(s);
         }
     } else {
@@ -629,16 +644,14 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
 #pragma unroll
         for (int i = 0; i <= D::nG; ++i) tot[i] = wave_sum_dpp(tot[i]);
     }
-    // ---- this group's partial; the last wave adds them up in a fixed order
+    // ---- this group's partial {sums.., bad boundaries, largest miss}; the last wave adds them up in a fixed order
+    constexpr int kPart = D::nG + 3;
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i <= D::nG; ++i)
-            __hip_atomic_store(a.part + (size_t)grp * (D::nG + 1) + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (wbad) {
-            atomicAdd(&a.ctl->acc_bad, wbad);
-            atomicAdd(&a.ctl->acc_gated, 1);
-        }
-        atomicMax(&a.ctl->acc_miss, __float_as_int(wmiss));
+            __hip_atomic_store(a.part + (size_t)grp * kPart + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.part + (size_t)grp * kPart + D::nG + 1, (double)wbad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.part + (size_t)grp * kPart + D::nG + 2, (double)wmiss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned old = 0;
@@ -646,22 +659,32 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
     old = __builtin_amdgcn_readfirstlane(old);
     if (old != (unsigned)(a.groups - 1)) return;
     if (lane == 0) *a.ticket = 0u;
-    double sum[D::nG + 1];
+    double sum[D::nG + 1], nbd = 0.0, ggd = 0.0;
+    float mm = 0.0f;
 #pragma unroll
-    for (int i = 0; i <= D::nG; ++i) {
-        double s = 0.0;
-        for (int64_t w = lane; w < a.groups; w += 64)
-            s += __hip_atomic_load(a.part + (size_t)w * (D::nG + 1) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sum[i] = wave_sum_dpp(s);
+    for (int i = 0; i <= D::nG; ++i) sum[i] = 0.0;
+    for (int64_t w = lane; w < a.groups; w += 64) {
+        double v[kPart];
+#pragma unroll
+        for (int i = 0; i < kPart; ++i) v[i] = __hip_atomic_load(a.part + (size_t)w * kPart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i <= D::nG; ++i) sum[i] += v[i];
+        nbd += v[D::nG + 1];
+        ggd += v[D::nG + 1] > 0.0 ? 1.0 : 0.0;
+        mm = fmaxf(mm, (float)v[D::nG + 2]);
     }
+#pragma unroll
+    for (int i = 0; i <= D::nG; ++i) sum[i] = wave_sum_dpp(sum[i]);
+    const int nb = (int)wave_sum_dpp(nbd), gg = (int)wave_sum_dpp(ggd);
+    mm = wave_max_dpp(mm);
     // the root's own values (ss_grad_reduce_kernel's formulas): L = log(Rp Is / V)
-    const double Is = *a.pIs, Vv = *a.pV, Rp = *a.pRp;
+    const double Is = pre.Is, Vv = pre.V, Rp = pre.Rp;
     const double sL = sum[C::kN], sV = sum[C::kN + 1];
     const double gRp = sL / Rp;
     if (lane < a.n_tree) {
-        double gp = gRp * a.jac[(size_t)C::kN * a.n_tree + lane];
+        double gp = gRp * pre.jac[C::kN];
 #pragma unroll
-        for (int i = 0; i < C::kN; ++i) gp += sum[i] * a.jac[(size_t)i * a.n_tree + lane];
+        for (int i = 0; i < C::kN; ++i) gp += sum[i] * pre.jac[i];
         a.out[1 + lane] = (float)gp;
     }
     if (lane == 0) {
@@ -671,37 +694,34 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
         a.out[2 + a.n_tree] = (float)(sV - sL / Vv);
         // what the snapshots of this call were taken with
 #pragma unroll
-        for (int i = 0; i < C::kN; ++i) a.coef_prev[i] = a.coef[i];
+        for (int i = 0; i < C::kN; ++i) a.coef_prev[i] = pre.coef[i];
         a.coef_prev[C::kN] = logf((float)Rp * (float)Is / (float)Vv);
         a.coef_prev[C::kN + 1] = (float)Vv;
         // the warm-up of the call after the next (the next one's is where this call's snapshots lie)
         NlStepCtl* ctl = a.ctl;
-        const int nb = atomicExch(&ctl->acc_bad, 0);
-        const float mm = __int_as_float(atomicExch(&ctl->acc_miss, 0));
-        const int gg = atomicExch(&ctl->acc_gated, 0);
         ctl->n_bad = nb;
         ctl->max_miss = mm;
         ctl->gated_groups = gg;
-        const int w_used = ctl->w_cur, ws = ctl->w_snap;
-        int w = ws, cool = ctl->cool;
-        if (ctl->have_snap) {                                    // (a cold call says nothing about the predicted starts)
+        const int w_used = c0.w_cur, ws = c0.w_snap;
+        int w = ws, cool = c0.cool;
+        if (c0.have_snap) {                                      // (a cold call says nothing about the predicted starts)
             const int base = w_used > ws ? w_used : ws;
-            if (nb) { w = base * 2; cool = ctl->cool_miss; }
-            else if (mm > ctl->grow_at * tol) { w = base + 16; if (cool < 2) cool = 2; }
+            if (nb) { w = base * 2; cool = c0.cool_miss; }
+            else if (mm > c0.grow_at * tol) { w = base + 16; if (cool < 2) cool = 2; }
             else if (cool > 0) --cool;
-            else if (mm <= ctl->shrink_at * tol && w_used <= ws) w = ws - 16;
+            else if (mm <= c0.shrink_at * tol && w_used <= ws) w = ws - 16;
         }
-        const int wmax = ctl->w_max < (int)a.L ? ctl->w_max : (int)a.L;
+        const int wmax = c0.w_max < (int)a.L ? c0.w_max : (int)a.L;
         if (w > wmax) w = wmax;
-        if (w < ctl->w_min) w = ctl->w_min;
+        if (w < c0.w_min) w = c0.w_min;
         ctl->w_used = w_used;
         ctl->w_cur = ws;
         ctl->w_snap = w;
         ctl->cool = cool;
         ctl->have_snap = (ws <= a.L) ? 1 : 0;
         ctl->parity = par ^ 1;
-        ctl->call += 1;
-        ctl->total_gated += gg;
+        ctl->call = c0.call + 1;
+        ctl->total_gated = c0.total_gated + gg;
     }
 }
 
