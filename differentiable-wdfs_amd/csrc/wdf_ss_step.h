@@ -44,6 +44,20 @@ static __global__ __launch_bounds__(64) void ss_probe_kernel(const int32_t* __re
                                                              int n_out, float* __restrict__ coef, double* __restrict__ coef64,
                                                              double* __restrict__ jac, const AdamJobs jobs, int n_jobs)
 {
+    __shared__ double val[kProbeMaxOps][kProbeLanes], tan[kProbeMaxOps][kProbeLanes];
+    __shared__ int ops[kProbeMaxOps * 3];
+    __shared__ double leaf[kProbeMaxOps];                         // the value of every CONST / PARAM node
+    // everything that does not depend on the parameters is asked for FIRST (one round trip to memory together with the
+    // optimizers' operands): the tape (six words per lane in registers; longer tapes: the rest goes the plain way), the
+    // first 64 output nodes
+    constexpr int kPre = 6;
+    int pre_ops[kPre];
+#pragma unroll
+    for (int r = 0; r < kPre; ++r) {
+        const int i = threadIdx.x + 64 * r;
+        pre_ops[r] = i < 3 * n_ops ? tape[i] : 0;
+    }
+    const int my_out = (int)threadIdx.x < n_out ? outs[threadIdx.x] : 0;
     if (n_jobs > 0) {                                            // eight lanes per job, all jobs side by side
         const int jb = threadIdx.x >> 3, li = threadIdx.x & 7;
         const bool mine = jb < n_jobs;
@@ -66,15 +80,14 @@ static __global__ __launch_bounds__(64) void ss_probe_kernel(const int32_t* __re
         }
         __syncthreads();                                          // (every lane has read its job's step count)
         if (mine && li == 0) *q.step = t;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the new values are out before anyone asks for them)
     }
-    if (n_jobs > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kPre; ++r) {
+        const int i = threadIdx.x + 64 * r;
+        if (i < 3 * n_ops) ops[i] = pre_ops[r];
     }
-    __shared__ double val[kProbeMaxOps][kProbeLanes], tan[kProbeMaxOps][kProbeLanes];
-    __shared__ int ops[kProbeMaxOps * 3];
-    __shared__ double leaf[kProbeMaxOps];                         // the value of every CONST / PARAM node
-    for (int i = threadIdx.x; i < 3 * n_ops; i += 64) ops[i] = tape[i];
+    for (int i = threadIdx.x + 64 * kPre; i < 3 * n_ops; i += 64) ops[i] = tape[i];
     __syncthreads();
     for (int i = threadIdx.x; i < n_ops; i += 64) {               // (all leaves fetched at once: no dependent global loads below)
         const int op = ops[3 * i], a = ops[3 * i + 1];
@@ -82,29 +95,32 @@ static __global__ __launch_bounds__(64) void ss_probe_kernel(const int32_t* __re
     }
     __syncthreads();
     const int p = threadIdx.x;
-    if (p >= kProbeLanes) return;
-    int nop = ops[0], na = ops[1], nb = ops[2];
-    for (int i = 0; i < n_ops; ++i) {
-        const int op = nop, a = na, b = nb;
-        if (i + 1 < n_ops) { nop = ops[3 * i + 3]; na = ops[3 * i + 4]; nb = ops[3 * i + 5]; }   // (the next instruction is fetched under this one)
-        double v = 0.0, t = 0.0;
-        switch (op) {
-        case kOpConst: v = leaf[i]; break;
-        case kOpParam: v = leaf[i]; t = (a == p) ? 1.0 : 0.0; break;
-        case kOpAdd: v = val[a][p] + val[b][p]; t = tan[a][p] + tan[b][p]; break;
-        case kOpSub: v = val[a][p] - val[b][p]; t = tan[a][p] - tan[b][p]; break;
-        case kOpMul: v = val[a][p] * val[b][p]; t = tan[a][p] * val[b][p] + val[a][p] * tan[b][p]; break;
-        case kOpDiv: { const double q = val[a][p] / val[b][p]; v = q; t = (tan[a][p] - q * tan[b][p]) / val[b][p]; break; }
-        case kOpNeg: v = -val[a][p]; t = -tan[a][p]; break;
-        case kOpRecip: { const double r = 1.0 / val[a][p]; v = r; t = -r * r * tan[a][p]; break; }
+    if (p < kProbeLanes) {
+        int nop = ops[0], na = ops[1], nb = ops[2];
+        for (int i = 0; i < n_ops; ++i) {
+            const int op = nop, a = na, b = nb;
+            if (i + 1 < n_ops) { nop = ops[3 * i + 3]; na = ops[3 * i + 4]; nb = ops[3 * i + 5]; }   // (the next instruction is fetched under this one)
+            double v = 0.0, t = 0.0;
+            switch (op) {
+            case kOpConst: v = leaf[i]; break;
+            case kOpParam: v = leaf[i]; t = (a == p) ? 1.0 : 0.0; break;
+            case kOpAdd: v = val[a][p] + val[b][p]; t = tan[a][p] + tan[b][p]; break;
+            case kOpSub: v = val[a][p] - val[b][p]; t = tan[a][p] - tan[b][p]; break;
+            case kOpMul: v = val[a][p] * val[b][p]; t = tan[a][p] * val[b][p] + val[a][p] * tan[b][p]; break;
+            case kOpDiv: { const double q = val[a][p] / val[b][p]; v = q; t = (tan[a][p] - q * tan[b][p]) / val[b][p]; break; }
+            case kOpNeg: v = -val[a][p]; t = -tan[a][p]; break;
+            case kOpRecip: { const double r = 1.0 / val[a][p]; v = r; t = -r * r * tan[a][p]; break; }
+            }
+            val[i][p] = v;
+            tan[i][p] = t;
         }
-        val[i][p] = v;
-        tan[i][p] = t;
     }
-    for (int o = 0; o < n_out; ++o) {
-        const int nd = outs[o];
-        if (p == 0) { coef[o] = (float)val[nd][0]; coef64[o] = val[nd][0]; }
-        if (p < n_params) jac[o * n_params + p] = tan[nd][p];
+    __syncthreads();
+    for (int o = threadIdx.x; o < n_out; o += 64) {               // lane o: output o and its row of the Jacobian
+        const int nd = o < 64 ? my_out : outs[o];
+        coef[o] = (float)val[nd][0];
+        coef64[o] = val[nd][0];
+        for (int q = 0; q < n_params; ++q) jac[o * n_params + q] = tan[nd][q];
     }
 }
 
