@@ -1010,6 +1010,8 @@ def main():
                               "detail": r_}), flush=True)
         return
     if args.config in ("lpf", "hpf"):
+        if world != 1:
+            raise SystemExit("--config lpf / hpf are one-GPU lines (the element API's resident loops do not shard)")
         return run_tree_step(args, rank, local, args.config)
     if args.root != "diode":
         return (run_mlp_root if args.mlp_path == "unfused" else run_mlp_step)(args, world, rank, local)
