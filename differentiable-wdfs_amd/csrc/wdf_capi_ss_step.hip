@@ -97,7 +97,7 @@ int wdf_ss_nl_step_chunk_len(int64_t T, int n_chunks)
 }
 
 // cold_warmup: the warm-up of the first call (chunks start from z = 0); warm_warmup: where that call takes the snapshots the
-// second one starts from; afterwards the device steers it inside [w_min, min(w_max, chunk length)].  All multiples of 16.
+// second one starts from; afterwards the device steers it inside [w_min, min(w_max, chunk length)].  All multiples of 8.
 int wdf_ss_nl_step_plan(void* ws, int ns, int ni, int64_t B, int64_t T, int n_chunks, int cold_warmup, int warm_warmup, int w_min,
                         int w_max, float tol, void* stream)
 {
@@ -105,9 +105,9 @@ int wdf_ss_nl_step_plan(void* ws, int ns, int ni, int64_t B, int64_t T, int n_ch
     if (!nl_ok(ns, ni)) return fail(WDF_EUNSUPPORTED, "wdf_ss_nl_step_plan: ns in 1..2, ni in 1..2 (got %d, %d)", ns, ni);
     if (B <= 0 || T <= 0 || n_chunks < 1) return fail(WDF_EINVAL, "B, T, n_chunks >= 1");
     const NlLayout l = nl_layout(ns, ni, B, T, n_chunks);
-    if (cold_warmup < 0 || cold_warmup % 16 || warm_warmup < 16 || warm_warmup % 16 || w_min < 16 || w_min % 16 || w_max < w_min ||
-        w_max % 16 || warm_warmup > l.L || !(tol > 0.0f))
-        return fail(WDF_EINVAL, "wdf_ss_nl_step_plan: warm-ups are multiples of 16, 16 <= w_min <= w_max, warm_warmup <= the chunk length %lld, tol > 0",
+    if (cold_warmup < 0 || cold_warmup % 8 || warm_warmup < 8 || warm_warmup % 8 || w_min < 8 || w_min % 8 || w_max < w_min ||
+        w_max % 8 || warm_warmup > l.L || !(tol > 0.0f))
+        return fail(WDF_EINVAL, "wdf_ss_nl_step_plan: warm-ups are multiples of 8, 8 <= w_min <= w_max, warm_warmup <= the chunk length %lld, tol > 0",
                     (long long)l.L);
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(ws, 0, l.rec, s) != hipSuccess) return fail(WDF_ELAUNCH, "wdf_ss_nl_step_plan: memset failed");

@@ -709,7 +709,7 @@ __global__ __launch_bounds__((64 * WD * NlTile<NS, WD>::n)) void ss_nl_step_fini
             if (nb) { w = base * 2; cool = c0.cool_miss; }
             else if (mm > c0.grow_at * tol) { w = base + 16; if (cool < 2) cool = 2; }
             else if (cool > 0) --cool;
-            else if (mm <= c0.shrink_at * tol && w_used <= ws) w = ws - 16;
+            else if (mm <= c0.shrink_at * tol && w_used <= ws) w = ws - 8;
         }
         const int wmax = c0.w_max < (int)a.L ? c0.w_max : (int)a.L;
         if (w > wmax) w = wmax;

@@ -156,6 +156,7 @@ class _StateSpaceFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------ resident linear trees
 _LIN_OCC = int(os.environ.get("WDF_LIN_OCC", "2"))       # chunks are cut so that every SIMD gets this many waves
 _NL_OCC = int(os.environ.get("WDF_NL_OCC", "1"))
+_NL_WMIN = int(os.environ.get("WDF_NL_WMIN", "16"))      # the shortest warm-up the device's controller may settle on
 NL_TOL = 1.0e-6                                          # boundary tolerance of the diode-root one-pass step (plan_ss_time_parallel's)
 
 
@@ -274,7 +275,7 @@ class _LinResident:
         Lc = L_.wdf_ss_nl_step_chunk_len(T, k)
         cold = min(4096, max(self.cold_warmup(), int(cold_floor) // 16 * 16))
         warm = max(16, min(Lc // 16 * 16, 64))
-        binding._check(L_.wdf_ss_nl_step_plan(binding._ptr(ws), circ.ns, circ.ni, B, T, k, cold, warm, 16,
+        binding._check(L_.wdf_ss_nl_step_plan(binding._ptr(ws), circ.ns, circ.ni, B, T, k, cold, warm, _NL_WMIN,
                                               max(16, Lc // 16 * 16), float(NL_TOL), binding._stream()), "wdf_ss_nl_step_plan")
         return ws
 

@@ -334,7 +334,7 @@ int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, in
  * state at that sample moved along its tangents by the change of the coefficients, every boundary is verified on the
  * device (tol) and a group of sequences that missed is re-run sequentially by its finishing wave; w is steered on the
  * device.  Two launches.  ns 1..2, ni 1..2, zero initial state, x TIME-major [T][ni][B].
- *   wdf_ss_nl_step_plan   zeroes the control part of ws and sets the warm-ups (multiples of 16): cold_warmup for the
+ *   wdf_ss_nl_step_plan   zeroes the control part of ws and sets the warm-ups (multiples of 8): cold_warmup for the
  *                         first call (from z = 0), warm_warmup where it takes the snapshots for the second; afterwards
  *                         the device moves it inside [w_min, min(w_max, chunk length)].
  *   wdf_ss_nl_step_mse    coef: wdf_ss_probe's float32 outputs (coefficients, then the port resistance the root sees);
