@@ -364,6 +364,16 @@ __global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict
     double acc[U::kG + 1];
 #pragma unroll
     for (int i = 0; i <= U::kG; ++i) acc[i] = 0.0;
+    // 8-step blocks, the next one's loads in flight under this one's arithmetic (a wave that loads, waits, computes keeps
+    // half as many bytes on their way)
+    V xn[kLinBlk][NI], tn[kLinBlk];
+    auto load_blk = [&](int64_t ts) {
+        const int n = t1 - ts < kLinBlk ? (int)(t1 - ts) : kLinBlk;
+        lin_load_x<NI, V>(x, B, b, ts, n, xn);
+#pragma unroll
+        for (int i = 0; i < kLinBlk; ++i) tn[i] = (i < n) ? lin_ld<V>(target + (ts + i) * B + b) : zero;
+    };
+    load_blk(t0);
     for (int64_t tb = t0; tb < t1; tb += 4 * kLinBlk) {           // fp32 sums within 32 steps, fp64 across
         V f[U::kG + 1];
 #pragma unroll
@@ -372,9 +382,13 @@ __global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict
         for (int64_t ts = tb; ts < tb + 4 * kLinBlk && ts < t1; ts += kLinBlk) {
             const int n = t1 - ts < kLinBlk ? (int)(t1 - ts) : kLinBlk;
             V xs[kLinBlk][NI], tg[kLinBlk];
-            lin_load_x<NI, V>(x, B, b, ts, n, xs);
 #pragma unroll
-            for (int i = 0; i < kLinBlk; ++i) tg[i] = (i < n) ? lin_ld<V>(target + (ts + i) * B + b) : zero;
+            for (int i = 0; i < kLinBlk; ++i) {
+                tg[i] = tn[i];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) xs[i][j] = xn[i][j];
+            }
+            if (ts + kLinBlk < t1) load_blk(ts + kLinBlk);
 #pragma unroll
             for (int i = 0; i < kLinBlk; ++i) {
                 if (i >= n) break;
