@@ -339,6 +339,19 @@ __device__ __forceinline__ void lin_walk_to(const SSCoef<NS, NI>& c, const float
 // before it (their zero-state ends: pass 1) -- no separate walk launch.
 // part: double [waves][kG + 1] = {gA.., gBx.., gcy.., gdy.., SSE}; ticket: one word, left 0.
 // jac: double [ncoef (+1)][n_params] of ss_probe_kernel (rows in SSCoef order).  out: float [1 + n_params] = {SSE, dLoss/dparam}.
+#ifndef WDF_LIN_BLK
+#define WDF_LIN_BLK 8
+#endif
+constexpr int kLinBlk2 = WDF_LIN_BLK;                            // pass 2's block (steps whose loads are issued together)
+template <int NI, typename V>
+__device__ __forceinline__ void lin_load_x2(const float* __restrict__ x, int64_t B, int64_t b, int64_t t, int n, V (&xs)[kLinBlk2][NI])
+{
+#pragma unroll
+    for (int k = 0; k < kLinBlk2; ++k)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xs[k][i] = (k < n) ? lin_ld<V>(x + ((t + k) * NI + i) * B + b) : vsplat<V>(0.0f);
+}
+
 template <int NS, int NI, typename V>
 __global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                          const float* __restrict__ uend0, const float* __restrict__ target,
@@ -366,31 +379,31 @@ __global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict
     for (int i = 0; i <= U::kG; ++i) acc[i] = 0.0;
     // 8-step blocks, the next one's loads in flight under this one's arithmetic (a wave that loads, waits, computes keeps
     // half as many bytes on their way)
-    V xn[kLinBlk][NI], tn[kLinBlk];
+    V xn[kLinBlk2][NI], tn[kLinBlk2];
     auto load_blk = [&](int64_t ts) {
-        const int n = t1 - ts < kLinBlk ? (int)(t1 - ts) : kLinBlk;
-        lin_load_x<NI, V>(x, B, b, ts, n, xn);
+        const int n = t1 - ts < kLinBlk2 ? (int)(t1 - ts) : kLinBlk2;
+        lin_load_x2<NI, V>(x, B, b, ts, n, xn);
 #pragma unroll
-        for (int i = 0; i < kLinBlk; ++i) tn[i] = (i < n) ? lin_ld<V>(target + (ts + i) * B + b) : zero;
+        for (int i = 0; i < kLinBlk2; ++i) tn[i] = (i < n) ? lin_ld<V>(target + (ts + i) * B + b) : zero;
     };
     load_blk(t0);
-    for (int64_t tb = t0; tb < t1; tb += 4 * kLinBlk) {           // fp32 sums within 32 steps, fp64 across
+    for (int64_t tb = t0; tb < t1; tb += 32) {                     // fp32 sums within 32 steps, fp64 across
         V f[U::kG + 1];
 #pragma unroll
         for (int i = 0; i <= U::kG; ++i) f[i] = zero;
 #pragma unroll 1
-        for (int64_t ts = tb; ts < tb + 4 * kLinBlk && ts < t1; ts += kLinBlk) {
-            const int n = t1 - ts < kLinBlk ? (int)(t1 - ts) : kLinBlk;
-            V xs[kLinBlk][NI], tg[kLinBlk];
+        for (int64_t ts = tb; ts < tb + 32 && ts < t1; ts += kLinBlk2) {
+            const int n = t1 - ts < kLinBlk2 ? (int)(t1 - ts) : kLinBlk2;
+            V xs[kLinBlk2][NI], tg[kLinBlk2];
 #pragma unroll
-            for (int i = 0; i < kLinBlk; ++i) {
+            for (int i = 0; i < kLinBlk2; ++i) {
                 tg[i] = tn[i];
 #pragma unroll
                 for (int j = 0; j < NI; ++j) xs[i][j] = xn[i][j];
             }
-            if (ts + kLinBlk < t1) load_blk(ts + kLinBlk);
+            if (ts + kLinBlk2 < t1) load_blk(ts + kLinBlk2);
 #pragma unroll
-            for (int i = 0; i < kLinBlk; ++i) {
+            for (int i = 0; i < kLinBlk2; ++i) {
                 if (i >= n) break;
                 V yv = zero;
 #pragma unroll
