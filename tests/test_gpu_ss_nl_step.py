@@ -311,3 +311,37 @@ def test_full_size_step_against_the_two_pass_path(wdf):
     want = float(((tgt - t2) ** 2).mean()) * 0.5
     print(f"L(t) - 2 L(mid) + L(t2) = {la - 2.0 * lm + lb:.7e}, mean((t - t2)^2) / 2 = {want:.7e}")
     assert abs((la - 2.0 * lm + lb) - want) < 2e-5 * want
+
+
+def test_one_state_two_sources_diode_tree_against_the_host_probe_path(wdf):
+    """ns = 1, ni = 2 with a diode-pair root (two resistive sources): nine tangents, x as [B, T, 2]."""
+    tf = wdf.tf
+    rng = np.random.default_rng(16)
+    B, T = 192, 2048
+    x = (rng.standard_normal((B, T, 2)) * 1.2).astype(np.float32)
+    tgt = (0.3 * rng.standard_normal((T, B))).astype(np.float32)
+
+    def build():
+        Va = wdf.ResistiveVoltageSource(1.0e3, trainable=True)
+        Vb = wdf.ResistiveVoltageSource(4.7e3, trainable=True)
+        Ca = wdf.Capacitor(2.2e-8, FS, True)
+        top = wdf.Parallel(wdf.Series(Va, Ca), Vb)
+        dp = wdf.DiodePair(top, 2.52e-9, Vt=25.85e-3, nDiodes=1.752, trainable=True)
+        return wdf.Circuit(top, dp, Ca), [Va.R, Vb.R, Ca.C, dp.Is, dp.nVt]
+
+    ref, pr = build()
+    assert (ref.ns, ref.ni) == (1, 2)
+    with tf.GradientTape() as tape:
+        y = ref(cuda(x))
+        l0 = tf.reduce_mean(tf.square(y - cuda(tgt)))
+    g0 = np.array([float(v) for v in tape.gradient(l0, pr)])
+    circ, p = build()
+    circ.to_device()
+    xd, td = cuda(x), cuda(tgt)
+    for call in range(3):
+        l1, g1, y1 = one_call(wdf, circ, p, xd, td)
+        ctl = circ._tree.read_ctl(next(iter(circ._tree.cache.values())))
+        e_y = float(np.max(np.abs(y1 - y.as_subclass(torch.Tensor).detach().cpu().numpy())))
+        print(f"call {call}: loss {float(l0):.6e} / {l1:.6e}; |y - host path| {e_y:.2e}; gradients {rel(g1, g0):.2e}; w {ctl['w_used']}")
+        assert e_y < 4e-6 and abs(l1 - float(l0)) < 1e-5 * float(l0) and rel(g1, g0) < 5e-4
+        assert ctl["gated_groups"] == 0
