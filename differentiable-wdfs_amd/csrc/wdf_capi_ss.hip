@@ -94,20 +94,30 @@ int wdf_ss_fwd_lin_tp(const float* x, const float* coef, int ns, int ni, float* 
     if (!y || !ws) return fail(WDF_EINVAL, "null y/ws");
     if (ns < 1) return fail(WDF_EINVAL, "a tree without states has nothing to scan: use wdf_ss_fwd");
     if (n_chunks < 1) return fail(WDF_EINVAL, "n_chunks >= 1");
-    const int64_t L = (T + n_chunks - 1) / n_chunks;
+    int64_t L = (T + n_chunks - 1) / n_chunks;
+    L = (L + wdf::kLinBurst - 1) / wdf::kLinBurst * wdf::kLinBurst;   // chunks in whole bursts of the row loads
     const int K = (int)((T + L - 1) / L);
     float* zend0 = (float*)ws;
     float* zstart = zend0 + (size_t)K * (size_t)ns * (size_t)B;
     const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K), one((unsigned)((B + 63) / 64));
     hipStream_t s = (hipStream_t)stream;
+    const bool v4 = ((T * ni) % 4 == 0) && aligned16(x);
+    if (K > 1 && hipMemsetAsync(zend0 + (size_t)(K - 1) * (size_t)ns * (size_t)B, 0, (size_t)ns * (size_t)B * sizeof(float), s) != hipSuccess)
+        return fail(WDF_ELAUNCH, "wdf_ss_fwd_lin_tp: memset failed");     // (the last chunk's zero-state end is never used nor written)
+#define WDF_LIN_V(NS_, NI_, V4_)                                                                                 \
+    {                                                                                                            \
+        if (K > 1) hipLaunchKernelGGL((wdf::ss_lin_zero_state_kernel<NS_, NI_, V4_>), grid, dim3(64), 0, s, x, coef, zend0, B, T, L);  \
+        hipLaunchKernelGGL((wdf::ss_lin_starts_kernel<NS_>), one, dim3(64), 0, s, coef, zend0, z0, zstart, B, (int64_t)K, L); \
+        EventBracket bracket(s);                                                                                 \
+        hipLaunchKernelGGL((wdf::ss_lin_chunk_kernel<NS_, NI_, V4_>), grid, dim3(64), 0, s, x, coef, zstart, y, zstash, zT, B, T, L); \
+    }
 #define WDF_LIN(NS_, NI_)                                                                                        \
     if (ns == NS_ && ni == NI_) {                                                                                \
-        hipLaunchKernelGGL((wdf::ss_lin_zero_state_kernel<NS_, NI_>), grid, dim3(64), 0, s, x, coef, zend0, B, T, L);  \
-        hipLaunchKernelGGL((wdf::ss_lin_starts_kernel<NS_>), one, dim3(64), 0, s, coef, zend0, z0, zstart, B, (int64_t)K, L); \
-        hipLaunchKernelGGL((wdf::ss_lin_chunk_kernel<NS_, NI_>), grid, dim3(64), 0, s, x, coef, zstart, y, zstash, zT, B, T, L); \
+        if (v4) WDF_LIN_V(NS_, NI_, true) else WDF_LIN_V(NS_, NI_, false)                                        \
     }
     WDF_LIN(1, 1) WDF_LIN(2, 1) WDF_LIN(3, 1) WDF_LIN(1, 2) WDF_LIN(2, 2) WDF_LIN(3, 2)
 #undef WDF_LIN
+#undef WDF_LIN_V
     return check_launch("wdf_ss_fwd_lin_tp");
 }
 

@@ -188,7 +188,34 @@ __global__ __launch_bounds__(64) void ss_fwd_kernel(const float* __restrict__ x,
 //                                (A^L by repeated squaring in double, once per lane);
 //   3. ss_lin_chunk_kernel       every chunk runs again from its exact start state and writes y and the stash.
 // Twice the arithmetic of the sequential kernel, K times the parallelism; same result up to fp32 rounding.
-template <int NS, int NI>
+// n steps x NI channels of lane b's row, N at a time (N = 32, one channel: a whole 128-byte line of the row per burst)
+template <int NI, bool VEC4, int N>
+__device__ __forceinline__ void ss_load_burst(const float* __restrict__ x, int64_t b, int64_t T, int64_t t0, float (&v)[N][NI])
+{
+    const float* p = x + (b * T + t0) * NI;
+    if constexpr (VEC4) {
+        const float4* q = reinterpret_cast<const float4*>(p);
+        float tmp[N * NI];
+#pragma unroll
+        for (int i = 0; i < N * NI / 4; ++i) {
+            const float4 f = q[i];
+            tmp[4 * i] = f.x; tmp[4 * i + 1] = f.y; tmp[4 * i + 2] = f.z; tmp[4 * i + 3] = f.w;
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int c = 0; c < NI; ++c) v[k][c] = tmp[k * NI + c];
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int c = 0; c < NI; ++c) v[k][c] = p[k * NI + c];
+    }
+}
+
+constexpr int kLinBurst = 32;        // steps per burst of the chunked linear forward (chunk starts are multiples of it)
+
+template <int NS, int NI, bool VEC4>
 __global__ __launch_bounds__(64) void ss_lin_zero_state_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                                float* __restrict__ zend0, int64_t B, int64_t T, int64_t L)
 {
@@ -196,17 +223,24 @@ __global__ __launch_bounds__(64) void ss_lin_zero_state_kernel(const float* __re
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;
     const int64_t k = blockIdx.y, t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+    if (t1 == T) return;                                      // (nothing comes after the last chunk)
     SSCoef<NS, NI> c;
     c.load(coef);
     const SSDiode dp = {};
     float z[NSa];
 #pragma unroll
     for (int s = 0; s < NSa; ++s) z[s] = 0.0f;
-    for (int64_t t = t0; t < t1; ++t) {
-        float xt[NI];
+    // (a chunk that is not the last is L steps, L a multiple of the burst) bursts of 32 steps, the next one in flight
+    float xc[kLinBurst][NI], xn[kLinBurst][NI];
+    ss_load_burst<NI, VEC4, kLinBurst>(x, b, T, t0, xn);
+    for (int64_t t = t0; t < t1; t += kLinBurst) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) xt[i] = x[(b * T + t) * NI + i];
-        (void)ss_fwd_step<NS, NI, kRootNone, true>(c, dp, xt, z);
+        for (int q = 0; q < kLinBurst; ++q)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) xc[q][i] = xn[q][i];
+        if (t + kLinBurst < t1) ss_load_burst<NI, VEC4, kLinBurst>(x, b, T, t + kLinBurst, xn);
+#pragma unroll
+        for (int q = 0; q < kLinBurst; ++q) (void)ss_fwd_step<NS, NI, kRootNone, true>(c, dp, xc[q], z);
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) zend0[(k * NS + s) * B + b] = z[s];
@@ -266,7 +300,7 @@ __global__ __launch_bounds__(64) void ss_lin_starts_kernel(const float* __restri
     }
 }
 
-template <int NS, int NI>
+template <int NS, int NI, bool VEC4>
 __global__ __launch_bounds__(64) void ss_lin_chunk_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                           const float* __restrict__ zstart, float* __restrict__ y,
                                                           float* __restrict__ zstash, float* __restrict__ zT, int64_t B,
@@ -283,7 +317,26 @@ __global__ __launch_bounds__(64) void ss_lin_chunk_kernel(const float* __restric
 #pragma unroll
     for (int s = 0; s < NSa; ++s) z[s] = (NS > 0) ? zstart[(k * NS + (s < NS ? s : 0)) * B + b] : 0.0f;
     const bool STASH = (zstash != nullptr) && NS > 0;
-    for (int64_t t = t0; t < t1; ++t) {
+    // bursts of 32 steps (t0 is a multiple of the burst), the next one in flight under this one's steps; then the tail
+    const int64_t tfull = t1 - (t1 - t0) % kLinBurst;
+    float xc[kLinBurst][NI], xn[kLinBurst][NI];
+    if (t0 < tfull) ss_load_burst<NI, VEC4, kLinBurst>(x, b, T, t0, xn);
+    for (int64_t t = t0; t < tfull; t += kLinBurst) {
+#pragma unroll
+        for (int q = 0; q < kLinBurst; ++q)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) xc[q][i] = xn[q][i];
+        if (t + kLinBurst < tfull) ss_load_burst<NI, VEC4, kLinBurst>(x, b, T, t + kLinBurst, xn);
+#pragma unroll
+        for (int q = 0; q < kLinBurst; ++q) {
+            if (STASH) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) zstash[((t + q) * NS + s) * B + b] = z[s];
+            }
+            y[(t + q) * B + b] = ss_fwd_step<NS, NI, kRootNone, true>(c, dp, xc[q], z);
+        }
+    }
+    for (int64_t t = tfull; t < t1; ++t) {
         float xt[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) xt[i] = x[(b * T + t) * NI + i];
