@@ -345,3 +345,22 @@ def test_one_state_two_sources_diode_tree_against_the_host_probe_path(wdf):
         print(f"call {call}: loss {float(l0):.6e} / {l1:.6e}; |y - host path| {e_y:.2e}; gradients {rel(g1, g0):.2e}; w {ctl['w_used']}")
         assert e_y < 4e-6 and abs(l1 - float(l0)) < 1e-5 * float(l0) and rel(g1, g0) < 5e-4
         assert ctl["gated_groups"] == 0
+
+
+def test_general_root_evaluation_against_the_oracle(wdf, oracle):
+    """A diode pair whose omega_1 argument leaves the series-only region (L - log N = -2.3: large Is, large port resistance):
+    the chunk kernel takes the general evaluation with its per-step ballot; two calls (cold, then from the snapshots)."""
+    rng = np.random.default_rng(31)
+    theta = np.array([1.0e5, 1.0e4, 2.2e-8, 1.0e-6, 0.045], dtype=np.float32).astype(np.float64)
+    B, T = 130, 1500
+    x = (rng.standard_normal((B, T)) * 1.2).astype(np.float32)
+    tgt = (0.3 * rng.standard_normal((T, B))).astype(np.float32)
+    circ, params = hpf(wdf, 2, 2, theta=theta)
+    circ.to_device()
+    rp = float(circ._tree.host_coef()[1])
+    assert np.log(rp * theta[3] / theta[4]) - np.log(2.0) > -4.0
+    yref, lref, gref = oracle_hpf(oracle, theta, x, tgt, 2, 2)
+    for call in range(2):
+        loss, g, y = one_call(wdf, circ, params, cuda(x), cuda(tgt))
+        print(f"call {call}: |y - oracle| {np.max(np.abs(y - yref)):.2e}, loss {abs(loss - lref) / lref:.1e}, gradients {rel(g, gref):.1e}")
+        assert np.max(np.abs(y - yref)) < 3e-6 and abs(loss - lref) < 2e-6 * lref and rel(g, gref) < 3e-4
