@@ -146,7 +146,10 @@ __device__ __forceinline__ V nl_step(const SSCoef<NS, NI>& c, const SSDiode& dp,
     const DiodeOutT<V> o = diode_pair<SYM, V, FAST>(a, vsplat<V>(dp.L), dp.d);
     const V b = o.b;
     // the root's partials (wdf_statespace.h, ss_bwd_tp_kernel's one_step): Da = db/da, DL = db/dL, DV = db/dV
-    const V w0p = o.w0 * vrcp(o.w0 + 1.0f), w1p = o.w1 * vrcp(o.w1 + 1.0f);
+    const V w0p = o.w0 * vrcp(o.w0 + 1.0f);
+    // omega_1 <= omega(-4) = 0.018 in the series-only region: omega / (1 + omega) by its alternating series to the cubic term
+    // (next term 1e-7 relative) instead of a second reciprocal (wdf_clipper_fused.h, fused_step)
+    const V w1p = (SYM && FAST) ? o.w1 * vfma(-o.w1, vfma(-o.w1, 1.0f - o.w1, 1.0f), 1.0f) : o.w1 * vrcp(o.w1 + 1.0f);
     const V sp = w0p + w1p;
     V Da, DL, DV;
     if constexpr (SYM && FAST) {
@@ -380,8 +383,11 @@ __device__ __forceinline__ void nl_chunk(const NlStepArgs& a, const SSCoef<NS, N
     }
 }
 
+#ifndef WDF_NL_WAVES
+#define WDF_NL_WAVES 1
+#endif
 template <int NS, int NI, bool SYM, typename V>
-__global__ __launch_bounds__(256) void ss_nl_step_kernel(const NlStepArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WDF_NL_WAVES, WDF_NL_WAVES))) void ss_nl_step_kernel(const NlStepArgs a)
 {
     SSCoef<NS, NI> c;
     c.load(a.coef);
