@@ -22,7 +22,8 @@
 // (exact), so results are within tol of the sequential recursion or ARE it.  The warm-up length is steered on the device from
 // the largest miss (NlStepCtl); the snapshots {z, S} for the next call are taken w_snap steps before each chunk's end.
 //
-// Launches per step: ss_nl_step_kernel, ss_nl_step_finish_kernel (+ the probe, wdf_ss_step.h).
+// Launches per step: ss_nl_step_kernel, ss_nl_step_finish_kernel (+ the probe, wdf_ss_step.h, which also carries the
+// optimizers' queued updates): three.
 #pragma once
 #include "wdf_ss_step.h"
 
@@ -34,7 +35,7 @@ struct NlStepCtl {                 // 128 bytes, device resident
     float tol, grow_at, shrink_at;            // grow when miss > grow_at tol; shrink when miss <= shrink_at tol
     int cool_miss;                            // calls without shrinking after a miss
     int n_bad; float max_miss; int gated_groups, total_gated;   // verdict of the last call; groups re-run since the plan
-    int acc_bad, acc_miss, acc_gated;         // the running call's verdict (the finishing waves add; its last wave moves it up)
+    int acc_bad, acc_miss, acc_gated;         // (unused: the groups' verdicts travel in their partial sums)
     int w_used;                               // the warm-up the last call ran with
     int pad[12];
 };
