@@ -896,6 +896,13 @@ def run_tree_step(args, rank, local, kind):
     n = B * T
     kname = "ss_lin_step_kernel" if kind == "lpf" else "ss_nl_step_kernel"
     kmean = float(np.mean(k_ms))
+    traffic = None                 # PMC bytes per launch of this kernel: a committed counter pass at the bench shape (tools/pmc_ss_step.sh)
+    try:
+        pm = json.load(open(os.path.join(REPO, "profiles", "r04_ss_step_pmc.json")))
+        if pm.get("samples") == n:
+            traffic = pm["kernels"][kname]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {"metric": f"samples/sec training step (forward + MSE + gradient + Adam per component), "
                      f"{'RC lowpass (lpf.py:20-49)' if kind == 'lpf' else 'HPF diode clipper (HPFDiodeClipper.h:28-32)'} @48kHz "
                      f"through Circuit.to_device() / circ.mse",
@@ -908,7 +915,8 @@ def run_tree_step(args, rank, local, kind):
            "parity": parity,
            "roofline": {"bound": "hbm" if kind == "lpf" else "valu", "kernel": kname,
                         "achieved": 12.0 * n / (kmean * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": 12.0 * n / (kmean * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": 12.0 * n / (kmean * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_source": None if traffic is None else "profiles/r04_ss_step_pmc.json (a committed counter pass of this shape)",
                         "note": "algorithmic bytes of this kernel: x, target read, y written = 12 B per sample" +
                                 ("" if kind == "lpf" else "; the kernel is VALU-issue-bound (171 instructions per step of two "
                                                           "sequences at one wave per SIMD), the HBM fraction is what it moves")}}
