@@ -533,10 +533,65 @@ def g8_dataimport():
     shutil.rmtree(tmp)
 
 
+def g9_mlp_relu():
+    """clipper_pot.py ClipperModel with a ReLU network (layers.py:63-67 accepts activation "relu"): the reference's pretrained
+    2x16 JSON with its hidden activations switched to "relu" (weights scaled by 0.5 so the unbounded units keep the loop tame),
+    same inputs / loss / gradient layout as g3.  Numeric arrays only."""
+    out = {}
+    B, T, skip = 4, 256, 50
+    C_val = 4.7e-9
+    x = clipper_inputs(B, T, 7)
+    R = np.array([10.0e3, 25.2e3, 45.2e3, 99.1e3])
+    data = np.stack([x, np.repeat(R[:, None], T, axis=1)], axis=-1)
+    target = np.tanh(1.5 * x)[:, :, None] * 0.4
+    out["x"], out["target"] = data, target
+    mj = json.load(open(os.path.join(REF, "wdf_py/diode_clipper/models", "pretrained/1N4148 (1U-1D)_2x16_pretrained_model.json")))
+    for l in mj["layers"]:
+        if l.get("activation") == "tanh":
+            l["activation"] = "relu"
+        if l.get("type") == "dense":
+            l["weights"] = [(0.5 * np.asarray(w)).tolist() for w in l["weights"]]
+    name = "2x16_relu"
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        tf._DTYPE = dt
+        wdf, layers = fresh_lib()
+        ns = {"tf": tf, "wdf": wdf, "np": np, "DenseRootModel": layers.DenseRootModel, "DenseLayer": layers.DenseLayer, "C_val": C_val, "FS": FS}
+        extract(os.path.join(REF, "wdf_py/diode_clipper/clipper_pot.py"), {"ClipperModel", "esr_loss", "eps", "mse_loss", "loss_func"}, ns)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ns["ClipperModel"](mj)
+        outs = tf.transpose(model.forward(data)[..., 0], perm=[1, 0, 2])
+        tgt = tf.constant(target)
+        loss = ns["loss_func"](outs[:, skip:, :], tgt[:, skip:, :])
+        tv = model.trainable_variables
+        grads = torch.autograd.grad(loss, tv)
+        out[f"{name}_y_{tag}"] = npy(outs)[:, :, 0].T
+        out[f"{name}_loss_{tag}"] = npy(loss)
+        dl = [l for l in model.model.layers if isinstance(l, layers.DenseLayer)]
+        order = []
+        for l in dl:
+            order += [l.kernel, l.bias]
+        idx = [next(i for i, v in enumerate(tv) if v is p) for p in order]
+        out[f"{name}_grad_{tag}"] = np.concatenate([npy(grads[i]).ravel() for i in idx])
+        if tag == "f64":
+            out[f"{name}_theta"] = np.concatenate([npy(p).ravel() for p in order])
+            out[f"{name}_sizes"] = np.array([2] + [l.bias.shape[-1] for l in dl])
+            acts = []
+            for i, l in enumerate(model.model.layers):
+                if isinstance(l, layers.DenseLayer):
+                    nxt = model.model.layers[i + 1] if i + 1 < len(model.model.layers) else None
+                    acts.append(1 if nxt is tf.nn.tanh else (2 if nxt is tf.nn.relu else 0))
+            out[f"{name}_acts"] = np.array(acts)
+    print("g9", name, out[f"{name}_loss_f32"], out[f"{name}_loss_f64"], out[f"{name}_sizes"], out[f"{name}_acts"],
+          "max |y|", float(np.max(np.abs(out[f"{name}_y_f64"]))))
+    out["C"], out["skip"] = C_val, skip
+    np.savez(os.path.join(HERE, "g9_mlp_relu.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     fns = {"g1": g1_rc_lowpass, "g2": g2_voltage_divider, "g3": g3_mlp_clipper,
            "g4": g4_diode_pair, "g5": g5_omega, "g6": g6_diode_clipper, "g7": g7_recorded_programs,
-           "g8": g8_dataimport}
+           "g8": g8_dataimport, "g9": g9_mlp_relu}
     for w in which:
         fns[w]()

@@ -337,3 +337,33 @@ def test_clipper_pot_loop_through_the_element_api_on_the_resident_step():
     print(f"loss {l0[0]:.5e} -> {l0[-1]:.5e} (plain) / {l1[-1]:.5e} (resident); |w - w'| {float((w0 - w1).abs().max()):.2e} of {moved:.2e}")
     assert all(abs(a - b) <= 5e-3 * a for a, b in zip(l0, l1))
     assert float((w0 - w1).abs().max()) <= 0.05 * moved
+
+
+def test_step_with_relu_network_against_the_reference_golden(golden):
+    """g9: the reference's own ClipperModel (clipper_pot.py:94-127) run on a ReLU network (layers.py:63-67; the pretrained
+    2x16 JSON with its activations switched and its weights halved), loss_func and tape.gradient of clipper_pot.py:246-249 --
+    outputs, loss and the gradient of every weight from the resident step."""
+    from wdf_hip import mlp_root
+    g = golden("g9_mlp_relu.npz")
+    name = "2x16_relu"
+    x, r = g["x"][:, :, 0], g["x"][:, :, 1]
+    target = cuda(g["target"][:, :, 0].T)                                   # [T,B]
+    sizes = [int(v) for v in g[f"{name}_sizes"]]
+    assert [int(a) for a in g[f"{name}_acts"]] == [2] * (len(sizes) - 2) + [0]
+    hidden, n_layers, skip = sizes[1], len(sizes) - 2, int(g["skip"])
+    w = cuda(g[f"{name}_theta"])
+    st = mlp_root.MlpTrainStep(cuda(x), cuda(r), target, w, hidden, n_layers, FS, float(g["C"]), skip=skip, adam=None,
+                               activation="relu", n_items=4, wgrad_chunks=4)
+    for call in range(2):                                                   # cold, then from the snapshots
+        st.step()
+    torch.cuda.synchronize()
+    y, gw, loss = st.y.cpu().numpy(), st.gw.cpu().numpy().astype(np.float64), float(st.loss3[2])
+    y64, g64, l64 = g[f"{name}_y_f64"], g[f"{name}_grad_f64"], float(g[f"{name}_loss_f64"])
+    e_y = float(np.max(np.abs(y - y64)))
+    e_g = float(np.max(np.abs(gw - g64)) / np.max(np.abs(g64)))
+    print(f"relu golden: |y - reference| {e_y:.2e} (the reference's own f32 run: {np.max(np.abs(g[f'{name}_y_f32'] - y64)):.2e}), "
+          f"loss {loss:.7f} / {l64:.7f}, gradient {e_g:.2e} (reference f32: "
+          f"{np.max(np.abs(g[f'{name}_grad_f32'] - g64)) / np.max(np.abs(g64)):.2e})")
+    assert e_y <= 1e-5 and abs(loss - l64) <= 1e-5 * l64
+    # (a relu kink crossed by fp32 rounding moves a sample's gradient: looser than tanh)
+    assert np.all(np.abs(gw - g64) <= 2e-3 * np.abs(g64) + 2e-4 * np.max(np.abs(g64))), e_g

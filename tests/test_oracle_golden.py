@@ -173,6 +173,34 @@ def test_mlp_clipper_forward_loss_grads(oracle, golden, name):
     assert np.max(np.abs(gr - ref)) < 1e-9 * max(1.0, np.max(np.abs(ref)))
 
 
+def test_mlp_clipper_relu_network(oracle, golden):
+    """g9: the reference's ClipperModel on a ReLU network (layers.py:63-67): the oracle's ACT_RELU against it -- outputs, the
+    MSE + ESR loss and a spread of weight gradients (complex step does not see a kink: every unit keeps its side in fp64)."""
+    g = golden("g9_mlp_relu.npz")
+    name = "2x16_relu"
+    sizes, acts = [int(s) for s in g[f"{name}_sizes"]], [int(a) for a in g[f"{name}_acts"]]
+    assert acts[:-1] == [oracle.ACT_RELU] * (len(acts) - 1)
+    circ = oracle.clipper_mlp_circuit(48000.0, sizes, acts)
+    theta = np.concatenate([[45.0e3, float(g["C"])], g[f"{name}_theta"]])
+    x = g["x"]
+    y = oracle.tree_fwd(circ, theta, x)
+    assert np.max(np.abs(y - g[f"{name}_y_f64"])) < 1e-12
+    skip = int(g["skip"])
+    outs, tgt = y.T[:, skip:, None], g["target"][:, skip:, :]
+    mse, esr = oracle.mse_loss(outs, tgt), oracle.esr_loss(outs, tgt)
+    assert abs(mse + esr - float(g[f"{name}_loss_f64"])) < 1e-13
+    n, d = outs.size, outs - tgt
+    S, E = np.sum(d * d), np.sum(outs * outs) + np.finfo(float).eps
+    g_outs = 2.0 * d / n + (1.0 / (2.0 * esr)) * (2.0 * d / E - S * 2.0 * outs / (E * E)) / n
+    gy = np.zeros_like(y)
+    gy[skip:, :] = g_outs[:, :, 0].T
+    ks = list(range(2, 2 + g[f"{name}_theta"].size))
+    ks = ks[:: max(1, len(ks) // 40)]
+    gr = oracle.tree_grad(circ, theta, x, gy, params=ks)
+    ref = g[f"{name}_grad_f64"][[k - 2 for k in ks]]
+    assert np.max(np.abs(gr - ref)) < 1e-9 * max(1.0, np.max(np.abs(ref)))
+
+
 # ---- g6: diode-pair clipper ------------------------------------------------------------
 @pytest.mark.parametrize("cfg,n_up,n_down", [("1u1d", 1, 1), ("2u3d", 2, 3)])
 def test_diode_clipper_forward_vs_reference_pieces(oracle, golden, cfg, n_up, n_down):
