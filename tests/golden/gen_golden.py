@@ -31,6 +31,8 @@ Goldens:
                         reference scripts has to travel to the GPU box.
   g8_dataimport.npz     the reference's dataimport.createDataset / load_diode_data and clipper_pot's
                         batch_data run on CSV files written by this repo's synthetic-dataset writer
+  g9_mlp_relu.npz       clipper_pot.py ClipperModel on a ReLU network (layers.py:63-67): the pretrained 2x16 JSON
+                        with its activations switched to "relu" and its weights halved; same arrays as g3
   g6_diode_clipper.npz  tf_wdf.py Parallel(ResVs, C) tree + diode-pair root:
                         (a) forward from reference pieces only (tf_wdf elements + diode_pair_func)
                         (b) f64 forward + autograd grads wrt Is, nVt, R, C with a torch
