@@ -367,3 +367,37 @@ def test_step_with_relu_network_against_the_reference_golden(golden):
     assert e_y <= 1e-5 and abs(loss - l64) <= 1e-5 * l64
     # (a relu kink crossed by fp32 rounding moves a sample's gradient: looser than tanh)
     assert np.all(np.abs(gw - g64) <= 2e-3 * np.abs(g64) + 2e-4 * np.max(np.abs(g64))), e_g
+
+
+def test_relu_network_through_the_element_api_against_the_reference_golden(golden):
+    """The drop-in surface on a ReLU DenseRootModel (layers.py:63-67): Circuit.to_device() + circ.mse_esr + tape.gradient over
+    model.trainable_variables -- loss and every weight's gradient against g9 (the reference's ClipperModel executed)."""
+    import tf_wdf as wdf
+    from layers import DenseRootModel
+    tf = wdf.tf
+    g = golden("g9_mlp_relu.npz")
+    name = "2x16_relu"
+    sizes = [int(v) for v in g[f"{name}_sizes"]]
+    wh, o, layers_json = g[f"{name}_theta"].astype(np.float32), 0, []
+    for i in range(len(sizes) - 1):
+        ni, no = sizes[i], sizes[i + 1]
+        k = wh[o:o + ni * no].reshape(ni, no); o += ni * no          # noqa: E702
+        b = wh[o:o + no]; o += no                                    # noqa: E702
+        layers_json.append({"type": "dense", "activation": "relu" if i < len(sizes) - 2 else "", "shape": [None, no],
+                            "weights": [k.tolist(), b.tolist()]})
+    Vs, C = wdf.ResistiveVoltageSource(45.0e3), wdf.Capacitor(float(g["C"]), FS)
+    model = DenseRootModel({"in_shape": [None, 2], "layers": layers_json})
+    circ = wdf.Circuit(wdf.Parallel(Vs, C), model, C, per_sample_R=Vs).to_device()
+    tv = model.trainable_variables
+    with tf.GradientTape() as tape:
+        loss = circ.mse_esr(cuda(g["x"]), cuda(g["target"][:, :, 0].T), int(g["skip"]))
+    grads = tape.gradient(loss, tv)
+    # golden order: kernel, bias per layer (trainable_variables lists bias first)
+    dl = [l for l in model.layers if hasattr(l, "kernel")]
+    got = np.concatenate([np.concatenate([next(gr for gr, v in zip(grads, tv) if v is l.kernel).detach().cpu().numpy().ravel(),
+                                          next(gr for gr, v in zip(grads, tv) if v is l.bias).detach().cpu().numpy().ravel()]) for l in dl])
+    g64, l64 = g[f"{name}_grad_f64"], float(g[f"{name}_loss_f64"])
+    print(f"element API, relu: loss {float(loss):.7f} / {l64:.7f}, gradient {np.max(np.abs(got - g64)) / np.max(np.abs(g64)):.2e}")
+    assert abs(float(loss) - l64) <= 1e-5 * l64
+    assert np.all(np.abs(got - g64) <= 2e-3 * np.abs(g64) + 2e-4 * np.max(np.abs(g64)))
+    assert float(np.max(np.abs(circ.last_output.detach().cpu().numpy() - g[f"{name}_y_f64"]))) <= 1e-5
