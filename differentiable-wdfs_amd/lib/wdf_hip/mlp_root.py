@@ -352,7 +352,9 @@ def run_clipper_mlp(circ, x, z0, return_state):
         raise binding.WdfHipError("the MLP root is supported on the diode-clipper topology "
                                   "Parallel(ResistiveVoltageSource, Capacitor) (clipper_pot.py:94-101)")
     model, vs, cap = circ.root, circ.top.P1, circ.top.P2
-    dense, hidden, n_tanh = describe(model)
+    dense, hidden, n_tanh, act = describe(model, with_activation=True)
+    if act == "relu":
+        return _run_clipper_relu(circ, x, z0, return_state, dense, hidden, n_tanh)
     dev = x.device
     Rv = vs.R if isinstance(vs.R, torch.Tensor) else torch.tensor(float(vs.R))
     theta2 = torch.stack([Rv.as_subclass(torch.Tensor).float().reshape(()),
@@ -364,6 +366,28 @@ def run_clipper_mlp(circ, x, z0, return_state):
                         time_parallel=getattr(circ, "time_parallel", None))
     y = y.as_subclass(tf.Tensor)
     return (y, zT.reshape(1, -1)) if return_state else y
+
+
+def _run_clipper_relu(circ, x, z0, return_state, dense, hidden, n_layers):
+    """Circuit.__call__ on a ReLU network (layers.py:63-67): the forward phase of the resident step's kernels (the row /
+    matrix-core kernels of the plain path are tanh-only).  Outputs only: the gradient of a ReLU network comes from
+    Circuit.mse_esr (to_device), the loss those kernels differentiate."""
+    if z0 is not None or return_state or int(x.shape[1]) % 16:
+        raise binding.WdfHipError("a ReLU DenseRootModel runs on the resident step's kernels: zero initial state, no returned state, "
+                                  "T a multiple of 16")
+    if torch.is_grad_enabled() and any(d.kernel.requires_grad or d.bias.requires_grad for d in dense):
+        raise binding.WdfHipError("a ReLU DenseRootModel is differentiated by Circuit.to_device() + Circuit.mse_esr(); call the "
+                                  "circuit under tf.stop_gradient / torch.no_grad for its outputs alone")
+    vs, cap = circ.top.P1, circ.top.P2
+    dev = x.device
+    xv, r = engine.split_channels(x, circ.per_sample_R is not None, anchor=getattr(circ, "_anchor", None))
+    with torch.no_grad():
+        w = flat_weights(dense).float().to(dev).contiguous()
+        Rv = float(vs.R) if not isinstance(vs.R, torch.Tensor) or vs.R.numel() == 1 else 45.0e3
+        st = MlpTrainStep(xv, r, torch.zeros((int(x.shape[1]), int(x.shape[0])), dtype=torch.float32, device=dev), w, hidden, n_layers,
+                          float(cap.FS), float(cap.C), R_static=Rv, skip=0, adam=None, activation="relu")
+        st.forward_only()
+    return st.y.as_subclass(tf.Tensor)
 
 
 # ------------------------------------------------------------------------------ the resident training step

@@ -401,3 +401,29 @@ def test_relu_network_through_the_element_api_against_the_reference_golden(golde
     assert abs(float(loss) - l64) <= 1e-5 * l64
     assert np.all(np.abs(got - g64) <= 2e-3 * np.abs(g64) + 2e-4 * np.max(np.abs(g64)))
     assert float(np.max(np.abs(circ.last_output.detach().cpu().numpy() - g[f"{name}_y_f64"]))) <= 1e-5
+
+
+def test_relu_network_forward_call_against_the_reference_golden(golden):
+    """circ(x) on a ReLU DenseRootModel with host-resident weights: the forward phase of the resident step's kernels; and the
+    gradient is refused there with a pointer to mse_esr (the plain path's kernels are tanh-only)."""
+    import tf_wdf as wdf
+    from layers import DenseRootModel
+    from wdf_hip import binding as wb
+    g = golden("g9_mlp_relu.npz")
+    name = "2x16_relu"
+    sizes = [int(v) for v in g[f"{name}_sizes"]]
+    wh, o, layers_json = g[f"{name}_theta"].astype(np.float32), 0, []
+    for i in range(len(sizes) - 1):
+        ni, no = sizes[i], sizes[i + 1]
+        k = wh[o:o + ni * no].reshape(ni, no); o += ni * no          # noqa: E702
+        b = wh[o:o + no]; o += no                                    # noqa: E702
+        layers_json.append({"type": "dense", "activation": "relu" if i < len(sizes) - 2 else "", "shape": [None, no],
+                            "weights": [k.tolist(), b.tolist()]})
+    Vs, C = wdf.ResistiveVoltageSource(45.0e3), wdf.Capacitor(float(g["C"]), FS)
+    circ = wdf.Circuit(wdf.Parallel(Vs, C), DenseRootModel({"in_shape": [None, 2], "layers": layers_json}), C, per_sample_R=Vs)
+    with torch.no_grad():
+        y = circ(cuda(g["x"]))
+    assert tuple(y.shape) == g[f"{name}_y_f64"].shape
+    assert float(np.max(np.abs(y.cpu().numpy() - g[f"{name}_y_f64"]))) <= 1e-5
+    with pytest.raises(wb.WdfHipError):
+        circ(cuda(g["x"]))
