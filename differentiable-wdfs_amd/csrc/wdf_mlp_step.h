@@ -392,6 +392,10 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int unit = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);   // item (MODE 0, 1) or column (MODE 2) of this wave
     if (unit >= (MODE == 2 ? A.n_cols : A.n_items)) return;
+    // the two repair launches leave at once unless their item / column is flagged (the common case): ONE load decides, before
+    // anything else is asked for (the control block, the item and its column are two more dependent round trips)
+    if constexpr (MODE == 1) { if (A.flag[unit] == 0u) return; }
+    if constexpr (MODE == 2) { if (A.colseq[unit] == 0u) return; }
     MlpStepCtl* ctl = A.ctl;
     const int par = ctl->parity;                                   // this call reads set `par`, writes the other
     const int64_t nblk = A.T >> 4;
