@@ -258,9 +258,12 @@ int wdf_clipper_mlp_step(const float* x, const float* p, const float* lr, const 
     const double* gsums = (phase & WDF_MLP_STEP_GLOBAL_SUMS) ? sums : nullptr;
     const bool dyn = p != nullptr;
     hipStream_t s = (hipStream_t)stream;
-    // steps staged per block of loads in the reverse sweep (registers against occupancy): 8 -> 3 waves per SIMD.
-    // WDF_MLP_STEP_BS = 4 / 16: A/B timing.
-    static const int wgrad_bs = [] { const char* e = getenv("WDF_MLP_STEP_BS"); return e ? atoi(e) : 8; }();
+    // steps staged per block of loads in the reverse sweep (registers against occupancy: 8 -> 3 waves per SIMD, 16 -> 2).
+    // Measured at 1340 x 2048 (same box, alternating): three hidden layers (2x16): 4: 0.2006 ms, 8: 0.1694-0.1707, 16: 0.1649-0.1654
+    // -> 16; five hidden layers (4x8): 8: 0.33, 16: 0.39 (its registers no longer fit two waves) -> 8.
+    // WDF_MLP_STEP_BS = 4 / 8 / 16: A/B timing.
+    static const int wgrad_env = [] { const char* e = getenv("WDF_MLP_STEP_BS"); return e ? atoi(e) : 0; }();
+    const int wgrad_bs = wgrad_env ? wgrad_env : (n_layers <= 3 ? 16 : 8);
     WDF_STEP_FWD(3) WDF_STEP_FWD(4) WDF_STEP_FWD(5)
     rc = check_launch("wdf_clipper_mlp_step");
     if (rc) return rc;
