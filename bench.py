@@ -61,17 +61,45 @@ def measured_valu_cycles(kernel, cfg):
     return _committed_pass(SQ_GLOB, kernel, cfg, lambda k: 4.0 * k["SQ_ACTIVE_INST_VALU"])
 
 
+def library_identity():
+    """What the committed counter passes are matched on: the first 16 hex digits of the sha256 of the library this process
+    loaded, and of the sources the diode-clipper translation unit is compiled from (so a pass stays valid when only ANOTHER
+    kernel family's translation unit changed)."""
+    import hashlib
+    out = {"path": os.path.relpath(binding.LIB_PATH, REPO), "sha16": None, "clipper_src_sha16": None}
+    try:
+        out["sha16"] = hashlib.sha256(open(binding.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        pass
+    csrc = os.path.join(REPO, "differentiable-wdfs_amd", "csrc")
+    h = hashlib.sha256()
+    try:
+        for name in ("Makefile", "wdf_capi_clipper.hip", "wdf_capi_common.h", "wdf_clipper.h", "wdf_clipper_fused.h", "wdf_omega.h",
+                     "wdf_omega64.h", "wdf_asym.h", "wdf_vec.h", "wdf_optim.h", "wdf_elementwise.h"):
+            h.update(open(os.path.join(csrc, name), "rb").read())
+        h.update(open(os.path.join(REPO, "include", "wdf_hip.h"), "rb").read())
+        out["clipper_src_sha16"] = h.hexdigest()[:16]
+    except OSError:
+        pass
+    return out
+
+
 def _committed_pass(pattern, kernel, cfg, value):
-    """The newest committed counter file whose configuration is the one being run: batch, layout, loss and the kernel's own
-    chunk count must match; among those the one whose warm-up (the device controller moves it by a few 16-step units from
-    run to run: < 3 % of the kernel's work) is closest."""
+    """The newest committed counter file taken ON THIS LIBRARY (the file's stamp -- library sha or the clipper translation
+    unit's source sha -- must equal this run's: a pass of another build is refused) whose configuration is the one being
+    run: batch, layout, loss and the kernel's own chunk count must match; among those the one whose warm-up (the device
+    controller moves it by a few 16-step units from run to run: < 3 % of the kernel's work) is closest."""
     import glob
+    ident = library_identity()
     best = None
     for path in sorted(glob.glob(pattern), reverse=True):
         try:
             d = json.load(open(path))
             c = d.get("config")
-            if not c or kernel not in d["kernels"]:
+            lib = d.get("library") or {}
+            same_build = (lib.get("sha16") is not None and lib.get("sha16") == ident["sha16"]) or \
+                         (lib.get("clipper_src_sha16") is not None and lib.get("clipper_src_sha16") == ident["clipper_src_sha16"])
+            if not c or not same_build or kernel not in d["kernels"]:
                 continue
             if all(c.get(k, "mse" if k == "loss" else None) == v for k, v in cfg.items() if k != "fwd_warmup_steps"):
                 dist = abs((c.get("fwd_warmup_steps") or 0) - (cfg.get("fwd_warmup_steps") or 0))
@@ -352,6 +380,7 @@ class Trainer:
         # its full sample of kernel durations from a pass of bracketed steps AFTER the closing synchronize.
         every = max(1, min(4, steps)) if steps <= 64 else max(4, -(-steps // 1024))
         evs = [[binding.Event() for _ in range(n_ev)] if (i % every == 0 and graph is None) else None for i in range(steps)]
+        self.n_in_region = sum(1 for e in evs if e is not None)     # (the first n_in_region entries of t_fwd are the timed region's own)
         wdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -364,8 +393,10 @@ class Trainer:
         torch.cuda.synchronize()
         wdist.barrier()
         dt = time.perf_counter() - t0
+        self.dt_local = dt
         if graph is not None:                                  # kernel durations: the warm-up steps' (their last ones: past the cold call)
             evs = [e for e in warm_evs if e is not None][-8:] + evs
+            self.n_in_region = 0
         elif steps <= 64:                                      # (untimed: the same loop continued, every step bracketed)
             post = [[binding.Event() for _ in range(n_ev)] for _ in range(steps)]
             keep = [t.clone() for t in ([self.theta] + ([self.adam.m, self.adam.v, self.adam.step] if self.adam is not None else []))]
@@ -374,7 +405,6 @@ class Trainer:
             torch.cuda.synchronize()
             for t, k in zip([self.theta] + ([self.adam.m, self.adam.v, self.adam.step] if self.adam is not None else []), keep):
                 t.copy_(k)                                     # (the report's loss / theta are those of the timed steps)
-            self.n_in_region = sum(1 for e in evs if e is not None)
             evs = evs + post
         for e in evs:
             if e is not None:
@@ -482,7 +512,7 @@ def run_mlp_step(args, world, rank, local):
     r_host = workload.dataset_resistance_batch(Bg, T, b0=b0, b1=b1)
     x, r = torch.as_tensor(x_host, device=dev), torch.as_tensor(r_host, device=dev)
     net = args.root[3:] + "_pre" if args.root == "mlp2x16" else args.root[3:]
-    wh, hidden, n_layers = workload.reference_mlp_weights(net)
+    wh, hidden, n_layers = workload.reference_mlp_weights(net, path=args.mlp_weights)
     w = torch.tensor(wh, device=dev)
     th4 = torch.tensor(workload.clipper_theta(), dtype=torch.float32, device=dev)
     target, _, _ = binding.clipper_fwd(x, th4, fs, r=r, want_stash=False)        # "measurement": the analytic diode pair
@@ -531,6 +561,7 @@ def run_mlp_step(args, world, rank, local):
             st.step()
     torch.cuda.synchronize(); wdist.barrier()
     dt = time.perf_counter() - t0
+    ranks = ranks_report(world, dev, dt, args.steps)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -580,6 +611,7 @@ def run_mlp_step(args, world, rank, local):
                                             "verdict_last_call": {k: info1[k] for k in ("n_bad", "max_miss", "flagged_columns", "sequential_columns")},
                                             "in_timed_region": {"boundaries_repaired": info1["total_flagged"] - info0["total_flagged"],
                                                                 "columns_sequential": info1["total_sequential"] - info0["total_sequential"]}}},
+               "ranks_seen": ranks["ranks_seen"], "ranks": ranks, "library": library_identity(),
                "step_launch": "one HIP-graph replay per step" if graph is not None else "eager launches",
                "kernel_ms": None if fk_ms is None else {"forward_chunks": spread(t_fk), "reverse_sweep": spread(t_wk)},
                "parity": parity,
@@ -926,6 +958,63 @@ def run_tree_step(args, rank, local, kind):
     print(json.dumps(out), flush=True)
 
 
+def self_launch(n, argv, rehearse):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here -- torch.distributed.run, one process per
+    GPU, rendezvous on 127.0.0.1 at a free port -- and hand their exit status back.  (Under a launcher WORLD_SIZE is set
+    and this is skipped: the driver's `python -m torch.distributed.run ... bench.py --gpus N` form is untouched.)"""
+    import socket
+    import subprocess
+    if not rehearse and torch.cuda.is_available() and torch.cuda.device_count() < n:
+        print(f"bench: --gpus {n} but this node shows {torch.cuda.device_count()} GPU(s) (--rehearse-on-one-gpu runs the {n}-rank "
+              f"code path on one)", file=sys.stderr, flush=True)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # (dmabuf IPC: what RCCL needs on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n)))
+    env["WDF_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def ranks_report(world, dev, dt_local, steps):
+    """What the line says about the ranks that really took part: `ranks_seen` = an all-reduce of ones on the step's own
+    process group (the collective's answer, not the environment's), the backend string, the distinct devices, and every
+    rank's own time per step (the line's ms_per_step is their max)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"ranks_seen": 1, "collective_backend": None, "devices_seen": 1,
+                "ms_per_step_per_rank": {"min": dt_local / steps * 1e3, "max": dt_local / steps * 1e3}}
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([dt_local / steps * 1e3], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    props = torch.cuda.get_device_properties(dev)
+    ident = f"{os.uname().nodename}:{getattr(props, 'uuid', None) or getattr(props, 'pci_bus_id', dev.index)}:{dev.index}"
+    idents = [None] * dist.get_world_size()
+    dist.all_gather_object(idents, ident)
+    backend = dist.get_backend()
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+    per = [float(t) for t in every]
+    return {"ranks_seen": int(round(float(ones))), "world_size": dist.get_world_size(),
+            "collective_backend": backend + (f" (RCCL {ver}: torch.distributed's nccl backend on ROCm)" if backend == "nccl" else
+                                             " (rehearsal: every rank on cuda:0)" if backend == "gloo" else ""),
+            "devices_seen": len(set(idents)),
+            "ms_per_step_per_rank": {"min": min(per), "max": max(per), "all": per},
+            "launcher": "bench.py started the ranks itself (torch.distributed.run)" if os.environ.get("WDF_BENCH_SELF_LAUNCHED")
+                        else "started under an external launcher (WORLD_SIZE in the environment)"}
+
+
 def spread(ts):
     ts = sorted(ts)
     return {"min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1], "n": len(ts)}
@@ -942,6 +1031,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch sequences on every rank (default).  strong: ONE batch of --batch sequences "
                          "split over the ranks (SURVEY 8e: global B = 8192 fixed)")
+    ap.add_argument("--no-companion", action="store_true",
+                    help="N > 1: skip the second measurement on the other scaling curve (strong next to a weak headline and vice versa)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the after-the-run check of y and the gradient against the oracle")
     ap.add_argument("--no-batch-major", action="store_true", help="skip the second measurement with x as [B,T]")
@@ -981,6 +1072,9 @@ def main():
     ap.add_argument("--root", default="diode", choices=["diode", "mlp2x16", "mlp2x8", "mlp4x8"],
                     help="diode: the metric's analytic diode-pair root (default).  mlp*: a secondary line -- the pot clipper "
                          "with the reference's DenseRootModel root at the training-set shape 1340 x 2048 (--batch to change)")
+    ap.add_argument("--mlp-weights", default=None, metavar="PATH",
+                    help="--root mlp*: the network's weights from this file (a model JSON in the reference's schema, or an .npz with "
+                         "<net>_theta / <net>_sizes) instead of the package's copy of the reference's committed networks")
     ap.add_argument("--mlp-path", default="step", choices=["step", "unfused"],
                     help="--root mlp*: step = the resident training step (five launches, default); unfused = the round-3 pipeline")
     ap.add_argument("--x-batch-major", action="store_true",
@@ -992,14 +1086,16 @@ def main():
     args.steps = 200 if args.steps is None else args.steps
     args.warmup = 20 if args.warmup is None else args.warmup
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the ranks ourselves (one process per GPU) and pass their line and status through
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], args.rehearse_on_one_gpu))
     if args.rehearse_on_one_gpu:
         os.environ["LOCAL_RANK"] = "0"
         world, rank, local = wdist.init(backend="gloo")
     else:
         world, rank, local = wdist.init(backend="nccl" if args.force_dist else None, force=args.force_dist)
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.force_dist and world != 1:
         raise SystemExit("--force-dist is for world size 1")
     binding.require_gpu()
@@ -1043,6 +1139,31 @@ def main():
     main_run = Trainer(args, x, target, fs, B, T, n_global, world, dev, tm)
     dt, loss, grad = main_run.run(args.warmup, args.steps, dev)
 
+    ranks = ranks_report(world, dev, main_run.dt_local, args.steps)
+    if ranks["ranks_seen"] != world:
+        raise SystemExit(f"the collective saw {ranks['ranks_seen']} ranks, WORLD_SIZE is {world}")
+
+    # the OTHER scaling curve from the same invocation: the headline is per-GPU work fixed at --batch sequences ("weak", the
+    # contract's default); SURVEY 8e's strong curve -- ONE batch of --batch sequences split over the ranks -- is timed right
+    # behind it with the same K / W (at N = 1 the two are the same run)
+    companion = None
+    if world > 1 and not args.no_companion and args.loss == "mse":
+        other_kind = "strong" if args.scaling == "weak" else "weak"
+        Bg2 = args.batch if other_kind == "strong" else args.batch * world
+        c0, c1 = wdist.shard_range(Bg2, rank, world)
+        if c1 - c0 >= 1:
+            x2_host = workload.sweep_batch(Bg2, T, b0=c0, b1=c1)
+            x2 = torch.as_tensor(x2_host, device=dev)
+            t2, _, _ = binding.clipper_fwd(x2, theta_star, fs, want_stash=False)
+            run2 = Trainer(args, x2, t2, fs, c1 - c0, T, float(Bg2 * T), world, dev, tm)
+            dt2, _, _ = run2.run(args.warmup, args.steps, dev)
+            r2 = ranks_report(world, dev, run2.dt_local, args.steps)
+            companion = {"scaling": other_kind, "value": Bg2 * T / (dt2 / args.steps), "unit": "samples/s",
+                         "ms_per_step": dt2 / args.steps * 1e3, "global_batch": Bg2, "sequences_per_rank": c1 - c0,
+                         "chunks": None if run2.tp is None else run2.tp.k_fwd,
+                         "ms_per_step_per_rank": r2["ms_per_step_per_rank"], "steps": args.steps, "warmup": args.warmup}
+            del run2, x2, t2
+
     # (per-launch durations: HIP events recorded inside the timed loop, Trainer.run)
     tp, stepper = main_run.tp, main_run.stepper
     tp_stat = binding.tp_status(stepper.status) if tp is not None and tp.k_fwd > 1 else None
@@ -1085,8 +1206,12 @@ def main():
         value = Bg * T / (dt / args.steps)
         t_fwd, t_bwd = main_run.t_fwd, main_run.t_bwd
         fused = main_run.fused
-        f_ms = float(np.mean(t_fwd))
-        b_ms = float(np.mean(t_bwd)) if t_bwd else None
+        # the kernel's duration the roofline is priced with: the mean over the samples taken INSIDE the timed region (HIP
+        # events on the launch stream); the untimed continuation's samples are reported beside them, never mixed in
+        n_in = main_run.n_in_region if getattr(main_run, "n_in_region", 0) else len(t_fwd)
+        f_in, b_in = t_fwd[:n_in], t_bwd[:n_in]
+        f_ms = float(np.mean(f_in))
+        b_ms = float(np.mean(b_in)) if t_bwd else None
         warm = None if stepper.warm is None else stepper.warm.info()
         # a kernel's traffic depends on the batch, the layout and its OWN chunking only
         key = {"B": B, "T": T, "x_layout": "time-major" if tm else "batch-major", "loss": args.loss}
@@ -1107,6 +1232,12 @@ def main():
         traffic, traffic_src = (None, None) if tp is None else measured_traffic(dom, key)
         layout_names = {True: "time-major [T,B] resident copy (one-off transpose at data load, outside the timed region)",
                         False: "batch-major [B,T] as the reference scripts hold it"}
+        curves = {args.scaling: {"value": value, "ms_per_step": ms_step, "global_batch": Bg, "sequences_per_rank": B}}
+        if companion is not None:
+            curves[companion["scaling"]] = companion
+        elif world == 1:
+            curves["strong" if args.scaling == "weak" else "weak"] = {"value": value, "ms_per_step": ms_step, "global_batch": Bg,
+                                                                       "sequences_per_rank": B, "note": "N = 1: the same run"}
         out = {
             "metric": "samples/sec fwd+bwd, 1N4148 diode clipper @48kHz batch=8192; 1->8 GPU scaling",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1128,16 +1259,25 @@ def main():
                        "time_parallel": None if tp is None else
                        {"fwd_chunks": tp.k_fwd, "fwd_warmup_steps": tp.warmup, "verify_tol": tp.tol,
                         "bwd_chunks": None if fused else tp.k_bwd, "verify_status": tp_stat, "warm_start": warm}},
+            # the ranks that took part, as the collective itself counted them; both scaling curves from this invocation:
+            # `value` is the curve named by `scaling` (weak by default: --batch sequences on EVERY rank, the contract's
+            # "per-GPU work fixed"); scaling_curves.strong is SURVEY 8e's global batch of --batch sequences split over the ranks
+            "ranks_seen": ranks["ranks_seen"], "ranks": ranks,
+            "headline_curve": f"{args.scaling}: `value` counts {Bg} sequences x {T} samples per step over {world} rank(s)",
+            "scaling_curves": curves,
             "value_batch_major" if tm else "value_time_major": other,
             "step_launch": "one HIP-graph replay per step" if args.graph else "eager launches",
             "step_kernels": ("one pass: clipper_fused_tp_kernel (forward + loss + tangent-carried gradient + combine / reduce / "
                              "Adam tail) and its gated repair launch") if fused else
                             "two kernels: clipper_fwd_tp_kernel (+ gated repair) and clipper_bwd_tp_kernel (MSE-fused reverse sweep)",
             "kernel_ms": {"fused_step": spread(t_fwd)} if fused else {"fwd": spread(t_fwd), "bwd": spread(t_bwd)},
-            "kernel_ms_sampling": ({"bracketed_in_timed_region": main_run.n_in_region,
-                                    "note": "runs of <= 64 steps: every 4th timed step carries events, then the same loop continues untimed "
-                                            "with every step bracketed (parameters and optimizer state restored afterwards)"}
-                                   if getattr(main_run, "n_in_region", None) is not None else None),
+            "kernel_ms_in_region": ({"fused_step": spread(f_in)} if fused else {"fwd": spread(f_in), "bwd": spread(b_in)}),
+            "kernel_ms_sampling": {"bracketed_in_timed_region": n_in, "all_samples": len(t_fwd),
+                                   "note": "kernel_ms_in_region: HIP events around the kernel of every 4th TIMED step (these price the "
+                                           "roofline); kernel_ms: those plus -- for runs of <= 64 steps -- the same loop continued "
+                                           "untimed with every step bracketed (parameters and optimizer state restored afterwards); "
+                                           "HIP-graph replay: the warm-up steps' kernels (a replayed step carries no events)"},
+            "library": library_identity(),
             "parity": parity,
             "value_cold": None if cold is None else cold["value"],
             "cold": cold,
@@ -1148,37 +1288,36 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_sample": dom_bytes,
+                         "algorithmic_bytes_per_sample": dom_bytes, "kernel_ms_used": dom_ms,
                          "copy_bandwidth": copy_gbs, "frac_of_copy_bandwidth": achieved / copy_gbs},
         }
         if fused:
-            # The one-pass step is bound by VALU issue, not by HBM: `frac` is the fraction of the chip's VALU issue cycles
-            # (1024 SIMDs x the 2.4 GHz peak clock x the kernel's duration) in which a VALU instruction was executing, from
-            # the committed SQ pass of this configuration.  The HBM side stays in the block: what the kernel itself moves
-            # (12 B/sample) and, demoted, SURVEY 8d's forward + backward equivalent (24 B/sample: the work one launch does).
+            # SURVEY 8(d)'s contract: frac = ALGORITHMIC bytes of forward + backward (24 B/sample) x the samples one launch
+            # processes / the kernel's mean duration in the timed region / the 8 TB/s HBM peak.  The one-pass kernel does that
+            # work moving 12 B/sample (x, target read; y written), so beside `frac` the block carries what the kernel itself
+            # moves (hbm.frac_moved), what the counters saw (hbm.frac_traffic, from a committed PMC pass OF THIS BUILD, else
+            # null) and the VALU-issue fraction (valu.frac: measured SQ pass of this build, else -- and it says so -- the
+            # instruction-count model) -- the kernel's practical bound.
             moved = BYTES_STEP_MOVED * B * T / (dom_ms * 1e-3) / 1e9
             valu, valu_src = (None, None) if tp is None else measured_valu_cycles(dom, key)
-            frac_kind = "VALU-active cycles of a COMMITTED counter pass of this configuration / this run's kernel time"
+            valu_kind = "measured: VALU-active cycles of a committed SQ counter pass of this build and configuration / this run's kernel time"
             if valu is None and tp is not None and key.get("x_layout") == "time-major" and args.loss == "mse":
                 valu, valu_src = valu_cycle_model(B, T, tp.k_fwd, w_used or 0), "instruction-count model (bench.py valu_cycle_model)"
-                frac_kind = "VALU-active cycles from the instruction-count model fitted to the committed passes / this run's kernel time"
+                valu_kind = "MODEL, not a measurement: VALU-active cycles from the instruction count fitted to earlier SQ passes / this run's kernel time"
             peak = N_SIMD * VALU_CLOCK_GHZ
             ach = None if valu is None else valu / (dom_ms * 1e-3) / 1e9
-            out["roofline"] = {
-                "bound": "valu", "kernel": dom, "achieved": ach, "peak": peak, "unit": "G VALU-active cycles/s (chip)",
-                "frac": None if ach is None else ach / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "valu_source": valu_src, "frac_kind": frac_kind, "step_kernel_ms": f_ms,
+            out["roofline"].update({
+                "frac_kind": "SURVEY 8(d): 24 algorithmic B/sample (forward 8 + stash 4; backward x, stash, dL/dy 12) x samples per "
+                             "launch / mean kernel time in the timed region / 8 TB/s -- nominal for a one-pass kernel that moves 12",
                 "hbm": {"bytes_moved_per_sample": BYTES_STEP_MOVED, "moved": moved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac_moved": moved / HBM_PEAK_GBS,
                         "frac_traffic": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "copy_bandwidth": copy_gbs},
-                "equivalent_two_pass": {"algorithmic_bytes_per_sample": BYTES_STEP, "achieved": achieved, "unit": "GB/s",
-                                        "frac": achieved / HBM_PEAK_GBS,
-                                        "note": "SURVEY 8d prices forward + backward at 24 B/sample (x, y, stash written; x, stash, "
-                                                "dL/dy read); one launch of the one-pass step does that work moving 12"},
-                "note": "VALU-bound: ~110 instructions per two sample-steps (69 packed) at 2 waves per SIMD; `frac` uses the "
-                        "peak clock, the chip sustains ~1.9-2.0 GHz under this kernel (frac / 0.8 is the share of the "
-                        "cycles it actually had)"}
+                        "traffic_over_moved": None if traffic is None else traffic / (BYTES_STEP_MOVED * B * T),
+                        "frac_moved_of_copy_bandwidth": moved / copy_gbs},
+                "valu": {"frac": None if ach is None else ach / peak, "achieved": ach, "peak": peak,
+                         "unit": "G VALU-active cycles/s (chip: 1024 SIMDs x 2.4 GHz)", "source": valu_src, "kind": valu_kind},
+                "practical_bound": "VALU issue: ~110 instructions per two sample-steps (69 packed) at 2 waves per SIMD; valu.frac uses the "
+                                   "2.4 GHz peak clock, the chip sustains ~1.9-2.2 GHz under this kernel (sustained.shader_clock_mhz)"})
         else:
             out["roofline"].update({"fwd_kernel_ms": f_ms, "bwd_kernel_ms": b_ms})
         if world == 1 and not args.no_cpu_baseline:

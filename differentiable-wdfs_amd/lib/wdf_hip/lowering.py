@@ -157,6 +157,7 @@ class _StateSpaceFn(torch.autograd.Function):
 _LIN_OCC = int(os.environ.get("WDF_LIN_OCC", "2"))       # chunks are cut so that every SIMD gets this many waves
 _NL_OCC = int(os.environ.get("WDF_NL_OCC", "1"))
 _NL_WMIN = int(os.environ.get("WDF_NL_WMIN", "16"))      # the shortest warm-up the device's controller may settle on
+_ROWS = 1024                                             # result rows per slab (see _LinResident.entry)
 NL_TOL = 1.0e-6                                          # boundary tolerance of the diode-root one-pass step (plan_ss_time_parallel's)
 
 
@@ -180,14 +181,24 @@ class _LinResident:
             pvars += [circ.root.Is, circ.root.nVt]
         if not 1 <= len(pvars) <= probe_tape.MAX_PARAMS:
             raise binding.WdfHipError(f"Circuit.to_device: 1..{probe_tape.MAX_PARAMS} component values (this tree has {len(pvars)})")
-        self.pb = tf.ParamBlock([float(v) for v in pvars], torch.device(device))
+        for (e, n), v in zip(self.params, pvars):
+            # what the resident step would silently freeze is refused (as on the clipper path): a value computed from other
+            # Variables would get no gradient and never move; a Variable another circuit's block already holds
+            if isinstance(v, torch.Tensor) and not getattr(v, "_is_tf_variable", False) and (v.requires_grad or v.grad_fn is not None):
+                raise binding.WdfHipError(f"Circuit.to_device: {type(e).__name__}.{n} is a tensor computed from other Variables; the "
+                                          "resident step would freeze it -- keep this circuit on the host path")
+            if isinstance(v, torch.Tensor) and getattr(v, "_wdf_block", None) is not None:
+                raise binding.WdfHipError("Circuit.to_device: a component Variable already lives in another circuit's block")
+        # the tape is recorded (and its size checked) BEFORE any Variable moves: a circuit the device probe cannot hold
+        # leaves its Variables where they were
+        tape, outs, rport = probe_tape.record(circ, pvars[:self.n_tree])
+        self.captured = list(pvars)                               # what every (element, attribute) held at to_device()
+        self.captured_val = [float(v) for v in pvars]
+        self.pb = tf.ParamBlock(self.captured_val, torch.device(device))
         for i, v in enumerate(pvars):
             if isinstance(v, torch.Tensor) and getattr(v, "_is_tf_variable", False) and v.numel() == 1:
-                if getattr(v, "_wdf_block", None) is not None:
-                    raise binding.WdfHipError("Circuit.to_device: a component Variable already lives in another circuit's block")
                 self.pb.adopt(i, v)
         self.adopted = {i: v for i, v in self.pb.members.items()}
-        tape, outs, rport = probe_tape.record(circ, pvars[:self.n_tree])
         self.host_tape, self.host_outs = tape, outs + [rport]
         ops, consts = tape.packed()
         dev = self.pb.block.device
@@ -201,11 +212,24 @@ class _LinResident:
         self.cache = {}
 
     def check(self):
-        """The adopted Variables must still be the elements' component values and still live in the block."""
+        """Every component value must still be what to_device() captured: an adopted Variable the same object, still in the
+        block; a frozen (non-Variable) value the same object or the same number -- set_resistance / `e.R = ...` afterwards
+        would otherwise be silently ignored by the resident step."""
         for i, (e, n) in enumerate(self.params):
             v = e.__dict__.get(n)
-            if i in self.adopted and (v is not self.adopted[i] or getattr(v, "_wdf_block", (None,))[0] is not self.pb):
-                raise binding.WdfHipError(f"Circuit.to_device: {type(e).__name__}.{n} was replaced after to_device(); build a new Circuit")
+            if i in self.adopted:
+                if v is not self.adopted[i] or getattr(v, "_wdf_block", (None,))[0] is not self.pb:
+                    raise binding.WdfHipError(f"Circuit.to_device: {type(e).__name__}.{n} was replaced after to_device(); build a new Circuit")
+            elif v is not self.captured[i]:
+                same = False
+                try:
+                    same = (not isinstance(v, torch.Tensor) or v.numel() == 1) and float(v) == self.captured_val[i]
+                except (TypeError, ValueError):
+                    pass
+                if not same:
+                    raise binding.WdfHipError(f"Circuit.to_device: {type(e).__name__}.{n} was changed after to_device() (the resident "
+                                              "step holds the value it had then); build a new Circuit")
+                self.captured[i] = v
 
     def probe(self):
         """The step's coefficients and their Jacobian from the block, on the device -- behind the optimizer updates the
@@ -257,10 +281,12 @@ class _LinResident:
                 if nbytes == 0:
                     raise binding.WdfHipError(L_.wdf_last_error().decode() or "wdf_ss_lin_step_ws_bytes: unsupported tree")
                 ws = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
-            # results of a call: {SSE, gradients} and the loss, in one of eight rows taken in turn (a call's results stay valid
-            # while up to seven more calls on this batch run: no copy per call)
+            # results of a call: {SSE, gradients} and the loss, each call in a row of its OWN (rows are handed out from a
+            # slab of _ROWS; a full slab is replaced by a fresh one and lives on for as long as anything still refers to
+            # it): the loss history a script keeps (lpf.py:99 `losses.append(loss)`) and gradients read after the loop stay
+            # what they were -- no copy per call, one allocation per _ROWS calls
             ent = self.cache[key] = {"x": x_tm, "t": tgt, "y": y, "ws": ws,
-                                     "ring": torch.zeros((8, 2 + self.pb.n), dtype=torch.float32, device=dev), "turn": 0,
+                                     "ring": torch.zeros((_ROWS, 2 + self.pb.n), dtype=torch.float32, device=dev), "turn": 0,
                                      "B": B, "T": T, "k": k, "hold": (x, target), "calls": 0, "watch": None, "replans": 0}
         return ent
 
@@ -333,12 +359,14 @@ class _LinResident:
 
     def step(self, ent):
         """probe + one-pass step -> (out = {SSE, d(mean squared error)/d component value}, loss = the mean squared error): views
-        of this call's row of the entry's result ring."""
+        of this call's own result row (never written again)."""
         circ = self.circ
         self.probe()
         B, T, n = ent["B"], ent["T"], self.pb.n
+        if ent["turn"] >= ent["ring"].shape[0]:
+            ent["ring"], ent["turn"] = torch.zeros_like(ent["ring"]), 0
         row = ent["ring"][ent["turn"]]
-        ent["turn"] = (ent["turn"] + 1) % ent["ring"].shape[0]
+        ent["turn"] += 1
         out, loss = row[:1 + n], row[1 + n]
         if circ.root_kind == "DiodePair":
             rc = binding.lib().wdf_ss_nl_step_mse(binding._ptr(ent["x"]), binding._ptr(self.coef), binding._ptr(self.pb.block),
@@ -392,7 +420,7 @@ class _LinResidentMseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, res, ent, inv_n, idx, *live):
-        out, loss = res.step(ent)                                # (this call's row of the result ring: nothing to copy)
+        out, loss = res.step(ent)                                # (this call's own result row: nothing to copy)
         ctx.save_for_backward(out)
         ctx.idx = idx
         ctx.mark_non_differentiable(out)

@@ -380,14 +380,32 @@ def _run_clipper_relu(circ, x, z0, return_state, dense, hidden, n_layers):
                                   "circuit under tf.stop_gradient / torch.no_grad for its outputs alone")
     vs, cap = circ.top.P1, circ.top.P2
     dev = x.device
-    xv, r = engine.split_channels(x, circ.per_sample_R is not None, anchor=getattr(circ, "_anchor", None))
+    if circ.per_sample_R is None and isinstance(vs.R, torch.Tensor) and vs.R.numel() != 1:
+        raise binding.WdfHipError("a ReLU DenseRootModel on the resident step's kernels: the source resistance is a scalar, or a "
+                                  f"per-sample channel declared with per_sample_R (got a tensor of shape {tuple(vs.R.shape)})")
+    # one forward-only stepper per input (clipper_pot.py:251-262 validates on the same val_X every epoch): its buffers, its
+    # plan and its warm-start snapshots are kept; only the weights are refreshed
+    anchor = getattr(circ, "_anchor", None)
+    key = None if anchor is None else (id(anchor), anchor._version, tuple(x.shape))
+    cache = circ.__dict__.setdefault("_relu_fwd", {})
+    ent = cache.get(key) if key is not None else None
     with torch.no_grad():
         w = flat_weights(dense).float().to(dev).contiguous()
-        Rv = float(vs.R) if not isinstance(vs.R, torch.Tensor) or vs.R.numel() == 1 else 45.0e3
-        st = MlpTrainStep(xv, r, torch.zeros((int(x.shape[1]), int(x.shape[0])), dtype=torch.float32, device=dev), w, hidden, n_layers,
-                          float(cap.FS), float(cap.C), R_static=Rv, skip=0, adam=None, activation="relu")
+        if ent is None or ent[0]() is not anchor:
+            xv, r = engine.split_channels(x, circ.per_sample_R is not None, anchor=anchor)
+            Rv = None if circ.per_sample_R is not None else float(vs.R)
+            st = MlpTrainStep(xv, r, torch.zeros((int(x.shape[1]), int(x.shape[0])), dtype=torch.float32, device=dev), w.clone(), hidden,
+                              n_layers, float(cap.FS), float(cap.C), R_static=Rv, skip=0, adam=None, activation="relu")
+            if key is not None:
+                if len(cache) >= 2:
+                    cache.pop(next(iter(cache)))
+                import weakref
+                cache[key] = (weakref.ref(anchor), st)
+        else:
+            st = ent[1]
+            st.w.copy_(w)
         st.forward_only()
-    return st.y.as_subclass(tf.Tensor)
+    return st.y.clone().as_subclass(tf.Tensor)
 
 
 # ------------------------------------------------------------------------------ the resident training step

@@ -62,12 +62,24 @@ def dataset_resistance_batch(B_global, T, b0=0, b1=None, grid=(10.0e3, 25.2e3, 7
     return np.ascontiguousarray(np.repeat(g[idx][:, None], T, axis=1), dtype=dtype)
 
 
-def reference_mlp_weights(name="2x16"):
-    """(flat weights float32, hidden, n_tanh) of a committed reference network, read from the golden fixture
-    tests/golden/g3_mlp_clipper.npz (weights of wdf_py/diode_clipper/models/*.json, kernel[in][out] then
-    bias[out] per layer)."""
+def reference_mlp_weights(name="2x16", path=None):
+    """(flat weights float32, hidden, n_tanh) of one of the reference's committed networks
+    (wdf_py/diode_clipper/models/*.json: kernel[in][out] then bias[out] per layer) -- from the package's own data file
+    wdf_hip/data/mlp_reference_weights.npz (the numbers tests/golden/gen_golden.py read out of those JSON files; the
+    package does not reach into tests/), or from `path`: another .npz with `<name>_theta` / `<name>_sizes`, or a model JSON
+    in the reference's schema (model_utils.save_model / layers.DenseRootModel)."""
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "..", "tests", "golden", "g3_mlp_clipper.npz")
+    if path is not None and str(path).endswith(".json"):
+        import json
+        layers = json.load(open(path))["layers"]
+        flat, sizes = [], [2]
+        for layer in layers:
+            k, b = np.asarray(layer["weights"][0], dtype=np.float32), np.asarray(layer["weights"][1], dtype=np.float32)
+            flat += [k.reshape(-1), b.reshape(-1)]
+            sizes.append(int(b.size))
+        return np.concatenate(flat), sizes[1], len(sizes) - 2
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "mlp_reference_weights.npz")
     g = np.load(path)
     sizes = [int(v) for v in g[f"{name}_sizes"]]
     return g[f"{name}_theta"].astype(np.float32), sizes[1], len(sizes) - 2

@@ -152,3 +152,31 @@ def test_loader_matches_the_reference_loader_fixture(tmp_path, golden):
     for got, ref in ((tX[..., 0], g["train_X_sum"][0]), (tX[..., 1], g["train_X_sum"][1]), (tY, g["train_Y_sum"]),
                      (vX[..., 0], g["val_X_sum"][0]), (vX[..., 1], g["val_X_sum"][1]), (vY, g["val_Y_sum"])):
         assert got.astype(np.float64).sum() == float(ref)
+
+
+def test_package_weight_file_is_the_goldens_and_json_path(golden, tmp_path):
+    """wdf_hip/data/mlp_reference_weights.npz (what bench.py --root mlp* and the tools read: the package does not reach into
+    tests/) holds the same numbers as the golden the reference's JSON models were read into; a model JSON written by
+    model_utils.save_model loads to the same flat vector through the `path` argument."""
+    from wdf_hip import workload
+    import layers, model_utils
+    g3 = golden("g3_mlp_clipper.npz")
+    for net in ("2x4", "2x8", "2x16", "2x16_pre", "4x4", "4x8"):
+        w, hidden, n_layers = workload.reference_mlp_weights(net)
+        assert np.array_equal(w, g3[f"{net}_theta"].astype(np.float32))
+        assert [2] + [hidden] * n_layers + [1] == [int(v) for v in g3[f"{net}_sizes"]]
+    w, hidden, n_layers = workload.reference_mlp_weights("2x8")
+    js = {"in_shape": [None, 2], "layers": []}
+    o, n_in = 0, 2
+    for i in range(n_layers + 1):
+        n_out = hidden if i < n_layers else 1
+        k = w[o:o + n_in * n_out].reshape(n_in, n_out); o += n_in * n_out
+        b = w[o:o + n_out]; o += n_out
+        js["layers"].append({"type": "dense", "activation": "tanh" if i < n_layers else "", "shape": [None, n_out],
+                             "weights": [k.tolist(), b.tolist()]})
+        n_in = n_out
+    import json
+    path = tmp_path / "m.json"
+    json.dump(js, open(path, "w"))
+    w2, h2, n2 = workload.reference_mlp_weights(path=str(path))
+    assert (h2, n2) == (hidden, n_layers) and np.array_equal(w2, w)

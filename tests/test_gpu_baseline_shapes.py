@@ -1,0 +1,101 @@
+"""GPU: the BASELINE.json configurations at their OWN shapes, through the plans bench.py uses for them.
+
+* configs[1] (C2): 1N4148 diode clipper forward only, 1024 sequences x 4096 samples, stateless calls -- every output
+  sample against the fp64 oracle, for the chunk counts the bench line's sweep tries (among them counts that do not divide
+  T: ragged last chunk, 8 waves per chunk);
+* configs[3] (C4) on one GPU: the dataset-shaped batch (1340 sequences of 2048 samples, pot value per sample in the
+  loader's layout) tiled to 8192 sequences, MSE + ESR past 50 samples, ten Adam steps of the one-pass step with
+  warm-started chunks -- y, the three loss values and the gradient of the LAST step against the oracle at that step's
+  parameters (clipper_pot.py:146-156,177,232,245-269).
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+FS = 48000.0
+
+
+@pytest.fixture(scope="module")
+def wb():
+    from wdf_hip import binding
+    binding.require_gpu()
+    return binding
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
+
+
+def test_c2_forward_only_1024x4096_every_sample_against_the_oracle(wb, oracle):
+    from wdf_hip import engine, workload
+    B, T = 1024, 4096
+    th = workload.clipper_theta()
+    x = workload.sweep_batch(B, T, seed=3)                      # bench.forward_only's input
+    xk = dev(x).t().contiguous()                                # the engine's resident layout
+    theta = dev(th)
+    plan = engine.plan_time_parallel(B, T, th[2], th[3], FS, time_major=True)
+    y_ref = oracle.clipper_fwd(th.astype(np.float32).astype(np.float64), FS, x.astype(np.float64))
+    # bench.forward_only's candidates, plus counts that do not divide T (42 is what the r04 line's sweep landed on)
+    cands = sorted({k for k in (plan.k_fwd // 2, plan.k_fwd, plan.k_fwd * 2, plan.k_fwd * 4, plan.k_fwd * 8) if 2 <= k <= T // 32} | {42, 37, 100})
+    ragged = 0
+    for k in cands:
+        used = wb.lib().wdf_clipper_tp_chunks(T, k)
+        ragged += int(T % used != 0)
+        y, zs, _, st = wb.clipper_fwd_tp(xk, theta, FS, k, plan.warmup, plan.tol, want_stash=False, time_major=True)
+        s = wb.tp_status(st)
+        assert zs is None and s["n_bad"] == 0 and s["max_miss"] <= plan.tol, (k, used, s)
+        err = float(np.max(np.abs(y.cpu().numpy() - y_ref)))
+        assert err < 2e-6, (k, used, err)                       # the fp32 path's own error is ~1.5e-7; the verification allows 1e-6
+    assert ragged >= 1, cands
+
+
+def _esr(y64, t64, skip, n, eps):
+    o, t = y64[skip:], t64[skip:]
+    S, E = float(np.sum((o - t) ** 2)), float(np.sum(o ** 2)) + eps
+    mse, esr = S / n, float(np.sqrt(S / E / n))
+    gy = np.zeros_like(y64)
+    gy[skip:] = (2.0 / n + 1.0 / (esr * E * n)) * (o - t) - (esr / E) * o
+    return mse, esr, gy
+
+
+def test_c4_dataset_shaped_training_loop_last_step_against_the_oracle(wb, oracle):
+    from wdf_hip import engine, workload
+    B0, T, skip, tiles = 1340, 2048, 50, 6
+    B = 8192
+    x0 = workload.sweep_batch(B0, T, seed=4)
+    r0 = workload.dataset_resistance_batch(B0, T)               # four contiguous blocks, one pot value each (the loader's layout)
+    idx = np.arange(B) % B0                                     # tiled to 8192 sequences
+    assert tiles * B0 < B <= (tiles + 1) * B0
+    x, r = x0[idx], r0[idx]
+    xt, rt = dev(x).t().contiguous(), dev(r).t().contiguous()
+    th0, ths = workload.clipper_theta(), workload.target_theta()
+    tgt, _, _ = wb.clipper_fwd(dev(x), dev(ths), FS, r=dev(r), want_stash=False)
+    plan = engine.plan_time_parallel(B, T, float(r.max()), th0[3], FS, time_major=True, R_min=float(r.min()))
+    assert plan.k_fwd > 1
+    st = engine.MseStep(B, T, FS, plan, xt.device, time_major=True, loss="mse+esr", skip=skip, warm=True)
+    theta = dev(th0)
+    opt = wb.Adam(4, lr=[1e-3 * float(v) for v in th0], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=xt.device)
+    losses = []
+    for it in range(10):
+        th_before = theta.clone()
+        st.step_fused(theta, xt, tgt, r=rt, adam=opt)
+        losses.append(float(st.loss[2]))
+    assert wb.tp_status(st.status)["n_bad"] == 0
+    assert losses[-1] < losses[0]
+    assert float(theta[2]) == float(np.float32(th0[2]))         # R is streamed per sample: the scalar is not trained
+    # the LAST step, at the parameters it ran with, against the oracle over the whole batch
+    n, eps = B * (T - skip), float(np.finfo(float).eps)
+    th64 = th_before.cpu().numpy().astype(np.float64)
+    x64, r64, t64 = x.astype(np.float64), r.astype(np.float64), tgt.cpu().numpy().astype(np.float64)
+    y64 = oracle.clipper_fwd(th64, FS, x64, r=r64)
+    mse, esr, gy = _esr(y64, t64, skip, n, eps)
+    _, g64 = oracle.clipper_fwd_bwd(th64, FS, x64, gy, r=r64)
+    assert float(np.max(np.abs(st.y.cpu().numpy() - y64))) < 2e-6
+    l = st.loss.cpu().numpy()
+    assert abs(l[0] - mse) <= 2e-5 * mse and abs(l[1] - esr) <= 2e-5 * esr and abs(l[2] - (mse + esr)) <= 2e-5 * (mse + esr)
+    got = st.gtheta.cpu().numpy().astype(np.float64)
+    for i in (0, 1, 3):
+        assert abs(got[i] - g64[i]) <= 1e-4 * abs(g64[i]), (i, got, g64)
+    assert got[2] == 0.0

@@ -102,17 +102,45 @@ def test_bench_two_rank_path_rehearsal():
     assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2048 * 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert d["roofline"]["bound"] == "valu" and 0.0 < d["roofline"]["hbm"]["frac_moved"] < 1.0
-    assert d["roofline"]["frac"] is None or 0.0 < d["roofline"]["frac"] < 1.0      # (needs a committed SQ pass of this shape)
+    assert d["roofline"]["bound"] == "hbm" and 0.0 < d["roofline"]["hbm"]["frac_moved"] < 1.0
+    assert abs(d["roofline"]["frac"] - 2.0 * d["roofline"]["hbm"]["frac_moved"]) < 1e-9      # 24 B/sample, the kernel moves 12
+    assert d["ranks_seen"] == 2 and d["ranks"]["collective_backend"].startswith("gloo") and len(d["ranks"]["ms_per_step_per_rank"]["all"]) == 2
+    assert "external launcher" in d["ranks"]["launcher"]
+    # both curves from the one invocation: the weak headline (1024 per rank) and SURVEY 8e's strong split of ONE 1024 batch
+    sc = d["scaling_curves"]
+    assert sc["weak"]["global_batch"] == 2048 and sc["strong"]["global_batch"] == 1024 and sc["strong"]["sequences_per_rank"] == 512
+    assert abs(sc["strong"]["value"] - 1024 * 2048 / (sc["strong"]["ms_per_step"] * 1e-3)) < 1e-6 * sc["strong"]["value"]
     assert "cpu_baseline" not in d                           # rank 0 at N = 1 only
     assert d["config"]["optimizer"]["loss_last_step"] < d["config"]["optimizer"]["loss_first_step"]
 
 
-def _run_bench(extra, launcher=None, timeout=900):
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the form a driver uses for N = 1): bench.py starts the two
+    ranks itself, the collective counts them (`ranks_seen`), rank 0 prints the one line.  Both ranks on cuda:0 over gloo
+    here (one-GPU box); on a node with N GPUs the same entry point runs one rank per GPU over RCCL."""
+    env_clean = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "1024", "--seq-len", "2048", "--rehearse-on-one-gpu",
+                    "--no-batch-major"], env=env_clean)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["ranks"]["world_size"] == 2
+    assert "started the ranks itself" in d["ranks"]["launcher"]
+    assert d["scaling"] == "weak" and d["config"]["global_batch"] == 2048
+    assert set(d["scaling_curves"]) == {"weak", "strong"} and d["scaling_curves"]["strong"]["global_batch"] == 1024
+    assert d["config"]["optimizer"]["loss_last_step"] < d["config"]["optimizer"]["loss_first_step"]
+    # more ranks than GPUs without the rehearsal flag: refused with a message, not a hang
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(n)], cwd=repo, env=env_clean,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "GPU(s)" in out.stderr
+
+
+def _run_bench(extra, launcher=None, timeout=900, env=None):
     import os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable] + (launcher or []) + [os.path.join(repo, "bench.py")] + extra
-    out = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=timeout)
+    out = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=timeout, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -151,7 +179,8 @@ def test_bench_strong_scaling_rehearsal():
     d = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "2048", "--seq-len", "2048", "--scaling", "strong",
                     "--rehearse-on-one-gpu", "--no-batch-major"], launcher=launcher)
     assert d["scaling"] == "strong" and d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
-    assert "1024 sequences" in d["config"]["workload"]
+    assert "1024 sequences" in d["config"]["workload"] and d["ranks_seen"] == 2
+    assert d["scaling_curves"]["weak"]["global_batch"] == 4096 and d["scaling_curves"]["strong"]["value"] == d["value"]
     assert abs(d["value"] - 2048 * 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 

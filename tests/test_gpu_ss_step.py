@@ -234,3 +234,74 @@ def test_resident_hpf_clipper_training_loop_follows_the_host_loop(wdf):
     (p0, l0), (p1, l1) = ends
     print(f"host loop {p0} loss {l0:.4e}\\nresident  {p1} loss {l1:.4e}")
     assert np.allclose(p1, p0, rtol=5e-4, atol=0) and abs(l1 - l0) < 1e-3 * l0
+
+
+def test_saved_losses_and_gradients_of_a_resident_loop_stay_what_they_were(wdf):
+    """lpf.py:86-101 keeps every epoch's loss (`losses.append(loss)`) and prints `grads` after the loop: what mse() and
+    tape.gradient hand out must not be overwritten by later calls on the same batch (each call's results live in a row of
+    their own)."""
+    tf = wdf.tf
+    rng = np.random.default_rng(3)
+    x = cuda(rng.standard_normal((64, 512)))
+    tgt = cuda(0.3 * rng.standard_normal((512, 64)))
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    circ = wdf.Circuit(I1, Vs, C1).to_device()
+    opts = [tf.keras.optimizers.Adam(learning_rate=1e-3 * float(p)) for p in (C1.C, R1.R)]
+    losses, first_grads, first_vals = [], None, None
+    for epoch in range(24):
+        with tf.GradientTape() as tape:
+            loss = circ.mse(x, tgt)
+        grads = tape.gradient(loss, [C1.C, R1.R])
+        for o, g, p in zip(opts, grads, (C1.C, R1.R)):
+            o.apply_gradients([(g, p)])
+        losses.append(loss)
+        if epoch == 0:
+            first_grads, first_vals = grads, ([float(g) for g in grads], float(loss))
+    vals = [float(v) for v in losses]
+    assert len(set(vals)) == 24 and vals[-1] < vals[0]          # 24 distinct values, still a descending history
+    assert float(losses[0]) == first_vals[1]
+    assert [float(g) for g in first_grads] == first_vals[0]     # the first epoch's gradients, read after 23 more epochs
+    # more calls than one slab of rows holds: the earliest results still stand
+    from wdf_hip import lowering
+    for _ in range(lowering._ROWS + 8):
+        circ.mse(x, tgt)
+    assert float(losses[0]) == first_vals[1] and [float(g) for g in first_grads] == first_vals[0]
+
+
+def test_to_device_refuses_derived_values_and_notices_later_changes(wdf):
+    """What the resident step would silently freeze is refused: a component computed from another Variable (no gradient
+    would reach it), a non-Variable value replaced after to_device(); and a circuit the device probe cannot hold leaves its
+    Variables where they were (the tape is recorded before anything is adopted)."""
+    from wdf_hip import binding as wb, probe_tape
+    tf = wdf.tf
+    base = tf.Variable(1000.0, dtype=tf.float32)
+    R1 = wdf.Resistor(1000.0, True)
+    R1.R = base * 2.0                                            # derived: requires grad through `base`
+    C1 = wdf.Capacitor(1.0e-6, FS, True)
+    circ = wdf.Circuit(wdf.Inverter(wdf.Series(R1, C1)), wdf.IdealVoltageSource(), C1)
+    with pytest.raises(wb.WdfHipError, match="computed from other Variables"):
+        circ.to_device()
+    assert getattr(C1.C, "_wdf_block", None) is None and not C1.C.is_cuda      # nothing was adopted on the way out
+    # a frozen (non-trainable python number) value changed after to_device()
+    R2 = wdf.Resistor(1000.0, False)
+    R2.R = 1000.0
+    C2 = wdf.Capacitor(1.0e-6, FS, True)
+    c2 = wdf.Circuit(wdf.Inverter(wdf.Series(R2, C2)), wdf.IdealVoltageSource(), C2).to_device()
+    x, tgt = cuda(np.ones((2, 64))), cuda(np.zeros((64, 2)))
+    c2.mse(x, tgt)
+    R2.R = 1000.0                                                # the same number again: fine
+    c2.mse(x, tgt)
+    R2.R = 2200.0
+    with pytest.raises(wb.WdfHipError, match="changed after to_device"):
+        c2.mse(x, tgt)
+    # a tree with more component values than the device probe holds: refused, Variables untouched
+    rs = [wdf.Resistor(100.0 * (i + 1), True) for i in range(probe_tape.MAX_PARAMS + 1)]
+    top = rs[0]
+    for r_ in rs[1:]:
+        top = wdf.Series(top, r_)
+    big = wdf.Circuit(wdf.Inverter(top), wdf.IdealVoltageSource(), rs[0])
+    with pytest.raises(wb.WdfHipError):
+        big.to_device()
+    assert all(getattr(r_.R, "_wdf_block", None) is None and not r_.R.is_cuda for r_ in rs)
+    ok = wdf.Circuit(wdf.Inverter(wdf.Series(rs[0], rs[1])), wdf.IdealVoltageSource(), rs[0]).to_device()   # ... and still adoptable
+    assert rs[0].R.is_cuda and ok._lin is not None
