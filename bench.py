@@ -92,7 +92,8 @@ def _committed_pass(pattern, kernel, cfg, value):
     import glob
     ident = library_identity()
     best = None
-    for path in sorted(glob.glob(pattern), reverse=True):
+    paths = sorted(glob.glob(pattern), reverse=True) + sorted(glob.glob(pattern.replace(os.sep + "profiles" + os.sep, os.sep + "gpurun_out" + os.sep)), reverse=True)
+    for path in paths:
         try:
             d = json.load(open(path))
             c = d.get("config")

@@ -15,11 +15,12 @@ for d in glob.glob(os.path.join(root, f"pmc_{tag}_*")):
                 continue
             per.setdefault(m.group(1), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 # the bench line of any pass names the configuration the counters belong to
-cfg = None
+cfg = library = None
 for log in glob.glob(os.path.join(root, f"pmc_{tag}_*.log")):
     for line in open(log):
         if line.startswith("{") and '"metric"' in line:
             d = json.loads(line)
+            library = d.get("library")
             tp = d["config"]["time_parallel"]
             fused = str(d.get("step_kernels", "")).startswith("one pass")
             cfg = {"B": d["config"]["global_batch"] // d["n_gpus"], "T": d["config"]["seq_len"],
@@ -29,10 +30,10 @@ for log in glob.glob(os.path.join(root, f"pmc_{tag}_*.log")):
                    # warm-started forward: the warm-up the device controller settled at, not the cold one
                    "fwd_warmup_steps": tp["fwd_warmup_steps"] if not tp.get("warm_start") else tp["warm_start"].get("warm_unit_steps", 32) * max(0, tp["warm_start"]["last_warm_tiles"])}
 out = {"_doc": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_* (separate passes, --kernel-trace) of `python bench.py "
-               "--steps 5 --warmup 2 --no-cpu-baseline` on MI355X (tools/pmc_traffic.sh); median per launch. Units KiB. "
+               "--steps 200 --warmup 20 --no-cpu-baseline ...` on MI355X (tools/pmc_traffic.sh); median per launch. Units KiB. "
                "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE reports exactly half the bytes on this box "
                "(calibration: profiles/r01_pmc_calibration_*.csv), WRITE_SIZE is exact.",
-       "config": cfg, "kernels": {}}
+       "config": cfg, "library": library, "kernels": {}}
 for k, c in per.items():
     med = {n: statistics.median(v) for n, v in c.items()}
     e = {"FETCH_SIZE_KiB_raw": med.get("FETCH_SIZE"), "fetch_correction": 2.0, "WRITE_SIZE_KiB": med.get("WRITE_SIZE")}
