@@ -341,6 +341,152 @@ static __global__ __launch_bounds__(256) void clipper_asym_grad_reduce_kernel(co
     }
 }
 
+// ---- time-parallel reverse sweep (both modes) ---------------------------------------------------------------------------
+// The sweep above is one dependent chain per sequence (128 waves on 1024 SIMDs at B = 8192) and re-solves the root by Newton
+// at every step.  Neither is needed:
+//  * Given the stash, every step's local quantities are independent of the adjoint: the root needs no re-solve -- the
+//    forward's z' = b + b_temp gives b = z[t+1] + p (z[t] - x[t]) from two CONSECUTIVE stash entries (the last step takes
+//    z[T] = zT), so v = (a + b)/2 costs a subtraction instead of an fp64 Newton solve (the stash is fp32: 6e-8 relative on
+//    z moves exp(v/V) by ~1e-6 relative -- far inside the gradient's 2e-4 against finite differences).
+//  * The adjoint recurrence is LINEAR in the adjoint entering a chunk from the future: with u = gz + g/2,
+//        gz <- kappa u + g/2,  kappa = Da - p (1 + Da) ;   S_i += c_i u
+//    a chunk run with the unknown entering adjoint Lam carries (m, g0): gz = m Lam + g0, and leaves
+//        {P, q}: gz at its first step's exit = P Lam + q ;  {alpha_i, beta_i}: its sums = alpha_i Lam + beta_i.
+//    clipper_asym_bwd_combine_kernel walks a sequence's K records last to first -- exact, no truncation.
+// NEWTON mode differentiates the exact Shockley pair implicitly (formulas above).  OMEGA mode differentiates the fp32
+// closed form the OMEGA forward evaluates (asym_omega_root): with xf = lf + |a|/Vf, xr = lr - |a|/Vr, w' = w/(1 + w):
+//     db/da   = 1 - 2 (wf' + wr')
+//     db/dVf  = -2 lam (wf - wf' (1 + |a|/Vf)) ;  db/dVr  = 2 lam (wr - wr' (1 - |a|/Vr))
+//     db/dIsf = -2 lam Vf wf' / Isf            ;  db/dIsr = 2 lam Vr wr' / Isr ;   db/dRp = -2 lam (Vf wf' - Vr wr') / Rp
+// (f = the diode conducting for this sign of a, r = the other).
+// rec: double [K][14][B] = {P, q, alpha[6], beta[6]}.   L is a multiple of 8.
+constexpr int kAsymRec = 14;
+
+template <bool NEWTON, bool VEC4>
+__global__ __launch_bounds__(64) void clipper_asym_bwd_tp_kernel(const float* __restrict__ x, const float* __restrict__ theta6,
+                                                                 float fs, const float* __restrict__ zstash,
+                                                                 const float* __restrict__ zT, const float* __restrict__ gy,
+                                                                 double* __restrict__ rec, int64_t B, int64_t T, int64_t L)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t k = blockIdx.y;
+    const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const AsymConsts c = asym_load(theta6, fs);
+    const double Rp = c.Rp, p = c.p, Is1 = c.Is1, Is2 = c.Is2, V1 = c.V1, V2 = c.V2;
+    const double iV1 = 1.0 / V1, iV2 = 1.0 / V2;
+    double m = 1.0, g0 = 0.0;
+    double al[6] = {0, 0, 0, 0, 0, 0}, be[6] = {0, 0, 0, 0, 0, 0};
+    const float* __restrict__ xp = x + b * T;
+    float znext = (t1 < T) ? zstash[t1 * B + b] : zT[b];         // the state AFTER the chunk's last step
+    constexpr int kB = 8;
+    // blocks of 8 steps, last to first; the chunk's ragged top block (t1 not a multiple of 8: the sequence's end) first
+    int64_t tb = (t1 - 1) / kB * kB;
+    float xc[kB];
+    for (; tb >= t0; tb -= kB) {
+        if constexpr (VEC4) {
+            if (tb + kB <= T) {
+                const float4* q4 = reinterpret_cast<const float4*>(xp + tb);
+                const float4 u0 = q4[0], u1 = q4[1];
+                xc[0] = u0.x; xc[1] = u0.y; xc[2] = u0.z; xc[3] = u0.w; xc[4] = u1.x; xc[5] = u1.y; xc[6] = u1.z; xc[7] = u1.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < kB; ++i) xc[i] = xp[tb + i < T ? tb + i : T - 1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kB; ++i) xc[i] = xp[tb + i < T ? tb + i : T - 1];
+        }
+#pragma unroll
+        for (int i = kB - 1; i >= 0; --i) {
+            const int64_t t = tb + i;
+            if (t < t1) {                                         // wave-uniform
+                const float zf = zstash[t * B + b];
+                const double z = (double)zf, xin = (double)xc[i], g = (double)gy[t * B + b];
+                const double b_diff = z - xin;
+                double Da, cth[5];
+                if constexpr (NEWTON) {
+                    const double a = z - p * b_diff;
+                    const double br = (double)znext + p * b_diff;
+                    const double v = 0.5 * (a + br);
+                    const double e1 = exp(v * iV1), e2 = exp(-v * iV2);
+                    const double iF = 1.0 / (1.0 + Rp * (Is1 * iV1 * e1 + Is2 * iV2 * e2));
+                    Da = 2.0 * iF - 1.0;
+                    const double k2 = -2.0 * iF;
+                    cth[0] = k2 * Rp * (e1 - 1.0);
+                    cth[1] = k2 * (-Rp * Is1 * e1 * v * iV1 * iV1);
+                    cth[2] = k2 * (-Rp * (e2 - 1.0));
+                    cth[3] = k2 * (-Rp * Is2 * e2 * v * iV2 * iV2);
+                    cth[4] = k2 * (Is1 * (e1 - 1.0) - Is2 * (e2 - 1.0));
+                } else {
+                    const float bd = zf - xc[i];
+                    const float a = zf - c.p * bd;                // the forward's own fp32 root input
+                    const float lam = vsign(a), aa = fabsf(a);
+                    const bool pos = a >= 0.0f;
+                    const float Vf = pos ? c.V1 : c.V2, Vr = pos ? c.V2 : c.V1;
+                    const float lf = pos ? c.l1 : c.l2, lr = pos ? c.l2 : c.l1;
+                    const float Isf = pos ? c.Is1 : c.Is2, Isr = pos ? c.Is2 : c.Is1;
+                    const float af = aa * fast_rcp(Vf), ar = aa * fast_rcp(Vr);
+                    const float wf = wright_omega(af + lf), wr = wright_omega(lr - ar);
+                    const double wfd = wf, wrd = wr;
+                    const double dwf = wfd / (1.0 + wfd), dwr = wrd / (1.0 + wrd);
+                    const double l2 = 2.0 * (double)lam;
+                    Da = 1.0 - 2.0 * (dwf + dwr);
+                    const double dVf = -l2 * (wfd - dwf * (1.0 + (double)af)), dVr = l2 * (wrd - dwr * (1.0 - (double)ar));
+                    const double dIsf = -l2 * (double)Vf * dwf / (double)Isf, dIsr = l2 * (double)Vr * dwr / (double)Isr;
+                    cth[0] = pos ? dIsf : dIsr;
+                    cth[1] = pos ? dVf : dVr;
+                    cth[2] = pos ? dIsr : dIsf;
+                    cth[3] = pos ? dVr : dVf;
+                    cth[4] = -l2 * ((double)Vf * dwf - (double)Vr * dwr) / Rp;
+                }
+                const double h = g0 + 0.5 * g;                    // u = gz + g/2 = m Lam + h
+#pragma unroll
+                for (int q = 0; q < 5; ++q) { al[q] = fma(cth[q], m, al[q]); be[q] = fma(cth[q], h, be[q]); }
+                const double c5 = -(1.0 + Da) * b_diff;
+                al[5] = fma(c5, m, al[5]);
+                be[5] = fma(c5, h, be[5]);
+                const double kap = Da - p * (1.0 + Da);
+                g0 = fma(kap, h, 0.5 * g);
+                m *= kap;
+                znext = zf;
+            }
+        }
+    }
+    double* __restrict__ r = rec + (k * kAsymRec) * B + b;
+    r[0] = m;
+    r[B] = g0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { r[(2 + q) * B] = al[q]; r[(8 + q) * B] = be[q]; }
+}
+
+// one lane per sequence: the K records last to first (Lam = gzT or 0 enters the last chunk), then the wave's sums ->
+// ws[wave][8] (clipper_asym_grad_reduce_kernel finishes); gz0 (optional): dL/dz0
+static __global__ __launch_bounds__(64) void clipper_asym_bwd_combine_kernel(const double* __restrict__ rec, const float* __restrict__ gzT,
+                                                                             double* __restrict__ ws, float* __restrict__ gz0,
+                                                                             int64_t B, int64_t K)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    double lam = gzT ? (double)gzT[b] : 0.0;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t k = K - 1; k >= 0; --k) {
+        const double* __restrict__ r = rec + (k * kAsymRec) * B + b;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s[q] += fma(r[(2 + q) * B], lam, r[(8 + q) * B]);
+        lam = fma(r[0], lam, r[B]);
+    }
+    if (gz0 && live) gz0[b] = (float)lam;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = live ? s[i] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0) ws[(int64_t)blockIdx.x * 8 + i] = v;
+    }
+}
+
 // element-wise root, for accuracy sweeps: b[i] = root(a[i])
 template <bool NEWTON>
 __global__ void asym_root_kernel(const float* __restrict__ a, const float* __restrict__ theta6, float fs,

@@ -364,6 +364,39 @@ int wdf_clipper_asym_bwd(const float* x, const float* theta6, float fs, double t
     return check_launch("wdf_clipper_asym_bwd");
 }
 
+size_t wdf_clipper_asym_bwd_tp_ws_bytes(int64_t B, int n_chunks)
+{
+    if (B <= 0 || n_chunks <= 0) return 0;
+    return (size_t)n_chunks * (size_t)wdf::kAsymRec * (size_t)B * sizeof(double) + (size_t)((B + 63) / 64) * 8 * sizeof(double);
+}
+
+int wdf_clipper_asym_bwd_tp(const float* x, const float* theta6, float fs, int mode, const float* zstash, const float* zT,
+                            const float* gy, const float* gzT, void* ws, float* gtheta6, float* gz0, int64_t B, int64_t T,
+                            int n_chunks, void* stream)
+{
+    if (!x || !theta6 || !zstash || !zT || !gy || !ws || !gtheta6) return fail(WDF_EINVAL, "null x/theta6/zstash/zT/gy/ws/gtheta6");
+    if (B <= 0 || T <= 0 || !(fs > 0.0f)) return fail(WDF_EINVAL, "B, T, fs must be positive");
+    if (mode != WDF_ASYM_OMEGA_F32 && mode != WDF_ASYM_NEWTON_F64) return fail(WDF_EINVAL, "unknown mode %d", mode);
+    if (n_chunks < 1) return fail(WDF_EINVAL, "n_chunks >= 1");
+    int64_t L = (T + n_chunks - 1) / n_chunks;
+    L = (L + 7) / 8 * 8;
+    const int K = (int)((T + L - 1) / L);
+    if (K != n_chunks) return fail(WDF_EINVAL, "n_chunks = %d does not tile T = %lld in 8-step units (%d does)", n_chunks, (long long)T, K);
+    double* rec = (double*)ws;
+    double* part = rec + (size_t)K * (size_t)wdf::kAsymRec * (size_t)B;
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K);
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = (T % 4 == 0) && aligned16(x);
+#define WDF_ASYM_BWD(NEWTON_, V4_) \
+    hipLaunchKernelGGL((wdf::clipper_asym_bwd_tp_kernel<NEWTON_, V4_>), grid, dim3(64), 0, s, x, theta6, fs, zstash, zT, gy, rec, B, T, L)
+    if (mode == WDF_ASYM_NEWTON_F64) { if (v4) WDF_ASYM_BWD(true, true); else WDF_ASYM_BWD(true, false); }
+    else { if (v4) WDF_ASYM_BWD(false, true); else WDF_ASYM_BWD(false, false); }
+#undef WDF_ASYM_BWD
+    hipLaunchKernelGGL(wdf::clipper_asym_bwd_combine_kernel, dim3(grid.x), dim3(64), 0, s, (const double*)rec, gzT, part, gz0, B, (int64_t)K);
+    hipLaunchKernelGGL(wdf::clipper_asym_grad_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)part, (int)grid.x, theta6, fs, gtheta6);
+    return check_launch("wdf_clipper_asym_bwd_tp");
+}
+
 int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, double tol, int max_iter, double* b, int64_t n,
                   void* stream)
 {

@@ -33,7 +33,7 @@ ONE_SEQUENCE_PER_LANE = os.environ.get("WDF_ONE_SEQUENCE_PER_LANE", "") not in (
 GENERAL_ROOT = False
 
 
-ABI_VERSION = 4                # include/wdf_hip.h WDF_HIP_ABI_VERSION
+ABI_VERSION = 5                # include/wdf_hip.h WDF_HIP_ABI_VERSION
 
 
 def _root_flag():
@@ -129,6 +129,10 @@ def lib():
     L.wdf_clipper_asym_bwd_ws_bytes.argtypes = [i64]
     L.wdf_clipper_asym_bwd.restype = ci
     L.wdf_clipper_asym_bwd.argtypes = [fp, fp, cf, C.c_double, ci, fp, fp, vp, fp, i64, i64, vp]
+    L.wdf_clipper_asym_bwd_tp_ws_bytes.restype = C.c_size_t
+    L.wdf_clipper_asym_bwd_tp_ws_bytes.argtypes = [i64, ci]
+    L.wdf_clipper_asym_bwd_tp.restype = ci
+    L.wdf_clipper_asym_bwd_tp.argtypes = [fp, fp, cf, ci, fp, fp, fp, fp, vp, fp, fp, i64, i64, ci, vp]
     L.wdf_asym_root.restype = ci
     L.wdf_asym_root.argtypes = [fp, fp, cf, ci, C.c_double, ci, vp, i64, vp]
     L.wdf_mlp_weight_count.restype = ci
@@ -260,7 +264,8 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_bwd_tp_ws_bytes", "wdf_clipper_bwd_tp_ws_init", "wdf_clipper_bwd_tp", "wdf_clipper_bwd_mse_tp",
     "wdf_clipper_bwd_mse_tp_adam", "wdf_clipper_step_mse_tp_ws_bytes", "wdf_clipper_step_mse_tp_ws_init",
     "wdf_clipper_step_mse_tp", "wdf_clipper_step_esr_tp", "wdf_esr_finish", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_loss_esr_grad", "wdf_clipper_bwd_esr_tp",
-    "wdf_clipper_asym_fwd", "wdf_clipper_asym_fwd_tp_ws_bytes", "wdf_clipper_asym_fwd_tp", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd", "wdf_asym_root",
+    "wdf_clipper_asym_fwd", "wdf_clipper_asym_fwd_tp_ws_bytes", "wdf_clipper_asym_fwd_tp", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd",
+    "wdf_clipper_asym_bwd_tp_ws_bytes", "wdf_clipper_asym_bwd_tp", "wdf_asym_root",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
     "wdf_clipper_mlp_tp_chunks", "wdf_clipper_mlp_fwd_tp_ws_bytes", "wdf_clipper_mlp_fwd_tp",
@@ -986,6 +991,29 @@ def clipper_asym_bwd(x, theta6, fs, zstash, gy, tol=1e-12, max_iter=50):
                                     _ptr(ws), _ptr(g), B, T, _stream())
     _check(rc, "wdf_clipper_asym_bwd")
     return g
+
+
+def clipper_asym_bwd_tp(x, theta6, fs, mode, zstash, zT, gy, n_chunks, gzT=None, want_gz0=False, ws=None):
+    """Time-parallel reverse sweep of the two-different-diode clipper, either mode (wdf_clipper_asym_bwd_tp): no root
+    re-solve (consecutive stash entries give b), chunks composed exactly.  zT [B]: the forward's final state.
+    -> gtheta6 (and dL/dz0 [B] when want_gz0)."""
+    require_gpu()
+    x, theta6, zstash, gy = _f32_dev(x, "x"), _f32_dev(theta6, "theta6"), _f32_dev(zstash, "zstash"), _f32_dev(gy, "gy")
+    zT, gzT = _f32_dev(zT, "zT"), _f32_dev(gzT, "gzT")
+    B, T = x.shape
+    if tuple(gy.shape) != (T, B) or tuple(zstash.shape) != (T, B) or zT is None or zT.numel() != B:
+        raise WdfHipError(f"gy / zstash must be [T,B] = [{T},{B}], zT [{B}]")
+    Lc = -(-(-(-T // max(1, int(n_chunks)))) // 8) * 8
+    K = -(-T // Lc)
+    need = lib().wdf_clipper_asym_bwd_tp_ws_bytes(B, K)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
+    g = torch.empty((6,), dtype=torch.float32, device=x.device)
+    gz0 = torch.empty((B,), dtype=torch.float32, device=x.device) if want_gz0 else None
+    rc = lib().wdf_clipper_asym_bwd_tp(_ptr(x), _ptr(theta6), float(fs), int(mode), _ptr(zstash), _ptr(zT), _ptr(gy), _ptr(gzT),
+                                       _ptr(ws), _ptr(g), _ptr(gz0), B, T, K, _stream())
+    _check(rc, "wdf_clipper_asym_bwd_tp")
+    return (g, gz0) if want_gz0 else g
 
 
 def asym_root(a, theta6, fs, mode, tol=1e-12, max_iter=50):

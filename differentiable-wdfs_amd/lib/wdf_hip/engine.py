@@ -190,33 +190,48 @@ def clipper_stateful(theta, x, fs, r=None, n_up=1, n_down=1, z0=None):
 
 
 class _ClipperAsymFn(torch.autograd.Function):
-    """y [T,B] = clipper with two different antiparallel diodes (fp64 Newton on the exact Shockley pair),
-    differentiable w.r.t. theta6 = {Is_up, nVt_up, Is_down, nVt_down, R, C} (csrc/wdf_asym.h)."""
+    """y [T,B] = clipper with two different antiparallel diodes, differentiable w.r.t.
+    theta6 = {Is_up, nVt_up, Is_down, nVt_down, R, C} (csrc/wdf_asym.h).  mode: fp64 Newton on the exact Shockley pair
+    (default) or the fp32 Wright-omega closed form -- each differentiates its own forward.  The reverse sweep is the
+    time-parallel one (no root re-solve, chunks composed exactly: wdf_clipper_asym_bwd_tp) unless tp says k_bwd = 0, which
+    keeps the sequential Newton-re-solving sweep (wdf_clipper_asym_bwd; Newton mode only)."""
 
     @staticmethod
-    def forward(ctx, theta6, x, fs, tol, max_iter, tp):
+    def forward(ctx, theta6, x, fs, tol, max_iter, tp, mode):
         th = theta6.detach().contiguous()
         if tp is not None and tp.k_fwd > 1:      # time chunks, verified on the device (wdf_clipper_asym_fwd_tp)
-            y, _, zs, st = binding.clipper_asym_fwd_tp(x, th, fs, binding.ASYM_NEWTON_F64, tp.k_fwd, tp.warmup, tol=tol,
-                                                       max_iter=max_iter, verify_tol=tp.tol, want_stash=True)
+            y, zT, zs, st = binding.clipper_asym_fwd_tp(x, th, fs, mode, tp.k_fwd, tp.warmup, tol=tol,
+                                                        max_iter=max_iter, verify_tol=tp.tol, want_stash=True, want_zT=True)
             LAST_TP_STATUS["status"] = st
         else:
-            y, _, _, zs = binding.clipper_asym_fwd(x, th, fs, binding.ASYM_NEWTON_F64, tol=tol, max_iter=max_iter, want_stash=True)
-        ctx.cfg = (fs, tol, max_iter)
-        ctx.save_for_backward(th, x, zs)
+            y, zT, _, zs = binding.clipper_asym_fwd(x, th, fs, mode, tol=tol, max_iter=max_iter, want_stash=True, want_zT=True)
+        B, T = x.shape
+        if tp is not None:
+            k_bwd = int(tp.k_bwd)
+        else:                                    # as many chunks as give every SIMD ~2 waves, none shorter than 64 steps
+            k_bwd = max(1, min(T // 64, (2 * N_SIMD) // max(1, -(-B // 64))))
+        ctx.cfg = (fs, tol, max_iter, mode, k_bwd)
+        ctx.save_for_backward(th, x, zs, zT)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        fs, tol, max_iter = ctx.cfg
-        th, x, zs = ctx.saved_tensors
-        return binding.clipper_asym_bwd(x, th, fs, zs, gy.contiguous(), tol=tol, max_iter=max_iter), None, None, None, None, None
+        fs, tol, max_iter, mode, k_bwd = ctx.cfg
+        th, x, zs, zT = ctx.saved_tensors
+        if k_bwd < 1 and mode == binding.ASYM_NEWTON_F64:
+            g = binding.clipper_asym_bwd(x, th, fs, zs, gy.contiguous(), tol=tol, max_iter=max_iter)
+        else:
+            g = binding.clipper_asym_bwd_tp(x, th, fs, mode, zs, zT, gy.contiguous(), max(1, k_bwd))
+        return g, None, None, None, None, None, None
 
 
-def clipper_asym(theta6, x, fs, tol=1.0e-12, max_iter=50, tp=None):
-    """Two-different-diode clipper loop (BASELINE config 5), Newton mode, with gradients to all six parameters.
-    tp: a TpPlan (plan_time_parallel with the circuit's R, C) -> the forward runs in time chunks."""
-    return _ClipperAsymFn.apply(theta6, x, float(fs), float(tol), int(max_iter), tp)
+def clipper_asym(theta6, x, fs, tol=1.0e-12, max_iter=50, tp=None, mode=None):
+    """Two-different-diode clipper loop (BASELINE config 5) with gradients to all six parameters.
+    mode: binding.ASYM_NEWTON_F64 (default: the exact model) or binding.ASYM_OMEGA_F32 (the fp32 closed form).
+    tp: a TpPlan (plan_time_parallel with the circuit's R, C) -> the forward runs in k_fwd verified time chunks and the
+    reverse sweep in k_bwd exact ones (k_bwd = 0: the sequential sweep)."""
+    mode = binding.ASYM_NEWTON_F64 if mode is None else int(mode)
+    return _ClipperAsymFn.apply(theta6, x, float(fs), float(tol), int(max_iter), tp, mode)
 
 
 class MseStep:

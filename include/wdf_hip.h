@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WDF_HIP_ABI_VERSION 4   /* 3: + wdf_clipper_mlp_step_* (round 4); TpCtl is 128 bytes, warm-up units are 16 steps.  4: + wdf_ss_nl_step_*; the linear step's workspace shrank */
+#define WDF_HIP_ABI_VERSION 5   /* 5: + wdf_clipper_asym_bwd_tp (round 5).  3: + wdf_clipper_mlp_step_* (round 4); TpCtl is 128 bytes, warm-up units are 16 steps.  4: + wdf_ss_nl_step_*; the linear step's workspace shrank */
 
 enum {
     WDF_OK = 0,
@@ -496,6 +496,16 @@ size_t wdf_clipper_asym_bwd_ws_bytes(int64_t B);
 int wdf_clipper_asym_bwd(const float* x, const float* theta6, float fs, double tol, int max_iter,
                          const float* zstash, const float* gy, void* ws, float* gtheta6,
                          int64_t B, int64_t T, void* stream);
+/* Time-parallel reverse sweep, BOTH modes (round 5).  The root is not re-solved: b = z[t+1] + p (z[t] - x[t]) from two
+ * consecutive stash entries (zT = z[T], as wdf_clipper_asym_fwd(_tp) returns it); the adjoint recurrence is linear in the
+ * adjoint entering a chunk, so the n_chunks chunks (a count that tiles T in 8-step units) run independently and one walk per
+ * sequence composes them -- exact.  mode NEWTON differentiates the exact Shockley pair implicitly (wdf_clipper_asym_bwd's
+ * formulas), mode OMEGA the fp32 closed form the OMEGA forward evaluates.  gzT (optional [B]): dL/dz[T]; gz0 (optional [B]):
+ * receives dL/dz[0].  ws: wdf_clipper_asym_bwd_tp_ws_bytes(B, n_chunks). */
+size_t wdf_clipper_asym_bwd_tp_ws_bytes(int64_t B, int n_chunks);
+int wdf_clipper_asym_bwd_tp(const float* x, const float* theta6, float fs, int mode, const float* zstash, const float* zT,
+                            const float* gy, const float* gzT, void* ws, float* gtheta6, float* gz0, int64_t B, int64_t T,
+                            int n_chunks, void* stream);
 int wdf_asym_root(const float* a, const float* theta6, float fs, int mode, double tol, int max_iter,
                   double* b, int64_t n, void* stream);
 

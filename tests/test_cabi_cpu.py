@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.wdf_abi_version() == 4
+    assert lib.wdf_abi_version() == 5
 
 
 def test_argument_validation_without_gpu(lib):

@@ -126,3 +126,84 @@ def test_time_parallel_forward_repairs_a_short_warmup():
     s = wb.mlp_tp_status(st)
     assert s["n_bad"] > 0 and s["gated_waves"] == 3, s
     assert torch.equal(y2, y) and torch.equal(zs2, zs)
+
+
+@pytest.mark.parametrize("B,T,K", [(70, 600, 1), (70, 600, 5), (256, 2048, 16), (5, 131, 3), (64, 4096, 64)])
+def test_time_parallel_reverse_sweep_equals_sequential(B, T, K):
+    """wdf_clipper_asym_bwd_tp, Newton mode: no root re-solve (b from two consecutive stash entries), chunks composed
+    exactly -> the sequential sweep's gradient (which re-solves the root by Newton at every step) to 2e-5 relative, for
+    ragged B / T and chunk counts; dL/dz0 and an adjoint entering at the end (gzT) included."""
+    from wdf_hip import binding as wb, workload
+    x = dev(workload.sweep_batch(B, T, seed=B + T))
+    th = dev(THETA6)
+    rng = np.random.default_rng(K)
+    gy = dev(rng.standard_normal((T, B)) / (B * T))
+    y, zT, _, zs = wb.clipper_asym_fwd(x, th, FS, wb.ASYM_NEWTON_F64, tol=1e-12, want_zT=True, want_stash=True)
+    g_seq = wb.clipper_asym_bwd(x, th, FS, zs, gy).cpu().numpy().astype(np.float64)
+    g_tp, gz0 = wb.clipper_asym_bwd_tp(x, th, FS, wb.ASYM_NEWTON_F64, zs, zT, gy, K, want_gz0=True)
+    g_tp = g_tp.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(g_tp - g_seq) / np.abs(g_seq)) < 2e-5, (g_tp, g_seq)
+    assert bool(torch.isfinite(gz0).all())
+    # linearity in the entering adjoint: sweep(gy, gzT) - sweep(gy, 0) = sweep(0, gzT), and dL/dz0 of a pure end-adjoint is
+    # the product of the step multipliers (|kappa| < 1: it decays)
+    gzT = dev(rng.standard_normal(B))
+    g_a, z_a = wb.clipper_asym_bwd_tp(x, th, FS, wb.ASYM_NEWTON_F64, zs, zT, gy, K, gzT=gzT, want_gz0=True)
+    g_b, z_b = wb.clipper_asym_bwd_tp(x, th, FS, wb.ASYM_NEWTON_F64, zs, zT, torch.zeros_like(gy), K, gzT=gzT, want_gz0=True)
+    assert torch.allclose(g_a - dev(g_tp), g_b, rtol=1e-3, atol=1e-6 * float(g_b.abs().max()))
+    assert torch.allclose(z_a - gz0, z_b, rtol=1e-3, atol=1e-9)
+    if T >= 600:
+        assert float(z_b.abs().max()) < 1e-6 * float(gzT.abs().max())
+
+
+def _omega_mode_forward_numpy(theta6, fs, x):
+    """The OMEGA-mode loop in numpy (scipy's Wright omega accepts complex arguments: complex-step derivatives)."""
+    from scipy.special import wrightomega
+    Is1, V1, Is2, V2, R, C = theta6
+    G1, G2 = 1.0 / R, 2.0 * C * fs
+    Rp, p = 1.0 / (G1 + G2), G1 / (G1 + G2)
+    l1, l2 = np.log(Rp * Is1 / V1), np.log(Rp * Is2 / V2)
+    B, T = x.shape
+    z = np.zeros(B, dtype=complex)
+    y = np.zeros((T, B), dtype=complex)
+    for t in range(T):
+        bd = z - x[:, t]
+        a = z - p * bd
+        pos = a.real >= 0
+        lam = np.where(pos, 1.0, -1.0)
+        aa = lam * a
+        Vf, Vr = np.where(pos, V1, V2), np.where(pos, V2, V1)
+        lf, lr = np.where(pos, l1, l2), np.where(pos, l2, l1)
+        b = a - 2.0 * lam * (Vf * wrightomega(lf + aa / Vf) - Vr * wrightomega(lr - aa / Vr))
+        zn = b - p * bd
+        y[t] = 0.5 * (zn + z)
+        z = zn
+    return y
+
+
+def test_omega_mode_reverse_sweep_against_complex_step():
+    """OMEGA mode differentiates the closed form its forward evaluates: dL/dtheta6 of L = sum(y gy) against the complex-step
+    derivative of a numpy restatement of that loop (scipy.special.wrightomega on complex arguments), 2e-4 relative per
+    component; the engine's autograd function in OMEGA mode gives the same numbers."""
+    from wdf_hip import binding as wb, engine, workload
+    B, T = 48, 500
+    x = workload.sweep_batch(B, T, seed=11)
+    rng = np.random.default_rng(2)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    t32 = THETA6.astype(np.float32).astype(np.float64)
+    y_ref = _omega_mode_forward_numpy(t32, FS, x.astype(np.float64)).real
+    yw, zT, _, zs = wb.clipper_asym_fwd(dev(x), dev(THETA6), FS, wb.ASYM_OMEGA_F32, want_zT=True, want_stash=True)
+    assert np.max(np.abs(yw.cpu().numpy() - y_ref)) < 5e-6
+    ref = np.zeros(6)
+    for i in range(6):
+        tc = t32.astype(complex)
+        h = 1e-20 * t32[i]
+        tc[i] += 1j * h
+        ref[i] = np.sum(_omega_mode_forward_numpy(tc, FS, x.astype(np.float64)).imag * gy) / h
+    for K in (1, 4):
+        got = wb.clipper_asym_bwd_tp(dev(x), dev(THETA6), FS, wb.ASYM_OMEGA_F32, zs, zT, dev(gy), K).cpu().numpy().astype(np.float64)
+        err = np.abs(got - ref) / np.abs(ref)
+        assert np.max(err) < 2e-4, (K, got, ref, err)
+    th = dev(THETA6).requires_grad_(True)
+    y = engine.clipper_asym(th, dev(x), FS, mode=wb.ASYM_OMEGA_F32)
+    (y * dev(gy)).sum().backward()
+    assert np.max(np.abs(th.grad.cpu().numpy() - ref) / np.abs(ref)) < 2e-4

@@ -69,5 +69,76 @@ for K in (4, 8, 16, 32):
         ms, err, st = run_tp(wb.ASYM_NEWTON_F64, tol, 50, K)
         rows.append({"root": f"fp64 Newton tol={tol:g}, {K} time chunks", "ms": ms, "samples_per_s": B * T / ms * 1e3,
                      "max_abs_err_vs_exact": err, "verify": st})
+
+
+# ---- forward + reverse sweep (gradients to all six parameters of L = mean((y - y*)^2)) --------------------------------------
+# error columns: the gradient on 32 picked sequences against fp64 central differences of the oracle's exact forward (Newton
+# mode: the model being differentiated; OMEGA mode differentiates its own closed form, so its distance to the exact model's
+# gradient is MODEL error) and, Newton mode, the time-parallel sweep against the sequential one that re-solves every root.
+th_star = torch.tensor(THETA6 * np.array([1.2, 0.95, 0.8, 1.05, 0.9, 1.1]), dtype=torch.float32, device="cuda")
+tgt, _, _ = wb.clipper_asym_fwd(xd, th_star, FS, wb.ASYM_NEWTON_F64, tol=1e-12)
+tgt_pick = tgt[:, pk].cpu().numpy().astype(np.float64)
+x_pick = x[pick].astype(np.float64)
+
+
+def fd_grad():
+    g = np.zeros(6)
+    for i in range(6):
+        h = 1e-6 * t32[i]
+        tp_, tm_ = t32.copy(), t32.copy()
+        tp_[i] += h
+        tm_[i] -= h
+        lp = np.mean((O.clipper_asym_fwd(tp_, FS, x_pick) - tgt_pick) ** 2)
+        lm = np.mean((O.clipper_asym_fwd(tm_, FS, x_pick) - tgt_pick) ** 2)
+        g[i] = (lp - lm) / (2 * h)
+    return g
+
+
+g_fd = fd_grad()
+xp_d = xd[pk].contiguous()
+
+
+def picked_grad(mode, kb):
+    y, zT, _, zs = wb.clipper_asym_fwd(xp_d, th, FS, mode, tol=1e-12, want_zT=True, want_stash=True)
+    gy = (2.0 * (y - tgt[:, pk]) / y.numel()).contiguous()
+    if kb == 0:
+        return wb.clipper_asym_bwd(xp_d, th, FS, zs, gy).cpu().numpy().astype(np.float64)
+    return wb.clipper_asym_bwd_tp(xp_d, th, FS, mode, zs, zT, gy, kb).cpu().numpy().astype(np.float64)
+
+
+def run_fwd_bwd(mode, kf, kb, tol=1e-12, W=192):
+    def once():
+        if kf > 1:
+            y, zT, zs, _ = wb.clipper_asym_fwd_tp(xd, th, FS, mode, kf, W, tol=tol, want_stash=True, want_zT=True)
+        else:
+            y, zT, _, zs = wb.clipper_asym_fwd(xd, th, FS, mode, tol=tol, want_stash=True, want_zT=True)
+        gy = (y - tgt) * (2.0 / y.numel())
+        if kb == 0:
+            return wb.clipper_asym_bwd(xd, th, FS, zs, gy, tol=tol)
+        return wb.clipper_asym_bwd_tp(xd, th, FS, mode, zs, zT, gy, kb)
+    once()
+    torch.cuda.synchronize()
+    e0, e1 = wb.Event(), wb.Event()
+    n = 3
+    e0.record()
+    for _ in range(n):
+        g = once()
+    e1.record()
+    return e0.elapsed_ms(e1) / n, g.cpu().numpy().astype(np.float64)
+
+
+g_seq_pick = picked_grad(wb.ASYM_NEWTON_F64, 0)
+for name, mode in (("fp64 Newton tol=1e-12", wb.ASYM_NEWTON_F64), ("fp32 Wright-omega closed form", wb.ASYM_OMEGA_F32)):
+    cases = ([(1, 0), (16, 0)] if mode == wb.ASYM_NEWTON_F64 else []) + [(16, 8), (16, 16), (16, 32), (32, 16), (32, 32)]
+    for kf, kb in cases:
+        ms, g = run_fwd_bwd(mode, kf, kb)
+        gp = picked_grad(mode, kb)
+        row = {"root": name, "step": "forward + reverse sweep", "fwd_chunks": kf,
+               "reverse": "sequential, Newton re-solve per step" if kb == 0 else f"time-parallel, {kb} chunks, no re-solve",
+               "ms": ms, "samples_per_s": B * T / ms * 1e3,
+               "max_rel_grad_err_vs_fd_of_exact_model_32seq": float(np.max(np.abs(gp - g_fd) / np.abs(g_fd)))}
+        if mode == wb.ASYM_NEWTON_F64:
+            row["max_rel_grad_err_vs_sequential_sweep_32seq"] = float(np.max(np.abs(gp - g_seq_pick) / np.abs(g_seq_pick)))
+        rows.append(row)
 for r in rows:
     print(json.dumps(r))
