@@ -1,0 +1,283 @@
+// wdf_ss_dyn.h -- the state-space recursion of wdf_statespace.h with the step's coefficients STREAMED per sample, and with
+// the tanh-MLP root (layers.DenseRootModel) as a third root kind: what lifts two restrictions of the lowering --
+//
+//   * per-sample impedance on ANY tree: in the reference set_resistance replaces R on any ResistiveVoltageSource / Resistor
+//     (tf_wdf.py:51-52,80-81) and calc_impedance may run every step (clipper_pot.py:116-117).  The adaptor coefficients
+//     (tf_wdf.py:139-145,168-177) are then functions of the sample's resistance; the host evaluates the probed step's tape
+//     (lib/wdf_hip/probe_tape.py) over the whole resistance channel -- the idea of wdf_clipper_mlp_step_prepare, for any tree --
+//     and this kernel reads one coefficient ROW per (sample, sequence);
+//   * DenseRootModel terminating any tree (layers.py:72-82): b = -MLP(a, log R_port) (clipper_pot.py:119-121) evaluated per
+//     lane (wdf_mlp.h, weights in LDS); its weight gradient is the dense pass mlp_wgrad_kernel over (a, log R_port, dL/db).
+//
+// One step, as in wdf_statespace.h:   a = ca.z + da.x ;  b = root(a) ;  z' = A z + Bx x + E b ;  y = cy.z + dy.x + fy b.
+// Row layout (ns <= 2 states, ni <= 2 inputs, both run-time):
+//     A[ns][ns] | Bx[ns][ni] | E[ns] | ca[ns] | da[ni] | cy[ns] | dy[ni] | fy | R_port          (kN1 = wdf_ss_ncoef + 1 entries)
+// addressed as  crow[i * cs + t * ts + b * bs]: per-sample rows [T][kN1][B] (cs = B, ts = kN1 B, bs = 1) or ONE static row
+// (cs = 1, ts = bs = 0) through the same code.  x [B][T][ni]; y, dL/dy [T][B]; state stash [T][ns][B]; z0 / zT [ns][B].
+// One lane per sequence, sequential in time: the general path, not a fast one (the clipper topology keeps its own kernels).
+//
+// Reverse sweep (formulas: wdf_statespace.h ss_bwd_step): emits dL/d(row) for EVERY sample -- grow [T][kN1][B] -- because
+// with per-sample rows the chain rule to the component values runs per sample too (the host contracts it with the tape's
+// Jacobian); diode root: the lane sums of gb D_L, gb D_V (-> dL/dIs, dL/dnVt) and dL/dR_port = gb D_L / R_port in the row;
+// MLP root: gb = dL/db, a and log R_port per sample for the weight-gradient pass, dL/dR_port = gb (-dMLP/dlr) / R_port.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wdf_mlp.h"
+#include "wdf_statespace.h"
+
+namespace wdf {
+
+enum { kDynRootNone = 0, kDynRootDiode = 2, kDynRootMlp = 3 };
+constexpr int kDynMaxS = 2, kDynMaxI = 2;
+
+struct DynRow {                     // one step's coefficients in registers (entries beyond ns / ni are zero)
+    float A[kDynMaxS][kDynMaxS], Bx[kDynMaxS][kDynMaxI], E[kDynMaxS], ca[kDynMaxS], da[kDynMaxI], cy[kDynMaxS], dy[kDynMaxI], fy, rp;
+};
+
+struct DynLayout {                  // offsets of the row's groups for this (ns, ni)
+    int oA, oB, oE, oCa, oDa, oCy, oDy, oFy, oRp, n;
+    __host__ __device__ DynLayout(int ns, int ni)
+    {
+        oA = 0; oB = ns * ns; oE = oB + ns * ni; oCa = oE + ns; oDa = oCa + ns; oCy = oDa + ni; oDy = oCy + ns; oFy = oDy + ni;
+        oRp = oFy + 1; n = oRp + 1;
+    }
+};
+
+__device__ __forceinline__ DynRow dyn_load_row(const float* __restrict__ p, int64_t cs, const DynLayout& L, int ns, int ni)
+{
+    DynRow r;
+#pragma unroll
+    for (int s = 0; s < kDynMaxS; ++s) {
+        const bool ls = s < ns;
+#pragma unroll
+        for (int s2 = 0; s2 < kDynMaxS; ++s2) r.A[s][s2] = (ls && s2 < ns) ? p[(L.oA + s * ns + s2) * cs] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < kDynMaxI; ++i) r.Bx[s][i] = (ls && i < ni) ? p[(L.oB + s * ni + i) * cs] : 0.0f;
+        r.E[s] = ls ? p[(L.oE + s) * cs] : 0.0f;
+        r.ca[s] = ls ? p[(L.oCa + s) * cs] : 0.0f;
+        r.cy[s] = ls ? p[(L.oCy + s) * cs] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < kDynMaxI; ++i) {
+        r.da[i] = i < ni ? p[(L.oDa + i) * cs] : 0.0f;
+        r.dy[i] = i < ni ? p[(L.oDy + i) * cs] : 0.0f;
+    }
+    r.fy = p[L.oFy * cs];
+    r.rp = p[L.oRp * cs];
+    return r;
+}
+
+// The root of this step: b (and, for the reverse sweep, its partials).
+//   diode: rootp = {Is, nVt}; L = log(R_port Is / nVt)
+//   MLP:   lr = log R_port; b = -MLP(a, lr)
+template <int ROOT, bool SYM, int H, int NL>
+struct DynRoot {
+    float Is, V;
+    DiodeStatic d;
+    __device__ __forceinline__ void load(const float* __restrict__ rootp, int n_up, int n_down)
+    {
+        if constexpr (ROOT == kDynRootDiode) {
+            Is = rootp[0]; V = rootp[1];
+            d = make_diode_static(V, n_up, n_down);
+        }
+    }
+};
+
+// x [B][T][ni] -> y [T][B]; w_in: flat MLP weights (MLP root) -- H, NL are ignored for the other roots
+template <int ROOT, bool SYM, int H, int NL>
+__global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ crow, int64_t cs,
+                                                        int64_t ts, int64_t bs, const float* __restrict__ rootp,
+                                                        const float* __restrict__ w_in, int n_up, int n_down,
+                                                        float* __restrict__ y, float* __restrict__ zstash,
+                                                        const float* __restrict__ z0, float* __restrict__ zT, int ns, int ni,
+                                                        int64_t B, int64_t T)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    const DynLayout L(ns, ni);
+    DynRoot<ROOT, SYM, H, NL> root;
+    root.load(rootp, n_up, n_down);
+    __shared__ __attribute__((aligned(16))) float w[(ROOT == kDynRootMlp ? Mlp<H, NL>::kCount : 0) + 4];
+    if constexpr (ROOT == kDynRootMlp) {
+        for (int i = threadIdx.x; i < Mlp<H, NL>::kCount; i += 64) w[i] = w_in[i];
+        __syncthreads();
+    }
+    float z[kDynMaxS];
+#pragma unroll
+    for (int s = 0; s < kDynMaxS; ++s) z[s] = (s < ns && z0) ? z0[s * B + b] : 0.0f;
+    const float* __restrict__ xp = x + b * T * ni;
+    const float* __restrict__ cp = crow + b * bs;
+    [[maybe_unused]] float act[NL][H];
+    for (int64_t t = 0; t < T; ++t) {
+        if constexpr (ROOT == kDynRootMlp) asm volatile("" ::: "memory");      // re-read the weights from LDS every step (wdf_mlp.h)
+        const DynRow c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
+        float xv[kDynMaxI];
+#pragma unroll
+        for (int i = 0; i < kDynMaxI; ++i) xv[i] = i < ni ? xp[t * ni + i] : 0.0f;
+        float a = 0.0f;
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) a = fmaf(c.ca[s], z[s], a);
+#pragma unroll
+        for (int i = 0; i < kDynMaxI; ++i) a = fmaf(c.da[i], xv[i], a);
+        float broot = 0.0f;
+        if constexpr (ROOT == kDynRootDiode) broot = diode_pair<SYM>(a, logf(c.rp * root.Is / root.V), root.d).b;
+        if constexpr (ROOT == kDynRootMlp) broot = -Mlp<H, NL>::fwd(w, a, logf(c.rp), act);
+        float yv = c.fy * broot;
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) yv = fmaf(c.cy[s], z[s], yv);
+#pragma unroll
+        for (int i = 0; i < kDynMaxI; ++i) yv = fmaf(c.dy[i], xv[i], yv);
+        float zn[kDynMaxS];
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) {
+            float acc = c.E[s] * broot;
+#pragma unroll
+            for (int s2 = 0; s2 < kDynMaxS; ++s2) acc = fmaf(c.A[s][s2], z[s2], acc);
+#pragma unroll
+            for (int i = 0; i < kDynMaxI; ++i) acc = fmaf(c.Bx[s][i], xv[i], acc);
+            zn[s] = acc;
+        }
+        if (zstash) {
+#pragma unroll
+            for (int s = 0; s < kDynMaxS; ++s)
+                if (s < ns) zstash[(t * ns + s) * B + b] = z[s];
+        }
+        y[t * B + b] = yv;
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) z[s] = zn[s];
+    }
+    if (zT) {
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s)
+            if (s < ns) zT[s * B + b] = z[s];
+    }
+}
+
+// grow [T][kN1][B]; ws: double[gridDim.x][2] = the wave's {sum gb D_L, sum gb D_V} (diode root);
+// gbroot / ain / lrin [T][B] (MLP root): dL/db, a, log R_port of every step for mlp_wgrad_kernel
+template <int ROOT, bool SYM, int H, int NL>
+__global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ crow, int64_t cs,
+                                                        int64_t ts, int64_t bs, const float* __restrict__ rootp,
+                                                        const float* __restrict__ w_in, int n_up, int n_down,
+                                                        const float* __restrict__ zstash, const float* __restrict__ gy,
+                                                        float* __restrict__ grow, double* __restrict__ ws,
+                                                        float* __restrict__ gbroot, float* __restrict__ ain,
+                                                        float* __restrict__ lrin, float* __restrict__ gz0, int ns, int ni,
+                                                        int64_t B, int64_t T)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;
+    const DynLayout L(ns, ni);
+    DynRoot<ROOT, SYM, H, NL> root;
+    root.load(rootp, n_up, n_down);
+    __shared__ __attribute__((aligned(16))) float w[(ROOT == kDynRootMlp ? Mlp<H, NL>::kCount : 0) + 4];
+    if constexpr (ROOT == kDynRootMlp) {
+        for (int i = threadIdx.x; i < Mlp<H, NL>::kCount; i += 64) w[i] = w_in[i];
+        __syncthreads();
+    }
+    const float* __restrict__ xp = x + b * T * ni;
+    const float* __restrict__ cp = crow + b * bs;
+    float lam[kDynMaxS] = {0.0f, 0.0f};
+    double sL = 0.0, sV = 0.0;
+    [[maybe_unused]] float act[NL][H];
+    for (int64_t t = T - 1; t >= 0; --t) {
+        if constexpr (ROOT == kDynRootMlp) asm volatile("" ::: "memory");
+        const DynRow c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
+        float xv[kDynMaxI], z[kDynMaxS];
+#pragma unroll
+        for (int i = 0; i < kDynMaxI; ++i) xv[i] = i < ni ? xp[t * ni + i] : 0.0f;
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) z[s] = s < ns ? zstash[(t * ns + s) * B + b] : 0.0f;
+        const float g = gy[t * B + b];
+        float a = 0.0f;
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) a = fmaf(c.ca[s], z[s], a);
+#pragma unroll
+        for (int i = 0; i < kDynMaxI; ++i) a = fmaf(c.da[i], xv[i], a);
+        float broot = 0.0f, Da = 0.0f, Drp = 0.0f;                 // d b / d a, d b / d R_port
+        [[maybe_unused]] float DL = 0.0f, DV = 0.0f, lr = 0.0f;
+        if constexpr (ROOT == kDynRootDiode) {
+            const DiodeOut o = diode_pair<SYM>(a, logf(c.rp * root.Is / root.V), root.d);
+            broot = o.b;
+            const float w0p = o.w0 * fast_rcp(1.0f + o.w0), w1p = o.w1 * fast_rcp(1.0f + o.w1);
+            const float l2 = o.lam * o.lam, sp = w0p + w1p;
+            Da = fmaf(-2.0f * l2, sp, 1.0f);
+            DL = -root.d.two_v * o.lam * (o.m0 * w0p - o.m1 * w1p);
+            DV = fmaf(2.0f * l2 * a, sp * fast_rcp(root.V), -2.0f * o.lam * (o.m0 * o.w0 - o.m1 * o.w1));
+            Drp = DL / c.rp;                                        // L = log(R_port Is / nVt)
+        }
+        if constexpr (ROOT == kDynRootMlp) {
+            lr = logf(c.rp);
+            broot = -Mlp<H, NL>::fwd(w, a, lr, act);
+            float da, dlr;
+            Mlp<H, NL>::grad_in(w, act, da, dlr);
+            Da = -da;
+            Drp = -dlr / c.rp;
+        }
+        float gb = c.fy * g;
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) gb = fmaf(c.E[s], lam[s], gb);
+        const float ga = gb * Da;
+        float* __restrict__ gp = grow + (t * L.n) * B + b;
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) {
+            if (s < ns) {
+#pragma unroll
+                for (int s2 = 0; s2 < kDynMaxS; ++s2)
+                    if (s2 < ns) gp[(L.oA + s * ns + s2) * B] = lam[s] * z[s2];
+#pragma unroll
+                for (int i = 0; i < kDynMaxI; ++i)
+                    if (i < ni) gp[(L.oB + s * ni + i) * B] = lam[s] * xv[i];
+                gp[(L.oE + s) * B] = lam[s] * broot;
+                gp[(L.oCa + s) * B] = ga * z[s];
+                gp[(L.oCy + s) * B] = g * z[s];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kDynMaxI; ++i) {
+            if (i < ni) {
+                gp[(L.oDa + i) * B] = ga * xv[i];
+                gp[(L.oDy + i) * B] = g * xv[i];
+            }
+        }
+        gp[L.oFy * B] = g * broot;
+        gp[L.oRp * B] = gb * Drp;
+        if constexpr (ROOT == kDynRootDiode) {
+            sL += (double)(gb * DL);
+            sV += (double)(gb * DV);
+        }
+        if constexpr (ROOT == kDynRootMlp) {
+            gbroot[t * B + b] = gb;
+            ain[t * B + b] = a;
+            lrin[t * B + b] = lr;
+        }
+        float ln[kDynMaxS];
+#pragma unroll
+        for (int s2 = 0; s2 < kDynMaxS; ++s2) {
+            float v = fmaf(c.ca[s2], ga, c.cy[s2] * g);
+#pragma unroll
+            for (int s = 0; s < kDynMaxS; ++s) v = fmaf(c.A[s][s2], lam[s], v);
+            ln[s2] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) lam[s] = ln[s];
+    }
+    if (live && gz0) {
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s)
+            if (s < ns) gz0[s * B + b] = lam[s];
+    }
+    if (!live) { sL = 0.0; sV = 0.0; }
+    sL = wave_sum(sL);
+    sV = wave_sum(sV);
+    if (threadIdx.x == 0 && ws) {
+        ws[(int64_t)blockIdx.x * 2 + 0] = sL;
+        ws[(int64_t)blockIdx.x * 2 + 1] = sV;
+    }
+}
+
+}  // namespace wdf

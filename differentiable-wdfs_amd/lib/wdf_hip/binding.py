@@ -133,6 +133,14 @@ def lib():
     L.wdf_clipper_asym_bwd_tp_ws_bytes.argtypes = [i64, ci]
     L.wdf_clipper_asym_bwd_tp.restype = ci
     L.wdf_clipper_asym_bwd_tp.argtypes = [fp, fp, cf, ci, fp, fp, fp, fp, vp, fp, fp, i64, i64, ci, vp]
+    L.wdf_ss_dyn_row_len.restype = ci
+    L.wdf_ss_dyn_row_len.argtypes = [ci, ci]
+    L.wdf_ss_dyn_fwd.restype = ci
+    L.wdf_ss_dyn_fwd.argtypes = [fp, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, vp]
+    L.wdf_ss_dyn_bwd_ws_bytes.restype = C.c_size_t
+    L.wdf_ss_dyn_bwd_ws_bytes.argtypes = [i64]
+    L.wdf_ss_dyn_bwd.restype = ci
+    L.wdf_ss_dyn_bwd.argtypes = [fp, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, fp, fp, fp, vp, fp, fp, fp, fp, i64, i64, vp]
     L.wdf_asym_root.restype = ci
     L.wdf_asym_root.argtypes = [fp, fp, cf, ci, C.c_double, ci, vp, i64, vp]
     L.wdf_mlp_weight_count.restype = ci
@@ -266,6 +274,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_step_mse_tp", "wdf_clipper_step_esr_tp", "wdf_esr_finish", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_loss_esr_grad", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_clipper_asym_fwd_tp_ws_bytes", "wdf_clipper_asym_fwd_tp", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd",
     "wdf_clipper_asym_bwd_tp_ws_bytes", "wdf_clipper_asym_bwd_tp", "wdf_asym_root",
+    "wdf_ss_dyn_row_len", "wdf_ss_dyn_fwd", "wdf_ss_dyn_bwd_ws_bytes", "wdf_ss_dyn_bwd",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
     "wdf_clipper_mlp_tp_chunks", "wdf_clipper_mlp_fwd_tp_ws_bytes", "wdf_clipper_mlp_fwd_tp",
@@ -1026,7 +1035,7 @@ def asym_root(a, theta6, fs, mode, tol=1e-12, max_iter=50):
     return b
 
 
-ROOT_NONE, ROOT_DIODE_PAIR = 0, 2
+ROOT_NONE, ROOT_DIODE_PAIR, ROOT_MLP = 0, 2, 3
 
 
 def ss_fwd(x, coef, ns, ni, root_kind=ROOT_NONE, rootp=None, n_up=1, n_down=1, want_stash=True, z0=None,
@@ -1128,6 +1137,57 @@ def ss_fwd_tp(x, coef, ns, ni, rootp, n_chunks, warmup, tol=1e-6, n_up=1, n_down
 def ss_tp_status(status):
     s = status.cpu()
     return {"n_bad": int(s[0]), "max_miss": float(s[1:2].view(torch.float32)[0]), "gated_waves": int(s[2])}
+
+
+def ss_dyn_fwd(x, rows, ns, ni, root_kind=ROOT_NONE, rootp=None, w=None, hidden=0, n_tanh=0, n_up=1, n_down=1, want_stash=True,
+               z0=None, want_zT=False):
+    """State-space recursion with streamed coefficient rows / the MLP root on any small tree (wdf_ss_dyn_fwd).
+    x [B,T,ni]; rows [T,n,B] (per sample) or [n] (one static row), n = wdf_ss_dyn_row_len(ns, ni).
+    -> y [T,B], zstash [T,ns,B] | None, zT [ns,B] | None."""
+    require_gpu()
+    x, rows, rootp, w, z0 = _f32_dev(x, "x"), _f32_dev(rows, "rows"), _f32_dev(rootp, "rootp"), _f32_dev(w, "w"), _f32_dev(z0, "z0")
+    B, T = int(x.shape[0]), int(x.shape[1])
+    n = lib().wdf_ss_dyn_row_len(int(ns), int(ni))
+    per = rows.dim() == 3
+    if n == 0 or tuple(rows.shape) not in ((T, n, B), (n,)) or x.dim() != 3 or int(x.shape[2]) != ni:
+        raise WdfHipError(f"ss_dyn_fwd: x [B,T,{ni}], rows [T,{n},B] or [{n}] (got x {tuple(x.shape)}, rows {tuple(rows.shape)})")
+    y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zs = torch.empty((T, max(ns, 1), B), dtype=torch.float32, device=x.device) if (want_stash and ns > 0) else None
+    zT = torch.empty((max(ns, 1), B), dtype=torch.float32, device=x.device) if want_zT else None
+    rc = lib().wdf_ss_dyn_fwd(_ptr(x), _ptr(rows), 1 if per else 0, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
+                              int(n_tanh), int(n_up), int(n_down), _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, _stream())
+    _check(rc, "wdf_ss_dyn_fwd")
+    return y, zs, zT
+
+
+def ss_dyn_bwd(x, rows, ns, ni, zstash, gy, root_kind=ROOT_NONE, rootp=None, w=None, hidden=0, n_tanh=0, n_up=1, n_down=1, want_gz0=False):
+    """Reverse sweep of ss_dyn_fwd for dL/dy = gy [T,B] (wdf_ss_dyn_bwd).
+    -> grows [T,n,B] (dL/d row entry of every sample), groot (diode: float64 [2] = dL/d{Is, nVt}; MLP: the flat weight gradient;
+    else None), gz0 [ns,B] | None."""
+    require_gpu()
+    x, rows, rootp, w = _f32_dev(x, "x"), _f32_dev(rows, "rows"), _f32_dev(rootp, "rootp"), _f32_dev(w, "w")
+    zstash, gy = _f32_dev(zstash, "zstash"), _f32_dev(gy, "gy")
+    B, T = int(x.shape[0]), int(x.shape[1])
+    n = lib().wdf_ss_dyn_row_len(int(ns), int(ni))
+    per = rows.dim() == 3
+    dev = x.device
+    grows = torch.empty((T, n, B), dtype=torch.float32, device=dev)
+    ws = torch.zeros(((B + 63) // 64, 2), dtype=torch.float64, device=dev)
+    mlp = root_kind == ROOT_MLP
+    gb, ain, lrin = (torch.empty((T, B), dtype=torch.float32, device=dev) for _ in range(3)) if mlp else (None, None, None)
+    gz0 = torch.empty((max(ns, 1), B), dtype=torch.float32, device=dev) if want_gz0 else None
+    rc = lib().wdf_ss_dyn_bwd(_ptr(x), _ptr(rows), 1 if per else 0, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
+                              int(n_tanh), int(n_up), int(n_down), _ptr(zstash), _ptr(gy), _ptr(grows), _ptr(ws), _ptr(gb), _ptr(ain),
+                              _ptr(lrin), _ptr(gz0), B, T, _stream())
+    _check(rc, "wdf_ss_dyn_bwd")
+    groot = None
+    if root_kind == ROOT_DIODE_PAIR:
+        s = ws.sum(dim=0)
+        rp = rootp.double()
+        groot = torch.stack([s[0] / rp[0], s[1] - s[0] / rp[1]])
+    elif mlp:
+        groot = clipper_mlp_wgrad(ain.reshape(-1), lrin.reshape(-1), gb.reshape(-1), None, w, hidden, n_tanh, 1.0)
+    return grows, groot, gz0
 
 
 def ss_bwd_tp(x, coef, ns, ni, zstash, gy, n_chunks, root_kind=ROOT_NONE, rootp=None, n_up=1, n_down=1, want_gz0=False):

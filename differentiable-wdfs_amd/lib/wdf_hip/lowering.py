@@ -153,6 +153,44 @@ class _StateSpaceFn(torch.autograd.Function):
         return gcoef, groot, None, gz0, None, None, None, None, None, None, None, None
 
 
+class _SsDynFn(torch.autograd.Function):
+    """y [T,B] = the state-space recursion with streamed coefficient rows and / or the MLP root (csrc/wdf_ss_dyn.h).
+    rows: [T,n,B] (per-sample impedance) or [n] (static), n = A | Bx | E | ca | da | cy | dy | fy | R_port.
+    rootvec: {Is, nVt} (diode root), the flat weights (MLP root) or None.  The reverse sweep hands back dL/d(row entry) for
+    every sample; torch chains it through the rows' own graph (the probe tape evaluated over the resistance channel) to the
+    component values -- calc_impedance's chain rule per sample (tf_wdf.py:114-115,139-145,168-177)."""
+
+    @staticmethod
+    def forward(ctx, rows, rootvec, x, z0, ns, ni, kind, hidden, n_tanh, n_up, n_down, want_zT):
+        need = rows.requires_grad or (rootvec is not None and rootvec.requires_grad) or (z0 is not None and z0.requires_grad)
+        r = rows.detach().float().contiguous()
+        rv = None if rootvec is None else rootvec.detach().float().contiguous()
+        z0d = None if z0 is None else z0.detach().float().contiguous()
+        rootp, w = (rv, None) if kind == binding.ROOT_DIODE_PAIR else (None, rv)
+        y, zs, zT = binding.ss_dyn_fwd(x, r, ns, ni, kind, rootp=rootp, w=w, hidden=hidden, n_tanh=n_tanh, n_up=n_up, n_down=n_down,
+                                       want_stash=need, z0=z0d, want_zT=want_zT)
+        ctx.cfg = (ns, ni, kind, hidden, n_tanh, n_up, n_down, z0 is not None, rows.dim() == 3)
+        ctx.save_for_backward(r, rv, x, zs)
+        if want_zT:
+            ctx.mark_non_differentiable(zT)
+            return y, zT
+        return y, None
+
+    @staticmethod
+    def backward(ctx, gy, _gzT):
+        ns, ni, kind, hidden, n_tanh, n_up, n_down, has_z0, per_sample = ctx.cfg
+        r, rv, x, zs = ctx.saved_tensors
+        rootp, w = (rv, None) if kind == binding.ROOT_DIODE_PAIR else (None, rv)
+        if zs is None:
+            zs = torch.zeros((x.shape[1], 1, x.shape[0]), dtype=torch.float32, device=x.device)      # (ns = 0: nothing to read)
+        grows, groot, gz0 = binding.ss_dyn_bwd(x, r, ns, ni, zs, gy.contiguous(), kind, rootp=rootp, w=w, hidden=hidden, n_tanh=n_tanh,
+                                               n_up=n_up, n_down=n_down, want_gz0=has_z0)
+        if not per_sample:
+            grows = grows.double().sum(dim=(0, 2)).float()
+        return (grows, None if groot is None else groot.float(), None, (gz0[:ns] if has_z0 else None), None, None, None, None, None,
+                None, None, None)
+
+
 # ------------------------------------------------------------------------------ resident linear trees
 _LIN_OCC = int(os.environ.get("WDF_LIN_OCC", "2"))       # chunks are cut so that every SIMD gets this many waves
 _NL_OCC = int(os.environ.get("WDF_NL_OCC", "1"))
@@ -516,11 +554,17 @@ class Circuit:
         self.ns = len(self.caps)
         self.ni = len(self.sources) + (1 if self.root_kind == "IdealVoltageSource" else 0)
         self.per_sample_R = per_sample_R
-        if per_sample_R is not None and not self._is_clipper():
-            raise binding.WdfHipError("a per-sample resistance channel is supported on the diode-clipper topology "
-                                      "Parallel(ResistiveVoltageSource, Capacitor) only (clipper_pot.py:94-101)")
+        if per_sample_R is not None and (per_sample_R not in self.elements or _kind(per_sample_R) not in ("ResistiveVoltageSource", "Resistor")):
+            raise ValueError("per_sample_R must be a ResistiveVoltageSource or a Resistor of the tree (set_resistance: "
+                             "tf_wdf.py:51-52,80-81)")
         if self.ni < 1:
             raise ValueError("the circuit has no voltage source")
+        # Outside the clipper topology a per-sample impedance or a DenseRootModel root runs on the streamed-coefficient kernels
+        # (csrc/wdf_ss_dyn.h): any tree of at most two capacitors and two sources
+        self._dyn = (per_sample_R is not None or self.root_kind == "DenseRootModel") and (self.force_generic or not self._is_clipper())
+        if self._dyn and (self.ns > 2 or self.ni > 2):
+            raise binding.WdfHipError("a per-sample resistance channel / an MLP root outside the clipper topology: trees of at most "
+                                      f"two capacitors and two sources (this one has {self.ns} and {self.ni})")
 
     # -- device-resident component values
     def to_device(self, device="cuda"):
@@ -533,6 +577,9 @@ class Circuit:
         binding.require_gpu()
         if any(getattr(self, a, None) is not None for a in ("_lin", "_pblock", "_tree", "_mlp")):
             return self
+        if self._dyn:
+            raise binding.WdfHipError("Circuit.to_device: a per-sample impedance / an MLP root outside the clipper topology runs on the "
+                                      "streamed-coefficient kernels with host-resident component values (no resident step)")
         if self.root_kind == "DenseRootModel":
             if not self._is_clipper():
                 raise binding.WdfHipError("the MLP root is supported on the diode-clipper topology (clipper_pot.py:94-101)")
@@ -774,6 +821,8 @@ class Circuit:
             raise binding.WdfHipError(f"x must be [B,T,{nchan}] (or [B,T] for one channel), got {tuple(x.shape)}")
         dev = x.device
 
+        if self._dyn:
+            return self._run_dyn(x, z0, return_state)
         if self._is_clipper() and self.root_kind == "DiodePair" and not self.force_generic:
             return self._run_clipper(x, z0, return_state)
         if self.root_kind == "DenseRootModel":
@@ -833,6 +882,60 @@ class Circuit:
                                     bool(return_state), tp, warm)
         y = y.as_subclass(tf.Tensor)
         return (y, zT) if return_state else y
+
+    def _run_dyn(self, x, z0, return_state):
+        """Per-sample impedance on any small tree and / or the MLP root on any small tree (csrc/wdf_ss_dyn.h).
+        The probed step is recorded once as a scalar tape over the component values (probe_tape.record: the elements' own
+        calc_impedance / reflected / incident code); with a resistance channel the tape is evaluated over the whole channel
+        in torch -- one coefficient row per (sample, sequence), with the autograd graph back to the static components -- which
+        is set_resistance + calc_impedance every step (clipper_pot.py:116-117) hoisted out of the time loop."""
+        from . import probe_tape
+        dev = x.device
+        B, T = int(x.shape[0]), int(x.shape[1])
+        own = {"Resistor": "R", "ResistiveVoltageSource": "R", "Capacitor": "C"}
+        if getattr(self, "_dyn_tape", None) is None:
+            params = [(e, own[_kind(e)]) for e in self.elements if _kind(e) in own]
+            pvars = [e.__dict__[n] for e, n in params]
+            tape, outs, rport = probe_tape.record(self, pvars, device_limits=False)
+            self._dyn_tape = (tape, outs + [rport], params)
+        tape, outs, params = self._dyn_tape
+        vals = []
+        for e, n in params:
+            if e is self.per_sample_R:
+                vals.append(x[:, :, self.ni].double())                            # the resistance channel: [B,T]
+            else:
+                v = e.__dict__[n]
+                v = v.as_subclass(torch.Tensor) if isinstance(v, torch.Tensor) else torch.tensor(float(v))
+                vals.append(v.double().reshape(()).to(dev))
+        with torch._C.DisableTorchFunctionSubclass():
+            nodes = tape.evaluate_torch(vals, outs)
+            if self.per_sample_R is not None:
+                rows = torch.stack([torch.broadcast_to(v, (B, T)) for v in nodes], dim=0)       # [n,B,T]
+                rows = rows.permute(2, 0, 1).float().contiguous()                                # [T,n,B]
+            else:
+                rows = torch.stack([v.reshape(()) for v in nodes]).float()                       # one static row [n]
+        hidden = n_tanh = 0
+        n_up = n_down = 1
+        if self.root_kind == "DiodePair":
+            dp = self.root
+            rootvec = torch.stack([dp.Is.as_subclass(torch.Tensor).double().reshape(()),
+                                   dp.nVt.as_subclass(torch.Tensor).double().reshape(())]).to(device=dev, dtype=torch.float32)
+            kind, n_up, n_down = binding.ROOT_DIODE_PAIR, dp.N_up, dp.N_down
+        elif self.root_kind == "DenseRootModel":
+            from . import mlp_root
+            dense, hidden, n_tanh, act = mlp_root.describe(self.root, with_activation=True)
+            if act != "tanh":
+                raise binding.WdfHipError("the MLP root outside the clipper topology: tanh networks (the ReLU kernels are the "
+                                          "clipper's resident step)")
+            rootvec = mlp_root.flat_weights(dense).float().to(dev)
+            kind = binding.ROOT_MLP
+        else:
+            rootvec, kind = None, binding.ROOT_NONE
+        z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(self.ns, -1).contiguous()
+        xs = x[:, :, :self.ni].contiguous()
+        y, zT = _SsDynFn.apply(rows, rootvec, xs, z0t, self.ns, self.ni, kind, hidden, n_tanh, n_up, n_down, bool(return_state))
+        y = y.as_subclass(tf.Tensor)
+        return (y, zT[:self.ns]) if return_state else y
 
     def _run_clipper(self, x, z0, return_state):
         from . import engine

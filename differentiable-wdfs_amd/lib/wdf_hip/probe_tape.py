@@ -138,6 +138,33 @@ class Tape:
         out = np.asarray(outputs, dtype=np.int64)
         return val[out], tan[out]
 
+    def evaluate_torch(self, params, outputs):
+        """The tape on torch values, with autograd: params are tensors -- 0-dim (a component value) or of any common shape
+        (a per-sample resistance channel [B,T]: every node that depends on it takes that shape, the others stay scalars).
+        -> the output nodes' tensors, in order.  What wdf_ss_dyn_* rows are made of (lowering.Circuit._run_dyn)."""
+        import torch
+        ref = next((p for p in params if isinstance(p, torch.Tensor)), None)
+        kw = {} if ref is None else {"dtype": ref.dtype, "device": ref.device}
+        val = [None] * len(self.ops)
+        for i, (op, a, b) in enumerate(self.ops):
+            if op == OP_CONST:
+                val[i] = torch.tensor(self.consts[a], **kw)
+            elif op == OP_PARAM:
+                val[i] = params[a]
+            elif op == OP_ADD:
+                val[i] = val[a] + val[b]
+            elif op == OP_SUB:
+                val[i] = val[a] - val[b]
+            elif op == OP_MUL:
+                val[i] = val[a] * val[b]
+            elif op == OP_DIV:
+                val[i] = val[a] / val[b]
+            elif op == OP_NEG:
+                val[i] = -val[a]
+            elif op == OP_RECIP:
+                val[i] = torch.reciprocal(val[a])
+        return [val[int(o)] for o in outputs]
+
     def packed(self):
         """(int32 [n_ops, 3], float64 [n_consts]) for the device."""
         return np.asarray(self.ops, dtype=np.int32).reshape(-1, 3), np.asarray(self.consts, dtype=np.float64)
@@ -202,7 +229,7 @@ class PVal:
         return self.tape.const(0.0 if fn_name == "zeros_like" else 1.0)
 
 
-def record(circ, param_vars):
+def record(circ, param_vars, device_limits=True):
     """Trace one probed step of lowering.Circuit `circ`.  param_vars: the component Variables (each an attribute `R` or `C`
     of an element) in parameter order.  -> (Tape, output node of every entry of the coefficient vector, in the layout of
     Circuit.matrices(): A, Bx, E, ca, da, cy, dy, fy).  Linear trees (ideal-source root folded in) and diode-pair roots."""
@@ -263,7 +290,7 @@ def record(circ, param_vars):
     tape, nodes = tape.pruned([v.n for v in flat] + [r_port.n])
     tape.n_recorded = n_recorded
     flat_n, rport_n = nodes[:-1], nodes[-1]
-    if len(tape.ops) > MAX_OPS or len(param_vars) > MAX_PARAMS:
+    if device_limits and (len(tape.ops) > MAX_OPS or len(param_vars) > MAX_PARAMS):
         from . import binding
         raise binding.WdfHipError(f"the probed step needs {len(tape.ops)} operations on {len(param_vars)} component values; "
                                   f"the device probe holds {MAX_OPS} on {MAX_PARAMS}")

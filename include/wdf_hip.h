@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WDF_HIP_ABI_VERSION 5   /* 5: + wdf_clipper_asym_bwd_tp (round 5).  3: + wdf_clipper_mlp_step_* (round 4); TpCtl is 128 bytes, warm-up units are 16 steps.  4: + wdf_ss_nl_step_*; the linear step's workspace shrank */
+#define WDF_HIP_ABI_VERSION 5   /* 5: + wdf_clipper_asym_bwd_tp, wdf_ss_dyn_* (round 5).  3: + wdf_clipper_mlp_step_* (round 4); TpCtl is 128 bytes, warm-up units are 16 steps.  4: + wdf_ss_nl_step_*; the linear step's workspace shrank */
 
 enum {
     WDF_OK = 0,
@@ -420,7 +420,7 @@ int wdf_clipper_mlp_step(const float* x, const float* p, const float* lr, const 
  * x       [B][T][ni] ; y [T][B] ; zstash [T][ns][B] ; z0, zT, gz0 [ns][B]
  * bwd:    gcoef[ncoef] = dL/dcoef, groot[3] = dL/d{Is, nVt, R_port}; ws of wdf_ss_bwd_ws_bytes.
  * ---------------------------------------------------------------------------------- */
-enum { WDF_ROOT_NONE = 0, WDF_ROOT_DIODE_PAIR = 2 };
+enum { WDF_ROOT_NONE = 0, WDF_ROOT_DIODE_PAIR = 2, WDF_ROOT_MLP = 3 /* wdf_ss_dyn_* only */ };
 
 int wdf_ss_ncoef(int ns, int ni);
 int wdf_ss_fwd(const float* x, const float* coef, const float* rootp,
@@ -463,6 +463,33 @@ int wdf_ss_bwd_tp(const float* x, const float* coef, const float* rootp, int ns,
                   const float* zstash, const float* gy, void* ws, float* gcoef, float* groot, float* gz0, int64_t B, int64_t T,
                   int n_chunks, void* stream);
 size_t wdf_ss_bwd_ws_bytes(int ns, int ni, int64_t B);
+
+/* ------------------------------------------------------------------------------------
+ * State-space recursion with PER-SAMPLE coefficient rows, and the MLP root on any small tree (round 5; csrc/wdf_ss_dyn.h).
+ * Replaces, for any tree of <= 2 capacitors and <= 2 sources:
+ *   - a per-sample impedance: set_resistance on any ResistiveVoltageSource / Resistor (tf_wdf.py:51-52,80-81) followed by
+ *     calc_impedance every step (clipper_pot.py:116-117) -- the host evaluates the probed step's coefficients over the whole
+ *     resistance channel and hands one ROW per (sample, sequence);
+ *   - layers.DenseRootModel terminating the tree (layers.py:72-82): b = -MLP(a, log R_port) (clipper_pot.py:119-121).
+ * rows       per_sample = 1: device float [T][n][B]; per_sample = 0: ONE row, float [n];  n = wdf_ss_dyn_row_len(ns, ni) =
+ *            wdf_ss_ncoef(ns, ni) + 1:  A | Bx | E | ca | da | cy | dy | fy | R_port   (the coef layout above, then the port resistance)
+ * root       WDF_ROOT_NONE, WDF_ROOT_DIODE_PAIR (rootp = device float[2] {Is, nVt}; R_port comes from the row) or WDF_ROOT_MLP
+ *            (w: flat weights, hidden in {4, 8, 16} with 3 tanh layers, {4, 8} with 5; tanh only)
+ * x [B][T][ni]; y, gy [T][B]; zstash [T][ns][B]; z0 / zT / gz0 [ns][B] (optional).
+ * wdf_ss_dyn_bwd: reverse sweep for dL/dy = gy.  grows [T][n][B] receives dL/d(row entry) of EVERY sample (per_sample = 0: the
+ *            caller sums over T and B); ws (wdf_ss_dyn_bwd_ws_bytes): double [(B+63)/64][2] = per-wave {sum gb D_L, sum gb D_V}
+ *            of a diode root (dL/dIs = S_L / Is, dL/dnVt = S_V - S_L / nVt); MLP root: gb, ain, lrin [T][B] receive dL/db, a and
+ *            log R_port of every step -- the operands of wdf_clipper_mlp_wgrad (gw = -sum gb dMLP/dw).
+ * One lane per sequence, sequential in time: the general path (the clipper topology keeps its own kernels).
+ * ---------------------------------------------------------------------------------- */
+int wdf_ss_dyn_row_len(int ns, int ni);
+int wdf_ss_dyn_fwd(const float* x, const float* rows, int per_sample, int ns, int ni, int root, const float* rootp, const float* w,
+                   int hidden, int n_tanh_layers, int n_up, int n_down, float* y, float* zstash, const float* z0, float* zT,
+                   int64_t B, int64_t T, void* stream);
+size_t wdf_ss_dyn_bwd_ws_bytes(int64_t B);
+int wdf_ss_dyn_bwd(const float* x, const float* rows, int per_sample, int ns, int ni, int root, const float* rootp, const float* w,
+                   int hidden, int n_tanh_layers, int n_up, int n_down, const float* zstash, const float* gy, float* grows,
+                   void* ws, float* gb, float* ain, float* lrin, float* gz0, int64_t B, int64_t T, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Clipper with two DIFFERENT antiparallel diodes (BASELINE config 5; csrc/wdf_asym.h).  New

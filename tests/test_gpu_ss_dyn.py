@@ -1,0 +1,236 @@
+"""GPU: per-sample impedance and the MLP root on ANY small tree (csrc/wdf_ss_dyn.h, lowering.Circuit._run_dyn).
+
+In the reference set_resistance replaces R on any ResistiveVoltageSource / Resistor (tf_wdf.py:51-52,80-81), calc_impedance is
+legal every step on any tree (clipper_pot.py:116-117) and DenseRootModel terminates any tree (layers.py:72-82).  Held against
+the oracle's tree interpreter (fp64; per-sample resistance channel `rin`, MLP root, complex-step gradients):
+  * HPFDiodeClipper.h:28-32's tree Parallel(R, Series(ResistiveVoltageSource, C)) with a pot channel on the source resistance,
+    diode-pair root: y and dL/d{R, C, Is, nVt};
+  * the same tree with the pot on the parallel RESISTOR;
+  * the same tree under a DenseRootModel root, static and with the pot channel: y, dL/d{R, C} and weight gradients;
+  * the RC lowpass of lpf.py:20-29 (ideal-source root) with a per-sample resistor;
+  * the clipper topology forced through these kernels against the clipper kernels' golden (g6, pot channel).
+Tolerances: y 3e-6 V (fp32 recursion), gradients 3e-4 relative (fp32 sweep, rows formed in fp64 and rounded to fp32).
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+FS = 48000.0
+
+
+def cuda(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
+
+
+@pytest.fixture
+def wdf():
+    import tf_wdf
+    return tf_wdf
+
+
+def pot_channel(B, T, lo, hi, seed):
+    """a slowly moving pot per sequence: log-uniform level, a slow sine on top (every sample its own resistance)"""
+    rng = np.random.default_rng(seed)
+    base = np.exp(rng.uniform(np.log(lo), np.log(hi), B))
+    wob = 1.0 + 0.3 * np.sin(2 * np.pi * np.arange(T)[None, :] / rng.uniform(200, 900, B)[:, None] + rng.uniform(0, 6, B)[:, None])
+    return (base[:, None] * wob).astype(np.float32)
+
+
+def hpf_oracle(O, root, pot_on, fs=FS, sizes=None, acts=None):
+    """nodes: R (param 0), Vs (param 1, voltage channel 0), C (param 2), Series(Vs, C), Parallel(R, Series)"""
+    rin_r = 1 if pot_on == "R" else -1
+    rin_s = 1 if pot_on == "Vs" else -1
+    nodes = [(O.NODE_RESISTOR, -1, -1, 0, -1, rin_r), (O.NODE_RES_VSOURCE, -1, -1, 1, 0, rin_s), (O.NODE_CAPACITOR, -1, -1, 2, -1, -1),
+             (O.NODE_SERIES, 1, 2, -1, -1, -1), (O.NODE_PARALLEL, 0, 3, -1, -1, -1)]
+    n_in = 2 if pot_on else 1
+    if root == "diode":
+        return O.Circuit(nodes, top=4, probe=0, n_in=n_in, root_kind=O.ROOT_DIODE_PAIR, fs=fs, p_is=3, p_nvt=4, n_up=1, n_down=2)
+    return O.Circuit(nodes, top=4, probe=0, n_in=n_in, root_kind=O.ROOT_MLP, fs=fs, mlp_off=3, mlp_sizes=sizes, mlp_act=acts)
+
+
+def build_hpf(wdf, root, pot_on, vals, net=None):
+    R = wdf.Resistor(vals[0], True)
+    Vs = wdf.ResistiveVoltageSource(vals[1], trainable=True)
+    C = wdf.Capacitor(vals[2], FS, True)
+    top = wdf.Parallel(R, wdf.Series(Vs, C))
+    if root == "diode":
+        rt = wdf.DiodePair(top, vals[3], Vt=vals[4], nDiodes=1.0, N_up=1, N_down=2, trainable=True)
+        params = [R.R, Vs.R, C.C, rt.Is, rt.nVt]
+    else:
+        from layers import DenseRootModel
+        rt = DenseRootModel(net)
+        params = [R.R, Vs.R, C.C]
+    pot = {"Vs": Vs, "R": R, None: None}[pot_on]
+    return wdf.Circuit(top, rt, R, per_sample_R=pot), params, rt
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+@pytest.mark.parametrize("pot_on,B,T", [("Vs", 37, 300), ("R", 70, 257), ("Vs", 130, 1024)])
+def test_hpf_clipper_with_a_pot_channel_diode_root(wdf, oracle, pot_on, B, T):
+    tf = wdf.tf
+    O = oracle
+    vals = [33.0e3, 1.0e3, 22.0e-9, 4.352e-9, 25.85e-3 * 1.906]
+    rng = np.random.default_rng(B + T)
+    x = (1.5 * rng.standard_normal((B, T))).astype(np.float32)
+    r = pot_channel(B, T, 300.0, 5.0e3, 1) if pot_on == "Vs" else pot_channel(B, T, 5.0e3, 80.0e3, 2)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    circ, params, _ = build_hpf(wdf, "diode", pot_on, vals)
+    xin = cuda(np.stack([x, r], axis=-1))
+    with tf.GradientTape() as tape:
+        y = circ(xin)
+        loss = tf.reduce_sum(y * cuda(gy))
+    grads = tape.gradient(loss, params)
+    oc = hpf_oracle(O, "diode", pot_on)
+    theta = np.array(vals, dtype=np.float32).astype(np.float64)
+    xin64 = np.stack([x, r], axis=-1).astype(np.float64)
+    y_ref = O.tree_fwd(oc, theta, xin64)
+    assert np.max(np.abs(y.cpu().numpy() - y_ref)) < 3e-6
+    live = [i for i in range(5) if not (i == 0 and pot_on == "R") and not (i == 1 and pot_on == "Vs")]   # the streamed one has no gradient
+    g_ref = O.tree_grad(oc, theta, xin64, gy.astype(np.float64), params=live)
+    got = np.array([float(grads[i]) for i in live])
+    assert rel(got, g_ref) < 3e-4, (got, g_ref)
+    dead = 0 if pot_on == "R" else 1
+    assert grads[dead] is None or float(grads[dead]) == 0.0
+
+
+def _net(golden, name):
+    from test_gpu_mlp_root import model_json
+    g = golden("g3_mlp_clipper.npz")
+    return model_json(g, name), g[f"{name}_theta"].astype(np.float64), [int(v) for v in g[f"{name}_sizes"]]
+
+
+@pytest.mark.parametrize("pot_on,name", [(None, "2x8"), ("Vs", "2x8"), ("Vs", "2x16"), ("R", "4x4")])
+def test_hpf_tree_under_an_mlp_root(wdf, oracle, golden, pot_on, name):
+    """DenseRootModel on a tree that is NOT the clipper: b = -MLP(a, log R_port) (clipper_pot.py:119-121), R_port per sample
+    when a pot channel moves it.  y, dL/d{R, Rs, C} and the weight gradient (every bias, first and last layer, every 7th
+    hidden-kernel entry) against the oracle's complex-step derivative."""
+    tf = wdf.tf
+    O = oracle
+    js, w64, sizes = _net(golden, name)
+    B, T = 24, 200
+    vals = [33.0e3, 4.0e3, 22.0e-9]
+    rng = np.random.default_rng(len(name) + (0 if pot_on is None else 5))
+    x = (0.8 * rng.standard_normal((B, T))).astype(np.float32)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    circ, params, model = build_hpf(wdf, "mlp", pot_on, vals, net=js)
+    if pot_on is None:
+        xin, xin64 = cuda(x), x.astype(np.float64)[:, :, None]
+    else:
+        r = pot_channel(B, T, 1.0e3, 20.0e3, 3) if pot_on == "Vs" else pot_channel(B, T, 8.0e3, 90.0e3, 4)
+        xin, xin64 = cuda(np.stack([x, r], axis=-1)), np.stack([x, r], axis=-1).astype(np.float64)
+    weights = list(model.trainable_variables)
+    with tf.GradientTape() as tape:
+        y = circ(xin)
+        loss = tf.reduce_sum(y * cuda(gy))
+    grads = tape.gradient(loss, params + weights)
+    acts = [O.ACT_TANH] * (len(sizes) - 2) + [O.ACT_NONE]
+    oc = hpf_oracle(O, "mlp", pot_on, sizes=sizes, acts=acts)
+    theta = np.concatenate([np.array(vals, dtype=np.float32).astype(np.float64), w64.astype(np.float32).astype(np.float64)])
+    y_ref = O.tree_fwd(oc, theta, xin64)
+    assert np.max(np.abs(y.cpu().numpy() - y_ref)) < 3e-6
+    live = [i for i in range(3) if not (i == 0 and pot_on == "R") and not (i == 1 and pot_on == "Vs")]
+    g_ref = O.tree_grad(oc, theta, xin64, gy.astype(np.float64), params=live)
+    got = np.array([float(grads[i]) for i in live])
+    assert rel(got, g_ref) < 3e-4, (got, g_ref)
+    # weights: the flat order of the oracle is kernel, bias per layer; trainable_variables lists bias before kernel per layer
+    flat = {}
+    o = 3
+    for l in range(len(sizes) - 1):
+        nk = sizes[l] * sizes[l + 1]
+        flat[("k", l)] = (o, nk); o += nk
+        flat[("b", l)] = (o, sizes[l + 1]); o += sizes[l + 1]
+    dense = [d for d in model.layers if type(d).__name__ == "DenseLayer"]
+    gw = np.zeros(len(theta))
+    gmap = {id(v): g for v, g in zip(weights, grads[3:])}
+    for l, d in enumerate(dense):
+        ok, nk = flat[("k", l)]
+        gw[ok:ok + nk] = gmap[id(d.kernel)].cpu().numpy().reshape(-1)
+        ob, nb = flat[("b", l)]
+        gw[ob:ob + nb] = gmap[id(d.bias)].cpu().numpy().reshape(-1)
+    pick = sorted(set(list(range(3, 3 + 3 * sizes[1])) + list(range(len(theta) - sizes[-2] - 1, len(theta))) + list(range(3, len(theta), 7))))
+    gw_ref = O.tree_grad(oc, theta, xin64, gy.astype(np.float64), params=pick)
+    scale = np.max(np.abs(gw_ref))
+    assert np.max(np.abs(gw[pick] - gw_ref)) < 3e-4 * scale, (np.max(np.abs(gw[pick] - gw_ref)), scale)
+
+
+def test_rc_lowpass_with_a_per_sample_resistor(wdf, oracle):
+    """lpf.py:20-29's tree Inverter(Series(R1, C1)) under the ideal source, R1 driven per sample (Resistor.set_resistance,
+    tf_wdf.py:80-81): the ideal-source root folds into the rows like it folds into the static matrices."""
+    tf = wdf.tf
+    O = oracle
+    B, T = 50, 400
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((B, T)).astype(np.float32)
+    r = pot_channel(B, T, 300.0, 3.0e3, 9)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    R1, C1 = wdf.Resistor(1000.0, True), wdf.Capacitor(1.0e-6, FS, True)
+    circ = wdf.Circuit(wdf.Inverter(wdf.Series(R1, C1)), wdf.IdealVoltageSource(), C1, per_sample_R=R1)
+    with tf.GradientTape() as tape:
+        y = circ(cuda(np.stack([x, r], axis=-1)))
+        loss = tf.reduce_sum(y * cuda(gy))
+    gC = tape.gradient(loss, [C1.C])[0]
+    nodes = [(O.NODE_RESISTOR, -1, -1, 0, -1, 1), (O.NODE_CAPACITOR, -1, -1, 1, -1, -1), (O.NODE_SERIES, 0, 1, -1, -1, -1),
+             (O.NODE_INVERTER, 2, -1, -1, -1, -1)]
+    oc = O.Circuit(nodes, top=3, probe=1, n_in=2, root_kind=O.ROOT_IDEAL_VSOURCE, fs=FS, root_vin=0)
+    theta = np.array([1000.0, np.float32(1.0e-6)], dtype=np.float64)
+    xin64 = np.stack([x, r], axis=-1).astype(np.float64)
+    assert np.max(np.abs(y.cpu().numpy() - O.tree_fwd(oc, theta, xin64))) < 3e-6
+    g_ref = O.tree_grad(oc, theta, xin64, gy.astype(np.float64), params=[1])
+    assert rel([float(gC)], g_ref) < 3e-4
+
+
+def test_clipper_topology_through_the_streamed_kernels_equals_the_clipper_kernels(wdf, golden):
+    """force_generic: Parallel(ResistiveVoltageSource, Capacitor) + diode pair + pot channel through wdf_ss_dyn_* against the
+    golden of the clipper kernels' pot path (g6 rpot: fp64 restatement, Newton-verified) and against those kernels."""
+    tf = wdf.tf
+    g = golden("g6_diode_clipper.npz")
+    Is, nVt, R, C = (float(v) for v in g["theta"])
+    x, r = g["x"].astype(np.float32), g["r"].astype(np.float32)
+
+    def build(generic):
+        Vs = wdf.ResistiveVoltageSource(R)
+        Cap = wdf.Capacitor(C, FS, trainable=True)
+        P1 = wdf.Parallel(Vs, Cap)
+        dp = wdf.DiodePair(P1, Is, Vt=nVt, trainable=True)
+        return wdf.Circuit(P1, dp, Cap, per_sample_R=Vs, force_generic=generic), [dp.Is, dp.nVt, Cap.C]
+
+    xin = cuda(np.stack([x, r], axis=-1))
+    outs = []
+    for generic in (True, False):
+        circ, params = build(generic)
+        with tf.GradientTape() as tape:
+            y = circ(xin)
+            loss = tf.reduce_mean(tf.square(y))
+        outs.append((y.cpu().numpy(), np.array([float(v) for v in tape.gradient(loss, params)])))
+    assert np.max(np.abs(outs[0][0] - g["y_1u1d_rpot_f64"])) < 3e-6
+    assert np.max(np.abs(outs[0][0] - outs[1][0])) < 3e-6
+    assert rel(outs[0][1], outs[1][1]) < 3e-4
+
+
+def test_what_the_streamed_kernels_refuse(wdf, golden):
+    from wdf_hip import binding as wb
+    from layers import DenseRootModel
+    R = [wdf.Resistor(1.0e3 * (i + 1)) for i in range(2)]
+    caps = [wdf.Capacitor(1.0e-8 * (i + 1), FS) for i in range(3)]
+    Vs = wdf.ResistiveVoltageSource(1.0e3)
+    top = wdf.Series(wdf.Series(wdf.Parallel(caps[0], R[0]), wdf.Parallel(caps[1], R[1])), wdf.Series(Vs, caps[2]))
+    dp = wdf.DiodePair(top, 4.352e-9, Vt=0.049)
+    with pytest.raises(wb.WdfHipError, match="two capacitors"):
+        wdf.Circuit(top, dp, caps[0], per_sample_R=Vs)            # three states
+    with pytest.raises(ValueError):
+        wdf.Circuit(wdf.Parallel(wdf.Resistor(1e3), wdf.Series(wdf.ResistiveVoltageSource(1e3), wdf.Capacitor(1e-8, FS))), dp, caps[0])
+    js, _, _ = _net(golden, "2x8")
+    for layer in js["layers"][:-1]:
+        layer["activation"] = "relu"
+    Rr, Vr, Cr = wdf.Resistor(33e3), wdf.ResistiveVoltageSource(1e3), wdf.Capacitor(22e-9, FS)
+    circ = wdf.Circuit(wdf.Parallel(Rr, wdf.Series(Vr, Cr)), DenseRootModel(js), Rr)
+    with pytest.raises(wb.WdfHipError, match="tanh"):
+        circ(cuda(np.zeros((2, 16))))
+    with pytest.raises(wb.WdfHipError, match="streamed-coefficient"):
+        circ.to_device()
