@@ -42,15 +42,17 @@ void ss_launch_bwd(const float* x, const float* coef, const float* rootp, int n_
     do {                                                                                         \
         WDF_SS_CASE(FN, 0, 1, __VA_ARGS__) WDF_SS_CASE(FN, 1, 1, __VA_ARGS__)                    \
         WDF_SS_CASE(FN, 2, 1, __VA_ARGS__) WDF_SS_CASE(FN, 3, 1, __VA_ARGS__)                    \
+        WDF_SS_CASE(FN, 4, 1, __VA_ARGS__)                                                       \
         WDF_SS_CASE(FN, 0, 2, __VA_ARGS__) WDF_SS_CASE(FN, 1, 2, __VA_ARGS__)                    \
         WDF_SS_CASE(FN, 2, 2, __VA_ARGS__) WDF_SS_CASE(FN, 3, 2, __VA_ARGS__)                    \
+        WDF_SS_CASE(FN, 4, 2, __VA_ARGS__)                                                       \
     } while (0)
 
 int ss_check(const float* x, const float* coef, const float* rootp, int ns, int ni, int root, int n_up, int n_down,
              int64_t B, int64_t T, int flags)
 {
     if (!x || !coef) return fail(WDF_EINVAL, "null x/coef");
-    if (ns < 0 || ns > 3 || ni < 1 || ni > 2) return fail(WDF_EUNSUPPORTED, "state-space kernels cover ns in [0,3], ni in [1,2] (got ns=%d ni=%d)", ns, ni);
+    if (ns < 0 || ns > 4 || ni < 1 || ni > 2) return fail(WDF_EUNSUPPORTED, "state-space kernels cover ns in [0,4], ni in [1,2] (got ns=%d ni=%d)", ns, ni);
     if (root != wdf::kRootNone && root != wdf::kRootDiode) return fail(WDF_EINVAL, "unknown root kind %d", root);
     if (root == wdf::kRootDiode && !rootp) return fail(WDF_EINVAL, "diode root needs rootp = {Is, nVt, R_port}");
     if (root == wdf::kRootDiode && (n_up < 1 || n_down < 1 || n_up > 16 || n_down > 16)) return fail(WDF_EINVAL, "n_up/n_down must be in [1,16]");
@@ -115,7 +117,7 @@ int wdf_ss_fwd_lin_tp(const float* x, const float* coef, int ns, int ni, float* 
     if (ns == NS_ && ni == NI_) {                                                                                \
         if (v4) WDF_LIN_V(NS_, NI_, true) else WDF_LIN_V(NS_, NI_, false)                                        \
     }
-    WDF_LIN(1, 1) WDF_LIN(2, 1) WDF_LIN(3, 1) WDF_LIN(1, 2) WDF_LIN(2, 2) WDF_LIN(3, 2)
+    WDF_LIN(1, 1) WDF_LIN(2, 1) WDF_LIN(3, 1) WDF_LIN(4, 1) WDF_LIN(1, 2) WDF_LIN(2, 2) WDF_LIN(3, 2) WDF_LIN(4, 2)
 #undef WDF_LIN
 #undef WDF_LIN_V
     return check_launch("wdf_ss_fwd_lin_tp");
@@ -218,7 +220,7 @@ int wdf_ss_fwd_tp(const float* x, const float* coef, const float* rootp, int ns,
                                     coef, rootp, n_up, n_down, y, zstash, z0, zT, B, T, (const unsigned*)gate);              \
         }                                                                                                                    \
     }
-    WDF_SS_TP(1, 1) WDF_SS_TP(2, 1) WDF_SS_TP(3, 1) WDF_SS_TP(1, 2) WDF_SS_TP(2, 2) WDF_SS_TP(3, 2)
+    WDF_SS_TP(1, 1) WDF_SS_TP(2, 1) WDF_SS_TP(3, 1) WDF_SS_TP(4, 1) WDF_SS_TP(1, 2) WDF_SS_TP(2, 2) WDF_SS_TP(3, 2) WDF_SS_TP(4, 2)
 #undef WDF_SS_TP
     return check_launch("wdf_ss_fwd_tp");
 }
@@ -275,7 +277,7 @@ int wdf_ss_bwd_tp(const float* x, const float* coef, const float* rootp, int ns,
         hipLaunchKernelGGL((wdf::ss_bwd_tp_combine_kernel<NS_, NI_>), dim3(grid.x), dim3(64), 0, s, (const float*)rec, part, gz0, B,   \
                            (int64_t)K);                                                                                      \
     }
-    WDF_SS_BTP(1, 1) WDF_SS_BTP(2, 1) WDF_SS_BTP(3, 1) WDF_SS_BTP(1, 2) WDF_SS_BTP(2, 2) WDF_SS_BTP(3, 2)
+    WDF_SS_BTP(1, 1) WDF_SS_BTP(2, 1) WDF_SS_BTP(3, 1) WDF_SS_BTP(4, 1) WDF_SS_BTP(1, 2) WDF_SS_BTP(2, 2) WDF_SS_BTP(3, 2) WDF_SS_BTP(4, 2)
 #undef WDF_SS_BTP
     rc = check_launch("wdf_ss_bwd_tp");
     if (rc) return rc;

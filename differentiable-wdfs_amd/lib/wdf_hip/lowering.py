@@ -191,6 +191,47 @@ class _SsDynFn(torch.autograd.Function):
                 None, None, None)
 
 
+# ------------------------------------------------------------------------------ resident entries: which batch is this?
+def tensor_key(t):
+    """What names a batch for the resident paths' caches: the STORAGE a tensor looks at (address, shape, strides, dtype,
+    device) and its version counter -- not the Python object.  A training loop that cuts the same mini-batches out of its
+    dataset every epoch (`X[i:j]`: a fresh tensor object each time, the same memory) then finds its stepper, its resident
+    time-major copy and its warm-start state again; an in-place change of the data bumps the version (shared by all views
+    of a storage) and misses.  The entry keeps the first tensor it was made for alive, so the address cannot be handed to
+    other data while the entry exists."""
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version, t.device.type, t.device.index)
+
+
+class EntryCache:
+    """Insertion-ordered cache of resident entries: at most `max_entries`, and -- beyond the first four -- at most
+    `max_bytes` of device buffers in total (a full-batch loop keeps a training and a validation set; a mini-batch loop
+    keeps every mini-batch of an epoch while they are small)."""
+
+    def __init__(self, max_entries=256, max_bytes=16 << 30):
+        self.d, self.nbytes, self.max_entries, self.max_bytes = {}, {}, int(max_entries), int(max_bytes)
+
+    def get(self, key):
+        return self.d.get(key)
+
+    def put(self, key, ent, nbytes=0):
+        self.d[key] = ent
+        self.nbytes[key] = int(nbytes)
+        while len(self.d) > self.max_entries or (len(self.d) > 4 and sum(self.nbytes.values()) > self.max_bytes):
+            old = next(iter(self.d))
+            del self.d[old], self.nbytes[old]
+        return ent
+
+    def values(self):
+        return self.d.values()
+
+    def __len__(self):
+        return len(self.d)
+
+
+def _nbytes(*ts):
+    return sum(t.numel() * t.element_size() for t in ts if isinstance(t, torch.Tensor))
+
+
 # ------------------------------------------------------------------------------ resident linear trees
 _LIN_OCC = int(os.environ.get("WDF_LIN_OCC", "2"))       # chunks are cut so that every SIMD gets this many waves
 _NL_OCC = int(os.environ.get("WDF_NL_OCC", "1"))
@@ -247,7 +288,7 @@ class _LinResident:
         self.coef = torch.zeros(self.n_out, dtype=torch.float32, device=dev)
         self.coef64 = torch.zeros(self.n_out, dtype=torch.float64, device=dev)
         self.jac = torch.zeros((self.n_out, self.n_tree), dtype=torch.float64, device=dev)
-        self.cache = {}
+        self.cache = EntryCache()
 
     def check(self):
         """Every component value must still be what to_device() captured: an adopted Variable the same object, still in the
@@ -292,11 +333,9 @@ class _LinResident:
         return self._hc_val
 
     def entry(self, x, target):
-        key = (id(x), x._version, tuple(x.shape), id(target), target._version)
+        key = (tensor_key(x), tensor_key(target))
         ent = self.cache.get(key)
         if ent is None:
-            if len(self.cache) >= 4:
-                self.cache.pop(next(iter(self.cache)))            # oldest out (a training and a validation set alternate)
             circ, dev = self.circ, self.pb.block.device
             xd = x.as_subclass(torch.Tensor).to(dev).float()
             if xd.dim() == 2:
@@ -323,9 +362,10 @@ class _LinResident:
             # slab of _ROWS; a full slab is replaced by a fresh one and lives on for as long as anything still refers to
             # it): the loss history a script keeps (lpf.py:99 `losses.append(loss)`) and gradients read after the loop stay
             # what they were -- no copy per call, one allocation per _ROWS calls
-            ent = self.cache[key] = {"x": x_tm, "t": tgt, "y": y, "ws": ws,
-                                     "ring": torch.zeros((_ROWS, 2 + self.pb.n), dtype=torch.float32, device=dev), "turn": 0,
-                                     "B": B, "T": T, "k": k, "hold": (x, target), "calls": 0, "watch": None, "replans": 0}
+            ent = self.cache.put(key, {"x": x_tm, "t": tgt, "y": y, "ws": ws,
+                                       "ring": torch.zeros((_ROWS, 2 + self.pb.n), dtype=torch.float32, device=dev), "turn": 0,
+                                       "B": B, "T": T, "k": k, "hold": (x, target), "calls": 0, "watch": None, "replans": 0},
+                                 _nbytes(x_tm, tgt, y, ws))
         return ent
 
     def _plan_nl(self, B, T, k, dev, cold_floor=0):
@@ -614,7 +654,7 @@ class Circuit:
             if isinstance(p, torch.Tensor) and getattr(p, "_is_tf_variable", False) and p.numel() == 1:
                 pb.adopt(i, p)
                 self._adopted_parts[i] = p
-        self._pblock, self._res_cache = pb, {}
+        self._pblock, self._res_cache = pb, EntryCache()
         return self
 
     def _theta(self, parts, dev):
@@ -648,11 +688,10 @@ class Circuit:
             if now[i] is not v or getattr(v, "_wdf_block", (None,))[0] is not pb:
                 raise binding.WdfHipError("Circuit.to_device: a component Variable was replaced (set_resistance?) or moved to another "
                                           "block after to_device(); build a new Circuit")
-        key = (id(x), x._version, tuple(x.shape), id(target), target._version, kind, int(skip))
+        with torch._C.DisableTorchFunctionSubclass():
+            key = (tensor_key(x), tensor_key(target), kind, int(skip))
         ent = self._res_cache.get(key)
         if ent is None:
-            if len(self._res_cache) >= 4:
-                self._res_cache.pop(next(iter(self._res_cache)))   # oldest out
             dp, cap = self.root, self.top.P2
             xd = x.as_subclass(torch.Tensor).to(pb.block.device).float()
             xv, r = engine.split_channels(xd, self.per_sample_R is not None, time_major=True, anchor=x)
@@ -667,10 +706,11 @@ class Circuit:
             st = engine.MseStep(B, T, float(cap.FS), tp, pb.block.device, n_up=dp.N_up, n_down=dp.N_down, time_major=True,
                                 warm=True, loss=kind, skip=int(skip))
             live = [(i, v) for i, v in sorted(pb.members.items()) if v.requires_grad]
-            ent = self._res_cache[key] = (st, xv, r, tgt, 1.0 / float(B * T) if kind == "mse" else 1.0,
-                                          [i for i, _ in live], [v for _, v in live],
-                                          x, target,                      # (x, target held: their ids stay their own)
-                                          {id(v): i for i, v in live})
+            ent = self._res_cache.put(key, (st, xv, r, tgt, 1.0 / float(B * T) if kind == "mse" else 1.0,
+                                            [i for i, _ in live], [v for _, v in live],
+                                            x, target,                    # (x, target held: their storage stays theirs)
+                                            {id(v): i for i, v in live}),
+                                      3 * _nbytes(xv, r, tgt))
         st, xv, r, tgt, inv_n, idx, live = ent[:7]
         engine.LAST_TP_STATUS["status"] = st.status
         loss, out = engine._ResidentMseFn.apply(st, pb.block, xv, r, tgt, inv_n, idx, *live)

@@ -758,14 +758,15 @@ class MlpResident:
                 self.vars.append(v)
                 o += n
         self.spec = {id(v): v._wdf_flat[1:] + (tuple(v.shape),) for v in self.vars}
-        self.cache = {}
+        from . import lowering
+        self.cache = lowering.EntryCache()
 
     def entry(self, x, target, skip):
-        key = (id(x), x._version, tuple(x.shape), id(target), target._version, int(skip))
+        from . import lowering
+        with torch._C.DisableTorchFunctionSubclass():
+            key = (lowering.tensor_key(x), lowering.tensor_key(target), int(skip))
         ent = self.cache.get(key)
         if ent is None:
-            if len(self.cache) >= 4:
-                self.cache.pop(next(iter(self.cache)))
             circ, dev = self.circ, self.w.device
             xd = x.as_subclass(torch.Tensor).to(dev).float()
             xv, r = engine.split_channels(xd, circ.per_sample_R is not None, anchor=x)
@@ -773,7 +774,7 @@ class MlpResident:
             tgt = target.as_subclass(torch.Tensor).to(dev).float().reshape(T, B).contiguous()
             st = MlpTrainStep(xv, r, tgt, self.w, self.hidden, self.n_layers, self.fs, self.C, R_static=self.R_static,
                               skip=int(skip), adam=None, activation=self.act)
-            ent = self.cache[key] = {"st": st, "hold": (x, target), "calls": 0}
+            ent = self.cache.put(key, {"st": st, "hold": (x, target), "calls": 0}, 8 * tgt.numel() * 4)
         return ent
 
 

@@ -412,7 +412,7 @@ int wdf_clipper_mlp_step(const float* x, const float* p, const float* lr, const 
  * (calc_impedance once per forward, lpf.py:38).  The host derives the matrices from the
  * component values by running its tf_wdf-compatible elements on unit vectors.
  *
- * ns (0..3) capacitor states, ni (1..2) input channels.
+ * ns (0..4) capacitor states (4 since round 5), ni (1..2) input channels.
  * coef    device float[wdf_ss_ncoef(ns, ni)]:
  *         A[ns][ns] | Bx[ns][ni] | E[ns] | ca[ns] | da[ni] | cy[ns] | dy[ni] | fy
  * root_kind  WDF_ROOT_NONE (ideal source folded into the matrices; IdealVoltageSource

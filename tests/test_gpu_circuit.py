@@ -212,6 +212,78 @@ def test_three_state_linear_ladder_vs_oracle(wdf, oracle):
     assert rel(np.array([float(v) for v in grads]), gref) < 3e-4
 
 
+@pytest.mark.parametrize("B,T", [(5, 300), (300, 2048)])
+def test_four_state_two_stage_trees_vs_oracle(wdf, oracle, B, T):
+    """Four capacitors (round 5: the state-space kernels' limit went from three to four): a four-section RC ladder under the
+    ideal source, and a two-stage tone-shaping network -- input coupling R-C, two shelving sections -- in front of a diode
+    pair (ns = 4, ni = 1); small batches run sequentially, the larger one through the chunked kernels (exact chunked scan /
+    verified chunks + exact chunked reverse sweep).  y and every component gradient against the oracle's tree interpreter."""
+    tf = wdf.tf
+    O = oracle
+    rng = np.random.default_rng(B)
+    x = rng.standard_normal((B, T)).astype(np.float32)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    rv = [1.0e3, 2.2e3, 4.7e3, 10.0e3]
+    cv = [1.0e-7, 2.2e-7, 4.7e-8, 1.0e-8]
+    # --- linear ladder: Inverter(Series(R0, Parallel(C0, Series(R1, Parallel(C1, Series(R2, Parallel(C2, Series(R3, C3))))))))
+    Rs = [wdf.Resistor(v, True) for v in rv]
+    Cs = [wdf.Capacitor(v, FS, True) for v in cv]
+    sec = wdf.Series(Rs[3], Cs[3])
+    for k in (2, 1, 0):
+        sec = wdf.Series(Rs[k], wdf.Parallel(Cs[k], sec))
+    circ = wdf.Circuit(wdf.Inverter(sec), wdf.IdealVoltageSource(), Cs[3])
+    assert (circ.ns, circ.ni) == (4, 1)
+    nodes = []
+
+    def leaf(kind, param):
+        nodes.append((kind, -1, -1, param, -1, -1))
+        return len(nodes) - 1
+
+    def join(kind, a, b=-1):
+        nodes.append((kind, a, b, -1, -1, -1))
+        return len(nodes) - 1
+
+    # the oracle's nodes in any order that puts children before parents; theta = [R0, C0, R1, C1, R2, C2, R3, C3]
+    r = [leaf(O.NODE_RESISTOR, 2 * k) for k in range(4)]
+    c = [leaf(O.NODE_CAPACITOR, 2 * k + 1) for k in range(4)]
+    s_ = join(O.NODE_SERIES, r[3], c[3])
+    for k in (2, 1, 0):
+        s_ = join(O.NODE_SERIES, r[k], join(O.NODE_PARALLEL, c[k], s_))
+    top = join(O.NODE_INVERTER, s_)
+    oc = O.Circuit(nodes, top=top, probe=c[3], n_in=1, root_kind=O.ROOT_IDEAL_VSOURCE, fs=FS, root_vin=0)
+    theta = np.array([v for pair in zip(rv, cv) for v in pair], dtype=np.float32).astype(np.float64)
+    y = circ(cuda(x))
+    assert np.max(np.abs(y.numpy() - O.tree_fwd(oc, theta, x.astype(np.float64)))) < 5e-6
+    params = [v for pair in zip([e.R for e in Rs], [e.C for e in Cs]) for v in pair]
+    grads = tf.GradientTape().gradient(tf.reduce_sum(y * cuda(gy)), params)
+    gref = O.tree_grad(oc, theta, x.astype(np.float64), gy.astype(np.float64))
+    assert rel(np.array([float(v) for v in grads]), gref) < 3e-4
+    # --- diode root: Parallel(C3, Series(R2, Parallel(C2, Series(R1, Parallel(C1, Series(Series(Vs, C0), R0))))))
+    Vs = wdf.ResistiveVoltageSource(1.0e3, trainable=True)
+    R2 = [wdf.Resistor(v, True) for v in (33.0e3, 6.8e3, 15.0e3)]
+    C2 = [wdf.Capacitor(v, FS, True) for v in (47.0e-9, 22.0e-9, 10.0e-9, 4.7e-9)]
+    inner = wdf.Series(wdf.Series(Vs, C2[0]), R2[0])
+    tree = wdf.Parallel(C2[3], wdf.Series(R2[2], wdf.Parallel(C2[2], wdf.Series(R2[1], wdf.Parallel(C2[1], inner)))))
+    dp = wdf.DiodePair(tree, 4.352e-9, Vt=0.0493, N_up=1, N_down=2, trainable=True)
+    circ2 = wdf.Circuit(tree, dp, C2[3])
+    assert (circ2.ns, circ2.ni) == (4, 1)
+    nodes.clear()
+    vs = len(nodes); nodes.append((O.NODE_RES_VSOURCE, -1, -1, 0, 0, -1))       # theta = [Rs, R0, R1, R2, C0..C3, Is, nVt]
+    rr = [leaf(O.NODE_RESISTOR, 1 + k) for k in range(3)]
+    cc = [leaf(O.NODE_CAPACITOR, 4 + k) for k in range(4)]
+    n_in = join(O.NODE_SERIES, join(O.NODE_SERIES, vs, cc[0]), rr[0])
+    n_t = join(O.NODE_PARALLEL, cc[3], join(O.NODE_SERIES, rr[2], join(O.NODE_PARALLEL, cc[2], join(O.NODE_SERIES, rr[1], join(O.NODE_PARALLEL, cc[1], n_in)))))
+    oc2 = O.Circuit(nodes, top=n_t, probe=cc[3], n_in=1, root_kind=O.ROOT_DIODE_PAIR, fs=FS, p_is=8, p_nvt=9, n_up=1, n_down=2)
+    th2 = np.array([1.0e3, 33.0e3, 6.8e3, 15.0e3, 47.0e-9, 22.0e-9, 10.0e-9, 4.7e-9, 4.352e-9, 0.0493], dtype=np.float32).astype(np.float64)
+    x2 = (1.5 * x).astype(np.float32)
+    y2 = circ2(cuda(x2))
+    assert np.max(np.abs(y2.numpy() - O.tree_fwd(oc2, th2, x2.astype(np.float64)))) < 5e-6
+    p2 = [Vs.R] + [e.R for e in R2] + [e.C for e in C2] + [dp.Is, dp.nVt]
+    g2 = tf.GradientTape().gradient(tf.reduce_sum(y2 * cuda(gy)), p2)
+    gref2 = O.tree_grad(oc2, th2, x2.astype(np.float64), gy.astype(np.float64))
+    assert rel(np.array([float(v) for v in g2]), gref2) < 5e-4, (np.array([float(v) for v in g2]), gref2)
+
+
 def test_training_loop_rc_lowpass_converges(wdf, golden):
     """lpf.py:77-113 with the fast tier: R -> ~315 ohm, C -> ~0.69 uF (RC_lpf.png), i.e.
     fc = 1/(2 pi R C) ~ 720-730 Hz, loss -> ~0."""
@@ -764,6 +836,44 @@ def test_resident_circuit_alternating_training_and_validation_sets(wdf):
         assert np.allclose(gd, gh, rtol=3e-4, atol=0)
     steppers = [e[0] for e in circ._res_cache.values()]
     assert all(s.warm is not None and s.warm.info()["valid"] == 3 for s in steppers)
+
+
+def test_resident_circuit_mini_batch_loop_with_fresh_slices(wdf):
+    """A loop that cuts its mini-batches out of the dataset every epoch (`X[i:j]`: a new tensor object each time, the same
+    memory): the resident entries are keyed on the storage a tensor looks at, so every mini-batch finds its stepper and its
+    warm-start state again (one entry per mini-batch, not one per call); changing the data in place makes a new entry."""
+    from wdf_hip import workload
+    tf = wdf.tf
+    theta = workload.clipper_theta()
+    B, T, nb = 256, 1024, 4
+    X = cuda(workload.sweep_batch(B, T, seed=41))
+    ref, _ = _clipper_circuit(wdf, workload.target_theta())
+    Y = ref(X).as_subclass(torch.Tensor).detach().t().contiguous()          # [B,T]: sliced by rows like X
+    circ, vs = _clipper_circuit(wdf, theta)
+    circ.to_device()
+    opt = tf.keras.optimizers.Adam(learning_rate=1.0e-12)
+    losses = []
+    targets = [Y[i * (B // nb):(i + 1) * (B // nb)].t().contiguous() for i in range(nb)]       # [T, B/nb] each, kept
+    for epoch in range(5):
+        for i in range(nb):
+            xb = X[i * (B // nb):(i + 1) * (B // nb)]                        # fresh objects every epoch
+            with tf.GradientTape() as tape:
+                loss = circ.mse(xb, targets[i])
+            opt.apply_gradients(zip(tape.gradient(loss, vs), vs))
+            losses.append(float(loss))
+    assert len(circ._res_cache) == nb                                        # 20 calls, four entries
+    steppers = [e[0] for e in circ._res_cache.values()]
+    assert all(s.warm is not None and s.warm.info()["n_calls"] == 5 for s in steppers)
+    # against a plain evaluation at the components the loop has reached
+    host, _ = _clipper_circuit(wdf, [float(v) for v in (circ.root.Is, circ.root.nVt, circ.top.P1.R, circ.top.P2.C)])
+    for i in range(nb):
+        xb = X[i * (B // nb):(i + 1) * (B // nb)]
+        want = float(host.mse(xb, targets[i]))
+        got = float(circ.mse(xb, targets[i]))
+        assert abs(got - want) <= 2e-5 * want
+    X[0, 0] += 0.25                                                          # in place: the version counter moves
+    circ.mse(X[0:B // nb], targets[0])
+    assert len(circ._res_cache) == nb + 1
 
 
 def _oracle_hpf(O, n_up=2, n_down=3):
