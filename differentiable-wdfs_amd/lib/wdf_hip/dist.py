@@ -37,11 +37,13 @@ def init(backend=None, force=False):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        limit = datetime.timedelta(minutes=5)            # (a rank that never arrives fails the job in minutes, not in half an hour)
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, device_id=torch.device("cuda", local), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return world, rank, local
