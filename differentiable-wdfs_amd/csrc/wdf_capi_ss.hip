@@ -480,7 +480,7 @@ int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, in
 {
     if (!x || !coef || !jac || !target || !y || !ws || !out) return fail(WDF_EINVAL, "null argument");
     if (!lin_step_ok(ns, ni)) return fail(WDF_EUNSUPPORTED, "wdf_ss_lin_step_mse: ns in 0..2, ni in 1..2 (got %d, %d)", ns, ni);
-    if (B <= 0 || T <= 0 || n_chunks < 1 || n_params < 1 || n_params > wdf::kProbeMaxParams) return fail(WDF_EINVAL, "B, T, n_chunks >= 1, 1..7 parameters");
+    if (B <= 0 || T <= 0 || n_chunks < 1 || n_params < 1 || n_params > wdf::kProbeMaxParams) return fail(WDF_EINVAL, "B, T, n_chunks >= 1, 1..%d parameters", wdf::kProbeMaxParams);
     int64_t L; int K;
     lin_step_geom(T, n_chunks, L, K);
     const int D = lin_step_d(ns, ni);

@@ -10,7 +10,7 @@
 //     lane (wdf_mlp.h, weights in LDS); its weight gradient is the dense pass mlp_wgrad_kernel over (a, log R_port, dL/db).
 //
 // One step, as in wdf_statespace.h:   a = ca.z + da.x ;  b = root(a) ;  z' = A z + Bx x + E b ;  y = cy.z + dy.x + fy b.
-// Row layout (ns <= 2 states, ni <= 2 inputs, both run-time):
+// Row layout (ns <= 4 states, ni <= 2 inputs, both run-time):
 //     A[ns][ns] | Bx[ns][ni] | E[ns] | ca[ns] | da[ni] | cy[ns] | dy[ni] | fy | R_port          (kN1 = wdf_ss_ncoef + 1 entries)
 // addressed as  crow[i * cs + t * ts + b * bs]: per-sample rows [T][kN1][B] (cs = B, ts = kN1 B, bs = 1) or ONE static row
 // (cs = 1, ts = bs = 0) through the same code.  x [B][T][ni]; y, dL/dy [T][B]; state stash [T][ns][B]; z0 / zT [ns][B].
@@ -31,7 +31,7 @@
 namespace wdf {
 
 enum { kDynRootNone = 0, kDynRootDiode = 2, kDynRootMlp = 3 };
-constexpr int kDynMaxS = 2, kDynMaxI = 2;
+constexpr int kDynMaxS = 4, kDynMaxI = 2;
 
 struct DynRow {                     // one step's coefficients in registers (entries beyond ns / ni are zero)
     float A[kDynMaxS][kDynMaxS], Bx[kDynMaxS][kDynMaxI], E[kDynMaxS], ca[kDynMaxS], da[kDynMaxI], cy[kDynMaxS], dy[kDynMaxI], fy, rp;
@@ -181,7 +181,9 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
     }
     const float* __restrict__ xp = x + b * T * ni;
     const float* __restrict__ cp = crow + b * bs;
-    float lam[kDynMaxS] = {0.0f, 0.0f};
+    float lam[kDynMaxS];
+#pragma unroll
+    for (int s = 0; s < kDynMaxS; ++s) lam[s] = 0.0f;
     double sL = 0.0, sV = 0.0;
     [[maybe_unused]] float act[NL][H];
     for (int64_t t = T - 1; t >= 0; --t) {

@@ -31,7 +31,7 @@
 
 namespace wdf {
 
-constexpr int kProbeMaxOps = 384, kProbeMaxParams = 7, kProbeLanes = 8;
+constexpr int kProbeMaxOps = 384, kProbeMaxParams = 15, kProbeLanes = 16;   // (round 5: 7 -> 15 component values; 106 KB of the CU's 160 KB LDS)
 enum { kOpConst = 0, kOpParam, kOpAdd, kOpSub, kOpMul, kOpDiv, kOpNeg, kOpRecip };
 
 // tape: int32 [n_ops][3] = {op, a, b}; consts: double; params: the float32 block the component values live in.

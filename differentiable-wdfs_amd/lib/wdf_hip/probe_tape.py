@@ -12,7 +12,7 @@ calc_impedance is in the reference, lpf.py:38,87-90).
 import numpy as np
 
 OP_CONST, OP_PARAM, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_RECIP = range(8)
-MAX_OPS, MAX_PARAMS = 384, 7
+MAX_OPS, MAX_PARAMS = 384, 15
 
 
 class Tape:

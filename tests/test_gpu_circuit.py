@@ -212,12 +212,14 @@ def test_three_state_linear_ladder_vs_oracle(wdf, oracle):
     assert rel(np.array([float(v) for v in grads]), gref) < 3e-4
 
 
-@pytest.mark.parametrize("B,T", [(5, 300), (300, 2048)])
-def test_four_state_two_stage_trees_vs_oracle(wdf, oracle, B, T):
+@pytest.mark.parametrize("B,T,resident", [(5, 300, False), (300, 2048, False), (70, 515, True)])
+def test_four_state_two_stage_trees_vs_oracle(wdf, oracle, B, T, resident):
     """Four capacitors (round 5: the state-space kernels' limit went from three to four): a four-section RC ladder under the
     ideal source, and a two-stage tone-shaping network -- input coupling R-C, two shelving sections -- in front of a diode
     pair (ns = 4, ni = 1); small batches run sequentially, the larger one through the chunked kernels (exact chunked scan /
-    verified chunks + exact chunked reverse sweep).  y and every component gradient against the oracle's tree interpreter."""
+    verified chunks + exact chunked reverse sweep).  y and every component gradient against the oracle's tree interpreter.
+    resident: the same through Circuit.to_device() -- eight and ten component values in the device block (the device probe
+    held seven until round 5), coefficients and their chain rule from the probe kernel."""
     tf = wdf.tf
     O = oracle
     rng = np.random.default_rng(B)
@@ -233,6 +235,9 @@ def test_four_state_two_stage_trees_vs_oracle(wdf, oracle, B, T):
         sec = wdf.Series(Rs[k], wdf.Parallel(Cs[k], sec))
     circ = wdf.Circuit(wdf.Inverter(sec), wdf.IdealVoltageSource(), Cs[3])
     assert (circ.ns, circ.ni) == (4, 1)
+    if resident:
+        circ.to_device()
+        assert all(e.R.is_cuda for e in Rs) and all(e.C.is_cuda for e in Cs)
     nodes = []
 
     def leaf(kind, param):
@@ -267,6 +272,9 @@ def test_four_state_two_stage_trees_vs_oracle(wdf, oracle, B, T):
     dp = wdf.DiodePair(tree, 4.352e-9, Vt=0.0493, N_up=1, N_down=2, trainable=True)
     circ2 = wdf.Circuit(tree, dp, C2[3])
     assert (circ2.ns, circ2.ni) == (4, 1)
+    if resident:
+        circ2.to_device()
+        assert dp.Is.is_cuda and Vs.R.is_cuda
     nodes.clear()
     vs = len(nodes); nodes.append((O.NODE_RES_VSOURCE, -1, -1, 0, 0, -1))       # theta = [Rs, R0, R1, R2, C0..C3, Is, nVt]
     rr = [leaf(O.NODE_RESISTOR, 1 + k) for k in range(3)]

@@ -185,6 +185,50 @@ def test_rc_lowpass_with_a_per_sample_resistor(wdf, oracle):
     assert rel([float(gC)], g_ref) < 3e-4
 
 
+def test_three_state_tree_with_a_pot_and_an_mlp_root(wdf, oracle, golden):
+    """Beyond two states: input coupling R0-C0, a shelving section R1 || C1, the pot Rp in series with C2, under a
+    DenseRootModel -- ns = 3, a per-sample resistor AND the network root on one tree; y and dL/d{R0, C0, R1, C1, C2}
+    against the oracle."""
+    tf = wdf.tf
+    O = oracle
+    from layers import DenseRootModel
+    js, w64, sizes = _net(golden, "2x8")
+    B, T = 20, 180
+    rng = np.random.default_rng(33)
+    x = (0.8 * rng.standard_normal((B, T))).astype(np.float32)
+    r = pot_channel(B, T, 2.0e3, 50.0e3, 6)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    Vs = wdf.ResistiveVoltageSource(2.2e3, trainable=True)
+    R1 = wdf.Resistor(15.0e3, True)
+    Rp = wdf.Resistor(10.0e3, True)
+    C0, C1, C2 = wdf.Capacitor(47.0e-9, FS, True), wdf.Capacitor(10.0e-9, FS, True), wdf.Capacitor(22.0e-9, FS, True)
+    top = wdf.Parallel(wdf.Series(Rp, C2), wdf.Series(wdf.Series(Vs, C0), wdf.Parallel(R1, C1)))
+    model = DenseRootModel(js)
+    circ = wdf.Circuit(top, model, C2, per_sample_R=Rp)
+    assert (circ.ns, circ.ni) == (3, 1)
+    params = [Vs.R, R1.R, C0.C, C1.C, C2.C]
+    with tf.GradientTape() as tape:
+        y = circ(cuda(np.stack([x, r], axis=-1)))
+        loss = tf.reduce_sum(y * cuda(gy))
+    grads = tape.gradient(loss, params)
+    # theta = [Rs, R1, Rp (streamed: channel 1), C0, C1, C2, weights...]
+    nodes = [(O.NODE_RES_VSOURCE, -1, -1, 0, 0, -1), (O.NODE_RESISTOR, -1, -1, 1, -1, -1), (O.NODE_RESISTOR, -1, -1, 2, -1, 1),
+             (O.NODE_CAPACITOR, -1, -1, 3, -1, -1), (O.NODE_CAPACITOR, -1, -1, 4, -1, -1), (O.NODE_CAPACITOR, -1, -1, 5, -1, -1),
+             (O.NODE_SERIES, 2, 5, -1, -1, -1),                    # 6: Rp - C2
+             (O.NODE_SERIES, 0, 3, -1, -1, -1),                    # 7: Vs - C0
+             (O.NODE_PARALLEL, 1, 4, -1, -1, -1),                  # 8: R1 || C1
+             (O.NODE_SERIES, 7, 8, -1, -1, -1),                    # 9
+             (O.NODE_PARALLEL, 6, 9, -1, -1, -1)]                  # 10: top
+    acts = [O.ACT_TANH] * (len(sizes) - 2) + [O.ACT_NONE]
+    oc = O.Circuit(nodes, top=10, probe=5, n_in=2, root_kind=O.ROOT_MLP, fs=FS, mlp_off=6, mlp_sizes=sizes, mlp_act=acts)
+    theta = np.concatenate([np.array([2.2e3, 15.0e3, 10.0e3, 47.0e-9, 10.0e-9, 22.0e-9], dtype=np.float32).astype(np.float64),
+                            w64.astype(np.float32).astype(np.float64)])
+    xin64 = np.stack([x, r], axis=-1).astype(np.float64)
+    assert np.max(np.abs(y.cpu().numpy() - O.tree_fwd(oc, theta, xin64))) < 3e-6
+    g_ref = O.tree_grad(oc, theta, xin64, gy.astype(np.float64), params=[0, 1, 3, 4, 5])
+    assert rel(np.array([float(g) for g in grads]), g_ref) < 3e-4
+
+
 def test_clipper_topology_through_the_streamed_kernels_equals_the_clipper_kernels(wdf, golden):
     """force_generic: Parallel(ResistiveVoltageSource, Capacitor) + diode pair + pot channel through wdf_ss_dyn_* against the
     golden of the clipper kernels' pot path (g6 rpot: fp64 restatement, Newton-verified) and against those kernels."""
@@ -216,13 +260,16 @@ def test_clipper_topology_through_the_streamed_kernels_equals_the_clipper_kernel
 def test_what_the_streamed_kernels_refuse(wdf, golden):
     from wdf_hip import binding as wb
     from layers import DenseRootModel
-    R = [wdf.Resistor(1.0e3 * (i + 1)) for i in range(2)]
-    caps = [wdf.Capacitor(1.0e-8 * (i + 1), FS) for i in range(3)]
+    R = [wdf.Resistor(1.0e3 * (i + 1)) for i in range(4)]
+    caps = [wdf.Capacitor(1.0e-8 * (i + 1), FS) for i in range(5)]
     Vs = wdf.ResistiveVoltageSource(1.0e3)
-    top = wdf.Series(wdf.Series(wdf.Parallel(caps[0], R[0]), wdf.Parallel(caps[1], R[1])), wdf.Series(Vs, caps[2]))
+    ladder = wdf.Series(Vs, caps[4])
+    for k in range(4):
+        ladder = wdf.Series(wdf.Parallel(caps[k], R[k]), ladder)
+    top = ladder
     dp = wdf.DiodePair(top, 4.352e-9, Vt=0.049)
-    with pytest.raises(wb.WdfHipError, match="two capacitors"):
-        wdf.Circuit(top, dp, caps[0], per_sample_R=Vs)            # three states
+    with pytest.raises(wb.WdfHipError, match="four capacitors"):
+        wdf.Circuit(top, dp, caps[0], per_sample_R=Vs)            # five states
     with pytest.raises(ValueError):
         wdf.Circuit(wdf.Parallel(wdf.Resistor(1e3), wdf.Series(wdf.ResistiveVoltageSource(1e3), wdf.Capacitor(1e-8, FS))), dp, caps[0])
     js, _, _ = _net(golden, "2x8")
