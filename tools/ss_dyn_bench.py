@@ -1,0 +1,71 @@
+"""GPU: the streamed-coefficient path (csrc/wdf_ss_dyn.h, lowering.Circuit._run_dyn) at the reference's training-set shape
+(1340 sequences x 2048 samples): HPFDiodeClipper.h:28-32's tree with a pot channel on the source resistance, under a diode
+pair and under the reference's 2x16 DenseRootModel; forward + reverse sweep through the element API (GradientTape ->
+tape.gradient), per phase: the rows (probe tape evaluated over the channel, torch), the forward kernel, the sweep."""
+import json, os, sys, time
+import numpy as np, torch
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "differentiable-wdfs_amd", "lib"))
+import tf_wdf as wdf
+from tf_wdf import tf
+from layers import DenseRootModel
+from wdf_hip import binding as wb, workload
+
+FS, B, T = 48000.0, 1340, 2048
+x = workload.sweep_batch(B, T, seed=4) * 0.6
+r = workload.dataset_resistance_batch(B, T, grid=(300.0, 1.0e3, 2.5e3, 5.0e3))
+xin = torch.as_tensor(np.stack([x, r], axis=-1).astype(np.float32), device="cuda")
+tgt = torch.zeros((T, B), device="cuda")
+
+
+def net_json(name):
+    wh, hidden, n_layers = workload.reference_mlp_weights(name)
+    layers, o, n_in = [], 0, 2
+    for i in range(n_layers + 1):
+        n_out = hidden if i < n_layers else 1
+        k = wh[o:o + n_in * n_out].reshape(n_in, n_out); o += n_in * n_out
+        b = wh[o:o + n_out]; o += n_out
+        layers.append({"type": "dense", "activation": "tanh" if i < n_layers else "", "shape": [None, n_out], "weights": [k.tolist(), b.tolist()]})
+        n_in = n_out
+    return {"in_shape": [None, 2], "layers": layers}
+
+
+def build(root):
+    R, Vs, C = wdf.Resistor(33.0e3, True), wdf.ResistiveVoltageSource(1.0e3), wdf.Capacitor(22.0e-9, FS, True)
+    top = wdf.Parallel(R, wdf.Series(Vs, C))
+    if root == "diode":
+        rt = wdf.DiodePair(top, 4.352e-9, Vt=25.85e-3 * 1.906, trainable=True)
+        params = [R.R, C.C, rt.Is, rt.nVt]
+    else:
+        rt = DenseRootModel(net_json("2x16_pre"))
+        params = [R.R, C.C] + list(rt.trainable_variables)
+    return wdf.Circuit(top, rt, R, per_sample_R=Vs), params
+
+
+for root in ("diode", "mlp2x16"):
+    circ, params = build(root)
+
+    def step():
+        with tf.GradientTape() as tape:
+            y = circ(xin)
+            loss = tf.reduce_mean(tf.square(y - tgt))
+        return tape.gradient(loss, params)
+
+    step(); step()
+    torch.cuda.synchronize()
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    e = [wb.Event() for _ in range(4)]
+    wb.Event.bracket_next(e[0], e[1])
+    with tf.GradientTape() as tape:
+        y = circ(xin)
+        loss = tf.reduce_mean(tf.square(y - tgt))
+    wb.Event.bracket_next(e[2], e[3])
+    g = tape.gradient(loss, params)
+    torch.cuda.synchronize()
+    print(json.dumps({"tree": "HPF clipper, pot on the source resistance", "root": root, "B": B, "T": T, "ms_per_fwd_bwd": ms,
+                      "samples_per_s": B * T / ms * 1e3, "fwd_kernel_ms": e[0].elapsed_ms(e[1]), "bwd_kernel_ms": e[2].elapsed_ms(e[3])}))
