@@ -469,6 +469,29 @@ def forward_only(args, dev, fs, B=1024, T=4096, steps=100, warmup=10):
     cands = sorted({k for k in (plan.k_fwd // 2, plan.k_fwd, plan.k_fwd * 2, plan.k_fwd * 4, plan.k_fwd * 8) if 2 <= k <= T // 32})
     times = {k: timed(k, 10)[0] for k in cands}
     k = min(times, key=times.get)
+    # ... and the warm-up, as engine.autotune_time_parallel does for the training pair: the planned W shrinks a 10 V error below
+    # 1e-7; on real data the diodes hold the state within ~1 V, so W - 32 is tried while the device's own verification reports a
+    # miss 8x inside the tolerance and the call gets faster (every call is verified and repaired whatever W is)
+    W_planned = plan.warmup
+    t_now = times[k]
+    for _ in range(6):
+        if plan.warmup < 96:
+            break
+        shorter = plan._replace(warmup=plan.warmup - 32)
+        keep = plan
+        plan = shorter
+        t_short, _, st_short = timed(k, 10)
+        stat = binding.tp_status(st_short)
+        if not (stat["n_bad"] == 0 and stat["max_miss"] <= plan.tol / 8.0 and t_short < 0.98 * t_now):
+            plan = keep
+            break
+        t_now = t_short
+    for k2 in (k * 2, k * 3 // 2):                               # (a shorter warm-up moves the best chunk count up)
+        if k2 <= T // 32 and k2 not in times:
+            t2, _, st2 = timed(k2, 10)
+            times[k2] = t2
+            if binding.tp_status(st2)["n_bad"] == 0 and t2 < 0.98 * t_now:
+                k, t_now = k2, t2
     for _ in range(warmup):
         binding.clipper_fwd_tp(xk, theta, fs, k, plan.warmup, plan.tol, want_stash=False, time_major=True)
     torch.cuda.synchronize()
@@ -476,6 +499,7 @@ def forward_only(args, dev, fs, B=1024, T=4096, steps=100, warmup=10):
     ms_ev, y, st = timed(k, steps)
     torch.cuda.synchronize()
     out = {"value": B * T / (ms_ev * 1e-3), "unit": "samples/s", "ms_per_call": ms_ev, "chunks": k, "warmup_steps": plan.warmup,
+           "warmup_steps_planned": W_planned,
            "chunk_sweep_ms": {str(kk): v for kk, v in times.items()}, "verify_status": binding.tp_status(st),
            "bytes_per_sample": 8, "hbm_frac": 8.0 * B * T / (ms_ev * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "workload": f"1N4148 diode clipper forward only, {B} sequences x {T} samples @ {int(fs)} Hz (BASELINE configs[1]); x resident "
