@@ -989,7 +989,7 @@ def self_launch(n, argv, rehearse):
     and this is skipped: the driver's `python -m torch.distributed.run ... bench.py --gpus N` form is untouched.)"""
     import socket
     import subprocess
-    if not rehearse and torch.cuda.is_available() and torch.cuda.device_count() < n:
+    if not rehearse and torch.cuda.is_available() and torch.cuda.device_count() < n and "--launch-check" not in argv:
         print(f"bench: --gpus {n} but this node shows {torch.cuda.device_count()} GPU(s) (--rehearse-on-one-gpu runs the {n}-rank "
               f"code path on one)", file=sys.stderr, flush=True)
         return 2
@@ -1019,8 +1019,11 @@ def ranks_report(world, dev, dt_local, steps):
     mine = torch.tensor([dt_local / steps * 1e3], dtype=torch.float64, device=dev)
     every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(every, mine)
-    props = torch.cuda.get_device_properties(dev)
-    ident = f"{os.uname().nodename}:{getattr(props, 'uuid', None) or getattr(props, 'pci_bus_id', dev.index)}:{dev.index}"
+    if dev.type == "cuda":
+        props = torch.cuda.get_device_properties(dev)
+        ident = f"{os.uname().nodename}:{getattr(props, 'uuid', None) or getattr(props, 'pci_bus_id', dev.index)}:{dev.index}"
+    else:
+        ident = f"{os.uname().nodename}:cpu"
     idents = [None] * dist.get_world_size()
     dist.all_gather_object(idents, ident)
     backend = dist.get_backend()
@@ -1033,7 +1036,8 @@ def ranks_report(world, dev, dt_local, steps):
     per = [float(t) for t in every]
     return {"ranks_seen": int(round(float(ones))), "world_size": dist.get_world_size(),
             "collective_backend": backend + (f" (RCCL {ver}: torch.distributed's nccl backend on ROCm)" if backend == "nccl" else
-                                             " (rehearsal: every rank on cuda:0)" if backend == "gloo" else ""),
+                                             " (rehearsal: every rank on cuda:0)" if backend == "gloo" and dev.type == "cuda" else
+                                             " (no GPU: host ranks)" if backend == "gloo" else ""),
             "devices_seen": len(set(idents)),
             "ms_per_step_per_rank": {"min": min(per), "max": max(per), "all": per},
             "launcher": "bench.py started the ranks itself (torch.distributed.run)" if os.environ.get("WDF_BENCH_SELF_LAUNCHED")
@@ -1056,6 +1060,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch sequences on every rank (default).  strong: ONE batch of --batch sequences "
                          "split over the ranks (SURVEY 8e: global B = 8192 fixed)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="pre-flight: start / join the ranks, count them with an all-reduce on the step's process group, print the "
+                         "`ranks` block and exit (no kernels; without a GPU the ranks meet over gloo)")
     ap.add_argument("--no-companion", action="store_true",
                     help="N > 1: skip the second measurement on the other scaling curve (strong next to a weak headline and vice versa)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1127,6 +1134,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.force_dist and world != 1:
         raise SystemExit("--force-dist is for world size 1")
+    if args.launch_check:
+        # pre-flight of the multi-rank entry point: the ranks are up (started here or by a launcher), the collective counts
+        # them, rank 0 prints what it saw -- seconds on an 8-GPU node, and (gloo, no kernels) runnable without a GPU
+        has_gpu = torch.cuda.is_available()
+        dev = torch.device("cuda", local) if has_gpu else torch.device("cpu")
+        r = ranks_report(world, dev, 0.0, 1)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": r["ranks_seen"], "ranks": r,
+                              "ok": r["ranks_seen"] == world}), flush=True)
+        if world > 1:
+            wdist.barrier()
+            torch.distributed.destroy_process_group()
+        raise SystemExit(0 if r["ranks_seen"] == world else 3)
     binding.require_gpu()
     if args.config == "c2":
         dev = torch.device("cuda", local)

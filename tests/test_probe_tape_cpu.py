@@ -73,3 +73,64 @@ def test_step_plan_tiles_every_column_and_balances_the_waves():
     k = [int((items[:, 0] == c).sum()) for c in (0, 21, 42, 63)]
     assert k[0] <= k[1] <= k[2] <= k[3] and k[3] >= k[0] + 6     # slow columns get more, shorter chunks
     assert max(cost) <= 1.25 * min(cost)                         # ... and every wave about the same number of steps
+
+
+def test_tape_evaluated_in_torch_over_a_resistance_channel():
+    """probe_tape.Tape.evaluate_torch (what the rows of wdf_ss_dyn_* are made of): with scalar parameters it reproduces
+    Circuit.matrices() (the host probe) and its gradient; with a [B,T] resistance channel in place of one parameter every
+    row equals the scalar evaluation at that sample's resistance, and the gradient to a static component is the sum over
+    the samples' gradients."""
+    import torch
+    import tf_wdf as wdf
+    from wdf_hip import probe_tape
+    FS = 48000.0
+    R, Vs, C = wdf.Resistor(33.0e3, True), wdf.ResistiveVoltageSource(1.0e3, trainable=True), wdf.Capacitor(22.0e-9, FS, True)
+    top = wdf.Parallel(R, wdf.Series(Vs, C))
+    dp = wdf.DiodePair(top, 4.352e-9, Vt=0.0493, trainable=True)
+    circ = wdf.Circuit(top, dp, R, per_sample_R=Vs)
+    own = {"Resistor": "R", "ResistiveVoltageSource": "R", "Capacitor": "C"}
+    params = [(e, own[type(e).__name__]) for e in circ.elements if type(e).__name__ in own]
+    pvars = [e.__dict__[n] for e, n in params]
+    tape, outs, rport = probe_tape.record(circ, pvars, device_limits=False)
+    coef, rp = circ.matrices()
+    vals = [torch.tensor(float(v), dtype=torch.float64, requires_grad=True) for v in pvars]
+    nodes = tape.evaluate_torch(vals, outs + [rport])
+    got = torch.stack([n.reshape(()) for n in nodes])
+    assert torch.allclose(got[:-1], coef.detach(), rtol=1e-6, atol=1e-12) and abs(float(got[-1]) - float(rp)) < 1e-6 * float(rp)
+    # a channel in place of the source resistance (parameter 1 in tree order: R, Vs, C)
+    i_pot = [k for k, (e, _) in enumerate(params) if e is Vs][0]
+    r = torch.tensor([[300.0, 1.0e3, 5.0e3], [2.0e3, 750.0, 1.2e4]], dtype=torch.float64)
+    vch = list(vals)
+    vch[i_pot] = r
+    rows = torch.stack([torch.broadcast_to(n, r.shape) for n in tape.evaluate_torch(vch, outs + [rport])], dim=-1)   # [B,T,n]
+    gC = torch.autograd.grad(rows.sum(), vals[2], retain_graph=True)[0]
+    gsum = 0.0
+    for b in range(2):
+        for t in range(3):
+            vs = [torch.tensor(float(v), dtype=torch.float64, requires_grad=True) for v in pvars]
+            vs[i_pot] = torch.tensor(float(r[b, t]), dtype=torch.float64)
+            one = torch.stack([n.reshape(()) for n in tape.evaluate_torch(vs, outs + [rport])])
+            assert torch.allclose(rows[b, t], one.detach(), rtol=1e-12, atol=0)
+            gsum += float(torch.autograd.grad(one.sum(), vs[2])[0])
+    assert abs(float(gC) - gsum) <= 1e-9 * abs(gsum)
+
+
+def test_resident_entries_are_found_by_storage_not_by_object():
+    """lowering.tensor_key / EntryCache: two slices of the same rows are the same batch, another slice or an in-place change
+    is another; the cache keeps at most max_entries, and beyond four entries at most max_bytes."""
+    import torch
+    from wdf_hip import lowering
+    X = torch.arange(24, dtype=torch.float32).reshape(6, 4)
+    a, b, c = X[0:2], X[0:2], X[2:4]
+    assert a is not b and lowering.tensor_key(a) == lowering.tensor_key(b) != lowering.tensor_key(c)
+    k0 = lowering.tensor_key(a)
+    X[0, 0] += 1.0
+    assert lowering.tensor_key(X[0:2]) != k0                     # the version counter moved
+    cache = lowering.EntryCache(max_entries=6, max_bytes=100)
+    for i in range(10):
+        cache.put(i, {"i": i}, nbytes=40)
+    assert len(cache) == 4 and cache.get(9) is not None and cache.get(5) is None        # 4 entries of 40 B: above 100 B only 4 stay
+    small = lowering.EntryCache(max_entries=6, max_bytes=10_000)
+    for i in range(10):
+        small.put(i, i, nbytes=40)
+    assert len(small) == 6 and small.get(3) is None and small.get(4) == 4
