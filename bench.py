@@ -816,11 +816,8 @@ def run_mlp_root(args, world, rank, local):
         # weight-gradient pass of the reverse sweep.  On the matrix cores (16-sequence waves, csrc/wdf_mlp_mfma.h) the
         # latter issues, per wave and step, (NL - 1) x 4 + 1 forward MFMAs, the same again transposed for the deltas and
         # 4 outer-product MFMAs per layer: 27 v_mfma_f32_16x16x4_f32 (2048 flop each) for three tanh layers.
-        # (the library's own dispatch rule, csrc/wdf_capi_mlp.hip: 16-sequence waves must fill half the chip)
-        w16 = (B + 15) // 16
-        wg_env = os.environ.get("WDF_MLP_WGRAD_MFMA")
-        wg_mfma = plan is not None and plan.k_bwd > 1 and \
-            (int(wg_env) > 0 if wg_env else w16 * min(max(2048 // w16, 1), max(1, T // 64)) >= 512)
+        # (which kernel ran: the library is asked, csrc/wdf_capi_mlp.hip wdf_clipper_mlp_wgrad_matrix_core_chunks)
+        wg_mfma = plan is not None and plan.k_bwd > 1 and binding.lib().wdf_clipper_mlp_wgrad_matrix_core_chunks(B, T) > 0
         n_mfma = 12 * (n_tanh - 1) + 3     # forward 4 (NL-1) + 1, deltas + outer products 8 (NL-1), d/da and d/dlr sums 2
         flops = (B + 15) // 16 * T * n_mfma * 2048
         achieved_tf = flops / (wk_ms * 1e-3) / 1e12

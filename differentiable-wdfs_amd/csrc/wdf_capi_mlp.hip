@@ -49,6 +49,22 @@ static int mlp_check(const float* x, const float* theta2, const float* w, int hi
     return WDF_OK;
 }
 
+// The weight-gradient pass of wdf_clipper_mlp_bwd_w_tp(_kappa) runs on the matrix cores (wdf_mlp_mfma.h, 16 sequences per wave)
+// when that fills at least half the chip at two waves per SIMD: the chunk count it then uses, else 0.  WDF_MLP_WGRAD_MFMA = a
+// chunk count forces it, 0 switches it off.  Exported so that a harness pricing that kernel asks the library instead of
+// restating the rule.
+extern "C" int wdf_clipper_mlp_wgrad_matrix_core_chunks(int64_t B, int64_t T)
+{
+    if (B <= 0 || T <= 0) return 0;
+    int wm_chunks = 0;
+    const int64_t w16 = (B + 15) / 16, kmax = T / 64 > 1 ? T / 64 : 1;
+    int64_t kw = 2048 / w16;
+    kw = kw > kmax ? kmax : (kw < 1 ? 1 : kw);
+    if (w16 * kw >= 512) wm_chunks = (int)kw;
+    if (const char* e = getenv("WDF_MLP_WGRAD_MFMA")) wm_chunks = atoi(e);
+    return wm_chunks;
+}
+
 // Which forward kernel: the row kernel (4 sequences per wave, DPP; the shorter dependent chain per step: 0.31 us against
 // 0.55 us) while the batch leaves SIMDs idle, the matrix-core kernel (16 per wave, wdf_mlp_mfma.h; 1.5x the row
 // kernel's throughput) once the row kernel would stack three waves on a SIMD.  WDF_MLP_FWD_ROW = 1 / 0 forces one.
@@ -347,14 +363,7 @@ static int mlp_bwd_w_tp_common(const float* x, const float* r, const float* thet
     // (C) on the matrix cores (wdf_mlp_mfma.h, 16 sequences per wave) when that fills at least half the chip, two waves
     // per SIMD -- bench.py --root mlp2x16 / 2x8 / 4x8: step 0.655 -> 0.578, 0.663 -> 0.596, 1.170 -> 0.978 ms.
     // WDF_MLP_WGRAD_MFMA = a chunk count forces it, 0 switches it off.
-    int wm_chunks = 0;
-    {
-        const int64_t w16 = (B + 15) / 16, kmax = T / 64 > 1 ? T / 64 : 1;
-        int64_t kw = 2048 / w16;
-        kw = kw > kmax ? kmax : (kw < 1 ? 1 : kw);
-        if (w16 * kw >= 512) wm_chunks = (int)kw;
-    }
-    if (const char* e = getenv("WDF_MLP_WGRAD_MFMA")) wm_chunks = atoi(e);
+    int wm_chunks = wdf_clipper_mlp_wgrad_matrix_core_chunks(B, T);
     const MlpTpGeom gm = mlp_tp_geom(T, wm_chunks > 0 ? wm_chunks : 1);
     const dim3 wmgrid((unsigned)((B + 15) / 16), (unsigned)gm.K);
     if (wm_chunks > 0 && (int64_t)wmgrid.x * wmgrid.y > (int64_t)nparts) wm_chunks = 0;     // (the partial buffers are sized for the row grid)

@@ -141,6 +141,8 @@ def lib():
     L.wdf_ss_dyn_bwd_ws_bytes.argtypes = [i64]
     L.wdf_ss_dyn_bwd.restype = ci
     L.wdf_ss_dyn_bwd.argtypes = [fp, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, fp, fp, fp, vp, fp, fp, fp, fp, i64, i64, vp]
+    L.wdf_clipper_mlp_wgrad_matrix_core_chunks.restype = ci
+    L.wdf_clipper_mlp_wgrad_matrix_core_chunks.argtypes = [i64, i64]
     L.wdf_asym_root.restype = ci
     L.wdf_asym_root.argtypes = [fp, fp, cf, ci, C.c_double, ci, vp, i64, vp]
     L.wdf_mlp_weight_count.restype = ci
@@ -274,7 +276,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_step_mse_tp", "wdf_clipper_step_esr_tp", "wdf_esr_finish", "wdf_loss_sums_ws_bytes", "wdf_loss_sums", "wdf_esr_coef", "wdf_loss_esr_grad", "wdf_clipper_bwd_esr_tp",
     "wdf_clipper_asym_fwd", "wdf_clipper_asym_fwd_tp_ws_bytes", "wdf_clipper_asym_fwd_tp", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd",
     "wdf_clipper_asym_bwd_tp_ws_bytes", "wdf_clipper_asym_bwd_tp", "wdf_asym_root",
-    "wdf_ss_dyn_row_len", "wdf_ss_dyn_fwd", "wdf_ss_dyn_bwd_ws_bytes", "wdf_ss_dyn_bwd",
+    "wdf_ss_dyn_row_len", "wdf_ss_dyn_fwd", "wdf_ss_dyn_bwd_ws_bytes", "wdf_ss_dyn_bwd", "wdf_clipper_mlp_wgrad_matrix_core_chunks",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
     "wdf_clipper_mlp_tp_chunks", "wdf_clipper_mlp_fwd_tp_ws_bytes", "wdf_clipper_mlp_fwd_tp",

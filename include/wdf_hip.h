@@ -614,6 +614,9 @@ int wdf_clipper_mlp_bwd_w_tp_kappa(const float* x, const float* r, const float* 
                                    float* gtheta2, float* gw, int64_t B, int64_t T, int n_chunks, void* stream);
 
 /* library / device info */
+/* chunk count the weight-gradient pass of wdf_clipper_mlp_bwd_w_tp(_kappa) uses on the matrix cores for this shape, 0 when it stays on
+ * the row kernel (the library's own dispatch rule, for a harness that prices that kernel). */
+int wdf_clipper_mlp_wgrad_matrix_core_chunks(int64_t B, int64_t T);
 int wdf_abi_version(void);
 const char* wdf_last_error(void);
 /* fills name (<= cap bytes) with the gcnArchName of `device`, returns the CU count or <0 */
