@@ -395,6 +395,9 @@ class Trainer:
         wdist.barrier()
         dt = time.perf_counter() - t0
         self.dt_local = dt
+        # the warm-start controller as the TIMED steps left it (the untimed continuation below puts the parameters back afterwards:
+        # a jump the controller answers with more warm-up -- not what the timed region ran with)
+        self.warm_after_timed = None if self.stepper.warm is None else self.stepper.warm.info()
         if graph is not None:                                  # kernel durations: the warm-up steps' (their last ones: past the cold call)
             evs = [e for e in warm_evs if e is not None][-8:] + evs
             self.n_in_region = 0
@@ -1258,7 +1261,7 @@ def main():
         f_in, b_in = t_fwd[:n_in], t_bwd[:n_in]
         f_ms = float(np.mean(f_in))
         b_ms = float(np.mean(b_in)) if t_bwd else None
-        warm = None if stepper.warm is None else stepper.warm.info()
+        warm = getattr(main_run, "warm_after_timed", None) or (None if stepper.warm is None else stepper.warm.info())
         # a kernel's traffic depends on the batch, the layout and its OWN chunking only
         key = {"B": B, "T": T, "x_layout": "time-major" if tm else "batch-major", "loss": args.loss}
         w_used = None if tp is None else (tp.warmup if warm is None else warm["warm_unit_steps"] * max(0, warm["last_warm_tiles"]))
