@@ -51,6 +51,40 @@ int wdf_ss_dyn_row_len(int ns, int ni) { return dyn_ok(ns, ni) ? wdf::DynLayout(
         else hipLaunchKernelGGL((wdf::KERNEL<wdf::kDynRootMlp, true, 8, 5>), grid, dim3(64), 0, s, __VA_ARGS__);               \
     } while (0)
 
+// the reverse sweep's kernel in one of its modes (0: sequential, 1: chunk maps + root partials; 2 -- no root code in it -- below)
+#define WDF_DYN_BWD(MODE_, ...)                                                                                               \
+    do {                                                                                                                     \
+        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 4, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__); \
+        else if (root == WDF_ROOT_DIODE_PAIR && n_up == n_down)                                                              \
+            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 4, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__);   \
+        else if (root == WDF_ROOT_DIODE_PAIR)                                                                                \
+            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, false, 4, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__);  \
+        else if (hidden == 4 && n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 4, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__); \
+        else if (hidden == 8 && n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 8, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__); \
+        else if (hidden == 16 && n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__); \
+        else if (hidden == 4 && n_tanh_layers == 5) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 4, 5, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 8, 5, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__);     \
+    } while (0)
+
+#define WDF_DYN_BWD_EMIT(...)                                                                                                 \
+    do {                                                                                                                     \
+        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 4, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__); \
+        else if (root == WDF_ROOT_DIODE_PAIR) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 4, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 4, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__);          \
+    } while (0)
+
+namespace {
+// chunk length (a multiple of 8) and count for n_chunks requested; false when the count does not tile T that way
+bool dyn_geom(int64_t T, int n_chunks, int64_t& L, int& K)
+{
+    if (n_chunks < 1) return false;
+    L = (T + n_chunks - 1) / n_chunks;
+    L = (L + 7) / 8 * 8;
+    K = (int)((T + L - 1) / L);
+    return K == n_chunks;
+}
+}  // namespace
+
 int wdf_ss_dyn_fwd(const float* x, const float* rows, int per_sample, int ns, int ni, int root, const float* rootp, const float* w,
                    int hidden, int n_tanh_layers, int n_up, int n_down, float* y, float* zstash, const float* z0, float* zT,
                    int64_t B, int64_t T, void* stream)
@@ -63,8 +97,51 @@ int wdf_ss_dyn_fwd(const float* x, const float* rows, int per_sample, int ns, in
     const dim3 grid((unsigned)((B + 63) / 64));
     hipStream_t s = (hipStream_t)stream;
     EventBracket bracket(s);
-    WDF_DYN_DISPATCH(ss_dyn_fwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T);
+    WDF_DYN_DISPATCH(ss_dyn_fwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, T, (int64_t)0,
+                     (float*)nullptr, (float*)nullptr, (const unsigned*)nullptr);
     return check_launch("wdf_ss_dyn_fwd");
+}
+
+size_t wdf_ss_dyn_fwd_tp_ws_bytes(int ns, int64_t B, int n_chunks)
+{
+    if (ns < 0 || B <= 0 || n_chunks <= 0) return 0;
+    return (size_t)2 * (size_t)n_chunks * (size_t)(ns > 0 ? ns : 1) * (size_t)B * sizeof(float) + (size_t)((B + 63) / 64) * sizeof(unsigned);
+}
+
+int wdf_ss_dyn_fwd_tp(const float* x, const float* rows, int per_sample, int ns, int ni, int root, const float* rootp, const float* w,
+                      int hidden, int n_tanh_layers, int n_up, int n_down, float* y, float* zstash, const float* z0, float* zT,
+                      int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws, void* status, void* stream)
+{
+    int rc = dyn_check("wdf_ss_dyn_fwd_tp", x, rows, ns, ni, root, rootp, w, hidden, n_tanh_layers, n_up, n_down, B, T, per_sample);
+    if (rc) return rc;
+    if (!y || !ws || !status) return fail(WDF_EINVAL, "wdf_ss_dyn_fwd_tp: null y / ws / status");
+    if (ns < 1) return fail(WDF_EINVAL, "wdf_ss_dyn_fwd_tp: a tree without states has no chunks to verify: use wdf_ss_dyn_fwd");
+    if (warmup < 0 || !(tol >= 0.0f)) return fail(WDF_EINVAL, "wdf_ss_dyn_fwd_tp: warmup >= 0, tol >= 0");
+    int64_t Lc;
+    int K;
+    if (!dyn_geom(T, n_chunks, Lc, K)) return fail(WDF_EINVAL, "wdf_ss_dyn_fwd_tp: n_chunks = %d does not tile T = %lld in 8-step units (%d does)", n_chunks, (long long)T, K);
+    const int64_t n = wdf::DynLayout(ns, ni).n;
+    const int64_t cs = per_sample ? B : 1, ts = per_sample ? n * B : 0, bs = per_sample ? 1 : 0;
+    float* zwarm = (float*)ws;
+    float* zend = zwarm + (size_t)K * (size_t)ns * (size_t)B;
+    unsigned* gate = (unsigned*)(zend + (size_t)K * (size_t)ns * (size_t)B);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(status, 0, sizeof(wdf::SsTpStatus), s) != hipSuccess) return fail(WDF_ELAUNCH, "wdf_ss_dyn_fwd_tp: memset failed");
+    {
+        const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K);
+        EventBracket bracket(s);
+        WDF_DYN_DISPATCH(ss_dyn_fwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, Lc,
+                         (int64_t)warmup, zwarm, zend, (const unsigned*)nullptr);
+    }
+    if (K > 1) {
+        const dim3 grid((unsigned)((B + 63) / 64));
+        hipLaunchKernelGGL(wdf::ss_tp_verify_kernel, grid, dim3(64), 0, s, (const float*)zwarm, (const float*)zend, ns, B, (int64_t)K, tol,
+                           gate, (wdf::SsTpStatus*)status);
+        // the waves with a miss again, sequentially (the gate lets the others leave at once)
+        WDF_DYN_DISPATCH(ss_dyn_fwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, T, (int64_t)0,
+                         (float*)nullptr, (float*)nullptr, (const unsigned*)gate);
+    }
+    return check_launch("wdf_ss_dyn_fwd_tp");
 }
 
 size_t wdf_ss_dyn_bwd_ws_bytes(int64_t B) { return B > 0 ? (size_t)((B + 63) / 64) * 2 * sizeof(double) : 0; }
@@ -82,9 +159,50 @@ int wdf_ss_dyn_bwd(const float* x, const float* rows, int per_sample, int ns, in
     const dim3 grid((unsigned)((B + 63) / 64));
     hipStream_t s = (hipStream_t)stream;
     EventBracket bracket(s);
-    WDF_DYN_DISPATCH(ss_dyn_bwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, (double*)ws, gb, ain, lrin,
-                     gz0, ns, ni, B, T);
+    WDF_DYN_BWD(0, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, (double*)ws, gb, ain, lrin, gz0, ns, ni, B, T, T,
+                (float*)nullptr, (float*)nullptr, (const float*)nullptr);
     return check_launch("wdf_ss_dyn_bwd");
+}
+
+// ws: double [K waves][2] partial sums | rec float [K][(ns + 1) ns][B] | lam_in float [K][ns][B] | rpart float [T][5][B]
+size_t wdf_ss_dyn_bwd_tp_ws_bytes(int ns, int64_t B, int64_t T, int n_chunks)
+{
+    if (ns < 0 || B <= 0 || T <= 0 || n_chunks <= 0) return 0;
+    const size_t nsa = ns > 0 ? ns : 1, waves = (size_t)((B + 63) / 64);
+    return (size_t)n_chunks * waves * 2 * sizeof(double) +
+           ((size_t)n_chunks * (nsa + 1) * nsa + (size_t)n_chunks * nsa + (size_t)T * wdf::kDynRpart) * (size_t)B * sizeof(float);
+}
+
+int wdf_ss_dyn_bwd_tp(const float* x, const float* rows, int per_sample, int ns, int ni, int root, const float* rootp, const float* w,
+                      int hidden, int n_tanh_layers, int n_up, int n_down, const float* zstash, const float* gy, float* grows,
+                      void* ws, float* gb, float* ain, float* lrin, float* gz0, int64_t B, int64_t T, int n_chunks, void* stream)
+{
+    int rc = dyn_check("wdf_ss_dyn_bwd_tp", x, rows, ns, ni, root, rootp, w, hidden, n_tanh_layers, n_up, n_down, B, T, per_sample);
+    if (rc) return rc;
+    if (!gy || !grows || !ws || !zstash) return fail(WDF_EINVAL, "wdf_ss_dyn_bwd_tp: null gy / grows / ws / zstash");
+    if (ns < 1) return fail(WDF_EINVAL, "wdf_ss_dyn_bwd_tp: a tree without states has no adjoint to chunk: use wdf_ss_dyn_bwd");
+    if (root == WDF_ROOT_MLP && (!gb || !ain || !lrin)) return fail(WDF_EINVAL, "wdf_ss_dyn_bwd_tp: the MLP root needs gb / ain / lrin [T][B]");
+    int64_t Lc;
+    int K;
+    if (!dyn_geom(T, n_chunks, Lc, K)) return fail(WDF_EINVAL, "wdf_ss_dyn_bwd_tp: n_chunks = %d does not tile T = %lld in 8-step units (%d does)", n_chunks, (long long)T, K);
+    const int64_t n = wdf::DynLayout(ns, ni).n;
+    const int64_t cs = per_sample ? B : 1, ts = per_sample ? n * B : 0, bs = per_sample ? 1 : 0;
+    const size_t waves = (size_t)((B + 63) / 64);
+    double* part = (double*)ws;
+    float* rec = (float*)(part + (size_t)K * waves * 2);
+    float* lam_in = rec + (size_t)K * (size_t)(ns + 1) * (size_t)ns * (size_t)B;
+    float* rpart = lam_in + (size_t)K * (size_t)ns * (size_t)B;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)waves, (unsigned)K);
+    {
+        EventBracket bracket(s);
+        WDF_DYN_BWD(1, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, part, gb, ain, lrin, gz0, ns, ni, B, T, Lc, rpart, rec,
+                    (const float*)nullptr);
+    }
+    hipLaunchKernelGGL(wdf::ss_dyn_bwd_combine_kernel, dim3((unsigned)waves), dim3(64), 0, s, (const float*)rec, lam_in, ns, B, (int64_t)K);
+    WDF_DYN_BWD_EMIT(x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, part, gb, ain, lrin, gz0, ns, ni, B, T, Lc, rpart, rec,
+                     (const float*)lam_in);
+    return check_launch("wdf_ss_dyn_bwd_tp");
 }
 
 }  // extern "C"

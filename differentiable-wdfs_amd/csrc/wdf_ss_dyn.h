@@ -93,10 +93,18 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ w_in, int n_up, int n_down,
                                                         float* __restrict__ y, float* __restrict__ zstash,
                                                         const float* __restrict__ z0, float* __restrict__ zT, int ns, int ni,
-                                                        int64_t B, int64_t T)
+                                                        int64_t B, int64_t T, int64_t Lc, int64_t W, float* __restrict__ zwarm,
+                                                        float* __restrict__ zend, const unsigned* __restrict__ gate)
 {
+    // Time chunks (grid.y = K; Lc = T, K = 1: the sequential recursion): chunk k owns [k Lc, (k + 1) Lc) and starts W steps early from
+    // z = 0 (or at t = 0 from z0); the state it ARRIVES with at its first owned step and the state it ends with go to zwarm /
+    // zend for ss_tp_verify_kernel; a second, gated launch with K = 1 re-runs the waves that missed (wdf_statespace.h's scheme).
+    if (gate != nullptr && gate[blockIdx.x] == 0u) return;
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;
+    const int64_t k = blockIdx.y;
+    const int64_t t0 = k * Lc, t1 = (t0 + Lc < T) ? t0 + Lc : T;
+    const int64_t tw = (k > 0 && t0 > W) ? t0 - W : 0;
     const DynLayout L(ns, ni);
     DynRoot<ROOT, SYM, H, NL> root;
     root.load(rootp, n_up, n_down);
@@ -107,11 +115,17 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
     }
     float z[kDynMaxS];
 #pragma unroll
-    for (int s = 0; s < kDynMaxS; ++s) z[s] = (s < ns && z0) ? z0[s * B + b] : 0.0f;
+    for (int s = 0; s < kDynMaxS; ++s) z[s] = (s < ns && z0 && tw == 0) ? z0[s * B + b] : 0.0f;
     const float* __restrict__ xp = x + b * T * ni;
     const float* __restrict__ cp = crow + b * bs;
     [[maybe_unused]] float act[NL][H];
-    for (int64_t t = 0; t < T; ++t) {
+    for (int64_t t = tw; t < t1; ++t) {
+        const bool owned = t >= t0;                                // wave-uniform
+        if (t == t0 && zwarm != nullptr) {
+#pragma unroll
+            for (int s = 0; s < kDynMaxS; ++s)
+                if (s < ns) zwarm[(k * ns + s) * B + b] = z[s];
+        }
         if constexpr (ROOT == kDynRootMlp) asm volatile("" ::: "memory");      // re-read the weights from LDS every step (wdf_mlp.h)
         const DynRow c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
         float xv[kDynMaxI];
@@ -140,25 +154,44 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
             for (int i = 0; i < kDynMaxI; ++i) acc = fmaf(c.Bx[s][i], xv[i], acc);
             zn[s] = acc;
         }
-        if (zstash) {
+        if (owned) {
+            if (zstash) {
 #pragma unroll
-            for (int s = 0; s < kDynMaxS; ++s)
-                if (s < ns) zstash[(t * ns + s) * B + b] = z[s];
+                for (int s = 0; s < kDynMaxS; ++s)
+                    if (s < ns) zstash[(t * ns + s) * B + b] = z[s];
+            }
+            y[t * B + b] = yv;
         }
-        y[t * B + b] = yv;
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s) z[s] = zn[s];
     }
-    if (zT) {
+    if (zend != nullptr) {
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s)
+            if (s < ns) zend[(k * ns + s) * B + b] = z[s];
+    }
+    if (zT && t1 == T) {
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s)
             if (s < ns) zT[s * B + b] = z[s];
     }
 }
 
-// grow [T][kN1][B]; ws: double[gridDim.x][2] = the wave's {sum gb D_L, sum gb D_V} (diode root);
-// gbroot / ain / lrin [T][B] (MLP root): dL/db, a, log R_port of every step for mlp_wgrad_kernel
-template <int ROOT, bool SYM, int H, int NL>
+// grow [T][kN1][B]; ws: double[gridDim.y gridDim.x][2] = the (chunk, wave)'s {sum gb D_L, sum gb D_V} (diode root);
+// gbroot / ain / lrin [T][B] (MLP root): dL/db, a, log R_port of every step for mlp_wgrad_kernel.
+//
+// Time chunks (round 5, wdf_ss_dyn_bwd_tp) -- EXACT: the adjoint recurrence is linear in the adjoint entering a chunk from the
+// future, so the sweep runs in three launches over grid (waves, K):
+//   MODE 1  evaluates the root's partials of every step ONCE (the expensive part: omega / the network and its input gradient),
+//           leaves them in rpart [T][5][B] = {Da, b, d b/d R_port, D_L, D_V} (and a, log R_port for the network's weight
+//           gradient), and carries the chunk's adjoint map: lam leaving the chunk = Phi lam entering + beta (ns homogeneous runs
+//           and the particular one) -> rec [K][(ns + 1) ns][B];
+//   ss_dyn_bwd_combine_kernel walks a sequence's K maps last to first -> the adjoint entering every chunk, lam_in [K][ns][B];
+//   MODE 2  re-walks every chunk from its true entering adjoint reading rpart -- no root evaluation -- and emits what MODE 0 emits.
+// MODE 0 (K = 1) is the sequential sweep: root evaluated and rows emitted in one walk.
+constexpr int kDynRpart = 5;
+
+template <int ROOT, bool SYM, int H, int NL, int MODE>
 __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ crow, int64_t cs,
                                                         int64_t ts, int64_t bs, const float* __restrict__ rootp,
                                                         const float* __restrict__ w_in, int n_up, int n_down,
@@ -166,16 +199,19 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ grow, double* __restrict__ ws,
                                                         float* __restrict__ gbroot, float* __restrict__ ain,
                                                         float* __restrict__ lrin, float* __restrict__ gz0, int ns, int ni,
-                                                        int64_t B, int64_t T)
+                                                        int64_t B, int64_t T, int64_t Lc, float* __restrict__ rpart,
+                                                        float* __restrict__ rec, const float* __restrict__ lam_in)
 {
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = b_raw < B;
     const int64_t b = live ? b_raw : B - 1;
+    const int64_t k = blockIdx.y;
+    const int64_t t0 = k * Lc, t1 = (t0 + Lc < T) ? t0 + Lc : T;
     const DynLayout L(ns, ni);
     DynRoot<ROOT, SYM, H, NL> root;
     root.load(rootp, n_up, n_down);
-    __shared__ __attribute__((aligned(16))) float w[(ROOT == kDynRootMlp ? Mlp<H, NL>::kCount : 0) + 4];
-    if constexpr (ROOT == kDynRootMlp) {
+    __shared__ __attribute__((aligned(16))) float w[((ROOT == kDynRootMlp && MODE != 2) ? Mlp<H, NL>::kCount : 0) + 4];
+    if constexpr (ROOT == kDynRootMlp && MODE != 2) {
         for (int i = threadIdx.x; i < Mlp<H, NL>::kCount; i += 64) w[i] = w_in[i];
         __syncthreads();
     }
@@ -183,11 +219,19 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
     const float* __restrict__ cp = crow + b * bs;
     float lam[kDynMaxS];
 #pragma unroll
-    for (int s = 0; s < kDynMaxS; ++s) lam[s] = 0.0f;
+    for (int s = 0; s < kDynMaxS; ++s) lam[s] = (MODE == 2 && s < ns) ? lam_in[(k * ns + s) * B + b] : 0.0f;
+    // MODE 1: the homogeneous runs -- hom[j] is the adjoint that enters as the unit vector e_j (dL/dy = 0)
+    [[maybe_unused]] float hom[kDynMaxS][kDynMaxS];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < kDynMaxS; ++j)
+#pragma unroll
+            for (int s = 0; s < kDynMaxS; ++s) hom[j][s] = (j == s && j < ns) ? 1.0f : 0.0f;
+    }
     double sL = 0.0, sV = 0.0;
     [[maybe_unused]] float act[NL][H];
-    for (int64_t t = T - 1; t >= 0; --t) {
-        if constexpr (ROOT == kDynRootMlp) asm volatile("" ::: "memory");
+    for (int64_t t = t1 - 1; t >= t0; --t) {
+        if constexpr (ROOT == kDynRootMlp && MODE != 2) asm volatile("" ::: "memory");
         const DynRow c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
         float xv[kDynMaxI], z[kDynMaxS];
 #pragma unroll
@@ -202,6 +246,13 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
         for (int i = 0; i < kDynMaxI; ++i) a = fmaf(c.da[i], xv[i], a);
         float broot = 0.0f, Da = 0.0f, Drp = 0.0f;                 // d b / d a, d b / d R_port
         [[maybe_unused]] float DL = 0.0f, DV = 0.0f, lr = 0.0f;
+        if constexpr (MODE == 2) {
+            if constexpr (ROOT != kDynRootNone) {
+                const float* __restrict__ rp_ = rpart + (t * kDynRpart) * B + b;
+                Da = rp_[0]; broot = rp_[B]; Drp = rp_[2 * B];
+                if constexpr (ROOT == kDynRootDiode) { DL = rp_[3 * B]; DV = rp_[4 * B]; }
+            }
+        } else
         if constexpr (ROOT == kDynRootDiode) {
             const DiodeOut o = diode_pair<SYM>(a, logf(c.rp * root.Is / root.V), root.d);
             broot = o.b;
@@ -212,7 +263,7 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
             DV = fmaf(2.0f * l2 * a, sp * fast_rcp(root.V), -2.0f * o.lam * (o.m0 * o.w0 - o.m1 * o.w1));
             Drp = DL / c.rp;                                        // L = log(R_port Is / nVt)
         }
-        if constexpr (ROOT == kDynRootMlp) {
+        if constexpr (ROOT == kDynRootMlp && MODE != 2) {
             lr = logf(c.rp);
             broot = -Mlp<H, NL>::fwd(w, a, lr, act);
             float da, dlr;
@@ -224,6 +275,36 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s) gb = fmaf(c.E[s], lam[s], gb);
         const float ga = gb * Da;
+        if constexpr (MODE == 1) {
+            // what MODE 2 needs of this step's root, and the network's operands; then the adjoint maps -- no rows
+            if constexpr (ROOT != kDynRootNone) {
+                float* __restrict__ rp_ = rpart + (t * kDynRpart) * B + b;
+                rp_[0] = Da; rp_[B] = broot; rp_[2 * B] = Drp; rp_[3 * B] = DL; rp_[4 * B] = DV;
+            }
+            if constexpr (ROOT == kDynRootMlp) {
+                ain[t * B + b] = a;
+                lrin[t * B + b] = lr;
+            }
+#pragma unroll
+            for (int j = 0; j < kDynMaxS; ++j) {
+                if (j < ns) {
+                    float gbj = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < kDynMaxS; ++s) gbj = fmaf(c.E[s], hom[j][s], gbj);
+                    const float gaj = gbj * Da;
+                    float hn[kDynMaxS];
+#pragma unroll
+                    for (int s2 = 0; s2 < kDynMaxS; ++s2) {
+                        float v = c.ca[s2] * gaj;
+#pragma unroll
+                        for (int s = 0; s < kDynMaxS; ++s) v = fmaf(c.A[s][s2], hom[j][s], v);
+                        hn[s2] = v;
+                    }
+#pragma unroll
+                    for (int s = 0; s < kDynMaxS; ++s) hom[j][s] = hn[s];
+                }
+            }
+        } else {
         float* __restrict__ gp = grow + (t * L.n) * B + b;
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s) {
@@ -254,9 +335,12 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
         }
         if constexpr (ROOT == kDynRootMlp) {
             gbroot[t * B + b] = gb;
-            ain[t * B + b] = a;
-            lrin[t * B + b] = lr;
+            if constexpr (MODE == 0) {
+                ain[t * B + b] = a;
+                lrin[t * B + b] = lr;
+            }
         }
+        }   // MODE != 1
         float ln[kDynMaxS];
 #pragma unroll
         for (int s2 = 0; s2 < kDynMaxS; ++s2) {
@@ -268,7 +352,20 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s) lam[s] = ln[s];
     }
-    if (live && gz0) {
+    if constexpr (MODE == 1) {
+        // rec [k][j][s][B]: j < ns the columns of Phi (the adjoint that entered as e_j), j = ns the particular run (beta)
+        float* __restrict__ r = rec + (k * (ns + 1) * ns) * B + b;
+#pragma unroll
+        for (int j = 0; j < kDynMaxS; ++j)
+#pragma unroll
+            for (int s = 0; s < kDynMaxS; ++s)
+                if (j < ns && s < ns) r[(j * ns + s) * B] = hom[j][s];
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s)
+            if (s < ns) r[(ns * ns + s) * B] = lam[s];
+        return;
+    }
+    if (live && gz0 && t0 == 0) {
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s)
             if (s < ns) gz0[s * B + b] = lam[s];
@@ -277,8 +374,35 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
     sL = wave_sum(sL);
     sV = wave_sum(sV);
     if (threadIdx.x == 0 && ws) {
-        ws[(int64_t)blockIdx.x * 2 + 0] = sL;
-        ws[(int64_t)blockIdx.x * 2 + 1] = sV;
+        const int64_t slot = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        ws[slot * 2 + 0] = sL;
+        ws[slot * 2 + 1] = sV;
+    }
+}
+
+// one lane per sequence: the K chunk maps last to first -> lam_in [K][ns][B], the adjoint entering every chunk (0 enters the last)
+static __global__ __launch_bounds__(64) void ss_dyn_bwd_combine_kernel(const float* __restrict__ rec, float* __restrict__ lam_in, int ns,
+                                                                       int64_t B, int64_t K)
+{
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
+    float lam[kDynMaxS];
+#pragma unroll
+    for (int s = 0; s < kDynMaxS; ++s) lam[s] = 0.0f;
+    for (int64_t k = K - 1; k >= 0; --k) {
+        const float* __restrict__ r = rec + (k * (ns + 1) * ns) * B + b;
+        float nx[kDynMaxS];
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) {
+            if (s < ns) lam_in[(k * ns + s) * B + b] = lam[s];
+            float v = s < ns ? r[(ns * ns + s) * B] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < kDynMaxS; ++j)
+                if (j < ns && s < ns) v = fmaf(r[(j * ns + s) * B], lam[j], v);
+            nx[s] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < kDynMaxS; ++s) lam[s] = nx[s];
     }
 }
 

@@ -141,6 +141,14 @@ def lib():
     L.wdf_ss_dyn_bwd_ws_bytes.argtypes = [i64]
     L.wdf_ss_dyn_bwd.restype = ci
     L.wdf_ss_dyn_bwd.argtypes = [fp, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, fp, fp, fp, vp, fp, fp, fp, fp, i64, i64, vp]
+    L.wdf_ss_dyn_fwd_tp_ws_bytes.restype = C.c_size_t
+    L.wdf_ss_dyn_fwd_tp_ws_bytes.argtypes = [ci, i64, ci]
+    L.wdf_ss_dyn_fwd_tp.restype = ci
+    L.wdf_ss_dyn_fwd_tp.argtypes = [fp, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, vp]
+    L.wdf_ss_dyn_bwd_tp_ws_bytes.restype = C.c_size_t
+    L.wdf_ss_dyn_bwd_tp_ws_bytes.argtypes = [ci, i64, i64, ci]
+    L.wdf_ss_dyn_bwd_tp.restype = ci
+    L.wdf_ss_dyn_bwd_tp.argtypes = [fp, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, fp, fp, fp, vp, fp, fp, fp, fp, i64, i64, ci, vp]
     L.wdf_clipper_mlp_wgrad_matrix_core_chunks.restype = ci
     L.wdf_clipper_mlp_wgrad_matrix_core_chunks.argtypes = [i64, i64]
     L.wdf_asym_root.restype = ci
@@ -277,6 +285,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_asym_fwd", "wdf_clipper_asym_fwd_tp_ws_bytes", "wdf_clipper_asym_fwd_tp", "wdf_clipper_asym_bwd_ws_bytes", "wdf_clipper_asym_bwd",
     "wdf_clipper_asym_bwd_tp_ws_bytes", "wdf_clipper_asym_bwd_tp", "wdf_asym_root",
     "wdf_ss_dyn_row_len", "wdf_ss_dyn_fwd", "wdf_ss_dyn_bwd_ws_bytes", "wdf_ss_dyn_bwd", "wdf_clipper_mlp_wgrad_matrix_core_chunks",
+    "wdf_ss_dyn_fwd_tp_ws_bytes", "wdf_ss_dyn_fwd_tp", "wdf_ss_dyn_bwd_tp_ws_bytes", "wdf_ss_dyn_bwd_tp",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
     "wdf_clipper_mlp_tp_chunks", "wdf_clipper_mlp_fwd_tp_ws_bytes", "wdf_clipper_mlp_fwd_tp",
@@ -1185,6 +1194,66 @@ def ss_dyn_bwd(x, rows, ns, ni, zstash, gy, root_kind=ROOT_NONE, rootp=None, w=N
     groot = None
     if root_kind == ROOT_DIODE_PAIR:
         s = ws.sum(dim=0)
+        rp = rootp.double()
+        groot = torch.stack([s[0] / rp[0], s[1] - s[0] / rp[1]])
+    elif mlp:
+        groot = clipper_mlp_wgrad(ain.reshape(-1), lrin.reshape(-1), gb.reshape(-1), None, w, hidden, n_tanh, 1.0)
+    return grows, groot, gz0
+
+
+def dyn_chunks(T, n_chunks):
+    """The chunk count wdf_ss_dyn_*_tp accept for a requested one: chunks are whole 8-step units."""
+    Lc = -(-(-(-int(T) // max(1, int(n_chunks)))) // 8) * 8
+    return -(-int(T) // Lc)
+
+
+def ss_dyn_fwd_tp(x, rows, ns, ni, n_chunks, warmup, tol=1.0e-6, root_kind=ROOT_NONE, rootp=None, w=None, hidden=0, n_tanh=0, n_up=1,
+                  n_down=1, want_stash=True, z0=None, want_zT=False):
+    """ss_dyn_fwd in verified time chunks (wdf_ss_dyn_fwd_tp).  -> y, zstash | None, zT | None, status (int32 [4]: ss_tp_status)."""
+    require_gpu()
+    x, rows, rootp, w, z0 = _f32_dev(x, "x"), _f32_dev(rows, "rows"), _f32_dev(rootp, "rootp"), _f32_dev(w, "w"), _f32_dev(z0, "z0")
+    B, T = int(x.shape[0]), int(x.shape[1])
+    n = lib().wdf_ss_dyn_row_len(int(ns), int(ni))
+    per = rows.dim() == 3
+    if n == 0 or tuple(rows.shape) not in ((T, n, B), (n,)) or x.dim() != 3 or int(x.shape[2]) != ni:
+        raise WdfHipError(f"ss_dyn_fwd_tp: x [B,T,{ni}], rows [T,{n},B] or [{n}] (got x {tuple(x.shape)}, rows {tuple(rows.shape)})")
+    K = dyn_chunks(T, n_chunks)
+    y = torch.empty((T, B), dtype=torch.float32, device=x.device)
+    zs = torch.empty((T, ns, B), dtype=torch.float32, device=x.device) if want_stash else None
+    zT = torch.empty((ns, B), dtype=torch.float32, device=x.device) if want_zT else None
+    ws = torch.empty((lib().wdf_ss_dyn_fwd_tp_ws_bytes(int(ns), B, K),), dtype=torch.uint8, device=x.device)
+    status = torch.zeros((4,), dtype=torch.int32, device=x.device)
+    rc = lib().wdf_ss_dyn_fwd_tp(_ptr(x), _ptr(rows), 1 if per else 0, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
+                                 int(n_tanh), int(n_up), int(n_down), _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, K, int(warmup),
+                                 float(tol), _ptr(ws), _ptr(status), _stream())
+    _check(rc, "wdf_ss_dyn_fwd_tp")
+    return y, zs, zT, status
+
+
+def ss_dyn_bwd_tp(x, rows, ns, ni, zstash, gy, n_chunks, root_kind=ROOT_NONE, rootp=None, w=None, hidden=0, n_tanh=0, n_up=1, n_down=1,
+                  want_gz0=False):
+    """ss_dyn_bwd in exact time chunks (wdf_ss_dyn_bwd_tp): same results up to fp32 summation order."""
+    require_gpu()
+    x, rows, rootp, w = _f32_dev(x, "x"), _f32_dev(rows, "rows"), _f32_dev(rootp, "rootp"), _f32_dev(w, "w")
+    zstash, gy = _f32_dev(zstash, "zstash"), _f32_dev(gy, "gy")
+    B, T = int(x.shape[0]), int(x.shape[1])
+    n = lib().wdf_ss_dyn_row_len(int(ns), int(ni))
+    per = rows.dim() == 3
+    dev = x.device
+    K = dyn_chunks(T, n_chunks)
+    grows = torch.empty((T, n, B), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib().wdf_ss_dyn_bwd_tp_ws_bytes(int(ns), B, T, K),), dtype=torch.uint8, device=dev)
+    mlp = root_kind == ROOT_MLP
+    gb, ain, lrin = (torch.empty((T, B), dtype=torch.float32, device=dev) for _ in range(3)) if mlp else (None, None, None)
+    gz0 = torch.empty((ns, B), dtype=torch.float32, device=dev) if want_gz0 else None
+    rc = lib().wdf_ss_dyn_bwd_tp(_ptr(x), _ptr(rows), 1 if per else 0, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
+                                 int(n_tanh), int(n_up), int(n_down), _ptr(zstash), _ptr(gy), _ptr(grows), _ptr(ws), _ptr(gb), _ptr(ain),
+                                 _ptr(lrin), _ptr(gz0), B, T, K, _stream())
+    _check(rc, "wdf_ss_dyn_bwd_tp")
+    groot = None
+    if root_kind == ROOT_DIODE_PAIR:
+        nparts = K * ((B + 63) // 64)
+        s = ws[:nparts * 16].view(torch.float64).reshape(nparts, 2).sum(dim=0)
         rp = rootp.double()
         groot = torch.stack([s[0] / rp[0], s[1] - s[0] / rp[1]])
     elif mlp:

@@ -161,14 +161,21 @@ class _SsDynFn(torch.autograd.Function):
     component values -- calc_impedance's chain rule per sample (tf_wdf.py:114-115,139-145,168-177)."""
 
     @staticmethod
-    def forward(ctx, rows, rootvec, x, z0, ns, ni, kind, hidden, n_tanh, n_up, n_down, want_zT):
+    def forward(ctx, rows, rootvec, x, z0, ns, ni, kind, hidden, n_tanh, n_up, n_down, want_zT, tp=None):
         need = rows.requires_grad or (rootvec is not None and rootvec.requires_grad) or (z0 is not None and z0.requires_grad)
         r = rows.detach().float().contiguous()
         rv = None if rootvec is None else rootvec.detach().float().contiguous()
         z0d = None if z0 is None else z0.detach().float().contiguous()
         rootp, w = (rv, None) if kind == binding.ROOT_DIODE_PAIR else (None, rv)
-        y, zs, zT = binding.ss_dyn_fwd(x, r, ns, ni, kind, rootp=rootp, w=w, hidden=hidden, n_tanh=n_tanh, n_up=n_up, n_down=n_down,
-                                       want_stash=need, z0=z0d, want_zT=want_zT)
+        if tp is not None and tp.k_fwd >= 2 and ns >= 1:       # verified time chunks; the waves that missed re-run sequentially
+            y, zs, zT, st = binding.ss_dyn_fwd_tp(x, r, ns, ni, tp.k_fwd, tp.warmup, tp.tol, kind, rootp=rootp, w=w, hidden=hidden,
+                                                  n_tanh=n_tanh, n_up=n_up, n_down=n_down, want_stash=need, z0=z0d, want_zT=want_zT)
+            LAST_SS_TP_STATUS["status"] = st
+            LAST_SS_TP_STATUS["warmup_used"], LAST_SS_TP_STATUS["chunks_used"] = tp.warmup, tp.k_fwd
+        else:
+            y, zs, zT = binding.ss_dyn_fwd(x, r, ns, ni, kind, rootp=rootp, w=w, hidden=hidden, n_tanh=n_tanh, n_up=n_up, n_down=n_down,
+                                           want_stash=need, z0=z0d, want_zT=want_zT)
+        ctx.tp = tp
         ctx.cfg = (ns, ni, kind, hidden, n_tanh, n_up, n_down, z0 is not None, rows.dim() == 3)
         ctx.save_for_backward(r, rv, x, zs)
         if want_zT:
@@ -183,12 +190,17 @@ class _SsDynFn(torch.autograd.Function):
         rootp, w = (rv, None) if kind == binding.ROOT_DIODE_PAIR else (None, rv)
         if zs is None:
             zs = torch.zeros((x.shape[1], 1, x.shape[0]), dtype=torch.float32, device=x.device)      # (ns = 0: nothing to read)
-        grows, groot, gz0 = binding.ss_dyn_bwd(x, r, ns, ni, zs, gy.contiguous(), kind, rootp=rootp, w=w, hidden=hidden, n_tanh=n_tanh,
-                                               n_up=n_up, n_down=n_down, want_gz0=has_z0)
+        tp = ctx.tp
+        if tp is not None and tp.k_bwd >= 2 and ns >= 1:       # exact time chunks
+            grows, groot, gz0 = binding.ss_dyn_bwd_tp(x, r, ns, ni, zs, gy.contiguous(), tp.k_bwd, kind, rootp=rootp, w=w, hidden=hidden,
+                                                      n_tanh=n_tanh, n_up=n_up, n_down=n_down, want_gz0=has_z0)
+        else:
+            grows, groot, gz0 = binding.ss_dyn_bwd(x, r, ns, ni, zs, gy.contiguous(), kind, rootp=rootp, w=w, hidden=hidden, n_tanh=n_tanh,
+                                                   n_up=n_up, n_down=n_down, want_gz0=has_z0)
         if not per_sample:
             grows = grows.double().sum(dim=(0, 2)).float()
         return (grows, None if groot is None else groot.float(), None, (gz0[:ns] if has_z0 else None), None, None, None, None, None,
-                None, None, None)
+                None, None, None, None)
 
 
 # ------------------------------------------------------------------------------ resident entries: which batch is this?
@@ -973,9 +985,50 @@ class Circuit:
             rootvec, kind = None, binding.ROOT_NONE
         z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(self.ns, -1).contiguous()
         xs = x[:, :, :self.ni].contiguous()
-        y, zT = _SsDynFn.apply(rows, rootvec, xs, z0t, self.ns, self.ni, kind, hidden, n_tanh, n_up, n_down, bool(return_state))
+        tp = self._plan_dyn(tape, outs, vals, kind, B, T) if self.time_parallel == "auto" else \
+            (self.time_parallel if isinstance(self.time_parallel, SsTpPlan) else None)
+        y, zT = _SsDynFn.apply(rows, rootvec, xs, z0t, self.ns, self.ni, kind, hidden, n_tanh, n_up, n_down, bool(return_state), tp)
         y = y.as_subclass(tf.Tensor)
         return (y, zT[:self.ns]) if return_state else y
+
+    def _plan_dyn(self, tape, outs, vals, kind, B, T, tol=1.0e-6):
+        """SsTpPlan for the streamed-coefficient kernels (or None: the batch fills the chip / no state).  The reverse sweep is
+        exact in chunks: as many as give every SIMD ~2 waves, none shorter than 64 steps.  The forward warms a chunk up from
+        z = 0: W outlasts the slowest mode of the step's Jacobian A + Da E ca^T over the root's slope Da in [-1, 1], taken at
+        BOTH ends of the resistance channel (the tape evaluated at its smallest and largest value -- the adaptor coefficients are
+        monotone in one resistance); every boundary is verified on the device whatever the estimate.  Re-derived every 32 calls
+        (the components train slowly; a stale W costs a re-run of the waves that missed, never a wrong result)."""
+        ns, ni = self.ns, self.ni
+        if ns < 1:
+            return None
+        waves = max(1, -(-B // 64))
+        k_max = min(T // 64, (2 * N_SIMD) // waves)
+        if k_max < 2:
+            return None
+        cache = self.__dict__.setdefault("_dyn_plans", {})
+        key = (B, T, kind)
+        hit = cache.get(key)
+        if hit is not None and hit[1] < 32:
+            cache[key] = (hit[0], hit[1] + 1)
+            return hit[0]
+        with torch.no_grad(), torch._C.DisableTorchFunctionSubclass():
+            ends = [[v if v.dim() == 0 else sel(v) for v in vals] for sel in (torch.amin, torch.amax)] if self.per_sample_R is not None \
+                else [list(vals)]
+            rho = 0.0
+            for pv in ends:
+                c = torch.stack([v.reshape(()) for v in tape.evaluate_torch(pv, outs)]).double().cpu().numpy()
+                A = c[:ns * ns].reshape(ns, ns)
+                oE = ns * ns + ns * ni
+                E, ca = c[oE:oE + ns], c[oE + ns:oE + 2 * ns]
+                slopes = (0.0,) if kind == binding.ROOT_NONE else (1.0, -1.0)
+                rho = max(rho, max(float(np.max(np.abs(np.linalg.eigvals(A + sgn * np.outer(E, ca))))) for sgn in slopes))
+        k_fwd, W = 1, 0
+        if rho < 1.0 - 1e-9:
+            W = 8 if rho <= 0.0 else max(8, -(-int(math.ceil(math.log(0.01 * tol) / math.log(rho))) // 8) * 8)
+            k_fwd = max(1, min(k_max, T // max(W, 64)))
+        plan = SsTpPlan(k_fwd, W, float(tol), k_max)
+        cache[key] = (plan, 0)
+        return plan
 
     def _run_clipper(self, x, z0, return_state):
         from . import engine

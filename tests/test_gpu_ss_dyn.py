@@ -281,3 +281,56 @@ def test_what_the_streamed_kernels_refuse(wdf, golden):
         circ(cuda(np.zeros((2, 16))))
     with pytest.raises(wb.WdfHipError, match="streamed-coefficient"):
         circ.to_device()
+
+
+@pytest.mark.parametrize("root,pot_on,B,T,fast", [("diode", "Vs", 70, 1000, True), ("mlp", "Vs", 40, 515, True), ("mlp", None, 130, 2048, False),
+                                                  ("diode", "R", 5, 131, True), ("diode", "Vs", 130, 2048, False)])
+def test_streamed_kernels_in_time_chunks_equal_the_sequential_ones(wdf, golden, root, pot_on, B, T, fast):
+    """wdf_ss_dyn_fwd_tp / _bwd_tp (round 5): the forward in verified chunks gives the sequential kernel's y within the verified
+    tolerance with a clean verdict, the chunked reverse sweep its gradients up to fp32 summation order; a warm-up that is far
+    too short is noticed on the device and the waves concerned are re-run sequentially (identical outputs then)."""
+    from wdf_hip import binding as wb, lowering
+    tf = wdf.tf
+    js = _net(golden, "2x8")[0] if root == "mlp" else None
+    # fast: a small capacitor -- the tree forgets its state in a few dozen steps, the planner cuts the forward into chunks;
+    # else HPFDiodeClipper.h's values: with the diodes off the state decays by 2.7 % per step (672 warm-up steps), the forward
+    # stays sequential (or nearly) and only the reverse sweep is chunked
+    vals = [3.3e3, 1.0e3, 1.0e-9, 4.352e-9, 25.85e-3 * 1.906] if fast else [33.0e3, 1.0e3, 22.0e-9, 4.352e-9, 25.85e-3 * 1.906]
+    rng = np.random.default_rng(B + T)
+    x = (1.2 * rng.standard_normal((B, T))).astype(np.float32)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    if pot_on is None:
+        xin = cuda(x)
+    else:
+        r = pot_channel(B, T, 300.0, 5.0e3, 1) if pot_on == "Vs" else pot_channel(B, T, 2.0e3, 30.0e3, 2)
+        xin = cuda(np.stack([x, r], axis=-1))
+
+    def run(time_parallel):
+        circ, params, model = build_hpf(wdf, root, pot_on, vals, net=js)
+        circ.time_parallel = time_parallel
+        plist = [p for i, p in enumerate(params) if not (i == 0 and pot_on == "R") and not (i == 1 and pot_on == "Vs")]
+        if root == "mlp":
+            plist = plist + list(model.trainable_variables)
+        lowering.LAST_SS_TP_STATUS["status"] = None
+        with tf.GradientTape() as tape:
+            y = circ(xin)
+            loss = tf.reduce_sum(y * cuda(gy))
+        g = tape.gradient(loss, plist)
+        st = lowering.LAST_SS_TP_STATUS["status"]
+        return y.cpu().numpy(), np.concatenate([v.cpu().numpy().reshape(-1) for v in g]), (None if st is None else wb.ss_tp_status(st))
+
+    y_seq, g_seq, st_seq = run(None)
+    y_tp, g_tp, st_tp = run("auto")
+    assert st_seq is None
+    if root == "diode" and fast and T >= 512:
+        assert st_tp is not None and lowering.LAST_SS_TP_STATUS["chunks_used"] >= 2
+    if st_tp is not None:
+        assert st_tp["n_bad"] == 0 and st_tp["max_miss"] <= 1e-6, st_tp
+    assert np.max(np.abs(y_tp - y_seq)) <= 2e-6
+    scale = np.max(np.abs(g_seq))
+    assert np.max(np.abs(g_tp - g_seq) / (np.abs(g_seq) + 1e-3 * scale)) < 5e-4
+    if T >= 512 and not fast:
+        k = wb.dyn_chunks(T, 8)
+        y_short, g_short, st_short = run(lowering.SsTpPlan(k, 8, 1.0e-6, k))      # 8 steps cannot forget the capacitor's state
+        assert st_short["n_bad"] > 0 and st_short["gated_waves"] >= 1, st_short
+        assert np.array_equal(y_short, y_seq)
