@@ -63,8 +63,9 @@ def measured_valu_cycles(kernel, cfg):
 
 def library_identity():
     """What the committed counter passes are matched on: the first 16 hex digits of the sha256 of the library this process
-    loaded, and of the sources the diode-clipper translation unit is compiled from (so a pass stays valid when only ANOTHER
-    kernel family's translation unit changed)."""
+    loaded, and of the sources the diode-clipper translation unit's DEVICE code is compiled from -- its .hip file, the kernel
+    headers it includes, the Makefile's flags; not include/wdf_hip.h, whose declarations of other families' entry points do
+    not reach a kernel -- so a pass stays valid when only ANOTHER kernel family changed."""
     import hashlib
     out = {"path": os.path.relpath(binding.LIB_PATH, REPO), "sha16": None, "clipper_src_sha16": None}
     try:
@@ -77,7 +78,6 @@ def library_identity():
         for name in ("Makefile", "wdf_capi_clipper.hip", "wdf_capi_common.h", "wdf_clipper.h", "wdf_clipper_fused.h", "wdf_omega.h",
                      "wdf_omega64.h", "wdf_asym.h", "wdf_vec.h", "wdf_optim.h", "wdf_elementwise.h"):
             h.update(open(os.path.join(csrc, name), "rb").read())
-        h.update(open(os.path.join(REPO, "include", "wdf_hip.h"), "rb").read())
         out["clipper_src_sha16"] = h.hexdigest()[:16]
     except OSError:
         pass
