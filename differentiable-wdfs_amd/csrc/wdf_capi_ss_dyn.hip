@@ -98,7 +98,7 @@ int wdf_ss_dyn_fwd(const float* x, const float* rows, int per_sample, int ns, in
     hipStream_t s = (hipStream_t)stream;
     EventBracket bracket(s);
     WDF_DYN_DISPATCH(ss_dyn_fwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, T, (int64_t)0,
-                     (float*)nullptr, (float*)nullptr, (const unsigned*)nullptr);
+                     (float*)nullptr, (float*)nullptr, (const unsigned*)nullptr, (const float*)nullptr);
     return check_launch("wdf_ss_dyn_fwd");
 }
 
@@ -110,7 +110,7 @@ size_t wdf_ss_dyn_fwd_tp_ws_bytes(int ns, int64_t B, int n_chunks)
 
 int wdf_ss_dyn_fwd_tp(const float* x, const float* rows, int per_sample, int ns, int ni, int root, const float* rootp, const float* w,
                       int hidden, int n_tanh_layers, int n_up, int n_down, float* y, float* zstash, const float* z0, float* zT,
-                      int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws, void* status, void* stream)
+                      int64_t B, int64_t T, int n_chunks, int warmup, float tol, const float* zinit, void* ws, void* status, void* stream)
 {
     int rc = dyn_check("wdf_ss_dyn_fwd_tp", x, rows, ns, ni, root, rootp, w, hidden, n_tanh_layers, n_up, n_down, B, T, per_sample);
     if (rc) return rc;
@@ -131,7 +131,7 @@ int wdf_ss_dyn_fwd_tp(const float* x, const float* rows, int per_sample, int ns,
         const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K);
         EventBracket bracket(s);
         WDF_DYN_DISPATCH(ss_dyn_fwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, Lc,
-                         (int64_t)warmup, zwarm, zend, (const unsigned*)nullptr);
+                         (int64_t)warmup, zwarm, zend, (const unsigned*)nullptr, zinit);
     }
     if (K > 1) {
         const dim3 grid((unsigned)((B + 63) / 64));
@@ -139,7 +139,7 @@ int wdf_ss_dyn_fwd_tp(const float* x, const float* rows, int per_sample, int ns,
                            gate, (wdf::SsTpStatus*)status);
         // the waves with a miss again, sequentially (the gate lets the others leave at once)
         WDF_DYN_DISPATCH(ss_dyn_fwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, T, (int64_t)0,
-                         (float*)nullptr, (float*)nullptr, (const unsigned*)gate);
+                         (float*)nullptr, (float*)nullptr, (const unsigned*)gate, (const float*)nullptr);
     }
     return check_launch("wdf_ss_dyn_fwd_tp");
 }

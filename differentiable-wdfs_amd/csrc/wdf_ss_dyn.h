@@ -94,10 +94,11 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
                                                         float* __restrict__ y, float* __restrict__ zstash,
                                                         const float* __restrict__ z0, float* __restrict__ zT, int ns, int ni,
                                                         int64_t B, int64_t T, int64_t Lc, int64_t W, float* __restrict__ zwarm,
-                                                        float* __restrict__ zend, const unsigned* __restrict__ gate)
+                                                        float* __restrict__ zend, const unsigned* __restrict__ gate,
+                                                        const float* __restrict__ zinit)
 {
     // Time chunks (grid.y = K; Lc = T, K = 1: the sequential recursion): chunk k owns [k Lc, (k + 1) Lc) and starts W steps early from
-    // z = 0 (or at t = 0 from z0); the state it ARRIVES with at its first owned step and the state it ends with go to zwarm /
+    // z = 0 -- or from zinit[k] -- (or at t = 0 from z0); the state it ARRIVES with at its first owned step and the state it ends with go to zwarm /
     // zend for ss_tp_verify_kernel; a second, gated launch with K = 1 re-runs the waves that missed (wdf_statespace.h's scheme).
     if (gate != nullptr && gate[blockIdx.x] == 0u) return;
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -115,7 +116,9 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
     }
     float z[kDynMaxS];
 #pragma unroll
-    for (int s = 0; s < kDynMaxS; ++s) z[s] = (s < ns && z0 && tw == 0) ? z0[s * B + b] : 0.0f;
+    for (int s = 0; s < kDynMaxS; ++s)                            // t = 0: the caller's z0; else zinit [K][ns][B] (a training loop: the
+        z[s] = s >= ns ? 0.0f                                     // previous call's state at the sample this warm-up begins) or 0
+               : (tw == 0 ? (z0 ? z0[s * B + b] : 0.0f) : (zinit ? zinit[(k * ns + s) * B + b] : 0.0f));
     const float* __restrict__ xp = x + b * T * ni;
     const float* __restrict__ cp = crow + b * bs;
     [[maybe_unused]] float act[NL][H];

@@ -144,7 +144,7 @@ def lib():
     L.wdf_ss_dyn_fwd_tp_ws_bytes.restype = C.c_size_t
     L.wdf_ss_dyn_fwd_tp_ws_bytes.argtypes = [ci, i64, ci]
     L.wdf_ss_dyn_fwd_tp.restype = ci
-    L.wdf_ss_dyn_fwd_tp.argtypes = [fp, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, vp, vp, vp]
+    L.wdf_ss_dyn_fwd_tp.argtypes = [fp, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, fp, fp, fp, fp, i64, i64, ci, ci, cf, fp, vp, vp, vp]
     L.wdf_ss_dyn_bwd_tp_ws_bytes.restype = C.c_size_t
     L.wdf_ss_dyn_bwd_tp_ws_bytes.argtypes = [ci, i64, i64, ci]
     L.wdf_ss_dyn_bwd_tp.restype = ci
@@ -1207,17 +1207,24 @@ def dyn_chunks(T, n_chunks):
     return -(-int(T) // Lc)
 
 
+def dyn_chunk_len(T, n_chunks):
+    return -(-(-(-int(T) // max(1, int(n_chunks)))) // 8) * 8
+
+
 def ss_dyn_fwd_tp(x, rows, ns, ni, n_chunks, warmup, tol=1.0e-6, root_kind=ROOT_NONE, rootp=None, w=None, hidden=0, n_tanh=0, n_up=1,
-                  n_down=1, want_stash=True, z0=None, want_zT=False):
+                  n_down=1, want_stash=True, z0=None, want_zT=False, zinit=None):
     """ss_dyn_fwd in verified time chunks (wdf_ss_dyn_fwd_tp).  -> y, zstash | None, zT | None, status (int32 [4]: ss_tp_status)."""
     require_gpu()
     x, rows, rootp, w, z0 = _f32_dev(x, "x"), _f32_dev(rows, "rows"), _f32_dev(rootp, "rootp"), _f32_dev(w, "w"), _f32_dev(z0, "z0")
+    zinit = _f32_dev(zinit, "zinit")
     B, T = int(x.shape[0]), int(x.shape[1])
     n = lib().wdf_ss_dyn_row_len(int(ns), int(ni))
     per = rows.dim() == 3
     if n == 0 or tuple(rows.shape) not in ((T, n, B), (n,)) or x.dim() != 3 or int(x.shape[2]) != ni:
         raise WdfHipError(f"ss_dyn_fwd_tp: x [B,T,{ni}], rows [T,{n},B] or [{n}] (got x {tuple(x.shape)}, rows {tuple(rows.shape)})")
     K = dyn_chunks(T, n_chunks)
+    if zinit is not None and tuple(zinit.shape) != (K, ns, B):
+        raise WdfHipError(f"ss_dyn_fwd_tp: zinit must be [{K},{ns},{B}], got {tuple(zinit.shape)}")
     y = torch.empty((T, B), dtype=torch.float32, device=x.device)
     zs = torch.empty((T, ns, B), dtype=torch.float32, device=x.device) if want_stash else None
     zT = torch.empty((ns, B), dtype=torch.float32, device=x.device) if want_zT else None
@@ -1225,7 +1232,7 @@ def ss_dyn_fwd_tp(x, rows, ns, ni, n_chunks, warmup, tol=1.0e-6, root_kind=ROOT_
     status = torch.zeros((4,), dtype=torch.int32, device=x.device)
     rc = lib().wdf_ss_dyn_fwd_tp(_ptr(x), _ptr(rows), 1 if per else 0, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
                                  int(n_tanh), int(n_up), int(n_down), _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, K, int(warmup),
-                                 float(tol), _ptr(ws), _ptr(status), _stream())
+                                 float(tol), _ptr(zinit), _ptr(ws), _ptr(status), _stream())
     _check(rc, "wdf_ss_dyn_fwd_tp")
     return y, zs, zT, status
 

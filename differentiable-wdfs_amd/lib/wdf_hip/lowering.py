@@ -108,6 +108,44 @@ class SsWarmStart:
         self.trace.append(w_used)
 
 
+class DynWarmStart:
+    """Warm-started chunks for the streamed-coefficient forward (csrc/wdf_ss_dyn.h) when the SAME batch is visited again with
+    components one optimizer step apart: the previous call's whole state stash is kept (T ns B floats), so chunk k may start
+    any number of steps W before its first owned step from the state that call had there; warmstart.WarmUpController steers
+    W from the device's verdicts (a miss costs a sequential re-run of the waves concerned, never a wrong result), and with
+    the shorter warm-up more chunks pay.  A tree whose cold warm-up outlasts its chunks (HPFDiodeClipper.h's: 672 steps) runs
+    its first call sequentially and is chunked from the second on."""
+
+    def __init__(self, T, B, ns, k_max, cold_W, tol):
+        self.T, self.B, self.ns, self.k_max = int(T), int(B), int(ns), int(k_max)
+        cap = max(32, min(int(cold_W), self.T // 2) // 16 * 16)
+        self.ctl = warmstart.WarmUpController(cap, max(32, cap // 2), unit=16, floor=16, miss_waves=1, wait_calls=16, bold_below=4.0,
+                                              tol=tol)
+        self.prev = None
+        self.trace = collections.deque(maxlen=256)
+
+    def start(self):
+        """-> (chunks, warm-up, zinit [K, ns, B]) or None (no earlier call to start from)."""
+        if self.prev is None:
+            return None
+        W = self.ctl.begin(range(0, 1 << 30))
+        K = binding.dyn_chunks(self.T, max(2, min(self.k_max, self.T // max(W, 64))))
+        if K < 2:
+            return None
+        Lc = binding.dyn_chunk_len(self.T, K)
+        key = (K, W)
+        if getattr(self, "_idx_key", None) != key:
+            self._idx_key = key
+            self._idx = torch.tensor([max(0, k * Lc - W) for k in range(K)], dtype=torch.int64, device=self.prev.device)
+        return K, W, self.prev.index_select(0, self._idx).contiguous()
+
+    def finish(self, zs, status, was_warm, w_used):
+        if was_warm and status is not None:
+            self.ctl.end(status, w_used)
+        self.prev = zs
+        self.trace.append(w_used)
+
+
 class _StateSpaceFn(torch.autograd.Function):
     """y [T,B] = statespace(coef, rootp, x [B,T,ni], z0).  tp: an SsTpPlan (time-parallel kernels) or None.
     warm: an SsWarmStart for this batch (training loops) or None."""
@@ -161,20 +199,28 @@ class _SsDynFn(torch.autograd.Function):
     component values -- calc_impedance's chain rule per sample (tf_wdf.py:114-115,139-145,168-177)."""
 
     @staticmethod
-    def forward(ctx, rows, rootvec, x, z0, ns, ni, kind, hidden, n_tanh, n_up, n_down, want_zT, tp=None):
+    def forward(ctx, rows, rootvec, x, z0, ns, ni, kind, hidden, n_tanh, n_up, n_down, want_zT, tp=None, warm=None):
         need = rows.requires_grad or (rootvec is not None and rootvec.requires_grad) or (z0 is not None and z0.requires_grad)
+        need_grad, need = need, need or (warm is not None and ns >= 1)          # (the next call's chunks start from this call's states)
+        hot = warm.start() if (warm is not None and z0 is None) else None
+        if hot is not None:
+            tp = SsTpPlan(hot[0], hot[1], tp.tol if tp is not None else 1.0e-6, tp.k_bwd if tp is not None else 1)
         r = rows.detach().float().contiguous()
         rv = None if rootvec is None else rootvec.detach().float().contiguous()
         z0d = None if z0 is None else z0.detach().float().contiguous()
         rootp, w = (rv, None) if kind == binding.ROOT_DIODE_PAIR else (None, rv)
         if tp is not None and tp.k_fwd >= 2 and ns >= 1:       # verified time chunks; the waves that missed re-run sequentially
             y, zs, zT, st = binding.ss_dyn_fwd_tp(x, r, ns, ni, tp.k_fwd, tp.warmup, tp.tol, kind, rootp=rootp, w=w, hidden=hidden,
-                                                  n_tanh=n_tanh, n_up=n_up, n_down=n_down, want_stash=need, z0=z0d, want_zT=want_zT)
+                                                  n_tanh=n_tanh, n_up=n_up, n_down=n_down, want_stash=need, z0=z0d, want_zT=want_zT,
+                                                  zinit=None if hot is None else hot[2])
             LAST_SS_TP_STATUS["status"] = st
             LAST_SS_TP_STATUS["warmup_used"], LAST_SS_TP_STATUS["chunks_used"] = tp.warmup, tp.k_fwd
         else:
+            st = None
             y, zs, zT = binding.ss_dyn_fwd(x, r, ns, ni, kind, rootp=rootp, w=w, hidden=hidden, n_tanh=n_tanh, n_up=n_up, n_down=n_down,
                                            want_stash=need, z0=z0d, want_zT=want_zT)
+        if warm is not None and z0 is None and zs is not None:
+            warm.finish(zs, st, hot is not None, tp.warmup if (tp is not None and st is not None) else 0)
         ctx.tp = tp
         ctx.cfg = (ns, ni, kind, hidden, n_tanh, n_up, n_down, z0 is not None, rows.dim() == 3)
         ctx.save_for_backward(r, rv, x, zs)
@@ -200,7 +246,7 @@ class _SsDynFn(torch.autograd.Function):
         if not per_sample:
             grows = grows.double().sum(dim=(0, 2)).float()
         return (grows, None if groot is None else groot.float(), None, (gz0[:ns] if has_z0 else None), None, None, None, None, None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------ resident entries: which batch is this?
@@ -987,7 +1033,17 @@ class Circuit:
         xs = x[:, :, :self.ni].contiguous()
         tp = self._plan_dyn(tape, outs, vals, kind, B, T) if self.time_parallel == "auto" else \
             (self.time_parallel if isinstance(self.time_parallel, SsTpPlan) else None)
-        y, zT = _SsDynFn.apply(rows, rootvec, xs, z0t, self.ns, self.ni, kind, hidden, n_tanh, n_up, n_down, bool(return_state), tp)
+        warm = None
+        if tp is not None and self.warm_start and self.ns >= 1 and z0t is None and isinstance(getattr(self, "_anchor", None), torch.Tensor):
+            # the same batch again (a training loop: lpf.py:86-99 re-runs data_in every epoch) -> its chunks start warm
+            wsd = self.__dict__.setdefault("_dyn_warm", EntryCache(max_entries=4))
+            with torch._C.DisableTorchFunctionSubclass():
+                wkey = (tensor_key(self._anchor), kind)
+            hit = wsd.get(wkey)
+            if hit is None:
+                hit = wsd.put(wkey, (self._anchor, DynWarmStart(T, B, self.ns, tp.k_bwd, tp.warmup if tp.warmup > 0 else 64, tp.tol)))
+            warm = hit[1]
+        y, zT = _SsDynFn.apply(rows, rootvec, xs, z0t, self.ns, self.ni, kind, hidden, n_tanh, n_up, n_down, bool(return_state), tp, warm)
         y = y.as_subclass(tf.Tensor)
         return (y, zT[:self.ns]) if return_state else y
 

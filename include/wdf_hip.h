@@ -489,14 +489,16 @@ int wdf_ss_dyn_fwd(const float* x, const float* rows, int per_sample, int ns, in
 /* The same in time chunks (n_chunks tiles T in 8-step units).  Forward: a chunk starts `warmup` steps early from z = 0, the device
  * compares what every chunk arrives with against what its predecessor ended with (tol) and re-runs, sequentially, exactly the
  * 64-sequence waves with a miss -- the result is within tol of wdf_ss_dyn_fwd's or IS it; status: int32 {n_bad, max-miss float
- * bits, gated waves, 0}; ws: wdf_ss_dyn_fwd_tp_ws_bytes.  Reverse sweep: EXACT (the adjoint is linear in the adjoint entering a
+ * bits, gated waves, 0}; ws: wdf_ss_dyn_fwd_tp_ws_bytes; zinit (optional) float [n_chunks][ns][B]: the state chunk k starts from at
+ * sample max(0, k L - warmup), L = the 8-step-rounded chunk length -- a training loop hands in the previous call's stash rows and
+ * runs a fraction of the cold warm-up.  Reverse sweep: EXACT (the adjoint is linear in the adjoint entering a
  * chunk: chunk maps, one walk per sequence, then every chunk re-walked from its true entering adjoint with the root's partials
  * kept from the first walk); ws: wdf_ss_dyn_bwd_tp_ws_bytes; the per-(chunk, wave) diode sums sit at its head as
  * double [n_chunks (B+63)/64][2]. */
 size_t wdf_ss_dyn_fwd_tp_ws_bytes(int ns, int64_t B, int n_chunks);
 int wdf_ss_dyn_fwd_tp(const float* x, const float* rows, int per_sample, int ns, int ni, int root, const float* rootp, const float* w,
                       int hidden, int n_tanh_layers, int n_up, int n_down, float* y, float* zstash, const float* z0, float* zT,
-                      int64_t B, int64_t T, int n_chunks, int warmup, float tol, void* ws, void* status, void* stream);
+                      int64_t B, int64_t T, int n_chunks, int warmup, float tol, const float* zinit, void* ws, void* status, void* stream);
 size_t wdf_ss_dyn_bwd_tp_ws_bytes(int ns, int64_t B, int64_t T, int n_chunks);
 int wdf_ss_dyn_bwd_tp(const float* x, const float* rows, int per_sample, int ns, int ni, int root, const float* rootp, const float* w,
                       int hidden, int n_tanh_layers, int n_up, int n_down, const float* zstash, const float* gy, float* grows,

@@ -334,3 +334,49 @@ def test_streamed_kernels_in_time_chunks_equal_the_sequential_ones(wdf, golden, 
         y_short, g_short, st_short = run(lowering.SsTpPlan(k, 8, 1.0e-6, k))      # 8 steps cannot forget the capacitor's state
         assert st_short["n_bad"] > 0 and st_short["gated_waves"] >= 1, st_short
         assert np.array_equal(y_short, y_seq)
+
+
+@pytest.mark.parametrize("root", ["diode", "mlp"])
+def test_streamed_forward_starts_warm_when_a_batch_is_visited_again(wdf, golden, root):
+    """A training loop on HPFDiodeClipper.h's tree with a pot channel (the tree whose cold warm-up, 672 steps, outlasts its
+    chunks): the first call runs sequentially, later calls cut the forward into chunks started from the previous call's states
+    (lowering.DynWarmStart) -- same losses and gradients as the same loop on the sequential kernels, every verdict clean or
+    repaired, and the chunked calls really happened."""
+    from wdf_hip import binding as wb, lowering
+    tf = wdf.tf
+    js = _net(golden, "2x8")[0] if root == "mlp" else None
+    vals = [33.0e3, 1.0e3, 22.0e-9, 4.352e-9, 25.85e-3 * 1.906]
+    B, T = 96, 2048
+    rng = np.random.default_rng(5)
+    x = (1.2 * rng.standard_normal((B, T))).astype(np.float32)
+    r = pot_channel(B, T, 300.0, 5.0e3, 1)
+    xin = cuda(np.stack([x, r], axis=-1))
+    tgt = cuda(0.2 * rng.standard_normal((T, B)))
+
+    def loop(time_parallel, steps=14):
+        circ, params, model = build_hpf(wdf, root, "Vs", vals, net=js)
+        circ.time_parallel = time_parallel
+        plist = [params[0], params[2]] + (params[3:] if root == "diode" else list(model.trainable_variables))
+        opts = [tf.keras.optimizers.Adam(learning_rate=(1.0e-3 * abs(float(p)) if p.numel() == 1 else 1.0e-4)) for p in plist]
+        out, chunks = [], []
+        for _ in range(steps):
+            lowering.LAST_SS_TP_STATUS["status"] = None
+            with tf.GradientTape() as tape:
+                y = circ(xin)
+                loss = tf.reduce_mean(tf.square(y - tgt))
+            g = tape.gradient(loss, plist)
+            st = lowering.LAST_SS_TP_STATUS["status"]
+            chunks.append(0 if st is None else lowering.LAST_SS_TP_STATUS["chunks_used"])
+            out.append((float(loss), np.concatenate([v.cpu().numpy().reshape(-1) for v in g])))
+            for o, gi, p in zip(opts, g, plist):
+                o.apply_gradients([(gi, p)])
+        return out, chunks
+
+    seq, c_seq = loop(None)
+    warm, c_warm = loop("auto")
+    assert all(c == 0 for c in c_seq)
+    assert c_warm[0] <= 3 and min(c_warm[2:]) >= 2, c_warm                      # chunked from the second or third call on
+    for (ls, gs), (lw, gw) in zip(seq, warm):
+        assert abs(lw - ls) <= 2e-5 * ls
+        scale = np.max(np.abs(gs))
+        assert np.max(np.abs(gw - gs) / (np.abs(gs) + 1e-3 * scale)) < 2e-3
