@@ -37,40 +37,40 @@ extern "C" {
 
 int wdf_ss_dyn_row_len(int ns, int ni) { return dyn_ok(ns, ni) ? wdf::DynLayout(ns, ni).n : 0; }
 
-#define WDF_DYN_DISPATCH(KERNEL, ...)                                                                                          \
+// grid.x: one lane per sequence, or -- the network root, evaluated in 16-lane rows (wdf_ss_dyn.h DynLanes) -- four sequences per wave
+#define WDF_DYN_GRIDX(ROW_) ((unsigned)((ROW_) ? (B + 3) / 4 : (B + 63) / 64))
+
+#define WDF_DYN_FWD(GY_, ...)                                                                                                 \
     do {                                                                                                                     \
-        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::KERNEL<wdf::kDynRootNone, true, 4, 3>), grid, dim3(64), 0, s, __VA_ARGS__); \
+        const dim3 grid(WDF_DYN_GRIDX(root == WDF_ROOT_MLP), (unsigned)(GY_));                                               \
+        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootNone, true, 16, 3>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
         else if (root == WDF_ROOT_DIODE_PAIR && n_up == n_down)                                                              \
-            hipLaunchKernelGGL((wdf::KERNEL<wdf::kDynRootDiode, true, 4, 3>), grid, dim3(64), 0, s, __VA_ARGS__);             \
+            hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootDiode, true, 16, 3>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);   \
         else if (root == WDF_ROOT_DIODE_PAIR)                                                                                \
-            hipLaunchKernelGGL((wdf::KERNEL<wdf::kDynRootDiode, false, 4, 3>), grid, dim3(64), 0, s, __VA_ARGS__);            \
-        else if (hidden == 4 && n_tanh_layers == 3) hipLaunchKernelGGL((wdf::KERNEL<wdf::kDynRootMlp, true, 4, 3>), grid, dim3(64), 0, s, __VA_ARGS__); \
-        else if (hidden == 8 && n_tanh_layers == 3) hipLaunchKernelGGL((wdf::KERNEL<wdf::kDynRootMlp, true, 8, 3>), grid, dim3(64), 0, s, __VA_ARGS__); \
-        else if (hidden == 16 && n_tanh_layers == 3) hipLaunchKernelGGL((wdf::KERNEL<wdf::kDynRootMlp, true, 16, 3>), grid, dim3(64), 0, s, __VA_ARGS__); \
-        else if (hidden == 4 && n_tanh_layers == 5) hipLaunchKernelGGL((wdf::KERNEL<wdf::kDynRootMlp, true, 4, 5>), grid, dim3(64), 0, s, __VA_ARGS__); \
-        else hipLaunchKernelGGL((wdf::KERNEL<wdf::kDynRootMlp, true, 8, 5>), grid, dim3(64), 0, s, __VA_ARGS__);               \
+            hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootDiode, false, 16, 3>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);  \
+        else if (n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootMlp, true, 16, 3>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
+        else hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootMlp, true, 16, 5>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);     \
     } while (0)
 
 // the reverse sweep's kernel in one of its modes (0: sequential, 1: chunk maps + root partials; 2 -- no root code in it -- below)
-#define WDF_DYN_BWD(MODE_, ...)                                                                                               \
+#define WDF_DYN_BWD(MODE_, GY_, ...)                                                                                          \
     do {                                                                                                                     \
-        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 4, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__); \
+        const dim3 grid(WDF_DYN_GRIDX(root == WDF_ROOT_MLP), (unsigned)(GY_));                                               \
+        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
         else if (root == WDF_ROOT_DIODE_PAIR && n_up == n_down)                                                              \
-            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 4, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__);   \
+            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);   \
         else if (root == WDF_ROOT_DIODE_PAIR)                                                                                \
-            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, false, 4, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__);  \
-        else if (hidden == 4 && n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 4, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__); \
-        else if (hidden == 8 && n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 8, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__); \
-        else if (hidden == 16 && n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__); \
-        else if (hidden == 4 && n_tanh_layers == 5) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 4, 5, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__); \
-        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 8, 5, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__);     \
+            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, false, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);  \
+        else if (n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
+        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 5, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);     \
     } while (0)
 
-#define WDF_DYN_BWD_EMIT(...)                                                                                                 \
+#define WDF_DYN_BWD_EMIT(GY_, ...)                                                                                            \
     do {                                                                                                                     \
-        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 4, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__); \
-        else if (root == WDF_ROOT_DIODE_PAIR) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 4, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__); \
-        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 4, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__);          \
+        const dim3 grid(WDF_DYN_GRIDX(false), (unsigned)(GY_));                                                              \
+        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
+        else if (root == WDF_ROOT_DIODE_PAIR) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
+        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);          \
     } while (0)
 
 namespace {
@@ -94,11 +94,10 @@ int wdf_ss_dyn_fwd(const float* x, const float* rows, int per_sample, int ns, in
     if (!y) return fail(WDF_EINVAL, "wdf_ss_dyn_fwd: null y");
     const int64_t n = wdf::DynLayout(ns, ni).n;
     const int64_t cs = per_sample ? B : 1, ts = per_sample ? n * B : 0, bs = per_sample ? 1 : 0;
-    const dim3 grid((unsigned)((B + 63) / 64));
     hipStream_t s = (hipStream_t)stream;
     EventBracket bracket(s);
-    WDF_DYN_DISPATCH(ss_dyn_fwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, T, (int64_t)0,
-                     (float*)nullptr, (float*)nullptr, (const unsigned*)nullptr, (const float*)nullptr);
+    WDF_DYN_FWD(1, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, T, (int64_t)0,
+                (float*)nullptr, (float*)nullptr, (const unsigned*)nullptr, (const float*)nullptr);
     return check_launch("wdf_ss_dyn_fwd");
 }
 
@@ -128,18 +127,16 @@ int wdf_ss_dyn_fwd_tp(const float* x, const float* rows, int per_sample, int ns,
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(status, 0, sizeof(wdf::SsTpStatus), s) != hipSuccess) return fail(WDF_ELAUNCH, "wdf_ss_dyn_fwd_tp: memset failed");
     {
-        const dim3 grid((unsigned)((B + 63) / 64), (unsigned)K);
         EventBracket bracket(s);
-        WDF_DYN_DISPATCH(ss_dyn_fwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, Lc,
-                         (int64_t)warmup, zwarm, zend, (const unsigned*)nullptr, zinit);
+        WDF_DYN_FWD(K, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, Lc,
+                    (int64_t)warmup, zwarm, zend, (const unsigned*)nullptr, zinit);
     }
     if (K > 1) {
-        const dim3 grid((unsigned)((B + 63) / 64));
-        hipLaunchKernelGGL(wdf::ss_tp_verify_kernel, grid, dim3(64), 0, s, (const float*)zwarm, (const float*)zend, ns, B, (int64_t)K, tol,
-                           gate, (wdf::SsTpStatus*)status);
-        // the waves with a miss again, sequentially (the gate lets the others leave at once)
-        WDF_DYN_DISPATCH(ss_dyn_fwd_kernel, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, T, (int64_t)0,
-                         (float*)nullptr, (float*)nullptr, (const unsigned*)gate, (const float*)nullptr);
+        hipLaunchKernelGGL(wdf::ss_tp_verify_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, (const float*)zwarm, (const float*)zend, ns,
+                           B, (int64_t)K, tol, gate, (wdf::SsTpStatus*)status);
+        // the 64-sequence groups with a miss again, sequentially (the gate lets the others leave at once)
+        WDF_DYN_FWD(1, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, T, (int64_t)0,
+                    (float*)nullptr, (float*)nullptr, (const unsigned*)gate, (const float*)nullptr);
     }
     return check_launch("wdf_ss_dyn_fwd_tp");
 }
@@ -156,10 +153,9 @@ int wdf_ss_dyn_bwd(const float* x, const float* rows, int per_sample, int ns, in
     if (root == WDF_ROOT_MLP && (!gb || !ain || !lrin)) return fail(WDF_EINVAL, "wdf_ss_dyn_bwd: the MLP root needs gb / ain / lrin [T][B]");
     const int64_t n = wdf::DynLayout(ns, ni).n;
     const int64_t cs = per_sample ? B : 1, ts = per_sample ? n * B : 0, bs = per_sample ? 1 : 0;
-    const dim3 grid((unsigned)((B + 63) / 64));
     hipStream_t s = (hipStream_t)stream;
     EventBracket bracket(s);
-    WDF_DYN_BWD(0, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, (double*)ws, gb, ain, lrin, gz0, ns, ni, B, T, T,
+    WDF_DYN_BWD(0, 1, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, (double*)ws, gb, ain, lrin, gz0, ns, ni, B, T, T,
                 (float*)nullptr, (float*)nullptr, (const float*)nullptr);
     return check_launch("wdf_ss_dyn_bwd");
 }
@@ -193,14 +189,13 @@ int wdf_ss_dyn_bwd_tp(const float* x, const float* rows, int per_sample, int ns,
     float* lam_in = rec + (size_t)K * (size_t)(ns + 1) * (size_t)ns * (size_t)B;
     float* rpart = lam_in + (size_t)K * (size_t)ns * (size_t)B;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)waves, (unsigned)K);
     {
         EventBracket bracket(s);
-        WDF_DYN_BWD(1, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, part, gb, ain, lrin, gz0, ns, ni, B, T, Lc, rpart, rec,
+        WDF_DYN_BWD(1, K, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, part, gb, ain, lrin, gz0, ns, ni, B, T, Lc, rpart, rec,
                     (const float*)nullptr);
     }
     hipLaunchKernelGGL(wdf::ss_dyn_bwd_combine_kernel, dim3((unsigned)waves), dim3(64), 0, s, (const float*)rec, lam_in, ns, B, (int64_t)K);
-    WDF_DYN_BWD_EMIT(x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, part, gb, ain, lrin, gz0, ns, ni, B, T, Lc, rpart, rec,
+    WDF_DYN_BWD_EMIT(K, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, part, gb, ain, lrin, gz0, ns, ni, B, T, Lc, rpart, rec,
                      (const float*)lam_in);
     return check_launch("wdf_ss_dyn_bwd_tp");
 }

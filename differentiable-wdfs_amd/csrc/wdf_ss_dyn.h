@@ -25,12 +25,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "wdf_mlp.h"
+#include "wdf_mlp_row.h"
 #include "wdf_statespace.h"
 
 namespace wdf {
 
 enum { kDynRootNone = 0, kDynRootDiode = 2, kDynRootMlp = 3 };
+
+// Who is who in a wave.  Ideal-source / diode roots: one lane per sequence.  MLP root: one 16-lane DPP ROW per sequence
+// (wdf_mlp_row.h: lane j = hidden neuron j, the layer's matrix-vector product as 16 v_fmac_f32_dpp, weights in registers) --
+// four sequences per wave, the tree's arithmetic replicated in the row's lanes, lane 0 of the row stores; the per-lane
+// evaluation of wdf_mlp.h (~600 dependent FMAs per step) made the network root ten times slower than this.
+template <int ROOT>
+struct DynLanes {
+    static constexpr bool kRow = ROOT == kDynRootMlp;
+    static __device__ __forceinline__ int64_t seq() { return kRow ? (int64_t)blockIdx.x * 4 + (threadIdx.x >> 4) : (int64_t)blockIdx.x * 64 + threadIdx.x; }
+    static __device__ __forceinline__ bool writer() { return kRow ? (threadIdx.x & 15) == 0 : true; }
+    static __device__ __forceinline__ unsigned gate_index() { return kRow ? blockIdx.x >> 4 : blockIdx.x; }   // (gates are per 64 sequences)
+};
 constexpr int kDynMaxS = 4, kDynMaxI = 2;
 
 struct DynRow {                     // one step's coefficients in registers (entries beyond ns / ni are zero)
@@ -95,25 +107,24 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ z0, float* __restrict__ zT, int ns, int ni,
                                                         int64_t B, int64_t T, int64_t Lc, int64_t W, float* __restrict__ zwarm,
                                                         float* __restrict__ zend, const unsigned* __restrict__ gate,
-                                                        const float* __restrict__ zinit)
+                                                        const float* __restrict__ zinit, int hidden)
 {
     // Time chunks (grid.y = K; Lc = T, K = 1: the sequential recursion): chunk k owns [k Lc, (k + 1) Lc) and starts W steps early from
     // z = 0 -- or from zinit[k] -- (or at t = 0 from z0); the state it ARRIVES with at its first owned step and the state it ends with go to zwarm /
     // zend for ss_tp_verify_kernel; a second, gated launch with K = 1 re-runs the waves that missed (wdf_statespace.h's scheme).
-    if (gate != nullptr && gate[blockIdx.x] == 0u) return;
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    using LN = DynLanes<ROOT>;
+    if (gate != nullptr && gate[LN::gate_index()] == 0u) return;
+    const int64_t b_raw = LN::seq();
     const int64_t b = b_raw < B ? b_raw : B - 1;
+    const bool writer = LN::writer();
     const int64_t k = blockIdx.y;
     const int64_t t0 = k * Lc, t1 = (t0 + Lc < T) ? t0 + Lc : T;
     const int64_t tw = (k > 0 && t0 > W) ? t0 - W : 0;
     const DynLayout L(ns, ni);
     DynRoot<ROOT, SYM, H, NL> root;
     root.load(rootp, n_up, n_down);
-    __shared__ __attribute__((aligned(16))) float w[(ROOT == kDynRootMlp ? Mlp<H, NL>::kCount : 0) + 4];
-    if constexpr (ROOT == kDynRootMlp) {
-        for (int i = threadIdx.x; i < Mlp<H, NL>::kCount; i += 64) w[i] = w_in[i];
-        __syncthreads();
-    }
+    [[maybe_unused]] RowWeights<NL> RW;
+    if constexpr (ROOT == kDynRootMlp) RW = row_load_weights<NL>(w_in, hidden, threadIdx.x & 15, false);
     float z[kDynMaxS];
 #pragma unroll
     for (int s = 0; s < kDynMaxS; ++s)                            // t = 0: the caller's z0; else zinit [K][ns][B] (a training loop: the
@@ -121,15 +132,14 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
                : (tw == 0 ? (z0 ? z0[s * B + b] : 0.0f) : (zinit ? zinit[(k * ns + s) * B + b] : 0.0f));
     const float* __restrict__ xp = x + b * T * ni;
     const float* __restrict__ cp = crow + b * bs;
-    [[maybe_unused]] float act[NL][H];
+    [[maybe_unused]] float act[NL];
     for (int64_t t = tw; t < t1; ++t) {
         const bool owned = t >= t0;                                // wave-uniform
-        if (t == t0 && zwarm != nullptr) {
+        if (t == t0 && zwarm != nullptr && writer) {
 #pragma unroll
             for (int s = 0; s < kDynMaxS; ++s)
                 if (s < ns) zwarm[(k * ns + s) * B + b] = z[s];
         }
-        if constexpr (ROOT == kDynRootMlp) asm volatile("" ::: "memory");      // re-read the weights from LDS every step (wdf_mlp.h)
         const DynRow c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
         float xv[kDynMaxI];
 #pragma unroll
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
         for (int i = 0; i < kDynMaxI; ++i) a = fmaf(c.da[i], xv[i], a);
         float broot = 0.0f;
         if constexpr (ROOT == kDynRootDiode) broot = diode_pair<SYM>(a, logf(c.rp * root.Is / root.V), root.d).b;
-        if constexpr (ROOT == kDynRootMlp) broot = -Mlp<H, NL>::fwd(w, a, logf(c.rp), act);
+        if constexpr (ROOT == kDynRootMlp) broot = -row_mlp_fwd<NL>(RW, a, logf(c.rp), act);
         float yv = c.fy * broot;
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s) yv = fmaf(c.cy[s], z[s], yv);
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
             for (int i = 0; i < kDynMaxI; ++i) acc = fmaf(c.Bx[s][i], xv[i], acc);
             zn[s] = acc;
         }
-        if (owned) {
+        if (owned && writer) {
             if (zstash) {
 #pragma unroll
                 for (int s = 0; s < kDynMaxS; ++s)
@@ -168,12 +178,12 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s) z[s] = zn[s];
     }
-    if (zend != nullptr) {
+    if (zend != nullptr && writer) {
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s)
             if (s < ns) zend[(k * ns + s) * B + b] = z[s];
     }
-    if (zT && t1 == T) {
+    if (zT && t1 == T && writer) {
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s)
             if (s < ns) zT[s * B + b] = z[s];
@@ -203,21 +213,22 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ gbroot, float* __restrict__ ain,
                                                         float* __restrict__ lrin, float* __restrict__ gz0, int ns, int ni,
                                                         int64_t B, int64_t T, int64_t Lc, float* __restrict__ rpart,
-                                                        float* __restrict__ rec, const float* __restrict__ lam_in)
+                                                        float* __restrict__ rec, const float* __restrict__ lam_in, int hidden)
 {
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool live = b_raw < B;
-    const int64_t b = live ? b_raw : B - 1;
+    // (MODE 2 evaluates no root: it runs one lane per sequence whatever the root)
+    using LN = DynLanes<(MODE == 2 ? kDynRootNone : ROOT)>;
+    constexpr bool kEval = ROOT == kDynRootMlp && MODE != 2;      // the network is evaluated here: 16-lane rows
+    const int64_t b_raw = LN::seq();
+    const bool writer = LN::writer();
+    const bool live = b_raw < B && writer;
+    const int64_t b = b_raw < B ? b_raw : B - 1;
     const int64_t k = blockIdx.y;
     const int64_t t0 = k * Lc, t1 = (t0 + Lc < T) ? t0 + Lc : T;
     const DynLayout L(ns, ni);
     DynRoot<ROOT, SYM, H, NL> root;
     root.load(rootp, n_up, n_down);
-    __shared__ __attribute__((aligned(16))) float w[((ROOT == kDynRootMlp && MODE != 2) ? Mlp<H, NL>::kCount : 0) + 4];
-    if constexpr (ROOT == kDynRootMlp && MODE != 2) {
-        for (int i = threadIdx.x; i < Mlp<H, NL>::kCount; i += 64) w[i] = w_in[i];
-        __syncthreads();
-    }
+    [[maybe_unused]] RowWeights<NL> RW;
+    if constexpr (kEval) RW = row_load_weights<NL>(w_in, hidden, threadIdx.x & 15, true);
     const float* __restrict__ xp = x + b * T * ni;
     const float* __restrict__ cp = crow + b * bs;
     float lam[kDynMaxS];
@@ -232,9 +243,8 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
             for (int s = 0; s < kDynMaxS; ++s) hom[j][s] = (j == s && j < ns) ? 1.0f : 0.0f;
     }
     double sL = 0.0, sV = 0.0;
-    [[maybe_unused]] float act[NL][H];
+    [[maybe_unused]] float act[NL];
     for (int64_t t = t1 - 1; t >= t0; --t) {
-        if constexpr (ROOT == kDynRootMlp && MODE != 2) asm volatile("" ::: "memory");
         const DynRow c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
         float xv[kDynMaxI], z[kDynMaxS];
 #pragma unroll
@@ -266,11 +276,11 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
             DV = fmaf(2.0f * l2 * a, sp * fast_rcp(root.V), -2.0f * o.lam * (o.m0 * o.w0 - o.m1 * o.w1));
             Drp = DL / c.rp;                                        // L = log(R_port Is / nVt)
         }
-        if constexpr (ROOT == kDynRootMlp && MODE != 2) {
+        if constexpr (kEval) {
             lr = logf(c.rp);
-            broot = -Mlp<H, NL>::fwd(w, a, lr, act);
+            broot = -row_mlp_fwd<NL>(RW, a, lr, act);
             float da, dlr;
-            Mlp<H, NL>::grad_in(w, act, da, dlr);
+            row_mlp_grad_in<NL>(RW, act, da, dlr);
             Da = -da;
             Drp = -dlr / c.rp;
         }
@@ -281,12 +291,16 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
         if constexpr (MODE == 1) {
             // what MODE 2 needs of this step's root, and the network's operands; then the adjoint maps -- no rows
             if constexpr (ROOT != kDynRootNone) {
-                float* __restrict__ rp_ = rpart + (t * kDynRpart) * B + b;
-                rp_[0] = Da; rp_[B] = broot; rp_[2 * B] = Drp; rp_[3 * B] = DL; rp_[4 * B] = DV;
+                if (writer) {
+                    float* __restrict__ rp_ = rpart + (t * kDynRpart) * B + b;
+                    rp_[0] = Da; rp_[B] = broot; rp_[2 * B] = Drp; rp_[3 * B] = DL; rp_[4 * B] = DV;
+                }
             }
             if constexpr (ROOT == kDynRootMlp) {
-                ain[t * B + b] = a;
-                lrin[t * B + b] = lr;
+                if (writer) {
+                    ain[t * B + b] = a;
+                    lrin[t * B + b] = lr;
+                }
             }
 #pragma unroll
             for (int j = 0; j < kDynMaxS; ++j) {
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
                     for (int s = 0; s < kDynMaxS; ++s) hom[j][s] = hn[s];
                 }
             }
-        } else {
+        } else if (writer) {
         float* __restrict__ gp = grow + (t * L.n) * B + b;
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s) {
@@ -357,6 +371,7 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
     }
     if constexpr (MODE == 1) {
         // rec [k][j][s][B]: j < ns the columns of Phi (the adjoint that entered as e_j), j = ns the particular run (beta)
+        if (!writer) return;
         float* __restrict__ r = rec + (k * (ns + 1) * ns) * B + b;
 #pragma unroll
         for (int j = 0; j < kDynMaxS; ++j)
@@ -373,13 +388,15 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
         for (int s = 0; s < kDynMaxS; ++s)
             if (s < ns) gz0[s * B + b] = lam[s];
     }
-    if (!live) { sL = 0.0; sV = 0.0; }
-    sL = wave_sum(sL);
-    sV = wave_sum(sV);
-    if (threadIdx.x == 0 && ws) {
-        const int64_t slot = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-        ws[slot * 2 + 0] = sL;
-        ws[slot * 2 + 1] = sV;
+    if constexpr (ROOT == kDynRootDiode) {
+        if (!live) { sL = 0.0; sV = 0.0; }
+        sL = wave_sum(sL);
+        sV = wave_sum(sV);
+        if (threadIdx.x == 0 && ws) {
+            const int64_t slot = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+            ws[slot * 2 + 0] = sL;
+            ws[slot * 2 + 1] = sV;
+        }
     }
 }
 

@@ -201,7 +201,7 @@ class _SsDynFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rows, rootvec, x, z0, ns, ni, kind, hidden, n_tanh, n_up, n_down, want_zT, tp=None, warm=None):
         need = rows.requires_grad or (rootvec is not None and rootvec.requires_grad) or (z0 is not None and z0.requires_grad)
-        need_grad, need = need, need or (warm is not None and ns >= 1)          # (the next call's chunks start from this call's states)
+        need = need or (warm is not None and ns >= 1)                         # (the next call's chunks start from this call's states)
         hot = warm.start() if (warm is not None and z0 is None) else None
         if hot is not None:
             tp = SsTpPlan(hot[0], hot[1], tp.tol if tp is not None else 1.0e-6, tp.k_bwd if tp is not None else 1)
