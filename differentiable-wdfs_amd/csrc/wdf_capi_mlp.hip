@@ -471,36 +471,7 @@ static unsigned mlp_wgrad_blocks(int64_t S)
     return (unsigned)(want < 2048 ? want : 2048);
 }
 
-int64_t wdf_clipper_mlp_wgrad_ws_bytes(int hidden, int n_tanh_layers, int64_t S)
-{
-    const int64_t count = wdf_mlp_weight_count(hidden, n_tanh_layers);
-    if (count <= 0 || S <= 0 || !mlp_arch_ok(hidden, n_tanh_layers)) return 0;
-    return (int64_t)mlp_wgrad_blocks(S) * count * (int64_t)sizeof(float);
-}
-
-#define WDF_WGRAD_CASE(H_, NL_)                                                                               \
-    if (hidden == H_ && n_tanh_layers == NL_)                                                                 \
-        hipLaunchKernelGGL((wdf::mlp_wgrad_kernel<H_, NL_>), dim3(nblk, wdf::Mlp<H_, NL_>::kParts), dim3(64), 0, (hipStream_t)stream, ain,  \
-                           lrin, gb, theta2, w, fs, (float*)ws, S);
-
-int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb, const float* theta2, const float* w,
-                          int hidden, int n_tanh_layers, float fs, void* ws, float* gw, int64_t S, void* stream)
-{
-    if (!ain || !gb || !w || !ws || !gw) return fail(WDF_EINVAL, "null ain/gb/w/ws/gw");
-    if (!lrin && !theta2) return fail(WDF_EINVAL, "theta2 is needed when lrin is NULL");
-    if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
-    const int count = wdf_mlp_weight_count(hidden, n_tanh_layers);
-    if (!mlp_arch_ok(hidden, n_tanh_layers))
-        return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
-    const unsigned nblk = mlp_wgrad_blocks(S);
-    WDF_WGRAD_CASE(4, 3) WDF_WGRAD_CASE(8, 3) WDF_WGRAD_CASE(16, 3) WDF_WGRAD_CASE(4, 4) WDF_WGRAD_CASE(8, 4)
-    WDF_WGRAD_CASE(4, 5) WDF_WGRAD_CASE(8, 5)
-    int rc = check_launch("wdf_clipper_mlp_wgrad");
-    if (rc) return rc;
-    hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)ws, (int)nblk, count, gw);
-    return check_launch("wdf_clipper_mlp_wgrad_reduce");
-}
+// (wdf_clipper_mlp_wgrad: wdf_capi_mlp_step.hip, next to the matrix-core accumulators it shares with the resident step)
 
 #define WDF_EVAL_CASE(H_, NL_)                                                                                \
     if (hidden == H_ && n_tanh_layers == NL_)                                                                 \

@@ -277,4 +277,55 @@ int wdf_clipper_mlp_step(const float* x, const float* p, const float* lr, const 
     return rc;
 }
 
+
+/* ---- weight gradient over a list of samples (wdf_mlp_step.h: mlp_wgrad_list_kernel) ---- */
+namespace {
+bool list_arch_ok(int hidden, int n_tanh_layers)                 // the MLP-root family's architectures (wdf_capi_mlp.hip)
+{
+    return ((hidden == 4 || hidden == 8 || hidden == 16) && n_tanh_layers == 3) ||
+           ((hidden == 4 || hidden == 8) && (n_tanh_layers == 4 || n_tanh_layers == 5));
+}
+// samples per wave: a multiple of 128, about one wave per SIMD, at most 4096 (fp32 accumulators: more waves instead)
+int64_t list_per_wave(int64_t S)
+{
+    int64_t p = ((S + 1023) / 1024 + 127) / 128 * 128;
+    return p < 128 ? 128 : (p > 4096 ? 4096 : p);
+}
+int64_t list_workgroups(int64_t S)
+{
+    const int64_t p = list_per_wave(S);
+    return ((S + p - 1) / p + 3) / 4;
+}
+}  // namespace
+
+int64_t wdf_clipper_mlp_wgrad_ws_bytes(int hidden, int n_tanh_layers, int64_t S)
+{
+    if (S <= 0 || !list_arch_ok(hidden, n_tanh_layers)) return 0;
+    return list_workgroups(S) * (int64_t)step_weight_count(hidden, n_tanh_layers) * (int64_t)sizeof(float);
+}
+
+int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb, const float* theta2, const float* w,
+                          int hidden, int n_tanh_layers, float fs, void* ws, float* gw, int64_t S, void* stream)
+{
+    if (!ain || !gb || !w || !ws || !gw) return fail(WDF_EINVAL, "null ain/gb/w/ws/gw");
+    if (!lrin && !theta2) return fail(WDF_EINVAL, "theta2 is needed when lrin is NULL");
+    if (S <= 0) return fail(WDF_EINVAL, "S must be positive");
+    if (!list_arch_ok(hidden, n_tanh_layers))
+        return fail(WDF_EUNSUPPORTED, "MLP root: unsupported network (width %d, %d tanh layers)", hidden, n_tanh_layers);
+    const int count = step_weight_count(hidden, n_tanh_layers);
+    const int64_t per_wave = list_per_wave(S), nwg = list_workgroups(S);
+    hipStream_t s = (hipStream_t)stream;
+#define WDF_LIST_CASE(NL_)                                                                                                     \
+    if (n_tanh_layers == NL_)                                                                                                  \
+        hipLaunchKernelGGL((wdf::mlp_wgrad_list_kernel<NL_>), dim3((unsigned)nwg), dim3(256), 0, s, ain, lrin, gb, theta2, fs, w, hidden, S,  \
+                           per_wave, (float*)ws);
+    WDF_LIST_CASE(3) WDF_LIST_CASE(4) WDF_LIST_CASE(5)
+#undef WDF_LIST_CASE
+    int rc = check_launch("wdf_clipper_mlp_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wdf::mlp_wgrad_reduce_wide_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64, 16), 0, s, (const float*)ws, (int)nwg,
+                       count, gw);
+    return check_launch("wdf_clipper_mlp_wgrad_reduce");
+}
+
 }  // extern "C"

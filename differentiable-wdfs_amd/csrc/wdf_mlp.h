@@ -401,51 +401,6 @@ static __global__ __launch_bounds__(256) void clipper_mlp_grad_reduce_kernel(con
     }
 }
 
-// Weight gradient of the MLP root: gw = -sum_n gb[n] dMLP(ain[n], lr[n])/dW over S = B*T
-// samples (lrin == nullptr: lr = log Rp from theta2).  grid = (nblk, Mlp::kParts): blockIdx.y is the
-// layer part (Mlp::wgrad); each wave writes its slice of ws [nblk][kCount].
-template <int H, int NL>
-__global__ __launch_bounds__(64) void mlp_wgrad_kernel(
-    const float* __restrict__ ain, const float* __restrict__ lrin, const float* __restrict__ gb,
-    const float* __restrict__ theta2, const float* __restrict__ w_in, float fs, float* __restrict__ ws, int64_t S)
-{
-    using M = Mlp<H, NL>;
-    __shared__ __attribute__((aligned(16))) float w[M::kCount + 4];
-    for (int i = threadIdx.x; i < M::kCount; i += 64) w[i] = w_in[i];
-    __syncthreads();
-    const int part = blockIdx.y;
-    const float lr_static = lrin ? 0.0f : mlp_load_consts(theta2, fs).lr;
-    float acc[M::kAcc];
-#pragma unroll
-    for (int i = 0; i < M::kAcc; ++i) acc[i] = 0.0f;
-    const int64_t stride = (int64_t)gridDim.x * 64;
-    float act[NL][H];
-    for (int64_t n0 = (int64_t)blockIdx.x * 64; n0 < S; n0 += stride) {
-        const int64_t n_raw = n0 + threadIdx.x;
-        const int64_t n = n_raw < S ? n_raw : S - 1;
-        const float a = ain[n];
-        const float lr = lrin ? lrin[n] : lr_static;
-        const float dout = n_raw < S ? -gb[n] : 0.0f;          // L depends on b_root = -MLP
-        (void)M::fwd(w, a, lr, act);
-        M::wgrad(w, act, a, lr, dout, part, acc);
-    }
-    // where acc[i] goes in the flat weight vector (-1: unused slot)
-    const int l = part == 0 ? 0 : 1 + (part - 1) / M::kSplit, g = part == 0 ? 0 : (part - 1) % M::kSplit;
-    const int layer = M::kMid + (l - 1) * M::kMidStride;
-    float* __restrict__ o = ws + (int64_t)blockIdx.x * M::kCount;
-#pragma unroll
-    for (int i = 0; i < M::kAcc; ++i) {
-        float v = acc[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        int dst;
-        if (part == 0) dst = i < 3 * H ? i : (i <= 4 * H ? M::kWo + (i - 3 * H) : -1);
-        else if (i < M::kRows * H) dst = layer + g * M::kRows * H + i;
-        else dst = g == 0 ? layer + H * H + (i - M::kRows * H) : -1;
-        if (threadIdx.x == 0 && dst >= 0) o[dst] = v;
-    }
-}
-
 // out[n] = MLP(a[n], lr[n]) over S independent samples: DenseRootModel.incident/reflected on a
 // table (layers.py:76-82), the forward of diode_pretraining.py's fit (:113-126, :159-160).
 template <int H, int NL>

@@ -565,6 +565,120 @@ __global__ __launch_bounds__(256) void mlp_step_fwd_kernel(const MlpStepArgs A)
     }
 }
 
+// ---- the weight gradient's per-wave accumulators: the forward / delta chain / outer products of ONE step of 16 sequences
+// (lane n + 16 g: sequence n, units 4 g + v), shared by the resident step's reverse sweep and by the sample-list pass below.
+// LDS of one wave: [step parity][layer][gd | h][sequence][unit, row padded to 20 floats].  A wave's LDS instructions
+// complete in order, so a write -> read pair of ONE wave needs no barrier, and tiles of their own per (parity, layer)
+// leave the scheduler free to run a step's transposes under the neighbouring step's matrix work.
+constexpr int kStepTile = 16 * 20;
+template <int NL> constexpr int step_wave_lds() { return 2 * (NL - 1) * 2 * kStepTile; }   // floats per wave
+
+template <int NL, int ACT>
+struct StepGradAcc {
+    float gk0a[4], gk0l[4], gb0[4], gwo[4], gbo;
+    float gbias[NL - 1][4];
+    mfma_v4f gK[NL - 1];
+
+    __device__ __forceinline__ void zero()
+    {
+        gbo = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gk0a[v] = gk0l[v] = gb0[v] = gwo[v] = 0.0f;
+#pragma unroll
+        for (int l = 0; l < NL - 1; ++l) {
+            gK[l] = mfma_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) gbias[l][v] = 0.0f;
+        }
+    }
+
+    // += G dMLP(a, lr)/dW for the 16 sequences of the wave.  tiles: the wave's LDS; parity: alternates from step to step.
+    __device__ __forceinline__ void add(const StepWeights<NL>& Wt, float a, float lr, float G, float* __restrict__ tiles, int parity,
+                                        int n, int g)
+    {
+        mfma_v4f act[NL];
+        (void)step_mlp_fwd<NL, ACT>(Wt, a, lr, act);
+        gbo += G;
+        mfma_v4f d;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            gwo[v] = fmaf(G, act[NL - 1][v], gwo[v]);
+            d[v] = Wt.wo[v] * step_dact<ACT>(act[NL - 1][v]);
+        }
+#pragma unroll
+        for (int l = NL - 1; l >= 1; --l) {
+            mfma_v4f gd;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { gd[v] = G * d[v]; gbias[l - 1][v] += gd[v]; }
+            // the two transposes through LDS: a lane writes its four units of sequence n as one 16-byte store
+            // (tile[sequence][unit]) and reads, for outer-product MFMA q, unit n of sequence 4 g + q
+            float* __restrict__ tg = tiles + ((parity * (NL - 1) + (l - 1)) * 2) * kStepTile;
+            float* __restrict__ th = tg + kStepTile;
+            *reinterpret_cast<float4*>(tg + n * 20 + 4 * g) = make_float4(gd[0], gd[1], gd[2], gd[3]);
+            *reinterpret_cast<float4*>(th + n * 20 + 4 * g) = make_float4(act[l - 1][0], act[l - 1][1], act[l - 1][2], act[l - 1][3]);
+            mfma_v4f gdT, hT;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gdT[q] = tg[(4 * g + q) * 20 + n];
+                hT[q] = th[(4 * g + q) * 20 + n];
+            }
+            if constexpr (WDF_DBG_STEP & 2) { gdT = gd; hT = act[l - 1]; }   // (pricing the transposes: the LDS traffic above goes dead)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (WDF_DBG_STEP & 4) gK[l - 1][q] += gdT[q] * hT[q];   // (pricing the outer-product MFMAs)
+                else gK[l - 1] = mfma4(gdT[q], hT[q], gK[l - 1]);
+            }
+            mfma_v4f nd = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if constexpr (WDF_DBG_STEP & 8) nd[v] += Wt.at[l - 1][v] * d[v];    // (pricing the delta chain's MFMAs)
+                else nd = mfma4(Wt.at[l - 1][v], d[v], nd);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) d[v] = nd[v] * step_dact<ACT>(act[l - 1][v]);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float gd0 = G * d[v];
+            gk0a[v] = fmaf(gd0, a, gk0a[v]);
+            gk0l[v] = fmaf(gd0, lr, gk0l[v]);
+            gb0[v] += gd0;
+        }
+    }
+
+    // the wave's partial, in the flat weight order, to o[count] (per-lane partials are per (unit 4 g + v, sequence n): summed
+    // over the 16 sequences of the lane group)
+    __device__ __forceinline__ void store(float* __restrict__ o, int H, int n, int g, int lane) const
+    {
+        const int count = 3 * H + (NL - 1) * (H * H + H) + H + 1;
+        // (the four lane groups carry the same sequences: gbo is the same in all of them)
+        const float vbo = row_sum(gbo);
+        if (lane == 0) o[count - 1] = vbo;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int u = 4 * g + v;
+            const float a0 = row_sum(gk0a[v]), a1 = row_sum(gk0l[v]), a2 = row_sum(gb0[v]), a3 = row_sum(gwo[v]);
+            if (n == 0 && u < H) {
+                o[u] = a0; o[H + u] = a1; o[2 * H + u] = a2;
+                o[3 * H + (NL - 1) * (H * H + H) + u] = a3;
+            }
+#pragma unroll
+            for (int l = 1; l < NL; ++l) {
+                const float vb = row_sum(gbias[l - 1][v]);
+                if (n == 0 && u < H) o[3 * H + (l - 1) * (H * H + H) + H * H + u] = vb;
+            }
+        }
+#pragma unroll
+        for (int l = 1; l < NL; ++l) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 4 * g + v;
+                if (n < H && i < H) o[3 * H + (l - 1) * (H * H + H) + n * H + i] = gK[l - 1][v];
+            }
+        }
+    }
+};
+
 // ---- (4) the reverse sweep: adjoint recurrence + weight gradient, one wave per (column, chunk of Lw steps) ----------
 // sums: the two GLOBAL loss sums {S, E} (multi-rank: after the all-reduce) or null -> this rank's colsum.
 // wsw: float[workgroups][count] (a workgroup = four consecutive parts, part = chunk * n_cols + column).  adam_step (or null): bumped once here, so the
@@ -621,25 +735,13 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
             gz = fmaf(m[0], gz, fmaf(ga, m[B], gb * m[2 * B]));
         }
     }
-    // the transposes' LDS tiles: [wave][step parity][layer][gd | h][sequence][unit, row padded to 20 floats].  A wave's LDS
-    // instructions complete in order, so a write -> read pair of ONE wave needs no barrier, and tiles of their own per
-    // (parity, layer) leave the scheduler free to run a step's transposes under the neighbouring step's matrix work.
-    constexpr int kTile = 16 * 20;
-    constexpr int kWaveLds = 2 * (NL - 1) * 2 * kTile;            // floats per wave
+    constexpr int kWaveLds = step_wave_lds<NL>();                 // the transposes' LDS tiles (StepGradAcc), per wave
     __shared__ __attribute__((aligned(16))) float tbuf_all[4 * kWaveLds];
     const float* __restrict__ xp = A.x + b * T;
     const float* __restrict__ pp = DYN_R ? A.p + b * T : nullptr;
     const float* __restrict__ lp = DYN_R ? A.lr + b * T : nullptr;
-    float gk0a[4] = {0, 0, 0, 0}, gk0l[4] = {0, 0, 0, 0}, gb0[4] = {0, 0, 0, 0}, gwo[4] = {0, 0, 0, 0}, gbo = 0.0f;
-    float gbias[NL - 1][4];
-    mfma_v4f gK[NL - 1];
-#pragma unroll
-    for (int l = 0; l < NL - 1; ++l) {
-        gK[l] = mfma_v4f{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int v = 0; v < 4; ++v) gbias[l][v] = 0.0f;
-    }
-    mfma_v4f act[NL];
+    StepGradAcc<NL, ACT> acc;
+    acc.zero();
     static_assert(BS == 4 || BS == 8 || BS == 16, "staging block");
     for (int64_t tb = t1 - BS; tb >= t0; tb -= BS) {         // (chunk bounds are multiples of 16)
         float xs[BS], ps[BS], ls[BS], zz[BS], kp[BS], gs[BS];
@@ -671,86 +773,60 @@ __global__ __launch_bounds__(256) void mlp_step_wgrad_kernel(const MlpStepArgs A
             const float G = live ? -g_b2n : 0.0f;                // b_root = -MLP; shadow sequences add nothing
             const float z = zz[i];
             const float a = fmaf(-p, z - xs[i], z);
-            (void)step_mlp_fwd<NL, ACT>(Wt, a, lr, act);
-            gbo += G;
-            mfma_v4f d;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                gwo[v] = fmaf(G, act[NL - 1][v], gwo[v]);
-                d[v] = Wt.wo[v] * step_dact<ACT>(act[NL - 1][v]);
-            }
-#pragma unroll
-            for (int l = NL - 1; l >= 1; --l) {
-                mfma_v4f gd;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { gd[v] = G * d[v]; gbias[l - 1][v] += gd[v]; }
-                // the two transposes through LDS: a lane writes its four units of sequence n as one 16-byte store
-                // (tile[sequence][unit]) and reads, for outer-product MFMA q, unit n of sequence 4 g + q
-                float* __restrict__ tg = tbuf_all + wv * kWaveLds + (((i & 1) * (NL - 1) + (l - 1)) * 2) * kTile;
-                float* __restrict__ th = tg + kTile;
-                *reinterpret_cast<float4*>(tg + n * 20 + 4 * g) = make_float4(gd[0], gd[1], gd[2], gd[3]);
-                *reinterpret_cast<float4*>(th + n * 20 + 4 * g) = make_float4(act[l - 1][0], act[l - 1][1], act[l - 1][2], act[l - 1][3]);
-                mfma_v4f gdT, hT;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    gdT[q] = tg[(4 * g + q) * 20 + n];
-                    hT[q] = th[(4 * g + q) * 20 + n];
-                }
-                if constexpr (WDF_DBG_STEP & 2) { gdT = gd; hT = act[l - 1]; }   // (pricing the transposes: the LDS traffic above goes dead)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if constexpr (WDF_DBG_STEP & 4) gK[l - 1][q] += gdT[q] * hT[q];   // (pricing the outer-product MFMAs)
-                    else gK[l - 1] = mfma4(gdT[q], hT[q], gK[l - 1]);
-                }
-                mfma_v4f nd = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    if constexpr (WDF_DBG_STEP & 8) nd[v] += Wt.at[l - 1][v] * d[v];    // (pricing the delta chain's MFMAs)
-                    else nd = mfma4(Wt.at[l - 1][v], d[v], nd);
-                }
-#pragma unroll
-                for (int v = 0; v < 4; ++v) d[v] = nd[v] * step_dact<ACT>(act[l - 1][v]);
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float gd0 = G * d[v];
-                gk0a[v] = fmaf(gd0, a, gk0a[v]);
-                gk0l[v] = fmaf(gd0, lr, gk0l[v]);
-                gb0[v] += gd0;
-            }
+            acc.add(Wt, a, lr, G, tbuf_all + wv * kWaveLds, i & 1, n, g);
         }
     }
-    // per-lane partials are per (unit 4 g + v, sequence n): sum over the 16 sequences of the lane group
     const int H = A.H;
     const int count = 3 * H + (NL - 1) * (H * H + H) + H + 1;
     // the wave's partial goes to LDS (its own transposes' tiles are free now), the workgroup's four are added there, in
     // wave order, and ONE partial per workgroup goes out: wsw float[workgroups][count]
-    float* __restrict__ o = tbuf_all + wv * kWaveLds;
-    // (the four lane groups carry the same sequences: gbo is the same in all of them)
-    const float vbo = row_sum(gbo);
-    if (lane == 0) o[count - 1] = vbo;
+    acc.store(tbuf_all + wv * kWaveLds, H, n, g, lane);
+    __syncthreads();
+    float* __restrict__ og = wsw + (int64_t)blockIdx.x * count;
+    for (int idx = threadIdx.x; idx < count; idx += 256) {
+        float t = 0.0f;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int u = 4 * g + v;
-        const float a0 = row_sum(gk0a[v]), a1 = row_sum(gk0l[v]), a2 = row_sum(gb0[v]), a3 = row_sum(gwo[v]);
-        if (n == 0 && u < H) {
-            o[u] = a0; o[H + u] = a1; o[2 * H + u] = a2;
-            o[3 * H + (NL - 1) * (H * H + H) + u] = a3;
-        }
-#pragma unroll
-        for (int l = 1; l < NL; ++l) {
-            const float vb = row_sum(gbias[l - 1][v]);
-            if (n == 0 && u < H) o[3 * H + (l - 1) * (H * H + H) + H * H + u] = vb;
-        }
+        for (int q = 0; q < 4; ++q) t += tbuf_all[q * kWaveLds + idx];
+        og[idx] = t;
     }
+}
+
+// ---- the same weight gradient over a LIST of S independent samples:  gw = -sum_n gb[n] dMLP(ain[n], lr[n])/dW  (lrin null:
+// lr = log P1.R from theta2).  What tape.gradient returns for DenseRootModel's variables once a reverse sweep has left
+// (a, log R, dL/db) of every sample (layers.py:72-82, clipper_pot.py:181-184): wdf_clipper_mlp_bwd's and wdf_ss_dyn_bwd's
+// emission.  A wave takes `per_wave` consecutive samples (a multiple of 128), 16 at a time on the matrix cores; partials as
+// above: wsw float[workgroups][count].
+template <int NL, int BS = 8>
+__global__ __launch_bounds__(256) void mlp_wgrad_list_kernel(const float* __restrict__ ain, const float* __restrict__ lrin,
+                                                             const float* __restrict__ gb, const float* __restrict__ theta2, float fs,
+                                                             const float* __restrict__ w, int H, int64_t S, int64_t per_wave,
+                                                             float* __restrict__ wsw)
+{
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int64_t s0 = ((int64_t)blockIdx.x * 4 + wv) * per_wave;
+    const int64_t s1 = s0 + per_wave < S ? s0 + per_wave : S;     // (a wave past the end: s0 >= s1, adds nothing)
+    const float lr_static = lrin ? 0.0f : mlp_load_consts(theta2, fs).lr;
+    const StepWeights<NL> Wt = step_load_weights<NL, 0>(w, H, lane);
+    constexpr int kWaveLds = step_wave_lds<NL>();
+    __shared__ __attribute__((aligned(16))) float tbuf_all[4 * kWaveLds];
+    StepGradAcc<NL, 0> acc;
+    acc.zero();
+    for (int64_t sb = s0; sb < s1; sb += 16 * BS) {
+        float as[BS], ls[BS], gs[BS];
 #pragma unroll
-    for (int l = 1; l < NL; ++l) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int i = 4 * g + v;
-            if (n < H && i < H) o[3 * H + (l - 1) * (H * H + H) + n * H + i] = gK[l - 1][v];
+        for (int i = 0; i < BS; ++i) {
+            const int64_t idx = sb + 16 * i + n;
+            const bool ok = idx < s1;
+            const int64_t j = ok ? idx : s1 - 1;
+            as[i] = ain[j];
+            ls[i] = lrin ? lrin[j] : lr_static;
+            gs[i] = ok ? -gb[j] : 0.0f;                          // L depends on b_root = -MLP
         }
+#pragma unroll
+        for (int i = 0; i < BS; ++i) acc.add(Wt, as[i], ls[i], gs[i], tbuf_all + wv * kWaveLds, i & 1, n, g);
     }
+    const int count = 3 * H + (NL - 1) * (H * H + H) + H + 1;
+    acc.store(tbuf_all + wv * kWaveLds, H, n, g, lane);
     __syncthreads();
     float* __restrict__ og = wsw + (int64_t)blockIdx.x * count;
     for (int idx = threadIdx.x; idx < count; idx += 256) {
