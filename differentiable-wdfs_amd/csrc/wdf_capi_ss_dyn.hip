@@ -2,6 +2,7 @@
 // any small tree (csrc/wdf_ss_dyn.h): argument checking, template dispatch, launches.
 #include "wdf_capi_common.h"
 #include "wdf_ss_dyn.h"
+#include "wdf_ss_dyn_rows.h"
 using namespace wdfcapi;
 
 namespace {
@@ -198,6 +199,116 @@ int wdf_ss_dyn_bwd_tp(const float* x, const float* rows, int per_sample, int ns,
     WDF_DYN_BWD_EMIT(K, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, part, gb, ain, lrin, gz0, ns, ni, B, T, Lc, rpart, rec,
                      (const float*)lam_in);
     return check_launch("wdf_ss_dyn_bwd_tp");
+}
+
+
+/* ---- the coefficient rows from the probed step's tape (wdf_ss_dyn_rows.h) ---- */
+namespace {
+// checks the tape (host arrays) and packs it for the kernels' argument block
+int rows_pack(const char* who, const int32_t* ops, int n_ops, const double* consts, int n_consts, const int32_t* outs, int n_out,
+              int n_params, int chan, wdf::RowsTape& tp)
+{
+    if (!ops || !outs || (n_consts > 0 && !consts)) return fail(WDF_EINVAL, "%s: null tape", who);
+    if (n_ops < 1 || n_ops > wdf::kRowsMaxOps || n_consts < 0 || n_consts > wdf::kRowsMaxConsts || n_out < 1 || n_out > wdf::kRowsMaxOut ||
+        n_params < 0 || n_params > wdf::kRowsMaxParams)
+        return fail(WDF_EUNSUPPORTED, "%s: the device evaluates tapes of <= %d operations, %d constants, %d row entries, %d component values "
+                                      "(got %d, %d, %d, %d)", who, wdf::kRowsMaxOps, wdf::kRowsMaxConsts, wdf::kRowsMaxOut, wdf::kRowsMaxParams,
+                    n_ops, n_consts, n_out, n_params);
+    if (chan < -1 || chan >= n_params) return fail(WDF_EINVAL, "%s: chan = %d with %d component values", who, chan, n_params);
+    for (int i = 0; i < n_ops; ++i) {
+        const int op = ops[3 * i], a = ops[3 * i + 1], b = ops[3 * i + 2];
+        bool ok;
+        switch (op) {
+        case wdf::kOpConst: ok = a >= 0 && a < n_consts; break;
+        case wdf::kOpParam: ok = a >= 0 && a < n_params; break;
+        case wdf::kOpAdd: case wdf::kOpSub: case wdf::kOpMul: case wdf::kOpDiv: ok = a >= 0 && a < i && b >= 0 && b < i; break;
+        case wdf::kOpNeg: case wdf::kOpRecip: ok = a >= 0 && a < i; break;
+        default: ok = false;
+        }
+        if (!ok) return fail(WDF_EINVAL, "%s: operation %d of the tape (%d, %d, %d) is not one the probe records", who, i, op, a, b);
+        tp.code[i] = (uint32_t)op | ((uint32_t)a << 8) | ((uint32_t)(op >= wdf::kOpAdd && op <= wdf::kOpDiv ? b : 0) << 16);
+    }
+    for (int k = 0; k < n_out; ++k) {
+        if (outs[k] < 0 || outs[k] >= n_ops) return fail(WDF_EINVAL, "%s: row entry %d names node %d of %d", who, k, outs[k], n_ops);
+        tp.outs[k] = (uint8_t)outs[k];
+    }
+    for (int j = 0; j < n_consts; ++j) tp.consts[j] = consts[j];
+    tp.n_ops = n_ops; tp.n_out = n_out; tp.n_params = n_params; tp.chan = chan;
+    return WDF_OK;
+}
+
+// samples a wave walks: enough waves for every SIMD, none shorter than 8 steps
+int64_t rows_tc(int64_t B, int64_t T)
+{
+    const int64_t cols = (B + 63) / 64;
+    int64_t per = (T * cols + 4095) / 4096;                       // ~4 waves per SIMD
+    per = per < 8 ? 8 : per;
+    return per > T ? T : per;
+}
+
+int rows_args(const char* who, const double* params, int n_params, int chan, const float* r, int64_t B, int64_t T)
+{
+    if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "%s: B and T must be positive", who);
+    if (n_params > 0 && !params) return fail(WDF_EINVAL, "%s: null params", who);
+    if ((chan >= 0) != (r != nullptr)) return fail(WDF_EINVAL, "%s: a channel parameter (chan >= 0) and its values r [T][B] come together", who);
+    return WDF_OK;
+}
+}  // namespace
+
+int wdf_ss_dyn_rows(const int32_t* tape_ops, int n_ops, const double* consts, int n_consts, const int32_t* outs, int n_out,
+                    const double* params, int n_params, int chan, const float* r, float* rows, int64_t B, int64_t T, void* stream)
+{
+    wdf::RowsTape tp;
+    int rc = rows_pack("wdf_ss_dyn_rows", tape_ops, n_ops, consts, n_consts, outs, n_out, n_params, chan, tp);
+    if (rc) return rc;
+    if ((rc = rows_args("wdf_ss_dyn_rows", params, n_params, chan, r, B, T))) return rc;
+    if (!rows) return fail(WDF_EINVAL, "wdf_ss_dyn_rows: null rows");
+    const int64_t tc = rows_tc(B, T);
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)((T + tc - 1) / tc));
+    const size_t lds = (size_t)n_ops * 64 * sizeof(double);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute((const void*)wdf::ss_dyn_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
+            return fail(WDF_ELAUNCH, "wdf_ss_dyn_rows: the kernel's LDS limit could not be raised");
+        raised = true;
+    }
+    hipLaunchKernelGGL(wdf::ss_dyn_rows_kernel, grid, dim3(64), lds, (hipStream_t)stream, tp, params, r, rows, B, T, tc);
+    return check_launch("wdf_ss_dyn_rows");
+}
+
+size_t wdf_ss_dyn_rows_bwd_ws_bytes(int n_params, int64_t B, int64_t T)
+{
+    if (B <= 0 || T <= 0 || n_params < 1 || n_params > wdf::kRowsMaxParams) return 0;
+    const int64_t tc = rows_tc(B, T);
+    return (size_t)((B + 63) / 64) * (size_t)((T + tc - 1) / tc) * (size_t)n_params * sizeof(double);
+}
+
+int wdf_ss_dyn_rows_bwd(const int32_t* tape_ops, int n_ops, const double* consts, int n_consts, const int32_t* outs, int n_out,
+                        const double* params, int n_params, int chan, const float* r, const float* grows, void* ws, double* gparams,
+                        int64_t B, int64_t T, void* stream)
+{
+    wdf::RowsTape tp;
+    int rc = rows_pack("wdf_ss_dyn_rows_bwd", tape_ops, n_ops, consts, n_consts, outs, n_out, n_params, chan, tp);
+    if (rc) return rc;
+    if ((rc = rows_args("wdf_ss_dyn_rows_bwd", params, n_params, chan, r, B, T))) return rc;
+    if (n_params < 1) return fail(WDF_EINVAL, "wdf_ss_dyn_rows_bwd: no component values to differentiate");
+    if (!grows || !ws || !gparams) return fail(WDF_EINVAL, "wdf_ss_dyn_rows_bwd: null grows / ws / gparams");
+    const int64_t tc = rows_tc(B, T);
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)((T + tc - 1) / tc));
+    const size_t lds = (size_t)n_ops * 64 * (sizeof(double) + sizeof(float)) + (size_t)n_params * 64 * sizeof(double);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute((const void*)wdf::ss_dyn_rows_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
+            return fail(WDF_ELAUNCH, "wdf_ss_dyn_rows_bwd: the kernel's LDS limit could not be raised");
+        raised = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wdf::ss_dyn_rows_bwd_kernel, grid, dim3(64), lds, s, tp, params, r, grows, (double*)ws, B, T, tc);
+    rc = check_launch("wdf_ss_dyn_rows_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wdf::ss_dyn_rows_reduce_kernel, dim3((unsigned)n_params), dim3(256), 0, s, (const double*)ws,
+                       (int64_t)grid.x * (int64_t)grid.y, n_params, gparams);
+    return check_launch("wdf_ss_dyn_rows_reduce");
 }
 
 }  // extern "C"

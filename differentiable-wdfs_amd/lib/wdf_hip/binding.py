@@ -149,6 +149,13 @@ def lib():
     L.wdf_ss_dyn_bwd_tp_ws_bytes.argtypes = [ci, i64, i64, ci]
     L.wdf_ss_dyn_bwd_tp.restype = ci
     L.wdf_ss_dyn_bwd_tp.argtypes = [fp, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, fp, fp, fp, vp, fp, fp, fp, fp, i64, i64, ci, vp]
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    L.wdf_ss_dyn_rows.restype = ci
+    L.wdf_ss_dyn_rows.argtypes = [ip, ci, dp, ci, ip, ci, vp, ci, ci, fp, fp, i64, i64, vp]
+    L.wdf_ss_dyn_rows_bwd_ws_bytes.restype = C.c_size_t
+    L.wdf_ss_dyn_rows_bwd_ws_bytes.argtypes = [ci, i64, i64]
+    L.wdf_ss_dyn_rows_bwd.restype = ci
+    L.wdf_ss_dyn_rows_bwd.argtypes = [ip, ci, dp, ci, ip, ci, vp, ci, ci, fp, fp, vp, vp, i64, i64, vp]
     L.wdf_clipper_mlp_wgrad_matrix_core_chunks.restype = ci
     L.wdf_clipper_mlp_wgrad_matrix_core_chunks.argtypes = [i64, i64]
     L.wdf_asym_root.restype = ci
@@ -286,6 +293,7 @@ EXPORTED_SYMBOLS = (
     "wdf_clipper_asym_bwd_tp_ws_bytes", "wdf_clipper_asym_bwd_tp", "wdf_asym_root",
     "wdf_ss_dyn_row_len", "wdf_ss_dyn_fwd", "wdf_ss_dyn_bwd_ws_bytes", "wdf_ss_dyn_bwd", "wdf_clipper_mlp_wgrad_matrix_core_chunks",
     "wdf_ss_dyn_fwd_tp_ws_bytes", "wdf_ss_dyn_fwd_tp", "wdf_ss_dyn_bwd_tp_ws_bytes", "wdf_ss_dyn_bwd_tp",
+    "wdf_ss_dyn_rows", "wdf_ss_dyn_rows_bwd_ws_bytes", "wdf_ss_dyn_rows_bwd",
     "wdf_mlp_weight_count", "wdf_clipper_mlp_fwd", "wdf_clipper_mlp_bwd", "wdf_clipper_mlp_bwd_ws_bytes",
     "wdf_clipper_mlp_bwd_w_ws_bytes", "wdf_clipper_mlp_bwd_w",
     "wdf_clipper_mlp_tp_chunks", "wdf_clipper_mlp_fwd_tp_ws_bytes", "wdf_clipper_mlp_fwd_tp",
@@ -1235,6 +1243,64 @@ def ss_dyn_fwd_tp(x, rows, ns, ni, n_chunks, warmup, tol=1.0e-6, root_kind=ROOT_
                                  float(tol), _ptr(zinit), _ptr(ws), _ptr(status), _stream())
     _check(rc, "wdf_ss_dyn_fwd_tp")
     return y, zs, zT, status
+
+
+ROWS_MAX_OPS, ROWS_MAX_CONSTS, ROWS_MAX_OUT, ROWS_MAX_PARAMS = 192, 32, 48, 15      # csrc/wdf_ss_dyn_rows.h
+
+
+class RowsTape:
+    """A probe tape (probe_tape.Tape.packed()) and the nodes of the row entries, as the host arrays wdf_ss_dyn_rows takes."""
+
+    def __init__(self, ops, consts, outs):
+        self.ops = np.ascontiguousarray(ops, dtype=np.int32).reshape(-1, 3)
+        self.consts = np.ascontiguousarray(consts, dtype=np.float64).reshape(-1)
+        self.outs = np.ascontiguousarray(outs, dtype=np.int32).reshape(-1)
+
+    def fits(self, n_params):
+        return (len(self.ops) <= ROWS_MAX_OPS and len(self.consts) <= ROWS_MAX_CONSTS and len(self.outs) <= ROWS_MAX_OUT
+                and n_params <= ROWS_MAX_PARAMS)
+
+    def args(self):
+        ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        return (self.ops.ctypes.data_as(ip), len(self.ops), self.consts.ctypes.data_as(dp), len(self.consts),
+                self.outs.ctypes.data_as(ip), len(self.outs))
+
+
+def _rows_params(params, r):
+    if params.dtype != torch.float64 or not params.is_cuda or not params.is_contiguous() or params.dim() != 1:
+        raise WdfHipError("ss_dyn_rows: params is a contiguous 1-d float64 tensor on the GPU")
+    if r is None:
+        return None, 1, 1
+    r = _f32_dev(r, "r")
+    if r.dim() != 2:
+        raise WdfHipError("ss_dyn_rows: r is [T, B]")
+    return r, int(r.shape[1]), int(r.shape[0])
+
+
+def ss_dyn_rows(tape, params, chan, r):
+    """rows [T, n, B] float32 (r None: [1, n, 1]) of the probed step `tape` (RowsTape) at the component values `params` (float64
+    [P], device), parameter `chan` taken per sample from r [T, B] (wdf_ss_dyn_rows)."""
+    require_gpu()
+    r, B, T = _rows_params(params, r)
+    rows = torch.empty((T, len(tape.outs), B), dtype=torch.float32, device=params.device)
+    rc = lib().wdf_ss_dyn_rows(*tape.args(), _ptr(params), int(params.numel()), int(chan), _ptr(r), _ptr(rows), B, T, _stream())
+    _check(rc, "wdf_ss_dyn_rows")
+    return rows
+
+
+def ss_dyn_rows_bwd(tape, params, chan, r, grows):
+    """dLoss/dparams float64 [P] from the rows' adjoint grows [T, n, B] (wdf_ss_dyn_rows_bwd); the channel's entry is 0."""
+    require_gpu()
+    r, B, T = _rows_params(params, r)
+    grows = _f32_dev(grows, "grows")
+    if tuple(grows.shape) != (T, len(tape.outs), B):
+        raise WdfHipError(f"ss_dyn_rows_bwd: grows must be [{T}, {len(tape.outs)}, {B}]")
+    P = int(params.numel())
+    ws = torch.empty((lib().wdf_ss_dyn_rows_bwd_ws_bytes(P, B, T),), dtype=torch.uint8, device=params.device)
+    gp = torch.empty((P,), dtype=torch.float64, device=params.device)
+    rc = lib().wdf_ss_dyn_rows_bwd(*tape.args(), _ptr(params), P, int(chan), _ptr(r), _ptr(grows), _ptr(ws), _ptr(gp), B, T, _stream())
+    _check(rc, "wdf_ss_dyn_rows_bwd")
+    return gp
 
 
 def ss_dyn_bwd_tp(x, rows, ns, ni, zstash, gy, n_chunks, root_kind=ROOT_NONE, rootp=None, w=None, hidden=0, n_tanh=0, n_up=1, n_down=1,

@@ -191,6 +191,28 @@ class _StateSpaceFn(torch.autograd.Function):
         return gcoef, groot, None, gz0, None, None, None, None, None, None, None, None
 
 
+class _DynRowsFn(torch.autograd.Function):
+    """rows [T,n,B] (or the static row [n]) of a probed step from its tape, on the device (csrc/wdf_ss_dyn_rows.h):
+    calc_impedance for every sample in one launch; backward: dLoss/d(component value) from the rows' adjoint in two."""
+
+    @staticmethod
+    def forward(ctx, rtape, chan, r, *vals):
+        params = torch.stack([v.detach().double().reshape(()) for v in vals]) if vals else torch.zeros((0,), dtype=torch.float64, device=r.device)
+        rows = binding.ss_dyn_rows(rtape, params, chan, r)
+        ctx.rtape, ctx.chan, ctx.r, ctx.params = rtape, chan, r, params
+        ctx.dtypes = [v.dtype for v in vals]
+        return rows if r is not None else rows.reshape(-1)
+
+    @staticmethod
+    def backward(ctx, grows):
+        g = grows.float().contiguous()
+        if ctx.r is None:
+            g = g.reshape(1, -1, 1)
+        gp = binding.ss_dyn_rows_bwd(ctx.rtape, ctx.params, ctx.chan, ctx.r, g)
+        need = ctx.needs_input_grad[3:]
+        return (None, None, None) + tuple(gp[i].to(ctx.dtypes[i]) if need[i] else None for i in range(len(need)))
+
+
 class _SsDynFn(torch.autograd.Function):
     """y [T,B] = the state-space recursion with streamed coefficient rows and / or the MLP root (csrc/wdf_ss_dyn.h).
     rows: [T,n,B] (per-sample impedance) or [n] (static), n = A | Bx | E | ca | da | cy | dy | fy | R_port.
@@ -997,21 +1019,33 @@ class Circuit:
             tape, outs, rport = probe_tape.record(self, pvars, device_limits=False)
             self._dyn_tape = (tape, outs + [rport], params)
         tape, outs, params = self._dyn_tape
+        chan = next((i for i, (e, _) in enumerate(params) if e is self.per_sample_R), -1)
+        rtape = self.__dict__.get("_dyn_rtape")
+        if rtape is None:
+            rtape = self._dyn_rtape = binding.RowsTape(*tape.packed(), outs)
+        on_device = rtape.fits(len(params)) and not x.requires_grad
         vals = []
-        for e, n in params:
-            if e is self.per_sample_R:
-                vals.append(x[:, :, self.ni].double())                            # the resistance channel: [B,T]
+        for i, (e, n) in enumerate(params):
+            if i == chan:
+                # the resistance channel: [T,B] for the device tape, [B,T] float64 for torch's
+                vals.append(x[:, :, self.ni].t().contiguous() if on_device else x[:, :, self.ni].double())
             else:
                 v = e.__dict__[n]
                 v = v.as_subclass(torch.Tensor) if isinstance(v, torch.Tensor) else torch.tensor(float(v))
-                vals.append(v.double().reshape(()).to(dev))
+                vals.append(v.reshape(()).to(dev) if on_device else v.double().reshape(()).to(dev))
         with torch._C.DisableTorchFunctionSubclass():
-            nodes = tape.evaluate_torch(vals, outs)
-            if self.per_sample_R is not None:
-                rows = torch.stack([torch.broadcast_to(v, (B, T)) for v in nodes], dim=0)       # [n,B,T]
-                rows = rows.permute(2, 0, 1).float().contiguous()                                # [T,n,B]
+            if on_device:
+                # calc_impedance of every sample in one launch (csrc/wdf_ss_dyn_rows.h); the channel's slot gets a placeholder
+                r = vals[chan].float() if chan >= 0 else None
+                rows = _DynRowsFn.apply(rtape, chan, r, *[v if i != chan else v.new_zeros(()) for i, v in enumerate(vals)])
             else:
-                rows = torch.stack([v.reshape(()) for v in nodes]).float()                       # one static row [n]
+                # (a tape past the device evaluator's sizes, or a channel that wants its own gradient: torch runs the tape)
+                nodes = tape.evaluate_torch(vals, outs)
+                if self.per_sample_R is not None:
+                    rows = torch.stack([torch.broadcast_to(v, (B, T)) for v in nodes], dim=0)       # [n,B,T]
+                    rows = rows.permute(2, 0, 1).float().contiguous()                                # [T,n,B]
+                else:
+                    rows = torch.stack([v.reshape(()) for v in nodes]).float()                       # one static row [n]
         hidden = n_tanh = 0
         n_up = n_down = 1
         if self.root_kind == "DiodePair":
@@ -1068,8 +1102,8 @@ class Circuit:
             cache[key] = (hit[0], hit[1] + 1)
             return hit[0]
         with torch.no_grad(), torch._C.DisableTorchFunctionSubclass():
-            ends = [[v if v.dim() == 0 else sel(v) for v in vals] for sel in (torch.amin, torch.amax)] if self.per_sample_R is not None \
-                else [list(vals)]
+            ends = [[(v if v.dim() == 0 else sel(v)).double() for v in vals] for sel in (torch.amin, torch.amax)] \
+                if self.per_sample_R is not None else [[v.double() for v in vals]]
             rho = 0.0
             for pv in ends:
                 c = torch.stack([v.reshape(()) for v in tape.evaluate_torch(pv, outs)]).double().cpu().numpy()

@@ -508,6 +508,27 @@ int wdf_ss_dyn_bwd(const float* x, const float* rows, int per_sample, int ns, in
                    int hidden, int n_tanh_layers, int n_up, int n_down, const float* zstash, const float* gy, float* grows,
                    void* ws, float* gb, float* ain, float* lrin, float* gz0, int64_t B, int64_t T, void* stream);
 
+/* The rows themselves, on the device (csrc/wdf_ss_dyn_rows.h): the probed step of the tree as a straight-line scalar program
+ * ("tape") over its component values -- the elements' own calc_impedance / reflected / incident arithmetic (tf_wdf.py:31-214)
+ * recorded once on the host -- run per (sample, sequence) in float64 with ONE component value taken from a resistance channel:
+ * set_resistance + calc_impedance every step (tf_wdf.py:51-52,80-81; clipper_pot.py:116-117) for the whole batch in one launch,
+ * and its chain rule (tape.gradient through calc_impedance, lpf.py:38,87-90) in two.
+ * tape_ops   HOST int32 [n_ops][3] = {op, a, b}: 0 CONST (a: index into consts), 1 PARAM (a: component value), 2 ADD, 3 SUB, 4 MUL,
+ *            5 DIV (a, b: earlier operations), 6 NEG, 7 RECIP (a); n_ops <= 192.  consts: HOST double [n_consts <= 32].
+ * outs       HOST int32 [n_out]: the operation whose value is row entry k (n_out = wdf_ss_dyn_row_len(ns, ni) for the kernels above)
+ * params     device double [n_params <= 15]: the component values; chan: the one that is the channel (-1: none)
+ * r          device float [T][B]: the channel (NULL with chan = -1 -- B = T = 1 then gives the one static row)
+ * rows       device float [T][n_out][B] (out)
+ * _bwd:      grows [T][n_out][B] (what wdf_ss_dyn_bwd left) -> gparams device double [n_params] = dLoss/d(component value) summed
+ *            over all samples in a fixed order (the channel's entry: 0); ws: wdf_ss_dyn_rows_bwd_ws_bytes.
+ * The tape is checked on every call (operands must name earlier operations); WDF_EUNSUPPORTED beyond the sizes above. */
+int wdf_ss_dyn_rows(const int32_t* tape_ops, int n_ops, const double* consts, int n_consts, const int32_t* outs, int n_out,
+                    const double* params, int n_params, int chan, const float* r, float* rows, int64_t B, int64_t T, void* stream);
+size_t wdf_ss_dyn_rows_bwd_ws_bytes(int n_params, int64_t B, int64_t T);
+int wdf_ss_dyn_rows_bwd(const int32_t* tape_ops, int n_ops, const double* consts, int n_consts, const int32_t* outs, int n_out,
+                        const double* params, int n_params, int chan, const float* r, const float* grows, void* ws, double* gparams,
+                        int64_t B, int64_t T, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Clipper with two DIFFERENT antiparallel diodes (BASELINE config 5; csrc/wdf_asym.h).  New
  * API, no reference counterpart (its pairs are copies of one diode, diode_pretraining.py:46-47).

@@ -380,3 +380,59 @@ def test_streamed_forward_starts_warm_when_a_batch_is_visited_again(wdf, golden,
         assert abs(lw - ls) <= 2e-5 * ls
         scale = np.max(np.abs(gs))
         assert np.max(np.abs(gw - gs) / (np.abs(gs) + 1e-3 * scale)) < 2e-3
+
+
+@pytest.mark.parametrize("tree,B,T", [("hpf", 70, 33), ("three", 130, 9), ("static", 1, 1)])
+def test_rows_made_on_the_device_equal_the_tape_in_float64(wdf, tree, B, T):
+    """wdf_ss_dyn_rows / _bwd (csrc/wdf_ss_dyn_rows.h) against the same tape run by torch in float64 with autograd: every row
+    entry of every sample, and dLoss/d(component value) for a random row adjoint.  (The end-to-end tests above go through
+    these kernels too; this one holds them alone, to float32 rounding.)"""
+    from wdf_hip import binding as wb, lowering, probe_tape
+    from tf_wdf import DiodePair
+    if tree in ("hpf", "static"):
+        circ, _, _ = build_hpf(wdf, "diode", "Vs" if tree == "hpf" else None, [33.0e3, 1.0e3, 22.0e-9, 4.0e-9, 0.049])
+        chan_el = circ.per_sample_R
+    else:
+        Vs = wdf.ResistiveVoltageSource(2.2e3, trainable=True)
+        R1, Rp = wdf.Resistor(15.0e3, True), wdf.Resistor(10.0e3, True)
+        C0, C1, C2 = wdf.Capacitor(47.0e-9, FS, True), wdf.Capacitor(10.0e-9, FS, True), wdf.Capacitor(22.0e-9, FS, True)
+        top = wdf.Parallel(wdf.Series(Rp, C2), wdf.Series(wdf.Series(Vs, C0), wdf.Parallel(R1, C1)))
+        circ = wdf.Circuit(top, DiodePair(top, 4.0e-9, Vt=0.049, trainable=True), C2, per_sample_R=Rp)
+        chan_el = Rp
+    own = {"Resistor": "R", "ResistiveVoltageSource": "R", "Capacitor": "C"}
+    els = [(e, own[lowering._kind(e)]) for e in circ.elements if lowering._kind(e) in own]
+    tape, outs, rport = probe_tape.record(circ, [e.__dict__[n] for e, n in els], device_limits=False)
+    outs = outs + [rport]
+    chan = next((i for i, (e, _) in enumerate(els) if e is chan_el), -1)
+    p64 = np.array([float(e.__dict__[n]) for e, n in els], dtype=np.float64)
+    rng = np.random.default_rng(5)
+    r = pot_channel(B, T, 300.0, 80.0e3, 9).T.copy() if chan >= 0 else None          # [T,B]
+    rt = wb.RowsTape(*tape.packed(), outs)
+    assert rt.fits(len(els))
+    params = torch.as_tensor(p64, device="cuda")
+    rows = wb.ss_dyn_rows(rt, params, chan, None if r is None else cuda(r))
+    n = len(outs)
+    assert tuple(rows.shape) == (T, n, B)
+    # the same tape in torch, float64, with autograd
+    pv = [torch.tensor(v, dtype=torch.float64, device="cuda", requires_grad=(i != chan)) for i, v in enumerate(p64)]
+    vals = [p if i != chan else torch.as_tensor(r.astype(np.float64), device="cuda") for i, p in enumerate(pv)]
+    nodes = tape.evaluate_torch(vals, outs)
+    ref = torch.stack([torch.broadcast_to(v, (T, B)) for v in nodes], dim=1)          # [T,n,B]
+    scale = ref.detach().abs().amax(dim=(0, 2), keepdim=True).clamp_min(1e-300)
+    assert float(((rows.double() - ref.detach()).abs() / scale).max()) < 2e-7
+    grows = torch.as_tensor((rng.standard_normal((T, n, B)) / scale.cpu().numpy()).astype(np.float32), device="cuda")
+    gp = wb.ss_dyn_rows_bwd(rt, params, chan, None if r is None else cuda(r), grows)
+    (ref * grows.double()).sum().backward()
+    for i, p in enumerate(pv):
+        if i == chan:
+            assert float(gp[i]) == 0.0
+        else:
+            # (float32 node adjoints under a random-sign row adjoint: the sum over T n B terms cancels to ~1e-3 of their size)
+            assert abs(float(gp[i]) - float(p.grad)) <= 2e-4 * abs(float(p.grad)) + 1e-30, (i, float(gp[i]), float(p.grad))
+    # refusals: a tape that names a later operation; a channel without its values
+    bad = wb.RowsTape(np.array([[2, 1, 0], [0, 0, 0]]), [1.0], [0])
+    with pytest.raises(wb.WdfHipError, match="not one the probe records"):
+        wb.ss_dyn_rows(bad, params, -1, None)
+    if chan >= 0:
+        with pytest.raises(wb.WdfHipError, match="come together"):
+            wb.ss_dyn_rows(rt, params, chan, None)
