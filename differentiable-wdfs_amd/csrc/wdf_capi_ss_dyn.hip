@@ -237,14 +237,7 @@ int rows_pack(const char* who, const int32_t* ops, int n_ops, const double* cons
     return WDF_OK;
 }
 
-// samples a wave walks: enough waves for every SIMD, none shorter than 8 steps
-int64_t rows_tc(int64_t B, int64_t T)
-{
-    const int64_t cols = (B + 63) / 64;
-    int64_t per = (T * cols + 4095) / 4096;                       // ~4 waves per SIMD
-    per = per < 8 ? 8 : per;
-    return per > T ? T : per;
-}
+int64_t rows_blocks_t(int64_t T) { return (T + wdf::kRowsSteps - 1) / wdf::kRowsSteps; }
 
 int rows_args(const char* who, const double* params, int n_params, int chan, const float* r, int64_t B, int64_t T)
 {
@@ -263,8 +256,7 @@ int wdf_ss_dyn_rows(const int32_t* tape_ops, int n_ops, const double* consts, in
     if (rc) return rc;
     if ((rc = rows_args("wdf_ss_dyn_rows", params, n_params, chan, r, B, T))) return rc;
     if (!rows) return fail(WDF_EINVAL, "wdf_ss_dyn_rows: null rows");
-    const int64_t tc = rows_tc(B, T);
-    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)((T + tc - 1) / tc));
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)rows_blocks_t(T));
     const size_t lds = (size_t)n_ops * 64 * sizeof(double);
     static bool raised = false;
     if (!raised) {
@@ -272,15 +264,14 @@ int wdf_ss_dyn_rows(const int32_t* tape_ops, int n_ops, const double* consts, in
             return fail(WDF_ELAUNCH, "wdf_ss_dyn_rows: the kernel's LDS limit could not be raised");
         raised = true;
     }
-    hipLaunchKernelGGL(wdf::ss_dyn_rows_kernel, grid, dim3(64), lds, (hipStream_t)stream, tp, params, r, rows, B, T, tc);
+    hipLaunchKernelGGL(wdf::ss_dyn_rows_kernel, grid, dim3(64), lds, (hipStream_t)stream, tp, params, r, rows, B, T);
     return check_launch("wdf_ss_dyn_rows");
 }
 
 size_t wdf_ss_dyn_rows_bwd_ws_bytes(int n_params, int64_t B, int64_t T)
 {
     if (B <= 0 || T <= 0 || n_params < 1 || n_params > wdf::kRowsMaxParams) return 0;
-    const int64_t tc = rows_tc(B, T);
-    return (size_t)((B + 63) / 64) * (size_t)((T + tc - 1) / tc) * (size_t)n_params * sizeof(double);
+    return (size_t)((B + 63) / 64) * (size_t)rows_blocks_t(T) * (size_t)n_params * sizeof(double);
 }
 
 int wdf_ss_dyn_rows_bwd(const int32_t* tape_ops, int n_ops, const double* consts, int n_consts, const int32_t* outs, int n_out,
@@ -293,8 +284,7 @@ int wdf_ss_dyn_rows_bwd(const int32_t* tape_ops, int n_ops, const double* consts
     if ((rc = rows_args("wdf_ss_dyn_rows_bwd", params, n_params, chan, r, B, T))) return rc;
     if (n_params < 1) return fail(WDF_EINVAL, "wdf_ss_dyn_rows_bwd: no component values to differentiate");
     if (!grows || !ws || !gparams) return fail(WDF_EINVAL, "wdf_ss_dyn_rows_bwd: null grows / ws / gparams");
-    const int64_t tc = rows_tc(B, T);
-    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)((T + tc - 1) / tc));
+    const dim3 grid((unsigned)((B + 63) / 64), (unsigned)rows_blocks_t(T));
     const size_t lds = (size_t)n_ops * 64 * (sizeof(double) + sizeof(float)) + (size_t)n_params * 64 * sizeof(double);
     static bool raised = false;
     if (!raised) {
@@ -303,7 +293,7 @@ int wdf_ss_dyn_rows_bwd(const int32_t* tape_ops, int n_ops, const double* consts
         raised = true;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(wdf::ss_dyn_rows_bwd_kernel, grid, dim3(64), lds, s, tp, params, r, grows, (double*)ws, B, T, tc);
+    hipLaunchKernelGGL(wdf::ss_dyn_rows_bwd_kernel, grid, dim3(64), lds, s, tp, params, r, grows, (double*)ws, B, T);
     rc = check_launch("wdf_ss_dyn_rows_bwd");
     if (rc) return rc;
     hipLaunchKernelGGL(wdf::ss_dyn_rows_reduce_kernel, dim3((unsigned)n_params), dim3(256), 0, s, (const double*)ws,

@@ -12,7 +12,8 @@
 //             (lpf.py:38,87-90) for all of a sequence's steps at once.  Adjoints of the nodes are float32 (they start from
 //             float32 row adjoints); per-lane sums are float64, reduced in a fixed order: lanes (DPP), waves (partials +
 //             one more launch).
-// The tape travels in the kernel arguments (one dword per operation: scalar loads, the switch is wave-uniform).
+// The tape travels in the kernel arguments and sits in three VGPRs (one dword per operation, lane = operation: v_readlane at a
+// wave-uniform index; the switch is wave-uniform).
 // No channel (r == null, B = T = 1): the one static row of a tree whose components only train.
 #pragma once
 
@@ -36,30 +37,84 @@ struct RowsTape {
     int n_ops, n_out, n_params, chan;  // chan: the parameter that is the channel, or -1
 };
 
+// The tape, the constants and the component values spread over the wave's lanes (operation i: lane i & 63 of word i >> 6),
+// read back with v_readlane at a wave-uniform index: no memory access in the interpreter's dependent chain but the nodes' LDS.
+struct RowsRegs {
+    uint32_t c0, c1, c2;
+    double kv, pv;
+
+    __device__ __forceinline__ void load(const RowsTape& tp, const double* __restrict__ params, int lane)
+    {
+        c0 = tp.code[lane]; c1 = tp.code[64 + lane]; c2 = tp.code[128 + lane];
+        kv = tp.consts[lane & (kRowsMaxConsts - 1)];
+        pv = lane < tp.n_params ? params[lane] : 0.0;
+    }
+    __device__ __forceinline__ uint32_t code(int i) const
+    {
+        // (three v_readlane and two scalar selects: selecting the VGPR first makes an indexed array of them, in scratch)
+        const int l = i & 63;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)c0, l), r1 = (uint32_t)__builtin_amdgcn_readlane((int)c1, l),
+                       r2 = (uint32_t)__builtin_amdgcn_readlane((int)c2, l);
+        return i < 64 ? r0 : (i < 128 ? r1 : r2);
+    }
+    static __device__ __forceinline__ double lane_f64(double v, int l)
+    {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+        return __hiloint2double(hi, lo);
+    }
+    __device__ __forceinline__ double constant(int a) const { return lane_f64(kv, a); }
+    __device__ __forceinline__ double param(int a) const { return lane_f64(pv, a); }
+};
+
+// +, -, *, negate as ONE branch-free form  v = c1 x + c2 y + c3 x y  with wave-uniform coefficients (the interpreter's time went
+// into the taken branches of a per-operation switch, not into the arithmetic); / and reciprocal, constants and component values
+// are the rare operations and branch.
+struct RowsForm {
+    double c1, c2, c3;
+    __device__ __forceinline__ explicit RowsForm(int op)
+        : c1(op == kOpMul ? 0.0 : (op == kOpNeg ? -1.0 : 1.0)), c2(op == kOpAdd ? 1.0 : (op == kOpSub ? -1.0 : 0.0)), c3(op == kOpMul ? 1.0 : 0.0) {}
+    static __device__ __forceinline__ bool covers(int op) { return op == kOpAdd || op == kOpSub || op == kOpMul || op == kOpNeg; }
+};
+
 // the tape forward for this lane's sample: val[node * 64 + lane]
-__device__ __forceinline__ void rows_forward(const RowsTape& tp, const double* __restrict__ params, double rv, double* __restrict__ val, int lane)
+__device__ __forceinline__ void rows_forward(const RowsRegs& rg, int n_ops, int chan, double rv, double* __restrict__ val, int lane)
 {
-    for (int i = 0; i < tp.n_ops; ++i) {
-        const uint32_t c = tp.code[i];
+    for (int i = 0; i < n_ops; ++i) {
+        const uint32_t c = rg.code(i);
         const int op = (int)(c & 0xffu), a = (int)((c >> 8) & 0xffu), b = (int)((c >> 16) & 0xffu);
         double v;
-        switch (op) {
-        case kOpConst: v = tp.consts[a]; break;
-        case kOpParam: v = (a == tp.chan) ? rv : params[a]; break;
-        case kOpAdd: v = val[a * 64 + lane] + val[b * 64 + lane]; break;
-        case kOpSub: v = val[a * 64 + lane] - val[b * 64 + lane]; break;
-        case kOpMul: v = val[a * 64 + lane] * val[b * 64 + lane]; break;
-        case kOpDiv: v = val[a * 64 + lane] / val[b * 64 + lane]; break;
-        case kOpNeg: v = -val[a * 64 + lane]; break;
-        default: v = 1.0 / val[a * 64 + lane]; break;             // kOpRecip
+        if (__builtin_expect(RowsForm::covers(op), 1)) {
+            const RowsForm f(op);
+            const double x = val[a * 64 + lane], y = val[b * 64 + lane];      // (negate: b = 0, c2 = c3 = 0)
+            v = fma(f.c3 * x, y, fma(f.c2, y, f.c1 * x));
+        } else if (op == kOpDiv) {
+            v = val[a * 64 + lane] / val[b * 64 + lane];
+        } else if (op == kOpRecip) {
+            v = 1.0 / val[a * 64 + lane];
+        } else if (op == kOpParam) {
+            v = (a == chan) ? rv : rg.param(a);
+        } else {
+            v = rg.constant(a);                                   // kOpConst
         }
         val[i * 64 + lane] = v;
     }
 }
 
-// grid (ceil(B / 64), ceil(T / tc)), block 64, dynamic LDS n_ops * 64 * 8 bytes
+constexpr int kRowsSteps = 8;          // samples a wave walks: their channel values are asked for at once, before the first tape pass
+
+// the channel values of the wave's steps (clamped reads past T; r null: zeros)
+__device__ __forceinline__ void rows_channel(const float* __restrict__ r, int64_t t0, int64_t T, int64_t B, int64_t b, float (&rv)[kRowsSteps])
+{
+#pragma unroll
+    for (int q = 0; q < kRowsSteps; ++q) {
+        const int64_t t = t0 + q < T ? t0 + q : T - 1;
+        rv[q] = r ? r[t * B + b] : 0.0f;
+    }
+}
+
+// grid (ceil(B / 64), ceil(T / kRowsSteps)), block 64, dynamic LDS n_ops * 64 * 8 bytes
 __global__ __launch_bounds__(64) void ss_dyn_rows_kernel(const RowsTape tp, const double* __restrict__ params, const float* __restrict__ r,
-                                                         float* __restrict__ rows, int64_t B, int64_t T, int64_t tc)
+                                                         float* __restrict__ rows, int64_t B, int64_t T)
 {
     extern __shared__ double rows_lds[];
     double* __restrict__ val = rows_lds;
@@ -67,12 +122,18 @@ __global__ __launch_bounds__(64) void ss_dyn_rows_kernel(const RowsTape tp, cons
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + lane;
     const bool live = b_raw < B;
     const int64_t b = live ? b_raw : B - 1;
-    const int64_t t0 = (int64_t)blockIdx.y * tc, t1 = t0 + tc < T ? t0 + tc : T;
+    const int64_t t0 = (int64_t)blockIdx.y * kRowsSteps;
     const int n = tp.n_out;
-    for (int64_t t = t0; t < t1; ++t) {
-        const double rv = r ? (double)r[t * B + b] : 0.0;
-        rows_forward(tp, params, rv, val, lane);
-        if (live) {
+    RowsRegs rg;
+    rg.load(tp, params, lane);
+    float rv[kRowsSteps];
+    rows_channel(r, t0, T, B, b, rv);
+#pragma unroll
+    for (int q = 0; q < kRowsSteps; ++q) {
+        const int64_t t = t0 + q;
+        if (t >= T) break;
+        rows_forward(rg, tp.n_ops, tp.chan, (double)rv[q], val, lane);
+        if (live) {                                                // (stores only: nothing in the loop waits for memory)
             float* __restrict__ o = rows + t * n * B + b;
             for (int k = 0; k < n; ++k) o[(int64_t)k * B] = (float)val[(int)tp.outs[k] * 64 + lane];
         }
@@ -82,8 +143,7 @@ __global__ __launch_bounds__(64) void ss_dyn_rows_kernel(const RowsTape tp, cons
 // The reverse pass.  grid as above; dynamic LDS n_ops * 64 * 12 + n_params * 64 * 8 bytes.
 // part: double [gridDim.y * gridDim.x][n_params] -- one partial per wave (the channel's entry is left 0).
 __global__ __launch_bounds__(64) void ss_dyn_rows_bwd_kernel(const RowsTape tp, const double* __restrict__ params, const float* __restrict__ r,
-                                                             const float* __restrict__ grows, double* __restrict__ part, int64_t B, int64_t T,
-                                                             int64_t tc)
+                                                             const float* __restrict__ grows, double* __restrict__ part, int64_t B, int64_t T)
 {
     extern __shared__ double rows_lds[];
     const int lane = threadIdx.x, n_ops = tp.n_ops, P = tp.n_params;
@@ -93,39 +153,54 @@ __global__ __launch_bounds__(64) void ss_dyn_rows_bwd_kernel(const RowsTape tp, 
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + lane;
     const bool live = b_raw < B;
     const int64_t b = live ? b_raw : B - 1;
-    const int64_t t0 = (int64_t)blockIdx.y * tc, t1 = t0 + tc < T ? t0 + tc : T;
+    const int64_t t0 = (int64_t)blockIdx.y * kRowsSteps;
     const int n = tp.n_out;
     for (int p = 0; p < P; ++p) gp[p * 64 + lane] = 0.0;
-    for (int64_t t = t0; t < t1; ++t) {
-        const double rv = r ? (double)r[t * B + b] : 0.0;
-        rows_forward(tp, params, rv, val, lane);
-        for (int i = 0; i < n_ops; ++i) adj[i * 64 + lane] = 0.0f;
+    RowsRegs rg;
+    rg.load(tp, params, lane);
+    const int chan = tp.chan;
+    float rv[kRowsSteps];
+    rows_channel(r, t0, T, B, b, rv);
+#pragma unroll
+    for (int q = 0; q < kRowsSteps; ++q) {
+        const int64_t t = t0 + q;
+        if (t >= T) break;
+        // the row's adjoint, four entries per round trip, asked for before the forward pass needs the LDS pipe
         const float* __restrict__ g = grows + t * n * B + b;
-        for (int k = 0; k < n; ++k) adj[(int)tp.outs[k] * 64 + lane] += live ? g[(int64_t)k * B] : 0.0f;    // (an entry may name a node twice)
+        for (int i = 0; i < n_ops; ++i) adj[i * 64 + lane] = 0.0f;
+        for (int k0 = 0; k0 < n; k0 += 4) {
+            float g4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g4[j] = (live && k0 + j < n) ? g[(int64_t)(k0 + j < n ? k0 + j : n - 1) * B] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < n) adj[(int)tp.outs[k0 + j] * 64 + lane] += g4[j];           // (an entry may name a node twice: in order)
+        }
+        rows_forward(rg, n_ops, chan, (double)rv[q], val, lane);
         for (int i = n_ops - 1; i >= 0; --i) {
-            const uint32_t c = tp.code[i];
+            const uint32_t c = rg.code(i);
             const int op = (int)(c & 0xffu), a = (int)((c >> 8) & 0xffu), bb = (int)((c >> 16) & 0xffu);
             const double gi = (double)adj[i * 64 + lane];
-            switch (op) {
-            case kOpConst: break;
-            case kOpParam: if (a != tp.chan) gp[a * 64 + lane] += gi; break;
-            case kOpAdd: adj[a * 64 + lane] += (float)gi; adj[bb * 64 + lane] += (float)gi; break;
-            case kOpSub: adj[a * 64 + lane] += (float)gi; adj[bb * 64 + lane] -= (float)gi; break;
-            case kOpMul: {
-                const double va = val[a * 64 + lane], vb = val[bb * 64 + lane];
-                adj[a * 64 + lane] += (float)(gi * vb);
-                adj[bb * 64 + lane] += (float)(gi * va);            // (a == bb: both land, 2 gi va)
-            } break;
-            case kOpDiv: {
+            if (__builtin_expect(RowsForm::covers(op), 1)) {
+                // v = c1 x + c2 y + c3 x y:  dx = g (c1 + c3 y), dy = g (c2 + c3 x)
+                const RowsForm f(op);
+                const double x = val[a * 64 + lane], y = val[bb * 64 + lane];
+                const float ga = (float)(gi * fma(f.c3, y, f.c1)), gb = (float)(gi * fma(f.c3, x, f.c2));
+                if (a == bb) adj[a * 64 + lane] += ga + gb;        // (x + x, x * x: one node, both parts)
+                else {
+                    const float aa = adj[a * 64 + lane], ab = adj[bb * 64 + lane];
+                    adj[a * 64 + lane] = aa + ga;
+                    adj[bb * 64 + lane] = ab + gb;
+                }
+            } else if (op == kOpDiv) {
                 const double ib = 1.0 / val[bb * 64 + lane], q = val[i * 64 + lane];
                 adj[a * 64 + lane] += (float)(gi * ib);
                 adj[bb * 64 + lane] -= (float)(gi * q * ib);
-            } break;
-            case kOpNeg: adj[a * 64 + lane] -= (float)gi; break;
-            default: {                                            // kOpRecip: d(1/u) = -(1/u)^2 du
+            } else if (op == kOpRecip) {                           // d(1/u) = -(1/u)^2 du
                 const double q = val[i * 64 + lane];
                 adj[a * 64 + lane] -= (float)(gi * q * q);
-            } break;
+            } else if (op == kOpParam) {
+                if (a != chan) gp[a * 64 + lane] += gi;
             }
         }
     }

@@ -73,6 +73,10 @@ for root in ("diode", "mlp2x16"):
     wb.Event.bracket_next(e[2], e[3])
     g = tape.gradient(loss, params)
     torch.cuda.synchronize()
+    if "--trace" in sys.argv:                                  # the warm start's controller: warm-ups run, the verdicts read back
+        for _, ws in circ.__dict__["_dyn_warm"].values():
+            print("# warm-ups of the last calls:", list(ws.trace)[-24:], file=sys.stderr)
+            print("# verdicts (warm-up, n_bad, max miss, gated groups, -):", list(ws.ctl.verdicts)[-12:], file=sys.stderr)
     print(json.dumps({"tree": "HPF clipper, pot on the source resistance", "root": root, "B": B, "T": T, "ms_per_fwd_bwd": ms,
                       "samples_per_s": B * T / ms * 1e3, "fwd_kernel_ms": e[0].elapsed_ms(e[1]), "bwd_kernel_ms": e[2].elapsed_ms(e[3]),
                       "fwd_chunks": wdf._lowering.LAST_SS_TP_STATUS.get("chunks_used"), "fwd_warmup": wdf._lowering.LAST_SS_TP_STATUS.get("warmup_used")}))
