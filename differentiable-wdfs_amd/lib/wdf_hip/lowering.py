@@ -191,6 +191,12 @@ class _StateSpaceFn(torch.autograd.Function):
         return gcoef, groot, None, gz0, None, None, None, None, None, None, None, None
 
 
+# The device tape interpreter keeps a sample's node values in LDS: its time grows with the square of the tape's length, torch's
+# (one launch per operation over the whole channel) linearly -- past this many operations torch runs the tape
+# (tools/ss_dyn_rows_crossover.py, profiles/r05_rows_crossover.txt: 32 operations 1.6 vs 2.2 ms per step, 48: 2.5 vs 3.3, 89: 5.5 vs 5.2, 138: 12.9 vs 7.5).
+DYN_ROWS_MAX_OPS = int(os.environ.get("WDF_DYN_ROWS_MAX_OPS", "80"))
+
+
 class _DynRowsFn(torch.autograd.Function):
     """rows [T,n,B] (or the static row [n]) of a probed step from its tape, on the device (csrc/wdf_ss_dyn_rows.h):
     calc_impedance for every sample in one launch; backward: dLoss/d(component value) from the rows' adjoint in two."""
@@ -1023,7 +1029,7 @@ class Circuit:
         rtape = self.__dict__.get("_dyn_rtape")
         if rtape is None:
             rtape = self._dyn_rtape = binding.RowsTape(*tape.packed(), outs)
-        on_device = rtape.fits(len(params)) and not x.requires_grad
+        on_device = rtape.fits(len(params)) and len(rtape.ops) <= DYN_ROWS_MAX_OPS and not x.requires_grad
         vals = []
         for i, (e, n) in enumerate(params):
             if i == chan:
