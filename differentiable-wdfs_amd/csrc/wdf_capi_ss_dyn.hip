@@ -239,9 +239,19 @@ int rows_pack(const char* who, const int32_t* ops, int n_ops, const double* cons
 
 int64_t rows_blocks_t(int64_t T) { return (T + wdf::kRowsSteps - 1) / wdf::kRowsSteps; }
 
+// a launch with more than the default 64 KB of dynamic LDS asks for it first (per function and device: asked every such call)
+int rows_lds_limit(const char* who, const void* kernel, size_t lds)
+{
+    if (lds <= 64 * 1024) return WDF_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return fail(WDF_ELAUNCH, "%s: %zu bytes of LDS for this tape could not be asked for", who, lds);
+    return WDF_OK;
+}
+
 int rows_args(const char* who, const double* params, int n_params, int chan, const float* r, int64_t B, int64_t T)
 {
     if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "%s: B and T must be positive", who);
+    if (rows_blocks_t(T) > 65535) return fail(WDF_EUNSUPPORTED, "%s: T <= %d", who, 65535 * wdf::kRowsSteps);
     if (n_params > 0 && !params) return fail(WDF_EINVAL, "%s: null params", who);
     if ((chan >= 0) != (r != nullptr)) return fail(WDF_EINVAL, "%s: a channel parameter (chan >= 0) and its values r [T][B] come together", who);
     return WDF_OK;
@@ -251,19 +261,14 @@ int rows_args(const char* who, const double* params, int n_params, int chan, con
 int wdf_ss_dyn_rows(const int32_t* tape_ops, int n_ops, const double* consts, int n_consts, const int32_t* outs, int n_out,
                     const double* params, int n_params, int chan, const float* r, float* rows, int64_t B, int64_t T, void* stream)
 {
-    wdf::RowsTape tp;
+    wdf::RowsTape tp{};
     int rc = rows_pack("wdf_ss_dyn_rows", tape_ops, n_ops, consts, n_consts, outs, n_out, n_params, chan, tp);
     if (rc) return rc;
     if ((rc = rows_args("wdf_ss_dyn_rows", params, n_params, chan, r, B, T))) return rc;
     if (!rows) return fail(WDF_EINVAL, "wdf_ss_dyn_rows: null rows");
     const dim3 grid((unsigned)((B + 63) / 64), (unsigned)rows_blocks_t(T));
     const size_t lds = (size_t)n_ops * 64 * sizeof(double);
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute((const void*)wdf::ss_dyn_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
-            return fail(WDF_ELAUNCH, "wdf_ss_dyn_rows: the kernel's LDS limit could not be raised");
-        raised = true;
-    }
+    if ((rc = rows_lds_limit("wdf_ss_dyn_rows", (const void*)wdf::ss_dyn_rows_kernel, lds))) return rc;
     hipLaunchKernelGGL(wdf::ss_dyn_rows_kernel, grid, dim3(64), lds, (hipStream_t)stream, tp, params, r, rows, B, T);
     return check_launch("wdf_ss_dyn_rows");
 }
@@ -278,7 +283,7 @@ int wdf_ss_dyn_rows_bwd(const int32_t* tape_ops, int n_ops, const double* consts
                         const double* params, int n_params, int chan, const float* r, const float* grows, void* ws, double* gparams,
                         int64_t B, int64_t T, void* stream)
 {
-    wdf::RowsTape tp;
+    wdf::RowsTape tp{};
     int rc = rows_pack("wdf_ss_dyn_rows_bwd", tape_ops, n_ops, consts, n_consts, outs, n_out, n_params, chan, tp);
     if (rc) return rc;
     if ((rc = rows_args("wdf_ss_dyn_rows_bwd", params, n_params, chan, r, B, T))) return rc;
@@ -286,12 +291,7 @@ int wdf_ss_dyn_rows_bwd(const int32_t* tape_ops, int n_ops, const double* consts
     if (!grows || !ws || !gparams) return fail(WDF_EINVAL, "wdf_ss_dyn_rows_bwd: null grows / ws / gparams");
     const dim3 grid((unsigned)((B + 63) / 64), (unsigned)rows_blocks_t(T));
     const size_t lds = (size_t)n_ops * 64 * (sizeof(double) + sizeof(float)) + (size_t)n_params * 64 * sizeof(double);
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute((const void*)wdf::ss_dyn_rows_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
-            return fail(WDF_ELAUNCH, "wdf_ss_dyn_rows_bwd: the kernel's LDS limit could not be raised");
-        raised = true;
-    }
+    if ((rc = rows_lds_limit("wdf_ss_dyn_rows_bwd", (const void*)wdf::ss_dyn_rows_bwd_kernel, lds))) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(wdf::ss_dyn_rows_bwd_kernel, grid, dim3(64), lds, s, tp, params, r, grows, (double*)ws, B, T);
     rc = check_launch("wdf_ss_dyn_rows_bwd");

@@ -436,3 +436,46 @@ def test_rows_made_on_the_device_equal_the_tape_in_float64(wdf, tree, B, T):
     if chan >= 0:
         with pytest.raises(wb.WdfHipError, match="come together"):
             wb.ss_dyn_rows(rt, params, chan, None)
+
+
+def test_rows_at_the_largest_tape_the_device_takes(wdf):
+    """192 operations, 15 component values, 32 constants, 48 row entries: the reverse kernel's 155 KB of LDS (asked for per
+    launch) -- against the tape's host evaluation with forward tangents (probe_tape.Tape.evaluate), sample by sample."""
+    from wdf_hip import binding as wb, probe_tape as pt
+    rng = np.random.default_rng(12)
+    P, n_ops, n_out, B, T = 15, 192, 48, 3, 5
+    ops = [[pt.OP_PARAM, p, 0] for p in range(P)] + [[pt.OP_CONST, j, 0] for j in range(32)]
+    while len(ops) < n_ops:
+        i = len(ops)
+        a, b = int(rng.integers(0, i)), int(rng.integers(0, i))
+        ops.append([[pt.OP_ADD, a, b], [pt.OP_SUB, a, b], [pt.OP_MUL, a, b], [pt.OP_NEG, a, 0], [pt.OP_DIV, a, int(rng.integers(0, P))],
+                    [pt.OP_RECIP, int(rng.integers(0, P)), 0]][int(rng.integers(0, 6))])
+    consts = rng.uniform(0.5, 1.5, 32)
+    outs = [int(v) for v in rng.integers(P, n_ops, n_out)]
+    tape = pt.Tape()
+    tape.ops, tape.consts = [tuple(o) for o in ops], list(consts)
+    p64 = rng.uniform(0.7, 1.3, P)
+    chan = 4
+    r = rng.uniform(0.7, 1.3, (T, B)).astype(np.float32)
+    rt = wb.RowsTape(ops, consts, outs)
+    assert rt.fits(P) and not wb.RowsTape(ops + [[pt.OP_NEG, 0, 0]], consts, outs).fits(P)
+    params = torch.as_tensor(p64, device="cuda")
+    rows = wb.ss_dyn_rows(rt, params, chan, cuda(r)).cpu().numpy().astype(np.float64)
+    grows = rng.standard_normal((T, n_out, B)).astype(np.float32)
+    gp = wb.ss_dyn_rows_bwd(rt, params, chan, cuda(r), cuda(grows)).cpu().numpy()
+    ref_rows, ref_gp, mag = np.zeros((T, n_out, B)), np.zeros(P), np.zeros(P)
+    for t in range(T):
+        for b in range(B):
+            pv = p64.copy()
+            pv[chan] = float(r[t, b])
+            val, jac = tape.evaluate(pv, outs)
+            ref_rows[t, :, b] = val
+            ref_gp += grows[t, :, b].astype(np.float64) @ jac
+            mag += np.abs(grows[t, :, b].astype(np.float64)) @ np.abs(jac)
+    ref_gp[chan] = 0.0
+    finite = np.isfinite(ref_rows) & (np.abs(ref_rows) < 1e30)
+    assert finite.mean() > 0.5
+    assert np.max(np.abs(rows[finite] - ref_rows[finite]) / (np.abs(ref_rows[finite]) + 1e-30)) < 3e-7
+    ok = np.isfinite(mag) & (mag < 1e30)
+    assert ok.sum() >= P // 2 and gp[chan] == 0.0
+    assert np.all(np.abs(gp[ok] - ref_gp[ok]) <= 1e-5 * mag[ok] + 1e-30), (gp, ref_gp, mag)
