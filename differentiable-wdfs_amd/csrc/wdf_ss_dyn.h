@@ -3,22 +3,24 @@
 //
 //   * per-sample impedance on ANY tree: in the reference set_resistance replaces R on any ResistiveVoltageSource / Resistor
 //     (tf_wdf.py:51-52,80-81) and calc_impedance may run every step (clipper_pot.py:116-117).  The adaptor coefficients
-//     (tf_wdf.py:139-145,168-177) are then functions of the sample's resistance; the host evaluates the probed step's tape
-//     (lib/wdf_hip/probe_tape.py) over the whole resistance channel -- the idea of wdf_clipper_mlp_step_prepare, for any tree --
-//     and this kernel reads one coefficient ROW per (sample, sequence);
-//   * DenseRootModel terminating any tree (layers.py:72-82): b = -MLP(a, log R_port) (clipper_pot.py:119-121) evaluated per
-//     lane (wdf_mlp.h, weights in LDS); its weight gradient is the dense pass mlp_wgrad_kernel over (a, log R_port, dL/db).
+//     (tf_wdf.py:139-145,168-177) are then functions of the sample's resistance; the probed step's tape
+//     (lib/wdf_hip/probe_tape.py) is run over the whole resistance channel first (wdf_ss_dyn_rows.h; long tapes: torch) -- the
+//     idea of wdf_clipper_mlp_step_prepare, for any tree -- and this kernel reads one coefficient ROW per (sample, sequence);
+//   * DenseRootModel terminating any tree (layers.py:72-82): b = -MLP(a, log R_port) (clipper_pot.py:119-121) evaluated in
+//     16-lane rows, four sequences per wave (wdf_mlp_row.h); its weight gradient is the dense pass mlp_wgrad_list_kernel
+//     (wdf_mlp_step.h, matrix cores) over (a, log R_port, dL/db).
 //
 // One step, as in wdf_statespace.h:   a = ca.z + da.x ;  b = root(a) ;  z' = A z + Bx x + E b ;  y = cy.z + dy.x + fy b.
 // Row layout (ns <= 4 states, ni <= 2 inputs, both run-time):
 //     A[ns][ns] | Bx[ns][ni] | E[ns] | ca[ns] | da[ni] | cy[ns] | dy[ni] | fy | R_port          (kN1 = wdf_ss_ncoef + 1 entries)
 // addressed as  crow[i * cs + t * ts + b * bs]: per-sample rows [T][kN1][B] (cs = B, ts = kN1 B, bs = 1) or ONE static row
 // (cs = 1, ts = bs = 0) through the same code.  x [B][T][ni]; y, dL/dy [T][B]; state stash [T][ns][B]; z0 / zT [ns][B].
-// One lane per sequence, sequential in time: the general path, not a fast one (the clipper topology keeps its own kernels).
+// One lane per sequence (the network root: four sequences per wave), sequential in time or in verified chunks: the general
+// path, not a fast one (the clipper topology keeps its own kernels).
 //
 // Reverse sweep (formulas: wdf_statespace.h ss_bwd_step): emits dL/d(row) for EVERY sample -- grow [T][kN1][B] -- because
-// with per-sample rows the chain rule to the component values runs per sample too (the host contracts it with the tape's
-// Jacobian); diode root: the lane sums of gb D_L, gb D_V (-> dL/dIs, dL/dnVt) and dL/dR_port = gb D_L / R_port in the row;
+// with per-sample rows the chain rule to the component values runs per sample too (wdf_ss_dyn_rows_bwd runs the tape
+// backwards over it); diode root: the lane sums of gb D_L, gb D_V (-> dL/dIs, dL/dnVt) and dL/dR_port = gb D_L / R_port in the row;
 // MLP root: gb = dL/db, a and log R_port per sample for the weight-gradient pass, dL/dR_port = gb (-dMLP/dlr) / R_port.
 #pragma once
 
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
 }
 
 // grow [T][kN1][B]; ws: double[gridDim.y gridDim.x][2] = the (chunk, wave)'s {sum gb D_L, sum gb D_V} (diode root);
-// gbroot / ain / lrin [T][B] (MLP root): dL/db, a, log R_port of every step for mlp_wgrad_kernel.
+// gbroot / ain / lrin [T][B] (MLP root): dL/db, a, log R_port of every step for mlp_wgrad_list_kernel.
 //
 // Time chunks (round 5, wdf_ss_dyn_bwd_tp) -- EXACT: the adjoint recurrence is linear in the adjoint entering a chunk from the
 // future, so the sweep runs in three launches over grid (waves, K):
