@@ -71,7 +71,8 @@ def rel(a, b):
     return float(np.max(np.abs(a - b) / np.abs(b)))
 
 
-@pytest.mark.parametrize("pot_on,B,T", [("Vs", 37, 300), ("R", 70, 257), ("Vs", 130, 1024)])
+# (the last three: one sequence of one sample; fewer samples than a row block or a chunk unit; a second wave of one sequence)
+@pytest.mark.parametrize("pot_on,B,T", [("Vs", 37, 300), ("R", 70, 257), ("Vs", 130, 1024), ("Vs", 1, 1), ("R", 3, 7), ("Vs", 65, 9)])
 def test_hpf_clipper_with_a_pot_channel_diode_root(wdf, oracle, pot_on, B, T):
     tf = wdf.tf
     O = oracle
