@@ -783,6 +783,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     if (threadIdx.x == 0 && g_dbg_times) {
         unsigned long long* dbg_o = g_dbg_times + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
         dbg_o[0] = dbg_t0; dbg_o[1] = wall_clock64(); dbg_o[3] = __builtin_amdgcn_s_memtime() - dbg_m0;
+#ifdef WDF_DBG_HWID                                          // where the wave ran instead of its back-edge wait: HW_ID | XCC_ID << 32
+        dbg_o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                   ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+#endif
     }
 #endif
     WDF_DBG_STAMP(0);

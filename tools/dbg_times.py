@@ -42,6 +42,34 @@ print("phases (us at 2.1 GHz), median / p90: set-up + first loads issued %.1f / 
     v for i in range(4) for v in (np.median(ph[:, i]), np.percentile(ph[:, i], 90))))
 wt = a[:, 2].astype(np.float64)
 print(f"shader cycles parked in the back-edge s_waitcnt per wave: median {np.median(wt):.0f} of {np.median(mt):.0f} ({100*np.median(wt/mt):.1f} %)")
+if os.environ.get("DBG_HWID"):      # a -DWDF_DBG_HWID build: slot 2 is HW_ID | XCC_ID << 32 (wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13])
+    import collections
+    hw = a[:, 2]
+    simd, cu, sh, se, xcc = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7, (hw >> 32) & 0xf
+    cnt = collections.Counter(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist(), simd.tolist()))
+    ccu = collections.Counter(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
+    print("SIMDs used:", len(cnt), "waves per SIMD:", sorted(collections.Counter(cnt.values()).items()), "; CUs used:", len(ccu),
+          "waves per CU:", sorted(collections.Counter(ccu.values()).items()))
+    per = np.array([cnt[t] for t in zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist(), simd.tolist())])
+    for n_on in sorted(set(per.tolist())):
+        m = per == n_on
+        print(f"  waves on a SIMD with {n_on}: {m.sum()}, lifetime median {np.median(life[m]):.1f} us, end median {np.median(t1[m]-base)*tick:.1f} us")
+    print("  lifetime median by XCC:", " ".join(f"{xx}:{np.median(life[xcc == xx]):.1f}" for xx in sorted(set(xcc.tolist()))))
+    print("  lifetime median by SE:", " ".join(f"{xx}:{np.median(life[se == xx]):.1f}" for xx in sorted(set(se.tolist()))))
+    kk_ = np.arange(nw) // (nw // K)
+    print("  lifetime median by chunk:", " ".join(f"{q}:{np.median(life[kk_ == q]):.0f}" for q in range(K)))
+    tile_ = np.arange(nw) % (nw // K)
+    print("  lifetime median by tile (every 4th):", " ".join(f"{q}:{np.median(life[tile_ == q]):.0f}" for q in range(0, nw // K, 4)))
+    # does a SIMD's pair finish together?  spread inside a SIMD vs across SIMDs
+    key = xcc * 100000 + se * 10000 + sh * 5000 + cu * 10 + simd
+    order = np.argsort(key, kind="stable")
+    ks, ls = key[order], life[order]
+    same = ks[1:] == ks[:-1]
+    print(f"  |lifetime difference| of the two waves of a SIMD: median {np.median(np.abs(ls[1:] - ls[:-1])[same]):.1f} us; SIMD mean lifetime: min {min(np.mean(life[key == q]) for q in set(key.tolist())):.1f} max {max(np.mean(life[key == q]) for q in set(key.tolist())):.1f}")
+    cukey = key // 10
+    cm = np.array([np.mean(life[cukey == q]) for q in sorted(set(cukey.tolist()))])
+    print(f"  CU mean lifetime: min {cm.min():.1f} p10 {np.percentile(cm,10):.1f} median {np.median(cm):.1f} p90 {np.percentile(cm,90):.1f} max {cm.max():.1f}")
+    sys.exit(0)
 k = np.arange(nw) // (nw // K)
 print("chunk: end median us:", " ".join(f"{kk}:{np.median(t1[k == kk]-base)*tick:.0f}" for kk in range(K)))
 if tail[:, 7].max() > 0:      # stamps along the tile's tail (the build has them): the tile that finished the step = latest stamp 7
