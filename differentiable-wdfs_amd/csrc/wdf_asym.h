@@ -57,6 +57,25 @@ __device__ __forceinline__ float asym_omega_root(const AsymConsts& c, float a)
     return a - 2.0f * lam * (Vf * wf - Vr * wr);
 }
 
+// Two Newton iterations of the exact Shockley pair in fp32 (v_exp_f32: a tenth of an fp64 iteration's cost) between the closed
+// form's start value (8 mV off for a germanium-like pair: it drops the reverse diode's saturation current) and the fp64
+// iterations: those then start ~1e-7 from the root and one or two of them meet any tolerance down to 1e-12 instead of three or
+// four.  Same damping as below.  iters counts these two as well.
+__device__ __forceinline__ float asym_newton_f32(const AsymConsts& c, float a, float v, int& iters)
+{
+    const float iV1 = fast_rcp(c.V1), iV2 = fast_rcp(c.V2), lim = 4.0f * fminf(c.V1, c.V2);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const float e1 = fast_exp(v * iV1), e2 = fast_exp(-v * iV2);
+        const float f = v + c.Rp * (c.Is1 * (e1 - 1.0f) - c.Is2 * (e2 - 1.0f)) - a;
+        const float fp = fmaf(c.Rp, fmaf(c.Is1 * iV1, e1, c.Is2 * iV2 * e2), 1.0f);
+        const float dv = fminf(fmaxf(f * fast_rcp(fp), -lim), lim);
+        v -= dv;
+    }
+    iters += 2;
+    return v;
+}
+
 // returns b; *iters += Newton iterations this wave ran
 __device__ __forceinline__ double asym_newton_root(const AsymConsts& c, double a, double v0, double tol, int max_iter,
                                                    int& iters)
@@ -93,8 +112,8 @@ struct AsymStep<true> {
         const double b_diff = z - (double)xin;
         const double b_temp = -(double)c.p * b_diff;
         const double a = z + b_temp;
-        const float bw = asym_omega_root(c, (float)a);                   // start value: v0 = (a + b)/2
-        const double br = asym_newton_root(c, a, 0.5 * (a + (double)bw), tol, max_iter, iters);
+        const float bw = asym_omega_root(c, (float)a);                   // start value: v0 = (a + b)/2 of the closed form
+        const double br = asym_newton_root(c, a, (double)asym_newton_f32(c, (float)a, 0.5f * ((float)a + bw), iters), tol, max_iter, iters);
         const double zn = br + b_temp;
         const float y = (float)(0.5 * (zn + z));
         z = zn;
@@ -373,8 +392,7 @@ __global__ __launch_bounds__(64) void clipper_asym_bwd_tp_kernel(const float* __
     const int64_t k = blockIdx.y;
     const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
     const AsymConsts c = asym_load(theta6, fs);
-    const double Rp = c.Rp, p = c.p, Is1 = c.Is1, Is2 = c.Is2, V1 = c.V1, V2 = c.V2;
-    const double iV1 = 1.0 / V1, iV2 = 1.0 / V2;
+    const double p = c.p;
     double m = 1.0, g0 = 0.0;
     double al[6] = {0, 0, 0, 0, 0, 0}, be[6] = {0, 0, 0, 0, 0, 0};
     const float* __restrict__ xp = x + b * T;
@@ -401,26 +419,28 @@ __global__ __launch_bounds__(64) void clipper_asym_bwd_tp_kernel(const float* __
         for (int i = kB - 1; i >= 0; --i) {
             const int64_t t = tb + i;
             if (t < t1) {                                         // wave-uniform
+                // The step's local partials in fp32: their inputs are fp32 already (the stash, x), 1e-6 relative is two orders
+                // inside the gradient's tolerance, and fp64 exp / divide were most of this kernel (0.58 ms at 8192 x 4096).
+                // The sums and the adjoint recurrence stay in fp64 below.
                 const float zf = zstash[t * B + b];
-                const double z = (double)zf, xin = (double)xc[i], g = (double)gy[t * B + b];
-                const double b_diff = z - xin;
-                double Da, cth[5];
+                const double g = (double)gy[t * B + b];
+                const float bd = zf - xc[i];
+                const float a = zf - c.p * bd;                    // the forward's own fp32 root input
+                float Daf, cf[5];
                 if constexpr (NEWTON) {
-                    const double a = z - p * b_diff;
-                    const double br = (double)znext + p * b_diff;
-                    const double v = 0.5 * (a + br);
-                    const double e1 = exp(v * iV1), e2 = exp(-v * iV2);
-                    const double iF = 1.0 / (1.0 + Rp * (Is1 * iV1 * e1 + Is2 * iV2 * e2));
-                    Da = 2.0 * iF - 1.0;
-                    const double k2 = -2.0 * iF;
-                    cth[0] = k2 * Rp * (e1 - 1.0);
-                    cth[1] = k2 * (-Rp * Is1 * e1 * v * iV1 * iV1);
-                    cth[2] = k2 * (-Rp * (e2 - 1.0));
-                    cth[3] = k2 * (-Rp * Is2 * e2 * v * iV2 * iV2);
-                    cth[4] = k2 * (Is1 * (e1 - 1.0) - Is2 * (e2 - 1.0));
+                    const float br = fmaf(c.p, bd, znext);        // b = z[t+1] + p (z[t] - x[t]): no re-solve
+                    const float v = 0.5f * (a + br);
+                    const float iV1 = fast_rcp(c.V1), iV2 = fast_rcp(c.V2);
+                    const float e1 = fast_exp(v * iV1), e2 = fast_exp(-v * iV2);
+                    const float iF = fast_rcp(fmaf(c.Rp, fmaf(c.Is1 * iV1, e1, c.Is2 * iV2 * e2), 1.0f));
+                    Daf = fmaf(2.0f, iF, -1.0f);
+                    const float k2 = -2.0f * iF, k2R = k2 * c.Rp;
+                    cf[0] = k2R * (e1 - 1.0f);
+                    cf[1] = -k2R * c.Is1 * e1 * v * iV1 * iV1;
+                    cf[2] = -k2R * (e2 - 1.0f);
+                    cf[3] = -k2R * c.Is2 * e2 * v * iV2 * iV2;
+                    cf[4] = k2 * fmaf(c.Is1, e1 - 1.0f, -c.Is2 * (e2 - 1.0f));
                 } else {
-                    const float bd = zf - xc[i];
-                    const float a = zf - c.p * bd;                // the forward's own fp32 root input
                     const float lam = vsign(a), aa = fabsf(a);
                     const bool pos = a >= 0.0f;
                     const float Vf = pos ? c.V1 : c.V2, Vr = pos ? c.V2 : c.V1;
@@ -428,18 +448,21 @@ __global__ __launch_bounds__(64) void clipper_asym_bwd_tp_kernel(const float* __
                     const float Isf = pos ? c.Is1 : c.Is2, Isr = pos ? c.Is2 : c.Is1;
                     const float af = aa * fast_rcp(Vf), ar = aa * fast_rcp(Vr);
                     const float wf = wright_omega(af + lf), wr = wright_omega(lr - ar);
-                    const double wfd = wf, wrd = wr;
-                    const double dwf = wfd / (1.0 + wfd), dwr = wrd / (1.0 + wrd);
-                    const double l2 = 2.0 * (double)lam;
-                    Da = 1.0 - 2.0 * (dwf + dwr);
-                    const double dVf = -l2 * (wfd - dwf * (1.0 + (double)af)), dVr = l2 * (wrd - dwr * (1.0 - (double)ar));
-                    const double dIsf = -l2 * (double)Vf * dwf / (double)Isf, dIsr = l2 * (double)Vr * dwr / (double)Isr;
-                    cth[0] = pos ? dIsf : dIsr;
-                    cth[1] = pos ? dVf : dVr;
-                    cth[2] = pos ? dIsr : dIsf;
-                    cth[3] = pos ? dVr : dVf;
-                    cth[4] = -l2 * ((double)Vf * dwf - (double)Vr * dwr) / Rp;
+                    const float dwf = wf * fast_rcp(1.0f + wf), dwr = wr * fast_rcp(1.0f + wr);
+                    const float l2 = 2.0f * lam;
+                    Daf = fmaf(-2.0f, dwf + dwr, 1.0f);
+                    const float dVf = -l2 * fmaf(-dwf, 1.0f + af, wf), dVr = l2 * fmaf(-dwr, 1.0f - ar, wr);
+                    const float dIsf = -l2 * Vf * dwf * fast_rcp(Isf), dIsr = l2 * Vr * dwr * fast_rcp(Isr);
+                    cf[0] = pos ? dIsf : dIsr;
+                    cf[1] = pos ? dVf : dVr;
+                    cf[2] = pos ? dIsr : dIsf;
+                    cf[3] = pos ? dVr : dVf;
+                    cf[4] = -l2 * fmaf(Vf, dwf, -Vr * dwr) * fast_rcp(c.Rp);
                 }
+                const double Da = (double)Daf, b_diff = (double)bd;
+                double cth[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) cth[q] = (double)cf[q];
                 const double h = g0 + 0.5 * g;                    // u = gz + g/2 = m Lam + h
 #pragma unroll
                 for (int q = 0; q < 5; ++q) { al[q] = fma(cth[q], m, al[q]); be[q] = fma(cth[q], h, be[q]); }

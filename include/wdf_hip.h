@@ -535,7 +535,8 @@ int wdf_ss_dyn_rows_bwd(const int32_t* tape_ops, int n_ops, const double* consts
  * theta6  device float[6] = {Is_up, nVt_up, Is_down, nVt_down, R, C}
  * mode    WDF_ASYM_OMEGA_F32: fp32 Wright-omega closed form (two-diode form of eqn 39);
  *         WDF_ASYM_NEWTON_F64: fp64 Newton on the exact Shockley pair, iterated per wave until
- *         every lane meets |dv| <= tol (|v| + nVt) (wavefront ballot) or max_iter.
+ *         every lane meets |dv| <= tol (|v| + nVt) (wavefront ballot) or max_iter; two iterations
+ *         in fp32 from the closed form's value come first (counted in iters).
  * iters   optional device int64[(B+63)/64]: Newton iterations each wave ran (sum / (B T / 64
  *         * ...) gives the mean per sample).
  * zstash  optional [T][B]: state before each step, for wdf_clipper_asym_bwd.
