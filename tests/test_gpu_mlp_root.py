@@ -163,13 +163,13 @@ def test_segmented_time_parallel_matches_sequential(golden):
 
 @pytest.mark.parametrize("hidden,n_tanh", [(4, 3), (8, 3), (16, 3), (8, 4), (4, 5), (8, 5)])
 @pytest.mark.parametrize("dyn", [False, True])
-def test_wgrad_kernel_matches_dense_autograd(hidden, n_tanh, dyn):
+@pytest.mark.parametrize("S", [64 * 700 + 37, 1, 17, 16 * 8 * 4 * 3 + 1])   # ragged: the tail lanes must contribute nothing; one sample;
+def test_wgrad_kernel_matches_dense_autograd(hidden, n_tanh, dyn, S):       # one partial block; one sample past a workgroup's share
     """wdf_clipper_mlp_wgrad == -sum_n gb[n] dMLP(a[n], lr[n])/dw by float64 torch autograd of the
-    same network (tolerance 2e-5 of the largest entry: fp32 per-lane accumulation, double reduction)."""
+    same network (tolerance 2e-5 of the largest entry: fp32 accumulation on the matrix cores, double reduction)."""
     import torch
     from wdf_hip import binding as wb
     rng = np.random.default_rng(hidden * 10 + n_tanh)
-    S = 64 * 700 + 37                                  # ragged: the tail lanes must contribute nothing
     nw = wb.lib().wdf_mlp_weight_count(hidden, n_tanh)
     w = cuda(rng.standard_normal(nw) * 0.4)
     a = cuda(rng.standard_normal(S) * 2.0)
