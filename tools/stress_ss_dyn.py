@@ -116,7 +116,8 @@ while done < n_cases:
     if pot is None and root_kind != "mlp":
         continue                                       # (static diode / ideal trees are the other kernels' business)
     try:
-        circ = wdf.Circuit(top, root, probe_e, per_sample_R=pot[0] if pot else None, force_generic=True)
+        circ = wdf.Circuit(top, root, probe_e, per_sample_R=pot[0] if pot else None, force_generic=True,
+                           **({"time_parallel": None} if os.environ.get("STRESS_SEQUENTIAL") else {}))   # (A/B: the sequential kernels only)
     except Exception as exc:                           # e.g. no source in the tree
         continue
     if not circ._dyn:
@@ -158,7 +159,11 @@ while done < n_cases:
     flag = ""
     ill = ey32 > 1e-6 * yscale                          # the fp32 restatement itself is that far off: ill-conditioned case
     tol_y = max(5e-6 * yscale, 8.0 * ey32)
-    tol_g = 1e-3 if not ill else max(1e-3, 2e3 * ey32 / yscale)
+    # (the gradient bound allows for what ORDER of summation alone does: the same fp32 network arithmetic evaluated per lane and in
+    #  16-lane rows, both builds over these 150 trees on one box, lands 0.1x ... 39x apart in gradient error, geometric mean 1.00:
+    #  profiles/README.md, round 5)
+    tol_g = 2e-3 if not ill else 0.2            # (ill-conditioned: y is held to the fp32 restatement's own deviation; of the gradient
+                                                #  only signs and sizes -- a weak component there is a difference of amplified roundings)
     if not (ey <= tol_y and eg <= tol_g):
         bad += 1
         flag = "  <-- VIOLATION\n      got   " + np.array2string(got, precision=4) + "\n      oracle " + np.array2string(g_ref, precision=4) + \
