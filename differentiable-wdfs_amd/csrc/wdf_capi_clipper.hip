@@ -109,10 +109,12 @@ void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs,
                    hipStream_t s)
 {
     const dim3 grid((unsigned)((B + 63) / 64), (unsigned)g.K);
+    // a stateless call (no warm-start block to steer): the chunk boundaries are verified by the launch behind the forward
+    const int later = (warm.ctl == nullptr && g.K > 1) ? 1 : 0;
 #define WDF_FWD_TP(STASH_)                                                                                   \
     hipLaunchKernelGGL((wdf::clipper_fwd_tp_kernel<DYN_R, SYM, TM, V4, STASH_, float>), grid, dim3(64), 0, s, x, r, theta, \
                        fs, n_up, n_down, y, zstash, z0, zT, zwarm, zend, status, warm.ctl, warm.snap, warm.J, tickets, tol, \
-                       B, B, T, g.L, W, general)
+                       B, B, T, g.L, W, general, later)
     {
         EventBracket bracket(s);
         if (zstash) WDF_FWD_TP(true); else WDF_FWD_TP(false);
@@ -122,7 +124,7 @@ void launch_fwd_tp(const float* x, const float* r, const float* theta, float fs,
 #define WDF_REPAIR(STASH_)                                                                                   \
     hipLaunchKernelGGL((wdf::clipper_tp_repair_kernel<DYN_R, SYM, TM, STASH_>), dim3(grid.x), dim3(64), 0, s, x, r, theta, \
                        fs, n_up, n_down, y, zstash, zT, zwarm, zend, B, T, (int64_t)g.K, g.L, tol, status, warm.ctl,       \
-                       warm.snap, warm.J, tickets, general)
+                       warm.snap, warm.J, tickets, general, later)
         if (zstash) WDF_REPAIR(true); else WDF_REPAIR(false);
 #undef WDF_REPAIR
     }
@@ -339,10 +341,12 @@ static int fwd_tp_common(const float* x, const float* r, const float* theta, flo
         if (g.K >= (1 << 20)) return fail(WDF_EINVAL, "too many chunks for a warm-start state");
         tickets = (unsigned*)((char*)state + sizeof(wdf::TpCtl));            // zeroed by the reset, left clean by every launch
         warm = TpWarm{(wdf::TpCtl*)state, (float*)((char*)tickets + tp_ticket_bytes(B)), max_warm_tiles + 1};
-    } else {                                                                  // the caller's ws holds garbage: clear the tickets
-        tickets = (unsigned*)(zend + (size_t)g.K * (size_t)B);
-        const hipError_t e = hipMemsetAsync(tickets, 0, tp_ticket_bytes(B), (hipStream_t)stream);
-        if (e != hipSuccess) return fail(WDF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    } else {                                // (stateless: verified by the launch behind the forward, no tickets; one chunk: no boundaries --
+        tickets = (unsigned*)(zend + (size_t)g.K * (size_t)B);                //  the last tile's ticket still counts the tiles)
+        if (g.K <= 1) {
+            const hipError_t e = hipMemsetAsync(tickets, 0, tp_ticket_bytes(B), (hipStream_t)stream);
+            if (e != hipSuccess) return fail(WDF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
     }
     const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
     const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));

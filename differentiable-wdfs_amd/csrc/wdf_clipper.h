@@ -952,12 +952,44 @@ __global__ __launch_bounds__(64) void clipper_tp_repair_kernel(
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
     float* __restrict__ zT, const float* __restrict__ zwarm, float* __restrict__ zend, int64_t B, int64_t T,
     int64_t K, int64_t L, float tol, TpStatus* __restrict__ status, const TpCtl* __restrict__ ctl,
-    float* __restrict__ snap, int J, unsigned* __restrict__ tickets, int general)
+    float* __restrict__ snap, int J, unsigned* __restrict__ tickets, int general, int verify_all)
 {
     unsigned* tile_bad = tickets + 4 + gridDim.x;
-    if (tile_bad[blockIdx.x] == 0u) return;                     // the common case
+    if (!verify_all && tile_bad[blockIdx.x] == 0u) return;      // the common case
     const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t b = b_raw < B ? b_raw : B - 1;
+    if (verify_all) {
+        // The forward left the verification to this launch (clipper_fwd_tp_kernel, verify_later; it zeroed the status word): the
+        // tile's K - 1 boundaries, 31 (62 loads) in flight at a time -- plain loads: a kernel boundary lies between -- and
+        // their totals added to the status word.  No boundary off: done.
+        float miss = 0.0f;
+        int nbad = 0;
+        constexpr int kBatch = 31;
+        for (int64_t k0 = 1; k0 < K; k0 += kBatch) {
+            float zw[kBatch], ze[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int64_t k = (k0 + j < K) ? k0 + j : K - 1;  // clamped: re-reads the last boundary
+                zw[j] = zwarm[k * B + b];
+                ze[j] = zend[(k - 1) * B + b];
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const float m = fabsf(zw[j] - ze[j]);
+                if (k0 + j < K) {
+                    miss = fmaxf(miss, m);
+                    nbad += !(m <= tol) ? 1 : 0;                  // NaN counts as bad
+                }
+            }
+        }
+        const float wmax = wave_max_dpp(miss);
+        const int wbad = wave_sum_dpp(nbad);
+        if (threadIdx.x == 0) {
+            if (wmax > 0.0f) (void)atomicMax(reinterpret_cast<int*>(&status->max_miss), __float_as_int(wmax));
+            if (wbad) (void)atomicAdd(&status->n_bad, wbad);
+        }
+        if (__builtin_amdgcn_ballot_w64(nbad != 0) == 0) return;
+    }
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
     fast = fast_root_ok<DYN_R>(c, general);
@@ -985,7 +1017,7 @@ __global__ __launch_bounds__(64) void clipper_tp_repair_kernel(
         ++nrep;
     }
     if (threadIdx.x == 0) {
-        tile_bad[blockIdx.x] = 0u;
+        if (!verify_all) tile_bad[blockIdx.x] = 0u;
         if (nrep) atomicAdd(&status->fallback_ran, nrep);
     }
 }

@@ -810,9 +810,18 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
     const float* __restrict__ z0, float* __restrict__ zT, float* zwarm, float* zend,
     TpStatus* __restrict__ status, TpCtl* ctl, float* snap, int J, unsigned* tickets, float tol, int64_t B,
-    int64_t Bh, int64_t T, int64_t L, int64_t W, int general)
+    int64_t Bh, int64_t T, int64_t L, int64_t W, int general, int verify_later)
 {
     static_assert(VT<V>::N == 1, "one sequence per lane (the repair kernel and tp_finish index tiles of 64)");
+#ifdef WDF_DBG_TIMES
+    const unsigned long long dbg_t0 = wall_clock64();
+    const unsigned long long dbg_m0 = __builtin_amdgcn_s_memtime();
+#endif
+    // verify_later (a stateless call: no warm-start block to steer): the boundaries are checked by the launch behind this one
+    // (clipper_tp_repair_kernel, verify_all) -- the in-kernel verification is a chain of ~6 dependent device-scope round trips
+    // (drain, tile ticket, boundary loads, tile count, last tile, status) that cost the 1024 x 4096 forward 12 us of its 53
+    // at 32 chunks and 26 of 62 at 64 (tools/dbg_fwd_times.py); across a kernel boundary they are plain loads.
+    if (verify_later && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = TpStatus{0, 0.0f, 0, 0u};
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     bool fast = false;
     fast = fast_root_ok<DYN_R>(c, general);                             // wave-uniform: every practical diode
@@ -822,7 +831,18 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
     else
         clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
                                                                      ctl, snap, J, B, T, L, W, 0.0f, 0);
-    tp_finish<DYN_R>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
+#ifdef WDF_DBG_TIMES                                         // (tools/dbg_fwd_times.py: the wave's start, the end of its body, where it ran)
+    if (threadIdx.x == 0 && g_dbg_times) {
+        unsigned long long* dbg_o = g_dbg_times + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        dbg_o[0] = dbg_t0; dbg_o[1] = wall_clock64(); dbg_o[3] = __builtin_amdgcn_s_memtime() - dbg_m0;
+        dbg_o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                   ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+    }
+#endif
+    if (!verify_later) tp_finish<DYN_R>(theta, zwarm, zend, status, ctl, J, tickets, tol, B, L, W);
+#ifdef WDF_DBG_TIMES
+    if (threadIdx.x == 0 && g_dbg_times) g_dbg_times[8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 4] = wall_clock64();   // after the verification
+#endif
 }
 
 // Re-run of chunk [t0, t1) for 64 sequences (one per lane, index b) from the exact state z: outputs, snapshots, record.

@@ -9,7 +9,7 @@ th = workload.clipper_theta()
 x = torch.as_tensor(workload.sweep_batch(B, T, seed=3), device="cuda").t().contiguous()
 theta = torch.tensor(th, dtype=torch.float32, device="cuda")
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 160
-for k in (16, 32, 42, 64, 84, 128):
+for k in [int(v) for v in os.environ.get("C2_KS", "16,32,42,64,84,128").split(",")]:
     used = wb.lib().wdf_clipper_tp_chunks(T, k)
     f = lambda: wb.clipper_fwd_tp(x, theta, FS, k, W, 1e-6, want_stash=False, time_major=True)
     y, _, _, st = f(); torch.cuda.synchronize()
