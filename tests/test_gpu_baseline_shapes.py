@@ -2,7 +2,7 @@
 
 * configs[1] (C2): 1N4148 diode clipper forward only, 1024 sequences x 4096 samples, stateless calls -- every output
   sample against the fp64 oracle, for the chunk counts the bench line's sweep tries (among them counts that do not divide
-  T: ragged last chunk, 8 waves per chunk);
+  T: ragged last chunk, 16 waves per chunk; stateless: the boundaries are verified by the launch behind the forward);
 * configs[3] (C4) on one GPU: the dataset-shaped batch (1340 sequences of 2048 samples, pot value per sample in the
   loader's layout) tiled to 8192 sequences, MSE + ESR past 50 samples, ten Adam steps of the one-pass step with
   warm-started chunks -- y, the three loss values and the gradient of the LAST step against the oracle at that step's
