@@ -83,30 +83,34 @@ __device__ __forceinline__ double asym_newton_root(const AsymConsts& c, double a
     const double Rp = c.Rp, Is1 = c.Is1, Is2 = c.Is2, iV1 = 1.0 / (double)c.V1, iV2 = 1.0 / (double)c.V2;
     const double vscale = fmin((double)c.V1, (double)c.V2);
     double v = v0;
-    double e1 = 0.0, e2 = 0.0, dv = 1.0;                          // the last iteration's exponentials (at v + dv) and its step
+    // The exponentials at v follow the iterate: two fp64 exp at the start value, and after a step dv the factor exp(-dv / V) --
+    // a 6th-order Taylor polynomial, exact to 2e-25 relative while |dv| / V < 1e-3, which is every step once the fp32
+    // iterations ahead of this loop have run (asym_newton_f32: the first fp64 step is ~1e-7) -- instead of two more exp per
+    // iteration and two for the current at the end (they were what an iteration costs).  A wave with a lane outside that
+    // bound (a cold start value, the damping at work) takes the library exp again.
+    auto step_exps = [&](double& e1, double& e2, double dv) {
+        const double d1 = -dv * iV1, d2 = dv * iV2;
+        if (__builtin_amdgcn_ballot_w64(!(fmax(fabs(d1), fabs(d2)) < 1.0e-3)) != 0) {
+            e1 = exp(v * iV1); e2 = exp(-v * iV2);
+        } else {
+            const double c6 = 1.0 / 720.0, c5 = 1.0 / 120.0, c4 = 1.0 / 24.0, c3 = 1.0 / 6.0;
+            e1 *= fma(d1, fma(d1, fma(d1, fma(d1, fma(d1, fma(d1, c6, c5), c4), c3), 0.5), 1.0), 1.0);
+            e2 *= fma(d2, fma(d2, fma(d2, fma(d2, fma(d2, fma(d2, c6, c5), c4), c3), 0.5), 1.0), 1.0);
+        }
+    };
+    double e1 = exp(v * iV1), e2 = exp(-v * iV2);
     for (int it = 0; it < max_iter; ++it) {
-        e1 = exp(v * iV1); e2 = exp(-v * iV2);
         const double f = v + Rp * (Is1 * (e1 - 1.0) - Is2 * (e2 - 1.0)) - a;
         const double fp = 1.0 + Rp * (Is1 * iV1 * e1 + Is2 * iV2 * e2);
-        dv = f / fp;
+        double dv = f / fp;
         // damping: never move more than a few thermal voltages (exp overshoot guard)
         const double lim = 4.0 * vscale;
         dv = fmin(fmax(dv, -lim), lim);
         v -= dv;
+        step_exps(e1, e2, dv);                                    // ... now at the new v: the next iteration's, or the current's below
         ++iters;
         const bool active = fabs(dv) > tol * (fabs(v) + vscale);
         if (__builtin_amdgcn_ballot_w64(active) == 0) break;     // the whole wave has converged
-    }
-    // The current at the final v.  The loop's last exponentials sit one (tiny) step away: exp((v + dv)/V) exp(-dv/V) with
-    // the second factor a 4th-order Taylor polynomial -- exact to 4e-14 relative while |dv|/V < 1e-3 -- instead of two more
-    // fp64 exp (a third of what a converged step costs).  A wave with a lane outside that takes them (no iteration run,
-    // max_iter cut the loop short).
-    const double d1 = -dv * iV1, d2 = dv * iV2;
-    if (__builtin_amdgcn_ballot_w64(!(fmax(fabs(d1), fabs(d2)) < 1.0e-3)) != 0) {
-        e1 = exp(v * iV1); e2 = exp(-v * iV2);
-    } else {
-        e1 *= fma(d1, fma(d1, fma(d1, fma(d1, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
-        e2 *= fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
     }
     const double i = Is1 * (e1 - 1.0) - Is2 * (e2 - 1.0);
     return v - Rp * i;
