@@ -118,45 +118,100 @@ def _oracle():
     return O
 
 
-def cpu_baseline(T, fs, budget_s=12.0):
-    """The oracle's fused fwd + MSE + bwd step ("port": C restatement of the reference
-    algorithm, OpenMP over sequences) timed on the host cores on a bounded sample of the
-    same workload.  Checker code used as a reported baseline only.  The thread count is
-    calibrated (the box may expose more logical CPUs than its cgroup lets run): the best
-    throughput found and the threads that gave it are what is reported."""
+def cgroup_cpu_quota():
+    """(text of the cgroup's CPU limit, cores it allows or None): cgroup v2 `cpu.max` ("max 100000" / "<quota> <period>"),
+    else v1 `cpu.cfs_quota_us` / `cpu.cfs_period_us`.  What a box exposes (`sched_getaffinity`) and what its cgroup lets
+    run are two numbers; the line prints both."""
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().strip()
+        q, per = txt.split()
+        return txt, (None if q == "max" else float(q) / float(per))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return f"{q} {per} (cgroup v1)", (None if q <= 0 else q / per)
+    except (OSError, ValueError):
+        return None, None
+
+
+def cpu_baseline(T, fs, hold_s=4.0, warm_floor_s=2.0):
+    """The oracle's fused fwd + MSE + bwd step ("port": C restatement of the reference algorithm, OpenMP over sequences)
+    timed on the host cores on a bounded sample of the same workload.  Checker code used as a reported baseline only.
+
+    The thread count is CALIBRATED, and every candidate is measured warm: the first passes at a new thread count pay for the
+    OpenMP pool's threads and for the page faults of the per-thread tapes and the output array (measured in the build
+    container, 8 threads: 5.6, 6.6, 5.5, 4.7, 5.5, 17, 48, 54, 54 M samples/s pass after pass), so a candidate's passes are
+    discarded for at least 2 s and until two in a row agree within 10 %, and its figure is the best of three timed runs of >= 0.25 s each, with
+    >= 32 sequences per thread.  Reported: the best figure (`value`, `cores`), the figure with every allowed core running
+    (`all_cores`), one core (`value_one_core`), the cgroup's quota next to the affinity count, and the whole table."""
     O = _oracle()
     avail = len(os.sched_getaffinity(0))
-    Bs = max(256, 8 * avail)
-    x = workload.sweep_batch(8192, T, b0=0, b1=Bs)
+    quota_txt, quota_cores = cgroup_cpu_quota()
     th = workload.clipper_theta()
-    tgt = O.clipper_fwd(workload.target_theta(), fs, x, dtype=np.float32, n_threads=avail)
-    cands = sorted({max(1, avail >> k) for k in range(0, 9)}, reverse=True)
-    best, best_rate = avail, 0.0
-    for nt in cands:                                   # short calibration passes
+    cands = {max(1, avail >> k) for k in range(0, 9)}
+    if quota_cores is not None:
+        cands.add(max(1, min(avail, int(round(quota_cores)))))
+    cands = sorted(cands, reverse=True)
+    # a cold plateau lasts over a second (the container: five 0.2 s passes at a tenth of the warm rate, then a jump), and looks
+    # steady while it lasts: every multi-thread candidate is warmed for at least this long
+    # (`warm_floor_s`, default 2 s; the CPU suite passes a shorter one)
+    data = {}
+
+    def batch(nt):
+        Bs = min(8192, max(64, 32 * nt))
+        if Bs not in data:
+            x = workload.sweep_batch(8192, T, b0=0, b1=Bs)
+            data[Bs] = (x, O.clipper_fwd(workload.target_theta(), fs, x, dtype=np.float32, n_threads=avail))
+        return (Bs,) + data[Bs]
+
+    def timed(nt, Bs, x, tgt, min_s):
         t0 = time.perf_counter()
-        O.clipper_mse_step(th, fs, x, tgt, n_threads=nt)
-        rate = Bs * T / (time.perf_counter() - t0)
-        if rate > best_rate:
-            best, best_rate = nt, rate
+        n = 0
+        while True:
+            O.clipper_mse_step(th, fs, x, tgt, n_threads=nt)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_s:
+                return Bs * T * n / dt
+
+    table = []
+    for nt in cands:
+        Bs, x, tgt = batch(nt)
+        t_c = time.perf_counter()
+        prev, n_warm = None, 0
+        warm_s = 0.5 if nt == 1 else warm_floor_s
+        while True:                                                           # warm: discarded passes
+            r = timed(nt, Bs, x, tgt, 0.0)
+            n_warm += 1
+            el = time.perf_counter() - t_c
+            if (el >= warm_s and prev is not None and abs(r - prev) <= 0.1 * max(r, prev)) or el >= 2.5 * warm_s:
+                break
+            prev = r
+        runs = [timed(nt, Bs, x, tgt, 0.25) for _ in range(3)]
+        table.append({"threads": nt, "sequences": Bs, "warm_passes_discarded": n_warm,
+                      "best": max(runs), "median": sorted(runs)[1]})
+    best = max(table, key=lambda e: e["best"])
+    allc = next(e for e in table if e["threads"] == avail)
+    one = next(e for e in table if e["threads"] == 1)
+    # the reported figure: the best thread count held for the rest of the budget (warm already)
+    Bs, x, tgt = batch(best["threads"])
     t0 = time.perf_counter()
-    n = 0
-    while True:
-        O.clipper_mse_step(th, fs, x, tgt, n_threads=best)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 400:
-            break
-    t1 = time.perf_counter()                            # and the same step on ONE core (SURVEY 8d)
-    n1 = 0
-    x1, tgt1 = x[:32], tgt[:, :32].copy()
-    while time.perf_counter() - t1 < 2.0:
-        O.clipper_mse_step(th, fs, x1, tgt1, n_threads=1)
-        n1 += 1
-    one_core = 32 * T * n1 / (time.perf_counter() - t1)
-    return {"value": Bs * T * n / dt, "unit": "samples/s", "cores": best, "kind": "port",
-            "logical_cpus": avail, "value_one_core": one_core,
-            "sample": f"{n} fused fwd+MSE+bwd steps of oracle_clipper_mse_step_f32 on {Bs} sequences x {T} "
-                      f"samples of the same sweep workload ({dt:.1f} s, OpenMP {best} threads, best of {cands})"}
+    value = max(best["best"], timed(best["threads"], Bs, x, tgt, hold_s))
+    dt = time.perf_counter() - t0
+    return {"value": value, "unit": "samples/s", "cores": best["threads"], "kind": "port",
+            "logical_cpus": avail, "cgroup_cpu_max": quota_txt, "cgroup_cores": quota_cores,
+            "cores_note": (f"{avail} logical CPUs in the affinity mask, cgroup quota "
+                           f"{'none' if quota_cores is None else f'{quota_cores:g} cores'}; best throughput at {best['threads']} "
+                           f"OpenMP threads"),
+            "all_cores": {"threads": avail, "value": allc["best"], "median": allc["median"]},
+            "value_one_core": one["best"],
+            "calibration": table,
+            "sample": f"oracle_clipper_mse_step_f32 (fused fwd + MSE + bwd) on {Bs} sequences x {T} samples of the same sweep "
+                      f"workload, OpenMP {best['threads']} threads: best of three warm >= 0.25 s runs and a {dt:.1f} s hold; every "
+                      f"candidate of {cands} measured the same way (>= 32 sequences per thread, passes discarded for >= 2 s and until two agree "
+                      f"within 10 %)"}
 
 
 def parity_check(stepper, theta, xk, x_host, target, fs, n_global, fused, g_first=None):
@@ -1371,6 +1426,10 @@ def main():
             out["roofline"].update({"fwd_kernel_ms": f_ms, "bwd_kernel_ms": b_ms})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, fs)
+            out["speedup_vs_cpu"] = {"vs_best": value / out["cpu_baseline"]["value"],
+                                     "vs_all_cores": value / out["cpu_baseline"]["all_cores"]["value"],
+                                     "vs_one_core": value / out["cpu_baseline"]["value_one_core"],
+                                     "target": 100.0, "met": value / out["cpu_baseline"]["value"] >= 100.0}
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_dist:
         wdist.barrier()                      # rank 0 finishes its report before any communicator goes away

@@ -48,3 +48,20 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     out, lines = _run(["--gpus", "2", "--launch-check"], env=env)
     assert out.returncode != 0 and not lines and "WORLD_SIZE=1" in out.stderr
+
+
+def test_cpu_baseline_reports_quota_table_and_both_figures():
+    """bench.py's CPU leg (the oracle as the reported baseline): every thread count measured warm, the all-cores figure and the
+    best figure both on the line, the cgroup's quota printed next to the affinity count."""
+    sys.path.insert(0, REPO)
+    import bench
+    txt, cores = bench.cgroup_cpu_quota()
+    assert cores is None or cores > 0
+    r = bench.cpu_baseline(256, 48000.0, hold_s=0.2, warm_floor_s=0.1)
+    avail = len(os.sched_getaffinity(0))
+    assert r["kind"] == "port" and r["logical_cpus"] == avail and r["all_cores"]["threads"] == avail
+    assert {e["threads"] for e in r["calibration"]} >= {1, avail}
+    assert all(e["sequences"] >= 32 * e["threads"] or e["sequences"] == 8192 for e in r["calibration"])
+    assert all(e["warm_passes_discarded"] >= 1 and e["best"] >= e["median"] > 0 for e in r["calibration"])
+    assert r["value"] >= max(e["best"] for e in r["calibration"]) and r["value"] >= r["all_cores"]["value"]
+    assert r["cores"] in {e["threads"] for e in r["calibration"]} and "cgroup_cpu_max" in r
