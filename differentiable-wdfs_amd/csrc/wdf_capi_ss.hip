@@ -474,10 +474,14 @@ size_t wdf_ss_lin_step_ws_bytes(int ns, int ni, int64_t B, int64_t T, int n_chun
 // out: float [1 + n_params] = {sum of squared errors, d(gscale/2 x that sum)/d component value}; loss_out: (or NULL) <- gscale/2 x
 // that sum; gcoef_out: float
 // [ns^2 + ns ni + ns + ni] (dLoss/d{A, Bx, cy, dy}) or NULL.
+// z0: float [ns][B] the capacitor states the call starts from, or NULL (zero); zT: float [ns][B] <- the states it ends in, or NULL
+// (lpf.py:30-49 never resets C1: epoch n starts from epoch n - 1's final state).  z0 is a constant of the call (no gradient
+// flows into the previous call, as in the reference, whose stored state belongs to the previous tape); zT must not alias z0.
 int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, int n_params, int ns, int ni, const float* target,
                         float gscale, float* y, void* ws, float* out, float* loss_out, float* gcoef_out, int64_t B, int64_t T, int n_chunks,
-                        void* stream)
+                        const float* z0, float* zT, void* stream)
 {
+    if (z0 && z0 == zT) return fail(WDF_EINVAL, "wdf_ss_lin_step_mse: zT must not alias z0 (every chunk reads z0)");
     if (!x || !coef || !jac || !target || !y || !ws || !out) return fail(WDF_EINVAL, "null argument");
     if (!lin_step_ok(ns, ni)) return fail(WDF_EUNSUPPORTED, "wdf_ss_lin_step_mse: ns in 0..2, ni in 1..2 (got %d, %d)", ns, ni);
     if (B <= 0 || T <= 0 || n_chunks < 1 || n_params < 1 || n_params > wdf::kProbeMaxParams) return fail(WDF_EINVAL, "B, T, n_chunks >= 1, 1..%d parameters", wdf::kProbeMaxParams);
@@ -488,7 +492,7 @@ int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, in
     float* uend0 = (float*)((char*)ws + 256);
     double* part = (double*)(((uintptr_t)(uend0 + (size_t)K * (size_t)D * (size_t)B) + 255) & ~(uintptr_t)255);
     // two sequences per lane (8-byte loads and stores) when the rows of x, target, y and the workspace allow it
-    const bool pair = (B % 2 == 0) && ((((uintptr_t)x | (uintptr_t)target | (uintptr_t)y | (uintptr_t)ws) & 7u) == 0);
+    const bool pair = (B % 2 == 0) && ((((uintptr_t)x | (uintptr_t)target | (uintptr_t)y | (uintptr_t)ws | (uintptr_t)z0 | (uintptr_t)zT) & 7u) == 0);
     const int64_t per_wave = pair ? 128 : 64;
     const dim3 grid((unsigned)((B + per_wave - 1) / per_wave), (unsigned)K);
     hipStream_t s = (hipStream_t)stream;
@@ -498,7 +502,7 @@ int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, in
             hipLaunchKernelGGL((wdf::ss_lin_step_zero_kernel<NS_, NI_, V_>), grid, dim3(64), 0, s, x, coef, uend0, B, T, L);   \
         EventBracket bracket(s);                                                                                   \
         hipLaunchKernelGGL((wdf::ss_lin_step_kernel<NS_, NI_, V_>), grid, dim3(64), 0, s, x, coef, (const float*)uend0, \
-                           target, gscale, y, part, ticket, jac, n_params, out, loss_out, gcoef_out, B, T, L);               \
+                           target, gscale, y, part, ticket, jac, n_params, out, loss_out, gcoef_out, B, T, L, z0, zT);       \
     }
 #define WDF_LIN_STEP(NS_, NI_)                                                                                     \
     if (ns == NS_ && ni == NI_) {                                                                                  \

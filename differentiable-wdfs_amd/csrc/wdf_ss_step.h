@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict
                                                          float gscale, float* __restrict__ y, double* __restrict__ part,
                                                          unsigned* __restrict__ ticket, const double* __restrict__ jac, int n_params,
                                                          float* __restrict__ out, float* __restrict__ loss_out, float* __restrict__ gcoef_out, int64_t B, int64_t T,
-                                                         int64_t L)
+                                                         int64_t L, const float* __restrict__ z0, float* __restrict__ zT)
 {
     using U = LinU<NS, NI, V>;
     using C = SSCoef<NS, NI>;
@@ -372,6 +372,12 @@ __global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict
     c.load(coef);
     U u;
     u.zero();
+    // z0 [NS][B] (or NULL): the capacitor states this call starts from -- lpf.py:30-49 never resets C1, so an epoch starts where
+    // the last one ended; a constant of this call's tape (the tangents start at 0), as the reference's stored tensor is
+    if (NS > 0 && z0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) u.z[s] = lin_ld<V>(z0 + s * B + b);
+    }
     if (NS > 0 && k > 0) lin_walk_to<NS, NI, V>(c, uend0, B, b, k, L, u);
     const float gs = live ? gscale : 0.0f, lv = live ? 1.0f : 0.0f;
     double acc[U::kG + 1];
@@ -437,6 +443,10 @@ __global__ __launch_bounds__(64) void ss_lin_step_kernel(const float* __restrict
         }
 #pragma unroll
         for (int i = 0; i <= U::kG; ++i) acc[i] += lin_hsum(f[i]);
+    }
+    if (NS > 0 && zT && t1 == T && live) {                          // the states the call ends in [NS][B] (never the z0 buffer)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) lin_st<V>(zT + s * B + b, u.z[s]);
     }
     // ---- this wave's partial; the last wave of the launch adds them up in a fixed order and applies the chain rule
     const int64_t wave = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwaves = (int64_t)gridDim.x * gridDim.y;

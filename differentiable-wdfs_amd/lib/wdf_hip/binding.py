@@ -33,7 +33,7 @@ ONE_SEQUENCE_PER_LANE = os.environ.get("WDF_ONE_SEQUENCE_PER_LANE", "") not in (
 GENERAL_ROOT = False
 
 
-ABI_VERSION = 5                # include/wdf_hip.h WDF_HIP_ABI_VERSION
+ABI_VERSION = 6                # include/wdf_hip.h WDF_HIP_ABI_VERSION
 
 
 def _root_flag():
@@ -219,7 +219,7 @@ def lib():
     L.wdf_ss_lin_step_ws_bytes.restype = C.c_size_t
     L.wdf_ss_lin_step_ws_bytes.argtypes = [ci, ci, i64, i64, ci]
     L.wdf_ss_lin_step_mse.restype = ci
-    L.wdf_ss_lin_step_mse.argtypes = [fp, fp, vp, ci, ci, ci, fp, cf, fp, vp, fp, fp, fp, i64, i64, ci, vp]
+    L.wdf_ss_lin_step_mse.argtypes = [fp, fp, vp, ci, ci, ci, fp, cf, fp, vp, fp, fp, fp, i64, i64, ci, fp, fp, vp]
     L.wdf_ss_nl_step_ws_bytes.restype = C.c_size_t
     L.wdf_ss_nl_step_ws_bytes.argtypes = [ci, ci, i64, i64, ci]
     L.wdf_ss_nl_step_chunk_len.restype = ci

@@ -272,7 +272,9 @@ class _SsDynFn(torch.autograd.Function):
             grows, groot, gz0 = binding.ss_dyn_bwd(x, r, ns, ni, zs, gy.contiguous(), kind, rootp=rootp, w=w, hidden=hidden, n_tanh=n_tanh,
                                                    n_up=n_up, n_down=n_down, want_gz0=has_z0)
         if not per_sample:
-            grows = grows.double().sum(dim=(0, 2)).float()
+            # static row: the kernel's per-sample products [T,n,B] reduced to n numbers, accumulated in float64 INSIDE the
+            # reduction (no float64 copy of the array: at 8192 x 4096 that copy alone was 2.4 GB), sequences first, then time
+            grows = grows.sum(dim=2, dtype=torch.float64).sum(dim=0).float()
         return (grows, None if groot is None else groot.float(), None, (gz0[:ns] if has_z0 else None), None, None, None, None, None,
                 None, None, None, None, None)
 
@@ -521,9 +523,11 @@ class _LinResident:
                 "w_min": int(raw[5]), "w_max": int(raw[6]), "cool": int(raw[7]), "tol": float(f[8]), "n_bad": int(raw[12]),
                 "max_miss": float(f[13]), "gated_groups": int(raw[14]), "total_gated": int(raw[15]), "w_used": int(raw[19])}
 
-    def step(self, ent):
+    def step(self, ent, z0=None, want_zT=False):
         """probe + one-pass step -> (out = {SSE, d(mean squared error)/d component value}, loss = the mean squared error): views
-        of this call's own result row (never written again)."""
+        of this call's own result row (never written again).  z0 [ns,B] float32 on the device: the capacitor states the call
+        starts from (linear trees; None: zero); want_zT: the states it ends in are left in ent["zT"] (a buffer of its own per
+        call parity, never the one z0 may be)."""
         circ = self.circ
         self.probe()
         B, T, n = ent["B"], ent["T"], self.pb.n
@@ -541,9 +545,15 @@ class _LinResident:
             binding._check(rc, "wdf_ss_nl_step_mse")
             self._watch(ent)
             return out, loss
+        zT = None
+        if want_zT and circ.ns > 0:
+            bufs = ent.setdefault("zT_bufs", [torch.empty((circ.ns, B), dtype=torch.float32, device=ent["y"].device) for _ in range(2)])
+            zT = bufs[0] if (z0 is None or z0.data_ptr() != bufs[0].data_ptr()) else bufs[1]
+        ent["zT"] = zT
         rc = binding.lib().wdf_ss_lin_step_mse(binding._ptr(ent["x"]), binding._ptr(self.coef), binding._ptr(self.jac), self.pb.n,
                                                circ.ns, circ.ni, binding._ptr(ent["t"]), 2.0 / float(B * T), binding._ptr(ent["y"]),
                                                binding._ptr(ent["ws"]), binding._ptr(out), binding._ptr(loss), None, B, T, ent["k"],
+                                               None if z0 is None else binding._ptr(z0), None if zT is None else binding._ptr(zT),
                                                binding._stream())
         binding._check(rc, "wdf_ss_lin_step_mse")
         return out, loss
@@ -583,8 +593,8 @@ class _LinResidentMseFn(torch.autograd.Function):
     _wdf_sends_pending = True        # (res.step() begins with res.probe(), which carries the queued optimizer updates)
 
     @staticmethod
-    def forward(ctx, res, ent, inv_n, idx, *live):
-        out, loss = res.step(ent)                                # (this call's own result row: nothing to copy)
+    def forward(ctx, res, ent, inv_n, idx, z0, want_zT, *live):
+        out, loss = res.step(ent, z0, want_zT)                   # (this call's own result row: nothing to copy)
         ctx.save_for_backward(out)
         ctx.idx = idx
         ctx.mark_non_differentiable(out)
@@ -594,7 +604,7 @@ class _LinResidentMseFn(torch.autograd.Function):
     def backward(ctx, gl, _):
         (out,) = ctx.saved_tensors
         g = gl * out
-        return (None,) * 4 + tuple(g[1 + i] for i in ctx.idx)
+        return (None,) * 6 + tuple(g[1 + i] for i in ctx.idx)
 
 
 # ------------------------------------------------------------------------------ tree walking
@@ -834,26 +844,50 @@ class Circuit:
         return S / n + tf.sqrt(S / E / n)
 
     # -- topology tests
-    def mse(self, x, target):
+    def mse(self, x, target, z0=None, carry_state=False):
         """tf.reduce_mean(tf.square(self(x) - target)) as ONE fused evaluation where the kernels allow
         it (diode-pair clipper: forward kernel + MSE-fused reverse sweep, the gradient of every
         trainable component ready when tape.gradient asks); any other circuit takes the plain path.
-        target: [T,B] like the output."""
+        target: [T,B] like the output.
+
+        z0 [ns,B]: the capacitor states the call starts from (default: zero, clipper_pot.py:110-111).  carry_state=True: the
+        call starts from the states the PREVIOUS carry_state call on this circuit ended in (zero the first time) -- lpf.py:30-49
+        never resets C1, so its epoch n starts where epoch n - 1 ended; the state handed over is a constant of the new call
+        (the reference's stored tensor belongs to the previous tape).  `circ.last_state` [ns,B] is what the call ended in
+        (set whenever z0 / carry_state is used); `circ.reset_state()` forgets it.  A resident linear tree runs this inside the
+        one-pass step (wdf_ss_lin_step_mse's z0 / zT); every other circuit composes it from __call__(x, z0, return_state)."""
         binding.require_gpu()
+        stateful = z0 is not None or carry_state
+        if carry_state and z0 is None:
+            z0 = getattr(self, "last_state", None)
+        if stateful and self.ns == 0:
+            stateful, z0 = False, None                            # (no capacitor: nothing to carry)
         lin = getattr(self, "_lin", None)
         if lin is None and getattr(self, "_tree", None) is not None and self.root_kind == "DiodePair" and 1 <= self.ns <= 2 \
                 and 1 <= self.ni <= 2 and not self.force_generic:
             lin = self._tree                                     # diode-pair root: the tangent-carried step (csrc/wdf_ss_nl_step.h)
+        if stateful and lin is not None and lin is not getattr(self, "_lin", None):
+            lin = None                                           # (diode-root one-pass step: zero state only -> the plain path)
         if lin is not None and isinstance(x, torch.Tensor) and isinstance(target, torch.Tensor):
             with torch._C.DisableTorchFunctionSubclass():        # (asking a tensor for its version or requires_grad must not
                 lin.check()                                      #  send the queued optimizer updates: the probe carries them)
                 ent = lin.entry(x, target)
                 live = [(i, v) for i, v in sorted(lin.pb.members.items()) if v.requires_grad]
-            loss, out = _LinResidentMseFn.apply(lin, ent, 1.0 / float(ent["B"] * ent["T"]), [i for i, _ in live], *[v for _, v in live])
+                z0d = None
+                if z0 is not None:                               # the linear step takes the state in and hands it out
+                    z0d = torch.as_tensor(z0).as_subclass(torch.Tensor).detach().to(ent["y"].device).float().reshape(self.ns, ent["B"]).contiguous()
+            loss, out = _LinResidentMseFn.apply(lin, ent, 1.0 / float(ent["B"] * ent["T"]), [i for i, _ in live], z0d, stateful,
+                                                *[v for _, v in live])
             loss = loss.as_subclass(tf.Tensor)
             loss._wdf_fused = (out, {id(v): i for i, v in live})
             self.last_output = ent["y"]                          # the forward's y [T,B] of this call (TensorArray.stack() layout)
+            if stateful:
+                self.last_state = ent["zT"]
             return loss
+        if stateful:
+            y, zT = self(x, z0=z0, return_state=True)
+            self.last_state, self.last_output = zT.detach(), y.detach()
+            return tf.reduce_mean(tf.square(y - tf.convert(target, device=y.device).reshape(y.shape)))
         if not (self._is_clipper() and self.root_kind == "DiodePair" and not self.force_generic):
             y = self(x)
             return tf.reduce_mean(tf.square(y - target))
@@ -880,6 +914,11 @@ class Circuit:
         loss = engine.clipper_mse(theta, xv, tgt, float(cap.FS), r=r, n_up=dp.N_up, n_down=dp.N_down, tp=tp,
                                   time_major=True)
         return loss.as_subclass(tf.Tensor)
+
+    def reset_state(self):
+        """Forget the state carried by mse(..., carry_state=True): the next such call starts from zero (Capacitor.reset,
+        tf_wdf.py:117-118)."""
+        self.last_state = None
 
     def _is_clipper(self):
         t = self.top

@@ -31,7 +31,11 @@
 extern "C" {
 #endif
 
-#define WDF_HIP_ABI_VERSION 5   /* 5: + wdf_clipper_asym_bwd_tp, wdf_ss_dyn_* (round 5).  3: + wdf_clipper_mlp_step_* (round 4); TpCtl is 128 bytes, warm-up units are 16 steps.  4: + wdf_ss_nl_step_*; the linear step's workspace shrank */
+/* The library is built with -fvisibility=hidden: exactly the functions declared between this push and the pop at the end of
+ * the header are exported (tests/test_cabi_cpu.py compares `nm -D` with this header both ways). */
+#pragma GCC visibility push(default)
+
+#define WDF_HIP_ABI_VERSION 6   /* 6: wdf_ss_lin_step_mse takes z0 / zT (round 6); exports limited to this header.  5: + wdf_clipper_asym_bwd_tp, wdf_ss_dyn_* (round 5).  3: + wdf_clipper_mlp_step_* (round 4); TpCtl is 128 bytes, warm-up units are 16 steps.  4: + wdf_ss_nl_step_*; the linear step's workspace shrank */
 
 enum {
     WDF_OK = 0,
@@ -312,7 +316,8 @@ int wdf_clipper_mlp_wgrad(const float* ain, const float* lrin, const float* gb,
  *   wdf_ss_lin_step_mse   forward, squared error and the gradient carried forward in time (no stash, no reverse sweep),
  *                         in EXACT time chunks (a pass from zero state, a walk over the chunk boundaries, the pass itself);
  *                         its last wave contracts dLoss/d coef with jac: out = {SSE, dLoss/d params}, *loss_out (optional) = gscale/2 SSE.  x is TIME-major
- *                         [T][ni][B].  ns <= 2, ni <= 2, zero initial state.                                   */
+ *                         [T][ni][B].  ns <= 2, ni <= 2.  z0 / zT (ABI 6): float [ns][B] capacitor states the
+ *                         call starts from (NULL: zero) / ends in (NULL: not wanted) -- lpf.py:30-49 never resets C1.      */
 int wdf_ss_probe(const int32_t* tape, int n_ops, const double* consts, const float* params, int n_params,
                  const int32_t* outs, int n_out, float* coef, double* coef64, double* jac, void* stream);
 /* wdf_adam_step_multi(jobs, n_jobs) (below: the optimizers' updates of `params`) and wdf_ss_probe in ONE launch. */
@@ -323,7 +328,8 @@ int wdf_ss_probe_adam(const struct wdf_adam_job* jobs, int n_jobs, const int32_t
 size_t wdf_ss_lin_step_ws_bytes(int ns, int ni, int64_t B, int64_t T, int n_chunks);
 int wdf_ss_lin_step_mse(const float* x, const float* coef, const double* jac, int n_params, int ns, int ni,
                         const float* target, float gscale, float* y, void* ws, float* out, float* loss_out,
-                        float* gcoef_out, int64_t B, int64_t T, int n_chunks, void* stream);
+                        float* gcoef_out, int64_t B, int64_t T, int n_chunks, const float* z0, float* zT,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------
  * The one-pass MSE training step of small trees with a DIODE-PAIR root (csrc/wdf_ss_nl_step.h): the same epoch
@@ -677,6 +683,8 @@ void wdf_event_destroy(void* ev);
  * stream reaches this point: two stamps around a stretch of work give the clock the chip sustained over it
  * (bench.py value_sustained).                                                                */
 int wdf_clock_stamp(uint64_t* out, void* stream);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -134,8 +134,18 @@ def g1_rc_lowpass():
         # reference quirk: lpf.py never resets C1, so a second forward() starts from the
         # final state of the first one
         out[f"z_after_{tag}"] = npy(model.C1.z).ravel()
+        # (round 6) ... and its gradient: a new `with tf.GradientTape()` block (lpf.py:87) records nothing of the previous
+        # epoch, so the stored state is a CONSTANT of the second epoch's tape -- torch's graph would still reach into the
+        # first forward, hence the detach (values unchanged)
+        model.C1.z = model.C1.z.detach()
         outs2 = model.forward(data_in)[..., 0]
         out[f"y_second_call_{tag}"] = npy(outs2)[:, 0]
+        loss2 = tf.keras.losses.MeanSquaredError()(outs2, np.transpose(np.array([target])))
+        grads2 = torch.autograd.grad(loss2, tv)
+        out[f"loss_second_call_{tag}"] = npy(loss2)
+        out[f"dC_second_call_{tag}"] = npy(grads2[0])
+        out[f"dR_second_call_{tag}"] = npy(grads2[1])
+        out[f"z_after_second_call_{tag}"] = npy(model.C1.z).ravel()
     out["R"] = 1000.0
     out["C"] = 1.0e-6
     np.savez(os.path.join(HERE, "g1_rc_lowpass.npz"), **out)

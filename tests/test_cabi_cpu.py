@@ -33,8 +33,18 @@ def test_every_declared_symbol_is_exported(lib):
     assert set(binding.EXPORTED_SYMBOLS) == set(syms)
 
 
+def test_nothing_but_the_declared_symbols_is_exported(lib):
+    """The other direction: the dynamic symbol table of the shipped library is EXACTLY the header (built with
+    -fvisibility=hidden + csrc/exports.map: no helper of a translation unit, no kernel host stub leaks out)."""
+    import subprocess
+    from wdf_hip import binding
+    out = subprocess.run(["nm", "-D", "--defined-only", binding.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if line.strip()})
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
+
+
 def test_abi_version(lib):
-    assert lib.wdf_abi_version() == 5
+    assert lib.wdf_abi_version() == 6
 
 
 def test_argument_validation_without_gpu(lib):

@@ -50,6 +50,84 @@ def test_resident_rc_lowpass_against_the_reference_golden(wdf, golden):
     assert rel(grads[1].cpu().numpy(), g["dR_f64"]) < 2e-4
 
 
+def test_resident_rc_lowpass_never_reset_epochs_against_the_reference_golden(wdf, golden):
+    """lpf.py:30-49 never resets C1: epoch 2 starts from epoch 1's final state (g1: the reference's Model.forward called
+    twice, the second tape's gradient with the stored state as its constant).  circ.mse(..., carry_state=True) on the resident
+    one-pass step: y, loss, the state handed over and both gradients of BOTH epochs."""
+    tf = wdf.tf
+    g = golden("g1_rc_lowpass.npz")
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    circ = wdf.Circuit(I1, Vs, C1).to_device()
+    x, tgt = cuda(g["x"][None, :]), cuda(g["target"][:, None])
+    for tag, zkey in (("", "z_after_f64"), ("_second_call", "z_after_second_call_f64")):
+        with tf.GradientTape() as tape:
+            loss = circ.mse(x, tgt, carry_state=True)
+        grads = tape.gradient(loss, [C1.C, R1.R])
+        assert np.max(np.abs(circ.last_output.cpu().numpy()[:, 0] - g["y" + tag + "_f64"])) < 2e-6
+        assert abs(float(loss) - float(g["loss" + tag + "_f64"])) < 1e-6
+        assert abs(float(circ.last_state[0, 0]) - float(g[zkey][0])) < 2e-6
+        assert rel(grads[0].cpu().numpy(), g["dC" + tag + "_f64"]) < 1e-4
+        assert rel(grads[1].cpu().numpy(), g["dR" + tag + "_f64"]) < 1e-4
+    # an explicit z0 is the same hand-over; reset_state() is Capacitor.reset (tf_wdf.py:117-118)
+    z1 = torch.full((1, 1), float(g["z_after_f64"][0]), device="cuda")
+    circ.mse(x, tgt, z0=z1)
+    assert np.max(np.abs(circ.last_output.cpu().numpy()[:, 0] - g["y_second_call_f64"])) < 2e-6
+    circ.reset_state()
+    circ.mse(x, tgt, carry_state=True)
+    assert np.max(np.abs(circ.last_output.cpu().numpy()[:, 0] - g["y_f64"])) < 2e-6
+
+
+@pytest.mark.parametrize("B,T,resident", [(70, 1000, True), (300, 4096, True), (70, 1000, False)])
+def test_rc_lowpass_three_never_reset_epochs_against_the_oracle(wdf, oracle, B, T, resident):
+    """Three epochs of lpf.py's loop shape (forward from the previous epoch's final state, MSE, tape.gradient, Adam on R and
+    C), every epoch against the oracle at that epoch's own component values with z0 = the oracle's own zT hand-over:
+    y, the state handed on, and the gradient (central differences of the fp64 oracle, z0 held -- the new tape's constant).
+    resident=False: the same call on host-resident Variables (composed from __call__(x, z0, return_state))."""
+    tf = wdf.tf
+    O = oracle
+    rng = np.random.default_rng(B + T + 1)
+    x = rng.standard_normal((B, T)).astype(np.float32)
+    tgt = (0.5 * rng.standard_normal((T, B))).astype(np.float32)
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    circ = wdf.Circuit(I1, Vs, C1)
+    if resident:
+        circ.to_device()
+    opts = [tf.keras.optimizers.Adam(learning_rate=25.0), tf.keras.optimizers.Adam(learning_rate=1.0e-8)]   # lpf.py:79-80
+    oc = O.rc_lowpass_circuit(float(FS))
+    x64 = x.astype(np.float64)
+    z_ref = None
+    xd, td = cuda(x), cuda(tgt)
+    for epoch in range(3):
+        theta = np.array([float(R1.R), float(C1.C)], dtype=np.float32).astype(np.float64)
+        with tf.GradientTape() as tape:
+            loss = circ.mse(xd, td, carry_state=True)
+        grads = tape.gradient(loss, [R1.R, C1.C])
+        yref, zT = O.tree_fwd(oc, theta, x64, z0=z_ref, return_state=True)
+
+        def loss_at(th):
+            return np.mean((O.tree_fwd(oc, th, x64, z0=z_ref) - tgt) ** 2)
+
+        gref = []
+        for k in range(2):
+            h = 1e-5 * theta[k]
+            tp, tm = theta.copy(), theta.copy()
+            tp[k] += h
+            tm[k] -= h
+            gref.append((loss_at(tp) - loss_at(tm)) / (2 * h))
+        got = np.array([float(v) for v in grads])
+        e_y = float(np.max(np.abs(circ.last_output.cpu().numpy() - yref)))
+        e_z = float(np.max(np.abs(circ.last_state.cpu().numpy()[0] - zT[:, 1])))
+        print(f"epoch {epoch}: |y - oracle| {e_y:.2e}, |zT - oracle| {e_z:.2e}, grads {rel(got, np.array(gref)):.2e}")
+        assert e_y < 3e-6 and e_z < 3e-6
+        assert abs(float(loss) - np.mean((yref - tgt) ** 2)) < 1e-5 * np.mean((yref - tgt) ** 2)
+        assert rel(got, np.array(gref)) < 3e-4
+        opts[0].apply_gradients([(grads[0], R1.R)])
+        opts[1].apply_gradients([(grads[1], C1.C)])
+        # the hand-over in the oracle's own precision: what the GPU carries differs by its fp32 rounding only (checked above)
+        z_ref = zT
+    assert abs(float(R1.R) - 1000.0) > 10.0                      # (the loop really moved the components)
+
+
 def test_resident_voltage_divider_against_the_reference_golden(wdf, golden):
     tf = wdf.tf
     g = golden("g2_voltage_divider.npz")

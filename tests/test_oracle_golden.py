@@ -103,8 +103,25 @@ def test_rc_lowpass_state_carries_across_calls(oracle, golden):
     x = g["x"][None, :]
     _, zT = oracle.tree_fwd(circ, theta, x, return_state=True)
     assert abs(zT[0, 1] - g["z_after_f64"][0]) < 1e-13
-    y2 = oracle.tree_fwd(circ, theta, x, z0=zT)[:, 0]
+    y2, zT2 = oracle.tree_fwd(circ, theta, x, z0=zT, return_state=True)
+    y2 = y2[:, 0]
     assert np.max(np.abs(y2 - g["y_second_call_f64"])) < 1e-13
+    assert abs(zT2[0, 1] - g["z_after_second_call_f64"][0]) < 1e-13
+    # the second epoch's gradient (round 6): the state handed over is a CONSTANT of the new tape -- central differences of the
+    # oracle with z0 held fixed reproduce what the reference's second tape.gradient gives
+    assert abs(np.mean((y2 - g["target"]) ** 2) - float(g["loss_second_call_f64"])) < 1e-14
+
+    def loss_at(th):
+        return np.mean((oracle.tree_fwd(circ, th, x, z0=zT)[:, 0] - g["target"]) ** 2)
+
+    for k, key in ((0, "dR_second_call_f64"), (1, "dC_second_call_f64")):
+        h = 1e-5 * theta[k]
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += h
+        tm[k] -= h
+        fd = (loss_at(tp) - loss_at(tm)) / (2 * h)
+        assert abs(fd - float(g[key])) < 1e-7 * abs(float(g[key])), (key, fd, float(g[key]))
+    assert abs(float(g["dC_second_call_f64"]) - float(g["dC_f64"])) > 3e-4 * abs(float(g["dC_f64"]))   # (the two epochs differ)
 
 
 def test_rc_lowpass_is_bilinear_one_pole(oracle, golden):
