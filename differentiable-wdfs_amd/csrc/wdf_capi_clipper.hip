@@ -1,6 +1,7 @@
 // wdf_capi_clipper.hip -- C ABI part 2 of 4: the diode-clipper sequence kernels (sequential and
 // time-parallel forward / reverse sweep).  Argument checking, template dispatch and launches.
 // 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -215,10 +216,20 @@ void launch_fused(const float* x, const float* r, const float* theta, float fs, 
     // pairs: two adjacent sequences per lane, packed fp32 arithmetic (wdf_clipper_fused.h); a tile is then 128 sequences
     const int per_tile = pairs ? 128 : 64;
     const dim3 grid((unsigned)((B + per_tile - 1) / per_tile), (unsigned)g.K);
+    // Round 6: the step's tail (verification, walk over the chunk records, reduction, chain rule, warm-start steering, Adam) and the
+    // repair of missed tiles are ONE launch behind the chunk kernel, several waves per tile (clipper_fused_finish_kernel).
+    // WDF_FUSED_FINISH=inkernel restores the round-5 form (the tile's last chunk wave does the tail, an idle repair launch follows).
+    static const bool finish_inkernel = []() { const char* e = getenv("WDF_FUSED_FINISH"); return e && strcmp(e, "inkernel") == 0; }();
+    const int later = (g.K > 1 && !finish_inkernel) ? 1 : 0;
+    const int fin_waves = (int)std::min<int64_t>(wdf::kFinMaxWaves, (g.K + wdf::kFinSeg - 1) / wdf::kFinSeg);
 #define WDF_FUSED(V_, LOSS_)                                                                                                     \
     hipLaunchKernelGGL((wdf::clipper_fused_tp_kernel<DYN_R, SYM, TM, V4, V_, LOSS_>), grid, dim3(64), 0, s, x, r, theta, fs, n_up, \
                        n_down, target, hgs, skip, y, z0, zT, w.zwarm, w.zend, w.rec, status, warm.ctl, warm.snap, warm.J,        \
-                       w.tickets, w.gticket, tol, B, T, g.L, W, general, w.part, out, skew, w.wpart)
+                       w.tickets, w.gticket, tol, B, T, g.L, W, general, w.part, out, skew, w.wpart, later)
+#define WDF_FUSED_FINISH(N_, LOSS_)                                                                                              \
+    hipLaunchKernelGGL((wdf::clipper_fused_finish_kernel<DYN_R, SYM, TM, N_, LOSS_>), dim3(grid.x), dim3(64 * fin_waves), 0, s, x, r, \
+                       theta, fs, n_up, n_down, target, hgs, skip, y, zT, w.zwarm, w.zend, w.rec, B, T, (int64_t)g.K, g.L, tol,   \
+                       status, warm.ctl, warm.snap, warm.J, w.tickets, w.gticket, general, w.part, out, skew, w.wpart, W)
 #define WDF_FUSED_REPAIR(N_, LOSS_)                                                                                              \
     hipLaunchKernelGGL((wdf::clipper_fused_repair_kernel<DYN_R, SYM, TM, N_, LOSS_>), dim3(grid.x), dim3(64), 0, s, x, r, theta, fs, \
                        n_up, n_down, target, hgs, skip, y, zT, w.zwarm, w.zend, w.rec, B, T, (int64_t)g.K, g.L, tol, status,     \
@@ -228,11 +239,15 @@ void launch_fused(const float* x, const float* r, const float* theta, float fs, 
         if (esr) { if (pairs) WDF_FUSED(wdf::v2f, 2); else WDF_FUSED(float, 2); }
         else { if (pairs) WDF_FUSED(wdf::v2f, 1); else WDF_FUSED(float, 1); }
     }
-    if (g.K > 1) {                              // blocks of unflagged tiles (normally all of them) leave at once
+    if (later) {
+        if (esr) { if (pairs) WDF_FUSED_FINISH(2, 2); else WDF_FUSED_FINISH(1, 2); }
+        else { if (pairs) WDF_FUSED_FINISH(2, 1); else WDF_FUSED_FINISH(1, 1); }
+    } else if (g.K > 1) {                       // blocks of unflagged tiles (normally all of them) leave at once
         if (esr) { if (pairs) WDF_FUSED_REPAIR(2, 2); else WDF_FUSED_REPAIR(1, 2); }
         else { if (pairs) WDF_FUSED_REPAIR(2, 1); else WDF_FUSED_REPAIR(1, 1); }
     }
 #undef WDF_FUSED
+#undef WDF_FUSED_FINISH
 #undef WDF_FUSED_REPAIR
 }
 

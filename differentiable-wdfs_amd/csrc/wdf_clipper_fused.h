@@ -762,7 +762,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, const float* __restrict__ z0,
     float* __restrict__ zT, float* zwarm, float* zend, float* rec, TpStatus* __restrict__ status, TpCtl* ctl, float* snap,
     int J, unsigned* tickets, unsigned* gticket, float tol, int64_t B, int64_t T, int64_t L, int64_t W, int general,
-    double* ws, FusedOut out, int64_t skew, double* wpart)
+    double* ws, FusedOut out, int64_t skew, double* wpart, int finish_later)
 {
     __shared__ double sh[64][4];
 #ifdef WDF_DBG_TIMES
@@ -790,6 +790,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     }
 #endif
     WDF_DBG_STAMP(0);
+    // finish_later (round 6, the default): the chunk waves are done here -- no drain, no tile ticket -- and the launch behind this
+    // one (clipper_fused_finish_kernel) verifies, repairs, combines and finishes the step with several waves per tile
+    if (finish_later) return;
     if (!tp_tile_last(tickets)) return;
     WDF_DBG_STAMP(1);
     // the tile adds its verification result to the accumulators; the status word and the warm-start steering are left to
@@ -938,6 +941,258 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the re-written records have landed (write-through)
     out.fc = TpFinishCtx{status, ctl, J, tickets, tol, K, L, W, skew != 0};
     fused_combine_tile<NSEQ, LOSS>(rec, wpart, K, B, ws, gticket, theta, fs, DYN_R ? 1 : 0, out, sh);
+}
+
+// ---- the step's finish as a launch of its own (round 6) --------------------------------------------------------------------
+// What the tile's last chunk wave did alone at the end of clipper_fused_tp_kernel -- drain its stores, take the tile's ticket,
+// load K - 1 boundaries, walk K records in time order (K / 16 dependent round trips), publish the tile's sums, take the step's
+// ticket, and as the last tile reduce, apply the chain rule, steer the warm start and run Adam: ~12 us of dependent device-scope
+// round trips at 32 chunks, 30+ at 128 -- and what the idle repair launch behind every step cost on top (4.7 us), as ONE launch
+// of 64 NW-thread workgroups, one per tile, behind the kernel boundary:
+//   * wave w of a tile owns the chunks [k0, k1) (at most kFinSeg = 8 at a time in registers): their records, their boundaries
+//     and the chunk waves' own sums are requested TOGETHER -- one round trip;
+//   * every wave verifies its own boundaries; the tile's verdict goes through LDS.  A tile with a missed boundary is re-run by
+//     its wave 0 exactly as clipper_fused_repair_kernel does it (sequentially, from the exact state: outputs, snapshots,
+//     records), the other waves wait at the barrier and then load the re-written records;
+//   * the walk is split: the tangent entering a chunk is affine in the tangent entering the tile, sigma' = A sigma + c, so a
+//     wave composes its chunks into ONE map {P, q[3]} (4 floats per sequence through LDS), every wave then builds the tangent
+//     entering ITS first chunk from the maps of the waves before it (<= 7 FMAs per component) and walks its own records with
+//     the sums -- the same sums in the same order inside a wave; across waves the partials are added in wave order;
+//   * the tile's sums go out through tile_partial_and_finish / esr_tile_partial_and_finish as before: the last tile to arrive
+//     reduces, applies the chain rule, publishes the status, steers the warm start and runs Adam.
+// Measured on the trial of round 5 (profiles/README.md): the one-pass kernel without its tail runs 0.089-0.090 ms instead of
+// 0.107-0.109; the serial tail as a second launch cost 19 us and gave all of it back.
+constexpr int kFinSeg = 8;          // chunk records a finishing wave holds in registers at a time
+constexpr int kFinMaxWaves = 8;     // waves per tile (512 threads: the repair path needs up to 161 VGPRs)
+
+template <bool DYN_R, bool SYM, bool TM, int NSEQ, int LOSS>
+__global__ __launch_bounds__(64 * kFinMaxWaves) void clipper_fused_finish_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
+    const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, float* __restrict__ zT,
+    const float* zwarm, float* zend, float* rec, int64_t B, int64_t T, int64_t K, int64_t L, float tol,
+    TpStatus* __restrict__ status, TpCtl* ctl, float* __restrict__ snap, int J, unsigned* tickets,
+    unsigned* gticket, int general, double* ws, FusedOut out, int64_t skew, double* wpart, int64_t W)
+{
+    constexpr int NREC = FusedRec<LOSS>::N, NP = FusedRec<LOSS>::NP, NQ = FusedQuads<NSEQ, LOSS>::NQ;
+    constexpr int NWQ = NSEQ * NP / 2;                     // 16-byte loads of a chunk's own sums
+    __shared__ double sh[64][4];
+    __shared__ float s_pq[kFinMaxWaves][NSEQ][64][4];      // per wave and sequence: the composed map {P, qL, qV, qP}
+    __shared__ double s_sum[kFinMaxWaves][8];
+    __shared__ float s_miss[kFinMaxWaves];
+    __shared__ int s_bad[kFinMaxWaves];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, NW = blockDim.x >> 6;
+    const int64_t seg = (K + NW - 1) / NW;
+    const int64_t k0 = (int64_t)w * seg < K ? (int64_t)w * seg : K, k1 = k0 + seg < K ? k0 + seg : K;
+    const int64_t raw = ((int64_t)blockIdx.x * 64 + lane) * NSEQ;
+    const bool live = raw < B;
+    const int64_t b_first = live ? raw : B - NSEQ;
+    const uint32_t lanes = gridDim.x * 64u, rl = blockIdx.x * 64u + (uint32_t)lane;
+    const bool one_batch = seg <= kFinSeg;
+
+    v4u g[kFinSeg][NQ];
+    auto load_batch = [&](int64_t kb) {                     // records of chunks kb .. kb + 7 (clamped to the wave's last)
+#pragma unroll
+        for (int j = 0; j < kFinSeg; ++j) {
+            const int64_t k = (kb + j < k1) ? kb + j : (k1 > k0 ? k1 - 1 : 0);
+            const __amdgpu_buffer_rsrc_t rs = row_rsrc(rec_chunk(rec, k));
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) g[j][q] = load_published_quad(rs, rl * 16u, (uint32_t)q * lanes * 16u);
+        }
+    };
+    const __amdgpu_buffer_rsrc_t rw = row_rsrc(reinterpret_cast<float*>(wpart + (int64_t)blockIdx.x * K * NSEQ * NP));
+    v4u wq[NWQ];
+    auto load_part = [&](int64_t kk) {
+        const uint32_t kc = (uint32_t)(kk < k1 ? kk : (k1 > k0 ? k1 - 1 : 0));
+#pragma unroll
+        for (int i = 0; i < NWQ; ++i) wq[i] = load_published_quad(rw, kc * (uint32_t)(NSEQ * NP * 8) + 16u * i, 0);
+    };
+    // ---- one flight: the first batch of records, the chunk waves' own sums, the boundaries
+    load_batch(k0);
+    load_part(k0 + lane);
+    float miss = 0.0f;
+    int nbad = 0;
+    for (int64_t kb = k0; kb < k1; kb += kFinSeg) {
+        float zw[kFinSeg][NSEQ], ze[kFinSeg][NSEQ];
+#pragma unroll
+        for (int j = 0; j < kFinSeg; ++j) {
+            int64_t k = (kb + j < k1) ? kb + j : k1 - 1;
+            k = k < 1 ? 1 : k;                                  // (chunk 0 has no boundary before it; K >= 2 here)
+            load_published_n<NSEQ>(zwarm + k * B + b_first, zw[j]);
+            load_published_n<NSEQ>(zend + (k - 1) * B + b_first, ze[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < kFinSeg; ++j)
+#pragma unroll
+            for (int h = 0; h < NSEQ; ++h) {
+                const float m = fabsf(zw[j][h] - ze[j][h]);
+                if (kb + j < k1 && kb + j >= 1) {
+                    miss = fmaxf(miss, m);
+                    nbad += !(m <= tol) ? 1 : 0;                // NaN counts as bad
+                }
+            }
+    }
+    {
+        const float wmax = wave_max_dpp(miss);
+        const int wbad = wave_sum_dpp(nbad);
+        if (lane == 0) { s_miss[w] = wmax; s_bad[w] = wbad; }
+    }
+    __syncthreads();
+    int tile_bad_pairs = 0;
+    float tile_miss = 0.0f;
+    for (int i = 0; i < NW; ++i) { tile_bad_pairs += s_bad[i]; tile_miss = fmaxf(tile_miss, s_miss[i]); }
+    if (threadIdx.x == 0) {                                  // the tile's share of the verification totals (tp_verify_tile, DEFER)
+        TpAcc* acc = reinterpret_cast<TpAcc*>(tickets);
+        if (tile_miss > 0.0f) (void)atomicMax(&acc->max_miss_bits, __float_as_int(tile_miss));
+        if (tile_bad_pairs) (void)atomicAdd(&acc->n_bad, (unsigned)tile_bad_pairs);
+    }
+    if (tile_bad_pairs != 0) {
+        // ---- the rare path: wave 0 re-runs the chunks that were entered off (clipper_fused_repair_kernel's walk)
+        if (w == 0) {
+            const ClipConsts c = load_consts(theta, fs, n_up, n_down);
+            bool fast = false;
+            fast = fast_root_ok<DYN_R>(c, general);
+            // the ring slot the step wrote its snapshots to (the control block is advanced by the wave that finishes the step:
+            // the last of this launch's tiles through the ticket below -- after every tile has read this)
+            int slot = 0;
+            if (ctl != nullptr && snap != nullptr) slot = ((ctl->geom == tp_geom_tag(K, J, skew != 0) ? ctl->head : 0) + 1) % kTpRing;
+            int nrep = 0;
+#pragma unroll 1
+            for (int h = 0; h < NSEQ; ++h) {
+                const int64_t b = b_first + h;
+                bool fixed_prev = false;
+                float ze_fix = 0.0f;
+                for (int64_t k = 1; k < K; ++k) {
+                    const float e = fixed_prev ? ze_fix : load_published(zend + (k - 1) * B + b);
+                    const float m = fabsf(load_published(zwarm + k * B + b) - e);
+                    fixed_prev = false;
+                    if (__builtin_amdgcn_ballot_w64(!(m <= tol)) == 0) continue;
+                    int64_t t0, t1;
+                    chunk_span(k, K, L, skew, T, t0, t1);
+                    float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
+                    float z = e;
+                    if (fast) fused_rerun_chunk<DYN_R, SYM, TM, true, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+                    else fused_rerun_chunk<DYN_R, SYM, TM, false, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+                    __hip_atomic_store(zend + k * B + b, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (zT && t1 == T) zT[b] = z;
+                    ze_fix = z;
+                    fixed_prev = true;
+                    ++nrep;
+                }
+            }
+            if (lane == 0 && nrep) atomicAdd(&status->fallback_ran, nrep);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the re-written records have landed (write-through)
+        }
+        __syncthreads();
+        load_batch(k0);                                        // (agent-scope loads: past this CU's L1)
+        load_part(k0 + lane);
+    }
+    // ---- phase A: this wave's chunks as one affine map of the tangent, per sequence
+    {
+        double P[NSEQ], qL[NSEQ], qV[NSEQ], qP[NSEQ];
+#pragma unroll
+        for (int h = 0; h < NSEQ; ++h) { P[h] = 1.0; qL[h] = qV[h] = qP[h] = 0.0; }
+        for (int64_t kb = k0; kb < k1; kb += kFinSeg) {
+            if (kb > k0) load_batch(kb);
+#pragma unroll
+            for (int j = 0; j < kFinSeg; ++j) {
+                if (kb + j >= k1) break;                        // wave-uniform
+                float v[NQ * 4];
+#pragma unroll
+                for (int i = 0; i < NQ * 4; ++i) v[i] = __uint_as_float(g[j][i / 4][i % 4]);
+#pragma unroll
+                for (int h = 0; h < NSEQ; ++h) {
+                    const float* rr = v + h * NREC;
+                    const double A = rr[0];
+                    P[h] *= A;
+                    qL[h] = A * qL[h] + (double)rr[1];
+                    qV[h] = A * qV[h] + (double)rr[2];
+                    qP[h] = A * qP[h] + (double)rr[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NSEQ; ++h) {
+            s_pq[w][h][lane][0] = (float)P[h]; s_pq[w][h][lane][1] = (float)qL[h];
+            s_pq[w][h][lane][2] = (float)qV[h]; s_pq[w][h][lane][3] = (float)qP[h];
+        }
+    }
+    __syncthreads();
+    // ---- phase B: the tangent entering this wave's first chunk, then the walk with the sums
+    double sL[NSEQ], sV[NSEQ], sP[NSEQ];                   // (the tangent entering the tile is 0: z0 does not depend on theta)
+#pragma unroll
+    for (int h = 0; h < NSEQ; ++h) {
+        sL[h] = sV[h] = sP[h] = 0.0;
+        for (int ww = 0; ww < w; ++ww) {
+            const double Pw = s_pq[ww][h][lane][0];
+            sL[h] = Pw * sL[h] + (double)s_pq[ww][h][lane][1];
+            sV[h] = Pw * sV[h] + (double)s_pq[ww][h][lane][2];
+            sP[h] = Pw * sP[h] + (double)s_pq[ww][h][lane][3];
+        }
+    }
+    double dL = 0.0, dV = 0.0, dP = 0.0, dS = 0.0, qL2 = 0.0, qV2 = 0.0, qP2 = 0.0, qE = 0.0;
+    for (int64_t kb = k0; kb < k1; kb += kFinSeg) {
+        if (!one_batch) load_batch(kb);
+#pragma unroll
+        for (int j = 0; j < kFinSeg; ++j) {
+            if (kb + j >= k1) break;                            // wave-uniform
+            float v[NQ * 4];
+#pragma unroll
+            for (int i = 0; i < NQ * 4; ++i) v[i] = __uint_as_float(g[j][i / 4][i % 4]);
+#pragma unroll
+            for (int h = 0; h < NSEQ; ++h) {
+                const float* rr = v + h * NREC;
+                const double A = rr[0], GA = rr[4];
+                dL += sL[h] * GA;
+                dV += sV[h] * GA;
+                dP += sP[h] * GA;
+                if constexpr (LOSS == 2) {
+                    const double HA = rr[5];
+                    qL2 += sL[h] * HA;
+                    qV2 += sV[h] * HA;
+                    qP2 += sP[h] * HA;
+                }
+                sL[h] = A * sL[h] + (double)rr[1];
+                sV[h] = A * sV[h] + (double)rr[2];
+                sP[h] = A * sP[h] + (double)rr[3];
+            }
+        }
+    }
+    if (!live) { dL = dV = dP = dS = qL2 = qV2 = qP2 = qE = 0.0; }
+    auto add_part = [&]() {                                 // the chunk wave's own sums (already masked to its live lanes)
+#pragma unroll
+        for (int h = 0; h < NSEQ; ++h) {
+            double p[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int e = h * NP + i;                     // double e of the chunk's block = dwords 2e, 2e + 1
+                p[i] = __hiloint2double((int)wq[e / 2][(e % 2) * 2 + 1], (int)wq[e / 2][(e % 2) * 2]);
+            }
+            dL += p[0]; dV += p[1]; dP += p[2]; dS += p[3];
+            if constexpr (LOSS == 2) { qL2 += p[4]; qV2 += p[5]; qP2 += p[6]; qE += p[7]; }
+        }
+    };
+    if (k0 + lane < k1) add_part();                         // lane i: chunk k0 + i
+    for (int64_t kk = k0 + lane + 64; kk < k1; kk += 64) { load_part(kk); add_part(); }   // (more than 64 chunks per wave)
+    {
+        const double v8[8] = {dL, dV, dP, dS, qL2, qV2, qP2, qE};
+#pragma unroll
+        for (int i = 0; i < (LOSS == 2 ? 8 : 4); ++i) {
+            const double t = wave_sum_dpp(v8[i]);
+            if (lane == 0) s_sum[w][i] = t;
+        }
+    }
+    __syncthreads();
+    if (w != 0) return;
+    double tot[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (lane == 0) {
+        for (int ww = 0; ww < NW; ++ww)
+#pragma unroll
+            for (int i = 0; i < (LOSS == 2 ? 8 : 4); ++i) tot[i] += s_sum[ww][i];
+    }
+    out.fc = TpFinishCtx{status, ctl, J, tickets, tol, K, L, W, skew != 0};
+    if constexpr (LOSS == 2) esr_tile_partial_and_finish(tot, ws, gticket, theta, fs, DYN_R ? 1 : 0, out);
+    else tile_partial_and_finish(tot[0], tot[1], tot[2], tot[3], ws, gticket, theta, fs, DYN_R ? 1 : 0, out.gtheta, out.accumulate, out.sse_out,
+                                 out.adam, sh, out.fc);
 }
 
 }  // namespace wdf

@@ -436,8 +436,20 @@ def autotune_fused(theta, x, target, fs, plan, time_major=False, n_up=1, n_down=
     # step runs two per lane, i.e. half the waves: the planned count is doubled to keep two waves per SIMD
     k_cap = T // max(plan.warmup // 2, 64)
     planned = plan.k_fwd * 2 if (B % 2 == 0 and not binding.ONE_SEQUENCE_PER_LANE and plan.k_fwd * 2 <= k_cap) else plan.k_fwd
+    cands = {k for k in (max(1, planned // 2), planned, planned * 2) if k == 1 or k <= k_cap}
+    if warm:
+        # Round 6: a stepper that keeps its warm-start state pays the cold warm-up ONCE, then runs 0-16 warm-up steps per chunk
+        # -- so its chunk count is not bounded by the cold warm-up's redundancy but by the chip: enough chunks for two waves
+        # on every SIMD, down to 32-step chunks (a few thousand sequences: the per-rank share of a strong-scaling run).  The
+        # step's tail no longer grows with the chunk count on one wave (clipper_fused_finish_kernel: 8 waves per tile).
+        per_tile = 128 if (B % 2 == 0 and not binding.ONE_SEQUENCE_PER_LANE) else 64
+        fill = (2 * N_SIMD) // max(1, -(-B // per_tile))
+        for k in (fill // 2, fill):
+            k = min(k, T // 32)
+            if k >= 2 and k > max(cands):
+                cands.add(int(binding.lib().wdf_clipper_tp_chunks(T, k)))
     times = {}
-    for k in sorted({k for k in (max(1, planned // 2), planned, planned * 2) if k == 1 or k <= k_cap}):
+    for k in sorted(cands):
         st = MseStep(B, T, fs, plan._replace(k_fwd=k), x.device, n_up=n_up, n_down=n_down, time_major=time_major, warm=warm)
         times[k] = timed(lambda: st.step_fused(theta, x, target, r))
         if binding.tp_status(st.status)["n_bad"]:

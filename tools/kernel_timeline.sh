@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 rm -rf gpurun_out/prof_timeline
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_timeline -o p -- python bench.py --steps 300 --warmup 3 --no-cpu-baseline --no-parity --no-cold --no-batch-major > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_timeline -o p -- python bench.py --steps 300 --warmup 3 --no-cpu-baseline --no-parity --no-cold --no-batch-major --no-strong-proxy > /dev/null 2>&1
 python - <<'PY'
 import csv,glob
 f=glob.glob("gpurun_out/prof_timeline/**/p_kernel_trace.csv", recursive=True)[0]

@@ -3,8 +3,8 @@
 TAG="$1"; shift
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_sq1 -o p -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity --no-batch-major --no-cold --no-sustained --no-fwd-1024 "$@" > gpurun_out/pmc_${TAG}_sq1.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_IFETCH --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_sq2 -o p -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity --no-batch-major --no-cold --no-sustained --no-fwd-1024 "$@" > gpurun_out/pmc_${TAG}_sq2.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_sq1 -o p -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity --no-batch-major --no-cold --no-sustained --no-fwd-1024 --no-strong-proxy "$@" > gpurun_out/pmc_${TAG}_sq1.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_IFETCH --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_sq2 -o p -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity --no-batch-major --no-cold --no-sustained --no-fwd-1024 --no-strong-proxy "$@" > gpurun_out/pmc_${TAG}_sq2.log 2>&1
 python - "$TAG" <<'PY'
 import csv, glob, re, statistics, sys, json
 tag = sys.argv[1]

@@ -11,6 +11,6 @@ mkdir -p gpurun_out
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   N=$(echo "$C" | cut -d' ' -f1)
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "gpurun_out/pmc_${TAG}_${N}" -o p -- \
-      python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity --no-batch-major --no-cold --no-sustained --no-fwd-1024 "$@" > "gpurun_out/pmc_${TAG}_${N}.log" 2>&1
+      python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity --no-batch-major --no-cold --no-sustained --no-fwd-1024 --no-strong-proxy "$@" > "gpurun_out/pmc_${TAG}_${N}.log" 2>&1
 done
 python tools/pmc_summarize.py "$TAG"

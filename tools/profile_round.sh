@@ -24,7 +24,7 @@ fi
 echo "plan $PLAN"
 rm -rf "gpurun_out/prof_${TAG}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "gpurun_out/prof_${TAG}" -o p -- \
-    python bench.py --steps "$STEPS" --warmup "$WARM" --no-cpu-baseline --no-parity --no-batch-major --no-cold --no-sustained --no-fwd-1024 --plan "$PLAN" \
+    python bench.py --steps "$STEPS" --warmup "$WARM" --no-cpu-baseline --no-parity --no-batch-major --no-cold --no-sustained --no-fwd-1024 --no-strong-proxy --plan "$PLAN" \
     > "gpurun_out/prof_${TAG}_bench.json" 2> "gpurun_out/prof_${TAG}.err"
 cp "$(find gpurun_out/prof_${TAG} -name '*kernel_stats.csv' | head -1)" "gpurun_out/${TAG}_kernel_stats.csv"
 python tools/kernel_steady.py "$TAG" "$WARM"
