@@ -1308,13 +1308,27 @@ def main():
         xs, ts = x[:Bs].contiguous(), target[:, :Bs].contiguous()
         sp = Trainer(args, xs, ts, fs, Bs, T, n_global, world, dev, tm)
         dt_s, _, _ = sp.run(args.warmup, args.steps, dev)
-        ms_s = dt_s / args.steps * 1e3
-        strong_proxy = {"ranks": 8, "B_per_rank": Bs, "ms_per_step": ms_s, "chunks": None if sp.tp is None else sp.tp.k_fwd,
-                        "verify_status": None if sp.tp is None or sp.tp.k_fwd < 2 else binding.tp_status(sp.stepper.status),
+        ms_e = dt_s / args.steps * 1e3
+        stat_e = None if sp.tp is None or sp.tp.k_fwd < 2 else binding.tp_status(sp.stepper.status)
+        k_e = None if sp.tp is None else sp.tp.k_fwd
+        # the same step replayed as a HIP graph: at ~45 us per step the eager loop is bound by the HOST (two launches and the
+        # torch glue of a step cost it ~55 us: a 200-step run shows it, a 20-step run hides it in the launch queue)
+        import copy
+        ga = copy.copy(args)
+        ga.graph, ga.plan = True, (args.plan if args.plan else (None if sp.tp is None else f"{sp.tp.k_fwd},{sp.tp.warmup},{sp.tp.k_bwd}"))
+        del sp
+        sg = Trainer(ga, xs, ts, fs, Bs, T, n_global, world, dev, tm)
+        dt_g, _, _ = sg.run(max(args.warmup, 8), args.steps, dev)
+        ms_g = dt_g / args.steps * 1e3 if ga.graph else None       # (a failed capture falls back to eager launches: not a graph figure)
+        ms_s = ms_e if ms_g is None else min(ms_e, ms_g)
+        strong_proxy = {"ranks": 8, "B_per_rank": Bs, "ms_per_step": ms_s, "ms_per_step_eager": ms_e, "ms_per_step_graph_replay": ms_g,
+                        "chunks": k_e, "verify_status": stat_e,
+                        "verify_status_graph_replay": None if sg.tp is None or sg.tp.k_fwd < 2 else binding.tp_status(sg.stepper.status),
                         "projected_value_8": Bg * T / (ms_s * 1e-3), "projected_speedup_8": (dt / args.steps * 1e3) / ms_s,
                         "note": "one-GPU proxy of the per-rank step of the 8-rank STRONG run (global batch fixed): compute only, "
-                                "the 20-byte all-reduce per step is not in it"}
-        del sp, xs, ts
+                                "the 20-byte all-reduce per step is not in it; ms_per_step = the better of eager launches and "
+                                "HIP-graph replay of the same step (--graph on is how a rank would run it)"}
+        del sg, xs, ts
 
     # the loop kept running (after the headline's burst of a few milliseconds), and BASELINE configs[1] (forward only)
     sustained = fwd1024 = None

@@ -151,7 +151,20 @@ __device__ __forceinline__ bool fast_root_ok(const ClipConsts& c, int general)
     else return series_only_omega1(c);
 }
 
-template <bool DYN_R, bool SYM, typename V, bool FAST = false>
+// The root tier of a launch (wdf_omega.h): one wave-uniform test on the circuit's constants.  LEAN: symmetric pair, static
+// port resistance, log(Rp Is / (N nVt)) in [-80, -7.5].
+template <bool DYN_R, bool SYM>
+__device__ __forceinline__ int root_tier(const ClipConsts& c, int general)
+{
+    if (!fast_root_ok<DYN_R>(c, general)) return kRootGeneral;
+    if constexpr (SYM && !DYN_R) {
+        const float l0 = c.L - c.d.l_dn;
+        if (l0 <= -7.5f && l0 >= -80.0f) return kRootLean;
+    }
+    return kRootFast;
+}
+
+template <bool DYN_R, bool SYM, typename V, int FAST = 0>
 __device__ __forceinline__ V fwd_step(const ClipConsts& c, V xin, V rin, V& z)
 {
     V p, Rp, L;
@@ -166,7 +179,7 @@ __device__ __forceinline__ V fwd_step(const ClipConsts& c, V xin, V rin, V& z)
     return y;
 }
 
-template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH, bool FAST>
+template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH, int FAST>
 __device__ __forceinline__ void clipper_fwd_body(const ClipConsts& c, const float* __restrict__ x,
                                                  const float* __restrict__ r, float* __restrict__ y,
                                                  float* __restrict__ zstash, const float* __restrict__ z0,
@@ -223,11 +236,18 @@ __global__ __launch_bounds__(64) void clipper_fwd_kernel(
     const float* __restrict__ z0, float* __restrict__ zT, int64_t B, int64_t T, int general)
 {
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    if (fast_root_ok<DYN_R>(c, general)) {
-        clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, true>(c, x, r, y, zstash, z0, zT, B, T);
+    const int tier = root_tier<DYN_R, SYM>(c, general);
+    if constexpr (SYM && !DYN_R) {
+        if (tier == kRootLean) {
+            clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, kRootLean>(c, x, r, y, zstash, z0, zT, B, T);
+            return;
+        }
+    }
+    if (tier != kRootGeneral) {
+        clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, kRootFast>(c, x, r, y, zstash, z0, zT, B, T);
         return;
     }
-    clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, false>(c, x, r, y, zstash, z0, zT, B, T);
+    clipper_fwd_body<DYN_R, SYM, TIME_MAJOR, VEC4, STASH, kRootGeneral>(c, x, r, y, zstash, z0, zT, B, T);
 }
 
 // =========================================================================================
@@ -738,7 +758,7 @@ __device__ __forceinline__ V gather_t(const float (&v)[VT<V>::N][kTile], int i)
 // at the first 32-step boundary where every lane is back within tol_conv of what the speculative
 // pass stored (everything after that point is then within tol_conv of the exact trajectory
 // already); returns true if it ran to the chunk's end (z = end state then).
-template <bool DYN_R, bool SYM, bool TM, bool STASH, bool FAST>
+template <bool DYN_R, bool SYM, bool TM, bool STASH, int FAST>
 __device__ __forceinline__ bool tp_rerun_chunk(const ClipConsts& c, const float* __restrict__ x,
                                             const float* __restrict__ r, float* __restrict__ y,
                                             float* __restrict__ zstash, float* __restrict__ snapw, int J, int64_t K,
@@ -991,8 +1011,7 @@ __global__ __launch_bounds__(64) void clipper_tp_repair_kernel(
         if (__builtin_amdgcn_ballot_w64(nbad != 0) == 0) return;
     }
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    bool fast = false;
-    fast = fast_root_ok<DYN_R>(c, general);
+    const int tier = root_tier<DYN_R, SYM>(c, general);          // (the forward's own tier: a re-run is its arithmetic)
     const int slot = (ctl != nullptr && snap != nullptr) ? ctl->head : 0;
     int nrep = 0;
     bool fixed_prev = false;                                    // wave-uniform: chunk k-1 was re-run to its end
@@ -1005,9 +1024,17 @@ __global__ __launch_bounds__(64) void clipper_tp_repair_kernel(
         const int64_t t0 = k * L, t1 = (t0 + L < T) ? t0 + L : T;
         float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
         float z = e;
-        bool done;
-        if (fast) done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, true>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, true, z);
-        else done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, false>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, true, z);
+        bool done = false, ran = false;
+        if constexpr (SYM && !DYN_R) {
+            if (tier == kRootLean) {
+                done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, kRootLean>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, true, z);
+                ran = true;
+            }
+        }
+        if (!ran) {
+            if (tier != kRootGeneral) done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, kRootFast>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, true, z);
+            else done = tp_rerun_chunk<DYN_R, SYM, TM, STASH, kRootGeneral>(c, x, r, y, zstash, snapw, J, K, b, B, T, t0, t1, 0.125f * tol, true, z);
+        }
         if (done) {
             zend[k * B + b] = z;
             if (zT && t1 == T) zT[b] = z;

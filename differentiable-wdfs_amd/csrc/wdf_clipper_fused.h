@@ -262,7 +262,7 @@ struct FusedTan {
 // sums S = sum (y - t)^2 and E = sum y^2, known only after the pass -- so the pass carries BOTH tangent-weighted sums,
 // P_i = sum (y - t) dy/dtheta_i and Q_i = sum y dy/dtheta_i (hgs = 1/2 on live steps), and the last tile forms
 // ga P + gb Q.  Seven more VALU per step.
-template <bool DYN_R, bool SYM, bool FAST, typename V, int LOSS = 1>
+template <bool DYN_R, bool SYM, int FAST, typename V, int LOSS = 1>
 __device__ __forceinline__ V fused_step(const ClipConsts& c, V xin, V rin, V tgt, float hgs, V& z, FusedTan<V>& s)
 {
     V p, Rp, L;
@@ -281,13 +281,15 @@ __device__ __forceinline__ V fused_step(const ClipConsts& c, V xin, V rin, V tgt
         // its alternating series to the cubic term (next term 1e-7 relative) instead of a reciprocal.
         // lam X = copysign(X, a) for the two differences, both >= 0 because omega and omega' are increasing and
         // both exactly 0 at a = 0 where w0 == w1 bit for bit (diode_pair, FAST); lam^2 = (a != 0).
-        const V w1p = o.w1 * vfma(-o.w1, vfma(-o.w1, 1.0f - o.w1, 1.0f), 1.0f);
+        V w1p;
+        if constexpr (FAST == kRootLean) w1p = vfma(-o.w1, o.w1, o.w1);      // omega_1 <= 5.6e-4 (root_tier): w (1 - w)
+        else w1p = o.w1 * vfma(-o.w1, vfma(-o.w1, 1.0f - o.w1, 1.0f), 1.0f);
         const V sp = w0p + w1p;
         const V tl = vsel_nonzero(a, -2.0f, 0.0f);                  // -2 lam^2
         const float tvm = c.d.two_v * c.d.m_dn;
         Da = vfma(tl, sp, 1.0f);
         DL = (-tvm) * vcopysign(w0p - w1p, a);
-        DV = vfma(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * vcopysign(o.w0 - o.w1, a));
+        DV = vfma(tl * a, sp * (-1.0f / c.V), (-2.0f * c.d.m_dn) * vcopysign(o.dw, a));
     } else {
         const V w1p = o.w1 * vrcp(o.w1 + 1.0f);
         const V l2 = o.lam * o.lam;
@@ -418,7 +420,7 @@ __device__ __forceinline__ void fused_publish_record(float* rec, double* wpart, 
 // Chunk geometry as clipper_fwd_tp_body (L, W multiples of kTile); target [T][B]; skip: steps below it carry no loss.
 // LOSS = 0: the plain time-parallel forward (no target, no tangent, no record; STASH: the state before every step goes to
 // zstash [T][B] for the reverse sweep) -- clipper_fwd_tp_kernel below runs this same body.
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool FAST, typename V, int LOSS, bool STASH = false>
+template <bool DYN_R, bool SYM, bool TM, bool VEC4, int FAST, typename V, int LOSS, bool STASH = false>
 __device__ __forceinline__ void clipper_fused_body(
     const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ target,
     float* __restrict__ y, float* __restrict__ zstash, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
@@ -771,14 +773,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
 #endif
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { status->fallback_ran = 0; status->pad = 0u; }   // (the repair launch counts)
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    bool fast = false;
-    fast = fast_root_ok<DYN_R>(c, general);
-    if (fast)
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, true, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
-                                                            T, L, W, hgs, skip, skew, wpart);
-    else
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap, J, B,
-                                                           T, L, W, hgs, skip, skew, wpart);
+    const int tier = root_tier<DYN_R, SYM>(c, general);
+    bool ran = false;
+    if constexpr (SYM && !DYN_R) {
+        if (tier == kRootLean) {
+            clipper_fused_body<DYN_R, SYM, TM, VEC4, kRootLean, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap,
+                                                                         J, B, T, L, W, hgs, skip, skew, wpart);
+            ran = true;
+        }
+    }
+    if (!ran) {
+        if (tier != kRootGeneral)
+            clipper_fused_body<DYN_R, SYM, TM, VEC4, kRootFast, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap,
+                                                                         J, B, T, L, W, hgs, skip, skew, wpart);
+        else
+            clipper_fused_body<DYN_R, SYM, TM, VEC4, kRootGeneral, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl,
+                                                                            snap, J, B, T, L, W, hgs, skip, skew, wpart);
+    }
 #ifdef WDF_DBG_TIMES
     if (threadIdx.x == 0 && g_dbg_times) {
         unsigned long long* dbg_o = g_dbg_times + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
@@ -826,14 +837,23 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
     // at 32 chunks and 26 of 62 at 64 (tools/dbg_fwd_times.py); across a kernel boundary they are plain loads.
     if (verify_later && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = TpStatus{0, 0.0f, 0, 0u};
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    bool fast = false;
-    fast = fast_root_ok<DYN_R>(c, general);                             // wave-uniform: every practical diode
-    if (fast)
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, true, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
-                                                                      ctl, snap, J, B, T, L, W, 0.0f, 0);
-    else
-        clipper_fused_body<DYN_R, SYM, TM, VEC4, false, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
-                                                                     ctl, snap, J, B, T, L, W, 0.0f, 0);
+    const int tier = root_tier<DYN_R, SYM>(c, general);                 // wave-uniform: every practical diode is LEAN / FAST
+    bool ran = false;
+    if constexpr (SYM && !DYN_R) {
+        if (tier == kRootLean) {
+            clipper_fused_body<DYN_R, SYM, TM, VEC4, kRootLean, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
+                                                                             ctl, snap, J, B, T, L, W, 0.0f, 0);
+            ran = true;
+        }
+    }
+    if (!ran) {
+        if (tier != kRootGeneral)
+            clipper_fused_body<DYN_R, SYM, TM, VEC4, kRootFast, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
+                                                                             ctl, snap, J, B, T, L, W, 0.0f, 0);
+        else
+            clipper_fused_body<DYN_R, SYM, TM, VEC4, kRootGeneral, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
+                                                                                ctl, snap, J, B, T, L, W, 0.0f, 0);
+    }
 #ifdef WDF_DBG_TIMES                                         // (tools/dbg_fwd_times.py: the wave's start, the end of its body, where it ran)
     if (threadIdx.x == 0 && g_dbg_times) {
         unsigned long long* dbg_o = g_dbg_times + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
@@ -849,7 +869,7 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
 }
 
 // Re-run of chunk [t0, t1) for 64 sequences (one per lane, index b) from the exact state z: outputs, snapshots, record.
-template <bool DYN_R, bool SYM, bool TM, bool FAST, int LOSS, int NSEQ>
+template <bool DYN_R, bool SYM, bool TM, int FAST, int LOSS, int NSEQ>
 __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r,
                                                   const float* __restrict__ target, float* __restrict__ y, float* rec, double* wpart,
                                                   float* __restrict__ snapw, int J, int64_t K, int64_t k, int64_t b, int64_t B,
@@ -904,8 +924,7 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
     const bool live = raw < B;
     const int64_t b0 = live ? raw : B - NSEQ;
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-    bool fast = false;
-    fast = fast_root_ok<DYN_R>(c, general);
+    const int tier = root_tier<DYN_R, SYM>(c, general);
     // The ring slot the step wrote its snapshots to.  The control block is advanced by the wave that FINISHES the step, and with
     // a flagged tile that wave is the last of THIS launch's blocks to combine -- after every block has read this:
     int slot = 0;
@@ -925,8 +944,17 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
             chunk_span(k, K, L, skew, T, t0, t1);
             float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
             float z = e;
-            if (fast) fused_rerun_chunk<DYN_R, SYM, TM, true, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
-            else fused_rerun_chunk<DYN_R, SYM, TM, false, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+            bool ran = false;
+            if constexpr (SYM && !DYN_R) {
+                if (tier == kRootLean) {
+                    fused_rerun_chunk<DYN_R, SYM, TM, kRootLean, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+                    ran = true;
+                }
+            }
+            if (!ran) {
+                if (tier != kRootGeneral) fused_rerun_chunk<DYN_R, SYM, TM, kRootFast, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+                else fused_rerun_chunk<DYN_R, SYM, TM, kRootGeneral, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+            }
             zend[k * B + b] = z;
             if (zT && t1 == T) zT[b] = z;
             ze_fix = z;
@@ -1049,8 +1077,7 @@ __global__ __launch_bounds__(64 * kFinMaxWaves) void clipper_fused_finish_kernel
         // ---- the rare path: wave 0 re-runs the chunks that were entered off (clipper_fused_repair_kernel's walk)
         if (w == 0) {
             const ClipConsts c = load_consts(theta, fs, n_up, n_down);
-            bool fast = false;
-            fast = fast_root_ok<DYN_R>(c, general);
+            const int tier = root_tier<DYN_R, SYM>(c, general);
             // the ring slot the step wrote its snapshots to (the control block is advanced by the wave that finishes the step:
             // the last of this launch's tiles through the ticket below -- after every tile has read this)
             int slot = 0;
@@ -1070,8 +1097,17 @@ __global__ __launch_bounds__(64 * kFinMaxWaves) void clipper_fused_finish_kernel
                     chunk_span(k, K, L, skew, T, t0, t1);
                     float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
                     float z = e;
-                    if (fast) fused_rerun_chunk<DYN_R, SYM, TM, true, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
-                    else fused_rerun_chunk<DYN_R, SYM, TM, false, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+                    bool ran = false;
+                    if constexpr (SYM && !DYN_R) {
+                        if (tier == kRootLean) {
+                            fused_rerun_chunk<DYN_R, SYM, TM, kRootLean, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+                            ran = true;
+                        }
+                    }
+                    if (!ran) {
+                        if (tier != kRootGeneral) fused_rerun_chunk<DYN_R, SYM, TM, kRootFast, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+                        else fused_rerun_chunk<DYN_R, SYM, TM, kRootGeneral, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
+                    }
                     __hip_atomic_store(zend + k * B + b, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (zT && t1 == T) zT[b] = z;
                     ze_fix = z;

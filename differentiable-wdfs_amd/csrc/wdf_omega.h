@@ -137,6 +137,38 @@ __device__ __forceinline__ float wright_omega(float x, int* iters = nullptr)
     return w;
 }
 
+// omega(x) for the LEAN root tier (diode_pair, TIER = 2): the region-3 start is the series' first two terms, p (1 - p)
+// (relative error 3/2 p^2 <= 0.0275 at x = -2, i.e. |r| < 0.03: inside the one FSC step's basin like the other regions), and the
+// step is applied on the WHOLE axis -- no "series only below -4" select.  Below -4 the step's residual carries the rounding of
+// log(w) ~ x (half an ulp of |x|: <= 7e-7 relative on omega), which is why the general path skips it there; here the caller has
+// checked that omega_0 matters only through 2 nVt omega_0 with omega_0 <= 0.018 in that region: 2e-9 V.  4 packed instructions,
+// 2 compares and 2 selects per pair of sequences less than omega_one_step.  x must stay above the exponential's underflow
+// (x > -87): the caller's tier test bounds it.
+template <typename V>
+__device__ __forceinline__ V omega_lean(V x)
+{
+    const V p = vexp2(x * kLog2e);
+    V wA = vfma(-p, p, p);                                     // region 3 (x <= -2); inf / NaN above it, discarded below
+    const V q = x - 1.0f;
+    const V sB = vfma(q, vfma(q, vfma(q, 13.0f / 61440.0f, -1.0f / 3072.0f), -1.0f / 192.0f), 1.0f / 16.0f);
+    V wB = vfma(sB, q * q, vfma(x, 0.5f, 0.5f));               // region 4, as omega_start
+    const V lg = vlog2(x);
+    const V l = lg * kLn2;
+    V wC = vfma(l, vrcp(x), vfma(lg, -kLn2, x));               // region 7, as omega_start
+    vpin(wA); vpin(wB); vpin(wC);
+    const V w0 = vsel(vle_c(x, -2.0f), wA, vsel(vle_c(x, kRegion4Hi), wB, wC));
+    V r;
+    return fsc_step(x, w0, r);
+}
+
+// Root tiers of the clipper kernels (one wave-uniform test per kernel, wdf_clipper.h root_tier):
+//   0  general: per-step ballot for omega_1's general evaluation and the second FSC iteration;
+//   1  FAST:    omega_1 provably in its series-only region (L - log N <= -4): no ballot, log2(e) folded into its exponent;
+//   2  LEAN:    (symmetric pair) L - log N <= -7.5, so omega_1 <= 5.6e-4: omega_1 = p (1 - p) and omega_1 / (1 + omega_1) =
+//               omega_1 (1 - omega_1) to 2e-10 absolute, and omega_0 by omega_lean.  Every practical diode: 1N4148 behind
+//               any pot value at 48 kHz sits at L < -8.5.
+constexpr int kRootGeneral = 0, kRootFast = 1, kRootLean = 2;
+
 // ---- diode pair ---------------------------------------------------------------------
 // Per-sign constants that do not depend on the port resistance.
 struct DiodeStatic {
@@ -165,6 +197,7 @@ struct DiodeOutT {
     V w0, w1;   // the two omega values
     V lam;      // sign(a)
     V m0, m1;   // mu0, mu1 used
+    V dw;       // w0 - w1 as b used it (LEAN: exactly 0 at a = 0)
 };
 using DiodeOut = DiodeOutT<float>;
 
@@ -178,9 +211,11 @@ using DiodeOut = DiodeOutT<float>;
 // kSecondIterResidual).  With SYM, lam (w0 - w1) becomes copysign(w0 - w1, a): w0 >= w1 since
 // omega is increasing, and at a = 0 both are the same series of the same argument, so the
 // difference is exactly 0 as lam = sign(0) = 0 requires.
-template <bool SYM, typename V, bool FAST = false>
+template <bool SYM, typename V, int TIER = 0>
 __device__ __forceinline__ DiodeOutT<V> diode_pair(V a, V L, const DiodeStatic& c)
 {
+    constexpr bool FAST = TIER >= kRootFast;
+    constexpr bool LEAN = TIER == kRootLean && SYM;
     DiodeOutT<V> o;
     o.lam = vsign(a);                                          // np.sign (:52)
     const V aa = vabs(a);                                      // lam * a
@@ -207,9 +242,14 @@ __device__ __forceinline__ DiodeOutT<V> diode_pair(V a, V L, const DiodeStatic& 
     // Everything else -- a lane whose u1 needs the general evaluation, or a lane asking for the
     // second FSC iteration -- is handled after ONE wavefront ballot, so a wave skips it unless
     // one of its sequences needs it.
-    typename VT<V>::mask again0;
-    o.w0 = omega_one_step<V>(u0, again0);
-    if constexpr (FAST && SYM) {
+    typename VT<V>::mask again0{};
+    if constexpr (LEAN) o.w0 = omega_lean<V>(u0);
+    else o.w0 = omega_one_step<V>(u0, again0);
+    if constexpr (LEAN) {
+        const V p1 = vexp2(e1);
+        o.w1 = vfma(-p1, p1, p1);                              // omega_1 <= 5.6e-4: p (1 - p), next term 3/2 p^3 < 3e-10
+        vpin(o.w1);
+    } else if constexpr (FAST && SYM) {
         // u1 <= kSeriesOnlyBelow on every lane: the same series as omega_series, with log2(e) folded
         // into the argument's FMA and without the overflow clamp.  At a = 0 the exponent is
         // l0 * log2(e), the very product omega_series(u0 = l0) forms, so w1 == w0 bit for bit there
@@ -229,7 +269,11 @@ __device__ __forceinline__ DiodeOutT<V> diode_pair(V a, V L, const DiodeStatic& 
             o.w1 = vsel(general1, w1g, o.w1);
         }
     }
-    if constexpr (SYM && FAST) o.b = a - (c.two_v * c.m_dn) * vcopysign(o.w0 - o.w1, a);
+    o.dw = o.w0 - o.w1;
+    // LEAN: omega_0 went through the FSC step and omega_1 did not, so at a = 0 the two differ in their last bits; lam =
+    // sign(0) = 0 (zero input gives exactly zero output, as in the reference) is restored by the select
+    if constexpr (LEAN) o.dw = vsel_nz(a, o.dw);
+    if constexpr (SYM && FAST) o.b = a - (c.two_v * c.m_dn) * vcopysign(o.dw, a);
     else if constexpr (SYM) o.b = a - (c.two_v * c.m_dn) * (o.lam * (o.w0 - o.w1));   // (:56-59)
     else o.b = a - c.two_v * (o.lam * (o.m0 * o.w0 - o.m1 * o.w1));
     return o;

@@ -79,6 +79,10 @@ __device__ __forceinline__ v2f vsel(v2i m, v2f a, v2f b) { return v2f{m.x ? a.x 
 __device__ __forceinline__ v2f vsel(v2i m, v2f a, float b) { return v2f{m.x ? a.x : b, m.y ? a.y : b}; }
 __device__ __forceinline__ v2f vsel(v2i m, float a, float b) { return v2f{m.x ? a : b, m.y ? a : b}; }
 
+// x where a != 0, else 0
+__device__ __forceinline__ float vsel_nz(float a, float x) { return a != 0.0f ? x : 0.0f; }
+__device__ __forceinline__ v2f vsel_nz(v2f a, v2f x) { return v2f{a.x != 0.0f ? x.x : 0.0f, a.y != 0.0f ? x.y : 0.0f}; }
+
 // sign(a) in {-1, 0, +1}  (np.sign)
 __device__ __forceinline__ float vsign(float a) { return (a > 0.0f) ? 1.0f : ((a < 0.0f) ? -1.0f : 0.0f); }
 __device__ __forceinline__ v2f vsign(v2f a) { return v2f{vsign(a.x), vsign(a.y)}; }
