@@ -102,6 +102,47 @@ def test_fused_vs_oracle_f64(wb, oracle):
     assert abs(float(sse) / (B * T) - loss_ref) <= 1e-5 * loss_ref
 
 
+@pytest.mark.parametrize("is_scale,tier", [(1.0, "lean"), (2.9, "lean"), (3.05, "fast"), (1.0e-3, "lean"), (40.0, "fast")])
+def test_root_tiers_against_the_oracle_across_the_tier_boundary(wb, oracle, is_scale, tier):
+    """The LEAN root tier (round 6: csrc/wdf_omega.h omega_lean, omega_1 = p (1 - p); taken when log(Rp Is / nVt) <= -7.5,
+    i.e. Is up to 2.97 x the 1N4148's behind this circuit) and the FAST tier above it: y, the loss and the four gradient
+    components of the one-pass step against the fp64 oracle on both sides of the boundary and deep inside (Is / 1000: omega_0's
+    arguments down to -15.5, where the FSC step now runs although the series alone would do), and the sequential forward
+    kernel against the same trajectory.  `tier` names what csrc/wdf_clipper.h root_tier picks for the row (asserted from L)."""
+    from wdf_hip import workload
+    B, T, K, W = 96, 2048, 8, 256
+    x, th, ths = problem(B, T, seed=23)
+    th = th.copy()
+    th[0] *= is_scale
+    ths = ths.copy()
+    ths[0] *= is_scale
+    th32 = th.astype(np.float32).astype(np.float64)
+    Rp = 1.0 / (1.0 / th32[2] + 2.0 * th32[3] * FS)
+    L = np.log(Rp * th32[0] / th32[1])
+    assert (L <= -7.5) == (tier == "lean"), L
+    tgt64 = oracle.clipper_fwd(ths.astype(np.float64), FS, x.astype(np.float64))
+    loss_ref, g_ref, y_ref = oracle.clipper_mse_step(th32, FS, x.astype(np.float64), tgt64.astype(np.float32).astype(np.float64),
+                                                     dtype=np.float64)
+    y, _, g, sse, st = wb.clipper_step_mse_tp(dev(x), dev(th), FS, dev(tgt64), 2.0 / (B * T), K, W)
+    assert wb.tp_status(st)["n_bad"] == 0
+    e_y = float(np.max(np.abs(y.cpu().numpy() - y_ref)))
+    got = g.cpu().numpy().astype(np.float64)
+    e_g = float(np.max(np.abs(got - g_ref) / np.abs(g_ref)))
+    ys, _, _ = wb.clipper_fwd(dev(x), dev(th), FS, want_stash=False)
+    e_s = float(np.max(np.abs(ys.cpu().numpy() - y_ref)))
+    print(f"Is x {is_scale}: L {L:.3f} ({tier}); |y - oracle| {e_y:.2e} (sequential kernel {e_s:.2e}), gradient {e_g:.2e}")
+    assert e_y <= Y_TOL and e_s <= Y_TOL
+    assert e_g <= G_RTOL, (got, g_ref)
+    assert abs(float(sse) / (B * T) - loss_ref) <= 1e-5 * loss_ref
+    # and against the general root (ballot path, five-term series, conditional FSC step): the tiers agree to fp32 rounding
+    wb.GENERAL_ROOT = True
+    try:
+        yg, _, _ = wb.clipper_fwd(dev(x), dev(th), FS, want_stash=False)
+    finally:
+        wb.GENERAL_ROOT = False
+    assert float((yg - ys).abs().max()) <= 3e-7
+
+
 def test_fused_per_sample_resistance_and_skip(wb):
     B, T, K, W, skip = 71, 1024, 2, 256, 50
     x, th, ths = problem(B, T, seed=3)
