@@ -17,7 +17,7 @@ int dyn_check(const char* who, const float* x, const float* crow, int ns, int ni
     if (!x || !crow) return fail(WDF_EINVAL, "%s: null x / rows", who);
     if (B <= 0 || T <= 0) return fail(WDF_EINVAL, "%s: B and T must be positive", who);
     if (!dyn_ok(ns, ni)) return fail(WDF_EUNSUPPORTED, "%s: ns <= %d, 1 <= ni <= %d (got %d, %d)", who, wdf::kDynMaxS, wdf::kDynMaxI, ns, ni);
-    if (per_sample != 0 && per_sample != 1) return fail(WDF_EINVAL, "%s: per_sample is 0 or 1", who);
+    if (per_sample < 0 || per_sample > 2) return fail(WDF_EINVAL, "%s: per_sample is 0 (one static row), 1 (a row per sample) or 2 (a row per sequence)", who);
     if (root == WDF_ROOT_DIODE_PAIR) {
         if (!rootp) return fail(WDF_EINVAL, "%s: diode root needs rootp = {Is, nVt}", who);
         if (n_up < 1 || n_down < 1) return fail(WDF_EINVAL, "%s: n_up, n_down >= 1", who);
@@ -57,21 +57,21 @@ int wdf_ss_dyn_row_len(int ns, int ni) { return dyn_ok(ns, ni) ? wdf::DynLayout(
 #define WDF_DYN_BWD(MODE_, GY_, ...)                                                                                          \
     do {                                                                                                                     \
         const dim3 grid(WDF_DYN_GRIDX(root == WDF_ROOT_MLP), (unsigned)(GY_));                                               \
-        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
+        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
         else if (root == WDF_ROOT_DIODE_PAIR && n_up == n_down)                                                              \
-            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);   \
+            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);   \
         else if (root == WDF_ROOT_DIODE_PAIR)                                                                                \
-            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, false, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);  \
-        else if (n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
-        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 5, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);     \
+            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, false, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);  \
+        else if (n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
+        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 5, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);     \
     } while (0)
 
 #define WDF_DYN_BWD_EMIT(GY_, ...)                                                                                            \
     do {                                                                                                                     \
         const dim3 grid(WDF_DYN_GRIDX(false), (unsigned)(GY_));                                                              \
-        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
-        else if (root == WDF_ROOT_DIODE_PAIR) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
-        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);          \
+        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
+        else if (root == WDF_ROOT_DIODE_PAIR) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
+        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);          \
     } while (0)
 
 namespace {
@@ -94,7 +94,7 @@ int wdf_ss_dyn_fwd(const float* x, const float* rows, int per_sample, int ns, in
     if (rc) return rc;
     if (!y) return fail(WDF_EINVAL, "wdf_ss_dyn_fwd: null y");
     const int64_t n = wdf::DynLayout(ns, ni).n;
-    const int64_t cs = per_sample ? B : 1, ts = per_sample ? n * B : 0, bs = per_sample ? 1 : 0;
+    const int64_t cs = per_sample ? B : 1, ts = per_sample == 1 ? n * B : 0, bs = per_sample ? 1 : 0;   // (2: rows [n][B], the same row at every step)
     hipStream_t s = (hipStream_t)stream;
     EventBracket bracket(s);
     WDF_DYN_FWD(1, x, rows, cs, ts, bs, rootp, w, n_up, n_down, y, zstash, z0, zT, ns, ni, B, T, T, (int64_t)0,
@@ -121,7 +121,7 @@ int wdf_ss_dyn_fwd_tp(const float* x, const float* rows, int per_sample, int ns,
     int K;
     if (!dyn_geom(T, n_chunks, Lc, K)) return fail(WDF_EINVAL, "wdf_ss_dyn_fwd_tp: n_chunks = %d does not tile T = %lld in 8-step units (%d does)", n_chunks, (long long)T, K);
     const int64_t n = wdf::DynLayout(ns, ni).n;
-    const int64_t cs = per_sample ? B : 1, ts = per_sample ? n * B : 0, bs = per_sample ? 1 : 0;
+    const int64_t cs = per_sample ? B : 1, ts = per_sample == 1 ? n * B : 0, bs = per_sample ? 1 : 0;   // (2: rows [n][B], the same row at every step)
     float* zwarm = (float*)ws;
     float* zend = zwarm + (size_t)K * (size_t)ns * (size_t)B;
     unsigned* gate = (unsigned*)(zend + (size_t)K * (size_t)ns * (size_t)B);
@@ -153,8 +153,9 @@ int wdf_ss_dyn_bwd(const float* x, const float* rows, int per_sample, int ns, in
     if (!gy || !grows || !ws || (ns > 0 && !zstash)) return fail(WDF_EINVAL, "wdf_ss_dyn_bwd: null gy / grows / ws / zstash");
     if (root == WDF_ROOT_MLP && (!gb || !ain || !lrin)) return fail(WDF_EINVAL, "wdf_ss_dyn_bwd: the MLP root needs gb / ain / lrin [T][B]");
     const int64_t n = wdf::DynLayout(ns, ni).n;
-    const int64_t cs = per_sample ? B : 1, ts = per_sample ? n * B : 0, bs = per_sample ? 1 : 0;
+    const int64_t cs = per_sample ? B : 1, ts = per_sample == 1 ? n * B : 0, bs = per_sample ? 1 : 0;   // (2: rows [n][B], the same row at every step)
     hipStream_t s = (hipStream_t)stream;
+    const int acc = per_sample != 1;       // rows that do not change in time: dL/d(row) summed over the steps -> grows [1][n][B]
     EventBracket bracket(s);
     WDF_DYN_BWD(0, 1, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, (double*)ws, gb, ain, lrin, gz0, ns, ni, B, T, T,
                 (float*)nullptr, (float*)nullptr, (const float*)nullptr);
@@ -183,13 +184,14 @@ int wdf_ss_dyn_bwd_tp(const float* x, const float* rows, int per_sample, int ns,
     int K;
     if (!dyn_geom(T, n_chunks, Lc, K)) return fail(WDF_EINVAL, "wdf_ss_dyn_bwd_tp: n_chunks = %d does not tile T = %lld in 8-step units (%d does)", n_chunks, (long long)T, K);
     const int64_t n = wdf::DynLayout(ns, ni).n;
-    const int64_t cs = per_sample ? B : 1, ts = per_sample ? n * B : 0, bs = per_sample ? 1 : 0;
+    const int64_t cs = per_sample ? B : 1, ts = per_sample == 1 ? n * B : 0, bs = per_sample ? 1 : 0;   // (2: rows [n][B], the same row at every step)
     const size_t waves = (size_t)((B + 63) / 64);
     double* part = (double*)ws;
     float* rec = (float*)(part + (size_t)K * waves * 2);
     float* lam_in = rec + (size_t)K * (size_t)(ns + 1) * (size_t)ns * (size_t)B;
     float* rpart = lam_in + (size_t)K * (size_t)ns * (size_t)B;
     hipStream_t s = (hipStream_t)stream;
+    const int acc = per_sample != 1;       // (grows [K][n][B] then: one partial per chunk, added up by the caller)
     {
         EventBracket bracket(s);
         WDF_DYN_BWD(1, K, x, rows, cs, ts, bs, rootp, w, n_up, n_down, zstash, gy, grows, part, gb, ain, lrin, gz0, ns, ni, B, T, Lc, rpart, rec,

@@ -135,6 +135,12 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
     const float* __restrict__ xp = x + b * T * ni;
     const float* __restrict__ cp = crow + b * bs;
     [[maybe_unused]] float act[NL];
+    // rows that do not change in time (ts = 0: one static row, or one row per sequence) are read ONCE, and with them what the
+    // root needs of R_port -- log(R_port Is / nVt) / log R_port: a full-precision logarithm per step otherwise
+    DynRow c = dyn_load_row(cp + tw * ts, cs, L, ns, ni);
+    [[maybe_unused]] float lroot = 0.0f;
+    if constexpr (ROOT == kDynRootDiode) lroot = logf(c.rp * root.Is / root.V);
+    if constexpr (ROOT == kDynRootMlp) lroot = logf(c.rp);
     for (int64_t t = tw; t < t1; ++t) {
         const bool owned = t >= t0;                                // wave-uniform
         if (t == t0 && zwarm != nullptr && writer) {
@@ -142,7 +148,11 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
             for (int s = 0; s < kDynMaxS; ++s)
                 if (s < ns) zwarm[(k * ns + s) * B + b] = z[s];
         }
-        const DynRow c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
+        if (ts != 0 && t != tw) {                                  // wave-uniform
+            c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
+            if constexpr (ROOT == kDynRootDiode) lroot = logf(c.rp * root.Is / root.V);
+            if constexpr (ROOT == kDynRootMlp) lroot = logf(c.rp);
+        }
         float xv[kDynMaxI];
 #pragma unroll
         for (int i = 0; i < kDynMaxI; ++i) xv[i] = i < ni ? xp[t * ni + i] : 0.0f;
@@ -152,8 +162,8 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < kDynMaxI; ++i) a = fmaf(c.da[i], xv[i], a);
         float broot = 0.0f;
-        if constexpr (ROOT == kDynRootDiode) broot = diode_pair<SYM>(a, logf(c.rp * root.Is / root.V), root.d).b;
-        if constexpr (ROOT == kDynRootMlp) broot = -row_mlp_fwd<NL>(RW, a, logf(c.rp), act);
+        if constexpr (ROOT == kDynRootDiode) broot = diode_pair<SYM>(a, lroot, root.d).b;
+        if constexpr (ROOT == kDynRootMlp) broot = -row_mlp_fwd<NL>(RW, a, lroot, act);
         float yv = c.fy * broot;
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s) yv = fmaf(c.cy[s], z[s], yv);
@@ -215,8 +225,12 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ gbroot, float* __restrict__ ain,
                                                         float* __restrict__ lrin, float* __restrict__ gz0, int ns, int ni,
                                                         int64_t B, int64_t T, int64_t Lc, float* __restrict__ rpart,
-                                                        float* __restrict__ rec, const float* __restrict__ lam_in, int hidden)
+                                                        float* __restrict__ rec, const float* __restrict__ lam_in, int hidden, int acc)
 {
+    // acc (round 6): the rows do not change in time -- ONE static row, or one row per SEQUENCE (a pot that is constant over a
+    // recording: dataimport.py:96 repeats the file's resistance down the channel) -- so dL/d(row entry) is wanted summed over the
+    // chunk's steps, not per sample: grow is then [K][kN1][B] (one partial per chunk and lane, double accumulators in registers at
+    // compile-time slots) instead of [T][kN1][B] -- 131 MB per call at 1340 x 2048 that only existed to be summed again.
     // (MODE 2 evaluates no root: it runs one lane per sequence whatever the root)
     using LN = DynLanes<(MODE == 2 ? kDynRootNone : ROOT)>;
     constexpr bool kEval = ROOT == kDynRootMlp && MODE != 2;      // the network is evaluated here: 16-lane rows
@@ -245,9 +259,23 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
             for (int s = 0; s < kDynMaxS; ++s) hom[j][s] = (j == s && j < ns) ? 1.0f : 0.0f;
     }
     double sL = 0.0, sV = 0.0;
+    // accumulators of the acc mode at fixed slots: A s*4+s2 | Bx 16+s*2+i | E 24+s | ca 28+s | da 32+i | cy 34+s | dy 38+i | fy 40 | R_port 41
+    [[maybe_unused]] double gacc[42];
+    if constexpr (MODE != 1) {
+#pragma unroll
+        for (int i = 0; i < 42; ++i) gacc[i] = 0.0;
+    }
     [[maybe_unused]] float act[NL];
+    DynRow c = dyn_load_row(cp + (t1 - 1) * ts, cs, L, ns, ni);    // (rows constant in time: read once, as in the forward)
+    [[maybe_unused]] float lroot = 0.0f;
+    if constexpr (ROOT == kDynRootDiode && MODE != 2) lroot = logf(c.rp * root.Is / root.V);
+    if constexpr (kEval) lroot = logf(c.rp);
     for (int64_t t = t1 - 1; t >= t0; --t) {
-        const DynRow c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
+        if (ts != 0 && t != t1 - 1) {                              // wave-uniform
+            c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
+            if constexpr (ROOT == kDynRootDiode && MODE != 2) lroot = logf(c.rp * root.Is / root.V);
+            if constexpr (kEval) lroot = logf(c.rp);
+        }
         float xv[kDynMaxI], z[kDynMaxS];
 #pragma unroll
         for (int i = 0; i < kDynMaxI; ++i) xv[i] = i < ni ? xp[t * ni + i] : 0.0f;
@@ -269,7 +297,7 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
             }
         } else
         if constexpr (ROOT == kDynRootDiode) {
-            const DiodeOut o = diode_pair<SYM>(a, logf(c.rp * root.Is / root.V), root.d);
+            const DiodeOut o = diode_pair<SYM>(a, lroot, root.d);
             broot = o.b;
             const float w0p = o.w0 * fast_rcp(1.0f + o.w0), w1p = o.w1 * fast_rcp(1.0f + o.w1);
             const float l2 = o.lam * o.lam, sp = w0p + w1p;
@@ -279,7 +307,7 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
             Drp = DL / c.rp;                                        // L = log(R_port Is / nVt)
         }
         if constexpr (kEval) {
-            lr = logf(c.rp);
+            lr = lroot;
             broot = -row_mlp_fwd<NL>(RW, a, lr, act);
             float da, dlr;
             row_mlp_grad_in<NL>(RW, act, da, dlr);
@@ -324,6 +352,25 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
                 }
             }
         } else if (writer) {
+        if (acc) {                                                  // wave-uniform: summed over the chunk's steps (entries past ns / ni stay 0)
+#pragma unroll
+            for (int s = 0; s < kDynMaxS; ++s) {
+#pragma unroll
+                for (int s2 = 0; s2 < kDynMaxS; ++s2) gacc[s * 4 + s2] += (double)(lam[s] * z[s2]);
+#pragma unroll
+                for (int i = 0; i < kDynMaxI; ++i) gacc[16 + s * 2 + i] += (double)(lam[s] * xv[i]);
+                gacc[24 + s] += (double)(lam[s] * broot);
+                gacc[28 + s] += (double)(ga * z[s]);
+                gacc[34 + s] += (double)(g * z[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < kDynMaxI; ++i) {
+                gacc[32 + i] += (double)(ga * xv[i]);
+                gacc[38 + i] += (double)(g * xv[i]);
+            }
+            gacc[40] += (double)(g * broot);
+            gacc[41] += (double)(gb * Drp);
+        } else {
         float* __restrict__ gp = grow + (t * L.n) * B + b;
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s) {
@@ -348,6 +395,7 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
         }
         gp[L.oFy * B] = g * broot;
         gp[L.oRp * B] = gb * Drp;
+        }
         if constexpr (ROOT == kDynRootDiode) {
             sL += (double)(gb * DL);
             sV += (double)(gb * DV);
@@ -389,6 +437,34 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int s = 0; s < kDynMaxS; ++s)
             if (s < ns) gz0[s * B + b] = lam[s];
+    }
+    if constexpr (MODE != 1) {
+        if (acc && writer && b_raw < B) {                          // the chunk's sums: grow [K][kN1][B]
+            float* __restrict__ gp = grow + (k * L.n) * B + b;
+#pragma unroll
+            for (int s = 0; s < kDynMaxS; ++s) {
+                if (s < ns) {
+#pragma unroll
+                    for (int s2 = 0; s2 < kDynMaxS; ++s2)
+                        if (s2 < ns) gp[(L.oA + s * ns + s2) * B] = (float)gacc[s * 4 + s2];
+#pragma unroll
+                    for (int i = 0; i < kDynMaxI; ++i)
+                        if (i < ni) gp[(L.oB + s * ni + i) * B] = (float)gacc[16 + s * 2 + i];
+                    gp[(L.oE + s) * B] = (float)gacc[24 + s];
+                    gp[(L.oCa + s) * B] = (float)gacc[28 + s];
+                    gp[(L.oCy + s) * B] = (float)gacc[34 + s];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kDynMaxI; ++i) {
+                if (i < ni) {
+                    gp[(L.oDa + i) * B] = (float)gacc[32 + i];
+                    gp[(L.oDy + i) * B] = (float)gacc[38 + i];
+                }
+            }
+            gp[L.oFy * B] = (float)gacc[40];
+            gp[L.oRp * B] = (float)gacc[41];
+        }
     }
     if constexpr (ROOT == kDynRootDiode) {
         if (!live) { sL = 0.0; sV = 0.0; }

@@ -1158,6 +1158,19 @@ def ss_tp_status(status):
     return {"n_bad": int(s[0]), "max_miss": float(s[1:2].view(torch.float32)[0]), "gated_waves": int(s[2])}
 
 
+def _dyn_rows_mode(rows, T, n, B, who):
+    """per_sample argument of the wdf_ss_dyn_* entry points from the rows' shape: [n] -> 0 (one static row), [T,n,B] -> 1 (a row
+    per sample), [1,n,B] with T > 1 -> 2 (a row per sequence: constant along the time axis)."""
+    shp = tuple(rows.shape)
+    if n and shp == (n,):
+        return 0
+    if n and shp == (T, n, B):
+        return 1
+    if n and shp == (1, n, B):
+        return 2
+    raise WdfHipError(f"{who}: rows [T,{n},B] (per sample), [1,{n},B] (per sequence) or [{n}] (static), got {shp}")
+
+
 def ss_dyn_fwd(x, rows, ns, ni, root_kind=ROOT_NONE, rootp=None, w=None, hidden=0, n_tanh=0, n_up=1, n_down=1, want_stash=True,
                z0=None, want_zT=False):
     """State-space recursion with streamed coefficient rows / the MLP root on any small tree (wdf_ss_dyn_fwd).
@@ -1167,13 +1180,13 @@ def ss_dyn_fwd(x, rows, ns, ni, root_kind=ROOT_NONE, rootp=None, w=None, hidden=
     x, rows, rootp, w, z0 = _f32_dev(x, "x"), _f32_dev(rows, "rows"), _f32_dev(rootp, "rootp"), _f32_dev(w, "w"), _f32_dev(z0, "z0")
     B, T = int(x.shape[0]), int(x.shape[1])
     n = lib().wdf_ss_dyn_row_len(int(ns), int(ni))
-    per = rows.dim() == 3
-    if n == 0 or tuple(rows.shape) not in ((T, n, B), (n,)) or x.dim() != 3 or int(x.shape[2]) != ni:
-        raise WdfHipError(f"ss_dyn_fwd: x [B,T,{ni}], rows [T,{n},B] or [{n}] (got x {tuple(x.shape)}, rows {tuple(rows.shape)})")
+    if x.dim() != 3 or int(x.shape[2]) != ni:
+        raise WdfHipError(f"ss_dyn_fwd: x [B,T,{ni}] (got {tuple(x.shape)})")
+    per = _dyn_rows_mode(rows, T, n, B, "ss_dyn_fwd")
     y = torch.empty((T, B), dtype=torch.float32, device=x.device)
     zs = torch.empty((T, max(ns, 1), B), dtype=torch.float32, device=x.device) if (want_stash and ns > 0) else None
     zT = torch.empty((max(ns, 1), B), dtype=torch.float32, device=x.device) if want_zT else None
-    rc = lib().wdf_ss_dyn_fwd(_ptr(x), _ptr(rows), 1 if per else 0, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
+    rc = lib().wdf_ss_dyn_fwd(_ptr(x), _ptr(rows), per, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
                               int(n_tanh), int(n_up), int(n_down), _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, _stream())
     _check(rc, "wdf_ss_dyn_fwd")
     return y, zs, zT
@@ -1181,21 +1194,23 @@ def ss_dyn_fwd(x, rows, ns, ni, root_kind=ROOT_NONE, rootp=None, w=None, hidden=
 
 def ss_dyn_bwd(x, rows, ns, ni, zstash, gy, root_kind=ROOT_NONE, rootp=None, w=None, hidden=0, n_tanh=0, n_up=1, n_down=1, want_gz0=False):
     """Reverse sweep of ss_dyn_fwd for dL/dy = gy [T,B] (wdf_ss_dyn_bwd).
-    -> grows [T,n,B] (dL/d row entry of every sample), groot (diode: float64 [2] = dL/d{Is, nVt}; MLP: the flat weight gradient;
+    -> grows [T,n,B] (dL/d row entry of every sample; rows constant in time -- [n] or [1,n,B] -- : [1,n,B], summed over the steps by
+    the kernel), groot (diode: float64 [2] = dL/d{Is, nVt}; MLP: the flat weight gradient;
     else None), gz0 [ns,B] | None."""
     require_gpu()
     x, rows, rootp, w = _f32_dev(x, "x"), _f32_dev(rows, "rows"), _f32_dev(rootp, "rootp"), _f32_dev(w, "w")
     zstash, gy = _f32_dev(zstash, "zstash"), _f32_dev(gy, "gy")
     B, T = int(x.shape[0]), int(x.shape[1])
     n = lib().wdf_ss_dyn_row_len(int(ns), int(ni))
-    per = rows.dim() == 3
+    per = _dyn_rows_mode(rows, T, n, B, "ss_dyn_bwd")
     dev = x.device
-    grows = torch.empty((T, n, B), dtype=torch.float32, device=dev)
+    # per sample: dL/d(row) of every sample [T,n,B]; rows constant in time: the kernel's own sum over the steps [1,n,B]
+    grows = torch.empty((T if per == 1 else 1, n, B), dtype=torch.float32, device=dev)
     ws = torch.zeros(((B + 63) // 64, 2), dtype=torch.float64, device=dev)
     mlp = root_kind == ROOT_MLP
     gb, ain, lrin = (torch.empty((T, B), dtype=torch.float32, device=dev) for _ in range(3)) if mlp else (None, None, None)
     gz0 = torch.empty((max(ns, 1), B), dtype=torch.float32, device=dev) if want_gz0 else None
-    rc = lib().wdf_ss_dyn_bwd(_ptr(x), _ptr(rows), 1 if per else 0, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
+    rc = lib().wdf_ss_dyn_bwd(_ptr(x), _ptr(rows), per, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
                               int(n_tanh), int(n_up), int(n_down), _ptr(zstash), _ptr(gy), _ptr(grows), _ptr(ws), _ptr(gb), _ptr(ain),
                               _ptr(lrin), _ptr(gz0), B, T, _stream())
     _check(rc, "wdf_ss_dyn_bwd")
@@ -1227,9 +1242,9 @@ def ss_dyn_fwd_tp(x, rows, ns, ni, n_chunks, warmup, tol=1.0e-6, root_kind=ROOT_
     zinit = _f32_dev(zinit, "zinit")
     B, T = int(x.shape[0]), int(x.shape[1])
     n = lib().wdf_ss_dyn_row_len(int(ns), int(ni))
-    per = rows.dim() == 3
-    if n == 0 or tuple(rows.shape) not in ((T, n, B), (n,)) or x.dim() != 3 or int(x.shape[2]) != ni:
-        raise WdfHipError(f"ss_dyn_fwd_tp: x [B,T,{ni}], rows [T,{n},B] or [{n}] (got x {tuple(x.shape)}, rows {tuple(rows.shape)})")
+    if x.dim() != 3 or int(x.shape[2]) != ni:
+        raise WdfHipError(f"ss_dyn_fwd_tp: x [B,T,{ni}] (got {tuple(x.shape)})")
+    per = _dyn_rows_mode(rows, T, n, B, "ss_dyn_fwd_tp")
     K = dyn_chunks(T, n_chunks)
     if zinit is not None and tuple(zinit.shape) != (K, ns, B):
         raise WdfHipError(f"ss_dyn_fwd_tp: zinit must be [{K},{ns},{B}], got {tuple(zinit.shape)}")
@@ -1238,7 +1253,7 @@ def ss_dyn_fwd_tp(x, rows, ns, ni, n_chunks, warmup, tol=1.0e-6, root_kind=ROOT_
     zT = torch.empty((ns, B), dtype=torch.float32, device=x.device) if want_zT else None
     ws = torch.empty((lib().wdf_ss_dyn_fwd_tp_ws_bytes(int(ns), B, K),), dtype=torch.uint8, device=x.device)
     status = torch.zeros((4,), dtype=torch.int32, device=x.device)
-    rc = lib().wdf_ss_dyn_fwd_tp(_ptr(x), _ptr(rows), 1 if per else 0, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
+    rc = lib().wdf_ss_dyn_fwd_tp(_ptr(x), _ptr(rows), per, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
                                  int(n_tanh), int(n_up), int(n_down), _ptr(y), _ptr(zs), _ptr(z0), _ptr(zT), B, T, K, int(warmup),
                                  float(tol), _ptr(zinit), _ptr(ws), _ptr(status), _stream())
     _check(rc, "wdf_ss_dyn_fwd_tp")
@@ -1311,15 +1326,16 @@ def ss_dyn_bwd_tp(x, rows, ns, ni, zstash, gy, n_chunks, root_kind=ROOT_NONE, ro
     zstash, gy = _f32_dev(zstash, "zstash"), _f32_dev(gy, "gy")
     B, T = int(x.shape[0]), int(x.shape[1])
     n = lib().wdf_ss_dyn_row_len(int(ns), int(ni))
-    per = rows.dim() == 3
+    per = _dyn_rows_mode(rows, T, n, B, "ss_dyn_bwd_tp")
     dev = x.device
     K = dyn_chunks(T, n_chunks)
-    grows = torch.empty((T, n, B), dtype=torch.float32, device=dev)
+    # per sample: [T,n,B]; rows constant in time: one partial per chunk [K,n,B], added up below
+    grows = torch.empty((T if per == 1 else K, n, B), dtype=torch.float32, device=dev)
     ws = torch.empty((lib().wdf_ss_dyn_bwd_tp_ws_bytes(int(ns), B, T, K),), dtype=torch.uint8, device=dev)
     mlp = root_kind == ROOT_MLP
     gb, ain, lrin = (torch.empty((T, B), dtype=torch.float32, device=dev) for _ in range(3)) if mlp else (None, None, None)
     gz0 = torch.empty((ns, B), dtype=torch.float32, device=dev) if want_gz0 else None
-    rc = lib().wdf_ss_dyn_bwd_tp(_ptr(x), _ptr(rows), 1 if per else 0, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
+    rc = lib().wdf_ss_dyn_bwd_tp(_ptr(x), _ptr(rows), per, int(ns), int(ni), int(root_kind), _ptr(rootp), _ptr(w), int(hidden),
                                  int(n_tanh), int(n_up), int(n_down), _ptr(zstash), _ptr(gy), _ptr(grows), _ptr(ws), _ptr(gb), _ptr(ain),
                                  _ptr(lrin), _ptr(gz0), B, T, K, _stream())
     _check(rc, "wdf_ss_dyn_bwd_tp")
@@ -1331,6 +1347,8 @@ def ss_dyn_bwd_tp(x, rows, ns, ni, zstash, gy, n_chunks, root_kind=ROOT_NONE, ro
         groot = torch.stack([s[0] / rp[0], s[1] - s[0] / rp[1]])
     elif mlp:
         groot = clipper_mlp_wgrad(ain.reshape(-1), lrin.reshape(-1), gb.reshape(-1), None, w, hidden, n_tanh, 1.0)
+    if per != 1:
+        grows = grows.sum(dim=0, keepdim=True, dtype=torch.float64).float() if K > 1 else grows      # [1,n,B]: the chunks in order
     return grows, groot, gz0
 
 

@@ -250,7 +250,7 @@ class _SsDynFn(torch.autograd.Function):
         if warm is not None and z0 is None and zs is not None:
             warm.finish(zs, st, hot is not None, tp.warmup if (tp is not None and st is not None) else 0)
         ctx.tp = tp
-        ctx.cfg = (ns, ni, kind, hidden, n_tanh, n_up, n_down, z0 is not None, rows.dim() == 3)
+        ctx.cfg = (ns, ni, kind, hidden, n_tanh, n_up, n_down, z0 is not None, rows.dim() == 3)   # (3 dims: [T,n,B] or [1,n,B])
         ctx.save_for_backward(r, rv, x, zs)
         if want_zT:
             ctx.mark_non_differentiable(zT)
@@ -272,9 +272,9 @@ class _SsDynFn(torch.autograd.Function):
             grows, groot, gz0 = binding.ss_dyn_bwd(x, r, ns, ni, zs, gy.contiguous(), kind, rootp=rootp, w=w, hidden=hidden, n_tanh=n_tanh,
                                                    n_up=n_up, n_down=n_down, want_gz0=has_z0)
         if not per_sample:
-            # static row: the kernel's per-sample products [T,n,B] reduced to n numbers, accumulated in float64 INSIDE the
-            # reduction (no float64 copy of the array: at 8192 x 4096 that copy alone was 2.4 GB), sequences first, then time
-            grows = grows.sum(dim=2, dtype=torch.float64).sum(dim=0).float()
+            # static row: the kernel summed over the steps itself (float64 accumulators, grows [1,n,B]: no [T,n,B] array of
+            # per-sample products exists any more); what is left is the sum over the sequences
+            grows = grows.sum(dim=(0, 2), dtype=torch.float64).float()
         return (grows, None if groot is None else groot.float(), None, (gz0[:ns] if has_z0 else None), None, None, None, None, None,
                 None, None, None, None, None)
 
@@ -559,6 +559,45 @@ class _LinResident:
         return out, loss
 
 
+class _DynResident:
+    """Circuit.to_device() of a circuit that runs on the streamed-coefficient kernels (per-sample impedance / an MLP root outside
+    the clipper topology, csrc/wdf_ss_dyn.h): the scalar component Variables (and a diode root's Is, nVt) become 0-dim views of one
+    device block (compat_tf.ParamBlock: same objects, same constraints, same autograd leaves; tf.keras.optimizers.Adam updates
+    them on the device), a DenseRootModel's kernels and biases views of one flat device vector.  _run_dyn is unchanged -- it
+    only ever handed these values to device code; what goes is the host round trip per Variable and step."""
+
+    def __init__(self, circ, device):
+        own = {"Resistor": "R", "ResistiveVoltageSource": "R", "Capacitor": "C"}
+        params = [(e, own[_kind(e)]) for e in circ.elements if _kind(e) in own]
+        if circ.root_kind == "DiodePair":
+            params += [(circ.root, "Is"), (circ.root, "nVt")]
+        pvars = [e.__dict__[n] for e, n in params]
+        for (e, n), v in zip(params, pvars):
+            if isinstance(v, torch.Tensor) and not getattr(v, "_is_tf_variable", False) and (v.requires_grad or v.grad_fn is not None):
+                raise binding.WdfHipError(f"Circuit.to_device: {type(e).__name__}.{n} is a tensor computed from other Variables -- "
+                                          "keep this circuit on the host path")
+            if isinstance(v, torch.Tensor) and getattr(v, "_wdf_block", None) is not None:
+                raise binding.WdfHipError("Circuit.to_device: a component Variable already lives in another circuit's block")
+        self.pb = tf.ParamBlock([float(v) for v in pvars], torch.device(device))
+        for i, v in enumerate(pvars):
+            if isinstance(v, torch.Tensor) and getattr(v, "_is_tf_variable", False) and v.numel() == 1:
+                self.pb.adopt(i, v)
+        self.w = None
+        if circ.root_kind == "DenseRootModel":
+            from . import mlp_root
+            dense, _, _ = mlp_root.describe(circ.root)
+            self.w = mlp_root.flat_weights(dense).detach().float().to(device).contiguous()
+            o = 0
+            for d in dense:
+                for v in (d.kernel, d.bias):
+                    n = v.numel()
+                    if getattr(v, "_wdf_flat", None) is not None:
+                        raise binding.WdfHipError("Circuit.to_device: this network's weights already live in another circuit's vector")
+                    with torch.no_grad():
+                        v.data = self.w[o:o + n].view(v.shape)
+                    o += n
+
+
 class _ProbeFn(torch.autograd.Function):
     """(coef float32 [ncoef], rootp float32 [3] | None) of a resident tree from its parameter block, on the device
     (wdf_ss_probe); backward contracts dLoss/d coef with the probe's Jacobian -- calc_impedance's chain rule
@@ -711,11 +750,14 @@ class Circuit:
         Variable still work: they copy back on demand).  Diode-clipper topology only: the generic lowering differentiates
         its float64 probe on the host and needs the Variables there.  Returns self."""
         binding.require_gpu()
-        if any(getattr(self, a, None) is not None for a in ("_lin", "_pblock", "_tree", "_mlp")):
+        if any(getattr(self, a, None) is not None for a in ("_lin", "_pblock", "_tree", "_mlp", "_dynres")):
             return self
         if self._dyn:
-            raise binding.WdfHipError("Circuit.to_device: a per-sample impedance / an MLP root outside the clipper topology runs on the "
-                                      "streamed-coefficient kernels with host-resident component values (no resident step)")
+            # (round 6) the streamed-coefficient path has no one-pass step, but nothing in it needs the component values on the
+            # host either: they move into a device block (the tape interpreter, the kernels and the optimizers read them there),
+            # a network root's weights into one flat device vector -- a training loop then makes no host round trip per step
+            self._dynres = _DynResident(self, device)
+            return self
         if self.root_kind == "DenseRootModel":
             if not self._is_clipper():
                 raise binding.WdfHipError("the MLP root is supported on the diode-clipper topology (clipper_pot.py:94-101)")
@@ -1058,6 +1100,9 @@ class Circuit:
         dev = x.device
         B, T = int(x.shape[0]), int(x.shape[1])
         own = {"Resistor": "R", "ResistiveVoltageSource": "R", "Capacitor": "C"}
+        res = getattr(self, "_dynres", None)
+        if res is not None:
+            res.pb.flush()                                   # (queued optimizer updates of the block go out before anything reads it)
         if getattr(self, "_dyn_tape", None) is None:
             params = [(e, own[_kind(e)]) for e in self.elements if _kind(e) in own]
             pvars = [e.__dict__[n] for e, n in params]
@@ -1069,10 +1114,32 @@ class Circuit:
         if rtape is None:
             rtape = self._dyn_rtape = binding.RowsTape(*tape.packed(), outs)
         on_device = rtape.fits(len(params)) and len(rtape.ops) <= DYN_ROWS_MAX_OPS and not x.requires_grad
+        # A pot that keeps its value along every sequence (the reference's recordings: dataimport.py:96 repeats the file's
+        # resistance down the whole channel, batch_data cuts sequences out of it): calc_impedance gives ONE row per sequence --
+        # the tape runs over B values instead of B x T, the kernels read rows [1,n,B] and the sweep sums dL/d(row) over the
+        # steps itself.  Looked at once per input tensor (one comparison pass, cached on the storage).
+        per_seq = False
+        if chan >= 0 and not x.requires_grad and T > 1 and getattr(self, "per_sequence_rows", True):
+            with torch._C.DisableTorchFunctionSubclass():
+                ckey = tensor_key(self._anchor) if isinstance(getattr(self, "_anchor", None), torch.Tensor) else None
+            cache = self.__dict__.setdefault("_dyn_chan_const", {})
+            if ckey is not None and ckey in cache:
+                per_seq = cache[ckey]
+            else:
+                with torch.no_grad():
+                    rch = x[:, :, self.ni]
+                    per_seq = bool((rch == rch[:, :1]).all())
+                if ckey is not None:
+                    if len(cache) > 16:
+                        cache.clear()
+                    cache[ckey] = per_seq
         vals = []
         for i, (e, n) in enumerate(params):
             if i == chan:
                 # the resistance channel: [T,B] for the device tape, [B,T] float64 for torch's
+                if per_seq:
+                    vals.append(x[:, :1, self.ni].t().contiguous() if on_device else x[:, :1, self.ni].double())
+                    continue
                 vals.append(x[:, :, self.ni].t().contiguous() if on_device else x[:, :, self.ni].double())
             else:
                 v = e.__dict__[n]
@@ -1087,8 +1154,9 @@ class Circuit:
                 # (a tape past the device evaluator's sizes, or a channel that wants its own gradient: torch runs the tape)
                 nodes = tape.evaluate_torch(vals, outs)
                 if self.per_sample_R is not None:
-                    rows = torch.stack([torch.broadcast_to(v, (B, T)) for v in nodes], dim=0)       # [n,B,T]
-                    rows = rows.permute(2, 0, 1).float().contiguous()                                # [T,n,B]
+                    Tr = 1 if per_seq else T
+                    rows = torch.stack([torch.broadcast_to(v, (B, Tr)) for v in nodes], dim=0)      # [n,B,T]
+                    rows = rows.permute(2, 0, 1).float().contiguous()                                # [T,n,B] ([1,n,B]: per sequence)
                 else:
                     rows = torch.stack([v.reshape(()) for v in nodes]).float()                       # one static row [n]
         hidden = n_tanh = 0

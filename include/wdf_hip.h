@@ -477,13 +477,18 @@ size_t wdf_ss_bwd_ws_bytes(int ns, int ni, int64_t B);
  *     calc_impedance every step (clipper_pot.py:116-117) -- the host evaluates the probed step's coefficients over the whole
  *     resistance channel and hands one ROW per (sample, sequence);
  *   - layers.DenseRootModel terminating the tree (layers.py:72-82): b = -MLP(a, log R_port) (clipper_pot.py:119-121).
- * rows       per_sample = 1: device float [T][n][B]; per_sample = 0: ONE row, float [n];  n = wdf_ss_dyn_row_len(ns, ni) =
+ * rows       per_sample = 1: device float [T][n][B]; per_sample = 0: ONE row, float [n]; per_sample = 2 (round 6): one row per
+ *            SEQUENCE, float [n][B] -- a pot that keeps its value over a recording (dataimport.py:96 repeats the file's
+ *            resistance down the channel): calc_impedance's result does not change along the sequence;
+ *            n = wdf_ss_dyn_row_len(ns, ni) =
  *            wdf_ss_ncoef(ns, ni) + 1:  A | Bx | E | ca | da | cy | dy | fy | R_port   (the coef layout above, then the port resistance)
  * root       WDF_ROOT_NONE, WDF_ROOT_DIODE_PAIR (rootp = device float[2] {Is, nVt}; R_port comes from the row) or WDF_ROOT_MLP
  *            (w: flat weights, hidden in {4, 8, 16} with 3 tanh layers, {4, 8} with 5; tanh only)
  * x [B][T][ni]; y, gy [T][B]; zstash [T][ns][B]; z0 / zT / gz0 [ns][B] (optional).
- * wdf_ss_dyn_bwd: reverse sweep for dL/dy = gy.  grows [T][n][B] receives dL/d(row entry) of EVERY sample (per_sample = 0: the
- *            caller sums over T and B); ws (wdf_ss_dyn_bwd_ws_bytes): double [(B+63)/64][2] = per-wave {sum gb D_L, sum gb D_V}
+ * wdf_ss_dyn_bwd: reverse sweep for dL/dy = gy.  per_sample = 1: grows [T][n][B] receives dL/d(row entry) of EVERY sample.
+ *            per_sample = 0 / 2 (round 6: rows constant in time): the kernel sums over the steps itself (float64 accumulators):
+ *            grows [K][n][B], K = 1 (wdf_ss_dyn_bwd) or the chunk count (wdf_ss_dyn_bwd_tp) -- the caller adds the K partials
+ *            (per_sample = 0: and the B sequences); ws (wdf_ss_dyn_bwd_ws_bytes): double [(B+63)/64][2] = per-wave {sum gb D_L, sum gb D_V}
  *            of a diode root (dL/dIs = S_L / Is, dL/dnVt = S_V - S_L / nVt); MLP root: gb, ain, lrin [T][B] receive dL/db, a and
  *            log R_port of every step -- the operands of wdf_clipper_mlp_wgrad (gw = -sum gb dMLP/dw).
  * One lane per sequence, sequential in time: the general path (the clipper topology keeps its own kernels).

@@ -100,6 +100,56 @@ def test_hpf_clipper_with_a_pot_channel_diode_root(wdf, oracle, pot_on, B, T):
     assert grads[dead] is None or float(grads[dead]) == 0.0
 
 
+@pytest.mark.parametrize("root,pot_on,B,T", [("diode", "Vs", 70, 1024), ("diode", "R", 37, 300), ("mlp", "Vs", 40, 512), ("diode", "Vs", 130, 8)])
+def test_a_pot_that_is_constant_along_each_sequence_takes_one_row_per_sequence(wdf, oracle, golden, root, pot_on, B, T):
+    """The reference's recordings hold ONE pot value per file (dataimport.py:96 repeats it down the channel; batch_data,
+    clipper_pot.py:61-80, cuts the sequences out of it): the resistance channel is constant along every sequence.  The lowering
+    notices (one comparison pass per input tensor) and hands the kernels one coefficient row per SEQUENCE -- rows [1,n,B], the
+    tape run over B values instead of B x T, dL/d(row) summed over the steps inside the sweep (wdf_ss_dyn_bwd, per_sample = 2).
+    Against the oracle (y, every gradient), and against the per-sample path on the same data (y bit for bit)."""
+    tf = wdf.tf
+    O = oracle
+    rng = np.random.default_rng(B + T + 5)
+    x = (1.5 * rng.standard_normal((B, T))).astype(np.float32)
+    grid = np.array([300.0, 1.0e3, 2.5e3, 5.0e3]) if pot_on == "Vs" else np.array([10.0e3, 25.2e3, 45.2e3, 75.0e3, 99.1e3])
+    r = np.repeat(grid[np.arange(B) % len(grid)][:, None], T, axis=1).astype(np.float32)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    if root == "diode":
+        vals = [33.0e3, 1.0e3, 22.0e-9, 4.352e-9, 25.85e-3 * 1.906]
+        net, oc, theta = None, hpf_oracle(O, "diode", pot_on), None
+        theta = np.array(vals, dtype=np.float32).astype(np.float64)
+    else:
+        vals = [33.0e3, 1.0e3, 22.0e-9]
+        net, wts, sizes = _net(golden, "2x8")
+        acts = [O.ACT_TANH] * (len(sizes) - 2) + [O.ACT_NONE]
+        oc = hpf_oracle(O, "mlp", pot_on, sizes=sizes, acts=acts)
+        theta = np.concatenate([np.array(vals, dtype=np.float32).astype(np.float64), wts.astype(np.float32).astype(np.float64)])
+    xin = cuda(np.stack([x, r], axis=-1))
+    out = {}
+    for per_seq in (True, False):
+        circ, params, rt = build_hpf(wdf, root, pot_on, vals, net)
+        circ.per_sequence_rows = per_seq
+        with tf.GradientTape() as tape:
+            y = circ(xin)
+            loss = tf.reduce_sum(y * cuda(gy))
+        grads = tape.gradient(loss, params)
+        out[per_seq] = (y.as_subclass(torch.Tensor).detach().clone(), [None if g is None else float(g) for g in grads])
+        if per_seq and T > 1:
+            assert list(circ._dyn_chan_const.values()) == [True]
+    assert torch.equal(out[True][0], out[False][0])                       # the same coefficients at every step: the same y
+    xin64 = np.stack([x, r], axis=-1).astype(np.float64)
+    y_ref = O.tree_fwd(oc, theta, xin64)
+    assert np.max(np.abs(out[True][0].cpu().numpy() - y_ref)) < 3e-6
+    n_comp = 5 if root == "diode" else 3
+    live = [i for i in range(n_comp) if not (i == 0 and pot_on == "R") and not (i == 1 and pot_on == "Vs")]
+    g_ref = O.tree_grad(oc, theta, xin64, gy.astype(np.float64), params=live)
+    got = np.array([out[True][1][i] for i in live])
+    got_ps = np.array([out[False][1][i] for i in live])
+    print(f"{root} pot on {pot_on} {B} x {T}: gradients vs oracle {rel(got, g_ref):.2e} (per-sample path {rel(got_ps, g_ref):.2e})")
+    assert rel(got, g_ref) < 3e-4, (got, g_ref)
+    assert rel(got, got_ps) < 1e-4
+
+
 def _net(golden, name):
     from test_gpu_mlp_root import model_json
     g = golden("g3_mlp_clipper.npz")
@@ -280,8 +330,54 @@ def test_what_the_streamed_kernels_refuse(wdf, golden):
     circ = wdf.Circuit(wdf.Parallel(Rr, wdf.Series(Vr, Cr)), DenseRootModel(js), Rr)
     with pytest.raises(wb.WdfHipError, match="tanh"):
         circ(cuda(np.zeros((2, 16))))
-    with pytest.raises(wb.WdfHipError, match="streamed-coefficient"):
+    with pytest.raises(wb.WdfHipError, match="tanh"):             # (to_device() of a streamed-coefficient circuit: round 6)
         circ.to_device()
+
+
+@pytest.mark.parametrize("root", ["diode", "mlp"])
+def test_streamed_coefficient_circuit_trains_with_resident_components(wdf, golden, root):
+    """Circuit.to_device() on HPFDiodeClipper.h's tree with a pot channel (round 6): the component Variables (and the diode's
+    Is, nVt / the network's weights) live on the device, tape.gradient hands back device tensors, tf.keras.optimizers.Adam
+    updates them there.  lpf.py:86-99's loop shape (one Adam per component) for eight epochs ends at the parameters the same
+    loop reaches with host-resident Variables."""
+    tf = wdf.tf
+    B, T = 48, 512
+    rng = np.random.default_rng(11)
+    x = (1.2 * rng.standard_normal((B, T))).astype(np.float32)
+    grid = np.array([300.0, 1.0e3, 2.5e3, 5.0e3])
+    r = np.repeat(grid[np.arange(B) % 4][:, None], T, axis=1).astype(np.float32)
+    tgt = cuda(0.2 * rng.standard_normal((T, B)))
+    xin = cuda(np.stack([x, r], axis=-1))
+    vals = [33.0e3, 1.0e3, 22.0e-9, 4.352e-9, 25.85e-3 * 1.906] if root == "diode" else [33.0e3, 1.0e3, 22.0e-9]
+    net = _net(golden, "2x8")[0] if root == "mlp" else None
+    ends = {}
+    for resident in (False, True):
+        circ, params, rt = build_hpf(wdf, root, "Vs", vals, net)
+        train = [p for i, p in enumerate(params) if i != 1]                       # (the source resistance is the streamed one)
+        weights = list(rt.trainable_variables) if root == "mlp" else []
+        if resident:
+            circ.to_device()
+            assert all(p.is_cuda for p in train + weights)
+        opts = [tf.keras.optimizers.Adam(learning_rate=1.0e-3 * abs(float(p))) for p in train]
+        wopt = tf.keras.optimizers.Adam(learning_rate=1.0e-4) if weights else None
+        losses = []
+        for epoch in range(8):
+            with tf.GradientTape() as tape:
+                y = circ(xin)
+                loss = tf.reduce_mean(tf.square(y - tgt))
+            g = tape.gradient(loss, train + weights)
+            for o, gi, p in zip(opts, g, train):
+                o.apply_gradients([(gi, p)])
+            if weights:
+                wopt.apply_gradients(zip(g[len(train):], weights))
+            losses.append(float(loss))
+        ends[resident] = (np.array([float(p) for p in train]), [w.detach().cpu().numpy().copy() for w in weights], losses)
+    a, b = ends[False], ends[True]
+    print(f"{root}: losses host {a[2][0]:.6e} -> {a[2][-1]:.6e}, resident {b[2][0]:.6e} -> {b[2][-1]:.6e}; components differ by {rel(b[0], a[0]):.2e}")
+    assert rel(b[0], a[0]) < 2e-5 and abs(b[2][-1] - a[2][-1]) < 1e-4 * a[2][-1]
+    assert np.max(np.abs(a[0] / np.array([v for i, v in enumerate(vals) if i != 1]) - 1.0)) > 1e-3   # (they really moved)
+    for wa, wb_ in zip(a[1], b[1]):
+        assert np.max(np.abs(wa - wb_)) < 2e-6
 
 
 @pytest.mark.parametrize("root,pot_on,B,T,fast", [("diode", "Vs", 70, 1000, True), ("mlp", "Vs", 40, 515, True), ("mlp", None, 130, 2048, False),

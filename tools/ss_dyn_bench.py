@@ -42,8 +42,10 @@ def build(root):
     return wdf.Circuit(top, rt, R, per_sample_R=Vs), params
 
 
-for root in ("diode", "mlp2x16"):
+for root, resident in (("diode", False), ("diode", True), ("mlp2x16", False), ("mlp2x16", True)):
     circ, params = build(root)
+    if resident:                                               # round 6: component values / weights on the device (Circuit.to_device)
+        circ.to_device()
 
     opts = [tf.keras.optimizers.Adam(learning_rate=(1.0e-3 * abs(float(p)) if p.numel() == 1 else 1.0e-4)) for p in params]
 
@@ -77,6 +79,7 @@ for root in ("diode", "mlp2x16"):
         for _, ws in circ.__dict__["_dyn_warm"].values():
             print("# warm-ups of the last calls:", list(ws.trace)[-24:], file=sys.stderr)
             print("# verdicts (warm-up, n_bad, max miss, gated groups, -):", list(ws.ctl.verdicts)[-12:], file=sys.stderr)
-    print(json.dumps({"tree": "HPF clipper, pot on the source resistance", "root": root, "B": B, "T": T, "ms_per_fwd_bwd": ms,
+    print(json.dumps({"tree": "HPF clipper, pot on the source resistance (one value per sequence, dataimport.py:96)", "root": root,
+                      "components": "device block (Circuit.to_device)" if resident else "host Variables", "B": B, "T": T, "ms_per_fwd_bwd": ms,
                       "samples_per_s": B * T / ms * 1e3, "fwd_kernel_ms": e[0].elapsed_ms(e[1]), "bwd_kernel_ms": e[2].elapsed_ms(e[3]),
                       "fwd_chunks": wdf._lowering.LAST_SS_TP_STATUS.get("chunks_used"), "fwd_warmup": wdf._lowering.LAST_SS_TP_STATUS.get("warmup_used")}))
