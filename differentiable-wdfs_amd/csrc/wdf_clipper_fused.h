@@ -276,6 +276,45 @@ __device__ __forceinline__ V fused_step(const ClipConsts& c, V xin, V rin, V tgt
     // partials of the root (wdf_clipper.h, bwd_step / bwd_tp_step)
     const V w0p = o.w0 * vrcp(o.w0 + 1.0f);
     V Da, DL, DV;
+    if constexpr (SYM && FAST == kRootLean && !DYN_R) {
+        // LEAN (round 6: three packed instructions less): the constant factors of D_L (-2 nVt N) and D_V (-1 / nVt) are left out
+        // of the per-step partials -- the tangent recurrences and their sums are linear in them, fused_publish_record puts the
+        // factors back (FusedScale) -- and kappa = Da (1 - p) - p, cP = -(1 + Da) b_diff are formed without 1 + Da.
+        const V w1p = vfma(-o.w1, o.w1, o.w1);                      // omega_1 <= 5.6e-4 (root_tier): w (1 - w)
+        const V sp = w0p + w1p;
+        const V tl = vsel_nonzero(a, -2.0f, 0.0f);                  // -2 lam^2
+        const float tvm = c.d.two_v * c.d.m_dn;
+        Da = vfma(tl, sp, 1.0f);
+        DL = vcopysign(w0p - w1p, a);                               // x (-2 nVt N)
+        DV = vfma(tl * a, sp, tvm * vcopysign(o.dw, a));            // x (-1 / nVt):  D_V = -(tl a sp + (a - b)) / nVt
+        const V cPl = vfma(-Da, b_diff, -b_diff);
+        const V kappa_l = vfma(Da, 1.0f - c.p, -c.p);
+        const V d = y - tgt;
+        const V hg = hgs * d;
+        s.sse = vfma(hg, d, s.sse);
+        const V hh = hg + s.hg_prev;
+        s.hg_prev = hg;
+        s.GA = vfma(hh, s.A, s.GA);
+        s.GL = vfma(hh, s.cL, s.GL);
+        s.GV = vfma(hh, s.cV, s.GV);
+        s.GP = vfma(hh, s.cP, s.GP);
+        if constexpr (LOSS == 2) {
+            const V hy = hgs * y;
+            s.syy = vfma(hy, y, s.syy);
+            const V h2 = hy + s.hy_prev;
+            s.hy_prev = hy;
+            s.HA = vfma(h2, s.A, s.HA);
+            s.HL = vfma(h2, s.cL, s.HL);
+            s.HV = vfma(h2, s.cV, s.HV);
+            s.HP = vfma(h2, s.cP, s.HP);
+        }
+        s.A = s.A * kappa_l;
+        s.cL = vfma(kappa_l, s.cL, DL);
+        s.cV = vfma(kappa_l, s.cV, DV);
+        s.cP = vfma(kappa_l, s.cP, cPl);
+        z = zn;
+        return y;
+    } else
     if constexpr (SYM && FAST) {
         // omega_1 <= omega(-4) = 0.018 here (series-only region, checked once per kernel): omega/(1 + omega) by
         // its alternating series to the cubic term (next term 1e-7 relative) instead of a reciprocal.
@@ -371,9 +410,14 @@ struct FusedSums {
 // sums.  wpart: double [tiles][K][NSEQ][NP]; `slot0`: the first sequence slot this call covers (the repair re-runs one slot
 // of 64 sequences at a time with V = float).  Dead lanes (past the end of the batch) add nothing to the sums and keep a
 // record slot of their own.
+// What the LEAN step leaves out of its per-step partials (fused_step): cL, GL, HL carry D_L / (-2 nVt N), cV, GV, HV carry
+// D_V / (-1 / nVt); every other tier runs with {1, 1}.
+struct FusedScale { float L, V; };
+
 template <typename V, int LOSS, int NSEQ>
 __device__ __forceinline__ void fused_publish_record(float* rec, double* wpart, int64_t k, int64_t K, bool live,
-                                                     int slot0, const FusedTan<V>& s, const FusedSums<V>& d, float hgs)
+                                                     int slot0, const FusedTan<V>& s, const FusedSums<V>& d, float hgs,
+                                                     FusedScale fsc = FusedScale{1.0f, 1.0f})
 {
     constexpr int NREC = FusedRec<LOSS>::N, NP = FusedRec<LOSS>::NP, NQ = FusedQuads<NSEQ, LOSS>::NQ;
     const double inv = hgs != 0.0f ? 1.0 / (double)hgs : 0.0;
@@ -386,7 +430,7 @@ __device__ __forceinline__ void fused_publish_record(float* rec, double* wpart, 
     for (int j = 0; j < VT<V>::N; ++j) {
         // the boundary term of the summation by parts: s[t1] hg_{t1-1}
         const double h = (double)vget(s.hg_prev, j), h2 = (double)vget(s.hy_prev, j);
-        const float A = vget(s.A, j), cL = vget(s.cL, j), cV = vget(s.cV, j), cP = vget(s.cP, j);
+        const float A = vget(s.A, j), cL = fsc.L * vget(s.cL, j), cV = fsc.V * vget(s.cV, j), cP = vget(s.cP, j);
         const float v[kFsOutEsr] = {A, cL, cV, cP, (float)(d.GA[j] + h * A), (float)(d.HA[j] + h2 * A)};
         if constexpr (VT<V>::N == NSEQ) {
 #pragma unroll
@@ -398,8 +442,8 @@ __device__ __forceinline__ void fused_publish_record(float* rec, double* wpart, 
                 __hip_atomic_store(chunk + ((size_t)(e >> 2) * lanes + lane) * 4 + (e & 3), v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        double p[kFsPartEsr] = {d.GL[j] + h * cL, d.GV[j] + h * cV, d.GP[j] + h * cP, d.sse[j] * inv,
-                                d.HL[j] + h2 * cL, d.HV[j] + h2 * cV, d.HP[j] + h2 * cP, d.syy[j] * inv};
+        double p[kFsPartEsr] = {(double)fsc.L * d.GL[j] + h * cL, (double)fsc.V * d.GV[j] + h * cV, d.GP[j] + h * cP, d.sse[j] * inv,
+                                (double)fsc.L * d.HL[j] + h2 * cL, (double)fsc.V * d.HV[j] + h2 * cV, d.HP[j] + h2 * cP, d.syy[j] * inv};
         double* w = wpart + (((int64_t)blockIdx.x * K + k) * NSEQ + slot0 + j) * NP;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -588,7 +632,11 @@ __device__ __forceinline__ void clipper_fused_body(
     publish_own<V>(zend + k * B, q, z);
     if (snapw != nullptr) store_own<V>(snapw, q, z);
     if (zT && t1 == T) store_own<V>(zT, q, z);
-    if constexpr (LOSS != 0) fused_publish_record<V, LOSS, VT<V>::N>(rec, wpart, k, K, q.live, 0, s, d, hgs);
+    if constexpr (LOSS != 0) {
+        FusedScale fsc{1.0f, 1.0f};
+        if constexpr (SYM && FAST == kRootLean && !DYN_R) fsc = FusedScale{-(c.d.two_v * c.d.m_dn), -1.0f / c.V};
+        fused_publish_record<V, LOSS, VT<V>::N>(rec, wpart, k, K, q.live, 0, s, d, hgs, fsc);
+    }
 #ifdef WDF_DBG_TIMES
     dbg_p[4] = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0 && g_dbg_times) {
@@ -902,7 +950,9 @@ __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const flo
     }
     d.template flush<LOSS>(s);
     if (snapw != nullptr) snapw[b] = z;
-    fused_publish_record<float, LOSS, NSEQ>(rec, wpart, k, K, live, slot, s, d, hgs);
+    FusedScale fsc{1.0f, 1.0f};
+    if constexpr (SYM && FAST == kRootLean && !DYN_R) fsc = FusedScale{-(c.d.two_v * c.d.m_dn), -1.0f / c.V};
+    fused_publish_record<float, LOSS, NSEQ>(rec, wpart, k, K, live, slot, s, d, hgs, fsc);
 }
 
 // Launched behind every fused step; a block leaves at once unless the step flagged its tile (the common
