@@ -572,11 +572,11 @@ def forward_only(args, dev, fs, B=1024, T=4096, steps=100, warmup=10):
 def valu_cycle_model(B, T, k, w_used):
     """VALU-active cycles per launch of the one-pass kernel when no committed SQ pass matches the autotuned plan: the count
     is deterministic in the work -- a wave (128 sequences, two per lane) runs T / k + W steps per chunk -- and the committed
-    passes (profiles/r03_c_sq_counters.json: 32 chunks; r03_c16: 16 chunks; warm-up 16 steps both) fit
-        SQ_ACTIVE_INST_VALU = 124.65 quad-cycles per wave-step + 210 per wave
-    to better than 0.1 %."""
+    passes fit  SQ_ACTIVE_INST_VALU = c quad-cycles per wave-step + 210 per wave:  c = 124.65 until round 5
+    (profiles/r03_c_sq_counters.json: 32 chunks; r03_c16: 16 chunks; warm-up 16 steps both; to better than 0.1 %), c = 109.4
+    since round 6's LEAN root tier (profiles/r06_m_sq_counters.json: 32.686 M per launch of 2048 waves x 144 steps)."""
     waves = (B + 127) // 128 * k
-    return 4.0 * (124.65 * waves * (T / k + w_used) + 210.0 * waves)
+    return 4.0 * (109.4 * waves * (T / k + w_used) + 210.0 * waves)
 
 
 def run_mlp_step(args, world, rank, local):
