@@ -99,3 +99,38 @@ def test_c4_dataset_shaped_training_loop_last_step_against_the_oracle(wb, oracle
     for i in (0, 1, 3):
         assert abs(got[i] - g64[i]) <= 1e-4 * abs(g64[i]), (i, got, g64)
     assert got[2] == 0.0
+
+
+@pytest.mark.parametrize("K", [128, 64])
+def test_strong_scaling_per_rank_step_1024x4096_against_the_oracle(wb, oracle, K):
+    """The per-rank step of SURVEY 8(e)'s strong curve (global batch 8192 over 8 ranks: 1024 sequences x 4096 samples), through the
+    plan bench.py's `strong_proxy` runs it with (round 6: a warm stepper cuts as many chunks as fill the chip -- 128 of 32 steps
+    here -- and clipper_fused_finish_kernel walks them on 8 waves per tile): twelve Adam steps of the warm-started one-pass MSE
+    step, then y, the loss and the four gradient components of the LAST step against the fp64 oracle over the whole shard, a
+    clean verdict at every step."""
+    from wdf_hip import engine, workload
+    B, T, Bg = 1024, 4096, 8192
+    x = workload.sweep_batch(Bg, T, b0=0, b1=B)                  # rank 0's shard of the global batch
+    th0, ths = workload.clipper_theta(), workload.target_theta()
+    xt = dev(x).t().contiguous()
+    tgt, _, _ = wb.clipper_fwd(dev(x), dev(ths), FS, want_stash=False)
+    plan = engine.plan_time_parallel(B, T, th0[2], th0[3], FS, time_major=True)._replace(k_fwd=K)
+    st = engine.MseStep(B, T, FS, plan, xt.device, n_global=float(Bg * T), time_major=True, warm=True)
+    theta = dev(th0)
+    opt = wb.Adam(4, lr=[1e-3 * float(v) for v in th0], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=xt.device)
+    for it in range(12):
+        th_before = theta.clone()
+        st.step_fused(theta, xt, tgt, adam=opt)
+        stat = wb.tp_status(st.status)
+        assert stat["n_bad"] == 0, (it, stat)
+    assert not torch.equal(theta, dev(th0))
+    th64 = th_before.cpu().numpy().astype(np.float64)
+    t64 = tgt.cpu().numpy().astype(np.float64)
+    loss_ref, g_ref, y_ref = oracle.clipper_mse_step(th64, FS, x.astype(np.float64), t64, dtype=np.float64)
+    g_ref = g_ref * (B / Bg)                                     # the oracle's mean is over this shard, the step's over the global batch
+    e_y = float(np.max(np.abs(st.y.cpu().numpy() - y_ref)))
+    got = st.gtheta.cpu().numpy().astype(np.float64)
+    e_g = float(np.max(np.abs(got - g_ref) / np.abs(g_ref)))
+    print(f"K {K}: |y - oracle| {e_y:.2e}, gradient {e_g:.2e}, SSE rel {abs(float(st.sse) / (B * T) - loss_ref) / loss_ref:.2e}")
+    assert e_y < 2e-6 and e_g < 1e-4
+    assert abs(float(st.sse) / (B * T) - loss_ref) <= 1e-5 * loss_ref
