@@ -106,7 +106,7 @@ __device__ __forceinline__ void nl_load_diode(const NlStepArgs& a, SSDiode& dp)
 }
 
 // the state alone (warm-up)
-template <int NS, int NI, bool SYM, typename V, bool FAST = false>
+template <int NS, int NI, bool SYM, typename V, int FAST = 0>
 __device__ __forceinline__ void nl_z_step(const SSCoef<NS, NI>& c, const SSDiode& dp, const V (&x)[NI], V (&z)[NS])
 {
     using C = SSCoef<NS, NI>;
@@ -132,7 +132,7 @@ __device__ __forceinline__ void nl_z_step(const SSCoef<NS, NI>& c, const SSDiode
 
 // one step with tangents -> y.  gs = gscale (0 on a padding lane), lv = 1 (0 on a padding lane).
 // FAST (with SYM): the kernel has checked that omega_1's argument never leaves the series-only region (diode_pair, wdf_omega.h).
-template <int NS, int NI, bool SYM, typename V, bool PSI, bool FAST = false>
+template <int NS, int NI, bool SYM, typename V, bool PSI, int FAST = 0>
 __device__ __forceinline__ V nl_step(const SSCoef<NS, NI>& c, const SSDiode& dp, const V (&x)[NI], V tgt, float gs, float lv,
                                      NlU<NS, NI, V, PSI>& u, V (&G)[NlDims<NS, NI>::nG], V (&H)[NS], V& sse)
 {
@@ -150,7 +150,10 @@ __device__ __forceinline__ V nl_step(const SSCoef<NS, NI>& c, const SSDiode& dp,
     const V w0p = o.w0 * vrcp(o.w0 + 1.0f);
     // omega_1 <= omega(-4) = 0.018 in the series-only region: omega / (1 + omega) by its alternating series to the cubic term
     // (next term 1e-7 relative) instead of a second reciprocal (wdf_clipper_fused.h, fused_step)
-    const V w1p = (SYM && FAST) ? o.w1 * vfma(-o.w1, vfma(-o.w1, 1.0f - o.w1, 1.0f), 1.0f) : o.w1 * vrcp(o.w1 + 1.0f);
+    V w1p;
+    if constexpr (SYM && FAST == kRootLean) w1p = vfma(-o.w1, o.w1, o.w1);      // LEAN tier (wdf_omega.h): omega_1 <= 5.6e-4, w (1 - w)
+    else if constexpr (SYM && FAST) w1p = o.w1 * vfma(-o.w1, vfma(-o.w1, 1.0f - o.w1, 1.0f), 1.0f);
+    else w1p = o.w1 * vrcp(o.w1 + 1.0f);
     const V sp = w0p + w1p;
     V Da, DL, DV;
     if constexpr (SYM && FAST) {
@@ -248,7 +251,7 @@ __device__ __forceinline__ V nl_step(const SSCoef<NS, NI>& c, const SSDiode& dp,
 
 // ---- the chunks ------------------------------------------------------------------------------------------------------
 // 256-thread workgroups (four chunks of four neighbouring groups): single-wave workgroups land unevenly on the SIMDs.
-template <int NS, int NI, bool SYM, typename V, bool FAST>
+template <int NS, int NI, bool SYM, typename V, int FAST>
 __device__ __forceinline__ void nl_chunk(const NlStepArgs& a, const SSCoef<NS, NI>& c, const SSDiode& dp)
 {
     using C = SSCoef<NS, NI>;
@@ -397,12 +400,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WDF_NL_WAVE
     if constexpr (SYM) {
         // the series-only evaluation of omega_1 and no per-step ballot when its argument can never leave that region
         // (u1 <= L - log N: a fact about the circuit, the same for every lane)
-        if (dp.L - dp.d.l_dn <= kSeriesOnlyBelow) {
-            nl_chunk<NS, NI, SYM, V, true>(a, c, dp);
+        const float l0 = dp.L - dp.d.l_dn;
+        if (l0 <= -7.5f && l0 >= -80.0f) {                     // the LEAN root tier (round 6, wdf_omega.h): every practical diode
+            nl_chunk<NS, NI, SYM, V, kRootLean>(a, c, dp);
+            return;
+        }
+        if (l0 <= kSeriesOnlyBelow) {
+            nl_chunk<NS, NI, SYM, V, kRootFast>(a, c, dp);
             return;
         }
     }
-    nl_chunk<NS, NI, SYM, V, false>(a, c, dp);
+    nl_chunk<NS, NI, SYM, V, kRootGeneral>(a, c, dp);
 }
 
 // ---- the finish: verify the boundaries, walk the tangents, re-run what missed, reduce, chain rule, steer -----------------
