@@ -41,38 +41,42 @@ int wdf_ss_dyn_row_len(int ns, int ni) { return dyn_ok(ns, ni) ? wdf::DynLayout(
 // grid.x: one lane per sequence, or -- the network root, evaluated in 16-lane rows (wdf_ss_dyn.h DynLanes) -- four sequences per wave
 #define WDF_DYN_GRIDX(ROW_) ((unsigned)((ROW_) ? (B + 3) / 4 : (B + 63) / 64))
 
-#define WDF_DYN_FWD(GY_, ...)                                                                                                 \
+// MS_: state slots the kernel is compiled for (4: trees of up to four capacitors; 8: five to eight)
+#define WDF_DYN_FWD_MS(MS_, GY_, ...)                                                                                         \
     do {                                                                                                                     \
         const dim3 grid(WDF_DYN_GRIDX(root == WDF_ROOT_MLP), (unsigned)(GY_));                                               \
-        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootNone, true, 16, 3>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
+        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootNone, true, 16, 3, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
         else if (root == WDF_ROOT_DIODE_PAIR && n_up == n_down)                                                              \
-            hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootDiode, true, 16, 3>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);   \
+            hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootDiode, true, 16, 3, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);   \
         else if (root == WDF_ROOT_DIODE_PAIR)                                                                                \
-            hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootDiode, false, 16, 3>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);  \
-        else if (n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootMlp, true, 16, 3>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
-        else hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootMlp, true, 16, 5>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);     \
+            hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootDiode, false, 16, 3, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);  \
+        else if (n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootMlp, true, 16, 3, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden); \
+        else hipLaunchKernelGGL((wdf::ss_dyn_fwd_kernel<wdf::kDynRootMlp, true, 16, 5, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden);     \
     } while (0)
+#define WDF_DYN_FWD(GY_, ...) do { if (ns > 4) WDF_DYN_FWD_MS(8, GY_, __VA_ARGS__); else WDF_DYN_FWD_MS(4, GY_, __VA_ARGS__); } while (0)
 
 // the reverse sweep's kernel in one of its modes (0: sequential, 1: chunk maps + root partials; 2 -- no root code in it -- below)
-#define WDF_DYN_BWD(MODE_, GY_, ...)                                                                                          \
+#define WDF_DYN_BWD_MS(MS_, MODE_, GY_, ...)                                                                                  \
     do {                                                                                                                     \
         const dim3 grid(WDF_DYN_GRIDX(root == WDF_ROOT_MLP), (unsigned)(GY_));                                               \
-        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
+        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 16, 3, MODE_, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
         else if (root == WDF_ROOT_DIODE_PAIR && n_up == n_down)                                                              \
-            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);   \
+            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 16, 3, MODE_, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);   \
         else if (root == WDF_ROOT_DIODE_PAIR)                                                                                \
-            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, false, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);  \
-        else if (n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
-        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 5, MODE_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);     \
+            hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, false, 16, 3, MODE_, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);  \
+        else if (n_tanh_layers == 3) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, MODE_, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
+        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 5, MODE_, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);     \
     } while (0)
+#define WDF_DYN_BWD(MODE_, GY_, ...) do { if (ns > 4) WDF_DYN_BWD_MS(8, MODE_, GY_, __VA_ARGS__); else WDF_DYN_BWD_MS(4, MODE_, GY_, __VA_ARGS__); } while (0)
 
-#define WDF_DYN_BWD_EMIT(GY_, ...)                                                                                            \
+#define WDF_DYN_BWD_EMIT_MS(MS_, GY_, ...)                                                                                    \
     do {                                                                                                                     \
         const dim3 grid(WDF_DYN_GRIDX(false), (unsigned)(GY_));                                                              \
-        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
-        else if (root == WDF_ROOT_DIODE_PAIR) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
-        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, 2>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);          \
+        if (root == WDF_ROOT_NONE) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootNone, true, 16, 3, 2, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
+        else if (root == WDF_ROOT_DIODE_PAIR) hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootDiode, true, 16, 3, 2, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc); \
+        else hipLaunchKernelGGL((wdf::ss_dyn_bwd_kernel<wdf::kDynRootMlp, true, 16, 3, 2, MS_>), grid, dim3(64), 0, s, __VA_ARGS__, hidden, acc);          \
     } while (0)
+#define WDF_DYN_BWD_EMIT(GY_, ...) do { if (ns > 4) WDF_DYN_BWD_EMIT_MS(8, GY_, __VA_ARGS__); else WDF_DYN_BWD_EMIT_MS(4, GY_, __VA_ARGS__); } while (0)
 
 namespace {
 // chunk length (a multiple of 8) and count for n_chunks requested; false when the count does not tile T that way

@@ -45,10 +45,14 @@ struct DynLanes {
     static __device__ __forceinline__ bool writer() { return kRow ? (threadIdx.x & 15) == 0 : true; }
     static __device__ __forceinline__ unsigned gate_index() { return kRow ? blockIdx.x >> 4 : blockIdx.x; }   // (gates are per 64 sequences)
 };
-constexpr int kDynMaxS = 4, kDynMaxI = 2;
+// Trees of up to kDynMaxS capacitors (round 6: 8; rounds 5: 4).  The kernels are compiled for MS = 4 and MS = 8 state slots -- the
+// loops over states are unrolled to MS with the run-time ns masking them -- and the C ABI picks MS = 4 whenever ns <= 4: small
+// trees pay nothing for the larger ones.
+constexpr int kDynMaxS = 8, kDynMaxI = 2;
 
-struct DynRow {                     // one step's coefficients in registers (entries beyond ns / ni are zero)
-    float A[kDynMaxS][kDynMaxS], Bx[kDynMaxS][kDynMaxI], E[kDynMaxS], ca[kDynMaxS], da[kDynMaxI], cy[kDynMaxS], dy[kDynMaxI], fy, rp;
+template <int MS>
+struct DynRowT {                    // one step's coefficients in registers (entries beyond ns / ni are zero)
+    float A[MS][MS], Bx[MS][kDynMaxI], E[MS], ca[MS], da[kDynMaxI], cy[MS], dy[kDynMaxI], fy, rp;
 };
 
 struct DynLayout {                  // offsets of the row's groups for this (ns, ni)
@@ -60,14 +64,15 @@ struct DynLayout {                  // offsets of the row's groups for this (ns,
     }
 };
 
-__device__ __forceinline__ DynRow dyn_load_row(const float* __restrict__ p, int64_t cs, const DynLayout& L, int ns, int ni)
+template <int MS>
+__device__ __forceinline__ DynRowT<MS> dyn_load_row(const float* __restrict__ p, int64_t cs, const DynLayout& L, int ns, int ni)
 {
-    DynRow r;
+    DynRowT<MS> r;
 #pragma unroll
-    for (int s = 0; s < kDynMaxS; ++s) {
+    for (int s = 0; s < MS; ++s) {
         const bool ls = s < ns;
 #pragma unroll
-        for (int s2 = 0; s2 < kDynMaxS; ++s2) r.A[s][s2] = (ls && s2 < ns) ? p[(L.oA + s * ns + s2) * cs] : 0.0f;
+        for (int s2 = 0; s2 < MS; ++s2) r.A[s][s2] = (ls && s2 < ns) ? p[(L.oA + s * ns + s2) * cs] : 0.0f;
 #pragma unroll
         for (int i = 0; i < kDynMaxI; ++i) r.Bx[s][i] = (ls && i < ni) ? p[(L.oB + s * ni + i) * cs] : 0.0f;
         r.E[s] = ls ? p[(L.oE + s) * cs] : 0.0f;
@@ -101,7 +106,7 @@ struct DynRoot {
 };
 
 // x [B][T][ni] -> y [T][B]; w_in: flat MLP weights (MLP root) -- H, NL are ignored for the other roots
-template <int ROOT, bool SYM, int H, int NL>
+template <int ROOT, bool SYM, int H, int NL, int MS = 4>
 __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ crow, int64_t cs,
                                                         int64_t ts, int64_t bs, const float* __restrict__ rootp,
                                                         const float* __restrict__ w_in, int n_up, int n_down,
@@ -127,9 +132,9 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
     root.load(rootp, n_up, n_down);
     [[maybe_unused]] RowWeights<NL> RW;
     if constexpr (ROOT == kDynRootMlp) RW = row_load_weights<NL>(w_in, hidden, threadIdx.x & 15, false);
-    float z[kDynMaxS];
+    float z[MS];
 #pragma unroll
-    for (int s = 0; s < kDynMaxS; ++s)                            // t = 0: the caller's z0; else zinit [K][ns][B] (a training loop: the
+    for (int s = 0; s < MS; ++s)                            // t = 0: the caller's z0; else zinit [K][ns][B] (a training loop: the
         z[s] = s >= ns ? 0.0f                                     // previous call's state at the sample this warm-up begins) or 0
                : (tw == 0 ? (z0 ? z0[s * B + b] : 0.0f) : (zinit ? zinit[(k * ns + s) * B + b] : 0.0f));
     const float* __restrict__ xp = x + b * T * ni;
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
     [[maybe_unused]] float act[NL];
     // rows that do not change in time (ts = 0: one static row, or one row per sequence) are read ONCE, and with them what the
     // root needs of R_port -- log(R_port Is / nVt) / log R_port: a full-precision logarithm per step otherwise
-    DynRow c = dyn_load_row(cp + tw * ts, cs, L, ns, ni);
+    DynRowT<MS> c = dyn_load_row<MS>(cp + tw * ts, cs, L, ns, ni);
     [[maybe_unused]] float lroot = 0.0f;
     if constexpr (ROOT == kDynRootDiode) lroot = logf(c.rp * root.Is / root.V);
     if constexpr (ROOT == kDynRootMlp) lroot = logf(c.rp);
@@ -145,11 +150,11 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
         const bool owned = t >= t0;                                // wave-uniform
         if (t == t0 && zwarm != nullptr && writer) {
 #pragma unroll
-            for (int s = 0; s < kDynMaxS; ++s)
+            for (int s = 0; s < MS; ++s)
                 if (s < ns) zwarm[(k * ns + s) * B + b] = z[s];
         }
         if (ts != 0 && t != tw) {                                  // wave-uniform
-            c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
+            c = dyn_load_row<MS>(cp + t * ts, cs, L, ns, ni);
             if constexpr (ROOT == kDynRootDiode) lroot = logf(c.rp * root.Is / root.V);
             if constexpr (ROOT == kDynRootMlp) lroot = logf(c.rp);
         }
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
         for (int i = 0; i < kDynMaxI; ++i) xv[i] = i < ni ? xp[t * ni + i] : 0.0f;
         float a = 0.0f;
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s) a = fmaf(c.ca[s], z[s], a);
+        for (int s = 0; s < MS; ++s) a = fmaf(c.ca[s], z[s], a);
 #pragma unroll
         for (int i = 0; i < kDynMaxI; ++i) a = fmaf(c.da[i], xv[i], a);
         float broot = 0.0f;
@@ -166,15 +171,15 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
         if constexpr (ROOT == kDynRootMlp) broot = -row_mlp_fwd<NL>(RW, a, lroot, act);
         float yv = c.fy * broot;
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s) yv = fmaf(c.cy[s], z[s], yv);
+        for (int s = 0; s < MS; ++s) yv = fmaf(c.cy[s], z[s], yv);
 #pragma unroll
         for (int i = 0; i < kDynMaxI; ++i) yv = fmaf(c.dy[i], xv[i], yv);
-        float zn[kDynMaxS];
+        float zn[MS];
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s) {
+        for (int s = 0; s < MS; ++s) {
             float acc = c.E[s] * broot;
 #pragma unroll
-            for (int s2 = 0; s2 < kDynMaxS; ++s2) acc = fmaf(c.A[s][s2], z[s2], acc);
+            for (int s2 = 0; s2 < MS; ++s2) acc = fmaf(c.A[s][s2], z[s2], acc);
 #pragma unroll
             for (int i = 0; i < kDynMaxI; ++i) acc = fmaf(c.Bx[s][i], xv[i], acc);
             zn[s] = acc;
@@ -182,22 +187,22 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
         if (owned && writer) {
             if (zstash) {
 #pragma unroll
-                for (int s = 0; s < kDynMaxS; ++s)
+                for (int s = 0; s < MS; ++s)
                     if (s < ns) zstash[(t * ns + s) * B + b] = z[s];
             }
             y[t * B + b] = yv;
         }
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s) z[s] = zn[s];
+        for (int s = 0; s < MS; ++s) z[s] = zn[s];
     }
     if (zend != nullptr && writer) {
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s)
+        for (int s = 0; s < MS; ++s)
             if (s < ns) zend[(k * ns + s) * B + b] = z[s];
     }
     if (zT && t1 == T && writer) {
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s)
+        for (int s = 0; s < MS; ++s)
             if (s < ns) zT[s * B + b] = z[s];
     }
 }
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(64) void ss_dyn_fwd_kernel(const float* __restrict_
 // MODE 0 (K = 1) is the sequential sweep: root evaluated and rows emitted in one walk.
 constexpr int kDynRpart = 5;
 
-template <int ROOT, bool SYM, int H, int NL, int MODE>
+template <int ROOT, bool SYM, int H, int NL, int MODE, int MS = 4>
 __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ crow, int64_t cs,
                                                         int64_t ts, int64_t bs, const float* __restrict__ rootp,
                                                         const float* __restrict__ w_in, int n_up, int n_down,
@@ -247,44 +252,46 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
     if constexpr (kEval) RW = row_load_weights<NL>(w_in, hidden, threadIdx.x & 15, true);
     const float* __restrict__ xp = x + b * T * ni;
     const float* __restrict__ cp = crow + b * bs;
-    float lam[kDynMaxS];
+    float lam[MS];
 #pragma unroll
-    for (int s = 0; s < kDynMaxS; ++s) lam[s] = (MODE == 2 && s < ns) ? lam_in[(k * ns + s) * B + b] : 0.0f;
+    for (int s = 0; s < MS; ++s) lam[s] = (MODE == 2 && s < ns) ? lam_in[(k * ns + s) * B + b] : 0.0f;
     // MODE 1: the homogeneous runs -- hom[j] is the adjoint that enters as the unit vector e_j (dL/dy = 0)
-    [[maybe_unused]] float hom[kDynMaxS][kDynMaxS];
+    [[maybe_unused]] float hom[MS][MS];
     if constexpr (MODE == 1) {
 #pragma unroll
-        for (int j = 0; j < kDynMaxS; ++j)
+        for (int j = 0; j < MS; ++j)
 #pragma unroll
-            for (int s = 0; s < kDynMaxS; ++s) hom[j][s] = (j == s && j < ns) ? 1.0f : 0.0f;
+            for (int s = 0; s < MS; ++s) hom[j][s] = (j == s && j < ns) ? 1.0f : 0.0f;
     }
     double sL = 0.0, sV = 0.0;
-    // accumulators of the acc mode at fixed slots: A s*4+s2 | Bx 16+s*2+i | E 24+s | ca 28+s | da 32+i | cy 34+s | dy 38+i | fy 40 | R_port 41
-    [[maybe_unused]] double gacc[42];
+    // accumulators of the acc mode at compile-time slots: A s MS + s2 | Bx | E | ca | da | cy | dy | fy | R_port
+    constexpr int gA = 0, gB = MS * MS, gE = gB + 2 * MS, gCa = gE + MS, gDa = gCa + MS, gCy = gDa + 2, gDy = gCy + MS, gFy = gDy + 2,
+                  gRp = gFy + 1, gN = gRp + 1;
+    [[maybe_unused]] double gacc[gN];
     if constexpr (MODE != 1) {
 #pragma unroll
-        for (int i = 0; i < 42; ++i) gacc[i] = 0.0;
+        for (int i = 0; i < gN; ++i) gacc[i] = 0.0;
     }
     [[maybe_unused]] float act[NL];
-    DynRow c = dyn_load_row(cp + (t1 - 1) * ts, cs, L, ns, ni);    // (rows constant in time: read once, as in the forward)
+    DynRowT<MS> c = dyn_load_row<MS>(cp + (t1 - 1) * ts, cs, L, ns, ni);    // (rows constant in time: read once, as in the forward)
     [[maybe_unused]] float lroot = 0.0f;
     if constexpr (ROOT == kDynRootDiode && MODE != 2) lroot = logf(c.rp * root.Is / root.V);
     if constexpr (kEval) lroot = logf(c.rp);
     for (int64_t t = t1 - 1; t >= t0; --t) {
         if (ts != 0 && t != t1 - 1) {                              // wave-uniform
-            c = dyn_load_row(cp + t * ts, cs, L, ns, ni);
+            c = dyn_load_row<MS>(cp + t * ts, cs, L, ns, ni);
             if constexpr (ROOT == kDynRootDiode && MODE != 2) lroot = logf(c.rp * root.Is / root.V);
             if constexpr (kEval) lroot = logf(c.rp);
         }
-        float xv[kDynMaxI], z[kDynMaxS];
+        float xv[kDynMaxI], z[MS];
 #pragma unroll
         for (int i = 0; i < kDynMaxI; ++i) xv[i] = i < ni ? xp[t * ni + i] : 0.0f;
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s) z[s] = s < ns ? zstash[(t * ns + s) * B + b] : 0.0f;
+        for (int s = 0; s < MS; ++s) z[s] = s < ns ? zstash[(t * ns + s) * B + b] : 0.0f;
         const float g = gy[t * B + b];
         float a = 0.0f;
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s) a = fmaf(c.ca[s], z[s], a);
+        for (int s = 0; s < MS; ++s) a = fmaf(c.ca[s], z[s], a);
 #pragma unroll
         for (int i = 0; i < kDynMaxI; ++i) a = fmaf(c.da[i], xv[i], a);
         float broot = 0.0f, Da = 0.0f, Drp = 0.0f;                 // d b / d a, d b / d R_port
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
         }
         float gb = c.fy * g;
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s) gb = fmaf(c.E[s], lam[s], gb);
+        for (int s = 0; s < MS; ++s) gb = fmaf(c.E[s], lam[s], gb);
         const float ga = gb * Da;
         if constexpr (MODE == 1) {
             // what MODE 2 needs of this step's root, and the network's operands; then the adjoint maps -- no rows
@@ -333,50 +340,50 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
                 }
             }
 #pragma unroll
-            for (int j = 0; j < kDynMaxS; ++j) {
+            for (int j = 0; j < MS; ++j) {
                 if (j < ns) {
                     float gbj = 0.0f;
 #pragma unroll
-                    for (int s = 0; s < kDynMaxS; ++s) gbj = fmaf(c.E[s], hom[j][s], gbj);
+                    for (int s = 0; s < MS; ++s) gbj = fmaf(c.E[s], hom[j][s], gbj);
                     const float gaj = gbj * Da;
-                    float hn[kDynMaxS];
+                    float hn[MS];
 #pragma unroll
-                    for (int s2 = 0; s2 < kDynMaxS; ++s2) {
+                    for (int s2 = 0; s2 < MS; ++s2) {
                         float v = c.ca[s2] * gaj;
 #pragma unroll
-                        for (int s = 0; s < kDynMaxS; ++s) v = fmaf(c.A[s][s2], hom[j][s], v);
+                        for (int s = 0; s < MS; ++s) v = fmaf(c.A[s][s2], hom[j][s], v);
                         hn[s2] = v;
                     }
 #pragma unroll
-                    for (int s = 0; s < kDynMaxS; ++s) hom[j][s] = hn[s];
+                    for (int s = 0; s < MS; ++s) hom[j][s] = hn[s];
                 }
             }
         } else if (writer) {
         if (acc) {                                                  // wave-uniform: summed over the chunk's steps (entries past ns / ni stay 0)
 #pragma unroll
-            for (int s = 0; s < kDynMaxS; ++s) {
+            for (int s = 0; s < MS; ++s) {
 #pragma unroll
-                for (int s2 = 0; s2 < kDynMaxS; ++s2) gacc[s * 4 + s2] += (double)(lam[s] * z[s2]);
+                for (int s2 = 0; s2 < MS; ++s2) gacc[gA + s * MS + s2] += (double)(lam[s] * z[s2]);
 #pragma unroll
-                for (int i = 0; i < kDynMaxI; ++i) gacc[16 + s * 2 + i] += (double)(lam[s] * xv[i]);
-                gacc[24 + s] += (double)(lam[s] * broot);
-                gacc[28 + s] += (double)(ga * z[s]);
-                gacc[34 + s] += (double)(g * z[s]);
+                for (int i = 0; i < kDynMaxI; ++i) gacc[gB + s * 2 + i] += (double)(lam[s] * xv[i]);
+                gacc[gE + s] += (double)(lam[s] * broot);
+                gacc[gCa + s] += (double)(ga * z[s]);
+                gacc[gCy + s] += (double)(g * z[s]);
             }
 #pragma unroll
             for (int i = 0; i < kDynMaxI; ++i) {
-                gacc[32 + i] += (double)(ga * xv[i]);
-                gacc[38 + i] += (double)(g * xv[i]);
+                gacc[gDa + i] += (double)(ga * xv[i]);
+                gacc[gDy + i] += (double)(g * xv[i]);
             }
-            gacc[40] += (double)(g * broot);
-            gacc[41] += (double)(gb * Drp);
+            gacc[gFy] += (double)(g * broot);
+            gacc[gRp] += (double)(gb * Drp);
         } else {
         float* __restrict__ gp = grow + (t * L.n) * B + b;
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s) {
+        for (int s = 0; s < MS; ++s) {
             if (s < ns) {
 #pragma unroll
-                for (int s2 = 0; s2 < kDynMaxS; ++s2)
+                for (int s2 = 0; s2 < MS; ++s2)
                     if (s2 < ns) gp[(L.oA + s * ns + s2) * B] = lam[s] * z[s2];
 #pragma unroll
                 for (int i = 0; i < kDynMaxI; ++i)
@@ -408,62 +415,62 @@ __global__ __launch_bounds__(64) void ss_dyn_bwd_kernel(const float* __restrict_
             }
         }
         }   // MODE != 1
-        float ln[kDynMaxS];
+        float ln[MS];
 #pragma unroll
-        for (int s2 = 0; s2 < kDynMaxS; ++s2) {
+        for (int s2 = 0; s2 < MS; ++s2) {
             float v = fmaf(c.ca[s2], ga, c.cy[s2] * g);
 #pragma unroll
-            for (int s = 0; s < kDynMaxS; ++s) v = fmaf(c.A[s][s2], lam[s], v);
+            for (int s = 0; s < MS; ++s) v = fmaf(c.A[s][s2], lam[s], v);
             ln[s2] = v;
         }
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s) lam[s] = ln[s];
+        for (int s = 0; s < MS; ++s) lam[s] = ln[s];
     }
     if constexpr (MODE == 1) {
         // rec [k][j][s][B]: j < ns the columns of Phi (the adjoint that entered as e_j), j = ns the particular run (beta)
         if (!writer) return;
         float* __restrict__ r = rec + (k * (ns + 1) * ns) * B + b;
 #pragma unroll
-        for (int j = 0; j < kDynMaxS; ++j)
+        for (int j = 0; j < MS; ++j)
 #pragma unroll
-            for (int s = 0; s < kDynMaxS; ++s)
+            for (int s = 0; s < MS; ++s)
                 if (j < ns && s < ns) r[(j * ns + s) * B] = hom[j][s];
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s)
+        for (int s = 0; s < MS; ++s)
             if (s < ns) r[(ns * ns + s) * B] = lam[s];
         return;
     }
     if (live && gz0 && t0 == 0) {
 #pragma unroll
-        for (int s = 0; s < kDynMaxS; ++s)
+        for (int s = 0; s < MS; ++s)
             if (s < ns) gz0[s * B + b] = lam[s];
     }
     if constexpr (MODE != 1) {
         if (acc && writer && b_raw < B) {                          // the chunk's sums: grow [K][kN1][B]
             float* __restrict__ gp = grow + (k * L.n) * B + b;
 #pragma unroll
-            for (int s = 0; s < kDynMaxS; ++s) {
+            for (int s = 0; s < MS; ++s) {
                 if (s < ns) {
 #pragma unroll
-                    for (int s2 = 0; s2 < kDynMaxS; ++s2)
-                        if (s2 < ns) gp[(L.oA + s * ns + s2) * B] = (float)gacc[s * 4 + s2];
+                    for (int s2 = 0; s2 < MS; ++s2)
+                        if (s2 < ns) gp[(L.oA + s * ns + s2) * B] = (float)gacc[gA + s * MS + s2];
 #pragma unroll
                     for (int i = 0; i < kDynMaxI; ++i)
-                        if (i < ni) gp[(L.oB + s * ni + i) * B] = (float)gacc[16 + s * 2 + i];
-                    gp[(L.oE + s) * B] = (float)gacc[24 + s];
-                    gp[(L.oCa + s) * B] = (float)gacc[28 + s];
-                    gp[(L.oCy + s) * B] = (float)gacc[34 + s];
+                        if (i < ni) gp[(L.oB + s * ni + i) * B] = (float)gacc[gB + s * 2 + i];
+                    gp[(L.oE + s) * B] = (float)gacc[gE + s];
+                    gp[(L.oCa + s) * B] = (float)gacc[gCa + s];
+                    gp[(L.oCy + s) * B] = (float)gacc[gCy + s];
                 }
             }
 #pragma unroll
             for (int i = 0; i < kDynMaxI; ++i) {
                 if (i < ni) {
-                    gp[(L.oDa + i) * B] = (float)gacc[32 + i];
-                    gp[(L.oDy + i) * B] = (float)gacc[38 + i];
+                    gp[(L.oDa + i) * B] = (float)gacc[gDa + i];
+                    gp[(L.oDy + i) * B] = (float)gacc[gDy + i];
                 }
             }
-            gp[L.oFy * B] = (float)gacc[40];
-            gp[L.oRp * B] = (float)gacc[41];
+            gp[L.oFy * B] = (float)gacc[gFy];
+            gp[L.oRp * B] = (float)gacc[gRp];
         }
     }
     if constexpr (ROOT == kDynRootDiode) {

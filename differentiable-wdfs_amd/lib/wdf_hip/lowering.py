@@ -735,11 +735,13 @@ class Circuit:
         if self.ni < 1:
             raise ValueError("the circuit has no voltage source")
         # Outside the clipper topology a per-sample impedance or a DenseRootModel root runs on the streamed-coefficient kernels
-        # (csrc/wdf_ss_dyn.h): any tree of at most four capacitors and two sources
-        self._dyn = (per_sample_R is not None or self.root_kind == "DenseRootModel") and (self.force_generic or not self._is_clipper())
-        if self._dyn and (self.ns > 4 or self.ni > 2):
-            raise binding.WdfHipError("a per-sample resistance channel / an MLP root outside the clipper topology: trees of at most "
-                                      f"four capacitors and two sources (this one has {self.ns} and {self.ni})")
+        # (csrc/wdf_ss_dyn.h) -- and so does, since round 6, ANY tree of five to eight capacitors (the static-coefficient kernels
+        # of csrc/wdf_statespace.h are compiled for at most four: a larger tree hands the streamed kernels one static row)
+        self._dyn = ((per_sample_R is not None or self.root_kind == "DenseRootModel") and (self.force_generic or not self._is_clipper())) \
+            or self.ns > 4
+        if self._dyn and (self.ns > 8 or self.ni > 2):
+            raise binding.WdfHipError("trees of at most eight capacitors and two sources run on the GPU kernels "
+                                      f"(this one has {self.ns} and {self.ni})")
 
     # -- device-resident component values
     def to_device(self, device="cuda"):

@@ -472,7 +472,7 @@ size_t wdf_ss_bwd_ws_bytes(int ns, int ni, int64_t B);
 
 /* ------------------------------------------------------------------------------------
  * State-space recursion with PER-SAMPLE coefficient rows, and the MLP root on any small tree (round 5; csrc/wdf_ss_dyn.h).
- * Replaces, for any tree of <= 4 capacitors and <= 2 sources:
+ * Replaces, for any tree of <= 8 capacitors (round 6; 4 until round 5) and <= 2 sources:
  *   - a per-sample impedance: set_resistance on any ResistiveVoltageSource / Resistor (tf_wdf.py:51-52,80-81) followed by
  *     calc_impedance every step (clipper_pot.py:116-117) -- the host evaluates the probed step's coefficients over the whole
  *     resistance channel and hands one ROW per (sample, sequence);

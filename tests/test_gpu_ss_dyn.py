@@ -150,6 +150,77 @@ def test_a_pot_that_is_constant_along_each_sequence_takes_one_row_per_sequence(w
     assert rel(got, got_ps) < 1e-4
 
 
+@pytest.mark.parametrize("root,n_sec,B,T,resident", [("ideal", 6, 70, 600, False), ("diode", 6, 37, 300, False), ("ideal", 8, 130, 1024, False),
+                                                     ("diode", 7, 24, 257, False), ("diode", 5, 70, 512, True)])
+def test_trees_of_five_to_eight_capacitors_against_the_oracle(wdf, oracle, root, n_sec, B, T, resident):
+    """Round 6: trees beyond four capacitors (tf_wdf.py:129-192 composes any binary tree; the static-coefficient kernels are
+    compiled for at most four states) run on the streamed-coefficient kernels with ONE static row, compiled for eight state
+    slots.  An RC ladder of n_sec sections -- Series(R_k, Parallel(C_k, rest)), the last section Series(R, C) -- under the ideal
+    source (through an Inverter, as lpf.py:28 connects it) or behind a resistive source in front of a diode pair: y and the
+    gradient of every component value against the oracle's tree interpreter (fp64, complex step).  resident: the same with the
+    component values in a device block (Circuit.to_device)."""
+    tf = wdf.tf
+    O = oracle
+    rng = np.random.default_rng(B + T + n_sec)
+    x = (1.2 * rng.standard_normal((B, T))).astype(np.float32)
+    gy = (rng.standard_normal((T, B)) / (B * T)).astype(np.float32)
+    rv = [1.0e3 * (1.0 + 0.7 * k) for k in range(n_sec)]
+    cv = [1.0e-7 / (1.0 + 0.5 * k) for k in range(n_sec)]
+    Rs = [wdf.Resistor(v, True) for v in rv]
+    Cs = [wdf.Capacitor(v, FS, True) for v in cv]
+    sec = wdf.Series(Rs[-1], Cs[-1])
+    for k in range(n_sec - 2, -1, -1):
+        sec = wdf.Series(Rs[k], wdf.Parallel(Cs[k], sec))
+    nodes = []
+
+    def leaf(kind, param, vin=-1):
+        nodes.append((kind, -1, -1, param, vin, -1))
+        return len(nodes) - 1
+
+    def join(kind, a, b=-1):
+        nodes.append((kind, a, b, -1, -1, -1))
+        return len(nodes) - 1
+
+    r = [leaf(O.NODE_RESISTOR, 2 * k) for k in range(n_sec)]
+    c = [leaf(O.NODE_CAPACITOR, 2 * k + 1) for k in range(n_sec)]
+    s_ = join(O.NODE_SERIES, r[-1], c[-1])
+    for k in range(n_sec - 2, -1, -1):
+        s_ = join(O.NODE_SERIES, r[k], join(O.NODE_PARALLEL, c[k], s_))
+    theta = [v for pair in zip(rv, cv) for v in pair]
+    params = [p for pair in zip([e.R for e in Rs], [e.C for e in Cs]) for p in pair]
+    if root == "ideal":
+        circ = wdf.Circuit(wdf.Inverter(sec), wdf.IdealVoltageSource(), Cs[-1])
+        top = join(O.NODE_INVERTER, s_)
+        oc = O.Circuit(nodes, top=top, probe=c[-1], n_in=1, root_kind=O.ROOT_IDEAL_VSOURCE, fs=FS, root_vin=0)
+    else:
+        Vs = wdf.ResistiveVoltageSource(2.2e3, trainable=True)
+        topw = wdf.Parallel(Vs, sec)
+        dp = wdf.DiodePair(topw, 4.352e-9, Vt=25.85e-3 * 1.906, nDiodes=1.0, trainable=True)
+        circ = wdf.Circuit(topw, dp, Cs[-1])
+        v = leaf(O.NODE_RES_VSOURCE, 2 * n_sec, vin=0)
+        top = join(O.NODE_PARALLEL, v, s_)
+        oc = O.Circuit(nodes, top=top, probe=c[-1], n_in=1, root_kind=O.ROOT_DIODE_PAIR, fs=FS, p_is=2 * n_sec + 1, p_nvt=2 * n_sec + 2,
+                       n_up=1, n_down=1)
+        theta = theta + [2.2e3, 4.352e-9, 25.85e-3 * 1.906]
+        params = params + [Vs.R, dp.Is, dp.nVt]
+    assert circ.ns == n_sec and circ._dyn
+    if resident:
+        circ.to_device()
+        assert all(p.is_cuda for p in params)
+    theta = np.array(theta, dtype=np.float32).astype(np.float64)
+    with tf.GradientTape() as tape:
+        y = circ(cuda(x))
+        loss = tf.reduce_sum(y * cuda(gy))
+    grads = tape.gradient(loss, params)
+    x64 = x.astype(np.float64)
+    e_y = float(np.max(np.abs(y.cpu().numpy() - O.tree_fwd(oc, theta, x64))))
+    g_ref = O.tree_grad(oc, theta, x64, gy.astype(np.float64))
+    got = np.array([float(g) for g in grads])
+    print(f"{root} root, {n_sec} capacitors, {B} x {T}: |y - oracle| {e_y:.2e}, gradients {rel(got, g_ref):.2e}")
+    assert e_y < 5e-6
+    assert rel(got, g_ref) < 5e-4, (got, g_ref)
+
+
 def _net(golden, name):
     from test_gpu_mlp_root import model_json
     g = golden("g3_mlp_clipper.npz")
@@ -319,8 +390,13 @@ def test_what_the_streamed_kernels_refuse(wdf, golden):
         ladder = wdf.Series(wdf.Parallel(caps[k], R[k]), ladder)
     top = ladder
     dp = wdf.DiodePair(top, 4.352e-9, Vt=0.049)
-    with pytest.raises(wb.WdfHipError, match="four capacitors"):
-        wdf.Circuit(top, dp, caps[0], per_sample_R=Vs)            # five states
+    c5 = wdf.Circuit(top, dp, caps[0], per_sample_R=Vs)           # five states: fine since round 6 (up to eight)
+    assert c5.ns == 5
+    big = wdf.Series(wdf.ResistiveVoltageSource(1e3), wdf.Capacitor(1e-8, FS))
+    for k in range(8):
+        big = wdf.Series(wdf.Parallel(wdf.Capacitor(1e-8 * (k + 1), FS), wdf.Resistor(1e3 * (k + 1))), big)
+    with pytest.raises(wb.WdfHipError, match="eight capacitors"):
+        wdf.Circuit(big, wdf.DiodePair(big, 4.352e-9, Vt=0.049), big.P2)   # nine states
     with pytest.raises(ValueError):
         wdf.Circuit(wdf.Parallel(wdf.Resistor(1e3), wdf.Series(wdf.ResistiveVoltageSource(1e3), wdf.Capacitor(1e-8, FS))), dp, caps[0])
     js, _, _ = _net(golden, "2x8")
