@@ -545,7 +545,8 @@ struct TpCtl {
     int geom;         // tp_geom_tag(K, J, skewed spans?) of the calls that wrote the snapshots; another geometry restarts cold
     int j_floor;      // low byte: the controller never goes below this many warm-up tiles (host: 0; = max pins it); above: hold counter
     float th3[4];     // theta of the call before th2's (the quadratic extrapolation's third point)
-    int pad[12];
+    int cold_hold;    // > 0: the next calls start their chunks COLD (z = 0, the planned warm-up) while still leaving snapshots
+    int pad[11];
 };
 static_assert(sizeof(TpCtl) == 128, "TpCtl layout");
 
@@ -842,11 +843,22 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
     int j = c.j_next;
     const int jfloor = c.j_floor & 0xff;                        // host's floor (low byte); the rest of the word: hold counter
     int hold = c.j_floor >> 8;
+    const int jmax_now = (int)(L / kWarmStep) < J - 1 ? (int)(L / kWarmStep) : J - 1;
+    int cold_hold = stateful ? c.cold_hold : 0;
     if (valid == 0) {                                           // that was the cold call: start 96 steps under its warm-up
         const int jc = (int)((W + kWarmStep - 1) / kWarmStep);      // (an O(1 V) guess needs ~160 steps here; a change of 1e-3 V ~64)
         j = jc - 6 < 1 ? 1 : jc - 6;
         hold = 0;
         c.j_used = -1;
+        // Round 6: chunks too short to hold the warm-up a single snapshot set needs (32-step chunks of a few thousand sequences:
+        // one 16-step unit at most) stay cold until THREE sets exist -- the extrapolation along the parameter path is what makes
+        // zero to one unit enough; a warm call that misses here costs a sequential re-run per tile, a cold one ~4x its chunk kernel
+        // (only there: a chunk of 64 steps and more holds the four units the first warm calls settle within)
+        cold_hold = (jmax_now < 4 && j > jmax_now) ? 2 : 0;
+    } else if (cold_hold > 0) {                                 // that was a cold call by hold: its snapshots count, nothing to steer
+        cold_hold -= 1;
+        c.j_used = -1;
+        j = jmax_now;
     } else {
         // One unit (16 steps) changes the miss by ~5x at the headline circuit, and two converged fp32 trajectories still
         // differ by ~3e-8: grow when the miss comes within 2x of tol (or a boundary failed), shrink -- once the
@@ -854,6 +866,7 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
         // growing do not probe lower again for 32 calls.  Measured in the bench loop (tools/warm_pin_probe.py, 32-step
         // units): 32 steps miss by <= 3e-7, 64 by <= 7e-8, 96 sit at the rounding floor.
         c.j_used = j;
+        if (nb > 0 && j >= jmax_now && jmax_now < 4) cold_hold = 3;   // missed with all the warm-up a SHORT chunk can hold: three cold calls, then again
         if (nb > 0) { j += 4; hold = 32; }
         else if (mm * 2.0f > tol) { j += 1; hold = j == 1 ? 8 : 32; }   // (from NO warm-up: an excursion of the extrapolation's
                                                                         //  noise, over in a call or two -- try again soon)
@@ -864,8 +877,9 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
         else if (valid > 1 && mm * 10.0f < tol) j -= 1;         // (down to NO warm-up: the chunk then starts from the
                                                                 //  extrapolated snapshot itself, and the check is the same)
     }
-    const int jmax = (int)(L / kWarmStep) < J - 1 ? (int)(L / kWarmStep) : J - 1;
+    const int jmax = jmax_now;
     const int jmin = jfloor < jmax ? jfloor : jmax;
+    c.cold_hold = cold_hold;
     c.j_next = j < jmin ? jmin : (j > jmax ? jmax : j);
     c.j_floor = jfloor | (hold << 8);
 #pragma unroll

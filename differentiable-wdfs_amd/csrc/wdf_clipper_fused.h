@@ -493,7 +493,7 @@ __device__ __forceinline__ void clipper_fused_body(
     const bool stateful = ctl != nullptr && c0.geom == tp_geom_tag(K, J, skew != 0);
     const int valid = stateful ? c0.valid : 0;
     const int head = stateful ? c0.head : 0;
-    const bool warm_start = k > 0 && valid > 0;             // (see clipper_fwd_tp_body)
+    const bool warm_start = k > 0 && valid > 0 && !(stateful && c0.cold_hold > 0);   // (cold_hold: tp_publish_status_and_steer)
     const int jw = warm_start ? c0.j_next : 0;
     if (warm_start) tw = t0 - (int64_t)kWarmStep * jw;
     else tw = (t0 > W) ? t0 - W : 0;

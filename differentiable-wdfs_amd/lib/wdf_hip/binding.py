@@ -432,10 +432,10 @@ class TpWarmState:
     def info(self):
         """Host view of the control block (synchronises): snapshot sets available, warm-up tiles the next
         call will run, tiles the last call ran (-1: cold), its largest boundary miss, calls so far."""
-        c = self.buf[:64].cpu()
+        c = self.buf[:96].cpu()
         i, f = c.view(torch.int32), c.view(torch.float32)
         return {"valid": int(i[0]), "next_warm_tiles": int(i[2]), "last_warm_tiles": int(i[3]),
-                "last_miss": float(f[12]), "n_calls": int(i[13]), "warm_unit_steps": self.unit}
+                "last_miss": float(f[12]), "n_calls": int(i[13]), "warm_unit_steps": self.unit, "cold_hold": int(i[20])}
 
 
 def warm_unit():
