@@ -69,7 +69,10 @@ __device__ __forceinline__ float asym_newton_f32(const AsymConsts& c, float a, f
         const float e1 = fast_exp(v * iV1), e2 = fast_exp(-v * iV2);
         const float f = v + c.Rp * (c.Is1 * (e1 - 1.0f) - c.Is2 * (e2 - 1.0f)) - a;
         const float fp = fmaf(c.Rp, fmaf(c.Is1 * iV1, e1, c.Is2 * iV2 * e2), 1.0f);
-        const float dv = fminf(fmaxf(f * fast_rcp(fp), -lim), lim);
+        const float q = f * fast_rcp(fp);
+        // (a quotient that is not a number -- v_exp_f32 overflowed on a wild start value -- moves nothing: fmaxf / fminf would turn
+        //  it into a full step of -lim, in a direction nobody chose; the fp64 iterations behind this take over)
+        const float dv = (q == q) ? fminf(fmaxf(q, -lim), lim) : 0.0f;
         v -= dv;
     }
     iters += 2;
@@ -90,7 +93,8 @@ __device__ __forceinline__ double asym_newton_root(const AsymConsts& c, double a
     // bound (a cold start value, the damping at work) takes the library exp again.
     auto step_exps = [&](double& e1, double& e2, double dv) {
         const double d1 = -dv * iV1, d2 = dv * iV2;
-        if (__builtin_amdgcn_ballot_w64(!(fmax(fabs(d1), fabs(d2)) < 1.0e-3)) != 0) {
+        // (also when a carried exponential is no longer finite: inf x polynomial stays inf, only a fresh exp recovers)
+        if (__builtin_amdgcn_ballot_w64(!(fmax(fabs(d1), fabs(d2)) < 1.0e-3) || !(fabs(e1) < 1.0e300) || !(fabs(e2) < 1.0e300)) != 0) {
             e1 = exp(v * iV1); e2 = exp(-v * iV2);
         } else {
             const double c6 = 1.0 / 720.0, c5 = 1.0 / 120.0, c4 = 1.0 / 24.0, c3 = 1.0 / 6.0;

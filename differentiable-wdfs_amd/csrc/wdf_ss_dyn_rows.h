@@ -69,6 +69,11 @@ struct RowsRegs {
 // +, -, *, negate as ONE branch-free form  v = c1 x + c2 y + c3 x y  with wave-uniform coefficients (the interpreter's time went
 // into the taken branches of a per-operation switch, not into the arithmetic); / and reciprocal, constants and component values
 // are the rare operations and branch.
+// FINITE TAPES ONLY: the form multiplies the operand an operation does not use by 0 (NEG reads node 0 as y, MUL forms 0 x), so an
+// infinite or NaN node would poison results that tape.evaluate_torch keeps finite (0 x inf).  The nodes of a probed step are
+// resistances, conductances and their ratios of component values the element classes clip to finite positive ranges
+// (tf_wdf.py:69-75,99-105: R in [180, 1e6], C in [1e-13, 1]) and of a resistance channel the caller owns: a channel holding 0, inf
+// or NaN gives NaN rows here (and a division by zero in the reference's own calc_impedance).
 struct RowsForm {
     double c1, c2, c3;
     __device__ __forceinline__ explicit RowsForm(int op)
