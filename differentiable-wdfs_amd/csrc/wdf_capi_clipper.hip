@@ -266,7 +266,7 @@ __global__ void esr_finish_kernel(const float* __restrict__ sums10, double n, do
 
 extern "C" {
 #ifdef WDF_DBG_TIMES
-int wdf_debug_set_times(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(wdf::g_dbg_times), &p, sizeof(p)); }
+__attribute__((visibility("default"))) int wdf_debug_set_times(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(wdf::g_dbg_times), &p, sizeof(p)); }
 #endif
 
 int wdf_clipper_fwd(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, float* y,

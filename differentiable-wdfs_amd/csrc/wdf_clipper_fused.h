@@ -1040,6 +1040,12 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
 //     reduces, applies the chain rule, publishes the status, steers the warm start and runs Adam.
 // Measured on the trial of round 5 (profiles/README.md): the one-pass kernel without its tail runs 0.089-0.090 ms instead of
 // 0.107-0.109; the serial tail as a second launch cost 19 us and gave all of it back.
+#ifdef WDF_DBG_TIMES      // tools/dbg_fin_times.py: wall-clock stamps of every tile's wave 0 along the finish launch: [8 tiles K + 8 tile + i]
+#define WDF_FIN_STAMP(i)                                                                                      \
+    do { if (threadIdx.x == 0 && g_dbg_times) g_dbg_times[8 * ((size_t)gridDim.x * (size_t)K) + 8 * (size_t)blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define WDF_FIN_STAMP(i) do {} while (0)
+#endif
 constexpr int kFinSeg = 8;          // chunk records a finishing wave holds in registers at a time
 constexpr int kFinMaxWaves = 8;     // waves per tile (512 threads: the repair path needs up to 161 VGPRs)
 
@@ -1066,6 +1072,7 @@ __global__ __launch_bounds__(64 * kFinMaxWaves) void clipper_fused_finish_kernel
     const int64_t b_first = live ? raw : B - NSEQ;
     const uint32_t lanes = gridDim.x * 64u, rl = blockIdx.x * 64u + (uint32_t)lane;
     const bool one_batch = seg <= kFinSeg;
+    WDF_FIN_STAMP(0);
 
     v4u g[kFinSeg][NQ];
     auto load_batch = [&](int64_t kb) {                     // records of chunks kb .. kb + 7 (clamped to the wave's last)
@@ -1114,6 +1121,7 @@ __global__ __launch_bounds__(64 * kFinMaxWaves) void clipper_fused_finish_kernel
         const int wbad = wave_sum_dpp(nbad);
         if (lane == 0) { s_miss[w] = wmax; s_bad[w] = wbad; }
     }
+    WDF_FIN_STAMP(1);
     __syncthreads();
     int tile_bad_pairs = 0;
     float tile_miss = 0.0f;
@@ -1202,6 +1210,7 @@ __global__ __launch_bounds__(64 * kFinMaxWaves) void clipper_fused_finish_kernel
             s_pq[w][h][lane][2] = (float)qV[h]; s_pq[w][h][lane][3] = (float)qP[h];
         }
     }
+    WDF_FIN_STAMP(2);
     __syncthreads();
     // ---- phase B: the tangent entering this wave's first chunk, then the walk with the sums
     double sL[NSEQ], sV[NSEQ], sP[NSEQ];                   // (the tangent entering the tile is 0: z0 does not depend on theta)
@@ -1267,6 +1276,7 @@ __global__ __launch_bounds__(64 * kFinMaxWaves) void clipper_fused_finish_kernel
             if (lane == 0) s_sum[w][i] = t;
         }
     }
+    WDF_FIN_STAMP(3);
     __syncthreads();
     if (w != 0) return;
     double tot[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1276,6 +1286,7 @@ __global__ __launch_bounds__(64 * kFinMaxWaves) void clipper_fused_finish_kernel
             for (int i = 0; i < (LOSS == 2 ? 8 : 4); ++i) tot[i] += s_sum[ww][i];
     }
     out.fc = TpFinishCtx{status, ctl, J, tickets, tol, K, L, W, skew != 0};
+    WDF_FIN_STAMP(4);
     if constexpr (LOSS == 2) esr_tile_partial_and_finish(tot, ws, gticket, theta, fs, DYN_R ? 1 : 0, out);
     else tile_partial_and_finish(tot[0], tot[1], tot[2], tot[3], ws, gticket, theta, fs, DYN_R ? 1 : 0, out.gtheta, out.accumulate, out.sse_out,
                                  out.adam, sh, out.fc);
