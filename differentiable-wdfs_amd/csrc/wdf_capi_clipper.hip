@@ -207,7 +207,7 @@ inline int64_t fused_skew(int64_t n_waves, int K, int64_t L, int64_t T, int max_
     return skew;
 }
 
-template <bool DYN_R, bool SYM, bool TM, bool V4>
+template <int DYN_R, bool SYM, bool TM, bool V4>
 void launch_fused(const float* x, const float* r, const float* theta, float fs, int n_up, int n_down, const float* target,
                   float hgs, int64_t skip, float* y, const float* z0, float* zT, FusedWs w, wdf::TpStatus* status, float tol,
                   int64_t B, int64_t T, TpGeom g, int64_t W, TpWarm warm, int general, bool pairs, bool esr, wdf::FusedOut out,
@@ -516,7 +516,7 @@ static int step_tp_common(const float* x, const float* r, float* theta, float fs
                           int warmup, float tol, void* ws, void* status, void* state, int max_warm_tiles, bool esr,
                           wdf::FusedOut out, int flags, void* stream, const char* what)
 {
-    int rc = check_common(x, theta, n_up, n_down, B, T, flags & ~WDF_ONE_SEQUENCE_PER_LANE);
+    int rc = check_common(x, theta, n_up, n_down, B, T, flags & ~(WDF_ONE_SEQUENCE_PER_LANE | WDF_R_PER_SEQUENCE));
     if (rc) return rc;
     if (!target || !y || !ws || !status) return fail(WDF_EINVAL, "null target/y/ws/status");
     if (!(fs > 0.0f)) return fail(WDF_EINVAL, "fs must be positive");
@@ -544,6 +544,19 @@ static int step_tp_common(const float* x, const float* r, float* theta, float fs
     const bool pairs = !(flags & WDF_ONE_SEQUENCE_PER_LANE) && (B % 2 == 0) && aligned8(x) && aligned8(target) && aligned8(y) &&
                        (!r || aligned8(r));
     const int64_t skew = fused_skew((B + (pairs ? 127 : 63)) / (pairs ? 128 : 64) * (int64_t)g.K, g.K, g.L, T, state ? max_warm_tiles : 0);
+    if (r != nullptr && (flags & WDF_R_PER_SEQUENCE)) {
+        // one pot value per sequence (the caller vouches for it): calc_impedance once per chunk, the channel not streamed
+#define WDF_FUSED_SEQ(SYM_, TM_, V4_)                                                                                             \
+        launch_fused<2, SYM_, TM_, V4_>(x, r, theta, fs, n_up, n_down, target, hgs, skip, y, z0, zT, fused_ws(ws, B, g.K),          \
+                                        (wdf::TpStatus*)status, tol, B, T, g, W, warm, (flags & WDF_GENERAL_ROOT) ? 1 : 0, pairs, esr, out, \
+                                        skew, (hipStream_t)stream)
+        const bool sym = n_up == n_down;
+        if (tm) { if (sym) WDF_FUSED_SEQ(true, true, false); else WDF_FUSED_SEQ(false, true, false); }
+        else if (v4) { if (sym) WDF_FUSED_SEQ(true, false, true); else WDF_FUSED_SEQ(false, false, true); }
+        else { if (sym) WDF_FUSED_SEQ(true, false, false); else WDF_FUSED_SEQ(false, false, false); }
+#undef WDF_FUSED_SEQ
+        return check_launch(what);
+    }
     WDF_DISPATCH4(launch_fused, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, target, hgs, skip, y, z0, zT,
                   fused_ws(ws, B, g.K), (wdf::TpStatus*)status, tol, B, T, g, W, warm,
                   (flags & WDF_GENERAL_ROOT) ? 1 : 0, pairs, esr, out, skew, (hipStream_t)stream);

@@ -67,11 +67,42 @@ __device__ __forceinline__ ClipConsts load_consts(const float* __restrict__ thet
     return c;
 }
 
+// DYN_R, the resistance channel's mode:  0 the source's own (trainable) R;  1 a value per sample (set_resistance +
+// calc_impedance every step, clipper_pot.py:116-117);  2 (round 6) a value per SEQUENCE -- the reference's recordings hold one
+// pot value per file (dataimport.py:96 repeats it down the channel), so the channel is constant along every sequence:
+// calc_impedance's result is formed ONCE per chunk (make_seq_consts: the per-sample arithmetic, bit for bit) instead of per
+// step (two reciprocals and a logarithm of the step's 14 transcendentals), and the channel is not streamed (4 B per sample less).
+// The kernels reach the per-sequence coefficients through the constants they are handed: a ClipConstsSeq IS a ClipConsts.
+template <typename VV>              // (ClipConsts has a member V: the parameter needs another name in here)
+struct ClipConstsSeq : ClipConsts {
+    VV p_v, Rp_v, L_v;
+};
+
+template <int DYN_R, typename V>
+__device__ __forceinline__ ClipConstsSeq<V> make_seq_consts(const ClipConsts& c, V rv)
+{
+    ClipConstsSeq<V> s;
+    static_cast<ClipConsts&>(s) = c;
+    s.p_v = s.Rp_v = s.L_v = vsplat<V>(0.0f);
+    if constexpr (DYN_R == 2) {
+        const V G1 = vrcp(rv);
+        s.Rp_v = vrcp(G1 + c.G2);
+        s.p_v = G1 * s.Rp_v;
+        s.L_v = vmax_c(vfma(vlog2(s.Rp_v), kLn2, vsplat<V>(c.lIV)), -80.0f);   // (a resistance of ~0 must not underflow the LEAN root's exponentials)
+    }
+    return s;
+}
+
 // adaptor coefficients for this step
-template <bool DYN_R, typename V>
+template <int DYN_R, typename V>
 __device__ __forceinline__ void step_coeffs(const ClipConsts& c, V rin, V& p, V& Rp, V& L)
 {
-    if constexpr (DYN_R) {                       // set_resistance + calc_impedance every step
+    if constexpr (DYN_R == 2) {                  // formed once per chunk (make_seq_consts)
+        const ClipConstsSeq<V>& s = static_cast<const ClipConstsSeq<V>&>(c);
+        p = s.p_v;
+        Rp = s.Rp_v;
+        L = s.L_v;
+    } else if constexpr (DYN_R) {                // set_resistance + calc_impedance every step
         const V G1 = vrcp(rin);
         Rp = vrcp(G1 + c.G2);
         p = G1 * Rp;
@@ -143,7 +174,7 @@ __device__ __forceinline__ bool series_only_omega1(const ClipConsts& c)
 // The same test with a per-sample resistance: L_n = log(Rp_n Is / nVt) varies per lane, but the port resistance of
 // Parallel(Vs, C) never exceeds the capacitor's, Rp_n < 1/G2, whatever the pot value -- so L_n < log(Is / (nVt G2)), a
 // wave-uniform bound, and the fast step is as safe for the dataset's streamed pot resistance as for a static one.
-template <bool DYN_R>
+template <int DYN_R>
 __device__ __forceinline__ bool fast_root_ok(const ClipConsts& c, int general)
 {
     if (general) return false;
@@ -153,7 +184,7 @@ __device__ __forceinline__ bool fast_root_ok(const ClipConsts& c, int general)
 
 // The root tier of a launch (wdf_omega.h): one wave-uniform test on the circuit's constants.  LEAN: symmetric pair, static
 // port resistance, log(Rp Is / (N nVt)) in [-80, -7.5].
-template <bool DYN_R, bool SYM>
+template <int DYN_R, bool SYM>
 __device__ __forceinline__ int root_tier(const ClipConsts& c, int general)
 {
     if (!fast_root_ok<DYN_R>(c, general)) return kRootGeneral;
@@ -161,10 +192,16 @@ __device__ __forceinline__ int root_tier(const ClipConsts& c, int general)
         const float l0 = c.L - c.d.l_dn;
         if (l0 <= -7.5f && l0 >= -80.0f) return kRootLean;
     }
+    if constexpr (SYM && DYN_R == 2) {
+        // one pot value per sequence: L varies per lane but not in time, and Rp < 1/G2 bounds it for the whole wave (fast_root_ok);
+        // from below the recordings' pots (kilo-ohms) keep it far above the exponential's underflow: Rp >= 1e-12 would do
+        const float lmax = (c.lIV - logf(c.G2)) - c.d.l_dn;
+        if (lmax <= -7.5f && c.lIV >= -50.0f) return kRootLean;
+    }
     return kRootFast;
 }
 
-template <bool DYN_R, bool SYM, typename V, int FAST = 0>
+template <int DYN_R, bool SYM, typename V, int FAST = 0>
 __device__ __forceinline__ V fwd_step(const ClipConsts& c, V xin, V rin, V& z)
 {
     V p, Rp, L;
@@ -179,7 +216,7 @@ __device__ __forceinline__ V fwd_step(const ClipConsts& c, V xin, V rin, V& z)
     return y;
 }
 
-template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH, int FAST>
+template <int DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH, int FAST>
 __device__ __forceinline__ void clipper_fwd_body(const ClipConsts& c, const float* __restrict__ x,
                                                  const float* __restrict__ r, float* __restrict__ y,
                                                  float* __restrict__ zstash, const float* __restrict__ z0,
@@ -229,7 +266,7 @@ __device__ __forceinline__ void clipper_fwd_body(const ClipConsts& c, const floa
 // The same FAST / general choice as the time-parallel forward (one wave-uniform test per kernel),
 // so both kernels run the same arithmetic on the same data: chunk 0 of the time-parallel forward
 // is bit-identical to this kernel, and a repaired tile is bit-identical to an unrepaired run.
-template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH>
+template <int DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4, bool STASH>
 __global__ __launch_bounds__(64) void clipper_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
@@ -267,7 +304,7 @@ struct StepGrads {
     float sL, sV, sP;   // dL/dL, dL/dV|_L, and dL/dp (static R) or Rp (g_p p + g_L) (per-sample R)
 };
 
-template <bool DYN_R, bool SYM>
+template <int DYN_R, bool SYM>
 __device__ __forceinline__ void bwd_step(const ClipConsts& c, float xin, float rin, float z, float g,
                                          float& gz, StepGrads& acc)
 {
@@ -350,7 +387,7 @@ __device__ __forceinline__ double wave_sum_dpp(double v)
 }
 
 // ws: double[gridDim.x][4] per-wave partial sums {S_L, S_V, S_P, 0}
-template <bool DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4>
+template <int DYN_R, bool SYM, bool TIME_MAJOR, bool VEC4>
 __global__ __launch_bounds__(64) void clipper_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, const float* __restrict__ zstash, const float* __restrict__ gy,
@@ -759,7 +796,7 @@ __device__ __forceinline__ V gather_t(const float (&v)[VT<V>::N][kTile], int i)
 // at the first 32-step boundary where every lane is back within tol_conv of what the speculative
 // pass stored (everything after that point is then within tol_conv of the exact trajectory
 // already); returns true if it ran to the chunk's end (z = end state then).
-template <bool DYN_R, bool SYM, bool TM, bool STASH, int FAST>
+template <int DYN_R, bool SYM, bool TM, bool STASH, int FAST>
 __device__ __forceinline__ bool tp_rerun_chunk(const ClipConsts& c, const float* __restrict__ x,
                                             const float* __restrict__ r, float* __restrict__ y,
                                             float* __restrict__ zstash, float* __restrict__ snapw, int J, int64_t K,
@@ -782,7 +819,7 @@ __device__ __forceinline__ bool tp_rerun_chunk(const ClipConsts& c, const float*
         for (int i = 0; i < kBlk; ++i) {
             const int64_t tt = (t + i < t1) ? t + i : t1 - 1;
             xv[i] = load_one<TM>(x, b, B, T, tt);
-            rv[i] = DYN_R ? load_one<TM>(r, b, B, T, tt) : 1.0f;
+            rv[i] = DYN_R == 1 ? load_one<TM>(r, b, B, T, tt) : 1.0f;
         }
 #pragma unroll
         for (int i = 0; i < kBlk; ++i) {
@@ -902,7 +939,7 @@ __device__ __forceinline__ void tp_publish_status_and_steer(const float* __restr
 // when a boundary failed; the step's finishing wave -- the last tile through the combine, in the step or in its repair
 // launch -- reads the totals and calls tp_publish_status_and_steer.  Otherwise (the forward kernel: nothing follows the
 // verification) the last tile to verify does it here, found by a returning count.
-template <bool DYN_R, int NSEQ = 1, bool DEFER = false>
+template <int DYN_R, int NSEQ = 1, bool DEFER = false>
 __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, const float* zwarm, const float* zend,
                                                TpStatus* __restrict__ status, TpCtl* __restrict__ ctl, int J,
                                                unsigned* tickets, float tol, int64_t B, int64_t L, int64_t W)
@@ -965,7 +1002,7 @@ __device__ __forceinline__ bool tp_verify_tile(const float* __restrict__ theta, 
     return tile_failed;
 }
 
-template <bool DYN_R>
+template <int DYN_R>
 __device__ __forceinline__ void tp_finish(const float* __restrict__ theta, const float* zwarm, const float* zend,
                                           TpStatus* __restrict__ status, TpCtl* __restrict__ ctl, int J,
                                           unsigned* tickets, float tol, int64_t B, int64_t L, int64_t W)
@@ -980,7 +1017,7 @@ __device__ __forceinline__ void tp_finish(const float* __restrict__ theta, const
 // and re-runs chunk k wherever one of its 64 sequences misses by more than tol (tp_rerun_chunk).
 // `head`: the ring slot the forward wrote its snapshots to is one past ctl->head BEFORE the forward
 // advanced it, i.e. ctl->head itself now.
-template <bool DYN_R, bool SYM, bool TM, bool STASH>
+template <int DYN_R, bool SYM, bool TM, bool STASH>
 __global__ __launch_bounds__(64) void clipper_tp_repair_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
@@ -1085,7 +1122,7 @@ __device__ __forceinline__ v2f vsel_nonzero(v2f a, float x, float y) { return v2
 // is recomputed with the forward's own shorter arithmetic and, for a symmetric pair, the partials take the one-pass
 // step's cheaper forms (wdf_clipper_fused.h, fused_step).  The sweep at 4 waves per SIMD is bound by VALU issue since the
 // loads stopped being the limit, so the ~40 % fewer instructions count.
-template <bool DYN_R, bool SYM, typename V, bool FAST = false>
+template <int DYN_R, bool SYM, typename V, bool FAST = false>
 __device__ __forceinline__ void bwd_tp_step(const ClipConsts& c, V xin, V rin, V z, V g, V& alpha, V& beta,
                                             TpAccT<V>& acc)
 {
@@ -1377,7 +1414,7 @@ __device__ __forceinline__ V gathern(const float (&v)[VT<V>::N][NB], int i)
     return r;
 }
 
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, int MSE, typename V, bool FAST>
+template <int DYN_R, bool SYM, bool TM, bool VEC4, int MSE, typename V, bool FAST>
 __device__ __forceinline__ void clipper_bwd_tp_body(
     const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r,
     const float* __restrict__ zstash, const float* __restrict__ gy,
@@ -1478,7 +1515,7 @@ __device__ __forceinline__ void clipper_bwd_tp_body(
     }
 }
 
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, int MSE, typename V>
+template <int DYN_R, bool SYM, bool TM, bool VEC4, int MSE, typename V>
 __global__ __launch_bounds__(64) void clipper_bwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, const float* __restrict__ zstash, const float* __restrict__ gy,

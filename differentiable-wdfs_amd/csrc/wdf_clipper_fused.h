@@ -77,7 +77,7 @@ constexpr int kFusedRows = WDF_FUSED_ROWS;
 // Steps per load burst: 16 with one sequence per lane and a static resistance, half of that with two sequences per
 // lane, half again with the per-sample resistance channel (the tile buffers are the bulk of the VGPRs: x, target and r,
 // current and next; a tile's loads + stores must also stay inside vmcnt's 6 bits).
-template <typename V, bool DYN_R> struct FusedTile { static constexpr int NR = kFusedRows / VT<V>::N / (DYN_R ? 2 : 1); };
+template <typename V, int DYN_R> struct FusedTile { static constexpr int NR = kFusedRows / VT<V>::N / (DYN_R == 1 ? 2 : 1); };
 
 // s_waitcnt vmcnt(N) (gfx9 encoding: vmcnt in bits 3:0 and 15:14; expcnt / lgkmcnt fields at "no wait").
 template <int N>
@@ -262,7 +262,7 @@ struct FusedTan {
 // sums S = sum (y - t)^2 and E = sum y^2, known only after the pass -- so the pass carries BOTH tangent-weighted sums,
 // P_i = sum (y - t) dy/dtheta_i and Q_i = sum y dy/dtheta_i (hgs = 1/2 on live steps), and the last tile forms
 // ga P + gb Q.  Seven more VALU per step.
-template <bool DYN_R, bool SYM, int FAST, typename V, int LOSS = 1>
+template <int DYN_R, bool SYM, int FAST, typename V, int LOSS = 1>
 __device__ __forceinline__ V fused_step(const ClipConsts& c, V xin, V rin, V tgt, float hgs, V& z, FusedTan<V>& s)
 {
     V p, Rp, L;
@@ -464,9 +464,9 @@ __device__ __forceinline__ void fused_publish_record(float* rec, double* wpart, 
 // Chunk geometry as clipper_fwd_tp_body (L, W multiples of kTile); target [T][B]; skip: steps below it carry no loss.
 // LOSS = 0: the plain time-parallel forward (no target, no tangent, no record; STASH: the state before every step goes to
 // zstash [T][B] for the reverse sweep) -- clipper_fwd_tp_kernel below runs this same body.
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, int FAST, typename V, int LOSS, bool STASH = false>
+template <int DYN_R, bool SYM, bool TM, bool VEC4, int FAST, typename V, int LOSS, bool STASH = false>
 __device__ __forceinline__ void clipper_fused_body(
-    const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ target,
+    const ClipConsts& c_in, const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ target,
     float* __restrict__ y, float* __restrict__ zstash, const float* __restrict__ z0, float* __restrict__ zT, float* __restrict__ zwarm,
     float* __restrict__ zend, float* rec, const float* __restrict__ theta, const TpCtl* __restrict__ ctl,
     float* __restrict__ snap, int J, int64_t B, int64_t T, int64_t L, int64_t W, float hgs, int64_t skip, int64_t skew = 0,
@@ -478,6 +478,8 @@ __device__ __forceinline__ void clipper_fused_body(
     dbg_p[0] = __builtin_amdgcn_s_memtime();
 #endif
     const LaneOwn<V> q(B);
+    // (DYN_R = 2: the lane's sequences' pot values, read once -- their first sample -- and calc_impedance's result with them)
+    const ClipConstsSeq<V> c = make_seq_consts<DYN_R, V>(c_in, DYN_R == 2 ? load_step<V, TM>(r, q, B, T, 0) : vsplat<V>(1.0f));
     const int64_t k = blockIdx.y, K = gridDim.y;
     int64_t t0, t1;
     chunk_span(k, K, L, skew, T, t0, t1);
@@ -507,7 +509,7 @@ __device__ __forceinline__ void clipper_fused_body(
     const int64_t nfull_end = t1 - (t1 - tw) % NR;
     if (tw < nfull_end) {
         load_x_tile<V, TM, VEC4, NR>(x, q, B, T, tw, rowb, xn);
-        if constexpr (DYN_R) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, tw, rowb, rn);
+        if constexpr (DYN_R == 1) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, tw, rowb, rn);
         if constexpr (LOSS != 0) { if (tw >= t0) load_rows<V, NR>(target + tw * B, boff, rowb, gn); }
     }
     if (warm_start) {
@@ -539,10 +541,10 @@ __device__ __forceinline__ void clipper_fused_body(
 #endif
     for (; t < t0 && t < nfull_end; t += NR) {              // ---- warm-up tiles: forward only, nothing stored
 #pragma unroll
-        for (int i = 0; i < NR; ++i) { xc[i] = xn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
+        for (int i = 0; i < NR; ++i) { xc[i] = xn[i]; if constexpr (DYN_R == 1) rc[i] = rn[i]; }
         if (t + NR < nfull_end) {
             load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
-            if constexpr (DYN_R) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, t + NR, rowb, rn);
+            if constexpr (DYN_R == 1) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, t + NR, rowb, rn);
             if constexpr (LOSS != 0) { if (t + NR >= t0) load_rows<V, NR>(target + (t + NR) * B, boff, rowb, gn); }   // the first owned tile's target
         }
 #pragma unroll
@@ -565,7 +567,7 @@ __device__ __forceinline__ void clipper_fused_body(
 #endif
     for (; t < nfull_end; t += NR) {                        // ---- owned tiles
 #pragma unroll
-        for (int i = 0; i < NR; ++i) { xc[i] = xn[i]; gc[i] = gn[i]; if constexpr (DYN_R) rc[i] = rn[i]; }
+        for (int i = 0; i < NR; ++i) { xc[i] = xn[i]; gc[i] = gn[i]; if constexpr (DYN_R == 1) rc[i] = rn[i]; }
         const bool more = t + NR < nfull_end;
         if (snapw != nullptr && t1 - t <= (int64_t)kWarmStep * (J - 1) && (t1 - t) % kWarmStep == 0)
             store_own<V>(snapw + ((t1 - t) / kWarmStep) * K * B, q, z);   // snapshot kWarmStep j steps before the chunk's end
@@ -583,7 +585,7 @@ __device__ __forceinline__ void clipper_fused_body(
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
                     load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
-                    if constexpr (DYN_R) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, t + NR, rowb, rn);
+                    if constexpr (DYN_R == 1) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, t + NR, rowb, rn);
                     if constexpr (LOSS != 0) load_rows<V, NR>(target + (t + NR) * B, boff, rowb, gn);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -619,7 +621,7 @@ __device__ __forceinline__ void clipper_fused_body(
     }
     for (int64_t tt = nfull_end; tt < t1; ++tt) {           // tail of the last chunk (T % NR)
         const V xin = load_step<V, TM>(x, q, B, T, tt);
-        const V rin = DYN_R ? load_step<V, TM>(r, q, B, T, tt) : vsplat<V>(1.0f);
+        const V rin = DYN_R == 1 ? load_step<V, TM>(r, q, B, T, tt) : vsplat<V>(1.0f);
         if constexpr (LOSS == 0) {
             if constexpr (STASH) store_own<V>(zstash + tt * B, q, z);
             store_own<V>(y + tt * B, q, fwd_step<DYN_R, SYM, V, FAST>(c, xin, rin, z));
@@ -806,7 +808,7 @@ __device__ __forceinline__ void fused_combine_tile(float* rec, double* wpart, in
 // tickets: the forward's verification area [TpAcc][per-tile tickets][per-tile repair flags];
 // gticket: [tiles combined, 0, 0, 0] -- both zero before the first launch and left zero by every step.
 // A tile is the 64 * VT<V>::N sequences of one wave.
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, typename V, int LOSS>
+template <int DYN_R, bool SYM, bool TM, bool VEC4, typename V, int LOSS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WAVES, WDF_FUSED_WAVES))) void clipper_fused_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, const float* __restrict__ z0,
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     const int tier = root_tier<DYN_R, SYM>(c, general);
     bool ran = false;
-    if constexpr (SYM && !DYN_R) {
+    if constexpr (SYM && DYN_R != 1) {
         if (tier == kRootLean) {
             clipper_fused_body<DYN_R, SYM, TM, VEC4, kRootLean, V, LOSS>(c, x, r, target, y, nullptr, z0, zT, zwarm, zend, rec, theta, ctl, snap,
                                                                          J, B, T, L, W, hgs, skip, skew, wpart);
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
 // The time-parallel FORWARD (wdf_clipper_fwd_tp / _warm: y and the state stash for a reverse sweep that arbitrary losses
 // drive) on the same body: buffer-descriptor rows, 16-row tiles prefetched a tile ahead, the wait on the back edge.
 // Verification and warm-start steering in its last waves (tp_finish), repairs in clipper_tp_repair_kernel (wdf_clipper.h).
-template <bool DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V>
+template <int DYN_R, bool SYM, bool TM, bool VEC4, bool STASH, typename V>
 __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ theta,
     float fs, int n_up, int n_down, float* __restrict__ y, float* __restrict__ zstash,
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
     const ClipConsts c = load_consts(theta, fs, n_up, n_down);
     const int tier = root_tier<DYN_R, SYM>(c, general);                 // wave-uniform: every practical diode is LEAN / FAST
     bool ran = false;
-    if constexpr (SYM && !DYN_R) {
+    if constexpr (SYM && DYN_R != 1) {
         if (tier == kRootLean) {
             clipper_fused_body<DYN_R, SYM, TM, VEC4, kRootLean, V, 0, STASH>(c, x, r, nullptr, y, zstash, z0, zT, zwarm, zend, nullptr, theta,
                                                                              ctl, snap, J, B, T, L, W, 0.0f, 0);
@@ -917,13 +919,14 @@ __global__ __launch_bounds__(64) void clipper_fwd_tp_kernel(
 }
 
 // Re-run of chunk [t0, t1) for 64 sequences (one per lane, index b) from the exact state z: outputs, snapshots, record.
-template <bool DYN_R, bool SYM, bool TM, int FAST, int LOSS, int NSEQ>
-__device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const float* __restrict__ x, const float* __restrict__ r,
+template <int DYN_R, bool SYM, bool TM, int FAST, int LOSS, int NSEQ>
+__device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c_in, const float* __restrict__ x, const float* __restrict__ r,
                                                   const float* __restrict__ target, float* __restrict__ y, float* rec, double* wpart,
                                                   float* __restrict__ snapw, int J, int64_t K, int64_t k, int64_t b, int64_t B,
                                                   bool live, int slot, int64_t T, int64_t t0, int64_t t1, float hgs, int64_t skip,
                                                   float& z)
 {
+    const ClipConstsSeq<float> c = make_seq_consts<DYN_R, float>(c_in, DYN_R == 2 ? load_one<TM>(r, b, B, T, 0) : 1.0f);
     FusedTan<float> s;
     s.init();
     FusedSums<float> d;
@@ -939,7 +942,7 @@ __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const flo
         for (int i = 0; i < kBlk; ++i) {
             const int64_t tt = (t + i < t1) ? t + i : t1 - 1;
             xv[i] = load_one<TM>(x, b, B, T, tt);
-            rv[i] = DYN_R ? load_one<TM>(r, b, B, T, tt) : 1.0f;
+            rv[i] = DYN_R == 1 ? load_one<TM>(r, b, B, T, tt) : 1.0f;
             gv[i] = target[tt * B + b];
         }
 #pragma unroll
@@ -959,7 +962,7 @@ __device__ __forceinline__ void fused_rerun_chunk(const ClipConsts& c, const flo
 // case).  For a flagged tile (64 NSEQ sequences; each of its NSEQ interleaved sets of 64 in turn): walk the chunk
 // boundaries in time order, re-run every chunk one of whose sequences arrived more than tol off (from the exact
 // state, one sequence per lane), then combine the tile.
-template <bool DYN_R, bool SYM, bool TM, int NSEQ, int LOSS>
+template <int DYN_R, bool SYM, bool TM, int NSEQ, int LOSS>
 __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, float* __restrict__ zT,
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
             float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
             float z = e;
             bool ran = false;
-            if constexpr (SYM && !DYN_R) {
+            if constexpr (SYM && DYN_R != 1) {
                 if (tier == kRootLean) {
                     fused_rerun_chunk<DYN_R, SYM, TM, kRootLean, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
                     ran = true;
@@ -1049,7 +1052,7 @@ __global__ __launch_bounds__(64) void clipper_fused_repair_kernel(
 constexpr int kFinSeg = 8;          // chunk records a finishing wave holds in registers at a time
 constexpr int kFinMaxWaves = 8;     // waves per tile (512 threads: the repair path needs up to 161 VGPRs)
 
-template <bool DYN_R, bool SYM, bool TM, int NSEQ, int LOSS>
+template <int DYN_R, bool SYM, bool TM, int NSEQ, int LOSS>
 __global__ __launch_bounds__(64 * kFinMaxWaves) void clipper_fused_finish_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* theta, float fs, int n_up, int n_down,
     const float* __restrict__ target, float hgs, int64_t skip, float* __restrict__ y, float* __restrict__ zT,
@@ -1156,7 +1159,7 @@ __global__ __launch_bounds__(64 * kFinMaxWaves) void clipper_fused_finish_kernel
                     float* __restrict__ snapw = (snap != nullptr && k + 1 < K) ? snap + ((int64_t)slot * J * K + k) * B : nullptr;
                     float z = e;
                     bool ran = false;
-                    if constexpr (SYM && !DYN_R) {
+                    if constexpr (SYM && DYN_R != 1) {
                         if (tier == kRootLean) {
                             fused_rerun_chunk<DYN_R, SYM, TM, kRootLean, LOSS, NSEQ>(c, x, r, target, y, rec, wpart, snapw, J, K, k, b, B, live, h, T, t0, t1, hgs, skip, z);
                             ran = true;

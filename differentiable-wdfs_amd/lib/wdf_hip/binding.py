@@ -20,6 +20,7 @@ WDF_PREC_F64 = 1 << 1
 WDF_GENERAL_ROOT = 1 << 3
 WDF_MLP_LANE_PER_SEQUENCE = 1 << 4
 WDF_ONE_SEQUENCE_PER_LANE = 1 << 5
+WDF_R_PER_SEQUENCE = 1 << 6
 
 # Set True to run the one-lane-per-sequence MLP kernels (csrc/wdf_mlp.h) instead of the default
 # 16-lane row per sequence (csrc/wdf_mlp_row.h): parity tests and A/B timing.
@@ -504,6 +505,27 @@ def clipper_bwd_mse_tp_adam(x, theta, fs, zstash, zT, target, gscale, n_chunks, 
     return gtheta, sse
 
 
+_R_SEQ_CACHE = {}       # (data_ptr, shape, strides, version) -> bool
+R_PER_SEQUENCE = os.environ.get("WDF_R_PER_SEQUENCE", "1") not in ("", "0")     # (0: always the per-sample evaluation, for A/B runs and tests)
+
+
+def r_is_per_sequence(r, time_major):
+    """Is the resistance channel constant along every sequence (the reference's recordings: one pot value per file,
+    dataimport.py:96 -- batch_data cuts the sequences out of it)?  One comparison pass per tensor (storage and version), cached:
+    the one-pass step then evaluates calc_impedance once per chunk instead of every step (WDF_R_PER_SEQUENCE)."""
+    if r is None or not R_PER_SEQUENCE:
+        return False
+    key = (r.data_ptr(), tuple(r.shape), tuple(r.stride()), r._version)
+    hit = _R_SEQ_CACHE.get(key)
+    if hit is None:
+        if len(_R_SEQ_CACHE) > 64:
+            _R_SEQ_CACHE.clear()
+        with torch.no_grad():
+            first = r[0:1, :] if time_major else r[:, 0:1]
+            hit = _R_SEQ_CACHE[key] = bool((r == first).all())
+    return hit
+
+
 def step_mse_workspace(B, n_chunks, device):
     """Workspace of the one-pass training step with its ticket words cleared: allocate once, reuse."""
     ws = torch.empty((lib().wdf_clipper_step_mse_tp_ws_bytes(int(B), int(n_chunks)),), dtype=torch.uint8, device=device)
@@ -554,7 +576,8 @@ def clipper_step_mse_tp(x, theta, fs, target, gscale, n_chunks, warmup, tol=1e-6
         1 if accumulate else 0, *((None,) * 4 if o is None else (_ptr(o.m), _ptr(o.v), _ptr(o.step), _ptr(o.lr))),
         0.0 if o is None else o.b1, 0.0 if o is None else o.b2, 0.0 if o is None else o.eps,
         None if o is None else _ptr(o.lo), None if o is None else _ptr(o.hi),
-        (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag() | (WDF_ONE_SEQUENCE_PER_LANE if ONE_SEQUENCE_PER_LANE else 0),
+        (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag() | (WDF_ONE_SEQUENCE_PER_LANE if ONE_SEQUENCE_PER_LANE else 0) |
+        (WDF_R_PER_SEQUENCE if r_is_per_sequence(r, time_major) else 0),
         _stream())
     _check(rc, "wdf_clipper_step_mse_tp")
     return y, zT, gtheta, sse, status
@@ -605,7 +628,8 @@ def clipper_step_esr_tp(x, theta, fs, target, n_global, eps_energy, skip, n_chun
         _ptr(loss3), *((None,) * 4 if o is None else (_ptr(o.m), _ptr(o.v), _ptr(o.step), _ptr(o.lr))),
         0.0 if o is None else o.b1, 0.0 if o is None else o.b2, 0.0 if o is None else o.eps,
         None if o is None else _ptr(o.lo), None if o is None else _ptr(o.hi),
-        (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag() | (WDF_ONE_SEQUENCE_PER_LANE if ONE_SEQUENCE_PER_LANE else 0),
+        (WDF_X_TIME_MAJOR if time_major else 0) | _root_flag() | (WDF_ONE_SEQUENCE_PER_LANE if ONE_SEQUENCE_PER_LANE else 0) |
+        (WDF_R_PER_SEQUENCE if r_is_per_sequence(r, time_major) else 0),
         _stream())
     _check(rc, "wdf_clipper_step_esr_tp")
     return y, zT, sums10, gtheta, loss3, status

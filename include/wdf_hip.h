@@ -57,6 +57,10 @@ enum {
                                   switch, once per launch, to a shorter step when the static port
                                   resistance keeps omega_1 in its series-only region); for parity tests
                                   and A/B timing -- results agree to fp32 rounding */
+    WDF_R_PER_SEQUENCE = 1 << 6, /* wdf_clipper_step_mse_tp / _esr_tp with a resistance channel r (round 6): the caller vouches that r is
+                                  constant along every sequence (the reference's recordings: one pot value per file,
+                                  dataimport.py:96) -- calc_impedance is then evaluated once per chunk from each sequence's
+                                  first sample and the channel is not streamed; results as with the per-sample evaluation */
     WDF_ONE_SEQUENCE_PER_LANE = 1 << 5 /* wdf_clipper_step_mse_tp: one sequence per lane even when the batch is even
                                   (by default a lane then runs two adjacent sequences with packed fp32
                                   arithmetic); for parity tests and A/B timing */

@@ -164,6 +164,60 @@ def test_fused_per_sample_resistance_and_skip(wb):
     assert ok, info
 
 
+@pytest.mark.parametrize("time_major", [True, False])
+@pytest.mark.parametrize("n_up,n_down", [(1, 1), (1, 2)])
+def test_fused_one_pot_value_per_sequence(wb, oracle, time_major, n_up, n_down):
+    """The reference's recordings hold ONE pot value per file (dataimport.py:96; batch_data cuts the sequences out of it): a
+    resistance channel that is constant along every sequence.  The binding notices (r_is_per_sequence: one comparison per
+    tensor) and the one-pass step evaluates calc_impedance once per chunk (WDF_R_PER_SEQUENCE: DYN_R = 2 in the kernels; the
+    symmetric pair then takes the LEAN root) instead of every step.  Against the per-sample evaluation of the same data (the
+    flag switched off) and against the fp64 oracle: y, SSE, gradients; MSE and MSE + ESR; a warm-started second call; a
+    channel that moves within a sequence keeps the per-sample path."""
+    from wdf_hip import workload
+    B, T, K, W, skip = 200, 2048, 8, 448, 50
+    x, th, ths = problem(B, T, seed=13)
+    r_host = workload.dataset_resistance_batch(B, T)                       # four blocks of sequences, one pot value each
+    xd, rd, thd = dev(x), dev(r_host), dev(th)
+    tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, r=rd, n_up=n_up, n_down=n_down, want_stash=False)
+    xin, rin = (xd.t().contiguous(), rd.t().contiguous()) if time_major else (xd, rd)
+    assert wb.r_is_per_sequence(rin, time_major)
+    gscale = 2.0 / (B * T)
+    out = {}
+    for per_seq in (True, False):
+        wb.R_PER_SEQUENCE = per_seq
+        try:
+            y, _, g, sse, st = wb.clipper_step_mse_tp(xin, thd, FS, tgt, gscale, K, W, r=rin, n_up=n_up, n_down=n_down, time_major=time_major)
+            assert wb.tp_status(st)["n_bad"] == 0
+            ye, _, s10, ge, l3, _ = wb.clipper_step_esr_tp(xin, thd, FS, tgt, float(B * (T - skip)), 2.2e-16, skip, K, W, r=rin, n_up=n_up,
+                                                          n_down=n_down, time_major=time_major)
+            out[per_seq] = (y.clone(), g.clone(), float(sse), ye.clone(), ge.clone(), l3.clone())
+        finally:
+            wb.R_PER_SEQUENCE = True
+    a, b = out[True], out[False]
+    assert float((a[0] - b[0]).abs().max()) <= 3e-7 and float((a[3] - b[3]).abs().max()) <= 3e-7
+    ok, info = close_grad(a[1][[0, 1, 3]], b[1][[0, 1, 3]], rtol=2e-5)
+    assert ok and float(a[1][2]) == 0.0, info
+    ok, info = close_grad(a[4][[0, 1, 3]], b[4][[0, 1, 3]], rtol=2e-5)
+    assert ok, info
+    assert abs(a[2] - b[2]) <= 1e-5 * b[2] and float((a[5] - b[5]).abs().max()) <= 1e-5 * float(b[5].abs().max())
+    # the oracle: y and the MSE gradient
+    th64 = th.astype(np.float32).astype(np.float64)
+    t64 = tgt.cpu().numpy().astype(np.float64)
+    y64 = oracle.clipper_fwd(th64, FS, x.astype(np.float64), r=r_host.astype(np.float64), n_up=n_up, n_down=n_down)
+    _, g64 = oracle.clipper_fwd_bwd(th64, FS, x.astype(np.float64), 2.0 * (y64 - t64) / (B * T), r=r_host.astype(np.float64), n_up=n_up,
+                                    n_down=n_down)
+    assert float(np.max(np.abs(a[0].cpu().numpy() - y64))) <= Y_TOL
+    got = a[1].cpu().numpy().astype(np.float64)
+    assert all(abs(got[i] - g64[i]) <= G_RTOL * abs(g64[i]) for i in (0, 1, 3)), (got, g64)
+    # a pot that moves within a sequence is not taken for a constant one
+    wob = rin.clone()
+    if time_major:
+        wob[T // 2:, 3] *= 1.01
+    else:
+        wob[3, T // 2:] *= 1.01
+    assert not wb.r_is_per_sequence(wob, time_major)
+
+
 def test_fused_initial_state_general_root_and_accumulate(wb):
     B, T, K, W = 64, 1024, 4, 256
     x, th, ths = problem(B, T, seed=2)
