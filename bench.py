@@ -1038,6 +1038,102 @@ def run_tree_step(args, rank, local, kind):
     print(json.dumps(out), flush=True)
 
 
+def run_c4(args, rank, local):
+    """--config c4: BASELINE configs[3]'s per-GPU share as a line of its own -- the dataset-style training loop: the reference's
+    training set shape (1340 sequences of 2048 samples, .MISSING_LARGE_BLOBS:1-5 / clipper_pot.py:58) tiled to --batch (8192)
+    sequences, one pot value per sequence on the recordings' grid laid out as the loader leaves it (dataimport.py:82-137: four
+    contiguous blocks), the pot streamed as input channel 1 (clipper_pot.py:114-117), loss MSE + ESR past 50 samples
+    (clipper_pot.py:146-156,177,232,248), Adam on {Is, nVt, C} in the step's own launch (R is data).  The diode-pair root of the
+    north star; one GPU (the 8-GPU run shards the batch and all-reduces ten floats per step: --gpus N --loss mse+esr)."""
+    dev = torch.device("cuda", local)
+    fs, B0, T, skip = workload.FS, 1340, 2048, 50
+    B = args.batch
+    idx = np.arange(B) % B0
+    x_host = workload.sweep_batch(B0, T, seed=4)[idx]
+    r_host = workload.dataset_resistance_batch(B0, T)[idx]
+    x, r = torch.as_tensor(x_host, device=dev), torch.as_tensor(r_host, device=dev)
+    xt, rt = x.t().contiguous(), r.t().contiguous()              # the engine's resident layout (one-off, at data load)
+    th0 = workload.clipper_theta()
+    tgt, _, _ = binding.clipper_fwd(x, torch.tensor(workload.target_theta(), dtype=torch.float32, device=dev), fs, r=r, want_stash=False)
+    plan = engine.plan_time_parallel(B, T, float(r_host.max()), th0[3], fs, time_major=True, R_min=float(r_host.min()))
+    best = None
+    for k in sorted({k for k in (plan.k_fwd, plan.k_fwd * 2, plan.k_fwd * 4, plan.k_fwd * 8) if 2 <= k <= T // 64}):
+        theta = torch.tensor(th0, dtype=torch.float32, device=dev)
+        adam = binding.Adam(4, lr=[1e-3 * float(v) for v in th0], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
+        st = engine.MseStep(B, T, fs, plan._replace(k_fwd=k), dev, time_major=True, loss="mse+esr", skip=skip, warm=True)
+        for _ in range(12):
+            st.step_fused(theta, xt, tgt, r=rt, adam=adam)
+        e0, e1 = binding.Event(), binding.Event()
+        e0.record()
+        for _ in range(10):
+            st.step_fused(theta, xt, tgt, r=rt, adam=adam)
+        e1.record()
+        ms = e0.elapsed_ms(e1) / 10
+        if binding.tp_status(st.status)["n_bad"] == 0 and (best is None or ms < best[0]):
+            best = (ms, k)
+    k = best[1] if best else plan.k_fwd
+    theta = torch.tensor(th0, dtype=torch.float32, device=dev)
+    adam = binding.Adam(4, lr=[1e-3 * float(v) for v in th0], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
+    st = engine.MseStep(B, T, fs, plan._replace(k_fwd=k), dev, time_major=True, loss="mse+esr", skip=skip, warm=True)
+    losses, g_first = [], None
+    for i in range(args.warmup):
+        st.step_fused(theta, xt, tgt, r=rt, adam=adam)
+        if i == 0:
+            losses.append(float(st.loss[2]))
+            g_first = st.gtheta.cpu().numpy().astype(np.float64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st.step_fused(theta, xt, tgt, r=rt, adam=adam)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    losses.append(float(st.loss[2]))
+    stat = binding.tp_status(st.status)
+    parity = None
+    if not args.no_parity:
+        # one more step (its parameters kept aside) against the fp64 oracle over the whole batch: y, the three loss values, the gradient
+        O = _oracle()
+        th_before = theta.clone()
+        st.step_fused(theta, xt, tgt, r=rt, adam=adam)
+        torch.cuda.synchronize()
+        n, eps = B * (T - skip), float(np.finfo(float).eps)
+        th64 = th_before.cpu().numpy().astype(np.float64)
+        x64, r64, t64 = x_host.astype(np.float64), r_host.astype(np.float64), tgt.cpu().numpy().astype(np.float64)
+        y64 = O.clipper_fwd(th64, fs, x64, r=r64)
+        o, t = y64[skip:], t64[skip:]
+        S, E = float(np.sum((o - t) ** 2)), float(np.sum(o * o)) + eps
+        mse, esr = S / n, float(np.sqrt(S / E / n))
+        gy = np.zeros_like(y64)
+        gy[skip:] = (2.0 / n + (1.0 / (esr * E * n) if esr > 0 else 0.0)) * (o - t) - esr / E * o
+        _, g64 = O.clipper_fwd_bwd(th64, fs, x64, gy, r=r64)
+        got, l3 = st.gtheta.cpu().numpy().astype(np.float64), st.loss.cpu().numpy().astype(np.float64)
+        parity = {"max_abs_y": float(np.max(np.abs(st.y.cpu().numpy() - y64))),
+                  # (every component against its OWN magnitude at the final parameters -- the loss has fallen by three orders of
+                  #  magnitude by then and the gradient is what is left of a cancellation -- and against its magnitude at the first step)
+                  "max_rel_grad": float(max(abs(got[i] - g64[i]) / abs(g64[i]) for i in (0, 1, 3))),
+                  "max_grad_err_vs_first_step": None if g_first is None else float(max(abs(got[i] - g64[i]) / abs(g_first[i]) for i in (0, 1, 3))),
+                  "grad_shrunk_to": None if g_first is None else [float(abs(g64[i]) / abs(g_first[i])) for i in (0, 1, 3)],
+                  "rel_loss": float(abs(l3[2] - (mse + esr)) / (mse + esr)),
+                  "checked": "y of all sequences, mse + esr and d loss / d{Is, nVt, C} of one more step, vs the fp64 oracle at that step's parameters"}
+    ms = dt / args.steps * 1e3
+    moved = 12.0 * B * T / (ms * 1e-3) / 1e9
+    if rank == 0:
+        print(json.dumps({
+            "metric": "samples/sec fwd+bwd, 1N4148 diode clipper, dataset-style training step (BASELINE configs[3], per-GPU share)",
+            "value": B * T / (ms * 1e-3), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"1N4148 diode clipper, {B} sequences x {T} samples (1340 x 2048 tiled), one pot value per sequence on "
+                                   "{10.0k, 25.2k, 75.0k, 99.1k} streamed as channel 1, MSE + ESR past 50 samples, Adam on {Is, nVt, C} in the step",
+                       "global_batch": B, "seq_len": T, "chunks": k, "resistance_channel": "one value per sequence (WDF_R_PER_SEQUENCE)"
+                       if binding.r_is_per_sequence(rt, True) else "per sample",
+                       "loss_first_step": losses[0] if losses else None, "loss_last_step": losses[-1], "verify_status": stat,
+                       "warm_start": st.warm.info() if st.warm is not None else None},
+            "parity": parity, "library": library_identity(),
+            "roofline": {"bound": "hbm", "kernel": "clipper_fused_tp_kernel", "achieved": moved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": moved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_sample": 12,
+                         "note": "whole step (chunk kernel + finish launch) over x 4 + target 4 + y 4 bytes per sample"}}), flush=True)
+
+
 def self_launch(n, argv, rehearse):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks here -- torch.distributed.run, one process per
     GPU, rendezvous on 127.0.0.1 at a free port -- and hand their exit status back.  (Under a launcher WORLD_SIZE is set
@@ -1128,8 +1224,9 @@ def main():
                     help="skip strong_proxy: the per-rank step of the 8-rank strong-scaling run (1/8 of the batch) timed on this GPU")
     ap.add_argument("--no-sustained", action="store_true", help="skip value_sustained: the headline loop kept running for ~2.5 s")
     ap.add_argument("--no-fwd-1024", action="store_true", help="skip value_fwd_1024: BASELINE configs[1], forward only at 1024 x 4096")
-    ap.add_argument("--config", default=None, choices=["c2", "lpf", "hpf"],
+    ap.add_argument("--config", default=None, choices=["c2", "c4", "lpf", "hpf"],
                     help="c2: ONLY BASELINE configs[1] (1N4148 diode clipper forward-only, 1024 sequences x 4096 samples), its own JSON line.  "
+                         "c4: BASELINE configs[3]'s per-GPU share (dataset-shaped batch, pot value per sequence, MSE + ESR, Adam).  "
                          "lpf / hpf: secondary lines -- lpf.py's training loop through the element API with resident components "
                          "(RC lowpass: linear one-pass step; HPF diode clipper: diode-root one-pass step)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
@@ -1219,6 +1316,10 @@ def main():
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_["hbm_frac"], "traffic": None},
                               "detail": r_}), flush=True)
         return
+    if args.config == "c4":
+        if world != 1:
+            raise SystemExit("--config c4 is the per-GPU share as a one-GPU line (the sharded run: --gpus N --loss mse+esr)")
+        return run_c4(args, rank, local)
     if args.config in ("lpf", "hpf"):
         if world != 1:
             raise SystemExit("--config lpf / hpf are one-GPU lines (the element API's resident loops do not shard)")
