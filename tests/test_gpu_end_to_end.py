@@ -197,3 +197,15 @@ def test_bench_tree_step_lines(kind):
     assert p["max_abs_y"] < 3e-6 and p["loss_rel"] < 2e-6 and p["grad_max_rel"] < 3e-4, p
     if kind == "hpf":
         assert d["control"]["gated_groups"] == 0
+
+
+def test_bench_c4_line():
+    """bench.py --config c4: BASELINE configs[3]'s per-GPU share (dataset-shaped batch, one pot value per sequence streamed as
+    channel 1, MSE + ESR past 50 samples, Adam in the step) as a line with its own parity block against the oracle."""
+    d = _run_bench(["--config", "c4", "--batch", "1340", "--steps", "6", "--warmup", "3"])
+    assert d["unit"] == "samples/s" and d["value"] > 0 and d["config"]["seq_len"] == 2048
+    assert d["config"]["resistance_channel"].startswith("one value per sequence")
+    assert d["config"]["verify_status"]["n_bad"] == 0
+    assert d["config"]["loss_last_step"] < d["config"]["loss_first_step"]
+    p = d["parity"]
+    assert p["max_abs_y"] < 2e-6 and p["max_rel_grad"] < 1e-4 and p["rel_loss"] < 2e-5, p
