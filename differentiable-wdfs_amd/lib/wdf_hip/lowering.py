@@ -859,13 +859,27 @@ class Circuit:
         loss._wdf_fused = (out, ent[9])
         return loss
 
-    def mse_esr(self, x, target, skip=0):
+    def mse_esr(self, x, target, skip=0, z0=None, carry_state=False):
         """The training loss of clipper_pot.py:146-156,177 on this circuit's output past `skip` samples (:232,248):
         mean((y - t)^2) + sqrt(sum((y - t)^2) / (sum(y^2) + eps) / n)  -- the scripts call esr_loss(outs, train_Y) on a
         function declared (target, predicted), so the normalising energy is the OUTPUT's.  target: [T,B] like the output.
         A resident diode-pair clipper (to_device()) evaluates loss and gradient in one pass over the data
-        (wdf_clipper_step_esr_tp); anything else composes it from the forward."""
+        (wdf_clipper_step_esr_tp); anything else composes it from the forward.
+        z0 / carry_state: as in mse() -- the state the call starts from, or the one the previous carry_state call ended in
+        (`circ.last_state`); composed from __call__(x, z0, return_state) (the resident one-pass steps start from zero state,
+        which is what clipper_pot.py:110-111 does before every forward)."""
         binding.require_gpu()
+        stateful = (z0 is not None or carry_state) and self.ns > 0
+        if stateful:
+            if carry_state and z0 is None:
+                z0 = getattr(self, "last_state", None)
+            y, zT = self(x, z0=z0, return_state=True)
+            self.last_state, self.last_output = zT.detach(), y.detach()
+            o = y[int(skip):]
+            t = tf.convert(target, device=o.device).reshape(y.shape)[int(skip):]
+            S, E = tf.reduce_sum(tf.square(o - t)), tf.reduce_sum(tf.square(o)) + float(np.finfo(float).eps)
+            n = float(o.numel())
+            return S / n + tf.sqrt(S / E / n)
         mres = getattr(self, "_mlp", None)
         if mres is not None and isinstance(x, torch.Tensor) and isinstance(target, torch.Tensor):
             from . import mlp_root

@@ -128,6 +128,23 @@ def test_rc_lowpass_three_never_reset_epochs_against_the_oracle(wdf, oracle, B, 
     assert abs(float(R1.R) - 1000.0) > 10.0                      # (the loop really moved the components)
 
 
+def test_mse_esr_carries_the_state_like_mse(wdf, golden):
+    """circ.mse_esr(..., carry_state=True): the second call starts where the first ended (g1's second-call output), the loss is
+    clipper_pot.py:146-156,177's on that output."""
+    g = golden("g1_rc_lowpass.npz")
+    Vs, R1, C1, I1 = build_lpf(wdf)
+    circ = wdf.Circuit(I1, Vs, C1)
+    x, tgt = cuda(g["x"][None, :]), cuda(g["target"][:, None])
+    for key in ("y_f64", "y_second_call_f64"):
+        loss = circ.mse_esr(x, tgt, skip=50, carry_state=True)
+        y = circ.last_output.cpu().numpy()[:, 0]
+        assert np.max(np.abs(y - g[key])) < 2e-6
+        o, t = g[key][50:], g["target"][50:]
+        S, E = np.sum((o - t) ** 2), np.sum(o * o) + np.finfo(float).eps
+        ref = S / o.size + np.sqrt(S / E / o.size)
+        assert abs(float(loss) - ref) < 2e-5 * ref
+
+
 def test_resident_voltage_divider_against_the_reference_golden(wdf, golden):
     tf = wdf.tf
     g = golden("g2_voltage_divider.npz")
