@@ -364,7 +364,7 @@ static int fwd_tp_common(const float* x, const float* r, const float* theta, flo
         }
     }
     const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
-    const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    const bool v4 = !tm && (T % 4 == 0) && T < (1 << 23) && aligned16(x) && (!r || aligned16(r));
     WDF_DISPATCH4(launch_fwd_tp, r != nullptr, n_up == n_down, tm, v4, x, r, theta, fs, n_up, n_down, y, zstash, z0, zT,
                   zwarm, zend, (wdf::TpStatus*)status, tol, B, T, g, W, warm, tickets, (flags & WDF_GENERAL_ROOT) ? 1 : 0,
                   (hipStream_t)stream);
@@ -539,7 +539,7 @@ static int step_tp_common(const float* x, const float* r, float* theta, float fs
         warm = TpWarm{(wdf::TpCtl*)state, (float*)((char*)state + sizeof(wdf::TpCtl) + tp_ticket_bytes(B)), max_warm_tiles + 1};
     }
     const bool tm = (flags & WDF_X_TIME_MAJOR) != 0;
-    const bool v4 = !tm && (T % 4 == 0) && aligned16(x) && (!r || aligned16(r));
+    const bool v4 = !tm && (T % 4 == 0) && T < (1 << 23) && aligned16(x) && (!r || aligned16(r));
     // two adjacent sequences per lane (8-byte row accesses, packed arithmetic) whenever the rows allow it
     const bool pairs = !(flags & WDF_ONE_SEQUENCE_PER_LANE) && (B % 2 == 0) && aligned8(x) && aligned8(target) && aligned8(y) &&
                        (!r || aligned8(r));

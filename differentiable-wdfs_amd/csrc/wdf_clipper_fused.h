@@ -201,6 +201,149 @@ __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, const L
     }
 }
 
+// Batch-major x through LDS.  Read straight from its own rows (load_x_tile above) a lane's 16-byte load touches a 128-byte
+// line of its own -- 64 lines per instruction, an eighth of each used -- and by the time the lane comes back for the next
+// 16 bytes the line has left L2: measured (TCC_EA0_RDREQ_128B, 8192 x 4096), every visit was a 128-byte read from HBM, and
+// with 16-step (64-byte) visits x was still fetched twice, 575 MB per step against the time-major step's 441.
+// Here a wave takes each line of x ONCE, whole: eight adjacent lanes read the eight 16-byte granules of one row's 128
+// bytes (32 steps), eight rows per instruction, and park them in LDS ([row][32 + 4 floats]: with the pad the eight lanes of
+// a 128-bit access fall on distinct banks but for one pair), from where each lane reads its own rows' steps a tile at a
+// time.  A whole 32-step window of the wave's 64 N rows would be 64 staging registers per lane; so the two HALVES of the
+// rows run their windows 16 steps apart -- rows [0, 32 N) start a window where t = 0 mod 32, rows [32 N, 64 N) where
+// t = 16 mod 32 (absolute time: a window is a line when the rows are line-aligned) -- and every 16 steps one half's next
+// window (4 N loads, 16 N registers) is issued, a tile later written over that half's spent window.  The loads go out a
+// tile before they are written to LDS, so their latency stays behind a tile of steps as the direct loads' did.  One
+// window buffer per wave: 18 KB with two sequences per lane, eight waves' worth fit a CU's 160 KB.
+// Only with 16-byte aligned rows (VEC4) and without the per-sample resistance channel (its tiles are half as long).
+constexpr int kWinSteps = 32, kWinPhase = 16, kWinPitch = kWinSteps + 4;
+template <int DYN_R, bool TM, bool VEC4> constexpr bool fused_x_window() { return !TM && VEC4 && DYN_R != 1; }
+template <int FLOATS>
+__device__ __forceinline__ float* wave_lds()
+{
+    __shared__ __attribute__((aligned(16))) float buf[FLOATS];
+    return buf;
+}
+template <typename V, bool ON> struct XWindow {
+    __device__ __forceinline__ XWindow(const float*, const LaneOwn<V>&, int64_t, int64_t) {}
+};
+template <typename V>
+struct XWindow<V, true> {
+    static constexpr int N = VT<V>::N, NR = kWinPhase / N;   // a tile: NR steps, N tiles to a phase of 16 steps
+    static constexpr int RW = 64 * N, HR = RW / 2;           // the wave's rows; a half
+#ifndef WDF_WIN_GRANULE
+#define WDF_WIN_GRANULE 4                                     // floats per lane and load: 4 (eight lanes to a line) or 2 (sixteen)
+#endif
+    static constexpr int G = WDF_WIN_GRANULE, LPR = kWinSteps / G, RPI = 64 / LPR;   // lanes per row, rows per instruction
+    static constexpr int NI = HR / RPI;                      // loads per lane and half window
+    static constexpr int kFloats = RW * kWinPitch;
+    typedef unsigned int raw_t __attribute__((ext_vector_type(G)));
+    raw_t raw[NI];
+    v4u tail[N * 2];            // (a chunk's start) the other half's 16 steps
+    float* lds;
+    float* wr;                  // where the lane's granule of a half window's load 0 goes (half 0)
+    const float* rd;            // the lane's first sequence's row in LDS
+    const float* x0;            // the wave's first row
+    int64_t T, rows;            // rows of this wave (RW but for the batch's last wave)
+    uint32_t voff, rstep;       // the lane's byte offset inside a load's rows; that many rows, bytes
+    uint32_t hfoff;             // 16 where the lane's rows are in the upper half
+    __device__ __forceinline__ XWindow(const float* __restrict__ x, const LaneOwn<V>& q, int64_t B, int64_t T_) : T(T_)
+    {
+        const int64_t row0 = (int64_t)blockIdx.x * RW;
+        rows = B - row0 < RW ? B - row0 : RW;
+        x0 = x + row0 * T;
+        lds = wave_lds<kFloats>();
+        const uint32_t lr = threadIdx.x / LPR, g = threadIdx.x % LPR;
+        wr = lds + lr * kWinPitch + g * G;
+        rd = lds + (q.b - row0) * kWinPitch;
+        hfoff = (q.b - row0) >= HR ? (uint32_t)kWinPhase : 0u;
+        voff = (lr * (uint32_t)T + g * G) * 4u;
+        rstep = (uint32_t)RPI * (uint32_t)T * 4u;
+#pragma unroll
+        for (int m = 0; m < NI; ++m) raw[m] = raw_t{};
+#pragma unroll
+        for (int m = 0; m < N * 2; ++m) tail[m] = v4u{0, 0, 0, 0};
+    }
+    static __device__ __forceinline__ void buf_load_raw(v4u& v, __amdgpu_buffer_rsrc_t rs, uint32_t vo, uint32_t so)
+    {
+        v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+    }
+    static __device__ __forceinline__ void buf_load_raw(v2u& v, __amdgpu_buffer_rsrc_t rs, uint32_t vo, uint32_t so)
+    {
+        v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+    }
+    // the window [ts, ts + 32) of one half's rows: global -> registers
+    __device__ __forceinline__ void issue(int half, int64_t ts)
+    {
+        if (rows == RW && ts + kWinSteps <= T) {
+            const __amdgpu_buffer_rsrc_t rs = row_rsrc(x0 + (int64_t)half * HR * T + ts);
+#pragma unroll
+            for (int m = 0; m < NI; ++m) buf_load_raw(raw[m], rs, voff, m * rstep);
+        } else {                // the batch's last wave / a window across the sequence's end: rows and granules clamped (read, not used)
+            const int64_t g = threadIdx.x % LPR, lr = threadIdx.x / LPR;
+            const int64_t tg = ts + G * g + G <= T ? ts + G * g : T - G;
+#pragma unroll
+            for (int m = 0; m < NI; ++m) {
+                const int64_t row = half * HR + m * RPI + lr < rows ? half * HR + m * RPI + lr : rows - 1;
+                raw[m] = *reinterpret_cast<const raw_t*>(x0 + row * T + tg);
+            }
+        }
+    }
+    // registers -> LDS, over that half's previous window (its last tile has been read)
+    __device__ __forceinline__ void commit(int half)
+    {
+        float* w = wr + half * (HR * kWinPitch);
+#pragma unroll
+        for (int m = 0; m < NI; ++m) *reinterpret_cast<raw_t*>(w + m * RPI * kWinPitch) = raw[m];
+    }
+    // the tile at t of the lane's sequences (the half whose window began this phase reads its head, the other half 16 steps in)
+    __device__ __forceinline__ void read(int64_t t, V (&v)[NR])
+    {
+        const uint32_t sel = (uint32_t)(t / kWinPhase) & 1u, u = (uint32_t)(t / NR) % N;
+        const float* p = rd + (((sel * kWinPhase) ^ hfoff) + u * NR);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+#pragma unroll
+            for (int e = 0; e < NR / 4; ++e) {
+                const float4 f = *reinterpret_cast<const float4*>(p + j * kWinPitch + e * 4);
+                vset(v[4 * e], j, f.x); vset(v[4 * e + 1], j, f.y); vset(v[4 * e + 2], j, f.z); vset(v[4 * e + 3], j, f.w);
+            }
+        }
+    }
+    // A chunk's start at tw (a multiple of 16): the half whose window starts there takes it whole; the other half is 16 steps
+    // into a window it never held, and takes its second 16 steps (four lanes to a row's 64 bytes, straight to LDS).
+    __device__ __forceinline__ void first_issue(int64_t tw)
+    {
+        const int a = (int)(tw / kWinPhase) & 1, o = a ^ 1;
+        issue(a, tw);
+        const int64_t g = threadIdx.x & 3, lr = threadIdx.x >> 2;
+        const int64_t tg = tw + 4 * g + 4 <= T ? tw + 4 * g : T - 4;
+#pragma unroll
+        for (int m = 0; m < N * 2; ++m) {
+            const int64_t row = o * HR + m * 16 + lr < rows ? o * HR + m * 16 + lr : rows - 1;
+            tail[m] = *reinterpret_cast<const v4u*>(x0 + row * T + tg);
+        }
+    }
+    __device__ __forceinline__ void first(int64_t tw, int64_t t_end, V (&v)[NR])
+    {
+        const int a = (int)(tw / kWinPhase) & 1, o = a ^ 1;
+        const int g = threadIdx.x & 3, lr = threadIdx.x >> 2;
+        commit(a);
+#pragma unroll
+        for (int m = 0; m < N * 2; ++m)
+            *reinterpret_cast<v4u*>(lds + (o * HR + m * 16 + lr) * kWinPitch + kWinPhase + g * 4) = tail[m];
+        read(tw, v);
+        if (N == 1 && tw + NR < t_end) issue(o, tw + NR);
+    }
+    // the tile at tn (called a tile ahead, as the direct loads are)
+    __device__ __forceinline__ void next(int64_t tn, int64_t t_end, V (&v)[NR])
+    {
+        const int sel = (int)(tn / kWinPhase) & 1, u = (int)(tn / NR) % N;
+        if (u == 0) commit(sel);
+        read(tn, v);
+        if (u == N - 1 && tn + NR < t_end) issue(sel ^ 1, tn + NR);
+    }
+};
+
 // the lane's N adjacent elements of a [B] row (plain / published)
 template <typename V>
 __device__ __forceinline__ V load_own(const float* row, const LaneOwn<V>& q)
@@ -507,8 +650,12 @@ __device__ __forceinline__ void clipper_fused_body(
 #pragma unroll
     for (int i = 0; i < NR; ++i) { xc[i] = xn[i] = gc[i] = gn[i] = vsplat<V>(0.0f); rc[i] = rn[i] = vsplat<V>(1.0f); }
     const int64_t nfull_end = t1 - (t1 - tw) % NR;
+    constexpr bool WIN = fused_x_window<DYN_R, TM, VEC4>();   // batch-major x: whole lines through LDS (XWindow)
+    XWindow<V, WIN> xw(x, q, B, T);
+    if constexpr (WIN) static_assert(NR == XWindow<V, true>::NR, "a window is N tiles");
     if (tw < nfull_end) {
-        load_x_tile<V, TM, VEC4, NR>(x, q, B, T, tw, rowb, xn);
+        if constexpr (WIN) xw.first_issue(tw);
+        else load_x_tile<V, TM, VEC4, NR>(x, q, B, T, tw, rowb, xn);
         if constexpr (DYN_R == 1) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, tw, rowb, rn);
         if constexpr (LOSS != 0) { if (tw >= t0) load_rows<V, NR>(target + tw * B, boff, rowb, gn); }
     }
@@ -536,6 +683,7 @@ __device__ __forceinline__ void clipper_fused_body(
         z = load_own<V>(z0, q);
     }
     int64_t t = tw;
+    if constexpr (WIN) { if (tw < nfull_end) xw.first(tw, nfull_end, xn); }
 #ifdef WDF_DBG_TIMES
     dbg_p[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -543,7 +691,8 @@ __device__ __forceinline__ void clipper_fused_body(
 #pragma unroll
         for (int i = 0; i < NR; ++i) { xc[i] = xn[i]; if constexpr (DYN_R == 1) rc[i] = rn[i]; }
         if (t + NR < nfull_end) {
-            load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
+            if constexpr (WIN) xw.next(t + NR, nfull_end, xn);
+            else load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
             if constexpr (DYN_R == 1) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, t + NR, rowb, rn);
             if constexpr (LOSS != 0) { if (t + NR >= t0) load_rows<V, NR>(target + (t + NR) * B, boff, rowb, gn); }   // the first owned tile's target
         }
@@ -584,7 +733,8 @@ __device__ __forceinline__ void clipper_fused_body(
                 // With 16-row tiles a tile's loads + stores (48) stay inside the counter's 6 bits.
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
-                    load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
+                    if constexpr (WIN) xw.next(t + NR, nfull_end, xn);
+                    else load_x_tile<V, TM, VEC4, NR>(x, q, B, T, t + NR, rowb, xn);
                     if constexpr (DYN_R == 1) load_x_tile<V, TM, VEC4, NR>(r, q, B, T, t + NR, rowb, rn);
                     if constexpr (LOSS != 0) load_rows<V, NR>(target + (t + NR) * B, boff, rowb, gn);
                 }
@@ -816,7 +966,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WDF_FUSED_WA
     int J, unsigned* tickets, unsigned* gticket, float tol, int64_t B, int64_t T, int64_t L, int64_t W, int general,
     double* ws, FusedOut out, int64_t skew, double* wpart, int finish_later)
 {
-    __shared__ double sh[64][4];
+    double (*sh)[4];                                        // the in-kernel tail's scratch; where x has a window in LDS, inside it
+    if constexpr (fused_x_window<DYN_R, TM, VEC4>()) {
+        sh = reinterpret_cast<double (*)[4]>(wave_lds<XWindow<V, true>::kFloats>());
+    } else {
+        __shared__ double sh_own[64][4];
+        sh = sh_own;
+    }
 #ifdef WDF_DBG_TIMES
     const unsigned long long dbg_t0 = wall_clock64();
     const unsigned long long dbg_m0 = __builtin_amdgcn_s_memtime();

@@ -476,6 +476,49 @@ def test_fused_randomized_plans_and_circuits(wb):
     assert repaired >= 5
 
 
+@pytest.mark.parametrize("B,T,K,W", [(130, 4096, 16, 256), (129, 3000, 47, 192), (64, 64, 1, 0), (300, 4000, 25, 160), (2, 2048, 8, 192),
+                                     (1024, 1056, 11, 96)])
+def test_fused_batch_major_windows_match_time_major(wb, B, T, K, W):
+    """x as the caller holds it, [B, T]: whole 128-byte lines through LDS, the two halves of a wave's rows 16 steps apart
+    (XWindow, wdf_clipper_fused.h).  Ragged last waves (130 = a wave of two rows, 129 / 300: one sequence per lane), windows
+    across the sequence's end (3000, 4000: T % 32 != 0), a single chunk, and a warm-started loop whose warm-up settles at an
+    odd number of 16-step units (a chunk then starts 16 steps into a line).  The steps are the time-major call's: y bit for
+    bit, the sums to rounding."""
+    x, th0, ths = problem(B, T, seed=B + T)
+    xd = dev(x)
+    xt = xd.t().contiguous()
+    tgt, _, _ = wb.clipper_fwd(xd, dev(ths), FS, want_stash=False)
+    gscale = 2.0 / (B * T)
+    K = wb.lib().wdf_clipper_tp_chunks(T, K)
+    for r in (None, dev(np.linspace(0.4, 1.6, B, dtype=np.float32)[:, None].repeat(T, 1))):     # static R; one pot value per sequence
+        rt = None if r is None else r.t().contiguous()
+        y_b, _, g_b, sse_b, st_b = wb.clipper_step_mse_tp(xd, dev(th0), FS, tgt, gscale, K, W, r=r, time_major=False)
+        y_t, _, g_t, sse_t, st_t = wb.clipper_step_mse_tp(xt, dev(th0), FS, tgt, gscale, K, W, r=rt, time_major=True)
+        assert torch.equal(y_b, y_t), float((y_b - y_t).abs().max())
+        assert wb.tp_status(st_b)["n_bad"] == wb.tp_status(st_t)["n_bad"]
+        ok, info = close_grad(g_b, g_t, rtol=1e-6)
+        assert ok, info
+        assert abs(float(sse_b) - float(sse_t)) <= 1e-6 * float(sse_t)
+    if K < 4:
+        return
+    state_b = wb.TpWarmState(B, T, K, max(1, W // wb.warm_unit()), xd.device)
+    state_t = wb.TpWarmState(B, T, K, max(1, W // wb.warm_unit()), xd.device)
+    th_b, th_t = dev(th0), dev(th0)
+    lr = [2e-4 * float(v) for v in th0]
+    lo, hi = [1e-15, 1e-3, 180.0, 1e-13], [1e-3, 1.0, 1.0e6, 1.0]
+    opt_b, opt_t = wb.Adam(4, lr=lr, lo=lo, hi=hi, device=xd.device), wb.Adam(4, lr=lr, lo=lo, hi=hi, device=xd.device)
+    units = set()
+    for it in range(10):
+        y_b, _, g_b, _, st_b = wb.clipper_step_mse_tp(xd, th_b, FS, tgt, gscale, K, W, state=state_b, opt=opt_b, time_major=False)
+        y_t, _, g_t, _, st_t = wb.clipper_step_mse_tp(xt, th_t, FS, tgt, gscale, K, W, state=state_t, opt=opt_t, time_major=True)
+        assert torch.equal(y_b, y_t), (it, float((y_b - y_t).abs().max()))
+        assert torch.allclose(th_b, th_t, rtol=1e-6, atol=0), (it, th_b, th_t)
+        th_t.copy_(th_b)
+        units.add(state_b.info()["last_warm_tiles"])
+        assert state_b.info()["last_warm_tiles"] == state_t.info()["last_warm_tiles"]
+    assert any(u % 2 == 1 for u in units), units                # a chunk started 16 steps into a line
+
+
 def test_fused_step_is_bit_reproducible(wb):
     """Which wave finishes a tile / the step varies from launch to launch; what they compute does not (records and partials
     are re-read in index order, fixed-order reductions): 100 launches, bit-identical y, gradient, SSE and status."""

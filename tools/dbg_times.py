@@ -4,12 +4,13 @@ import numpy as np, torch
 from wdf_hip import binding, engine, workload
 one = len(sys.argv) > 1 and sys.argv[1] == "one"
 binding.ONE_SEQUENCE_PER_LANE = one
-B, T, fs, K = 8192, 4096, workload.FS, int(os.environ.get("DBG_K", "16"))
+B, T, fs, K = 8192, int(os.environ.get("DBG_T", "4096")), workload.FS, int(os.environ.get("DBG_K", "16"))
 dev = torch.device("cuda", 0)
-x = torch.as_tensor(workload.sweep_batch(B, T), device=dev); xt = x.t().contiguous()
+TM = not os.environ.get("DBG_BM")          # DBG_BM=1: x batch-major ([B, T], as the caller holds it)
+x = torch.as_tensor(workload.sweep_batch(B, T), device=dev); xt = x.t().contiguous() if TM else x
 th_host = workload.clipper_theta()
 tgt, _, _ = binding.clipper_fwd(x, torch.tensor(workload.target_theta(), dtype=torch.float32, device=dev), fs, want_stash=False)
-st = engine.MseStep(B, T, fs, engine.TpPlan(K, 160, 1e-6, 32), dev, time_major=True, warm=True)
+st = engine.MseStep(B, T, fs, engine.TpPlan(K, 160, 1e-6, 32), dev, time_major=TM, warm=True)
 theta = torch.tensor(th_host, dtype=torch.float32, device=dev)
 adam = None if os.environ.get("DBG_NO_ADAM") else binding.Adam(4, lr=[1e-3 * float(v) for v in th_host], lo=[1e-15, 1e-3, 180.0, 1e-13], hi=[1e-3, 1.0, 1.0e6, 1.0], device=dev)
 nw = (B // (64 if one else 128)) * K
