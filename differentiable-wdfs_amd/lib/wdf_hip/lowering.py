@@ -1194,7 +1194,7 @@ class Circuit:
             rootvec, kind = None, binding.ROOT_NONE
         z0t = None if z0 is None else z0.as_subclass(torch.Tensor).to(dev).float().reshape(self.ns, -1).contiguous()
         xs = x[:, :, :self.ni].contiguous()
-        tp = self._plan_dyn(tape, outs, vals, kind, B, T) if self.time_parallel == "auto" else \
+        tp = self._plan_dyn(tape, outs, vals, kind, B, T, xs=xs) if self.time_parallel == "auto" else \
             (self.time_parallel if isinstance(self.time_parallel, SsTpPlan) else None)
         warm = None
         if tp is not None and self.warm_start and self.ns >= 1 and z0t is None and isinstance(getattr(self, "_anchor", None), torch.Tensor):
@@ -1210,13 +1210,15 @@ class Circuit:
         y = y.as_subclass(tf.Tensor)
         return (y, zT[:self.ns]) if return_state else y
 
-    def _plan_dyn(self, tape, outs, vals, kind, B, T, tol=1.0e-6):
+    def _plan_dyn(self, tape, outs, vals, kind, B, T, tol=1.0e-6, xs=None):
         """SsTpPlan for the streamed-coefficient kernels (or None: the batch fills the chip / no state).  The reverse sweep is
         exact in chunks: as many as give every SIMD ~2 waves, none shorter than 64 steps.  The forward warms a chunk up from
-        z = 0: W outlasts the slowest mode of the step's Jacobian A + Da E ca^T over the root's slope Da in [-1, 1], taken at
-        BOTH ends of the resistance channel (the tape evaluated at its smallest and largest value -- the adaptor coefficients are
-        monotone in one resistance); every boundary is verified on the device whatever the estimate.  Re-derived every 32 calls
-        (the components train slowly; a stale W costs a re-run of the waves that missed, never a wrong result)."""
+        z = 0: W outlasts the slowest mode of the step's Jacobian A + Da E ca^T over the root's slope Da -- [-1, 1] for a diode
+        pair (passive), for a network root what its weights give over the batch's amplitude (mlp_root.slope_range: a learned
+        b(a) is not bounded by 1) -- taken at BOTH ends of the resistance channel (the tape evaluated at its smallest and largest
+        value -- the adaptor coefficients are monotone in one resistance); every boundary is verified on the device whatever the
+        estimate.  Re-derived every 32 calls (the components train slowly; a stale W costs a re-run of the waves that missed,
+        never a wrong result)."""
         ns, ni = self.ns, self.ni
         if ns < 1:
             return None
@@ -1239,7 +1241,18 @@ class Circuit:
                 A = c[:ns * ns].reshape(ns, ns)
                 oE = ns * ns + ns * ni
                 E, ca = c[oE:oE + ns], c[oE + ns:oE + 2 * ns]
-                slopes = (0.0,) if kind == binding.ROOT_NONE else (1.0, -1.0)
+                if kind == binding.ROOT_NONE:
+                    slopes = (0.0,)
+                elif kind == binding.ROOT_MLP:
+                    from . import mlp_root
+                    # the a-range the network is asked about: four times the batch's largest input (the incident wave is
+                    # ca.z + da.x, both of the input's order); one read-back per re-derivation
+                    a_max = 4.0 * max(float(xs.abs().max()) if xs is not None else 1.0, 0.25)
+                    s_lo, s_hi = mlp_root.slope_range(mlp_root.describe(self.root, with_activation=True)[0],
+                                                      [math.log(max(float(c[-1]), 1e-30))], a_max)
+                    slopes = tuple(np.linspace(s_lo, s_hi, 5))          # (the radius need not peak at an end of the range)
+                else:
+                    slopes = (1.0, -1.0)
                 rho = max(rho, max(float(np.max(np.abs(np.linalg.eigvals(A + sgn * np.outer(E, ca))))) for sgn in slopes))
         k_fwd, W = 1, 0
         if rho < 1.0 - 1e-9:

@@ -48,6 +48,27 @@ def flat_weights(dense):
     return torch.cat(parts)
 
 
+def slope_range(dense, log_r, a_max, n=513):
+    """(min, max) of db/da of the root b = -MLP(a, log R) over a in [-a_max, a_max] at the given log R values: the
+    network evaluated in float64 on the host (609 weights), its derivative by autograd.  What the warm-up estimate of the
+    streamed-coefficient kernels needs instead of a diode's |db/da| <= 1 (lowering._plan_dyn): a learned network's slope is
+    whatever its weights say."""
+    ws = [(d.kernel.as_subclass(torch.Tensor)[0].detach().double().cpu(), d.bias.as_subclass(torch.Tensor)[0].detach().double().cpu())
+          for d in dense]
+    lo, hi = float("inf"), float("-inf")
+    with torch.enable_grad():
+        for lr in log_r:
+            a = torch.linspace(-float(a_max), float(a_max), int(n), dtype=torch.float64, requires_grad=True)
+            h = torch.stack([a, torch.full_like(a, float(lr))], dim=1)
+            for i, (k, b) in enumerate(ws):
+                h = h @ k + b
+                if i + 1 < len(ws):
+                    h = torch.tanh(h)
+            (g,) = torch.autograd.grad(-h.sum(), a)
+            lo, hi = min(lo, float(g.min())), max(hi, float(g.max()))
+    return lo, hi
+
+
 MlpTpPlan = namedtuple("MlpTpPlan", ["k_fwd", "warmup", "warmup_per_wave", "tol", "k_bwd"])
 LAST_TP_STATUS = {"status": None}
 WARM_START = os.environ.get("WDF_MLP_WARM_START", "1") != "0"        # 0: every call warms its chunks up from z = 0

@@ -11,6 +11,8 @@ the oracle's tree interpreter (fp64; per-sample resistance channel `rin`, MLP ro
   * the clipper topology forced through these kernels against the clipper kernels' golden (g6, pot channel).
 Tolerances: y 3e-6 V (fp32 recursion), gradients 3e-4 relative (fp32 sweep, rows formed in fp64 and rounded to fp32).
 """
+import math
+
 import numpy as np
 import pytest
 
@@ -507,6 +509,39 @@ def test_streamed_kernels_in_time_chunks_equal_the_sequential_ones(wdf, golden, 
         y_short, g_short, st_short = run(lowering.SsTpPlan(k, 8, 1.0e-6, k))      # 8 steps cannot forget the capacitor's state
         assert st_short["n_bad"] > 0 and st_short["gated_waves"] >= 1, st_short
         assert np.array_equal(y_short, y_seq)
+
+
+def test_network_root_slope_sizes_the_planned_warm_up(wdf, golden):
+    """lowering._plan_dyn under a network root: the warm-up outlasts the slowest mode of A + Da E ca^T with Da taken from the
+    WEIGHTS over the batch's amplitude (mlp_root.slope_range), not from a diode's |db/da| <= 1.  The pretrained 2x8 network and
+    the same network with its output layer scaled by 3 (a root three times as steep: the state is forgotten more slowly, or not
+    at all) must get different plans; both still give the sequential kernel's outputs."""
+    from wdf_hip import binding as wb, lowering, mlp_root
+    tf = wdf.tf
+    js = _net(golden, "2x8")[0]
+    vals = [3.3e3, 1.0e3, 1.0e-9, 4.352e-9, 25.85e-3 * 1.906]
+    B, T = 64, 1024
+    rng = np.random.default_rng(11)
+    xin = cuda((1.2 * rng.standard_normal((B, T))).astype(np.float32))
+    plans, slopes = [], []
+    for scale in (1.0, 3.0):
+        outs = []
+        for tp in (None, "auto"):
+            circ, params, model = build_hpf(wdf, "mlp", None, vals, net=js)
+            last = [l for l in model.layers if type(l).__name__ == "DenseLayer"][-1]
+            with torch.no_grad():
+                last.kernel.mul_(scale)
+                last.bias.mul_(scale)
+            circ.time_parallel = tp
+            outs.append(circ(xin).cpu().numpy())
+            if tp == "auto":
+                plans.append(next(iter(circ._dyn_plans.values()))[0])
+                dense = mlp_root.describe(model, with_activation=True)[0]
+                slopes.append(mlp_root.slope_range(dense, [math.log(1.0e3)], 4.0 * float(xin.abs().max())))
+        assert np.max(np.abs(outs[0] - outs[1])) <= 2e-6, scale
+    assert abs(slopes[1][1] - 3.0 * slopes[0][1]) < 1e-6 * abs(slopes[1][1])      # (the weights are scaled in float32)
+    assert plans[0] != plans[1], (plans, slopes)
+    assert plans[1].warmup == 0 or plans[1].warmup > plans[0].warmup, (plans, slopes)     # (0: no contraction -> one chunk)
 
 
 @pytest.mark.parametrize("root", ["diode", "mlp"])

@@ -1,6 +1,8 @@
 """CPU: the probed step as a tape (lib/wdf_hip/probe_tape.py) against the host probe (lowering.Circuit.matrices: the elements'
 own calc_impedance / reflected / incident code on float64 torch scalars with autograd) -- values and Jacobian; and the
 chunk planner of the MLP-root training step (mlp_root.plan_step_items)."""
+import math
+
 import numpy as np
 import pytest
 
@@ -134,3 +136,31 @@ def test_resident_entries_are_found_by_storage_not_by_object():
     for i in range(10):
         small.put(i, i, nbytes=40)
     assert len(small) == 6 and small.get(3) is None and small.get(4) == 4
+
+
+def test_network_root_slope_range_is_the_networks_derivative():
+    """mlp_root.slope_range (what lowering._plan_dyn sizes a network root's warm-up with): min / max of d(-MLP(a, log R))/da over
+    the a grid, against central differences of the same float64 network."""
+    from types import SimpleNamespace
+
+    from wdf_hip import mlp_root
+    rng = np.random.default_rng(3)
+    sizes = [2, 8, 8, 1]
+    dense = [SimpleNamespace(kernel=torch.tensor(rng.standard_normal((1, i, o)) * 0.9), bias=torch.tensor(rng.standard_normal((1, o)) * 0.3))
+             for i, o in zip(sizes[:-1], sizes[1:])]
+
+    def net(a, lr):
+        h = np.stack([a, np.full_like(a, lr)], axis=1)
+        for n, d in enumerate(dense):
+            h = h @ d.kernel[0].numpy() + d.bias[0].numpy()
+            if n + 1 < len(dense):
+                h = np.tanh(h)
+        return -h[:, 0]
+
+    a = np.linspace(-3.0, 3.0, 513)
+    lo, hi = float("inf"), float("-inf")
+    for lr in (math.log(500.0), math.log(2.0e4)):
+        d = (net(a + 1e-6, lr) - net(a - 1e-6, lr)) / 2e-6
+        lo, hi = min(lo, d.min()), max(hi, d.max())
+    got = mlp_root.slope_range(dense, [math.log(500.0), math.log(2.0e4)], 3.0, n=513)
+    assert abs(got[0] - lo) < 1e-6 and abs(got[1] - hi) < 1e-6, (got, lo, hi)
